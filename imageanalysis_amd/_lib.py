@@ -1,0 +1,84 @@
+"""ctypes loader for libiamx.so (the C ABI declared in include/iamx.h).
+
+The product path has no CPU fallback: if the HIP library is missing, or a kernel is
+asked to run without a GPU, this raises.  torch is imported first so that the HIP
+runtime already mapped by torch (its bundled libamdhip64, soname libamdhip64.so.7) is
+the one libiamx.so binds to -- one runtime per process, device pointers interchangeable.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libiamx.so')
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_double = ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/iamx.h one to one
+SIGNATURES = {
+    'iamx_version': (c_int, []),
+    'iamx_last_error': (ctypes.c_char_p, []),
+    'iamx_arch': (ctypes.c_char_p, []),
+    'iamx_desc_padded_rows': (c_int64, [c_int64]),
+    'iamx_desc_pack_u8': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'iamx_desc_pack_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'iamx_knn2_wg_per_pair': (c_int, [c_int]),
+    'iamx_knn2_l2_pairs': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'iamx_knn2_l2_u8': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                c_void_p, c_void_p, c_void_p]),
+    'iamx_match_metric': (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    'iamx_match_compact': (c_int, [c_void_p] * 5 + [c_int] + [c_void_p] * 4),
+    'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_void_p, c_void_p, c_void_p]),
+    'iamx_ba_residual_jac': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+}
+
+
+class IamxError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libiamx.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (maps the HIP runtime first, see module docstring)
+        if not os.path.exists(LIB_PATH):
+            raise IamxError(
+                "libiamx.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(imageanalysis_amd/csrc/build.sh); there is no CPU fallback" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)          # AttributeError if the ABI and the header drift apart
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().iamx_last_error()
+        raise IamxError("%s failed (%d): %s" % (what or 'libiamx call', rc,
+                                                msg.decode() if msg else '?'))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise IamxError("no HIP device visible: the iamx hot path runs on an MI355X only "
+                        "(no CPU fallback)")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

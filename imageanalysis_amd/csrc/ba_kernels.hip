@@ -1,0 +1,233 @@
+// K3 -- bundle-adjustment reprojection residual and analytic Jacobian blocks (gfx950).
+//
+// Replaces Optimizer.fun (scripts/lib/optimizer.py:174-229): for every observation
+//   body2ned = quaternion_matrix(q)            lib/archive/transformations.py:1395-1420
+//   R = body2cam . body2ned^T, t = -R.ned      lib/optimizer.py:120-126
+//   (u,v) = pinhole + Brown(k1,k2,p1,p2,k3)    lib/project.py:300-329 (= cv2.projectPoints)
+//   r = observed - projected                   lib/optimizer.py:222
+// One thread per observation, float64 throughout; HBM-bound streaming of the
+// camera-major observation list (idx 8 B + uv 16 B + point 24 B gathered + r 16 B = 64 B/obs,
+// SURVEY.md 8d), camera blocks (56 B) are shared by consecutive observations and stay in L2.
+//
+// With body2cam = [[0,1,0],[0,0,1],[1,0,0]]:  Xc = (y1, y2, y0),  y = M(q)^T (X-ned) / |q|^2,
+// M the homogeneous (unnormalised) rotation matrix of q = (w,x,y,z).
+#include "iamx_common.h"
+
+namespace {
+
+constexpr double QEPS = 2.220446049250313e-16 * 4.0;   // transformations._EPS
+
+struct Proj {
+    double u, v;
+    // intermediates kept for the Jacobian
+    double x, y, r2, rad, iz;
+    double yb[3];      // body-frame point
+    double dX[3];
+    double q[4];
+    double inv_n;
+    bool degenerate;
+};
+
+__device__ __forceinline__ void project_obs(const double *__restrict__ cam,
+                                            const double *__restrict__ X,
+                                            const double *__restrict__ cal, Proj &P)
+{
+    const double w = cam[3], x = cam[4], y = cam[5], z = cam[6];
+    const double a = X[0] - cam[0], b = X[1] - cam[1], c = X[2] - cam[2];
+    P.dX[0] = a; P.dX[1] = b; P.dX[2] = c;
+    P.q[0] = w; P.q[1] = x; P.q[2] = y; P.q[3] = z;
+    const double n = w * w + x * x + y * y + z * z;
+    double y0, y1, y2;
+    if (n < QEPS) {
+        P.degenerate = true;
+        P.inv_n = 0.0;
+        y0 = a; y1 = b; y2 = c;
+    } else {
+        P.degenerate = false;
+        const double inv_n = 1.0 / n;
+        P.inv_n = inv_n;
+        const double ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+        const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+        y0 = ((ww + xx - yy - zz) * a + 2.0 * (xy + wz) * b + 2.0 * (xz - wy) * c) * inv_n;
+        y1 = (2.0 * (xy - wz) * a + (ww - xx + yy - zz) * b + 2.0 * (yz + wx) * c) * inv_n;
+        y2 = (2.0 * (xz + wy) * a + 2.0 * (yz - wx) * b + (ww - xx - yy + zz) * c) * inv_n;
+    }
+    P.yb[0] = y0; P.yb[1] = y1; P.yb[2] = y2;
+    const double iz = 1.0 / y0;            // camera z = body x
+    const double px = y1 * iz, py = y2 * iz;
+    const double r2 = px * px + py * py;
+    const double k1 = cal[4], k2 = cal[5], p1 = cal[6], p2 = cal[7], k3 = cal[8];
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double xd = px * rad + 2.0 * p1 * px * py + p2 * (r2 + 2.0 * px * px);
+    const double yd = py * rad + p1 * (r2 + 2.0 * py * py) + 2.0 * p2 * px * py;
+    P.u = cal[0] * xd + cal[2];
+    P.v = cal[1] * yd + cal[3];
+    P.x = px; P.y = py; P.r2 = r2; P.rad = rad; P.iz = iz;
+}
+
+__global__ __launch_bounds__(256) void ba_residual_kernel(
+    const double *__restrict__ cams, int n_cams, const double *__restrict__ pts,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
+    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
+    double *__restrict__ r)
+{
+    double cal[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cal[i] = calib[i];
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n_obs;
+         o += (int64_t)gridDim.x * 256) {
+        const int ci = cam_idx[o];
+        const int pi = pt_idx[o];
+        const double2 obs = *reinterpret_cast<const double2 *>(uv + 2 * o);
+        Proj P;
+        project_obs(cams + (int64_t)ci * 7, pts + (int64_t)pi * 3, cal, P);
+        *reinterpret_cast<double2 *>(r + 2 * o) = make_double2(obs.x - P.u, obs.y - P.v);
+    }
+}
+
+template <bool WITH_CALIB>
+__global__ __launch_bounds__(256) void ba_residual_jac_kernel(
+    const double *__restrict__ cams, int n_cams, const double *__restrict__ pts,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
+    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
+    double *__restrict__ r, double *__restrict__ Jc, double *__restrict__ Jp,
+    double *__restrict__ Jk)
+{
+    double cal[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cal[i] = calib[i];
+    const double fx = cal[0], fy = cal[1];
+    const double k1 = cal[4], k2 = cal[5], p1 = cal[6], p2 = cal[7], k3 = cal[8];
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n_obs;
+         o += (int64_t)gridDim.x * 256) {
+        const int ci = cam_idx[o];
+        const int pi = pt_idx[o];
+        Proj P;
+        project_obs(cams + (int64_t)ci * 7, pts + (int64_t)pi * 3, cal, P);
+        if (r) {
+            const double2 obs = *reinterpret_cast<const double2 *>(uv + 2 * o);
+            *reinterpret_cast<double2 *>(r + 2 * o) = make_double2(obs.x - P.u, obs.y - P.v);
+        }
+        const double x = P.x, y = P.y, r2 = P.r2, rad = P.rad, iz = P.iz;
+        const double drad = k1 + r2 * (2.0 * k2 + 3.0 * k3 * r2);
+        // d(xd,yd)/d(x,y)
+        const double xdx = rad + 2.0 * x * x * drad + 2.0 * p1 * y + 6.0 * p2 * x;
+        const double xdy = 2.0 * x * y * drad + 2.0 * p1 * x + 2.0 * p2 * y;
+        const double ydx = xdy;
+        const double ydy = rad + 2.0 * y * y * drad + 6.0 * p1 * y + 2.0 * p2 * x;
+        // d(u,v)/d(body point yb): camera (X,Y,Z) = (yb1, yb2, yb0)
+        //   x = yb1/yb0, y = yb2/yb0
+        const double ux = fx * xdx, uy = fx * xdy, vx = fy * ydx, vy = fy * ydy;
+        double du[3], dv[3];
+        du[0] = -(ux * x + uy * y) * iz;   dv[0] = -(vx * x + vy * y) * iz;
+        du[1] = ux * iz;                    dv[1] = vx * iz;
+        du[2] = uy * iz;                    dv[2] = vy * iz;
+
+        // d yb / d X = B^T (rows of M^T / n);  d yb / d ned = -B^T
+        const double w = P.q[0], qx = P.q[1], qy = P.q[2], qz = P.q[3];
+        const double a = P.dX[0], b = P.dX[1], c = P.dX[2];
+        const double inv_n = P.inv_n;
+        double BT[3][3];
+        if (P.degenerate) {
+            BT[0][0] = 1; BT[0][1] = 0; BT[0][2] = 0;
+            BT[1][0] = 0; BT[1][1] = 1; BT[1][2] = 0;
+            BT[2][0] = 0; BT[2][1] = 0; BT[2][2] = 1;
+        } else {
+            const double ww = w * w, xx = qx * qx, yy = qy * qy, zz = qz * qz;
+            const double xy = qx * qy, xz = qx * qz, yz = qy * qz;
+            const double wx = w * qx, wy = w * qy, wz = w * qz;
+            BT[0][0] = (ww + xx - yy - zz) * inv_n; BT[0][1] = 2.0 * (xy + wz) * inv_n; BT[0][2] = 2.0 * (xz - wy) * inv_n;
+            BT[1][0] = 2.0 * (xy - wz) * inv_n; BT[1][1] = (ww - xx + yy - zz) * inv_n; BT[1][2] = 2.0 * (yz + wx) * inv_n;
+            BT[2][0] = 2.0 * (xz + wy) * inv_n; BT[2][1] = 2.0 * (yz - wx) * inv_n; BT[2][2] = (ww - xx - yy + zz) * inv_n;
+        }
+        double jp_u[3], jp_v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            jp_u[j] = du[0] * BT[0][j] + du[1] * BT[1][j] + du[2] * BT[2][j];
+            jp_v[j] = dv[0] * BT[0][j] + dv[1] * BT[1][j] + dv[2] * BT[2][j];
+        }
+        // d yb / d q_k = (dM^T/dq_k . dX - 2 q_k yb) / n
+        double jq_u[4], jq_v[4];
+        if (P.degenerate) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) jq_u[k] = jq_v[k] = 0.0;
+        } else {
+            const double s = w * a + qz * b - qy * c;     // recurring bilinear forms
+            const double t = -qz * a + w * b + qx * c;
+            const double p = qy * a - qx * b + w * c;
+            const double d = qx * a + qy * b + qz * c;
+            const double dvq[4][3] = {{s, t, p}, {d, p, -t}, {-p, d, s}, {t, -s, d}};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double qk = P.q[k];
+                const double e0 = 2.0 * (dvq[k][0] - qk * P.yb[0]) * inv_n;
+                const double e1 = 2.0 * (dvq[k][1] - qk * P.yb[1]) * inv_n;
+                const double e2 = 2.0 * (dvq[k][2] - qk * P.yb[2]) * inv_n;
+                jq_u[k] = du[0] * e0 + du[1] * e1 + du[2] * e2;
+                jq_v[k] = dv[0] * e0 + dv[1] * e1 + dv[2] * e2;
+            }
+        }
+        // r = observed - projected  =>  J = -d(u,v)/d(params)
+        double *jc = Jc + o * 14;
+        jc[0] = jp_u[0]; jc[1] = jp_u[1]; jc[2] = jp_u[2];          // d/d ned = -(-B^T) -> +
+        jc[3] = -jq_u[0]; jc[4] = -jq_u[1]; jc[5] = -jq_u[2]; jc[6] = -jq_u[3];
+        jc[7] = jp_v[0]; jc[8] = jp_v[1]; jc[9] = jp_v[2];
+        jc[10] = -jq_v[0]; jc[11] = -jq_v[1]; jc[12] = -jq_v[2]; jc[13] = -jq_v[3];
+        double *jp = Jp + o * 6;
+        jp[0] = -jp_u[0]; jp[1] = -jp_u[1]; jp[2] = -jp_u[2];
+        jp[3] = -jp_v[0]; jp[4] = -jp_v[1]; jp[5] = -jp_v[2];
+        if constexpr (WITH_CALIB) {
+            const double xd = (P.u - cal[2]) / fx, yd = (P.v - cal[3]) / fy;
+            const double r4 = r2 * r2, r6 = r4 * r2;
+            double *jk = Jk + o * 16;
+            // (f, cu, cv, k1, k2, p1, p2, k3), fx = fy = f
+            jk[0] = -xd;  jk[1] = -1.0; jk[2] = 0.0;
+            jk[3] = -fx * x * r2; jk[4] = -fx * x * r4;
+            jk[5] = -fx * 2.0 * x * y; jk[6] = -fx * (r2 + 2.0 * x * x); jk[7] = -fx * x * r6;
+            jk[8] = -yd;  jk[9] = 0.0; jk[10] = -1.0;
+            jk[11] = -fy * y * r2; jk[12] = -fy * y * r4;
+            jk[13] = -fy * (r2 + 2.0 * y * y); jk[14] = -fy * 2.0 * x * y; jk[15] = -fy * y * r6;
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t n)
+{
+    int64_t g = (n + 255) / 256;
+    const int64_t cap = 256 * 16;      // 256 CUs x 16 resident blocks is plenty; grid-stride the rest
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int iamx_ba_residual(const double *cams, int n_cams, const double *pts, int n_pts,
+                                const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
+                                int64_t n_obs, const double *calib, double *r, void *stream)
+{
+    IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && r, "null pointer");
+    IAMX_REQUIRE(n_cams > 0 && n_pts > 0 && n_obs >= 0, "bad size");
+    if (n_obs == 0) return IAMX_OK;
+    hipLaunchKernelGGL(ba_residual_kernel, dim3(grid_for(n_obs)), dim3(256), 0,
+                       iamx::as_stream(stream), cams, n_cams, pts, cam_idx, pt_idx, uv, n_obs,
+                       calib, r);
+    return iamx::check_launch("iamx_ba_residual");
+}
+
+extern "C" int iamx_ba_residual_jac(const double *cams, int n_cams, const double *pts, int n_pts,
+                                    const int32_t *cam_idx, const int32_t *pt_idx,
+                                    const double *uv, int64_t n_obs, const double *calib,
+                                    double *r, double *Jc, double *Jp, double *Jk, void *stream)
+{
+    IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && Jc && Jp, "null pointer");
+    IAMX_REQUIRE(n_cams > 0 && n_pts > 0 && n_obs >= 0, "bad size");
+    if (n_obs == 0) return IAMX_OK;
+    if (Jk)
+        hipLaunchKernelGGL(ba_residual_jac_kernel<true>, dim3(grid_for(n_obs)), dim3(256), 0,
+                           iamx::as_stream(stream), cams, n_cams, pts, cam_idx, pt_idx, uv, n_obs,
+                           calib, r, Jc, Jp, Jk);
+    else
+        hipLaunchKernelGGL(ba_residual_jac_kernel<false>, dim3(grid_for(n_obs)), dim3(256), 0,
+                           iamx::as_stream(stream), cams, n_cams, pts, cam_idx, pt_idx, uv, n_obs,
+                           calib, r, Jc, Jp, Jk);
+    return iamx::check_launch("iamx_ba_residual_jac");
+}

@@ -1,0 +1,202 @@
+"""Thin python bindings over the C ABI: torch tensors are device-buffer containers only,
+every number is produced by a hand-written HIP kernel in libiamx.so (csrc/*.hip)."""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, require_gpu, stream_ptr
+
+I8, I32, I64, F64, U8 = torch.int8, torch.int32, torch.int64, torch.float64, torch.uint8
+
+
+def _ptr(t):
+    return _lib.c_void_p(t.data_ptr()) if t is not None else _lib.c_void_p(0)
+
+
+def _dev(x, dtype):
+    """numpy / tensor -> contiguous device tensor of `dtype` (a copy, not a compute step)."""
+    dev = require_gpu()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device=dev, dtype=dtype).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# descriptor store
+# --------------------------------------------------------------------------------------
+class DescriptorStore(object):
+    """All images' SIFT descriptors packed back to back in HBM (include/iamx.h, 'Descriptor
+    store'): int8 rows (value-128), each image zero-padded to 128 rows, + two int32 norms
+    per row.  288 GB of HBM hold > 10^9 descriptors, so a whole survey stays resident."""
+
+    def __init__(self, counts):
+        dev = require_gpu()
+        L = lib()
+        self.counts = [int(c) for c in counts]
+        pads = [int(L.iamx_desc_padded_rows(c)) for c in self.counts]
+        offs = np.zeros(len(pads) + 1, np.int64)
+        np.cumsum(pads, out=offs[1:])
+        if offs[-1] >= 2 ** 31:
+            raise ValueError("descriptor store limited to 2^31 rows")
+        self.offsets = offs
+        total = max(int(offs[-1]), 1)
+        self.desc = torch.empty((total, 128), dtype=I8, device=dev)
+        self.norm_q = torch.empty(total, dtype=I32, device=dev)
+        self.norm_t = torch.empty(total, dtype=I32, device=dev)
+        self.img_off = torch.from_numpy(offs[:-1].astype(np.int32)).to(dev)
+        self.img_n = torch.tensor(self.counts, dtype=I32, device=dev) if self.counts else \
+            torch.zeros(0, dtype=I32, device=dev)
+
+    def __len__(self):
+        return len(self.counts)
+
+    def set_image(self, i, des):
+        """Pack descriptors of image i.  `des`: [n,128] float32 (cv2/reference layout, integer
+        valued) or uint8, numpy or device tensor."""
+        n = self.counts[i]
+        if n == 0:
+            return
+        if isinstance(des, np.ndarray) and des.dtype != np.uint8 and des.dtype != np.float32:
+            des = des.astype(np.float32)
+        is_u8 = (des.dtype == np.uint8) if isinstance(des, np.ndarray) else (des.dtype == U8)
+        src = _dev(des, U8 if is_u8 else torch.float32)
+        if tuple(src.shape) != (n, 128):
+            raise ValueError("image %d: expected descriptors of shape (%d,128), got %s"
+                             % (i, n, tuple(src.shape)))
+        o = int(self.offsets[i])
+        fn = lib().iamx_desc_pack_u8 if is_u8 else lib().iamx_desc_pack_f32
+        check(fn(_ptr(src), n, _ptr(self.desc[o:]), _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]),
+                 stream_ptr()), 'iamx_desc_pack')
+        # the source buffer must outlive the enqueued kernel
+        torch.cuda.current_stream().synchronize()
+
+    @classmethod
+    def from_arrays(cls, arrays):
+        st = cls([a.shape[0] for a in arrays])
+        for i, a in enumerate(arrays):
+            st.set_image(i, a)
+        return st
+
+
+def wg_per_pair(nq):
+    return (int(nq) + 255) // 256
+
+
+def knn2_pairs(store, pairs):
+    """Exact 2-NN for a batch of ordered (query image, train image) pairs.
+
+    Returns (idx, d2, out_off): idx/d2 int32 device tensors [sum n_q, 2], out_off a numpy
+    int64 [n_pairs+1] of each pair's first output row."""
+    dev = require_gpu()
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    counts = np.asarray(store.counts, np.int64)
+    P = len(pairs)
+    nq = counts[pairs[:, 0]] if P else np.zeros(0, np.int64)
+    if P and counts[pairs[:, 1]].min() < 2:
+        raise ValueError("train image with fewer than 2 descriptors "
+                         "(the reference returns no matches there, lib/matcher.py:205-210)")
+    out_off = np.zeros(P + 1, np.int64)
+    np.cumsum(nq, out=out_off[1:])
+    wg = np.zeros(P + 1, np.int64)
+    np.cumsum((nq + 255) // 256, out=wg[1:])
+    if wg[-1] >= 2 ** 31:
+        raise ValueError("batch too large: split the pair list")
+    total = int(out_off[-1])
+    idx = torch.empty((max(total, 1), 2), dtype=I32, device=dev)
+    d2 = torch.empty((max(total, 1), 2), dtype=I32, device=dev)
+    if P == 0 or total == 0:
+        return idx[:0], d2[:0], out_off
+    d_pairs = torch.from_numpy(pairs).to(dev)
+    d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
+    d_out = torch.from_numpy(out_off[:-1].copy()).to(dev)
+    check(lib().iamx_knn2_l2_pairs(_ptr(store.desc), _ptr(store.norm_q), _ptr(store.norm_t),
+                                   _ptr(store.img_off), _ptr(store.img_n), _ptr(d_pairs),
+                                   _ptr(d_wg), _ptr(d_out), P, int(wg[-1]), _ptr(idx), _ptr(d2),
+                                   stream_ptr()), 'iamx_knn2_l2_pairs')
+    torch.cuda.current_stream().synchronize()      # launch tables are temporaries
+    return idx[:total], d2[:total], out_off
+
+
+def knn2(des_q, des_t):
+    """Single pair convenience (packs both sides): returns device (idx[nq,2], d2[nq,2])."""
+    dev = require_gpu()
+    st = DescriptorStore.from_arrays([des_q, des_t])
+    nq, nt = st.counts
+    idx = torch.empty((max(nq, 1), 2), dtype=I32, device=dev)
+    d2 = torch.empty((max(nq, 1), 2), dtype=I32, device=dev)
+    o = int(st.offsets[1])
+    check(lib().iamx_knn2_l2_u8(_ptr(st.desc), _ptr(st.norm_q), nq, _ptr(st.desc[o:]),
+                                _ptr(st.norm_t[o:]), nt, _ptr(idx), _ptr(d2), stream_ptr()),
+          'iamx_knn2_l2_u8')
+    torch.cuda.current_stream().synchronize()
+    return idx[:nq], d2[:nq]
+
+
+# --------------------------------------------------------------------------------------
+# metric filter + compaction
+# --------------------------------------------------------------------------------------
+def match_metric(d2, seg_off, thresh):
+    """d2 [n,2] int32 device; seg_off numpy/tensor int64 [n_seg+1].  Returns device tensors
+    (metric f64 [n], keep u8 [n], seg_count i32 [n_seg]) and the number of d1==0 rows."""
+    dev = require_gpu()
+    n = d2.shape[0]
+    seg = _dev(seg_off, I64)
+    n_seg = seg.numel() - 1
+    metric = torch.empty(max(n, 1), dtype=F64, device=dev)
+    keep = torch.empty(max(n, 1), dtype=U8, device=dev)
+    cnt = torch.zeros(max(n_seg, 1), dtype=I32, device=dev)
+    zd = torch.zeros(1, dtype=I32, device=dev)
+    check(lib().iamx_match_metric(_ptr(d2), _ptr(seg), n_seg, float(thresh), _ptr(metric),
+                                  _ptr(keep), _ptr(cnt), _ptr(zd), stream_ptr()),
+          'iamx_match_metric')
+    return metric[:n], keep[:n], cnt[:n_seg], zd
+
+
+def exclusive_scan(counts):
+    dev = require_gpu()
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=I64, device=dev)
+    check(lib().iamx_exclusive_scan_i32(_ptr(counts), n, _ptr(out), stream_ptr()),
+          'iamx_exclusive_scan_i32')
+    return out
+
+
+def match_compact(idx, metric, keep, seg_off, surv_off, total):
+    dev = require_gpu()
+    seg = _dev(seg_off, I64)
+    n_seg = seg.numel() - 1
+    sq = torch.empty(max(total, 1), dtype=I32, device=dev)
+    stt = torch.empty(max(total, 1), dtype=I32, device=dev)
+    sm = torch.empty(max(total, 1), dtype=F64, device=dev)
+    check(lib().iamx_match_compact(_ptr(idx), _ptr(metric), _ptr(keep), _ptr(seg), _ptr(surv_off),
+                                   n_seg, _ptr(sq), _ptr(stt), _ptr(sm), stream_ptr()),
+          'iamx_match_compact')
+    return sq[:total], stt[:total], sm[:total]
+
+
+# --------------------------------------------------------------------------------------
+# bundle adjustment
+# --------------------------------------------------------------------------------------
+def ba_residual(cams, pts, cam_idx, pt_idx, uv, calib, out=None):
+    """All arguments device tensors (f64 / i32).  Returns r [2*n_obs] f64."""
+    dev = require_gpu()
+    n_obs = cam_idx.numel()
+    r = out if out is not None else torch.empty(max(2 * n_obs, 1), dtype=F64, device=dev)
+    check(lib().iamx_ba_residual(_ptr(cams), cams.numel() // 7, _ptr(pts), pts.numel() // 3,
+                                 _ptr(cam_idx), _ptr(pt_idx), _ptr(uv), n_obs, _ptr(calib),
+                                 _ptr(r), stream_ptr()), 'iamx_ba_residual')
+    return r[:2 * n_obs]
+
+
+def ba_residual_jac(cams, pts, cam_idx, pt_idx, uv, calib, with_calib=False):
+    dev = require_gpu()
+    n_obs = cam_idx.numel()
+    r = torch.empty(max(2 * n_obs, 1), dtype=F64, device=dev)
+    Jc = torch.empty((max(n_obs, 1), 2, 7), dtype=F64, device=dev)
+    Jp = torch.empty((max(n_obs, 1), 2, 3), dtype=F64, device=dev)
+    Jk = torch.empty((max(n_obs, 1), 2, 8), dtype=F64, device=dev) if with_calib else None
+    check(lib().iamx_ba_residual_jac(_ptr(cams), cams.numel() // 7, _ptr(pts), pts.numel() // 3,
+                                     _ptr(cam_idx), _ptr(pt_idx), _ptr(uv), n_obs, _ptr(calib),
+                                     _ptr(r), _ptr(Jc), _ptr(Jp), _ptr(Jk), stream_ptr()),
+          'iamx_ba_residual_jac')
+    return r[:2 * n_obs], Jc[:n_obs], Jp[:n_obs], (Jk[:n_obs] if with_calib else None)

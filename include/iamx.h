@@ -1,0 +1,146 @@
+/* iamx.h -- C ABI of libiamx.so: the MI355X (gfx950) feature-matching and sparse
+ * bundle-adjustment hot path of NorthStarUAS/ImageAnalysis.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, a negative IAMX_E* code otherwise;
+ *     iamx_last_error() gives the message of the calling thread's last failure.
+ *   - every pointer marked DEV is a HIP device pointer (e.g. torch.Tensor.data_ptr());
+ *     HOST pointers are ordinary host memory.  The caller allocates every buffer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
+ *     enqueue work, the caller synchronises.  No hidden globals, no allocation.
+ *   - reference citations are file:line in NorthStarUAS/ImageAnalysis.
+ *
+ * A reference-side binding (ctypes) is shown in INTEGRATION.md.
+ */
+#ifndef IAMX_H
+#define IAMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IAMX_OK            0
+#define IAMX_EINVAL       -1   /* bad argument (null pointer, size out of range)        */
+#define IAMX_ELAUNCH      -2   /* HIP reported a launch / runtime error                 */
+#define IAMX_ENODEVICE    -3   /* no gfx950 device visible                              */
+
+#define IAMX_DESC_DIM      128 /* SIFT descriptor length (scripts/lib/image.py:324)      */
+#define IAMX_ROW_PAD       128 /* packed images are padded to a multiple of this many rows */
+
+int         iamx_version(void);
+const char *iamx_last_error(void);
+/* name of the architecture the kernels were compiled for ("gfx950") */
+const char *iamx_arch(void);
+
+/* ------------------------------------------------------------------------------------
+ * Descriptor store.  cv2.SIFT hands the reference float32 rows holding integers 0..255
+ * (scripts/lib/image.py:324, cache format :204-217).  The device store keeps them as
+ * int8 (value-128), each image padded to IAMX_ROW_PAD rows of zeros, plus two int32 per
+ * row: norm_q = sum((a-128)^2) and norm_t = norm_q + 2*sum(a-128), so that
+ *     sum((a-b)^2) = norm_q[a] + norm_t[b] + 2 * sum((127-a)*(b-128))      (exact, int32)
+ * and the inner sum is one i8 MFMA contraction.
+ * ------------------------------------------------------------------------------------ */
+/* rows of storage needed for an image with n_rows descriptors */
+int64_t iamx_desc_padded_rows(int64_t n_rows);
+
+/* src: DEV [n_rows][128] uint8 (or float32 integer-valued for _f32; values are clamped
+ * to 0..255 after rounding to nearest).  dst: DEV [padded_rows][128] int8;
+ * norm_q/norm_t: DEV [padded_rows] int32. */
+int iamx_desc_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst,
+                      int32_t *norm_q, int32_t *norm_t, void *stream);
+int iamx_desc_pack_f32(const float *src, int64_t n_rows, int8_t *dst,
+                       int32_t *norm_q, int32_t *norm_t, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2: exact 2-nearest-neighbour search in L2 -- replaces
+ *   the_matcher.knnMatch(des1, des2, k=2)           scripts/lib/matcher.py:212-214
+ * (FLANN there; the exact search FLANN approximates == cv2.BFMatcher(NORM_L2)).
+ * For every query row: the two train rows with the smallest squared distance, nearest
+ * first, equal distances ordered by train index (lowest first).  cv2's DMatch.distance
+ * is float32(sqrt(float32(d2))).
+ *
+ * Batched form: one launch matches many ordered (query image, train image) pairs out of
+ * one packed descriptor store.
+ *   desc/norm_q/norm_t  DEV  packed store (all images back to back)
+ *   img_off  DEV [n_img] int32  first packed row of each image (multiple of IAMX_ROW_PAD)
+ *   img_n    DEV [n_img] int32  valid rows of each image (>= 2 for a train image)
+ *   pairs    DEV [n_pairs][2] int32  (query image, train image)
+ *   wg_off   DEV [n_pairs+1] int32   exclusive scan of iamx_knn2_wg_per_pair(n_q)
+ *   out_off  DEV [n_pairs] int64     first output row of each pair
+ *   out_idx  DEV [sum n_q][2] int32  train row (0-based inside the train image)
+ *   out_d2   DEV [sum n_q][2] int32  squared distances
+ *   total_wg = wg_off[n_pairs] (HOST value)
+ * ------------------------------------------------------------------------------------ */
+int iamx_knn2_wg_per_pair(int n_query_rows);
+
+int iamx_knn2_l2_pairs(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
+                       const int32_t *img_off, const int32_t *img_n,
+                       const int32_t *pairs, const int32_t *wg_off, const int64_t *out_off,
+                       int n_pairs, int total_wg,
+                       int32_t *out_idx, int32_t *out_d2, void *stream);
+
+/* Single pair over two packed images (thin wrapper over the batched kernel).
+ * q_*, t_*: DEV packed image (iamx_desc_pack_*); idx/d2: DEV [nq][2] int32. */
+int iamx_knn2_l2_u8(const int8_t *q_desc, const int32_t *q_norm_q, int nq,
+                    const int8_t *t_desc, const int32_t *t_norm_t, int nt,
+                    int32_t *idx, int32_t *d2, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Quality metric + threshold -- replaces the python loop scripts/lib/matcher.py:253-263:
+ *     ratio = d0/d1 ; metric = d0*ratio ; keep metric < max_distance*match_ratio
+ * with d0,d1 = float32 sqrt of the squared distances, the rest in float64 like python.
+ *   idx,d2     DEV [n][2] int32  (output of iamx_knn2_*)
+ *   seg_off    DEV [n_seg+1] int64  rows of each (ordered) pair inside idx/d2
+ *   metric     DEV [n] float64     (all rows; NaN where d1 == 0 -> python raises there)
+ *   keep       DEV [n] uint8
+ *   seg_count  DEV [n_seg] int32   survivors per pair
+ *   zero_div   DEV [1] int32       incremented for rows with d1 == 0 (matcher.py:255)
+ * ------------------------------------------------------------------------------------ */
+int iamx_match_metric(const int32_t *d2, const int64_t *seg_off, int n_seg, double thresh,
+                      double *metric, uint8_t *keep, int32_t *seg_count, int32_t *zero_div,
+                      void *stream);
+
+/* Order-preserving compaction of the survivors of every pair.
+ *   surv_off   DEV [n_seg+1] int64  exclusive scan of seg_count (caller computes it, or
+ *                                   iamx_exclusive_scan_i32)
+ *   surv_q/surv_t  DEV [sum seg_count] int32   query row / train row
+ *   surv_metric    DEV [sum seg_count] float64 */
+int iamx_match_compact(const int32_t *idx, const double *metric, const uint8_t *keep,
+                       const int64_t *seg_off, const int64_t *surv_off, int n_seg,
+                       int32_t *surv_q, int32_t *surv_t, double *surv_metric, void *stream);
+
+/* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
+int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3: bundle-adjustment reprojection residual -- replaces Optimizer.fun
+ *   scripts/lib/optimizer.py:174-229 (per-camera cv2.projectPoints + concatenate).
+ *   cams    DEV [n_cams][7] float64  ned(3), quat w,x,y,z (unnormalised; :326-328)
+ *   pts     DEV [n_pts][3]  float64
+ *   cam_idx / pt_idx  DEV [n_obs] int32   camera-major observation list (:397-404)
+ *   uv      DEV [n_obs][2] float64   observed (distorted, full-res px; :383)
+ *   calib   DEV [9] float64  fx, fy, cu, cv, k1, k2, p1, p2, k3   (lib/camera.py:94)
+ *   r       DEV [2*n_obs] float64   (du0, dv0, du1, dv1, ...) = observed - projected
+ * ------------------------------------------------------------------------------------ */
+int iamx_ba_residual(const double *cams, int n_cams, const double *pts, int n_pts,
+                     const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
+                     int64_t n_obs, const double *calib, double *r, void *stream);
+
+/* Residual + analytic Jacobian blocks (the reference has only finite differences:
+ * scripts/lib/optimizer.py:142-169,491-501).  d r / d params, row-major per observation:
+ *   Jc  DEV [n_obs][2][7]   wrt that observation's camera (ned, quat)
+ *   Jp  DEV [n_obs][2][3]   wrt its 3-D point
+ *   Jk  DEV [n_obs][2][8] or NULL   wrt (f, cu, cv, k1, k2, p1, p2, k3) with fx=fy=f
+ *                                   ('global' calibration, optimizer.py:181-189)
+ *   r may be NULL. */
+int iamx_ba_residual_jac(const double *cams, int n_cams, const double *pts, int n_pts,
+                         const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
+                         int64_t n_obs, const double *calib, double *r,
+                         double *Jc, double *Jp, double *Jk, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAMX_H */

@@ -1,0 +1,67 @@
+"""ORACLE / TEST INFRASTRUCTURE ONLY -- ctypes wrapper over oracle/cpu_ref.c
+(liboracle_cpu.so, built by oracle/Makefile or __graft_entry__.build())."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'liboracle_cpu.so')
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or \
+            os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, 'cpu_ref.c')):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle_cpu.so'],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_knn2_l2_u8.restype = ctypes.c_int
+        _lib.oracle_ba_residual.restype = ctypes.c_int
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def knn2_l2_u8(q, t, nthreads=0):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    idx = np.empty((q.shape[0], 2), np.int32)
+    d2 = np.empty((q.shape[0], 2), np.int32)
+    rc = lib().oracle_knn2_l2_u8(_p(q), ctypes.c_int(q.shape[0]), _p(t), ctypes.c_int(t.shape[0]),
+                                 _p(idx), _p(d2), ctypes.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_knn2_l2_u8 rc=%d" % rc)
+    return idx, d2
+
+
+def ba_residual(cams, pts, cam_idx, pt_idx, uv, intr, dist, nthreads=0):
+    cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 7)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    cam_idx = np.ascontiguousarray(cam_idx, np.int32)
+    pt_idx = np.ascontiguousarray(pt_idx, np.int32)
+    uv = np.ascontiguousarray(uv, np.float64)
+    intr = np.ascontiguousarray(intr, np.float64)
+    dist = np.ascontiguousarray(dist, np.float64)
+    r = np.empty(2 * cam_idx.size, np.float64)
+    lib().oracle_ba_residual(_p(cams), ctypes.c_int(cams.shape[0]), _p(pts),
+                             ctypes.c_int(pts.shape[0]), _p(cam_idx), _p(pt_idx), _p(uv),
+                             ctypes.c_int64(cam_idx.size), _p(intr), _p(dist), _p(r),
+                             ctypes.c_int(nthreads))
+    return r
+
+
+def num_threads():
+    return lib().oracle_num_threads()

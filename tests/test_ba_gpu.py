@@ -1,0 +1,114 @@
+"""GPU: BA residual / Jacobian kernels against the oracle and the reference's golden vectors.
+Floating point: tolerance 1e-5 relative (BASELINE.json north_star); we assert far tighter."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
+REL_TOL = 1e-5          # north_star tolerance
+TIGHT = 1e-10           # what float64 on the device actually delivers
+
+
+def _dev(a, dt=None):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda()
+
+
+def _problem(g):
+    C, P = int(g['n_cameras']), int(g['n_points'])
+    x = g['x0']
+    K = g['K']
+    if bool(g['cam_calib']):
+        cal = x[C * 7 + P * 3:]
+        calib = np.array([cal[0], cal[0], cal[1], cal[2], *cal[3:8]])
+    else:
+        calib = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], *g['dist']])
+    return C, P, x, calib
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_residual_golden(path):
+    from imageanalysis_amd import kernels
+    g = np.load(path)
+    C, P, x, calib = _problem(g)
+    r = kernels.ba_residual(_dev(x[:C * 7]), _dev(x[C * 7:C * 7 + P * 3]),
+                            _dev(g['camera_indices']), _dev(g['point_indices']),
+                            _dev(g['points_2d']), _dev(calib)).cpu().numpy()
+    scale = np.abs(g['f0']).max()
+    err = np.abs(r - g['f0']).max() / scale
+    assert err < TIGHT < REL_TOL
+    # and at the reference's converged solution
+    xf = g['x_final']
+    if bool(g['cam_calib']):
+        cal = xf[C * 7 + P * 3:]
+        calib = np.array([cal[0], cal[0], cal[1], cal[2], *cal[3:8]])
+    r = kernels.ba_residual(_dev(xf[:C * 7]), _dev(xf[C * 7:C * 7 + P * 3]),
+                            _dev(g['camera_indices']), _dev(g['point_indices']),
+                            _dev(g['points_2d']), _dev(calib)).cpu().numpy()
+    assert np.abs(r - g['f_final']).max() / scale < TIGHT
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_jacobian_vs_reference_finite_differences(path):
+    """Analytic 2x(7+3[+8]) blocks == scipy's sparse finite differences of the REFERENCE's own
+    fun (3-point scheme), entry by entry."""
+    from imageanalysis_amd import kernels
+    g = np.load(path)
+    C, P, x, calib = _problem(g)
+    wc = bool(g['cam_calib'])
+    r, Jc, Jp, Jk = kernels.ba_residual_jac(_dev(x[:C * 7]), _dev(x[C * 7:C * 7 + P * 3]),
+                                            _dev(g['camera_indices']), _dev(g['point_indices']),
+                                            _dev(g['points_2d']), _dev(calib), with_calib=wc)
+    assert np.abs(r.cpu().numpy() - g['f0']).max() / np.abs(g['f0']).max() < TIGHT
+    Jc, Jp = Jc.cpu().numpy(), Jp.cpu().numpy()
+    import scipy.sparse as sp
+    n = x.size
+    O = g['camera_indices'].size
+    J3 = sp.csr_matrix((g['J3_data'], g['J3_indices'], g['J3_indptr']), shape=(2 * O, n)).toarray()
+    ci, pi = g['camera_indices'], g['point_indices']
+    ref_c = np.empty((O, 2, 7))
+    ref_p = np.empty((O, 2, 3))
+    for o in range(O):
+        ref_c[o] = J3[2 * o:2 * o + 2, ci[o] * 7:ci[o] * 7 + 7]
+        ref_p[o] = J3[2 * o:2 * o + 2, C * 7 + pi[o] * 3:C * 7 + pi[o] * 3 + 3]
+    # finite differences are good to ~1e-7 relative to the largest entry of a row
+    sc = np.abs(ref_c).max()
+    assert np.abs(Jc - ref_c).max() / sc < 1e-6
+    sp_ = np.abs(ref_p).max()
+    assert np.abs(Jp - ref_p).max() / sp_ < 1e-6
+    if wc:
+        Jk = Jk.cpu().numpy()
+        ref_k = J3[:, C * 7 + P * 3:].reshape(O, 2, 8)
+        for k in range(8):
+            s = max(np.abs(ref_k[:, :, k]).max(), 1e-12)
+            assert np.abs(Jk[:, :, k] - ref_k[:, :, k]).max() / s < 1e-5, k
+
+
+def test_residual_large_vs_c_oracle():
+    """200k observations, random gather pattern, vs the plain-C oracle."""
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(7)
+    C, P, O = 300, 30000, 200000
+    cams = np.zeros((C, 7))
+    cams[:, :3] = rng.normal(0, 50, (C, 3)) + [0, 0, -100]
+    cams[:, 3:] = np.array([0.7071, 0, -0.7071, 0]) * rng.uniform(0.5, 2.0, (C, 1)) \
+        + rng.normal(0, 0.02, (C, 4))
+    pts = rng.normal(0, 40, (P, 3))
+    ci = np.sort(rng.integers(0, C, O)).astype(np.int32)
+    pi = rng.integers(0, P, O).astype(np.int32)
+    uv = rng.uniform(0, 5000, (O, 2))
+    calib = np.array([3666.6665, 3666.6665, 2736.0, 1824.0, -0.12, 0.083, -0.0016, -0.00096, -0.012])
+    r = kernels.ba_residual(_dev(cams), _dev(pts), _dev(ci), _dev(pi), _dev(uv),
+                            _dev(calib)).cpu().numpy()
+    rr = cpu_ref.ba_residual(cams, pts, ci, pi, uv, calib[:4], calib[4:])
+    assert np.abs(r - rr).max() / np.abs(rr).max() < TIGHT

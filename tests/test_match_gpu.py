@@ -1,0 +1,202 @@
+"""GPU: the HIP matching kernels (through the C ABI) against the oracle and the golden
+vectors.  Integer work -> bit-exact."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+MATCH_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'match_*.npz')))
+
+
+def _sift_like(rng, n):
+    g = rng.gamma(0.6, 1.0, size=(n, 128))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g = np.minimum(g, 0.2)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    return np.clip(np.rint(g * 512.0), 0, 255).astype(np.uint8)
+
+
+def test_single_hip_runtime_and_native_lib_loaded():
+    import torch
+    from imageanalysis_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+    maps = open('/proc/self/maps').read()
+    hips = {l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l}
+    assert len(hips) == 1, hips
+    assert 'libiamx.so' in maps
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_knn2_golden(path):
+    from imageanalysis_amd import kernels
+    from oracle import match_oracle as mo
+    g = np.load(path)
+    for tag, (a, b) in dict(fwd=(g['des1'], g['des2']), rev=(g['des2'], g['des1'])).items():
+        idx, d2 = kernels.knn2(a, b)
+        assert np.array_equal(idx.cpu().numpy(), g['knn_%s_idx' % tag])
+        assert np.array_equal(mo.distances_f32(d2.cpu().numpy()), g['knn_%s_dist' % tag])
+        # the reference hands float32 descriptors to knnMatch
+        idx, d2b = kernels.knn2(a.astype(np.float32), b.astype(np.float32))
+        assert np.array_equal(idx.cpu().numpy(), g['knn_%s_idx' % tag])
+        assert np.array_equal(d2b.cpu().numpy(), d2.cpu().numpy())
+
+
+@pytest.mark.parametrize('nq,nt', [(1, 2), (2, 2), (31, 5), (33, 127), (64, 128), (255, 129),
+                                   (257, 300), (1000, 257), (300, 4096), (4096, 1031)])
+def test_knn2_ragged_sizes_vs_oracle(nq, nt):
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q = rng.integers(0, 256, (nq, 128), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, 128), dtype=np.uint8)
+    idx, d2 = kernels.knn2(q, t)
+    ridx, rd2 = cpu_ref.knn2_l2_u8(q, t)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_knn2_ties_lowest_train_index_wins():
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(3)
+    t = _sift_like(rng, 1500)
+    t[700:1400] = t[:700]                  # exact duplicates 700 rows apart (other lane half,
+    t[5] = t[4]                            # other 256-row epoch, neighbouring rows)
+    q = t[rng.permutation(1500)[:600]].copy()
+    idx, d2 = kernels.knn2(q, t)
+    ridx, rd2 = cpu_ref.knn2_l2_u8(q, t)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+    assert (rd2[:, 0] == 0).all()
+
+
+def test_knn2_extreme_values_no_overflow():
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    q = np.zeros((40, 128), np.uint8)
+    q[1::2] = 255
+    t = np.zeros((300, 128), np.uint8)
+    t[::3] = 255
+    t[1::3] = 128
+    idx, d2 = kernels.knn2(q, t)
+    ridx, rd2 = cpu_ref.knn2_l2_u8(q, t)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+    # only far neighbours: every distance is the maximum 128*255^2
+    idx, d2 = kernels.knn2(np.zeros((5, 128), np.uint8), np.full((9, 128), 255, np.uint8))
+    assert (d2.cpu().numpy() == 128 * 255 * 255).all()
+    assert (idx.cpu().numpy() == [0, 1]).all()
+
+
+def test_knn2_rejects_single_row_train_like_reference():
+    from imageanalysis_amd import kernels, _lib
+    with pytest.raises(_lib.IamxError):
+        kernels.knn2(np.zeros((4, 128), np.uint8), np.zeros((1, 128), np.uint8))
+
+
+def test_knn2_pairs_batch_ragged_images():
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(9)
+    sizes = [300, 2, 257, 1024, 129, 640, 77]
+    imgs = [_sift_like(rng, n) for n in sizes]
+    imgs[3][:200] = np.clip(imgs[0][:200].astype(int) + rng.integers(-5, 6, (200, 128)), 0, 255)
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    idx, d2, off = kernels.knn2_pairs(store, np.array(pairs, np.int32))
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    for p, (i, j) in enumerate(pairs):
+        ridx, rd2 = cpu_ref.knn2_l2_u8(imgs[i], imgs[j])
+        assert np.array_equal(idx[off[p]:off[p + 1]], ridx), (i, j)
+        assert np.array_equal(d2[off[p]:off[p + 1]], rd2), (i, j)
+
+
+def test_metric_kernel_sqrt_and_division_exact():
+    """float32 sqrt + float64 divide/multiply on the device == numpy (IEEE) for every
+    representable squared distance class we can meet."""
+    import torch
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(1)
+    n = 1 << 20
+    d0 = rng.integers(0, 128 * 255 * 255 + 1, n)
+    d1 = np.maximum(d0, rng.integers(1, 128 * 255 * 255 + 1, n))
+    d2 = np.stack([d0, d1], 1).astype(np.int32)
+    d2[:4096, 0] = np.arange(4096)               # small values incl. perfect squares
+    d2[:4096, 1] = np.maximum(d2[:4096, 0], 1)
+    seg = np.array([0, 1000, 1000, n], np.int64)
+    metric, keep, cnt, zd = kernels.match_metric(torch.from_numpy(d2).cuda(), seg, 202.5)
+    f = np.sqrt(d2.astype(np.float32)).astype(np.float64)
+    ref = f[:, 0] * (f[:, 0] / f[:, 1])
+    assert np.array_equal(metric.cpu().numpy(), ref)
+    rk = ref < 202.5
+    assert np.array_equal(keep.cpu().numpy().astype(bool), rk)
+    assert cnt.cpu().numpy().tolist() == [int(rk[:1000].sum()), 0, int(rk[1000:].sum())]
+    assert int(zd.item()) == 0
+
+
+def test_metric_kernel_flags_zero_division():
+    import torch
+    from imageanalysis_amd import kernels
+    d2 = torch.tensor([[0, 0], [4, 9], [0, 5]], dtype=torch.int32).cuda()
+    metric, keep, cnt, zd = kernels.match_metric(d2, np.array([0, 3], np.int64), 202.5)
+    assert int(zd.item()) == 1
+    m = metric.cpu().numpy()
+    assert np.isnan(m[0]) and m[1] == 2.0 * (2.0 / 3.0) and m[2] == 0.0
+    assert keep.cpu().numpy().tolist() == [0, 1, 1]
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_metric_filter_and_compaction_golden(path):
+    """device top-2 -> metric -> threshold -> compaction, then the host's stable sort + clip
+    == the list the reference hands to matchGMS (lib/matcher.py:253-269)."""
+    import torch
+    from imageanalysis_amd import kernels
+    g = np.load(path)
+    imgs = [g['des1'], g['des2']]
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    idx, d2, off = kernels.knn2_pairs(store, np.array([[0, 1], [1, 0]], np.int32))
+    thresh = 270.0 * float(g['match_ratio'])
+    metric, keep, cnt, zd = kernels.match_metric(d2, off, thresh)
+    soff = kernels.exclusive_scan(cnt)
+    total = int(soff[-1].item())
+    sq, st, sm = kernels.match_compact(idx, metric, keep, off, soff, total)
+    soff = soff.cpu().numpy()
+    sq, st, sm = sq.cpu().numpy(), st.cpu().numpy(), sm.cpu().numpy()
+    for p, tag in enumerate(['fwd', 'rev']):
+        a, b = soff[p], soff[p + 1]
+        order = np.argsort(sm[a:b], kind='stable')[:2000]
+        got = np.stack([sq[a:b][order], st[a:b][order]], 1)
+        want = g['pregms_%s' % tag]
+        if len(want) == 0:
+            assert len(got) < int(g['min_pairs'])
+        else:
+            assert np.array_equal(got, want)
+
+
+def test_config2_shape_properties():
+    """BASELINE config 2 shape (4096 x 4096 x 128) where the oracle is too slow to run for
+    every pair: size-independent properties.  (a) a planted copy is found at distance 0 with
+    the right index, (b) query-order permutation invariance, (c) one pair vs the C oracle."""
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(42)
+    imgs = [_sift_like(rng, 4096) for _ in range(3)]
+    perm = rng.permutation(4096)
+    imgs[1][perm[:1200]] = imgs[0][:1200]
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    idx, d2, off = kernels.knn2_pairs(store, np.array([[0, 1], [1, 0], [2, 1], [0, 2]], np.int32))
+    idx, d2 = idx.cpu().numpy(), d2.cpu().numpy()
+    assert (d2[:1200, 0] == 0).all() and np.array_equal(idx[:1200, 0], perm[:1200])
+    ridx, rd2 = cpu_ref.knn2_l2_u8(imgs[2], imgs[1])
+    assert np.array_equal(idx[off[2]:off[3]], ridx) and np.array_equal(d2[off[2]:off[3]], rd2)
+    # permuting the queries permutes the answers
+    p2 = rng.permutation(4096)
+    i2, dd2 = kernels.knn2(imgs[0][p2], imgs[2])
+    assert np.array_equal(i2.cpu().numpy(), idx[off[3]:off[4]][p2])
+    assert np.array_equal(dd2.cpu().numpy(), d2[off[3]:off[4]][p2])

@@ -1,0 +1,119 @@
+"""CPU: the oracle (numpy + plain C restatement) against the golden vectors that were produced
+by the reference's own scripts/lib/{matcher,optimizer}.py (oracle/gen_golden.py)."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as bo
+from oracle import cpu_ref
+from oracle import match_oracle as mo
+
+from conftest import GOLDEN
+
+MATCH_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'match_*.npz')))
+BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
+
+
+def test_fixtures_present():
+    assert len(MATCH_CASES) >= 5 and len(BA_CASES) >= 4
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_match_pipeline_matches_reference(path):
+    g = np.load(path)
+    size = (int(g['width']), int(g['height']))
+    ratio, min_pairs = float(g['match_ratio']), int(g['min_pairs'])
+    for tag, (da, xa, db, xb) in dict(fwd=(g['des1'], g['xy1'], g['des2'], g['xy2']),
+                                      rev=(g['des2'], g['xy2'], g['des1'], g['xy1'])).items():
+        st = {}
+        basic = mo.basic_pair_matches(da, xa, db, xb, ratio, min_pairs, size, st)
+        assert np.array_equal(st['knn_idx'], g['knn_%s_idx' % tag])
+        assert np.array_equal(mo.distances_f32(st['knn_d2']), g['knn_%s_dist' % tag])
+        if len(g['pregms_%s' % tag]):
+            assert np.array_equal(st['pregms'], g['pregms_%s' % tag])
+            assert np.array_equal(st['postgms'], g['postgms_%s' % tag])
+        else:
+            assert len(st['pregms']) < min_pairs         # reference quit before matchGMS
+        assert np.array_equal(basic, g['basic_%s' % tag])
+    f, r = mo.bidirectional_pair_matches(g['des1'], g['xy1'], g['des2'], g['xy2'], ratio,
+                                         min_pairs, size)
+    assert np.array_equal(f, g['bidir_fwd']) and np.array_equal(r, g['bidir_rev'])
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_c_knn2_matches_reference(path):
+    g = np.load(path)
+    for tag, (a, b) in dict(fwd=(g['des1'], g['des2']), rev=(g['des2'], g['des1'])).items():
+        idx, d2 = cpu_ref.knn2_l2_u8(a, b)
+        assert np.array_equal(idx, g['knn_%s_idx' % tag])
+        assert np.array_equal(mo.distances_f32(d2), g['knn_%s_dist' % tag])
+        idx1, d21 = cpu_ref.knn2_l2_u8(a, b, nthreads=1)
+        assert np.array_equal(idx, idx1) and np.array_equal(d2, d21)
+
+
+def test_c_knn2_ties_and_extremes():
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, 256, (300, 128), dtype=np.uint8)
+    t[100:200] = t[:100]                      # every row has an exact duplicate
+    q = t[rng.permutation(300)[:64]].copy()
+    idx, d2 = cpu_ref.knn2_l2_u8(q, t)
+    idx2, d22 = mo.knn2_l2(q, t)
+    assert np.array_equal(idx, idx2) and np.array_equal(d2, d22)
+    q = np.zeros((3, 128), np.uint8)
+    t = np.full((4, 128), 255, np.uint8)
+    idx, d2 = cpu_ref.knn2_l2_u8(q, t)
+    assert (d2 == 128 * 255 * 255).all() and (idx == [0, 1]).all()
+
+
+def test_metric_zero_division_like_python():
+    idx = np.array([[0, 1]], np.int32)
+    with pytest.raises(ZeroDivisionError):
+        mo.metric_filter(idx, np.array([[0, 0]], np.int32), 0.75)
+
+
+def _calib(g):
+    K = g['K']
+    return [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_ba_residual_matches_reference(path):
+    g = np.load(path)
+    C, P = int(g['n_cameras']), int(g['n_points'])
+    r = bo.residuals(g['x0'], C, P, g['camera_indices'], g['point_indices'], g['points_2d'],
+                     g['K'], g['dist'], bool(g['cam_calib']))
+    scale = np.abs(g['f0']).max()
+    assert np.abs(r - g['f0']).max() <= 1e-9 * scale
+    # reference's rvec/tvec (lib/optimizer.py:120-126) <-> oracle's direct R, t
+    import math
+    for c in range(C):
+        R, t = bo.camera_rt(g['x0'][c * 7:c * 7 + 7])
+        assert np.allclose(t, g['tvecs'][c], rtol=0, atol=1e-9)
+        rv = g['rvecs'][c]
+        th = math.sqrt(float(rv @ rv))
+        k = rv / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        Rr = math.cos(th) * np.identity(3) + (1 - math.cos(th)) * np.outer(k, k) + math.sin(th) * Kx
+        assert np.allclose(R, Rr, rtol=0, atol=1e-12)
+    if not bool(g['cam_calib']):
+        x = g['x0']
+        rc = cpu_ref.ba_residual(x[:C * 7], x[C * 7:C * 7 + P * 3], g['camera_indices'],
+                                 g['point_indices'], g['points_2d'], _calib(g), g['dist'])
+        assert np.abs(rc - g['f0']).max() <= 1e-9 * scale
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_ba_setup_matches_reference(path):
+    g = np.load(path)
+    with open(path.replace('.npz', '_in.pkl'), 'rb') as f:
+        inp = pickle.load(f)
+    s = bo.setup(inp['names'], inp['groups'], 0, inp['matches'])
+    assert np.array_equal(s['camera_map_fwd'], g['camera_map_fwd'])
+    assert np.array_equal(s['feat_map_rev'], g['feat_map_rev'])
+    assert np.array_equal(s['camera_indices'], g['camera_indices'])
+    assert np.array_equal(s['point_indices'], g['point_indices'])
+    assert np.array_equal(s['points_2d'], g['points_2d'])
+    assert np.array_equal(s['by_camera_counts'], g['by_camera_counts'])
