@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs matched / s on MI355X (BASELINE.json metric), with roofline and a
+CPU baseline on the same line.
+
+Workload (N=1): BASELINE.json configs[1] -- 500 synthetic images x 4096 keypoints x 128-D
+SIFT-like descriptors, brute-force L2 2-NN in BOTH directions for all 124 750 image pairs,
+plus the reference's quality-metric filter and survivor compaction on the device
+(metric M1).  A "step" = one pass over all pairs of the rank's shard.
+N>1 (weak scaling): the survey grows to ~500*sqrt(N) images so that every rank still matches
+~124 750 pairs; each rank owns 1/N of the images' descriptors, they are all-gathered over RCCL
+inside the step (the path's one exchange step), then every rank matches its shard of the pair
+schedule -- no other data-path collective.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+KPTS = 4096
+DIM = 128
+FLOP_PER_PAIR = 2.0 * KPTS * KPTS * DIM          # one distance matrix serves both directions
+I8_DENSE_PEAK_TFLOPS = 5000.0                    # 2 x bf16 dense (MI355X_MICROARCH.md)
+PAIRS_PER_RANK = 124750                          # configs[1]: C(500, 2)
+MATCH_RATIO = 0.75
+MAX_DISTANCE = 270.0
+
+
+def synth_descriptors(n_img, first, count, device, seed=1234):
+    """SIFT-like u8 descriptors for images [first, first+count): gamma(0.6)
+    -> L2 normalise -> clip 0.2 -> renormalise -> x512 -> saturate; image j copies 30 % of
+    image j-1's rows with integer noise U[-6,6].  Data generation only (torch), not the path."""
+    out = torch.empty((count, KPTS, DIM), dtype=torch.uint8, device=device)
+    alpha = torch.full((KPTS, DIM), 0.6, device=device)
+
+    def base(j):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + j)
+        x = torch._standard_gamma(alpha, generator=g)
+        x = x / x.norm(dim=1, keepdim=True)
+        x = x.clamp(max=0.2)
+        x = x / x.norm(dim=1, keepdim=True)
+        return (x * 512.0).round().clamp(0, 255), g
+
+    prev = None                                # base (pre-copy) descriptors of image j-1
+    for j in range(max(first - 1, 0), first + count):
+        cur, g = base(j)
+        base_j = cur.clone()
+        if prev is not None:
+            k = int(0.3 * KPTS)
+            src = torch.randperm(KPTS, generator=g, device=device)[:k]
+            dst = torch.randperm(KPTS, generator=g, device=device)[:k]
+            noise = torch.randint(-6, 7, (k, DIM), generator=g, device=device)
+            cur[dst] = (prev[src] + noise).clamp(0, 255)
+        prev = base_j
+        if j >= first:
+            out[j - first] = cur.to(torch.uint8)
+    return out
+
+
+def pair_schedule(n_img, rank, world):
+    """All unordered pairs, dealt to ranks in contiguous blocks of the train-major order, both
+    directions of a pair on the same rank."""
+    ii, jj = np.triu_indices(n_img, k=1)
+    n = len(ii)
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    ii, jj = ii[lo:hi], jj[lo:hi]
+    ordered = np.concatenate([np.stack([ii, jj], 1), np.stack([jj, ii], 1)]).astype(np.int32)
+    order = np.lexsort((ordered[:, 0], ordered[:, 1]))       # train-major: L2 reuse of the train
+    return ordered[order], hi - lo
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--images', type=int, default=0, help='override the survey size')
+    ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group('nccl', device_id=dev)
+
+    from imageanalysis_amd import kernels
+
+    # ---- survey size: total pairs ~= world * PAIRS_PER_RANK, a multiple of world images
+    n_img = args.images or int(round((1 + math.sqrt(1 + 8.0 * world * PAIRS_PER_RANK)) / 2))
+    per = (n_img + world - 1) // world
+    n_img = per * world
+    first, mine = rank * per, per
+
+    # ---- this rank's images (as if it had detected them there), packed locally
+    raw = synth_descriptors(n_img, first, mine, dev)
+    store = kernels.DescriptorStore([KPTS] * n_img)
+    rows_per = int(store.offsets[1] - store.offsets[0])
+
+    def pack_and_gather():
+        """pack own images into the store, then RCCL all-gather (desc, norm_q, norm_t) in
+        place: rank r's shard already sits at offset r*shard of the receive buffer."""
+        L, _ptr, sp = kernels.lib(), kernels._ptr, kernels.stream_ptr()
+        o = int(store.offsets[first])
+        kernels.check(L.iamx_desc_pack_u8(_ptr(raw), mine * KPTS, _ptr(store.desc[o:]),
+                                          _ptr(store.norm_q[o:]), _ptr(store.norm_t[o:]), sp),
+                      'iamx_desc_pack_u8')
+        if dist is not None:
+            for buf, width in ((store.desc, rows_per * DIM), (store.norm_q, rows_per),
+                               (store.norm_t, rows_per)):
+                flat = buf.view(-1)
+                shard = per * width
+                dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard])
+
+    ordered, n_pairs_rank = pair_schedule(n_img, rank, world)
+    sb = args.sub_batch
+    batches = [kernels.PairBatch(store, ordered[s:s + sb]) for s in range(0, len(ordered), sb)]
+    ws = kernels.PairWorkspace(max(b.rows for b in batches), max(b.n_pairs for b in batches))
+    thresh = MAX_DISTANCE * MATCH_RATIO
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in batches]
+    survivors = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step(timed_events=False):
+        pack_and_gather()
+        for b, (e0, e1) in zip(batches, ev):
+            if timed_events:
+                e0.record()
+            b.run_knn2(ws)
+            if timed_events:
+                e1.record()
+            b.run_filter(ws, thresh)
+            survivors.add_(ws.surv_off[b.n_pairs])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    survivors.zero_()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(timed_events=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([n_pairs_rank], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        total_pairs = int(cnt.item())
+    else:
+        total_pairs = n_pairs_rank
+
+    # ---- roofline of the dominant kernel (knn2_pairs_kernel), HIP events of the last step
+    k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    k_pairs = [b.n_pairs / 2.0 for b in batches]           # unordered pairs per launch
+    achieved = sum(k_pairs) * FLOP_PER_PAIR / (sum(k_ms) * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "knn2_pairs_kernel",
+                "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
+                "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR}
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(raw[:2].cpu().numpy() if mine >= 2 else None)
+        value = total_pairs * args.steps / dt
+        out = {
+            "metric": "image_pairs_matched_per_sec", "value": round(value, 1), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (int8 MFMA, int32 accumulate)",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic images x %d kpts x 128-D, all-pairs "
+                                   "brute-force L2 2-NN both directions + metric filter + "
+                                   "compaction" % (n_img, KPTS),
+                       "images": n_img, "kpts": KPTS, "pairs_per_step": total_pairs,
+                       "parallelism": "pair-shard x%d%s" % (world, " + RCCL descriptor all-gather"
+                                                            if world > 1 else "")},
+            "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(two_images):
+    """The oracle's plain-C brute-force 2-NN (oracle/cpu_ref.c, OpenMP over all host cores)
+    on a bounded sample of the same workload: 4096x4096x128 pairs, both directions, ~10 s."""
+    from oracle import cpu_ref
+    rng = np.random.default_rng(0)
+    if two_images is None:
+        two_images = rng.integers(0, 256, (2, KPTS, DIM), dtype=np.uint8)
+    a, b = np.ascontiguousarray(two_images[0]), np.ascontiguousarray(two_images[1])
+    threads = cpu_ref.num_threads()
+    cpu_ref.knn2_l2_u8(a, b)                        # warm
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cpu_ref.knn2_l2_u8(a, b)
+        cpu_ref.knn2_l2_u8(b, a)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 4096:
+            break
+    return {"value": round(n / el, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "%d pairs of 4096x4096x128 (both directions, top-2 only) in %.1f s with "
+                      "oracle/cpu_ref.c (OpenMP, %d threads)" % (n, el, threads)}
+
+
+if __name__ == '__main__':
+    main()

@@ -200,3 +200,80 @@ def ba_residual_jac(cams, pts, cam_idx, pt_idx, uv, calib, with_calib=False):
                                      _ptr(r), _ptr(Jc), _ptr(Jp), _ptr(Jk), stream_ptr()),
           'iamx_ba_residual_jac')
     return r[:2 * n_obs], Jc[:n_obs], Jp[:n_obs], (Jk[:n_obs] if with_calib else None)
+
+
+# --------------------------------------------------------------------------------------
+# a reusable, allocation-free batch of ordered pairs: knn2 -> metric -> scan -> compaction
+# --------------------------------------------------------------------------------------
+class PairWorkspace(object):
+    """Output buffers for up to `max_rows` query rows / `max_pairs` ordered pairs."""
+
+    def __init__(self, max_rows, max_pairs):
+        dev = require_gpu()
+        r, p = max(int(max_rows), 1), max(int(max_pairs), 1)
+        self.max_rows, self.max_pairs = r, p
+        self.idx = torch.empty((r, 2), dtype=I32, device=dev)
+        self.d2 = torch.empty((r, 2), dtype=I32, device=dev)
+        self.metric = torch.empty(r, dtype=F64, device=dev)
+        self.keep = torch.empty(r, dtype=U8, device=dev)
+        self.seg_count = torch.zeros(p, dtype=I32, device=dev)
+        self.surv_off = torch.zeros(p + 1, dtype=I64, device=dev)
+        self.surv_q = torch.empty(r, dtype=I32, device=dev)
+        self.surv_t = torch.empty(r, dtype=I32, device=dev)
+        self.surv_metric = torch.empty(r, dtype=F64, device=dev)
+        self.zero_div = torch.zeros(1, dtype=I32, device=dev)
+
+
+class PairBatch(object):
+    """Device-side launch tables of one batch of ordered (query image, train image) pairs.
+    `run()` only enqueues kernels on the current stream (no host sync, no allocation)."""
+
+    def __init__(self, store, pairs):
+        dev = require_gpu()
+        self.store = store
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        counts = np.asarray(store.counts, np.int64)
+        self.pairs = pairs
+        self.n_pairs = P = len(pairs)
+        nq = counts[pairs[:, 0]] if P else np.zeros(0, np.int64)
+        if P and counts[pairs[:, 1]].min() < 2:
+            raise ValueError("train image with fewer than 2 descriptors")
+        self.out_off = np.zeros(P + 1, np.int64)
+        np.cumsum(nq, out=self.out_off[1:])
+        wg = np.zeros(P + 1, np.int64)
+        np.cumsum((nq + 255) // 256, out=wg[1:])
+        if wg[-1] >= 2 ** 31:
+            raise ValueError("batch too large: split the pair list")
+        self.rows = int(self.out_off[-1])
+        self.total_wg = int(wg[-1])
+        self.d_pairs = torch.from_numpy(pairs).to(dev)
+        self.d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
+        self.d_out = torch.from_numpy(self.out_off.copy()).to(dev)     # also the metric seg_off
+
+    def run_knn2(self, ws):
+        st = self.store
+        check(lib().iamx_knn2_l2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t),
+                                       _ptr(st.img_off), _ptr(st.img_n), _ptr(self.d_pairs),
+                                       _ptr(self.d_wg), _ptr(self.d_out), self.n_pairs,
+                                       self.total_wg, _ptr(ws.idx), _ptr(ws.d2), stream_ptr()),
+              'iamx_knn2_l2_pairs')
+
+    def run_filter(self, ws, thresh):
+        L, s = lib(), stream_ptr()
+        check(L.iamx_match_metric(_ptr(ws.d2), _ptr(self.d_out), self.n_pairs, float(thresh),
+                                  _ptr(ws.metric), _ptr(ws.keep), _ptr(ws.seg_count),
+                                  _ptr(ws.zero_div), s), 'iamx_match_metric')
+        check(L.iamx_exclusive_scan_i32(_ptr(ws.seg_count), self.n_pairs, _ptr(ws.surv_off), s),
+              'iamx_exclusive_scan_i32')
+        check(L.iamx_match_compact(_ptr(ws.idx), _ptr(ws.metric), _ptr(ws.keep), _ptr(self.d_out),
+                                   _ptr(ws.surv_off), self.n_pairs, _ptr(ws.surv_q),
+                                   _ptr(ws.surv_t), _ptr(ws.surv_metric), s),
+              'iamx_match_compact')
+
+    def run(self, ws, thresh):
+        if self.rows > ws.max_rows or self.n_pairs > ws.max_pairs:
+            raise ValueError("workspace too small for this batch")
+        if self.n_pairs == 0 or self.rows == 0:
+            return
+        self.run_knn2(ws)
+        self.run_filter(ws, thresh)

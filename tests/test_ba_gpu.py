@@ -100,10 +100,11 @@ def test_residual_large_vs_c_oracle():
     rng = np.random.default_rng(7)
     C, P, O = 300, 30000, 200000
     cams = np.zeros((C, 7))
-    cams[:, :3] = rng.normal(0, 50, (C, 3)) + [0, 0, -100]
+    cams[:, :3] = rng.normal(0, 50, (C, 3)) * [1, 1, 0.05] + [0, 0, -100]
+    # nadir cameras (ypr = heading,-90,0 <=> q ~ (c,0,-c,0)), unnormalised quaternions
     cams[:, 3:] = np.array([0.7071, 0, -0.7071, 0]) * rng.uniform(0.5, 2.0, (C, 1)) \
         + rng.normal(0, 0.02, (C, 4))
-    pts = rng.normal(0, 40, (P, 3))
+    pts = rng.normal(0, 40, (P, 3)) * [1, 1, 0.05]
     ci = np.sort(rng.integers(0, C, O)).astype(np.int32)
     pi = rng.integers(0, P, O).astype(np.int32)
     uv = rng.uniform(0, 5000, (O, 2))

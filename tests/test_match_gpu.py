@@ -140,6 +140,19 @@ def test_metric_kernel_sqrt_and_division_exact():
     assert int(zd.item()) == 0
 
 
+def test_metric_kernel_sqrt_exhaustive():
+    """every possible squared distance 0..128*255^2: device float32 sqrt == IEEE sqrt."""
+    import torch
+    from imageanalysis_amd import kernels
+    n = 128 * 255 * 255 + 1
+    d = np.arange(n, dtype=np.int64)
+    d2 = np.stack([d, np.maximum(d, 1)], 1).astype(np.int32)     # ratio 1 -> metric = d0
+    metric, keep, cnt, zd = kernels.match_metric(torch.from_numpy(d2).cuda(),
+                                                 np.array([0, n], np.int64), 202.5)
+    f = np.sqrt(d2.astype(np.float32)).astype(np.float64)
+    assert np.array_equal(metric.cpu().numpy(), f[:, 0] * (f[:, 0] / f[:, 1]))
+
+
 def test_metric_kernel_flags_zero_division():
     import torch
     from imageanalysis_amd import kernels
