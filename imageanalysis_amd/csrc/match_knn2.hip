@@ -117,8 +117,18 @@ __device__ __forceinline__ bool lex_less(int da, int ia, int db, int ib)
     return da < db || (da == db && ia < ib);
 }
 
-__global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
+// VARIANT is 0 in the product; other values are timing ablations reachable only through
+// the iamxdbg_knn2_variant entry point (tools/knn2_ablate.py): bit0 skip the top-2 epilogue,
+// bit1 skip the MFMAs, bit2 stage only the first chunk (no barriers in the sweep).
+// QW_ = 32-query blocks per wave, WAVES_ = waves per workgroup, OCC = launch-bounds waves/SIMD,
+// FLAGS bit0: s_setprio(1) around the MFMA groups, bit1: two independent top-2 chains per query.
+template <int VARIANT, int QW_, int WAVES_, int OCC, int FLAGS>
+__global__ __launch_bounds__(WAVES_ * 64, OCC) void knn2_pairs_kernel(Knn2Args A)
 {
+    constexpr int NT = WAVES_ * 64;            // threads
+    constexpr int QB_ = WAVES_ * QW_ * 32;     // query rows per workgroup
+    constexpr int PIECES = CHUNK * D / 16 / NT;  // 16-byte pieces staged per thread
+    constexpr int NCH = (FLAGS & 2) ? 2 : 1;   // independent top-2 chains
     __shared__ __attribute__((aligned(16))) int8_t lds[2 * CHUNK * D + 2 * CHUNK * 4];
     int8_t *lds_tile = lds;                                   // [2][CHUNK][128]
     int *lds_tb = reinterpret_cast<int *>(lds + 2 * CHUNK * D);  // [2][CHUNK]
@@ -154,12 +164,12 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
         wg0 = A.wg_off[lo];
         obase = A.out_off[lo];
     }
-    const int q0 = (vid - wg0) * QB + wave * (QW * 32);
+    const int q0 = (vid - wg0) * QB_ + wave * (QW_ * 32);
 
     // ---- query fragments: B operand, lane (c,g) holds bytes [32s+16g, +16) of row c
-    v4i bq[QW][4];
+    v4i bq[QW_][4];
 #pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
+    for (int qb = 0; qb < QW_; ++qb) {
         int row = q0 + qb * 32 + c;
         row = row < nq ? row : nq - 1;
         const v4i *src = reinterpret_cast<const v4i *>(A.desc_q + (int64_t)(qoff + row) * D);
@@ -167,24 +177,25 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
         for (int s = 0; s < 4; ++s) bq[qb][s] = ~src[2 * s + g];
     }
 
-    int m1[QW], m2[QW];
-    Top2 best[QW];
+    int m1[QW_][NCH], m2[QW_][NCH];
+    Top2 best[QW_];
 #pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-        m1[qb] = m2[qb] = KEY_INVALID;
+    for (int qb = 0; qb < QW_; ++qb) {
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) m1[qb][h] = m2[qb][h] = KEY_INVALID;
         best[qb].d1 = best[qb].d2 = KEY_INVALID;
         best[qb].i1 = best[qb].i2 = 0;
     }
 
-    // ---- staging: thread loads 4 x 16 B of the 16 KiB chunk + (tid<128) one key term
+    // ---- staging: thread loads PIECES x 16 B of the 16 KiB chunk + (tid<128) one key term
     const int8_t *tbase = A.desc_t + (int64_t)toff * D;
     const int32_t *tnorm = A.norm_t + toff;
-    v4i st[4];
+    v4i st[PIECES];
     int st_tb = KEY_INVALID;
     auto load_chunk = [&](int ch) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int e = j * 256 + tid;
+        for (int j = 0; j < PIECES; ++j) {
+            int e = j * NT + tid;
             st[j] = *reinterpret_cast<const v4i *>(tbase + (int64_t)(ch * CHUNK) * D + e * 16);
         }
         if (tid < CHUNK) {
@@ -194,8 +205,8 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int e = j * 256 + tid;
+        for (int j = 0; j < PIECES; ++j) {
+            int e = j * NT + tid;
             int row = e >> 3, slot = e & 7;
             int phys = slot ^ ((row >> 1) & 7);
             *reinterpret_cast<v4i *>(lds_tile + buf * (CHUNK * D) + row * D + phys * 16) = st[j];
@@ -210,10 +221,11 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
 
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        if constexpr (!(VARIANT & 4))
+            if (ch + 1 < nchunks) load_chunk(ch + 1);
 
-        const int8_t *tile_base = lds_tile + buf * (CHUNK * D);
-        const int *tb_base = lds_tb + buf * CHUNK;
+        const int8_t *tile_base = lds_tile + ((VARIANT & 4) ? 0 : buf) * (CHUNK * D);
+        const int *tb_base = lds_tb + ((VARIANT & 4) ? 0 : buf) * CHUNK;
 #pragma unroll
         for (int tile = 0; tile < CHUNK / 32; ++tile) {
             const int r = tile * 32 + c;
@@ -227,16 +239,28 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
             for (int k = 0; k < 4; ++k)
                 tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
 #pragma unroll
-            for (int qb = 0; qb < QW; ++qb) {
+            for (int qb = 0; qb < QW_; ++qb) {
                 v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if constexpr (FLAGS & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qb][s], acc, 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (VARIANT & 2) {
+                        acc[s] += a[s][0] ^ bq[qb][s][1];
+                    } else {
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qb][s], acc, 0, 0, 0);
+                    }
+                }
+                if constexpr (FLAGS & 1) __builtin_amdgcn_s_setprio(0);
+                if constexpr (VARIANT & 1) {
+                    asm volatile("" ::"v"(acc));
+                } else {
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    int key = tbv[reg >> 2][reg & 3] + (acc[reg] << 9);
-                    m2[qb] = med3_i32(m1[qb], m2[qb], key);
-                    m1[qb] = min(m1[qb], key);
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int h = (NCH == 2) ? (reg & 1) : 0;
+                        int key = tbv[reg >> 2][reg & 3] + (acc[reg] << 9);
+                        m2[qb][h] = med3_i32(m1[qb][h], m2[qb][h], key);
+                        m1[qb][h] = min(m1[qb][h], key);
+                    }
                 }
             }
         }
@@ -245,9 +269,16 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
         if ((ch & 1) || ch == nchunks - 1) {
             const int sbase = (ch >> 1) * 256;
 #pragma unroll
-            for (int qb = 0; qb < QW; ++qb) {
-                int d1k = m1[qb] >> 8, i1k = sbase + (m1[qb] & 255);
-                int d2k = m2[qb] >> 8, i2k = sbase + (m2[qb] & 255);
+            for (int qb = 0; qb < QW_; ++qb) {
+                int k1 = m1[qb][0], k2 = m2[qb][0];
+                if constexpr (NCH == 2) {
+                    // merge the two sorted key pairs (keys are unique inside an epoch)
+                    const int a1 = m1[qb][0], a2 = m2[qb][0], b1 = m1[qb][1], b2 = m2[qb][1];
+                    k1 = min(a1, b1);
+                    k2 = min(max(a1, b1), min(a2, b2));
+                }
+                int d1k = k1 >> 8, i1k = sbase + (k1 & 255);
+                int d2k = k2 >> 8, i2k = sbase + (k2 & 255);
                 Top2 &b = best[qb];
                 if (d1k < b.d1) {
                     if (d2k < b.d1) { b.d2 = d2k; b.i2 = i2k; }
@@ -256,17 +287,20 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
                 } else if (d1k < b.d2) {
                     b.d2 = d1k; b.i2 = i1k;
                 }
-                m1[qb] = m2[qb] = KEY_INVALID;
+#pragma unroll
+                for (int h = 0; h < NCH; ++h) m1[qb][h] = m2[qb][h] = KEY_INVALID;
             }
         }
 
-        if (ch + 1 < nchunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        if constexpr (!(VARIANT & 4)) {
+            if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- merge the two lane halves, add the query norm, store
 #pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
+    for (int qb = 0; qb < QW_; ++qb) {
         Top2 a = best[qb], b;
         b.d1 = __shfl_xor(a.d1, 32);
         b.i1 = __shfl_xor(a.i1, 32);
@@ -292,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void knn2_pairs_kernel(Knn2Args A)
         }
     }
 }
+
+// the configuration the product launches
+#define IAMX_KNN2_PRODUCT knn2_pairs_kernel<0, QW, WAVES, 2, 0>
 
 // ---------------------------------------------------------------------------------
 // metric / threshold (scripts/lib/matcher.py:253-263), one workgroup per ordered pair
@@ -469,9 +506,48 @@ extern "C" int iamx_knn2_l2_pairs(const int8_t *desc, const int32_t *norm_q,
     if (n_pairs == 0 || total_wg == 0) return IAMX_OK;
     Knn2Args a{desc, desc, norm_q, norm_t, img_off, img_n, pairs, wg_off, out_off,
                out_idx, out_d2, n_pairs, total_wg, 0, 0};
-    hipLaunchKernelGGL(knn2_pairs_kernel, dim3((unsigned)total_wg), dim3(256), 0,
+    hipLaunchKernelGGL(IAMX_KNN2_PRODUCT, dim3((unsigned)total_wg), dim3(WAVES * 64), 0,
                        iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2_l2_pairs");
+}
+
+// timing ablations (not part of the C ABI; see the VARIANT comment above)
+extern "C" int iamxdbg_knn2_variant(int variant, const int8_t *desc, const int32_t *norm_q,
+                                    const int32_t *norm_t, const int32_t *img_off,
+                                    const int32_t *img_n, const int32_t *pairs,
+                                    const int32_t *wg_off, const int64_t *out_off, int n_pairs,
+                                    int total_wg, int32_t *out_idx, int32_t *out_d2, void *stream)
+{
+    Knn2Args a{desc, desc, norm_q, norm_t, img_off, img_n, pairs, wg_off, out_off,
+               out_idx, out_d2, n_pairs, total_wg, 0, 0};
+    hipStream_t st = iamx::as_stream(stream);
+    dim3 g((unsigned)total_wg);
+#define V(id, ...) case id: hipLaunchKernelGGL((knn2_pairs_kernel<__VA_ARGS__>), g, dim3(WV * 64), 0, st, a); break;
+    switch (variant) {
+#define WV 4
+        V(0, 0, 2, 4, 2, 0) V(1, 1, 2, 4, 2, 0) V(2, 2, 2, 4, 2, 0) V(4, 4, 2, 4, 2, 0)
+        V(5, 5, 2, 4, 2, 0) V(6, 6, 2, 4, 2, 0)
+        V(10, 0, 2, 4, 2, 1)      // setprio
+        V(11, 0, 2, 4, 2, 2)      // dual chains
+        V(12, 0, 2, 4, 2, 3)      // both
+        V(13, 0, 2, 4, 3, 0)      // occupancy hint 3
+        V(14, 0, 2, 4, 4, 0)      // occupancy hint 4 (<=128 VGPR)
+        V(15, 0, 2, 4, 4, 2)
+        V(16, 0, 1, 4, 4, 0)      // QW=1: 128 queries per workgroup
+        V(17, 0, 1, 4, 4, 2)
+        V(18, 0, 3, 4, 2, 0)      // QW=3
+        V(19, 0, 4, 4, 1, 0)      // QW=4
+#undef WV
+#define WV 8
+        V(20, 0, 2, 8, 2, 0)      // 8 waves share the staged tile
+        V(21, 0, 2, 8, 2, 2)
+        V(22, 0, 1, 8, 2, 0)
+        V(23, 0, 1, 8, 4, 2)
+#undef WV
+    default: return iamx::fail(IAMX_EINVAL, "unknown variant");
+    }
+#undef V
+    return iamx::check_launch("iamxdbg_knn2_variant");
 }
 
 extern "C" int iamx_knn2_l2_u8(const int8_t *q_desc, const int32_t *q_norm_q, int nq,
@@ -485,7 +561,7 @@ extern "C" int iamx_knn2_l2_u8(const int8_t *q_desc, const int32_t *q_norm_q, in
     if (nq == 0) return IAMX_OK;
     Knn2Args a{q_desc, t_desc, q_norm_q, t_norm_t, nullptr, nullptr, nullptr, nullptr, nullptr,
                idx, d2, 1, iamx_knn2_wg_per_pair(nq), nq, nt};
-    hipLaunchKernelGGL(knn2_pairs_kernel, dim3((unsigned)a.total_wg), dim3(256), 0,
+    hipLaunchKernelGGL(IAMX_KNN2_PRODUCT, dim3((unsigned)a.total_wg), dim3(WAVES * 64), 0,
                        iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2_l2_u8");
 }
