@@ -1,0 +1,43 @@
+"""Late binding of the pieces of the reference environment the hot-path modules talk to.
+
+Inside the reference tree (scripts/ on sys.path, aura-props installed) the real modules are
+used so that state -- the global property tree, the message log, smart.json -- is shared with
+the rest of process.py.  Outside it (tests, bench) small equivalents from hostlib/ are used."""
+import importlib
+
+try:                                    # third-party aura-props
+    from props import getNode, PropertyNode   # noqa: F401
+    HAVE_PROPS = True
+except ImportError:
+    from .hostlib.props_compat import getNode, PropertyNode   # noqa: F401
+    HAVE_PROPS = False
+
+
+def _ref_or_host(name):
+    if HAVE_PROPS:
+        try:
+            return importlib.import_module('lib.' + name)
+        except Exception:
+            pass
+    try:
+        return importlib.import_module('imageanalysis_amd.hostlib.' + name)
+    except ImportError:
+        return None
+
+
+def camera():
+    return _ref_or_host('camera')
+
+
+def logger():
+    return _ref_or_host('logger')
+
+
+def smart():
+    """lib.smart (per-pair surface / yaw estimates) or None."""
+    if HAVE_PROPS:
+        try:
+            return importlib.import_module('lib.smart')
+        except Exception:
+            return None
+    return None

@@ -1,0 +1,84 @@
+"""A minimal image record with the pose accessors the BA / matching modules call on the
+reference's lib.image.Image objects (scripts/lib/image.py:462-521): property-tree backed
+camera_pose / camera_pose_opt {ned[3], yaw_deg, pitch_deg, roll_deg, quat[4] (w first,
+euler 'rzyx')}.  Used by tests and the synthetic BA generator; inside the reference tree
+the real Image class is used."""
+import numpy as np
+
+from .._deps import getNode
+from . import transforms as tf
+
+d2r = np.pi / 180.0
+
+
+class PoseImage(object):
+    def __init__(self, name):
+        self.name = name
+        self.node = getNode("/images/" + name, True)
+        self.kp_list = []
+        self.des_list = None
+        self.match_list = {}
+        self.matches_clean = True
+        self.uv_list = []
+        self.num_features = 0
+        self.placed = False
+        self.desc_timestamp = 0.0
+
+    def set_camera_pose(self, ned, yaw_deg, pitch_deg, roll_deg, opt=False):
+        quat = tf.quaternion_from_euler(yaw_deg * d2r, pitch_deg * d2r, roll_deg * d2r, 'rzyx')
+        if opt:
+            node = self.node.getChild('camera_pose_opt', True)
+            node.setBool('valid', True)
+        else:
+            node = self.node.getChild('camera_pose', True)
+        for i in range(3):
+            node.setFloatEnum('ned', i, ned[i])
+        node.setFloat('yaw_deg', yaw_deg)
+        node.setFloat('pitch_deg', pitch_deg)
+        node.setFloat('roll_deg', roll_deg)
+        node.setLen('quat', 4)
+        for i in range(4):
+            node.setFloatEnum('quat', i, quat[i])
+
+    def get_camera_pose(self, opt=False):
+        node = self.node.getChild('camera_pose_opt' if opt else 'camera_pose', True)
+        ned = [node.getFloatEnum('ned', i) for i in range(3)]
+        ypr = [node.getFloat('yaw_deg'), node.getFloat('pitch_deg'), node.getFloat('roll_deg')]
+        quat = [node.getFloatEnum('quat', i) for i in range(4)]
+        return ned, ypr, quat
+
+    def get_body2ned(self, opt=False):
+        ned, ypr, quat = self.get_camera_pose(opt)
+        return tf.quaternion_matrix(np.array(quat))[:3, :3]
+
+    def set_aircraft_yaw_error_estimate(self, yaw_error_deg):
+        self.node.getChild('aircraft_pose', True).setFloat("yaw_error_deg", yaw_error_deg)
+
+    def detect_features(self, scale, use_cache=True):
+        raise RuntimeError("PoseImage carries no pixels: attach kp_list/des_list yourself")
+
+    def save_matches(self):
+        self.matches_clean = True
+
+
+class PoseProject(object):
+    """The slice of lib.project.ProjectMgr the hot path touches."""
+
+    def __init__(self, names, analysis_dir=None):
+        self.analysis_dir = analysis_dir
+        self.image_list = [PoseImage(n) for n in names]
+
+    def findIndexByName(self, name):
+        for i, im in enumerate(self.image_list):
+            if im.name == name:
+                return i
+        return None
+
+    def findImageByName(self, name):
+        for im in self.image_list:
+            if im.name == name:
+                return im
+        return None
+
+    def save_images_info(self):
+        pass

