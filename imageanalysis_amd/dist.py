@@ -1,0 +1,106 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on the node; "gloo" in the CPU tests).  The path shards by *pair* (matching) and by
+*point* (BA); the only data-path exchanges are
+
+  * descriptors: every rank packs the images it detected, then the packed store
+    (int8 rows + two int32 norms) is gathered so that every rank holds all images
+    (`gather_store_shards`), 1.57 GB in total for the 2812-image survey;
+  * match lists: variable-length per-pair results return to every rank as python objects
+    (`allgather_objects`) -- kilobytes;
+  * BA: one all-reduce of the camera-side accumulators per operator application
+    (`allreduce_sum_`), see ba_solver.py.
+
+xGMI is point to point (7 links x ~153 GB/s per GPU): the store exchange is done as a few
+large transfers (one per owner per buffer), never per image.
+"""
+import numpy as np
+import torch
+
+
+def world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous, balanced split of range(n_items): sizes differ by at most one."""
+    lo = (n_items * rank) // world_size
+    hi = (n_items * (rank + 1)) // world_size
+    return lo, hi
+
+
+def owner_of_images(n_images, world_size):
+    """image i is detected / packed by rank owner[i] (contiguous blocks: IO locality)."""
+    owner = np.empty(n_images, np.int32)
+    for r in range(world_size):
+        lo, hi = shard_bounds(n_images, r, world_size)
+        owner[lo:hi] = r
+    return owner
+
+
+def shard_pairs(pairs, rank, world_size):
+    """Deal a train-major ordered list of unordered pairs to ranks in contiguous blocks so
+    that (a) both directions of a pair stay on one rank (the cross check needs both) and
+    (b) consecutive pairs on a rank share their train image (L2 reuse in knn2_pairs_kernel).
+    Returns the slice owned by `rank`; the union over ranks is exactly `pairs`, in order."""
+    lo, hi = shard_bounds(len(pairs), rank, world_size)
+    return pairs[lo:hi]
+
+
+def gather_store_shards(buffers, row_offsets, owner, rank, world_size, group=None):
+    """In-place gather of a sharded packed store.
+
+    buffers: list of (tensor, row_width) -- e.g. (desc.view(-1), 128), (norm_q, 1), (norm_t, 1),
+    each covering ALL images; row_offsets: int64 [n_images+1] first packed row of each image;
+    owner: int [n_images], contiguous blocks (owner_of_images).  On entry rank r has filled the
+    rows of its own images; on exit every rank has every row.  One broadcast per (owner,
+    buffer): few, large transfers.
+    """
+    import torch.distributed as dist
+    if world_size == 1:
+        return
+    for r in range(world_size):
+        mine = np.nonzero(owner == r)[0]
+        if len(mine) == 0:
+            continue
+        lo, hi = int(row_offsets[mine[0]]), int(row_offsets[mine[-1] + 1])
+        if hi == lo:
+            continue
+        for buf, width in buffers:
+            dist.broadcast(buf[lo * width:hi * width], src=r, group=group)
+
+
+def allgather_objects(obj, group=None):
+    """Every rank contributes one picklable object; returns the list ordered by rank."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return [obj]
+    out = [None] * ws
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def allreduce_sum_(tensor, group=None):
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+def shard_observations_by_point(point_indices, n_points, rank, world_size):
+    """BA: all observations of a point live on one rank (point blocks and point elimination
+    stay rank-local; only camera-side sums are reduced).  Points are dealt in contiguous
+    blocks balanced by observation count.  Returns the indices (into the camera-major
+    observation list) owned by `rank`, in ascending order (camera-major order is preserved)."""
+    point_indices = np.asarray(point_indices)
+    per_point = np.bincount(point_indices, minlength=n_points)
+    csum = np.cumsum(per_point)
+    total = int(csum[-1]) if len(csum) else 0
+    # point p belongs to rank floor(world * (obs before p) / total)
+    before = csum - per_point
+    owner = np.minimum((before * world_size) // max(total, 1), world_size - 1)
+    return np.nonzero(owner[point_indices] == rank)[0]

@@ -341,8 +341,40 @@ def _match_batch(batch, match_ratio):
     return out
 
 
+def _process_batch(lines, match_ratio):
+    """lines: [(dist, i, j, i1, i2)].  Device k=2 NN + threshold for both directions of every
+    pair, then the host filters.  Returns [(i, j, match_fwd, match_rev, n_fwd, n_rev)]."""
+    batch = [(l[3], l[4]) for l in lines]
+    xys = [(_kp_xy(a), _kp_xy(b)) for a, b in batch]
+    results = _match_batch(batch, match_ratio)
+    out = []
+    for (dist, i, j, i1, i2), ((fwd_t, n_fwd), (rev_t, n_rev)), (xy1, xy2) in \
+            zip(lines, results, xys):
+        _qlog("Matching %s vs %s" % (i1.name, i2.name))
+        _qlog("  separation (approx) = %.0f (m)" % dist)
+        # ---- both directions, then the cross check (:304-318)
+        _qlog("  raw matches:", len(xy1))
+        _qlog("  quality matches:", n_fwd)
+        match_fwd = _post_filter(i1, i2, fwd_t, (xy1, xy2))
+        if len(match_fwd) >= min_pairs:
+            _qlog("  raw matches:", len(xy2))
+            _qlog("  quality matches:", n_rev)
+            match_rev = _post_filter(i2, i1, rev_t, (xy2, xy1))
+        else:
+            match_rev = []
+        match_fwd, match_rev = filter_cross_check(match_fwd, match_rev)
+        out.append((i, j, match_fwd, match_rev))
+    return out
+
+
 def find_matches(proj, K, strategy="smart", transform="homography", sort=False, review=False):
-    """transform / review are accepted and unused, as on the reference's live path."""
+    """transform / review are accepted and unused, as on the reference's live path.
+
+    With torch.distributed initialised (one process per GPU) the pairs that still need
+    matching are dealt to the ranks in contiguous blocks (dist.shard_pairs); after every round
+    the per-pair match lists are exchanged so that every rank keeps the full, identical
+    bookkeeping; rank 0 writes the files."""
+    from . import dist as _dist
     if strategy != "traditional":
         _log("Match strategy", strategy, "is not on the MI355X path; only 'traditional'",
              "(bidirectional k=2 NN + metric + GMS + cross check) is.")
@@ -350,30 +382,35 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
     if the_matcher is None:
         configure()
     smart = _deps.smart()
+    rank, ws = _dist.world()
     t_start = time.time()
     work_list = _work_list(proj, sort)
     match_ratio = matcher_node.getFloat('match_ratio')
 
-    n_count = 0
+    # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
+    pending = []
+    for dist, i, j in work_list:
+        i1, i2 = proj.image_list[i], proj.image_list[j]
+        if i2.name in i1.match_list and i1.name in i2.match_list:
+            if len(i1.match_list[i2.name]) == 0:
+                _log("Retrying: ", i1.name, "vs", i2.name, "(no matches found previously)")
+            else:
+                _log("Skipping: ", i1.name, "vs", i2.name, "already done.")
+                continue
+        pending.append((dist, i, j))
+
     save_time = time.time()
     save_interval = 300     # seconds
     _log("Processing worklist matches:")
-
-    pos = 0
-    while pos < len(work_list):
-        # ---- next batch of pairs that still need matching (skip rule :946-951)
-        batch, lines = [], []
-        while pos < len(work_list) and len(batch) < PAIRS_PER_BATCH:
-            dist, i, j = work_list[pos]
-            pos += 1
+    mine = _dist.shard_pairs(pending, rank, ws)
+    shard_sizes = [_dist.shard_bounds(len(pending), r, ws) for r in range(ws)]
+    n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
+        if pending else 0
+    n_done = 0
+    for rnd in range(n_rounds):
+        lines = []
+        for dist, i, j in mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]:
             i1, i2 = proj.image_list[i], proj.image_list[j]
-            if i2.name in i1.match_list and i1.name in i2.match_list:
-                if len(i1.match_list[i2.name]) == 0:
-                    _log("Retrying: ", i1.name, "vs", i2.name, "(no matches found previously)")
-                else:
-                    _log("Skipping: ", i1.name, "vs", i2.name, "already done.")
-                    n_count += 1
-                    continue
             i1.desc_timestamp = time.time()
             i2.desc_timestamp = time.time()
             _ensure_features(i1)
@@ -382,79 +419,63 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
                 if im.des_list is None or len(im.des_list.shape) == 0 or im.des_list.shape[0] <= 1:
                     # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                     raise ZeroDivisionError("float division by zero")
-            batch.append((i1, i2))
-            lines.append((dist, i1, i2))
-        if not batch:
-            break
-        xy_keepalive = [(_kp_xy(a), _kp_xy(b)) for a, b in batch]   # survive cache flushes
-        results = _match_batch(batch, match_ratio)
+            lines.append((dist, i, j, i1, i2))
+        results = _process_batch(lines, match_ratio) if lines else []
+        gathered = _dist.allgather_objects(results)
 
-        for (dist, i1, i2), ((fwd_t, n_fwd), (rev_t, n_rev)), (xy1, xy2) in \
-                zip(lines, results, xy_keepalive):
-            percent = n_count / float(len(work_list))
-            n_count += 1
-            t_elapsed = time.time() - t_start
-            t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
-            msg = "Matching %s vs %s - %.1f%% done: " % (i1.name, i2.name, percent * 100.0)
-            msg += "%.1f (min)" % (t_remain / 60.0) if t_remain < 3600 \
-                else "%.1f (hr)" % (t_remain / 3600.0)
-            _qlog(msg)
-            _qlog("  separation (approx) = %.0f (m)" % dist)
+        for part in gathered:
+            for i, j, match_fwd, match_rev in part:
+                i1, i2 = proj.image_list[i], proj.image_list[j]
+                n_done += 1
+                i1.match_list[i2.name] = match_fwd
+                i2.match_list[i1.name] = match_rev
+                i1.matches_clean = False
+                i2.matches_clean = False
 
-            # ---- both directions, then the cross check (:304-318)
-            _qlog("  raw matches:", len(xy1))
-            _qlog("  quality matches:", n_fwd)
-            match_fwd = _post_filter(i1, i2, fwd_t, (xy1, xy2))
-            if len(match_fwd) >= min_pairs:
-                _qlog("  raw matches:", len(xy2))
-                _qlog("  quality matches:", n_rev)
-                match_rev = _post_filter(i2, i1, rev_t, (xy2, xy1))
-            else:
-                match_rev = []
-            match_fwd, match_rev = filter_cross_check(match_fwd, match_rev)
-            i1.match_list[i2.name] = match_fwd
-            i2.match_list[i1.name] = match_rev
-            i1.matches_clean = False
-            i2.matches_clean = False
+                # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
+                avg = std = None
+                if smart is not None:
+                    avg, std = smart.update_surface_estimate(i1, i2)
+                    if avg and std:
+                        _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
+                    i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
+                    i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
+                if std and std >= 50 and len(i1.match_list[i2.name]) < 100:
+                    _log("Std dev of surface triangulation blew up, matches are probably bad so "
+                         "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
+                         "count:", len(match_fwd))
+                    i1.match_list[i2.name] = []
+                    i2.match_list[i1.name] = []
 
-            # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
-            avg = std = None
-            if smart is not None:
-                avg, std = smart.update_surface_estimate(i1, i2)
-                if avg and std:
-                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
-                i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
-                i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
-            if std and std >= 50 and len(i1.match_list[i2.name]) < 100:
-                _log("Std dev of surface triangulation blew up, matches are probably bad so "
-                     "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
-                     "count:", len(match_fwd))
-                i1.match_list[i2.name] = []
-                i2.match_list[i1.name] = []
+        t_elapsed = time.time() - t_start
+        percent = n_done / float(max(len(pending), 1))
+        t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
+        _qlog("%.1f%% done: %.1f (min) remaining" % (percent * 100.0, t_remain / 60.0))
 
-            # ---- periodic save + host descriptor cache flush (:1008-1026)
-            if time.time() >= save_time + save_interval:
+        # ---- periodic save + host descriptor cache flush (:1008-1026)
+        if time.time() >= save_time + save_interval:
+            if rank == 0:
                 saveMatches(proj.image_list, check_if_dirty=True)
                 if smart is not None:
                     smart.save(proj.analysis_dir)
-                save_time = time.time()
-                time_list = [[i3.desc_timestamp, i3] for i3 in proj.image_list
-                             if i3.des_list is not None]
-                time_list = sorted(time_list, key=lambda fields: fields[0], reverse=True)
-                cache_size = 20 + 5 * (int(sqrt(len(proj.image_list))) + 1)
-                flush_list = time_list[cache_size:]
-                _qlog("flushing keypoint/descriptor cache - size: %d (over by: %d)"
-                      % (cache_size, len(flush_list)))
-                for line in flush_list:
-                    _qlog('  clearing descriptors for:', line[1].name)
-                    line[1].kp_list = None
-                    line[1].des_list = None
-                    line[1].uv_list = None
-        del xy_keepalive
+            save_time = time.time()
+            time_list = [[i3.desc_timestamp, i3] for i3 in proj.image_list
+                         if i3.des_list is not None]
+            time_list = sorted(time_list, key=lambda fields: fields[0], reverse=True)
+            cache_size = 20 + 5 * (int(sqrt(len(proj.image_list))) + 1)
+            flush_list = time_list[cache_size:]
+            _qlog("flushing keypoint/descriptor cache - size: %d (over by: %d)"
+                  % (cache_size, len(flush_list)))
+            for line in flush_list:
+                _qlog('  clearing descriptors for:', line[1].name)
+                line[1].kp_list = None
+                line[1].des_list = None
+                line[1].uv_list = None
 
-    saveMatches(proj.image_list)
-    if smart is not None:
-        smart.save(proj.analysis_dir)
+    if rank == 0:
+        saveMatches(proj.image_list)
+        if smart is not None:
+            smart.save(proj.analysis_dir)
     print('Pair-wise matches successfully saved.')
 
 

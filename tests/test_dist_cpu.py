@@ -1,0 +1,167 @@
+"""CPU, world_size 2 over gloo: the N>1 sharding / exchange logic (no kernels run here; the
+device step of find_matches is replaced by the oracle INSIDE THE TEST ONLY)."""
+import os
+import pickle
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    return dist
+
+
+def _strip(n_img=6, seed=5):
+    from test_match_gpu import _sift_like
+    rng = np.random.default_rng(seed)
+    W, H = 5472, 3648
+    des, xy = [], []
+    for i in range(n_img):
+        n = int(rng.integers(300, 500))
+        d = _sift_like(rng, n)
+        p = np.stack([rng.uniform(600, W - 600, n), rng.uniform(400, H - 400, n)], 1)
+        if i:
+            k = min(int(0.5 * n), len(des[i - 1]))
+            src, dst = rng.permutation(len(des[i - 1]))[:k], rng.permutation(n)[:k]
+            d[dst] = np.clip(des[i - 1][src].astype(int) + rng.integers(-5, 6, (k, 128)), 0, 255)
+            p[dst] = xy[i - 1][src] + [250.0, -120.0] + rng.normal(0, 0.6, (k, 2))
+        des.append(d)
+        xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
+    return des, xy
+
+
+def _oracle_match_batch(batch, match_ratio):
+    """stand-in for matcher._match_batch (device) used only by this CPU test"""
+    from imageanalysis_amd import matcher
+    from oracle import match_oracle as mo
+    out = []
+    for a, b in batch:
+        res = []
+        for q, t in ((a, b), (b, a)):
+            idx, d2 = mo.knn2_l2(q.des_list, t.des_list)
+            dist = mo.distances_f32(d2).astype(np.float64)
+            metric = dist[:, 0] * (dist[:, 0] / dist[:, 1])
+            keep = np.nonzero(metric < matcher.max_distance * match_ratio)[0]
+            res.append((matcher._threshold_sort_clip(keep.astype(np.int32), idx[keep, 0],
+                                                     metric[keep]), len(keep)))
+        out.append(res)
+    return out
+
+
+def _run_find_matches(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    if world > 1:
+        _init(rank, world, port)
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from test_host_logic import _image
+    des, xy = _strip()
+    names = ['D%02d' % i for i in range(len(des))]
+    proj = PoseProject(names)
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        f = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = f.des_list, f.kp_list
+    matcher.detector_node.setString('detector', 'SIFT')
+    matcher.detector_node.setFloat('scale', 0.4)
+    matcher.matcher_node.setFloat('match_ratio', 0.75)
+    matcher.matcher_node.setInt('min_pairs', 25)
+    camera.set_image_params(5472, 3648)
+    matcher.max_distance, matcher.min_pairs = 270.0, 25.0
+    matcher.the_matcher = object()                  # configure() would need the GPU library
+    matcher._match_batch = _oracle_match_batch      # TEST-ONLY injection
+    matcher.PAIRS_PER_BATCH = 3                     # several rounds
+    matcher.find_matches(proj, None, strategy='traditional', sort=True)
+    with open(os.path.join(outdir, 'r%d_of_%d.pkl' % (rank, world)), 'wb') as f:
+        pickle.dump({im.name: im.match_list for im in proj.image_list}, f)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_find_matches_two_ranks_equals_one_rank():
+    with tempfile.TemporaryDirectory() as d:
+        _run_find_matches(0, 1, 0, d)
+        mp.spawn(_run_find_matches, args=(2, _free_port(), d), nprocs=2, join=True)
+        one = pickle.load(open(os.path.join(d, 'r0_of_1.pkl'), 'rb'))
+        for r in range(2):
+            two = pickle.load(open(os.path.join(d, 'r%d_of_2.pkl' % r), 'rb'))
+            assert two == one
+        assert sum(len(v) > 0 for m in one.values() for v in m.values()) >= 8
+
+
+def _run_helpers(rank, world, port):
+    sys.path.insert(0, REPO)
+    dist = _init(rank, world, port)
+    from imageanalysis_amd import dist as D
+    assert D.world() == (rank, world)
+    # ragged store gather: images of 3, 1, 4, 2 "rows"
+    rows = np.array([3, 1, 4, 2])
+    off = np.concatenate([[0], np.cumsum(rows)])
+    owner = D.owner_of_images(4, world)
+    assert owner.tolist() == [0, 0, 1, 1]
+    desc = torch.zeros(int(off[-1]) * 128, dtype=torch.int8)
+    norm = torch.zeros(int(off[-1]), dtype=torch.int32)
+    for i in np.nonzero(owner == rank)[0]:
+        desc[off[i] * 128:off[i + 1] * 128] = i + 1
+        norm[off[i]:off[i + 1]] = 100 + i
+    D.gather_store_shards([(desc, 128), (norm, 1)], off, owner, rank, world)
+    want = np.repeat(np.arange(4) + 1, rows)
+    assert np.array_equal(desc.view(-1, 128)[:, 0].numpy(), want)
+    assert np.array_equal(norm.numpy(), 100 + np.repeat(np.arange(4), rows))
+    # objects
+    got = D.allgather_objects({'rank': rank, 'pairs': [[rank, 1]]})
+    assert [g['rank'] for g in got] == [0, 1]
+    # BA: observation sharding by point + all-reduce of camera-side sums == unsharded sums
+    rng = np.random.default_rng(3)
+    P, C, O = 50, 6, 400
+    pt = rng.integers(0, P, O)
+    cam = np.sort(rng.integers(0, C, O))
+    val = rng.normal(size=O)
+    mine = D.shard_observations_by_point(pt, P, rank, world)
+    assert np.all(np.diff(mine) > 0)
+    acc = torch.zeros(C, dtype=torch.float64)
+    acc.index_add_(0, torch.from_numpy(cam[mine]), torch.from_numpy(val[mine]))
+    D.allreduce_sum_(acc)
+    full = np.bincount(cam, weights=val, minlength=C)
+    assert np.allclose(acc.numpy(), full, atol=1e-12)
+    owners = D.allgather_objects(sorted(set(pt[mine].tolist())))
+    assert not (set(owners[0]) & set(owners[1]))          # a point lives on exactly one rank
+    assert sum(len(D.shard_observations_by_point(pt, P, r, world)) for r in range(world)) == O
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dist_helpers_world2_gloo():
+    mp.spawn(_run_helpers, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_shard_pairs_partition():
+    from imageanalysis_amd import dist as D
+    pairs = [(i, j) for j in range(9) for i in range(j)]
+    for ws in (1, 2, 3, 8):
+        parts = [D.shard_pairs(pairs, r, ws) for r in range(ws)]
+        assert sum(parts, []) == pairs
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
