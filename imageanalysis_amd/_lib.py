@@ -38,6 +38,13 @@ SIGNATURES = {
     'iamx_ba_residual_jac': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'iamx_ba_jv': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'iamx_ba_jtv': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p,
+                            c_void_p, c_void_p]),
+    'iamx_vec_axpby': (c_int, [c_int64, c_double, c_void_p, c_double, c_void_p, c_void_p]),
+    'iamx_vec_mul2': (c_int, [c_int64] + [c_void_p] * 6),
+    'iamx_vec_dot': (c_int, [c_int64] + [c_void_p] * 5),
+    'iamx_vec_lsmr_update': (c_int, [c_int64] + [c_void_p] * 4 + [c_double] * 3 + [c_void_p]),
 }
 
 

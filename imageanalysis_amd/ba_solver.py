@@ -1,0 +1,553 @@
+"""Device-resident trust-region-reflective solver for the bundle adjustment
+(`Optimizer.solver = 'device'`).
+
+The reference calls scipy.optimize.least_squares(method='trf', jac_sparsity=A, x_scale='jac',
+bounds, ftol=1e-4)  (scripts/lib/optimizer.py:491-501): SciPy finite-differences fun() into a
+sparse J and runs `trf_bounds` with an LSMR subproblem solver.  SciPy refuses x_scale='jac'
+for operator Jacobians (scipy/optimize/_lsq/least_squares.py), so to keep J in HBM the outer
+iteration is restated here -- same sequence as scipy/optimize/_lsq/trf.py:205-400 (SciPy 1.15.3;
+the reference pins 1.6.2, same algorithm): Coleman-Li scaling, x_scale='jac' column norms,
+regularised Gauss-Newton step by LSMR, 2-D subspace trust-region solve, reflective step
+selection, radius update, ftol/xtol/gtol tests.  The O(n) scalar logic on the host uses
+SciPy's own helper functions; everything that touches J or an m-vector runs on the device
+through the K3/K4 kernels (ba_kernels.hip, ba_linalg.hip):
+
+    fun / jac           iamx_ba_residual, iamx_ba_residual_jac
+    g = J^T f, ||J_j||  iamx_ba_jtv (square=0 / 1)
+    LSMR                iamx_ba_jv / iamx_ba_jtv + iamx_vec_* (scipy/sparse/linalg/_isolve/lsmr.py)
+    quadratic models    Gram matrices of J_h s_i  (iamx_ba_jv + iamx_vec_dot)
+
+Multi-GPU: observations are sharded by point (dist.shard_observations_by_point); m-vectors are
+rank-local, n-vectors replicated; J^T u and every m-dot are summed over ranks (RCCL all-reduce).
+"""
+import numpy as np
+import torch
+from numpy.linalg import norm
+
+from . import _lib, dist as _dist
+from ._lib import check, lib, stream_ptr
+
+F64, I32 = torch.float64, torch.int32
+
+
+def _ptr(t):
+    return _lib.c_void_p(t.data_ptr()) if t is not None else _lib.c_void_p(0)
+
+
+class DeviceBA(object):
+    """The BA problem of an Optimizer after setup(), resident in HBM."""
+
+    def __init__(self, n_cameras, n_points, camera_indices, point_indices, points_2d,
+                 with_calib, fixed_calib=None, rank=0, world=1):
+        dev = _lib.require_gpu()
+        self.dev = dev
+        self.C, self.P = int(n_cameras), int(n_points)
+        self.with_calib = bool(with_calib)
+        self.fixed_calib = None if fixed_calib is None else np.asarray(fixed_calib, np.float64)
+        self.n = self.C * 7 + self.P * 3 + (8 if with_calib else 0)
+        cam = np.asarray(camera_indices, np.int64)
+        pt = np.asarray(point_indices, np.int64)
+        uv = np.asarray(points_2d, np.float64).reshape(-1, 2)
+        self.rank, self.world = rank, world
+        if world > 1:
+            sel = _dist.shard_observations_by_point(pt, self.P, rank, world)
+            cam, pt, uv = cam[sel], pt[sel], uv[sel]
+            self.local_obs = sel
+        else:
+            self.local_obs = None
+        self.O = int(cam.size)
+        self.m = 2 * self.O
+        if self.O and np.any(np.diff(cam) < 0):
+            raise ValueError("observations must be camera-major (optimizer.py:397-404)")
+        cam_ptr = np.zeros(self.C + 1, np.int64)
+        np.cumsum(np.bincount(cam, minlength=self.C), out=cam_ptr[1:])
+        order = np.argsort(pt, kind='stable')
+        pt_ptr = np.zeros(self.P + 1, np.int64)
+        np.cumsum(np.bincount(pt, minlength=self.P), out=pt_ptr[1:])
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+        self.cam_idx, self.pt_idx = t(cam, I32), t(pt, I32)
+        self.cam_ptr, self.pt_ptr, self.pt_obs = t(cam_ptr, I32), t(pt_ptr, I32), t(order, I32)
+        self.uv = t(uv, F64)
+        z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
+        self.x = z(self.n)
+        self.calib = z(9)
+        self.r = z(self.m)
+        self.Jc, self.Jp = z(self.O * 14), z(self.O * 6)
+        self.Jk = z(self.O * 16) if with_calib else None
+        self.scratch = z(2048)
+        self.out1 = z(4)
+        self.tmp_n, self.tmp_n2, self.tmp_m, self.tmp_m2 = z(self.n), z(self.n), z(self.m), z(self.m)
+
+    # ---- parameters ------------------------------------------------------------------
+    def set_x(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        self.x.copy_(torch.from_numpy(x))
+        if self.with_calib:
+            c = x[self.C * 7 + self.P * 3:]
+            cal = np.array([c[0], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]])
+        else:
+            cal = self.fixed_calib
+        self.calib.copy_(torch.from_numpy(np.ascontiguousarray(cal, np.float64)))
+
+    def _cams_pts(self):
+        return self.x[:self.C * 7], self.x[self.C * 7:self.C * 7 + self.P * 3]
+
+    # ---- kernels ---------------------------------------------------------------------
+    def residual(self, out=None):
+        cams, pts = self._cams_pts()
+        r = self.r if out is None else out
+        if self.O:
+            check(lib().iamx_ba_residual(_ptr(cams), self.C, _ptr(pts), self.P, _ptr(self.cam_idx),
+                                         _ptr(self.pt_idx), _ptr(self.uv), self.O,
+                                         _ptr(self.calib), _ptr(r), stream_ptr()), 'iamx_ba_residual')
+        return r
+
+    def residual_jac(self):
+        cams, pts = self._cams_pts()
+        if self.O:
+            check(lib().iamx_ba_residual_jac(_ptr(cams), self.C, _ptr(pts), self.P,
+                                             _ptr(self.cam_idx), _ptr(self.pt_idx), _ptr(self.uv),
+                                             self.O, _ptr(self.calib), _ptr(self.r), _ptr(self.Jc),
+                                             _ptr(self.Jp), _ptr(self.Jk), stream_ptr()),
+                  'iamx_ba_residual_jac')
+        return self.r
+
+    def jv(self, x_dev, y_dev):
+        if self.O:
+            check(lib().iamx_ba_jv(_ptr(self.Jc), _ptr(self.Jp), _ptr(self.Jk), _ptr(self.cam_idx),
+                                   _ptr(self.pt_idx), self.O, self.C, self.P, _ptr(x_dev),
+                                   _ptr(y_dev), stream_ptr()), 'iamx_ba_jv')
+
+    def jtv(self, u_dev, out_dev, square=False):
+        check(lib().iamx_ba_jtv(_ptr(self.Jc), _ptr(self.Jp), _ptr(self.Jk), _ptr(self.cam_ptr),
+                                _ptr(self.pt_ptr), _ptr(self.pt_obs), self.O, self.C, self.P,
+                                _ptr(u_dev), 1 if square else 0, _ptr(out_dev),
+                                _ptr(self.scratch), stream_ptr()), 'iamx_ba_jtv')
+        if self.world > 1:
+            _dist.allreduce_sum_(out_dev[:self.n])
+
+    def dot(self, a, b, n, reduce_ranks):
+        if n == 0:
+            v = torch.zeros(1, dtype=F64, device=self.dev)
+        else:
+            check(lib().iamx_vec_dot(n, _ptr(a), _ptr(b), _ptr(self.out1), _ptr(self.scratch),
+                                     stream_ptr()), 'iamx_vec_dot')
+            v = self.out1[:1]
+        if reduce_ranks and self.world > 1:
+            v = v.clone()
+            _dist.allreduce_sum_(v)
+        return float(v.item())
+
+    def axpby(self, n, a, x, b, y):
+        check(lib().iamx_vec_axpby(n, float(a), _ptr(x), float(b), _ptr(y), stream_ptr()),
+              'iamx_vec_axpby')
+
+    def mul2(self, n, a, b, out, c=None, d=None):
+        check(lib().iamx_vec_mul2(n, _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(out), stream_ptr()),
+              'iamx_vec_mul2')
+
+    def lsmr_update(self, n, h, hbar, x, v, c_hbar, c_x, c_h):
+        check(lib().iamx_vec_lsmr_update(n, _ptr(h), _ptr(hbar), _ptr(x), _ptr(v), float(c_hbar),
+                                         float(c_x), float(c_h), stream_ptr()),
+              'iamx_vec_lsmr_update')
+
+    # ---- composite operations --------------------------------------------------------
+    def cost_of_r(self, r):
+        return 0.5 * self.dot(r, r, self.m, True)
+
+    def grad(self):
+        """J^T r -> host n-vector."""
+        self.jtv(self.r, self.tmp_n)
+        return self.tmp_n[:self.n].cpu().numpy()
+
+    def colnorm(self):
+        """sqrt of the column sums of J.^2 -> host n-vector (scipy compute_jac_scale)."""
+        self.jtv(self.r, self.tmp_n, square=True)
+        return np.sqrt(self.tmp_n[:self.n].cpu().numpy())
+
+    def gram(self, d_host, vectors):
+        """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks."""
+        k = len(vectors)
+        ys = []
+        for s in vectors:
+            vs = torch.from_numpy(np.ascontiguousarray(d_host * s)).to(self.dev)
+            y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
+            self.jv(vs, y)
+            ys.append(y)
+        G = np.zeros((k, k))
+        for i in range(k):
+            for j in range(i, k):
+                G[i, j] = G[j, i] = self.dot(ys[i], ys[j], self.m, True)
+        return G
+
+
+def _sym_ortho(a, b):
+    """stable Givens rotation (scipy/sparse/linalg/_isolve/lsqr.py:_sym_ortho)."""
+    if b == 0:
+        return np.sign(a), 0.0, abs(a)
+    if a == 0:
+        return 0.0, np.sign(b), abs(b)
+    if abs(b) > abs(a):
+        tau = a / b
+        s = np.sign(b) / np.sqrt(1 + tau * tau)
+        c = s * tau
+        r = b / s
+    else:
+        tau = b / a
+        c = np.sign(a) / np.sqrt(1 + tau * tau)
+        s = c * tau
+        r = a / c
+    return c, s, r
+
+
+def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None):
+    """min || [J diag(d); diag(dreg)] x - [r; 0] ||  on the device; returns host x and stats.
+    Follows scipy/sparse/linalg/_isolve/lsmr.py (Fong & Saunders 2011) step by step."""
+    n, m = prob.n, prob.m
+    dev = prob.dev
+    z = lambda k: torch.zeros(max(k, 1), dtype=F64, device=dev)
+    u1, u2, v, h, hbar, x = z(m), z(n), z(n), z(n), z(n), z(n)
+    if maxiter is None:
+        maxiter = n
+    u1[:m].copy_(prob.r[:m])
+    normb = np.sqrt(prob.dot(u1, u1, m, True))
+    beta = normb
+
+    def matvec_into_u(alpha):           # u = A v - alpha u
+        prob.mul2(n, d_dev, v, prob.tmp_n)
+        prob.jv(prob.tmp_n, prob.tmp_m)
+        prob.axpby(m, 1.0, prob.tmp_m, -alpha, u1)
+        prob.mul2(n, dreg_dev, v, prob.tmp_n2)
+        prob.axpby(n, 1.0, prob.tmp_n2, -alpha, u2)
+
+    def rmatvec_into_v(beta_):          # v = A^T u - beta v
+        prob.jtv(u1, prob.tmp_n)
+        prob.mul2(n, d_dev, prob.tmp_n, prob.tmp_n2, dreg_dev, u2)
+        prob.axpby(n, 1.0, prob.tmp_n2, -beta_, v)
+
+    def unorm():
+        return np.sqrt(prob.dot(u1, u1, m, True) + prob.dot(u2, u2, n, False))
+
+    if beta > 0:
+        prob.axpby(m, 0.0, u1, 1.0 / beta, u1)
+        rmatvec_into_v(0.0)
+        alpha = np.sqrt(prob.dot(v, v, n, False))
+    else:
+        alpha = 0.0
+    if alpha > 0:
+        prob.axpby(n, 0.0, v, 1.0 / alpha, v)
+
+    itn = 0
+    zetabar = alpha * beta
+    alphabar = alpha
+    rho = rhobar = cbar = 1.0
+    sbar = 0.0
+    h.copy_(v)
+    betadd, betad, rhodold, tautildeold, thetatilde, zeta, dsum = beta, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0
+    normA2 = alpha * alpha
+    maxrbar, minrbar = 0.0, 1e+100
+    normA, condA, normx = np.sqrt(normA2), 1.0, 0.0
+    istop = 0
+    ctol = 1.0 / conlim if conlim > 0 else 0.0
+    normr = beta
+    normar = alpha * beta
+    if normar == 0 or normb == 0:
+        return x[:n].cpu().numpy(), istop, itn, normr, normar
+
+    while itn < maxiter:
+        itn += 1
+        matvec_into_u(alpha)
+        beta = unorm()
+        if beta > 0:
+            prob.axpby(m, 0.0, u1, 1.0 / beta, u1)
+            prob.axpby(n, 0.0, u2, 1.0 / beta, u2)
+            rmatvec_into_v(beta)
+            alpha = np.sqrt(prob.dot(v, v, n, False))
+            if alpha > 0:
+                prob.axpby(n, 0.0, v, 1.0 / alpha, v)
+        chat, shat, alphahat = _sym_ortho(alphabar, 0.0)
+        rhoold = rho
+        c, s, rho = _sym_ortho(alphahat, beta)
+        thetanew = s * alpha
+        alphabar = c * alpha
+        rhobarold, zetaold = rhobar, zeta
+        thetabar = sbar * rho
+        rhotemp = cbar * rho
+        cbar, sbar, rhobar = _sym_ortho(cbar * rho, thetanew)
+        zeta = cbar * zetabar
+        zetabar = -sbar * zetabar
+        prob.lsmr_update(n, h, hbar, x, v, -(thetabar * rho / (rhoold * rhobarold)),
+                         zeta / (rho * rhobar), -(thetanew / rho))
+        betaacute = chat * betadd
+        betacheck = -shat * betadd
+        betahat = c * betaacute
+        betadd = -s * betaacute
+        thetatildeold = thetatilde
+        ctildeold, stildeold, rhotildeold = _sym_ortho(rhodold, thetabar)
+        thetatilde = stildeold * rhobar
+        rhodold = ctildeold * rhobar
+        betad = -stildeold * betad + ctildeold * betahat
+        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold
+        taud = (zeta - thetatilde * tautildeold) / rhodold
+        dsum += betacheck * betacheck
+        normr = np.sqrt(dsum + (betad - taud) ** 2 + betadd * betadd)
+        normA2 += beta * beta
+        normA = np.sqrt(normA2)
+        normA2 += alpha * alpha
+        maxrbar = max(maxrbar, rhobarold)
+        if itn > 1:
+            minrbar = min(minrbar, rhobarold)
+        condA = max(maxrbar, rhotemp) / min(minrbar, rhotemp)
+        normar = abs(zetabar)
+        normx = np.sqrt(prob.dot(x, x, n, False))
+        test1 = normr / normb
+        test2 = normar / (normA * normr) if (normA * normr) != 0 else np.inf
+        test3 = 1.0 / condA
+        t1 = test1 / (1 + normA * normx / normb)
+        rtol = btol + atol * normA * normx / normb
+        if itn >= maxiter:
+            istop = 7
+        if 1 + test3 <= 1:
+            istop = 6
+        if 1 + test2 <= 1:
+            istop = 5
+        if 1 + t1 <= 1:
+            istop = 4
+        if test3 <= ctol:
+            istop = 3
+        if test2 <= atol:
+            istop = 2
+        if test1 <= rtol:
+            istop = 1
+        if istop > 0:
+            break
+    return x[:n].cpu().numpy(), istop, itn, normr, normar
+
+
+# --------------------------------------------------------------------------------------
+# reflective step selection (scipy/optimize/_lsq/trf.py select_step) on Gram matrices
+# --------------------------------------------------------------------------------------
+def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
+    from scipy.optimize._lsq.common import (in_bounds, intersect_trust_region,
+                                            minimize_quadratic_1d, step_size_to_bound)
+
+    def quad(G, i, s):        # 0.5 s^T (J_h^T J_h + D) s + g_h^T s
+        return 0.5 * (G[i, i] + np.dot(s * diag_h, s)) + np.dot(g_h, s)
+
+    if in_bounds(x + p, lb, ub):
+        G = prob.gram(d, [p_h])
+        return p, p_h, -quad(G, 0, p_h)
+
+    p_stride, hits = step_size_to_bound(x, p, lb, ub)
+    r_h = np.copy(p_h)
+    r_h[hits.astype(bool)] *= -1
+    r = d * r_h
+    p = p * p_stride
+    p_h = p_h * p_stride
+    x_on_bound = x + p
+    _, to_tr = intersect_trust_region(p_h, r_h, Delta)
+    to_bound, _ = step_size_to_bound(x_on_bound, r, lb, ub)
+    r_stride = min(to_bound, to_tr)
+    if r_stride > 0:
+        r_stride_l = (1 - theta) * p_stride / r_stride
+        r_stride_u = theta * to_bound if r_stride == to_bound else to_tr
+    else:
+        r_stride_l, r_stride_u = 0, -1
+
+    ag_h = -g_h
+    G = prob.gram(d, [p_h, r_h, ag_h])          # all three model directions in one go
+    if r_stride_l <= r_stride_u:
+        # 1-d quadratic along r_h from s0 = p_h (scipy build_quadratic_1d with s0)
+        a = 0.5 * (G[1, 1] + np.dot(r_h * diag_h, r_h))
+        b = np.dot(g_h, r_h) + G[0, 1] + np.dot(p_h * diag_h, r_h)
+        c0 = 0.5 * (G[0, 0] + np.dot(p_h * diag_h, p_h)) + np.dot(g_h, p_h)
+        r_stride, r_value = minimize_quadratic_1d(a, b, r_stride_l, r_stride_u, c=c0)
+        r_h = r_h * r_stride + p_h
+        r = r_h * d
+    else:
+        r_value = np.inf
+
+    p = p * theta
+    p_h_t = p_h * theta
+    p_value = 0.5 * theta * theta * (G[0, 0] + np.dot(p_h * diag_h, p_h)) + theta * np.dot(g_h, p_h)
+
+    ag = d * ag_h
+    to_tr = Delta / norm(ag_h)
+    to_bound, _ = step_size_to_bound(x, ag, lb, ub)
+    ag_stride = theta * to_bound if to_bound < to_tr else to_tr
+    a = 0.5 * (G[2, 2] + np.dot(ag_h * diag_h, ag_h))
+    b = np.dot(g_h, ag_h)
+    ag_stride, ag_value = minimize_quadratic_1d(a, b, 0, ag_stride)
+    ag_h = ag_h * ag_stride
+    ag = ag * ag_stride
+
+    if p_value < r_value and p_value < ag_value:
+        return p, p_h_t, -p_value
+    elif r_value < p_value and r_value < ag_value:
+        return r, r_h, -r_value
+    return ag, ag_h, -ag_value
+
+
+def trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
+               callback=None, lsmr_opts=None):
+    """scipy/optimize/_lsq/trf.py trf_bounds with tr_solver='lsmr', x_scale='jac',
+    loss='linear', on a DeviceBA problem."""
+    from scipy.optimize import OptimizeResult
+    from scipy.optimize._lsq.common import (CL_scaling_vector, check_termination,
+                                            find_active_constraints, make_strictly_feasible,
+                                            minimize_quadratic_1d, print_header_nonlinear,
+                                            print_iteration_nonlinear, solve_trust_region_2d,
+                                            update_tr_radius)
+    from scipy.linalg import qr
+    lsmr_opts = dict(lsmr_opts or {})
+    n = prob.n
+    x = make_strictly_feasible(np.asarray(x0, np.float64).copy(), lb, ub)
+    prob.set_x(x)
+    prob.residual_jac()
+    nfev = njev = 1
+    cost = prob.cost_of_r(prob.r)
+    g = prob.grad()
+    scale_inv = prob.colnorm()
+    scale_inv[scale_inv == 0] = 1
+    scale = 1 / scale_inv
+
+    v, dv = CL_scaling_vector(x, g, lb, ub)
+    v[dv != 0] *= scale_inv[dv != 0]
+    Delta = norm(x * scale_inv / v ** 0.5)
+    if Delta == 0:
+        Delta = 1.0
+    g_norm = norm(g * v, ord=np.inf)
+    if max_nfev is None:
+        max_nfev = n * 100
+    termination_status = None
+    iteration = 0
+    step_norm = actual_reduction = None
+    lsmr_iters = 0
+    r_new = torch.empty_like(prob.r)
+    if verbose == 2 and prob.rank == 0:
+        print_header_nonlinear()
+
+    while True:
+        v, dv = CL_scaling_vector(x, g, lb, ub)
+        g_norm = norm(g * v, ord=np.inf)
+        if g_norm < gtol:
+            termination_status = 1
+        if verbose == 2 and prob.rank == 0:
+            print_iteration_nonlinear(iteration, nfev, cost, actual_reduction, step_norm, g_norm)
+        if termination_status is not None or nfev == max_nfev:
+            break
+
+        v[dv != 0] *= scale_inv[dv != 0]
+        d = v ** 0.5 * scale
+        diag_h = g * dv * scale
+        g_h = d * g
+
+        # regularisation term (trf.py: build_quadratic_1d along -g_h)
+        G = prob.gram(d, [g_h])
+        a = 0.5 * (G[0, 0] + np.dot(g_h * diag_h, g_h))
+        b = -np.dot(g_h, g_h)
+        to_tr = Delta / norm(g_h)
+        ag_value = minimize_quadratic_1d(a, b, 0, to_tr)[1]
+        reg_term = -ag_value / Delta ** 2
+
+        d_dev = torch.from_numpy(d).to(prob.dev)
+        dreg_dev = torch.from_numpy((diag_h + reg_term) ** 0.5).to(prob.dev)
+        gn_h, _istop, itn, _nr, _nar = lsmr_device(prob, d_dev, dreg_dev, **lsmr_opts)
+        lsmr_iters += itn
+        S = np.vstack((g_h, gn_h)).T
+        S, _ = qr(S, mode='economic')
+        GS = prob.gram(d, [S[:, 0].copy(), S[:, 1].copy()])
+        B_S = GS + np.dot(S.T * diag_h, S)
+        g_S = S.T.dot(g_h)
+
+        theta = max(0.995, 1 - g_norm)
+        actual_reduction = -1
+        while actual_reduction <= 0 and nfev < max_nfev:
+            p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
+            p_h = S.dot(p_S)
+            p = d * p_h
+            step, step_h, predicted_reduction = _select_step(prob, x, d, diag_h, g_h, p, p_h,
+                                                             Delta, lb, ub, theta)
+            x_new = make_strictly_feasible(x + step, lb, ub, rstep=0)
+            prob.set_x(x_new)
+            prob.residual(out=r_new)
+            nfev += 1
+            step_h_norm = norm(step_h)
+            cost_new = prob.cost_of_r(r_new)
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual_reduction = cost - cost_new
+            Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
+                                                step_h_norm, step_h_norm > 0.95 * Delta)
+            step_norm = norm(step)
+            termination_status = check_termination(actual_reduction, cost, step_norm, norm(x),
+                                                   ratio, ftol, xtol)
+            if termination_status is not None:
+                break
+            Delta = Delta_new
+
+        if actual_reduction > 0:
+            x = x_new
+            cost = cost_new
+            prob.set_x(x)
+            prob.residual_jac()
+            njev += 1
+            g = prob.grad()
+            cn = prob.colnorm()
+            scale_inv = np.maximum(scale_inv, cn)        # compute_jac_scale(J, scale_inv_old)
+            scale = 1 / scale_inv
+            if callback is not None:
+                callback(x, cost)
+        else:
+            prob.set_x(x)
+            prob.residual()
+            step_norm = 0
+            actual_reduction = 0
+        iteration += 1
+
+    if termination_status is None:
+        termination_status = 0
+    active_mask = find_active_constraints(x, lb, ub, rtol=xtol)
+    return OptimizeResult(x=x, cost=cost, grad=g, optimality=g_norm, active_mask=active_mask,
+                          nfev=nfev, njev=njev, status=termination_status,
+                          lsmr_iterations=lsmr_iters, iterations=iteration)
+
+
+def gather_residual(prob, n_obs_total):
+    """full camera-major residual vector on the host (all ranks)."""
+    r = prob.r[:prob.m].cpu().numpy()
+    if prob.world == 1:
+        return r
+    full = np.zeros(2 * n_obs_total)
+    sel = prob.local_obs
+    full[2 * sel] = r[0::2]
+    full[2 * sel + 1] = r[1::2]
+    t = torch.from_numpy(full).to(prob.dev)
+    _dist.allreduce_sum_(t)
+    return t.cpu().numpy()
+
+
+def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None):
+    """Entry point used by Optimizer.run() when opt.solver == 'device'."""
+    rank, world = _dist.world()
+    n = x0.size
+    if isinstance(bounds, (list, tuple)) and np.ndim(bounds[0]) > 0:
+        lb, ub = np.asarray(bounds[0], np.float64), np.asarray(bounds[1], np.float64)
+    else:
+        lb, ub = np.full(n, -np.inf), np.full(n, np.inf)
+    wc = opt.optimize_calib == 'global'
+    K, dc = opt.K, np.asarray(opt.distCoeffs, np.float64)
+    fixed = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], *dc])
+    uv = np.concatenate([np.asarray(a, np.float64).reshape(-1, 2)
+                         for a in opt.by_camera_points_2d if len(a)])
+    prob = DeviceBA(opt.n_cameras, opt.n_points, opt.camera_indices, opt.point_indices, uv, wc,
+                    fixed_calib=fixed, rank=rank, world=world)
+    res = trf_device(prob, x0, lb, ub, ftol=ftol, verbose=verbose, max_nfev=max_nfev)
+    prob.set_x(res.x)
+    prob.residual()
+    res.fun = gather_residual(prob, opt.camera_indices.size)
+    opt._feedback(res.fun, prob.calib)
+    res.message = 'device TRF status %d' % res.status
+    res.success = res.status > 0
+    return res

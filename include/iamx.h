@@ -140,6 +140,40 @@ int iamx_ba_residual_jac(const double *cams, int n_cams, const double *pts, int 
                          int64_t n_obs, const double *calib, double *r,
                          double *Jc, double *Jp, double *Jk, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * K4: linear algebra on the device-resident block Jacobian (what SciPy's TRF/LSMR does on
+ * the sparse matrix the reference gives it: scripts/lib/optimizer.py:491-501,
+ * scipy/optimize/_lsq/trf.py:205-400).  n = 7*n_cams + 3*n_pts (+8 with Jk), m = 2*n_obs.
+ *   iamx_ba_jv   y[m] = J x
+ *   iamx_ba_jtv  out[n] = J^T u            (square = 0)
+ *                out[n] = column sums of J.^2 (square != 0; u unused) -- x_scale='jac'
+ *     cam_ptr DEV [n_cams+1] int32: observations of camera c are [cam_ptr[c], cam_ptr[c+1])
+ *             (the camera-major order of optimizer.py:397-404)
+ *     pt_ptr  DEV [n_pts+1], pt_obs DEV [n_obs] int32: observation ids grouped by point
+ *     scratch DEV [2048] float64 (only read/written when Jk != NULL)
+ *   No atomics: results are bitwise reproducible.
+ * ------------------------------------------------------------------------------------ */
+int iamx_ba_jv(const double *Jc, const double *Jp, const double *Jk, const int32_t *cam_idx,
+               const int32_t *pt_idx, int64_t n_obs, int n_cams, int n_pts, const double *x,
+               double *y, void *stream);
+int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int32_t *cam_ptr,
+                const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                int n_pts, const double *u, int square, double *out, double *scratch,
+                void *stream);
+
+/* float64 vector kernels used by the device LSMR (scipy/sparse/linalg/_isolve/lsmr.py):
+ *   axpby: y = a*x + b*y (b == 0 ignores y's old content)
+ *   mul2:  out = a.*b (+ c.*d when c != NULL)
+ *   dot:   out[0] = sum x.*y, fixed reduction tree (scratch: DEV [256] float64)
+ *   lsmr_update: hbar = h + c_hbar*hbar; x += c_x*hbar; h = v + c_h*h */
+int iamx_vec_axpby(int64_t n, double a, const double *x, double b, double *y, void *stream);
+int iamx_vec_mul2(int64_t n, const double *a, const double *b, const double *c, const double *d,
+                  double *out, void *stream);
+int iamx_vec_dot(int64_t n, const double *x, const double *y, double *out, double *scratch,
+                 void *stream);
+int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *x, const double *v,
+                         double c_hbar, double c_x, double c_h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,163 @@
+"""GPU: K4 operator kernels, device LSMR and the device TRF driver."""
+import glob
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from test_host_logic import _scene
+
+pytestmark = pytest.mark.gpu
+BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
+
+
+def _problem(path):
+    import torch
+    from imageanalysis_amd import ba_solver, optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    wc = bool(g['cam_calib'])
+    K, dc = opt.K, opt.distCoeffs
+    prob = ba_solver.DeviceBA(opt.n_cameras, opt.n_points, opt.camera_indices, opt.point_indices,
+                              g['points_2d'], wc,
+                              fixed_calib=[K[0, 0], K[1, 1], K[0, 2], K[1, 2], *dc])
+    return g, opt, prob
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_k4_operators_vs_csr(path):
+    import torch
+    g, opt, prob = _problem(path)
+    x0 = g['x0']
+    args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+    J = opt.jac(x0, *args)
+    prob.set_x(x0)
+    prob.residual_jac()
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=prob.n)
+    u = rng.normal(size=prob.m)
+    y = torch.empty(prob.m, dtype=torch.float64, device='cuda')
+    prob.jv(torch.from_numpy(v).cuda(), y)
+    ref = J @ v
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    out = torch.empty(prob.n, dtype=torch.float64, device='cuda')
+    prob.jtv(torch.from_numpy(u).cuda(), out)
+    ref = J.T @ u
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    cn = prob.colnorm()
+    ref = np.sqrt(np.asarray(J.power(2).sum(axis=0)).ravel())
+    assert np.abs(cn - ref).max() <= 1e-12 * ref.max()
+    gr = prob.grad()
+    ref = J.T @ g['f0']
+    assert np.abs(gr - ref).max() <= 1e-9 * np.abs(ref).max()
+    assert abs(prob.cost_of_r(prob.r) - 0.5 * g['f0'] @ g['f0']) <= 1e-12 * (g['f0'] @ g['f0'])
+
+
+@pytest.mark.parametrize('path', BA_CASES[:2], ids=os.path.basename)
+def test_device_lsmr_equals_scipy_lsmr(path):
+    import torch
+    from scipy.sparse import diags, vstack
+    from scipy.sparse.linalg import lsmr
+    from imageanalysis_amd import ba_solver
+    g, opt, prob = _problem(path)
+    x0 = g['x0']
+    args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+    J = opt.jac(x0, *args)
+    prob.set_x(x0)
+    prob.residual_jac()
+    rng = np.random.default_rng(1)
+    d = 1.0 / np.maximum(np.sqrt(np.asarray(J.power(2).sum(axis=0)).ravel()), 1e-9)
+    dreg = rng.uniform(0.01, 0.1, prob.n)
+    A = vstack([J @ diags(d), diags(dreg)]).tocsr()
+    b = np.concatenate([g['f0'], np.zeros(prob.n)])
+    # same recurrences => after the same number of iterations the iterates agree to rounding
+    # (for a few iterations: Golub-Kahan bidiagonalisation amplifies rounding differences
+    #  exponentially on this ill-conditioned operator, 3e-3 after 40 steps)
+    for k in (1, 2, 5, 10):
+        ref = lsmr(A, b, atol=0, btol=0, conlim=0, maxiter=k)
+        x, istop, itn, normr, normar = ba_solver.lsmr_device(
+            prob, torch.from_numpy(d).cuda(), torch.from_numpy(dreg).cuda(),
+            atol=0, btol=0, conlim=0, maxiter=k)
+        assert istop == ref[1] == 7 and itn == ref[2] == k
+        assert np.abs(x - ref[0]).max() <= 1e-10 * np.abs(ref[0]).max()
+        assert abs(normr - ref[3]) <= 1e-10 * ref[3]
+    # with the default tolerances both stop on the same test with equally good solutions
+    ref = lsmr(A, b, atol=1e-6, btol=1e-6, conlim=1e8)
+    x, istop, itn, normr, normar = ba_solver.lsmr_device(
+        prob, torch.from_numpy(d).cuda(), torch.from_numpy(dreg).cuda())
+    assert istop == ref[1] and abs(itn - ref[2]) <= max(3, ref[2] // 10)
+    res_dev, res_ref = np.linalg.norm(A @ x - b), np.linalg.norm(A @ ref[0] - b)
+    assert abs(res_dev - res_ref) <= 1e-4 * res_ref
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_device_trf_reaches_reference_minimum(path):
+    from imageanalysis_amd import optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = 'device'
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    ret = opt.run()
+    res = opt.result
+    cost = 0.5 * float(res.fun @ res.fun)
+    ref = float(g['cost_final'])
+    assert abs(cost - ref) / ref < 2e-2, (cost, ref)
+    assert abs(np.mean(np.abs(res.fun)) - np.mean(np.abs(g['f_final']))) < 0.02
+    assert res.njev <= 3 * 8 and res.status in (1, 2, 3, 4)
+    lo, up = opt._bounds()
+    assert np.all(res.x >= np.asarray(lo) - 1e-12) and np.all(res.x <= np.asarray(up) + 1e-12)
+    assert ret[0].shape == (opt.n_cameras, 7)
+
+
+def _two_rank_solve(rank, world, port, path, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)                         # both ranks share the one GPU of the box
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imageanalysis_amd import optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = 'device'
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    opt.run()
+    np.save(os.path.join(outdir, 'x_r%d.npy' % rank), opt.result.x)
+    np.save(os.path.join(outdir, 'f_r%d.npy' % rank), opt.result.fun)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_device_trf_two_ranks_point_sharded(tmp_path):
+    """observations sharded by point over 2 ranks (gloo, same GPU): same solution as 1 rank."""
+    import torch.multiprocessing as mp
+    from imageanalysis_amd import optimizer
+    path = [p for p in BA_CASES if p.endswith('ba_mid.npz')][0]
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_solve, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = 'device'
+    opt.setup(proj, inp['groups'], 0, inp['matches'])
+    opt.run()
+    x0 = np.load(tmp_path / 'x_r0.npy')
+    x1 = np.load(tmp_path / 'x_r1.npy')
+    assert np.array_equal(x0, x1)
+    f0 = np.load(tmp_path / 'f_r0.npy')
+    assert f0.shape == opt.result.fun.shape
+    c1, c2 = 0.5 * f0 @ f0, 0.5 * opt.result.fun @ opt.result.fun
+    assert abs(c1 - c2) / c2 < 1e-6
+    assert np.abs(x0 - opt.result.x).max() < 1e-5 * np.abs(opt.result.x).max()
