@@ -88,6 +88,8 @@ def main():
     ap.add_argument('--images', type=int, default=0, help='override the survey size')
     ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
+    ap.add_argument('--ba-iters', type=int, default=3, help='TRF iterations to time')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,6 +188,13 @@ def main():
                 "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
                 "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR}
 
+    # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
+    ba = None
+    if not args.no_ba:
+        del batches, ws, raw, store
+        torch.cuda.empty_cache()
+        ba = ba_bench(rank, world, dev, dist, args)
+
     out = None
     if rank == 0:
         cpu = None
@@ -205,13 +214,82 @@ def main():
                        "parallelism": "pair-shard x%d%s" % (world, " + RCCL descriptor all-gather"
                                                             if world > 1 else "")},
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "ba": ba,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def ba_bench(rank, world, dev, dist, args):
+    """BA iterations / s on BASELINE configs[3] (2812 cameras, ~300 k points, ~2 M observations,
+    synthetic): one "iteration" = one TRF outer iteration (Jacobian build +
+    LSMR Gauss-Newton step + >= 1 residual evaluation).  Observations are sharded by point over
+    the ranks; J^T u and the m-dots are all-reduced (RCCL)."""
+    from imageanalysis_amd import ba_solver, synth
+    p = synth.make_ba_problem()
+    C, P, O = len(p['cams0']), len(p['pts0']), len(p['cam_idx'])
+    K = p['K']
+    calib = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], *p['dist']]
+    prob = ba_solver.DeviceBA(C, P, p['cam_idx'], p['pt_idx'], p['uv'], False, fixed_calib=calib,
+                              rank=rank, world=world)
+    x0 = np.hstack([p['cams0'].ravel(), p['pts0'].ravel()])
+    lb = np.full(x0.size, -np.inf)
+    ub = np.full(x0.size, np.inf)
+    cp = p['cams0']
+    for j, dlt in ((0, 3.0), (1, 3.0), (2, 9.0)):          # optimizer.py:425-446
+        lb[j:C * 7:7] = cp[:, j] - dlt
+        ub[j:C * 7:7] = cp[:, j] + dlt
+    prob.set_x(x0)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, reps):
+        fn()
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    t_res = timed(prob.residual, 20)
+    t_jac = timed(prob.residual_jac, 20)
+    o_local = prob.O
+    sync()
+    t0 = time.perf_counter()
+    res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=args.ba_iters + 1, verbose=0)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, t_res, t_jac], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_res, t_jac = [float(v) for v in t.tolist()]
+    prob.set_x(res.x)
+    mre = float(np.sqrt(2.0 * res.cost / (2 * O)))
+    HBM = 8000.0
+    return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
+            "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),
+            "lsmr_iterations": int(res.lsmr_iterations), "seconds": round(dt, 3),
+            "cameras": C, "points": P, "observations": O, "rms_residual_px": round(mre, 3),
+            "residual_evals_per_sec": round(1.0 / t_res, 1),
+            "residual": {"bound": "hbm", "achieved": round(64.0 * o_local * world / t_res / 1e9, 1),
+                         "peak": HBM, "unit": "GB/s",
+                         "frac": round(64.0 * o_local / t_res / 1e9 / HBM, 4),
+                         "bytes_per_obs": 64},
+            "residual_jac": {"bound": "hbm",
+                             "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
+                             "peak": HBM, "unit": "GB/s",
+                             "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
+                             "bytes_per_obs": 224},
+            "dtype": "f64", "parallelism": "point-shard x%d" % world}
 
 
 def cpu_baseline(two_images):

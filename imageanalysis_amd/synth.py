@@ -1,0 +1,99 @@
+"""Synthetic survey generators for bench.py and tests: numpy only, data
+generation -- never on a timed path."""
+import numpy as np
+
+from .hostlib import transforms as tf
+
+W_PX, H_PX = 5472, 3648
+FX = 3666.6665
+K_FC6310S = np.array([[FX, 0.0, 2736.0], [0.0, FX, 1824.0], [0.0, 0.0, 1.0]])
+BODY2CAM = np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0]])
+
+
+def _rotations(quats):
+    """R (ned -> camera) for [C,4] w,x,y,z quaternions."""
+    q = quats / np.linalg.norm(quats, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    B = np.empty((len(q), 3, 3))
+    B[:, 0, 0] = 1 - 2 * (y * y + z * z); B[:, 0, 1] = 2 * (x * y - z * w); B[:, 0, 2] = 2 * (x * z + y * w)
+    B[:, 1, 0] = 2 * (x * y + z * w); B[:, 1, 1] = 1 - 2 * (x * x + z * z); B[:, 1, 2] = 2 * (y * z - x * w)
+    B[:, 2, 0] = 2 * (x * z - y * w); B[:, 2, 1] = 2 * (y * z + x * w); B[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return np.einsum('ij,ckj->cik', BODY2CAM, B)          # body2cam . body2ned^T
+
+
+def project(cams, pts, cam_idx, pt_idx, K, dist):
+    R = _rotations(cams[:, 3:7])[cam_idx]
+    Xc = np.einsum('oij,oj->oi', R, pts[pt_idx] - cams[cam_idx, :3])
+    x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
+    k1, k2, p1, p2, k3 = dist
+    r2 = x * x + y * y
+    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return np.stack([K[0, 0] * xd + K[0, 2], K[1, 1] * yd + K[1, 2]], 1), Xc[:, 2]
+
+
+def make_ba_problem(rows=38, cols=74, n_points=300000, n_obs=2000000, spacing=20.0, agl=100.0,
+                    dist=(0.0, 0.0, 0.0, 0.0, 0.0), seed=42, cam_sigma=1.0, pt_sigma=2.0,
+                    px_sigma=0.5):
+    """BASELINE config 4: nadir cameras on a lawn-mower grid, ground points, noisy projections
+    capped at n_obs, initial guess = truth + noise (cameras inside the +-3 m bounds).
+    Returns dict(cams0 [C,7], pts0 [P,3], cam_idx, pt_idx (camera-major int32), uv [O,2], K, dist)."""
+    rng = np.random.default_rng(seed)
+    C = rows * cols
+    r, c = np.divmod(np.arange(C), cols)
+    c = np.where(r % 2 == 1, cols - 1 - c, c)
+    ned = np.stack([r * spacing, c * spacing, np.full(C, -agl)], 1) + rng.normal(0, 0.3, (C, 3))
+    yaw = np.where(r % 2 == 0, 0.0, 180.0) + rng.normal(0, 3.0, C)
+    pitch = -90.0 + rng.normal(0, 2.0, C)
+    roll = rng.normal(0, 2.0, C)
+    d2r = np.pi / 180
+    quat = np.array([tf.quaternion_from_euler(y * d2r, p * d2r, q * d2r, 'rzyx')
+                     for y, p, q in zip(yaw, pitch, roll)])
+    cams = np.hstack([ned, quat])
+    K = K_FC6310S
+    pts = np.stack([rng.uniform(-40, (rows - 1) * spacing + 40, n_points),
+                    rng.uniform(-60, (cols - 1) * spacing + 60, n_points),
+                    rng.normal(0, 2.0, n_points)], 1)
+    # candidate cameras of a point: the grid cells within the footprint half extents
+    half_r = int(np.ceil(0.5 * H_PX / FX * agl / spacing)) + 1
+    half_c = int(np.ceil(0.5 * W_PX / FX * agl / spacing)) + 1
+    pr = np.rint(pts[:, 0] / spacing).astype(np.int64)
+    pc = np.rint(pts[:, 1] / spacing).astype(np.int64)
+    cand_c, cand_p = [], []
+    grid = -np.ones((rows, cols), np.int64)
+    grid[r, c] = np.arange(C)
+    for dr in range(-half_r, half_r + 1):           # headings are 0/180 deg: wide axis = east
+        for dc in range(-half_c, half_c + 1):
+            rr, cc = pr + dr, pc + dc
+            ok = (rr >= 0) & (rr < rows) & (cc >= 0) & (cc < cols)
+            idx = np.nonzero(ok)[0]
+            cand_c.append(grid[rr[idx], cc[idx]])
+            cand_p.append(idx)
+    cam_idx = np.concatenate(cand_c)
+    pt_idx = np.concatenate(cand_p)
+    uv, z = project(cams, pts, cam_idx, pt_idx, K, dist)
+    vis = (z > 1.0) & (uv[:, 0] >= 0) & (uv[:, 0] < W_PX) & (uv[:, 1] >= 0) & (uv[:, 1] < H_PX)
+    cam_idx, pt_idx, uv = cam_idx[vis], pt_idx[vis], uv[vis]
+    if len(cam_idx) > n_obs:
+        keep = np.sort(rng.permutation(len(cam_idx))[:n_obs])
+        cam_idx, pt_idx, uv = cam_idx[keep], pt_idx[keep], uv[keep]
+    # drop points with < 3 observations (min_chain_len, optimizer.py:79) and renumber
+    cnt = np.bincount(pt_idx, minlength=n_points)
+    good = cnt >= 3
+    sel = good[pt_idx]
+    cam_idx, pt_idx, uv = cam_idx[sel], pt_idx[sel], uv[sel]
+    remap = -np.ones(n_points, np.int64)
+    remap[good] = np.arange(int(good.sum()))
+    pt_idx = remap[pt_idx]
+    pts = pts[good]
+    order = np.lexsort((pt_idx, cam_idx))              # camera-major, points ascending
+    cam_idx, pt_idx, uv = cam_idx[order], pt_idx[order], uv[order]
+    uv = uv + rng.normal(0, px_sigma, uv.shape)
+    cams0 = cams.copy()
+    cams0[:, :3] += rng.normal(0, cam_sigma, (C, 3))
+    cams0[:, 3:] += rng.normal(0, 0.005, (C, 4))
+    pts0 = pts + rng.normal(0, pt_sigma, pts.shape)
+    return dict(cams0=cams0, pts0=pts0, cams_true=cams, pts_true=pts,
+                cam_idx=cam_idx.astype(np.int32), pt_idx=pt_idx.astype(np.int32), uv=uv,
+                K=K, dist=np.asarray(dist, np.float64))
