@@ -161,15 +161,17 @@ __global__ __launch_bounds__(256) void jt_cal_kernel(const double *__restrict__ 
     }
 }
 
-__global__ void final_sum_kernel(const double *__restrict__ partial, int n_partial, int width,
-                                 double *__restrict__ out)
+__global__ __launch_bounds__(256) void final_sum_kernel(const double *__restrict__ partial,
+                                                        int n_partial, int width,
+                                                        double *__restrict__ out)
 {
-    // width independent columns, n_partial partials each; summed in index order
-    const int k = threadIdx.x;
-    if (k >= width) return;
-    double s = 0.0;
-    for (int i = 0; i < n_partial; ++i) s += partial[i * width + k];
-    out[k] = s;
+    // `width` independent columns of n_partial (<= 256) partials each; fixed reduction tree
+    __shared__ double sh[4];
+    for (int k = 0; k < width; ++k) {
+        const double v = (int)threadIdx.x < n_partial ? partial[threadIdx.x * width + k] : 0.0;
+        const double s = block_sum_256(v, sh);
+        if (threadIdx.x == 0) out[k] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -270,7 +272,7 @@ extern "C" int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk,
         else
             hipLaunchKernelGGL(jt_cal_kernel<false>, dim3(RED_BLOCKS), dim3(256), 0, st, Jk, n_obs,
                                u, scratch);
-        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(64), 0, st, scratch, RED_BLOCKS, 8,
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, scratch, RED_BLOCKS, 8,
                            out_p + (int64_t)n_pts * 3);
     }
     return iamx::check_launch("iamx_ba_jtv");
@@ -302,7 +304,7 @@ extern "C" int iamx_vec_dot(int64_t n, const double *x, const double *y, double 
     IAMX_REQUIRE(x && y && out && scratch, "null pointer");
     hipStream_t st = iamx::as_stream(stream);
     hipLaunchKernelGGL(dot_kernel, dim3(RED_BLOCKS), dim3(256), 0, st, n, x, y, scratch);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(64), 0, st, scratch, RED_BLOCKS, 1, out);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, st, scratch, RED_BLOCKS, 1, out);
     return iamx::check_launch("iamx_vec_dot");
 }
 

@@ -55,6 +55,29 @@ int oracle_knn2_l2_u8(const uint8_t *q, int nq, const uint8_t *t, int nt,
     return 0;
 }
 
+/* Batched form for the CPU baseline: many ordered (query image, train image) pairs of equal
+ * size in ONE parallel region (work item = 64 query rows of one ordered pair), so that all host
+ * cores stay busy the way a tuned CPU matcher would keep them. */
+int oracle_knn2_l2_u8_batch(const uint8_t *images, int n_rows, const int32_t *pairs, int n_pairs,
+                            int32_t *idx, int32_t *d2, int nthreads)
+{
+    if (n_rows < 2) return -1;
+    const int blocks = (n_rows + 63) / 64;
+    const long items = (long)n_pairs * blocks;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (long it = 0; it < items; ++it) {
+        const int p = (int)(it / blocks), b = (int)(it % blocks);
+        const uint8_t *q = images + (size_t)pairs[2 * p] * n_rows * D;
+        const uint8_t *t = images + (size_t)pairs[2 * p + 1] * n_rows * D;
+        const int r0 = b * 64, r1 = r0 + 64 < n_rows ? r0 + 64 : n_rows;
+        knn2_rows(q, r0, r1, t, n_rows, idx + (size_t)p * n_rows * 2, d2 + (size_t)p * n_rows * 2);
+    }
+    return 0;
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

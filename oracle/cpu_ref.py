@@ -47,6 +47,24 @@ def knn2_l2_u8(q, t, nthreads=0):
     return idx, d2
 
 
+def knn2_l2_u8_batch(images, pairs, nthreads=0):
+    """images [n_img, n_rows, 128] u8, pairs [n_pairs, 2] (query, train) -> idx, d2
+    [n_pairs, n_rows, 2]; one OpenMP region over all pairs (the CPU-baseline form)."""
+    images = np.ascontiguousarray(images, np.uint8)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    n_rows = images.shape[1]
+    idx = np.empty((len(pairs), n_rows, 2), np.int32)
+    d2 = np.empty((len(pairs), n_rows, 2), np.int32)
+    L = lib()
+    L.oracle_knn2_l2_u8_batch.restype = ctypes.c_int
+    rc = L.oracle_knn2_l2_u8_batch(_p(images), ctypes.c_int(n_rows), _p(pairs),
+                                   ctypes.c_int(len(pairs)), _p(idx), _p(d2),
+                                   ctypes.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_knn2_l2_u8_batch rc=%d" % rc)
+    return idx, d2
+
+
 def ba_residual(cams, pts, cam_idx, pt_idx, uv, intr, dist, nthreads=0):
     cams = np.ascontiguousarray(cams, np.float64).reshape(-1, 7)
     pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)

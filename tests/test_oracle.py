@@ -117,3 +117,13 @@ def test_ba_setup_matches_reference(path):
     assert np.array_equal(s['point_indices'], g['point_indices'])
     assert np.array_equal(s['points_2d'], g['points_2d'])
     assert np.array_equal(s['by_camera_counts'], g['by_camera_counts'])
+
+
+def test_c_knn2_batch_equals_single():
+    rng = np.random.default_rng(2)
+    imgs = rng.integers(0, 256, (4, 300, 128), dtype=np.uint8)
+    pairs = np.array([[0, 1], [1, 0], [2, 3], [3, 1]], np.int32)
+    idx, d2 = cpu_ref.knn2_l2_u8_batch(imgs, pairs)
+    for p, (a, b) in enumerate(pairs):
+        i, d = cpu_ref.knn2_l2_u8(imgs[a], imgs[b])
+        assert np.array_equal(i, idx[p]) and np.array_equal(d, d2[p])
