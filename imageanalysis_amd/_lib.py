@@ -38,6 +38,10 @@ SIGNATURES = {
     'iamx_ba_residual_jac': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'iamx_sift_workspace_bytes': (c_int64, [c_int, c_int]),
+    'iamx_sift_detect': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p]),
     'iamx_ba_jv': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_ba_jtv': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p]),

@@ -277,3 +277,43 @@ class PairBatch(object):
             return
         self.run_knn2(ws)
         self.run_filter(ws, thresh)
+
+
+# --------------------------------------------------------------------------------------
+# SIFT
+# --------------------------------------------------------------------------------------
+_sift_ws = {}
+
+
+def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6):
+    """image: [h,w,3] BGR or [h,w] gray uint8 (numpy or device tensor).  Returns numpy
+    (kp [N,5] float32: x, y, size, angle, response; octave [N] int32 (cv2 packing);
+    desc [N,128] uint8), in the canonical (octave, layer, y, x, angle) order."""
+    dev = require_gpu()
+    img = _dev(image, U8)
+    if img.dim() == 2:
+        h, w, ch = img.shape[0], img.shape[1], 1
+    else:
+        h, w, ch = img.shape
+    need = int(lib().iamx_sift_workspace_bytes(h, w))
+    ws = _sift_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=U8, device=dev)
+        _sift_ws[dev.index] = ws
+    kp = torch.empty((cap, 8), dtype=torch.float32, device=dev)
+    desc = torch.empty((cap, 128), dtype=U8, device=dev)
+    n = torch.zeros(1, dtype=I32, device=dev)
+    check(lib().iamx_sift_detect(_ptr(img), h, w, ch, contrast_threshold, edge_threshold, sigma,
+                                 _ptr(ws), need, _ptr(kp), _ptr(desc), cap, _ptr(n), stream_ptr()),
+          'iamx_sift_detect')
+    cnt = int(n.item())
+    if cnt > cap:
+        raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (cnt, cap))
+    k = kp[:cnt].cpu().numpy()
+    d = desc[:cnt].cpu().numpy()
+    octave = k[:, 5].copy().view(np.int32)
+    # octave byte is (o-1) & 255 with o = pyramid octave index
+    o_idx = (((octave & 255) + 1) & 255).astype(np.int64)
+    layer = ((octave >> 8) & 255).astype(np.int64)
+    order = np.lexsort((d[:, 0], k[:, 3], k[:, 0], k[:, 1], layer, o_idx))
+    return np.ascontiguousarray(k[order, :5]), octave[order], np.ascontiguousarray(d[order])

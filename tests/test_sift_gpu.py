@@ -1,0 +1,81 @@
+"""GPU: the SIFT kernels (csrc/sift.hip) against the CPU restatement of the same published
+algorithm (oracle/sift_oracle.py).  PARITY UNPINNED against cv2 (absent); the bar here is
+agreement with the oracle: same keypoint set, descriptors equal up to u8 rounding ties."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def texture(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w), np.float64)
+    for s in (2, 4, 8, 16, 32):
+        g = rng.normal(size=(h // s + 2, w // s + 2))
+        img += np.kron(g, np.ones((s, s)))[:h, :w] * s ** 0.7
+    k = np.array([1, 4, 6, 4, 1.]) / 16
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, 'same'), 1, img)
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, 'same'), 0, img)
+    img = (img - img.min()) / (img.max() - img.min()) * 255
+    return np.stack([img, img * 0.9 + 10, img * 0.8 + 20], 2).clip(0, 255).astype(np.uint8)
+
+
+def _match(ka, oa, kb, ob):
+    """greedy one-to-one matching of keypoints with identical packed octave"""
+    used = np.zeros(len(kb), bool)
+    pairs = []
+    for i in range(len(ka)):
+        cand = np.nonzero((ob == oa[i]) & ~used & (np.abs(kb[:, 0] - ka[i, 0]) < 0.02)
+                          & (np.abs(kb[:, 1] - ka[i, 1]) < 0.02))[0]
+        if len(cand) == 0:
+            continue
+        da = np.abs(((kb[cand, 3] - ka[i, 3]) + 180.0) % 360.0 - 180.0)
+        j = cand[np.argmin(da)]
+        if da.min() < 0.2:
+            used[j] = True
+            pairs.append((i, j))
+    return np.array(pairs).reshape(-1, 2)
+
+
+@pytest.mark.parametrize('shape,seed,gray', [((200, 260), 0, False), ((167, 301), 3, False),
+                                             ((240, 180), 5, True)])
+def test_sift_equals_oracle(shape, seed, gray):
+    from imageanalysis_amd import kernels
+    from oracle import sift_oracle as so
+    img = texture(shape[0], shape[1], seed)
+    if gray:
+        img = so.bgr_to_gray(img)
+    kps, des = so.detect_and_compute(img)
+    kp, octv, d = kernels.sift_detect(img)
+    assert len(kps) > 100
+    assert abs(len(kp) - len(kps)) <= max(2, len(kps) // 100)
+    pairs = _match(kps, kps[:, 5].astype(np.int64), kp.astype(np.float64), octv.astype(np.int64))
+    assert len(pairs) >= 0.99 * len(kps)
+    a, b = kps[pairs[:, 0]], kp[pairs[:, 1]].astype(np.float64)
+    assert np.abs(a[:, 0] - b[:, 0]).max() < 2e-3 and np.abs(a[:, 1] - b[:, 1]).max() < 2e-3
+    assert np.abs(a[:, 2] - b[:, 2]).max() < 1e-3 * a[:, 2].max()
+    assert np.abs(a[:, 4] - b[:, 4]).max() < 1e-5
+    da, db = des[pairs[:, 0]].astype(int), d[pairs[:, 1]].astype(int)
+    diff = np.abs(da - db)
+    assert diff.max() <= 2 and (diff == 0).mean() > 0.99
+    # descriptor invariants of the format (x512, clip 0.2): u8, L2 norm ~ 512
+    nrm = np.sqrt((d.astype(float) ** 2).sum(1))
+    assert np.all(np.abs(nrm - 512) < 40)
+
+
+def test_sift_translation_repeatability():
+    """a crop shifted by whole pixels yields the same features shifted (interior ones)."""
+    from imageanalysis_amd import kernels
+    big = texture(260, 320, 9)
+    a = big[10:250, 10:310]
+    b = big[18:258, 26:326]                     # content of b at (x,y) = a at (x+16, y+8)
+    ka, oa, da = kernels.sift_detect(a)
+    kb, ob, db = kernels.sift_detect(b)
+    inner = (ka[:, 0] > 60) & (ka[:, 0] < 240) & (ka[:, 1] > 50) & (ka[:, 1] < 190) & (ka[:, 2] < 8)
+    ka2 = ka[inner].astype(np.float64)
+    ka2[:, 0] -= 16
+    ka2[:, 1] -= 8
+    pairs = _match(ka2, oa[inner].astype(np.int64), kb.astype(np.float64), ob.astype(np.int64))
+    assert len(pairs) >= 0.85 * inner.sum()
+    dd = np.abs(da[inner][pairs[:, 0]].astype(int) - db[pairs[:, 1]].astype(int))
+    assert np.median(dd.sum(1)) < 60
