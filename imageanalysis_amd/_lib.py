@@ -38,6 +38,10 @@ SIGNATURES = {
     'iamx_ba_residual_jac': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
+    'iamx_image_prep_workspace_bytes': (c_int64, [c_int, c_int]),
+    'iamx_image_resized_dims': (c_int, [c_int, c_int, c_double, c_void_p, c_void_p]),
+    'iamx_image_equalize_resize': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, c_double,
+                                           c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_sift_workspace_bytes': (c_int64, [c_int, c_int]),
     'iamx_sift_detect': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, c_void_p, c_int64, c_void_p, c_void_p, c_int,

@@ -1,0 +1,236 @@
+"""MI355X-native stand-in for the feature part of the reference's scripts/lib/image.py:
+
+    Image.load_rgb(equalize)                       image.py:99-121   (decode + CLAHE on HSV-V)
+    Image.detect_features(scale, use_cache=True)   image.py:287-350  (resize + SIFT + cache)
+    load_/save_features, _descriptors, _matches    image.py:140-228  (same on-disk formats)
+
+JPEG decoding stays on the host (Pillow; the reference uses cv2.imread); CLAHE, resize, the
+SIFT pyramid, keypoints and descriptors run on the GPU (csrc/image_prep.hip, csrc/sift.hip).
+Cache files are byte-compatible with the reference's: `.feat` = gzip(level 6) pickle of
+[((x, y), size, angle, response, octave, class_id), ...] in FULL-RES pixels, `.desc` =
+gzip(level 6) of np.save(float32 [N,128]), `.match` = pickle {other_name: [[i, j], ...]}.
+
+Use `install(lib.image)` to give the reference's own Image class these methods (drop-in), or
+the stand-alone `Image` class below.
+"""
+import gzip
+import os
+import pickle
+import sys
+
+import numpy as np
+
+from . import _deps
+from .hostlib.image_pose import PoseImage
+
+try:                                     # inside the reference environment keep cv2's type
+    from cv2 import KeyPoint as _CvKeyPoint
+except Exception:                        # noqa: BLE001
+    _CvKeyPoint = None
+
+
+class KeyPoint(object):
+    """the fields of cv2.KeyPoint the pipeline reads and caches (image.py:192-198)"""
+    __slots__ = ('pt', 'size', 'angle', 'response', 'octave', 'class_id')
+
+    def __init__(self, x=0.0, y=0.0, size=0.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
+        f32 = np.float32                 # cv2.KeyPoint stores float32 members
+        self.pt = (float(f32(x)), float(f32(y)))
+        self.size = float(f32(size))
+        self.angle = float(f32(angle))
+        self.response = float(f32(response))
+        self.octave = int(octave)
+        self.class_id = int(class_id)
+
+
+def make_keypoint(x, y, size, angle, response, octave, class_id=-1):
+    if _CvKeyPoint is not None:
+        return _CvKeyPoint(x=float(x), y=float(y), size=float(size), angle=float(angle),
+                           response=float(response), octave=int(octave), class_id=int(class_id))
+    return KeyPoint(x, y, size, angle, response, octave, class_id)
+
+
+def _log(*a):
+    _deps.logger().log(*a)
+
+
+def _qlog(*a):
+    _deps.logger().qlog(*a)
+
+
+# --------------------------------------------------------------------------------------
+# cache I/O -- image.py:140-228
+# --------------------------------------------------------------------------------------
+def load_features(self):
+    if os.path.exists(self.features_file):
+        try:
+            with gzip.open(self.features_file, "rb") as fp:
+                feature_list = pickle.load(fp)
+            self.kp_list = [make_keypoint(p[0][0], p[0][1], p[1], p[2], p[3], p[4], p[5])
+                            for p in feature_list]
+            return True
+        except Exception:                 # noqa: BLE001  (the reference prints and carries on)
+            print(self.features_file + ":\n" + "  feature load error: "
+                  + str(sys.exc_info()[0]) + ": " + str(sys.exc_info()[1]))
+    return False
+
+
+def load_descriptors(self):
+    if os.path.exists(self.desc_file):
+        if self.des_list is None:
+            try:
+                with gzip.open(self.desc_file, 'rb') as fp:
+                    self.des_list = np.load(fp)
+                return True
+            except Exception:             # noqa: BLE001
+                print(self.desc_file + ":\n" + "  desc load error: " + str(sys.exc_info()[1]))
+    return False
+
+
+def load_matches(self):
+    try:
+        with open(self.match_file, "rb") as fp:
+            self.match_list = pickle.load(fp)
+        self.matches_clean = True
+    except Exception:                     # noqa: BLE001
+        print(self.match_file + ":\n" + "  matches load error: "
+              + str(sys.exc_info()[0]) + ": " + str(sys.exc_info()[1]))
+
+
+def save_features(self):
+    feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
+                    for kp in self.kp_list]
+    try:
+        with gzip.open(self.features_file, 'wb', compresslevel=6) as fp:
+            pickle.dump(feature_list, fp)
+    except IOError as e:
+        print("save_features(): I/O error({0}): {1}".format(e.errno, e.strerror))
+
+
+def save_descriptors(self):
+    try:
+        with gzip.open(self.desc_file, 'wb', compresslevel=6) as fp:
+            np.save(fp, self.des_list)
+    except Exception:                     # noqa: BLE001
+        print(self.desc_file + ": error saving file: " + str(sys.exc_info()[1]))
+
+
+def save_matches(self):
+    try:
+        with open(self.match_file, 'wb') as fp:
+            pickle.dump(self.match_list, fp)
+        self.matches_clean = True
+    except IOError:
+        print(self.match_file + ": error saving file: " + str(sys.exc_info()[1]))
+
+
+# --------------------------------------------------------------------------------------
+# decode / equalise -- image.py:99-121
+# --------------------------------------------------------------------------------------
+def _decode_bgr(path):
+    from PIL import Image as PILImage      # host-side JPEG decode, EXIF orientation ignored
+    with PILImage.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def load_rgb(self, equalize=False):
+    """BGR uint8 [h,w,3] like cv2.imread; with equalize=True CLAHE(3.0, 8x8) on the HSV value
+    channel (on the device).  Records width/height in the image's property node."""
+    try:
+        bgr = _decode_bgr(self.image_file)
+        if equalize:
+            from . import kernels
+            bgr = kernels.equalize_resize(bgr, 1.0, equalize=True).cpu().numpy()
+        h, w = bgr.shape[:2]
+        self.node.setInt('height', h)
+        self.node.setInt('width', w)
+        return bgr
+    except Exception:                     # noqa: BLE001
+        print(str(self.image_file) + ":\n" + "  rgb load error: " + str(sys.exc_info()[1]))
+        return None
+
+
+# --------------------------------------------------------------------------------------
+# detect -- image.py:287-350
+# --------------------------------------------------------------------------------------
+def features_from_bgr(bgr, scale, equalize=True):
+    """full-res BGR -> (kp_list in full-res pixels, des_list float32 [N,128]); everything
+    after the decode runs on the GPU."""
+    from . import kernels
+    scaled = kernels.equalize_resize(bgr, scale, equalize=equalize)
+    kp, octave, desc = kernels.sift_detect(scaled)
+    # kp.pt = (kp.pt[0]/scale, kp.pt[1]/scale): keypoints are cached in FULL-RES pixels (:344-346)
+    kp_list = [make_keypoint(k[0] / scale, k[1] / scale, k[2], k[3], k[4], int(o))
+               for k, o in zip(kp.tolist(), octave.tolist())]
+    return kp_list, desc.astype(np.float32)
+
+
+def detect_features(self, scale, use_cache=True):
+    if use_cache:
+        success = True
+        if not self.load_features():
+            success = False
+        if not self.load_descriptors():
+            success = False
+        if success:
+            _qlog("Loaded features/descriptors from cache:", self.name)
+            return
+    _qlog("Detecting features/descriptors for:", self.name)
+    detector_node = _deps.getNode('/config/detector', True)
+    if detector_node.getString('detector') not in ('SIFT', ''):
+        _log("Detector", detector_node.getString('detector'),
+             "is not on the MI355X path (SIFT only)")
+        quit()
+    bgr = _decode_bgr(self.image_file)
+    h, w = bgr.shape[:2]
+    self.node.setInt('height', h)
+    self.node.setInt('width', w)
+    cam_w, cam_h = _deps.camera().get_image_params()
+    if w != cam_w or h != cam_h:
+        _log("Error: image dimensions", w, h, "do not match camera config",
+             cam_w, cam_h, "cannot continue safely.")
+        _log("Please track down and fix the camera config vs. image size issue.")
+        quit()
+    self.kp_list, self.des_list = features_from_bgr(bgr, scale, equalize=True)
+    self.num_features = len(self.kp_list)
+    self.save_features()
+    self.save_descriptors()
+
+
+_METHODS = dict(load_features=load_features, load_descriptors=load_descriptors,
+                load_matches=load_matches, save_features=save_features,
+                save_descriptors=save_descriptors, save_matches=save_matches,
+                load_rgb=load_rgb, detect_features=detect_features)
+
+
+def install(ref_image_module):
+    """Give the reference's lib.image.Image the GPU feature methods (drop-in)."""
+    for name, fn in _METHODS.items():
+        setattr(ref_image_module.Image, name, fn)
+
+
+class Image(PoseImage):
+    """Stand-alone image record: poses (hostlib.image_pose) + the feature methods above, with
+    the reference's file layout under <analysis_dir>/{meta,cache} (image.py:76-97)."""
+
+    def __init__(self, analysis_dir=None, image_base=None):
+        super(Image, self).__init__(image_base if image_base is not None else 'unnamed')
+        self.image_file = None
+        if image_base and analysis_dir:
+            project_dir = _deps.getNode('/config/directories', True).getString('project_dir')
+            for d in (project_dir, os.path.join(project_dir, 'images')):
+                for ext in ('.JPG', '.jpg'):
+                    p = os.path.join(d, image_base + ext)
+                    if os.path.isfile(p):
+                        self.image_file = p
+            self.features_file = os.path.join(analysis_dir, 'cache', image_base + ".feat")
+            self.desc_file = os.path.join(analysis_dir, 'cache', image_base + ".desc")
+            self.match_file = os.path.join(analysis_dir, 'meta', image_base + ".match")
+
+    def get_size(self):
+        return self.node.getInt('width'), self.node.getInt('height')
+
+
+for _n, _f in _METHODS.items():
+    setattr(Image, _n, _f)

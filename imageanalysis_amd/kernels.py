@@ -317,3 +317,25 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     layer = ((octave >> 8) & 255).astype(np.int64)
     order = np.lexsort((d[:, 0], k[:, 3], k[:, 0], k[:, 1], layer, o_idx))
     return np.ascontiguousarray(k[order, :5]), octave[order], np.ascontiguousarray(d[order])
+
+
+def equalize_resize(bgr, scale, equalize=True, clip_limit=3.0):
+    """Image.load_rgb(equalize=True) + cv2.resize(fx=fy=scale) on the device.
+    bgr [h,w,3] uint8 (numpy or device) -> device tensor [round(h*s), round(w*s), 3] uint8."""
+    dev = require_gpu()
+    img = _dev(bgr, U8)
+    h, w, ch = img.shape
+    if ch != 3:
+        raise ValueError("expected a BGR image")
+    import ctypes
+    oh, ow = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib().iamx_image_resized_dims(h, w, float(scale), ctypes.byref(oh), ctypes.byref(ow)),
+          'iamx_image_resized_dims')
+    need = int(lib().iamx_image_prep_workspace_bytes(h, w))
+    ws = torch.empty(need, dtype=U8, device=dev)
+    out = torch.empty((oh.value, ow.value, 3), dtype=U8, device=dev)
+    check(lib().iamx_image_equalize_resize(_ptr(img), h, w, 1 if equalize else 0, float(clip_limit),
+                                           float(scale), _ptr(ws), need, _ptr(out), stream_ptr()),
+          'iamx_image_equalize_resize')
+    torch.cuda.current_stream().synchronize()
+    return out

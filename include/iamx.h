@@ -141,6 +141,19 @@ int iamx_ba_residual_jac(const double *cams, int n_cams, const double *pts, int 
                          double *Jc, double *Jp, double *Jk, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Image preparation -- replaces the cv2 calls of Image.load_rgb(equalize=True) and the resize
+ * in detect_features (scripts/lib/image.py:105-112,313): BGR->HSV, CLAHE(clip_limit, 8x8) on
+ * V, HSV->BGR, cv2.resize(fx=fy=scale, INTER_LINEAR).
+ *   bgr  DEV [height][width][3] uint8;  out  DEV [out_h][out_w][3] uint8 with
+ *   (out_h, out_w) = iamx_image_resized_dims = round(size*scale);  equalize = 0 skips CLAHE.
+ * ------------------------------------------------------------------------------------ */
+int64_t iamx_image_prep_workspace_bytes(int height, int width);
+int iamx_image_resized_dims(int height, int width, double scale, int *out_h, int *out_w);
+int iamx_image_equalize_resize(const uint8_t *bgr, int height, int width, int equalize,
+                               float clip_limit, double scale, void *workspace,
+                               int64_t workspace_bytes, uint8_t *out, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * K1: SIFT detect + describe -- replaces cv2.SIFT_create().detectAndCompute(scaled, None)
  *   scripts/lib/image.py:235-237,324 (OpenCV defaults: 3 layers/octave, sigma 1.6, image
  *   doubled, contrastThreshold 0.04, edgeThreshold 10, no feature cap).

@@ -187,3 +187,29 @@ def test_transforms_known_answers():
     assert np.allclose(tf.quaternion_matrix([0, 1, 0, 0]), np.diag([1, -1, -1, 1]))
     q = tf.quaternion_from_euler(0.3, -1.2, 0.5, 'rzyx')
     assert np.allclose(tf.euler_from_quaternion(q, 'rzyx'), (0.3, -1.2, 0.5))
+
+
+def test_feature_cache_formats_roundtrip(tmp_path):
+    """.feat/.desc/.match files in the reference's formats (lib/image.py:140-228), no GPU."""
+    import gzip
+    from imageanalysis_amd import image as iimg
+    from imageanalysis_amd._deps import getNode
+    an = tmp_path / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    getNode('/config/directories', True).setString('project_dir', str(tmp_path))
+    im = iimg.Image(str(an), 'IMG_7')
+    im.kp_list = [iimg.make_keypoint(10.25, 20.5, 3.0, 45.0, 0.03, 65793),
+                  iimg.make_keypoint(1.0, 2.0, 5.0, 300.0, 0.01, 16711935)]
+    im.des_list = np.arange(256, dtype=np.float32).reshape(2, 128) % 200
+    im.match_list = {'IMG_8': [[0, 5], [1, 2]], 'IMG_9': []}
+    im.save_features(); im.save_descriptors(); im.save_matches()
+    raw = pickle.load(gzip.open(im.features_file, 'rb'))
+    assert raw == [((10.25, 20.5), 3.0, 45.0, im.kp_list[0].response, 65793, -1),
+                   ((1.0, 2.0), 5.0, 300.0, im.kp_list[1].response, 16711935, -1)]
+    assert pickle.load(open(im.match_file, 'rb')) == im.match_list
+    im2 = iimg.Image(str(an), 'IMG_7')
+    assert im2.load_features() and im2.load_descriptors()
+    im2.load_matches()
+    assert im2.kp_list[1].pt == (1.0, 2.0) and im2.kp_list[1].octave == 16711935
+    assert np.array_equal(im2.des_list, im.des_list) and im2.match_list == im.match_list

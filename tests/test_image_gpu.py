@@ -1,0 +1,78 @@
+"""GPU: image preparation kernels and the Image.detect_features mirror (decode -> CLAHE ->
+resize -> SIFT -> reference cache formats) against the oracle."""
+import gzip
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from test_sift_gpu import texture, _match
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('shape,scale', [((96, 128), 0.4), ((101, 77), 0.5), ((240, 320), 1.0)])
+def test_equalize_resize_equals_oracle(shape, scale):
+    from imageanalysis_amd import kernels
+    from oracle import image_oracle as io
+    rng = np.random.default_rng(shape[0])
+    img = texture(shape[0], shape[1], 1)
+    img[..., 1] = np.roll(img[..., 1], 7, axis=1)          # colourful: exercise the hue path
+    img[::5, ::7] = rng.integers(0, 256, img[::5, ::7].shape, dtype=np.uint8)
+    want = io.resize_linear_u8(io.equalize_bgr(img), scale)
+    got = kernels.equalize_resize(img, scale).cpu().numpy()
+    assert got.shape == want.shape
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.995     # u8 rounding ties of float chains
+    plain = kernels.equalize_resize(img, scale, equalize=False).cpu().numpy()
+    assert np.array_equal(plain, io.resize_linear_u8(img, scale))
+
+
+def test_detect_features_end_to_end(tmp_path):
+    from PIL import Image as PILImage
+    from imageanalysis_amd import image as iimg
+    from imageanalysis_amd._deps import getNode
+    from imageanalysis_amd.hostlib import camera
+    from oracle import image_oracle as io
+    from oracle import sift_oracle as so
+    proj = tmp_path / 'proj'
+    (proj / 'images').mkdir(parents=True)
+    an = proj / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    rgb = texture(300, 400, 11)[:, :, ::-1]
+    PILImage.fromarray(np.ascontiguousarray(rgb)).save(str(proj / 'images' / 'T001.JPG'), quality=95)
+    getNode('/config/directories', True).setString('project_dir', str(proj))
+    getNode('/config/detector', True).setString('detector', 'SIFT')
+    camera.set_image_params(400, 300)
+    im = iimg.Image(str(an), 'T001')
+    assert im.image_file.endswith('T001.JPG')
+    im.detect_features(0.5)
+    assert im.num_features == len(im.kp_list) > 100
+    assert im.des_list.dtype == np.float32 and im.des_list.shape == (len(im.kp_list), 128)
+    assert im.get_size() == (400, 300)
+    # the cache files are the reference's formats (image.py:192-217)
+    with gzip.open(im.features_file, 'rb') as f:
+        feats = pickle.load(f)
+    assert isinstance(feats, list) and len(feats[0]) == 6 and len(feats[0][0]) == 2
+    with gzip.open(im.desc_file, 'rb') as f:
+        des = np.load(f)
+    assert des.dtype == np.float32 and np.array_equal(des, im.des_list)
+    im2 = iimg.Image(str(an), 'T001')
+    im2.detect_features(0.5)                          # served from the cache
+    assert len(im2.kp_list) == len(im.kp_list) and np.array_equal(im2.des_list, im.des_list)
+    assert im2.kp_list[3].pt == im.kp_list[3].pt and im2.kp_list[3].octave == im.kp_list[3].octave
+    # against the oracle chain on the same decoded pixels
+    bgr = iimg._decode_bgr(im.image_file)
+    kps, odes = so.detect_and_compute(io.resize_linear_u8(io.equalize_bgr(bgr), 0.5))
+    got = np.array([[k.pt[0] * 0.5, k.pt[1] * 0.5, k.size, k.angle, k.response] for k in im.kp_list])
+    octv = np.array([k.octave for k in im.kp_list], np.int64)
+    pairs = _match(kps, kps[:, 5].astype(np.int64), got, octv)
+    assert len(pairs) >= 0.97 * len(kps)
+    dd = np.abs(odes[pairs[:, 0]].astype(int) - im.des_list[pairs[:, 1]].astype(int))
+    assert (dd == 0).mean() > 0.97
+    # wrong camera size -> quit(), like the reference (image.py:300-306)
+    camera.set_image_params(401, 300)
+    with pytest.raises(SystemExit):
+        iimg.Image(str(an), 'T001').detect_features(0.5, use_cache=False)
