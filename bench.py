@@ -118,6 +118,7 @@ def main():
     raw = synth_descriptors(n_img, first, mine, dev)
     store = kernels.DescriptorStore([KPTS] * n_img)
     rows_per = int(store.offsets[1] - store.offsets[0])
+    rows_per2 = int(store.offsets2[1] - store.offsets2[0])
 
     def pack_and_gather():
         """pack own images into the store, then RCCL all-gather (desc, norm_q, norm_t) in
@@ -127,9 +128,16 @@ def main():
         kernels.check(L.iamx_desc_pack_u8(_ptr(raw), mine * KPTS, _ptr(store.desc[o:]),
                                           _ptr(store.norm_q[o:]), _ptr(store.norm_t[o:]), sp),
                       'iamx_desc_pack_u8')
+        for k in range(mine):                  # train-side (parity partitioned) layout
+            o2 = int(store.offsets2[first + k])
+            kernels.check(L.iamx_desc2_pack_u8(_ptr(raw[k]), KPTS, _ptr(store.desc2[o2:]),
+                                               _ptr(store.norm2[o2:]), _ptr(store.cinit[o2:]),
+                                               _ptr(store.perm[o2:]), _ptr(store.meta[first + k]),
+                                               sp), 'iamx_desc2_pack_u8')
         if dist is not None:
             for buf, width in ((store.desc, rows_per * DIM), (store.norm_q, rows_per),
-                               (store.norm_t, rows_per)):
+                               (store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),
+                               (store.cinit, rows_per2), (store.perm, rows_per2), (store.meta, 4)):
                 flat = buf.view(-1)
                 shard = per * width
                 dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard])
@@ -148,10 +156,10 @@ def main():
         for b, (e0, e1) in zip(batches, ev):
             if timed_events:
                 e0.record()
-            b.run_knn2(ws)
+            b.run_knn2_fast(ws)
             if timed_events:
                 e1.record()
-            b.run_filter(ws, thresh)
+            b.run_filter_fast(ws, thresh)
             survivors.add_(ws.surv_off[b.n_pairs])
 
     def barrier():
@@ -182,12 +190,13 @@ def main():
     k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     k_pairs = [b.n_pairs / 2.0 for b in batches]           # unordered pairs per launch
     achieved = sum(k_pairs) * FLOP_PER_PAIR / (sum(k_ms) * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "knn2_pairs_kernel",
+    roofline = {"bound": "mfma", "kernel": "knn2v2_kernel",
                 "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
                 "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR}
 
+    ws_unresolved = int(ws.unresolved.item())
     # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
     ba = None
     cpu_sample = raw[:2].cpu().numpy() if (rank == 0 and mine >= 2) else None
@@ -215,6 +224,7 @@ def main():
                        "parallelism": "pair-shard x%d%s" % (world, " + RCCL descriptor all-gather"
                                                             if world > 1 else "")},
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
+            "unresolved": int(ws_unresolved),
             "roofline": roofline, "cpu_baseline": cpu, "ba": ba,
         }
         print(json.dumps(out), flush=True)

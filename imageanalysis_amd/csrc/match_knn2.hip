@@ -54,6 +54,10 @@ struct Knn2Args {
 
 __device__ __forceinline__ int med3_i32(int a, int b, int c)
 {
+    // inline asm on purpose: it also keeps the scheduler from hoisting whole tiles (the plain
+    // max/min form selects v_med3_i32 too but the kernel then needs 256 VGPRs and spills).
+    // Its `c` operand is always the compiler-generated key (a VALU result), never a raw MFMA
+    // accumulator, so no MFMA->VALU hazard hides inside the asm statement.
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void metric_kernel(const int32_t *__restrict__
 }
 
 // order-preserving compaction, one workgroup per ordered pair
-__global__ __launch_bounds__(256) void compact_kernel(const int32_t *__restrict__ idx,
+__global__ __launch_bounds__(256) void compact_kernel(const int32_t *__restrict__ idx, int idx_stride,
                                                       const double *__restrict__ metric,
                                                       const uint8_t *__restrict__ keep,
                                                       const int64_t *__restrict__ seg_off,
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int32_t *__restrict_
         if (k) {
             const int64_t o = out + woff + before;
             surv_q[o] = (int32_t)(i - b);
-            surv_t[o] = idx[2 * i];
+            surv_t[o] = idx[(int64_t)idx_stride * i];
             surv_metric[o] = metric[i];
         }
         out += tot;
@@ -578,18 +582,19 @@ extern "C" int iamx_match_metric(const int32_t *d2, const int64_t *seg_off, int 
     return iamx::check_launch("iamx_match_metric");
 }
 
-extern "C" int iamx_match_compact(const int32_t *idx, const double *metric, const uint8_t *keep,
+extern "C" int iamx_match_compact(const int32_t *idx, int idx_stride, const double *metric,
+                                  const uint8_t *keep,
                                   const int64_t *seg_off, const int64_t *surv_off, int n_seg,
                                   int32_t *surv_q, int32_t *surv_t, double *surv_metric,
                                   void *stream)
 {
     IAMX_REQUIRE(idx && metric && keep && seg_off && surv_off && surv_q && surv_t && surv_metric,
                  "null pointer");
-    IAMX_REQUIRE(n_seg >= 0, "negative count");
+    IAMX_REQUIRE(n_seg >= 0 && idx_stride >= 1, "bad count / stride");
     if (n_seg == 0) return IAMX_OK;
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)n_seg), dim3(256), 0,
-                       iamx::as_stream(stream), idx, metric, keep, seg_off, surv_off, surv_q,
-                       surv_t, surv_metric);
+                       iamx::as_stream(stream), idx, idx_stride, metric, keep, seg_off, surv_off,
+                       surv_q, surv_t, surv_metric);
     return iamx::check_launch("iamx_match_compact");
 }
 

@@ -1,0 +1,498 @@
+// K2 (fast form) -- exact top-2 *distances* with 2 VALU instructions per distance (gfx950).
+//
+// Why a second form: on gfx950 the 32-bit min/max/med3/lshl_add VALU ops are half rate and an
+// MFMA hides only ~5 of them (profiles/r1_ubench_valu_mfma.txt), so the general kernel
+// (match_knn2.hip: key = (acc<<9)+term, med3, min = 3 ops per distance) is VALU-issue bound.
+// Here the per-train-row term rides in through the MFMA's C operand and the index is not
+// tracked in the sweep at all:
+//     d2(q,t) = norm_q[q] + NB[t] + 2*acc,   NB = |s_t|^2 + 2*sum(s_t),   acc = sum(~s_q * s_t)
+//     val     = (NB >> 1) + acc              (C operand initialised with NB >> 1)
+//     d2      = norm_q[q] + 2*val + (NB & 1)
+// Inside one parity class (NB & 1 equal) ordering by `val` IS ordering by d2, so the train
+// rows of an image are stored partitioned by that parity (stable, each class padded to 128
+// rows) and the sweep keeps (m1, m2) per class with  m2 = med3(m1, m2, val); m1 = min(m1, val).
+// Distances of different parity cannot tie, so merging the two classes at the end is exact.
+// Besides (d2_best, d2_second) the kernel records the 32-row tile in which the best value first
+// appeared (1 compare + 1 select per 16 distances); the train index is then recovered only for
+// the queries that survive the reference's metric threshold (scripts/lib/matcher.py:253-263) by
+// knn2v2_resolve_kernel, which recomputes the 32 exact distances of that tile with v_dot4 and
+// takes the lowest original row that reaches d2_best (= cv2.BFMatcher order, lowest index on
+// ties: the partition is stable, so the first tile / first row is the lowest original index).
+#include "iamx_common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int D = IAMX_DESC_DIM;
+constexpr int WAVES = 4, CHUNK = 128;
+constexpr int QW_PRODUCT = 2;             // 32-query blocks per wave in the shipped kernel
+constexpr int BIG = 0x3F000000;          // value of padding rows: loses every comparison
+
+__device__ __forceinline__ int med3_after(int a, int b, int c, int dep)
+{
+    // v_med3_i32 as inline asm (keeps register pressure at ~150 VGPRs; the plain max/min form
+    // lets the scheduler hoist whole tiles and spill).  hipcc does not pad hazards inside asm
+    // statements, and `c` is a raw MFMA accumulator here: `dep` must be the result of a
+    // compiler-generated VALU instruction that already read the same accumulator (the v_min in
+    // front), so the MFMA -> VALU wait states are in place before this statement can issue.
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(dep));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------
+// pack: one workgroup per image; stable partition of the rows by the parity of NB
+// ---------------------------------------------------------------------------------
+template <typename SRC>
+__device__ __forceinline__ void row_sums(const SRC *p, int &s2, int &s1, unsigned w[32])
+{
+    s2 = 0; s1 = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) w[i] = 0;
+#pragma unroll 4
+    for (int i = 0; i < D; ++i) {
+        int v;
+        if constexpr (sizeof(SRC) == 1) {
+            v = (int)p[i];
+        } else {
+            v = (int)rintf((float)p[i]);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        const int s = v - 128;
+        s2 += s * s;
+        s1 += s;
+        w[i >> 2] |= (unsigned)(s & 0xFF) << (8 * (i & 3));
+    }
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(1024) void pack2_kernel(const SRC *__restrict__ src, int n,
+                                                     int rows_cap, int8_t *__restrict__ dst,
+                                                     int32_t *__restrict__ norm2,
+                                                     int32_t *__restrict__ cinit,
+                                                     int32_t *__restrict__ perm,
+                                                     int32_t *__restrict__ meta)
+{
+    __shared__ int wcnt[16];
+    __shared__ int s_run_even, s_run_odd, s_ne;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- pass A: count even-parity rows
+    int cnt = 0;
+    for (int r = tid; r < n; r += 1024) {
+        int s2, s1;
+        unsigned w[32];
+        row_sums(src + (int64_t)r * D, s2, s1, w);
+        cnt += ((s2 + 2 * s1) & 1) == 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    if (lane == 0) wcnt[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int i = 0; i < 16; ++i) t += wcnt[i];
+        s_ne = t;
+        s_run_even = 0;
+        s_run_odd = 0;
+    }
+    __syncthreads();
+    const int ne = s_ne, no = n - ne;
+    const int ne_pad = (ne + CHUNK - 1) / CHUNK * CHUNK, no_pad = (no + CHUNK - 1) / CHUNK * CHUNK;
+    // ---- pass B: stable partition, 1024 rows per round
+    for (int base = 0; base < n; base += 1024) {
+        const int r = base + tid;
+        int s2 = 0, s1 = 0;
+        unsigned w[32];
+        bool valid = r < n, even = false;
+        if (valid) {
+            row_sums(src + (int64_t)r * D, s2, s1, w);
+            even = ((s2 + 2 * s1) & 1) == 0;
+        }
+        const unsigned long long mask = __ballot(valid && even);
+        const int before_w = __popcll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int before = before_w, total_even = 0;
+        for (int i = 0; i < 16; ++i) {
+            if (i < wave) before += wcnt[i];
+            total_even += wcnt[i];
+        }
+        const int run_e = s_run_even, run_o = s_run_odd;
+        if (valid) {
+            const int pos = even ? run_e + before : ne_pad + run_o + (tid - before);
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst + (int64_t)pos * D);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+            norm2[pos] = s2;
+            const int nb = s2 + 2 * s1;
+            cinit[pos] = nb >> 1;
+            perm[pos] = r;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int rows = n - base < 1024 ? n - base : 1024;
+            s_run_even = run_e + total_even;
+            s_run_odd = run_o + rows - total_even;
+        }
+        __syncthreads();
+    }
+    // ---- pads
+    for (int p = tid; p < rows_cap; p += 1024) {
+        const bool pad = (p >= ne && p < ne_pad) || p >= ne_pad + no;
+        if (pad) {
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst + (int64_t)p * D);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d4[i] = make_uint4(0, 0, 0, 0);
+            norm2[p] = 0;
+            cinit[p] = BIG;
+            perm[p] = -1;
+        }
+    }
+    if (tid == 0) {
+        meta[0] = n;
+        meta[1] = ne_pad / CHUNK;
+        meta[2] = no_pad / CHUNK;
+        meta[3] = ne;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sweep
+// ---------------------------------------------------------------------------------
+struct Args2 {
+    const int8_t *desc_q;        // query store (original row order, 128-row padded, v1 layout)
+    const int32_t *norm_q;
+    const int32_t *qimg_off, *qimg_n;
+    const int8_t *desc_t;        // train store (parity partitioned)
+    const int32_t *cinit;
+    const int32_t *timg_off;     // first packed row of each image in the train store
+    const int32_t *tmeta;        // [n_img][4]: n, even chunks, odd chunks, n_even
+    const int32_t *pairs, *wg_off;
+    const int64_t *out_off;
+    int32_t *out_d2;             // [rows][2]
+    int32_t *out_tile;           // [rows]
+    int n_pairs, total_wg;
+};
+
+// VARIANT != 0: timing ablations (iamxdbg_knn2v2_variant): bit0 no epilogue, bit1 no MFMA,
+// bit2 no re-staging / barriers, bit3 two interleaved (m1,m2) chains per query block
+template <int VARIANT, int QW, int OCC>
+__global__ __launch_bounds__(WAVES * 64, OCC) void knn2v2_kernel(Args2 A)
+{
+    constexpr int QB = WAVES * QW * 32;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * CHUNK * D + 2 * CHUNK * 4];
+    int8_t *lds_tile = lds;
+    int *lds_tb = reinterpret_cast<int *>(lds + 2 * CHUNK * D);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, g = lane >> 5;
+
+    int vid;
+    {
+        const int total = A.total_wg, bid = blockIdx.x;
+        const int xcd = bid & 7, k = bid >> 3, q = total >> 3, r = total & 7;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int lo = 0, hi = A.n_pairs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.wg_off[mid] <= vid) lo = mid; else hi = mid;
+    }
+    const int qimg = A.pairs[2 * lo], timg = A.pairs[2 * lo + 1];
+    const int qoff = A.qimg_off[qimg], nq = A.qimg_n[qimg];
+    const int toff = A.timg_off[timg];
+    const int ne_ch = A.tmeta[4 * timg + 1], no_ch = A.tmeta[4 * timg + 2];
+    const int64_t obase = A.out_off[lo];
+    const int q0 = (vid - A.wg_off[lo]) * QB + wave * (QW * 32);
+
+    v4i bq[QW][4];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        int row = q0 + qb * 32 + c;
+        row = row < nq ? row : nq - 1;
+        const v4i *src = reinterpret_cast<const v4i *>(A.desc_q + (int64_t)(qoff + row) * D);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[qb][s] = ~src[2 * s + g];
+    }
+    int m1[QW], m2[QW], t1[QW];           // running class
+    int e1[QW], e2[QW], et[QW];           // finished even class
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        m1[qb] = m2[qb] = BIG; t1[qb] = 0;
+        e1[qb] = e2[qb] = BIG; et[qb] = 0;
+    }
+
+    const int8_t *tbase = A.desc_t + (int64_t)toff * D;
+    const int32_t *tci = A.cinit + toff;
+    v4i st[4];
+    int st_tb = BIG;
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            st[j] = *reinterpret_cast<const v4i *>(tbase + (int64_t)(ch * CHUNK) * D + (j * 256 + tid) * 16);
+        if (tid < CHUNK) st_tb = tci[ch * CHUNK + tid];
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = j * 256 + tid, row = e >> 3, slot = e & 7;
+            *reinterpret_cast<v4i *>(lds_tile + buf * (CHUNK * D) + row * D + ((slot ^ ((row >> 1) & 7)) * 16)) = st[j];
+        }
+        if (tid < CHUNK) lds_tb[buf * CHUNK + tid] = st_tb;
+    };
+
+    const int nchunks = ne_ch + no_ch;
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if constexpr (!(VARIANT & 4))
+            if (ch + 1 < nchunks) load_chunk(ch + 1);
+        if (ch == ne_ch) {                 // class boundary: park the even class
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb) {
+                e1[qb] = m1[qb]; e2[qb] = m2[qb]; et[qb] = t1[qb];
+                m1[qb] = m2[qb] = BIG;
+            }
+        }
+        const int8_t *tile_base = lds_tile + ((VARIANT & 4) ? 0 : buf) * (CHUNK * D);
+        const int *tb_base = lds_tb + ((VARIANT & 4) ? 0 : buf) * CHUNK;
+#pragma unroll
+        for (int tile = 0; tile < CHUNK / 32; ++tile) {
+            const int r = tile * 32 + c, swz = (r >> 1) & 7;
+            v4i a[4];
+            v4i tbv[4];
+            if constexpr (VARIANT & 8) {       // ablation: operands without LDS traffic
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { a[s] = bq[0][s] + ch; tbv[s] = bq[1][s]; }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    a[s] = *reinterpret_cast<const v4i *>(tile_base + r * D + (((2 * s + g) ^ swz) * 16));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
+            }
+            const int tile_id = ch * (CHUNK / 32) + tile;
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb) {
+                v16i acc;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[reg] = tbv[reg >> 2][reg & 3];   // C operand
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (VARIANT & 2) acc[s] += a[s][0] ^ bq[qb][s][1];
+                    else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qb][s], acc, 0, 0, 0);
+                }
+                if constexpr (VARIANT & 1) {
+                    asm volatile("" ::"v"(acc));
+                } else {
+                    const int before = m1[qb];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int lo1 = min(m1[qb], acc[reg]);
+                        m2[qb] = med3_after(m1[qb], m2[qb], acc[reg], lo1);
+                        m1[qb] = lo1;
+                    }
+                    t1[qb] = m1[qb] < before ? tile_id : t1[qb];
+                }
+            }
+        }
+        if constexpr (!(VARIANT & 4)) {
+            if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    if (nchunks == ne_ch) {                // no odd chunks at all: the running class is the even one
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) {
+            e1[qb] = m1[qb]; e2[qb] = m2[qb]; et[qb] = t1[qb];
+            m1[qb] = m2[qb] = BIG;
+        }
+    }
+
+    // ---- merge lane halves per class, then the two classes; store
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        auto merge_halves = [&](int &a1, int &a2, int &ta) {
+            const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32), tb = __shfl_xor(ta, 32);
+            const int n1 = min(a1, b1);
+            const int n2 = min(max(a1, b1), min(a2, b2));
+            const int nt = a1 < b1 ? ta : (b1 < a1 ? tb : min(ta, tb));
+            a1 = n1; a2 = n2; ta = nt;
+        };
+        merge_halves(e1[qb], e2[qb], et[qb]);
+        merge_halves(m1[qb], m2[qb], t1[qb]);          // odd class
+        const int row = q0 + qb * 32 + c;
+        if (g == 0 && row < nq) {
+            const int na = A.norm_q[qoff + row];
+            // d2 = norm_q + 2*val + parity; BIG stays far above every real distance
+            const int de1 = na + 2 * e1[qb], de2 = na + 2 * e2[qb];
+            const int do1 = na + 2 * m1[qb] + 1, do2 = na + 2 * m2[qb] + 1;
+            int best, second, tile;
+            if (de1 < do1) { best = de1; tile = et[qb]; second = min(de2, do1); }
+            else           { best = do1; tile = t1[qb]; second = min(do2, de1); }
+            v2i od = {best, second};
+            *reinterpret_cast<v2i *>(A.out_d2 + 2 * (obase + row)) = od;
+            A.out_tile[obase + row] = tile;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// train index of the survivors: one workgroup per ordered pair, 32 lanes per survivor
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resolve_kernel(const int8_t *__restrict__ desc_q,
+                                                      const int32_t *__restrict__ norm_q,
+                                                      const int32_t *__restrict__ qimg_off,
+                                                      const int8_t *__restrict__ desc_t,
+                                                      const int32_t *__restrict__ norm2_t,
+                                                      const int32_t *__restrict__ perm,
+                                                      const int32_t *__restrict__ timg_off,
+                                                      const int32_t *__restrict__ pairs,
+                                                      const int64_t *__restrict__ out_off,
+                                                      const int32_t *__restrict__ d2,
+                                                      const int64_t *__restrict__ surv_off,
+                                                      const int32_t *__restrict__ surv_q,
+                                                      int32_t *__restrict__ surv_t /* in: tile, out: train row */,
+                                                      int32_t *__restrict__ n_unresolved)
+{
+    const int p = blockIdx.x;
+    const int qoff = qimg_off[pairs[2 * p]], toff = timg_off[pairs[2 * p + 1]];
+    const int64_t b = surv_off[p], e = surv_off[p + 1], ob = out_off[p];
+    const int grp = threadIdx.x >> 5, j = threadIdx.x & 31;
+    for (int64_t s = b + grp; s < e; s += 8) {
+        const int q = surv_q[s], tile = surv_t[s];
+        const int best = d2[2 * (ob + q)];
+        const int trow = toff + tile * 32 + j;
+        const int *qa = reinterpret_cast<const int *>(desc_q + (int64_t)(qoff + q) * D);
+        const int *ta = reinterpret_cast<const int *>(desc_t + (int64_t)trow * D);
+        int dot = 0;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) dot = __builtin_amdgcn_sdot4(qa[k], ta[k], dot, false);
+        const int dd = norm_q[qoff + q] + norm2_t[trow] - 2 * dot;
+        const int orig = perm[trow];
+        const unsigned long long m = __ballot(orig >= 0 && dd == best);
+        const unsigned half = (unsigned)(m >> (32 * ((threadIdx.x >> 5) & 1)));
+        if (j == 0) {
+            if (half) {
+                surv_t[s] = perm[toff + tile * 32 + (__ffs(half) - 1)];
+            } else {
+                surv_t[s] = -1;
+                atomicAdd(n_unresolved, 1);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" int64_t iamx_desc2_rows_cap(int64_t n_rows)
+{
+    if (n_rows < 0) return 0;
+    return (n_rows + CHUNK - 1) / CHUNK * CHUNK + CHUNK;
+}
+
+template <typename SRC>
+static int pack2_impl(const SRC *src, int64_t n_rows, int8_t *dst, int32_t *norm2, int32_t *cinit,
+                      int32_t *perm, int32_t *meta, void *stream, const char *what)
+{
+    if (n_rows < 0 || n_rows > (1 << 24) || (n_rows > 0 && !src) || !dst || !norm2 || !cinit ||
+        !perm || !meta)
+        return iamx::fail(IAMX_EINVAL, "%s: null pointer or bad row count", what);
+    hipLaunchKernelGGL(pack2_kernel<SRC>, dim3(1), dim3(1024), 0, iamx::as_stream(stream), src,
+                       (int)n_rows, (int)iamx_desc2_rows_cap(n_rows), dst, norm2, cinit, perm, meta);
+    return iamx::check_launch(what);
+}
+
+extern "C" int iamx_desc2_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
+                                  int32_t *cinit, int32_t *perm, int32_t *meta, void *stream)
+{
+    return pack2_impl(src, n_rows, dst, norm2, cinit, perm, meta, stream, "iamx_desc2_pack_u8");
+}
+
+extern "C" int iamx_desc2_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
+                                   int32_t *cinit, int32_t *perm, int32_t *meta, void *stream)
+{
+    return pack2_impl(src, n_rows, dst, norm2, cinit, perm, meta, stream, "iamx_desc2_pack_f32");
+}
+
+extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,
+                                 const int32_t *qimg_off, const int32_t *qimg_n,
+                                 const int8_t *desc_t, const int32_t *cinit,
+                                 const int32_t *timg_off, const int32_t *tmeta,
+                                 const int32_t *pairs, const int32_t *wg_off,
+                                 const int64_t *out_off, int n_pairs, int total_wg,
+                                 int32_t *out_d2, int32_t *out_tile, void *stream)
+{
+    IAMX_REQUIRE(desc_q && norm_q && qimg_off && qimg_n && desc_t && cinit && timg_off && tmeta &&
+                     pairs && wg_off && out_off && out_d2 && out_tile,
+                 "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && total_wg >= 0, "negative count");
+    if (n_pairs == 0 || total_wg == 0) return IAMX_OK;
+    Args2 a{desc_q, norm_q, qimg_off, qimg_n, desc_t, cinit, timg_off, tmeta, pairs, wg_off,
+            out_off, out_d2, out_tile, n_pairs, total_wg};
+    hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2>), dim3((unsigned)total_wg), dim3(WAVES * 64), 0,
+                       iamx::as_stream(stream), a);
+    return iamx::check_launch("iamx_knn2v2_pairs");
+}
+
+extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const int32_t *norm_q,
+                                      const int32_t *qimg_off, const int32_t *qimg_n,
+                                      const int8_t *desc_t, const int32_t *cinit,
+                                      const int32_t *timg_off, const int32_t *tmeta,
+                                      const int32_t *pairs, const int32_t *wg_off,
+                                      const int64_t *out_off, int n_pairs, int total_wg,
+                                      int32_t *out_d2, int32_t *out_tile, void *stream)
+{
+    Args2 a{desc_q, norm_q, qimg_off, qimg_n, desc_t, cinit, timg_off, tmeta, pairs, wg_off,
+            out_off, out_d2, out_tile, n_pairs, total_wg};
+    dim3 g((unsigned)total_wg), b(WAVES * 64);
+    hipStream_t st = iamx::as_stream(stream);
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 2>), g, b, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((knn2v2_kernel<1, 2, 2>), g, b, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((knn2v2_kernel<2, 2, 2>), g, b, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((knn2v2_kernel<4, 2, 2>), g, b, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((knn2v2_kernel<5, 2, 2>), g, b, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((knn2v2_kernel<6, 2, 2>), g, b, 0, st, a); break;
+    case 13: hipLaunchKernelGGL((knn2v2_kernel<13, 2, 2>), g, b, 0, st, a); break;
+    case 12: hipLaunchKernelGGL((knn2v2_kernel<12, 2, 2>), g, b, 0, st, a); break;
+    case 9: hipLaunchKernelGGL((knn2v2_kernel<9, 2, 2>), g, b, 0, st, a); break;
+    case 30: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2>), g, b, 0, st, a); break;
+    case 31: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2>), g, b, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 1>), g, b, 0, st, a); break;
+    case 33: hipLaunchKernelGGL((knn2v2_kernel<0, 1, 4>), g, b, 0, st, a); break;
+    case 34: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 3>), g, b, 0, st, a); break;
+    case 35: hipLaunchKernelGGL((knn2v2_kernel<1, 4, 2>), g, b, 0, st, a); break;
+    default: return iamx::fail(IAMX_EINVAL, "unknown variant");
+    }
+    return iamx::check_launch("iamxdbg_knn2v2_variant");
+}
+
+extern "C" int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q,
+                                   const int32_t *qimg_off, const int8_t *desc_t,
+                                   const int32_t *norm2_t, const int32_t *perm,
+                                   const int32_t *timg_off, const int32_t *pairs,
+                                   const int64_t *out_off, const int32_t *d2,
+                                   const int64_t *surv_off, const int32_t *surv_q, int32_t *surv_t,
+                                   int n_pairs, int32_t *n_unresolved, void *stream)
+{
+    IAMX_REQUIRE(desc_q && norm_q && qimg_off && desc_t && norm2_t && perm && timg_off && pairs &&
+                     out_off && d2 && surv_off && surv_q && surv_t && n_unresolved,
+                 "null pointer");
+    if (n_pairs <= 0) return IAMX_OK;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)n_pairs), dim3(256), 0,
+                       iamx::as_stream(stream), desc_q, norm_q, qimg_off, desc_t, norm2_t, perm,
+                       timg_off, pairs, out_off, d2, surv_off, surv_q, surv_t, n_unresolved);
+    return iamx::check_launch("iamx_knn2v2_resolve");
+}

@@ -46,6 +46,20 @@ class DescriptorStore(object):
         self.img_off = torch.from_numpy(offs[:-1].astype(np.int32)).to(dev)
         self.img_n = torch.tensor(self.counts, dtype=I32, device=dev) if self.counts else \
             torch.zeros(0, dtype=I32, device=dev)
+        # train-side layout of the fast kernel (parity partitioned, include/iamx.h "desc2")
+        caps = [int(L.iamx_desc2_rows_cap(c)) for c in self.counts]
+        offs2 = np.zeros(len(caps) + 1, np.int64)
+        np.cumsum(caps, out=offs2[1:])
+        if offs2[-1] >= 2 ** 31:
+            raise ValueError("descriptor store limited to 2^31 rows")
+        self.offsets2 = offs2
+        total2 = max(int(offs2[-1]), 1)
+        self.desc2 = torch.empty((total2, 128), dtype=I8, device=dev)
+        self.norm2 = torch.empty(total2, dtype=I32, device=dev)
+        self.cinit = torch.empty(total2, dtype=I32, device=dev)
+        self.perm = torch.empty(total2, dtype=I32, device=dev)
+        self.meta = torch.zeros((max(len(caps), 1), 4), dtype=I32, device=dev)
+        self.img_off2 = torch.from_numpy(offs2[:-1].astype(np.int32)).to(dev)
 
     def __len__(self):
         return len(self.counts)
@@ -67,6 +81,10 @@ class DescriptorStore(object):
         fn = lib().iamx_desc_pack_u8 if is_u8 else lib().iamx_desc_pack_f32
         check(fn(_ptr(src), n, _ptr(self.desc[o:]), _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]),
                  stream_ptr()), 'iamx_desc_pack')
+        o2 = int(self.offsets2[i])
+        fn2 = lib().iamx_desc2_pack_u8 if is_u8 else lib().iamx_desc2_pack_f32
+        check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
+                  _ptr(self.perm[o2:]), _ptr(self.meta[i]), stream_ptr()), 'iamx_desc2_pack')
         # the source buffer must outlive the enqueued kernel
         torch.cuda.current_stream().synchronize()
 
@@ -168,7 +186,7 @@ def match_compact(idx, metric, keep, seg_off, surv_off, total):
     sq = torch.empty(max(total, 1), dtype=I32, device=dev)
     stt = torch.empty(max(total, 1), dtype=I32, device=dev)
     sm = torch.empty(max(total, 1), dtype=F64, device=dev)
-    check(lib().iamx_match_compact(_ptr(idx), _ptr(metric), _ptr(keep), _ptr(seg), _ptr(surv_off),
+    check(lib().iamx_match_compact(_ptr(idx), 2, _ptr(metric), _ptr(keep), _ptr(seg), _ptr(surv_off),
                                    n_seg, _ptr(sq), _ptr(stt), _ptr(sm), stream_ptr()),
           'iamx_match_compact')
     return sq[:total], stt[:total], sm[:total]
@@ -222,6 +240,8 @@ class PairWorkspace(object):
         self.surv_t = torch.empty(r, dtype=I32, device=dev)
         self.surv_metric = torch.empty(r, dtype=F64, device=dev)
         self.zero_div = torch.zeros(1, dtype=I32, device=dev)
+        self.tile = torch.empty(r, dtype=I32, device=dev)
+        self.unresolved = torch.zeros(1, dtype=I32, device=dev)
 
 
 class PairBatch(object):
@@ -265,18 +285,51 @@ class PairBatch(object):
                                   _ptr(ws.zero_div), s), 'iamx_match_metric')
         check(L.iamx_exclusive_scan_i32(_ptr(ws.seg_count), self.n_pairs, _ptr(ws.surv_off), s),
               'iamx_exclusive_scan_i32')
-        check(L.iamx_match_compact(_ptr(ws.idx), _ptr(ws.metric), _ptr(ws.keep), _ptr(self.d_out),
-                                   _ptr(ws.surv_off), self.n_pairs, _ptr(ws.surv_q),
-                                   _ptr(ws.surv_t), _ptr(ws.surv_metric), s),
+        check(L.iamx_match_compact(_ptr(ws.idx), 2, _ptr(ws.metric), _ptr(ws.keep),
+                                   _ptr(self.d_out), _ptr(ws.surv_off), self.n_pairs,
+                                   _ptr(ws.surv_q), _ptr(ws.surv_t), _ptr(ws.surv_metric), s),
               'iamx_match_compact')
 
-    def run(self, ws, thresh):
+    # ---- fast form: distances + tile in the sweep, train index only for the survivors
+    def run_knn2_fast(self, ws):
+        st = self.store
+        check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
+                                      _ptr(st.img_n), _ptr(st.desc2), _ptr(st.cinit),
+                                      _ptr(st.img_off2), _ptr(st.meta), _ptr(self.d_pairs),
+                                      _ptr(self.d_wg), _ptr(self.d_out), self.n_pairs,
+                                      self.total_wg, _ptr(ws.d2), _ptr(ws.tile), stream_ptr()),
+              'iamx_knn2v2_pairs')
+
+    def run_filter_fast(self, ws, thresh):
+        L, s, st = lib(), stream_ptr(), self.store
+        check(L.iamx_match_metric(_ptr(ws.d2), _ptr(self.d_out), self.n_pairs, float(thresh),
+                                  _ptr(ws.metric), _ptr(ws.keep), _ptr(ws.seg_count),
+                                  _ptr(ws.zero_div), s), 'iamx_match_metric')
+        check(L.iamx_exclusive_scan_i32(_ptr(ws.seg_count), self.n_pairs, _ptr(ws.surv_off), s),
+              'iamx_exclusive_scan_i32')
+        check(L.iamx_match_compact(_ptr(ws.tile), 1, _ptr(ws.metric), _ptr(ws.keep),
+                                   _ptr(self.d_out), _ptr(ws.surv_off), self.n_pairs,
+                                   _ptr(ws.surv_q), _ptr(ws.surv_t), _ptr(ws.surv_metric), s),
+              'iamx_match_compact')
+        check(L.iamx_knn2v2_resolve(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
+                                    _ptr(st.desc2), _ptr(st.norm2), _ptr(st.perm),
+                                    _ptr(st.img_off2), _ptr(self.d_pairs), _ptr(self.d_out),
+                                    _ptr(ws.d2), _ptr(ws.surv_off), _ptr(ws.surv_q),
+                                    _ptr(ws.surv_t), self.n_pairs, _ptr(ws.unresolved), s),
+              'iamx_knn2v2_resolve')
+
+    def run(self, ws, thresh, fast=True):
+        """enqueue top-2 + metric threshold + survivor compaction (+ index resolve)."""
         if self.rows > ws.max_rows or self.n_pairs > ws.max_pairs:
             raise ValueError("workspace too small for this batch")
         if self.n_pairs == 0 or self.rows == 0:
             return
-        self.run_knn2(ws)
-        self.run_filter(ws, thresh)
+        if fast:
+            self.run_knn2_fast(ws)
+            self.run_filter_fast(ws, thresh)
+        else:
+            self.run_knn2(ws)
+            self.run_filter(ws, thresh)
 
 
 # --------------------------------------------------------------------------------------

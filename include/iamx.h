@@ -107,9 +107,44 @@ int iamx_match_metric(const int32_t *d2, const int64_t *seg_off, int n_seg, doub
  *                                   iamx_exclusive_scan_i32)
  *   surv_q/surv_t  DEV [sum seg_count] int32   query row / train row
  *   surv_metric    DEV [sum seg_count] float64 */
-int iamx_match_compact(const int32_t *idx, const double *metric, const uint8_t *keep,
-                       const int64_t *seg_off, const int64_t *surv_off, int n_seg,
-                       int32_t *surv_q, int32_t *surv_t, double *surv_metric, void *stream);
+int iamx_match_compact(const int32_t *idx, int idx_stride, const double *metric,
+                       const uint8_t *keep, const int64_t *seg_off, const int64_t *surv_off,
+                       int n_seg, int32_t *surv_q, int32_t *surv_t, double *surv_metric,
+                       void *stream);
+/* (surv_t[k] = idx[idx_stride * row]: stride 2 reads the best index of iamx_knn2_l2_*, stride 1
+ *  the tile ids of iamx_knn2v2_pairs, which iamx_knn2v2_resolve then turns into train rows) */
+
+/* ------------------------------------------------------------------------------------
+ * K2, fast form: exact top-2 DISTANCES with 2 VALU ops per distance; the train index is
+ * recovered afterwards, only for the rows that survive the metric threshold.  Same results
+ * as iamx_knn2_l2_pairs + iamx_match_metric + iamx_match_compact (tests pin that).
+ *
+ * Train-side store ("desc2"): rows of an image stably partitioned by the parity of
+ * NB = |a-128|^2 + 2*sum(a-128), each class zero-padded to 128 rows:
+ *   rows_cap = iamx_desc2_rows_cap(n)   rows to reserve per image
+ *   dst DEV [rows_cap][128] int8, norm2/cinit/perm DEV [rows_cap] int32 (perm = original row,
+ *   -1 on padding), meta DEV [4] int32 = {n, even chunks, odd chunks, n_even}
+ * Query side = the ordinary store of iamx_desc_pack_*.
+ *   out_d2   DEV [sum n_q][2]  squared distances (best, second)
+ *   out_tile DEV [sum n_q]     32-row tile of the packed train image holding the best row
+ * iamx_knn2v2_resolve: surv_t holds tile ids on entry and train rows (original numbering,
+ * lowest row among equal distances) on exit; n_unresolved counts internal inconsistencies (0).
+ * ------------------------------------------------------------------------------------ */
+int64_t iamx_desc2_rows_cap(int64_t n_rows);
+int iamx_desc2_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
+                       int32_t *cinit, int32_t *perm, int32_t *meta, void *stream);
+int iamx_desc2_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
+                        int32_t *cinit, int32_t *perm, int32_t *meta, void *stream);
+int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
+                      const int32_t *qimg_n, const int8_t *desc_t, const int32_t *cinit,
+                      const int32_t *timg_off, const int32_t *tmeta, const int32_t *pairs,
+                      const int32_t *wg_off, const int64_t *out_off, int n_pairs, int total_wg,
+                      int32_t *out_d2, int32_t *out_tile, void *stream);
+int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
+                        const int8_t *desc_t, const int32_t *norm2_t, const int32_t *perm,
+                        const int32_t *timg_off, const int32_t *pairs, const int64_t *out_off,
+                        const int32_t *d2, const int64_t *surv_off, const int32_t *surv_q,
+                        int32_t *surv_t, int n_pairs, int32_t *n_unresolved, void *stream);
 
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);

@@ -213,3 +213,87 @@ def test_config2_shape_properties():
     i2, dd2 = kernels.knn2(imgs[0][p2], imgs[2])
     assert np.array_equal(i2.cpu().numpy(), idx[off[3]:off[4]][p2])
     assert np.array_equal(dd2.cpu().numpy(), d2[off[3]:off[4]][p2])
+
+
+def _run_batch(store, pairs, thresh, fast):
+    import torch
+    from imageanalysis_amd import kernels
+    pb = kernels.PairBatch(store, np.asarray(pairs, np.int32))
+    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb.run(ws, thresh, fast=fast)
+    torch.cuda.synchronize()
+    soff = ws.surv_off[:pb.n_pairs + 1].cpu().numpy()
+    tot = int(soff[-1])
+    return dict(d2=ws.d2[:pb.rows].cpu().numpy(), soff=soff, sq=ws.surv_q[:tot].cpu().numpy(),
+                st=ws.surv_t[:tot].cpu().numpy(), sm=ws.surv_metric[:tot].cpu().numpy(),
+                unresolved=int(ws.unresolved.item()), off=pb.out_off)
+
+
+def test_desc2_store_layout():
+    """parity-partitioned train store: stable partition, padding, C-operand terms"""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(4)
+    for n in (2, 127, 128, 129, 1000, 4096):
+        a = _sift_like(rng, n)
+        st = kernels.DescriptorStore.from_arrays([a])
+        meta = st.meta.cpu().numpy()[0]
+        s = a.astype(np.int64) - 128
+        nb = (s * s).sum(1) + 2 * s.sum(1)
+        even = np.nonzero(nb % 2 == 0)[0]
+        odd = np.nonzero(nb % 2 != 0)[0]
+        ne_pad, no_pad = -(-len(even) // 128) * 128, -(-len(odd) // 128) * 128
+        assert meta.tolist() == [n, ne_pad // 128, no_pad // 128, len(even)]
+        perm = st.perm.cpu().numpy()[:ne_pad + no_pad]
+        assert np.array_equal(perm[:len(even)], even) and (perm[len(even):ne_pad] == -1).all()
+        assert np.array_equal(perm[ne_pad:ne_pad + len(odd)], odd)
+        assert (perm[ne_pad + len(odd):] == -1).all()
+        rows = st.desc2.cpu().numpy()[:ne_pad + no_pad].astype(np.int64)
+        ok = perm >= 0
+        assert np.array_equal(rows[ok], s[perm[ok]]) and (rows[~ok] == 0).all()
+        cin = st.cinit.cpu().numpy()[:ne_pad + no_pad]
+        assert np.array_equal(cin[ok], nb[perm[ok]] >> 1) and (cin[~ok] == 0x3F000000).all()
+        assert np.array_equal(st.norm2.cpu().numpy()[:ne_pad + no_pad][ok], (s * s).sum(1)[perm[ok]])
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_fast_path_equals_general_path_golden(path):
+    from imageanalysis_amd import kernels
+    g = np.load(path)
+    store = kernels.DescriptorStore.from_arrays([g['des1'], g['des2']])
+    thresh = 270.0 * float(g['match_ratio'])
+    a = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=True)
+    b = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=False)
+    assert a['unresolved'] == 0
+    for k in ('d2', 'soff', 'sq', 'st', 'sm'):
+        assert np.array_equal(a[k], b[k]), k
+    # and == the reference's pre-GMS list after the host's stable sort + clip
+    for p, tag in enumerate(['fwd', 'rev']):
+        lo, hi = a['soff'][p], a['soff'][p + 1]
+        order = np.argsort(a['sm'][lo:hi], kind='stable')[:2000]
+        got = np.stack([a['sq'][lo:hi][order], a['st'][lo:hi][order]], 1)
+        if len(g['pregms_%s' % tag]):
+            assert np.array_equal(got, g['pregms_%s' % tag])
+
+
+def test_fast_path_ragged_ties_and_tiny_classes():
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref
+    rng = np.random.default_rng(21)
+    sizes = [300, 2, 257, 1024, 129, 640, 3]
+    imgs = [_sift_like(rng, n) for n in sizes]
+    imgs[3][:200] = np.clip(imgs[0][:200].astype(int) + rng.integers(-5, 6, (200, 128)), 0, 255)
+    imgs[3][500:700] = imgs[3][:200]                 # exact duplicates: lowest row must win
+    imgs[5][:129] = imgs[4]                          # identical rows across images (distance 0)
+    imgs[1][:] = 128                                 # an image whose rows all share one parity
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    # a generous threshold keeps most rows so the index resolve is exercised everywhere
+    a = _run_batch(store, pairs, 1e9, fast=True)
+    assert a['unresolved'] == 0
+    for p, (i, j) in enumerate(pairs):
+        ridx, rd2 = cpu_ref.knn2_l2_u8(imgs[i], imgs[j])
+        assert np.array_equal(a['d2'][a['off'][p]:a['off'][p + 1]], rd2), (i, j)
+        lo, hi = a['soff'][p], a['soff'][p + 1]
+        keep = rd2[:, 1] > 0                         # d1 == 0 -> NaN metric, never kept
+        assert np.array_equal(a['sq'][lo:hi], np.nonzero(keep)[0]), (i, j)
+        assert np.array_equal(a['st'][lo:hi], ridx[keep, 0]), (i, j)

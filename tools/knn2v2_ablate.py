@@ -1,0 +1,38 @@
+"""Timing ablation of the fast knn2 kernel (GPU box only)"""
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, '.')
+from imageanalysis_amd import kernels
+from imageanalysis_amd.kernels import _ptr, lib, stream_ptr
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 4, 5, 6]
+n_img = 64
+rng = np.random.default_rng(0)
+imgs = rng.integers(0, 256, (n_img, 4096, 128), dtype=np.uint8)
+store = kernels.DescriptorStore.from_arrays(list(imgs))
+L = lib()
+pairs = np.array([(i, j) for j in range(n_img) for i in range(n_img) if i != j], np.int32)
+b = kernels.PairBatch(store, pairs)
+ws = kernels.PairWorkspace(b.rows, b.n_pairs)
+fn = L.iamxdbg_knn2v2_variant
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+st = store
+QB = {30: 384, 31: 512, 32: 512, 33: 128, 35: 512}
+ref = None
+for v in variants:
+    ts = []
+    qb = QB.get(v, 256)
+    wg = np.zeros(b.n_pairs + 1, np.int64); wg[1:] = np.cumsum(np.full(b.n_pairs, (4096 + qb - 1) // qb))
+    b.d_wg = torch.from_numpy(wg.astype(np.int32)).cuda(); b.total_wg = int(wg[-1])
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        kernels.check(fn(v, _ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off), _ptr(st.img_n), _ptr(st.desc2), _ptr(st.cinit),
+                         _ptr(st.img_off2), _ptr(st.meta), _ptr(b.d_pairs), _ptr(b.d_wg), _ptr(b.d_out), b.n_pairs, b.total_wg,
+                         _ptr(ws.d2), _ptr(ws.tile), stream_ptr()))
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    t = min(ts[1:])
+    if v == 0: ref = (ws.d2.clone(), ws.tile.clone())
+    elif v >= 30 and v != 35 and ref is not None:
+        assert torch.equal(ref[0], ws.d2) and torch.equal(ref[1], ws.tile), "variant %d differs" % v
+    print("v2 variant %d: %.3f ms for %d ordered pairs -> %.3f us/ordered pair" % (v, t, b.n_pairs, t * 1e3 / b.n_pairs))
