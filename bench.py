@@ -119,6 +119,8 @@ def main():
     store = kernels.DescriptorStore([KPTS] * n_img)
     rows_per = int(store.offsets[1] - store.offsets[0])
     rows_per2 = int(store.offsets2[1] - store.offsets2[0])
+    src_off = (torch.arange(mine + 1, dtype=torch.int64, device=dev) * KPTS)
+    pack_scratch = torch.empty(3 * mine * KPTS, dtype=torch.int32, device=dev)
 
     def pack_and_gather():
         """pack own images into the store, then RCCL all-gather (desc, norm_q, norm_t) in
@@ -128,12 +130,12 @@ def main():
         kernels.check(L.iamx_desc_pack_u8(_ptr(raw), mine * KPTS, _ptr(store.desc[o:]),
                                           _ptr(store.norm_q[o:]), _ptr(store.norm_t[o:]), sp),
                       'iamx_desc_pack_u8')
-        for k in range(mine):                  # train-side (parity partitioned) layout
-            o2 = int(store.offsets2[first + k])
-            kernels.check(L.iamx_desc2_pack_u8(_ptr(raw[k]), KPTS, _ptr(store.desc2[o2:]),
-                                               _ptr(store.norm2[o2:]), _ptr(store.cinit[o2:]),
-                                               _ptr(store.perm[o2:]), _ptr(store.meta[first + k]),
-                                               sp), 'iamx_desc2_pack_u8')
+        # train-side (parity partitioned) layout, all of this rank's images in one batch
+        kernels.check(L.iamx_desc2_pack_batch_u8(_ptr(raw), _ptr(src_off), _ptr(store.img_off2[first:]),
+                                                 mine, mine * KPTS, KPTS, _ptr(store.desc2),
+                                                 _ptr(store.norm2), _ptr(store.cinit),
+                                                 _ptr(store.perm), _ptr(store.meta[first]),
+                                                 _ptr(pack_scratch), sp), 'iamx_desc2_pack_batch_u8')
         if dist is not None:
             for buf, width in ((store.desc, rows_per * DIM), (store.norm_q, rows_per),
                                (store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),

@@ -46,47 +46,67 @@ __device__ __forceinline__ int med3_after(int a, int b, int c, int dep)
 // ---------------------------------------------------------------------------------
 // pack: one workgroup per image; stable partition of the rows by the parity of NB
 // ---------------------------------------------------------------------------------
+// Batched pack in three passes (all images of a batch per launch):
+//   A  per row (8 threads): s2 = sum s^2, NB = s2 + 2*sum s            -> scratch
+//   B  per image (one 1024-thread block): stable partition positions, meta, padding rows
+//   C  per row (8 threads): convert + scatter the row, norm2 / cinit / perm
+struct PackArgs {
+    const void *src;             // [rows][128] u8 or f32, images back to back
+    const int64_t *src_off;      // DEV [n_img+1] first source row of each image, or NULL:
+    int64_t single_n;            //   one image of single_n rows
+    const int32_t *dst_off;      // DEV [n_img] first packed row of each image (NULL: 0)
+    int8_t *dst;
+    int32_t *norm2, *cinit, *perm, *meta;
+    int32_t *nb, *s2, *pos;      // scratch, one int per source row each
+    int n_img;
+};
+
 template <typename SRC>
-__device__ __forceinline__ void row_sums(const SRC *p, int &s2, int &s1, unsigned w[32])
+__global__ __launch_bounds__(256) void pack2_rows_kernel(PackArgs P, int64_t total_rows)
 {
-    s2 = 0; s1 = 0;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int part = (int)(t & 7);
+    int s2 = 0, s1 = 0;
+    if (row < total_rows) {
+        const SRC *p = static_cast<const SRC *>(P.src) + row * D + part * 16;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) w[i] = 0;
-#pragma unroll 4
-    for (int i = 0; i < D; ++i) {
-        int v;
-        if constexpr (sizeof(SRC) == 1) {
-            v = (int)p[i];
-        } else {
-            v = (int)rintf((float)p[i]);
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        for (int i = 0; i < 16; ++i) {
+            int v;
+            if constexpr (sizeof(SRC) == 1) {
+                v = (int)p[i];
+            } else {
+                v = (int)rintf((float)p[i]);
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            }
+            const int s = v - 128;
+            s2 += s * s;
+            s1 += s;
         }
-        const int s = v - 128;
-        s2 += s * s;
-        s1 += s;
-        w[i >> 2] |= (unsigned)(s & 0xFF) << (8 * (i & 3));
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        s2 += __shfl_xor(s2, m, 8);
+        s1 += __shfl_xor(s1, m, 8);
+    }
+    if (row < total_rows && part == 0) {
+        P.s2[row] = s2;
+        P.nb[row] = s2 + 2 * s1;
     }
 }
 
-template <typename SRC>
-__global__ __launch_bounds__(1024) void pack2_kernel(const SRC *__restrict__ src, int n,
-                                                     int rows_cap, int8_t *__restrict__ dst,
-                                                     int32_t *__restrict__ norm2,
-                                                     int32_t *__restrict__ cinit,
-                                                     int32_t *__restrict__ perm,
-                                                     int32_t *__restrict__ meta)
+__global__ __launch_bounds__(1024) void pack2_partition_kernel(PackArgs P)
 {
     __shared__ int wcnt[16];
     __shared__ int s_run_even, s_run_odd, s_ne;
+    const int img = blockIdx.x;
+    const int64_t r0 = P.src_off ? P.src_off[img] : 0;
+    const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
+    const int d0 = P.dst_off ? P.dst_off[img] : 0;
+    const int rows_cap = (n + CHUNK - 1) / CHUNK * CHUNK + CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- pass A: count even-parity rows
     int cnt = 0;
-    for (int r = tid; r < n; r += 1024) {
-        int s2, s1;
-        unsigned w[32];
-        row_sums(src + (int64_t)r * D, s2, s1, w);
-        cnt += ((s2 + 2 * s1) & 1) == 0;
-    }
+    for (int r = tid; r < n; r += 1024) cnt += (P.nb[r0 + r] & 1) == 0;
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
     if (lane == 0) wcnt[wave] = cnt;
@@ -101,17 +121,11 @@ __global__ __launch_bounds__(1024) void pack2_kernel(const SRC *__restrict__ src
     __syncthreads();
     const int ne = s_ne, no = n - ne;
     const int ne_pad = (ne + CHUNK - 1) / CHUNK * CHUNK, no_pad = (no + CHUNK - 1) / CHUNK * CHUNK;
-    // ---- pass B: stable partition, 1024 rows per round
     for (int base = 0; base < n; base += 1024) {
         const int r = base + tid;
-        int s2 = 0, s1 = 0;
-        unsigned w[32];
-        bool valid = r < n, even = false;
-        if (valid) {
-            row_sums(src + (int64_t)r * D, s2, s1, w);
-            even = ((s2 + 2 * s1) & 1) == 0;
-        }
-        const unsigned long long mask = __ballot(valid && even);
+        const bool valid = r < n;
+        const bool even = valid && (P.nb[r0 + r] & 1) == 0;
+        const unsigned long long mask = __ballot(even);
         const int before_w = __popcll(mask & ((1ull << lane) - 1ull));
         __syncthreads();
         if (lane == 0) wcnt[wave] = __popcll(mask);
@@ -122,16 +136,7 @@ __global__ __launch_bounds__(1024) void pack2_kernel(const SRC *__restrict__ src
             total_even += wcnt[i];
         }
         const int run_e = s_run_even, run_o = s_run_odd;
-        if (valid) {
-            const int pos = even ? run_e + before : ne_pad + run_o + (tid - before);
-            uint4 *d4 = reinterpret_cast<uint4 *>(dst + (int64_t)pos * D);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) d4[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-            norm2[pos] = s2;
-            const int nb = s2 + 2 * s1;
-            cinit[pos] = nb >> 1;
-            perm[pos] = r;
-        }
+        if (valid) P.pos[r0 + r] = even ? run_e + before : ne_pad + run_o + (tid - before);
         __syncthreads();
         if (tid == 0) {
             const int rows = n - base < 1024 ? n - base : 1024;
@@ -140,23 +145,55 @@ __global__ __launch_bounds__(1024) void pack2_kernel(const SRC *__restrict__ src
         }
         __syncthreads();
     }
-    // ---- pads
     for (int p = tid; p < rows_cap; p += 1024) {
         const bool pad = (p >= ne && p < ne_pad) || p >= ne_pad + no;
         if (pad) {
-            uint4 *d4 = reinterpret_cast<uint4 *>(dst + (int64_t)p * D);
+            uint4 *d4 = reinterpret_cast<uint4 *>(P.dst + (int64_t)(d0 + p) * D);
 #pragma unroll
             for (int i = 0; i < 8; ++i) d4[i] = make_uint4(0, 0, 0, 0);
-            norm2[p] = 0;
-            cinit[p] = BIG;
-            perm[p] = -1;
+            P.norm2[d0 + p] = 0;
+            P.cinit[d0 + p] = BIG;
+            P.perm[d0 + p] = -1;
         }
     }
     if (tid == 0) {
-        meta[0] = n;
-        meta[1] = ne_pad / CHUNK;
-        meta[2] = no_pad / CHUNK;
-        meta[3] = ne;
+        P.meta[4 * img + 0] = n;
+        P.meta[4 * img + 1] = ne_pad / CHUNK;
+        P.meta[4 * img + 2] = no_pad / CHUNK;
+        P.meta[4 * img + 3] = ne;
+    }
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void pack2_scatter_kernel(PackArgs P)
+{
+    // grid = (blocks over the rows of an image, images)
+    const int img = blockIdx.y;
+    const int64_t r0 = P.src_off ? P.src_off[img] : 0;
+    const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
+    const int d0 = P.dst_off ? P.dst_off[img] : 0;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = t >> 3, part = t & 7;
+    if (r >= n) return;
+    const SRC *p = static_cast<const SRC *>(P.src) + (r0 + r) * D + part * 16;
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int v;
+        if constexpr (sizeof(SRC) == 1) {
+            v = (int)p[i];
+        } else {
+            v = (int)rintf((float)p[i]);
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        w[i >> 2] |= (unsigned)((v - 128) & 0xFF) << (8 * (i & 3));
+    }
+    const int pos = d0 + P.pos[r0 + r];
+    *reinterpret_cast<uint4 *>(P.dst + (int64_t)pos * D + part * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (part == 0) {
+        P.norm2[pos] = P.s2[r0 + r];
+        P.cinit[pos] = P.nb[r0 + r] >> 1;
+        P.perm[pos] = r;
     }
 }
 
@@ -403,27 +440,62 @@ extern "C" int64_t iamx_desc2_rows_cap(int64_t n_rows)
 }
 
 template <typename SRC>
-static int pack2_impl(const SRC *src, int64_t n_rows, int8_t *dst, int32_t *norm2, int32_t *cinit,
-                      int32_t *perm, int32_t *meta, void *stream, const char *what)
+static int pack2_launch(PackArgs P, int64_t total_rows, int max_rows, void *stream, const char *what)
 {
-    if (n_rows < 0 || n_rows > (1 << 24) || (n_rows > 0 && !src) || !dst || !norm2 || !cinit ||
-        !perm || !meta)
-        return iamx::fail(IAMX_EINVAL, "%s: null pointer or bad row count", what);
-    hipLaunchKernelGGL(pack2_kernel<SRC>, dim3(1), dim3(1024), 0, iamx::as_stream(stream), src,
-                       (int)n_rows, (int)iamx_desc2_rows_cap(n_rows), dst, norm2, cinit, perm, meta);
+    hipStream_t st = iamx::as_stream(stream);
+    if (total_rows > 0)
+        hipLaunchKernelGGL(pack2_rows_kernel<SRC>, dim3((unsigned)((total_rows * 8 + 255) / 256)),
+                           dim3(256), 0, st, P, total_rows);
+    hipLaunchKernelGGL(pack2_partition_kernel, dim3((unsigned)P.n_img), dim3(1024), 0, st, P);
+    if (max_rows > 0)
+        hipLaunchKernelGGL(pack2_scatter_kernel<SRC>,
+                           dim3((unsigned)(((int64_t)max_rows * 8 + 255) / 256), (unsigned)P.n_img),
+                           dim3(256), 0, st, P);
     return iamx::check_launch(what);
 }
 
-extern "C" int iamx_desc2_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
-                                  int32_t *cinit, int32_t *perm, int32_t *meta, void *stream)
+template <typename SRC>
+static int pack2_single(const SRC *src, int64_t n_rows, int8_t *dst, int32_t *norm2, int32_t *cinit,
+                        int32_t *perm, int32_t *meta, int32_t *scratch, void *stream,
+                        const char *what)
 {
-    return pack2_impl(src, n_rows, dst, norm2, cinit, perm, meta, stream, "iamx_desc2_pack_u8");
+    if (n_rows < 0 || n_rows > (1 << 24) || (n_rows > 0 && !src) || !dst || !norm2 || !cinit ||
+        !perm || !meta || !scratch)
+        return iamx::fail(IAMX_EINVAL, "%s: null pointer or bad row count", what);
+    PackArgs P{src, nullptr, n_rows, nullptr, dst, norm2, cinit, perm, meta,
+               scratch, scratch + n_rows, scratch + 2 * n_rows, 1};
+    return pack2_launch<SRC>(P, n_rows, (int)n_rows, stream, what);
+}
+
+extern "C" int iamx_desc2_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
+                                  int32_t *cinit, int32_t *perm, int32_t *meta, int32_t *scratch,
+                                  void *stream)
+{
+    return pack2_single(src, n_rows, dst, norm2, cinit, perm, meta, scratch, stream,
+                        "iamx_desc2_pack_u8");
 }
 
 extern "C" int iamx_desc2_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
-                                   int32_t *cinit, int32_t *perm, int32_t *meta, void *stream)
+                                   int32_t *cinit, int32_t *perm, int32_t *meta, int32_t *scratch,
+                                   void *stream)
 {
-    return pack2_impl(src, n_rows, dst, norm2, cinit, perm, meta, stream, "iamx_desc2_pack_f32");
+    return pack2_single(src, n_rows, dst, norm2, cinit, perm, meta, scratch, stream,
+                        "iamx_desc2_pack_f32");
+}
+
+extern "C" int iamx_desc2_pack_batch_u8(const uint8_t *src, const int64_t *src_off,
+                                        const int32_t *dst_off, int n_img, int64_t total_rows,
+                                        int max_rows_per_image, int8_t *dst, int32_t *norm2,
+                                        int32_t *cinit, int32_t *perm, int32_t *meta,
+                                        int32_t *scratch, void *stream)
+{
+    IAMX_REQUIRE(src && src_off && dst_off && dst && norm2 && cinit && perm && meta && scratch,
+                 "null pointer");
+    IAMX_REQUIRE(n_img > 0 && total_rows >= 0 && max_rows_per_image >= 0, "bad count");
+    PackArgs P{src, src_off, 0, dst_off, dst, norm2, cinit, perm, meta,
+               scratch, scratch + total_rows, scratch + 2 * total_rows, n_img};
+    return pack2_launch<uint8_t>(P, total_rows, max_rows_per_image, stream,
+                                 "iamx_desc2_pack_batch_u8");
 }
 
 extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,

@@ -83,8 +83,10 @@ class DescriptorStore(object):
                  stream_ptr()), 'iamx_desc_pack')
         o2 = int(self.offsets2[i])
         fn2 = lib().iamx_desc2_pack_u8 if is_u8 else lib().iamx_desc2_pack_f32
+        scratch = torch.empty(3 * n, dtype=I32, device=src.device)
         check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
-                  _ptr(self.perm[o2:]), _ptr(self.meta[i]), stream_ptr()), 'iamx_desc2_pack')
+                  _ptr(self.perm[o2:]), _ptr(self.meta[i]), _ptr(scratch), stream_ptr()),
+              'iamx_desc2_pack')
         # the source buffer must outlive the enqueued kernel
         torch.cuda.current_stream().synchronize()
 

@@ -131,10 +131,19 @@ int iamx_match_compact(const int32_t *idx, int idx_stride, const double *metric,
  * lowest row among equal distances) on exit; n_unresolved counts internal inconsistencies (0).
  * ------------------------------------------------------------------------------------ */
 int64_t iamx_desc2_rows_cap(int64_t n_rows);
+/* scratch: DEV [3 * n_rows] int32 (3 * total_rows for the batch form).  Batch form: images
+ * back to back in `src`, src_off DEV [n_img+1] int64 first source row, dst_off DEV [n_img]
+ * int32 first packed row (multiples of 128, >= rows_cap apart), meta DEV [n_img][4]. */
 int iamx_desc2_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
-                       int32_t *cinit, int32_t *perm, int32_t *meta, void *stream);
+                       int32_t *cinit, int32_t *perm, int32_t *meta, int32_t *scratch,
+                       void *stream);
 int iamx_desc2_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *norm2,
-                        int32_t *cinit, int32_t *perm, int32_t *meta, void *stream);
+                        int32_t *cinit, int32_t *perm, int32_t *meta, int32_t *scratch,
+                        void *stream);
+int iamx_desc2_pack_batch_u8(const uint8_t *src, const int64_t *src_off, const int32_t *dst_off,
+                             int n_img, int64_t total_rows, int max_rows_per_image, int8_t *dst,
+                             int32_t *norm2, int32_t *cinit, int32_t *perm, int32_t *meta,
+                             int32_t *scratch, void *stream);
 int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
                       const int32_t *qimg_n, const int8_t *desc_t, const int32_t *cinit,
                       const int32_t *timg_off, const int32_t *tmeta, const int32_t *pairs,
