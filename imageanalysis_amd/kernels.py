@@ -271,6 +271,12 @@ class PairBatch(object):
         self.d_pairs = torch.from_numpy(pairs).to(dev)
         self.d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
         self.d_out = torch.from_numpy(self.out_off.copy()).to(dev)     # also the metric seg_off
+        # fast kernel: 512 query rows per workgroup when the images are large enough
+        self.fast_rows = 512 if (P and nq.min() >= 2048) else 256
+        wgf = np.zeros(P + 1, np.int64)
+        np.cumsum((nq + self.fast_rows - 1) // self.fast_rows, out=wgf[1:])
+        self.total_wg_fast = int(wgf[-1])
+        self.d_wg_fast = torch.from_numpy(wgf.astype(np.int32)).to(dev)
 
     def run_knn2(self, ws):
         st = self.store
@@ -298,8 +304,9 @@ class PairBatch(object):
         check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
                                       _ptr(st.img_n), _ptr(st.desc2), _ptr(st.cinit),
                                       _ptr(st.img_off2), _ptr(st.meta), _ptr(self.d_pairs),
-                                      _ptr(self.d_wg), _ptr(self.d_out), self.n_pairs,
-                                      self.total_wg, _ptr(ws.d2), _ptr(ws.tile), stream_ptr()),
+                                      _ptr(self.d_wg_fast), _ptr(self.d_out), self.n_pairs,
+                                      self.total_wg_fast, self.fast_rows, _ptr(ws.d2),
+                                      _ptr(ws.tile), stream_ptr()),
               'iamx_knn2v2_pairs')
 
     def run_filter_fast(self, ws, thresh):

@@ -3,7 +3,7 @@ import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from imageanalysis_amd import kernels
 from imageanalysis_amd.kernels import _ptr, lib, stream_ptr
-variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 4, 5, 6]
+variants = [int(v) for v in sys.argv[1:]] or [0, 31, 40, 41, 42, 43]
 n_img = 64
 rng = np.random.default_rng(0)
 imgs = rng.integers(0, 256, (n_img, 4096, 128), dtype=np.uint8)
@@ -16,7 +16,7 @@ fn = L.iamxdbg_knn2v2_variant
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
 st = store
-QB = {30: 384, 31: 512, 32: 512, 33: 128, 35: 512}
+QB = {30: 384, 31: 512, 32: 512, 33: 128, 35: 512, 40: 512, 41: 1024, 42: 768, 43: 256}
 ref = None
 for v in variants:
     ts = []
