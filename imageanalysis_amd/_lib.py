@@ -42,6 +42,8 @@ SIGNATURES = {
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
+    'iamx_ba_residual_prepared': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'iamx_ba_residual_jac': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),
@@ -56,6 +58,11 @@ SIGNATURES = {
     'iamx_ba_jv': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_ba_jtv': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p]),
+    'iamx_ba_lsmr_state_size': (c_int, []),
+    'iamx_ba_lsmr_partials_size': (c_int64, [c_int, c_int]),
+    'iamx_ba_lsmr_prepare': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
+    'iamx_ba_lsmr_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 9
+                             + [c_int, c_void_p]),
     'iamx_vec_axpby': (c_int, [c_int64, c_double, c_void_p, c_double, c_void_p, c_void_p]),
     'iamx_vec_mul2': (c_int, [c_int64] + [c_void_p] * 6),
     'iamx_vec_dot': (c_int, [c_int64] + [c_void_p] * 5),

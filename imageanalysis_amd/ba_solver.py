@@ -34,6 +34,26 @@ def _ptr(t):
     return _lib.c_void_p(t.data_ptr()) if t is not None else _lib.c_void_p(0)
 
 
+class _Phase(object):
+    """wall-clock per solver phase (only when DeviceBA.profile is a dict; synchronises)."""
+
+    def __init__(self, prob, name):
+        self.prob, self.name = prob, name
+
+    def __enter__(self):
+        if self.prob.profile is not None:
+            import time
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.prob.profile is not None:
+            import time
+            torch.cuda.synchronize()
+            d = self.prob.profile
+            d[self.name] = d.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
 class DeviceBA(object):
     """The BA problem of an Optimizer after setup(), resident in HBM."""
 
@@ -75,19 +95,52 @@ class DeviceBA(object):
         self.Jc, self.Jp = z(self.O * 14), z(self.O * 6)
         self.Jk = z(self.O * 16) if with_calib else None
         self.scratch = z(2048)
+        self.cam_rt = z(self.C * 12)
         self.out1 = z(4)
         self.tmp_n, self.tmp_n2, self.tmp_m, self.tmp_m2 = z(self.n), z(self.n), z(self.m), z(self.m)
+        self.lsmr_ws = None
+        self._pin = None
+        self.profile = None
+        self.force_stepwise_lsmr = False
+
+    # ---- host <-> device staging -------------------------------------------------------
+    # Every n-/m-vector crosses PCIe through ONE page-locked buffer allocated up front.
+    # Pageable transfers make the runtime pin/unpin the numpy pages per call; the unmapping
+    # evicts the process's GPU queues and stalls whatever is in flight for 60-90 ms
+    # (measured: one such stall per LSMR solve, profiles/r1_ba_notes.txt).
+    def _stage(self, k):
+        if self._pin is None or self._pin.numel() < k:
+            self._pin = torch.empty(max(int(k), self.n, self.m, 64), dtype=F64).pin_memory()
+        return self._pin[:k]
+
+    def upload(self, a, out=None):
+        """host float64 array -> device vector (new tensor unless `out` is given)."""
+        a = np.asarray(a, np.float64).ravel()
+        st = self._stage(a.size)
+        st.numpy()[:] = a
+        if out is None:
+            out = torch.empty(max(a.size, 1), dtype=F64, device=self.dev)
+        out[:a.size].copy_(st, non_blocking=True)
+        torch.cuda.current_stream().synchronize()          # the staging buffer is reused
+        return out
+
+    def download(self, t, k):
+        """first k entries of a device vector -> new host float64 array."""
+        st = self._stage(k)
+        st.copy_(t[:k], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return st.numpy().copy()
 
     # ---- parameters ------------------------------------------------------------------
     def set_x(self, x):
         x = np.ascontiguousarray(x, np.float64)
-        self.x.copy_(torch.from_numpy(x))
+        self.upload(x, out=self.x)
         if self.with_calib:
             c = x[self.C * 7 + self.P * 3:]
             cal = np.array([c[0], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]])
         else:
             cal = self.fixed_calib
-        self.calib.copy_(torch.from_numpy(np.ascontiguousarray(cal, np.float64)))
+        self.upload(cal, out=self.calib)
 
     def _cams_pts(self):
         return self.x[:self.C * 7], self.x[self.C * 7:self.C * 7 + self.P * 3]
@@ -97,9 +150,11 @@ class DeviceBA(object):
         cams, pts = self._cams_pts()
         r = self.r if out is None else out
         if self.O:
-            check(lib().iamx_ba_residual(_ptr(cams), self.C, _ptr(pts), self.P, _ptr(self.cam_idx),
-                                         _ptr(self.pt_idx), _ptr(self.uv), self.O,
-                                         _ptr(self.calib), _ptr(r), stream_ptr()), 'iamx_ba_residual')
+            check(lib().iamx_ba_residual_prepared(_ptr(cams), self.C, _ptr(pts), self.P,
+                                                  _ptr(self.cam_idx), _ptr(self.pt_idx),
+                                                  _ptr(self.uv), self.O, _ptr(self.calib),
+                                                  _ptr(self.cam_rt), _ptr(r), stream_ptr()),
+                  'iamx_ba_residual_prepared')
         return r
 
     def residual_jac(self):
@@ -158,19 +213,19 @@ class DeviceBA(object):
     def grad(self):
         """J^T r -> host n-vector."""
         self.jtv(self.r, self.tmp_n)
-        return self.tmp_n[:self.n].cpu().numpy()
+        return self.download(self.tmp_n, self.n)
 
     def colnorm(self):
         """sqrt of the column sums of J.^2 -> host n-vector (scipy compute_jac_scale)."""
         self.jtv(self.r, self.tmp_n, square=True)
-        return np.sqrt(self.tmp_n[:self.n].cpu().numpy())
+        return np.sqrt(self.download(self.tmp_n, self.n))
 
     def gram(self, d_host, vectors):
         """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks."""
         k = len(vectors)
         ys = []
         for s in vectors:
-            vs = torch.from_numpy(np.ascontiguousarray(d_host * s)).to(self.dev)
+            vs = self.upload(d_host * s)
             y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
             self.jv(vs, y)
             ys.append(y)
@@ -252,7 +307,7 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
     normr = beta
     normar = alpha * beta
     if normar == 0 or normb == 0:
-        return x[:n].cpu().numpy(), istop, itn, normr, normar
+        return prob.download(x, n), istop, itn, normr, normar
 
     while itn < maxiter:
         itn += 1
@@ -321,7 +376,94 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
             istop = 1
         if istop > 0:
             break
-    return x[:n].cpu().numpy(), istop, itn, normr, normar
+    return prob.download(x, n), istop, itn, normr, normar
+
+
+# state block layout of iamx_ba_lsmr_iterate (csrc/ba_linalg.hip, enums S_* / R_*)
+_S = {k: i for i, k in enumerate(
+    'ALPHA BETA ZETABAR ALPHABAR RHO RHOBAR CBAR SBAR BETADD BETAD RHODOLD TAUTILDEOLD THETATILDE '
+    'ZETA D NORMA2 MAXRBAR MINRBAR ITN NORMR NORMAR NORMA CONDA'.split())}
+_R = {k: 2 * len(_S) + i for i, k in enumerate(
+    'ATOL BTOL CTOL MAXITER NORMB ISTOP ITN NORMR NORMAR NORMA CONDA NORMX'.split())}
+
+
+def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None,
+                      chunk=64):
+    """Same recurrence as lsmr_device with the scalars resident on the device: iterations are
+    enqueued `chunk` at a time by iamx_ba_lsmr_iterate (3 launches each) and the host only
+    reads the state block between chunks (single rank, no calibration columns)."""
+    n, m = prob.n, prob.m
+    dev = prob.dev
+    L = lib()
+    if maxiter is None:
+        maxiter = n
+    chunk = max(2, int(chunk) & ~1)
+    ws = prob.lsmr_ws
+    if ws is None:
+        z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
+        ws = prob.lsmr_ws = dict(u1=z(m), u2=z(n), vt=z(n), h=z(n), hbar=z(n), x=z(n),
+                                 Jc_s=z(prob.O * 14), Jp_s=z(prob.O * 6), Jp_p=z(prob.O * 6),
+                                 state=z(L.iamx_ba_lsmr_state_size()),
+                                 part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)))
+    u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
+    ph = _Phase(prob, 'lsmr:init')
+    ph.__enter__()
+    check(L.iamx_ba_lsmr_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx),
+                                 _ptr(prob.pt_idx), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
+                                 _ptr(d_dev), _ptr(ws['Jc_s']), _ptr(ws['Jp_s']),
+                                 _ptr(ws['Jp_p']), stream_ptr()), 'iamx_ba_lsmr_prepare')
+    u1[:m].copy_(prob.r[:m])
+    u2.zero_(); hbar.zero_(); x.zero_()
+    normb = np.sqrt(prob.dot(u1, u1, m, False))
+    beta = normb
+    alpha = 0.0
+    if beta > 0:
+        prob.jtv(u1, prob.tmp_n)
+        prob.mul2(n, d_dev, prob.tmp_n, vt)
+        prob.axpby(n, 0.0, vt, 1.0 / beta, vt)
+        alpha = np.sqrt(prob.dot(vt, vt, n, False))
+    if alpha > 0:
+        prob.axpby(n, 1.0 / alpha, vt, 0.0, h)
+    normar = alpha * beta
+    if normar == 0 or normb == 0:
+        return prob.download(x, n), 0, 0, beta, normar
+    st = np.zeros(L.iamx_ba_lsmr_state_size())
+    for k, val in dict(ALPHA=alpha, BETA=beta, ZETABAR=alpha * beta, ALPHABAR=alpha, RHO=1.0,
+                       RHOBAR=1.0, CBAR=1.0, SBAR=0.0, BETADD=beta, RHODOLD=1.0,
+                       NORMA2=alpha * alpha, MINRBAR=1e100, NORMR=beta, NORMAR=normar,
+                       NORMA=abs(alpha), CONDA=1.0).items():
+        st[_S[k]] = val
+    for k, val in dict(ATOL=atol, BTOL=btol, CTOL=1.0 / conlim if conlim > 0 else 0.0,
+                       MAXITER=float(maxiter), NORMB=normb).items():
+        st[_R[k]] = val
+    prob.upload(st, out=ws['state'])
+    ph.__exit__()
+    ph = _Phase(prob, 'lsmr:iterate')
+    ph.__enter__()
+    for _ in range(int(maxiter) // chunk + 3):
+        check(L.iamx_ba_lsmr_iterate(_ptr(ws['Jc_s']), _ptr(ws['Jp_s']), _ptr(ws['Jp_p']),
+                                     _ptr(prob.cam_idx), _ptr(prob.pt_idx), _ptr(prob.cam_ptr),
+                                     _ptr(prob.pt_ptr), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
+                                     _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h),
+                                     _ptr(hbar), _ptr(x), _ptr(ws['state']), _ptr(ws['part']),
+                                     chunk, stream_ptr()), 'iamx_ba_lsmr_iterate')
+        st = prob.download(ws['state'], st.size)
+        if st[_R['ISTOP']] != 0:
+            break
+    else:
+        raise _lib.IamxError('fused LSMR did not latch a stop condition')
+    ph.__exit__()
+    if st[_R['ISTOP']] == 8:
+        raise _lib.IamxError('fused LSMR broke down (NaN in the recurrence)')
+    return (prob.download(x, n), int(st[_R['ISTOP']]), int(st[_R['ITN']]), float(st[_R['NORMR']]),
+            float(st[_R['NORMAR']]))
+
+
+def lsmr(prob, d_dev, dreg_dev, **opts):
+    """fused host-free iterations when the problem allows it, else the stepwise form."""
+    if prob.world == 1 and not prob.with_calib and prob.O and not prob.force_stepwise_lsmr:
+        return lsmr_device_fused(prob, d_dev, dreg_dev, **opts)
+    return lsmr_device(prob, d_dev, dreg_dev, **opts)
 
 
 # --------------------------------------------------------------------------------------
@@ -388,10 +530,24 @@ def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     return ag, ag_h, -ag_value
 
 
-def trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
-               callback=None, lsmr_opts=None):
+def trf_device(prob, x0, lb, ub, **kw):
     """scipy/optimize/_lsq/trf.py trf_bounds with tr_solver='lsmr', x_scale='jac',
-    loss='linear', on a DeviceBA problem."""
+    loss='linear', on a DeviceBA problem.
+
+    The host-side O(n) vector algebra runs with the BLAS thread pool limited to one thread: a
+    multi-threaded np.dot/norm leaves ~100 OpenBLAS workers spinning for a while, and the
+    device queue then stalls 60-90 ms in the next LSMR solve (measured, tools/diag_stall2.py;
+    profiles/r1_ba_notes.txt).  The vectors are memory-bound; one thread loses nothing."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:                   # pragma: no cover
+        return _trf_device(prob, x0, lb, ub, **kw)
+    with threadpool_limits(limits=1, user_api='blas'):
+        return _trf_device(prob, x0, lb, ub, **kw)
+
+
+def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
+                callback=None, lsmr_opts=None):
     from scipy.optimize import OptimizeResult
     from scipy.optimize._lsq.common import (CL_scaling_vector, check_termination,
                                             find_active_constraints, make_strictly_feasible,
@@ -437,43 +593,48 @@ def trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None,
         if termination_status is not None or nfev == max_nfev:
             break
 
-        v[dv != 0] *= scale_inv[dv != 0]
-        d = v ** 0.5 * scale
-        diag_h = g * dv * scale
-        g_h = d * g
+        with _Phase(prob, 'scaling+reg'):
+            v[dv != 0] *= scale_inv[dv != 0]
+            d = v ** 0.5 * scale
+            diag_h = g * dv * scale
+            g_h = d * g
 
-        # regularisation term (trf.py: build_quadratic_1d along -g_h)
-        G = prob.gram(d, [g_h])
-        a = 0.5 * (G[0, 0] + np.dot(g_h * diag_h, g_h))
-        b = -np.dot(g_h, g_h)
-        to_tr = Delta / norm(g_h)
-        ag_value = minimize_quadratic_1d(a, b, 0, to_tr)[1]
-        reg_term = -ag_value / Delta ** 2
+            # regularisation term (trf.py: build_quadratic_1d along -g_h)
+            G = prob.gram(d, [g_h])
+            a = 0.5 * (G[0, 0] + np.dot(g_h * diag_h, g_h))
+            b = -np.dot(g_h, g_h)
+            to_tr = Delta / norm(g_h)
+            ag_value = minimize_quadratic_1d(a, b, 0, to_tr)[1]
+            reg_term = -ag_value / Delta ** 2
 
-        d_dev = torch.from_numpy(d).to(prob.dev)
-        dreg_dev = torch.from_numpy((diag_h + reg_term) ** 0.5).to(prob.dev)
-        gn_h, _istop, itn, _nr, _nar = lsmr_device(prob, d_dev, dreg_dev, **lsmr_opts)
-        lsmr_iters += itn
-        S = np.vstack((g_h, gn_h)).T
-        S, _ = qr(S, mode='economic')
-        GS = prob.gram(d, [S[:, 0].copy(), S[:, 1].copy()])
-        B_S = GS + np.dot(S.T * diag_h, S)
-        g_S = S.T.dot(g_h)
+        with _Phase(prob, 'lsmr'):
+            d_dev = prob.upload(d)
+            dreg_dev = prob.upload((diag_h + reg_term) ** 0.5)
+            gn_h, _istop, itn, _nr, _nar = lsmr(prob, d_dev, dreg_dev, **lsmr_opts)
+            lsmr_iters += itn
+        with _Phase(prob, 'subspace'):
+            S = np.vstack((g_h, gn_h)).T
+            S, _ = qr(S, mode='economic')
+            GS = prob.gram(d, [S[:, 0].copy(), S[:, 1].copy()])
+            B_S = GS + np.dot(S.T * diag_h, S)
+            g_S = S.T.dot(g_h)
 
         theta = max(0.995, 1 - g_norm)
         actual_reduction = -1
         while actual_reduction <= 0 and nfev < max_nfev:
-            p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
-            p_h = S.dot(p_S)
-            p = d * p_h
-            step, step_h, predicted_reduction = _select_step(prob, x, d, diag_h, g_h, p, p_h,
-                                                             Delta, lb, ub, theta)
-            x_new = make_strictly_feasible(x + step, lb, ub, rstep=0)
-            prob.set_x(x_new)
-            prob.residual(out=r_new)
-            nfev += 1
-            step_h_norm = norm(step_h)
-            cost_new = prob.cost_of_r(r_new)
+            with _Phase(prob, 'select_step'):
+                p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
+                p_h = S.dot(p_S)
+                p = d * p_h
+                step, step_h, predicted_reduction = _select_step(prob, x, d, diag_h, g_h, p, p_h,
+                                                                 Delta, lb, ub, theta)
+            with _Phase(prob, 'fun'):
+                x_new = make_strictly_feasible(x + step, lb, ub, rstep=0)
+                prob.set_x(x_new)
+                prob.residual(out=r_new)
+                nfev += 1
+                step_h_norm = norm(step_h)
+                cost_new = prob.cost_of_r(r_new)
             if not np.isfinite(cost_new):
                 Delta = 0.25 * step_h_norm
                 continue
@@ -488,15 +649,16 @@ def trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None,
             Delta = Delta_new
 
         if actual_reduction > 0:
-            x = x_new
-            cost = cost_new
-            prob.set_x(x)
-            prob.residual_jac()
-            njev += 1
-            g = prob.grad()
-            cn = prob.colnorm()
-            scale_inv = np.maximum(scale_inv, cn)        # compute_jac_scale(J, scale_inv_old)
-            scale = 1 / scale_inv
+            with _Phase(prob, 'jac+grad'):
+                x = x_new
+                cost = cost_new
+                prob.set_x(x)
+                prob.residual_jac()
+                njev += 1
+                g = prob.grad()
+                cn = prob.colnorm()
+                scale_inv = np.maximum(scale_inv, cn)    # compute_jac_scale(J, scale_inv_old)
+                scale = 1 / scale_inv
             if callback is not None:
                 callback(x, cost)
         else:
@@ -516,16 +678,16 @@ def trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None,
 
 def gather_residual(prob, n_obs_total):
     """full camera-major residual vector on the host (all ranks)."""
-    r = prob.r[:prob.m].cpu().numpy()
+    r = prob.download(prob.r, prob.m)
     if prob.world == 1:
         return r
     full = np.zeros(2 * n_obs_total)
     sel = prob.local_obs
     full[2 * sel] = r[0::2]
     full[2 * sel + 1] = r[1::2]
-    t = torch.from_numpy(full).to(prob.dev)
+    t = prob.upload(full)
     _dist.allreduce_sum_(t)
-    return t.cpu().numpy()
+    return prob.download(t, full.size)
 
 
 def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None):

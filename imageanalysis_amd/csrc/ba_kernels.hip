@@ -65,6 +65,58 @@ __device__ __forceinline__ void project_obs(const double *__restrict__ cam,
     P.x = px; P.y = py; P.r2 = r2; P.rad = rad; P.iz = iz;
 }
 
+// per camera: R (ned -> camera, row major) and the camera position; 12 doubles
+__global__ __launch_bounds__(256) void ba_cam_prep_kernel(const double *__restrict__ cams, int n_cams,
+                                                          double *__restrict__ rt)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cams) return;
+    const double *cam = cams + (int64_t)c * 7;
+    const double w = cam[3], x = cam[4], y = cam[5], z = cam[6];
+    const double n = w * w + x * x + y * y + z * z;
+    double *o = rt + (int64_t)c * 12;
+    // rows of M(q)^T / n = body-frame axes; camera (X,Y,Z) = body (y1, y2, y0)
+    if (n < QEPS) {
+        o[0] = 1; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 1; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = 1;
+    } else {
+        const double inv_n = 1.0 / n;
+        const double ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+        const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+        o[0] = (ww + xx - yy - zz) * inv_n; o[1] = 2.0 * (xy + wz) * inv_n; o[2] = 2.0 * (xz - wy) * inv_n;
+        o[3] = 2.0 * (xy - wz) * inv_n; o[4] = (ww - xx + yy - zz) * inv_n; o[5] = 2.0 * (yz + wx) * inv_n;
+        o[6] = 2.0 * (xz + wy) * inv_n; o[7] = 2.0 * (yz - wx) * inv_n; o[8] = (ww - xx - yy + zz) * inv_n;
+    }
+    o[9] = cam[0]; o[10] = cam[1]; o[11] = cam[2];
+}
+
+// residual from the prepared camera blocks: the per-observation work is 9 FMAs, one
+// reciprocal and the distortion polynomial; identical arithmetic to project_obs()
+__global__ __launch_bounds__(256) void ba_residual_rt_kernel(
+    const double *__restrict__ rt, const double *__restrict__ pts,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
+    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
+    double *__restrict__ r)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obs) return;
+    const double fx = calib[0], fy = calib[1], cu = calib[2], cv = calib[3];
+    const double k1 = calib[4], k2 = calib[5], p1 = calib[6], p2 = calib[7], k3 = calib[8];
+    const double *R = rt + (int64_t)cam_idx[o] * 12;
+    const double *X = pts + (int64_t)pt_idx[o] * 3;
+    const double2 obs = *reinterpret_cast<const double2 *>(uv + 2 * o);
+    const double a = X[0] - R[9], b = X[1] - R[10], c = X[2] - R[11];
+    const double y0 = (R[0] * a + R[1] * b + R[2] * c);
+    const double y1 = (R[3] * a + R[4] * b + R[5] * c);
+    const double y2 = (R[6] * a + R[7] * b + R[8] * c);
+    const double iz = 1.0 / y0;
+    const double px = y1 * iz, py = y2 * iz;
+    const double r2 = px * px + py * py;
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double xd = px * rad + 2.0 * p1 * px * py + p2 * (r2 + 2.0 * px * px);
+    const double yd = py * rad + p1 * (r2 + 2.0 * py * py) + 2.0 * p2 * px * py;
+    *reinterpret_cast<double2 *>(r + 2 * o) = make_double2(obs.x - (fx * xd + cu), obs.y - (fy * yd + cv));
+}
+
 __global__ __launch_bounds__(256) void ba_residual_kernel(
     const double *__restrict__ cams, int n_cams, const double *__restrict__ pts,
     const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
@@ -211,6 +263,23 @@ extern "C" int iamx_ba_residual(const double *cams, int n_cams, const double *pt
                        iamx::as_stream(stream), cams, n_cams, pts, cam_idx, pt_idx, uv, n_obs,
                        calib, r);
     return iamx::check_launch("iamx_ba_residual");
+}
+
+extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const double *pts,
+                                         int n_pts, const int32_t *cam_idx,
+                                         const int32_t *pt_idx, const double *uv, int64_t n_obs,
+                                         const double *calib, double *cam_scratch, double *r,
+                                         void *stream)
+{
+    IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && r && cam_scratch, "null pointer");
+    IAMX_REQUIRE(n_cams > 0 && n_pts > 0 && n_obs >= 0, "bad size");
+    if (n_obs == 0) return IAMX_OK;
+    hipStream_t st = iamx::as_stream(stream);
+    hipLaunchKernelGGL(ba_cam_prep_kernel, dim3((n_cams + 255) / 256), dim3(256), 0, st, cams,
+                       n_cams, cam_scratch);
+    hipLaunchKernelGGL(ba_residual_rt_kernel, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0,
+                       st, cam_scratch, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
+    return iamx::check_launch("iamx_ba_residual_prepared");
 }
 
 extern "C" int iamx_ba_residual_jac(const double *cams, int n_cams, const double *pts, int n_pts,

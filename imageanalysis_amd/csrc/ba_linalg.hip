@@ -317,3 +317,416 @@ extern "C" int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *
                        n, h, hbar, x, v, c_hbar, c_x, c_h);
     return iamx::check_launch("iamx_vec_lsmr_update");
 }
+
+// =====================================================================================
+// Fused, host-free LSMR iterations (scipy/sparse/linalg/_isolve/lsmr.py) on the operator
+//     A = [ J diag(d) ; diag(dreg) ],   b = [ r ; 0 ]
+//
+// * iamx_ba_lsmr_prepare folds the column scaling into J once per solve and lays the blocks
+//   out structure-of-arrays so that every load of the iteration kernels is coalesced:
+//       Jc_s [14][O] observation order,  Jp_s [6][O] observation order (forward product),
+//       Jp_p [6][O]  point-sorted order (adjoint product, one thread per point).
+// * The Golub-Kahan vectors are kept UNnormalised (ut = beta*u, vt = alpha*v), so one
+//   bidiagonalisation step is a forward and an adjoint kernel whose epilogues emit the
+//   squared-norm partials:
+//       ut' = (1/alpha) A vt - (alpha/beta) ut          beta'  = |ut'|
+//       vt' = (1/beta') A^T ut' - (beta'/alpha) vt      alpha' = |vt'|
+// * All scalars of the recurrence live in a double-buffered device state block.  Every
+//   workgroup re-derives the scalars it needs in its prologue from the partial sums of the
+//   previous kernel (same instruction sequence => bit-identical in all workgroups); workgroup 0
+//   writes the next state buffer, which nobody reads in the same kernel.  An iteration is
+//   three launches (forward, adjoint, update) and no host synchronisation; the stopping tests
+//   of iteration k run in the prologue of iteration k+1's forward kernel and latch R_ISTOP,
+//   which turns everything enqueued behind it into no-ops.
+// =====================================================================================
+namespace {
+
+// carried recurrences, double-buffered by iteration parity
+enum {
+    S_ALPHA, S_BETA, S_ZETABAR, S_ALPHABAR, S_RHO, S_RHOBAR, S_CBAR, S_SBAR, S_BETADD, S_BETAD,
+    S_RHODOLD, S_TAUTILDEOLD, S_THETATILDE, S_ZETA, S_D, S_NORMA2, S_MAXRBAR, S_MINRBAR, S_ITN,
+    S_NORMR, S_NORMAR, S_NORMA, S_CONDA, S_NBUF
+};
+// constants + latched results, after the two buffers
+enum {
+    R_ATOL = 2 * S_NBUF, R_BTOL, R_CTOL, R_MAXITER, R_NORMB, R_ISTOP, R_ITN, R_NORMR, R_NORMAR,
+    R_NORMA, R_CONDA, R_NORMX, R_COUNT
+};
+
+struct LsmrArgs {
+    const double *Jc_s, *Jp_s, *Jp_p;
+    const int32_t *cam_idx, *pt_idx, *cam_ptr, *pt_ptr, *pt_obs;
+    int64_t n_obs;
+    int n_cams, n_pts;
+    const double *dreg;
+    double *u1, *u2, *vt, *h, *hbar, *x;
+    double *S;                   // state block [R_COUNT]
+    double *partU, *partV, *partX;
+    int n_partV;
+};
+
+constexpr int LS_FWD_BLOCKS = 1024;   // fixed grids => fixed reduction trees
+constexpr int LS_UPD_BLOCKS = 1024;
+
+struct Givens { double c, s, r; };
+
+__device__ __forceinline__ double sign_of(double v) { return v > 0 ? 1.0 : (v < 0 ? -1.0 : 0.0); }
+
+// stable plane rotation (scipy/sparse/linalg/_isolve/lsqr.py:_sym_ortho)
+__device__ __forceinline__ Givens sym_ortho(double a, double b)
+{
+    Givens g;
+    if (b == 0) { g.c = sign_of(a); g.s = 0; g.r = fabs(a); return g; }
+    if (a == 0) { g.c = 0; g.s = sign_of(b); g.r = fabs(b); return g; }
+    if (fabs(b) > fabs(a)) {
+        const double tau = a / b;
+        g.s = sign_of(b) / sqrt(1 + tau * tau);
+        g.c = g.s * tau;
+        g.r = b / g.s;
+    } else {
+        const double tau = b / a;
+        g.c = sign_of(a) / sqrt(1 + tau * tau);
+        g.s = g.c * tau;
+        g.r = a / g.c;
+    }
+    return g;
+}
+
+__device__ __forceinline__ double sum_partials(const double *__restrict__ part, int n, double *sh)
+{
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    return block_sum_256(acc, sh);
+}
+
+// one thread per observation: scaled SoA copies in observation order
+__global__ __launch_bounds__(256) void lsmr_prepare_obs_kernel(
+    const double *__restrict__ Jc, const double *__restrict__ Jp,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx, int64_t n_obs,
+    int n_cams, const double *__restrict__ d, double *__restrict__ Jc_s, double *__restrict__ Jp_s)
+{
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= n_obs) return;
+    const double *dc = d + (int64_t)cam_idx[o] * 7;
+    const double *dp = d + (int64_t)n_cams * 7 + (int64_t)pt_idx[o] * 3;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        Jc_s[(int64_t)k * n_obs + o] = Jc[o * 14 + k] * dc[k];
+        Jc_s[(int64_t)(7 + k) * n_obs + o] = Jc[o * 14 + 7 + k] * dc[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Jp_s[(int64_t)k * n_obs + o] = Jp[o * 6 + k] * dp[k];
+        Jp_s[(int64_t)(3 + k) * n_obs + o] = Jp[o * 6 + 3 + k] * dp[k];
+    }
+}
+
+// one thread per point-sorted slot e: Jp_p[.][e] = scaled Jp of observation pt_obs[e]
+__global__ __launch_bounds__(256) void lsmr_prepare_pt_kernel(
+    const double *__restrict__ Jp, const int32_t *__restrict__ pt_idx,
+    const int32_t *__restrict__ pt_obs, int64_t n_obs, int n_cams, const double *__restrict__ d,
+    double *__restrict__ Jp_p)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_obs) return;
+    const int64_t o = pt_obs[e];
+    const double *dp = d + (int64_t)n_cams * 7 + (int64_t)pt_idx[o] * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Jp_p[(int64_t)k * n_obs + e] = Jp[o * 6 + k] * dp[k];
+        Jp_p[(int64_t)(3 + k) * n_obs + e] = Jp[o * 6 + 3 + k] * dp[k];
+    }
+}
+
+// ---- kernel A: stopping tests of the previous iteration, then ut' ------------------------
+__global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
+{
+    __shared__ double sh[4];
+    double *S = A.S;
+    if (S[R_ISTOP] != 0.0) return;
+    const double *in = S + parity * S_NBUF;
+    const double itn = in[S_ITN];
+    if (itn > 0.0) {             // lsmr.py: "Test for convergence" of iteration itn
+        const double normx = sqrt(sum_partials(A.partX, LS_UPD_BLOCKS, sh));
+        const double normb = S[R_NORMB], normA = in[S_NORMA], normr = in[S_NORMR];
+        const double normar = in[S_NORMAR], condA = in[S_CONDA];
+        const double test1 = normr / normb;
+        const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
+        const double test3 = 1.0 / condA;
+        const double t1 = test1 / (1 + normA * normx / normb);
+        const double rtol = S[R_BTOL] + S[R_ATOL] * normA * normx / normb;
+        double istop = 0;
+        if (itn >= S[R_MAXITER]) istop = 7;
+        if (1 + test3 <= 1) istop = 6;
+        if (1 + test2 <= 1) istop = 5;
+        if (1 + t1 <= 1) istop = 4;
+        if (test3 <= S[R_CTOL]) istop = 3;
+        if (test2 <= S[R_ATOL]) istop = 2;
+        if (test1 <= rtol) istop = 1;
+        if (!(test1 == test1) || !(normx == normx)) istop = 8;     // breakdown (NaN)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            S[R_ITN] = itn; S[R_NORMR] = normr; S[R_NORMAR] = normar; S[R_NORMA] = normA;
+            S[R_CONDA] = condA; S[R_NORMX] = normx;
+            if (istop != 0) S[R_ISTOP] = istop;
+        }
+        if (istop != 0) return;
+    }
+    const double ia = 1.0 / in[S_ALPHA], ab = in[S_ALPHA] / in[S_BETA];
+    const int64_t O = A.n_obs;
+    const double *xp = A.vt + (int64_t)A.n_cams * 7;
+    double acc = 0.0;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < O; o += (int64_t)LS_FWD_BLOCKS * 256) {
+        const double *vc = A.vt + (int64_t)A.cam_idx[o] * 7;
+        const double *vp = xp + (int64_t)A.pt_idx[o] * 3;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double v = vc[k];
+            a += A.Jc_s[(int64_t)k * O + o] * v;
+            b += A.Jc_s[(int64_t)(7 + k) * O + o] * v;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = vp[k];
+            a += A.Jp_s[(int64_t)k * O + o] * v;
+            b += A.Jp_s[(int64_t)(3 + k) * O + o] * v;
+        }
+        double2 u = *reinterpret_cast<double2 *>(A.u1 + 2 * o);
+        u.x = a * ia - ab * u.x;
+        u.y = b * ia - ab * u.y;
+        *reinterpret_cast<double2 *>(A.u1 + 2 * o) = u;
+        acc += u.x * u.x + u.y * u.y;
+    }
+    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_FWD_BLOCKS * 256) {
+        const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
+        A.u2[i] = v;
+        acc += v * v;
+    }
+    const double s = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) A.partU[blockIdx.x] = s;
+}
+
+// ---- kernel B: beta', then vt' ---------------------------------------------------------------
+// Point workgroups come first (they are the long ones): 256 consecutive points each, whose
+// point-sorted slots form one contiguous range.  The range is streamed in rounds of ADJ_CH
+// slots: every thread forms the 3 products of 4 slots with fully coalesced loads (only the
+// 16-byte ut gather is indirect) into LDS, then thread t adds up the slots of point t in
+// ascending order.  Camera workgroups: one per camera, coalesced over its observations.
+constexpr int ADJ_CH = 1024;
+
+__global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
+{
+    __shared__ double sh[4];
+    __shared__ double red[4][7];
+    __shared__ double prod[3][ADJ_CH];
+    if (A.S[R_ISTOP] != 0.0) return;
+    const double *in = A.S + parity * S_NBUF;
+    const double bn = sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
+    if (!(bn > 0)) {             // exact solution reached: v keeps its value (lsmr.py "if beta > 0")
+        if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
+        return;
+    }
+    const double ib = 1.0 / bn, ba = bn / in[S_ALPHA];
+    const int64_t O = A.n_obs;
+    const int n_pt_blocks = (A.n_pts + 255) / 256;
+    double sq = 0.0;
+    if ((int)blockIdx.x < n_pt_blocks) {
+        const int p0 = blockIdx.x * 256;
+        const int p1 = min(p0 + 256, A.n_pts);
+        const int p = p0 + threadIdx.x;
+        const int e0 = A.pt_ptr[p0], e1 = A.pt_ptr[p1];
+        const int my_lo = p < p1 ? A.pt_ptr[p] : e1, my_hi = p < p1 ? A.pt_ptr[p + 1] : e1;
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int base = e0; base < e1; base += ADJ_CH) {
+            const int cnt = min(ADJ_CH, e1 - base);
+#pragma unroll
+            for (int i = 0; i < ADJ_CH / 256; ++i) {
+                const int jx = threadIdx.x + 256 * i;
+                if (jx < cnt) {
+                    const int64_t e = base + jx;
+                    const double2 uu = *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)A.pt_obs[e]);
+                    prod[0][jx] = A.Jp_p[e] * uu.x + A.Jp_p[3 * O + e] * uu.y;
+                    prod[1][jx] = A.Jp_p[O + e] * uu.x + A.Jp_p[4 * O + e] * uu.y;
+                    prod[2][jx] = A.Jp_p[2 * O + e] * uu.x + A.Jp_p[5 * O + e] * uu.y;
+                }
+            }
+            __syncthreads();
+            const int lo = max(my_lo, base) - base, hi = min(my_hi, base + cnt) - base;
+            for (int jx = lo; jx < hi; ++jx) {
+                a0 += prod[0][jx];
+                a1 += prod[1][jx];
+                a2 += prod[2][jx];
+            }
+            __syncthreads();
+        }
+        if (p < p1) {
+            const double acc[3] = {a0, a1, a2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int64_t i = (int64_t)A.n_cams * 7 + (int64_t)p * 3 + k;
+                const double v = (acc[k] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
+                A.vt[i] = v;
+                sq += v * v;
+            }
+        }
+    } else {
+        const int c = (int)blockIdx.x - n_pt_blocks;
+        double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int o = A.cam_ptr[c] + threadIdx.x; o < A.cam_ptr[c + 1]; o += 256) {
+            const double2 uu = *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)o);
+#pragma unroll
+            for (int k = 0; k < 7; ++k)
+                acc[k] += A.Jc_s[(int64_t)k * O + o] * uu.x + A.Jc_s[(int64_t)(7 + k) * O + o] * uu.y;
+        }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 7) {
+            const int k = threadIdx.x;
+            const double t = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            const int64_t i = (int64_t)c * 7 + k;
+            const double v = (t + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
+            A.vt[i] = v;
+            sq = v * v;
+        }
+    }
+    const double s = block_sum_256(sq, sh);
+    if (threadIdx.x == 0) A.partV[blockIdx.x] = s;
+}
+
+// ---- kernel C: alpha', plane rotations (lsmr.py main loop), then h / hbar / x -------------
+__global__ __launch_bounds__(256) void lsmr_update3_kernel(LsmrArgs A, int parity)
+{
+    __shared__ double sh[4];
+    double *S = A.S;
+    if (S[R_ISTOP] != 0.0) return;
+    const double *in = S + parity * S_NBUF;
+    double *out = S + (1 - parity) * S_NBUF;
+    const double beta = sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
+    const double s2 = sum_partials(A.partV, A.n_partV, sh);
+    const double alpha = beta > 0 ? sqrt(s2) : in[S_ALPHA];
+
+    const Givens g1 = sym_ortho(in[S_ALPHABAR], 0.0);
+    const double chat = g1.c, shat = g1.s, alphahat = g1.r;
+    const double rhoold = in[S_RHO];
+    const Givens g2 = sym_ortho(alphahat, beta);
+    const double c = g2.c, s = g2.s, rho = g2.r;
+    const double thetanew = s * alpha;
+    const double alphabar = c * alpha;
+    const double rhobarold = in[S_RHOBAR], zetaold = in[S_ZETA];
+    const double thetabar = in[S_SBAR] * rho;
+    const double rhotemp = in[S_CBAR] * rho;
+    const Givens g3 = sym_ortho(in[S_CBAR] * rho, thetanew);
+    const double cbar = g3.c, sbar = g3.s, rhobar = g3.r;
+    const double zeta = cbar * in[S_ZETABAR];
+    const double zetabar = -sbar * in[S_ZETABAR];
+    const double chb = -(thetabar * rho / (rhoold * rhobarold));
+    const double cx = zeta / (rho * rhobar);
+    const double ch = -(thetanew / rho);
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // estimate of ||r||, ||A||, cond(A)
+        const double betaacute = chat * in[S_BETADD], betacheck = -shat * in[S_BETADD];
+        const double betahat = c * betaacute;
+        const double betadd = -s * betaacute;
+        const double thetatildeold = in[S_THETATILDE];
+        const Givens g4 = sym_ortho(in[S_RHODOLD], thetabar);
+        const double ct = g4.c, st = g4.s, rhotildeold = g4.r;
+        const double thetatilde = st * rhobar;
+        const double rhodold = ct * rhobar;
+        const double betad = -st * in[S_BETAD] + ct * betahat;
+        const double tautildeold = (zetaold - thetatildeold * in[S_TAUTILDEOLD]) / rhotildeold;
+        const double taud = (zeta - thetatilde * tautildeold) / rhodold;
+        const double dsum = in[S_D] + betacheck * betacheck;
+        const double itn = in[S_ITN] + 1.0;
+        double normA2 = in[S_NORMA2] + beta * beta;
+        out[S_NORMA] = sqrt(normA2);
+        normA2 += alpha * alpha;
+        const double maxrbar = fmax(in[S_MAXRBAR], rhobarold);
+        const double minrbar = itn > 1.0 ? fmin(in[S_MINRBAR], rhobarold) : in[S_MINRBAR];
+        out[S_ALPHA] = alpha; out[S_BETA] = beta; out[S_ZETABAR] = zetabar;
+        out[S_ALPHABAR] = alphabar; out[S_RHO] = rho; out[S_RHOBAR] = rhobar; out[S_CBAR] = cbar;
+        out[S_SBAR] = sbar; out[S_BETADD] = betadd; out[S_BETAD] = betad; out[S_RHODOLD] = rhodold;
+        out[S_TAUTILDEOLD] = tautildeold; out[S_THETATILDE] = thetatilde; out[S_ZETA] = zeta;
+        out[S_D] = dsum; out[S_NORMA2] = normA2; out[S_MAXRBAR] = maxrbar; out[S_MINRBAR] = minrbar;
+        out[S_ITN] = itn;
+        out[S_NORMR] = sqrt(dsum + (betad - taud) * (betad - taud) + betadd * betadd);
+        out[S_NORMAR] = fabs(zetabar);
+        out[S_CONDA] = fmax(maxrbar, rhotemp) / fmin(minrbar, rhotemp);
+    }
+
+    const double ia = alpha > 0 ? 1.0 / alpha : 0.0;
+    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_UPD_BLOCKS * 256) {
+        const double hb = A.h[i] + chb * A.hbar[i];
+        A.hbar[i] = hb;
+        const double xv = A.x[i] + cx * hb;
+        A.x[i] = xv;
+        A.h[i] = A.vt[i] * ia + ch * A.h[i];
+        acc += xv * xv;
+    }
+    const double t = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) A.partX[blockIdx.x] = t;
+}
+
+}  // namespace
+
+extern "C" int iamx_ba_lsmr_state_size(void) { return R_COUNT; }
+
+extern "C" int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts)
+{
+    return (int64_t)LS_FWD_BLOCKS + LS_UPD_BLOCKS + n_cams + (n_pts + 255) / 256;
+}
+
+extern "C" int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
+                                    const int32_t *pt_idx, const int32_t *pt_obs, int64_t n_obs,
+                                    int n_cams, int n_pts, const double *d, double *Jc_s,
+                                    double *Jp_s, double *Jp_p, void *stream)
+{
+    IAMX_REQUIRE(Jc && Jp && cam_idx && pt_idx && pt_obs && d && Jc_s && Jp_s && Jp_p, "null pointer");
+    IAMX_REQUIRE(n_obs > 0 && n_cams > 0 && n_pts > 0, "bad size");
+    hipStream_t st = iamx::as_stream(stream);
+    const unsigned g = (unsigned)((n_obs + 255) / 256);
+    hipLaunchKernelGGL(lsmr_prepare_obs_kernel, dim3(g), dim3(256), 0, st, Jc, Jp, cam_idx, pt_idx,
+                       n_obs, n_cams, d, Jc_s, Jp_s);
+    hipLaunchKernelGGL(lsmr_prepare_pt_kernel, dim3(g), dim3(256), 0, st, Jp, pt_idx, pt_obs, n_obs,
+                       n_cams, d, Jp_p);
+    return iamx::check_launch("iamx_ba_lsmr_prepare");
+}
+
+extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *Jp_p,
+                                    const int32_t *cam_idx, const int32_t *pt_idx,
+                                    const int32_t *cam_ptr, const int32_t *pt_ptr,
+                                    const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+                                    const double *dreg, double *u1, double *u2, double *vt,
+                                    double *h, double *hbar, double *x, double *state,
+                                    double *partials, int n_iter, void *stream)
+{
+    IAMX_REQUIRE(Jc_s && Jp_s && Jp_p && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && dreg &&
+                     u1 && u2 && vt && h && hbar && x && state && partials,
+                 "null pointer");
+    IAMX_REQUIRE(n_obs > 0 && n_cams > 0 && n_pts > 0 && n_iter >= 0 && (n_iter & 1) == 0,
+                 "bad size (n_iter must be even: the state block is double-buffered)");
+    const int n_adj_blocks = n_cams + (n_pts + 255) / 256;
+    LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
+               dreg, u1, u2, vt, h, hbar, x, state,
+               partials, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
+               n_adj_blocks};
+    hipStream_t st = iamx::as_stream(stream);
+    for (int it = 0; it < n_iter; ++it) {
+        const int parity = it & 1;
+        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(LS_FWD_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_adj_kernel, dim3(n_adj_blocks), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
+    }
+    return iamx::check_launch("iamx_ba_lsmr_iterate");
+}

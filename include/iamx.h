@@ -173,6 +173,14 @@ int iamx_ba_residual(const double *cams, int n_cams, const double *pts, int n_pt
                      const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
                      int64_t n_obs, const double *calib, double *r, void *stream);
 
+/* Same residual in two launches: a per-camera rotation/position block (cam_scratch DEV
+ * [n_cams][12] float64) is prepared first, the per-observation kernel then does 9 FMAs, one
+ * reciprocal and the distortion polynomial.  Results agree with iamx_ba_residual to rounding. */
+int iamx_ba_residual_prepared(const double *cams, int n_cams, const double *pts, int n_pts,
+                              const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
+                              int64_t n_obs, const double *calib, double *cam_scratch, double *r,
+                              void *stream);
+
 /* Residual + analytic Jacobian blocks (the reference has only finite differences:
  * scripts/lib/optimizer.py:142-169,491-501).  d r / d params, row-major per observation:
  *   Jc  DEV [n_obs][2][7]   wrt that observation's camera (ned, quat)
@@ -237,6 +245,29 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
                 const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
                 int n_pts, const double *u, int square, double *out, double *scratch,
                 void *stream);
+
+/* Host-free LSMR (scipy/sparse/linalg/_isolve/lsmr.py) on A = [J diag(d); diag(dreg)],
+ * b = [r; 0], no calibration columns.
+ * iamx_ba_lsmr_prepare: once per solve, folds d into J and writes the coalesced forms
+ *   Jc_s [14][n_obs], Jp_s [6][n_obs] (observation order), Jp_p [6][n_obs] (point-sorted).
+ * iamx_ba_lsmr_iterate: enqueues n_iter (even) iterations, three launches each, no host
+ *   synchronisation.  `state` (DEV, iamx_ba_lsmr_state_size() doubles) holds the double-
+ *   buffered scalar recurrences, the tolerances and the latched results (layout and
+ *   initialisation: imageanalysis_amd/ba_solver.py); once istop is latched the remaining
+ *   iterations are no-ops.  u1 [2 n_obs], u2/vt/h/hbar/x [n] DEV work vectors; partials DEV
+ *   [iamx_ba_lsmr_partials_size].  Deterministic (fixed reduction trees, no atomics). */
+int iamx_ba_lsmr_state_size(void);
+int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts);
+int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
+                         const int32_t *pt_idx, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                         int n_pts, const double *d, double *Jc_s, double *Jp_s, double *Jp_p,
+                         void *stream);
+int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *Jp_p,
+                         const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
+                         const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                         int n_pts, const double *dreg, double *u1, double *u2, double *vt,
+                         double *h, double *hbar, double *x, double *state, double *partials,
+                         int n_iter, void *stream);
 
 /* float64 vector kernels used by the device LSMR (scipy/sparse/linalg/_isolve/lsmr.py):
  *   axpby: y = a*x + b*y (b == 0 ignores y's old content)

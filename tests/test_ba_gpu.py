@@ -113,3 +113,19 @@ def test_residual_large_vs_c_oracle():
                             _dev(calib)).cpu().numpy()
     rr = cpu_ref.ba_residual(cams, pts, ci, pi, uv, calib[:4], calib[4:])
     assert np.abs(r - rr).max() / np.abs(rr).max() < TIGHT
+
+
+def test_residual_prepared_equals_plain():
+    import torch
+    from imageanalysis_amd import ba_solver, synth
+    p = synth.make_ba_problem(rows=6, cols=8, n_points=4000, n_obs=30000, seed=3,
+                              dist=(-0.12, 0.083, -0.0016, -0.00096, -0.012))
+    K = p['K']
+    calib = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], *p['dist']]
+    prob = ba_solver.DeviceBA(len(p['cams0']), len(p['pts0']), p['cam_idx'], p['pt_idx'], p['uv'],
+                              False, fixed_calib=calib)
+    prob.set_x(np.hstack([p['cams0'].ravel(), p['pts0'].ravel()]))
+    a = prob.residual().clone().cpu().numpy()
+    prob.residual_jac()
+    b = prob.r.cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
