@@ -162,7 +162,7 @@ def main():
             if timed_events:
                 e1.record()
             b.run_filter_fast(ws, thresh)
-            survivors.add_(ws.surv_off[b.n_pairs])
+            survivors.add_(ws.surv_cnt[:b.n_pairs].sum())
 
     def barrier():
         if dist is not None:

@@ -37,8 +37,10 @@ SIGNATURES = {
     'iamx_desc2_pack_f32': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
     'iamx_desc2_pack_batch_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]
                                  + [c_void_p] * 7),
-    'iamx_knn2v2_pairs': (c_int, [c_void_p] * 11 + [c_int, c_int, c_int] + [c_void_p] * 3),
+    'iamx_knn2v2_pairs': (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_int] + [c_void_p] * 3),
     'iamx_knn2v2_resolve': (c_int, [c_void_p] * 13 + [c_int, c_void_p, c_void_p]),
+    'iamx_knn2v2_finish': (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 5 + [c_int]
+                           + [c_void_p] * 3),
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_void_p, c_void_p]),

@@ -18,6 +18,17 @@
 // knn2v2_resolve_kernel, which recomputes the 32 exact distances of that tile with v_dot4 and
 // takes the lowest original row that reaches d2_best (= cv2.BFMatcher order, lowest index on
 // ties: the partition is stable, so the first tile / first row is the lowest original index).
+//
+// Bound form (BOUND = true, the shipped fast path): the sweep keeps only the two smallest
+// *16-row group minima* per query (min3 tree: 8 + 4 ops per 16 distances instead of 34), i.e.
+//     best   = exact smallest distance,
+//     second = smallest distance outside the best's group  >=  true second.
+// The metric test of the reference is monotone in `second`, so thresholding with this upper
+// bound keeps a superset of the true survivors; knn2v2_finish_kernel then recomputes the 32
+// distances of the best's tile for those rows, takes second = min(bound, second inside the
+// tile), re-applies the test, records the train index and compacts the survivors in place.
+// Everything that leaves the path (survivor lists, their metrics, d2 of every survivor) is
+// identical to the exact form; d2[.][1] of rows that fail the test stays an upper bound.
 #include "iamx_common.h"
 
 namespace {
@@ -217,7 +228,7 @@ struct Args2 {
 
 // VARIANT != 0: timing ablations (iamxdbg_knn2v2_variant): bit0 no epilogue, bit1 no MFMA,
 // bit2 no re-staging / barriers, bit3 two interleaved (m1,m2) chains per query block
-template <int VARIANT, int QW, int OCC, int NW = WAVES>
+template <int VARIANT, int QW, int OCC, int NW = WAVES, bool BOUND = false>
 __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
 {
     constexpr int QB = NW * QW * 32;
@@ -302,14 +313,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
         }
         const int8_t *tile_base = lds_tile + ((VARIANT & 4) ? 0 : buf) * (CHUNK * D);
         const int *tb_base = lds_tb + ((VARIANT & 4) ? 0 : buf) * CHUNK;
-#pragma unroll
-        for (int tile = 0; tile < CHUNK / 32; ++tile) {
+        // operands of tile t+1 are fetched from LDS before the MFMAs of tile t are issued
+        auto load_ops = [&](int tile, v4i (&a)[4], v4i (&tbv)[4]) {
             const int r = tile * 32 + c, swz = (r >> 1) & 7;
-            v4i a[4];
-            v4i tbv[4];
             if constexpr (VARIANT & 8) {       // ablation: operands without LDS traffic
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { a[s] = bq[0][s] + ch; tbv[s] = bq[1][s]; }
+                for (int s = 0; s < 4; ++s) { a[s] = bq[0][s] + ch + tile; tbv[s] = bq[1][s]; }
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -318,29 +327,58 @@ __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
                 for (int k = 0; k < 4; ++k)
                     tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
             }
-            const int tile_id = ch * (CHUNK / 32) + tile;
+        };
+        // C operand + 4 MFMAs (K = 128) of one 32x32 block
+        auto chain = [&](v16i &acc, const v4i (&a)[4], const v4i (&tbv)[4], int qb) {
 #pragma unroll
-            for (int qb = 0; qb < QW; ++qb) {
-                v16i acc;
+            for (int reg = 0; reg < 16; ++reg) acc[reg] = tbv[reg >> 2][reg & 3];
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) acc[reg] = tbv[reg >> 2][reg & 3];   // C operand
+            for (int s = 0; s < 4; ++s) {
+                if constexpr (VARIANT & 2) acc[s] += a[s][0] ^ bq[qb][s][1];
+                else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qb][s], acc, 0, 0, 0);
+            }
+        };
+        auto epilogue = [&](const v16i &acc, int qb, int tile_id) {
+            if constexpr (VARIANT & 1) {
+                asm volatile("" ::"v"(acc));
+            } else {
+                const int before = m1[qb];
+                if constexpr (BOUND) {
+                    // (m1, m2) = two smallest 16-row group minima: 8 + 2 ops per 16 distances
+                    int tm = min(min(acc[0], acc[1]), acc[2]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if constexpr (VARIANT & 2) acc[s] += a[s][0] ^ bq[qb][s][1];
-                    else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qb][s], acc, 0, 0, 0);
-                }
-                if constexpr (VARIANT & 1) {
-                    asm volatile("" ::"v"(acc));
+                    for (int reg = 3; reg < 15; reg += 2) tm = min(min(tm, acc[reg]), acc[reg + 1]);
+                    tm = min(tm, acc[15]);
+                    const int lo1 = min(m1[qb], tm);
+                    m2[qb] = med3_after(m1[qb], m2[qb], tm, lo1);
+                    m1[qb] = lo1;
                 } else {
-                    const int before = m1[qb];
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int lo1 = min(m1[qb], acc[reg]);
                         m2[qb] = med3_after(m1[qb], m2[qb], acc[reg], lo1);
                         m1[qb] = lo1;
                     }
-                    t1[qb] = m1[qb] < before ? tile_id : t1[qb];
                 }
+                t1[qb] = m1[qb] < before ? tile_id : t1[qb];
+            }
+        };
+        v4i a[4], tbv[4];
+        load_ops(0, a, tbv);
+#pragma unroll
+        for (int tile = 0; tile < CHUNK / 32; ++tile) {
+            v4i a_nx[4], tb_nx[4];
+            if (tile + 1 < CHUNK / 32) load_ops(tile + 1, a_nx, tb_nx);
+            const int tile_id = ch * (CHUNK / 32) + tile;
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb) {
+                v16i acc;
+                chain(acc, a, tbv, qb);
+                epilogue(acc, qb, tile_id);
+            }
+            if (tile + 1 < CHUNK / 32) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { a[s] = a_nx[s]; tbv[s] = tb_nx[s]; }
             }
         }
         if constexpr (!(VARIANT & 4)) {
@@ -430,6 +468,93 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int8_t *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------
+// bound form: exact second + final threshold + train index + in-place compaction;
+// one workgroup per ordered pair, 32 lanes per candidate, candidates in ascending query order
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void finish_kernel(const int8_t *__restrict__ desc_q,
+                                                     const int32_t *__restrict__ norm_q,
+                                                     const int32_t *__restrict__ qimg_off,
+                                                     const int8_t *__restrict__ desc_t,
+                                                     const int32_t *__restrict__ norm2_t,
+                                                     const int32_t *__restrict__ perm,
+                                                     const int32_t *__restrict__ timg_off,
+                                                     const int32_t *__restrict__ pairs,
+                                                     const int64_t *__restrict__ out_off,
+                                                     int32_t *__restrict__ d2, double thresh,
+                                                     const int64_t *__restrict__ surv_off,
+                                                     int32_t *__restrict__ surv_q,
+                                                     int32_t *__restrict__ surv_t /* in: tile, out: train row */,
+                                                     double *__restrict__ surv_metric,
+                                                     int32_t *__restrict__ surv_cnt,
+                                                     int32_t *__restrict__ zero_div,
+                                                     int32_t *__restrict__ n_unresolved)
+{
+    __shared__ int s_q[8], s_t[8], s_ok[8];
+    __shared__ double s_m[8];
+    const int p = blockIdx.x;
+    const int qoff = qimg_off[pairs[2 * p]], toff = timg_off[pairs[2 * p + 1]];
+    const int64_t b = surv_off[p], e = surv_off[p + 1], ob = out_off[p];
+    const int grp = threadIdx.x >> 5, j = threadIdx.x & 31;
+    int64_t w = b;                                   // next write position (w <= read position)
+    for (int64_t s0 = b; s0 < e; s0 += 8) {
+        const int64_t s = s0 + grp;
+        if (s < e) {
+            const int q = surv_q[s], tile = surv_t[s];
+            const v2i dd2 = *reinterpret_cast<const v2i *>(d2 + 2 * (ob + q));
+            const int best = dd2.x;
+            const int trow = toff + tile * 32 + j;
+            const int *qa = reinterpret_cast<const int *>(desc_q + (int64_t)(qoff + q) * D);
+            const int *ta = reinterpret_cast<const int *>(desc_t + (int64_t)trow * D);
+            int dot = 0;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) dot = __builtin_amdgcn_sdot4(qa[k], ta[k], dot, false);
+            const int orig = perm[trow];
+            const int dd = orig >= 0 ? norm_q[qoff + q] + norm2_t[trow] - 2 * dot : 0x7FFFFFFF;
+            const unsigned long long m = __ballot(dd == best);
+            const unsigned half = (unsigned)(m >> (32 * ((threadIdx.x >> 5) & 1)));
+            // second inside the tile: the best again if it occurs twice, else the next value
+            int other = (half & (half - 1)) ? best : (dd == best ? 0x7FFFFFFF : dd);
+#pragma unroll
+            for (int sh = 16; sh >= 1; sh >>= 1) other = min(other, __shfl_xor(other, sh));
+            if (j == 0) {
+                const int second = min(dd2.y, other);
+                d2[2 * (ob + q) + 1] = second;
+                const float f0 = (float)sqrt((double)best);
+                const float f1 = (float)sqrt((double)second);
+                double mt;
+                bool ok = false;
+                if (f1 == 0.0f) {
+                    mt = __longlong_as_double(0x7FF8000000000000LL);
+                    atomicAdd(zero_div, 1);
+                } else {
+                    const double ratio = (double)f0 / (double)f1;
+                    mt = (double)f0 * ratio;
+                    ok = mt < thresh;
+                }
+                int t = -1;
+                if (half) t = perm[toff + tile * 32 + (__ffs(half) - 1)];
+                else if (ok) atomicAdd(n_unresolved, 1);
+                s_q[grp] = q; s_t[grp] = t; s_m[grp] = mt; s_ok[grp] = ok ? 1 : 0;
+            }
+        } else if (j == 0) {
+            s_ok[grp] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (s_ok[k]) {
+                    surv_q[w] = s_q[k]; surv_t[w] = s_t[k]; surv_metric[w] = s_m[k];
+                    ++w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) surv_cnt[p] = (int)(w - b);
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -506,7 +631,8 @@ extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,
                                  const int32_t *timg_off, const int32_t *tmeta,
                                  const int32_t *pairs, const int32_t *wg_off,
                                  const int64_t *out_off, int n_pairs, int total_wg,
-                                 int rows_per_wg, int32_t *out_d2, int32_t *out_tile, void *stream)
+                                 int rows_per_wg, int exact_second, int32_t *out_d2,
+                                 int32_t *out_tile, void *stream)
 {
     IAMX_REQUIRE(desc_q && norm_q && qimg_off && qimg_n && desc_t && cinit && timg_off && tmeta &&
                      pairs && wg_off && out_off && out_d2 && out_tile,
@@ -516,12 +642,13 @@ extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,
     if (n_pairs == 0 || total_wg == 0) return IAMX_OK;
     Args2 a{desc_q, norm_q, qimg_off, qimg_n, desc_t, cinit, timg_off, tmeta, pairs, wg_off,
             out_off, out_d2, out_tile, n_pairs, total_wg};
-    if (rows_per_wg == 512)      // 4 query blocks per wave: fewer LDS reads per MFMA (-7 %)
-        hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2>), dim3((unsigned)total_wg), dim3(WAVES * 64), 0,
-                           iamx::as_stream(stream), a);
-    else
-        hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2>), dim3((unsigned)total_wg),
-                           dim3(WAVES * 64), 0, iamx::as_stream(stream), a);
+    const dim3 g((unsigned)total_wg), b(WAVES * 64);
+    hipStream_t st = iamx::as_stream(stream);
+    // 512 rows = 4 query blocks per wave: fewer LDS reads per MFMA (-7 %)
+    if (rows_per_wg == 512 && exact_second) hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2>), g, b, 0, st, a);
+    else if (rows_per_wg == 512) hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, WAVES, true>), g, b, 0, st, a);
+    else if (exact_second) hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2, WAVES, true>), g, b, 0, st, a);
     return iamx::check_launch("iamx_knn2v2_pairs");
 }
 
@@ -557,6 +684,18 @@ extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const i
     case 41: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 8>), g, dim3(512), 0, st, a); break;
     case 42: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2, 8>), g, dim3(512), 0, st, a); break;
     case 43: hipLaunchKernelGGL((knn2v2_kernel<0, 1, 4, 8>), g, dim3(512), 0, st, a); break;
+    case 50: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 2, 4, true>), g, b, 0, st, a); break;
+    case 51: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 52: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 2, 8, true>), g, dim3(512), 0, st, a); break;
+    case 53: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 1, 4, true>), g, b, 0, st, a); break;
+    case 54: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 4, 4, true>), g, b, 0, st, a); break;
+    case 55: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2, 4, true>), g, b, 0, st, a); break;
+    case 60: hipLaunchKernelGGL((knn2v2_kernel<1, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 61: hipLaunchKernelGGL((knn2v2_kernel<4, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 62: hipLaunchKernelGGL((knn2v2_kernel<12, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 63: hipLaunchKernelGGL((knn2v2_kernel<13, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((knn2v2_kernel<5, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 65: hipLaunchKernelGGL((knn2v2_kernel<2, 4, 2, 4, true>), g, b, 0, st, a); break;
     default: return iamx::fail(IAMX_EINVAL, "unknown variant");
     }
     return iamx::check_launch("iamxdbg_knn2v2_variant");
@@ -578,4 +717,25 @@ extern "C" int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q,
                        iamx::as_stream(stream), desc_q, norm_q, qimg_off, desc_t, norm2_t, perm,
                        timg_off, pairs, out_off, d2, surv_off, surv_q, surv_t, n_unresolved);
     return iamx::check_launch("iamx_knn2v2_resolve");
+}
+
+extern "C" int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q,
+                                  const int32_t *qimg_off, const int8_t *desc_t,
+                                  const int32_t *norm2_t, const int32_t *perm,
+                                  const int32_t *timg_off, const int32_t *pairs,
+                                  const int64_t *out_off, int32_t *d2, double thresh,
+                                  const int64_t *surv_off, int32_t *surv_q, int32_t *surv_t,
+                                  double *surv_metric, int32_t *surv_cnt, int n_pairs,
+                                  int32_t *zero_div, int32_t *n_unresolved, void *stream)
+{
+    IAMX_REQUIRE(desc_q && norm_q && qimg_off && desc_t && norm2_t && perm && timg_off && pairs &&
+                     out_off && d2 && surv_off && surv_q && surv_t && surv_metric && surv_cnt &&
+                     zero_div && n_unresolved,
+                 "null pointer");
+    if (n_pairs <= 0) return IAMX_OK;
+    hipLaunchKernelGGL(finish_kernel, dim3((unsigned)n_pairs), dim3(256), 0,
+                       iamx::as_stream(stream), desc_q, norm_q, qimg_off, desc_t, norm2_t, perm,
+                       timg_off, pairs, out_off, d2, thresh, surv_off, surv_q, surv_t, surv_metric,
+                       surv_cnt, zero_div, n_unresolved);
+    return iamx::check_launch("iamx_knn2v2_finish");
 }

@@ -244,6 +244,16 @@ class PairWorkspace(object):
         self.zero_div = torch.zeros(1, dtype=I32, device=dev)
         self.tile = torch.empty(r, dtype=I32, device=dev)
         self.unresolved = torch.zeros(1, dtype=I32, device=dev)
+        self.surv_cnt = torch.zeros(p, dtype=I32, device=dev)
+
+    def survivors(self, n_pairs):
+        """host copies: (first, count) per pair and the survivor arrays they index
+        (pair p owns [first[p], first[p] + count[p]); query rows ascending)."""
+        first = self.surv_off[:n_pairs + 1].cpu().numpy()
+        count = self.surv_cnt[:n_pairs].cpu().numpy().astype(np.int64)
+        total = int(first[-1])
+        return (first[:-1], count, self.surv_q[:total].cpu().numpy(),
+                self.surv_t[:total].cpu().numpy(), self.surv_metric[:total].cpu().numpy())
 
 
 class PairBatch(object):
@@ -299,17 +309,19 @@ class PairBatch(object):
               'iamx_match_compact')
 
     # ---- fast form: distances + tile in the sweep, train index only for the survivors
-    def run_knn2_fast(self, ws):
+    def run_knn2_fast(self, ws, exact_second=False):
         st = self.store
         check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
                                       _ptr(st.img_n), _ptr(st.desc2), _ptr(st.cinit),
                                       _ptr(st.img_off2), _ptr(st.meta), _ptr(self.d_pairs),
                                       _ptr(self.d_wg_fast), _ptr(self.d_out), self.n_pairs,
-                                      self.total_wg_fast, self.fast_rows, _ptr(ws.d2),
-                                      _ptr(ws.tile), stream_ptr()),
+                                      self.total_wg_fast, self.fast_rows, 1 if exact_second else 0,
+                                      _ptr(ws.d2), _ptr(ws.tile), stream_ptr()),
               'iamx_knn2v2_pairs')
 
-    def run_filter_fast(self, ws, thresh):
+    def run_filter_fast(self, ws, thresh, exact_second=False):
+        """threshold + compaction + train rows.  With the bound form of the sweep the first
+        threshold keeps a superset; iamx_knn2v2_finish makes it exact (include/iamx.h)."""
         L, s, st = lib(), stream_ptr(), self.store
         check(L.iamx_match_metric(_ptr(ws.d2), _ptr(self.d_out), self.n_pairs, float(thresh),
                                   _ptr(ws.metric), _ptr(ws.keep), _ptr(ws.seg_count),
@@ -320,25 +332,39 @@ class PairBatch(object):
                                    _ptr(self.d_out), _ptr(ws.surv_off), self.n_pairs,
                                    _ptr(ws.surv_q), _ptr(ws.surv_t), _ptr(ws.surv_metric), s),
               'iamx_match_compact')
-        check(L.iamx_knn2v2_resolve(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
-                                    _ptr(st.desc2), _ptr(st.norm2), _ptr(st.perm),
-                                    _ptr(st.img_off2), _ptr(self.d_pairs), _ptr(self.d_out),
-                                    _ptr(ws.d2), _ptr(ws.surv_off), _ptr(ws.surv_q),
-                                    _ptr(ws.surv_t), self.n_pairs, _ptr(ws.unresolved), s),
-              'iamx_knn2v2_resolve')
+        if exact_second:
+            check(L.iamx_knn2v2_resolve(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
+                                        _ptr(st.desc2), _ptr(st.norm2), _ptr(st.perm),
+                                        _ptr(st.img_off2), _ptr(self.d_pairs), _ptr(self.d_out),
+                                        _ptr(ws.d2), _ptr(ws.surv_off), _ptr(ws.surv_q),
+                                        _ptr(ws.surv_t), self.n_pairs, _ptr(ws.unresolved), s),
+                  'iamx_knn2v2_resolve')
+            ws.surv_cnt[:self.n_pairs].copy_(ws.seg_count[:self.n_pairs])
+        else:
+            check(L.iamx_knn2v2_finish(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
+                                       _ptr(st.desc2), _ptr(st.norm2), _ptr(st.perm),
+                                       _ptr(st.img_off2), _ptr(self.d_pairs), _ptr(self.d_out),
+                                       _ptr(ws.d2), float(thresh), _ptr(ws.surv_off),
+                                       _ptr(ws.surv_q), _ptr(ws.surv_t), _ptr(ws.surv_metric),
+                                       _ptr(ws.surv_cnt), self.n_pairs, _ptr(ws.zero_div),
+                                       _ptr(ws.unresolved), s), 'iamx_knn2v2_finish')
 
     def run(self, ws, thresh, fast=True):
-        """enqueue top-2 + metric threshold + survivor compaction (+ index resolve)."""
+        """enqueue top-2 + metric threshold + survivor compaction (+ index resolve).
+        fast: True = bound-form sweep (shipped), 'exact' = exact-second fast sweep,
+        False = the general kernel that tracks indices in the sweep."""
         if self.rows > ws.max_rows or self.n_pairs > ws.max_pairs:
             raise ValueError("workspace too small for this batch")
         if self.n_pairs == 0 or self.rows == 0:
             return
         if fast:
-            self.run_knn2_fast(ws)
-            self.run_filter_fast(ws, thresh)
+            exact = fast == 'exact'
+            self.run_knn2_fast(ws, exact_second=exact)
+            self.run_filter_fast(ws, thresh, exact_second=exact)
         else:
             self.run_knn2(ws)
             self.run_filter(ws, thresh)
+            ws.surv_cnt[:self.n_pairs].copy_(ws.seg_count[:self.n_pairs])
 
 
 # --------------------------------------------------------------------------------------

@@ -325,17 +325,13 @@ def _match_batch(batch, match_ratio):
     torch.cuda.current_stream().synchronize()
     if int(ws.zero_div.item()):
         raise ZeroDivisionError("float division by zero")       # matcher.py:255
-    soff = ws.surv_off[:pb.n_pairs + 1].cpu().numpy()
-    total = int(soff[-1])
-    sq = ws.surv_q[:total].cpu().numpy()
-    st = ws.surv_t[:total].cpu().numpy()
-    sm = ws.surv_metric[:total].cpu().numpy()
+    first, count, sq, st, sm = ws.survivors(pb.n_pairs)
     n = len(batch)
     out = []
     for k in range(n):
         res = []
         for p in (k, n + k):
-            a, b = soff[p], soff[p + 1]
+            a, b = first[p], first[p] + count[p]
             res.append((_threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), int(b - a)))
         out.append(res)
     return out

@@ -115,9 +115,18 @@ int iamx_match_compact(const int32_t *idx, int idx_stride, const double *metric,
  *  the tile ids of iamx_knn2v2_pairs, which iamx_knn2v2_resolve then turns into train rows) */
 
 /* ------------------------------------------------------------------------------------
- * K2, fast form: exact top-2 DISTANCES with 2 VALU ops per distance; the train index is
- * recovered afterwards, only for the rows that survive the metric threshold.  Same results
- * as iamx_knn2_l2_pairs + iamx_match_metric + iamx_match_compact (tests pin that).
+ * K2, fast form: top-2 DISTANCES without index tracking in the sweep; the train index is
+ * recovered afterwards, only for the rows that survive the metric threshold.  Same survivor
+ * lists as iamx_knn2_l2_pairs + iamx_match_metric + iamx_match_compact (tests pin that).
+ *   exact_second = 1: out_d2 = exact (best, second) for every row (2 VALU ops / distance);
+ *                     finish with iamx_match_metric/_compact + iamx_knn2v2_resolve.
+ *   exact_second = 0: out_d2[.][1] is an UPPER BOUND of the second distance (smallest distance
+ *                     outside the best's 16-row group; 0.75 VALU ops / distance).  Threshold
+ *                     with it (iamx_match_metric/_compact keep a superset of the survivors),
+ *                     then iamx_knn2v2_finish makes `second` exact for those rows (d2 updated
+ *                     in place), re-applies the test, resolves the train rows and compacts
+ *                     each pair's survivors in place: pair p owns
+ *                     surv_*[surv_off[p] .. surv_off[p] + surv_cnt[p]).
  *
  * Train-side store ("desc2"): rows of an image stably partitioned by the parity of
  * NB = |a-128|^2 + 2*sum(a-128), each class zero-padded to 128 rows:
@@ -149,12 +158,20 @@ int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q, const int32_t
                       const int32_t *timg_off, const int32_t *tmeta, const int32_t *pairs,
                       const int32_t *wg_off, const int64_t *out_off, int n_pairs, int total_wg,
                       int rows_per_wg /* 256 or 512: wg_off = scan of ceil(n_q / rows_per_wg) */,
-                      int32_t *out_d2, int32_t *out_tile, void *stream);
+                      int exact_second, int32_t *out_d2, int32_t *out_tile, void *stream);
 int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
                         const int8_t *desc_t, const int32_t *norm2_t, const int32_t *perm,
                         const int32_t *timg_off, const int32_t *pairs, const int64_t *out_off,
                         const int32_t *d2, const int64_t *surv_off, const int32_t *surv_q,
                         int32_t *surv_t, int n_pairs, int32_t *n_unresolved, void *stream);
+/* thresh: the same value as given to iamx_match_metric; zero_div is incremented for every row
+ * whose exact second distance is 0 (scripts/lib/matcher.py:255 divides by it). */
+int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
+                       const int8_t *desc_t, const int32_t *norm2_t, const int32_t *perm,
+                       const int32_t *timg_off, const int32_t *pairs, const int64_t *out_off,
+                       int32_t *d2, double thresh, const int64_t *surv_off, int32_t *surv_q,
+                       int32_t *surv_t, double *surv_metric, int32_t *surv_cnt, int n_pairs,
+                       int32_t *zero_div, int32_t *n_unresolved, void *stream);
 
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);

@@ -216,17 +216,21 @@ def test_config2_shape_properties():
 
 
 def _run_batch(store, pairs, thresh, fast):
+    """survivor lists are returned densely packed per pair (soff = exclusive scan of counts)"""
     import torch
     from imageanalysis_amd import kernels
     pb = kernels.PairBatch(store, np.asarray(pairs, np.int32))
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
     pb.run(ws, thresh, fast=fast)
     torch.cuda.synchronize()
-    soff = ws.surv_off[:pb.n_pairs + 1].cpu().numpy()
-    tot = int(soff[-1])
-    return dict(d2=ws.d2[:pb.rows].cpu().numpy(), soff=soff, sq=ws.surv_q[:tot].cpu().numpy(),
-                st=ws.surv_t[:tot].cpu().numpy(), sm=ws.surv_metric[:tot].cpu().numpy(),
-                unresolved=int(ws.unresolved.item()), off=pb.out_off)
+    first, count, q, t, m = ws.survivors(pb.n_pairs)
+    take = np.concatenate([np.arange(f, f + c) for f, c in zip(first, count)] + [np.zeros(0, np.int64)])
+    take = take.astype(np.int64)
+    soff = np.zeros(pb.n_pairs + 1, np.int64)
+    np.cumsum(count, out=soff[1:])
+    return dict(d2=ws.d2[:pb.rows].cpu().numpy(), soff=soff, sq=q[take], st=t[take], sm=m[take],
+                unresolved=int(ws.unresolved.item()), zero_div=int(ws.zero_div.item()),
+                off=pb.out_off)
 
 
 def test_desc2_store_layout():
@@ -255,17 +259,27 @@ def test_desc2_store_layout():
         assert np.array_equal(st.norm2.cpu().numpy()[:ne_pad + no_pad][ok], (s * s).sum(1)[perm[ok]])
 
 
+@pytest.mark.parametrize('form', [True, 'exact'], ids=['bound', 'exact-second'])
 @pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
-def test_fast_path_equals_general_path_golden(path):
+def test_fast_path_equals_general_path_golden(path, form):
     from imageanalysis_amd import kernels
     g = np.load(path)
     store = kernels.DescriptorStore.from_arrays([g['des1'], g['des2']])
     thresh = 270.0 * float(g['match_ratio'])
-    a = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=True)
+    a = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=form)
     b = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=False)
-    assert a['unresolved'] == 0
-    for k in ('d2', 'soff', 'sq', 'st', 'sm'):
+    assert a['unresolved'] == 0 and a['zero_div'] == b['zero_div']
+    for k in ('soff', 'sq', 'st', 'sm'):
         assert np.array_equal(a[k], b[k]), k
+    if form == 'exact':
+        assert np.array_equal(a['d2'], b['d2'])
+    else:
+        # bound form: best exact everywhere; second exact on every survivor, an upper bound
+        # (smallest distance outside the best's 16-row group) elsewhere
+        assert np.array_equal(a['d2'][:, 0], b['d2'][:, 0])
+        assert (a['d2'][:, 1] >= b['d2'][:, 1]).all()
+        rows = np.concatenate([a['off'][p] + a['sq'][a['soff'][p]:a['soff'][p + 1]] for p in (0, 1)])
+        assert np.array_equal(a['d2'][rows], b['d2'][rows])
     # and == the reference's pre-GMS list after the host's stable sort + clip
     for p, tag in enumerate(['fwd', 'rev']):
         lo, hi = a['soff'][p], a['soff'][p + 1]
@@ -273,6 +287,46 @@ def test_fast_path_equals_general_path_golden(path):
         got = np.stack([a['sq'][lo:hi][order], a['st'][lo:hi][order]], 1)
         if len(g['pregms_%s' % tag]):
             assert np.array_equal(got, g['pregms_%s' % tag])
+
+
+def test_bound_form_second_inside_best_group():
+    """Adversarial for the bound form: the true second neighbour sits in the same 16-row group
+    as the best (so the sweep only sees an upper bound), on both sides of the threshold, with
+    duplicates of the best (second == best) and exact-zero seconds (ZeroDivisionError path)."""
+    from imageanalysis_amd import kernels
+    from oracle import cpu_ref, match_oracle
+    rng = np.random.default_rng(77)
+    n = 640
+    train = _sift_like(rng, n)
+    query = _sift_like(rng, 500)
+    # queries 0..199: best = train row r, second = a near copy placed right next to it
+    rows = rng.choice(np.arange(0, n - 1, 2), 200, replace=False)
+    for k, r in enumerate(rows):
+        query[k] = np.clip(train[r].astype(int) + rng.integers(-2, 3, 128), 0, 255)
+        amp = (1, 3, 8, 20)[k % 4]                     # some pass the ratio test, some fail it
+        train[r + 1] = np.clip(train[r].astype(int) + rng.integers(-amp, amp + 1, 128), 0, 255)
+    for k in range(200, 230):                          # duplicates of the best: second == best
+        r = rows[k - 200]
+        query[k] = train[r]
+        train[r + 1] = train[r]                        # exact zero second for these queries
+    store = kernels.DescriptorStore.from_arrays([query, train])
+    for thresh in (270.0 * 0.75, 270.0 * 0.6, 1e9):
+        a = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=True)
+        b = _run_batch(store, [[0, 1], [1, 0]], thresh, fast=False)
+        assert a['unresolved'] == 0
+        assert a['zero_div'] == b['zero_div'] and b['zero_div'] > 0
+        for k in ('soff', 'sq', 'st', 'sm'):
+            assert np.array_equal(a[k], b[k]), (thresh, k)
+        ridx, rd2 = cpu_ref.knn2_l2_u8(query, train)
+        lo, hi = a['soff'][0], a['soff'][1]
+        assert np.array_equal(a['d2'][:500][a['sq'][lo:hi]], rd2[a['sq'][lo:hi]])
+        assert np.array_equal(a['st'][lo:hi], ridx[a['sq'][lo:hi], 0])
+    # the bound really was loose somewhere (otherwise this test exercises nothing)
+    pb = kernels.PairBatch(store, np.array([[0, 1]], np.int32))
+    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb.run_knn2_fast(ws)
+    d2b = ws.d2[:500].cpu().numpy()
+    assert (d2b[:, 1] > rd2[:, 1]).sum() >= 30 and np.array_equal(d2b[:, 0], rd2[:, 0])
 
 
 def test_fast_path_ragged_ties_and_tiny_classes():
