@@ -196,7 +196,13 @@ def main():
                 "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
-                "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR}
+                "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR,
+                # the kernel runs both directions of a pair as two MFMA passes: executed =
+                # 2 x algorithmic; sustained i8 MFMA ceiling with real operand bits measured
+                # at ~3200 TOP/s (power limited, profiles/r1_ubench_mfma_clock.txt)
+                "executed_tflops": round(2 * achieved, 1),
+                "executed_frac_of_peak": round(2 * achieved / I8_DENSE_PEAK_TFLOPS, 4),
+                "executed_frac_of_sustained_3200": round(2 * achieved / 3200.0, 4)}
 
     ws_unresolved = int(ws.unresolved.item())
     # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
@@ -290,6 +296,31 @@ def ba_bench(rank, world, dev, dist, args):
     prob.set_x(res.x)
     mre = float(np.sqrt(2.0 * res.cost / (2 * O)))
     HBM = 8000.0
+    # the dominant BA kernels: one fused LSMR iteration (forward, adjoint, update) streams
+    #   forward  O*(160 J + 8 idx + 32 ut r/w) + n*32        adjoint O*(160 J + 32 ut + 4 idx) + n*40
+    #   update   n*56                                          (bytes; J = scaled f64 blocks)
+    lsmr = None
+    if world == 1:
+        prob.residual_jac()
+        cn = prob.colnorm()
+        cn[cn == 0] = 1
+        d_dev = prob.upload(1.0 / cn)
+        dreg = prob.upload(np.full(prob.n, 1e-3))
+        its = 256
+        ba_solver.lsmr_device_fused(prob, d_dev, dreg, atol=0, btol=0, conlim=0, maxiter=64)
+        sync()
+        t1 = time.perf_counter()
+        ba_solver.lsmr_device_fused(prob, d_dev, dreg, atol=0, btol=0, conlim=0, maxiter=its)
+        sync()
+        t_it = (time.perf_counter() - t1) / its
+        by = O * (200.0 + 196.0) + prob.n * 128.0
+        lsmr = {"bound": "hbm", "kernels": "lsmr_fwd + lsmr_adj + lsmr_update3",
+                "achieved": round(by / t_it / 1e9, 1), "peak": HBM, "unit": "GB/s",
+                "frac": round(by / t_it / 1e9 / HBM, 4), "us_per_iteration": round(t_it * 1e6, 1),
+                "bytes_per_iteration": by}
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = ba_cpu_baseline()
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
             "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),
             "lsmr_iterations": int(res.lsmr_iterations), "seconds": round(dt, 3),
@@ -304,7 +335,51 @@ def ba_bench(rank, world, dev, dist, args):
                              "peak": HBM, "unit": "GB/s",
                              "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
                              "bytes_per_obs": 224},
+            "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
+
+
+def ba_cpu_baseline():
+    """The reference's solver call (scipy least_squares, trf, jac_sparsity, x_scale='jac',
+    ftol=1e-4; scripts/lib/optimizer.py:491-501) on the host cores, with the residual from the
+    oracle's OpenMP C restatement instead of the per-camera python loop (generous to the CPU),
+    on a REDUCED instance of the same synthetic scene (300 cameras, ~195 k observations,
+    SURVEY.md 8d) for 3 TRF iterations; the full-size figure is a linear extrapolation in the
+    observation count."""
+    from scipy.optimize import least_squares
+    from scipy.sparse import csr_matrix
+    from oracle import cpu_ref
+    from imageanalysis_amd import synth
+    p = synth.make_ba_problem(rows=10, cols=30, n_points=32000, n_obs=195000)
+    C, P, O = len(p['cams0']), len(p['pts0']), len(p['cam_idx'])
+    K = p['K']
+    intr = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+    cam, pt = p['cam_idx'].astype(np.int64), p['pt_idx'].astype(np.int64)
+    cols = np.concatenate([cam[:, None] * 7 + np.arange(7), C * 7 + pt[:, None] * 3 + np.arange(3)], 1)
+    rows = np.repeat(np.arange(2 * O), 10)
+    A = csr_matrix((np.ones(20 * O, np.int8), (rows, np.repeat(cols, 2, axis=0).ravel())),
+                   shape=(2 * O, C * 7 + P * 3))
+    x0 = np.hstack([p['cams0'].ravel(), p['pts0'].ravel()])
+    lb, ub = np.full(x0.size, -np.inf), np.full(x0.size, np.inf)
+    for j, dlt in ((0, 3.0), (1, 3.0), (2, 9.0)):
+        lb[j:C * 7:7] = p['cams0'][:, j] - dlt
+        ub[j:C * 7:7] = p['cams0'][:, j] + dlt
+
+    def fun(x):
+        return cpu_ref.ba_residual(x[:C * 7], x[C * 7:], p['cam_idx'], p['pt_idx'], p['uv'], intr,
+                                   p['dist'])
+
+    t0 = time.perf_counter()
+    res = least_squares(fun, x0, jac_sparsity=A, verbose=0, x_scale='jac', ftol=1e-4,
+                        method='trf', bounds=(lb, ub), max_nfev=4)
+    dt = time.perf_counter() - t0
+    its = max(int(res.njev) - 1, 1)
+    return {"value": round(its / dt, 4), "unit": "TRF iterations/s", "cores": cpu_ref.num_threads(),
+            "kind": "port",
+            "sample": "scipy least_squares(trf, jac_sparsity, x_scale='jac') + oracle/cpu_ref.c "
+                      "residual on %d cameras / %d points / %d observations, %d iterations in "
+                      "%.1f s" % (C, P, O, its, dt),
+            "extrapolated_to_full_config": round(its / dt * O / 1960898.0, 4)}
 
 
 def cpu_baseline(sample_images):

@@ -91,19 +91,10 @@ __global__ __launch_bounds__(256) void ba_cam_prep_kernel(const double *__restri
 
 // residual from the prepared camera blocks: the per-observation work is 9 FMAs, one
 // reciprocal and the distortion polynomial; identical arithmetic to project_obs()
-__global__ __launch_bounds__(256) void ba_residual_rt_kernel(
-    const double *__restrict__ rt, const double *__restrict__ pts,
-    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
-    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
-    double *__restrict__ r)
+__device__ __forceinline__ double2 residual_rt(const double *__restrict__ R,
+                                               const double *__restrict__ X, double2 obs,
+                                               const double (&cal)[9])
 {
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= n_obs) return;
-    const double fx = calib[0], fy = calib[1], cu = calib[2], cv = calib[3];
-    const double k1 = calib[4], k2 = calib[5], p1 = calib[6], p2 = calib[7], k3 = calib[8];
-    const double *R = rt + (int64_t)cam_idx[o] * 12;
-    const double *X = pts + (int64_t)pt_idx[o] * 3;
-    const double2 obs = *reinterpret_cast<const double2 *>(uv + 2 * o);
     const double a = X[0] - R[9], b = X[1] - R[10], c = X[2] - R[11];
     const double y0 = (R[0] * a + R[1] * b + R[2] * c);
     const double y1 = (R[3] * a + R[4] * b + R[5] * c);
@@ -111,10 +102,38 @@ __global__ __launch_bounds__(256) void ba_residual_rt_kernel(
     const double iz = 1.0 / y0;
     const double px = y1 * iz, py = y2 * iz;
     const double r2 = px * px + py * py;
-    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
-    const double xd = px * rad + 2.0 * p1 * px * py + p2 * (r2 + 2.0 * px * px);
-    const double yd = py * rad + p1 * (r2 + 2.0 * py * py) + 2.0 * p2 * px * py;
-    *reinterpret_cast<double2 *>(r + 2 * o) = make_double2(obs.x - (fx * xd + cu), obs.y - (fy * yd + cv));
+    const double rad = 1.0 + r2 * (cal[4] + r2 * (cal[5] + r2 * cal[8]));
+    const double xd = px * rad + 2.0 * cal[6] * px * py + cal[7] * (r2 + 2.0 * px * px);
+    const double yd = py * rad + cal[6] * (r2 + 2.0 * py * py) + 2.0 * cal[7] * px * py;
+    return make_double2(obs.x - (cal[0] * xd + cal[2]), obs.y - (cal[1] * yd + cal[3]));
+}
+
+// two consecutive observations per thread: 8-byte index loads, 32 bytes of uv in and of r out
+__global__ __launch_bounds__(256) void ba_residual_rt_kernel(
+    const double *__restrict__ rt, const double *__restrict__ pts,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
+    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
+    double *__restrict__ r)
+{
+    const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (o >= n_obs) return;
+    double cal[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cal[i] = calib[i];
+    if (o + 1 < n_obs) {
+        const int2 ci = *reinterpret_cast<const int2 *>(cam_idx + o);
+        const int2 pi = *reinterpret_cast<const int2 *>(pt_idx + o);
+        const double4 ob = *reinterpret_cast<const double4 *>(uv + 2 * o);
+        const double2 r0 = residual_rt(rt + (int64_t)ci.x * 12, pts + (int64_t)pi.x * 3,
+                                       make_double2(ob.x, ob.y), cal);
+        const double2 r1 = residual_rt(rt + (int64_t)ci.y * 12, pts + (int64_t)pi.y * 3,
+                                       make_double2(ob.z, ob.w), cal);
+        *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
+    } else {
+        const double2 ob = *reinterpret_cast<const double2 *>(uv + 2 * o);
+        *reinterpret_cast<double2 *>(r + 2 * o) =
+            residual_rt(rt + (int64_t)cam_idx[o] * 12, pts + (int64_t)pt_idx[o] * 3, ob, cal);
+    }
 }
 
 __global__ __launch_bounds__(256) void ba_residual_kernel(
@@ -274,10 +293,13 @@ extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const d
     IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && r && cam_scratch, "null pointer");
     IAMX_REQUIRE(n_cams > 0 && n_pts > 0 && n_obs >= 0, "bad size");
     if (n_obs == 0) return IAMX_OK;
+    IAMX_REQUIRE((((uintptr_t)uv | (uintptr_t)r) & 31) == 0 &&
+                     (((uintptr_t)cam_idx | (uintptr_t)pt_idx) & 7) == 0,
+                 "uv / r must be 32-byte aligned, cam_idx / pt_idx 8-byte aligned");
     hipStream_t st = iamx::as_stream(stream);
     hipLaunchKernelGGL(ba_cam_prep_kernel, dim3((n_cams + 255) / 256), dim3(256), 0, st, cams,
                        n_cams, cam_scratch);
-    hipLaunchKernelGGL(ba_residual_rt_kernel, dim3((unsigned)((n_obs + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(ba_residual_rt_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
                        st, cam_scratch, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
     return iamx::check_launch("iamx_ba_residual_prepared");
 }
