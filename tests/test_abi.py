@@ -51,3 +51,15 @@ def test_product_has_no_cpu_fallback():
     from imageanalysis_amd import _lib
     with pytest.raises(_lib.IamxError):
         _lib.require_gpu()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under imageanalysis_amd/ may import or load it."""
+    import re
+    pkg = os.path.join(REPO, 'imageanalysis_amd')
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b|oracle[/.]cpu_ref|liboracle|oracle/_ref', re.M)
+    for root, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.sh')):
+                text = open(os.path.join(root, f)).read()
+                assert not pat.search(text), os.path.join(root, f)
