@@ -89,6 +89,7 @@ def main():
     ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
+    ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
     ap.add_argument('--ba-iters', type=int, default=3, help='TRF iterations to time')
     args = ap.parse_args()
 
@@ -222,6 +223,10 @@ def main():
         torch.cuda.empty_cache()
         ba = ba_bench(rank, world, dev, dist, args)
 
+    sift = None
+    if not args.no_sift:
+        sift = sift_bench(rank, world, dev, dist, args)
+
     out = None
     if rank == 0:
         cpu = None
@@ -242,13 +247,90 @@ def main():
                                                             if world > 1 else "")},
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
             "unresolved": int(ws_unresolved),
-            "roofline": roofline, "cpu_baseline": cpu, "ba": ba,
+            "roofline": roofline, "cpu_baseline": cpu, "ba": ba, "sift": sift,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def sift_bench(rank, world, dev, dist, args):
+    """Feature detection on BASELINE's 20 MP frames (5472x3648, detect scale 0.4): CLAHE + resize +
+    SIFT on the device, per image, inputs resident in HBM, keypoints/descriptors delivered to
+    the host in canonical order.  Images shard over ranks (independent), no collective."""
+    from imageanalysis_amd import kernels, synth
+    n_local = 4
+    imgs = [synth.make_survey_image(seed=100 * rank + i, device=dev) for i in range(2)]
+    scale = 0.4
+
+    def detect(img):
+        scaled = kernels.equalize_resize(img, scale)
+        return scaled, kernels.sift_detect(scaled, cap=400000)
+
+    scaled, (kp, _o, _d) = detect(imgs[0])                  # warm-up (workspace, code objects)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nkp = 0
+    for i in range(n_local):
+        nkp += len(detect(imgs[i % 2])[1][0])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # device-only time of the detector kernels (no download / sort)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    L = kernels.lib()
+    h, w = scaled.shape[0], scaled.shape[1]
+    need = int(L.iamx_sift_workspace_bytes(h, w))
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    kpd = torch.empty((400000, 8), dtype=torch.float32, device=dev)
+    dd = torch.empty((400000, 128), dtype=torch.uint8, device=dev)
+    nn = torch.zeros(1, dtype=torch.int32, device=dev)
+    e0.record()
+    for _ in range(n_local):
+        kernels.check(L.iamx_sift_detect(kernels._ptr(scaled), h, w, 3, 0.04, 10.0, 1.6,
+                                         kernels._ptr(ws), need, kernels._ptr(kpd), kernels._ptr(dd),
+                                         400000, kernels._ptr(nn), kernels.stream_ptr()),
+                      'iamx_sift_detect')
+    e1.record()
+    torch.cuda.synchronize()
+    t_k = e0.elapsed_time(e1) / n_local * 1e-3
+    if dist is not None:
+        t = torch.tensor([dt, t_k], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_k = [float(v) for v in t.tolist()]
+    alg = 469.0 * h * w                                     # SURVEY.md 8d: bytes per image
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = sift_cpu_baseline()
+    return {"metric": "sift_images_per_sec", "value": round(n_local * world / dt, 2),
+            "image": "5472x3648 synthetic, CLAHE + resize 0.4 -> %dx%d detect image" % (w, h),
+            "keypoints_per_image": nkp // n_local, "ms_per_image": round(dt / n_local * 1e3, 2),
+            "ms_per_image_detector_kernels": round(t_k * 1e3, 2),
+            "roofline": {"bound": "hbm", "kernels": "pyramid + extrema + orientation + descriptor",
+                         "achieved": round(alg / t_k / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg},
+            "cpu_baseline": cpu, "dtype": "f32 pyramid, f64 histograms", "parallelism": "image-shard x%d" % world}
+
+
+def sift_cpu_baseline():
+    """oracle/sift_oracle.py (numpy restatement, one core) on a 400x520 crop-sized texture; cv2
+    (absent) would be orders of magnitude faster than this port -- reported for completeness."""
+    from oracle import sift_oracle as so
+    rng = np.random.default_rng(0)
+    h, w = 400, 520
+    img = np.zeros((h, w))
+    for s in (2, 4, 8, 16, 32):
+        img += np.kron(rng.normal(size=(h // s + 2, w // s + 2)), np.ones((s, s)))[:h, :w] * s ** 0.7
+    img = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    t0 = time.perf_counter()
+    kps, _ = so.detect_and_compute(img)
+    dt = time.perf_counter() - t0
+    return {"value": round(h * w / dt / (2189 * 1459), 5), "unit": "images/s (extrapolated by pixels)",
+            "cores": 1, "kind": "port",
+            "sample": "oracle/sift_oracle.py on a %dx%d image: %d keypoints in %.1f s" % (w, h, len(kps), dt)}
 
 
 def ba_bench(rank, world, dev, dist, args):

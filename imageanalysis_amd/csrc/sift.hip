@@ -8,11 +8,14 @@
 //
 // Stages (all enqueued on one stream, no host round trip inside):
 //   gray_up2x      BGR u8 -> gray u8 (fixed point) -> x2 bilinear -> f32                HBM
-//   blur_h/blur_v  separable Gaussian, BORDER_REFLECT_101, f32, taps in fixed order     HBM
-//   downsample, dog                                                                     HBM
+//   blur_h/blur_v  separable Gaussian, BORDER_REFLECT_101, f32, taps in fixed order;    HBM
+//                  LDS row tiles / 8-row register windows; blur_v also writes the DoG
+//   downsample                                                                          HBM
 //   extrema        26-neighbour test on the DoG stack -> candidate list (atomic append)
-//   refine_orient  one thread per candidate: 3-D quadratic fit (<=5 steps), contrast/edge
-//                  tests, orientation histogram + peaks -> keypoints (atomic append)
+//   refine         one thread per candidate: 3-D quadratic fit (<=5 steps), contrast/edge
+//                  tests -> refined list (atomic append)
+//   orient         one wave per refined candidate: orientation histogram (f64 LDS atomics),
+//                  smoothing, peaks -> keypoints (atomic append)
 //   descriptor     one wave per keypoint: rotated 4x4x8 trilinear histogram in LDS (f64
 //                  atomics), clip/normalise/quantise
 // The per-pixel arithmetic of the pyramid uses explicit round-to-nearest mul/add (no FMA
@@ -76,21 +79,97 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
     dst[i] = __fadd_rn(__fmul_rn(top, omty), __fmul_rn(bot, ty));
 }
 
-template <bool VERTICAL>
-__global__ __launch_bounds__(256) void blur_kernel(const float *__restrict__ src, int h, int w,
-                                                   Taps T, float *__restrict__ dst)
+// Separable Gaussian.  Both passes add the taps in ascending order with separately rounded
+// mul and add (acc = 0; acc = acc + v*k[t], t = -r..r) -- the order the CPU oracle uses, so
+// the pyramid is bit-identical to it.
+// Horizontal: one workgroup per 1024-pixel row segment, staged (with its halo) in LDS.
+constexpr int BLUR_TW = 1024;
+
+__global__ __launch_bounds__(256) void blur_h_kernel(const float *__restrict__ src, int h, int w,
+                                                     Taps T, float *__restrict__ dst)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)w * h) return;
-    const int x = (int)(i % w), y = (int)(i / w);
-    float acc = 0.f;
-    for (int t = -T.r; t <= T.r; ++t) {
-        float v;
-        if (VERTICAL) v = src[(int64_t)reflect101(y + t, h) * w + x];
-        else          v = src[(int64_t)y * w + reflect101(x + t, w)];
-        acc = __fadd_rn(acc, __fmul_rn(v, T.k[t + T.r]));
+    __shared__ float row[BLUR_TW + 2 * (MAX_TAPS / 2) + 2];
+    __shared__ float sk[MAX_TAPS];
+    const int r = T.r, y = blockIdx.y, x0 = blockIdx.x * BLUR_TW;
+    if (threadIdx.x < 2 * r + 1) sk[threadIdx.x] = T.k[threadIdx.x];
+    const int n_out = min(BLUR_TW, w - x0);
+    const float *srow = src + (int64_t)y * w;
+    for (int i = threadIdx.x; i < n_out + 2 * r; i += 256) {
+        const int xx = x0 - r + i;
+        row[i] = srow[(xx >= 0 && xx < w) ? xx : reflect101(xx, w)];
     }
-    dst[i] = acc;
+    __syncthreads();
+    float *drow = dst + (int64_t)y * w + x0;
+#pragma unroll
+    for (int p = 0; p < BLUR_TW / 256; ++p) {
+        const int j = threadIdx.x + 256 * p;
+        if (j < n_out) {
+            float acc = 0.f;
+            for (int t = 0; t <= 2 * r; ++t) acc = __fadd_rn(acc, __fmul_rn(row[j + t], sk[t]));
+            drow[j] = acc;
+        }
+    }
+}
+
+// Vertical: one thread per column and BLUR_RV output rows.  The tap radius is a template
+// parameter so the (BLUR_RV + 2R)-row window lives in registers and the taps in SGPRs: every
+// input row is loaded once (coalesced), each output adds its taps in ascending order.
+// Optionally also writes the DoG level  dog = out - prev  (fused).
+constexpr int BLUR_RV = 8;
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_v_kernel(const float *__restrict__ src, int h, int w,
+                                                     Taps T, float *__restrict__ dst,
+                                                     const float *__restrict__ prev,
+                                                     float *__restrict__ dog)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * BLUR_RV;
+    if (x >= w) return;
+    float win[BLUR_RV + 2 * R];
+    const bool interior = y0 - R >= 0 && y0 + BLUR_RV - 1 + R < h;
+    if (interior) {
+        const float *p = src + (int64_t)(y0 - R) * w + x;
+#pragma unroll
+        for (int i = 0; i < BLUR_RV + 2 * R; ++i) win[i] = p[(int64_t)i * w];
+    } else {
+#pragma unroll
+        for (int i = 0; i < BLUR_RV + 2 * R; ++i) {
+            const int yy = y0 - R + i;
+            win[i] = src[(int64_t)((yy >= 0 && yy < h) ? yy : reflect101(yy, h)) * w + x];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BLUR_RV; ++j) {
+        const int y = y0 + j;
+        if (y < h) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) acc = __fadd_rn(acc, __fmul_rn(win[j + t], T.k[t]));
+            const int64_t i = (int64_t)y * w + x;
+            dst[i] = acc;
+            if (dog) dog[i] = __fsub_rn(acc, prev[i]);
+        }
+    }
+}
+
+template <int R>
+void launch_blur_v(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
+                   const float *prev, float *dog)
+{
+    hipLaunchKernelGGL(blur_v_kernel<R>, dim3((w + 255) / 256, (h + BLUR_RV - 1) / BLUR_RV), dim3(256),
+                       0, st, src, h, w, tp, dst, prev, dog);
+}
+
+void blur_v(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
+            const float *prev, float *dog)
+{
+    switch (tp.r) {
+#define IAMX_BV(r) case r: launch_blur_v<r>(st, src, h, w, tp, dst, prev, dog); break;
+        IAMX_BV(1) IAMX_BV(2) IAMX_BV(3) IAMX_BV(4) IAMX_BV(5) IAMX_BV(6) IAMX_BV(7) IAMX_BV(8)
+        IAMX_BV(9) IAMX_BV(10) IAMX_BV(11) IAMX_BV(12) IAMX_BV(13) IAMX_BV(14) IAMX_BV(15) IAMX_BV(16)
+#undef IAMX_BV
+    default: launch_blur_v<0>(st, src, h, w, tp, dst, prev, dog); break;
+    }
 }
 
 __global__ __launch_bounds__(256) void downsample_kernel(const float *__restrict__ src, int sw,
@@ -100,14 +179,6 @@ __global__ __launch_bounds__(256) void downsample_kernel(const float *__restrict
     if (i >= (int64_t)dw * dh) return;
     const int x = (int)(i % dw), y = (int)(i / dw);
     dst[i] = src[(int64_t)(2 * y) * sw + 2 * x];
-}
-
-__global__ __launch_bounds__(256) void dog_kernel(const float *__restrict__ a,
-                                                  const float *__restrict__ b, int64_t n,
-                                                  float *__restrict__ d)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) d[i] = __fsub_rn(b[i], a[i]);
 }
 
 struct Cand {
@@ -188,14 +259,20 @@ __device__ __forceinline__ int round_half_even(double v)
     return (int)rint(v);
 }
 
-__global__ __launch_bounds__(64) void refine_orient_kernel(PyrTable T, const Cand *__restrict__ cand,
-                                                           const int *__restrict__ n_cand, int cap_c,
-                                                           float contrast_threshold,
-                                                           float edge_threshold, float sigma,
-                                                           float *__restrict__ kp, int cap_k,
-                                                           int *__restrict__ n_kp)
+// a candidate that passed the sub-pixel fit and the contrast / edge tests
+struct Refined {
+    int o, layer, r, c;
+    double xi, xr, xc, contr;
+};
+
+// one thread per candidate: 3-D quadratic fit (<= 5 steps), contrast and edge tests
+__global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__restrict__ cand,
+                                                     const int *__restrict__ n_cand, int cap_c,
+                                                     float contrast_threshold, float edge_threshold,
+                                                     Refined *__restrict__ refined,
+                                                     int *__restrict__ n_refined)
 {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
     const int total = *n_cand < cap_c ? *n_cand : cap_c;
     if (idx >= total) return;
     const Cand cd = cand[idx];
@@ -252,48 +329,77 @@ __global__ __launch_bounds__(64) void refine_orient_kernel(PyrTable T, const Can
         const double e = edge_threshold;
         if (det <= 0 || tr * tr * e >= (e + 1) * (e + 1) * det) return;
     }
-    const int o = cd.o;
+    const int k = atomicAdd(n_refined, 1);
+    if (k < cap_c) {
+        Refined R;
+        R.o = cd.o; R.layer = layer; R.r = r; R.c = c;
+        R.xi = xi; R.xr = xr; R.xc = xc; R.contr = contr;
+        refined[k] = R;
+    }
+}
+
+// one wave per refined candidate: 36-bin gradient orientation histogram over the
+// (2*radius+1)^2 window (lanes stride over the pixels, f64 LDS atomics), smoothing, peaks
+__global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *__restrict__ refined,
+                                                     const int *__restrict__ n_refined, int cap_c,
+                                                     float sigma, float *__restrict__ kp, int cap_k,
+                                                     int *__restrict__ n_kp)
+{
+    __shared__ double hist_s[4][ORI_BINS];
+    __shared__ double sm_s[4][ORI_BINS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int total = *n_refined < cap_c ? *n_refined : cap_c;
+    // persistent waves (wave-uniform control flow; no block-level barriers below)
+    for (int idx = blockIdx.x * 4 + wave; idx < total; idx += gridDim.x * 4) {
+    const Refined R = refined[idx];
+    const Pyr &P = T.oct[R.o];
+    const int h = P.h, w = P.w, o = R.o, layer = R.layer, r = R.r, c = R.c;
+    const double xi = R.xi, xr = R.xr, xc = R.xc, contr = R.contr;
     const double size = (double)sigma * exp2((layer + xi) / NL) * (double)(1 << o) * 2.0;
     const double px = (c + xc) * (double)(1 << o), py = (r + xr) * (double)(1 << o);
     const int octave = o + (layer << 8) + (round_half_even((xi + 0.5) * 255) << 16);
     const double scl_octv = size * 0.5 / (double)(1 << o);
 
-    // ---- orientation histogram on the Gaussian level
     const float *g = P.g[layer];
     const int radius = round_half_even(4.5 * scl_octv);
     const double osig = 1.5 * scl_octv;
     const double expf_scale = -1.0 / (2.0 * osig * osig);
-    double hist[ORI_BINS];
-    for (int k = 0; k < ORI_BINS; ++k) hist[k] = 0.0;
-    for (int i = -radius; i <= radius; ++i) {
-        const int y = r + i;
-        if (y <= 0 || y >= h - 1) continue;
-        for (int j = -radius; j <= radius; ++j) {
-            const int x = c + j;
-            if (x <= 0 || x >= w - 1) continue;
-            const double dx = (double)g[(int64_t)y * w + x + 1] - (double)g[(int64_t)y * w + x - 1];
-            const double dy = (double)g[(int64_t)(y - 1) * w + x] - (double)g[(int64_t)(y + 1) * w + x];
-            const double wgt = exp((double)(i * i + j * j) * expf_scale);
-            double ori = atan2(dy, dx) * (180.0 / 3.141592653589793);
-            if (ori < 0) ori += 360.0;
-            if (ori >= 360.0) ori -= 360.0;
-            const double mag = sqrt(dx * dx + dy * dy);
-            int b = round_half_even((ORI_BINS / 360.0) * ori);
-            if (b >= ORI_BINS) b -= ORI_BINS;
-            if (b < 0) b += ORI_BINS;
-            hist[b] += wgt * mag;
-        }
+    double *hist = hist_s[wave], *sm = sm_s[wave];
+    if (lane < ORI_BINS) hist[lane] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    const int side = 2 * radius + 1;
+    for (int e = lane; e < side * side; e += 64) {
+        const int i = e / side - radius, j = e % side - radius;
+        const int y = r + i, x = c + j;
+        if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
+        const double dx = (double)g[(int64_t)y * w + x + 1] - (double)g[(int64_t)y * w + x - 1];
+        const double dy = (double)g[(int64_t)(y - 1) * w + x] - (double)g[(int64_t)(y + 1) * w + x];
+        const double wgt = exp((double)(i * i + j * j) * expf_scale);
+        double ori = atan2(dy, dx) * (180.0 / 3.141592653589793);
+        if (ori < 0) ori += 360.0;
+        if (ori >= 360.0) ori -= 360.0;
+        const double mag = sqrt(dx * dx + dy * dy);
+        int b = round_half_even((ORI_BINS / 360.0) * ori);
+        if (b >= ORI_BINS) b -= ORI_BINS;
+        if (b < 0) b += ORI_BINS;
+        atomicAdd(&hist[b], wgt * mag);
     }
-    double sm[ORI_BINS];
-    double omax = 0.0;
-    for (int k = 0; k < ORI_BINS; ++k) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): LDS atomics landed
+    if (lane < ORI_BINS) {
+        const int k = lane;
         const double m2 = hist[(k + ORI_BINS - 2) % ORI_BINS], p2 = hist[(k + 2) % ORI_BINS];
         const double m1 = hist[(k + ORI_BINS - 1) % ORI_BINS], p1 = hist[(k + 1) % ORI_BINS];
         sm[k] = (m2 + p2) * (1.0 / 16) + (m1 + p1) * (4.0 / 16) + hist[k] * (6.0 / 16);
-        omax = sm[k] > omax ? sm[k] : omax;
     }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    double omax = lane < ORI_BINS ? sm[lane] : 0.0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) omax = fmax(omax, __shfl_xor(omax, m));
     const double mag_thr = omax * 0.8;
-    for (int j = 0; j < ORI_BINS; ++j) {
+    if (lane < ORI_BINS) {
+        const int j = lane;
         const double lft = sm[(j + ORI_BINS - 1) % ORI_BINS], rgt = sm[(j + 1) % ORI_BINS];
         if (sm[j] > lft && sm[j] > rgt && sm[j] >= mag_thr) {
             double bin = j + 0.5 * (lft - rgt) / (lft - 2 * sm[j] + rgt);
@@ -315,6 +421,8 @@ __global__ __launch_bounds__(64) void refine_orient_kernel(PyrTable T, const Can
                 q[7] = 0.f;
             }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -451,7 +559,7 @@ struct Layout {
     int n_oct;
     int h[MAX_OCT], w[MAX_OCT];
     int64_t g_off[MAX_OCT][6], d_off[MAX_OCT][5];
-    int64_t tmp_off, cand_off, count_off, total;
+    int64_t tmp_off, cand_off, refined_off, count_off, total;
 };
 
 Layout make_layout(int height, int width, int cap_c)
@@ -473,6 +581,7 @@ Layout make_layout(int height, int width, int cap_c)
     }
     L.tmp_off = take((int64_t)L.h[0] * L.w[0] * 4);
     L.cand_off = take((int64_t)cap_c * sizeof(Cand));
+    L.refined_off = take((int64_t)cap_c * sizeof(Refined));
     L.count_off = take(256);
     L.total = off;
     return L;
@@ -510,8 +619,10 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     }
     float *tmp = reinterpret_cast<float *>(ws + L.tmp_off);
     Cand *cand = reinterpret_cast<Cand *>(ws + L.cand_off);
+    Refined *refined = reinterpret_cast<Refined *>(ws + L.refined_off);
     int *n_cand = reinterpret_cast<int *>(ws + L.count_off);
-    (void)hipMemsetAsync(n_cand, 0, 4, st);
+    int *n_refined = n_cand + 1;
+    (void)hipMemsetAsync(n_cand, 0, 8, st);
     (void)hipMemsetAsync(n_out, 0, 4, st);
 
     // layer sigmas (Lowe / OpenCV buildGaussianPyramid)
@@ -522,12 +633,13 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         const double sp = pow(kf, (double)(i - 1)) * sigma, stt = sp * kf;
         sig[i] = sqrt(stt * stt - sp * sp);
     }
-    auto blur = [&](const float *src, float *dst, int h, int w, double s) {
+    // dst = G_sigma * src; with `dog` also dog = dst - src (the DoG level between the two)
+    auto blur = [&](const float *src, float *dst, int h, int w, double s, float *dog) {
         Taps tp;
         gaussian_taps(s, tp);
-        const unsigned g = blocks((int64_t)h * w, 256);
-        hipLaunchKernelGGL(blur_kernel<false>, dim3(g), dim3(256), 0, st, src, h, w, tp, tmp);
-        hipLaunchKernelGGL(blur_kernel<true>, dim3(g), dim3(256), 0, st, tmp, h, w, tp, dst);
+        hipLaunchKernelGGL(blur_h_kernel, dim3((w + BLUR_TW - 1) / BLUR_TW, h), dim3(256), 0, st, src,
+                           h, w, tp, tmp);
+        blur_v(st, tmp, h, w, tp, dst, src, dog);
     };
     // base image: gray -> x2 -> blur(sqrt(sigma^2 - 1))
     {
@@ -536,7 +648,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)H * W, 256)), dim3(256), 0, st,
                            image, height, width, channels, up);
         const double sd = sqrt(fmax((double)sigma * sigma - 1.0, 0.01));
-        blur(up, T.oct[0].g[0], H, W, sd);
+        blur(up, T.oct[0].g[0], H, W, sd, nullptr);
     }
     const float threshold = floorf(0.5f * contrast_threshold / NL * 255.f);
     for (int o = 0; o < L.n_oct; ++o) {
@@ -545,10 +657,8 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         if (o > 0)
             hipLaunchKernelGGL(downsample_kernel, dim3(blocks(npx, 256)), dim3(256), 0, st,
                                T.oct[o - 1].g[NL], L.w[o - 1], H, W, T.oct[o].g[0]);
-        for (int i = 1; i < NL + 3; ++i) blur(T.oct[o].g[i - 1], T.oct[o].g[i], H, W, sig[i]);
-        for (int i = 0; i < NL + 2; ++i)
-            hipLaunchKernelGGL(dog_kernel, dim3(blocks(npx, 256)), dim3(256), 0, st, T.oct[o].g[i],
-                               T.oct[o].g[i + 1], npx, T.oct[o].d[i]);
+        for (int i = 1; i < NL + 3; ++i)
+            blur(T.oct[o].g[i - 1], T.oct[o].g[i], H, W, sig[i], T.oct[o].d[i - 1]);
         if (H > 2 * BORDER && W > 2 * BORDER) {
             const int64_t inner = (int64_t)(H - 2 * BORDER) * (W - 2 * BORDER);
             for (int layer = 1; layer <= NL; ++layer)
@@ -559,8 +669,10 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     }
     // the number of candidates is only known on the device: launch for the capacity in slabs
     // sized by the largest plausible count (threads beyond *n_cand exit immediately)
-    hipLaunchKernelGGL(refine_orient_kernel, dim3(blocks(CAP_CAND, 64)), dim3(64), 0, st, T, cand,
-                       n_cand, CAP_CAND, contrast_threshold, edge_threshold, sigma, kp, cap, n_out);
+    hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,
+                       CAP_CAND, contrast_threshold, edge_threshold, refined, n_refined);
+    hipLaunchKernelGGL(orient_kernel, dim3(256 * 8), dim3(256), 0, st, T, refined, n_refined,
+                       CAP_CAND, sigma, kp, cap, n_out);
     hipLaunchKernelGGL(descriptor_kernel, dim3(blocks(cap, 4)), dim3(256), 0, st, T, kp, n_out, cap,
                        desc);
     return iamx::check_launch("iamx_sift_detect");

@@ -397,14 +397,39 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     cnt = int(n.item())
     if cnt > cap:
         raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (cnt, cap))
-    k = kp[:cnt].cpu().numpy()
-    d = desc[:cnt].cpu().numpy()
-    octave = k[:, 5].copy().view(np.int32)
-    # octave byte is (o-1) & 255 with o = pyramid octave index
-    o_idx = (((octave & 255) + 1) & 255).astype(np.int64)
-    layer = ((octave >> 8) & 255).astype(np.int64)
-    order = np.lexsort((d[:, 0], k[:, 3], k[:, 0], k[:, 1], layer, o_idx))
-    return np.ascontiguousarray(k[order, :5]), octave[order], np.ascontiguousarray(d[order])
+    # canonical (octave, layer, y, x, angle, desc[0]) order: the kernels append in a
+    # nondeterministic order.  Three stable device sorts on integer keys (the floats are
+    # non-negative, so their bit patterns order like their values), gather, one pinned download.
+    kpv, dv = kp[:cnt], desc[:cnt]
+    bits = kpv.view(I32).to(I64)
+    octave_d = bits[:, 5]
+    o_idx = ((octave_d & 255) + 1) & 255
+    layer = (octave_d >> 8) & 255
+    order = torch.sort((bits[:, 3] << 8) | dv[:, 0].to(I64), stable=True)[1]
+    order = order[torch.sort(((bits[:, 1] << 32) | bits[:, 0])[order], stable=True)[1]]
+    order = order[torch.sort((o_idx * 256 + layer)[order], stable=True)[1]]
+    kps = kpv.index_select(0, order)
+    ds = dv.index_select(0, order)
+    hk, hd = _sift_pinned(dev, cnt)
+    hk[:cnt].copy_(kps, non_blocking=True)
+    hd[:cnt].copy_(ds, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    k = hk[:cnt].numpy()
+    return k[:, :5].copy(), k[:, 5].copy().view(np.int32), hd[:cnt].numpy().copy()
+
+
+_sift_pin = {}
+
+
+def _sift_pinned(dev, n):
+    """page-locked staging for the keypoint / descriptor download (grown geometrically)"""
+    cur = _sift_pin.get(dev.index)
+    if cur is None or cur[0].shape[0] < n:
+        m = max(1 << 16, 1 << int(n - 1).bit_length())
+        cur = (torch.empty((m, 8), dtype=torch.float32).pin_memory(),
+               torch.empty((m, 128), dtype=U8).pin_memory())
+        _sift_pin[dev.index] = cur
+    return cur
 
 
 def equalize_resize(bgr, scale, equalize=True, clip_limit=3.0):

@@ -97,3 +97,20 @@ def make_ba_problem(rows=38, cols=74, n_points=300000, n_obs=2000000, spacing=20
     return dict(cams0=cams0, pts0=pts0, cams_true=cams, pts_true=pts,
                 cam_idx=cam_idx.astype(np.int32), pt_idx=pt_idx.astype(np.int32), uv=uv,
                 K=K, dist=np.asarray(dist, np.float64))
+
+
+def make_survey_image(h=3648, w=5472, seed=0, device='cuda'):
+    """SURVEY.md 8d "20 MP" SIFT input: seeded procedural fractal noise, BGR uint8 [h,w,3] on the
+    device, textured enough for several 10^4 SIFT keypoints at scale 0.4."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    img = torch.zeros((1, 1, h, w), device=device)
+    for s in (2, 4, 8, 16, 32, 64):
+        n = torch.randn((1, 1, h // s + 2, w // s + 2), generator=g, device=device)
+        up = torch.nn.functional.interpolate(n, scale_factor=s, mode='bilinear',
+                                             align_corners=False)[:, :, :h, :w]
+        img += up * s ** 0.7
+    img = (img - img.min()) / (img.max() - img.min()) * 255
+    img = img[0, 0]
+    return torch.stack([img, img * 0.9 + 10, img * 0.8 + 20], 2).clamp(0, 255).to(torch.uint8).contiguous()

@@ -33,6 +33,7 @@ def main(d, out):
             for c, v in sorted(acc[k].items()):
                 lines.append('    %-28s dispatches=%-5d sum=%-18.6g avg=%.6g' % (
                     c, len(v), sum(v), sum(v) / len(v)))
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 
