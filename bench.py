@@ -99,13 +99,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # IAMX_BENCH_DEBUG_ONE_GPU=1: all ranks on device 0 over gloo -- a smoke test of the N > 1
+    # code path on a 1-GPU box (RCCL refuses two ranks on one device); never used for numbers
+    one_gpu = os.environ.get('IAMX_BENCH_DEBUG_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from imageanalysis_amd import kernels
 
@@ -143,7 +151,12 @@ def main():
                                (store.cinit, rows_per2), (store.perm, rows_per2), (store.meta, 4)):
                 flat = buf.view(-1)
                 shard = per * width
-                dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard])
+                if one_gpu:          # gloo: no in-place all_gather_into_tensor on device memory
+                    parts = [torch.empty(shard, dtype=flat.dtype, device=dev) for _ in range(world)]
+                    dist.all_gather(parts, flat[rank * shard:(rank + 1) * shard].clone())
+                    flat.copy_(torch.cat(parts))
+                else:
+                    dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard])
 
     ordered, n_pairs_rank = pair_schedule(n_img, rank, world)
     sb = args.sub_batch
@@ -230,8 +243,9 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # CPU baselines: rank 0 at N=1 only
             cpu = cpu_baseline(cpu_sample)
+        host_post = host_postprocess_rate()
         value = total_pairs * args.steps / dt
         out = {
             "metric": "image_pairs_matched_per_sec", "value": round(value, 1), "unit": "pairs/s",
@@ -247,13 +261,49 @@ def main():
                                                             if world > 1 else "")},
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
             "unresolved": int(ws_unresolved),
-            "roofline": roofline, "cpu_baseline": cpu, "ba": ba, "sift": sift,
+            "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
+            "sift": sift,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def host_postprocess_rate():
+    """GMS / de-dup / cross-check are host post-processing, timed separately from
+    `value`: one pair = both directions with 2000 thresholded matches each (the clip limit of
+    scripts/lib/matcher.py:267), 70 % of them on a consistent motion, through
+    gms_inlier_mask + _dedupe + filter_cross_check (imageanalysis_amd/matcher.py), one core."""
+    from imageanalysis_amd import gms, matcher
+    rng = np.random.default_rng(5)
+    n, W, H = 4096, 5472.0, 3648.0
+    xy1 = np.stack([rng.uniform(0, W, n), rng.uniform(0, H, n)], 1).astype(np.float32)
+    xy2 = xy1.copy()
+    xy2[:, 0] = np.clip(xy1[:, 0] + 300.0, 0, W - 1)
+    q = rng.permutation(n)[:2000]
+    t = q.copy()
+    bad = rng.random(2000) < 0.3
+    t[bad] = rng.integers(0, n, bad.sum())
+    fwd, rev = np.stack([q, t], 1), np.stack([t, q], 1)
+
+    def one():
+        out = []
+        for a, b, pr in ((xy1, xy2, fwd), (xy2, xy1, rev)):
+            m = gms.gms_inlier_mask(a, b, (W, H), (W, H), pr, with_rotation=True, with_scale=False,
+                                    threshold_factor=5.0)
+            out.append(matcher._dedupe(a, b, [[int(u), int(v)] for u, v in pr[m]])[0])
+        return matcher.filter_cross_check(out[0], out[1])
+
+    one()
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 2.0:
+        kept = one()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(reps / dt, 1), "unit": "pairs/s", "cores": 1,
+            "sample": "2 x 2000 matches per pair, %d kept after GMS + de-dup + cross-check" % len(kept[0])}
 
 
 def sift_bench(rank, world, dev, dist, args):
@@ -303,7 +353,7 @@ def sift_bench(rank, world, dev, dist, args):
         dt, t_k = [float(v) for v in t.tolist()]
     alg = 469.0 * h * w                                     # bytes per image
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = sift_cpu_baseline()
     return {"metric": "sift_images_per_sec", "value": round(n_local * world / dt, 2),
             "image": "5472x3648 synthetic, CLAHE + resize 0.4 -> %dx%d detect image" % (w, h),
@@ -410,7 +460,7 @@ def ba_bench(rank, world, dev, dist, args):
                 "frac": round(by / t_it / 1e9 / HBM, 4), "us_per_iteration": round(t_it * 1e6, 1),
                 "bytes_per_iteration": by}
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = ba_cpu_baseline()
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
             "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),

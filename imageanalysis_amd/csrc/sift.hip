@@ -463,10 +463,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         radius = radius < diag ? radius : diag;
         cos_t /= hist_width;
         sin_t /= hist_width;
+        // radius <= diag of the octave image (< 2^14 for any image that fits the workspace),
+        // so the window index fits 32 bits: no 64-bit division in the sample loop
         const int side = 2 * radius + 1;
-        const int64_t nsamp = (int64_t)side * side;
-        for (int64_t s = lane; s < nsamp; s += 64) {
-            const int i = (int)(s / side) - radius, j = (int)(s % side) - radius;
+        const int nsamp = side * side;
+        for (int s = lane; s < nsamp; s += 64) {
+            const int i0 = s / side;
+            const int i = i0 - radius, j = s - i0 * side - radius;
             const double c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             const double rbin = r_rot + d / 2 - 0.5, cbin = c_rot + d / 2 - 0.5;
             const int r = py + i, c = px + j;
