@@ -286,11 +286,16 @@ def host_postprocess_rate():
     t = q.copy()
     bad = rng.random(2000) < 0.3
     t[bad] = rng.integers(0, n, bad.sum())
-    fwd, rev = np.stack([q, t], 1), np.stack([t, q], 1)
+    # survivors of both directions as the matching stage delivers them: query rows ascending
+    metric = rng.uniform(1.0, 200.0, 2000)
+    of, orv = np.argsort(q, kind='stable'), np.argsort(t, kind='stable')
+    sf = (q[of].astype(np.int32), t[of].astype(np.int32), metric[of])
+    sr = (t[orv].astype(np.int32), q[orv].astype(np.int32), metric[orv])
 
     def one():
         out = []
-        for a, b, pr in ((xy1, xy2, fwd), (xy2, xy1, rev)):
+        for a, b, sv in ((xy1, xy2, sf), (xy2, xy1, sr)):
+            pr = matcher._threshold_sort_clip(*sv)
             m = gms.gms_inlier_mask(a, b, (W, H), (W, H), pr, with_rotation=True, with_scale=False,
                                     threshold_factor=5.0)
             out.append(matcher._dedupe(a, b, [[int(u), int(v)] for u, v in pr[m]])[0])
@@ -302,8 +307,56 @@ def host_postprocess_rate():
         kept = one()
         reps += 1
     dt = time.perf_counter() - t0
-    return {"value": round(reps / dt, 1), "unit": "pairs/s", "cores": 1,
-            "sample": "2 x 2000 matches per pair, %d kept after GMS + de-dup + cross-check" % len(kept[0])}
+    out = {"host": {"value": round(reps / dt, 1), "unit": "pairs/s", "cores": 1,
+                    "sample": "2 x 2000 matches per pair, %d kept after GMS + de-dup + cross-check"
+                              % len(kept[0])}}
+    # the same pair through iamx_match_postfilter (one workgroup per pair), 2048 pairs per launch
+    from imageanalysis_amd import kernels
+    from imageanalysis_amd.kernels import _ptr
+    dev = torch.device('cuda', torch.cuda.current_device())
+    n_pairs = 2048
+    L = kernels.lib()
+    clip = int(L.iamx_match_postfilter_clip())
+    t = lambda a, dt_: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt_)
+    sq = np.concatenate([np.tile(sf[0], n_pairs), np.tile(sr[0], n_pairs)])
+    st = np.concatenate([np.tile(sf[1], n_pairs), np.tile(sr[1], n_pairs)])
+    sm = np.concatenate([np.tile(sf[2], n_pairs), np.tile(sr[2], n_pairs)])
+    d = dict(off=t(np.arange(2 * n_pairs + 1) * 2000, torch.int64),
+             cnt=t(np.full(2 * n_pairs, 2000), torch.int32), q=t(sq, torch.int32),
+             t=t(st, torch.int32), m=t(sm, torch.float64),
+             pairs=t(np.array([[0, 1]] * n_pairs + [[1, 0]] * n_pairs), torch.int32),
+             kp_off=t(np.array([0, n]), torch.int64), xy=t(np.concatenate([xy1, xy2]), torch.float32),
+             key2=t(matcher.kp_key2(np.concatenate([xy1, xy2])), torch.int32),
+             out_cnt=torch.empty(n_pairs, dtype=torch.int32, device=dev),
+             out_pairs=torch.empty((n_pairs, clip, 2), dtype=torch.int32, device=dev),
+             scratch=torch.empty((n_pairs, 2, clip, 2), dtype=torch.int32, device=dev),
+             stat=torch.empty((n_pairs, 4), dtype=torch.int32, device=dev),
+             status=torch.empty(n_pairs, dtype=torch.int32, device=dev))
+
+    def launch():
+        kernels.check(L.iamx_match_postfilter(_ptr(d['off']), _ptr(d['cnt']), _ptr(d['q']), _ptr(d['t']),
+                                              _ptr(d['m']), _ptr(d['pairs']), _ptr(d['kp_off']),
+                                              _ptr(d['xy']), _ptr(d['key2']), n_pairs, W, H, 25.0, 5.0,
+                                              _ptr(d['out_cnt']), _ptr(d['out_pairs']),
+                                              _ptr(d['scratch']), _ptr(d['stat']), _ptr(d['status']),
+                                              kernels.stream_ptr()), 'iamx_match_postfilter')
+
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    got = d['out_pairs'][0, :int(d['out_cnt'][0].item())].cpu().numpy()
+    if not np.array_equal(got, np.array(kept[0]).reshape(-1, 2)):
+        raise RuntimeError("device post filter disagrees with the host filters")
+    out["device"] = {"value": round(n_pairs / (ms * 1e-3), 1), "unit": "pairs/s",
+                     "kernel": "postfilter_kernel", "ms_per_launch": round(ms, 3),
+                     "pairs_per_launch": n_pairs,
+                     "kept_per_pair": int(d['out_cnt'][0].item())}
+    return out
 
 
 def sift_bench(rank, world, dev, dist, args):

@@ -41,6 +41,9 @@ SIGNATURES = {
     'iamx_knn2v2_resolve': (c_int, [c_void_p] * 13 + [c_int, c_void_p, c_void_p]),
     'iamx_knn2v2_finish': (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 5 + [c_int]
                            + [c_void_p] * 3),
+    'iamx_match_postfilter_clip': (c_int, []),
+    'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]
+                              + [c_void_p] * 6),
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_void_p, c_void_p]),

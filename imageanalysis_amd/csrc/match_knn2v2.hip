@@ -228,7 +228,7 @@ struct Args2 {
 
 // VARIANT != 0: timing ablations (iamxdbg_knn2v2_variant): bit0 no epilogue, bit1 no MFMA,
 // bit2 no re-staging / barriers, bit3 two interleaved (m1,m2) chains per query block
-template <int VARIANT, int QW, int OCC, int NW = WAVES, bool BOUND = false>
+template <int VARIANT, int QW, int OCC, int NW = WAVES, bool BOUND = false, bool DLDS = false>
 __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
 {
     constexpr int QB = NW * QW * 32;
@@ -294,16 +294,43 @@ __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
         if (tid < CHUNK) lds_tb[buf * CHUNK + tid] = st_tb;
     };
 
+    // DLDS: global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write).
+    // The LDS destination of lane i is base + 16*i, so the XOR swizzle is applied on the
+    // SOURCE side: position (row, p) of the tile receives logical slot p ^ ((row>>1)&7).
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto stage_direct = [&](int ch, int buf) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int e = j * NT + tid, row = e >> 3, slot = (e & 7) ^ ((row >> 1) & 7);
+            const int8_t *gsrc = tbase + (int64_t)(ch * CHUNK + row) * D + slot * 16;
+            int8_t *ldst = lds_tile + buf * (CHUNK * D) + (j * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr)ldst, 16, 0, 0);
+        }
+        if (wave < CHUNK / 64)
+            __builtin_amdgcn_global_load_lds(tci + ch * CHUNK + tid,
+                                             (lds_ptr)(lds_tb + buf * CHUNK + wave * 64), 4, 0, 0);
+    };
+    auto wait_direct = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };       // vmcnt(0)
+
     const int nchunks = ne_ch + no_ch;
     if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
+        if constexpr (DLDS) {
+            stage_direct(0, 0);
+            wait_direct();
+        } else {
+            load_chunk(0);
+            store_chunk(0);
+        }
     }
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
-        if constexpr (!(VARIANT & 4))
-            if (ch + 1 < nchunks) load_chunk(ch + 1);
+        if constexpr (!(VARIANT & 4)) {
+            if (ch + 1 < nchunks) {
+                if constexpr (DLDS) stage_direct(ch + 1, buf ^ 1);
+                else load_chunk(ch + 1);
+            }
+        }
         if (ch == ne_ch) {                 // class boundary: park the even class
 #pragma unroll
             for (int qb = 0; qb < QW; ++qb) {
@@ -382,7 +409,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
             }
         }
         if constexpr (!(VARIANT & 4)) {
-            if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+            if constexpr (DLDS) {
+                wait_direct();
+            } else {
+                if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+            }
             __syncthreads();
         }
     }
@@ -690,6 +721,10 @@ extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const i
     case 53: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 1, 4, true>), g, b, 0, st, a); break;
     case 54: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 4, 4, true>), g, b, 0, st, a); break;
     case 55: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2, 4, true>), g, b, 0, st, a); break;
+    case 56: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 4, true, true>), g, b, 0, st, a); break;
+    case 57: hipLaunchKernelGGL((knn2v2_kernel<0, 2, 2, 4, true, true>), g, b, 0, st, a); break;
+    case 58: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 8, true, true>), g, dim3(512), 0, st, a); break;
+    case 59: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2, 4, true, true>), g, b, 0, st, a); break;
     case 60: hipLaunchKernelGGL((knn2v2_kernel<1, 4, 2, 4, true>), g, b, 0, st, a); break;
     case 61: hipLaunchKernelGGL((knn2v2_kernel<4, 4, 2, 4, true>), g, b, 0, st, a); break;
     case 62: hipLaunchKernelGGL((knn2v2_kernel<12, 4, 2, 4, true>), g, b, 0, st, a); break;

@@ -59,6 +59,8 @@ class DeviceMatcher(object):
         self._counts = []
         self._store = None
         self._pending = []
+        self._kp = {}             # slot -> (xy float32 [n,2], key2 int32 [n,2]) host copies
+        self._kp_dev = None       # (n_slots, kp_off, xy, key2) device arena of the post filter
 
     # cv2-style single pair call (returns numpy (idx[nq,2], dist[nq,2] float32))
     def knnMatch(self, des1, des2, k=2):
@@ -79,7 +81,27 @@ class DeviceMatcher(object):
         self._slots[image.name] = (slot, n)
         self._counts.append(n)
         self._pending.append((slot, image.des_list))
+        xy = _kp_xy(image)
+        self._kp[slot] = (xy, kp_key2(xy))
         return slot
+
+    def keypoints(self):
+        """device arena of kp.pt and their "%.2f" keys for every slot (rebuilt when images
+        were added): (kp_off int64 [n_slots], xy float32 [total,2], key2 int32 [total,2])"""
+        import torch
+        from . import _lib
+        n = len(self._counts)
+        if self._kp_dev is None or self._kp_dev[0] != n:
+            dev = _lib.require_gpu()
+            cnt = [len(self._kp[s][0]) for s in range(n)]
+            off = np.zeros(n + 1, np.int64)
+            np.cumsum(cnt, out=off[1:])
+            xy = np.concatenate([self._kp[s][0] for s in range(n)] + [np.zeros((0, 2), np.float32)])
+            k2 = np.concatenate([self._kp[s][1] for s in range(n)] + [np.zeros((0, 2), np.int32)])
+            self._kp_dev = (n, torch.from_numpy(off[:-1].copy()).to(dev),
+                            torch.from_numpy(np.ascontiguousarray(xy, np.float32)).to(dev),
+                            torch.from_numpy(np.ascontiguousarray(k2, np.int32)).to(dev))
+        return self._kp_dev[1:]
 
     def store(self):
         """(Re)build the arena when new images arrived; old rows are copied on the device."""
@@ -107,6 +129,21 @@ def _kp_xy(image):
     xy = np.array([kp.pt for kp in image.kp_list], np.float32).reshape(-1, 2)
     image._iamx_xy = (image.kp_list, xy)
     return xy
+
+
+def kp_key2(xy):
+    """[N,2] int32: round-half-even(100 * kp.pt) computed exactly -- two keypoints have the same
+    "%.2f-%.2f" % kp.pt string (matcher.py:166-167) iff their key pairs are equal.  kp.pt holds
+    float32 values; x * 2**40 is an exact integer for every float32 in [2**-16, 2**14) and
+    smaller values print as 0.00 either way."""
+    x = np.asarray(xy, np.float64).reshape(-1, 2)
+    if x.size and (x.min() < 0 or x.max() >= 16384.0):
+        raise ValueError("keypoint coordinates outside [0, 16384)")
+    m = (x * float(1 << 40)).astype(np.int64) * 100
+    q, rem = m >> 40, m & ((1 << 40) - 1)
+    half = 1 << 39
+    q = q + ((rem > half) | ((rem == half) & ((q & 1) == 1)))
+    return q.astype(np.int32)
 
 
 # --------------------------------------------------------------------------------------
@@ -196,16 +233,7 @@ def _post_filter(i1, i2, thresh_pairs, xy=None):
     """matcher.py:271-300 from the thresholded list on: min_pairs gate, GMS, de-dup, gate."""
     if len(thresh_pairs) < min_pairs:
         return []
-    cam = _deps.camera()
-    w, h = cam.get_image_params()
-    if not w or not h:
-        _log("Zero image sizes will crash matchGMS():", w, h)
-        _log("Recommend removing all meta/*.feat files and")
-        _log("rerun the matching step.")
-        _log("... or do some coding to add this information to the")
-        _log("ImageAnalysis/meta/<image_name>.json files")
-        quit()
-    size = (w, h)
+    size = _camera_size()
     xy1, xy2 = xy if xy is not None else (_kp_xy(i1), _kp_xy(i2))
     mask = gms_inlier_mask(xy1, xy2, size, size, thresh_pairs, with_rotation=True,
                            with_scale=False, threshold_factor=5.0)
@@ -308,57 +336,97 @@ def _ensure_features(image):
         image.detect_features(detect_scale)
 
 
-def _match_batch(batch, match_ratio):
-    """batch: list of (i1, i2) image objects.  Returns per pair (fwd_thresh, rev_thresh):
-    the metric-thresholded, sorted, clipped [q,t] arrays of both directions."""
+def _match_batch(batch, match_ratio, device_filters=True):
+    """batch: list of (i1, i2) image objects.  Device k=2 NN + metric threshold for both
+    directions of every pair, then the per-pair filters (sort/clip, GMS, de-dup, gates, cross
+    check) -- on the device too (iamx_match_postfilter) unless `device_filters` is False or a
+    pair has more survivors than the device sort holds.  Returns per pair
+    (match_fwd, match_rev, n_fwd_quality, n_rev_quality)."""
     import torch
     from . import kernels
+    from .kernels import _ptr, check, lib, stream_ptr
     dm = the_matcher
     slots = [(dm.slot_of(a), dm.slot_of(b)) for a, b in batch]
     store = dm.store()
     ordered = np.array([[sa, sb] for sa, sb in slots] + [[sb, sa] for sa, sb in slots], np.int32)
-    # the reference's guards: no matching against images with <= 1 descriptors
     pb = kernels.PairBatch(store, ordered)
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
     thresh = max_distance * match_ratio
     pb.run(ws, thresh)
+    n = len(batch)
+    post = None
+    if device_filters:
+        cam_w, cam_h = _camera_size()
+        kp_off, xy, key2 = dm.keypoints()
+        L = lib()
+        clip = int(L.iamx_match_postfilter_clip())
+        dev = xy.device
+        post = dict(cnt=torch.empty(n, dtype=torch.int32, device=dev),
+                    pairs=torch.empty((n, clip, 2), dtype=torch.int32, device=dev),
+                    scratch=torch.empty((n, 2, clip, 2), dtype=torch.int32, device=dev),
+                    stat=torch.empty((n, 4), dtype=torch.int32, device=dev),
+                    status=torch.empty(n, dtype=torch.int32, device=dev))
+        check(L.iamx_match_postfilter(_ptr(ws.surv_off), _ptr(ws.surv_cnt), _ptr(ws.surv_q),
+                                      _ptr(ws.surv_t), _ptr(ws.surv_metric), _ptr(pb.d_pairs),
+                                      _ptr(kp_off), _ptr(xy), _ptr(key2), n, float(cam_w),
+                                      float(cam_h), float(min_pairs), 5.0, _ptr(post['cnt']),
+                                      _ptr(post['pairs']), _ptr(post['scratch']), _ptr(post['stat']),
+                                      _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
     torch.cuda.current_stream().synchronize()
     if int(ws.zero_div.item()):
         raise ZeroDivisionError("float division by zero")       # matcher.py:255
     first, count, sq, st, sm = ws.survivors(pb.n_pairs)
-    n = len(batch)
+    if post is not None:
+        cnt = post['cnt'].cpu().numpy()
+        status = post['status'].cpu().numpy()
+        lists = post['pairs'].cpu().numpy()
     out = []
     for k in range(n):
-        res = []
-        for p in (k, n + k):
-            a, b = first[p], first[p] + count[p]
-            res.append((_threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), int(b - a)))
-        out.append(res)
+        n_fwd, n_rev = int(count[k]), int(count[n + k])
+        if post is not None and status[k] == 0:
+            fwd = lists[k, :cnt[k]].tolist()
+            rev = [[b, a] for a, b in fwd]
+        else:
+            i1, i2 = batch[k]
+            xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
+            a, b = first[k], first[k] + count[k]
+            fwd = _post_filter(i1, i2, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), (xy1, xy2))
+            rev = []
+            if len(fwd) >= min_pairs:
+                a, b = first[n + k], first[n + k] + count[n + k]
+                rev = _post_filter(i2, i1, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]),
+                                   (xy2, xy1))
+            fwd, rev = filter_cross_check(fwd, rev)
+        out.append((fwd, rev, n_fwd, n_rev))
     return out
 
 
+def _camera_size():
+    cam = _deps.camera()
+    w, h = cam.get_image_params()
+    if not w or not h:
+        _log("Zero image sizes will crash matchGMS():", w, h)
+        _log("Recommend removing all meta/*.feat files and")
+        _log("rerun the matching step.")
+        _log("... or do some coding to add this information to the")
+        _log("ImageAnalysis/meta/<image_name>.json files")
+        quit()
+    return w, h
+
+
 def _process_batch(lines, match_ratio):
-    """lines: [(dist, i, j, i1, i2)].  Device k=2 NN + threshold for both directions of every
-    pair, then the host filters.  Returns [(i, j, match_fwd, match_rev, n_fwd, n_rev)]."""
+    """lines: [(dist, i, j, i1, i2)].  Returns [(i, j, match_fwd, match_rev)]."""
     batch = [(l[3], l[4]) for l in lines]
-    xys = [(_kp_xy(a), _kp_xy(b)) for a, b in batch]
     results = _match_batch(batch, match_ratio)
     out = []
-    for (dist, i, j, i1, i2), ((fwd_t, n_fwd), (rev_t, n_rev)), (xy1, xy2) in \
-            zip(lines, results, xys):
+    for (dist, i, j, i1, i2), (match_fwd, match_rev, n_fwd, n_rev) in zip(lines, results):
         _qlog("Matching %s vs %s" % (i1.name, i2.name))
         _qlog("  separation (approx) = %.0f (m)" % dist)
-        # ---- both directions, then the cross check (:304-318)
-        _qlog("  raw matches:", len(xy1))
+        _qlog("  raw matches:", len(i1.kp_list))
         _qlog("  quality matches:", n_fwd)
-        match_fwd = _post_filter(i1, i2, fwd_t, (xy1, xy2))
-        if len(match_fwd) >= min_pairs:
-            _qlog("  raw matches:", len(xy2))
-            _qlog("  quality matches:", n_rev)
-            match_rev = _post_filter(i2, i1, rev_t, (xy2, xy1))
-        else:
-            match_rev = []
-        match_fwd, match_rev = filter_cross_check(match_fwd, match_rev)
+        _qlog("  raw matches:", len(i2.kp_list))
+        _qlog("  quality matches:", n_rev)
+        _qlog("  cross checked matches:", len(match_fwd))
         out.append((i, j, match_fwd, match_rev))
     return out
 

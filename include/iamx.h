@@ -173,6 +173,33 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
                        int32_t *surv_t, double *surv_metric, int32_t *surv_cnt, int n_pairs,
                        int32_t *zero_div, int32_t *n_unresolved, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Per-pair match filters on the device, both directions of n_pairs image pairs, one workgroup
+ * per pair -- replaces the python between the metric threshold and find_matches' bookkeeping:
+ *   scripts/lib/matcher.py:258-269 (stable sort by metric, clip 2000), :271-283 (< min_pairs),
+ *   :285 cv2.xfeatures2d.matchGMS(withRotation=True, withScale=False, thresholdFactor),
+ *   :157-182 filter_duplicates, :296-299, :304-318 (reverse only if forward kept >= min_pairs),
+ *   :187-200 filter_cross_check.
+ * Ordered pair k (k < n_pairs) is the forward direction of pair k, ordered pair n_pairs + k its
+ * reverse: surv_off DEV [2 n_pairs + 1], surv_cnt DEV [2 n_pairs], pairs DEV [2 n_pairs][2]
+ * (image slots) and surv_q/_t/_metric are the outputs of the matching stage.
+ *   kp_off DEV [n_images] int64   first keypoint of an image slot in xy / key2
+ *   xy     DEV [total kp][2] f32  kp.pt (full-res pixels, inside [0,width) x [0,height))
+ *   key2   DEV [total kp][2] i32  round-half-even(100 * kp.pt): the "%.2f" keys of :166-167
+ *   out_cnt DEV [n_pairs], out_pairs DEV [n_pairs][clip][2]: the cross-checked forward list
+ *   [query row, train row] (the reverse list is its mirror); scratch DEV [n_pairs][2][clip][2];
+ *   out_stat DEV [n_pairs][4]: forward after GMS / after de-dup, reverse after GMS / after
+ *   de-dup (-1 = stage not reached); status DEV [n_pairs]: 1 = a direction has more than 4096
+ *   survivors and must take the host path.  clip = iamx_match_postfilter_clip() = 2000.
+ * ------------------------------------------------------------------------------------ */
+int iamx_match_postfilter_clip(void);
+int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, const int32_t *surv_q,
+                          const int32_t *surv_t, const double *surv_metric, const int32_t *pairs,
+                          const int64_t *kp_off, const float *xy, const int32_t *key2, int n_pairs,
+                          double width, double height, double min_pairs, double threshold_factor,
+                          int32_t *out_cnt, int32_t *out_pairs, int32_t *scratch,
+                          int32_t *out_stat, int32_t *status, void *stream);
+
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);
 

@@ -43,6 +43,58 @@ def test_pair_matches_equal_reference(path):
     assert np.array_equal(np.array(r).reshape(-1, 2), g['bidir_rev'])
 
 
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_device_post_filter_equals_reference(path):
+    """iamx_match_postfilter (sort/clip, GMS, de-dup, gates, cross check on the device) ==
+    the reference's bidirectional_pair_matches output == the host filters."""
+    g = np.load(path)
+    ratio = float(g['match_ratio'])
+    matcher = _configure(ratio, int(g['min_pairs']))
+    i1, i2 = _image('A', g['des1'], g['xy1']), _image('B', g['des2'], g['xy2'])
+    (f, r, _nf, _nr), = matcher._match_batch([(i1, i2)], ratio)
+    assert np.array_equal(np.array(f).reshape(-1, 2), g['bidir_fwd'])
+    assert np.array_equal(np.array(r).reshape(-1, 2), g['bidir_rev'])
+    (f2, r2, _nf2, _nr2), = matcher._match_batch([(i1, i2)], ratio, device_filters=False)
+    assert f == f2 and r == r2
+    assert all(type(v) is int for pair in f for v in pair)
+
+
+def test_device_post_filter_dense_duplicates_and_gates():
+    """many pairs in one launch: dense motion-consistent matches (GMS keeps), random matches
+    (GMS rejects), repeated keypoint positions (de-dup replay), pairs below min_pairs, pairs
+    whose reverse direction fails; device lists == host filters on the same survivors."""
+    from test_match_gpu import _sift_like
+    matcher = _configure(0.75, 25)
+    rng = np.random.default_rng(123)
+    W, H = 5472, 3648
+    base = _sift_like(rng, 1500)
+    base_xy = np.stack([rng.uniform(300, W - 900, 1500), rng.uniform(300, H - 600, 1500)], 1)
+    imgs = []
+    for k in range(8):
+        n = int(rng.integers(900, 1500))
+        d = _sift_like(rng, n)
+        xy = np.stack([rng.uniform(0, W - 1, n), rng.uniform(0, H - 1, n)], 1)
+        m = int((0.05, 0.3, 0.6, 0.9, 0.02, 0.5, 0.7, 0.4)[k] * 900)
+        src, dst = rng.permutation(1500)[:m], rng.permutation(n)[:m]
+        d[dst] = np.clip(base[src].astype(int) + rng.integers(-6, 7, (m, 128)), 0, 255)
+        xy[dst] = base_xy[src] + [40.0 * k, -25.0 * k] + rng.normal(0, 0.5, (m, 2))
+        if k in (2, 5):                       # same pixel position for many keypoints
+            xy[dst[:m // 3]] = np.round(xy[dst[:m // 3]] / 8) * 8
+            d[dst[m // 2:m // 2 + 50]] = d[dst[:50]]          # and twin descriptors
+        if k == 6:                            # geometry scrambled: matches exist, GMS rejects
+            xy[dst] = np.stack([rng.uniform(0, W - 1, m), rng.uniform(0, H - 1, m)], 1)
+        imgs.append(_image('D%d' % k, d, np.clip(xy, 0, [W - 1, H - 1]).astype(np.float32)))
+    batch = [(imgs[a], imgs[b]) for a in range(8) for b in range(a + 1, 8)]
+    dev = matcher._match_batch(batch, 0.75)
+    host = matcher._match_batch(batch, 0.75, device_filters=False)
+    n_nonempty = 0
+    for (a, b), d_, h_ in zip(batch, dev, host):
+        assert d_[0] == h_[0] and d_[1] == h_[1], (a.name, b.name)
+        assert d_[2:] == h_[2:]
+        n_nonempty += len(d_[0]) > 0
+    assert 8 <= n_nonempty < len(batch)
+
+
 def test_find_matches_batched_equals_pairwise_oracle():
     """find_matches over a 7-image strip: every match list == the oracle's bidirectional
     pipeline for that pair; already-matched pairs are skipped, empty ones retried."""
