@@ -50,7 +50,8 @@ def _strip(n_img=6, seed=5):
 
 
 def _oracle_match_batch(batch, match_ratio):
-    """stand-in for matcher._match_batch (device) used only by this CPU test"""
+    """stand-in for matcher._match_batch (device) used only by this CPU test: oracle k=2 NN +
+    threshold, then the host filters; same return format (fwd, rev, n_fwd, n_rev)"""
     from imageanalysis_amd import matcher
     from oracle import match_oracle as mo
     out = []
@@ -63,7 +64,10 @@ def _oracle_match_batch(batch, match_ratio):
             keep = np.nonzero(metric < matcher.max_distance * match_ratio)[0]
             res.append((matcher._threshold_sort_clip(keep.astype(np.int32), idx[keep, 0],
                                                      metric[keep]), len(keep)))
-        out.append(res)
+        fwd = matcher._post_filter(a, b, res[0][0])
+        rev = matcher._post_filter(b, a, res[1][0]) if len(fwd) >= matcher.min_pairs else []
+        fwd, rev = matcher.filter_cross_check(fwd, rev)
+        out.append((fwd, rev, res[0][1], res[1][1]))
     return out
 
 
