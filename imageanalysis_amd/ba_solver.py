@@ -389,12 +389,16 @@ _R = {k: 2 * len(_S) + i for i, k in enumerate(
 
 def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None,
                       chunk=64):
-    """Same recurrence as lsmr_device with the scalars resident on the device: iterations are
-    enqueued `chunk` at a time by iamx_ba_lsmr_iterate (3 launches each) and the host only
-    reads the state block between chunks (single rank, no calibration columns)."""
+    """Same recurrence as lsmr_device with the scalars resident on the device.  Single rank:
+    iterations are enqueued `chunk` at a time by iamx_ba_lsmr_iterate (3 launches each).
+    Several ranks (observations sharded by point): every iteration is three
+    iamx_ba_lsmr_phase calls with two RCCL all-reduces between them (|ut1|^2 and J^T ut1), all
+    enqueued asynchronously.  Either way the host only reads the state block between chunks.
+    No calibration columns."""
     n, m = prob.n, prob.m
     dev = prob.dev
     L = lib()
+    multi = prob.world > 1
     if maxiter is None:
         maxiter = n
     chunk = max(2, int(chunk) & ~1)
@@ -404,21 +408,23 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
         ws = prob.lsmr_ws = dict(u1=z(m), u2=z(n), vt=z(n), h=z(n), hbar=z(n), x=z(n),
                                  Jc_s=z(prob.O * 14), Jp_s=z(prob.O * 6), Jp_p=z(prob.O * 6),
                                  state=z(L.iamx_ba_lsmr_state_size()),
-                                 part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)))
+                                 part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
+                                 xr=z(1), tbuf=z(n if multi else 1))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
     ph = _Phase(prob, 'lsmr:init')
     ph.__enter__()
-    check(L.iamx_ba_lsmr_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx),
-                                 _ptr(prob.pt_idx), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
-                                 _ptr(d_dev), _ptr(ws['Jc_s']), _ptr(ws['Jp_s']),
-                                 _ptr(ws['Jp_p']), stream_ptr()), 'iamx_ba_lsmr_prepare')
+    if prob.O:
+        check(L.iamx_ba_lsmr_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx),
+                                     _ptr(prob.pt_idx), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
+                                     _ptr(d_dev), _ptr(ws['Jc_s']), _ptr(ws['Jp_s']),
+                                     _ptr(ws['Jp_p']), stream_ptr()), 'iamx_ba_lsmr_prepare')
     u1[:m].copy_(prob.r[:m])
     u2.zero_(); hbar.zero_(); x.zero_()
-    normb = np.sqrt(prob.dot(u1, u1, m, False))
+    normb = np.sqrt(prob.dot(u1, u1, m, True))
     beta = normb
     alpha = 0.0
     if beta > 0:
-        prob.jtv(u1, prob.tmp_n)
+        prob.jtv(u1, prob.tmp_n)                   # all-reduced over ranks inside
         prob.mul2(n, d_dev, prob.tmp_n, vt)
         prob.axpby(n, 0.0, vt, 1.0 / beta, vt)
         alpha = np.sqrt(prob.dot(vt, vt, n, False))
@@ -440,13 +446,23 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     ph.__exit__()
     ph = _Phase(prob, 'lsmr:iterate')
     ph.__enter__()
+    common = (_ptr(ws['Jc_s']), _ptr(ws['Jp_s']), _ptr(ws['Jp_p']), _ptr(prob.cam_idx),
+              _ptr(prob.pt_idx), _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), prob.O,
+              prob.C, prob.P, _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h), _ptr(hbar),
+              _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
     for _ in range(int(maxiter) // chunk + 3):
-        check(L.iamx_ba_lsmr_iterate(_ptr(ws['Jc_s']), _ptr(ws['Jp_s']), _ptr(ws['Jp_p']),
-                                     _ptr(prob.cam_idx), _ptr(prob.pt_idx), _ptr(prob.cam_ptr),
-                                     _ptr(prob.pt_ptr), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
-                                     _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h),
-                                     _ptr(hbar), _ptr(x), _ptr(ws['state']), _ptr(ws['part']),
-                                     chunk, stream_ptr()), 'iamx_ba_lsmr_iterate')
+        if not multi:
+            check(L.iamx_ba_lsmr_iterate(*common, chunk, stream_ptr()), 'iamx_ba_lsmr_iterate')
+        else:
+            xr, tbuf = ws['xr'], ws['tbuf']
+            tail = (_ptr(xr), _ptr(tbuf))
+            for it in range(chunk):
+                par = it & 1
+                check(L.iamx_ba_lsmr_phase(*common, *tail, 0, par, stream_ptr()), 'iamx_ba_lsmr_phase')
+                _dist.allreduce_sum_(xr)
+                check(L.iamx_ba_lsmr_phase(*common, *tail, 1, par, stream_ptr()), 'iamx_ba_lsmr_phase')
+                _dist.allreduce_sum_(tbuf[:n])
+                check(L.iamx_ba_lsmr_phase(*common, *tail, 2, par, stream_ptr()), 'iamx_ba_lsmr_phase')
         st = prob.download(ws['state'], st.size)
         if st[_R['ISTOP']] != 0:
             break
@@ -461,7 +477,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
 
 def lsmr(prob, d_dev, dreg_dev, **opts):
     """fused host-free iterations when the problem allows it, else the stepwise form."""
-    if prob.world == 1 and not prob.with_calib and prob.O and not prob.force_stepwise_lsmr:
+    if not prob.with_calib and not prob.force_stepwise_lsmr and (prob.O or prob.world > 1):
         return lsmr_device_fused(prob, d_dev, dreg_dev, **opts)
     return lsmr_device(prob, d_dev, dreg_dev, **opts)
 

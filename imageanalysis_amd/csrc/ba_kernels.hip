@@ -124,10 +124,21 @@ __global__ __launch_bounds__(256) void ba_residual_rt_kernel(
         const int2 ci = *reinterpret_cast<const int2 *>(cam_idx + o);
         const int2 pi = *reinterpret_cast<const int2 *>(pt_idx + o);
         const double4 ob = *reinterpret_cast<const double4 *>(uv + 2 * o);
-        const double2 r0 = residual_rt(rt + (int64_t)ci.x * 12, pts + (int64_t)pi.x * 3,
-                                       make_double2(ob.x, ob.y), cal);
-        const double2 r1 = residual_rt(rt + (int64_t)ci.y * 12, pts + (int64_t)pi.y * 3,
-                                       make_double2(ob.z, ob.w), cal);
+        // observations are camera-major: almost every wave sees a single camera, whose block
+        // then comes through the scalar cache (12 s_loads per wave instead of 24 vector loads
+        // per lane)
+        const int c0 = __builtin_amdgcn_readfirstlane(ci.x);
+        double2 r0, r1;
+        if (__all(ci.x == c0 && ci.y == c0)) {
+            const double *R = rt + (int64_t)c0 * 12;
+            r0 = residual_rt(R, pts + (int64_t)pi.x * 3, make_double2(ob.x, ob.y), cal);
+            r1 = residual_rt(R, pts + (int64_t)pi.y * 3, make_double2(ob.z, ob.w), cal);
+        } else {
+            r0 = residual_rt(rt + (int64_t)ci.x * 12, pts + (int64_t)pi.x * 3,
+                             make_double2(ob.x, ob.y), cal);
+            r1 = residual_rt(rt + (int64_t)ci.y * 12, pts + (int64_t)pi.y * 3,
+                             make_double2(ob.z, ob.w), cal);
+        }
         *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
     } else {
         const double2 ob = *reinterpret_cast<const double2 *>(uv + 2 * o);

@@ -363,7 +363,13 @@ struct LsmrArgs {
     double *S;                   // state block [R_COUNT]
     double *partU, *partV, *partX;
     int n_partV;
+    // multi-rank form (observations sharded by point, n-vectors replicated): the two sums that
+    // span ranks leave the chain through `xr[0]` (local |ut1|^2) and `tbuf` (local J^T ut1, n
+    // doubles), which the caller all-reduces between the phases; null on a single rank.
+    double *partU2;
+    double *xr, *tbuf;
 };
+
 
 constexpr int LS_FWD_BLOCKS = 1024;   // fixed grids => fixed reduction trees
 constexpr int LS_UPD_BLOCKS = 1024;
@@ -397,6 +403,14 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
     return block_sum_256(acc, sh);
+}
+
+// beta' = |ut'|: single rank from the forward kernel's partials; multi rank from the all-reduced
+// rank-local part xr[0] plus the replicated part
+__device__ __forceinline__ double beta_new(const LsmrArgs &A, double *sh)
+{
+    if (A.xr) return sqrt(A.xr[0] + sum_partials(A.partU2, LS_FWD_BLOCKS, sh));
+    return sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
 }
 
 // one thread per observation: scaled SoA copies in observation order
@@ -498,13 +512,29 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
         acc += u.x * u.x + u.y * u.y;
     }
     const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    double acc2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_FWD_BLOCKS * 256) {
         const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
         A.u2[i] = v;
-        acc += v * v;
+        acc2 += v * v;
     }
-    const double s = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) A.partU[blockIdx.x] = s;
+    if (A.xr) {                  // rank-local and replicated parts are summed separately
+        const double s1 = block_sum_256(acc, sh);
+        const double s2 = block_sum_256(acc2, sh);
+        if (threadIdx.x == 0) { A.partU[blockIdx.x] = s1; A.partU2[blockIdx.x] = s2; }
+    } else {
+        const double s = block_sum_256(acc + acc2, sh);
+        if (threadIdx.x == 0) A.partU[blockIdx.x] = s;
+    }
+}
+
+// multi-rank: xr[0] = this rank's |ut1|^2 (all-reduced by the caller before the next phase)
+__global__ __launch_bounds__(256) void lsmr_sumU_kernel(LsmrArgs A)
+{
+    __shared__ double sh[4];
+    if (A.S[R_ISTOP] != 0.0) { if (threadIdx.x == 0) A.xr[0] = 0.0; return; }
+    const double s = sum_partials(A.partU, LS_FWD_BLOCKS, sh);
+    if (threadIdx.x == 0) A.xr[0] = s;
 }
 
 // ---- kernel B: beta', then vt' ---------------------------------------------------------------
@@ -520,14 +550,19 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
     __shared__ double sh[4];
     __shared__ double red[4][7];
     __shared__ double prod[3][ADJ_CH];
-    if (A.S[R_ISTOP] != 0.0) return;
+    const bool raw = A.tbuf != nullptr;          // multi-rank: only the local J^T ut1, no update
+    if (A.S[R_ISTOP] != 0.0) return;             // (tbuf keeps stale values: nobody reads them)
     const double *in = A.S + parity * S_NBUF;
-    const double bn = sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
-    if (!(bn > 0)) {             // exact solution reached: v keeps its value (lsmr.py "if beta > 0")
-        if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
-        return;
+    double ib = 0.0, ba = 0.0;
+    if (!raw) {
+        const double bn = beta_new(A, sh);
+        if (!(bn > 0)) {         // exact solution reached: v keeps its value (lsmr.py "if beta > 0")
+            if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
+            return;
+        }
+        ib = 1.0 / bn;
+        ba = bn / in[S_ALPHA];
     }
-    const double ib = 1.0 / bn, ba = bn / in[S_ALPHA];
     const int64_t O = A.n_obs;
     const int n_pt_blocks = (A.n_pts + 255) / 256;
     double sq = 0.0;
@@ -565,6 +600,7 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int64_t i = (int64_t)A.n_cams * 7 + (int64_t)p * 3 + k;
+                if (raw) { A.tbuf[i] = acc[k]; continue; }
                 const double v = (acc[k] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
                 A.vt[i] = v;
                 sq += v * v;
@@ -593,10 +629,38 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
             const int k = threadIdx.x;
             const double t = red[0][k] + red[1][k] + red[2][k] + red[3][k];
             const int64_t i = (int64_t)c * 7 + k;
-            const double v = (t + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
-            A.vt[i] = v;
-            sq = v * v;
+            if (raw) {
+                A.tbuf[i] = t;
+            } else {
+                const double v = (t + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
+                A.vt[i] = v;
+                sq = v * v;
+            }
         }
+    }
+    if (raw) return;
+    const double s = block_sum_256(sq, sh);
+    if (threadIdx.x == 0) A.partV[blockIdx.x] = s;
+}
+
+// multi-rank: vt' from the all-reduced J^T ut1 (tbuf), squared-norm partials
+__global__ __launch_bounds__(256) void lsmr_vt_kernel(LsmrArgs A, int parity)
+{
+    __shared__ double sh[4];
+    if (A.S[R_ISTOP] != 0.0) return;
+    const double *in = A.S + parity * S_NBUF;
+    const double bn = beta_new(A, sh);
+    if (!(bn > 0)) {
+        if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
+        return;
+    }
+    const double ib = 1.0 / bn, ba = bn / in[S_ALPHA];
+    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    double sq = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_UPD_BLOCKS * 256) {
+        const double v = (A.tbuf[i] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
+        A.vt[i] = v;
+        sq += v * v;
     }
     const double s = block_sum_256(sq, sh);
     if (threadIdx.x == 0) A.partV[blockIdx.x] = s;
@@ -610,7 +674,7 @@ __global__ __launch_bounds__(256) void lsmr_update3_kernel(LsmrArgs A, int parit
     if (S[R_ISTOP] != 0.0) return;
     const double *in = S + parity * S_NBUF;
     double *out = S + (1 - parity) * S_NBUF;
-    const double beta = sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
+    const double beta = beta_new(A, sh);
     const double s2 = sum_partials(A.partV, A.n_partV, sh);
     const double alpha = beta > 0 ? sqrt(s2) : in[S_ALPHA];
 
@@ -684,7 +748,8 @@ extern "C" int iamx_ba_lsmr_state_size(void) { return R_COUNT; }
 
 extern "C" int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts)
 {
-    return (int64_t)LS_FWD_BLOCKS + LS_UPD_BLOCKS + n_cams + (n_pts + 255) / 256;
+    const int64_t n_adj = (int64_t)n_cams + (n_pts + 255) / 256;
+    return (int64_t)2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS + (n_adj > LS_UPD_BLOCKS ? n_adj : LS_UPD_BLOCKS);
 }
 
 extern "C" int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
@@ -719,8 +784,8 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
     const int n_adj_blocks = n_cams + (n_pts + 255) / 256;
     LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
-               partials, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
-               n_adj_blocks};
+               partials, partials + 2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
+               n_adj_blocks, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, nullptr, nullptr};
     hipStream_t st = iamx::as_stream(stream);
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
@@ -729,4 +794,41 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
     }
     return iamx::check_launch("iamx_ba_lsmr_iterate");
+}
+
+// One phase of one iteration of the multi-rank form (the caller all-reduces xr[0] after phase 0
+// and tbuf[0..n) after phase 1, on the same stream):
+//   phase 0: stopping tests of the previous iteration, ut', xr[0] = local |ut1'|^2
+//   phase 1: tbuf = local J^T ut1'
+//   phase 2: vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
+extern "C" int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
+                                  const int32_t *cam_idx, const int32_t *pt_idx,
+                                  const int32_t *cam_ptr, const int32_t *pt_ptr,
+                                  const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+                                  const double *dreg, double *u1, double *u2, double *vt, double *h,
+                                  double *hbar, double *x, double *state, double *partials,
+                                  double *xr, double *tbuf, int phase, int parity, void *stream)
+{
+    IAMX_REQUIRE(Jc_s && Jp_s && Jp_p && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && dreg &&
+                     u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
+                 "null pointer");
+    IAMX_REQUIRE(n_obs >= 0 && n_cams > 0 && n_pts > 0 && phase >= 0 && phase <= 2 &&
+                     (parity == 0 || parity == 1),
+                 "bad size / phase / parity");
+    const int n_adj_blocks = n_cams + (n_pts + 255) / 256;
+    LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
+               dreg, u1, u2, vt, h, hbar, x, state,
+               partials, partials + 2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
+               LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, xr, tbuf};
+    hipStream_t st = iamx::as_stream(stream);
+    if (phase == 0) {
+        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(LS_FWD_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A);
+    } else if (phase == 1) {
+        hipLaunchKernelGGL(lsmr_adj_kernel, dim3(n_adj_blocks), dim3(256), 0, st, A, parity);
+    } else {
+        hipLaunchKernelGGL(lsmr_vt_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
+    }
+    return iamx::check_launch("iamx_ba_lsmr_phase");
 }

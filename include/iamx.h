@@ -315,6 +315,18 @@ int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *J
                          double *h, double *hbar, double *x, double *state, double *partials,
                          int n_iter, void *stream);
 
+/* Multi-rank form of the same iteration (observations sharded by point, n-vectors replicated):
+ * one call per phase; the caller all-reduces (sum) xr[0] after phase 0 and tbuf[0..n) after
+ * phase 1 on the same stream (RCCL).  phase 0: stopping tests of the previous iteration, ut',
+ * xr[0] = local |ut1'|^2;  phase 1: tbuf = local J^T ut1';  phase 2: vt' from the reduced tbuf,
+ * alpha', plane rotations, h / hbar / x.  parity = iteration & 1.  xr DEV [1], tbuf DEV [n]. */
+int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
+                       const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
+                       const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                       int n_pts, const double *dreg, double *u1, double *u2, double *vt, double *h,
+                       double *hbar, double *x, double *state, double *partials, double *xr,
+                       double *tbuf, int phase, int parity, void *stream);
+
 /* float64 vector kernels used by the device LSMR (scipy/sparse/linalg/_isolve/lsmr.py):
  *   axpby: y = a*x + b*y (b == 0 ignores y's old content)
  *   mul2:  out = a.*b (+ c.*d when c != NULL)
