@@ -479,11 +479,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(const int8_t *__restrict__
         const int q = surv_q[s], tile = surv_t[s];
         const int best = d2[2 * (ob + q)];
         const int trow = toff + tile * 32 + j;
-        const int *qa = reinterpret_cast<const int *>(desc_q + (int64_t)(qoff + q) * D);
-        const int *ta = reinterpret_cast<const int *>(desc_t + (int64_t)trow * D);
+        const v4i *qa = reinterpret_cast<const v4i *>(desc_q + (int64_t)(qoff + q) * D);
+        const v4i *ta = reinterpret_cast<const v4i *>(desc_t + (int64_t)trow * D);
         int dot = 0;
-#pragma unroll 8
-        for (int k = 0; k < 32; ++k) dot = __builtin_amdgcn_sdot4(qa[k], ta[k], dot, false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const v4i a = qa[k], b = ta[k];
+            dot = __builtin_amdgcn_sdot4(a.x, b.x, dot, false);
+            dot = __builtin_amdgcn_sdot4(a.y, b.y, dot, false);
+            dot = __builtin_amdgcn_sdot4(a.z, b.z, dot, false);
+            dot = __builtin_amdgcn_sdot4(a.w, b.w, dot, false);
+        }
         const int dd = norm_q[qoff + q] + norm2_t[trow] - 2 * dot;
         const int orig = perm[trow];
         const unsigned long long m = __ballot(orig >= 0 && dd == best);
@@ -535,11 +541,17 @@ __global__ __launch_bounds__(256) void finish_kernel(const int8_t *__restrict__ 
             const v2i dd2 = *reinterpret_cast<const v2i *>(d2 + 2 * (ob + q));
             const int best = dd2.x;
             const int trow = toff + tile * 32 + j;
-            const int *qa = reinterpret_cast<const int *>(desc_q + (int64_t)(qoff + q) * D);
-            const int *ta = reinterpret_cast<const int *>(desc_t + (int64_t)trow * D);
+            const v4i *qa = reinterpret_cast<const v4i *>(desc_q + (int64_t)(qoff + q) * D);
+            const v4i *ta = reinterpret_cast<const v4i *>(desc_t + (int64_t)trow * D);
             int dot = 0;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) dot = __builtin_amdgcn_sdot4(qa[k], ta[k], dot, false);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {            // 16-byte loads: 8 per row instead of 32
+                const v4i a = qa[k], b = ta[k];
+                dot = __builtin_amdgcn_sdot4(a.x, b.x, dot, false);
+                dot = __builtin_amdgcn_sdot4(a.y, b.y, dot, false);
+                dot = __builtin_amdgcn_sdot4(a.z, b.z, dot, false);
+                dot = __builtin_amdgcn_sdot4(a.w, b.w, dot, false);
+            }
             const int orig = perm[trow];
             const int dd = orig >= 0 ? norm_q[qoff + q] + norm2_t[trow] - 2 * dot : 0x7FFFFFFF;
             const unsigned long long m = __ballot(dd == best);
