@@ -69,6 +69,25 @@ class DeviceBA(object):
         pt = np.asarray(point_indices, np.int64)
         uv = np.asarray(points_2d, np.float64).reshape(-1, 2)
         self.rank, self.world = rank, world
+        # Internal point order: by the first camera that observes a point (then by id).  The
+        # reference numbers points by chain length, unrelated to where they are; with
+        # camera-major observations that turns every 24-byte point access of the residual /
+        # Jacobian / J.v kernels into a random gather over the whole point array.  Renumbered,
+        # a camera's points sit in a few contiguous runs.  The permutation is private to this
+        # class: host n-vectors keep the reference's order and cross through upload_n /
+        # download_n.  It is computed from ALL observations, so every rank uses the same one.
+        first_cam = np.full(self.P, self.C, np.int64)
+        if cam.size:
+            np.minimum.at(first_cam, pt, cam)
+        old_of_new = np.lexsort((np.arange(self.P), first_cam))
+        new_of_old = np.empty(self.P, np.int64)
+        new_of_old[old_of_new] = np.arange(self.P)
+        pt = new_of_old[pt]
+        tail = np.arange(self.C * 7 + self.P * 3, self.n)
+        h2i = np.concatenate([np.arange(self.C * 7),
+                              (self.C * 7 + 3 * old_of_new[:, None] + np.arange(3)).ravel(), tail])
+        i2h = np.concatenate([np.arange(self.C * 7),
+                              (self.C * 7 + 3 * new_of_old[:, None] + np.arange(3)).ravel(), tail])
         if world > 1:
             sel = _dist.shard_observations_by_point(pt, self.P, rank, world)
             cam, pt, uv = cam[sel], pt[sel], uv[sel]
@@ -88,6 +107,7 @@ class DeviceBA(object):
         self.cam_idx, self.pt_idx = t(cam, I32), t(pt, I32)
         self.cam_ptr, self.pt_ptr, self.pt_obs = t(cam_ptr, I32), t(pt_ptr, I32), t(order, I32)
         self.uv = t(uv, F64)
+        self.idx_h2i, self.idx_i2h = t(h2i, torch.int64), t(i2h, torch.int64)
         z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
         self.x = z(self.n)
         self.calib = z(9)
@@ -98,6 +118,7 @@ class DeviceBA(object):
         self.cam_rt = z(self.C * 12)
         self.out1 = z(4)
         self.tmp_n, self.tmp_n2, self.tmp_m, self.tmp_m2 = z(self.n), z(self.n), z(self.m), z(self.m)
+        self.tmp_perm = z(self.n)
         self.lsmr_ws = None
         self._pin = None
         self.profile = None
@@ -131,10 +152,23 @@ class DeviceBA(object):
         torch.cuda.current_stream().synchronize()
         return st.numpy().copy()
 
+    def upload_n(self, a, out=None):
+        """host n-vector (reference order) -> device n-vector (internal point order)"""
+        raw = self.upload(a, out=self.tmp_perm)
+        if out is None:
+            out = torch.empty(max(self.n, 1), dtype=F64, device=self.dev)
+        torch.index_select(raw[:self.n], 0, self.idx_h2i, out=out[:self.n])
+        return out
+
+    def download_n(self, t):
+        """device n-vector (internal point order) -> host n-vector (reference order)"""
+        torch.index_select(t[:self.n], 0, self.idx_i2h, out=self.tmp_perm[:self.n])
+        return self.download(self.tmp_perm, self.n)
+
     # ---- parameters ------------------------------------------------------------------
     def set_x(self, x):
         x = np.ascontiguousarray(x, np.float64)
-        self.upload(x, out=self.x)
+        self.upload_n(x, out=self.x)
         if self.with_calib:
             c = x[self.C * 7 + self.P * 3:]
             cal = np.array([c[0], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]])
@@ -156,6 +190,19 @@ class DeviceBA(object):
                                                   _ptr(self.cam_rt), _ptr(r), stream_ptr()),
                   'iamx_ba_residual_prepared')
         return r
+
+    def bound_launchers(self):
+        """(residual, residual_jac) as zero-argument callables with the ctypes arguments bound
+        once -- for timing the kernels without the per-call python marshalling."""
+        cams, pts = self._cams_pts()
+        L = lib()
+        a1 = (_ptr(cams), self.C, _ptr(pts), self.P, _ptr(self.cam_idx), _ptr(self.pt_idx),
+              _ptr(self.uv), self.O, _ptr(self.calib), _ptr(self.cam_rt), _ptr(self.r), stream_ptr())
+        a2 = (_ptr(cams), self.C, _ptr(pts), self.P, _ptr(self.cam_idx), _ptr(self.pt_idx),
+              _ptr(self.uv), self.O, _ptr(self.calib), _ptr(self.r), _ptr(self.Jc), _ptr(self.Jp),
+              _ptr(self.Jk), stream_ptr())
+        f1, f2 = L.iamx_ba_residual_prepared, L.iamx_ba_residual_jac
+        return (lambda: f1(*a1)), (lambda: f2(*a2))
 
     def residual_jac(self):
         cams, pts = self._cams_pts()
@@ -213,19 +260,19 @@ class DeviceBA(object):
     def grad(self):
         """J^T r -> host n-vector."""
         self.jtv(self.r, self.tmp_n)
-        return self.download(self.tmp_n, self.n)
+        return self.download_n(self.tmp_n)
 
     def colnorm(self):
         """sqrt of the column sums of J.^2 -> host n-vector (scipy compute_jac_scale)."""
         self.jtv(self.r, self.tmp_n, square=True)
-        return np.sqrt(self.download(self.tmp_n, self.n))
+        return np.sqrt(self.download_n(self.tmp_n))
 
     def gram(self, d_host, vectors):
         """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks."""
         k = len(vectors)
         ys = []
         for s in vectors:
-            vs = self.upload(d_host * s)
+            vs = self.upload_n(d_host * s)
             y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
             self.jv(vs, y)
             ys.append(y)
@@ -307,7 +354,7 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
     normr = beta
     normar = alpha * beta
     if normar == 0 or normb == 0:
-        return prob.download(x, n), istop, itn, normr, normar
+        return prob.download_n(x), istop, itn, normr, normar
 
     while itn < maxiter:
         itn += 1
@@ -376,7 +423,7 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
             istop = 1
         if istop > 0:
             break
-    return prob.download(x, n), istop, itn, normr, normar
+    return prob.download_n(x), istop, itn, normr, normar
 
 
 # state block layout of iamx_ba_lsmr_iterate (csrc/ba_linalg.hip, enums S_* / R_*)
@@ -432,7 +479,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
         prob.axpby(n, 1.0 / alpha, vt, 0.0, h)
     normar = alpha * beta
     if normar == 0 or normb == 0:
-        return prob.download(x, n), 0, 0, beta, normar
+        return prob.download_n(x), 0, 0, beta, normar
     st = np.zeros(L.iamx_ba_lsmr_state_size())
     for k, val in dict(ALPHA=alpha, BETA=beta, ZETABAR=alpha * beta, ALPHABAR=alpha, RHO=1.0,
                        RHOBAR=1.0, CBAR=1.0, SBAR=0.0, BETADD=beta, RHODOLD=1.0,
@@ -471,7 +518,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     ph.__exit__()
     if st[_R['ISTOP']] == 8:
         raise _lib.IamxError('fused LSMR broke down (NaN in the recurrence)')
-    return (prob.download(x, n), int(st[_R['ISTOP']]), int(st[_R['ITN']]), float(st[_R['NORMR']]),
+    return (prob.download_n(x), int(st[_R['ISTOP']]), int(st[_R['ITN']]), float(st[_R['NORMR']]),
             float(st[_R['NORMAR']]))
 
 
@@ -624,8 +671,8 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             reg_term = -ag_value / Delta ** 2
 
         with _Phase(prob, 'lsmr'):
-            d_dev = prob.upload(d)
-            dreg_dev = prob.upload((diag_h + reg_term) ** 0.5)
+            d_dev = prob.upload_n(d)
+            dreg_dev = prob.upload_n((diag_h + reg_term) ** 0.5)
             gn_h, _istop, itn, _nr, _nar = lsmr(prob, d_dev, dreg_dev, **lsmr_opts)
             lsmr_iters += itn
         with _Phase(prob, 'subspace'):

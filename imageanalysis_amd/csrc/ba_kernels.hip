@@ -66,15 +66,10 @@ __device__ __forceinline__ void project_obs(const double *__restrict__ cam,
 }
 
 // per camera: R (ned -> camera, row major) and the camera position; 12 doubles
-__global__ __launch_bounds__(256) void ba_cam_prep_kernel(const double *__restrict__ cams, int n_cams,
-                                                          double *__restrict__ rt)
+__device__ __forceinline__ void cam_block(const double *__restrict__ cam, double *__restrict__ o)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cams) return;
-    const double *cam = cams + (int64_t)c * 7;
     const double w = cam[3], x = cam[4], y = cam[5], z = cam[6];
     const double n = w * w + x * x + y * y + z * z;
-    double *o = rt + (int64_t)c * 12;
     // rows of M(q)^T / n = body-frame axes; camera (X,Y,Z) = body (y1, y2, y0)
     if (n < QEPS) {
         o[0] = 1; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 1; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = 1;
@@ -108,42 +103,60 @@ __device__ __forceinline__ double2 residual_rt(const double *__restrict__ R,
     return make_double2(obs.x - (cal[0] * xd + cal[2]), obs.y - (cal[1] * yd + cal[3]));
 }
 
-// two consecutive observations per thread: 8-byte index loads, 32 bytes of uv in and of r out
-__global__ __launch_bounds__(256) void ba_residual_rt_kernel(
-    const double *__restrict__ rt, const double *__restrict__ pts,
+// One launch: every workgroup (512 observations) first builds the camera blocks of the camera
+// range it touches in LDS (camera-major observations: 1-2 cameras), then evaluates from LDS.
+// A workgroup that spans more than RES_MAXCAM cameras (any observation order is legal) builds
+// the block per observation in registers instead.
+constexpr int RES_MAXCAM = 16;
+
+__global__ __launch_bounds__(256) void ba_residual_lds_kernel(
+    const double *__restrict__ cams, const double *__restrict__ pts,
     const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
     const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
     double *__restrict__ r)
 {
+    __shared__ double Rs[RES_MAXCAM][12];
+    __shared__ int range[2];
     const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (o >= n_obs) return;
+    const bool two = o + 1 < n_obs, one = o < n_obs;
+    int2 ci = make_int2(0, 0);
+    if (two) ci = *reinterpret_cast<const int2 *>(cam_idx + o);
+    else if (one) ci.x = ci.y = cam_idx[o];
+    // camera range of the workgroup (any observation order is handled; camera-major makes it small)
+    int lo = one ? min(ci.x, ci.y) : 0x7FFFFFFF, hi = one ? max(ci.x, ci.y) : -1;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, __shfl_xor(lo, m));
+        hi = max(hi, __shfl_xor(hi, m));
+    }
+    if (threadIdx.x == 0) { range[0] = 0x7FFFFFFF; range[1] = -1; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lo); atomicMax(&range[1], hi); }
+    __syncthreads();
+    const int c_lo = range[0], ncam = range[1] - c_lo + 1;
+    const bool in_lds = ncam <= RES_MAXCAM;
+    if (in_lds && (int)threadIdx.x < ncam) cam_block(cams + (int64_t)(c_lo + threadIdx.x) * 7, Rs[threadIdx.x]);
+    __syncthreads();
+    if (!one) return;
     double cal[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cal[i] = calib[i];
-    if (o + 1 < n_obs) {
-        const int2 ci = *reinterpret_cast<const int2 *>(cam_idx + o);
+    double Rl0[12], Rl1[12];
+    if (!in_lds) {
+        cam_block(cams + (int64_t)ci.x * 7, Rl0);
+        cam_block(cams + (int64_t)ci.y * 7, Rl1);
+    }
+    const double *R0 = in_lds ? Rs[ci.x - c_lo] : Rl0;
+    if (two) {
+        const double *R1 = in_lds ? Rs[ci.y - c_lo] : Rl1;
         const int2 pi = *reinterpret_cast<const int2 *>(pt_idx + o);
         const double4 ob = *reinterpret_cast<const double4 *>(uv + 2 * o);
-        // observations are camera-major: almost every wave sees a single camera, whose block
-        // then comes through the scalar cache (12 s_loads per wave instead of 24 vector loads
-        // per lane)
-        const int c0 = __builtin_amdgcn_readfirstlane(ci.x);
-        double2 r0, r1;
-        if (__all(ci.x == c0 && ci.y == c0)) {
-            const double *R = rt + (int64_t)c0 * 12;
-            r0 = residual_rt(R, pts + (int64_t)pi.x * 3, make_double2(ob.x, ob.y), cal);
-            r1 = residual_rt(R, pts + (int64_t)pi.y * 3, make_double2(ob.z, ob.w), cal);
-        } else {
-            r0 = residual_rt(rt + (int64_t)ci.x * 12, pts + (int64_t)pi.x * 3,
-                             make_double2(ob.x, ob.y), cal);
-            r1 = residual_rt(rt + (int64_t)ci.y * 12, pts + (int64_t)pi.y * 3,
-                             make_double2(ob.z, ob.w), cal);
-        }
+        const double2 r0 = residual_rt(R0, pts + (int64_t)pi.x * 3, make_double2(ob.x, ob.y), cal);
+        const double2 r1 = residual_rt(R1, pts + (int64_t)pi.y * 3, make_double2(ob.z, ob.w), cal);
         *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
     } else {
         const double2 ob = *reinterpret_cast<const double2 *>(uv + 2 * o);
-        *reinterpret_cast<double2 *>(r + 2 * o) =
-            residual_rt(rt + (int64_t)cam_idx[o] * 12, pts + (int64_t)pt_idx[o] * 3, ob, cal);
+        *reinterpret_cast<double2 *>(r + 2 * o) = residual_rt(R0, pts + (int64_t)pt_idx[o] * 3, ob, cal);
     }
 }
 
@@ -301,17 +314,16 @@ extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const d
                                          const double *calib, double *cam_scratch, double *r,
                                          void *stream)
 {
-    IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && r && cam_scratch, "null pointer");
+    IAMX_REQUIRE(cams && pts && cam_idx && pt_idx && uv && calib && r, "null pointer");
     IAMX_REQUIRE(n_cams > 0 && n_pts > 0 && n_obs >= 0, "bad size");
     if (n_obs == 0) return IAMX_OK;
     IAMX_REQUIRE((((uintptr_t)uv | (uintptr_t)r) & 31) == 0 &&
                      (((uintptr_t)cam_idx | (uintptr_t)pt_idx) & 7) == 0,
                  "uv / r must be 32-byte aligned, cam_idx / pt_idx 8-byte aligned");
     hipStream_t st = iamx::as_stream(stream);
-    hipLaunchKernelGGL(ba_cam_prep_kernel, dim3((n_cams + 255) / 256), dim3(256), 0, st, cams,
-                       n_cams, cam_scratch);
-    hipLaunchKernelGGL(ba_residual_rt_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
-                       st, cam_scratch, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
+    (void)cam_scratch;           // kept in the signature; the camera blocks now live in LDS
+    hipLaunchKernelGGL(ba_residual_lds_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
+                       st, cams, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
     return iamx::check_launch("iamx_ba_residual_prepared");
 }
 

@@ -217,11 +217,12 @@ int iamx_ba_residual(const double *cams, int n_cams, const double *pts, int n_pt
                      const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
                      int64_t n_obs, const double *calib, double *r, void *stream);
 
-/* Same residual in two launches: a per-camera rotation/position block (cam_scratch DEV
- * [n_cams][12] float64) is prepared first, the per-observation kernel then does 9 FMAs, one
- * reciprocal and the distortion polynomial (two observations per thread: uv and r must be
- * 32-byte aligned, cam_idx and pt_idx 8-byte aligned).  Results agree with iamx_ba_residual
- * to rounding. */
+/* Same residual, faster form: each workgroup (512 observations, two per thread) builds the
+ * rotation/position blocks of the cameras it touches in LDS first, then does 9 FMAs, one
+ * reciprocal and the distortion polynomial per observation.  Fastest with camera-major
+ * cam_idx (any order is legal).  uv and r must be 32-byte aligned, cam_idx and pt_idx 8-byte
+ * aligned; cam_scratch is unused (may be NULL).  Results agree with iamx_ba_residual to
+ * rounding. */
 int iamx_ba_residual_prepared(const double *cams, int n_cams, const double *pts, int n_pts,
                               const int32_t *cam_idx, const int32_t *pt_idx, const double *uv,
                               int64_t n_obs, const double *calib, double *cam_scratch, double *r,

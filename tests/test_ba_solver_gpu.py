@@ -42,13 +42,15 @@ def test_k4_operators_vs_csr(path):
     v = rng.normal(size=prob.n)
     u = rng.normal(size=prob.m)
     y = torch.empty(prob.m, dtype=torch.float64, device='cuda')
-    prob.jv(torch.from_numpy(v).cuda(), y)
+    prob.jv(prob.upload_n(v), y)               # n-vectors cross in the reference's order
     ref = J @ v
     assert np.abs(y.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
     out = torch.empty(prob.n, dtype=torch.float64, device='cuda')
     prob.jtv(torch.from_numpy(u).cuda(), out)
     ref = J.T @ u
-    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(prob.download_n(out) - ref).max() <= 1e-12 * np.abs(ref).max()
+    # the private point order really is a permutation of the reference's
+    assert np.array_equal(prob.download_n(prob.upload_n(v)), v)
     cn = prob.colnorm()
     ref = np.sqrt(np.asarray(J.power(2).sum(axis=0)).ravel())
     assert np.abs(cn - ref).max() <= 1e-12 * ref.max()
@@ -81,7 +83,7 @@ def test_device_lsmr_equals_scipy_lsmr(path):
     for k in (1, 2, 5, 10):
         ref = lsmr(A, b, atol=0, btol=0, conlim=0, maxiter=k)
         x, istop, itn, normr, normar = ba_solver.lsmr_device(
-            prob, torch.from_numpy(d).cuda(), torch.from_numpy(dreg).cuda(),
+            prob, prob.upload_n(d), prob.upload_n(dreg),
             atol=0, btol=0, conlim=0, maxiter=k)
         assert istop == ref[1] == 7 and itn == ref[2] == k
         assert np.abs(x - ref[0]).max() <= 1e-10 * np.abs(ref[0]).max()
@@ -89,7 +91,7 @@ def test_device_lsmr_equals_scipy_lsmr(path):
     # with the default tolerances both stop on the same test with equally good solutions
     ref = lsmr(A, b, atol=1e-6, btol=1e-6, conlim=1e8)
     x, istop, itn, normr, normar = ba_solver.lsmr_device(
-        prob, torch.from_numpy(d).cuda(), torch.from_numpy(dreg).cuda())
+        prob, prob.upload_n(d), prob.upload_n(dreg))
     assert istop == ref[1] and abs(itn - ref[2]) <= max(3, ref[2] // 10)
     res_dev, res_ref = np.linalg.norm(A @ x - b), np.linalg.norm(A @ ref[0] - b)
     assert abs(res_dev - res_ref) <= 1e-4 * res_ref
@@ -115,7 +117,7 @@ def test_fused_lsmr_equals_stepwise_and_scipy(path):
     dreg = rng.uniform(0.01, 0.1, prob.n)
     A = vstack([J @ diags(d), diags(dreg)]).tocsr()
     b = np.concatenate([g['f0'], np.zeros(prob.n)])
-    dd, dr = torch.from_numpy(d).cuda(), torch.from_numpy(dreg).cuda()
+    dd, dr = prob.upload_n(d), prob.upload_n(dreg)
     for k in (1, 2, 5, 10):
         ref = lsmr(A, b, atol=0, btol=0, conlim=0, maxiter=k)
         x, istop, itn, normr, normar = ba_solver.lsmr_device_fused(

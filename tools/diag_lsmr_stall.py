@@ -21,7 +21,7 @@ prob.set_x(x0)
 prob.residual_jac()
 cn = prob.colnorm()
 cn[cn == 0] = 1
-d = torch.from_numpy(1.0 / cn).cuda()
+d = prob.upload_n(1.0 / cn)
 dreg = torch.full((prob.n,), 1e-3, dtype=torch.float64, device='cuda')
 
 L = _lib.lib()
