@@ -193,8 +193,17 @@ __global__ __launch_bounds__(256) void ba_residual_jac_kernel(
     for (int i = 0; i < 9; ++i) cal[i] = calib[i];
     const double fx = cal[0], fy = cal[1];
     const double k1 = cal[4], k2 = cal[5], p1 = cal[6], p2 = cal[7], k3 = cal[8];
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n_obs;
-         o += (int64_t)gridDim.x * 256) {
+    // Without calibration columns the 14 + 6 doubles of an observation are staged in LDS and
+    // the workgroup's contiguous [256][14] / [256][6] output ranges are written with coalesced
+    // stores (a thread writing its own 112-byte record makes every store instruction touch 64
+    // different cache lines).
+    constexpr int SC = WITH_CALIB ? 1 : 15, SP = WITH_CALIB ? 1 : 7;      // padded LDS strides
+    __shared__ double sJc[WITH_CALIB ? 1 : 256 * SC];
+    __shared__ double sJp[WITH_CALIB ? 1 : 256 * SP];
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < n_obs; base += (int64_t)gridDim.x * 256) {
+        const int64_t o = base + threadIdx.x;
+        const bool valid = o < n_obs;
+        if (valid) {
         const int ci = cam_idx[o];
         const int pi = pt_idx[o];
         Proj P;
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(256) void ba_residual_jac_kernel(
             }
         }
         // r = observed - projected  =>  J = -d(u,v)/d(params)
-        double *jc = Jc + o * 14;
+        double *jc = WITH_CALIB ? Jc + o * 14 : sJc + threadIdx.x * SC;
         jc[0] = jp_u[0]; jc[1] = jp_u[1]; jc[2] = jp_u[2];          // d/d ned = -(-B^T) -> +
         jc[3] = -jq_u[0]; jc[4] = -jq_u[1]; jc[5] = -jq_u[2]; jc[6] = -jq_u[3];
         jc[7] = jp_v[0]; jc[8] = jp_v[1]; jc[9] = jp_v[2];
         jc[10] = -jq_v[0]; jc[11] = -jq_v[1]; jc[12] = -jq_v[2]; jc[13] = -jq_v[3];
-        double *jp = Jp + o * 6;
+        double *jp = WITH_CALIB ? Jp + o * 6 : sJp + threadIdx.x * SP;
         jp[0] = -jp_u[0]; jp[1] = -jp_u[1]; jp[2] = -jp_u[2];
         jp[3] = -jp_v[0]; jp[4] = -jp_v[1]; jp[5] = -jp_v[2];
         if constexpr (WITH_CALIB) {
@@ -282,6 +291,14 @@ __global__ __launch_bounds__(256) void ba_residual_jac_kernel(
             jk[8] = -yd;  jk[9] = 0.0; jk[10] = -1.0;
             jk[11] = -fy * y * r2; jk[12] = -fy * y * r4;
             jk[13] = -fy * (r2 + 2.0 * y * y); jk[14] = -fy * 2.0 * x * y; jk[15] = -fy * y * r6;
+        }
+        }   // valid
+        if constexpr (!WITH_CALIB) {
+            __syncthreads();
+            const int cnt = (int)((n_obs - base) < 256 ? (n_obs - base) : 256);
+            for (int e = threadIdx.x; e < cnt * 14; e += 256) Jc[base * 14 + e] = sJc[(e / 14) * SC + e % 14];
+            for (int e = threadIdx.x; e < cnt * 6; e += 256) Jp[base * 6 + e] = sJp[(e / 6) * SP + e % 6];
+            __syncthreads();
         }
     }
 }
