@@ -110,10 +110,17 @@ class DeviceMatcher(object):
         if self._store is None or len(self._store.counts) != len(self._counts):
             new = kernels.DescriptorStore(self._counts)
             if self._store is not None and len(self._store.counts):
-                n_old = int(self._store.offsets[-1])
-                new.desc[:n_old].copy_(self._store.desc[:n_old])
-                new.norm_q[:n_old].copy_(self._store.norm_q[:n_old])
-                new.norm_t[:n_old].copy_(self._store.norm_t[:n_old])
+                old = self._store
+                n_old, n_old2, k = int(old.offsets[-1]), int(old.offsets2[-1]), len(old.counts)
+                new.desc[:n_old].copy_(old.desc[:n_old])
+                new.norm_q[:n_old].copy_(old.norm_q[:n_old])
+                new.norm_t[:n_old].copy_(old.norm_t[:n_old])
+                # ... and the train-side (parity partitioned) form the fast kernel reads
+                new.desc2[:n_old2].copy_(old.desc2[:n_old2])
+                new.norm2[:n_old2].copy_(old.norm2[:n_old2])
+                new.cinit[:n_old2].copy_(old.cinit[:n_old2])
+                new.perm[:n_old2].copy_(old.perm[:n_old2])
+                new.meta[:k].copy_(old.meta[:k])
             self._store = new
         for slot, des in pend:
             self._store.set_image(slot, np.ascontiguousarray(des))

@@ -147,6 +147,57 @@ def test_find_matches_batched_equals_pairwise_oracle():
     assert n_nonempty >= 4
 
 
+def test_find_matches_growing_arena_and_oversize_pairs():
+    """several batches: the descriptor / keypoint arenas grow while old slots stay valid; and a
+    pair with more survivors than the device sort holds takes the host filters -- same lists."""
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from oracle import match_oracle as mo
+    from test_match_gpu import _sift_like
+    matcher = _configure(0.75, 25)
+    rng = np.random.default_rng(31)
+    n_img, W, H = 6, 5472, 3648
+    names = ['G%02d' % i for i in range(n_img)]
+    proj = PoseProject(names)
+    des, xy = [], []
+    for i in range(n_img):
+        n = 700 + 50 * i
+        d = _sift_like(rng, n)
+        p = np.stack([rng.uniform(600, W - 600, n), rng.uniform(400, H - 400, n)], 1)
+        if i:
+            k = 350
+            src, dst = rng.permutation(len(des[i - 1]))[:k], rng.permutation(n)[:k]
+            d[dst] = np.clip(des[i - 1][src].astype(int) + rng.integers(-5, 6, (k, 128)), 0, 255)
+            p[dst] = xy[i - 1][src] + [250.0, -120.0] + rng.normal(0, 0.6, (k, 2))
+        des.append(d)
+        xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        fresh = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
+    old = matcher.PAIRS_PER_BATCH
+    matcher.PAIRS_PER_BATCH = 2                     # images join the arena batch by batch
+    try:
+        matcher.find_matches(proj, None, strategy='traditional', sort=True)
+    finally:
+        matcher.PAIRS_PER_BATCH = old
+    n_nonempty = 0
+    for i in range(n_img):
+        for j in range(i + 1, min(i + 5, n_img)):
+            f, r = mo.bidirectional_pair_matches(des[i], xy[i], des[j], xy[j], 0.75, 25, (W, H))
+            a, b = proj.image_list[i], proj.image_list[j]
+            assert np.array_equal(np.array(a.match_list[names[j]]).reshape(-1, 2), f), (i, j)
+            assert np.array_equal(np.array(b.match_list[names[i]]).reshape(-1, 2), r), (i, j)
+            n_nonempty += len(f) > 0
+    assert n_nonempty >= 5
+    # oversize: > 4096 survivors in one direction -> status 1 -> host filters
+    big = [_image('B%d' % k, _sift_like(rng, 5000),
+                  np.stack([rng.uniform(0, W - 1, 5000), rng.uniform(0, H - 1, 5000)], 1).astype(np.float32))
+           for k in range(2)]
+    dev = matcher._match_batch([(big[0], big[1])], 1e6)         # threshold keeps every row
+    host = matcher._match_batch([(big[0], big[1])], 1e6, device_filters=False)
+    assert dev == host and dev[0][2] == 5000
+
+
 def test_find_matches_zero_division_like_reference():
     from imageanalysis_amd.hostlib.image_pose import PoseProject
     matcher = _configure()
