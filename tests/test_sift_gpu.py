@@ -79,3 +79,48 @@ def test_sift_translation_repeatability():
     assert len(pairs) >= 0.85 * inner.sum()
     dd = np.abs(da[inner][pairs[:, 0]].astype(int) - db[pairs[:, 1]].astype(int))
     assert np.median(dd.sum(1)) < 60
+
+
+@pytest.mark.parametrize('k', [1, 2, 3])
+def test_sift_rotation_invariance(k):
+    """np.rot90 is an exact pixel permutation: the same scene must give the same keypoints at
+    the rotated positions, orientations turned by k*90 degrees and (orientation-normalised)
+    descriptors that agree -- what matching between the opposite headings of a lawn-mower
+    survey relies on."""
+    from imageanalysis_amd import kernels
+    img = texture(240, 240, 11)[:, :, 0].copy()
+    rot = np.ascontiguousarray(np.rot90(img, k))
+    ka, oa, da = kernels.sift_detect(img)
+    kb, ob, db = kernels.sift_detect(rot)
+    assert len(ka) > 150 and abs(len(ka) - len(kb)) <= len(ka) // 10
+    n = img.shape[0]
+    # pixel (x, y) of img lands at rot90^k: k=1 -> (y, n-1-x), k=2 -> (n-1-x, n-1-y), k=3 -> (n-1-y, x)
+    x, y = ka[:, 0].astype(np.float64), ka[:, 1].astype(np.float64)
+    xr, yr = {1: (y, n - 1 - x), 2: (n - 1 - x, n - 1 - y), 3: (n - 1 - y, x)}[k]
+    matched, dist, dang = 0, [], []
+    for i in range(len(ka)):
+        d2 = (kb[:, 0] - xr[i]) ** 2 + (kb[:, 1] - yr[i]) ** 2
+        # (cv2 convention: no half-pixel shift for octave -1 => up to 0.5 px between the frames;
+        #  the packed octave also carries the sub-layer offset in its top bits: compare octave+layer)
+        cand = np.nonzero((d2 < 2.0) & ((ob & 0xFFFF) == (oa[i] & 0xFFFF)))[0]
+        if len(cand) == 0:
+            continue
+        # image rotated counter-clockwise by k*90 deg; keypoint angles are clockwise (y down)
+        want = (ka[i, 3] - 90.0 * k) % 360.0
+        da_ = np.abs(((kb[cand, 3] - want) + 180.0) % 360.0 - 180.0)
+        j = cand[np.argmin(da_)]
+        if da_.min() < 3.0:
+            matched += 1
+            dang.append(da_.min())
+            dist.append(np.sqrt(((da[i].astype(float) - db[j].astype(float)) ** 2).sum()))
+    print('rot90 x%d: %d / %d keypoints re-found, median angle error %.3f deg, descriptor distance '
+          'median %.1f p90 %.1f' % (k, matched, len(ka), np.median(dang), np.median(dist),
+                                  np.percentile(dist, 90)))
+    assert matched >= 0.8 * len(ka), (matched, len(ka))
+    # |desc| = 512, unrelated descriptors are ~500 apart; the half-pixel frame shift costs a little
+    assert np.median(dist) < 80 and np.percentile(dist, 90) < 200
+    # and they are each other's nearest neighbours among all descriptors
+    from oracle import cpu_ref
+    idx, dd = cpu_ref.knn2_l2_u8(da, db)
+    ratio_ok = (np.sqrt(dd[:, 0].astype(float)) < 0.6 * np.sqrt(dd[:, 1].astype(float))).mean()
+    assert ratio_ok > 0.6
