@@ -76,3 +76,47 @@ def test_detect_features_end_to_end(tmp_path):
     camera.set_image_params(401, 300)
     with pytest.raises(SystemExit):
         iimg.Image(str(an), 'T001').detect_features(0.5, use_cache=False)
+
+
+def test_full_chain_overlapping_views(tmp_path):
+    """JPEG -> Image.detect_features -> matcher.bidirectional_pair_matches on two overlapping
+    views of one scene, the second flown on the opposite heading (turned 180 deg): the chain
+    must return many matches and they must all obey the known view-to-view transform."""
+    from PIL import Image as PILImage
+    from imageanalysis_amd import image as iimg, matcher
+    from imageanalysis_amd._deps import getNode
+    from imageanalysis_amd.hostlib import camera
+    proj = tmp_path / 'proj'
+    (proj / 'images').mkdir(parents=True)
+    an = proj / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    W, H, dx, dy = 800, 600, 210, 90
+    scene = texture(H + dy, W + dx, 21)
+    a = scene[:H, :W]
+    b = np.ascontiguousarray(scene[dy:dy + H, dx:dx + W][::-1, ::-1])     # shifted, then 180 deg
+    for name, arr in (('V001', a), ('V002', b)):
+        PILImage.fromarray(np.ascontiguousarray(arr[:, :, ::-1])).save(
+            str(proj / 'images' / (name + '.JPG')), quality=92)
+    getNode('/config/directories', True).setString('project_dir', str(proj))
+    matcher.detector_node.setString('detector', 'SIFT')
+    matcher.detector_node.setFloat('scale', 0.5)
+    matcher.matcher_node.setFloat('match_ratio', 0.75)
+    matcher.matcher_node.setInt('min_pairs', 25)
+    camera.set_image_params(W, H)
+    matcher.configure()
+    i1, i2 = iimg.Image(str(an), 'V001'), iimg.Image(str(an), 'V002')
+    for im in (i1, i2):
+        im.detect_features(0.5, use_cache=False)
+        assert len(im.kp_list) > 500
+    fwd, rev = matcher.bidirectional_pair_matches(i1, i2)
+    assert len(fwd) >= 150 and rev == [[q, p] for p, q in fwd]
+    p1 = np.array([i1.kp_list[p].pt for p, _ in fwd])
+    p2 = np.array([i2.kp_list[q].pt for _, q in fwd])
+    # scene point s: view a at s, view b at (W-1, H-1) - (s - (dx, dy))
+    want = np.array([W - 1, H - 1]) - (p1 - [dx, dy])
+    err = np.linalg.norm(p2 - want, axis=1)
+    assert np.median(err) < 1.5 and (err < 4.0).mean() > 0.97, (np.median(err), (err < 4.0).mean())
+    # and the batched find_matches path gives the same lists as the single-pair call
+    (f2, r2, _a, _b), = matcher._match_batch([(i1, i2)], 0.75)
+    assert f2 == fwd and r2 == rev
