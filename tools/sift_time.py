@@ -11,6 +11,6 @@ for it in range(3):
     t0 = time.perf_counter()
     scaled = kernels.equalize_resize(bgr, scale)
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    kp, octv, desc = kernels.sift_detect(scaled, cap=400000)
+    kp, octv, desc = kernels.sift_detect(scaled, cap=1500000)
     t2 = time.perf_counter()
     print("iter %d: prep %.1f ms, sift %.1f ms (incl. host sort), %d keypoints, detect image %s" % (it, (t1 - t0) * 1e3, (t2 - t1) * 1e3, len(kp), tuple(scaled.shape)))
