@@ -24,7 +24,8 @@ namespace {
 
 constexpr int GRID = 20, NCELL = GRID * GRID;
 constexpr int CLIP = 2000;             // MYMAX of matcher.py:267
-constexpr int SORT_CAP = 4096;         // survivors of one direction that can be sorted in LDS
+constexpr int SORT_CAP = 2048;         // elements of the in-LDS bitonic sort (>= CLIP)
+constexpr int MAX_SURV = 1 << 24;      // survivors of one direction the selection accepts
 constexpr int TAB = 4096;              // hash slots (<= 2000 distinct keys: load <= 0.49)
 constexpr int NT = 256;
 
@@ -45,7 +46,7 @@ struct PostArgs {
     int32_t *scratch;                  // [n_pairs][2][CLIP][2] work lists of both directions
     int32_t *out_stat;                 // [n_pairs][4]: fwd after GMS, fwd after de-dup, rev after
                                        // GMS, rev after de-dup (-1: stage not reached)
-    int32_t *status;                   // [n_pairs] 0 ok, 1 = more than SORT_CAP survivors (host path)
+    int32_t *status;                   // [n_pairs] 0 ok, 1 = more than MAX_SURV survivors (host path)
 };
 
 __constant__ int ROT[8][9] = {{0, 1, 2, 3, 4, 5, 6, 7, 8}, {3, 0, 1, 6, 4, 2, 7, 8, 5},
@@ -57,7 +58,8 @@ struct Lds {
     union {
         struct {                       // sort phase
             unsigned long long key[SORT_CAP];
-            unsigned short idx[SORT_CAP];
+            int idx[SORT_CAP];
+            int hist[256];
         } s;
         struct {                       // GMS / de-dup / cross-check phases
             int tab_key[TAB];
@@ -95,18 +97,81 @@ __device__ __forceinline__ int nb9(int c, int k)
     return (x >= 0 && x < GRID && y >= 0 && y < GRID) ? x + y * GRID : -1;
 }
 
-// stable sort by metric + clip: list[0..m) = (q, t) of the m best survivors; returns m
+// stable sort by metric + clip: list[0..m) = (q, t) of the m best survivors; returns m.
+// More than SORT_CAP survivors: an 8-pass radix select on the metric bits finds the key of the
+// CLIP-th smallest, an order-preserving pass collects everything below it plus the first ties
+// (position order = what a stable sort would keep), and only those <= CLIP entries are sorted.
 __device__ int sort_clip(Lds &L, const PostArgs &A, int op, int32_t *list)
 {
     const int64_t b = A.surv_off[op];
     const int n = A.surv_cnt[op];
-    int cap = 1;
-    while (cap < n) cap <<= 1;
-    for (int i = threadIdx.x; i < cap; i += NT) {
-        // metric >= 0 (or NaN, never kept): the f64 bit pattern orders like the value
-        L.s.key[i] = i < n ? (unsigned long long)__double_as_longlong(A.surv_metric[b + i]) : ~0ull;
-        L.s.idx[i] = (unsigned short)i;
+    const double *metric = A.surv_metric + b;
+    // metric >= 0 (NaN is never kept): the f64 bit pattern orders like the value
+    auto key_of = [&](int i) { return (unsigned long long)__double_as_longlong(metric[i]); };
+    int m;                               // elements placed in L.s.key / L.s.idx
+    if (n <= SORT_CAP) {
+        m = n;
+        for (int i = threadIdx.x; i < n; i += NT) { L.s.key[i] = key_of(i); L.s.idx[i] = i; }
+    } else {
+        unsigned long long prefix = 0;   // the bits of the CLIP-th smallest key decided so far
+        int want = CLIP;                 // rank (1-based) of the wanted key among the prefix group
+        for (int byte = 7; byte >= 0; --byte) {
+            L.s.hist[threadIdx.x] = 0;
+            __syncthreads();
+            const int sh = 8 * byte;
+            for (int i = threadIdx.x; i < n; i += NT) {
+                const unsigned long long k = key_of(i);
+                if (byte == 7 || (k >> (sh + 8)) == (prefix >> (sh + 8)))
+                    atomicAdd(&L.s.hist[(int)((k >> sh) & 255)], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int acc = 0, bin = 0;
+                for (; bin < 256; ++bin) {
+                    if (acc + L.s.hist[bin] >= want) break;
+                    acc += L.s.hist[bin];
+                }
+                L.bcast[0] = bin;
+                L.bcast[1] = want - acc;
+            }
+            __syncthreads();
+            prefix |= (unsigned long long)L.bcast[0] << sh;
+            want = L.bcast[1];
+            __syncthreads();
+        }
+        // prefix = key of the CLIP-th smallest; `want` ties of it are kept, in position order
+        const unsigned long long T = prefix;
+        int base = 0, ties = 0;
+        for (int s0 = 0; s0 < n; s0 += NT) {
+            const int i = s0 + threadIdx.x;
+            const unsigned long long k = i < n ? key_of(i) : ~0ull;
+            const bool less = i < n && k < T, tie = i < n && k == T;
+            const unsigned long long bl = __ballot(less), bt = __ballot(tie);
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            __syncthreads();
+            if (lane == 0) { L.red[wave] = __popcll(bl); L.bcast[wave] = __popcll(bt); }
+            __syncthreads();
+            int tie_before = ties, less_before = 0, tie_all = 0, less_all = 0;
+            for (int w = 0; w < NT / 64; ++w) {
+                if (w < wave) { tie_before += L.bcast[w]; less_before += L.red[w]; }
+                tie_all += L.bcast[w]; less_all += L.red[w];
+            }
+            const unsigned long long below = (1ull << lane) - 1;
+            const int my_tie = tie_before + __popcll(bt & below);          // ties in front of me
+            const bool take = less || (tie && my_tie < want);
+            // output position = kept entries in front: all `less` + the ties below the quota
+            const int ties_kept_before = min(my_tie, want);
+            const int pos = base + less_before + __popcll(bl & below) + (ties_kept_before - min(ties, want));
+            if (take) { L.s.key[pos] = k; L.s.idx[pos] = i; }
+            base += less_all + (min(ties + tie_all, want) - min(ties, want));
+            ties += tie_all;
+            __syncthreads();
+        }
+        m = base;                         // == CLIP
     }
+    int cap = 1;
+    while (cap < m) cap <<= 1;
+    for (int i = m + threadIdx.x; i < cap; i += NT) { L.s.key[i] = ~0ull; L.s.idx[i] = 0x7FFFFFFF; }
     __syncthreads();
     for (int k = 2; k <= cap; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -114,7 +179,7 @@ __device__ int sort_clip(Lds &L, const PostArgs &A, int op, int32_t *list)
                 const int l = i ^ j;
                 if (l > i) {
                     const unsigned long long ki = L.s.key[i], kl = L.s.key[l];
-                    const unsigned short ii = L.s.idx[i], il = L.s.idx[l];
+                    const int ii = L.s.idx[i], il = L.s.idx[l];
                     const bool gt = ki > kl || (ki == kl && ii > il);     // (metric, position)
                     const bool up = (i & k) == 0;
                     if (gt == up) {
@@ -126,14 +191,14 @@ __device__ int sort_clip(Lds &L, const PostArgs &A, int op, int32_t *list)
             __syncthreads();
         }
     }
-    const int m = n < CLIP ? n : CLIP;
-    for (int i = threadIdx.x; i < m; i += NT) {
-        const int s = L.s.idx[i];
-        list[2 * i] = A.surv_q[b + s];
-        list[2 * i + 1] = A.surv_t[b + s];
+    const int mm = m < CLIP ? m : CLIP;
+    for (int i = threadIdx.x; i < mm; i += NT) {
+        const int sidx = L.s.idx[i];
+        list[2 * i] = A.surv_q[b + sidx];
+        list[2 * i + 1] = A.surv_t[b + sidx];
     }
     __syncthreads();
-    return m;
+    return mm;
 }
 
 // GMS inlier bits: after the call bit r of L.g.bits[i] is the mask of rotation r; returns the
@@ -338,7 +403,7 @@ __global__ __launch_bounds__(NT) void postfilter_kernel(PostArgs A)
     int32_t *fwd = A.scratch + (int64_t)p * 2 * CLIP * 2, *rev = fwd + CLIP * 2;
     int32_t *stat = A.out_stat + 4 * p;
     if (threadIdx.x < 4) stat[threadIdx.x] = -1;
-    if (A.surv_cnt[p] > SORT_CAP || A.surv_cnt[n + p] > SORT_CAP) {
+    if (A.surv_cnt[p] > MAX_SURV || A.surv_cnt[n + p] > MAX_SURV) {
         if (threadIdx.x == 0) { A.status[p] = 1; A.out_cnt[p] = 0; }
         return;
     }

@@ -346,8 +346,8 @@ def _ensure_features(image):
 def _match_batch(batch, match_ratio, device_filters=True):
     """batch: list of (i1, i2) image objects.  Device k=2 NN + metric threshold for both
     directions of every pair, then the per-pair filters (sort/clip, GMS, de-dup, gates, cross
-    check) -- on the device too (iamx_match_postfilter) unless `device_filters` is False or a
-    pair has more survivors than the device sort holds.  Returns per pair
+    check) -- on the device too (iamx_match_postfilter) unless `device_filters` is False (or a
+    direction has more than 2^24 survivors).  Returns per pair
     (match_fwd, match_rev, n_fwd_quality, n_rev_quality)."""
     import torch
     from . import kernels

@@ -189,7 +189,7 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  *   out_cnt DEV [n_pairs], out_pairs DEV [n_pairs][clip][2]: the cross-checked forward list
  *   [query row, train row] (the reverse list is its mirror); scratch DEV [n_pairs][2][clip][2];
  *   out_stat DEV [n_pairs][4]: forward after GMS / after de-dup, reverse after GMS / after
- *   de-dup (-1 = stage not reached); status DEV [n_pairs]: 1 = a direction has more than 4096
+ *   de-dup (-1 = stage not reached); status DEV [n_pairs]: 1 = a direction has more than 2^24
  *   survivors and must take the host path.  clip = iamx_match_postfilter_clip() = 2000.
  * ------------------------------------------------------------------------------------ */
 int iamx_match_postfilter_clip(void);

@@ -189,13 +189,68 @@ def test_find_matches_growing_arena_and_oversize_pairs():
             assert np.array_equal(np.array(b.match_list[names[i]]).reshape(-1, 2), r), (i, j)
             n_nonempty += len(f) > 0
     assert n_nonempty >= 5
-    # oversize: > 4096 survivors in one direction -> status 1 -> host filters
+    # > 2048 survivors in a direction: radix select of the best 2000 instead of a full sort
     big = [_image('B%d' % k, _sift_like(rng, 5000),
                   np.stack([rng.uniform(0, W - 1, 5000), rng.uniform(0, H - 1, 5000)], 1).astype(np.float32))
            for k in range(2)]
     dev = matcher._match_batch([(big[0], big[1])], 1e6)         # threshold keeps every row
     host = matcher._match_batch([(big[0], big[1])], 1e6, device_filters=False)
     assert dev == host and dev[0][2] == 5000
+
+
+def test_post_filter_clip_with_ties_at_the_boundary():
+    """6000 survivors per direction whose metrics take only a few dozen distinct values: the
+    2000-th smallest sits inside a long run of equal metrics, so the device selection must keep
+    exactly the first ties in position order (what python's stable sort + [:2000] keeps)."""
+    import torch
+    from imageanalysis_amd import kernels
+    from imageanalysis_amd.kernels import _ptr
+    matcher = _configure(0.75, 25)
+    rng = np.random.default_rng(9)
+    n, W, H, ns = 9000, 5472.0, 3648.0, 6000
+    xy1 = np.stack([rng.uniform(0, W - 400, n), rng.uniform(0, H - 1, n)], 1).astype(np.float32)
+    xy2 = xy1.copy()
+    xy2[:, 0] += 300.0
+    L = kernels.lib()
+    clip = int(L.iamx_match_postfilter_clip())
+    dev = torch.device('cuda')
+    t = lambda a, dt_: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt_)
+    for trial in range(3):
+        q = np.sort(rng.choice(n, ns, replace=False))
+        tt = q.copy()
+        bad = rng.random(ns) < 0.35
+        tt[bad] = rng.integers(0, n, bad.sum())
+        metric = rng.choice(np.linspace(5.0, 200.0, (3, 40, 400)[trial]), ns)
+        order_r = np.argsort(tt, kind='stable')
+        sf = (q.astype(np.int32), tt.astype(np.int32), metric)
+        sr = (tt[order_r].astype(np.int32), q[order_r].astype(np.int32), metric[order_r])
+        host = []
+        for a, b, sv in ((xy1, xy2, sf), (xy2, xy1, sr)):
+            pr = matcher._threshold_sort_clip(*sv)
+            i1, i2 = _image('X', np.zeros((2, 128), np.uint8), a[:2]), _image('Y', np.zeros((2, 128), np.uint8), b[:2])
+            host.append(matcher._post_filter(i1, i2, pr, (a, b)))
+        want = matcher.filter_cross_check(host[0], host[1])[0]
+        d = dict(off=t(np.array([0, ns, 2 * ns]), torch.int64), cnt=t(np.array([ns, ns]), torch.int32),
+                 q=t(np.concatenate([sf[0], sr[0]]), torch.int32), t=t(np.concatenate([sf[1], sr[1]]), torch.int32),
+                 m=t(np.concatenate([sf[2], sr[2]]), torch.float64),
+                 pairs=t(np.array([[0, 1], [1, 0]]), torch.int32), kp_off=t(np.array([0, n]), torch.int64),
+                 xy=t(np.concatenate([xy1, xy2]), torch.float32),
+                 key2=t(matcher.kp_key2(np.concatenate([xy1, xy2])), torch.int32),
+                 out_cnt=torch.empty(1, dtype=torch.int32, device=dev),
+                 out_pairs=torch.empty((1, clip, 2), dtype=torch.int32, device=dev),
+                 scratch=torch.empty((1, 2, clip, 2), dtype=torch.int32, device=dev),
+                 stat=torch.empty((1, 4), dtype=torch.int32, device=dev),
+                 status=torch.empty(1, dtype=torch.int32, device=dev))
+        kernels.check(L.iamx_match_postfilter(_ptr(d['off']), _ptr(d['cnt']), _ptr(d['q']), _ptr(d['t']),
+                                              _ptr(d['m']), _ptr(d['pairs']), _ptr(d['kp_off']),
+                                              _ptr(d['xy']), _ptr(d['key2']), 1, W, H, 25.0, 5.0,
+                                              _ptr(d['out_cnt']), _ptr(d['out_pairs']), _ptr(d['scratch']),
+                                              _ptr(d['stat']), _ptr(d['status']), kernels.stream_ptr()),
+                      'iamx_match_postfilter')
+        torch.cuda.synchronize()
+        assert int(d['status'][0].item()) == 0
+        got = d['out_pairs'][0, :int(d['out_cnt'][0].item())].cpu().numpy()
+        assert len(want) > 200 and np.array_equal(got, np.array(want).reshape(-1, 2)), trial
 
 
 def test_find_matches_zero_division_like_reference():
