@@ -97,8 +97,9 @@ class Optimizer():
         self.ncp = 7
         self.cam2body = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)
         self.body2cam = np.linalg.inv(self.cam2body)
-        # 'scipy': SciPy TRF driven by the device residual/Jacobian; 'device': ba_solver.py
-        self.solver = 'scipy'
+        # 'device' (default): the TRF restatement of ba_solver.py, J and LSMR resident on the
+        # GPU; 'scipy': SciPy's own TRF driven by the device residual / analytic Jacobian
+        self.solver = 'device'
         self._dev = None
 
     # ---------------------------------------------------------------------------------

@@ -266,13 +266,16 @@ def test_find_matches_zero_division_like_reference():
         matcher.find_matches(proj, None, strategy='traditional')
 
 
+@pytest.mark.parametrize('solver', ['device', 'scipy'])
 @pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
-def test_optimizer_fun_jac_run_against_reference(path):
+def test_optimizer_fun_jac_run_against_reference(path, solver):
     import scipy.sparse as sp
     from imageanalysis_amd import optimizer
     g = np.load(path)
     proj, inp = _scene(path)
     opt = optimizer.Optimizer('/nonexistent')
+    assert opt.solver == 'device'                       # the shipped default
+    opt.solver = solver
     opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
     args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
     scale = np.abs(g['f0']).max()
