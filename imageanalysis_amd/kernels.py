@@ -64,12 +64,14 @@ class DescriptorStore(object):
     def __len__(self):
         return len(self.counts)
 
-    def set_image(self, i, des):
+    def set_image(self, i, des, sync=True):
         """Pack descriptors of image i.  `des`: [n,128] float32 (cv2/reference layout, integer
-        valued) or uint8, numpy or device tensor."""
+        valued) or uint8, numpy or device tensor.  With sync=False the kernels are only
+        enqueued and the temporaries they read are returned: keep them alive until the stream
+        has been synchronised."""
         n = self.counts[i]
         if n == 0:
-            return
+            return ()
         if isinstance(des, np.ndarray) and des.dtype != np.uint8 and des.dtype != np.float32:
             des = des.astype(np.float32)
         is_u8 = (des.dtype == np.uint8) if isinstance(des, np.ndarray) else (des.dtype == U8)
@@ -87,8 +89,11 @@ class DescriptorStore(object):
         check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
                   _ptr(self.perm[o2:]), _ptr(self.meta[i]), _ptr(scratch), stream_ptr()),
               'iamx_desc2_pack')
-        # the source buffer must outlive the enqueued kernel
-        torch.cuda.current_stream().synchronize()
+        # the source buffer must outlive the enqueued kernels
+        if sync:
+            torch.cuda.current_stream().synchronize()
+            return ()
+        return (src, scratch)
 
     @classmethod
     def from_arrays(cls, arrays):

@@ -122,8 +122,12 @@ class DeviceMatcher(object):
                 new.perm[:n_old2].copy_(old.perm[:n_old2])
                 new.meta[:k].copy_(old.meta[:k])
             self._store = new
-        for slot, des in pend:
-            self._store.set_image(slot, np.ascontiguousarray(des))
+        keep = [self._store.set_image(slot, np.ascontiguousarray(des), sync=False)
+                for slot, des in pend]
+        if keep:
+            import torch
+            torch.cuda.current_stream().synchronize()        # one sync for the whole batch
+        del keep
         self._pending = []
         return self._store
 
