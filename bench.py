@@ -207,7 +207,7 @@ def main():
     k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     k_pairs = [b.n_pairs / 2.0 for b in batches]           # unordered pairs per launch
     achieved = sum(k_pairs) * FLOP_PER_PAIR / (sum(k_ms) * 1e-3) / 1e12
-    traffic, traffic_src = None, None
+    traffic, traffic_src, mfma_busy, mfma_busy_src = None, None, None, None
     tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json')
     if n_img == 500 and world == 1 and os.path.exists(tf):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -215,10 +215,14 @@ def main():
         with open(tf) as fp:
             t = json.load(fp)
         traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
+        mfma_busy, mfma_busy_src = t.get("mfma_busy"), t.get("mfma_busy_source")
     roofline = {"bound": "mfma", "kernel": "knn2v2_kernel",
                 "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
+                # MFMA pipe busy fraction from the committed PMC pass (the north star's
+                # "MFMA utilisation" figure)
+                "mfma_busy": mfma_busy, "mfma_busy_source": mfma_busy_src,
                 "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
                 "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR,
                 # the kernel runs both directions of a pair as two MFMA passes: executed =
