@@ -227,7 +227,10 @@ struct Args2 {
 };
 
 // VARIANT != 0: timing ablations (iamxdbg_knn2v2_variant): bit0 no epilogue, bit1 no MFMA,
-// bit2 no re-staging / barriers, bit3 two interleaved (m1,m2) chains per query block
+// bit2 no re-staging / barriers, bit3 operands without LDS traffic, bit4 = cost model of a
+// single sweep that also serves the reverse direction (per-row minima over the queries:
+// shift-add of the query term, running min per accumulator register, cross-lane DPP reduction
+// per tile, one store per row and tile) -- timing only, results meaningless
 template <int VARIANT, int QW, int OCC, int NW = WAVES, bool BOUND = false, bool DLDS = false>
 __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
 {
@@ -397,11 +400,40 @@ __global__ __launch_bounds__(NW * 64, OCC) void knn2v2_kernel(Args2 A)
             v4i a_nx[4], tb_nx[4];
             if (tile + 1 < CHUNK / 32) load_ops(tile + 1, a_nx, tb_nx);
             const int tile_id = ch * (CHUNK / 32) + tile;
+            int rowmin[16];
+            if constexpr (VARIANT & 16) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) rowmin[reg] = BIG;
+            }
 #pragma unroll
             for (int qb = 0; qb < QW; ++qb) {
                 v16i acc;
                 chain(acc, a, tbv, qb);
                 epilogue(acc, qb, tile_id);
+                if constexpr (VARIANT & 16) {
+                    const int nqv = bq[qb][0][0];                  // stands for norm_q of the column
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) rowmin[reg] = min(rowmin[reg], (acc[reg] << 1) + nqv);
+                }
+            }
+            if constexpr (VARIANT & 16) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    int v = rowmin[reg];
+                    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true));     // quad xor 1
+                    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true));     // quad xor 2
+                    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true));    // row_half_mirror
+                    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true));    // row_mirror
+                    v = min(v, __shfl_xor(v, 16));
+                    rowmin[reg] = v;
+                }
+                if (c == 0) {
+                    const unsigned slot = ((unsigned)(vid * NW + wave) * 977u + (unsigned)tile_id) & 0xFFFFu;
+                    int *dst = A.out_tile + slot * 32 + g * 16;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg += 4)
+                        *reinterpret_cast<v4i *>(dst + reg) = v4i{rowmin[reg], rowmin[reg + 1], rowmin[reg + 2], rowmin[reg + 3]};
+                }
             }
             if (tile + 1 < CHUNK / 32) {
 #pragma unroll
@@ -738,6 +770,9 @@ extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const i
     case 58: hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 8, true, true>), g, dim3(512), 0, st, a); break;
     case 59: hipLaunchKernelGGL((knn2v2_kernel<0, 3, 2, 4, true, true>), g, b, 0, st, a); break;
     case 60: hipLaunchKernelGGL((knn2v2_kernel<1, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 70: hipLaunchKernelGGL((knn2v2_kernel<16, 4, 2, 4, true>), g, b, 0, st, a); break;
+    case 71: hipLaunchKernelGGL((knn2v2_kernel<16, 4, 1, 4, true>), g, b, 0, st, a); break;
+    case 72: hipLaunchKernelGGL((knn2v2_kernel<16, 2, 2, 4, true>), g, b, 0, st, a); break;
     case 61: hipLaunchKernelGGL((knn2v2_kernel<4, 4, 2, 4, true>), g, b, 0, st, a); break;
     case 62: hipLaunchKernelGGL((knn2v2_kernel<12, 4, 2, 4, true>), g, b, 0, st, a); break;
     case 63: hipLaunchKernelGGL((knn2v2_kernel<13, 4, 2, 4, true>), g, b, 0, st, a); break;

@@ -18,7 +18,7 @@ fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 11 + [ctypes.c_int, ctypes.c_
 st = store
 QB = {30: 384, 31: 512, 32: 512, 33: 128, 35: 512, 40: 512, 41: 1024, 42: 768, 43: 256,
       50: 256, 51: 512, 52: 512, 53: 512, 54: 256, 55: 384, 60: 512, 61: 512, 62: 512, 63: 512,
-      64: 512, 65: 512, 56: 512, 57: 256, 58: 1024, 59: 384, 36: 512}
+      64: 512, 65: 512, 56: 512, 57: 256, 58: 1024, 59: 384, 36: 512, 70: 512, 71: 512, 72: 256}
 ref = None
 for v in variants:
     ts = []
