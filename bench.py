@@ -244,6 +244,7 @@ def main():
     sift = None
     if not args.no_sift:
         sift = sift_bench(rank, world, dev, dist, args)
+    cleanup = cleanup_bench(args) if rank == 0 else None
 
     out = None
     if rank == 0:
@@ -267,7 +268,7 @@ def main():
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
             "unresolved": int(ws_unresolved),
             "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
-            "sift": sift,
+            "sift": sift, "cleanup": cleanup,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -361,6 +362,124 @@ def host_postprocess_rate():
                      "kernel": "postfilter_kernel", "ms_per_launch": round(ms, 3),
                      "pairs_per_launch": n_pairs,
                      "kept_per_pair": int(d['out_cnt'][0].item())}
+    return out
+
+
+def cleanup_bench(args):
+    """SURVEY.md 8f ranks 1-2 (between matching and BA): chain linking of the pair-wise matches
+    (native host code) and the initial ground-plane triangulation (device), on a synthetic strip
+    of 600 images x 4 neighbours x 800 matches; CPU baseline = a literal python transcription
+    of the reference's linking loop on a 1/4 sample."""
+    from imageanalysis_amd import kernels, match_cleanup
+    from imageanalysis_amd.kernels import _ptr
+    rng = np.random.default_rng(7)
+    n_img, n_kp, per = 600, 4096, 800
+
+    class _KP(object):
+        __slots__ = ('pt',)
+
+    class _Img(object):
+        pass
+
+    class _Proj(object):
+        pass
+
+    proj = _Proj()
+    proj.image_list = []
+    for i in range(n_img):
+        im = _Img()
+        im.name = 'S%04d' % i
+        xy = np.stack([rng.uniform(0, 5471, n_kp), rng.uniform(0, 3647, n_kp)], 1).astype(np.float32)
+        im.kp_list = None
+        im._iamx_xy = (None, xy)
+        im.match_list = {}
+        proj.image_list.append(im)
+    for i in range(n_img):
+        for j in range(i + 1, min(i + 5, n_img)):
+            a, b = rng.choice(n_kp, per, replace=False), rng.choice(n_kp, per, replace=False)
+            proj.image_list[i].match_list['S%04d' % j] = np.stack([a, b], 1).tolist()
+            proj.image_list[j].match_list['S%04d' % i] = np.stack([b, a], 1).tolist()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        direct = match_cleanup.make_match_structure(proj)
+        t1 = time.perf_counter()
+        grouped = match_cleanup.link_matches(proj, direct)
+        t_link = time.perf_counter() - t1
+    out = {"link_matches": {"value": round(len(direct) / t_link, 1), "unit": "pair matches/s",
+                            "pair_matches": len(direct), "chains": len(grouped),
+                            "seconds": round(t_link, 3),
+                            "make_match_structure_seconds": round(t1 - t0, 3)}}
+    if not args.no_cpu_baseline:
+        sample = direct[:len(direct) // 4]
+
+        def python_rules(matches):               # scripts/lib/match_cleanup.py:246-286
+            matches = [list(m) for m in matches]
+            while True:
+                new, lookup = [], {}
+                for match in matches:
+                    index = -1
+                    for p in match[2:]:
+                        key = "%d-%d" % (p[0], p[1])
+                        if key in lookup:
+                            index = lookup[key]
+                            break
+                    if index < 0:
+                        for p in match[2:]:
+                            lookup["%d-%d" % (p[0], p[1])] = len(new)
+                        new.append(list(match))
+                    else:
+                        existing = new[index]
+                        for p in match[2:]:
+                            if not any(p[0] == e[0] for e in existing[2:]):
+                                existing.append(list(p))
+                                lookup["%d-%d" % (p[0], p[1])] = index
+                if len(new) == len(matches):
+                    return new
+                matches = new
+
+        t0 = time.perf_counter()
+        python_rules(sample)
+        dt = time.perf_counter() - t0
+        out["link_matches"]["cpu_baseline"] = {
+            "value": round(len(sample) / dt, 1), "unit": "pair matches/s", "cores": 1, "kind": "port",
+            "sample": "python transcription of the reference loop on %d pair matches in %.1f s"
+                      % (len(sample), dt)}
+    # triangulation on the device: the features of the linked chains
+    dev = torch.device('cuda', torch.cuda.current_device())
+    n = len(grouped)
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum([len(m) - 2 for m in grouped], out=ptr[1:])
+    obs_img = np.array([p[0] for m in grouped for p in m[2:]], np.int32)
+    obs_uv = np.array([p[1] for m in grouped for p in m[2:]], np.float64).reshape(-1, 2)
+    M = rng.normal(0, 1e-3, (n_img, 9))
+    M[:, 8] = 1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = [t(a) for a in (M, rng.normal(0, 50, (n_img, 3)), np.zeros(n_img), obs_img, obs_uv, ptr)]
+    res = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    sky = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = kernels.lib()
+
+    def launch():
+        kernels.check(L.iamx_triangulate_ground(_ptr(d[0]), _ptr(d[1]), _ptr(d[2]), n_img, _ptr(d[3]),
+                                                _ptr(d[4]), _ptr(d[5]), n, _ptr(res), _ptr(sky),
+                                                kernels.stream_ptr()), 'iamx_triangulate_ground')
+
+    launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    by = len(obs_img) * 20.0 + n * (8.0 + 24.0)           # idx + uv per observation, ptr + out per feature
+    out["triangulate"] = {"value": round(n / (ms * 1e-3), 1), "unit": "features/s", "features": n,
+                          "observations": int(len(obs_img)), "ms_per_launch": round(ms, 4),
+                          "roofline": {"bound": "hbm", "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                                       "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(by / (ms * 1e-3) / 1e9 / 8000.0, 4)}}
     return out
 
 

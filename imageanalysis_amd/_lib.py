@@ -44,6 +44,10 @@ SIGNATURES = {
     'iamx_match_postfilter_clip': (c_int, []),
     'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]
                               + [c_void_p] * 6),
+    'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    'iamx_triangulate_ground': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int64]
+                                + [c_void_p] * 3),
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_void_p, c_void_p]),

@@ -5,7 +5,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../libiamx.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_post.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/sift.hip $HERE/image_prep.hip"
+SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/sift.hip $HERE/image_prep.hip"
 mkdir -p "$HERE/obj"
 OBJS=""
 for f in $SRCS; do

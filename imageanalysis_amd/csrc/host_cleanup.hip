@@ -1,0 +1,149 @@
+// Host-side (no device code) match consolidation -- scripts/lib/match_cleanup.py:246-301
+// link_matches(): union of the pair-wise matches into per-feature chains.  The reference does it
+// with python dicts keyed by "%d-%d" strings, one full pass over all matches per iteration until
+// a pass no longer shrinks the list.  The rules are order dependent and are kept verbatim:
+//   * a match joins the chain of the FIRST of its points (in stored order) that was seen before;
+//   * joining appends only the points whose IMAGE is not yet in that chain, and only appended
+//     points become look-up keys of the chain;
+//   * a match none of whose points was seen starts a new chain and registers all its points.
+// at 2812-10 k images this serial python is the wall-clock bottleneck after
+// GPU matching; here it is flat arrays + one hash map, O(points) per pass.
+#include "iamx_common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// open-addressing map (img, kp) -> chain index, cleared per pass
+struct PointMap {
+    std::vector<uint64_t> key;          // 0 = empty, else ((img << 32) | kp) + 1
+    std::vector<int32_t> val;
+    uint64_t mask;
+
+    explicit PointMap(size_t n_points)
+    {
+        size_t cap = 16;
+        while (cap < 2 * n_points + 16) cap <<= 1;
+        key.assign(cap, 0);
+        val.resize(cap);
+        mask = cap - 1;
+    }
+    void clear() { std::memset(key.data(), 0, key.size() * sizeof(uint64_t)); }
+    static uint64_t mix(uint64_t k)
+    {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+        return k;
+    }
+    static uint64_t code(int32_t img, int32_t kp) { return (((uint64_t)(uint32_t)img << 32) | (uint32_t)kp) + 1; }
+    // slot of the key, or of the empty slot where it would go
+    size_t slot(uint64_t c) const
+    {
+        size_t h = (size_t)(mix(c) & mask);
+        while (key[h] != 0 && key[h] != c) h = (h + 1) & mask;
+        return h;
+    }
+};
+
+}  // namespace
+
+// in : n_matches chains, chain i = points [ptr[i], ptr[i+1]) of (img[], kp[])
+// out: linked chains in the reference's order (NOT yet sorted by length), same flat layout;
+//      out arrays must hold ptr[n_matches] points / n_matches + 1 offsets.
+// returns the number of chains (>= 0) or a negative error code; *n_passes = passes executed.
+extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
+                                     int64_t n_matches, int32_t *out_img, int32_t *out_kp,
+                                     int64_t *out_ptr, int32_t *n_passes)
+{
+    if (n_matches < 0 || !ptr || !out_ptr || (n_matches > 0 && (!img || !kp || !out_img || !out_kp))) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_matches: null pointer or negative count");
+        return IAMX_EINVAL;
+    }
+    for (int64_t i = 0; i < n_matches; ++i)
+        if (ptr[i + 1] < ptr[i]) {
+            iamx::fail(IAMX_EINVAL, "iamx_link_matches: offsets not monotone");
+            return IAMX_EINVAL;
+        }
+    const int64_t n_pts = n_matches ? ptr[n_matches] : 0;
+    if (n_matches >= (1LL << 31) || n_pts >= (1LL << 31)) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_matches: more than 2^31 matches / points");
+        return IAMX_EINVAL;
+    }
+    // current pass input: flat points + offsets (two buffers, swapped per pass)
+    std::vector<int32_t> c_img(img, img + n_pts), c_kp(kp, kp + n_pts);
+    std::vector<int64_t> c_ptr(ptr, ptr + n_matches + 1);
+    // chains under construction: singly linked nodes in insertion order
+    std::vector<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_next((size_t)n_pts);
+    std::vector<int32_t> head, tail;
+    PointMap map((size_t)n_pts);
+    int passes = 0;
+    int64_t n_cur = n_matches;
+    while (true) {
+        ++passes;
+        map.clear();
+        head.clear();
+        tail.clear();
+        int32_t n_nodes = 0;
+        auto append = [&](int32_t chain, int32_t pi, int32_t pk) {
+            const int32_t nd = n_nodes++;
+            node_img[nd] = pi; node_kp[nd] = pk; node_next[nd] = -1;
+            if (head[chain] < 0) head[chain] = nd; else node_next[tail[chain]] = nd;
+            tail[chain] = nd;
+        };
+        for (int64_t m = 0; m < n_cur; ++m) {
+            const int64_t b = c_ptr[m], e = c_ptr[m + 1];
+            int32_t index = -1;
+            for (int64_t j = b; j < e; ++j) {               // first point seen before decides
+                const size_t h = map.slot(PointMap::code(c_img[j], c_kp[j]));
+                if (map.key[h] != 0) { index = map.val[h]; break; }
+            }
+            if (index < 0) {                                // new chain: register every point
+                index = (int32_t)head.size();
+                head.push_back(-1);
+                tail.push_back(-1);
+                for (int64_t j = b; j < e; ++j) {
+                    const uint64_t c = PointMap::code(c_img[j], c_kp[j]);
+                    const size_t h = map.slot(c);
+                    map.key[h] = c;
+                    map.val[h] = index;
+                    append(index, c_img[j], c_kp[j]);
+                }
+            } else {                                        // join: only images new to the chain
+                for (int64_t j = b; j < e; ++j) {
+                    bool found = false;
+                    for (int32_t nd = head[index]; nd >= 0; nd = node_next[nd])
+                        if (node_img[nd] == c_img[j]) { found = true; break; }
+                    if (!found) {
+                        append(index, c_img[j], c_kp[j]);
+                        const uint64_t c = PointMap::code(c_img[j], c_kp[j]);
+                        const size_t h = map.slot(c);
+                        map.key[h] = c;
+                        map.val[h] = index;
+                    }
+                }
+            }
+        }
+        // next pass input = the chains in creation order, points in insertion order
+        const int64_t n_new = (int64_t)head.size();
+        int64_t o = 0;
+        c_ptr.resize((size_t)n_new + 1);
+        for (int64_t i = 0; i < n_new; ++i) {
+            c_ptr[(size_t)i] = o;
+            for (int32_t nd = head[(size_t)i]; nd >= 0; nd = node_next[nd]) {
+                c_img[(size_t)o] = node_img[nd];
+                c_kp[(size_t)o] = node_kp[nd];
+                ++o;
+            }
+        }
+        c_ptr[(size_t)n_new] = o;
+        const bool done = n_new == n_cur;
+        n_cur = n_new;
+        if (done) break;
+    }
+    const int64_t total = c_ptr[(size_t)n_cur];
+    std::memcpy(out_img, c_img.data(), (size_t)total * sizeof(int32_t));
+    std::memcpy(out_kp, c_kp.data(), (size_t)total * sizeof(int32_t));
+    std::memcpy(out_ptr, c_ptr.data(), (size_t)(n_cur + 1) * sizeof(int64_t));
+    if (n_passes) *n_passes = passes;
+    return n_cur;
+}

@@ -1,0 +1,290 @@
+"""MI355X-path stand-in for the reference's scripts/lib/match_cleanup.py (SURVEY.md 8f ranks
+1-2): the steps process.py runs between pair matching and bundle adjustment
+(scripts/process.py:305-331).
+
+    merge_duplicates(proj)          match_cleanup.py:19-104   keypoints with the same "%.2f-%.2f"
+                                                               pixel collapse onto the first used one
+    check_for_pair_dups(proj)       :117-146                   repeated [i, j] pairs dropped
+    check_for_1vn_dups(proj)        :158-188                   report only
+    make_match_structure(proj)      :190-220                   [None, -1, [i, kp_i], [j, kp_j]] for j > i
+    link_matches(proj, direct)      :223-301                   chains per feature, kp -> uv, longest first
+    triangulate_smart(proj, matches):303-347                   match[0] = mean ground intersection
+
+Same function names, arguments, in-place effects and result structures (plain python lists, so
+the `matches_grouped` pickle stays readable by the reference's tools).  What changes is how the
+work is done: keys are exact integers instead of formatted strings (matcher.kp_key2), per-pair
+work is numpy, the chain linking is one native routine over flat arrays
+(csrc/host_cleanup.hip, same order-dependent rules), and the per-feature ray / ground
+intersection runs on the GPU (csrc/triangulate.hip)."""
+import contextlib
+import gc
+
+import numpy as np
+
+from . import _deps
+from .matcher import _kp_xy, kp_key2
+
+CAM2BODY = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)     # lib/image.py:50-52
+
+
+def _log(*a):
+    _deps.logger().log(*a)
+
+
+def _qlog(*a):
+    _deps.logger().qlog(*a)
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """building millions of small lists: the cyclic collector would rescan them over and over"""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
+def _index_by_name(proj):
+    """name -> index of the FIRST image with that name (findImageByName / findIndexByName)."""
+    index = {}
+    for i, im in enumerate(proj.image_list):
+        index.setdefault(im.name, i)
+    return index
+
+
+def _pairs(matches):
+    return np.asarray(matches, np.int64).reshape(-1, 2)
+
+
+# --------------------------------------------------------------------------------------
+# duplicates -- match_cleanup.py:19-188 (+ project.py:331-350 compute_kp_usage)
+# --------------------------------------------------------------------------------------
+def compute_kp_usage(proj):
+    index = _index_by_name(proj)
+    for im in proj.image_list:
+        im.kp_used = np.zeros(len(im.kp_list), np.bool_)
+    for i1 in proj.image_list:
+        for key, matches in i1.match_list.items():
+            j = index.get(key)
+            if j is None or len(matches) == 0:
+                continue                      # pairs outside our area set
+            p = _pairs(matches)
+            i1.kp_used[p[:, 0]] = True
+            proj.image_list[j].kp_used[p[:, 1]] = True
+
+
+def merge_duplicates(proj):
+    compute_kp_usage(proj)
+    _log("Indexing features by unique uv coordinates:")
+    remaps = []
+    for im in proj.image_list:
+        remap = np.arange(len(im.kp_list), dtype=np.int64)
+        used = np.nonzero(im.kp_used)[0]
+        if len(used):
+            k2 = kp_key2(_kp_xy(im)[used]).astype(np.int64)
+            key = (k2[:, 0] << 32) | k2[:, 1]
+            _uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+            remap[used] = used[first[inv]]    # first used keypoint (lowest index) with that pixel
+        im.kp_remap_index = remap             # (the reference keeps a {"x-y": index} dict here)
+        remaps.append(remap)
+    _log("Merging keypoints with duplicate uv coordinates:")
+    index = _index_by_name(proj)
+    for i, i1 in enumerate(proj.image_list):
+        for key, matches in i1.match_list.items():
+            j = index.get(key)
+            if j is None or len(matches) == 0:
+                continue
+            p = _pairs(matches)
+            matches[:] = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1).tolist()
+
+
+def check_for_pair_dups(proj):
+    _log("Checking for pair duplicates (there never should be any):")
+    index = _index_by_name(proj)
+    for i1 in proj.image_list:
+        for key in list(i1.match_list):
+            matches = i1.match_list[key]
+            j = index.get(key)
+            if j is None:
+                continue
+            if len(matches) == 0:
+                i1.match_list[key] = []
+                continue
+            p = _pairs(matches)
+            code = (p[:, 0] << 32) | p[:, 1]
+            _u, first = np.unique(code, return_index=True)
+            count = len(p) - len(first)
+            if count > 0:
+                print('Match:', i1.name, 'vs', proj.image_list[j].name, 'matches:', len(matches),
+                      'dups:', count)
+            i1.match_list[key] = p[np.sort(first)].tolist()
+
+
+def check_for_1vn_dups(proj):
+    _log("Testing for 1 vs. n keypoint duplicates (there never should be any):")
+    index = _index_by_name(proj)
+    for i, i1 in enumerate(proj.image_list):
+        for key, matches in i1.match_list.items():
+            if index.get(key) is None or len(matches) == 0:
+                continue
+            p = _pairs(matches)
+            count = len(p) - len(np.unique(p[:, 0]))
+            if count > 0:
+                _qlog('Match:', i, 'vs', len(matches) - 1, 'matches:', len(matches), 'dups:', count)
+
+
+# --------------------------------------------------------------------------------------
+# unified structure + chains -- match_cleanup.py:190-301
+# --------------------------------------------------------------------------------------
+def make_match_structure(proj):
+    _log("Constructing unified match structure:")
+    index = _index_by_name(proj)
+    blocks = []
+    for i, img in enumerate(proj.image_list):
+        for key, matches in img.match_list.items():
+            j = index.get(key)
+            if j is None or j <= i or len(matches) == 0:
+                continue
+            p = _pairs(matches)
+            blocks.append(np.stack([np.full(len(p), i), p[:, 0], np.full(len(p), j), p[:, 1]], 1))
+    flat = np.concatenate(blocks) if blocks else np.zeros((0, 4), np.int64)
+    with _no_gc():
+        matches_direct = [[None, -1, [i, a], [j, b]] for i, a, j, b in flat.tolist()]
+    # link_matches() normally receives this very list: keep the array form beside it
+    n = len(flat)
+    proj._iamx_direct = (matches_direct, n,
+                         np.ascontiguousarray(flat[:, [0, 2]].ravel(), np.int32),
+                         np.ascontiguousarray(flat[:, [1, 3]].ravel(), np.int32),
+                         np.arange(n + 1, dtype=np.int64) * 2)
+    if n:
+        _log("Total feature pairs in image set:", n)
+        _log("Keypoint average instances = %.1f (should be 2.0 here)" % 2.0)
+    return matches_direct
+
+
+def _flatten(matches):
+    n = len(matches)
+    ptr = np.zeros(n + 1, np.int64)
+    if n:
+        np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
+    flat = np.array([p for m in matches for p in m[2:]], np.int64).reshape(-1, 2)
+    return (np.ascontiguousarray(flat[:, 0], np.int32), np.ascontiguousarray(flat[:, 1], np.int32),
+            ptr)
+
+
+def link_matches(proj, matches_direct):
+    """Chains of [img, kp] per feature by the reference's order-dependent rules (native code),
+    keypoint indices replaced by [u, v], longest chains first (stable)."""
+    from ._lib import c_void_p, lib
+    _log("Linking common matches together into chains:")
+    n = len(matches_direct)
+    cached = getattr(proj, '_iamx_direct', None)
+    if cached is not None and cached[0] is matches_direct and cached[1] == n:
+        img, kp, ptr = cached[2:]                 # untouched output of make_match_structure()
+    else:
+        img, kp, ptr = _flatten(matches_direct)
+    o_img, o_kp = np.empty_like(img), np.empty_like(kp)
+    o_ptr = np.zeros(n + 1, np.int64)
+    passes = np.zeros(1, np.int32)
+    P = lambda a: c_void_p(a.ctypes.data)
+    n_chain = int(lib().iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr),
+                                          P(passes)))
+    if n_chain < 0:
+        raise RuntimeError("iamx_link_matches failed (%d): %s"
+                           % (n_chain, (lib().iamx_last_error() or b'?').decode()))
+    _log("Iterations: %d (%d -> %d)" % (int(passes[0]), n, n_chain))
+    _log('Replacing keypoint indices with uv coordinates:')
+    o_ptr = o_ptr[:n_chain + 1]
+    total = int(o_ptr[-1])
+    # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt))
+    uv = np.zeros((total, 2), np.float64)
+    for i in np.unique(o_img[:total]):
+        sel = np.nonzero(o_img[:total] == i)[0]
+        uv[sel] = _kp_xy(proj.image_list[int(i)])[o_kp[sel]].astype(np.float64)
+    _log("Sorting matches by longest chain first.")
+    lens = np.diff(o_ptr)
+    order = np.argsort(-lens, kind='stable')          # list.sort(key=len, reverse=True) is stable
+    with _no_gc():
+        pts = [[i, p] for i, p in zip(o_img[:total].tolist(), uv.tolist())]
+        lo, hi = o_ptr[:-1].tolist(), o_ptr[1:].tolist()
+        out = [[None, -1] + pts[lo[c]:hi[c]] for c in order.tolist()]
+    if n_chain:
+        _log("Total unique features in image set:", n_chain)
+        _log("Keypoint average instances:", "%.2f" % (total / float(n_chain)))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# initial triangulation -- match_cleanup.py:303-347
+# --------------------------------------------------------------------------------------
+def _base_elevations(proj):
+    """per image: /smart/<name>/tri_surface_m if present, else the SRTM ground under the camera
+    (lib.srtm, only inside the reference environment); never above 1 m below the camera."""
+    smart = _deps.smart()
+    if smart is not None:
+        smart.load(proj.analysis_dir)
+        smart_node = smart.smart_node
+    else:
+        smart_node = _deps.getNode("/smart", True)
+    srtm = None
+    base = np.zeros(len(proj.image_list))
+    for i, image in enumerate(proj.image_list):
+        image_node = smart_node.getChild(image.name, True)
+        ned, _ypr, _quat = image.get_camera_pose()
+        if image_node.hasChild("tri_surface_m"):
+            b = image_node.getFloat("tri_surface_m")
+        else:
+            if srtm is None:
+                import importlib
+                try:
+                    srtm = importlib.import_module('lib.srtm')
+                except Exception:
+                    raise RuntimeError("no /smart/%s/tri_surface_m estimate and no lib.srtm to "
+                                       "look the ground elevation up" % image.name)
+            b = srtm.ned_interp([ned[0], ned[1]])[0]
+        if -ned[2] - 1 < b:
+            b = -ned[2] - 1
+        image.base_elev = b
+        base[i] = b
+    return base
+
+
+def triangulate_smart(proj, matches):
+    import torch
+    from . import kernels
+    from .kernels import _ptr, check, lib, stream_ptr
+    cam = _deps.camera()
+    IK = np.linalg.inv(cam.get_K(optimized=False))
+    _log("Looking up [smart] base elevation for each image location...")
+    base = _base_elevations(proj)
+    _log("Estimating initial projection for each feature...")
+    n_img = len(proj.image_list)
+    M = np.zeros((n_img, 9))
+    ned = np.zeros((n_img, 3))
+    for i, image in enumerate(proj.image_list):
+        cam2body = image.get_cam2body() if hasattr(image, 'get_cam2body') else CAM2BODY
+        M[i] = image.get_body2ned().dot(cam2body).dot(IK).ravel()
+        ned[i] = image.get_camera_pose()[0]
+    n = len(matches)
+    if n == 0:
+        return
+    ptr = np.zeros(n + 1, np.int64)
+    np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
+    obs_img = np.array([p[0] for m in matches for p in m[2:]], np.int32)
+    obs_uv = np.array([p[1] for m in matches for p in m[2:]], np.float64).reshape(-1, 2)
+    dev = kernels.require_gpu()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_M, d_ned, d_base, d_img, d_uv, d_ptr = (t(a) for a in (M, ned, base, obs_img, obs_uv, ptr))
+    out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    n_sky = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().iamx_triangulate_ground(_ptr(d_M), _ptr(d_ned), _ptr(d_base), n_img, _ptr(d_img),
+                                        _ptr(d_uv), _ptr(d_ptr), n, _ptr(out), _ptr(n_sky),
+                                        stream_ptr()), 'iamx_triangulate_ground')
+    res = out.cpu().numpy().tolist()
+    for _ in range(int(n_sky.item())):
+        _log('vector projected above horizon.')
+    for m, p in zip(matches, res):
+        m[0] = p

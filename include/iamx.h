@@ -200,6 +200,28 @@ int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, cons
                           int32_t *out_cnt, int32_t *out_pairs, int32_t *scratch,
                           int32_t *out_stat, int32_t *status, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * match consolidation (host) and initial triangulation (device).
+ *
+ * iamx_link_matches -- scripts/lib/match_cleanup.py:246-301 link_matches(): HOST arrays in and
+ *   out (no device involved).  Chain i of the input = points [ptr[i], ptr[i+1]) of (img[],
+ *   kp[]); the linked chains come back in the reference's order (the caller sorts by length),
+ *   out arrays sized like the input.  Returns the number of chains or a negative error code.
+ * iamx_triangulate_ground -- match_cleanup.py:320-347 triangulate_smart(): per feature the mean
+ *   of the ground-plane intersections of its observation rays.
+ *   M DEV [n_images][9] = (body2ned . cam2body) . inv(K) row major, ned DEV [n_images][3],
+ *   base_elev DEV [n_images], obs_img DEV [n_obs] int32, obs_uv DEV [n_obs][2] f64,
+ *   feat_ptr DEV [n_feat+1] int64, out_ned DEV [n_feat][3], n_sky DEV [1] (+= rays that point
+ *   above the horizon; they add nothing to the sum but count in the divisor, like the reference)
+ * ------------------------------------------------------------------------------------ */
+int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
+                          int64_t n_matches, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
+                          int32_t *n_passes);
+int iamx_triangulate_ground(const double *M, const double *ned, const double *base_elev,
+                            int n_images, const int32_t *obs_img, const double *obs_uv,
+                            const int64_t *feat_ptr, int64_t n_feat, double *out_ned,
+                            int32_t *n_sky, void *stream);
+
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);
 

@@ -347,6 +347,89 @@ def run_ba_case(name, seed, rows, cols, n_pts, dist, cam_calib=False, solve=True
     print(msg)
 
 
+# ---------------------------------------------------------------------------
+# G7: match consolidation + initial triangulation through the
+# reference's own lib/match_cleanup.py (merge_duplicates, check_for_*_dups,
+# make_match_structure, link_matches, triangulate_smart)
+# ---------------------------------------------------------------------------
+def run_cleanup_case(name, seed, n_img, n_kp, n_tracks):
+    from lib import match_cleanup, project as ref_project, smart as ref_smart
+    rng = np.random.default_rng(seed)
+    tmp = '/tmp/iamx_golden_%s' % name
+    os.makedirs(os.path.join(tmp, 'meta'), exist_ok=True)
+    names = ['C%03d' % i for i in range(n_img)]
+
+    class Proj(FakeProj):
+        compute_kp_usage = ref_project.ProjectMgr.compute_kp_usage      # the reference's own
+
+    proj = Proj(names, tmp)
+    # keypoints: random positions; a few share the exact same pixel (different "scales")
+    xy = []
+    for i in range(n_img):
+        p = np.stack([rng.uniform(0, W_PX - 1, n_kp), rng.uniform(0, H_PX - 1, n_kp)], 1).astype(np.float32)
+        dup = rng.permutation(n_kp)[:n_kp // 10]
+        p[dup] = p[(dup + 7) % n_kp]
+        xy.append(p)
+    # ground-truth tracks: a feature seen by a run of consecutive images, through random kps
+    pair_lists = {}
+    for _ in range(n_tracks):
+        length = int(rng.integers(2, min(6, n_img) + 1))
+        start = int(rng.integers(0, n_img - length + 1))
+        kps = rng.integers(0, n_kp, length)
+        for a in range(length):
+            for b in range(a + 1, length):
+                if b - a <= 2 and rng.random() < 0.8:
+                    pair_lists.setdefault((start + a, start + b), []).append([int(kps[a]), int(kps[b])])
+    for (i, j), lst in sorted(pair_lists.items()):
+        order = rng.permutation(len(lst))
+        lst = [lst[k] for k in order]
+        if rng.random() < 0.3 and len(lst) > 3:
+            lst.append(list(lst[1]))                          # an exact duplicate pair
+        proj.image_list[i].match_list[names[j]] = [list(p) for p in lst]
+        proj.image_list[j].match_list[names[i]] = [[p[1], p[0]] for p in lst]
+    proj.image_list[0].match_list['NOT_IN_PROJECT'] = [[1, 2], [3, 4]]
+    poses = []
+    for i, im in enumerate(proj.image_list):
+        im.kp_list = [cv2.KeyPoint(float(x), float(y), 3.0) for x, y in xy[i]]
+        ned = [30.0 * (i // 4) + rng.normal(0, 0.3), 25.0 * (i % 4) + rng.normal(0, 0.3),
+               -100.0 + rng.normal(0, 0.5)]
+        ypr = [rng.normal(0, 20.0) + (180.0 if (i // 4) % 2 else 0.0), -90.0 + rng.normal(0, 3.0),
+               rng.normal(0, 3.0)]
+        im.set_camera_pose(ned, *ypr)
+        poses.append(dict(ned=ned, ypr=ypr))
+    camera.set_K(*[K_FC6310S[k] for k in (0, 4, 2, 5)])
+    inputs = dict(names=names, xy=[p.copy() for p in xy], poses=poses,
+                  match_lists=[{k: [list(p) for p in v] for k, v in im.match_list.items()}
+                               for im in proj.image_list],
+                  K=K_FC6310S, width=W_PX, height=H_PX)
+    with quiet():
+        match_cleanup.merge_duplicates(proj)
+        match_cleanup.check_for_pair_dups(proj)
+        match_cleanup.check_for_1vn_dups(proj)
+    after = [{k: [list(map(int, p)) for p in v] for k, v in im.match_list.items()}
+             for im in proj.image_list]
+    kp_used = [im.kp_used.copy() for im in proj.image_list]
+    with quiet():
+        direct = match_cleanup.make_match_structure(proj)
+        direct_copy = pickle.loads(pickle.dumps(direct))
+        grouped = match_cleanup.link_matches(proj, direct)
+    # triangulate_smart: per-image surface estimate from the smart node (no SRTM tiles here)
+    base = {}
+    for i, im in enumerate(proj.image_list):
+        base[im.name] = float(rng.uniform(-3.0, 12.0))
+        ref_smart.smart_node.getChild(im.name, True).setFloat('tri_surface_m', base[im.name])
+    ref_smart.load = lambda path: None                        # keep the values set above
+    tri = pickle.loads(pickle.dumps(grouped))
+    with quiet():
+        match_cleanup.triangulate_smart(proj, tri)
+    with open(os.path.join(GOLD, 'cleanup_%s.pkl' % name), 'wb') as f:
+        pickle.dump(dict(inputs=inputs, match_lists_after=after, kp_used=kp_used,
+                         matches_direct=direct_copy, matches_grouped=grouped, base_elev=base,
+                         matches_triangulated=tri), f, protocol=4)
+    print('cleanup_%s: %d images, %d direct pairs -> %d chains (longest %d)'
+          % (name, n_img, len(direct_copy), len(grouped), len(grouped[0]) - 2))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     # G1 ------------------------------------------------------------------
@@ -363,6 +446,9 @@ def main():
     run_ba_case('calib', seed=23, rows=3, cols=3, n_pts=120,
                 dist=(-0.05, 0.02, 0.001, -0.0005, 0.0), cam_calib=True)
     run_ba_case('mid', seed=24, rows=5, cols=6, n_pts=700, dist=(0, 0, 0, 0, 0))
+    # G7 ------------------------------------------------------------------
+    run_cleanup_case('small', seed=31, n_img=6, n_kp=120, n_tracks=150)
+    run_cleanup_case('strip', seed=32, n_img=16, n_kp=600, n_tracks=1500)
 
 
 if __name__ == '__main__':

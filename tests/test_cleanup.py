@@ -1,0 +1,128 @@
+"""Match consolidation against the golden vectors produced by the reference's
+own scripts/lib/match_cleanup.py (oracle/gen_golden.py G7).  The chain linking is native HOST code
+in libiamx.so (no device work), so these run without a GPU; the triangulation test is the GPU one."""
+import copy
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+CASES = sorted(glob.glob(os.path.join(GOLDEN, 'cleanup_*.pkl')))
+
+
+class KP(object):
+    def __init__(self, x, y):
+        self.pt = (float(x), float(y))
+
+
+def _project(g):
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    inp = g['inputs']
+    proj = PoseProject(inp['names'])
+    for i, im in enumerate(proj.image_list):
+        im.kp_list = [KP(x, y) for x, y in inp['xy'][i]]
+        im.match_list = copy.deepcopy(inp['match_lists'][i])
+        im.set_camera_pose(inp['poses'][i]['ned'], *inp['poses'][i]['ypr'])
+    K = inp['K']
+    camera.set_K(K[0], K[4], K[2], K[5])
+    return proj
+
+
+@pytest.mark.parametrize('path', CASES, ids=os.path.basename)
+def test_consolidation_equals_reference(path):
+    from imageanalysis_amd import match_cleanup
+    with open(path, 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    match_cleanup.merge_duplicates(proj)
+    match_cleanup.check_for_pair_dups(proj)
+    match_cleanup.check_for_1vn_dups(proj)
+    for im, want, used in zip(proj.image_list, g['match_lists_after'], g['kp_used']):
+        assert list(im.match_list.keys()) == list(want.keys())
+        for k in want:
+            assert im.match_list[k] == want[k], (im.name, k)
+        assert np.array_equal(im.kp_used, used)
+    direct = match_cleanup.make_match_structure(proj)
+    assert direct == g['matches_direct']
+    grouped = match_cleanup.link_matches(proj, direct)
+    assert grouped == g['matches_grouped']
+    assert all(type(p[0]) is int and type(p[1][0]) is float for m in grouped for p in m[2:])
+    pickle.loads(pickle.dumps(grouped))                   # plain python: the matches_grouped pickle
+
+
+def test_link_matches_scale_and_determinism():
+    """a larger random survey: native linking == a literal python transcription of the rules"""
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    rng = np.random.default_rng(5)
+    n_img, n_kp = 40, 3000
+    proj = PoseProject(['L%03d' % i for i in range(n_img)])
+    for im in proj.image_list:
+        xy = np.stack([rng.uniform(0, 5000, n_kp), rng.uniform(0, 3000, n_kp)], 1).astype(np.float32)
+        im.kp_list = [KP(x, y) for x, y in xy]
+    direct = []
+    for i in range(n_img):
+        for j in range(i + 1, min(i + 4, n_img)):
+            a = rng.choice(n_kp, 800, replace=False)
+            b = rng.choice(n_kp, 800, replace=False)
+            direct += [[None, -1, [i, int(x)], [j, int(y)]] for x, y in zip(a, b)]
+
+    def python_rules(matches):                           # match_cleanup.py:246-286, verbatim logic
+        matches = [list(m) for m in matches]
+        while True:
+            new, lookup = [], {}
+            for match in matches:
+                index = -1
+                for p in match[2:]:
+                    if (p[0], p[1]) in lookup:
+                        index = lookup[(p[0], p[1])]
+                        break
+                if index < 0:
+                    for p in match[2:]:
+                        lookup[(p[0], p[1])] = len(new)
+                    new.append(list(match))
+                else:
+                    existing = new[index]
+                    for p in match[2:]:
+                        if not any(p[0] == e[0] for e in existing[2:]):
+                            existing.append(list(p))
+                            lookup[(p[0], p[1])] = index
+            if len(new) == len(matches):
+                return new
+            matches = new
+
+    want = python_rules(direct)
+    want.sort(key=len, reverse=True)
+    got = match_cleanup.link_matches(proj, direct)
+    assert len(got) == len(want) and len(got) < len(direct)
+    for a, b in zip(got, want):
+        assert [p[0] for p in a[2:]] == [p[0] for p in b[2:]]
+        for p, q in zip(a[2:], b[2:]):
+            assert p[1] == list(proj.image_list[q[0]].kp_list[q[1]].pt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', CASES, ids=os.path.basename)
+def test_triangulate_smart_equals_reference(path):
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd._deps import getNode
+    with open(path, 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    for name, b in g['base_elev'].items():
+        getNode('/smart', True).getChild(name, True).setFloat('tri_surface_m', b)
+    matches = copy.deepcopy(g['matches_grouped'])
+    match_cleanup.triangulate_smart(proj, matches)
+    want = g['matches_triangulated']
+    assert len(matches) == len(want)
+    got = np.array([m[0] for m in matches])
+    ref = np.array([m[0] for m in want])
+    assert got.shape == ref.shape == (len(want), 3)
+    assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())     # f64, same formulas
+    assert all(m[2:] == w[2:] for m, w in zip(matches, want))
+    assert all(type(m[0]) is list and type(m[0][0]) is float for m in matches)
