@@ -147,3 +147,71 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     if (n_passes) *n_passes = passes;
     return n_cur;
 }
+
+// One group level of scripts/lib/groups.py:59-118 compute() (HOST): pick the seed feature (the
+// unused chain with the most unplaced images, > 2, none of its images placed before), then
+// sweep all chains repeatedly, adding every unused chain that is connected to the growing group
+// by the reference's counting rules, until a sweep adds nothing.
+//   img / ptr        the chains (image index of every point)
+//   level            [n_matches] in/out: -1 = unused, else the group level it was added at
+//   placed_images    [n_images] 0/1: images placed by EARLIER levels
+//   placed_matches   [n_images] out: features placed per image at this level
+// returns the seed chain index, or -1 when no seed exists (placed_matches is zeroed either way).
+extern "C" int64_t iamx_group_level(const int32_t *img, const int64_t *ptr, int64_t n_matches,
+                                    int n_images, int32_t *level, const uint8_t *placed_images,
+                                    int group_level, int use_single_pairs, int max_wanted,
+                                    int min_connections, int32_t *placed_matches)
+{
+    if (n_matches < 0 || n_images <= 0 || !ptr || !level || !placed_images || !placed_matches ||
+        (n_matches > 0 && !img)) {
+        iamx::fail(IAMX_EINVAL, "iamx_group_level: null pointer or bad count");
+        return IAMX_EINVAL;
+    }
+    std::memset(placed_matches, 0, (size_t)n_images * sizeof(int32_t));
+    int max_connections = 2;
+    int64_t seed = -1;
+    for (int64_t i = 0; i < n_matches; ++i) {
+        if (level[i] >= 0) continue;
+        int count = 0;
+        bool connected = false;
+        for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) {
+            if (placed_images[img[j]]) connected = true; else ++count;
+        }
+        if (!connected && count > max_connections) { max_connections = count; seed = i; }
+    }
+    if (seed < 0) return -1;
+    auto add = [&](int64_t i) {
+        for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) ++placed_matches[img[j]];
+        level[i] = group_level;
+    };
+    const int seed_image = img[ptr[seed] + 1];          // match[3]: the SECOND point of the chain
+    add(seed);
+    bool still_working = true;
+    while (still_working) {
+        still_working = false;
+        for (int64_t i = 0; i < n_matches; ++i) {
+            if (level[i] >= 0) continue;
+            const int64_t len = ptr[i + 1] - ptr[i];
+            if (!(use_single_pairs || len > 2)) continue;
+            int placed_count = 0, placed_need_count = 0, unplaced_count = 0;
+            bool seed_connection = false;
+            for (int64_t j = ptr[i]; j < ptr[i + 1]; ++j) {
+                const int im = img[j];
+                if (placed_images[im]) continue;        // placed in a previous grouping
+                if (im == seed_image) seed_connection = true;
+                const int pm = placed_matches[im];
+                if (pm >= max_wanted) ++placed_count;
+                else if (pm >= min_connections) { ++placed_count; ++placed_need_count; }
+                else if (pm > 0) ++placed_need_count;
+                else ++unplaced_count;
+            }
+            if (placed_count > 1 || (use_single_pairs && placed_count > 0) || seed_connection) {
+                if (placed_need_count > 0 || unplaced_count > 0) {
+                    add(i);
+                    still_working = true;
+                }
+            }
+        }
+    }
+    return seed;
+}

@@ -217,6 +217,14 @@ int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, cons
 int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
                           int64_t n_matches, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                           int32_t *n_passes);
+/* iamx_group_level -- one group level of scripts/lib/groups.py:59-118 compute() (HOST arrays):
+ * seed chain + sweeps until nothing can be added.  level [n_matches] in/out (-1 = unused),
+ * placed_images [n_images] 0/1 from earlier levels, placed_matches [n_images] out.  Returns the
+ * seed chain index, -1 if there is none, or a negative error code < -1. */
+int64_t iamx_group_level(const int32_t *img, const int64_t *ptr, int64_t n_matches, int n_images,
+                         int32_t *level, const uint8_t *placed_images, int group_level,
+                         int use_single_pairs, int max_wanted, int min_connections,
+                         int32_t *placed_matches);
 int iamx_triangulate_ground(const double *M, const double *ned, const double *base_elev,
                             int n_images, const int32_t *obs_img, const double *obs_uv,
                             const int64_t *feat_ptr, int64_t n_feat, double *out_ned,

@@ -352,7 +352,7 @@ def run_ba_case(name, seed, rows, cols, n_pts, dist, cam_calib=False, solve=True
 # reference's own lib/match_cleanup.py (merge_duplicates, check_for_*_dups,
 # make_match_structure, link_matches, triangulate_smart)
 # ---------------------------------------------------------------------------
-def run_cleanup_case(name, seed, n_img, n_kp, n_tracks):
+def run_cleanup_case(name, seed, n_img, n_kp, n_tracks, gap=None):
     from lib import match_cleanup, project as ref_project, smart as ref_smart
     rng = np.random.default_rng(seed)
     tmp = '/tmp/iamx_golden_%s' % name
@@ -375,6 +375,8 @@ def run_cleanup_case(name, seed, n_img, n_kp, n_tracks):
     for _ in range(n_tracks):
         length = int(rng.integers(2, min(6, n_img) + 1))
         start = int(rng.integers(0, n_img - length + 1))
+        if gap is not None and start < gap <= start + length - 1:
+            continue                                          # two disconnected blocks of images
         kps = rng.integers(0, n_kp, length)
         for a in range(length):
             for b in range(a + 1, length):
@@ -422,10 +424,21 @@ def run_cleanup_case(name, seed, n_img, n_kp, n_tracks):
     tri = pickle.loads(pickle.dumps(grouped))
     with quiet():
         match_cleanup.triangulate_smart(proj, tri)
+    # lib/groups.py:25-133 compute(): connected image groups + per-feature group level
+    from lib import groups as ref_groups
+    grp_in = pickle.loads(pickle.dumps(tri))
+    group_out = {}
+    for mcl in (0, 2):
+        getNode('/config/matcher', True).setInt('min_chain_len', mcl)
+        work = pickle.loads(pickle.dumps(grp_in))
+        with quiet():
+            gl = ref_groups.compute(proj.image_list, work)
+        group_out[mcl] = dict(groups=gl, levels=[m[1] for m in work])
+    getNode('/config/matcher', True).setInt('min_chain_len', 0)
     with open(os.path.join(GOLD, 'cleanup_%s.pkl' % name), 'wb') as f:
         pickle.dump(dict(inputs=inputs, match_lists_after=after, kp_used=kp_used,
                          matches_direct=direct_copy, matches_grouped=grouped, base_elev=base,
-                         matches_triangulated=tri), f, protocol=4)
+                         matches_triangulated=tri, groups=group_out), f, protocol=4)
     print('cleanup_%s: %d images, %d direct pairs -> %d chains (longest %d)'
           % (name, n_img, len(direct_copy), len(grouped), len(grouped[0]) - 2))
 
@@ -449,6 +462,7 @@ def main():
     # G7 ------------------------------------------------------------------
     run_cleanup_case('small', seed=31, n_img=6, n_kp=120, n_tracks=150)
     run_cleanup_case('strip', seed=32, n_img=16, n_kp=600, n_tracks=1500)
+    run_cleanup_case('twoblocks', seed=33, n_img=22, n_kp=1500, n_tracks=2600, gap=12)
 
 
 if __name__ == '__main__':

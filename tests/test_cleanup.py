@@ -106,6 +106,33 @@ def test_link_matches_scale_and_determinism():
             assert p[1] == list(proj.image_list[q[0]].kp_list[q[1]].pt)
 
 
+@pytest.mark.parametrize('min_chain_len', [0, 2])
+@pytest.mark.parametrize('path', CASES, ids=os.path.basename)
+def test_groups_compute_equals_reference(path, min_chain_len):
+    from imageanalysis_amd import groups
+    from imageanalysis_amd._deps import getNode
+    with open(path, 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    matches = copy.deepcopy(g['matches_triangulated'])
+    getNode('/config/matcher', True).setInt('min_chain_len', min_chain_len)
+    try:
+        got = groups.compute(proj.image_list, matches)
+    finally:
+        getNode('/config/matcher', True).setInt('min_chain_len', 0)
+    want = g['groups'][min_chain_len]
+    assert got == want['groups']                          # same groups, same order of names
+    assert [m[1] for m in matches] == want['levels']
+
+
+def test_groups_save_load_roundtrip(tmp_path):
+    from imageanalysis_amd import groups
+    gl = [['b', 'a', 'c'], ['z']]
+    groups.save(str(tmp_path), gl)
+    assert groups.load(str(tmp_path)) == gl
+    assert groups.load(str(tmp_path / 'missing')) == []
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('path', CASES, ids=os.path.basename)
 def test_triangulate_smart_equals_reference(path):
