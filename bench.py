@@ -628,9 +628,10 @@ def ba_bench(rank, world, dev, dist, args):
     prob.set_x(res.x)
     mre = float(np.sqrt(2.0 * res.cost / (2 * O)))
     HBM = 8000.0
-    # the dominant BA kernels: one fused LSMR iteration (forward, adjoint, update) streams
-    #   forward  O*(160 J + 8 idx + 32 ut r/w) + n*32        adjoint O*(160 J + 32 ut + 4 idx) + n*40
-    #   update   n*56                                          (bytes; J = scaled f64 blocks)
+    # the dominant BA kernels: one fused LSMR iteration streams (bytes; J = scaled f64 blocks)
+    #   forward + camera adjoint  O*(160 J + 8 idx + 32 ut r/w) + n*32   (J read once per iteration)
+    #   point adjoint             O*(48 Jp + 16 ut gather + 4 idx) + n*40
+    #   update                    n*56
     lsmr = None
     if world == 1:
         prob.residual_jac()
@@ -645,8 +646,8 @@ def ba_bench(rank, world, dev, dist, args):
         ba_solver.lsmr_device_fused(prob, d_dev, dreg, atol=0, btol=0, conlim=0, maxiter=its)
         sync()
         t_it = (time.perf_counter() - t1) / its
-        by = O * (200.0 + 196.0) + prob.n * 128.0
-        lsmr = {"bound": "hbm", "kernels": "lsmr_fwd + lsmr_adj + lsmr_update3",
+        by = O * (200.0 + 68.0) + prob.n * 128.0
+        lsmr = {"bound": "hbm", "kernels": "lsmr_fwd (+camera adjoint) + lsmr_sumU + lsmr_adj + lsmr_update3",
                 "achieved": round(by / t_it / 1e9, 1), "peak": HBM, "unit": "GB/s",
                 "frac": round(by / t_it / 1e9 / HBM, 4), "us_per_iteration": round(t_it * 1e6, 1),
                 "bytes_per_iteration": by}

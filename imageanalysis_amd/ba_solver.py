@@ -456,7 +456,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
                                  Jc_s=z(prob.O * 14), Jp_s=z(prob.O * 6), Jp_p=z(prob.O * 6),
                                  state=z(L.iamx_ba_lsmr_state_size()),
                                  part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
-                                 xr=z(1), tbuf=z(n if multi else 1))
+                                 xr=z(1), tbuf=z(n))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
     ph = _Phase(prob, 'lsmr:init')
     ph.__enter__()
@@ -499,7 +499,8 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
               _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
     for _ in range(int(maxiter) // chunk + 3):
         if not multi:
-            check(L.iamx_ba_lsmr_iterate(*common, chunk, stream_ptr()), 'iamx_ba_lsmr_iterate')
+            check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
+                                         stream_ptr()), 'iamx_ba_lsmr_iterate')
         else:
             xr, tbuf = ws['xr'], ws['tbuf']
             tail = (_ptr(xr), _ptr(tbuf))

@@ -335,9 +335,15 @@ extern "C" int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *
 //   workgroup re-derives the scalars it needs in its prologue from the partial sums of the
 //   previous kernel (same instruction sequence => bit-identical in all workgroups); workgroup 0
 //   writes the next state buffer, which nobody reads in the same kernel.  An iteration is
-//   three launches (forward, adjoint, update) and no host synchronisation; the stopping tests
-//   of iteration k run in the prologue of iteration k+1's forward kernel and latch R_ISTOP,
-//   which turns everything enqueued behind it into no-ops.
+//   four launches and no host synchronisation; the stopping tests of iteration k run in the
+//   prologue of iteration k+1's forward kernel and latch R_ISTOP, which turns everything
+//   enqueued behind it into no-ops.
+// * Each camera block of J is read ONCE per iteration: the forward kernel runs one workgroup per
+//   camera (observations are camera-major), forms ut' for its observations and, with the
+//   blocks still in registers, the camera part of J^T ut' (raw, unscaled: beta' is not known
+//   yet).  The point part of J^T ut' is a second kernel over the point-sorted copy of Jp.
+//       forward+camera adjoint   O*(160 J + 8 idx + 32 ut r/w)
+//       point adjoint            O*(48 Jp + 16 ut gather + 4 idx)      + n-vectors
 // =====================================================================================
 namespace {
 
@@ -363,15 +369,16 @@ struct LsmrArgs {
     double *S;                   // state block [R_COUNT]
     double *partU, *partV, *partX;
     int n_partV;
-    // multi-rank form (observations sharded by point, n-vectors replicated): the two sums that
-    // span ranks leave the chain through `xr[0]` (local |ut1|^2) and `tbuf` (local J^T ut1, n
-    // doubles), which the caller all-reduces between the phases; null on a single rank.
     double *partU2;
+    // xr[0] = |ut1'|^2 (rank local), tbuf = raw J^T ut1' (camera part always; with multi != 0
+    // also the point part).  Multi-rank form (observations sharded by point, n-vectors
+    // replicated): the caller all-reduces xr[0] and tbuf[0..n) between the phases.
     double *xr, *tbuf;
+    int multi;
 };
 
 
-constexpr int LS_FWD_BLOCKS = 1024;   // fixed grids => fixed reduction trees
+constexpr int LS_U2_BLOCKS = 256;     // fixed grids => fixed reduction trees
 constexpr int LS_UPD_BLOCKS = 1024;
 
 struct Givens { double c, s, r; };
@@ -405,12 +412,11 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
     return block_sum_256(acc, sh);
 }
 
-// beta' = |ut'|: single rank from the forward kernel's partials; multi rank from the all-reduced
-// rank-local part xr[0] plus the replicated part
+// beta' = |ut'|: the observation part xr[0] (summed by lsmr_sumU_kernel, all-reduced by the
+// caller on several ranks) plus the replicated n-vector part
 __device__ __forceinline__ double beta_new(const LsmrArgs &A, double *sh)
 {
-    if (A.xr) return sqrt(A.xr[0] + sum_partials(A.partU2, LS_FWD_BLOCKS, sh));
-    return sqrt(sum_partials(A.partU, LS_FWD_BLOCKS, sh));
+    return sqrt(A.xr[0] + sum_partials(A.partU2, LS_U2_BLOCKS, sh));
 }
 
 // one thread per observation: scaled SoA copies in observation order
@@ -487,17 +493,34 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
     }
     const double ia = 1.0 / in[S_ALPHA], ab = in[S_ALPHA] / in[S_BETA];
     const int64_t O = A.n_obs;
+    if ((int)blockIdx.x >= A.n_cams) {       // the replicated n-vector part of ut'
+        const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+        double acc2 = 0.0;
+        for (int64_t i = (int64_t)(blockIdx.x - A.n_cams) * 256 + threadIdx.x; i < n; i += (int64_t)LS_U2_BLOCKS * 256) {
+            const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
+            A.u2[i] = v;
+            acc2 += v * v;
+        }
+        const double s2 = block_sum_256(acc2, sh);
+        if (threadIdx.x == 0) A.partU2[blockIdx.x - A.n_cams] = s2;
+        return;
+    }
+    // one camera: its 7 entries of vt are wave-uniform (scalar loads)
+    const int c = blockIdx.x;
+    const double *vc = A.vt + (int64_t)c * 7;
     const double *xp = A.vt + (int64_t)A.n_cams * 7;
     double acc = 0.0;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < O; o += (int64_t)LS_FWD_BLOCKS * 256) {
-        const double *vc = A.vt + (int64_t)A.cam_idx[o] * 7;
+    double t7[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int o = A.cam_ptr[c] + threadIdx.x; o < A.cam_ptr[c + 1]; o += 256) {
         const double *vp = xp + (int64_t)A.pt_idx[o] * 3;
+        double ju[7], jv[7];
         double a = 0.0, b = 0.0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-            const double v = vc[k];
-            a += A.Jc_s[(int64_t)k * O + o] * v;
-            b += A.Jc_s[(int64_t)(7 + k) * O + o] * v;
+            ju[k] = A.Jc_s[(int64_t)k * O + o];
+            jv[k] = A.Jc_s[(int64_t)(7 + k) * O + o];
+            a += ju[k] * vc[k];
+            b += jv[k] * vc[k];
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -505,52 +528,58 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
             a += A.Jp_s[(int64_t)k * O + o] * v;
             b += A.Jp_s[(int64_t)(3 + k) * O + o] * v;
         }
-        double2 u = *reinterpret_cast<double2 *>(A.u1 + 2 * o);
+        double2 u = *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o);
         u.x = a * ia - ab * u.x;
         u.y = b * ia - ab * u.y;
-        *reinterpret_cast<double2 *>(A.u1 + 2 * o) = u;
+        *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o) = u;
         acc += u.x * u.x + u.y * u.y;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t7[k] += ju[k] * u.x + jv[k] * u.y;      // camera part of J^T ut'
     }
-    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
-    double acc2 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_FWD_BLOCKS * 256) {
-        const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
-        A.u2[i] = v;
-        acc2 += v * v;
+    __shared__ double red[4][8];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) t7[k] += __shfl_xor(t7[k], m);
     }
-    if (A.xr) {                  // rank-local and replicated parts are summed separately
-        const double s1 = block_sum_256(acc, sh);
-        const double s2 = block_sum_256(acc2, sh);
-        if (threadIdx.x == 0) { A.partU[blockIdx.x] = s1; A.partU2[blockIdx.x] = s2; }
-    } else {
-        const double s = block_sum_256(acc + acc2, sh);
-        if (threadIdx.x == 0) A.partU[blockIdx.x] = s;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = t7[k];
+        red[threadIdx.x >> 6][7] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 7) A.tbuf[(int64_t)c * 7 + threadIdx.x] = v;
+        else A.partU[c] = v;
     }
 }
 
-// multi-rank: xr[0] = this rank's |ut1|^2 (all-reduced by the caller before the next phase)
+// xr[0] = this rank's |ut1'|^2 (all-reduced by the caller on several ranks)
 __global__ __launch_bounds__(256) void lsmr_sumU_kernel(LsmrArgs A)
 {
     __shared__ double sh[4];
     if (A.S[R_ISTOP] != 0.0) { if (threadIdx.x == 0) A.xr[0] = 0.0; return; }
-    const double s = sum_partials(A.partU, LS_FWD_BLOCKS, sh);
+    const double s = sum_partials(A.partU, A.n_cams, sh);
     if (threadIdx.x == 0) A.xr[0] = s;
 }
 
-// ---- kernel B: beta', then vt' ---------------------------------------------------------------
-// Point workgroups come first (they are the long ones): 256 consecutive points each, whose
-// point-sorted slots form one contiguous range.  The range is streamed in rounds of ADJ_CH
-// slots: every thread forms the 3 products of 4 slots with fully coalesced loads (only the
-// 16-byte ut gather is indirect) into LDS, then thread t adds up the slots of point t in
-// ascending order.  Camera workgroups: one per camera, coalesced over its observations.
+// ---- kernel B: beta', point part of J^T ut', vt' --------------------------------------------
+// Point workgroups: 256 consecutive points each, whose point-sorted slots form one contiguous
+// range.  The range is streamed in rounds of ADJ_CH slots: every thread forms the 3 products of
+// 4 slots with fully coalesced loads (only the 16-byte ut gather is indirect) into LDS, then
+// thread t adds up the slots of point t in ascending order.  The workgroups behind them turn
+// the raw camera sums of the forward kernel into vt' (single rank only; on several ranks both
+// parts stay raw in tbuf for the all-reduce and lsmr_vt_kernel finishes).
 constexpr int ADJ_CH = 1024;
 
 __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
-    __shared__ double red[4][7];
     __shared__ double prod[3][ADJ_CH];
-    const bool raw = A.tbuf != nullptr;          // multi-rank: only the local J^T ut1, no update
+    const bool raw = A.multi != 0;
     if (A.S[R_ISTOP] != 0.0) return;             // (tbuf keeps stale values: nobody reads them)
     const double *in = A.S + parity * S_NBUF;
     double ib = 0.0, ba = 0.0;
@@ -606,36 +635,12 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
                 sq += v * v;
             }
         }
-    } else {
-        const int c = (int)blockIdx.x - n_pt_blocks;
-        double acc[7] = {0, 0, 0, 0, 0, 0, 0};
-        for (int o = A.cam_ptr[c] + threadIdx.x; o < A.cam_ptr[c + 1]; o += 256) {
-            const double2 uu = *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)o);
-#pragma unroll
-            for (int k = 0; k < 7; ++k)
-                acc[k] += A.Jc_s[(int64_t)k * O + o] * uu.x + A.Jc_s[(int64_t)(7 + k) * O + o] * uu.y;
-        }
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m);
-        }
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = acc[k];
-        }
-        __syncthreads();
-        if (threadIdx.x < 7) {
-            const int k = threadIdx.x;
-            const double t = red[0][k] + red[1][k] + red[2][k] + red[3][k];
-            const int64_t i = (int64_t)c * 7 + k;
-            if (raw) {
-                A.tbuf[i] = t;
-            } else {
-                const double v = (t + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
-                A.vt[i] = v;
-                sq = v * v;
-            }
+    } else {                                     // camera entries (launched on a single rank only)
+        const int i = ((int)blockIdx.x - n_pt_blocks) * 256 + threadIdx.x;
+        if (i < A.n_cams * 7) {
+            const double v = (A.tbuf[i] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
+            A.vt[i] = v;
+            sq = v * v;
         }
     }
     if (raw) return;
@@ -746,10 +751,29 @@ __global__ __launch_bounds__(256) void lsmr_update3_kernel(LsmrArgs A, int parit
 
 extern "C" int iamx_ba_lsmr_state_size(void) { return R_COUNT; }
 
+namespace {
+
+struct PartLayout {
+    int n_adj;                    // single-rank adjoint workgroups (points + camera entries)
+    int64_t off_U2, off_X, off_V, total;
+};
+
+PartLayout part_layout(int n_cams, int n_pts)
+{
+    PartLayout L;
+    L.n_adj = (n_pts + 255) / 256 + (n_cams * 7 + 255) / 256;
+    L.off_U2 = n_cams;
+    L.off_X = L.off_U2 + LS_U2_BLOCKS;
+    L.off_V = L.off_X + LS_UPD_BLOCKS;
+    L.total = L.off_V + (L.n_adj > LS_UPD_BLOCKS ? L.n_adj : LS_UPD_BLOCKS);
+    return L;
+}
+
+}  // namespace
+
 extern "C" int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts)
 {
-    const int64_t n_adj = (int64_t)n_cams + (n_pts + 255) / 256;
-    return (int64_t)2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS + (n_adj > LS_UPD_BLOCKS ? n_adj : LS_UPD_BLOCKS);
+    return part_layout(n_cams, n_pts).total;
 }
 
 extern "C" int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
@@ -774,23 +798,25 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
                                     const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
                                     const double *dreg, double *u1, double *u2, double *vt,
                                     double *h, double *hbar, double *x, double *state,
-                                    double *partials, int n_iter, void *stream)
+                                    double *partials, double *xr, double *tbuf, int n_iter,
+                                    void *stream)
 {
     IAMX_REQUIRE(Jc_s && Jp_s && Jp_p && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && dreg &&
-                     u1 && u2 && vt && h && hbar && x && state && partials,
+                     u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
                  "null pointer");
     IAMX_REQUIRE(n_obs > 0 && n_cams > 0 && n_pts > 0 && n_iter >= 0 && (n_iter & 1) == 0,
                  "bad size (n_iter must be even: the state block is double-buffered)");
-    const int n_adj_blocks = n_cams + (n_pts + 255) / 256;
+    const PartLayout L = part_layout(n_cams, n_pts);
     LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
-               partials, partials + 2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
-               n_adj_blocks, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, nullptr, nullptr};
+               partials, partials + L.off_V, partials + L.off_X, L.n_adj, partials + L.off_U2,
+               xr, tbuf, 0};
     hipStream_t st = iamx::as_stream(stream);
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
-        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(LS_FWD_BLOCKS), dim3(256), 0, st, A, parity);
-        hipLaunchKernelGGL(lsmr_adj_kernel, dim3(n_adj_blocks), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(lsmr_adj_kernel, dim3(L.n_adj), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
     }
     return iamx::check_launch("iamx_ba_lsmr_iterate");
@@ -798,8 +824,9 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
 
 // One phase of one iteration of the multi-rank form (the caller all-reduces xr[0] after phase 0
 // and tbuf[0..n) after phase 1, on the same stream):
-//   phase 0: stopping tests of the previous iteration, ut', xr[0] = local |ut1'|^2
-//   phase 1: tbuf = local J^T ut1'
+//   phase 0: stopping tests of the previous iteration, ut', raw camera part of J^T ut1' -> tbuf,
+//            xr[0] = local |ut1'|^2
+//   phase 1: raw point part of J^T ut1' -> tbuf
 //   phase 2: vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
 extern "C" int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
                                   const int32_t *cam_idx, const int32_t *pt_idx,
@@ -815,17 +842,17 @@ extern "C" int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const 
     IAMX_REQUIRE(n_obs >= 0 && n_cams > 0 && n_pts > 0 && phase >= 0 && phase <= 2 &&
                      (parity == 0 || parity == 1),
                  "bad size / phase / parity");
-    const int n_adj_blocks = n_cams + (n_pts + 255) / 256;
+    const PartLayout L = part_layout(n_cams, n_pts);
     LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
-               partials, partials + 2 * LS_FWD_BLOCKS + LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS,
-               LS_UPD_BLOCKS, partials + LS_FWD_BLOCKS + LS_UPD_BLOCKS, xr, tbuf};
+               partials, partials + L.off_V, partials + L.off_X, LS_UPD_BLOCKS, partials + L.off_U2,
+               xr, tbuf, 1};
     hipStream_t st = iamx::as_stream(stream);
     if (phase == 0) {
-        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(LS_FWD_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A);
     } else if (phase == 1) {
-        hipLaunchKernelGGL(lsmr_adj_kernel, dim3(n_adj_blocks), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_adj_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, A, parity);
     } else {
         hipLaunchKernelGGL(lsmr_vt_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);

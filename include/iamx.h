@@ -332,7 +332,9 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
  *   buffered scalar recurrences, the tolerances and the latched results (layout and
  *   initialisation: imageanalysis_amd/ba_solver.py); once istop is latched the remaining
  *   iterations are no-ops.  u1 [2 n_obs], u2/vt/h/hbar/x [n] DEV work vectors; partials DEV
- *   [iamx_ba_lsmr_partials_size].  Deterministic (fixed reduction trees, no atomics). */
+ *   [iamx_ba_lsmr_partials_size]; xr DEV [1], tbuf DEV [n] scratch (|ut1|^2, raw J^T ut1).
+ *   Deterministic (fixed reduction trees, no atomics).  Every camera block of J is read once
+ *   per iteration (forward product and camera part of the adjoint in one kernel). */
 int iamx_ba_lsmr_state_size(void);
 int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts);
 int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
@@ -344,12 +346,13 @@ int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *J
                          const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
                          int n_pts, const double *dreg, double *u1, double *u2, double *vt,
                          double *h, double *hbar, double *x, double *state, double *partials,
-                         int n_iter, void *stream);
+                         double *xr, double *tbuf, int n_iter, void *stream);
 
 /* Multi-rank form of the same iteration (observations sharded by point, n-vectors replicated):
  * one call per phase; the caller all-reduces (sum) xr[0] after phase 0 and tbuf[0..n) after
  * phase 1 on the same stream (RCCL).  phase 0: stopping tests of the previous iteration, ut',
- * xr[0] = local |ut1'|^2;  phase 1: tbuf = local J^T ut1';  phase 2: vt' from the reduced tbuf,
+ * camera part of tbuf, xr[0] = local |ut1'|^2;  phase 1: point part of tbuf = local J^T ut1';
+ * phase 2: vt' from the reduced tbuf,
  * alpha', plane rotations, h / hbar / x.  parity = iteration & 1.  xr DEV [1], tbuf DEV [n]. */
 int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
                        const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
