@@ -713,14 +713,18 @@ extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,
                      pairs && wg_off && out_off && out_d2 && out_tile,
                  "null pointer");
     IAMX_REQUIRE(n_pairs >= 0 && total_wg >= 0, "negative count");
-    IAMX_REQUIRE(rows_per_wg == 256 || rows_per_wg == 512, "rows_per_wg must be 256 or 512");
+    IAMX_REQUIRE(rows_per_wg == 256 || rows_per_wg == 512 || (rows_per_wg == 1024 && !exact_second),
+                 "rows_per_wg must be 256, 512 or (bound form only) 1024");
     if (n_pairs == 0 || total_wg == 0) return IAMX_OK;
     Args2 a{desc_q, norm_q, qimg_off, qimg_n, desc_t, cinit, timg_off, tmeta, pairs, wg_off,
             out_off, out_d2, out_tile, n_pairs, total_wg};
     const dim3 g((unsigned)total_wg), b(WAVES * 64);
     hipStream_t st = iamx::as_stream(stream);
     // 512 rows = 4 query blocks per wave: fewer LDS reads per MFMA (-7 %)
-    if (rows_per_wg == 512 && exact_second) hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2>), g, b, 0, st, a);
+    // 1024 rows = 8 waves x 4 query blocks, train chunks staged global -> LDS directly (-2 %)
+    if (rows_per_wg == 1024)
+        hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, 8, true, true>), g, dim3(512), 0, st, a);
+    else if (rows_per_wg == 512 && exact_second) hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2>), g, b, 0, st, a);
     else if (rows_per_wg == 512) hipLaunchKernelGGL((knn2v2_kernel<0, 4, 2, WAVES, true>), g, b, 0, st, a);
     else if (exact_second) hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2>), g, b, 0, st, a);
     else hipLaunchKernelGGL((knn2v2_kernel<0, QW_PRODUCT, 2, WAVES, true>), g, b, 0, st, a);

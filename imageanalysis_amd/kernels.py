@@ -287,7 +287,8 @@ class PairBatch(object):
         self.d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
         self.d_out = torch.from_numpy(self.out_off.copy()).to(dev)     # also the metric seg_off
         # fast kernel: 512 query rows per workgroup when the images are large enough
-        self.fast_rows = 512 if (P and nq.min() >= 2048) else 256
+        # query rows per workgroup of the fast sweep: bigger = fewer LDS reads / barriers per MFMA
+        self.fast_rows = 256 if not (P and nq.min() >= 2048) else (1024 if nq.min() >= 4096 else 512)
         wgf = np.zeros(P + 1, np.int64)
         np.cumsum((nq + self.fast_rows - 1) // self.fast_rows, out=wgf[1:])
         self.total_wg_fast = int(wgf[-1])
@@ -316,6 +317,8 @@ class PairBatch(object):
     # ---- fast form: distances + tile in the sweep, train index only for the survivors
     def run_knn2_fast(self, ws, exact_second=False):
         st = self.store
+        if exact_second and self.fast_rows == 1024:          # the exact-second form stops at 512
+            self._use_rows(512)
         check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
                                       _ptr(st.img_n), _ptr(st.desc2), _ptr(st.cinit),
                                       _ptr(st.img_off2), _ptr(st.meta), _ptr(self.d_pairs),
@@ -323,6 +326,13 @@ class PairBatch(object):
                                       self.total_wg_fast, self.fast_rows, 1 if exact_second else 0,
                                       _ptr(ws.d2), _ptr(ws.tile), stream_ptr()),
               'iamx_knn2v2_pairs')
+
+    def _use_rows(self, rows):
+        nq = np.asarray(self.store.counts, np.int64)[self.pairs[:, 0]]
+        wgf = np.zeros(self.n_pairs + 1, np.int64)
+        np.cumsum((nq + rows - 1) // rows, out=wgf[1:])
+        self.fast_rows, self.total_wg_fast = rows, int(wgf[-1])
+        self.d_wg_fast = torch.from_numpy(wgf.astype(np.int32)).to(self.d_pairs.device)
 
     def run_filter_fast(self, ws, thresh, exact_second=False):
         """threshold + compaction + train rows.  With the bound form of the sweep the first

@@ -157,7 +157,8 @@ int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q, const int32_t
                       const int32_t *qimg_n, const int8_t *desc_t, const int32_t *cinit,
                       const int32_t *timg_off, const int32_t *tmeta, const int32_t *pairs,
                       const int32_t *wg_off, const int64_t *out_off, int n_pairs, int total_wg,
-                      int rows_per_wg /* 256 or 512: wg_off = scan of ceil(n_q / rows_per_wg) */,
+                      int rows_per_wg /* 256, 512 or (exact_second = 0 only) 1024:
+                                         wg_off = scan of ceil(n_q / rows_per_wg) */,
                       int exact_second, int32_t *out_d2, int32_t *out_tile, void *stream);
 int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q, const int32_t *qimg_off,
                         const int8_t *desc_t, const int32_t *norm2_t, const int32_t *perm,
