@@ -286,8 +286,8 @@ class PairBatch(object):
         self.d_pairs = torch.from_numpy(pairs).to(dev)
         self.d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
         self.d_out = torch.from_numpy(self.out_off.copy()).to(dev)     # also the metric seg_off
-        # fast kernel: 512 query rows per workgroup when the images are large enough
-        # query rows per workgroup of the fast sweep: bigger = fewer LDS reads / barriers per MFMA
+        # query rows per workgroup of the fast sweep (256 / 512 / 1024 by image size): bigger =
+        # fewer LDS reads and barriers per MFMA
         self.fast_rows = 256 if not (P and nq.min() >= 2048) else (1024 if nq.min() >= 4096 else 512)
         wgf = np.zeros(P + 1, np.int64)
         np.cumsum((nq + self.fast_rows - 1) // self.fast_rows, out=wgf[1:])
