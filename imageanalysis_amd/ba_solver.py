@@ -267,12 +267,17 @@ class DeviceBA(object):
         self.jtv(self.r, self.tmp_n, square=True)
         return np.sqrt(self.download_n(self.tmp_n))
 
-    def gram(self, d_host, vectors):
-        """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks."""
+    def gram(self, d_host, vectors, d_dev=None):
+        """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks.  With `d_dev` (d
+        already on the device) the scaling is applied there instead of on the host."""
         k = len(vectors)
         ys = []
         for s in vectors:
-            vs = self.upload_n(d_host * s)
+            if d_dev is None:
+                vs = self.upload_n(d_host * s)
+            else:
+                vs = self.upload_n(s)
+                self.mul2(self.n, d_dev, vs, vs)
             y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
             self.jv(vs, y)
             ys.append(y)
@@ -533,7 +538,7 @@ def lsmr(prob, d_dev, dreg_dev, **opts):
 # --------------------------------------------------------------------------------------
 # reflective step selection (scipy/optimize/_lsq/trf.py select_step) on Gram matrices
 # --------------------------------------------------------------------------------------
-def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
+def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta, d_dev=None):
     from scipy.optimize._lsq.common import (in_bounds, intersect_trust_region,
                                             minimize_quadratic_1d, step_size_to_bound)
 
@@ -541,7 +546,7 @@ def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
         return 0.5 * (G[i, i] + np.dot(s * diag_h, s)) + np.dot(g_h, s)
 
     if in_bounds(x + p, lb, ub):
-        G = prob.gram(d, [p_h])
+        G = prob.gram(d, [p_h], d_dev)
         return p, p_h, -quad(G, 0, p_h)
 
     p_stride, hits = step_size_to_bound(x, p, lb, ub)
@@ -561,7 +566,7 @@ def _select_step(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
         r_stride_l, r_stride_u = 0, -1
 
     ag_h = -g_h
-    G = prob.gram(d, [p_h, r_h, ag_h])          # all three model directions in one go
+    G = prob.gram(d, [p_h, r_h, ag_h], d_dev)   # all three model directions in one go
     if r_stride_l <= r_stride_u:
         # 1-d quadratic along r_h from s0 = p_h (scipy build_quadratic_1d with s0)
         a = 0.5 * (G[1, 1] + np.dot(r_h * diag_h, r_h))
@@ -663,8 +668,9 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             diag_h = g * dv * scale
             g_h = d * g
 
+            d_dev = prob.upload_n(d)
             # regularisation term (trf.py: build_quadratic_1d along -g_h)
-            G = prob.gram(d, [g_h])
+            G = prob.gram(d, [g_h], d_dev)
             a = 0.5 * (G[0, 0] + np.dot(g_h * diag_h, g_h))
             b = -np.dot(g_h, g_h)
             to_tr = Delta / norm(g_h)
@@ -672,14 +678,13 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             reg_term = -ag_value / Delta ** 2
 
         with _Phase(prob, 'lsmr'):
-            d_dev = prob.upload_n(d)
             dreg_dev = prob.upload_n((diag_h + reg_term) ** 0.5)
             gn_h, _istop, itn, _nr, _nar = lsmr(prob, d_dev, dreg_dev, **lsmr_opts)
             lsmr_iters += itn
         with _Phase(prob, 'subspace'):
             S = np.vstack((g_h, gn_h)).T
             S, _ = qr(S, mode='economic')
-            GS = prob.gram(d, [S[:, 0].copy(), S[:, 1].copy()])
+            GS = prob.gram(d, [S[:, 0].copy(), S[:, 1].copy()], d_dev)
             B_S = GS + np.dot(S.T * diag_h, S)
             g_S = S.T.dot(g_h)
 
@@ -691,7 +696,7 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
                 p_h = S.dot(p_S)
                 p = d * p_h
                 step, step_h, predicted_reduction = _select_step(prob, x, d, diag_h, g_h, p, p_h,
-                                                                 Delta, lb, ub, theta)
+                                                                 Delta, lb, ub, theta, d_dev)
             with _Phase(prob, 'fun'):
                 x_new = make_strictly_feasible(x + step, lb, ub, rstep=0)
                 prob.set_x(x_new)
@@ -715,9 +720,8 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
         if actual_reduction > 0:
             with _Phase(prob, 'jac+grad'):
                 x = x_new
-                cost = cost_new
-                prob.set_x(x)
-                prob.residual_jac()
+                cost = cost_new                   # (the device already holds x_new: the accepted
+                prob.residual_jac()               #  trial was the last one evaluated)
                 njev += 1
                 g = prob.grad()
                 cn = prob.colnorm()
