@@ -90,10 +90,15 @@ class DeviceBA(object):
                               (self.C * 7 + 3 * new_of_old[:, None] + np.arange(3)).ravel(), tail])
         if world > 1:
             sel = _dist.shard_observations_by_point(pt, self.P, rank, world)
-            cam, pt, uv = cam[sel], pt[sel], uv[sel]
-            self.local_obs = sel
         else:
-            self.local_obs = None
+            sel = np.arange(cam.size)
+        # Internal observation order: camera-major like the reference, but inside a camera by the
+        # (renumbered) point id, so that the point gathers of a camera walk forward through
+        # memory and the ut gathers of neighbouring points land next to each other.  local_obs[k]
+        # = position of internal observation k in the reference's list (gather_residual()).
+        sel = sel[np.lexsort((pt[sel], cam[sel]))]
+        cam, pt, uv = cam[sel], pt[sel], uv[sel]
+        self.local_obs = sel
         self.O = int(cam.size)
         self.m = 2 * self.O
         if self.O and np.any(np.diff(cam) < 0):
@@ -164,6 +169,20 @@ class DeviceBA(object):
         """device n-vector (internal point order) -> host n-vector (reference order)"""
         torch.index_select(t[:self.n], 0, self.idx_i2h, out=self.tmp_perm[:self.n])
         return self.download(self.tmp_perm, self.n)
+
+    def upload_m(self, a):
+        """host m-vector in the order of this rank's slice of the reference's observation list
+        (ascending reference index) -> device m-vector in the internal order"""
+        a = np.asarray(a, np.float64).reshape(-1, 2)
+        rank_of = np.argsort(np.argsort(self.local_obs, kind='stable'), kind='stable')
+        return self.upload(a[rank_of].ravel())
+
+    def download_m(self, t):
+        """device m-vector (internal order) -> host, ascending reference index of this rank's slice"""
+        a = self.download(t, self.m).reshape(-1, 2)
+        out = np.empty_like(a)
+        out[np.argsort(np.argsort(self.local_obs, kind='stable'), kind='stable')] = a
+        return out.ravel()
 
     # ---- parameters ------------------------------------------------------------------
     def set_x(self, x):
@@ -745,14 +764,14 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
 
 
 def gather_residual(prob, n_obs_total):
-    """full camera-major residual vector on the host (all ranks)."""
+    """full camera-major residual vector in the reference's observation order (all ranks)."""
     r = prob.download(prob.r, prob.m)
-    if prob.world == 1:
-        return r
     full = np.zeros(2 * n_obs_total)
     sel = prob.local_obs
     full[2 * sel] = r[0::2]
     full[2 * sel + 1] = r[1::2]
+    if prob.world == 1:
+        return full
     t = prob.upload(full)
     _dist.allreduce_sum_(t)
     return prob.download(t, full.size)

@@ -129,3 +129,10 @@ def test_residual_prepared_equals_plain():
     prob.residual_jac()
     b = prob.r.cpu().numpy()
     assert np.abs(a - b).max() <= 1e-9 * np.abs(b).max()
+    # ... and, back in the reference's observation order, equal the plain C-ABI residual
+    from imageanalysis_amd import kernels
+    dev = torch.device('cuda')
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    plain = kernels.ba_residual(t(p['cams0']), t(p['pts0']), t(p['cam_idx']), t(p['pt_idx']),
+                                t(p['uv']), t(np.array(calib))).cpu().numpy()
+    assert np.abs(prob.download_m(prob.r) - plain).max() <= 1e-9 * np.abs(plain).max()

@@ -44,13 +44,15 @@ def test_k4_operators_vs_csr(path):
     y = torch.empty(prob.m, dtype=torch.float64, device='cuda')
     prob.jv(prob.upload_n(v), y)               # n-vectors cross in the reference's order
     ref = J @ v
-    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(prob.download_m(y) - ref).max() <= 1e-12 * np.abs(ref).max()   # m-vectors too
     out = torch.empty(prob.n, dtype=torch.float64, device='cuda')
-    prob.jtv(torch.from_numpy(u).cuda(), out)
+    prob.jtv(prob.upload_m(u), out)
     ref = J.T @ u
     assert np.abs(prob.download_n(out) - ref).max() <= 1e-12 * np.abs(ref).max()
-    # the private point order really is a permutation of the reference's
+    # the private point / observation orders really are permutations of the reference's
     assert np.array_equal(prob.download_n(prob.upload_n(v)), v)
+    assert np.array_equal(prob.download_m(prob.upload_m(u)), u)
+    assert np.abs(prob.download_m(prob.r) - g['f0']).max() <= 1e-9 * np.abs(g['f0']).max()
     cn = prob.colnorm()
     ref = np.sqrt(np.asarray(J.power(2).sum(axis=0)).ravel())
     assert np.abs(cn - ref).max() <= 1e-12 * ref.max()
