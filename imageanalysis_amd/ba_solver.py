@@ -126,6 +126,7 @@ class DeviceBA(object):
         self.tmp_perm = z(self.n)
         self.lsmr_ws = None
         self._pin = None
+        self._state_pin = None
         self.profile = None
         self.force_stepwise_lsmr = False
 
@@ -521,7 +522,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
               _ptr(prob.pt_idx), _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), prob.O,
               prob.C, prob.P, _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h), _ptr(hbar),
               _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
-    for _ in range(int(maxiter) // chunk + 3):
+    def enqueue_chunk():
         if not multi:
             check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
                                          stream_ptr()), 'iamx_ba_lsmr_iterate')
@@ -535,9 +536,31 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
                 check(L.iamx_ba_lsmr_phase(*common, *tail, 1, par, stream_ptr()), 'iamx_ba_lsmr_phase')
                 _dist.allreduce_sum_(tbuf[:n])
                 check(L.iamx_ba_lsmr_phase(*common, *tail, 2, par, stream_ptr()), 'iamx_ba_lsmr_phase')
-        st = prob.download(ws['state'], st.size)
+
+    # The state block is copied out behind every chunk into its own pinned slot; the NEXT chunk
+    # is enqueued before the host waits for that copy, so the device never idles while the host
+    # enqueues (a chunk behind a latched stop is made of no-ops).
+    ns = st.size
+    if prob._state_pin is None:
+        prob._state_pin = (torch.empty(ns, dtype=F64).pin_memory(), torch.empty(ns, dtype=F64).pin_memory(),
+                           torch.cuda.Event(), torch.cuda.Event())
+    slots, events = prob._state_pin[:2], prob._state_pin[2:]
+
+    def snapshot(k):
+        slots[k].copy_(ws['state'][:ns], non_blocking=True)
+        events[k].record()
+
+    enqueue_chunk()
+    snapshot(0)
+    cur = 0
+    for _ in range(int(maxiter) // chunk + 3):
+        enqueue_chunk()
+        snapshot(cur ^ 1)
+        events[cur].synchronize()
+        st = slots[cur].numpy().copy()
         if st[_R['ISTOP']] != 0:
             break
+        cur ^= 1
     else:
         raise _lib.IamxError('fused LSMR did not latch a stop condition')
     ph.__exit__()
