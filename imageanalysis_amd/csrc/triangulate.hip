@@ -65,3 +65,116 @@ extern "C" int iamx_triangulate_ground(const double *M, const double *ned, const
                        out_ned, n_sky);
     return iamx::check_launch("iamx_triangulate_ground");
 }
+
+// ---------------------------------------------------------------------------------
+// Two-view linear (DLT) triangulation of matched keypoints -- scripts/lib/smart.py:26-63
+// triangulate_features(): cv2.triangulatePoints(PROJ1, PROJ2, IK.uv1, IK.uv2), then / w.
+// Per match the 4x4 system  [x1*P1_3 - P1_1; y1*P1_3 - P1_2; x2*P2_3 - P2_1; y2*P2_3 - P2_2]
+// whose null direction (right singular vector of the smallest singular value) is the point;
+// found by one-sided Jacobi (Hestenes) rotations on the columns, f64.  One thread per match;
+// all pairs of a batch in one launch.
+//   pair_img [n_pairs][2] image slots, PROJ [n_images][12] = [R | t] row major,
+//   IK [9] inverse camera matrix, match lists as iamx_match_postfilter leaves them.
+// out_z [n_pairs][clip]: NED "down" of every triangulated match (w-normalised).
+// ---------------------------------------------------------------------------------
+namespace {
+
+__device__ void null_vector_4x4(double A[4][4], double v_out[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    alpha += A[i][p] * A[i][p];
+                    beta += A[i][q] * A[i][q];
+                    gamma += A[i][p] * A[i][q];
+                }
+                off = fmax(off, fabs(gamma) / sqrt(fmax(alpha * beta, 1e-300)));
+                if (fabs(gamma) < 1e-300) continue;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double ap = A[i][p], aq = A[i][q];
+                    A[i][p] = c * ap - s * aq;
+                    A[i][q] = s * ap + c * aq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][q] = s * vp + c * vq;
+                }
+            }
+        }
+        if (off < 1e-15) break;
+    }
+    int best = 0;
+    double bn = 1e300;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double nrm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nrm += A[i][j] * A[i][j];
+        if (nrm < bn) { bn = nrm; best = j; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double v = V[i][0];
+        if (best == 1) v = V[i][1];
+        if (best == 2) v = V[i][2];
+        if (best == 3) v = V[i][3];
+        v_out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void triangulate_pairs_kernel(
+    const int32_t *__restrict__ pair_img, const double *__restrict__ PROJ, const double *__restrict__ IK,
+    const int64_t *__restrict__ kp_off, const float *__restrict__ xy,
+    const int32_t *__restrict__ m_cnt, const int32_t *__restrict__ m_pairs, int clip,
+    double *__restrict__ out_z)
+{
+    const int p = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= m_cnt[p]) return;
+    const int im1 = pair_img[2 * p], im2 = pair_img[2 * p + 1];
+    const int q = m_pairs[((int64_t)p * clip + k) * 2], t = m_pairs[((int64_t)p * clip + k) * 2 + 1];
+    const float *p1 = xy + 2 * (kp_off[im1] + q), *p2 = xy + 2 * (kp_off[im2] + t);
+    const double uv[2][2] = {{(double)p1[0], (double)p1[1]}, {(double)p2[0], (double)p2[1]}};
+    const double *P[2] = {PROJ + (int64_t)im1 * 12, PROJ + (int64_t)im2 * 12};
+    double A[4][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        // normalised image point: IK . [u, v, 1], first two components
+        const double x = IK[0] * uv[j][0] + IK[1] * uv[j][1] + IK[2];
+        const double y = IK[3] * uv[j][0] + IK[4] * uv[j][1] + IK[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            A[2 * j][c] = x * P[j][8 + c] - P[j][c];
+            A[2 * j + 1][c] = y * P[j][8 + c] - P[j][4 + c];
+        }
+    }
+    double X[4];
+    null_vector_4x4(A, X);
+    out_z[(int64_t)p * clip + k] = X[2] / X[3];
+}
+
+}  // namespace
+
+extern "C" int iamx_triangulate_pairs(const int32_t *pair_img, const double *PROJ, const double *IK,
+                                      const int64_t *kp_off, const float *xy, const int32_t *m_cnt,
+                                      const int32_t *m_pairs, int n_pairs, int clip, double *out_z,
+                                      void *stream)
+{
+    IAMX_REQUIRE(pair_img && PROJ && IK && kp_off && xy && m_cnt && m_pairs && out_z, "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && clip > 0, "bad size");
+    if (n_pairs == 0) return IAMX_OK;
+    hipLaunchKernelGGL(triangulate_pairs_kernel, dim3((unsigned)((clip + 255) / 256), (unsigned)n_pairs),
+                       dim3(256), 0, iamx::as_stream(stream), pair_img, PROJ, IK, kp_off, xy, m_cnt,
+                       m_pairs, clip, out_z);
+    return iamx::check_launch("iamx_triangulate_pairs");
+}

@@ -1,0 +1,187 @@
+"""MI355X-path stand-in for the deterministic half of the reference's scripts/lib/smart.py:
+the per-pair ground-surface estimate find_matches() keeps while it runs (lib/matcher.py:987-1005)
+and its discard policy depends on.
+
+    triangulate_features(i1, i2)        smart.py:26-63    two-view DLT of the pair's matches
+    estimate_surface_elevation(i1, i2)  smart.py:117-130  -mean / std of the "down" coordinate
+    update_surface_estimate(i1, i2)     smart.py:196-250  /smart/<image>/tri_surface_pairs/...
+    get_surface_estimate, load, save    smart.py:283-340
+
+The triangulation runs on the GPU (csrc/triangulate.hip iamx_triangulate_pairs; find_matches
+does a whole batch of pairs in one launch and hands the statistics to record_surface_estimate).
+NOT here: estimate_yaw_error / update_yaw_error_estimate (smart.py:138-281) rest on
+cv2.estimateAffinePartial2D, a RANSAC fit that is not reproducible; update_yaw_error_estimate
+returns 0 and records nothing.  Inside the reference environment lib.smart itself is used
+(_deps.smart())."""
+import json
+import os
+
+import numpy as np
+
+from . import _deps
+
+smart_node = _deps.getNode("/smart", True)
+CAM2BODY = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)      # lib/image.py:50-52
+
+
+def projection_matrix(image):
+    """[R | t] with R = body2cam . ned2body, t = -R . ned  (lib/image.py:542-553 get_proj,
+    without the detour through a Rodrigues vector)."""
+    ned, _ypr, _quat = image.get_camera_pose()
+    cam2body = image.get_cam2body() if hasattr(image, 'get_cam2body') else CAM2BODY
+    R = np.linalg.inv(cam2body).dot(np.asarray(image.get_body2ned()).T)
+    return np.hstack([R, -R.dot(np.asarray(ned, float).reshape(3, 1))])
+
+
+def triangulate_down(i1, i2, pairs):
+    """NED "down" of the DLT-triangulated matches `pairs` ([[kp1, kp2], ...]) of one image pair."""
+    import torch
+    from . import kernels
+    from .kernels import _ptr, check, lib, stream_ptr
+    from .matcher import _kp_xy
+    cam = _deps.camera()
+    dev = kernels.require_gpu()
+    pairs = np.asarray(pairs, np.int32).reshape(-1, 2)
+    n = len(pairs)
+    if n == 0:
+        return np.zeros(0)
+    xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    PROJ = np.stack([projection_matrix(i1).ravel(), projection_matrix(i2).ravel()])
+    IK = np.linalg.inv(cam.get_K())
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    args = (t(np.array([[0, 1]]), torch.int32), t(PROJ, torch.float64), t(IK.ravel(), torch.float64),
+            t(np.array([0, len(xy1)]), torch.int64), t(np.concatenate([xy1, xy2]), torch.float32),
+            t(np.array([n]), torch.int32), t(pairs, torch.int32))
+    check(lib().iamx_triangulate_pairs(*[_ptr(a) for a in args], 1, n, _ptr(out), stream_ptr()),
+          'iamx_triangulate_pairs')
+    return out.cpu().numpy()
+
+
+def triangulate_features(i1, i2):
+    """only the row the callers use is produced: a [1, N] array of "down" coordinates is NOT
+    the reference's 4xN; use estimate_surface_elevation()."""
+    raise NotImplementedError("use estimate_surface_elevation(); the device kernel returns the "
+                              "down coordinate only")
+
+
+def _pair_distance(i1, i2):
+    ned1, _, _ = i1.get_camera_pose()
+    ned2, _, _ = i2.get_camera_pose()
+    return np.linalg.norm(np.array(ned2) - np.array(ned1))
+
+
+def estimate_surface_elevation(i1, i2):
+    dist_m = _pair_distance(i1, i2)
+    if i1 == i2 or i2.name not in i1.match_list or len(i1.match_list[i2.name]) == 0:
+        return None, None, dist_m
+    z = triangulate_down(i1, i2, i1.match_list[i2.name])
+    return -np.average(z), np.std(z), dist_m
+
+
+def record_surface_estimate(i1, i2, avg, std, dist_m):
+    """the property-tree bookkeeping of update_surface_estimate (smart.py:203-250)"""
+    if avg is None:
+        return None, None
+    i1_node = smart_node.getChild(i1.name, True)
+    i2_node = smart_node.getChild(i2.name, True)
+    tri1_node = i1_node.getChild("tri_surface_pairs", True)
+    tri2_node = i2_node.getChild("tri_surface_pairs", True)
+    weight = dist_m * dist_m
+    for tri, other in ((tri1_node, i2), (tri2_node, i1)):
+        pair_node = tri.getChild(other.name, True)
+        pair_node.setFloat("surface_m", float("%.1f" % avg))
+        pair_node.setInt("weight", weight)
+        pair_node.setFloat("stddev", float("%.1f" % std))
+        pair_node.setInt("dist_m", dist_m)
+    cutoff_std = 25             # more than this suggests a bad set of matches
+    for node, tri in ((i1_node, tri1_node), (i2_node, tri2_node)):
+        total, count = 0, 0
+        for child in tri.getChildren():
+            pair_node = tri.getChild(child)
+            if pair_node.getFloat("stddev") < cutoff_std:
+                w = pair_node.getInt("weight")
+                total += pair_node.getFloat("surface_m") * w
+                count += w
+        if count > 0:
+            node.setFloat("tri_surface_m", float("%.1f" % (total / count)))
+    return avg, std
+
+
+def update_surface_estimate(i1, i2):
+    avg, std, dist_m = estimate_surface_elevation(i1, i2)
+    return record_surface_estimate(i1, i2, avg, std, dist_m)
+
+
+def update_yaw_error_estimate(i1, i2):
+    return 0                     # RANSAC affine fit of the reference: not reproduced (see above)
+
+
+def get_yaw_error_estimate(i1):
+    i1_node = smart_node.getChild(i1.name, True)
+    return i1_node.getFloat("yaw_error") if i1_node.hasChild("yaw_error") else 0.0
+
+
+def get_surface_estimate(i1, i2):
+    i1_node = smart_node.getChild(i1.name, True)
+    i2_node = smart_node.getChild(i2.name, True)
+    vals = [n.getFloat("tri_surface_m") for n in (i1_node, i2_node) if n.hasChild("tri_surface_m")]
+    if vals:
+        return sum(vals) / len(vals)
+    return (i1_node.getFloat("srtm_surface_m") + i2_node.getFloat("srtm_surface_m")) * 0.5
+
+
+# ---- smart.json (props_json inside the reference environment, plain json here) ----------------
+def _to_dict(node):
+    out = {}
+    for k in node.getChildren():
+        child = node.getChild(k)
+        if child is not None:
+            out[k] = _to_dict(child)
+        elif node.getLen(k):
+            out[k] = [node.getFloatEnum(k, i) for i in range(node.getLen(k))]
+        else:
+            out[k] = node.__dict__[k]
+    return out
+
+
+def _from_dict(node, d):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _from_dict(node.getChild(k, True), v)
+        elif isinstance(v, bool):
+            node.setBool(k, v)
+        elif isinstance(v, int):
+            node.setInt(k, v)
+        elif isinstance(v, float):
+            node.setFloat(k, v)
+        elif isinstance(v, list):
+            node.setLen(k, len(v))
+            for i, x in enumerate(v):
+                node.setFloatEnum(k, i, x)
+        else:
+            node.setString(k, v)
+
+
+def load(analysis_dir):
+    if analysis_dir is None:
+        return
+    path = os.path.join(analysis_dir, "smart.json")
+    if _deps.HAVE_PROPS:
+        import props_json
+        props_json.load(path, smart_node)
+    elif os.path.exists(path):
+        with open(path) as f:
+            _from_dict(smart_node, json.load(f))
+
+
+def save(analysis_dir):
+    if analysis_dir is None:
+        return
+    path = os.path.join(analysis_dir, "smart.json")
+    if _deps.HAVE_PROPS:
+        import props_json
+        props_json.save(path, smart_node)
+    else:
+        with open(path, 'w') as f:
+            json.dump(_to_dict(smart_node), f, indent=4, sort_keys=True)

@@ -231,6 +231,19 @@ int iamx_triangulate_ground(const double *M, const double *ned, const double *ba
                             const int64_t *feat_ptr, int64_t n_feat, double *out_ned,
                             int32_t *n_sky, void *stream);
 
+/* iamx_triangulate_pairs -- scripts/lib/smart.py:26-63 triangulate_features(): two-view linear
+ * (DLT) triangulation of the matches of every pair of a batch, what cv2.triangulatePoints
+ * computes (null direction of the 4x4 system, f64), w-normalised; only the NED "down" component
+ * is returned because estimate_surface_elevation() (:117-130) needs nothing else.
+ *   pair_img DEV [n_pairs][2] image slots, PROJ DEV [n_images][12] = [R | t] row major,
+ *   IK DEV [9] inverse camera matrix, kp_off / xy as for iamx_match_postfilter,
+ *   m_cnt DEV [n_pairs], m_pairs DEV [n_pairs][clip][2] (query row, train row),
+ *   out_z DEV [n_pairs][clip] */
+int iamx_triangulate_pairs(const int32_t *pair_img, const double *PROJ, const double *IK,
+                           const int64_t *kp_off, const float *xy, const int32_t *m_cnt,
+                           const int32_t *m_pairs, int n_pairs, int clip, double *out_z,
+                           void *stream);
+
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);
 

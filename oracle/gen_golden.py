@@ -443,6 +443,66 @@ def run_cleanup_case(name, seed, n_img, n_kp, n_tracks, gap=None):
           % (name, n_img, len(direct_copy), len(grouped), len(grouped[0]) - 2))
 
 
+# ---------------------------------------------------------------------------
+# G8: per-pair surface estimate through the reference's own lib/smart.py
+# (triangulate_features -> estimate_surface_elevation -> update_surface_estimate) with the
+# cv2 stand-in's triangulatePoints (published DLT); pins layout, conventions, bookkeeping.
+# ---------------------------------------------------------------------------
+def run_smart_case(name, seed, n_img, n_kp):
+    from lib import smart as ref_smart
+    rng = np.random.default_rng(seed)
+    tmp = '/tmp/iamx_golden_%s' % name
+    os.makedirs(os.path.join(tmp, 'meta'), exist_ok=True)
+    names = ['M%03d' % i for i in range(n_img)]
+    proj = FakeProj(names, tmp)
+    camera.set_K(*[K_FC6310S[k] for k in (0, 4, 2, 5)])
+    K = np.array(K_FC6310S).reshape(3, 3)
+    poses, xy = [], []
+    ground = rng.uniform(-5.0, 20.0)                          # true surface elevation (m, up)
+    pts = np.stack([rng.uniform(-40, 140, 4 * n_kp), rng.uniform(-60, 160, 4 * n_kp),
+                    -ground + rng.normal(0, 1.5, 4 * n_kp)], 1)          # NED
+    for i, im in enumerate(proj.image_list):
+        ned = [30.0 * (i // 3) + rng.normal(0, 0.5), 35.0 * (i % 3) + rng.normal(0, 0.5),
+               -110.0 + rng.normal(0, 1.0)]
+        ypr = [rng.normal(0, 15.0), -90.0 + rng.normal(0, 2.0), rng.normal(0, 2.0)]
+        im.set_camera_pose(ned, *ypr)
+        poses.append(dict(ned=ned, ypr=ypr))
+        rvec, tvec = im.get_proj()
+        uvp, _ = cv2.projectPoints(pts.reshape(-1, 1, 3), rvec, np.asarray(tvec).reshape(3, 1), K,
+                                   np.zeros(5))
+        uvp = uvp.reshape(-1, 2)
+        vis = np.nonzero((uvp[:, 0] > 0) & (uvp[:, 0] < W_PX) & (uvp[:, 1] > 0) & (uvp[:, 1] < H_PX))[0]
+        vis = vis[:n_kp]
+        im._pt_ids = vis
+        p = (uvp[vis] + rng.normal(0, 0.4, (len(vis), 2))).astype(np.float32)
+        im.kp_list = [cv2.KeyPoint(float(x), float(y), 3.0) for x, y in p]
+        xy.append(p)
+    out_pairs = []
+    for i in range(n_img):
+        for j in range(i + 1, n_img):
+            a, b = proj.image_list[i], proj.image_list[j]
+            common, ia, ib = np.intersect1d(a._pt_ids, b._pt_ids, return_indices=True)
+            if len(common) < 8:
+                continue
+            lst = [[int(x), int(y)] for x, y in zip(ia, ib)]
+            if (i + j) % 3 == 0:                              # a bad pair: scrambled partners
+                perm = rng.permutation(len(lst))
+                lst = [[lst[k][0], lst[perm[k]][1]] for k in range(len(lst))]
+            a.match_list[b.name] = lst
+            b.match_list[a.name] = [[q, p_] for p_, q in lst]
+            with quiet():
+                avg, std = ref_smart.update_surface_estimate(a, b)
+            out_pairs.append(dict(i=i, j=j, matches=lst, avg=float(avg), std=float(std)))
+    tri = {im.name: (ref_smart.smart_node.getChild(im.name, True).getFloat('tri_surface_m')
+                     if ref_smart.smart_node.getChild(im.name, True).hasChild('tri_surface_m') else None)
+           for im in proj.image_list}
+    with open(os.path.join(GOLD, 'smart_%s.pkl' % name), 'wb') as f:
+        pickle.dump(dict(names=names, poses=poses, xy=xy, K=K_FC6310S, pairs=out_pairs,
+                         tri_surface_m=tri, ground=float(ground)), f, protocol=4)
+    print('smart_%s: %d pairs, surface truth %.1f m, estimates %s'
+          % (name, len(out_pairs), ground, sorted(set(v for v in tri.values() if v is not None))))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     # G1 ------------------------------------------------------------------
@@ -463,6 +523,8 @@ def main():
     run_cleanup_case('small', seed=31, n_img=6, n_kp=120, n_tracks=150)
     run_cleanup_case('strip', seed=32, n_img=16, n_kp=600, n_tracks=1500)
     run_cleanup_case('twoblocks', seed=33, n_img=22, n_kp=1500, n_tracks=2600, gap=12)
+    # G8 ------------------------------------------------------------------
+    run_smart_case('grid', seed=41, n_img=6, n_kp=400)
 
 
 if __name__ == '__main__':

@@ -16,6 +16,10 @@ here (oracle/gen_golden.py) to produce golden vectors.  What it restates:
   port scripts/lib/archive/gms_matcher.py (imported from /root/reference at
   run time, never copied) with the live call's thresholdFactor.
 
+* ``triangulatePoints`` -> the published linear (DLT) two-view triangulation OpenCV
+  implements: per point the 4x4 system [x*P3-P1; y*P3-P2] of both views, solution = right
+  singular vector of the smallest singular value (homogeneous, not normalised).
+
 Anything else raises AttributeError on purpose.
 """
 import math
@@ -177,3 +181,18 @@ def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs):
     u = K[0, 0] * xd + K[0, 2]
     v = K[1, 1] * yd + K[1, 2]
     return np.stack([u, v], axis=1).reshape(-1, 1, 2), None
+
+
+def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2):
+    """4xN homogeneous points (see module docstring)."""
+    P = [np.asarray(projMatr1, np.float64), np.asarray(projMatr2, np.float64)]
+    x = [np.asarray(projPoints1, np.float64), np.asarray(projPoints2, np.float64)]
+    n = x[0].shape[1]
+    out = np.zeros((4, n))
+    for i in range(n):
+        A = np.zeros((4, 4))
+        for j in range(2):
+            A[2 * j] = x[j][0, i] * P[j][2] - P[j][0]
+            A[2 * j + 1] = x[j][1, i] * P[j][2] - P[j][1]
+        out[:, i] = np.linalg.svd(A)[2][3]
+    return out

@@ -153,3 +153,36 @@ def test_triangulate_smart_equals_reference(path):
     assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())     # f64, same formulas
     assert all(m[2:] == w[2:] for m, w in zip(matches, want))
     assert all(type(m[0]) is list and type(m[0][0]) is float for m in matches)
+
+
+@pytest.mark.gpu
+def test_surface_estimate_equals_reference():
+    """imageanalysis_amd.smart (device DLT + the property-tree bookkeeping) against the
+    reference's lib/smart.py outputs (oracle/gen_golden.py G8)."""
+    from imageanalysis_amd import smart
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    with open(os.path.join(GOLDEN, 'smart_grid.pkl'), 'rb') as f:
+        g = pickle.load(f)
+    proj = PoseProject(g['names'])
+    K = g['K']
+    camera.set_K(K[0], K[4], K[2], K[5])
+    for im, pose, xy in zip(proj.image_list, g['poses'], g['xy']):
+        im.set_camera_pose(pose['ned'], *pose['ypr'])
+        im.kp_list = [KP(x, y) for x, y in xy]
+        smart.smart_node.__dict__.pop(im.name, None)
+    n_bad = 0
+    for rec in g['pairs']:
+        a, b = proj.image_list[rec['i']], proj.image_list[rec['j']]
+        a.match_list[b.name] = rec['matches']
+        b.match_list[a.name] = [[q, p] for p, q in rec['matches']]
+        avg, std = smart.update_surface_estimate(a, b)
+        scale = max(1.0, abs(rec['avg']), rec['std'])
+        assert abs(avg - rec['avg']) <= 1e-6 * scale and abs(std - rec['std']) <= 1e-6 * scale, rec['i']
+        n_bad += rec['std'] >= 25
+    assert 0 < n_bad < len(g['pairs'])                       # scrambled pairs are in the set
+    for im in proj.image_list:
+        node = smart.smart_node.getChild(im.name, True)
+        want = g['tri_surface_m'][im.name]
+        assert (node.getFloat('tri_surface_m') if node.hasChild('tri_surface_m') else None) == want
+    assert abs(g['tri_surface_m'][g['names'][0]] - g['ground']) < 0.5

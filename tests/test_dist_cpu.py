@@ -95,6 +95,7 @@ def _run_find_matches(rank, world, port, outdir):
     matcher.max_distance, matcher.min_pairs = 270.0, 25.0
     matcher.the_matcher = object()                  # configure() would need the GPU library
     matcher._match_batch = _oracle_match_batch      # TEST-ONLY injection
+    matcher._deps.smart = lambda: None              # the pairwise surface estimate is a GPU kernel
     matcher.PAIRS_PER_BATCH = 3                     # several rounds
     matcher.find_matches(proj, None, strategy='traditional', sort=True)
     with open(os.path.join(outdir, 'r%d_of_%d.pkl' % (rank, world)), 'wb') as f:

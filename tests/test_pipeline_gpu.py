@@ -125,9 +125,13 @@ def test_detect_match_consolidate_triangulate_group_optimize(tmp_path):
     grouped = match_cleanup.link_matches(proj, direct)
     assert len(grouped) > 500 and len(grouped[0]) - 2 >= 4  # chains through >= 4 images exist
     match_cleanup.triangulate_smart(proj, grouped)
-    # the triangulated features lie on the ground plane the images were rendered from
+    # the triangulated features lie on the per-image surface estimates find_matches accumulated
+    # (smart: pairwise DLT triangulation with the ~1 m / ~1 deg pose errors => within ~2.5 m of
+    # the plane the images were rendered from)
     pts = np.array([m[0] for m in grouped])
-    assert np.abs(pts[:, 2]).max() < 1e-6 and pts[:, 0].min() > -60 and pts[:, 1].max() < 240
+    assert np.abs(pts[:, 2]).max() < 2.5 and pts[:, 0].min() > -60 and pts[:, 1].max() < 240
+    surf = [getNode('/smart', True).getChild(n, True).getFloat('tri_surface_m') for n in names]
+    assert max(abs(v) for v in surf) < 2.5 and os.path.exists(os.path.join(str(an), 'smart.json'))
     pickle.loads(pickle.dumps(grouped))
     group_list = groups.compute(proj.image_list, grouped)
     assert len(group_list) == 1 and sorted(group_list[0]) == names
