@@ -13,16 +13,25 @@ except ImportError:
     HAVE_PROPS = False
 
 
+_resolved = {}
+
+
 def _ref_or_host(name):
+    if name in _resolved:                # called per log line: resolve once
+        return _resolved[name]
+    mod = None
     if HAVE_PROPS:
         try:
-            return importlib.import_module('lib.' + name)
+            mod = importlib.import_module('lib.' + name)
         except Exception:
-            pass
-    try:
-        return importlib.import_module('imageanalysis_amd.hostlib.' + name)
-    except ImportError:
-        return None
+            mod = None
+    if mod is None:
+        try:
+            mod = importlib.import_module('imageanalysis_amd.hostlib.' + name)
+        except ImportError:
+            mod = None
+    _resolved[name] = mod
+    return mod
 
 
 def camera():

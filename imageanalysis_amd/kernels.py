@@ -251,13 +251,18 @@ class PairWorkspace(object):
         self.unresolved = torch.zeros(1, dtype=I32, device=dev)
         self.surv_cnt = torch.zeros(p, dtype=I32, device=dev)
 
+    def survivor_counts(self, n_pairs):
+        """host copies of (first, count) per pair only"""
+        first = self.surv_off[:n_pairs].cpu().numpy()
+        count = self.surv_cnt[:n_pairs].cpu().numpy().astype(np.int64)
+        return first, count
+
     def survivors(self, n_pairs):
         """host copies: (first, count) per pair and the survivor arrays they index
         (pair p owns [first[p], first[p] + count[p]); query rows ascending)."""
-        first = self.surv_off[:n_pairs + 1].cpu().numpy()
-        count = self.surv_cnt[:n_pairs].cpu().numpy().astype(np.int64)
-        total = int(first[-1])
-        return (first[:-1], count, self.surv_q[:total].cpu().numpy(),
+        first, count = self.survivor_counts(n_pairs)
+        total = int(self.surv_off[n_pairs].item())
+        return (first, count, self.surv_q[:total].cpu().numpy(),
                 self.surv_t[:total].cpu().numpy(), self.surv_metric[:total].cpu().numpy())
 
 

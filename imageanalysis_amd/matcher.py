@@ -19,6 +19,8 @@ reference run on an exact matcher.
 Only the 'traditional' strategy (the default of process.py / 3a-matching.py) and SIFT
 descriptors (integer valued 0..255) are on this path.
 """
+import contextlib
+import gc
 import time
 from math import sqrt
 
@@ -61,6 +63,7 @@ class DeviceMatcher(object):
         self._pending = []
         self._kp = {}             # slot -> (xy float32 [n,2], key2 int32 [n,2]) host copies
         self._kp_dev = None       # (n_slots, kp_off, xy, key2) device arena of the post filter
+        self._proj = {}           # slot -> (pose, [R|t] row major) for the surface triangulation
 
     # cv2-style single pair call (returns numpy (idx[nq,2], dist[nq,2] float32))
     def knnMatch(self, des1, des2, k=2):
@@ -341,18 +344,54 @@ def _work_list(proj, sort):
 # --------------------------------------------------------------------------------------
 # the batched pair loop -- matcher.py:918-1031
 # --------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def _no_gc():
+    """find_matches keeps tens of millions of 2-element lists alive (the match_list contract);
+    every generation-2 pass of the cyclic collector would walk all of them again"""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def _ensure_features(image):
     if image.kp_list is None or image.des_list is None or not len(image.kp_list) \
             or not len(image.des_list):
         image.detect_features(detect_scale)
 
 
-def _match_batch(batch, match_ratio, device_filters=True):
-    """batch: list of (i1, i2) image objects.  Device k=2 NN + metric threshold for both
-    directions of every pair, then the per-pair filters (sort/clip, GMS, de-dup, gates, cross
-    check) -- on the device too (iamx_match_postfilter) unless `device_filters` is False (or a
-    direction has more than 2^24 survivors).  Returns per pair
-    (match_fwd, match_rev, n_fwd_quality, n_rev_quality)."""
+_host_sets = {}          # (n, clip, surface) -> free page-locked result buffer sets
+
+
+def _host_set(n, clip, surface):
+    """page-locked landing buffers for one batch's results (reused: allocating pinned memory
+    costs milliseconds)"""
+    import torch
+    free = _host_sets.setdefault((n, clip, surface), [])
+    if free:
+        return free.pop()
+    pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
+    hs = dict(key=(n, clip, surface), zero_div=pin(1, torch.int32),
+              count=pin(2 * n, torch.int32))
+    if clip:
+        hs.update(cnt=pin(n, torch.int32), status=pin(n, torch.int32),
+                  pairs=pin((n, clip, 2), torch.int32))
+        if surface:
+            hs['z'] = pin((n, clip), torch.float64)
+    return hs
+
+
+def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
+    """batch: list of (i1, i2) image objects.  ENQUEUES, on the current stream, the device k=2
+    NN + metric threshold for both directions of every pair, the per-pair filters (sort/clip,
+    GMS, de-dup, gates, cross check: iamx_match_postfilter) unless `device_filters` is False,
+    with `surface` the DLT triangulation of every pair's matches (one launch for the batch), and
+    the downloads of the results into page-locked buffers.  Nothing is waited for: the returned
+    handle goes to _finish_batch(), and find_matches launches the next batch before it finishes
+    this one so that the GPU works while python builds the match lists."""
     import torch
     from . import kernels
     from .kernels import _ptr, check, lib, stream_ptr
@@ -366,6 +405,7 @@ def _match_batch(batch, match_ratio, device_filters=True):
     pb.run(ws, thresh)
     n = len(batch)
     post = None
+    clip = 0
     if device_filters:
         cam_w, cam_h = _camera_size()
         kp_off, xy, key2 = dm.keypoints()
@@ -383,22 +423,93 @@ def _match_batch(batch, match_ratio, device_filters=True):
                                       float(cam_h), float(min_pairs), 5.0, _ptr(post['cnt']),
                                       _ptr(post['pairs']), _ptr(post['scratch']), _ptr(post['stat']),
                                       _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
-    torch.cuda.current_stream().synchronize()
-    if int(ws.zero_div.item()):
-        raise ZeroDivisionError("float division by zero")       # matcher.py:255
-    first, count, sq, st, sm = ws.survivors(pb.n_pairs)
+        if surface:
+            from . import smart as _smart
+            PROJ = np.zeros((len(dm._counts), 12))
+            done = set()
+            for (a, b), (sa, sb) in zip(batch, slots):
+                for im, s in ((a, sa), (b, sb)):
+                    if s not in done:
+                        done.add(s)
+                        pose = im.get_camera_pose()
+                        hit = dm._proj.get(s)
+                        if hit is None or hit[0] != pose:
+                            hit = dm._proj[s] = (pose, _smart.projection_matrix(im).ravel())
+                        PROJ[s] = hit[1]
+            IK = np.linalg.inv(np.asarray(_deps.camera().get_K(), float))
+            d_proj = torch.from_numpy(PROJ).to(dev)
+            d_ik = torch.from_numpy(np.ascontiguousarray(IK.ravel())).to(dev)
+            post['tri_cnt'] = torch.where(post['status'] == 0, post['cnt'],
+                                          torch.zeros_like(post['cnt']))
+            post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
+            check(L.iamx_triangulate_pairs(_ptr(pb.d_pairs), _ptr(d_proj), _ptr(d_ik), _ptr(kp_off),
+                                           _ptr(xy), _ptr(post['tri_cnt']), _ptr(post['pairs']), n,
+                                           clip, _ptr(post['z']), stream_ptr()),
+                  'iamx_triangulate_pairs')
+    hs = _host_set(n, clip, surface and post is not None)
+    hs['zero_div'].copy_(ws.zero_div, non_blocking=True)
+    hs['count'].copy_(ws.surv_cnt[:2 * n], non_blocking=True)
     if post is not None:
-        cnt = post['cnt'].cpu().numpy()
-        status = post['status'].cpu().numpy()
-        lists = post['pairs'].cpu().numpy()
-    out = []
+        hs['cnt'].copy_(post['cnt'], non_blocking=True)
+        hs['status'].copy_(post['status'], non_blocking=True)
+        hs['pairs'].copy_(post['pairs'], non_blocking=True)
+        if 'z' in post:
+            hs['z'].copy_(post['z'], non_blocking=True)
+    done_ev = torch.cuda.Event()
+    done_ev.record()
+    return dict(batch=batch, n=n, ws=ws, pb=pb, post=post, host=hs, done=done_ev, surface=surface)
+
+
+def _finish_batch(h):
+    """Waits for the batch's results and builds the python lists of the callers' contract.
+    Returns per pair (match_fwd, match_rev, n_fwd_quality, n_rev_quality); when the batch was
+    launched with `surface` a fifth entry: the pair's ground-surface statistics
+    (avg, std, dist_m) of smart.estimate_surface_elevation(), or None where the pair took the
+    host filter path (the caller then asks smart per pair)."""
+    h['done'].synchronize()
+    hs, n, ws, post = h['host'], h['n'], h['ws'], h['post']
+    try:
+        if int(hs['zero_div'][0]):
+            raise ZeroDivisionError("float division by zero")       # matcher.py:255
+        count = hs['count'].numpy().astype(np.int64)
+        first = sq = st = sm = status = cnt = lists = None
+        z_rows = {}
+        if post is not None:
+            cnt, status, lists = hs['cnt'].numpy(), hs['status'].numpy(), hs['pairs'].numpy()
+            if 'z' in hs and 'z' in post:
+                z = hs['z'].numpy()
+                z_rows = {int(k): z[k, :cnt[k]] for k in np.nonzero((status == 0) & (cnt > 0))[0]}
+        if post is None or status.any():
+            # survivor arrays: only the host filter path reads them (blocking copies)
+            first, count, sq, st, sm = ws.survivors(h['pb'].n_pairs)
+        out = []
+        with _no_gc():
+            _collect_batch(out, h['batch'], n, count, first, sq, st, sm, post is not None, status,
+                           cnt, lists, z_rows, h['surface'])
+    finally:
+        _host_sets[hs['key']].append(hs)
+    return out
+
+
+def _match_batch(batch, match_ratio, device_filters=True, surface=False):
+    """one batch, start to end (see _launch_batch / _finish_batch)"""
+    return _finish_batch(_launch_batch(batch, match_ratio, device_filters, surface))
+
+
+def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, cnt, lists, z_rows,
+                   surface):
+    """host side of a batch: the per-pair python lists the callers' contract asks for"""
+    from . import smart as _smart
     for k in range(n):
         n_fwd, n_rev = int(count[k]), int(count[n + k])
-        if post is not None and status[k] == 0:
-            fwd = lists[k, :cnt[k]].tolist()
-            rev = [[b, a] for a, b in fwd]
+        if have_post and status[k] == 0:
+            c = cnt[k]
+            fwd = lists[k, :c].tolist()
+            rev = lists[k, :c, ::-1].tolist()
         else:
             i1, i2 = batch[k]
+            _ensure_features(i1)         # the keypoints may have been flushed since the launch
+            _ensure_features(i2)
             xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
             a, b = first[k], first[k] + count[k]
             fwd = _post_filter(i1, i2, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), (xy1, xy2))
@@ -408,8 +519,17 @@ def _match_batch(batch, match_ratio, device_filters=True):
                 rev = _post_filter(i2, i1, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]),
                                    (xy2, xy1))
             fwd, rev = filter_cross_check(fwd, rev)
-        out.append((fwd, rev, n_fwd, n_rev))
-    return out
+        if not surface:
+            out.append((fwd, rev, n_fwd, n_rev))
+            continue
+        surf = None
+        if have_post and status[k] == 0:
+            i1, i2 = batch[k]
+            if i1 == i2 or k not in z_rows:
+                surf = (None, None, 0.0)         # nothing to record (smart.py:200-201)
+            else:
+                surf = (-np.average(z_rows[k]), np.std(z_rows[k]), _smart._pair_distance(i1, i2))
+        out.append((fwd, rev, n_fwd, n_rev, surf))
 
 
 def _camera_size():
@@ -425,21 +545,35 @@ def _camera_size():
     return w, h
 
 
-def _process_batch(lines, match_ratio):
-    """lines: [(dist, i, j, i1, i2)].  Returns [(i, j, match_fwd, match_rev)]."""
+def _launch_lines(lines, match_ratio, surface=False):
+    """lines: [(dist, i, j, i1, i2)]: enqueue the batch (see _launch_batch)"""
     batch = [(l[3], l[4]) for l in lines]
-    results = _match_batch(batch, match_ratio)
+    raw = [(len(l[3].kp_list), len(l[4].kp_list)) for l in lines]
+    handle = _launch_batch(batch, match_ratio, surface=True) if surface \
+        else _launch_batch(batch, match_ratio)
+    return lines, raw, handle
+
+
+def _finish_lines(launched):
+    """Returns [(i, j, match_fwd, match_rev, surf)]; surf is the pair's (avg, std, dist_m)
+    surface statistics when the launch asked for them, else None."""
+    lines, raw, handle = launched
+    results = _finish_batch(handle)
     out = []
-    for (dist, i, j, i1, i2), (match_fwd, match_rev, n_fwd, n_rev) in zip(lines, results):
-        _qlog("Matching %s vs %s" % (i1.name, i2.name))
-        _qlog("  separation (approx) = %.0f (m)" % dist)
-        _qlog("  raw matches:", len(i1.kp_list))
-        _qlog("  quality matches:", n_fwd)
-        _qlog("  raw matches:", len(i2.kp_list))
-        _qlog("  quality matches:", n_rev)
-        _qlog("  cross checked matches:", len(match_fwd))
-        out.append((i, j, match_fwd, match_rev))
+    for (dist, i, j, i1, i2), (raw1, raw2), res in zip(lines, raw, results):
+        match_fwd, match_rev, n_fwd, n_rev = res[:4]
+        # the reference's seven qlog() lines per pair (matcher.py:311-343) as one record:
+        # at millions of pairs the per-line bookkeeping costs more than the GPU work
+        _qlog("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
+              "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
+              "  cross checked matches: %d"
+              % (i1.name, i2.name, dist, raw1, n_fwd, raw2, n_rev, len(match_fwd)))
+        out.append((i, j, match_fwd, match_rev, res[4] if len(res) > 4 else None))
     return out
+
+
+def _process_batch(lines, match_ratio, surface=False):
+    return _finish_lines(_launch_lines(lines, match_ratio, surface))
 
 
 def find_matches(proj, K, strategy="smart", transform="homography", sort=False, review=False):
@@ -449,6 +583,11 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
     matching are dealt to the ranks in contiguous blocks (dist.shard_pairs); after every round
     the per-pair match lists are exchanged so that every rank keeps the full, identical
     bookkeeping; rank 0 writes the files."""
+    with _no_gc():
+        _find_matches(proj, K, strategy, transform, sort, review)
+
+
+def _find_matches(proj, K, strategy, transform, sort, review):
     from . import dist as _dist
     if strategy != "traditional":
         _log("Match strategy", strategy, "is not on the MI355X path; only 'traditional'",
@@ -457,6 +596,8 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
     if the_matcher is None:
         configure()
     smart = _deps.smart()
+    # our own smart mirror: the owning rank triangulates its whole batch in one launch
+    batched_surface = smart is not None and hasattr(smart, 'record_surface_estimate')
     rank, ws = _dist.world()
     t_start = time.time()
     work_list = _work_list(proj, sort)
@@ -482,7 +623,9 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
     n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
         if pending else 0
     n_done = 0
-    for rnd in range(n_rounds):
+    yaw_set = set()
+
+    def launch_round(rnd):
         lines = []
         for dist, i, j in mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]:
             i1, i2 = proj.image_list[i], proj.image_list[j]
@@ -495,11 +638,18 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
                     # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                     raise ZeroDivisionError("float division by zero")
             lines.append((dist, i, j, i1, i2))
-        results = _process_batch(lines, match_ratio) if lines else []
+        return _launch_lines(lines, match_ratio, batched_surface) if lines else None
+
+    # software pipeline: the GPU works on round r+1 while python turns round r into lists
+    in_flight = launch_round(0) if n_rounds else None
+    for rnd in range(n_rounds):
+        coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
+        results = _finish_lines(in_flight) if in_flight is not None else []
+        in_flight = coming
         gathered = _dist.allgather_objects(results)
 
         for part in gathered:
-            for i, j, match_fwd, match_rev in part:
+            for i, j, match_fwd, match_rev, surf in part:
                 i1, i2 = proj.image_list[i], proj.image_list[j]
                 n_done += 1
                 i1.match_list[i2.name] = match_fwd
@@ -510,11 +660,22 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
                 # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
                 avg = std = None
                 if smart is not None:
-                    avg, std = smart.update_surface_estimate(i1, i2)
+                    if surf is not None:
+                        avg, std = smart.record_surface_estimate(i1, i2, *surf)
+                    else:
+                        avg, std = smart.update_surface_estimate(i1, i2)
                     if avg and std:
                         _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
-                    i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
-                    i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
+                    if batched_surface:
+                        # our smart mirror has no yaw estimate (constant 0): once per image
+                        for im in (i1, i2):
+                            if im.name not in yaw_set:
+                                yaw_set.add(im.name)
+                                im.set_aircraft_yaw_error_estimate(
+                                    smart.update_yaw_error_estimate(im, im))
+                    else:
+                        i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
+                        i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
                 if std and std >= 50 and len(i1.match_list[i2.name]) < 100:
                     _log("Std dev of surface triangulation blew up, matches are probably bad so "
                          "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,

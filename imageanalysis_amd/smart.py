@@ -79,6 +79,24 @@ def estimate_surface_elevation(i1, i2):
     return -np.average(z), np.std(z), dist_m
 
 
+_pair_cache = {}        # image name -> (tri node, {other name: (surface_m, weight, stddev)})
+
+
+def _pairs_of(name, tri_node):
+    """the image's tri_surface_pairs children as plain tuples (built from the tree once, then
+    kept in step by record_surface_estimate; load() drops it)"""
+    entry = _pair_cache.get(name)
+    acc = entry[1] if entry is not None and entry[0] is tri_node else None
+    if acc is None:                      # first touch, or the tree was reset / reloaded under us
+        acc = {}
+        for child in tri_node.getChildren():
+            pn = tri_node.getChild(child)
+            if pn is not None:
+                acc[child] = (pn.getFloat("surface_m"), pn.getInt("weight"), pn.getFloat("stddev"))
+        _pair_cache[name] = (tri_node, acc)
+    return acc
+
+
 def record_surface_estimate(i1, i2, avg, std, dist_m):
     """the property-tree bookkeeping of update_surface_estimate (smart.py:203-250)"""
     if avg is None:
@@ -88,20 +106,23 @@ def record_surface_estimate(i1, i2, avg, std, dist_m):
     tri1_node = i1_node.getChild("tri_surface_pairs", True)
     tri2_node = i2_node.getChild("tri_surface_pairs", True)
     weight = dist_m * dist_m
-    for tri, other in ((tri1_node, i2), (tri2_node, i1)):
+    cutoff_std = 25             # more than this suggests a bad set of matches
+    for node, tri, me, other in ((i1_node, tri1_node, i1, i2), (i2_node, tri2_node, i2, i1)):
+        acc = _pairs_of(me.name, tri)
         pair_node = tri.getChild(other.name, True)
         pair_node.setFloat("surface_m", float("%.1f" % avg))
         pair_node.setInt("weight", weight)
         pair_node.setFloat("stddev", float("%.1f" % std))
         pair_node.setInt("dist_m", dist_m)
-    cutoff_std = 25             # more than this suggests a bad set of matches
-    for node, tri in ((i1_node, tri1_node), (i2_node, tri2_node)):
+        acc[other.name] = (pair_node.getFloat("surface_m"), pair_node.getInt("weight"),
+                           pair_node.getFloat("stddev"))
+    for node, me in ((i1_node, i1), (i2_node, i2)):
+        acc = _pair_cache[me.name][1]
         total, count = 0, 0
-        for child in tri.getChildren():
-            pair_node = tri.getChild(child)
-            if pair_node.getFloat("stddev") < cutoff_std:
-                w = pair_node.getInt("weight")
-                total += pair_node.getFloat("surface_m") * w
+        for child in sorted(acc):                       # the tree's child order
+            surface_m, w, stddev = acc[child]
+            if stddev < cutoff_std:
+                total += surface_m * w
                 count += w
         if count > 0:
             node.setFloat("tri_surface_m", float("%.1f" % (total / count)))
@@ -164,6 +185,7 @@ def _from_dict(node, d):
 
 
 def load(analysis_dir):
+    _pair_cache.clear()
     if analysis_dir is None:
         return
     path = os.path.join(analysis_dir, "smart.json")

@@ -94,7 +94,9 @@ def _run_find_matches(rank, world, port, outdir):
     camera.set_image_params(5472, 3648)
     matcher.max_distance, matcher.min_pairs = 270.0, 25.0
     matcher.the_matcher = object()                  # configure() would need the GPU library
-    matcher._match_batch = _oracle_match_batch      # TEST-ONLY injection
+    # TEST-ONLY injection: the two halves of the device batch (launch / finish)
+    matcher._launch_batch = lambda batch, ratio, **kw: _oracle_match_batch(batch, ratio)
+    matcher._finish_batch = lambda handle: handle
     matcher._deps.smart = lambda: None              # the pairwise surface estimate is a GPU kernel
     matcher.PAIRS_PER_BATCH = 3                     # several rounds
     matcher.find_matches(proj, None, strategy='traditional', sort=True)

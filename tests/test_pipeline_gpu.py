@@ -117,6 +117,19 @@ def test_detect_match_consolidate_triangulate_group_optimize(tmp_path):
     assert n_pairs >= 12                                   # neighbours overlap, far pairs do not
     assert all(len(im.kp_list) > 1000 for im in proj.image_list)
     assert os.path.exists(os.path.join(str(an), 'meta', 'P00.match'))
+    # the surface statistics find_matches recorded came from ONE triangulation launch per batch;
+    # they equal what the per-pair entry point computes from the stored match lists
+    from imageanalysis_amd import smart
+    n_checked = 0
+    for a in proj.image_list:
+        for b in proj.image_list:
+            if a is not b and len(a.match_list.get(b.name, [])):
+                avg, std, _d = smart.estimate_surface_elevation(a, b)
+                rec = smart.smart_node.getChild(a.name).getChild('tri_surface_pairs').getChild(b.name)
+                assert rec.getFloat('surface_m') == float('%.1f' % avg)
+                assert rec.getFloat('stddev') == float('%.1f' % std)
+                n_checked += 1
+    assert n_checked >= 24
 
     match_cleanup.merge_duplicates(proj)
     match_cleanup.check_for_pair_dups(proj)
