@@ -1,0 +1,146 @@
+"""Host I/O around the GPU feature detector: with SIFT at a few
+milliseconds per frame the reference's cache formats and the JPEG decode are what an image
+costs -- gzip(level 6) of a 50 k x 128 float32 `.desc` takes ~2 s on one core, a 20 MP JPEG
+~0.2-0.4 s to decode (scripts/lib/image.py:99-121,140-217).
+
+* `write_gzip(path, payload)`: the file is written by background threads as a MULTI-MEMBER
+  gzip stream (1 MiB of payload per member, members compressed in parallel; zlib releases the
+  GIL).  gzip.open() -- what the reference's loaders use -- reads such a file exactly like a
+  single-member one, and the decompressed bytes are identical to what the reference writes.
+* `wait(path)`: readers of a path first wait for its pending write; everything is flushed at
+  interpreter exit.
+* `Prefetch`: decodes / cache-loads the next few images on worker threads while the GPU works
+  on the current one (bounded window: a decoded 20 MP frame is 60 MB).
+"""
+import atexit
+import os
+import threading
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+MEMBER_BYTES = 1 << 20
+GZIP_LEVEL = 6                        # the reference's compresslevel (image.py:201,213)
+
+_lock = threading.Lock()
+_jobs = None                          # one job per file (serialise + orchestrate)
+_workers = None                       # member compression / decode
+_pending = {}                         # path -> Future
+
+
+def _pools():
+    global _jobs, _workers
+    with _lock:
+        if _jobs is None:
+            n = max(2, min(32, os.cpu_count() or 2))
+            _jobs = ThreadPoolExecutor(max_workers=4, thread_name_prefix='iamx-cache')
+            _workers = ThreadPoolExecutor(max_workers=n, thread_name_prefix='iamx-io')
+    return _jobs, _workers
+
+
+def _member(chunk, level):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)            # wbits 31: gzip container
+    return c.compress(chunk) + c.flush()
+
+
+def gzip_members(raw, level=GZIP_LEVEL):
+    """bytes -> multi-member gzip stream of the same bytes (members compressed in parallel)"""
+    raw = memoryview(raw)
+    if len(raw) <= MEMBER_BYTES:
+        return _member(raw, level)
+    _j, workers = _pools()
+    chunks = [raw[i:i + MEMBER_BYTES] for i in range(0, len(raw), MEMBER_BYTES)]
+    return b''.join(workers.map(lambda c: _member(c, level), chunks))
+
+
+def _write_job(path, payload, on_error=None):
+    try:
+        raw = payload() if callable(payload) else payload
+        blob = gzip_members(raw)
+        tmp = '%s.tmp%d' % (path, threading.get_ident())
+        with open(tmp, 'wb') as f:
+            f.write(blob)
+        os.replace(tmp, path)                                 # readers never see half a file
+    except Exception as e:                                    # noqa: BLE001
+        if on_error is None:
+            raise
+        on_error(e)
+
+
+def write_gzip(path, payload, background=True, on_error=None):
+    """payload: bytes or a callable returning bytes (run on the job thread, e.g. np.save into a
+    buffer).  Errors go to `on_error(exc)` if given, else surface in wait()."""
+    if not background:
+        _write_job(path, payload, on_error)
+        return None
+    jobs, _w = _pools()
+    wait(path)                                                # keep two writes of a path ordered
+    fut = jobs.submit(_write_job, path, payload, on_error)
+    with _lock:
+        _pending[path] = fut
+    return fut
+
+
+def wait(path=None):
+    """Block until the pending write of `path` (all paths if None) is on disk; re-raises the
+    write's exception."""
+    with _lock:
+        if path is None:
+            futs = list(_pending.items())
+        else:
+            futs = [(path, _pending[path])] if path in _pending else []
+    for p, fut in futs:
+        try:
+            fut.result()
+        finally:
+            with _lock:
+                if _pending.get(p) is fut:
+                    del _pending[p]
+
+
+def _flush_at_exit():
+    try:
+        wait()
+    except Exception as e:                                    # noqa: BLE001
+        print("cache write failed at exit:", e)
+
+
+atexit.register(_flush_at_exit)
+
+
+class Prefetch(object):
+    """Runs `fn(item)` for a sequence of items on the worker threads, at most `depth` results
+    outstanding; `take(item)` returns the result (computing it inline if it was never
+    scheduled) and schedules the next one."""
+
+    def __init__(self, fn, items, depth=6):
+        self.fn = fn
+        self.todo = list(items)
+        self.depth = depth
+        self.next = 0
+        self.futs = {}
+        # own threads: a job may wait for a pending cache write, which needs the shared workers
+        self.workers = ThreadPoolExecutor(max_workers=max(1, depth), thread_name_prefix='iamx-pre')
+        for _ in range(min(depth, len(self.todo))):
+            self._schedule()
+
+    def _schedule(self):
+        if self.next < len(self.todo):
+            item = self.todo[self.next]
+            self.next += 1
+            self.futs[id(item)] = (item, self.workers.submit(self.fn, item))
+
+    def take(self, item):
+        ent = self.futs.pop(id(item), None)
+        if ent is None:
+            return self.fn(item)
+        self._schedule()
+        return ent[1].result()
+
+    def pending(self, item):
+        return id(item) in self.futs
+
+    def close(self):
+        for _item, fut in self.futs.values():
+            fut.cancel()
+        self.futs = {}
+        self.workers.shutdown(wait=False)

@@ -14,13 +14,14 @@ Use `install(lib.image)` to give the reference's own Image class these methods (
 the stand-alone `Image` class below.
 """
 import gzip
+import io
 import os
 import pickle
 import sys
 
 import numpy as np
 
-from . import _deps
+from . import _deps, cacheio
 from .hostlib.image_pose import PoseImage
 
 try:                                     # inside the reference environment keep cv2's type
@@ -50,6 +51,40 @@ def make_keypoint(x, y, size, angle, response, octave, class_id=-1):
     return KeyPoint(x, y, size, angle, response, octave, class_id)
 
 
+def make_keypoints(x, y, size, angle, response, octave, class_id=None):
+    """column arrays -> list of keypoints; the float32 rounding cv2.KeyPoint applies to its
+    members is done once per column instead of five times per object (50 k keypoints per
+    frame: the per-object constructor costs more than the whole GPU detector)"""
+    n = len(x)
+    if class_id is None:
+        class_id = np.full(n, -1, np.int64)
+    if _CvKeyPoint is not None:
+        return [make_keypoint(*t) for t in zip(np.asarray(x).tolist(), np.asarray(y).tolist(),
+                                               np.asarray(size).tolist(), np.asarray(angle).tolist(),
+                                               np.asarray(response).tolist(),
+                                               np.asarray(octave).tolist(),
+                                               np.asarray(class_id).tolist())]
+    f32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64).tolist()
+    new, cls = KeyPoint.__new__, KeyPoint
+    out = []
+    for px, py, s, a, r, o, c in zip(f32(x), f32(y), f32(size), f32(angle), f32(response),
+                                     np.asarray(octave, np.int64).tolist(),
+                                     np.asarray(class_id, np.int64).tolist()):
+        k = new(cls)
+        k.pt = (px, py)
+        k.size = s
+        k.angle = a
+        k.response = r
+        k.octave = o
+        k.class_id = c
+        out.append(k)
+    return out
+
+
+ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
+PREFETCH_DEPTH = 6             # decoded / cache-loaded images held ahead of the detector
+
+
 def _log(*a):
     _deps.logger().log(*a)
 
@@ -61,13 +96,21 @@ def _qlog(*a):
 # --------------------------------------------------------------------------------------
 # cache I/O -- image.py:140-228
 # --------------------------------------------------------------------------------------
+def _keypoints_from_tuples(feature_list):
+    if not len(feature_list):
+        return []
+    pt, size, angle, response, octave, class_id = zip(*feature_list)
+    x, y = zip(*pt)
+    return make_keypoints(x, y, size, angle, response, octave, class_id)
+
+
 def load_features(self):
+    cacheio.wait(self.features_file)
     if os.path.exists(self.features_file):
         try:
             with gzip.open(self.features_file, "rb") as fp:
                 feature_list = pickle.load(fp)
-            self.kp_list = [make_keypoint(p[0][0], p[0][1], p[1], p[2], p[3], p[4], p[5])
-                            for p in feature_list]
+            self.kp_list = _keypoints_from_tuples(feature_list)
             return True
         except Exception:                 # noqa: BLE001  (the reference prints and carries on)
             print(self.features_file + ":\n" + "  feature load error: "
@@ -76,6 +119,7 @@ def load_features(self):
 
 
 def load_descriptors(self):
+    cacheio.wait(self.desc_file)
     if os.path.exists(self.desc_file):
         if self.des_list is None:
             try:
@@ -98,21 +142,25 @@ def load_matches(self):
 
 
 def save_features(self):
+    """same bytes as the reference's gzip.open(..., compresslevel=6) + pickle.dump once
+    decompressed; written in the background as a multi-member gzip stream (cacheio)"""
     feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
                     for kp in self.kp_list]
-    try:
-        with gzip.open(self.features_file, 'wb', compresslevel=6) as fp:
-            pickle.dump(feature_list, fp)
-    except IOError as e:
-        print("save_features(): I/O error({0}): {1}".format(e.errno, e.strerror))
+    cacheio.write_gzip(self.features_file, lambda: pickle.dumps(feature_list),
+                       background=ASYNC_CACHE_WRITES,
+                       on_error=lambda e: print("save_features(): I/O error: %s" % e))
+
+
+def _npy_bytes(arr):
+    buf = io.BytesIO()
+    np.save(buf, arr)
+    return buf.getbuffer()
 
 
 def save_descriptors(self):
-    try:
-        with gzip.open(self.desc_file, 'wb', compresslevel=6) as fp:
-            np.save(fp, self.des_list)
-    except Exception:                     # noqa: BLE001
-        print(self.desc_file + ": error saving file: " + str(sys.exc_info()[1]))
+    des = self.des_list                    # the array as it is now (a later flush drops only the name)
+    cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
+                       on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)))
 
 
 def save_matches(self):
@@ -161,13 +209,56 @@ def features_from_bgr(bgr, scale, equalize=True):
     scaled = kernels.equalize_resize(bgr, scale, equalize=equalize)
     kp, octave, desc = kernels.sift_detect(scaled)
     # kp.pt = (kp.pt[0]/scale, kp.pt[1]/scale): keypoints are cached in FULL-RES pixels (:344-346)
-    kp_list = [make_keypoint(k[0] / scale, k[1] / scale, k[2], k[3], k[4], int(o))
-               for k, o in zip(kp.tolist(), octave.tolist())]
+    kp = np.asarray(kp)
+    # python-float division like `kp.pt[0] / scale` on a cv2.KeyPoint, then float32 members
+    kp_list = make_keypoints(kp[:, 0].astype(np.float64) / scale, kp[:, 1].astype(np.float64) / scale,
+                             kp[:, 2], kp[:, 3], kp[:, 4], octave)
     return kp_list, desc.astype(np.float32)
 
 
+def _prefetch_job(self):
+    """worker-thread half of detect_features: the parts that release the GIL -- gunzip of both
+    cache files, or the JPEG decode when there is no cache"""
+    try:
+        cacheio.wait(self.features_file)
+        cacheio.wait(self.desc_file)
+        if os.path.exists(self.features_file) and os.path.exists(self.desc_file):
+            with gzip.open(self.features_file, 'rb') as fp:
+                feat = fp.read()
+            with gzip.open(self.desc_file, 'rb') as fp:
+                desc = fp.read()
+            return ('cache', feat, desc)
+    except Exception:                     # noqa: BLE001  (fall through to a fresh detection)
+        pass
+    try:
+        return ('bgr', _decode_bgr(self.image_file))
+    except Exception:                     # noqa: BLE001  (detect_features repeats it and reports)
+        return None
+
+
+def prefetch(images, depth=None):
+    """Start decoding / cache-loading `images` (in this order) on worker threads; each image's
+    next detect_features() picks its result up.  Returns the cacheio.Prefetch (close() it)."""
+    todo = [im for im in images if getattr(im, 'image_file', None) or
+            os.path.exists(getattr(im, 'features_file', '') or '')]
+    pf = cacheio.Prefetch(_prefetch_job, todo, PREFETCH_DEPTH if depth is None else depth)
+    for im in todo:
+        im._iamx_prefetch = pf
+    return pf
+
+
 def detect_features(self, scale, use_cache=True):
+    pf = getattr(self, '_iamx_prefetch', None)
+    pre = pf.take(self) if pf is not None and pf.pending(self) else None
     if use_cache:
+        if pre is not None and pre[0] == 'cache':
+            try:
+                self.kp_list = _keypoints_from_tuples(pickle.loads(pre[1]))
+                self.des_list = np.load(io.BytesIO(pre[2]))
+                _qlog("Loaded features/descriptors from cache:", self.name)
+                return
+            except Exception:             # noqa: BLE001
+                pass
         success = True
         if not self.load_features():
             success = False
@@ -182,7 +273,7 @@ def detect_features(self, scale, use_cache=True):
         _log("Detector", detector_node.getString('detector'),
              "is not on the MI355X path (SIFT only)")
         quit()
-    bgr = _decode_bgr(self.image_file)
+    bgr = pre[1] if pre is not None and pre[0] == 'bgr' else _decode_bgr(self.image_file)
     h, w = bgr.shape[:2]
     self.node.setInt('height', h)
     self.node.setInt('width', w)

@@ -625,6 +625,22 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     n_done = 0
     yaw_set = set()
 
+    # ---- images this rank will have to detect / load, in the order the rounds reach them:
+    # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
+    from . import image as _image
+    need, seen = [], set()
+    for _d, i, j in mine:
+        for k in (i, j):
+            if k not in seen:
+                seen.add(k)
+                im = proj.image_list[k]
+                if (im.kp_list is None or im.des_list is None or not len(im.kp_list)) and \
+                        getattr(type(im), 'detect_features', None) is _image.detect_features:
+                    need.append(im)
+        if len(seen) == len(proj.image_list):
+            break
+    prefetcher = _image.prefetch(need) if need else None
+
     def launch_round(rnd):
         lines = []
         for dist, i, j in mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]:
@@ -708,6 +724,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 line[1].des_list = None
                 line[1].uv_list = None
 
+    if prefetcher is not None:
+        prefetcher.close()
     if rank == 0:
         saveMatches(proj.image_list)
         if smart is not None:

@@ -284,18 +284,18 @@ class Optimizer():
                 continue
             self.feat_map_fwd[i] = feat_used
             self.feat_map_rev[feat_used] = i
-            ned = np.array(match[0])
-            if np.any(np.isnan(ned)):
-                print(i, ned)
-            pts.append(ned)
+            pts.append(match[0])
             for m in obs:
                 obs_cam.append(cam_rev[m[0]])
                 obs_feat.append(feat_used)
                 obs_uv.append(m[1])
             feat_used += 1
         self.n_points = feat_used
-        self.points_3d = np.asarray(pts, np.float64).reshape(-1)[:self.n_points * 3].copy() \
-            if self.n_points else np.empty(0)
+        pts = np.asarray(pts, np.float64).reshape(-1, 3)
+        for k in np.nonzero(np.isnan(pts).any(axis=1))[0]:       # optimizer.py:352-353
+            print(self.feat_map_rev[int(k)], pts[k])
+        self.points_3d = pts.reshape(-1)[:self.n_points * 3].copy() if self.n_points \
+            else np.empty(0)
         n_observations = len(obs_cam)
 
         # camera-major, order of appearance inside a camera (stable sort)

@@ -1,0 +1,131 @@
+"""CPU: the host I/O runtime around the detector (imageanalysis_amd/cacheio.py) -- the cache
+files stay readable by the reference's loaders (scripts/lib/image.py:140-180: gzip.open +
+pickle.load / np.load) and hold byte-identical payloads."""
+import gzip
+import io
+import os
+import pickle
+import threading
+import time
+
+import numpy as np
+
+from imageanalysis_amd import cacheio, image as iimg
+from imageanalysis_amd._deps import getNode
+
+
+def _reference_style_read(feat_path, desc_path):
+    with gzip.open(feat_path, 'rb') as fp:                   # image.py:143-145
+        feats = pickle.load(fp)
+    with gzip.open(desc_path, 'rb') as fp:                   # image.py:166-168
+        des = np.load(fp)
+    return feats, des
+
+
+def test_multi_member_stream_is_a_plain_gzip_file(tmp_path):
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, 3 * cacheio.MEMBER_BYTES + 12345, dtype=np.uint8).tobytes()
+    blob = cacheio.gzip_members(raw)
+    assert blob[:2] == b'\x1f\x8b' and blob.count(b'\x1f\x8b\x08') >= 4   # several members
+    assert gzip.decompress(blob) == raw
+    p = tmp_path / 'x.gz'
+    cacheio.write_gzip(str(p), raw)
+    cacheio.wait(str(p))
+    with gzip.open(str(p), 'rb') as fp:
+        assert fp.read() == raw
+    small = b'abc' * 100
+    assert gzip.decompress(cacheio.gzip_members(small)) == small
+    assert cacheio.gzip_members(b'') and gzip.decompress(cacheio.gzip_members(b'')) == b''
+
+
+def test_feature_cache_roundtrip_and_reference_reader(tmp_path):
+    rng = np.random.default_rng(1)
+    getNode('/config/directories', True).setString('project_dir', str(tmp_path))
+    an = tmp_path / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    im = iimg.Image(str(an), 'A0001')
+    n = 20000                                               # > 1 MiB of descriptors: many members
+    xy = rng.uniform(0, 5000, (n, 2)).astype(np.float32)
+    im.kp_list = [iimg.make_keypoint(x, y, 3.5, 10.0, 0.02, 65793 + k % 3)
+                  for k, (x, y) in enumerate(xy.tolist())]
+    im.des_list = rng.integers(0, 256, (n, 128)).astype(np.float32)
+    want_feat = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id) for kp in im.kp_list]
+    want_des = im.des_list.copy()
+    im.save_features()
+    im.save_descriptors()
+    im.des_list = None                                      # find_matches' flush does this
+    im.kp_list = None
+    # a reader in the same process waits for the background write ...
+    assert im.load_features() and im.load_descriptors()
+    assert np.array_equal(im.des_list, want_des) and im.des_list.dtype == np.float32
+    assert [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
+            for kp in im.kp_list] == want_feat
+    # ... and the files are what the reference's own loader expects
+    feats, des = _reference_style_read(im.features_file, im.desc_file)
+    assert feats == want_feat and np.array_equal(des, want_des)
+    # decompressed payloads are byte-identical to what the reference's writer produces
+    buf = io.BytesIO()
+    np.save(buf, want_des)
+    with gzip.open(im.desc_file, 'rb') as fp:
+        assert fp.read() == buf.getvalue()
+    with gzip.open(im.features_file, 'rb') as fp:
+        assert fp.read() == pickle.dumps(want_feat)
+    assert not [f for f in os.listdir(str(an / 'cache')) if '.tmp' in f]
+
+
+def test_write_errors_are_reported_not_raised(tmp_path, capsys):
+    im = iimg.Image.__new__(iimg.Image)
+    im.features_file = str(tmp_path / 'missing_dir' / 'x.feat')
+    im.kp_list = [iimg.make_keypoint(1.0, 2.0, 3.0, 4.0, 0.5, 1)]
+    im.save_features()
+    cacheio.wait(im.features_file)
+    assert 'save_features(): I/O error' in capsys.readouterr().out
+
+
+def test_prefetch_window_and_order():
+    started, lock = [], threading.Lock()
+
+    def job(x):
+        with lock:
+            started.append(x)
+        time.sleep(0.02)
+        return x * x
+
+    class Item(object):
+        def __init__(self, v):
+            self.v = v
+
+    items = [Item(v) for v in range(10)]
+    pf = cacheio.Prefetch(lambda it: job(it.v), items, depth=3)
+    time.sleep(0.15)
+    assert sorted(started) == [0, 1, 2]                     # never more than `depth` ahead
+    assert pf.pending(items[0]) and not pf.pending(items[5])
+    assert pf.take(items[0]) == 0                           # frees a slot: item 3 starts
+    assert pf.take(items[7]) == 49                          # not scheduled yet: computed inline
+    out = [pf.take(it) for it in items[1:7]]
+    assert out == [1, 4, 9, 16, 25, 36]
+    pf.close()
+
+
+def test_prefetch_feeds_detect_features_from_cache(tmp_path):
+    rng = np.random.default_rng(2)
+    getNode('/config/directories', True).setString('project_dir', str(tmp_path))
+    an = tmp_path / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    imgs = []
+    for k in range(4):
+        im = iimg.Image(str(an), 'B%04d' % k)
+        im.kp_list = [iimg.make_keypoint(x, y, 2.0, 1.0, 0.1, 7) for x, y in rng.uniform(0, 99, (50, 2))]
+        im.des_list = rng.integers(0, 256, (50, 128)).astype(np.float32)
+        im.save_features()
+        im.save_descriptors()
+        im._want = im.des_list.copy()
+        im.kp_list = im.des_list = None
+        imgs.append(im)
+    pf = iimg.prefetch(imgs, depth=2)
+    for im in imgs:
+        im.detect_features(0.4)                             # cache hit through the prefetched bytes
+        assert np.array_equal(im.des_list, im._want) and len(im.kp_list) == 50
+    pf.close()

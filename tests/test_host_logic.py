@@ -204,6 +204,8 @@ def test_feature_cache_formats_roundtrip(tmp_path):
     im.des_list = np.arange(256, dtype=np.float32).reshape(2, 128) % 200
     im.match_list = {'IMG_8': [[0, 5], [1, 2]], 'IMG_9': []}
     im.save_features(); im.save_descriptors(); im.save_matches()
+    from imageanalysis_amd import cacheio
+    cacheio.wait()                        # the gzip files are written in the background
     raw = pickle.load(gzip.open(im.features_file, 'rb'))
     assert raw == [((10.25, 20.5), 3.0, 45.0, im.kp_list[0].response, 65793, -1),
                    ((1.0, 2.0), 5.0, 300.0, im.kp_list[1].response, 16711935, -1)]

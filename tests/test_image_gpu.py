@@ -52,7 +52,10 @@ def test_detect_features_end_to_end(tmp_path):
     assert im.num_features == len(im.kp_list) > 100
     assert im.des_list.dtype == np.float32 and im.des_list.shape == (len(im.kp_list), 128)
     assert im.get_size() == (400, 300)
-    # the cache files are the reference's formats (image.py:192-217)
+    # the cache files are the reference's formats (image.py:192-217); they are written in the
+    # background: a reader outside our loaders waits for them
+    from imageanalysis_amd import cacheio
+    cacheio.wait()
     with gzip.open(im.features_file, 'rb') as f:
         feats = pickle.load(f)
     assert isinstance(feats, list) and len(feats[0]) == 6 and len(feats[0][0]) == 2
