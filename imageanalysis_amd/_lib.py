@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libiamx.so')
+LIB_PATH = os.environ.get('IAMX_LIB') or os.path.join(_HERE, 'libiamx.so')   # IAMX_LIB: A/B builds
 _lib = None
 
 c_void_p = ctypes.c_void_p

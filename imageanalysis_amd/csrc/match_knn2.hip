@@ -28,6 +28,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+#ifndef IAMX_DESC_OFFSET
+#define IAMX_DESC_OFFSET 128      // stored byte s = value - offset (int8); d^2 does not depend on it
+#endif
 constexpr int D = IAMX_DESC_DIM;        // 128 bytes per row
 constexpr int QW = 2;                   // 32-query blocks per wave
 constexpr int WAVES = 4;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const SRC *__restrict__ src, 
                 v = (int)rintf(f);
                 v = v < 0 ? 0 : (v > 255 ? 255 : v);
             }
-            int s = v - 128;
+            int s = v - IAMX_DESC_OFFSET;
             s2 += s * s;
             s1 += s;
             w[i >> 2] |= (unsigned)(s & 0xFF) << (8 * (i & 3));

@@ -37,6 +37,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+#ifndef IAMX_DESC_OFFSET
+#define IAMX_DESC_OFFSET 128      // stored byte s = value - offset (int8); d^2 does not depend on it
+#endif
 constexpr int D = IAMX_DESC_DIM;
 constexpr int WAVES = 4, CHUNK = 128;
 constexpr int QW_PRODUCT = 2;             // 32-query blocks per wave in the shipped kernel
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void pack2_rows_kernel(PackArgs P, int64_t tot
                 v = (int)rintf((float)p[i]);
                 v = v < 0 ? 0 : (v > 255 ? 255 : v);
             }
-            const int s = v - 128;
+            const int s = v - IAMX_DESC_OFFSET;
             s2 += s * s;
             s1 += s;
         }
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void pack2_scatter_kernel(PackArgs P)
             v = (int)rintf((float)p[i]);
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
-        w[i >> 2] |= (unsigned)((v - 128) & 0xFF) << (8 * (i & 3));
+        w[i >> 2] |= (unsigned)((v - IAMX_DESC_OFFSET) & 0xFF) << (8 * (i & 3));
     }
     const int pos = d0 + P.pos[r0 + r];
     *reinterpret_cast<uint4 *>(P.dst + (int64_t)pos * D + part * 16) = make_uint4(w[0], w[1], w[2], w[3]);
