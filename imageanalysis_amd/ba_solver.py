@@ -8,9 +8,12 @@ for operator Jacobians (scipy/optimize/_lsq/least_squares.py), so to keep J in H
 iteration is restated here -- same sequence as scipy/optimize/_lsq/trf.py:205-400 (SciPy 1.15.3;
 the reference pins 1.6.2, same algorithm): Coleman-Li scaling, x_scale='jac' column norms,
 regularised Gauss-Newton step by LSMR, 2-D subspace trust-region solve, reflective step
-selection, radius update, ftol/xtol/gtol tests.  The O(n) scalar logic on the host uses
-SciPy's own helper functions; everything that touches J or an m-vector runs on the device
-through the K3/K4 kernels (ba_kernels.hip, ba_linalg.hip):
+selection, radius update, ftol/xtol/gtol tests.  The n-vectors of that logic (x, g, the
+Coleman-Li vectors, candidate steps) live on the device too (_trf_device: torch elementwise ops
+and reductions, the host sees a few dozen scalars per outer iteration and calls SciPy's scalar
+helpers); _trf_host keeps the numpy form with SciPy's own vector helpers as the cross-check.
+Everything that touches J or an m-vector runs through the K3/K4 kernels (ba_kernels.hip,
+ba_linalg.hip):
 
     fun / jac           iamx_ba_residual, iamx_ba_residual_jac
     g = J^T f, ||J_j||  iamx_ba_jtv (square=0 / 1)
@@ -129,6 +132,9 @@ class DeviceBA(object):
         self._state_pin = None
         self.profile = None
         self.force_stepwise_lsmr = False
+        self.host_logic = False          # True: the O(n) TRF vector logic in numpy (_trf_host)
+        self._calib_idx = None
+        self._fixed_calib_up = False
 
     # ---- host <-> device staging -------------------------------------------------------
     # Every n-/m-vector crosses PCIe through ONE page-locked buffer allocated up front.
@@ -195,6 +201,19 @@ class DeviceBA(object):
         else:
             cal = self.fixed_calib
         self.upload(cal, out=self.calib)
+
+    def set_x_dev(self, x_dev):
+        """device n-vector in the INTERNAL order -> current parameters (no host round trip)"""
+        self.x[:self.n].copy_(x_dev[:self.n])
+        if self.with_calib:
+            if self._calib_idx is None:
+                base = self.C * 7 + self.P * 3
+                self._calib_idx = torch.tensor([base, base, base + 1, base + 2, base + 3, base + 4,
+                                                base + 5, base + 6, base + 7], device=self.dev)
+            self.calib.copy_(self.x[self._calib_idx])
+        elif not self._fixed_calib_up:
+            self.upload(self.fixed_calib, out=self.calib)
+            self._fixed_calib_up = True
 
     def _cams_pts(self):
         return self.x[:self.C * 7], self.x[self.C * 7:self.C * 7 + self.P * 3]
@@ -287,6 +306,36 @@ class DeviceBA(object):
         self.jtv(self.r, self.tmp_n, square=True)
         return np.sqrt(self.download_n(self.tmp_n))
 
+    def grad_dev(self):
+        """J^T r as a device n-vector (internal order)"""
+        self.jtv(self.r, self.tmp_n)
+        return self.tmp_n[:self.n].clone()
+
+    def colnorm_dev(self):
+        self.jtv(self.r, self.tmp_n, square=True)
+        return torch.sqrt(self.tmp_n[:self.n])
+
+    def gram_dev(self, d_dev, vectors):
+        """gram() for device n-vectors (internal order); one host read for the whole matrix"""
+        k = len(vectors)
+        ys = []
+        for s in vectors:
+            torch.mul(d_dev[:self.n], s[:self.n], out=self.tmp_n2[:self.n])
+            y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
+            self.jv(self.tmp_n2, y)
+            ys.append(y[:self.m])
+        vals = [torch.dot(ys[i], ys[j]) for i in range(k) for j in range(i, k)]
+        g = torch.stack(vals)
+        if self.world > 1:
+            _dist.allreduce_sum_(g)
+        g = g.tolist()
+        G = np.zeros((k, k))
+        it = iter(g)
+        for i in range(k):
+            for j in range(i, k):
+                G[i, j] = G[j, i] = next(it)
+        return G
+
     def gram(self, d_host, vectors, d_dev=None):
         """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks.  With `d_dev` (d
         already on the device) the scaling is applied there instead of on the host."""
@@ -327,7 +376,8 @@ def _sym_ortho(a, b):
     return c, s, r
 
 
-def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None):
+def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None,
+                to_host=True):
     """min || [J diag(d); diag(dreg)] x - [r; 0] ||  on the device; returns host x and stats.
     Follows scipy/sparse/linalg/_isolve/lsmr.py (Fong & Saunders 2011) step by step."""
     n, m = prob.n, prob.m
@@ -378,8 +428,9 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
     ctol = 1.0 / conlim if conlim > 0 else 0.0
     normr = beta
     normar = alpha * beta
+    result = (lambda t: prob.download_n(t)) if to_host else (lambda t: t[:n].clone())
     if normar == 0 or normb == 0:
-        return prob.download_n(x), istop, itn, normr, normar
+        return result(x), istop, itn, normr, normar
 
     while itn < maxiter:
         itn += 1
@@ -448,7 +499,7 @@ def lsmr_device(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter
             istop = 1
         if istop > 0:
             break
-    return prob.download_n(x), istop, itn, normr, normar
+    return result(x), istop, itn, normr, normar
 
 
 # state block layout of iamx_ba_lsmr_iterate (csrc/ba_linalg.hip, enums S_* / R_*)
@@ -460,7 +511,7 @@ _R = {k: 2 * len(_S) + i for i, k in enumerate(
 
 
 def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, maxiter=None,
-                      chunk=64):
+                      chunk=64, to_host=True):
     """Same recurrence as lsmr_device with the scalars resident on the device.  Single rank:
     iterations are enqueued `chunk` at a time by iamx_ba_lsmr_iterate (3 launches each).
     Several ranks (observations sharded by point): every iteration is three
@@ -503,8 +554,9 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     if alpha > 0:
         prob.axpby(n, 1.0 / alpha, vt, 0.0, h)
     normar = alpha * beta
+    result = (lambda t: prob.download_n(t)) if to_host else (lambda t: t[:n].clone())
     if normar == 0 or normb == 0:
-        return prob.download_n(x), 0, 0, beta, normar
+        return result(x), 0, 0, beta, normar
     st = np.zeros(L.iamx_ba_lsmr_state_size())
     for k, val in dict(ALPHA=alpha, BETA=beta, ZETABAR=alpha * beta, ALPHABAR=alpha, RHO=1.0,
                        RHOBAR=1.0, CBAR=1.0, SBAR=0.0, BETADD=beta, RHODOLD=1.0,
@@ -566,7 +618,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     ph.__exit__()
     if st[_R['ISTOP']] == 8:
         raise _lib.IamxError('fused LSMR broke down (NaN in the recurrence)')
-    return (prob.download_n(x), int(st[_R['ISTOP']]), int(st[_R['ITN']]), float(st[_R['NORMR']]),
+    return (result(x), int(st[_R['ISTOP']]), int(st[_R['ITN']]), float(st[_R['NORMR']]),
             float(st[_R['NORMAR']]))
 
 
@@ -652,13 +704,16 @@ def trf_device(prob, x0, lb, ub, **kw):
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:                   # pragma: no cover
-        return _trf_device(prob, x0, lb, ub, **kw)
+        return (_trf_host if prob.host_logic else _trf_device)(prob, x0, lb, ub, **kw)
+    fn = _trf_host if prob.host_logic else _trf_device
     with threadpool_limits(limits=1, user_api='blas'):
-        return _trf_device(prob, x0, lb, ub, **kw)
+        return fn(prob, x0, lb, ub, **kw)
 
 
-def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
-                callback=None, lsmr_opts=None):
+def _trf_host(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
+              callback=None, lsmr_opts=None):
+    """the O(n) vector logic in numpy with SciPy's own helpers (DeviceBA.host_logic = True):
+    the cross-check of _trf_device, and ~40 % slower at config 4 (every n-vector crosses PCIe)"""
     from scipy.optimize import OptimizeResult
     from scipy.optimize._lsq.common import (CL_scaling_vector, check_termination,
                                             find_active_constraints, make_strictly_feasible,
@@ -784,6 +839,276 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     return OptimizeResult(x=x, cost=cost, grad=g, optimality=g_norm, active_mask=active_mask,
                           nfev=nfev, njev=njev, status=termination_status,
                           lsmr_iterations=lsmr_iters, iterations=iteration)
+
+
+# --------------------------------------------------------------------------------------
+# the same outer iteration with every n-vector resident on the device (internal order)
+# --------------------------------------------------------------------------------------
+_INF = float('inf')
+
+
+def _cl_scaling_dev(x, g, lb, ub, fin_lb, fin_ub):
+    """scipy/optimize/_lsq/common.py CL_scaling_vector"""
+    one, zero = torch.ones_like(x), torch.zeros_like(x)
+    up = (g < 0) & fin_ub
+    lo = (g > 0) & fin_lb
+    v = torch.where(up, ub - x, one)
+    v = torch.where(lo, x - lb, v)
+    dv = torch.where(up, -one, zero)
+    dv = torch.where(lo, one, dv)
+    return v, dv
+
+
+def _step_size_to_bound_dev(x, s, lb, ub):
+    """common.py step_size_to_bound: (min step, hits) with hits in {-1, 0, 1}"""
+    steps = torch.maximum((lb - x) / s, (ub - x) / s)
+    steps = torch.where(s != 0, steps, torch.full_like(steps, _INF))
+    min_step = steps.min()
+    hits = (steps == min_step).to(s.dtype) * torch.sign(s)
+    return float(min_step), hits
+
+
+def _in_bounds_dev(x, lb, ub):
+    return bool(((x >= lb) & (x <= ub)).all())
+
+
+def _strictly_feasible_dev(x, lb, ub, fin_lb, fin_ub):
+    """common.py make_strictly_feasible(x, lb, ub, rstep=0) with find_active_constraints
+    (rtol = 0): points on a bound move one ulp inside"""
+    lower, upper = x <= lb, x >= ub
+    x_new = torch.where(lower, torch.nextafter(lb, ub), x)
+    x_new = torch.where(upper, torch.nextafter(ub, lb), x_new)
+    tight = (x_new < lb) | (x_new > ub)
+    return torch.where(tight, 0.5 * (lb + ub), x_new)
+
+
+def _active_constraints_dev(x, lb, ub, fin_lb, fin_ub, rtol):
+    """common.py find_active_constraints (rtol > 0)"""
+    lower_dist, upper_dist = x - lb, ub - x
+    lower_thr = rtol * torch.clamp(lb.abs(), min=1.0)
+    upper_thr = rtol * torch.clamp(ub.abs(), min=1.0)
+    active = torch.zeros_like(x)
+    active = torch.where(fin_lb & (lower_dist <= torch.minimum(upper_dist, lower_thr)),
+                         -torch.ones_like(x), active)
+    active = torch.where(fin_ub & (upper_dist <= torch.minimum(lower_dist, upper_thr)),
+                         torch.ones_like(x), active)
+    return active
+
+
+def _dots(*pairs):
+    """several inner products, one host read"""
+    return torch.stack([torch.dot(a, b) for a, b in pairs]).tolist()
+
+
+def _select_step_dev(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
+    """trf.py select_step on device vectors; the J products go through Gram matrices"""
+    from scipy.optimize._lsq.common import minimize_quadratic_1d
+
+    if _in_bounds_dev(x + p, lb, ub):
+        G = prob.gram_dev(d, [p_h])
+        ph_d_ph, g_ph = _dots((p_h * diag_h, p_h), (g_h, p_h))
+        return p, p_h, -(0.5 * (G[0, 0] + ph_d_ph) + g_ph)
+
+    p_stride, hits = _step_size_to_bound_dev(x, p, lb, ub)
+    r_h = torch.where(hits != 0, -p_h, p_h)
+    r = d * r_h
+    p = p * p_stride
+    p_h = p_h * p_stride
+    x_on_bound = x + p
+    # intersect_trust_region(p_h, r_h, Delta): positive root of |p_h + t r_h| = Delta
+    a, b, c = _dots((r_h, r_h), (p_h, r_h), (p_h, p_h))
+    c -= Delta * Delta
+    if a == 0:
+        raise ValueError("`s` is zero.")
+    if c > 0:
+        raise ValueError("`x` is not within the trust region.")
+    disc = np.sqrt(b * b - a * c)
+    q = -(b + np.copysign(disc, b))
+    t1, t2 = q / a, c / q
+    to_tr = max(t1, t2)
+    to_bound, _ = _step_size_to_bound_dev(x_on_bound, r, lb, ub)
+    r_stride = min(to_bound, to_tr)
+    if r_stride > 0:
+        r_stride_l = (1 - theta) * p_stride / r_stride
+        r_stride_u = theta * to_bound if r_stride == to_bound else to_tr
+    else:
+        r_stride_l, r_stride_u = 0, -1
+
+    ag_h = -g_h
+    G = prob.gram_dev(d, [p_h, r_h, ag_h])          # all three model directions in one go
+    (rh_d_rh, g_rh, ph_d_rh, ph_d_ph, g_ph, ag_d_ag, g_ag, ag_ag) = _dots(
+        (r_h * diag_h, r_h), (g_h, r_h), (p_h * diag_h, r_h), (p_h * diag_h, p_h), (g_h, p_h),
+        (ag_h * diag_h, ag_h), (g_h, ag_h), (ag_h, ag_h))
+    if r_stride_l <= r_stride_u:
+        qa = 0.5 * (G[1, 1] + rh_d_rh)
+        qb = g_rh + G[0, 1] + ph_d_rh
+        c0 = 0.5 * (G[0, 0] + ph_d_ph) + g_ph
+        r_stride, r_value = minimize_quadratic_1d(qa, qb, r_stride_l, r_stride_u, c=c0)
+        r_h = r_h * r_stride + p_h
+        r = r_h * d
+    else:
+        r_value = np.inf
+
+    p = p * theta
+    p_h_t = p_h * theta
+    p_value = 0.5 * theta * theta * (G[0, 0] + ph_d_ph) + theta * g_ph
+
+    ag = d * ag_h
+    to_tr = Delta / np.sqrt(ag_ag)
+    to_bound, _ = _step_size_to_bound_dev(x, ag, lb, ub)
+    ag_stride = theta * to_bound if to_bound < to_tr else to_tr
+    qa = 0.5 * (G[2, 2] + ag_d_ag)
+    ag_stride, ag_value = minimize_quadratic_1d(qa, g_ag, 0, ag_stride)
+    ag_h = ag_h * ag_stride
+    ag = ag * ag_stride
+
+    if p_value < r_value and p_value < ag_value:
+        return p, p_h_t, -p_value
+    elif r_value < p_value and r_value < ag_value:
+        return r, r_h, -r_value
+    return ag, ag_h, -ag_value
+
+
+def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
+                callback=None, lsmr_opts=None):
+    """scipy/optimize/_lsq/trf.py trf_bounds, n-vectors on the device in the internal order:
+    x, g, the Coleman-Li vectors, the scaled Gauss-Newton step and the candidate steps never
+    cross PCIe; per outer iteration the host sees a few dozen scalars."""
+    from scipy.optimize import OptimizeResult
+    from scipy.optimize._lsq.common import (check_termination, make_strictly_feasible,
+                                            minimize_quadratic_1d, print_header_nonlinear,
+                                            print_iteration_nonlinear, solve_trust_region_2d,
+                                            update_tr_radius)
+    lsmr_opts = dict(lsmr_opts or {})
+    lsmr_opts['to_host'] = False
+    n = prob.n
+    vnorm = torch.linalg.vector_norm
+    x_host = make_strictly_feasible(np.asarray(x0, np.float64).copy(), lb, ub)
+    lb_d = prob.upload_n(np.broadcast_to(np.asarray(lb, np.float64), (n,)))[:n].clone()
+    ub_d = prob.upload_n(np.broadcast_to(np.asarray(ub, np.float64), (n,)))[:n].clone()
+    fin_lb, fin_ub = torch.isfinite(lb_d), torch.isfinite(ub_d)
+    x = prob.upload_n(x_host)[:n].clone()
+    prob.set_x_dev(x)
+    prob.residual_jac()
+    nfev = njev = 1
+    cost = prob.cost_of_r(prob.r)
+    g = prob.grad_dev()
+    scale_inv = prob.colnorm_dev().clone()
+    scale_inv = torch.where(scale_inv == 0, torch.ones_like(scale_inv), scale_inv)
+    scale = 1 / scale_inv
+
+    v, dv = _cl_scaling_dev(x, g, lb_d, ub_d, fin_lb, fin_ub)
+    v = torch.where(dv != 0, v * scale_inv, v)
+    Delta = float(vnorm(x * scale_inv / v ** 0.5))
+    if Delta == 0:
+        Delta = 1.0
+    if max_nfev is None:
+        max_nfev = n * 100
+    termination_status = None
+    iteration = 0
+    step_norm = actual_reduction = None
+    lsmr_iters = 0
+    r_new = torch.empty_like(prob.r)
+    if verbose == 2 and prob.rank == 0:
+        print_header_nonlinear()
+
+    while True:
+        v, dv = _cl_scaling_dev(x, g, lb_d, ub_d, fin_lb, fin_ub)
+        g_norm = float((g * v).abs().max())
+        if g_norm < gtol:
+            termination_status = 1
+        if verbose == 2 and prob.rank == 0:
+            print_iteration_nonlinear(iteration, nfev, cost, actual_reduction, step_norm, g_norm)
+        if termination_status is not None or nfev == max_nfev:
+            break
+
+        with _Phase(prob, 'scaling+reg'):
+            v = torch.where(dv != 0, v * scale_inv, v)
+            d = v ** 0.5 * scale
+            diag_h = g * dv * scale
+            g_h = d * g
+            # regularisation term (trf.py: build_quadratic_1d along -g_h)
+            G = prob.gram_dev(d, [g_h])
+            gdg, gg = _dots((g_h * diag_h, g_h), (g_h, g_h))
+            a = 0.5 * (G[0, 0] + gdg)
+            to_tr = Delta / np.sqrt(gg)
+            ag_value = minimize_quadratic_1d(a, -gg, 0, to_tr)[1]
+            reg_term = -ag_value / Delta ** 2
+
+        with _Phase(prob, 'lsmr'):
+            dreg = (diag_h + reg_term) ** 0.5
+            gn_h, _istop, itn, _nr, _nar = lsmr(prob, d, dreg, **lsmr_opts)
+            lsmr_iters += itn
+        with _Phase(prob, 'subspace'):
+            # orthonormal basis of span{g_h, gn_h} (SciPy: economic QR; the step S p_S does not
+            # depend on which orthonormal basis is used): Gram-Schmidt with re-orthogonalisation
+            s0 = g_h / np.sqrt(gg)
+            w = gn_h - torch.dot(s0, gn_h) * s0
+            w = w - torch.dot(s0, w) * s0
+            wn = float(vnorm(w))
+            s1 = w / wn if wn > 0 else torch.zeros_like(w)
+            GS = prob.gram_dev(d, [s0, s1])
+            e00, e01, e11, gs0, gs1 = _dots((s0 * diag_h, s0), (s0 * diag_h, s1), (s1 * diag_h, s1),
+                                            (s0, g_h), (s1, g_h))
+            B_S = GS + np.array([[e00, e01], [e01, e11]])
+            g_S = np.array([gs0, gs1])
+
+        theta = max(0.995, 1 - g_norm)
+        actual_reduction = -1
+        while actual_reduction <= 0 and nfev < max_nfev:
+            with _Phase(prob, 'select_step'):
+                p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
+                p_h = float(p_S[0]) * s0 + float(p_S[1]) * s1
+                p = d * p_h
+                step, step_h, predicted_reduction = _select_step_dev(
+                    prob, x, d, diag_h, g_h, p, p_h, Delta, lb_d, ub_d, theta)
+            with _Phase(prob, 'fun'):
+                x_new = _strictly_feasible_dev(x + step, lb_d, ub_d, fin_lb, fin_ub)
+                prob.set_x_dev(x_new)
+                prob.residual(out=r_new)
+                nfev += 1
+                step_h_norm = float(vnorm(step_h))
+                cost_new = prob.cost_of_r(r_new)
+            if not np.isfinite(cost_new):
+                Delta = 0.25 * step_h_norm
+                continue
+            actual_reduction = cost - cost_new
+            Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
+                                                step_h_norm, step_h_norm > 0.95 * Delta)
+            step_norm, x_norm = torch.stack([vnorm(step), vnorm(x)]).tolist()
+            termination_status = check_termination(actual_reduction, cost, step_norm, x_norm,
+                                                   ratio, ftol, xtol)
+            if termination_status is not None:
+                break
+            Delta = Delta_new
+
+        if actual_reduction > 0:
+            with _Phase(prob, 'jac+grad'):
+                x = x_new
+                cost = cost_new                   # (the device already holds x_new: the accepted
+                prob.residual_jac()               #  trial was the last one evaluated)
+                njev += 1
+                g = prob.grad_dev()
+                scale_inv = torch.maximum(scale_inv, prob.colnorm_dev())   # compute_jac_scale
+                scale = 1 / scale_inv
+            if callback is not None:
+                callback(prob.download_n(x), cost)
+        else:
+            prob.set_x_dev(x)
+            prob.residual()
+            step_norm = 0
+            actual_reduction = 0
+        iteration += 1
+
+    if termination_status is None:
+        termination_status = 0
+    active = _active_constraints_dev(x, lb_d, ub_d, fin_lb, fin_ub, xtol)
+    return OptimizeResult(x=prob.download_n(x), cost=cost, grad=prob.download_n(g),
+                          optimality=g_norm,
+                          active_mask=prob.download_n(active).astype(int), nfev=nfev, njev=njev,
+                          status=termination_status, lsmr_iterations=lsmr_iters,
+                          iterations=iteration)
+
 
 
 def gather_residual(prob, n_obs_total):
