@@ -72,7 +72,7 @@ SIGNATURES = {
                             c_void_p, c_void_p]),
     'iamx_ba_lsmr_state_size': (c_int, []),
     'iamx_ba_lsmr_partials_size': (c_int64, [c_int, c_int]),
-    'iamx_ba_lsmr_prepare': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 5),
+    'iamx_ba_lsmr_prepare': (c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 3),
     'iamx_ba_lsmr_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 11
                              + [c_int, c_void_p]),
     'iamx_ba_lsmr_phase': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 11

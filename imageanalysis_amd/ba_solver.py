@@ -114,6 +114,8 @@ class DeviceBA(object):
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
         self.cam_idx, self.pt_idx = t(cam, I32), t(pt, I32)
         self.cam_ptr, self.pt_ptr, self.pt_obs = t(cam_ptr, I32), t(pt_ptr, I32), t(order, I32)
+        # (camera, point) of the observation in every point-sorted slot (matrix-free LSMR adjoint)
+        self.slot_cp = t(np.stack([cam[order], pt[order]], 1) if cam.size else np.zeros((1, 2)), I32)
         self.uv = t(uv, F64)
         self.idx_h2i, self.idx_i2h = t(h2i, torch.int64), t(i2h, torch.int64)
         z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
@@ -529,18 +531,19 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     if ws is None:
         z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
         ws = prob.lsmr_ws = dict(u1=z(m), u2=z(n), vt=z(n), h=z(n), hbar=z(n), x=z(n),
-                                 Jc_s=z(prob.O * 14), Jp_s=z(prob.O * 6), Jp_p=z(prob.O * 6),
+                                 ctab=z(prob.C * 32), ptab=z(prob.P * 6),
                                  state=z(L.iamx_ba_lsmr_state_size()),
                                  part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
-                                 xr=z(1), tbuf=z(n))
+                                 xr=z(2), tbuf=z(n))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
     ph = _Phase(prob, 'lsmr:init')
     ph.__enter__()
-    if prob.O:
-        check(L.iamx_ba_lsmr_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx),
-                                     _ptr(prob.pt_idx), _ptr(prob.pt_obs), prob.O, prob.C, prob.P,
-                                     _ptr(d_dev), _ptr(ws['Jc_s']), _ptr(ws['Jp_s']),
-                                     _ptr(ws['Jp_p']), stream_ptr()), 'iamx_ba_lsmr_prepare')
+    # the tables of the matrix-free operator at the current parameters (the point J was
+    # evaluated at: residual_jac() ran on prob.x)
+    cams, pts = prob._cams_pts()
+    check(L.iamx_ba_lsmr_prepare(_ptr(cams), _ptr(pts), _ptr(d_dev), prob.C, prob.P,
+                                 _ptr(ws['ctab']), _ptr(ws['ptab']), stream_ptr()),
+          'iamx_ba_lsmr_prepare')
     u1[:m].copy_(prob.r[:m])
     u2.zero_(); hbar.zero_(); x.zero_()
     normb = np.sqrt(prob.dot(u1, u1, m, True))
@@ -570,8 +573,8 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     ph.__exit__()
     ph = _Phase(prob, 'lsmr:iterate')
     ph.__enter__()
-    common = (_ptr(ws['Jc_s']), _ptr(ws['Jp_s']), _ptr(ws['Jp_p']), _ptr(prob.cam_idx),
-              _ptr(prob.pt_idx), _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), prob.O,
+    common = (_ptr(ws['ctab']), _ptr(ws['ptab']), _ptr(prob.calib), _ptr(prob.pt_idx),
+              _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), _ptr(prob.slot_cp), prob.O,
               prob.C, prob.P, _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h), _ptr(hbar),
               _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
     def enqueue_chunk():
@@ -584,7 +587,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
             for it in range(chunk):
                 par = it & 1
                 check(L.iamx_ba_lsmr_phase(*common, *tail, 0, par, stream_ptr()), 'iamx_ba_lsmr_phase')
-                _dist.allreduce_sum_(xr)
+                _dist.allreduce_sum_(xr[:1])        # xr[1] (replicated part) is not summed
                 check(L.iamx_ba_lsmr_phase(*common, *tail, 1, par, stream_ptr()), 'iamx_ba_lsmr_phase')
                 _dist.allreduce_sum_(tbuf[:n])
                 check(L.iamx_ba_lsmr_phase(*common, *tail, 2, par, stream_ptr()), 'iamx_ba_lsmr_phase')

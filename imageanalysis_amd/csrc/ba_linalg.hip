@@ -322,10 +322,18 @@ extern "C" int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *
 // Fused, host-free LSMR iterations (scipy/sparse/linalg/_isolve/lsmr.py) on the operator
 //     A = [ J diag(d) ; diag(dreg) ],   b = [ r ; 0 ]
 //
-// * iamx_ba_lsmr_prepare folds the column scaling into J once per solve and lays the blocks
-//   out structure-of-arrays so that every load of the iteration kernels is coalesced:
-//       Jc_s [14][O] observation order,  Jp_s [6][O] observation order (forward product),
-//       Jp_p [6][O]  point-sorted order (adjoint product, one thread per point).
+// * Matrix free: the iteration kernels re-derive the 2x10 block of an observation from the
+//   camera and the point instead of reading it (the analytic Jacobian of ba_kernels.hip,
+//   factored so that the per-observation work is ~200 flops).  A materialised, scaled J is
+//   408 MB per pass at BASELINE config 4; the matrix-free working set (ut 31 MB, the point /
+//   camera tables 13 MB, the n-vectors) stays in the 256 MB Infinity Cache.
+//   iamx_ba_lsmr_prepare builds the tables once per solve:
+//       ctab [C][32]: B^T = M(q)^T/|q|^2 (9), ned (3), q (4), 1/|q|^2, d of the 7 columns
+//       ptab [P][6] : X (3), d of the 3 columns
+//   With  w = du*ut_x + dv*ut_y  (du, dv = d(u,v)/d(body point)):
+//       J_point^T ut = -B w,   J_ned^T ut = +B w,   J_q[k]^T ut = -w.e_k,
+//       e_k = 2 (Q_k dX - q_k yb)/|q|^2,  Q_k the bilinear forms of ba_residual_jac_kernel
+//   and J v = du.g, dv.g with g = B^T (v_ned - v_point) - sum_k v_q[k] e_k.
 // * The Golub-Kahan vectors are kept UNnormalised (ut = beta*u, vt = alpha*v), so one
 //   bidiagonalisation step is a forward and an adjoint kernel whose epilogues emit the
 //   squared-norm partials:
@@ -338,12 +346,13 @@ extern "C" int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *
 //   four launches and no host synchronisation; the stopping tests of iteration k run in the
 //   prologue of iteration k+1's forward kernel and latch R_ISTOP, which turns everything
 //   enqueued behind it into no-ops.
-// * Each camera block of J is read ONCE per iteration: the forward kernel runs one workgroup per
-//   camera (observations are camera-major), forms ut' for its observations and, with the
-//   blocks still in registers, the camera part of J^T ut' (raw, unscaled: beta' is not known
-//   yet).  The point part of J^T ut' is a second kernel over the point-sorted copy of Jp.
-//       forward+camera adjoint   O*(160 J + 8 idx + 32 ut r/w)
-//       point adjoint            O*(48 Jp + 16 ut gather + 4 idx)      + n-vectors
+// * The forward kernel runs one workgroup per camera (observations are camera-major, the
+//   camera's table row comes through the scalar cache), forms ut' for its observations and,
+//   with the geometry still in registers, the camera part of J^T ut' (raw: beta' is not known
+//   yet; accumulated as sum w and sum w (x) dX, 12 numbers, and expanded once per camera).
+//   The point part of J^T ut' is a second kernel over the point-sorted slots.
+//       forward+camera adjoint   O*(4 idx + 32 ut r/w) + cached point rows and vt gathers
+//       point adjoint            O*(12 idx + 16 ut gather) + cached point / camera rows
 // =====================================================================================
 namespace {
 
@@ -359,9 +368,13 @@ enum {
     R_NORMA, R_CONDA, R_NORMX, R_COUNT
 };
 
+constexpr int CT = 32;            // doubles per camera table row
+enum { CT_BT = 0, CT_NED = 9, CT_Q = 12, CT_INVN = 16, CT_D = 17 };
+
 struct LsmrArgs {
-    const double *Jc_s, *Jp_s, *Jp_p;
-    const int32_t *cam_idx, *pt_idx, *cam_ptr, *pt_ptr, *pt_obs;
+    const double *ctab, *ptab, *calib;
+    const int32_t *pt_idx, *cam_ptr, *pt_ptr, *pt_obs;
+    const int2 *slot_cp;         // per point-sorted slot: (camera, point) of its observation
     int64_t n_obs;
     int n_cams, n_pts;
     const double *dreg;
@@ -416,58 +429,268 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
 // caller on several ranks) plus the replicated n-vector part
 __device__ __forceinline__ double beta_new(const LsmrArgs &A, double *sh)
 {
-    return sqrt(A.xr[0] + sum_partials(A.partU2, LS_U2_BLOCKS, sh));
+    (void)sh;
+    return sqrt(A.xr[0] + A.xr[1]);
 }
 
-// one thread per observation: scaled SoA copies in observation order
-__global__ __launch_bounds__(256) void lsmr_prepare_obs_kernel(
-    const double *__restrict__ Jc, const double *__restrict__ Jp,
-    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx, int64_t n_obs,
-    int n_cams, const double *__restrict__ d, double *__restrict__ Jc_s, double *__restrict__ Jp_s)
+// d(u,v)/d(body point) of one observation from its camera table row and point -- the
+// arithmetic of ba_residual_jac_kernel (ba_kernels.hip) up to `du`, `dv`
+struct ObsGeom { double du[3], dv[3], dX[3], yb[3]; };
+
+__device__ __forceinline__ void obs_geom(const double *__restrict__ ct, const double *__restrict__ X,
+                                         const double (&cal)[9], ObsGeom &G)
 {
-    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (o >= n_obs) return;
-    const double *dc = d + (int64_t)cam_idx[o] * 7;
-    const double *dp = d + (int64_t)n_cams * 7 + (int64_t)pt_idx[o] * 3;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        Jc_s[(int64_t)k * n_obs + o] = Jc[o * 14 + k] * dc[k];
-        Jc_s[(int64_t)(7 + k) * n_obs + o] = Jc[o * 14 + 7 + k] * dc[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        Jp_s[(int64_t)k * n_obs + o] = Jp[o * 6 + k] * dp[k];
-        Jp_s[(int64_t)(3 + k) * n_obs + o] = Jp[o * 6 + 3 + k] * dp[k];
-    }
+    const double a = X[0] - ct[CT_NED], b = X[1] - ct[CT_NED + 1], c = X[2] - ct[CT_NED + 2];
+    G.dX[0] = a; G.dX[1] = b; G.dX[2] = c;
+    const double y0 = ct[0] * a + ct[1] * b + ct[2] * c;
+    const double y1 = ct[3] * a + ct[4] * b + ct[5] * c;
+    const double y2 = ct[6] * a + ct[7] * b + ct[8] * c;
+    G.yb[0] = y0; G.yb[1] = y1; G.yb[2] = y2;
+    const double iz = 1.0 / y0;            // camera z = body x
+    const double x = y1 * iz, y = y2 * iz;
+    const double r2 = x * x + y * y;
+    const double k1 = cal[4], k2 = cal[5], p1 = cal[6], p2 = cal[7], k3 = cal[8];
+    const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+    const double drad = k1 + r2 * (2.0 * k2 + 3.0 * k3 * r2);
+    const double xdx = rad + 2.0 * x * x * drad + 2.0 * p1 * y + 6.0 * p2 * x;
+    const double xdy = 2.0 * x * y * drad + 2.0 * p1 * x + 2.0 * p2 * y;
+    const double ydy = rad + 2.0 * y * y * drad + 6.0 * p1 * y + 2.0 * p2 * x;
+    const double ux = cal[0] * xdx, uy = cal[0] * xdy, vx = cal[1] * xdy, vy = cal[1] * ydy;
+    G.du[0] = -(ux * x + uy * y) * iz;   G.dv[0] = -(vx * x + vy * y) * iz;
+    G.du[1] = ux * iz;                   G.dv[1] = vx * iz;
+    G.du[2] = uy * iz;                   G.dv[2] = vy * iz;
 }
 
-// one thread per point-sorted slot e: Jp_p[.][e] = scaled Jp of observation pt_obs[e]
-__global__ __launch_bounds__(256) void lsmr_prepare_pt_kernel(
-    const double *__restrict__ Jp, const int32_t *__restrict__ pt_idx,
-    const int32_t *__restrict__ pt_obs, int64_t n_obs, int n_cams, const double *__restrict__ d,
-    double *__restrict__ Jp_p)
+// one thread per camera / per point: the tables of a solve
+__global__ __launch_bounds__(256) void lsmr_prepare_mf_kernel(
+    const double *__restrict__ cams, const double *__restrict__ pts, const double *__restrict__ d,
+    int n_cams, int n_pts, double *__restrict__ ctab, double *__restrict__ ptab)
 {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_obs) return;
-    const int64_t o = pt_obs[e];
-    const double *dp = d + (int64_t)n_cams * 7 + (int64_t)pt_idx[o] * 3;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cams) {
+        const double *cam = cams + (int64_t)i * 7;
+        double *o = ctab + (int64_t)i * CT;
+        const double w = cam[3], x = cam[4], y = cam[5], z = cam[6];
+        const double n = w * w + x * x + y * y + z * z;
+        if (n < 2.220446049250313e-16 * 4.0) {       // transformations._EPS: identity, no q columns
+            o[0] = 1; o[1] = 0; o[2] = 0; o[3] = 0; o[4] = 1; o[5] = 0; o[6] = 0; o[7] = 0; o[8] = 1;
+            o[CT_INVN] = 0.0;
+        } else {
+            const double inv_n = 1.0 / n;
+            const double ww = w * w, xx = x * x, yy = y * y, zz = z * z;
+            const double xy = x * y, xz = x * z, yz = y * z, wx = w * x, wy = w * y, wz = w * z;
+            o[0] = (ww + xx - yy - zz) * inv_n; o[1] = 2.0 * (xy + wz) * inv_n; o[2] = 2.0 * (xz - wy) * inv_n;
+            o[3] = 2.0 * (xy - wz) * inv_n; o[4] = (ww - xx + yy - zz) * inv_n; o[5] = 2.0 * (yz + wx) * inv_n;
+            o[6] = 2.0 * (xz + wy) * inv_n; o[7] = 2.0 * (yz - wx) * inv_n; o[8] = (ww - xx - yy + zz) * inv_n;
+            o[CT_INVN] = inv_n;
+        }
+        o[CT_NED] = cam[0]; o[CT_NED + 1] = cam[1]; o[CT_NED + 2] = cam[2];
+        o[CT_Q] = w; o[CT_Q + 1] = x; o[CT_Q + 2] = y; o[CT_Q + 3] = z;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        Jp_p[(int64_t)k * n_obs + e] = Jp[o * 6 + k] * dp[k];
-        Jp_p[(int64_t)(3 + k) * n_obs + e] = Jp[o * 6 + 3 + k] * dp[k];
+        for (int k = 0; k < 7; ++k) o[CT_D + k] = d[(int64_t)i * 7 + k];
+#pragma unroll
+        for (int k = CT_D + 7; k < CT; ++k) o[k] = 0.0;
+    }
+    const int p = i - n_cams;
+    if (p >= 0 && p < n_pts) {
+        double *o = ptab + (int64_t)p * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = pts[(int64_t)p * 3 + k];
+            o[3 + k] = d[(int64_t)n_cams * 7 + (int64_t)p * 3 + k];
+        }
     }
 }
 
-// ---- kernel A: stopping tests of the previous iteration, then ut' ------------------------
+// ---- kernel A: ut' ------------------------------------------------------------------------
+// (the stopping tests of the previous iteration run in lsmr_sumU_kernel, one workgroup, instead
+// of in the prologue of all ~3000 workgroups here: if they latch a stop, this launch has only
+// touched ut / tbuf, which nobody reads any more, and x is final)
 __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
     double *S = A.S;
     if (S[R_ISTOP] != 0.0) return;
     const double *in = S + parity * S_NBUF;
+    const double ia = 1.0 / in[S_ALPHA], ab = in[S_ALPHA] / in[S_BETA];
+    if ((int)blockIdx.x >= A.n_cams) {       // the replicated n-vector part of ut'
+        const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+        double acc2 = 0.0;
+        for (int64_t i = (int64_t)(blockIdx.x - A.n_cams) * 256 + threadIdx.x; i < n; i += (int64_t)LS_U2_BLOCKS * 256) {
+            const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
+            A.u2[i] = v;
+            acc2 += v * v;
+        }
+        const double s2 = block_sum_256(acc2, sh);
+        if (threadIdx.x == 0) A.partU2[blockIdx.x - A.n_cams] = s2;
+        return;
+    }
+    // one camera: its table row and its 7 entries of vt are wave-uniform (scalar loads)
+    const int c = blockIdx.x;
+    const double *ct = A.ctab + (int64_t)c * CT;
+    const double *vc = A.vt + (int64_t)c * 7;
+    const double *xp = A.vt + (int64_t)A.n_cams * 7;
+    double cal[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cal[i] = A.calib[i];
+    const double qw = ct[CT_Q], qx = ct[CT_Q + 1], qy = ct[CT_Q + 2], qz = ct[CT_Q + 3];
+    const double inv_n2 = 2.0 * ct[CT_INVN];
+    // rows of the bilinear forms s, t, p, d of (q, dX) (ba_residual_jac_kernel)
+    const double Sr[3] = {qw, qz, -qy}, Tr[3] = {-qz, qw, qx}, Pr[3] = {qy, -qx, qw}, Dr[3] = {qx, qy, qz};
+    const double wn0 = ct[CT_D] * vc[0], wn1 = ct[CT_D + 1] * vc[1], wn2 = ct[CT_D + 2] * vc[2];
+    const double wq0 = ct[CT_D + 3] * vc[3], wq1 = ct[CT_D + 4] * vc[4];
+    const double wq2 = ct[CT_D + 5] * vc[5], wq3 = ct[CT_D + 6] * vc[6];
+    // sum_k wq[k] e_k = inv_n2 * (N dX - qs yb)
+    double N[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        N[0][j] = wq0 * Sr[j] + wq1 * Dr[j] - wq2 * Pr[j] + wq3 * Tr[j];
+        N[1][j] = wq0 * Tr[j] + wq1 * Pr[j] + wq2 * Dr[j] - wq3 * Sr[j];
+        N[2][j] = wq0 * Pr[j] - wq1 * Tr[j] + wq2 * Sr[j] + wq3 * Dr[j];
+    }
+    const double qs = wq0 * qw + wq1 * qx + wq2 * qy + wq3 * qz;
+    double acc = 0.0;
+    double sw[3] = {0, 0, 0};
+    double Mo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    // K observations per thread and pass, their loads issued before the arithmetic.  K = 3
+    // (a whole camera in one pass) was measured SLOWER than K = 1 (74 vs 61 us): 206 instead of
+    // 142 VGPRs drop the occupancy to 2 waves per SIMD, which costs more than the overlap gains.
+    constexpr int K = 1;
+    const int o_end = A.cam_ptr[c + 1];
+    for (int base = A.cam_ptr[c] + threadIdx.x; base < o_end; base += 256 * K) {
+        int pi[K];
+        double2 uo[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int o = base + 256 * k;
+            pi[k] = o < o_end ? A.pt_idx[o] : -1;
+            uo[k] = o < o_end ? *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)o) : make_double2(0, 0);
+        }
+        double pr[K][6], vp[K][3];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (pi[k] < 0) continue;
+            const double2 *src = reinterpret_cast<const double2 *>(A.ptab + (int64_t)pi[k] * 6);
+            const double2 p0 = src[0], p1 = src[1], p2 = src[2];
+            pr[k][0] = p0.x; pr[k][1] = p0.y; pr[k][2] = p1.x; pr[k][3] = p1.y; pr[k][4] = p2.x; pr[k][5] = p2.y;
+            const double *v = xp + (int64_t)pi[k] * 3;
+            vp[k][0] = v[0]; vp[k][1] = v[1]; vp[k][2] = v[2];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (pi[k] < 0) continue;
+            const int o = base + 256 * k;
+            ObsGeom G;
+            obs_geom(ct, pr[k], cal, G);
+            // z = (d v)_ned - (d v)_point  (J_ned = +B, J_point = -B in the body frame)
+            const double z0 = wn0 - pr[k][3] * vp[k][0], z1 = wn1 - pr[k][4] * vp[k][1];
+            const double z2 = wn2 - pr[k][5] * vp[k][2];
+            double g[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double bz = ct[3 * i] * z0 + ct[3 * i + 1] * z1 + ct[3 * i + 2] * z2;
+                const double nd = N[i][0] * G.dX[0] + N[i][1] * G.dX[1] + N[i][2] * G.dX[2];
+                g[i] = bz - inv_n2 * (nd - qs * G.yb[i]);
+            }
+            const double a = G.du[0] * g[0] + G.du[1] * g[1] + G.du[2] * g[2];
+            const double b = G.dv[0] * g[0] + G.dv[1] * g[1] + G.dv[2] * g[2];
+            double2 u = uo[k];
+            u.x = a * ia - ab * u.x;
+            u.y = b * ia - ab * u.y;
+            *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o) = u;
+            acc += u.x * u.x + u.y * u.y;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double w = G.du[i] * u.x + G.dv[i] * u.y;
+                sw[i] += w;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Mo[i][j] += w * G.dX[j];
+            }
+        }
+    }
+    __shared__ double red[4][13];
+    double vals[13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vals[i] = sw[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vals[3 + 3 * i + j] = Mo[i][j];
+    }
+    vals[12] = acc;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) vals[k] += __shfl_xor(vals[k], m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) red[threadIdx.x >> 6][k] = vals[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) t[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        // camera part of J^T ut' from sum w (t[0..2]) and sum w (x) dX (t[3..11])
+        double out7[7];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out7[j] = ct[j] * t[0] + ct[3 + j] * t[1] + ct[6 + j] * t[2];
+        // w.yb = sum_ij B^T[i][j] Mo[i][j];  w.(Q_k dX) = sum_ij Q_k[i][j] Mo[i][j]
+        double wy = 0.0, f[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double m0 = t[3 + j], m1 = t[6 + j], m2 = t[9 + j];
+            wy += ct[j] * m0 + ct[3 + j] * m1 + ct[6 + j] * m2;
+            f[0] += Sr[j] * m0 + Tr[j] * m1 + Pr[j] * m2;
+            f[1] += Dr[j] * m0 + Pr[j] * m1 - Tr[j] * m2;
+            f[2] += -Pr[j] * m0 + Dr[j] * m1 + Sr[j] * m2;
+            f[3] += Tr[j] * m0 - Sr[j] * m1 + Dr[j] * m2;
+        }
+        const double qq[4] = {qw, qx, qy, qz};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out7[3 + k] = -inv_n2 * (f[k] - qq[k] * wy);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) A.tbuf[(int64_t)c * 7 + k] = out7[k] * ct[CT_D + k];
+        A.partU[c] = t[12];
+    }
+}
+
+// One workgroup between the forward and the adjoint kernel:
+//   * lsmr.py "Test for convergence" of the PREVIOUS iteration (state buffer `parity`, |x|^2
+//     partials of its update kernel); a latched R_ISTOP turns everything enqueued behind this
+//     launch into no-ops
+//   * xr[0] = this rank's |ut1'|^2 (all-reduced by the caller on several ranks),
+//     xr[1] = |ut2'|^2 (replicated part), so that beta' is two loads for everybody else.
+// A separate launch on purpose: letting the last forward workgroup do it ("threadfence
+// reduction") needs device-scope fences, and on this 8-XCD part every such fence writes the
+// XCD's L2 back -- measured 48 -> 297 us for the forward kernel.
+__global__ __launch_bounds__(256) void lsmr_sumU_kernel(LsmrArgs A, int parity)
+{
+    double *S = A.S;
+    if (S[R_ISTOP] != 0.0) return;
+    const double *in = S + parity * S_NBUF;
     const double itn = in[S_ITN];
+    // the three sums in one pass: all loads in flight together, one reduction
+    double aX = 0.0, aU = 0.0, aU2 = 0.0;
+    for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) aX += A.partX[i];
+    for (int i = threadIdx.x; i < A.n_cams; i += 256) aU += A.partU[i];
+    for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) aU2 += A.partU2[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        aX += __shfl_xor(aX, m);
+        aU += __shfl_xor(aU, m);
+        aU2 += __shfl_xor(aU2, m);
+    }
+    __shared__ double sh3[4][3];
+    if ((threadIdx.x & 63) == 0) {
+        sh3[threadIdx.x >> 6][0] = aX; sh3[threadIdx.x >> 6][1] = aU; sh3[threadIdx.x >> 6][2] = aU2;
+    }
+    __syncthreads();
+    const double sumX = sh3[0][0] + sh3[1][0] + sh3[2][0] + sh3[3][0];
+    const double s = sh3[0][1] + sh3[1][1] + sh3[2][1] + sh3[3][1];
+    const double s2 = sh3[0][2] + sh3[1][2] + sh3[2][2] + sh3[3][2];
     if (itn > 0.0) {             // lsmr.py: "Test for convergence" of iteration itn
-        const double normx = sqrt(sum_partials(A.partX, LS_UPD_BLOCKS, sh));
+        const double normx = sqrt(sumX);
         const double normb = S[R_NORMB], normA = in[S_NORMA], normr = in[S_NORMR];
         const double normar = in[S_NORMAR], condA = in[S_CONDA];
         const double test1 = normr / normb;
@@ -484,86 +707,14 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
         if (test2 <= S[R_ATOL]) istop = 2;
         if (test1 <= rtol) istop = 1;
         if (!(test1 == test1) || !(normx == normx)) istop = 8;     // breakdown (NaN)
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (threadIdx.x == 0) {
             S[R_ITN] = itn; S[R_NORMR] = normr; S[R_NORMAR] = normar; S[R_NORMA] = normA;
             S[R_CONDA] = condA; S[R_NORMX] = normx;
             if (istop != 0) S[R_ISTOP] = istop;
         }
         if (istop != 0) return;
     }
-    const double ia = 1.0 / in[S_ALPHA], ab = in[S_ALPHA] / in[S_BETA];
-    const int64_t O = A.n_obs;
-    if ((int)blockIdx.x >= A.n_cams) {       // the replicated n-vector part of ut'
-        const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
-        double acc2 = 0.0;
-        for (int64_t i = (int64_t)(blockIdx.x - A.n_cams) * 256 + threadIdx.x; i < n; i += (int64_t)LS_U2_BLOCKS * 256) {
-            const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
-            A.u2[i] = v;
-            acc2 += v * v;
-        }
-        const double s2 = block_sum_256(acc2, sh);
-        if (threadIdx.x == 0) A.partU2[blockIdx.x - A.n_cams] = s2;
-        return;
-    }
-    // one camera: its 7 entries of vt are wave-uniform (scalar loads)
-    const int c = blockIdx.x;
-    const double *vc = A.vt + (int64_t)c * 7;
-    const double *xp = A.vt + (int64_t)A.n_cams * 7;
-    double acc = 0.0;
-    double t7[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (int o = A.cam_ptr[c] + threadIdx.x; o < A.cam_ptr[c + 1]; o += 256) {
-        const double *vp = xp + (int64_t)A.pt_idx[o] * 3;
-        double ju[7], jv[7];
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            ju[k] = A.Jc_s[(int64_t)k * O + o];
-            jv[k] = A.Jc_s[(int64_t)(7 + k) * O + o];
-            a += ju[k] * vc[k];
-            b += jv[k] * vc[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double v = vp[k];
-            a += A.Jp_s[(int64_t)k * O + o] * v;
-            b += A.Jp_s[(int64_t)(3 + k) * O + o] * v;
-        }
-        double2 u = *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o);
-        u.x = a * ia - ab * u.x;
-        u.y = b * ia - ab * u.y;
-        *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o) = u;
-        acc += u.x * u.x + u.y * u.y;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) t7[k] += ju[k] * u.x + jv[k] * u.y;      // camera part of J^T ut'
-    }
-    __shared__ double red[4][8];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) t7[k] += __shfl_xor(t7[k], m);
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) red[threadIdx.x >> 6][k] = t7[k];
-        red[threadIdx.x >> 6][7] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        if (threadIdx.x < 7) A.tbuf[(int64_t)c * 7 + threadIdx.x] = v;
-        else A.partU[c] = v;
-    }
-}
-
-// xr[0] = this rank's |ut1'|^2 (all-reduced by the caller on several ranks)
-__global__ __launch_bounds__(256) void lsmr_sumU_kernel(LsmrArgs A)
-{
-    __shared__ double sh[4];
-    if (A.S[R_ISTOP] != 0.0) { if (threadIdx.x == 0) A.xr[0] = 0.0; return; }
-    const double s = sum_partials(A.partU, A.n_cams, sh);
-    if (threadIdx.x == 0) A.xr[0] = s;
+    if (threadIdx.x == 0) { A.xr[0] = s; A.xr[1] = s2; }
 }
 
 // ---- kernel B: beta', point part of J^T ut', vt' --------------------------------------------
@@ -592,10 +743,12 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
         ib = 1.0 / bn;
         ba = bn / in[S_ALPHA];
     }
-    const int64_t O = A.n_obs;
     const int n_pt_blocks = (A.n_pts + 255) / 256;
     double sq = 0.0;
     if ((int)blockIdx.x < n_pt_blocks) {
+        double cal[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) cal[i] = A.calib[i];
         const int p0 = blockIdx.x * 256;
         const int p1 = min(p0 + 256, A.n_pts);
         const int p = p0 + threadIdx.x;
@@ -609,10 +762,17 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
                 const int jx = threadIdx.x + 256 * i;
                 if (jx < cnt) {
                     const int64_t e = base + jx;
+                    const int2 cp = A.slot_cp[e];
                     const double2 uu = *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)A.pt_obs[e]);
-                    prod[0][jx] = A.Jp_p[e] * uu.x + A.Jp_p[3 * O + e] * uu.y;
-                    prod[1][jx] = A.Jp_p[O + e] * uu.x + A.Jp_p[4 * O + e] * uu.y;
-                    prod[2][jx] = A.Jp_p[2 * O + e] * uu.x + A.Jp_p[5 * O + e] * uu.y;
+                    const double *ct = A.ctab + (int64_t)cp.x * CT;
+                    ObsGeom G;
+                    obs_geom(ct, A.ptab + (int64_t)cp.y * 6, cal, G);
+                    const double w0 = G.du[0] * uu.x + G.dv[0] * uu.y;
+                    const double w1 = G.du[1] * uu.x + G.dv[1] * uu.y;
+                    const double w2 = G.du[2] * uu.x + G.dv[2] * uu.y;
+                    prod[0][jx] = -(ct[0] * w0 + ct[3] * w1 + ct[6] * w2);      // J_point = -B
+                    prod[1][jx] = -(ct[1] * w0 + ct[4] * w1 + ct[7] * w2);
+                    prod[2][jx] = -(ct[2] * w0 + ct[5] * w1 + ct[8] * w2);
                 }
             }
             __syncthreads();
@@ -625,7 +785,8 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
             __syncthreads();
         }
         if (p < p1) {
-            const double acc[3] = {a0, a1, a2};
+            const double *dp = A.ptab + (int64_t)p * 6 + 3;
+            const double acc[3] = {a0 * dp[0], a1 * dp[1], a2 * dp[2]};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int64_t i = (int64_t)A.n_cams * 7 + (int64_t)p * 3 + k;
@@ -776,38 +937,35 @@ extern "C" int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts)
     return part_layout(n_cams, n_pts).total;
 }
 
-extern "C" int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                                    const int32_t *pt_idx, const int32_t *pt_obs, int64_t n_obs,
-                                    int n_cams, int n_pts, const double *d, double *Jc_s,
-                                    double *Jp_s, double *Jp_p, void *stream)
+extern "C" int iamx_ba_lsmr_prepare(const double *cams, const double *pts, const double *d,
+                                    int n_cams, int n_pts, double *ctab, double *ptab,
+                                    void *stream)
 {
-    IAMX_REQUIRE(Jc && Jp && cam_idx && pt_idx && pt_obs && d && Jc_s && Jp_s && Jp_p, "null pointer");
-    IAMX_REQUIRE(n_obs > 0 && n_cams > 0 && n_pts > 0, "bad size");
-    hipStream_t st = iamx::as_stream(stream);
-    const unsigned g = (unsigned)((n_obs + 255) / 256);
-    hipLaunchKernelGGL(lsmr_prepare_obs_kernel, dim3(g), dim3(256), 0, st, Jc, Jp, cam_idx, pt_idx,
-                       n_obs, n_cams, d, Jc_s, Jp_s);
-    hipLaunchKernelGGL(lsmr_prepare_pt_kernel, dim3(g), dim3(256), 0, st, Jp, pt_idx, pt_obs, n_obs,
-                       n_cams, d, Jp_p);
+    IAMX_REQUIRE(cams && pts && d && ctab && ptab, "null pointer");
+    IAMX_REQUIRE(n_cams > 0 && n_pts > 0, "bad size");
+    const unsigned g = (unsigned)(((int64_t)n_cams + n_pts + 255) / 256);
+    hipLaunchKernelGGL(lsmr_prepare_mf_kernel, dim3(g), dim3(256), 0, iamx::as_stream(stream), cams,
+                       pts, d, n_cams, n_pts, ctab, ptab);
     return iamx::check_launch("iamx_ba_lsmr_prepare");
 }
 
-extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *Jp_p,
-                                    const int32_t *cam_idx, const int32_t *pt_idx,
-                                    const int32_t *cam_ptr, const int32_t *pt_ptr,
-                                    const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, const double *calib,
+                                    const int32_t *pt_idx, const int32_t *cam_ptr,
+                                    const int32_t *pt_ptr, const int32_t *pt_obs,
+                                    const int32_t *slot_cp, int64_t n_obs, int n_cams, int n_pts,
                                     const double *dreg, double *u1, double *u2, double *vt,
                                     double *h, double *hbar, double *x, double *state,
                                     double *partials, double *xr, double *tbuf, int n_iter,
                                     void *stream)
 {
-    IAMX_REQUIRE(Jc_s && Jp_s && Jp_p && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && dreg &&
+    IAMX_REQUIRE(ctab && ptab && calib && pt_idx && cam_ptr && pt_ptr && pt_obs && slot_cp && dreg &&
                      u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
                  "null pointer");
     IAMX_REQUIRE(n_obs > 0 && n_cams > 0 && n_pts > 0 && n_iter >= 0 && (n_iter & 1) == 0,
                  "bad size (n_iter must be even: the state block is double-buffered)");
     const PartLayout L = part_layout(n_cams, n_pts);
-    LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
+    LsmrArgs A{ctab, ptab, calib, pt_idx, cam_ptr, pt_ptr, pt_obs,
+               reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
                partials, partials + L.off_V, partials + L.off_X, L.n_adj, partials + L.off_U2,
                xr, tbuf, 0};
@@ -815,7 +973,7 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
         hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
-        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_adj_kernel, dim3(L.n_adj), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
     }
@@ -828,29 +986,30 @@ extern "C" int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, cons
 //            xr[0] = local |ut1'|^2
 //   phase 1: raw point part of J^T ut1' -> tbuf
 //   phase 2: vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
-extern "C" int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
-                                  const int32_t *cam_idx, const int32_t *pt_idx,
-                                  const int32_t *cam_ptr, const int32_t *pt_ptr,
-                                  const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+extern "C" int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *calib,
+                                  const int32_t *pt_idx, const int32_t *cam_ptr,
+                                  const int32_t *pt_ptr, const int32_t *pt_obs,
+                                  const int32_t *slot_cp, int64_t n_obs, int n_cams, int n_pts,
                                   const double *dreg, double *u1, double *u2, double *vt, double *h,
                                   double *hbar, double *x, double *state, double *partials,
                                   double *xr, double *tbuf, int phase, int parity, void *stream)
 {
-    IAMX_REQUIRE(Jc_s && Jp_s && Jp_p && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && dreg &&
+    IAMX_REQUIRE(ctab && ptab && calib && pt_idx && cam_ptr && pt_ptr && pt_obs && slot_cp && dreg &&
                      u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
                  "null pointer");
     IAMX_REQUIRE(n_obs >= 0 && n_cams > 0 && n_pts > 0 && phase >= 0 && phase <= 2 &&
                      (parity == 0 || parity == 1),
                  "bad size / phase / parity");
     const PartLayout L = part_layout(n_cams, n_pts);
-    LsmrArgs A{Jc_s, Jp_s, Jp_p, cam_idx, pt_idx, cam_ptr, pt_ptr, pt_obs, n_obs, n_cams, n_pts,
+    LsmrArgs A{ctab, ptab, calib, pt_idx, cam_ptr, pt_ptr, pt_obs,
+               reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
                partials, partials + L.off_V, partials + L.off_X, LS_UPD_BLOCKS, partials + L.off_U2,
                xr, tbuf, 1};
     hipStream_t st = iamx::as_stream(stream);
     if (phase == 0) {
         hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
-        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A, parity);
     } else if (phase == 1) {
         hipLaunchKernelGGL(lsmr_adj_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, A, parity);
     } else {

@@ -337,40 +337,42 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
                 int n_pts, const double *u, int square, double *out, double *scratch,
                 void *stream);
 
-/* Host-free LSMR (scipy/sparse/linalg/_isolve/lsmr.py) on A = [J diag(d); diag(dreg)],
- * b = [r; 0], no calibration columns.
- * iamx_ba_lsmr_prepare: once per solve, folds d into J and writes the coalesced forms
- *   Jc_s [14][n_obs], Jp_s [6][n_obs] (observation order), Jp_p [6][n_obs] (point-sorted).
- * iamx_ba_lsmr_iterate: enqueues n_iter (even) iterations, three launches each, no host
+/* Host-free, matrix-free LSMR (scipy/sparse/linalg/_isolve/lsmr.py) on
+ * A = [J diag(d); diag(dreg)], b = [r; 0], no calibration columns.  J is the analytic Jacobian
+ * of iamx_ba_residual_jac at (cams, pts, calib); the kernels re-derive an observation's 2x10
+ * block from its camera and point instead of reading a stored copy.
+ * iamx_ba_lsmr_prepare: once per solve, the tables
+ *   ctab DEV [n_cams][32] (rotation, position, quaternion, 1/|q|^2, d of the 7 columns),
+ *   ptab DEV [n_pts][6]  (X, d of the 3 columns).
+ * iamx_ba_lsmr_iterate: enqueues n_iter (even) iterations, four launches each, no host
  *   synchronisation.  `state` (DEV, iamx_ba_lsmr_state_size() doubles) holds the double-
  *   buffered scalar recurrences, the tolerances and the latched results (layout and
  *   initialisation: imageanalysis_amd/ba_solver.py); once istop is latched the remaining
  *   iterations are no-ops.  u1 [2 n_obs], u2/vt/h/hbar/x [n] DEV work vectors; partials DEV
- *   [iamx_ba_lsmr_partials_size]; xr DEV [1], tbuf DEV [n] scratch (|ut1|^2, raw J^T ut1).
- *   Deterministic (fixed reduction trees, no atomics).  Every camera block of J is read once
- *   per iteration (forward product and camera part of the adjoint in one kernel). */
+ *   [iamx_ba_lsmr_partials_size]; xr DEV [2] (|ut1|^2, |ut2|^2), tbuf DEV [n] (raw J^T ut1).
+ *   pt_idx [n_obs] camera-major; cam_ptr / pt_ptr / pt_obs as for iamx_ba_jtv; slot_cp DEV
+ *   [n_obs][2] int32 = (camera, point) of the observation in point-sorted slot e = pt_obs[e].
+ *   Deterministic (fixed reduction trees, no atomics). */
 int iamx_ba_lsmr_state_size(void);
 int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts);
-int iamx_ba_lsmr_prepare(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                         const int32_t *pt_idx, const int32_t *pt_obs, int64_t n_obs, int n_cams,
-                         int n_pts, const double *d, double *Jc_s, double *Jp_s, double *Jp_p,
-                         void *stream);
-int iamx_ba_lsmr_iterate(const double *Jc_s, const double *Jp_s, const double *Jp_p,
-                         const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
-                         const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+int iamx_ba_lsmr_prepare(const double *cams, const double *pts, const double *d, int n_cams,
+                         int n_pts, double *ctab, double *ptab, void *stream);
+int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, const double *calib,
+                         const int32_t *pt_idx, const int32_t *cam_ptr, const int32_t *pt_ptr,
+                         const int32_t *pt_obs, const int32_t *slot_cp, int64_t n_obs, int n_cams,
                          int n_pts, const double *dreg, double *u1, double *u2, double *vt,
                          double *h, double *hbar, double *x, double *state, double *partials,
                          double *xr, double *tbuf, int n_iter, void *stream);
 
 /* Multi-rank form of the same iteration (observations sharded by point, n-vectors replicated):
- * one call per phase; the caller all-reduces (sum) xr[0] after phase 0 and tbuf[0..n) after
+ * one call per phase; the caller all-reduces (sum) xr[0] (not xr[1]) after phase 0 and tbuf[0..n) after
  * phase 1 on the same stream (RCCL).  phase 0: stopping tests of the previous iteration, ut',
  * camera part of tbuf, xr[0] = local |ut1'|^2;  phase 1: point part of tbuf = local J^T ut1';
  * phase 2: vt' from the reduced tbuf,
- * alpha', plane rotations, h / hbar / x.  parity = iteration & 1.  xr DEV [1], tbuf DEV [n]. */
-int iamx_ba_lsmr_phase(const double *Jc_s, const double *Jp_s, const double *Jp_p,
-                       const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
-                       const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+ * alpha', plane rotations, h / hbar / x.  parity = iteration & 1.  xr DEV [2] (only xr[0] is reduced), tbuf DEV [n]. */
+int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *calib,
+                       const int32_t *pt_idx, const int32_t *cam_ptr, const int32_t *pt_ptr,
+                       const int32_t *pt_obs, const int32_t *slot_cp, int64_t n_obs, int n_cams,
                        int n_pts, const double *dreg, double *u1, double *u2, double *vt, double *h,
                        double *hbar, double *x, double *state, double *partials, double *xr,
                        double *tbuf, int phase, int parity, void *stream);
