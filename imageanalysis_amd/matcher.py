@@ -559,16 +559,18 @@ def _finish_lines(launched):
     surface statistics when the launch asked for them, else None."""
     lines, raw, handle = launched
     results = _finish_batch(handle)
-    out = []
+    out, records = [], []
     for (dist, i, j, i1, i2), (raw1, raw2), res in zip(lines, raw, results):
         match_fwd, match_rev, n_fwd, n_rev = res[:4]
-        # the reference's seven qlog() lines per pair (matcher.py:311-343) as one record:
-        # at millions of pairs the per-line bookkeeping costs more than the GPU work
-        _qlog("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
-              "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
-              "  cross checked matches: %d"
-              % (i1.name, i2.name, dist, raw1, n_fwd, raw2, n_rev, len(match_fwd)))
+        # the reference's seven qlog() lines per pair (matcher.py:311-343), one log record per
+        # batch: at millions of pairs the per-line bookkeeping costs more than the GPU work
+        records.append("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
+                       "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
+                       "  cross checked matches: %d"
+                       % (i1.name, i2.name, dist, raw1, n_fwd, raw2, n_rev, len(match_fwd)))
         out.append((i, j, match_fwd, match_rev, res[4] if len(res) > 4 else None))
+    if records:
+        _qlog("\n".join(records))
     return out
 
 
