@@ -433,6 +433,15 @@ __device__ __forceinline__ double beta_new(const LsmrArgs &A, double *sh)
     return sqrt(A.xr[0] + A.xr[1]);
 }
 
+// a wave-uniform double that the compiler computed with vector instructions: move it to scalar
+// registers (two v_readfirstlane) so that it stops occupying a VGPR pair in every lane
+__device__ __forceinline__ double uniform(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
 // d(u,v)/d(body point) of one observation from its camera table row and point -- the
 // arithmetic of ba_residual_jac_kernel (ba_kernels.hip) up to `du`, `dv`
 struct ObsGeom { double du[3], dv[3], dX[3], yb[3]; };
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
     double *S = A.S;
     if (S[R_ISTOP] != 0.0) return;
     const double *in = S + parity * S_NBUF;
-    const double ia = 1.0 / in[S_ALPHA], ab = in[S_ALPHA] / in[S_BETA];
+    const double ia = uniform(1.0 / in[S_ALPHA]), ab = uniform(in[S_ALPHA] / in[S_BETA]);
     if ((int)blockIdx.x >= A.n_cams) {       // the replicated n-vector part of ut'
         const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
         double acc2 = 0.0;
@@ -534,21 +543,23 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
 #pragma unroll
     for (int i = 0; i < 9; ++i) cal[i] = A.calib[i];
     const double qw = ct[CT_Q], qx = ct[CT_Q + 1], qy = ct[CT_Q + 2], qz = ct[CT_Q + 3];
-    const double inv_n2 = 2.0 * ct[CT_INVN];
+    const double inv_n2 = uniform(2.0 * ct[CT_INVN]);
     // rows of the bilinear forms s, t, p, d of (q, dX) (ba_residual_jac_kernel)
     const double Sr[3] = {qw, qz, -qy}, Tr[3] = {-qz, qw, qx}, Pr[3] = {qy, -qx, qw}, Dr[3] = {qx, qy, qz};
-    const double wn0 = ct[CT_D] * vc[0], wn1 = ct[CT_D + 1] * vc[1], wn2 = ct[CT_D + 2] * vc[2];
+    const double wn0 = uniform(ct[CT_D] * vc[0]), wn1 = uniform(ct[CT_D + 1] * vc[1]);
+    const double wn2 = uniform(ct[CT_D + 2] * vc[2]);
     const double wq0 = ct[CT_D + 3] * vc[3], wq1 = ct[CT_D + 4] * vc[4];
     const double wq2 = ct[CT_D + 5] * vc[5], wq3 = ct[CT_D + 6] * vc[6];
-    // sum_k wq[k] e_k = inv_n2 * (N dX - qs yb)
+    // sum_k wq[k] e_k = inv_n2 * (N dX - qs yb); N, qs are the same in every lane: keep them
+    // in scalar registers (142 -> fewer VGPRs = one more wave per SIMD)
     double N[3][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        N[0][j] = wq0 * Sr[j] + wq1 * Dr[j] - wq2 * Pr[j] + wq3 * Tr[j];
-        N[1][j] = wq0 * Tr[j] + wq1 * Pr[j] + wq2 * Dr[j] - wq3 * Sr[j];
-        N[2][j] = wq0 * Pr[j] - wq1 * Tr[j] + wq2 * Sr[j] + wq3 * Dr[j];
+        N[0][j] = uniform(wq0 * Sr[j] + wq1 * Dr[j] - wq2 * Pr[j] + wq3 * Tr[j]);
+        N[1][j] = uniform(wq0 * Tr[j] + wq1 * Pr[j] + wq2 * Dr[j] - wq3 * Sr[j]);
+        N[2][j] = uniform(wq0 * Pr[j] - wq1 * Tr[j] + wq2 * Sr[j] + wq3 * Dr[j]);
     }
-    const double qs = wq0 * qw + wq1 * qx + wq2 * qy + wq3 * qz;
+    const double qs = uniform(wq0 * qw + wq1 * qx + wq2 * qy + wq3 * qz);
     double acc = 0.0;
     double sw[3] = {0, 0, 0};
     double Mo[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
