@@ -398,9 +398,31 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     dm = the_matcher
     slots = [(dm.slot_of(a), dm.slot_of(b)) for a, b in batch]
     store = dm.store()
+    d_proj = d_ik = None
+    if surface and device_filters:
+        # pageable uploads wait for everything already enqueued: do them BEFORE this batch's
+        # kernels go in, or the host would sit here until they have run
+        from . import smart as _smart
+        PROJ = np.zeros((len(dm._counts), 12))
+        done = set()
+        for (a, b), (sa, sb) in zip(batch, slots):
+            for im, s in ((a, sa), (b, sb)):
+                if s not in done:
+                    done.add(s)
+                    pose = im.get_camera_pose()
+                    hit = dm._proj.get(s)
+                    if hit is None or hit[0] != pose:
+                        hit = dm._proj[s] = (pose, _smart.projection_matrix(im).ravel())
+                    PROJ[s] = hit[1]
+        IK = np.linalg.inv(np.asarray(_deps.camera().get_K(), float))
+        dev0 = kernels.require_gpu()
+        d_proj = torch.from_numpy(PROJ).to(dev0)
+        d_ik = torch.from_numpy(np.ascontiguousarray(IK.ravel())).to(dev0)
     ordered = np.array([[sa, sb] for sa, sb in slots] + [[sb, sa] for sa, sb in slots], np.int32)
     pb = kernels.PairBatch(store, ordered)
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    if device_filters:
+        kp_off, xy, key2 = dm.keypoints()        # (may upload: before the kernels, like PROJ)
     thresh = max_distance * match_ratio
     pb.run(ws, thresh)
     n = len(batch)
@@ -408,7 +430,6 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     clip = 0
     if device_filters:
         cam_w, cam_h = _camera_size()
-        kp_off, xy, key2 = dm.keypoints()
         L = lib()
         clip = int(L.iamx_match_postfilter_clip())
         dev = xy.device
@@ -424,21 +445,6 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                                       _ptr(post['pairs']), _ptr(post['scratch']), _ptr(post['stat']),
                                       _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
         if surface:
-            from . import smart as _smart
-            PROJ = np.zeros((len(dm._counts), 12))
-            done = set()
-            for (a, b), (sa, sb) in zip(batch, slots):
-                for im, s in ((a, sa), (b, sb)):
-                    if s not in done:
-                        done.add(s)
-                        pose = im.get_camera_pose()
-                        hit = dm._proj.get(s)
-                        if hit is None or hit[0] != pose:
-                            hit = dm._proj[s] = (pose, _smart.projection_matrix(im).ravel())
-                        PROJ[s] = hit[1]
-            IK = np.linalg.inv(np.asarray(_deps.camera().get_K(), float))
-            d_proj = torch.from_numpy(PROJ).to(dev)
-            d_ik = torch.from_numpy(np.ascontiguousarray(IK.ravel())).to(dev)
             post['tri_cnt'] = torch.where(post['status'] == 0, post['cnt'],
                                           torch.zeros_like(post['cnt']))
             post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
