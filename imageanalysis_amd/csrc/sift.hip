@@ -381,8 +381,9 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
         if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
         const double dx = (double)g[(int64_t)y * w + x + 1] - (double)g[(int64_t)y * w + x - 1];
         const double dy = (double)g[(int64_t)(y - 1) * w + x] - (double)g[(int64_t)(y + 1) * w + x];
-        const double wgt = exp((double)(i * i + j * j) * expf_scale);
-        double ori = atan2(dy, dx) * (180.0 / 3.141592653589793);
+        // float32 transcendentals like OpenCV's calcOrientationHist (see descriptor_kernel)
+        const double wgt = (double)expf((float)((double)(i * i + j * j) * expf_scale));
+        double ori = (double)atan2f((float)dy, (float)dx) * (180.0 / 3.141592653589793);
         if (ori < 0) ori += 360.0;
         if (ori >= 360.0) ori -= 360.0;
         const double mag = sqrt(dx * dx + dy * dy);
@@ -442,6 +443,9 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     constexpr int HB = (d + 2) * (d + 2) * (n + 2);       // 360
     __shared__ double hist_s[4][HB];
     __shared__ double red_s[4][2];
+    constexpr int DESC_ROWS = 160;                        // window rows handled by the interval walk
+    __shared__ int rowlo_s[4][DESC_ROWS];
+    __shared__ int rowpre_s[4][DESC_ROWS + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int total = *n_kp < cap_k ? *n_kp : cap_k;
     double *hist = hist_s[wave];
@@ -478,19 +482,18 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         // radius <= diag of the octave image (< 2^14 for any image that fits the workspace),
         // so the window index fits 32 bits: no 64-bit division in the sample loop
         const int side = 2 * radius + 1;
-        const int nsamp = side * side;
-        for (int s = lane; s < nsamp; s += 64) {
-            const int i0 = s / side;
-            const int i = i0 - radius, j = s - i0 * side - radius;
+        auto sample = [&](int i, int j) {
             const double c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             const double rbin = r_rot + d / 2 - 0.5, cbin = c_rot + d / 2 - 0.5;
             const int r = py + i, c = px + j;
             if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1))
-                continue;
+                return;
             const double dx = (double)img[(int64_t)r * w + c + 1] - (double)img[(int64_t)r * w + c - 1];
             const double dy = (double)img[(int64_t)(r - 1) * w + c] - (double)img[(int64_t)(r + 1) * w + c];
-            const double wgt = exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            double og = atan2(dy, dx) * (180.0 / 3.141592653589793);
+            // the two transcendentals in float32 (what OpenCV's calcSIFTDescriptor computes in --
+            // its fastAtan2 is only good to 0.3 deg); the interpolation and sums stay float64
+            const double wgt = (double)expf((float)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
+            double og = (double)atan2f((float)dy, (float)dx) * (180.0 / 3.141592653589793);
             if (og < 0) og += 360.0;
             if (og >= 360.0) og -= 360.0;
             const double mag = sqrt(dx * dx + dy * dy) * wgt;
@@ -512,6 +515,64 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
                 const double v1 = vv[q4] * fo;
                 atomicAdd(&hist[base], vv[q4] - v1);
                 atomicAdd(&hist[base + 1], v1);
+            }
+        };
+        if (side <= DESC_ROWS) {
+            // The samples that pass the test above fill a ROTATED square, half of the upright
+            // window at best.  Per window row: a conservative column interval (one column of
+            // slack on each side; the exact test still runs per sample), then the lanes walk the
+            // concatenated intervals instead of the whole window.
+            int *rowlo = rowlo_s[wave], *rowpre = rowpre_s[wave];
+            int carry = 0;
+            for (int base = 0; base < side; base += 64) {
+                const int row = base + lane;
+                int jl = 0, cnt = 0;
+                if (row < side) {
+                    const int i = row - radius, r = py + i;
+                    if (r > 0 && r < h - 1) {
+                        double lo = fmax((double)-radius, (double)(1 - px));
+                        double hi = fmin((double)radius, (double)(w - 2 - px));
+                        // -1 < j*a + b < d  for (a, b) = (sin_t, i*cos_t + 1.5) and (cos_t, -i*sin_t + 1.5)
+                        const double aa[2] = {sin_t, cos_t};
+                        const double bb[2] = {i * cos_t + d / 2 - 0.5, -i * sin_t + d / 2 - 0.5};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (fabs(aa[e]) < 1e-9) continue;          // no usable bound: keep all
+                            double x1 = (-1.0 - bb[e]) / aa[e], x2 = ((double)d - bb[e]) / aa[e];
+                            if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; }
+                            lo = fmax(lo, floor(x1));
+                            hi = fmin(hi, ceil(x2));
+                        }
+                        if (hi >= lo) { jl = (int)lo; cnt = (int)hi - jl + 1; }
+                    }
+                }
+                int x = cnt;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    const int y = __shfl_up(x, sft);
+                    if (lane >= sft) x += y;
+                }
+                if (row < side) { rowlo[row] = jl; rowpre[row] = carry + x - cnt; }
+                carry += __shfl(x, 63);
+            }
+            if (lane == 0) rowpre[side] = carry;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            // blocked, not cyclic: lane L walks samples [L*chunk, (L+1)*chunk), so at any moment
+            // the 64 lanes sit in different parts of the window and their LDS atomics mostly hit
+            // different histogram cells (neighbouring samples share a cell: 8-way conflicts)
+            const int chunk = (carry + 63) >> 6;
+            const int s0 = lane * chunk, s1 = min(s0 + chunk, carry);
+            int row = 0;
+            for (int s = s0; s < s1; ++s) {
+                while (s >= rowpre[row + 1]) ++row;
+                sample(row - radius, rowlo[row] + (s - rowpre[row]));
+            }
+        } else {
+            const int nsamp = side * side;
+            for (int s = lane; s < nsamp; s += 64) {
+                const int i0 = s / side;
+                sample(i0 - radius, s - i0 * side - radius);
             }
         }
     }
