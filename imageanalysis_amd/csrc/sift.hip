@@ -191,36 +191,71 @@ struct DogStack {
     const float *d[NL + 2];
 };
 
+// One wave per row segment of 62 pixels (+1 halo column each side): every lane loads its own
+// column of the five DoG images on three rows (15 coalesced loads serve all NL layer tests; the
+// per-pixel form issued 27 loads per layer), takes the max / min of its 9 values per layer
+// triple, and gets the neighbouring columns' with two lane shifts.  val >= (<=) every one of
+// the 26 neighbours  <=>  val >= (<=) the max (min) over the 3x3x3 block, which contains val.
+constexpr int EXT_RPT = 4;        // row groups (of 4 rows) per workgroup
+constexpr int EXT_LIST = 512;     // candidates a workgroup collects before its one global atomic
+
 __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, int o,
                                                       float threshold, Cand *__restrict__ cand,
                                                       int cap, int *__restrict__ count)
 {
-    const int iw = w - 2 * BORDER, ih = h - 2 * BORDER;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)iw * ih) return;
-    const int c = (int)(i % iw) + BORDER, r = (int)(i / iw) + BORDER;
-    const int64_t p = (int64_t)r * w + c;
+    // Candidates are ~1 % of the pixels; one global atomicAdd each on the single counter was the
+    // whole cost of this kernel (~150 k same-address device-scope atomics per image = 0.75 ms).
+    // A workgroup collects its candidates in LDS and reserves their slots with ONE atomic.
+    __shared__ Cand s_list[EXT_LIST];
+    __shared__ int s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = BORDER + blockIdx.x * 62 - 1 + lane;
+    const int cl = c < w - 1 ? c : w - 1;              // clamped: only feeds masked-out lanes
+    const bool out = lane >= 1 && lane <= 62 && c < w - BORDER;
+    for (int rr = 0; rr < EXT_RPT; ++rr) {
+        const int r = BORDER + (blockIdx.y * EXT_RPT + rr) * 4 + wave;
+        if (r >= h - BORDER) continue;                 // (whole wave)
+        float v[NL + 2][3];
 #pragma unroll
-    for (int layer = 1; layer <= NL; ++layer) {
-        const float *prv = D.d[layer - 1], *cur = D.d[layer], *nxt = D.d[layer + 1];
-        const float val = cur[p];
-        if (!(fabsf(val) > threshold)) continue;
-        bool is_max = val > 0.f, is_min = val < 0.f;
-        if (!is_max && !is_min) continue;
+        for (int L = 0; L < NL + 2; ++L) {
 #pragma unroll
-        for (int dr = -1; dr <= 1; ++dr) {
+            for (int dr = 0; dr < 3; ++dr) v[L][dr] = D.d[L][(int64_t)(r - 1 + dr) * w + cl];
+        }
+        float cmax[NL + 2], cmin[NL + 2];
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                const int64_t q = p + (int64_t)dr * w + dc;
-                const float a = prv[q], b = nxt[q], m = cur[q];
-                is_max = is_max && val >= a && val >= b && val >= m;
-                is_min = is_min && val <= a && val <= b && val <= m;
+        for (int L = 0; L < NL + 2; ++L) {
+            cmax[L] = fmaxf(fmaxf(v[L][0], v[L][1]), v[L][2]);
+            cmin[L] = fminf(fminf(v[L][0], v[L][1]), v[L][2]);
+        }
+#pragma unroll
+        for (int layer = 1; layer <= NL; ++layer) {
+            const float val = v[layer][1];
+            float mx = fmaxf(fmaxf(cmax[layer - 1], cmax[layer]), cmax[layer + 1]);
+            float mn = fminf(fminf(cmin[layer - 1], cmin[layer]), cmin[layer + 1]);
+            mx = fmaxf(mx, fmaxf(__shfl_up(mx, 1), __shfl_down(mx, 1)));
+            mn = fminf(mn, fminf(__shfl_up(mn, 1), __shfl_down(mn, 1)));
+            if (!out || !(fabsf(val) > threshold)) continue;
+            const bool is_max = val > 0.f && val >= mx, is_min = val < 0.f && val <= mn;
+            if (is_max || is_min) {
+                const int k = atomicAdd(&s_n, 1);
+                if (k < EXT_LIST) {
+                    s_list[k] = Cand{o, layer, r, c};
+                } else {                               // (a block this dense: straight to global)
+                    const int g = atomicAdd(count, 1);
+                    if (g < cap) cand[g] = Cand{o, layer, r, c};
+                }
             }
         }
-        if (is_max || is_min) {
-            const int k = atomicAdd(count, 1);
-            if (k < cap) cand[k] = Cand{o, layer, r, c};
-        }
+    }
+    __syncthreads();
+    const int n = s_n < EXT_LIST ? s_n : EXT_LIST;
+    if (threadIdx.x == 0 && n > 0) s_base = atomicAdd(count, n);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int g = s_base + k;
+        if (g < cap) cand[g] = s_list[k];
     }
 }
 
@@ -273,16 +308,10 @@ struct Refined {
 };
 
 // one thread per candidate: 3-D quadratic fit (<= 5 steps), contrast and edge tests
-__global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__restrict__ cand,
-                                                     const int *__restrict__ n_cand, int cap_c,
-                                                     float contrast_threshold, float edge_threshold,
-                                                     Refined *__restrict__ refined,
-                                                     int *__restrict__ n_refined)
+__device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
+                                           float contrast_threshold, float edge_threshold,
+                                           Refined &R)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int total = *n_cand < cap_c ? *n_cand : cap_c;
-    if (idx >= total) return;
-    const Cand cd = cand[idx];
     const Pyr &P = T.oct[cd.o];
     const int h = P.h, w = P.w;
     int layer = cd.layer, r = cd.r, c = cd.c;
@@ -305,18 +334,18 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__r
         const float dys = __fmul_rn(__fadd_rn(__fsub_rn(__fsub_rn(at(nxt, r + 1, c), at(nxt, r - 1, c)), at(prv, r + 1, c)), at(prv, r - 1, c)), cross_scale);
         double A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
         double b[3] = {dDx, dDy, dDs}, X[3];
-        if (!solve3(A, b, X)) return;
+        if (!solve3(A, b, X)) return false;
         xc = -X[0]; xr = -X[1]; xi = -X[2];
         if (fabs(xi) < 0.5 && fabs(xr) < 0.5 && fabs(xc) < 0.5) break;
         if (fabs(xi) > 2147483647.0 / 3 || fabs(xr) > 2147483647.0 / 3 || fabs(xc) > 2147483647.0 / 3)
-            return;
+            return false;
         c += round_half_even(xc);
         r += round_half_even(xr);
         layer += round_half_even(xi);
         if (layer < 1 || layer > NL || c < BORDER || c >= w - BORDER || r < BORDER || r >= h - BORDER)
-            return;
+            return false;
     }
-    if (it >= MAX_STEPS) return;
+    if (it >= MAX_STEPS) return false;
     double contr;
     {
         const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
@@ -326,7 +355,7 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__r
         const double dDs = (double)__fmul_rn(__fsub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
         const double t = dDx * xc + dDy * xr + dDs * xi;
         contr = (double)at(img, r, c) * (double)img_scale + t * 0.5;
-        if (fabs(contr) * NL < (double)contrast_threshold) return;
+        if (fabs(contr) * NL < (double)contrast_threshold) return false;
         const double v2 = (double)at(img, r, c) * 2.0;
         const double dxx = ((double)at(img, r, c + 1) + (double)at(img, r, c - 1) - v2) * (double)second_scale;
         const double dyy = ((double)at(img, r + 1, c) + (double)at(img, r - 1, c) - v2) * (double)second_scale;
@@ -334,15 +363,58 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__r
                             - (double)at(img, r - 1, c + 1) + (double)at(img, r - 1, c - 1)) * (double)cross_scale;
         const double tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
         const double e = edge_threshold;
-        if (det <= 0 || tr * tr * e >= (e + 1) * (e + 1) * det) return;
+        if (det <= 0 || tr * tr * e >= (e + 1) * (e + 1) * det) return false;
     }
-    const int k = atomicAdd(n_refined, 1);
-    if (k < cap_c) {
-        Refined R;
-        R.o = cd.o; R.layer = layer; R.r = r; R.c = c;
-        R.xi = xi; R.xr = xr; R.xc = xc; R.contr = contr;
-        refined[k] = R;
+    R.o = cd.o; R.layer = layer; R.r = r; R.c = c;
+    R.xi = xi; R.xr = xr; R.xc = xc; R.contr = contr;
+    return true;
+}
+
+// one thread per candidate; the survivors of a wave reserve their output slots with one
+// atomicAdd (a per-thread atomic on the single counter serialises ~10^5 device-scope atomics)
+__global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__restrict__ cand,
+                                                     const int *__restrict__ n_cand, int cap_c,
+                                                     float contrast_threshold, float edge_threshold,
+                                                     Refined *__restrict__ refined,
+                                                     int *__restrict__ n_refined)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = *n_cand < cap_c ? *n_cand : cap_c;
+    Refined R;
+    const bool ok = idx < total && refine_one(T, cand[idx < total ? idx : 0], contrast_threshold,
+                                              edge_threshold, R);
+    const unsigned long long m = __ballot(ok);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(n_refined, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (ok) {
+        const int k = base + __popcll(m & ((1ull << lane) - 1));
+        if (k < cap_c) refined[k] = R;
     }
+}
+
+
+
+constexpr int ORI_BUF = 72;       // keypoints a wave collects before it touches the global counter
+
+// wave-wide: copy `n` buffered keypoints (8 floats each) behind one atomicAdd
+__device__ __forceinline__ void flush_keypoints(const float *__restrict__ kbuf, int n,
+                                                float *__restrict__ kp, int cap_k,
+                                                int *__restrict__ n_kp, int lane)
+{
+    if (n == 0) return;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // the LDS writes of the list have landed
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_kp, n);
+    base = __shfl(base, 0);
+    for (int e = lane; e < n * 8; e += 64) {
+        const int k = base + (e >> 3);
+        if (k < cap_k) kp[(int64_t)k * 8 + (e & 7)] = kbuf[e];
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // one wave per refined candidate: 36-bin gradient orientation histogram over the
@@ -354,8 +426,11 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 {
     __shared__ double hist_s[4][ORI_BINS];
     __shared__ double sm_s[4][ORI_BINS];
+    __shared__ float kbuf_s[4][ORI_BUF * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int total = *n_refined < cap_c ? *n_refined : cap_c;
+    float *kbuf = kbuf_s[wave];
+    int n_buf = 0;
     // persistent waves (wave-uniform control flow; no block-level barriers below)
     for (int idx = blockIdx.x * 4 + wave; idx < total; idx += gridDim.x * 4) {
     const Refined R = refined[idx];
@@ -406,32 +481,44 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) omax = fmax(omax, __shfl_xor(omax, m));
     const double mag_thr = omax * 0.8;
+    bool peak = false;
+    double angle = 0.0;
     if (lane < ORI_BINS) {
         const int j = lane;
         const double lft = sm[(j + ORI_BINS - 1) % ORI_BINS], rgt = sm[(j + 1) % ORI_BINS];
         if (sm[j] > lft && sm[j] > rgt && sm[j] >= mag_thr) {
             double bin = j + 0.5 * (lft - rgt) / (lft - 2 * sm[j] + rgt);
             bin = bin < 0 ? ORI_BINS + bin : (bin >= ORI_BINS ? bin - ORI_BINS : bin);
-            double angle = 360.0 - (360.0 / ORI_BINS) * bin;
+            angle = 360.0 - (360.0 / ORI_BINS) * bin;
             if (fabs(angle - 360.0) < 1.1920929e-07) angle = 0.0;
-            const int k = atomicAdd(n_kp, 1);
-            if (k < cap_k) {
-                float *q = kp + (int64_t)k * 8;
-                // first octave is -1: report in input-image pixels (detectAndCompute)
-                q[0] = (float)(px * 0.5);
-                q[1] = (float)(py * 0.5);
-                q[2] = (float)(size * 0.5);
-                q[3] = (float)angle;
-                q[4] = (float)fabs(contr);
-                const int oct_out = (octave & ~255) | ((octave - 1) & 255);
-                q[5] = __int_as_float(oct_out);
-                q[6] = __int_as_float(o * 256 + layer);        // pyramid address for the descriptor
-                q[7] = 0.f;
-            }
+            peak = true;
         }
     }
+    // keypoints go to a per-wave LDS list first; the wave reserves output slots with one
+    // atomicAdd when the list fills up or the wave is done (not one atomic per keypoint)
+    const unsigned long long pm = __ballot(peak);
+    const int npk = __popcll(pm);
+    if (n_buf + npk > ORI_BUF) {
+        flush_keypoints(kbuf, n_buf, kp, cap_k, n_kp, lane);
+        n_buf = 0;
+    }
+    if (peak) {
+        float *q = kbuf + (n_buf + __popcll(pm & ((1ull << lane) - 1))) * 8;
+        // first octave is -1: report in input-image pixels (detectAndCompute)
+        q[0] = (float)(px * 0.5);
+        q[1] = (float)(py * 0.5);
+        q[2] = (float)(size * 0.5);
+        q[3] = (float)angle;
+        q[4] = (float)fabs(contr);
+        const int oct_out = (octave & ~255) | ((octave - 1) & 255);
+        q[5] = __int_as_float(oct_out);
+        q[6] = __int_as_float(o * 256 + layer);        // pyramid address for the descriptor
+        q[7] = 0.f;
+    }
+    n_buf += npk;
     __builtin_amdgcn_wave_barrier();
     }
+    flush_keypoints(kbuf, n_buf, kp, cap_k, n_kp, lane);
 }
 
 // one wave per keypoint
@@ -742,8 +829,11 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
             const int64_t inner = (int64_t)(H - 2 * BORDER) * (W - 2 * BORDER);
             DogStack D;
             for (int i = 0; i < NL + 2; ++i) D.d[i] = T.oct[o].d[i];
-            hipLaunchKernelGGL(extrema_kernel, dim3(blocks(inner, 256)), dim3(256), 0, st, D, H, W, o,
-                               threshold, cand, CAP_CAND, n_cand);
+            (void)inner;
+            hipLaunchKernelGGL(extrema_kernel,
+                               dim3((unsigned)((W - 2 * BORDER + 61) / 62),
+                                    (unsigned)((H - 2 * BORDER + 4 * EXT_RPT - 1) / (4 * EXT_RPT))),
+                               dim3(256), 0, st, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
         }
     }
     // the number of candidates is only known on the device: launch for the capacity in slabs
