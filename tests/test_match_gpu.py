@@ -351,3 +351,49 @@ def test_fast_path_ragged_ties_and_tiny_classes():
         keep = rd2[:, 1] > 0                         # d1 == 0 -> NaN metric, never kept
         assert np.array_equal(a['sq'][lo:hi], np.nonzero(keep)[0]), (i, j)
         assert np.array_equal(a['st'][lo:hi], ridx[keep, 0]), (i, j)
+
+
+def test_overlapped_sweeps_equal_sequential_runs():
+    """kernels.OverlappedSweeps (filter kernels of launch k on a second stream beside the sweep
+    of launch k+1, two workspaces) leaves exactly what the one-stream sequence leaves"""
+    import torch
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(5)
+    sizes = [700, 513, 1024, 300, 900, 640]
+    imgs = [_sift_like(rng, n) for n in sizes]
+    for k in range(1, len(imgs)):                    # overlapping neighbours: real survivors
+        m = min(len(imgs[k]), len(imgs[k - 1])) // 3
+        imgs[k][:m] = np.clip(imgs[k - 1][:m].astype(int) + rng.integers(-4, 5, (m, 128)), 0, 255)
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = np.array([(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j], np.int32)
+    batches = [kernels.PairBatch(store, pairs[s:s + 6]) for s in range(0, len(pairs), 6)]   # 5 launches
+    rows, npairs = max(b.rows for b in batches), max(b.n_pairs for b in batches)
+    thresh = 270.0 * 0.75
+
+    def snapshot(b, w):
+        n = int(w.surv_off[b.n_pairs].item())
+        return (w.surv_cnt[:b.n_pairs].clone(), w.surv_off[:b.n_pairs + 1].clone(),
+                w.surv_q[:n].clone(), w.surv_t[:n].clone(), w.surv_metric[:n].clone())
+
+    ws = kernels.PairWorkspace(rows, npairs)
+    want = []
+    for b in batches:
+        b.run_knn2_fast(ws)
+        b.run_filter_fast(ws, thresh)
+        torch.cuda.synchronize()
+        want.append(snapshot(b, ws))
+    got = []
+    runner = kernels.OverlappedSweeps(rows, npairs)
+    # snapshots are taken on the side stream right behind each launch's filter kernels
+    lazy = []
+    runner.run(batches, thresh, after_filter=lambda b, w: lazy.append(
+        (w.surv_cnt[:b.n_pairs].clone(), w.surv_off[:b.n_pairs + 1].clone(), w.surv_q.clone(),
+         w.surv_t.clone(), w.surv_metric.clone())))
+    torch.cuda.synchronize()
+    assert len(lazy) == len(batches)
+    for (cnt, off, q, t, m), (wc, wo, wq, wt, wm) in zip(lazy, want):
+        n = int(off[-1].item())
+        assert n == len(wq) > 0
+        assert torch.equal(cnt, wc) and torch.equal(off, wo)
+        assert torch.equal(q[:n], wq) and torch.equal(t[:n], wt) and torch.equal(m[:n], wm)
+    assert sum(int(w.unresolved.item()) for w in runner.ws) == 0
