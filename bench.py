@@ -251,17 +251,27 @@ def main():
     # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
     ba = None
     cpu_sample = raw[:2].cpu().numpy() if (rank == 0 and mine >= 2) else None
-    if not args.no_ba:
-        del batches, ws, raw, store
-        if overlap:
-            del ws_pair, runner
-        torch.cuda.empty_cache()
-        ba = ba_bench(rank, world, dev, dist, args)
-
-    sift = None
-    if not args.no_sift:
-        sift = sift_bench(rank, world, dev, dist, args)
-    cleanup = cleanup_bench(args) if rank == 0 else None
+    # The GPU sections below run with the BLAS thread pool limited to one thread: after a
+    # multi-threaded numpy call ~100 OpenBLAS workers keep spinning for a while and the device
+    # queue of whatever is timed next stalls for tens of milliseconds (profiles/r1_ba_notes.txt;
+    # seen here as 13 instead of 4 ms per SIFT frame right after the BA section's numpy setup).
+    try:
+        from threadpoolctl import threadpool_limits
+        quiet_blas = threadpool_limits(limits=1, user_api='blas')
+    except ImportError:                                   # pragma: no cover
+        import contextlib
+        quiet_blas = contextlib.nullcontext()
+    sift = cleanup = None
+    with quiet_blas:
+        if not args.no_ba:
+            del batches, ws, raw, store
+            if overlap:
+                del ws_pair, runner
+            torch.cuda.empty_cache()
+            ba = ba_bench(rank, world, dev, dist, args)
+        if not args.no_sift:
+            sift = sift_bench(rank, world, dev, dist, args)
+        cleanup = cleanup_bench(args) if rank == 0 else None
     # CPU baselines of the BA and SIFT sections run AFTER every timed GPU section: their OpenMP /
     # OpenBLAS worker threads keep spinning for a while after a parallel region and a GPU
     # section timed right behind them loses 4x (measured: 3.9 -> 20.9 ms per SIFT frame)
