@@ -343,9 +343,10 @@ extern "C" int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *
 //   workgroup re-derives the scalars it needs in its prologue from the partial sums of the
 //   previous kernel (same instruction sequence => bit-identical in all workgroups); workgroup 0
 //   writes the next state buffer, which nobody reads in the same kernel.  An iteration is
-//   four launches and no host synchronisation; the stopping tests of iteration k run in the
-//   prologue of iteration k+1's forward kernel and latch R_ISTOP, which turns everything
-//   enqueued behind it into no-ops.
+//   three launches (forward, adjoint, update) and no host synchronisation; the stopping tests
+//   of iteration k run in the prologue of iteration k+1's adjoint kernel (several ranks: in
+//   the one-workgroup kernel in front of the all-reduce) and latch R_ISTOP, which turns
+//   everything enqueued behind it into no-ops.
 // * The forward kernel runs one workgroup per camera (observations are camera-major, the
 //   camera's table row comes through the scalar cache), forms ut' for its observations and,
 //   with the geometry still in registers, the camera part of J^T ut' (raw: beta' is not known
@@ -512,9 +513,9 @@ __global__ __launch_bounds__(256) void lsmr_prepare_mf_kernel(
 }
 
 // ---- kernel A: ut' ------------------------------------------------------------------------
-// (the stopping tests of the previous iteration run in lsmr_sumU_kernel, one workgroup, instead
-// of in the prologue of all ~3000 workgroups here: if they latch a stop, this launch has only
-// touched ut / tbuf, which nobody reads any more, and x is final)
+// (the stopping tests of the previous iteration run behind this kernel -- adjoint prologue on a
+// single rank, lsmr_sumU_kernel on several: if they latch a stop, this launch has only touched
+// ut / tbuf, which nobody reads any more, and x is final)
 __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
@@ -666,7 +667,8 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
     }
 }
 
-// One workgroup between the forward and the adjoint kernel:
+// Several ranks only -- one workgroup between the forward kernel and the all-reduce of xr[0]
+// (a single rank does the same in the prologue of every adjoint workgroup):
 //   * lsmr.py "Test for convergence" of the PREVIOUS iteration (state buffer `parity`, |x|^2
 //     partials of its update kernel); a latched R_ISTOP turns everything enqueued behind this
 //     launch into no-ops
@@ -746,7 +748,57 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
     const double *in = A.S + parity * S_NBUF;
     double ib = 0.0, ba = 0.0;
     if (!raw) {
-        const double bn = beta_new(A, sh);
+        // Single rank: no launch between the forward and this kernel.  Every workgroup sums
+        // |x|^2, |ut1'|^2, |ut2'|^2 partials itself (same code, same order => bit-identical
+        // decisions everywhere), runs the stopping tests of the previous iteration and derives
+        // beta'; workgroup 0 records them.  (Several ranks: lsmr_sumU_kernel + all-reduce.)
+        double *S = A.S;
+        double aX = 0.0, aU = 0.0, aU2 = 0.0;
+        for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) aX += A.partX[i];
+        for (int i = threadIdx.x; i < A.n_cams; i += 256) aU += A.partU[i];
+        for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) aU2 += A.partU2[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            aX += __shfl_xor(aX, m);
+            aU += __shfl_xor(aU, m);
+            aU2 += __shfl_xor(aU2, m);
+        }
+        __shared__ double sh3[4][3];
+        if ((threadIdx.x & 63) == 0) {
+            sh3[threadIdx.x >> 6][0] = aX; sh3[threadIdx.x >> 6][1] = aU; sh3[threadIdx.x >> 6][2] = aU2;
+        }
+        __syncthreads();
+        const double sumX = sh3[0][0] + sh3[1][0] + sh3[2][0] + sh3[3][0];
+        const double sU = sh3[0][1] + sh3[1][1] + sh3[2][1] + sh3[3][1];
+        const double sU2 = sh3[0][2] + sh3[1][2] + sh3[2][2] + sh3[3][2];
+        const double itn = in[S_ITN];
+        if (itn > 0.0) {             // lsmr.py: "Test for convergence" of iteration itn
+            const double normx = sqrt(sumX);
+            const double normb = S[R_NORMB], normA = in[S_NORMA], normr = in[S_NORMR];
+            const double normar = in[S_NORMAR], condA = in[S_CONDA];
+            const double test1 = normr / normb;
+            const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
+            const double test3 = 1.0 / condA;
+            const double t1 = test1 / (1 + normA * normx / normb);
+            const double rtol = S[R_BTOL] + S[R_ATOL] * normA * normx / normb;
+            double istop = 0;
+            if (itn >= S[R_MAXITER]) istop = 7;
+            if (1 + test3 <= 1) istop = 6;
+            if (1 + test2 <= 1) istop = 5;
+            if (1 + t1 <= 1) istop = 4;
+            if (test3 <= S[R_CTOL]) istop = 3;
+            if (test2 <= S[R_ATOL]) istop = 2;
+            if (test1 <= rtol) istop = 1;
+            if (!(test1 == test1) || !(normx == normx)) istop = 8;     // breakdown (NaN)
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                S[R_ITN] = itn; S[R_NORMR] = normr; S[R_NORMAR] = normar; S[R_NORMA] = normA;
+                S[R_CONDA] = condA; S[R_NORMX] = normx;
+                if (istop != 0) S[R_ISTOP] = istop;
+            }
+            if (istop != 0) return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { A.xr[0] = sU; A.xr[1] = sU2; }
+        const double bn = sqrt(sU + sU2);
         if (!(bn > 0)) {         // exact solution reached: v keeps its value (lsmr.py "if beta > 0")
             if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
             return;
@@ -984,7 +1036,6 @@ extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, cons
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
         hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
-        hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_adj_kernel, dim3(L.n_adj), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
     }

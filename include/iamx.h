@@ -344,7 +344,7 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
  * iamx_ba_lsmr_prepare: once per solve, the tables
  *   ctab DEV [n_cams][32] (rotation, position, quaternion, 1/|q|^2, d of the 7 columns),
  *   ptab DEV [n_pts][6]  (X, d of the 3 columns).
- * iamx_ba_lsmr_iterate: enqueues n_iter (even) iterations, four launches each, no host
+ * iamx_ba_lsmr_iterate: enqueues n_iter (even) iterations, three launches each, no host
  *   synchronisation.  `state` (DEV, iamx_ba_lsmr_state_size() doubles) holds the double-
  *   buffered scalar recurrences, the tolerances and the latched results (layout and
  *   initialisation: imageanalysis_amd/ba_solver.py); once istop is latched the remaining
