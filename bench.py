@@ -684,7 +684,7 @@ def ba_bench(rank, world, dev, dist, args):
         sync()
         t_it = (time.perf_counter() - t1) / its
         by = O * (200.0 + 68.0) + prob.n * 128.0
-        lsmr = {"bound": "hbm", "kernels": "lsmr_fwd (+camera adjoint) + lsmr_sumU (+stopping tests) + lsmr_adj + lsmr_update3",
+        lsmr = {"bound": "hbm", "kernels": "lsmr_fwd (+camera adjoint) + lsmr_adj (+sums, stopping tests) + lsmr_update3",
                 "achieved": round(by / t_it / 1e9, 1), "peak": HBM, "unit": "GB/s",
                 "frac": round(by / t_it / 1e9 / HBM, 4), "us_per_iteration": round(t_it * 1e6, 1),
                 "bytes_per_iteration": by, "form": "matrix-free",
