@@ -49,7 +49,13 @@ def gzip_members(raw, level=GZIP_LEVEL):
         return _member(raw, level)
     _j, workers = _pools()
     chunks = [raw[i:i + MEMBER_BYTES] for i in range(0, len(raw), MEMBER_BYTES)]
-    return b''.join(workers.map(lambda c: _member(c, level), chunks))
+    try:
+        parts = list(workers.map(lambda c: _member(c, level), chunks))
+    except RuntimeError:
+        # "cannot schedule new futures after interpreter shutdown": the process is exiting while
+        # this file is still queued -- compress it right here, the file must not be lost
+        parts = [_member(c, level) for c in chunks]
+    return b''.join(parts)
 
 
 def _write_job(path, payload, on_error=None):
@@ -105,6 +111,13 @@ def _flush_at_exit():
 
 
 atexit.register(_flush_at_exit)
+try:
+    # runs at threading shutdown, BEFORE concurrent.futures stops accepting work (callbacks run
+    # in reverse order of registration and concurrent.futures registered first): queued files
+    # are still compressed in parallel when the process ends right after a save
+    threading._register_atexit(_flush_at_exit)
+except Exception:                                             # noqa: BLE001 (private API)
+    pass
 
 
 class Prefetch(object):

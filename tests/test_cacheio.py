@@ -9,6 +9,7 @@ import threading
 import time
 
 import numpy as np
+import pytest
 
 from imageanalysis_amd import cacheio, image as iimg
 from imageanalysis_amd._deps import getNode
@@ -129,3 +130,33 @@ def test_prefetch_feeds_detect_features_from_cache(tmp_path):
         im.detect_features(0.4)                             # cache hit through the prefetched bytes
         assert np.array_equal(im.des_list, im._want) and len(im.kp_list) == 50
     pf.close()
+
+
+@pytest.mark.parametrize('early_hook', [True, False])
+def test_queued_files_survive_an_immediate_exit(tmp_path, early_hook):
+    """a process that ends right after save_*() must still leave complete cache files: either
+    the flush runs before concurrent.futures shuts down (threading hook) or, without that
+    hook, the queued jobs compress their members themselves"""
+    import subprocess
+    import sys
+    code = '''
+import sys, threading
+sys.path.insert(0, %r)
+import concurrent.futures.thread
+if not %r:
+    del threading._register_atexit          # (after concurrent.futures took its own hook)
+import numpy as np
+import pytest
+from imageanalysis_amd import cacheio
+raw = np.random.default_rng(0).integers(0, 255, 6 << 20, dtype=np.uint8).tobytes()
+for k in range(6):
+    cacheio.write_gzip(%r + '/f%%d.gz' %% k, raw)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), early_hook, str(tmp_path))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert 'failed' not in r.stdout + r.stderr
+    files = sorted(os.listdir(str(tmp_path)))
+    assert files == ['f%d.gz' % k for k in range(6)]
+    for f in files:
+        with gzip.open(os.path.join(str(tmp_path), f), 'rb') as fp:
+            assert len(fp.read()) == 6 << 20
