@@ -2,14 +2,15 @@
 """bench.py -- image-pairs matched / s on MI355X (BASELINE.json metric), with roofline and a
 CPU baseline on the same line.
 
-Workload (N=1): BASELINE.json configs[1] -- 500 synthetic images x 4096 keypoints x 128-D
+Workload, N=1: BASELINE.json configs[1] -- 500 synthetic images x 4096 keypoints x 128-D
 SIFT-like descriptors, brute-force L2 2-NN in BOTH directions for all 124 750 image pairs,
 plus the reference's quality-metric filter and survivor compaction on the device
 (metric M1).  A "step" = one pass over all pairs of the rank's shard.
-N>1 (weak scaling): the survey grows to ~500*sqrt(N) images so that every rank still matches
-~124 750 pairs; each rank owns 1/N of the images' descriptors, they are all-gathered over RCCL
-inside the step (the path's one exchange step), then every rank matches its shard of the pair
-schedule -- no other data-path collective.
+N>1: BASELINE.json configs[2] -- the 2812-image survey, all 3 952 266 pairs, pair-sharded over
+the ranks (strong scaling: the total work is fixed).  Each rank owns 1/N of the images'
+descriptors ("detected there"), packs them, they are all-gathered over RCCL inside the step (the
+path's one exchange step), then every rank matches its shard of the pair schedule -- no other
+data-path collective.  The BA section runs configs[3] point-sharded.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
@@ -31,7 +32,8 @@ KPTS = 4096
 DIM = 128
 FLOP_PER_PAIR = 2.0 * KPTS * KPTS * DIM          # one distance matrix serves both directions
 I8_DENSE_PEAK_TFLOPS = 5000.0                    # 2 x bf16 dense (MI355X_MICROARCH.md)
-PAIRS_PER_RANK = 124750                          # configs[1]: C(500, 2)
+CONFIG1_IMAGES = 500                             # configs[1]: C(500, 2) = 124 750 pairs
+CONFIG2_IMAGES = 2812                            # configs[2]: 3 952 266 pairs
 MATCH_RATIO = 0.75
 MAX_DISTANCE = 270.0
 
@@ -68,16 +70,19 @@ def synth_descriptors(n_img, first, count, device, seed=1234):
     return out
 
 
-def pair_schedule(n_img, rank, world):
-    """All unordered pairs, dealt to ranks in contiguous blocks of the train-major order, both
-    directions of a pair on the same rank."""
+def pair_schedule(n_img, rank, world, sub_batch):
+    """All unordered pairs, dealt to ranks in contiguous blocks of the train-major order.  Returns
+    the rank's launches: ordered-pair arrays [fwd ..., rev ...] of `sub_batch` / 2 image pairs
+    each (both directions of a pair in the same launch), and the rank's unordered pair count."""
     ii, jj = np.triu_indices(n_img, k=1)
+    order = np.lexsort((ii, jj))                              # train-major: L2 reuse of the train
+    ii, jj = ii[order], jj[order]
     n = len(ii)
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world
-    ii, jj = ii[lo:hi], jj[lo:hi]
-    ordered = np.concatenate([np.stack([ii, jj], 1), np.stack([jj, ii], 1)]).astype(np.int32)
-    order = np.lexsort((ordered[:, 0], ordered[:, 1]))       # train-major: L2 reuse of the train
-    return ordered[order], hi - lo
+    und = np.stack([ii[lo:hi], jj[lo:hi]], 1).astype(np.int32)
+    half = max(sub_batch // 2, 1)
+    launches = [np.concatenate([und[s:s + half], und[s:s + half, ::-1]]) for s in range(0, len(und), half)]
+    return launches, hi - lo
 
 
 def main():
@@ -88,6 +93,10 @@ def main():
     ap.add_argument('--images', type=int, default=0, help='override the survey size')
     ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--one-direction', action='store_true',
+                    help='A/B: the round-1 form, one MFMA sweep per ORDERED pair (iamx_knn2v2_pairs)')
+    ap.add_argument('--verify-pairs', type=int, default=6,
+                    help='ordered pairs of the timed store checked against the oracle afterwards')
     ap.add_argument('--no-overlap', action='store_true',
                     help='filter kernels on the sweep stream (default: on a second stream)')
     ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
@@ -119,38 +128,50 @@ def main():
 
     from imageanalysis_amd import kernels
 
-    # ---- survey size: total pairs ~= world * PAIRS_PER_RANK, a multiple of world images
-    n_img = args.images or int(round((1 + math.sqrt(1 + 8.0 * world * PAIRS_PER_RANK)) / 2))
+    # ---- survey: configs[1] on one GPU, configs[2] (strong scaling) on several.  Image slots
+    #      are dealt to the ranks in equal blocks (the last block may hold spare slots that no
+    #      pair refers to), so the all-gather is one equal-sized collective per buffer
+    n_img = args.images or (CONFIG1_IMAGES if world == 1 else CONFIG2_IMAGES)
     per = (n_img + world - 1) // world
-    n_img = per * world
+    n_slots = per * world
     first, mine = rank * per, per
 
     # ---- this rank's images (as if it had detected them there), packed locally
-    raw = synth_descriptors(n_img, first, mine, dev)
-    store = kernels.DescriptorStore([KPTS] * n_img)
+    raw = synth_descriptors(n_slots, first, mine, dev)
+    store = kernels.DescriptorStore([KPTS] * n_slots)
     rows_per = int(store.offsets[1] - store.offsets[0])
-    rows_per2 = int(store.offsets2[1] - store.offsets2[0])
+    rows_per3 = int(store.offsets3[1] - store.offsets3[0])
     src_off = (torch.arange(mine + 1, dtype=torch.int64, device=dev) * KPTS)
     pack_scratch = torch.empty(3 * mine * KPTS, dtype=torch.int32, device=dev)
 
     def pack_and_gather():
-        """pack own images into the store, then RCCL all-gather (desc, norm_q, norm_t) in
-        place: rank r's shard already sits at offset r*shard of the receive buffer."""
+        """pack own images into the stores (original order for the exact re-scan, sorted order
+        for the sweep), then RCCL all-gather in place: rank r's shard already sits at offset
+        r*shard of the receive buffer."""
         L, _ptr, sp = kernels.lib(), kernels._ptr, kernels.stream_ptr()
         o = int(store.offsets[first])
         kernels.check(L.iamx_desc_pack_u8(_ptr(raw), mine * KPTS, _ptr(store.desc[o:]),
                                           _ptr(store.norm_q[o:]), _ptr(store.norm_t[o:]), sp),
                       'iamx_desc_pack_u8')
-        # train-side (parity partitioned) layout, all of this rank's images in one batch
-        kernels.check(L.iamx_desc2_pack_batch_u8(_ptr(raw), _ptr(src_off), _ptr(store.img_off2[first:]),
-                                                 mine, mine * KPTS, KPTS, _ptr(store.desc2),
-                                                 _ptr(store.norm2), _ptr(store.cinit),
-                                                 _ptr(store.perm), _ptr(store.meta[first]),
-                                                 _ptr(pack_scratch), sp), 'iamx_desc2_pack_batch_u8')
+        kernels.check(L.iamx_desc3_pack_batch_u8(_ptr(raw), _ptr(src_off), _ptr(store.img_off3[first:]),
+                                                 mine, mine * KPTS, KPTS, _ptr(store.desc3),
+                                                 _ptr(store.sn2), _ptr(store.sct), _ptr(store.sperm),
+                                                 _ptr(store.sinv), _ptr(pack_scratch), sp),
+                      'iamx_desc3_pack_batch_u8')
+        bufs = [(store.desc, rows_per * DIM), (store.norm_q, rows_per),
+                (store.desc3, rows_per3 * DIM), (store.sn2, rows_per3),
+                (store.sct, rows_per3), (store.sinv, rows_per3)]
+        if args.one_direction:       # parity-partitioned train layout of the one-direction form
+            kernels.check(L.iamx_desc2_pack_batch_u8(_ptr(raw), _ptr(src_off), _ptr(store.img_off2[first:]),
+                                                     mine, mine * KPTS, KPTS, _ptr(store.desc2),
+                                                     _ptr(store.norm2), _ptr(store.cinit),
+                                                     _ptr(store.perm), _ptr(store.meta[first]),
+                                                     _ptr(pack_scratch), sp), 'iamx_desc2_pack_batch_u8')
+            rows_per2 = int(store.offsets2[1] - store.offsets2[0])
+            bufs = bufs[:2] + [(store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),
+                               (store.cinit, rows_per2), (store.perm, rows_per2), (store.meta, 4)]
         if dist is not None:
-            for buf, width in ((store.desc, rows_per * DIM), (store.norm_q, rows_per),
-                               (store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),
-                               (store.cinit, rows_per2), (store.perm, rows_per2), (store.meta, 4)):
+            for buf, width in bufs:
                 flat = buf.view(-1)
                 shard = per * width
                 if one_gpu:          # gloo: no in-place all_gather_into_tensor on device memory
@@ -160,9 +181,8 @@ def main():
                 else:
                     dist.all_gather_into_tensor(flat, flat[rank * shard:(rank + 1) * shard])
 
-    ordered, n_pairs_rank = pair_schedule(n_img, rank, world)
-    sb = args.sub_batch
-    batches = [kernels.PairBatch(store, ordered[s:s + sb]) for s in range(0, len(ordered), sb)]
+    launches, n_pairs_rank = pair_schedule(n_img, rank, world, args.sub_batch)
+    batches = [kernels.PairBatch(store, o, sym=not args.one_direction) for o in launches]
     ws = kernels.PairWorkspace(max(b.rows for b in batches), max(b.n_pairs for b in batches))
     thresh = MAX_DISTANCE * MATCH_RATIO
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -175,8 +195,11 @@ def main():
         runner = kernels.OverlappedSweeps(ws.max_rows, ws.max_pairs, first_workspace=ws)
         ws_pair = runner.ws
 
+    candidates = torch.zeros(1, dtype=torch.int64, device=dev)
+
     def count_survivors(b, w):
         survivors.add_(w.surv_cnt[:b.n_pairs].sum())
+        candidates.add_(w.seg_count[:b.n_pairs].sum())     # rows that passed the bound test
 
     def step(timed_events=False):
         pack_and_gather()
@@ -202,6 +225,7 @@ def main():
         step()
     barrier()
     survivors.zero_()
+    candidates.zero_()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed_events=True)
@@ -218,20 +242,23 @@ def main():
     else:
         total_pairs = n_pairs_rank
 
-    # ---- roofline of the dominant kernel (knn2_pairs_kernel), HIP events of the last step
+    # ---- roofline of the dominant kernel, HIP events of the last step (recorded on the stream
+    #      the sweeps are launched on)
     k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     k_pairs = [b.n_pairs / 2.0 for b in batches]           # unordered pairs per launch
     achieved = sum(k_pairs) * FLOP_PER_PAIR / (sum(k_ms) * 1e-3) / 1e12
     traffic, traffic_src, mfma_busy, mfma_busy_src = None, None, None, None
-    tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json')
-    if n_img == 500 and world == 1 and os.path.exists(tf):
+    sweeps = 2 if args.one_direction else 1                # MFMA passes per distance matrix
+    tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json' if args.one_direction
+                      else 'r2_knn2sym_traffic.json')
+    if n_img == CONFIG1_IMAGES and world == 1 and os.path.exists(tf):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); PMC cannot be collected from inside
         with open(tf) as fp:
             t = json.load(fp)
         traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
         mfma_busy, mfma_busy_src = t.get("mfma_busy"), t.get("mfma_busy_source")
-    roofline = {"bound": "mfma", "kernel": "knn2v2_kernel",
+    roofline = {"bound": "mfma", "kernel": "knn2v2_kernel" if args.one_direction else "knn2sym_kernel",
                 "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -240,12 +267,23 @@ def main():
                 "mfma_busy": mfma_busy, "mfma_busy_source": mfma_busy_src,
                 "launches": len(batches), "avg_launch_ms": round(sum(k_ms) / len(k_ms), 4),
                 "flop_per_launch": sum(k_pairs) / len(k_pairs) * FLOP_PER_PAIR,
-                # the kernel runs both directions of a pair as two MFMA passes: executed =
-                # 2 x algorithmic; sustained i8 MFMA ceiling with real operand bits measured
-                # at ~3200 TOP/s (power limited, profiles/r1_ubench_mfma_clock.txt)
-                "executed_tflops": round(2 * achieved, 1),
-                "executed_frac_of_peak": round(2 * achieved / I8_DENSE_PEAK_TFLOPS, 4),
-                "executed_frac_of_sustained_3200": round(2 * achieved / 3200.0, 4)}
+                # algorithmic = one distance matrix per unordered pair.  The
+                # symmetric sweep executes exactly that on the MFMA pipe (+ the exact re-scan of
+                # the candidate rows on the VALU, off this kernel); the one-direction form runs
+                # every matrix twice.  Sustained i8 MFMA ceiling with real operand bits ~3200
+                # TOP/s (power limited, profiles/r1_ubench_mfma_clock.txt)
+                "mfma_passes_per_matrix": sweeps,
+                "executed_tflops": round(sweeps * achieved, 1),
+                "executed_frac_of_peak": round(sweeps * achieved / I8_DENSE_PEAK_TFLOPS, 4),
+                "executed_frac_of_sustained_3200": round(sweeps * achieved / 3200.0, 4)}
+
+    # ---- self-check outside the timed region: a sample of ordered pairs of the store that was
+    #      just timed (neighbours, which overlap, and far pairs), through the same path, against
+    #      the oracle (oracle/cpu_ref.c) -- survivor rows, train rows, metrics
+    verified = None
+    if rank == 0 and args.verify_pairs > 0:
+        verified = verify_sample(kernels, store, raw, first, mine, n_img, thresh,
+                                 args.verify_pairs, not args.one_direction)
 
     ws_unresolved = sum(int(w.unresolved.item()) for w in (ws_pair if overlap else [ws]))
     # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
@@ -292,16 +330,21 @@ def main():
             "metric": "image_pairs_matched_per_sec", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8 (int8 MFMA, int32 accumulate)",
+            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "dtype": "u8 (int8 MFMA, int32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic images x %d kpts x 128-D, all-pairs "
+            "config": {"workload": "%s: %d synthetic images x %d kpts x 128-D, all-pairs "
                                    "brute-force L2 2-NN both directions + metric filter + "
-                                   "compaction" % (n_img, KPTS),
+                                   "compaction" % ("configs[1]" if n_img == CONFIG1_IMAGES else
+                                                   "configs[2]" if n_img == CONFIG2_IMAGES else
+                                                   "custom survey", n_img, KPTS),
                        "images": n_img, "kpts": KPTS, "pairs_per_step": total_pairs,
                        "parallelism": "pair-shard x%d%s" % (world, " + RCCL descriptor all-gather"
                                                             if world > 1 else "")},
             "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
+            "candidates_per_step": int(candidates.item()) // max(args.steps, 1),
             "unresolved": int(ws_unresolved),
+            "verified_pairs": verified["verified_pairs"] if verified else 0, "verify": verified,
             "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,
         }
@@ -310,6 +353,45 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym):
+    """oracle check of `n_check` ordered pairs among this rank's own images (their raw
+    descriptors are at hand): the shipped path on the timed store vs oracle/cpu_ref.c"""
+    from oracle import cpu_ref
+    hi = min(first + mine, n_img)
+    cand = [(first, first + 1), (first + 1, first), (first + 1, first + 2), (first + 2, first + 1),
+            (first, hi - 1), (hi - 1, first), (first + 3, hi - 2), (hi - 2, first + 3)]
+    cand = [(a, b) for a, b in cand if first <= a < hi and first <= b < hi and a != b]
+    und = []
+    for a, b in cand:
+        if (a, b) not in und and (b, a) not in und:
+            und.append((a, b))
+    und = und[:max(1, n_check // 2)]
+    ordered = np.array(und + [(b, a) for a, b in und], np.int32)
+    pb = kernels.PairBatch(store, ordered, sym=sym)
+    w = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb.run(w, thresh)
+    torch.cuda.synchronize()
+    f, c, sq, st, sm = w.survivors(pb.n_pairs)
+    host = {}
+    for p, (a, b) in enumerate(ordered):
+        for i in (a, b):
+            if i not in host:
+                host[i] = raw[i - first].cpu().numpy()
+        ridx, rd2 = cpu_ref.knn2_l2_u8(host[a], host[b])
+        d = np.sqrt(rd2.astype(np.float32)).astype(np.float64)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            metric = d[:, 0] * (d[:, 0] / d[:, 1])
+        keep = np.nonzero(metric < thresh)[0]
+        lo, hi_ = f[p], f[p] + c[p]
+        ok = (np.array_equal(sq[lo:hi_], keep) and np.array_equal(st[lo:hi_], ridx[keep, 0])
+              and np.array_equal(sm[lo:hi_], metric[keep]))
+        if not ok:
+            raise RuntimeError("bench self-check: pair (%d, %d) differs from the oracle" % (a, b))
+    return {"verified_pairs": int(len(ordered)), "survivors_checked": int(c.sum()),
+            "against": "oracle/cpu_ref.c", "form": "symmetric sweep, form %d" % pb.sym_form
+            if pb.sym else "one-direction sweep, %d-row workgroups" % pb.fast_rows}
 
 
 def host_postprocess_rate():

@@ -41,6 +41,15 @@ SIGNATURES = {
     'iamx_knn2v2_resolve': (c_int, [c_void_p] * 13 + [c_int, c_void_p, c_void_p]),
     'iamx_knn2v2_finish': (c_int, [c_void_p] * 10 + [c_double] + [c_void_p] * 5 + [c_int]
                            + [c_void_p] * 3),
+    'iamx_desc3_rows_cap': (c_int64, [c_int64]),
+    'iamx_knn2sym_rows_per_wg': (c_int, [c_int]),
+    'iamx_desc3_pack_u8': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
+    'iamx_desc3_pack_f32': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
+    'iamx_desc3_pack_batch_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]
+                                 + [c_void_p] * 7),
+    'iamx_knn2sym_sweep': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int] + [c_void_p] * 3),
+    'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 5),
+    'iamx_knn2sym_exact': (c_int, [c_void_p] * 9 + [c_int, c_double] + [c_void_p] * 7),
     'iamx_match_postfilter_clip': (c_int, []),
     'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]
                               + [c_void_p] * 6),

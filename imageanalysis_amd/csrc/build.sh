@@ -1,15 +1,23 @@
 #!/bin/bash
 # Builds libiamx.so (gfx950 only) next to the python package.  Cross-compiles without a GPU.
+# IAMX_ABLATE=1 builds libiamx_ablate.so instead: the same library plus the iamxdbg_* timing
+# variants used by tools/*_ablate.py (never loaded by the product; select it with IAMX_LIB).
 set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../libiamx.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/sift.hip $HERE/image_prep.hip"
-mkdir -p "$HERE/obj"
+OUT="$HERE/../libiamx.so"
+OBJDIR="$HERE/obj"
+if [ -n "$IAMX_ABLATE" ]; then
+    OUT="$HERE/../libiamx_ablate.so"
+    OBJDIR="$HERE/obj_ablate"
+    FLAGS="$FLAGS -DIAMX_ABLATE"
+fi
+SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_knn2sym.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/sift.hip $HERE/image_prep.hip"
+mkdir -p "$OBJDIR"
 OBJS=""
 for f in $SRCS; do
-    o="$HERE/obj/$(basename ${f%.hip}).o"
+    o="$OBJDIR/$(basename ${f%.hip}).o"
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/iamx_common.h" -nt "$o" ] || [ "$HERE/../../include/iamx.h" -nt "$o" ]; then
         $HIPCC $FLAGS ${IAMX_EXTRA_FLAGS} -c "$f" -o "$o" &
     fi

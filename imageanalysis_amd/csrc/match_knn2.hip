@@ -518,6 +518,7 @@ extern "C" int iamx_knn2_l2_pairs(const int8_t *desc, const int32_t *norm_q,
     return iamx::check_launch("iamx_knn2_l2_pairs");
 }
 
+#ifdef IAMX_ABLATE   // scaffolding of tools/*_ablate.py: built into libiamx_ablate.so only
 // timing ablations (not part of the C ABI; see the VARIANT comment above)
 extern "C" int iamxdbg_knn2_variant(int variant, const int8_t *desc, const int32_t *norm_q,
                                     const int32_t *norm_t, const int32_t *img_off,
@@ -556,6 +557,7 @@ extern "C" int iamxdbg_knn2_variant(int variant, const int8_t *desc, const int32
 #undef V
     return iamx::check_launch("iamxdbg_knn2_variant");
 }
+#endif
 
 extern "C" int iamx_knn2_l2_u8(const int8_t *q_desc, const int32_t *q_norm_q, int nq,
                                const int8_t *t_desc, const int32_t *t_norm_t, int nt,

@@ -1,0 +1,860 @@
+// K2 (symmetric form) -- ONE i8-MFMA sweep of a distance matrix serves BOTH directions of an
+// image pair (gfx950).  Replaces the two knnMatch calls of bidirectional_pair_matches
+// (scripts/lib/matcher.py:304-347 -> :203-216) and the metric loop (:253-263).
+//
+// Why: the one-direction fast form (match_knn2v2.hip) runs the MFMA pipe at ~80 % of its
+// power-limited rate, but every distance matrix is executed twice (queries = image i against
+// train = image j, then j against i).  The only factor left is that 2x.
+//
+// How: the sweep does not try to be exact.  For every row of BOTH images it only produces
+//     L  <= exact best squared distance,      U  >= exact second squared distance
+// cheaply enough to stay MFMA bound; the reference's test  d0*(d0/d1) < 270*ratio  is monotone
+// (increasing in d0, decreasing in d1), so thresholding (L, U) keeps a SUPERSET of the rows the
+// reference keeps (a few rows per image pair), and symexact_kernel recomputes those rows
+// exactly (all train rows, v_dot4, lowest train row wins ties = cv2.BFMatcher order).  What
+// leaves the path is bit-identical to the exact forms (tests/test_match_sym_gpu.py).
+//
+// Arithmetic.  s = value-128 (int8), n2 = |s|^2, nb = n2 + 2*sum(s), Ct = nb>>1, Cq = n2>>1,
+// p = n2&1 (= nb&1).  With the B operand holding ~s_a = -s_a-1 and the C operand Ct[t]:
+//     acc_out(a,t) = Ct[t] + sum(~s_a * s_t)         d2(a,t) = 2*(acc_out + Cq[a]) + p[a] + p[t]
+// Column direction (queries = B rows, lane local): v = min_t acc_out, kept as 4 interleaved
+//   running minima per lane (tile & 3) x 2 lane halves = 8 groups of train rows:
+//   best >= 2*(v1+Cq[a]) + p[a],  second <= 2*(v2+Cq[a]) + p[a] + 1   (v2 = 2nd smallest group
+//   minimum; 8 v_min3 per 16 distances = 0.5 VALU / distance).
+// Row direction (queries = A rows, across lanes): R_w(t) = min over the 128 B rows of a wave of
+//   acc_out: v_min3 across the wave's four 32-row blocks (0.5 VALU / distance), then a
+//   TRANSPOSING butterfly over the 32 lanes (DPP quad_perm with bank masks, row_ror,
+//   v_permlane16_swap: 36 instructions for 16 registers instead of 80).  The B rows of an image
+//   are stored SORTED by n2, so Cq of a wave's rows lies in a narrow [lo_w, hi_w]:
+//   group minimum in [R_w + lo_w, R_w + hi_w]; per train row the 8 waves of a workgroup are
+//   merged through LDS into (L, U1, U2) = (min lower bound, two smallest upper bounds).
+// One sorted store serves both roles (any order is legal for the A side).
+#include "iamx_common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+#ifndef IAMX_DESC_OFFSET
+#define IAMX_DESC_OFFSET 128
+#endif
+constexpr int D = IAMX_DESC_DIM;
+constexpr int CHUNK = 128;
+constexpr int BIG = 0x3F000000;          // Ct of padding rows: loses every comparison
+
+// ---------------------------------------------------------------------------------
+// pack ("desc3"): rows of an image sorted by n2 (stable), padded to 128 rows
+//   A  per row (8 threads): n2, nb                       -> scratch
+//   B  per row: rank = #{r' : (n2', r') < (n2, r)}        -> scratch (O(n^2), LDS tiled)
+//   C  per row (8 threads): convert + scatter, sn2 / sct / sperm / sinv
+//   D  padding rows
+// ---------------------------------------------------------------------------------
+struct Pack3Args {
+    const void *src;             // [rows][128] u8 or f32, images back to back
+    const int64_t *src_off;      // DEV [n_img+1] first source row of each image, or NULL:
+    int64_t single_n;            //   one image of single_n rows
+    const int32_t *dst_off;      // DEV [n_img] first packed row of each image (NULL: 0)
+    int8_t *dst;
+    int32_t *sn2, *sct, *sperm, *sinv;
+    int32_t *n2, *nb, *pos;      // scratch, one int per source row each
+    int n_img;
+};
+
+template <typename SRC>
+__device__ __forceinline__ int load_value(const SRC *p, int i)
+{
+    if constexpr (sizeof(SRC) == 1) {
+        return (int)p[i];
+    } else {
+        int v = (int)rintf((float)p[i]);
+        return v < 0 ? 0 : (v > 255 ? 255 : v);
+    }
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void pack3_rows_kernel(Pack3Args P, int64_t total_rows)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int part = (int)(t & 7);
+    int s2 = 0, s1 = 0;
+    if (row < total_rows) {
+        const SRC *p = static_cast<const SRC *>(P.src) + row * D + part * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int s = load_value(p, i) - IAMX_DESC_OFFSET;
+            s2 += s * s;
+            s1 += s;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+        s2 += __shfl_xor(s2, m, 8);
+        s1 += __shfl_xor(s1, m, 8);
+    }
+    if (row < total_rows && part == 0) {
+        P.n2[row] = s2;
+        P.nb[row] = s2 + 2 * s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack3_rank_kernel(Pack3Args P)
+{
+    __shared__ __attribute__((aligned(16))) int keys[1024];
+    const int img = blockIdx.y;
+    const int64_t r0 = P.src_off ? P.src_off[img] : 0;
+    const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int mine = r < n ? P.n2[r0 + r] : 0;
+    int cnt = 0;
+    for (int base = 0; base < n; base += 1024) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = base + k * 256 + threadIdx.x;
+            keys[k * 256 + threadIdx.x] = j < n ? P.n2[r0 + j] : 0x7FFFFFFF;
+        }
+        __syncthreads();
+        // rows before r with key <= mine, rows after r with key < mine (the fill value of the
+        // last tile never counts)
+        for (int j = 0; j < 1024; j += 4) {
+            const v4i k = *reinterpret_cast<const v4i *>(&keys[j]);
+            cnt += (k.x < mine) || (k.x == mine && base + j < r);
+            cnt += (k.y < mine) || (k.y == mine && base + j + 1 < r);
+            cnt += (k.z < mine) || (k.z == mine && base + j + 2 < r);
+            cnt += (k.w < mine) || (k.w == mine && base + j + 3 < r);
+        }
+    }
+    if (r < n) P.pos[r0 + r] = cnt;
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void pack3_scatter_kernel(Pack3Args P)
+{
+    const int img = blockIdx.y;
+    const int64_t r0 = P.src_off ? P.src_off[img] : 0;
+    const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
+    const int d0 = P.dst_off ? P.dst_off[img] : 0;
+    const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = t >> 3, part = t & 7;
+    if (r >= cap) return;
+    if (r >= n) {                              // padding rows n .. cap-1
+        *reinterpret_cast<uint4 *>(P.dst + (int64_t)(d0 + r) * D + part * 16) = make_uint4(0, 0, 0, 0);
+        if (part == 0) {
+            P.sn2[d0 + r] = 0;
+            P.sct[d0 + r] = BIG;
+            P.sperm[d0 + r] = -1;
+            P.sinv[d0 + r] = -1;
+        }
+        return;
+    }
+    const SRC *p = static_cast<const SRC *>(P.src) + (r0 + r) * D + part * 16;
+    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        w[i >> 2] |= (unsigned)((load_value(p, i) - IAMX_DESC_OFFSET) & 0xFF) << (8 * (i & 3));
+    const int pos = d0 + P.pos[r0 + r];
+    *reinterpret_cast<uint4 *>(P.dst + (int64_t)pos * D + part * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (part == 0) {
+        P.sn2[pos] = P.n2[r0 + r];
+        P.sct[pos] = P.nb[r0 + r] >> 1;
+        P.sperm[pos] = r;
+        P.sinv[d0 + r] = pos - d0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// sweep
+// ---------------------------------------------------------------------------------
+struct SymArgs {
+    const int8_t *sdesc;
+    const int32_t *sn2, *sct;
+    const int32_t *img_off, *img_n;
+    const int32_t *upairs;       // [n_u][2]: (B image = register resident, A image = streamed)
+    const int32_t *wg_off;       // [n_u+1] scan of ceil(n_B / rows per workgroup)
+    const int64_t *col_off;      // [n_u] first column-result row (sum of B caps)
+    const int64_t *rowp_off;     // [n_u] first row partial (sum of workgroups x A caps)
+    int32_t *col;                // [..][2]  (v1, v2)
+    int32_t *rowp;               // [..][4]  (L, U1, U2, -)
+    int n_u, total_wg;
+};
+
+// min over the 32 lanes of a half wave (lanes 0-31: g = 0, lanes 32-63: g = 1) of 16 registers
+// in 40 VALU instructions (32 half-rate slots) instead of 80: a DPP bank mask selects QUADS
+// (lane bits 3:2) and a row mask 16-lane rows, so the levels "xor 8", "xor 4" and "xor 16" can
+// keep a DIFFERENT register in the two halves they combine (a transposing butterfly: 16 -> 8
+// -> 4 -> 2 registers); only the two levels inside a quad run on every remaining register.
+// On return every lane of quad (b4 = lane bit 4, b3, b2) holds
+//     m0 = min over the half wave of r[4*b4 + 2*b2 + b3],   m1 = ... of r[8 + 4*b4 + 2*b2 + b3].
+__device__ __forceinline__ void half_wave_min16(const int (&r)[16], int &m0, int &m1)
+{
+    int s[8], u[4], w[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {          // lanes xor 8: quads 0,1 keep r[2k], quads 2,3 r[2k+1]
+        const int a = r[2 * k], b = r[2 * k + 1];
+        const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);   // row_ror:8
+        const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);
+        s[k] = min(t1, t2);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // lanes xor 4: quads 0,2 keep s[2k], quads 1,3 s[2k+1]
+        const int a = s[2 * k], b = s[2 * k + 1];
+        const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x12C, 0xF, 0x5, false);   // row_ror:12 = lane+4
+        const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x124, 0xF, 0xA, false);   // row_ror:4  = lane-4
+        u[k] = min(t1, t2);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {          // lanes xor 16: v_permlane16_swap exchanges the odd rows
+        // of its first operand with the even rows of its second: even rows keep u[2k], odd u[2k+1]
+        const v2u x = __builtin_amdgcn_permlane16_swap((unsigned)u[2 * k], (unsigned)u[2 * k + 1], false, false);
+        w[k] = min((int)x[0], (int)x[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {          // inside the quads
+        w[k] = min(w[k], __builtin_amdgcn_update_dpp(0, w[k], 0xB1, 0xF, 0xF, true));    // quad_perm:[1,0,3,2]
+        w[k] = min(w[k], __builtin_amdgcn_update_dpp(0, w[k], 0x4E, 0xF, 0xF, true));    // quad_perm:[2,3,0,1]
+    }
+    m0 = w[0];
+    m1 = w[1];
+}
+
+// VARIANT != 0: timing ablations, compiled only with -DIAMX_ABLATE (tools/knn2sym_ablate.py):
+// bit0 no column direction, bit1 no row direction, bit2 row direction without the cross-lane
+// butterfly, bit3 no MFMA.  Results are meaningless.
+template <int QW, int NW, int VARIANT = 0>
+__global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
+{
+    constexpr int WGROWS = NW * QW * 32;
+    constexpr int NT = NW * 64;
+    constexpr int PIECES = CHUNK * D / 16 / NT;
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * CHUNK * D + 2 * CHUNK * 4 + 2 * NW * CHUNK * 4 + 2 * NW * 4 + NW * 256 * 4];   // (lds_cq: NW used)
+    int8_t *lds_tile = lds;
+    int *lds_tb = reinterpret_cast<int *>(lds + 2 * CHUNK * D);      // [2][CHUNK]     Ct
+    int *lds_row = lds_tb + 2 * CHUNK;                               // [2][NW][CHUNK] R_w
+    int *lds_cq = lds_row + 2 * NW * CHUNK;                          // [NW] (2 NW reserved) S_w
+    int *lds_dump = lds_cq + 2 * NW;                                 // [NW][256]      unused stores
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, g = lane >> 5;
+
+    int vid;
+    {
+        const int total = A.total_wg, bid = blockIdx.x;
+        const int xcd = bid & 7, k = bid >> 3, q = total >> 3, r = total & 7;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int lo = 0, hi = A.n_u;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.wg_off[mid] <= vid) lo = mid; else hi = mid;
+    }
+    const int u = lo;
+    const int bimg = A.upairs[2 * u], aimg = A.upairs[2 * u + 1];
+    const int boff = A.img_off[bimg], nb = A.img_n[bimg];
+    const int aoff = A.img_off[aimg], na = A.img_n[aimg];
+    const int capA = (na + CHUNK - 1) / CHUNK * CHUNK;
+    const int nchunks = capA / CHUNK;
+    const int wgi = vid - A.wg_off[u];
+    const int q0 = wgi * WGROWS + wave * (QW * 32);
+    const bool wave_valid = q0 < nb;
+    const int64_t rbase = A.rowp_off[u] + (int64_t)wgi * capA;
+
+    // B operand: lane (c, g) holds bytes [32s+16g, +16) of the QW consecutive (sorted) B rows
+    // q0 + QW*c + qb; rows past the end repeat the last row (it belongs to this wave, so the
+    // group minimum is unchanged).  Cq of a lane's rows lies in [lo_lane, lo_lane + spread]:
+    // lo_lane rides into the sweep with the C operand, the wave's largest spread S_w (a few
+    // hundred for SIFT-like rows, the rows are sorted) widens the upper bound afterwards.
+    v4i bq[QW][4];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        int row = q0 + QW * c + qb;
+        row = row < nb ? row : nb - 1;
+        const v4i *src = reinterpret_cast<const v4i *>(A.sdesc + (int64_t)(boff + row) * D);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[qb][s] = ~src[2 * s + g];
+    }
+    int lo_lane = 0;
+    {
+        int spread = 0;
+        if (wave_valid) {
+            const int r_lo = q0 + QW * c < nb ? q0 + QW * c : nb - 1;
+            const int r_hi = q0 + QW * c + QW - 1 < nb ? q0 + QW * c + QW - 1 : nb - 1;
+            lo_lane = A.sn2[boff + r_lo] >> 1;
+            spread = (A.sn2[boff + r_hi] >> 1) - lo_lane;
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) spread = max(spread, __shfl_xor(spread, sh));
+        if (lane == 0) lds_cq[wave] = spread;
+    }
+    if (!wave_valid) {
+#pragma unroll
+        for (int k = 0; k < 2 * CHUNK / 64; ++k)
+            lds_row[((k >> 1) * NW + wave) * CHUNK + (k & 1) * 64 + lane] = BIG;
+    }
+    int m[QW][4];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[qb][k] = BIG;
+
+    const int8_t *tbase = A.sdesc + (int64_t)aoff * D;
+    const int32_t *tci = A.sct + aoff;
+    // global -> LDS directly; the XOR swizzle of the 16-byte slots is applied on the source side
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto stage_direct = [&](int ch, int buf) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int e = j * NT + tid, row = e >> 3, slot = (e & 7) ^ ((row >> 1) & 7);
+            const int8_t *gsrc = tbase + (int64_t)(ch * CHUNK + row) * D + slot * 16;
+            int8_t *ldst = lds_tile + buf * (CHUNK * D) + (j * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr)ldst, 16, 0, 0);
+        }
+        if (wave < CHUNK / 64)
+            __builtin_amdgcn_global_load_lds(tci + ch * CHUNK + tid,
+                                             (lds_ptr)(lds_tb + buf * CHUNK + wave * 64), 4, 0, 0);
+    };
+    auto wait_direct = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };       // vmcnt(0)
+    // per train row: the waves' group minima -> (L, U1, U2)
+    auto merge_rows = [&](int ch, int buf) {
+        int L = BIG, U1 = BIG, U2 = BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int R = lds_row[(buf * NW + w) * CHUNK + tid];
+            const int lw = R, uw = R + lds_cq[w];
+            L = min(L, lw);
+            U2 = min(max(U1, uw), U2);
+            U1 = min(U1, uw);
+        }
+        *reinterpret_cast<v4i *>(A.rowp + 4 * (rbase + ch * CHUNK + tid)) = v4i{L, U1, U2, 0};
+    };
+
+    stage_direct(0, 0);
+    wait_direct();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) stage_direct(ch + 1, buf ^ 1);
+        if (ch > 0 && tid < CHUNK) merge_rows(ch - 1, buf ^ 1);
+        if (wave_valid) {
+            const int8_t *tile_base = lds_tile + buf * (CHUNK * D);
+            const int *tb_base = lds_tb + buf * CHUNK;
+            auto load_ops = [&](int tile, v4i (&a)[4], v4i (&tbv)[4]) {
+                const int r = tile * 32 + c, swz = (r >> 1) & 7;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    a[s] = *reinterpret_cast<const v4i *>(tile_base + r * D + (((2 * s + g) ^ swz) * 16));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
+            };
+            v4i a[4], tbv[4];
+            load_ops(0, a, tbv);
+            int *row_dst = (lane & 3) == 0
+                ? lds_row + (buf * NW + wave) * CHUNK + 8 * ((lane >> 4) & 1) + 4 * g + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1)
+                : lds_dump + wave * 256 + lane;                 // + tile*32 (+16) stays inside [0, 256)
+#pragma unroll
+            for (int tile = 0; tile < CHUNK / 32; ++tile) {
+                v4i a_nx[4], tb_nx[4];
+                if (tile + 1 < CHUNK / 32) load_ops(tile + 1, a_nx, tb_nx);
+                int r[16];
+                static_assert(QW % 2 == 0, "query blocks are processed in pairs");
+                int cl[16];                    // C operand: Ct of the 16 rows + the lane's Cq floor
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) cl[reg] = tbv[reg >> 2][reg & 3] + lo_lane;
+#pragma unroll
+                for (int qp = 0; qp < QW; qp += 2) {
+                    // two independent accumulator chains in flight (C operand = Ct of the rows)
+                    v16i acc0, acc1;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc0[reg] = acc1[reg] = cl[reg];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if constexpr (VARIANT & 8) {
+                            acc0[s] += a[s][0] ^ bq[qp][s][1];
+                            acc1[s] += a[s][1] ^ bq[qp + 1][s][1];
+                        } else {
+                            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qp][s], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qp + 1][s], acc1, 0, 0, 0);
+                        }
+                    }
+                    if constexpr (VARIANT & 1) {
+                        asm volatile("" ::"v"(acc0), "v"(acc1));
+                    } else {
+                        // column direction: one of four interleaved running minima per query
+                        int t0 = min(min(m[qp][tile], acc0[0]), acc0[1]);
+                        int t1 = min(min(m[qp + 1][tile], acc1[0]), acc1[1]);
+#pragma unroll
+                        for (int reg = 2; reg < 16; reg += 2) {
+                            t0 = min(min(t0, acc0[reg]), acc0[reg + 1]);
+                            t1 = min(min(t1, acc1[reg]), acc1[reg + 1]);
+                        }
+                        m[qp][tile] = t0;
+                        m[qp + 1][tile] = t1;
+                    }
+                    // row direction: minimum over the wave's query blocks, per accumulator register
+                    if constexpr (VARIANT & 2) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) r[reg] = 0;
+                    } else if (qp == 0) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) r[reg] = min(acc0[reg], acc1[reg]);
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) r[reg] = min(min(r[reg], acc0[reg]), acc1[reg]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // keep the pairs apart: two chains live
+                }
+                int m0, m1;
+                if constexpr (VARIANT & 6) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) asm volatile("" ::"v"(r[reg]));
+                    m0 = r[0];
+                    m1 = r[1];
+                } else {
+                    half_wave_min16(r, m0, m1);
+                }
+                {
+                    // accumulator register reg of lane half g is tile row 8*(reg>>2) + 4*g + (reg&3);
+                    // this quad holds reg = 4*b4 + 2*b2 + b3 (m0) and 8 + that (m1).  One lane per
+                    // quad stores them; the others store into a dump area (no branch in the tile
+                    // loop: a branch here makes the compiler sink the column minima of all four
+                    // tiles below it and keep 128 accumulator registers alive)
+                    int *dst = row_dst + tile * 32;
+                    dst[0] = m0;
+                    dst[16] = m1;
+                }
+                if (tile + 1 < CHUNK / 32) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) { a[s] = a_nx[s]; tbv[s] = tb_nx[s]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);     // keep tiles apart (no hoisting -> no spills)
+            }
+        }
+        wait_direct();
+        __syncthreads();
+    }
+    if (tid < CHUNK) merge_rows(nchunks - 1, (nchunks - 1) & 1);
+
+    // ---- column results: two smallest of the 4 x 2 group minima of every query
+    if (wave_valid) {
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) {
+            const int lo01 = min(m[qb][0], m[qb][1]), hi01 = max(m[qb][0], m[qb][1]);
+            const int lo23 = min(m[qb][2], m[qb][3]), hi23 = max(m[qb][2], m[qb][3]);
+            const int a1 = min(lo01, lo23), a2 = min(max(lo01, lo23), min(hi01, hi23));
+            const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+            const int v1 = min(a1, b1), v2 = min(max(a1, b1), min(a2, b2));
+            const int row = q0 + QW * c + qb;
+            if (g == 0 && row < nb)
+                *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1 - lo_lane, v2 - lo_lane};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// candidates: one workgroup per ORDERED pair, rows in the query image's original order
+// ---------------------------------------------------------------------------------
+struct CandArgs {
+    const int32_t *sn2, *sinv, *img_off, *img_n;
+    const int32_t *pairs;        // [n_pairs][2] ordered (query image, train image)
+    const int32_t *osrc;         // [n_pairs][2]: unordered pair u, role (0: query = B, 1: query = A)
+    const int32_t *wg_off;       // [n_u+1]
+    const int64_t *col_off, *rowp_off, *out_off;
+    const int32_t *col, *rowp;
+    double thresh;
+    uint8_t *keep;
+    int32_t *seg_count;
+};
+
+__global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
+{
+    __shared__ int wsum[4];
+    const int p = blockIdx.x;
+    const int qimg = A.pairs[2 * p];
+    const int u = A.osrc[2 * p], role = A.osrc[2 * p + 1];
+    const int soff = A.img_off[qimg], n = A.img_n[qimg];
+    const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
+    const int nwg = A.wg_off[u + 1] - A.wg_off[u];
+    const int64_t ob = A.out_off[p];
+    int cnt = 0;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        const int pos = A.sinv[soff + r];
+        const int n2 = A.sn2[soff + pos], par = n2 & 1;
+        long long Lb, Ub;
+        if (role == 0) {
+            const v2i v = *reinterpret_cast<const v2i *>(A.col + 2 * (A.col_off[u] + pos));
+            const long long cq = n2 >> 1;
+            Lb = 2 * (v.x + cq) + par;
+            Ub = 2 * (v.y + cq) + par + 1;
+        } else {
+            int L = 0x7FFFFFFF, U1 = 0x7FFFFFFF, U2 = 0x7FFFFFFF;
+            for (int w = 0; w < nwg; ++w) {
+                const v4i e = *reinterpret_cast<const v4i *>(A.rowp + 4 * (A.rowp_off[u] + (int64_t)w * cap + pos));
+                L = min(L, e.x);
+                // merge the sorted pairs (U1, U2) and (e.y, e.z)
+                const int n1 = min(U1, e.y);
+                U2 = min(max(U1, e.y), min(U2, e.z));
+                U1 = n1;
+            }
+            Lb = 2ll * L + par;
+            Ub = 2ll * U2 + par + 1;
+        }
+        if (Lb < 0) Lb = 0;
+        const float f0 = (float)sqrt((double)Lb);
+        const float f1 = (float)sqrt((double)Ub);
+        const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
+        A.keep[ob + r] = k ? 1 : 0;
+        cnt += k ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) A.seg_count[p] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// order-preserving list of the candidate rows of every ordered pair
+__global__ __launch_bounds__(256) void symlist_kernel(const uint8_t *__restrict__ keep,
+                                                      const int64_t *__restrict__ seg_off,
+                                                      const int64_t *__restrict__ cand_off,
+                                                      int32_t *__restrict__ cand_q)
+{
+    __shared__ int wcnt[4];
+    const int seg = blockIdx.x;
+    const int64_t b = seg_off[seg], e = seg_off[seg + 1];
+    int64_t out = cand_off[seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = b; base < e; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool k = i < e && keep[i];
+        const unsigned long long mask = __ballot(k);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) woff += wcnt[w];
+            tot += wcnt[w];
+        }
+        if (k) cand_q[out + woff + before] = (int32_t)(i - b);
+        out += tot;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// exact top-2 of the candidate rows (original-order store), metric, final keep flag.
+// The candidate lists of all pairs are one flat array; workgroup w takes candidates w, w + grid,
+// ... (the survivors cluster in the few overlapping image pairs of a launch: one workgroup per
+// pair would leave most of the chip idle).  8 lanes share a train row (16 bytes each: coalesced
+// 1 KiB per wave instruction), a wave covers 8 rows per step, a workgroup 32.
+// ---------------------------------------------------------------------------------
+struct ExactArgs {
+    const int8_t *desc;          // original-order store (iamx_desc_pack_*)
+    const int32_t *norm_q;       // |s|^2 per row
+    const int32_t *img_off, *img_n;
+    const int32_t *pairs;
+    const int64_t *out_off, *cand_off;
+    const int32_t *cand_q;
+    int n_pairs;
+    double thresh;
+    int32_t *d2;                 // [rows][2]: exact (best, second) written for the candidates
+    int32_t *cand_t;
+    double *cand_metric;
+    uint8_t *cand_keep;
+    int32_t *zero_div;
+};
+
+__global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
+{
+    __shared__ int s_d1[4], s_i1[4], s_d2[4];
+    const int64_t total = A.cand_off[A.n_pairs];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = lane & 7, sub = lane >> 3;            // 16-byte slice of a row, row of the step
+    for (int64_t k = blockIdx.x; k < total; k += gridDim.x) {
+        int lo = 0, hi = A.n_pairs;                        // pair p: cand_off[p] <= k < cand_off[p+1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.cand_off[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int p = lo;
+        const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
+        const int qoff = A.img_off[qimg], toff = A.img_off[timg], nt = A.img_n[timg];
+        const int q = A.cand_q[k];
+        const v4i qv = *reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q) * D + part * 16);
+        const int nq2 = A.norm_q[qoff + q];
+        int d1 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, d2 = 0x7FFFFFFF;
+        const int8_t *tb = A.desc + (int64_t)toff * D + part * 16;
+        for (int r0 = wave * 8 + sub; r0 < nt; r0 += 128) {           // 4 rows in flight per lane
+            int dot[4], row[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                row[j] = r0 + 32 * j;
+                const int rr = row[j] < nt ? row[j] : nt - 1;
+                const v4i b = *reinterpret_cast<const v4i *>(tb + (int64_t)rr * D);
+                int t = __builtin_amdgcn_sdot4(qv.x, b.x, 0, false);
+                t = __builtin_amdgcn_sdot4(qv.y, b.y, t, false);
+                t = __builtin_amdgcn_sdot4(qv.z, b.z, t, false);
+                dot[j] = __builtin_amdgcn_sdot4(qv.w, b.w, t, false);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int t = dot[j];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                if (row[j] < nt) {
+                    const int dd = nq2 + A.norm_q[toff + row[j]] - 2 * t;
+                    if (dd < d1) { d2 = d1; d1 = dd; i1 = row[j]; }   // rows ascend per lane: ties keep the first
+                    else if (dd < d2) d2 = dd;
+                }
+            }
+        }
+        // merge (d1, i1, d2) triples: lexicographic (distance, row) for the best.  The 8 lanes of
+        // a row hold identical triples: start above them
+#pragma unroll
+        for (int sh = 32; sh >= 8; sh >>= 1) {
+            const int e1 = __shfl_xor(d1, sh), ei = __shfl_xor(i1, sh), e2 = __shfl_xor(d2, sh);
+            const bool other = e1 < d1 || (e1 == d1 && ei < i1);
+            const int n2 = other ? min(d1, e2) : min(d2, e1);
+            d1 = other ? e1 : d1;
+            i1 = other ? ei : i1;
+            d2 = n2;
+        }
+        if (lane == 0) { s_d1[wave] = d1; s_i1[wave] = i1; s_d2[wave] = d2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const int e1 = s_d1[w], ei = s_i1[w], e2 = s_d2[w];
+                const bool other = e1 < d1 || (e1 == d1 && ei < i1);
+                const int n2 = other ? min(d1, e2) : min(d2, e1);
+                d1 = other ? e1 : d1;
+                i1 = other ? ei : i1;
+                d2 = n2;
+            }
+            *reinterpret_cast<v2i *>(A.d2 + 2 * (A.out_off[p] + q)) = v2i{d1, d2};
+            // cv2 L2 distance = float32 sqrt; the rest in float64 like python (matcher.py:253-263)
+            const float f0 = (float)sqrt((double)d1);
+            const float f1 = (float)sqrt((double)d2);
+            double mt;
+            bool ok = false;
+            if (f1 == 0.0f) {
+                mt = __longlong_as_double(0x7FF8000000000000LL);    // python raises ZeroDivisionError
+                atomicAdd(A.zero_div, 1);
+            } else {
+                mt = (double)f0 * ((double)f0 / (double)f1);
+                ok = mt < A.thresh;
+            }
+            A.cand_t[k] = i1;
+            A.cand_metric[k] = mt;
+            A.cand_keep[k] = ok ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+// in-place, order-preserving compaction of every pair's candidate list to its survivors
+__global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restrict__ cand_off,
+                                                         const int32_t *__restrict__ cand_cnt,
+                                                         const uint8_t *__restrict__ cand_keep,
+                                                         int32_t *__restrict__ q, int32_t *__restrict__ t,
+                                                         double *__restrict__ metric,
+                                                         int32_t *__restrict__ surv_cnt)
+{
+    __shared__ int wcnt[4];
+    const int p = blockIdx.x;
+    const int64_t b = cand_off[p];
+    const int cnt = cand_cnt[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int out = 0;
+    for (int base = 0; base < cnt; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool k = i < cnt && cand_keep[b + i];
+        int vq = 0, vt = 0;
+        double vm = 0.0;
+        if (k) { vq = q[b + i]; vt = t[b + i]; vm = metric[b + i]; }
+        const unsigned long long mask = __ballot(k);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave] = __popcll(mask);
+        __syncthreads();                       // every read of this block precedes its writes
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) woff += wcnt[w];
+            tot += wcnt[w];
+        }
+        if (k) {
+            const int64_t o = b + out + woff + before;
+            q[o] = vq; t[o] = vt; metric[o] = vm;
+        }
+        out += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) surv_cnt[p] = out;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" int64_t iamx_desc3_rows_cap(int64_t n_rows)
+{
+    if (n_rows <= 0) return 0;
+    return (n_rows + CHUNK - 1) / CHUNK * CHUNK;
+}
+
+extern "C" int iamx_knn2sym_rows_per_wg(int form)
+{
+    return form == 2 ? 1024 : (form == 1 ? 512 : (form == 0 ? 256 : 0));
+}
+
+template <typename SRC>
+static int pack3_launch(Pack3Args P, int64_t total_rows, int max_rows, void *stream, const char *what)
+{
+    hipStream_t st = iamx::as_stream(stream);
+    if (total_rows <= 0 || max_rows <= 0) return IAMX_OK;
+    const int cap = (max_rows + CHUNK - 1) / CHUNK * CHUNK;
+    hipLaunchKernelGGL(pack3_rows_kernel<SRC>, dim3((unsigned)((total_rows * 8 + 255) / 256)),
+                       dim3(256), 0, st, P, total_rows);
+    hipLaunchKernelGGL(pack3_rank_kernel, dim3((unsigned)((max_rows + 255) / 256), (unsigned)P.n_img),
+                       dim3(256), 0, st, P);
+    hipLaunchKernelGGL(pack3_scatter_kernel<SRC>,
+                       dim3((unsigned)(((int64_t)cap * 8 + 255) / 256), (unsigned)P.n_img),
+                       dim3(256), 0, st, P);
+    return iamx::check_launch(what);
+}
+
+template <typename SRC>
+static int pack3_single(const SRC *src, int64_t n_rows, int8_t *dst, int32_t *sn2, int32_t *sct,
+                        int32_t *sperm, int32_t *sinv, int32_t *scratch, void *stream,
+                        const char *what)
+{
+    if (n_rows < 0 || n_rows > (1 << 24) || (n_rows > 0 && !src) || !dst || !sn2 || !sct || !sperm ||
+        !sinv || !scratch)
+        return iamx::fail(IAMX_EINVAL, "%s: null pointer or bad row count", what);
+    Pack3Args P{src, nullptr, n_rows, nullptr, dst, sn2, sct, sperm, sinv,
+                scratch, scratch + n_rows, scratch + 2 * n_rows, 1};
+    return pack3_launch<SRC>(P, n_rows, (int)n_rows, stream, what);
+}
+
+extern "C" int iamx_desc3_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *sn2,
+                                  int32_t *sct, int32_t *sperm, int32_t *sinv, int32_t *scratch,
+                                  void *stream)
+{
+    return pack3_single(src, n_rows, dst, sn2, sct, sperm, sinv, scratch, stream, "iamx_desc3_pack_u8");
+}
+
+extern "C" int iamx_desc3_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *sn2,
+                                   int32_t *sct, int32_t *sperm, int32_t *sinv, int32_t *scratch,
+                                   void *stream)
+{
+    return pack3_single(src, n_rows, dst, sn2, sct, sperm, sinv, scratch, stream, "iamx_desc3_pack_f32");
+}
+
+extern "C" int iamx_desc3_pack_batch_u8(const uint8_t *src, const int64_t *src_off,
+                                        const int32_t *dst_off, int n_img, int64_t total_rows,
+                                        int max_rows_per_image, int8_t *dst, int32_t *sn2,
+                                        int32_t *sct, int32_t *sperm, int32_t *sinv,
+                                        int32_t *scratch, void *stream)
+{
+    IAMX_REQUIRE(src && src_off && dst_off && dst && sn2 && sct && sperm && sinv && scratch,
+                 "null pointer");
+    IAMX_REQUIRE(n_img > 0 && total_rows >= 0 && max_rows_per_image >= 0, "bad count");
+    Pack3Args P{src, src_off, 0, dst_off, dst, sn2, sct, sperm, sinv,
+                scratch, scratch + total_rows, scratch + 2 * total_rows, n_img};
+    return pack3_launch<uint8_t>(P, total_rows, max_rows_per_image, stream, "iamx_desc3_pack_batch_u8");
+}
+
+extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const int32_t *sct,
+                                  const int32_t *img_off, const int32_t *img_n,
+                                  const int32_t *upairs, const int32_t *wg_off,
+                                  const int64_t *col_off, const int64_t *rowp_off, int n_u,
+                                  int total_wg, int form, int32_t *col, int32_t *rowp, void *stream)
+{
+    IAMX_REQUIRE(sdesc && sn2 && sct && img_off && img_n && upairs && wg_off && col_off && rowp_off &&
+                     col && rowp,
+                 "null pointer");
+    IAMX_REQUIRE(n_u >= 0 && total_wg >= 0, "negative count");
+    IAMX_REQUIRE(form >= 0 && form <= 2, "form must be 0 (256 rows), 1 (512) or 2 (1024)");
+    if (n_u == 0 || total_wg == 0) return IAMX_OK;
+    SymArgs a{sdesc, sn2, sct, img_off, img_n, upairs, wg_off, col_off, rowp_off, col, rowp, n_u, total_wg};
+    const dim3 g((unsigned)total_wg);
+    hipStream_t st = iamx::as_stream(stream);
+    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8>), g, dim3(512), 0, st, a);
+    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((knn2sym_kernel<2, 4>), g, dim3(256), 0, st, a);
+    return iamx::check_launch("iamx_knn2sym_sweep");
+}
+
+extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sinv,
+                                       const int32_t *img_off, const int32_t *img_n,
+                                       const int32_t *pairs, const int32_t *osrc,
+                                       const int32_t *wg_off, const int64_t *col_off,
+                                       const int64_t *rowp_off, const int64_t *out_off,
+                                       const int32_t *col, const int32_t *rowp, int n_pairs,
+                                       double thresh, uint8_t *keep, int32_t *cand_cnt,
+                                       int64_t *cand_off, int32_t *cand_q, void *stream)
+{
+    IAMX_REQUIRE(sn2 && sinv && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
+                     out_off && col && rowp && keep && cand_cnt && cand_off && cand_q,
+                 "null pointer");
+    if (n_pairs <= 0) return IAMX_OK;
+    hipStream_t st = iamx::as_stream(stream);
+    CandArgs a{sn2, sinv, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
+               thresh, keep, cand_cnt};
+    hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, a);
+    int rc = iamx_exclusive_scan_i32(cand_cnt, n_pairs, cand_off, stream);
+    if (rc != IAMX_OK) return rc;
+    hipLaunchKernelGGL(symlist_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, keep, out_off,
+                       cand_off, cand_q);
+    return iamx::check_launch("iamx_knn2sym_candidates");
+}
+
+extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *img_off,
+                                  const int32_t *img_n, const int32_t *pairs, const int64_t *out_off,
+                                  const int64_t *cand_off, const int32_t *cand_cnt, int32_t *cand_q,
+                                  int n_pairs, double thresh, int32_t *d2, int32_t *cand_t,
+                                  double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
+                                  int32_t *zero_div, void *stream)
+{
+    IAMX_REQUIRE(desc && norm_q && img_off && img_n && pairs && out_off && cand_off && cand_cnt &&
+                     cand_q && d2 && cand_t && cand_metric && cand_keep && surv_cnt && zero_div,
+                 "null pointer");
+    if (n_pairs <= 0) return IAMX_OK;
+    hipStream_t st = iamx::as_stream(stream);
+    ExactArgs a{desc, norm_q, img_off, img_n, pairs, out_off, cand_off, cand_q, n_pairs, thresh,
+                d2, cand_t, cand_metric, cand_keep, zero_div};
+    hipLaunchKernelGGL(symexact_kernel, dim3(256 * 16), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, cand_off,
+                       cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt);
+    return iamx::check_launch("iamx_knn2sym_exact");
+}
+
+#ifdef IAMX_ABLATE
+// timing ablations of the 1024-row form (not part of the C ABI; tools/knn2sym_ablate.py)
+extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const int32_t *sn2,
+                                       const int32_t *sct, const int32_t *img_off,
+                                       const int32_t *img_n, const int32_t *upairs,
+                                       const int32_t *wg_off, const int64_t *col_off,
+                                       const int64_t *rowp_off, int n_u, int total_wg, int32_t *col,
+                                       int32_t *rowp, void *stream)
+{
+    SymArgs a{sdesc, sn2, sct, img_off, img_n, upairs, wg_off, col_off, rowp_off, col, rowp, n_u, total_wg};
+    const dim3 g((unsigned)total_wg);
+    hipStream_t st = iamx::as_stream(stream);
+    switch (variant) {
+#define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
+        V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
+#undef V
+    default: return iamx::fail(IAMX_EINVAL, "unknown variant");
+    }
+    return iamx::check_launch("iamxdbg_knn2sym_variant");
+}
+#endif

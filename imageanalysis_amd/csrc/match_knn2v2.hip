@@ -734,6 +734,7 @@ extern "C" int iamx_knn2v2_pairs(const int8_t *desc_q, const int32_t *norm_q,
     return iamx::check_launch("iamx_knn2v2_pairs");
 }
 
+#ifdef IAMX_ABLATE   // scaffolding of tools/*_ablate.py: built into libiamx_ablate.so only
 extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const int32_t *norm_q,
                                       const int32_t *qimg_off, const int32_t *qimg_n,
                                       const int8_t *desc_t, const int32_t *cinit,
@@ -789,6 +790,7 @@ extern "C" int iamxdbg_knn2v2_variant(int variant, const int8_t *desc_q, const i
     }
     return iamx::check_launch("iamxdbg_knn2v2_variant");
 }
+#endif
 
 extern "C" int iamx_knn2v2_resolve(const int8_t *desc_q, const int32_t *norm_q,
                                    const int32_t *qimg_off, const int8_t *desc_t,

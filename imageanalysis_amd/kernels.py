@@ -60,6 +60,19 @@ class DescriptorStore(object):
         self.perm = torch.empty(total2, dtype=I32, device=dev)
         self.meta = torch.zeros((max(len(caps), 1), 4), dtype=I32, device=dev)
         self.img_off2 = torch.from_numpy(offs2[:-1].astype(np.int32)).to(dev)
+        # sorted layout of the symmetric sweep (rows ordered by |a-128|^2, include/iamx.h "desc3")
+        caps3 = [int(L.iamx_desc3_rows_cap(c)) for c in self.counts]
+        offs3 = np.zeros(len(caps3) + 1, np.int64)
+        np.cumsum(caps3, out=offs3[1:])
+        self.caps3 = np.asarray(caps3, np.int64)
+        self.offsets3 = offs3
+        total3 = max(int(offs3[-1]), 1)
+        self.desc3 = torch.empty((total3, 128), dtype=I8, device=dev)
+        self.sn2 = torch.empty(total3, dtype=I32, device=dev)
+        self.sct = torch.empty(total3, dtype=I32, device=dev)
+        self.sperm = torch.empty(total3, dtype=I32, device=dev)
+        self.sinv = torch.empty(total3, dtype=I32, device=dev)
+        self.img_off3 = torch.from_numpy(offs3[:-1].astype(np.int32)).to(dev)
 
     def __len__(self):
         return len(self.counts)
@@ -89,11 +102,17 @@ class DescriptorStore(object):
         check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
                   _ptr(self.perm[o2:]), _ptr(self.meta[i]), _ptr(scratch), stream_ptr()),
               'iamx_desc2_pack')
+        o3 = int(self.offsets3[i])
+        fn3 = lib().iamx_desc3_pack_u8 if is_u8 else lib().iamx_desc3_pack_f32
+        scratch3 = torch.empty(3 * n, dtype=I32, device=src.device)
+        check(fn3(_ptr(src), n, _ptr(self.desc3[o3:]), _ptr(self.sn2[o3:]), _ptr(self.sct[o3:]),
+                  _ptr(self.sperm[o3:]), _ptr(self.sinv[o3:]), _ptr(scratch3), stream_ptr()),
+              'iamx_desc3_pack')
         # the source buffer must outlive the enqueued kernels
         if sync:
             torch.cuda.current_stream().synchronize()
             return ()
-        return (src, scratch)
+        return (src, scratch, scratch3)
 
     @classmethod
     def from_arrays(cls, arrays):
@@ -105,6 +124,59 @@ class DescriptorStore(object):
 
 def wg_per_pair(nq):
     return (int(nq) + 255) // 256
+
+
+SYM_ROWS_PER_WG = {0: 256, 1: 512, 2: 1024}       # iamx_knn2sym_rows_per_wg(form)
+
+
+def sym_tables(pairs, counts, caps3):
+    """Host-side launch tables of the symmetric sweep (include/iamx.h, iamx_knn2sym_sweep) for a
+    batch of ORDERED pairs [P,2], or None when the batch does not hold both directions of every
+    image pair exactly once.  Unordered pair u = (B image, A image): B = the query image of the
+    first of its two ordered pairs; the list is sorted by A so that consecutive workgroups
+    re-read the same streamed rows from L2.  osrc[p] = (u, role) with role 0 when the query image
+    of ordered pair p is B (its bounds come from the lane-local column direction), 1 when it is A."""
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    P = len(pairs)
+    if P == 0 or P % 2 or (pairs[:, 0] == pairs[:, 1]).any():
+        return None
+    counts = np.asarray(counts, np.int64)
+    caps3 = np.asarray(caps3, np.int64)
+    n_img = len(counts)
+    key = pairs[:, 0].astype(np.int64) * n_img + pairs[:, 1]
+    mkey = pairs[:, 1].astype(np.int64) * n_img + pairs[:, 0]
+    order = np.argsort(key, kind='stable')
+    skey = key[order]
+    if (skey[1:] == skey[:-1]).any():
+        return None                                   # an ordered pair listed twice
+    where = np.minimum(np.searchsorted(skey, mkey), P - 1)
+    if (skey[where] != mkey).any():
+        return None                                   # a pair without its mirror
+    mirror = order[where]
+    first = np.nonzero(np.arange(P) < mirror)[0]      # one ordered pair per unordered pair
+    first = first[np.argsort(pairs[first, 1], kind='stable')]
+    up = pairs[first]                                 # (B, A)
+    n_u = len(up)
+    nb = counts[up[:, 0]]
+    mn = int(min(nb.min(), counts[up[:, 1]].min()))
+    if mn < 2:
+        return None
+    form = 0 if mn < 2048 else (2 if mn >= 4096 else 1)
+    rows_wg = SYM_ROWS_PER_WG[form]
+    nwg = (nb + rows_wg - 1) // rows_wg
+    wg = np.zeros(n_u + 1, np.int64)
+    np.cumsum(nwg, out=wg[1:])
+    if wg[-1] >= 2 ** 31:
+        return None
+    col_off = np.zeros(n_u + 1, np.int64)
+    np.cumsum(caps3[up[:, 0]], out=col_off[1:])
+    rowp_off = np.zeros(n_u + 1, np.int64)
+    np.cumsum(nwg * caps3[up[:, 1]], out=rowp_off[1:])
+    osrc = np.zeros((P, 2), np.int32)
+    osrc[first, 0] = np.arange(n_u)
+    osrc[mirror[first], 0] = np.arange(n_u)
+    osrc[mirror[first], 1] = 1
+    return dict(upairs=up, form=form, wg=wg, col_off=col_off, rowp_off=rowp_off, osrc=osrc)
 
 
 def knn2_pairs(store, pairs):
@@ -250,6 +322,16 @@ class PairWorkspace(object):
         self.tile = torch.empty(r, dtype=I32, device=dev)
         self.unresolved = torch.zeros(1, dtype=I32, device=dev)
         self.surv_cnt = torch.zeros(p, dtype=I32, device=dev)
+        # symmetric sweep: bounds per row (allocated on first use, grown when a batch needs more)
+        self.col = self.rowp = None
+        self.cand_keep = torch.empty(r, dtype=U8, device=dev)
+
+    def ensure_sym(self, col_rows, rowp_rows):
+        dev = self.d2.device
+        if self.col is None or self.col.shape[0] < col_rows:
+            self.col = torch.empty((max(col_rows, 1), 2), dtype=I32, device=dev)
+        if self.rowp is None or self.rowp.shape[0] < rowp_rows:
+            self.rowp = torch.empty((max(rowp_rows, 1), 4), dtype=I32, device=dev)
 
     def survivor_counts(self, n_pairs):
         """host copies of (first, count) per pair only"""
@@ -270,7 +352,10 @@ class PairBatch(object):
     """Device-side launch tables of one batch of ordered (query image, train image) pairs.
     `run()` only enqueues kernels on the current stream (no host sync, no allocation)."""
 
-    def __init__(self, store, pairs):
+    def __init__(self, store, pairs, sym=None):
+        """sym: None = use the symmetric sweep (one MFMA pass for both directions of an image
+        pair) when the batch holds both directions of every pair, False = never (one sweep per
+        ordered pair), True = require it."""
         dev = require_gpu()
         self.store = store
         pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
@@ -298,6 +383,53 @@ class PairBatch(object):
         np.cumsum((nq + self.fast_rows - 1) // self.fast_rows, out=wgf[1:])
         self.total_wg_fast = int(wgf[-1])
         self.d_wg_fast = torch.from_numpy(wgf.astype(np.int32)).to(dev)
+        self.sym = False
+        if sym is not False:
+            self._setup_sym(dev)
+            if sym and not self.sym:
+                raise ValueError("symmetric sweep needs both directions of every pair (i != j) "
+                                 "in the batch")
+
+    def _setup_sym(self, dev):
+        t = sym_tables(self.pairs, self.store.counts, self.store.caps3)
+        if t is None:
+            return
+        assert SYM_ROWS_PER_WG[t['form']] == int(lib().iamx_knn2sym_rows_per_wg(t['form']))
+        self.sym = True
+        self.sym_form = t['form']
+        self.n_u, self.sym_total_wg = len(t['upairs']), int(t['wg'][-1])
+        self.sym_col_rows, self.sym_rowp_rows = int(t['col_off'][-1]), int(t['rowp_off'][-1])
+        self.d_upairs = torch.from_numpy(np.ascontiguousarray(t['upairs'])).to(dev)
+        self.d_sym_wg = torch.from_numpy(t['wg'].astype(np.int32)).to(dev)
+        self.d_col_off = torch.from_numpy(t['col_off'][:-1].copy()).to(dev)
+        self.d_rowp_off = torch.from_numpy(t['rowp_off'][:-1].copy()).to(dev)
+        self.d_osrc = torch.from_numpy(t['osrc']).to(dev)
+
+    def run_sym_sweep(self, ws):
+        st = self.store
+        ws.ensure_sym(self.sym_col_rows, self.sym_rowp_rows)
+        check(lib().iamx_knn2sym_sweep(_ptr(st.desc3), _ptr(st.sn2), _ptr(st.sct), _ptr(st.img_off3),
+                                       _ptr(st.img_n), _ptr(self.d_upairs), _ptr(self.d_sym_wg),
+                                       _ptr(self.d_col_off), _ptr(self.d_rowp_off), self.n_u,
+                                       self.sym_total_wg, self.sym_form, _ptr(ws.col), _ptr(ws.rowp),
+                                       stream_ptr()), 'iamx_knn2sym_sweep')
+
+    def run_sym_filter(self, ws, thresh):
+        """candidate rows from the sweep's bounds, exact top-2 + metric test for those rows,
+        survivors compacted in place (pair p: surv_*[surv_off[p] .. + surv_cnt[p]))"""
+        L, s, st = lib(), stream_ptr(), self.store
+        check(L.iamx_knn2sym_candidates(_ptr(st.sn2), _ptr(st.sinv), _ptr(st.img_off3), _ptr(st.img_n),
+                                        _ptr(self.d_pairs), _ptr(self.d_osrc), _ptr(self.d_sym_wg),
+                                        _ptr(self.d_col_off), _ptr(self.d_rowp_off), _ptr(self.d_out),
+                                        _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),
+                                        _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_off),
+                                        _ptr(ws.surv_q), s), 'iamx_knn2sym_candidates')
+        check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off), _ptr(st.img_n),
+                                   _ptr(self.d_pairs), _ptr(self.d_out), _ptr(ws.surv_off),
+                                   _ptr(ws.seg_count), _ptr(ws.surv_q), self.n_pairs, float(thresh),
+                                   _ptr(ws.d2), _ptr(ws.surv_t), _ptr(ws.surv_metric),
+                                   _ptr(ws.cand_keep), _ptr(ws.surv_cnt), _ptr(ws.zero_div), s),
+              'iamx_knn2sym_exact')
 
     def run_knn2(self, ws):
         st = self.store
@@ -322,6 +454,8 @@ class PairBatch(object):
     # ---- fast form: distances + tile in the sweep, train index only for the survivors
     def run_knn2_fast(self, ws, exact_second=False):
         st = self.store
+        if self.sym and not exact_second:
+            return self.run_sym_sweep(ws)
         if exact_second and self.fast_rows == 1024:          # the exact-second form stops at 512
             self._use_rows(512)
         check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
@@ -342,6 +476,8 @@ class PairBatch(object):
     def run_filter_fast(self, ws, thresh, exact_second=False):
         """threshold + compaction + train rows.  With the bound form of the sweep the first
         threshold keeps a superset; iamx_knn2v2_finish makes it exact (include/iamx.h)."""
+        if self.sym and not exact_second:
+            return self.run_sym_filter(ws, thresh)
         L, s, st = lib(), stream_ptr(), self.store
         check(L.iamx_match_metric(_ptr(ws.d2), _ptr(self.d_out), self.n_pairs, float(thresh),
                                   _ptr(ws.metric), _ptr(ws.keep), _ptr(ws.seg_count),
@@ -371,7 +507,8 @@ class PairBatch(object):
 
     def run(self, ws, thresh, fast=True):
         """enqueue top-2 + metric threshold + survivor compaction (+ index resolve).
-        fast: True = bound-form sweep (shipped), 'exact' = exact-second fast sweep,
+        fast: True = the shipped form (symmetric sweep when the batch holds both directions of
+        every pair, else the one-direction bound form), 'exact' = exact-second fast sweep,
         False = the general kernel that tracks indices in the sweep."""
         if self.rows > ws.max_rows or self.n_pairs > ws.max_pairs:
             raise ValueError("workspace too small for this batch")

@@ -175,6 +175,70 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
                        int32_t *zero_div, int32_t *n_unresolved, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * K2, symmetric form (shipped for batches that hold both directions of every image pair, which
+ * is what bidirectional_pair_matches asks for, scripts/lib/matcher.py:304-347): ONE MFMA sweep
+ * of the distance matrix of an unordered pair serves both directions.  The sweep only produces,
+ * for every row of both images, a lower bound of the best and an upper bound of the second
+ * squared distance; the reference's test d0*(d0/d1) < thresh (:253-263) is monotone in both,
+ * so iamx_knn2sym_candidates keeps a superset of its survivors and iamx_knn2sym_exact
+ * recomputes exactly those rows against the whole train image (lowest train row on ties, like
+ * cv2.BFMatcher) and re-applies the test.  What leaves the path -- surv_q / surv_t /
+ * surv_metric per ordered pair in ascending query order, d2 of the survivors, zero_div -- is
+ * identical to iamx_knn2_l2_pairs + iamx_match_metric + iamx_match_compact.
+ *
+ * Store ("desc3"): the rows of an image sorted by sn2 = |a-128|^2 (stable), zero-padded to
+ * rows_cap = iamx_desc3_rows_cap(n) (a multiple of 128) rows:
+ *   dst DEV [rows_cap][128] int8; sn2 / sct / sperm / sinv DEV [rows_cap] int32 with
+ *   sct = (sn2 + 2*sum(a-128)) >> 1 (2^30-ish on padding), sperm = original row of a sorted
+ *   row (-1 on padding), sinv = sorted position of an original row.
+ *   scratch DEV [3 * n_rows] int32 (3 * total_rows for the batch form, laid out like
+ *   iamx_desc2_pack_batch_u8).
+ * Sweep: upairs DEV [n_u][2] = (B image, A image): B rows stay in registers (1024 / 512 / 256
+ * per workgroup for form 2 / 1 / 0 = iamx_knn2sym_rows_per_wg(form)), A rows stream through LDS.
+ *   wg_off   DEV [n_u+1] int32  scan of ceil(n_B / rows_per_wg);  total_wg = wg_off[n_u]
+ *   col_off  DEV [n_u] int64    first entry of pair u in col  (scan of rows_cap(B))
+ *   rowp_off DEV [n_u] int64    first entry of pair u in rowp (scan of workgroups x rows_cap(A))
+ *   col  DEV [..][2] int32, rowp DEV [..][4] int32 (16-byte aligned): the bounds, internal format
+ * Candidates: pairs DEV [n_pairs][2] ordered (query image, train image); osrc DEV [n_pairs][2] =
+ *   (index u of its unordered pair, role: 0 if the query image is B, 1 if it is A);
+ *   out_off DEV [n_pairs+1] int64 rows of each ordered pair; keep DEV [rows] uint8 scratch;
+ *   cand_cnt DEV [n_pairs], cand_off DEV [n_pairs+1] (written), cand_q DEV [rows]: candidate
+ *   query rows (original numbering, ascending) of pair p at cand_off[p] .. + cand_cnt[p].
+ * Exact: desc / norm_q / img_off = the ORIGINAL-order store of iamx_desc_pack_*.  Writes d2 DEV
+ *   [rows][2] for the candidate rows, then compacts every pair's list in place to its survivors:
+ *   pair p owns cand_q / cand_t / cand_metric [cand_off[p] .. + surv_cnt[p]); zero_div is
+ *   incremented for every row whose exact second distance is 0 (matcher.py:255 divides by it).
+ * ------------------------------------------------------------------------------------ */
+int64_t iamx_desc3_rows_cap(int64_t n_rows);
+int iamx_knn2sym_rows_per_wg(int form);
+int iamx_desc3_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *sn2,
+                       int32_t *sct, int32_t *sperm, int32_t *sinv, int32_t *scratch,
+                       void *stream);
+int iamx_desc3_pack_f32(const float *src, int64_t n_rows, int8_t *dst, int32_t *sn2,
+                        int32_t *sct, int32_t *sperm, int32_t *sinv, int32_t *scratch,
+                        void *stream);
+int iamx_desc3_pack_batch_u8(const uint8_t *src, const int64_t *src_off, const int32_t *dst_off,
+                             int n_img, int64_t total_rows, int max_rows_per_image, int8_t *dst,
+                             int32_t *sn2, int32_t *sct, int32_t *sperm, int32_t *sinv,
+                             int32_t *scratch, void *stream);
+int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const int32_t *sct,
+                       const int32_t *img_off, const int32_t *img_n, const int32_t *upairs,
+                       const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
+                       int n_u, int total_wg, int form, int32_t *col, int32_t *rowp, void *stream);
+int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sinv, const int32_t *img_off,
+                            const int32_t *img_n, const int32_t *pairs, const int32_t *osrc,
+                            const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
+                            const int64_t *out_off, const int32_t *col, const int32_t *rowp,
+                            int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
+                            int64_t *cand_off, int32_t *cand_q, void *stream);
+int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *img_off,
+                       const int32_t *img_n, const int32_t *pairs, const int64_t *out_off,
+                       const int64_t *cand_off, const int32_t *cand_cnt, int32_t *cand_q,
+                       int n_pairs, double thresh, int32_t *d2, int32_t *cand_t,
+                       double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
+                       int32_t *zero_div, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Per-pair match filters on the device, both directions of n_pairs image pairs, one workgroup
  * per pair -- replaces the python between the metric threshold and find_matches' bookkeeping:
  *   scripts/lib/matcher.py:258-269 (stable sort by metric, clip 2000), :271-283 (< min_pairs),

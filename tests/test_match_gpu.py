@@ -215,11 +215,13 @@ def test_config2_shape_properties():
     assert np.array_equal(dd2.cpu().numpy(), d2[off[3]:off[4]][p2])
 
 
-def _run_batch(store, pairs, thresh, fast):
-    """survivor lists are returned densely packed per pair (soff = exclusive scan of counts)"""
+def _run_batch(store, pairs, thresh, fast, sym=False):
+    """survivor lists are returned densely packed per pair (soff = exclusive scan of counts);
+    sym=False: one sweep per ordered pair (the symmetric sweep has its own tests in
+    tests/test_match_sym_gpu.py)"""
     import torch
     from imageanalysis_amd import kernels
-    pb = kernels.PairBatch(store, np.asarray(pairs, np.int32))
+    pb = kernels.PairBatch(store, np.asarray(pairs, np.int32), sym=sym)
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
     pb.run(ws, thresh, fast=fast)
     torch.cuda.synchronize()
@@ -322,7 +324,7 @@ def test_bound_form_second_inside_best_group():
         assert np.array_equal(a['d2'][:500][a['sq'][lo:hi]], rd2[a['sq'][lo:hi]])
         assert np.array_equal(a['st'][lo:hi], ridx[a['sq'][lo:hi], 0])
     # the bound really was loose somewhere (otherwise this test exercises nothing)
-    pb = kernels.PairBatch(store, np.array([[0, 1]], np.int32))
+    pb = kernels.PairBatch(store, np.array([[0, 1]], np.int32), sym=False)
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
     pb.run_knn2_fast(ws)
     d2b = ws.d2[:500].cpu().numpy()

@@ -1,0 +1,257 @@
+"""GPU: the shipped matching forms against the oracle -- the symmetric sweep (one MFMA pass for
+both directions of an image pair + exact re-scan of the candidate rows) in all three workgroup
+shapes, and the one-direction fast forms at the sizes that select their 512- and 1024-row
+instantiations.  Integer work -> bit-exact: survivor rows, train rows, metrics, squared
+distances of the survivors (scripts/lib/matcher.py:203-216,253-269)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+MATCH_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'match_*.npz')))
+
+
+def _sift_like(rng, n):
+    g = rng.gamma(0.6, 1.0, size=(n, 128))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g = np.minimum(g, 0.2)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    return np.clip(np.rint(g * 512.0), 0, 255).astype(np.uint8)
+
+
+def _run(store, pairs, thresh, fast=True, sym=None):
+    import torch
+    from imageanalysis_amd import kernels
+    pb = kernels.PairBatch(store, np.asarray(pairs, np.int32), sym=sym)
+    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb.run(ws, thresh, fast=fast)
+    torch.cuda.synchronize()
+    first, count, q, t, m = ws.survivors(pb.n_pairs)
+    take = np.concatenate([np.arange(f, f + c) for f, c in zip(first, count)]
+                          + [np.zeros(0, np.int64)]).astype(np.int64)
+    soff = np.zeros(pb.n_pairs + 1, np.int64)
+    np.cumsum(count, out=soff[1:])
+    return dict(d2=ws.d2[:pb.rows].cpu().numpy(), soff=soff, sq=q[take], st=t[take], sm=m[take],
+                unresolved=int(ws.unresolved.item()), zero_div=int(ws.zero_div.item()),
+                off=pb.out_off, pb=pb)
+
+
+def _oracle_survivors(q, t, thresh):
+    from oracle import cpu_ref
+    ridx, rd2 = cpu_ref.knn2_l2_u8(q, t)
+    d = np.sqrt(rd2.astype(np.float32)).astype(np.float64)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        metric = d[:, 0] * (d[:, 0] / d[:, 1])
+    keep = np.nonzero(metric < thresh)[0]              # NaN (d1 == 0) compares false
+    return keep, ridx[keep, 0], metric[keep], rd2[keep], int((rd2[:, 1] == 0).sum())
+
+
+def _same_survivors(a, b):
+    assert a['zero_div'] == b['zero_div']
+    for k in ('soff', 'sq', 'st', 'sm'):
+        assert np.array_equal(a[k], b[k]), k
+    # squared distances of the survivors
+    for p in range(len(a['soff']) - 1):
+        rows = a['off'][p] + a['sq'][a['soff'][p]:a['soff'][p + 1]]
+        assert np.array_equal(a['d2'][rows], b['d2'][rows]), p
+
+
+def test_desc3_store_layout():
+    """sorted store of the symmetric sweep: stable sort by |a-128|^2, padding, inverse maps,
+    C-operand terms"""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(4)
+    for n in (2, 127, 128, 129, 1000, 4096, 5000):
+        a = _sift_like(rng, n)
+        if n >= 1000:
+            a[500:600] = a[100:200]                   # equal keys: the sort must be stable
+        st = kernels.DescriptorStore.from_arrays([a])
+        cap = -(-n // 128) * 128
+        assert int(st.offsets3[1]) == cap
+        s = a.astype(np.int64) - 128
+        n2 = (s * s).sum(1)
+        nb = n2 + 2 * s.sum(1)
+        order = np.argsort(n2, kind='stable')
+        perm = st.sperm.cpu().numpy()[:cap]
+        assert np.array_equal(perm[:n], order) and (perm[n:] == -1).all()
+        inv = st.sinv.cpu().numpy()[:cap]
+        assert np.array_equal(inv[:n][order], np.arange(n)) and (inv[n:] == -1).all()
+        rows = st.desc3.cpu().numpy()[:cap].astype(np.int64)
+        assert np.array_equal(rows[:n], s[order]) and (rows[n:] == 0).all()
+        assert np.array_equal(st.sn2.cpu().numpy()[:n], n2[order])
+        sct = st.sct.cpu().numpy()[:cap]
+        assert np.array_equal(sct[:n], nb[order] >> 1) and (sct[n:] == 0x3F000000).all()
+    # float32 input (what the reference hands over) packs like uint8
+    a = _sift_like(rng, 300)
+    s1 = kernels.DescriptorStore.from_arrays([a])
+    s2 = kernels.DescriptorStore.from_arrays([a.astype(np.float32)])
+    for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
+        assert np.array_equal(getattr(s1, name).cpu().numpy(), getattr(s2, name).cpu().numpy()), name
+
+
+@pytest.mark.parametrize('path', MATCH_CASES, ids=os.path.basename)
+def test_sym_equals_general_path_golden(path):
+    from imageanalysis_amd import kernels
+    g = np.load(path)
+    store = kernels.DescriptorStore.from_arrays([g['des1'], g['des2']])
+    thresh = 270.0 * float(g['match_ratio'])
+    a = _run(store, [[0, 1], [1, 0]], thresh, sym=True)
+    b = _run(store, [[0, 1], [1, 0]], thresh, fast=False, sym=False)
+    assert a['pb'].sym and not b['pb'].sym
+    _same_survivors(a, b)
+    # and == the reference's pre-GMS list after the host's stable sort + clip
+    for p, tag in enumerate(['fwd', 'rev']):
+        lo, hi = a['soff'][p], a['soff'][p + 1]
+        order = np.argsort(a['sm'][lo:hi], kind='stable')[:2000]
+        got = np.stack([a['sq'][lo:hi][order], a['st'][lo:hi][order]], 1)
+        if len(g['pregms_%s' % tag]):
+            assert np.array_equal(got, g['pregms_%s' % tag])
+
+
+def _survey(rng, sizes, overlap=0.3):
+    imgs = [_sift_like(rng, n) for n in sizes]
+    for k in range(1, len(imgs)):                    # neighbours overlap: real survivors
+        m = int(min(len(imgs[k]), len(imgs[k - 1])) * overlap)
+        src = rng.permutation(len(imgs[k - 1]))[:m]
+        dst = rng.permutation(len(imgs[k]))[:m]
+        imgs[k][dst] = np.clip(imgs[k - 1][src].astype(int) + rng.integers(-6, 7, (m, 128)), 0, 255)
+    return imgs
+
+
+@pytest.mark.parametrize('sizes,form', [
+    ([4096, 4097, 5000, 4224, 4608, 4096], 2),       # 1024-row workgroups (BASELINE configs[1] shape)
+    ([2048, 2049, 3000, 4095, 2500], 1),             # 512-row workgroups
+    ([300, 2, 257, 1024, 129, 640, 3], 0),           # 256-row workgroups, ragged and tiny images
+], ids=['rows1024', 'rows512', 'rows256'])
+def test_sym_forms_vs_general_kernel_and_oracle(sizes, form):
+    """every ordered pair of a small survey: survivors of the symmetric path == the general
+    kernel's; a sample of pairs == oracle/cpu_ref.c.  Planted: near copies between neighbours,
+    exact duplicates inside an image (lowest train row must win), duplicates of the best (second
+    == best), identical rows across images (distance 0 -> ZeroDivisionError count), an image
+    whose rows all share one parity of |a-128|^2."""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(100 + form)
+    imgs = _survey(rng, sizes)
+    big = int(np.argmax(sizes))
+    n = sizes[big]
+    if n >= 600:
+        imgs[big][n // 2:n // 2 + 200] = imgs[big][:200]          # duplicates 'n/2' rows apart
+        other = (big + 2) % len(sizes)
+        m = min(100, sizes[other])
+        imgs[other][:m] = imgs[big][300:300 + m]                   # identical rows across images
+    if form == 0:
+        imgs[1][:] = 128                                           # two identical rows, one parity
+    else:
+        par = imgs[0].astype(np.int64).sum(1) & 1                  # parity of |a-128|^2 = parity of sum
+        imgs[0][:, 5] = np.where(par == 1, imgs[0][:, 5] ^ 1, imgs[0][:, 5])
+        assert (((imgs[0].astype(np.int64) - 128) ** 2).sum(1) & 1).max() == 0
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    for thresh in (270.0 * 0.75, 1e9):
+        if thresh > 1e6 and form == 2:
+            sub = [p for p in pairs if p[0] < 3 and p[1] < 3]      # all rows are candidates here
+        else:
+            sub = pairs
+        a = _run(store, sub, thresh, sym=True)
+        assert a['pb'].sym and a['pb'].sym_form == form and a['unresolved'] == 0
+        b = _run(store, sub, thresh, fast=False, sym=False)
+        _same_survivors(a, b)
+        if thresh < 1e6:
+            assert (np.diff(a['soff']) > 50).sum() >= 2            # the planted overlaps survive
+        # oracle on a sample of ordered pairs (both roles of the sweep: a pair and its mirror)
+        sample = [0, 1, len(sub) // 2, len(sub) - 1]
+        sample += [sub.index((j, i)) for (i, j) in [sub[k] for k in sample]]
+        for p in sorted(set(sample)):
+            i, j = sub[p]
+            keep, tr, mt, d2, zd = _oracle_survivors(imgs[i], imgs[j], thresh)
+            lo, hi = a['soff'][p], a['soff'][p + 1]
+            assert np.array_equal(a['sq'][lo:hi], keep), (i, j)
+            assert np.array_equal(a['st'][lo:hi], tr), (i, j)
+            assert np.array_equal(a['sm'][lo:hi], mt), (i, j)
+            assert np.array_equal(a['d2'][a['off'][p] + keep], d2), (i, j)
+
+
+def test_sym_second_inside_best_group_and_loose_bounds():
+    """Adversarial for the bounds of the sweep: the true second neighbour next to the best (same
+    group of train rows), on both sides of the threshold; duplicates of the best; exact-zero
+    seconds; and an image whose |a-128|^2 values spread widely (loose row-direction bounds)."""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(77)
+    n = 640
+    train = _sift_like(rng, n)
+    query = _sift_like(rng, 500)
+    rows = rng.choice(np.arange(0, n - 1, 2), 200, replace=False)
+    for k, r in enumerate(rows):
+        query[k] = np.clip(train[r].astype(int) + rng.integers(-2, 3, 128), 0, 255)
+        amp = (1, 3, 8, 20)[k % 4]
+        train[r + 1] = np.clip(train[r].astype(int) + rng.integers(-amp, amp + 1, 128), 0, 255)
+    for k in range(200, 230):
+        r = rows[k - 200]
+        query[k] = train[r]
+        train[r + 1] = train[r]
+    query[300:400] = rng.integers(0, 256, (100, 128))              # wide norm spread
+    train[500:600] = rng.integers(0, 256, (100, 128))
+    store = kernels.DescriptorStore.from_arrays([query, train])
+    for thresh in (270.0 * 0.75, 270.0 * 0.6, 1e9):
+        a = _run(store, [[0, 1], [1, 0]], thresh, sym=True)
+        b = _run(store, [[0, 1], [1, 0]], thresh, fast=False, sym=False)
+        assert b['zero_div'] > 0
+        _same_survivors(a, b)
+        for p, (x, y) in enumerate(((query, train), (train, query))):
+            keep, tr, mt, d2, zd = _oracle_survivors(x, y, thresh)
+            lo, hi = a['soff'][p], a['soff'][p + 1]
+            assert np.array_equal(a['sq'][lo:hi], keep) and np.array_equal(a['st'][lo:hi], tr)
+            assert np.array_equal(a['sm'][lo:hi], mt)
+
+
+def test_sym_extreme_values_and_uniform_images():
+    """all-0 / all-255 / constant images: maximum distances, every distance equal, zero seconds"""
+    from imageanalysis_amd import kernels
+    a0 = np.zeros((200, 128), np.uint8)
+    a0[1::2] = 255
+    a1 = np.zeros((300, 128), np.uint8)
+    a1[::3] = 255
+    a1[1::3] = 128
+    a2 = np.full((130, 128), 255, np.uint8)
+    store = kernels.DescriptorStore.from_arrays([a0, a1, a2])
+    pairs = [(i, j) for i in range(3) for j in range(3) if i != j]
+    for thresh in (202.5, 1e9):
+        a = _run(store, pairs, thresh, sym=True)
+        b = _run(store, pairs, thresh, fast=False, sym=False)
+        _same_survivors(a, b)
+        assert a['zero_div'] > 0
+
+
+@pytest.mark.parametrize('sizes,rows', [([4096, 4097, 5000, 4224], 1024), ([2048, 2049, 3000, 4095], 512)],
+                         ids=['rows1024', 'rows512'])
+def test_one_direction_fast_forms_at_their_sizes(sizes, rows):
+    """iamx_knn2v2_pairs in its 1024-row (8 waves, direct global->LDS staging) and 512-row
+    instantiations -- what batches WITHOUT mirrored pairs run -- against the general kernel on
+    every ordered pair and the oracle on four of them."""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(rows)
+    imgs = _survey(rng, sizes)
+    imgs[1][2000:2040] = imgs[1][:40]                              # ties: lowest row wins
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    thresh = 270.0 * 0.75
+    for form in (True, 'exact'):
+        a = _run(store, pairs, thresh, fast=form, sym=False)
+        assert not a['pb'].sym and a['unresolved'] == 0
+        assert a['pb'].fast_rows == (rows if form is True else 512)
+        b = _run(store, pairs, thresh, fast=False, sym=False)
+        _same_survivors(a, b)
+        assert np.array_equal(a['d2'][:, 0], b['d2'][:, 0])        # best exact on every row
+        assert (a['d2'][:, 1] >= b['d2'][:, 1]).all()
+        for p in (0, 3, 7, len(pairs) - 1):
+            i, j = pairs[p]
+            keep, tr, mt, d2, zd = _oracle_survivors(imgs[i], imgs[j], thresh)
+            lo, hi = a['soff'][p], a['soff'][p + 1]
+            assert np.array_equal(a['sq'][lo:hi], keep) and np.array_equal(a['st'][lo:hi], tr)
+            assert np.array_equal(a['sm'][lo:hi], mt)
+            assert np.array_equal(a['d2'][a['off'][p] + keep], d2)

@@ -1,0 +1,53 @@
+"""Timing ablation of the symmetric sweep (GPU box only).  Needs the ablation build:
+    IAMX_ABLATE=1 bash imageanalysis_amd/csrc/build.sh
+    IAMX_LIB=imageanalysis_amd/libiamx_ablate.so python tools/knn2sym_ablate.py [variants]
+variant bits: 1 no column direction, 2 no row direction, 4 row direction without the cross-lane
+butterfly, 8 no MFMA (0 = the shipped kernel)."""
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, '.')
+from imageanalysis_amd import kernels
+from imageanalysis_amd.kernels import _ptr, lib, stream_ptr
+import os
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3, 4, 5, 8, 11]
+n_img = int(os.environ.get('ABL_IMAGES', '64'))
+reps = int(os.environ.get('ABL_REPS', '4'))
+max_pairs = int(os.environ.get('ABL_PAIRS', '1000000'))
+rng = np.random.default_rng(0)
+
+
+def sift_like(n):
+    g = rng.gamma(0.6, 1.0, size=(n, 128))
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    g = np.minimum(g, 0.2)
+    g /= np.linalg.norm(g, axis=1, keepdims=True)
+    return np.clip(np.rint(g * 512.0), 0, 255).astype(np.uint8)
+
+
+store = kernels.DescriptorStore.from_arrays([sift_like(4096) for _ in range(n_img)])
+L = lib()
+und = np.array([(i, j) for j in range(n_img) for i in range(j)], np.int32)[-max_pairs:]
+pairs = np.concatenate([und, und[:, ::-1]])
+b = kernels.PairBatch(store, pairs, sym=True)
+ws = kernels.PairWorkspace(b.rows, b.n_pairs)
+ws.ensure_sym(b.sym_col_rows, b.sym_rowp_rows)
+fn = L.iamxdbg_knn2sym_variant
+fn.restype = ctypes.c_int
+fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+st = store
+names = {0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
+         4: 'row direction without butterfly', 5: 'row min tree only', 8: 'no MFMA',
+         11: 'staging + barriers only'}
+for v in variants:
+    ts = []
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+          kernels.check(fn(v, _ptr(st.desc3), _ptr(st.sn2), _ptr(st.sct), _ptr(st.img_off3), _ptr(st.img_n),
+                           _ptr(b.d_upairs), _ptr(b.d_sym_wg), _ptr(b.d_col_off), _ptr(b.d_rowp_off), b.n_u,
+                         b.sym_total_wg, _ptr(ws.col), _ptr(ws.rowp), stream_ptr()))
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / reps)
+    t = min(ts[1:])
+    print("sym variant %2d (%s): %.3f ms for %d image pairs -> %.3f us / unordered pair"
+          % (v, names.get(v, '?'), t, b.n_u, t * 1e3 / b.n_u))
