@@ -160,7 +160,7 @@ def main():
                       'iamx_desc3_pack_batch_u8')
         bufs = [(store.desc, rows_per * DIM), (store.norm_q, rows_per),
                 (store.desc3, rows_per3 * DIM), (store.sn2, rows_per3),
-                (store.sct, rows_per3), (store.sinv, rows_per3)]
+                (store.sct, rows_per3), (store.sperm, rows_per3)]
         if args.one_direction:       # parity-partitioned train layout of the one-direction form
             kernels.check(L.iamx_desc2_pack_batch_u8(_ptr(raw), _ptr(src_off), _ptr(store.img_off2[first:]),
                                                      mine, mine * KPTS, KPTS, _ptr(store.desc2),

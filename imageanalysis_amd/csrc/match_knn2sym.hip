@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 // candidates: one workgroup per ORDERED pair, rows in the query image's original order
 // ---------------------------------------------------------------------------------
 struct CandArgs {
-    const int32_t *sn2, *sinv, *img_off, *img_n;
+    const int32_t *sn2, *sperm, *img_off, *img_n;
     const int32_t *pairs;        // [n_pairs][2] ordered (query image, train image)
     const int32_t *osrc;         // [n_pairs][2]: unordered pair u, role (0: query = B, 1: query = A)
     const int32_t *wg_off;       // [n_u+1]
@@ -472,6 +472,8 @@ struct CandArgs {
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
 {
+    // rows are visited in SORTED order (the order the sweep wrote its bounds in: coalesced
+    // reads); the flag goes to the row's original position
     __shared__ int wsum[4];
     const int p = blockIdx.x;
     const int qimg = A.pairs[2 * p];
@@ -480,20 +482,21 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
     const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
     const int nwg = A.wg_off[u + 1] - A.wg_off[u];
     const int64_t ob = A.out_off[p];
+    const int32_t *colp = A.col + 2 * A.col_off[u];
+    const int32_t *rowq = A.rowp + 4 * A.rowp_off[u];
     int cnt = 0;
-    for (int r = threadIdx.x; r < n; r += 256) {
-        const int pos = A.sinv[soff + r];
+    for (int pos = threadIdx.x; pos < n; pos += 256) {
         const int n2 = A.sn2[soff + pos], par = n2 & 1;
         long long Lb, Ub;
         if (role == 0) {
-            const v2i v = *reinterpret_cast<const v2i *>(A.col + 2 * (A.col_off[u] + pos));
+            const v2i v = *reinterpret_cast<const v2i *>(colp + 2 * pos);
             const long long cq = n2 >> 1;
             Lb = 2 * (v.x + cq) + par;
             Ub = 2 * (v.y + cq) + par + 1;
         } else {
             int L = 0x7FFFFFFF, U1 = 0x7FFFFFFF, U2 = 0x7FFFFFFF;
             for (int w = 0; w < nwg; ++w) {
-                const v4i e = *reinterpret_cast<const v4i *>(A.rowp + 4 * (A.rowp_off[u] + (int64_t)w * cap + pos));
+                const v4i e = *reinterpret_cast<const v4i *>(rowq + 4 * ((int64_t)w * cap + pos));
                 L = min(L, e.x);
                 // merge the sorted pairs (U1, U2) and (e.y, e.z)
                 const int n1 = min(U1, e.y);
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         const float f0 = (float)sqrt((double)Lb);
         const float f1 = (float)sqrt((double)Ub);
         const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
-        A.keep[ob + r] = k ? 1 : 0;
+        A.keep[ob + A.sperm[soff + pos]] = k ? 1 : 0;
         cnt += k ? 1 : 0;
     }
 #pragma unroll
@@ -590,29 +593,30 @@ __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
         const int nq2 = A.norm_q[qoff + q];
         int d1 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, d2 = 0x7FFFFFFF;
         const int8_t *tb = A.desc + (int64_t)toff * D + part * 16;
+        const int32_t *tn = A.norm_q + toff;
         for (int r0 = wave * 8 + sub; r0 < nt; r0 += 128) {           // 4 rows in flight per lane
-            int dot[4], row[4];
+            v4i b[4];
+            int nrm[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                row[j] = r0 + 32 * j;
-                const int rr = row[j] < nt ? row[j] : nt - 1;
-                const v4i b = *reinterpret_cast<const v4i *>(tb + (int64_t)rr * D);
-                int t = __builtin_amdgcn_sdot4(qv.x, b.x, 0, false);
-                t = __builtin_amdgcn_sdot4(qv.y, b.y, t, false);
-                t = __builtin_amdgcn_sdot4(qv.z, b.z, t, false);
-                dot[j] = __builtin_amdgcn_sdot4(qv.w, b.w, t, false);
+                const int rr = r0 + 32 * j < nt ? r0 + 32 * j : nt - 1;
+                b[j] = *reinterpret_cast<const v4i *>(tb + (int64_t)rr * D);
+                nrm[j] = tn[rr];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int t = dot[j];
-                t += __shfl_xor(t, 1);
-                t += __shfl_xor(t, 2);
-                t += __shfl_xor(t, 4);
-                if (row[j] < nt) {
-                    const int dd = nq2 + A.norm_q[toff + row[j]] - 2 * t;
-                    if (dd < d1) { d2 = d1; d1 = dd; i1 = row[j]; }   // rows ascend per lane: ties keep the first
-                    else if (dd < d2) d2 = dd;
-                }
+                int t = __builtin_amdgcn_sdot4(qv.x, b[j].x, 0, false);
+                t = __builtin_amdgcn_sdot4(qv.y, b[j].y, t, false);
+                t = __builtin_amdgcn_sdot4(qv.z, b[j].z, t, false);
+                t = __builtin_amdgcn_sdot4(qv.w, b[j].w, t, false);
+                // sum over the 8 lanes of the row: two steps inside the quads, then the other quad
+                t += __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);     // quad_perm:[1,0,3,2]
+                t += __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);     // quad_perm:[2,3,0,1]
+                t += __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, true);    // row_half_mirror
+                const int row = r0 + 32 * j;
+                const int dd = row < nt ? nq2 + nrm[j] - 2 * t : 0x7FFFFFFF;
+                if (dd < d1) { d2 = d1; d1 = dd; i1 = row; }       // rows ascend per lane: ties keep the first
+                else if (dd < d2) d2 = dd;
             }
         }
         // merge (d1, i1, d2) triples: lexicographic (distance, row) for the best.  The 8 lanes of
@@ -793,7 +797,7 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     return iamx::check_launch("iamx_knn2sym_sweep");
 }
 
-extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sinv,
+extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int32_t *img_off, const int32_t *img_n,
                                        const int32_t *pairs, const int32_t *osrc,
                                        const int32_t *wg_off, const int64_t *col_off,
@@ -802,12 +806,12 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sinv,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
                                        int64_t *cand_off, int32_t *cand_q, void *stream)
 {
-    IAMX_REQUIRE(sn2 && sinv && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
+    IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
                      out_off && col && rowp && keep && cand_cnt && cand_off && cand_q,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     hipStream_t st = iamx::as_stream(stream);
-    CandArgs a{sn2, sinv, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
+    CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
                thresh, keep, cand_cnt};
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, a);
     int rc = iamx_exclusive_scan_i32(cand_cnt, n_pairs, cand_off, stream);

@@ -418,7 +418,7 @@ class PairBatch(object):
         """candidate rows from the sweep's bounds, exact top-2 + metric test for those rows,
         survivors compacted in place (pair p: surv_*[surv_off[p] .. + surv_cnt[p]))"""
         L, s, st = lib(), stream_ptr(), self.store
-        check(L.iamx_knn2sym_candidates(_ptr(st.sn2), _ptr(st.sinv), _ptr(st.img_off3), _ptr(st.img_n),
+        check(L.iamx_knn2sym_candidates(_ptr(st.sn2), _ptr(st.sperm), _ptr(st.img_off3), _ptr(st.img_n),
                                         _ptr(self.d_pairs), _ptr(self.d_osrc), _ptr(self.d_sym_wg),
                                         _ptr(self.d_col_off), _ptr(self.d_rowp_off), _ptr(self.d_out),
                                         _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),

@@ -225,7 +225,7 @@ int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const int32_t *s
                        const int32_t *img_off, const int32_t *img_n, const int32_t *upairs,
                        const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
                        int n_u, int total_wg, int form, int32_t *col, int32_t *rowp, void *stream);
-int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sinv, const int32_t *img_off,
+int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int32_t *img_off,
                             const int32_t *img_n, const int32_t *pairs, const int32_t *osrc,
                             const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
                             const int64_t *out_off, const int32_t *col, const int32_t *rowp,
