@@ -468,6 +468,7 @@ struct CandArgs {
     double thresh;
     uint8_t *keep;
     int32_t *seg_count;
+    int32_t *seg_tasks;          // ceil(seg_count / 32): 32-candidate tasks of symexact_kernel
 };
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
@@ -517,7 +518,11 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
     for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0) A.seg_count[p] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        A.seg_count[p] = tot;
+        A.seg_tasks[p] = (tot + 31) >> 5;
+    }
 }
 
 // order-preserving list of the candidate rows of every ordered pair
@@ -552,17 +557,20 @@ __global__ __launch_bounds__(256) void symlist_kernel(const uint8_t *__restrict_
 
 // ---------------------------------------------------------------------------------
 // exact top-2 of the candidate rows (original-order store), metric, final keep flag.
-// The candidate lists of all pairs are one flat array; workgroup w takes candidates w, w + grid,
-// ... (the survivors cluster in the few overlapping image pairs of a launch: one workgroup per
-// pair would leave most of the chip idle).  8 lanes share a train row (16 bytes each: coalesced
-// 1 KiB per wave instruction), a wave covers 8 rows per step, a workgroup 32.
+// A TASK = up to 32 candidate rows of one ordered pair against every row of its train image,
+// on the MFMA like the general kernel (match_knn2.hip: packed key = distance | train row,
+// v_med3 / v_min, lowest train row wins ties), run by ONE wave on its own: the candidates are
+// the B operand, the train rows come straight from L2 (16 bytes per lane and 32-row tile; all
+// tasks of a pair read the same 512 KiB).  Survivors cluster in the few overlapping image pairs
+// of a launch, so the tasks of all pairs form one flat list that a persistent grid walks.
 // ---------------------------------------------------------------------------------
 struct ExactArgs {
     const int8_t *desc;          // original-order store (iamx_desc_pack_*)
     const int32_t *norm_q;       // |s|^2 per row
+    const int32_t *norm_t;       // |s|^2 + 2 sum(s) per row
     const int32_t *img_off, *img_n;
     const int32_t *pairs;
-    const int64_t *out_off, *cand_off;
+    const int64_t *out_off, *cand_off, *task_off;
     const int32_t *cand_q;
     int n_pairs;
     double thresh;
@@ -573,75 +581,105 @@ struct ExactArgs {
     int32_t *zero_div;
 };
 
+__device__ __forceinline__ int med3_key(int a, int b, int c)
+{
+    // `c` is always a compiler-generated VALU result (the packed key), never a raw MFMA
+    // accumulator: no MFMA -> VALU hazard hides inside the asm statement
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
 {
-    __shared__ int s_d1[4], s_i1[4], s_d2[4];
-    const int64_t total = A.cand_off[A.n_pairs];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int part = lane & 7, sub = lane >> 3;            // 16-byte slice of a row, row of the step
-    for (int64_t k = blockIdx.x; k < total; k += gridDim.x) {
-        int lo = 0, hi = A.n_pairs;                        // pair p: cand_off[p] <= k < cand_off[p+1]
+    constexpr int KEY_INVALID = 0x7FFFFFFF;
+    const int64_t total = A.task_off[A.n_pairs];
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, g = lane >> 5;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
+        int lo = 0, hi = A.n_pairs;                        // pair p: task_off[p] <= t < task_off[p+1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (A.cand_off[mid] <= k) lo = mid; else hi = mid;
+            if (A.task_off[mid] <= t) lo = mid; else hi = mid;
         }
         const int p = lo;
+        const int64_t cb = A.cand_off[p];
+        const int cnt = (int)(A.cand_off[p + 1] - cb);
+        const int k = (int)(t - A.task_off[p]) * 32 + c;
+        const int q = A.cand_q[cb + (k < cnt ? k : cnt - 1)];
         const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
         const int qoff = A.img_off[qimg], toff = A.img_off[timg], nt = A.img_n[timg];
-        const int q = A.cand_q[k];
-        const v4i qv = *reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q) * D + part * 16);
-        const int nq2 = A.norm_q[qoff + q];
-        int d1 = 0x7FFFFFFF, i1 = 0x7FFFFFFF, d2 = 0x7FFFFFFF;
-        const int8_t *tb = A.desc + (int64_t)toff * D + part * 16;
-        const int32_t *tn = A.norm_q + toff;
-        for (int r0 = wave * 8 + sub; r0 < nt; r0 += 128) {           // 4 rows in flight per lane
-            v4i b[4];
-            int nrm[4];
+        v4i bq[4];
+        {
+            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q) * D);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rr = r0 + 32 * j < nt ? r0 + 32 * j : nt - 1;
-                b[j] = *reinterpret_cast<const v4i *>(tb + (int64_t)rr * D);
-                nrm[j] = tn[rr];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int t = __builtin_amdgcn_sdot4(qv.x, b[j].x, 0, false);
-                t = __builtin_amdgcn_sdot4(qv.y, b[j].y, t, false);
-                t = __builtin_amdgcn_sdot4(qv.z, b[j].z, t, false);
-                t = __builtin_amdgcn_sdot4(qv.w, b[j].w, t, false);
-                // sum over the 8 lanes of the row: two steps inside the quads, then the other quad
-                t += __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true);     // quad_perm:[1,0,3,2]
-                t += __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true);     // quad_perm:[2,3,0,1]
-                t += __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, true);    // row_half_mirror
-                const int row = r0 + 32 * j;
-                const int dd = row < nt ? nq2 + nrm[j] - 2 * t : 0x7FFFFFFF;
-                if (dd < d1) { d2 = d1; d1 = dd; i1 = row; }       // rows ascend per lane: ties keep the first
-                else if (dd < d2) d2 = dd;
-            }
+            for (int s = 0; s < 4; ++s) bq[s] = ~src[2 * s + g];
         }
-        // merge (d1, i1, d2) triples: lexicographic (distance, row) for the best.  The 8 lanes of
-        // a row hold identical triples: start above them
+        const int8_t *tbase = A.desc + (int64_t)toff * D;
+        const int32_t *tnorm = A.norm_t + toff;
+        const int ntiles = (nt + 31) / 32;
+        auto load_tile = [&](int tile, v4i (&a)[4], v4i (&tb)[4]) {
+            // rows past the end stay inside the image's 128-row padding; their keys are masked
+            const v4i *src = reinterpret_cast<const v4i *>(tbase + (int64_t)(tile * 32 + c) * D);
 #pragma unroll
-        for (int sh = 32; sh >= 8; sh >>= 1) {
-            const int e1 = __shfl_xor(d1, sh), ei = __shfl_xor(i1, sh), e2 = __shfl_xor(d2, sh);
-            const bool other = e1 < d1 || (e1 == d1 && ei < i1);
-            const int n2 = other ? min(d1, e2) : min(d2, e1);
-            d1 = other ? e1 : d1;
-            i1 = other ? ei : i1;
-            d2 = n2;
-        }
-        if (lane == 0) { s_d1[wave] = d1; s_i1[wave] = i1; s_d2[wave] = d2; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
+            for (int s = 0; s < 4; ++s) a[s] = src[2 * s + g];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const int e1 = s_d1[w], ei = s_i1[w], e2 = s_d2[w];
-                const bool other = e1 < d1 || (e1 == d1 && ei < i1);
-                const int n2 = other ? min(d1, e2) : min(d2, e1);
-                d1 = other ? e1 : d1;
-                i1 = other ? ei : i1;
-                d2 = n2;
+            for (int kk = 0; kk < 4; ++kk)
+                tb[kk] = *reinterpret_cast<const v4i *>(tnorm + tile * 32 + 8 * kk + 4 * g);
+        };
+        int m1 = KEY_INVALID, m2 = KEY_INVALID;
+        int bd1 = KEY_INVALID, bi1 = 0, bd2 = KEY_INVALID, bi2 = 0;
+        v4i a[4], tb[4];
+        load_tile(0, a, tb);
+        for (int tile = 0; tile < ntiles; ++tile) {
+            v4i a_nx[4], tb_nx[4];
+            load_tile(tile + 1 < ntiles ? tile + 1 : tile, a_nx, tb_nx);
+            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[s], acc, 0, 0, 0);
+            const bool ragged = tile * 32 + 32 > nt;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = tile * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3);
+                int key = tb[reg >> 2][reg & 3] * 256 + (row & 255) + (acc[reg] << 9);
+                if (ragged) key = row < nt ? key : KEY_INVALID;
+                m2 = med3_key(m1, m2, key);
+                m1 = min(m1, key);
             }
+            // fold the packed keys of this 256-row epoch into (distance, index) pairs
+            if ((tile & 7) == 7 || tile == ntiles - 1) {
+                const int sbase = (tile >> 3) * 256;
+                const int d1k = m1 >> 8, i1k = sbase + (m1 & 255);
+                const int d2k = m2 >> 8, i2k = sbase + (m2 & 255);
+                if (d1k < bd1) {
+                    if (d2k < bd1) { bd2 = d2k; bi2 = i2k; }
+                    else           { bd2 = bd1; bi2 = bi1; }
+                    bd1 = d1k; bi1 = i1k;
+                } else if (d1k < bd2) {
+                    bd2 = d1k; bi2 = i1k;
+                }
+                m1 = m2 = KEY_INVALID;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { a[s] = a_nx[s]; tb[s] = tb_nx[s]; }
+        }
+        // merge the two lane halves (rows +4) lexicographically by (distance, row)
+        const int od1 = __shfl_xor(bd1, 32), oi1 = __shfl_xor(bi1, 32);
+        const int od2 = __shfl_xor(bd2, 32), oi2 = __shfl_xor(bi2, 32);
+        auto less = [](int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); };
+        int f_d, f_i, s_d;
+        if (less(od1, oi1, bd1, bi1)) {
+            f_d = od1; f_i = oi1;
+            s_d = less(bd1, bi1, od2, oi2) ? bd1 : od2;
+        } else {
+            f_d = bd1; f_i = bi1;
+            s_d = less(od1, oi1, bd2, bi2) ? od1 : bd2;
+        }
+        if (g == 0 && k < cnt) {
+            const int na = A.norm_q[qoff + q];
+            const int d1 = f_d + na, d2 = s_d + na;
             *reinterpret_cast<v2i *>(A.d2 + 2 * (A.out_off[p] + q)) = v2i{d1, d2};
             // cv2 L2 distance = float32 sqrt; the rest in float64 like python (matcher.py:253-263)
             const float f0 = (float)sqrt((double)d1);
@@ -655,11 +693,10 @@ __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
                 mt = (double)f0 * ((double)f0 / (double)f1);
                 ok = mt < A.thresh;
             }
-            A.cand_t[k] = i1;
-            A.cand_metric[k] = mt;
-            A.cand_keep[k] = ok ? 1 : 0;
+            A.cand_t[cb + k] = f_i;
+            A.cand_metric[cb + k] = mt;
+            A.cand_keep[cb + k] = ok ? 1 : 0;
         }
-        __syncthreads();
     }
 }
 
@@ -804,38 +841,44 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int64_t *rowp_off, const int64_t *out_off,
                                        const int32_t *col, const int32_t *rowp, int n_pairs,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
-                                       int64_t *cand_off, int32_t *cand_q, void *stream)
+                                       int64_t *cand_off, int32_t *cand_q, int32_t *task_cnt,
+                                       int64_t *task_off, void *stream)
 {
     IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
-                     out_off && col && rowp && keep && cand_cnt && cand_off && cand_q,
+                     out_off && col && rowp && keep && cand_cnt && cand_off && cand_q && task_cnt &&
+                     task_off,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     hipStream_t st = iamx::as_stream(stream);
     CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
-               thresh, keep, cand_cnt};
+               thresh, keep, cand_cnt, task_cnt};
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, a);
     int rc = iamx_exclusive_scan_i32(cand_cnt, n_pairs, cand_off, stream);
+    if (rc != IAMX_OK) return rc;
+    rc = iamx_exclusive_scan_i32(task_cnt, n_pairs, task_off, stream);
     if (rc != IAMX_OK) return rc;
     hipLaunchKernelGGL(symlist_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, keep, out_off,
                        cand_off, cand_q);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
 
-extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *img_off,
-                                  const int32_t *img_n, const int32_t *pairs, const int64_t *out_off,
-                                  const int64_t *cand_off, const int32_t *cand_cnt, int32_t *cand_q,
+extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
+                                  const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
+                                  const int64_t *out_off, const int64_t *cand_off,
+                                  const int32_t *cand_cnt, const int64_t *task_off, int32_t *cand_q,
                                   int n_pairs, double thresh, int32_t *d2, int32_t *cand_t,
                                   double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
                                   int32_t *zero_div, void *stream)
 {
-    IAMX_REQUIRE(desc && norm_q && img_off && img_n && pairs && out_off && cand_off && cand_cnt &&
-                     cand_q && d2 && cand_t && cand_metric && cand_keep && surv_cnt && zero_div,
+    IAMX_REQUIRE(desc && norm_q && norm_t && img_off && img_n && pairs && out_off && cand_off &&
+                     cand_cnt && task_off && cand_q && d2 && cand_t && cand_metric && cand_keep &&
+                     surv_cnt && zero_div,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     hipStream_t st = iamx::as_stream(stream);
-    ExactArgs a{desc, norm_q, img_off, img_n, pairs, out_off, cand_off, cand_q, n_pairs, thresh,
-                d2, cand_t, cand_metric, cand_keep, zero_div};
-    hipLaunchKernelGGL(symexact_kernel, dim3(256 * 16), dim3(256), 0, st, a);
+    ExactArgs a{desc, norm_q, norm_t, img_off, img_n, pairs, out_off, cand_off, task_off, cand_q,
+                n_pairs, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
+    hipLaunchKernelGGL(symexact_kernel, dim3(1024), dim3(256), 0, st, a);
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, cand_off,
                        cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt);
     return iamx::check_launch("iamx_knn2sym_exact");
