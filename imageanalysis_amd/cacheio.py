@@ -62,7 +62,8 @@ def _write_job(path, payload, on_error=None):
     try:
         raw = payload() if callable(payload) else payload
         blob = gzip_members(raw)
-        tmp = '%s.tmp%d' % (path, threading.get_ident())
+        # pid + thread id: two ranks may write the same boundary image's cache at the same time
+        tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
             f.write(blob)
         os.replace(tmp, path)                                 # readers never see half a file

@@ -5,8 +5,8 @@ xGMI on the node; "gloo" in the CPU tests).  The path shards by *pair* (matching
   * descriptors: every rank packs the images it detected, then the packed store
     (int8 rows + two int32 norms) is gathered so that every rank holds all images
     (`gather_store_shards`), 1.57 GB in total for the 2812-image survey;
-  * match lists: variable-length per-pair results return to every rank as python objects
-    (`allgather_objects`) -- kilobytes;
+  * match lists: variable-length per-pair results are gathered on rank 0 as python objects
+    (`gather_results`) -- kilobytes per round;
   * BA: one all-reduce of the camera-side accumulators per operator application
     (`allreduce_sum_`), see ba_solver.py.
 
@@ -81,6 +81,35 @@ def allgather_objects(obj, group=None):
     out = [None] * ws
     dist.all_gather_object(out, obj, group=group)
     return out
+
+
+def gather_results(results, failure=None, dst=0, group=None):
+    """find_matches' per-round exchange.  The per-pair match lists go to rank `dst` ONLY (it
+    keeps the survey's bookkeeping and writes the files; match consolidation and everything after
+    it are rank-0 steps): returns the parts of all ranks, ordered by rank, on `dst` and just
+    this rank's own part elsewhere.  `failure`: an exception raised on this rank while it
+    produced its part -- a one-line note of it is all-gathered first and the failure is re-raised
+    on EVERY rank, so that no rank is left waiting in a collective."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        if failure is not None:
+            raise failure
+        return [results]
+    note = None if failure is None else (type(failure).__name__, str(failure))
+    notes = allgather_objects(note, group=group)
+    for r, n in enumerate(notes):
+        if n is not None:
+            if r == rank and failure is not None:
+                raise failure
+            if n[0] == 'ZeroDivisionError':
+                raise ZeroDivisionError(n[1])
+            if n[0] == 'SystemExit':
+                raise SystemExit("rank %d quit: %s" % (r, n[1]))
+            raise RuntimeError("rank %d failed: %s: %s" % (r, n[0], n[1]))
+    parts = [None] * ws if rank == dst else None
+    dist.gather_object(results, parts, dst=dst, group=group)
+    return parts if rank == dst else [results]
 
 
 def allreduce_sum_(tensor, group=None):

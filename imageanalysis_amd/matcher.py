@@ -124,6 +124,10 @@ class DeviceMatcher(object):
                 new.cinit[:n_old2].copy_(old.cinit[:n_old2])
                 new.perm[:n_old2].copy_(old.perm[:n_old2])
                 new.meta[:k].copy_(old.meta[:k])
+                # ... and the sorted form of the symmetric sweep
+                n_old3 = int(old.offsets3[-1])
+                for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
+                    getattr(new, name)[:n_old3].copy_(getattr(old, name)[:n_old3])
             self._store = new
         keep = [self._store.set_image(slot, np.ascontiguousarray(des), sync=False)
                 for slot, des in pend]
@@ -136,12 +140,29 @@ class DeviceMatcher(object):
 
 
 def _kp_xy(image):
-    """[N,2] float32 array of kp.pt (cached on the image while kp_list is the same object)."""
+    """[N,2] float32 array of kp.pt, cached on the image while kp_list is the same object.
+    The cache holds a WEAK reference to the list (a plain-list kp_list, which cannot be weakly
+    referenced, is identified by id + length): find_matches' periodic flush sets kp_list to
+    None and the keypoint objects of ~50 k-keypoint images must go with it, as in the reference
+    (scripts/lib/matcher.py:1008-1026) -- a strong reference here kept every list ever matched."""
+    import weakref
+    kl = image.kp_list
     cache = getattr(image, '_iamx_xy', None)
-    if cache is not None and cache[0] is image.kp_list:
-        return cache[1]
-    xy = np.array([kp.pt for kp in image.kp_list], np.float32).reshape(-1, 2)
-    image._iamx_xy = (image.kp_list, xy)
+    if cache is not None:
+        tag, xy = cache
+        if tag is None:
+            return xy                                  # array handed over without a list (bench)
+        if isinstance(tag, weakref.ref):
+            if tag() is kl and kl is not None:
+                return xy
+        elif kl is not None and tag == (id(kl), len(kl)):
+            return xy
+    xy = np.array([kp.pt for kp in kl], np.float32).reshape(-1, 2)
+    try:
+        tag = weakref.ref(kl)
+    except TypeError:
+        tag = (id(kl), len(kl))
+    image._iamx_xy = (tag, xy)
     return xy
 
 
@@ -589,8 +610,9 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
 
     With torch.distributed initialised (one process per GPU) the pairs that still need
     matching are dealt to the ranks in contiguous blocks (dist.shard_pairs); after every round
-    the per-pair match lists are exchanged so that every rank keeps the full, identical
-    bookkeeping; rank 0 writes the files."""
+    the per-pair match lists are gathered on rank 0, which keeps the survey's bookkeeping
+    (match lists, surface estimates) and writes the files -- the other ranks only record the
+    pairs they matched themselves."""
     with _no_gc():
         _find_matches(proj, K, strategy, transform, sort, review)
 
@@ -667,10 +689,19 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # software pipeline: the GPU works on round r+1 while python turns round r into lists
     in_flight = launch_round(0) if n_rounds else None
     for rnd in range(n_rounds):
-        coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
-        results = _finish_lines(in_flight) if in_flight is not None else []
-        in_flight = coming
-        gathered = _dist.allgather_objects(results)
+        # an exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
+        # image-size mismatch) travels with the results and is re-raised on EVERY rank: the
+        # others would otherwise wait in the collective forever
+        failure = None
+        try:
+            coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
+            results = _finish_lines(in_flight) if in_flight is not None else []
+            in_flight = coming
+        except (Exception, SystemExit) as exc:
+            if ws == 1:
+                raise
+            failure, results = exc, []
+        gathered = _dist.gather_results(results, failure)
 
         for part in gathered:
             for i, j, match_fwd, match_rev, surf in part:
@@ -687,6 +718,11 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                     if surf is not None:
                         avg, std = smart.record_surface_estimate(i1, i2, *surf)
                     else:
+                        # the reference's lib.smart reads kp_list / uv_list of both images; the
+                        # flush at the end of an earlier round, or a non-owning rank, may not
+                        # have them
+                        _ensure_features(i1)
+                        _ensure_features(i2)
                         avg, std = smart.update_surface_estimate(i1, i2)
                     if avg and std:
                         _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)

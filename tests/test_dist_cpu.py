@@ -113,9 +113,16 @@ def test_find_matches_two_ranks_equals_one_rank():
         _run_find_matches(0, 1, 0, d)
         mp.spawn(_run_find_matches, args=(2, _free_port(), d), nprocs=2, join=True)
         one = pickle.load(open(os.path.join(d, 'r0_of_1.pkl'), 'rb'))
-        for r in range(2):
-            two = pickle.load(open(os.path.join(d, 'r%d_of_2.pkl' % r), 'rb'))
-            assert two == one
+        # rank 0 holds the whole survey's bookkeeping, the other rank the pairs it matched itself
+        two = pickle.load(open(os.path.join(d, 'r0_of_2.pkl'), 'rb'))
+        assert two == one
+        part = pickle.load(open(os.path.join(d, 'r1_of_2.pkl'), 'rb'))
+        seen = 0
+        for name, ml in part.items():
+            for other, lst in ml.items():
+                assert lst == one[name][other]
+                seen += 1
+        assert 0 < seen < sum(len(m) for m in one.values())
         assert sum(len(v) > 0 for m in one.values() for v in m.values()) >= 8
 
 
@@ -141,6 +148,14 @@ def _run_helpers(rank, world, port):
     # objects
     got = D.allgather_objects({'rank': rank, 'pairs': [[rank, 1]]})
     assert [g['rank'] for g in got] == [0, 1]
+    # per-round results: everything on rank 0, own part elsewhere; a failure on ONE rank is
+    # re-raised on every rank instead of leaving the others in the collective
+    got = D.gather_results([('pair', rank)])
+    assert got == ([[('pair', 0)], [('pair', 1)]] if rank == 0 else [[('pair', 1)]])
+    with pytest.raises(ZeroDivisionError):
+        D.gather_results([], ZeroDivisionError("float division by zero") if rank == 1 else None)
+    with pytest.raises((RuntimeError, ValueError)):
+        D.gather_results([], ValueError("bad image") if rank == 0 else None)
     # BA: observation sharding by point + all-reduce of camera-side sums == unsharded sums
     rng = np.random.default_rng(3)
     P, C, O = 50, 6, 400

@@ -215,3 +215,41 @@ def test_feature_cache_formats_roundtrip(tmp_path):
     im2.load_matches()
     assert im2.kp_list[1].pt == (1.0, 2.0) and im2.kp_list[1].octave == 16711935
     assert np.array_equal(im2.des_list, im.des_list) and im2.match_list == im.match_list
+
+
+def test_kp_xy_cache_does_not_keep_the_keypoint_list_alive():
+    """find_matches' periodic flush sets kp_list to None (scripts/lib/matcher.py:1008-1026); the
+    cached coordinate array must not hold the KeyPoint objects."""
+    import gc
+    import weakref
+    from imageanalysis_amd import matcher
+
+    class KP(object):
+        def __init__(self, x, y):
+            self.pt = (x, y)
+
+    class KPList(list):                       # weak-referenceable, like cacheio's lazy sequences
+        pass
+
+    class Img(object):
+        pass
+
+    for make in (KPList, list):
+        im = Img()
+        im.kp_list = make(KP(float(i), float(2 * i)) for i in range(100))
+        probe = weakref.ref(im.kp_list[0])
+        xy = matcher._kp_xy(im)
+        assert xy.shape == (100, 2) and xy[7, 1] == 14.0
+        assert matcher._kp_xy(im) is xy                      # cached while the list is the same
+        im.kp_list = None
+        gc.collect()
+        assert probe() is None                               # the flush frees the objects
+        im.kp_list = make(KP(1.0, 1.0) for _ in range(3))    # a reload gets fresh coordinates
+        assert matcher._kp_xy(im).shape == (3, 2)
+
+
+def test_gather_results_reraises_single_rank():
+    from imageanalysis_amd import dist
+    assert dist.gather_results([1, 2]) == [[1, 2]]
+    with pytest.raises(ZeroDivisionError):
+        dist.gather_results([], ZeroDivisionError("float division by zero"))
