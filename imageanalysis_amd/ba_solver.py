@@ -23,6 +23,8 @@ ba_linalg.hip):
 Multi-GPU: observations are sharded by point (dist.shard_observations_by_point); m-vectors are
 rank-local, n-vectors replicated; J^T u and every m-dot are summed over ranks (RCCL all-reduce).
 """
+import os
+
 import numpy as np
 import torch
 from numpy.linalg import norm
@@ -134,6 +136,8 @@ class DeviceBA(object):
         self._state_pin = None
         self.profile = None
         self.force_stepwise_lsmr = False
+        # fused single-rank LSMR: replay a captured HIP graph per 64-iteration chunk
+        self.use_graph = os.environ.get('IAMX_BA_GRAPH', '1') != '0'
         self.host_logic = False          # True: the O(n) TRF vector logic in numpy (_trf_host)
         self._calib_idx = None
         self._fixed_calib_up = False
@@ -536,6 +540,10 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
                                  part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
                                  xr=z(2), tbuf=z(n))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
+    if 'dreg' not in ws:
+        ws['dreg'] = torch.zeros(max(n, 1), dtype=F64, device=dev)
+    ws['dreg'][:n].copy_(dreg_dev[:n])           # a fixed address for the captured launches
+    dreg_dev = ws['dreg']
     ph = _Phase(prob, 'lsmr:init')
     ph.__enter__()
     # the tables of the matrix-free operator at the current parameters (the point J was
@@ -577,10 +585,29 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
               _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), _ptr(prob.slot_cp), prob.O,
               prob.C, prob.P, _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h), _ptr(hbar),
               _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
+    def enqueue_launches():
+        check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
+                                     stream_ptr()), 'iamx_ba_lsmr_iterate')
+
+    # Single rank: the 3 x chunk launches of a chunk are captured once into a HIP graph (every
+    # pointer they take lives in prob.lsmr_ws; dreg is copied into it) and replayed per chunk:
+    # one graph launch instead of 192 kernel launches from the host.
+    graph = None
+    if not multi and prob.use_graph:
+        key = (chunk, prob.O, dreg_dev.data_ptr())
+        if ws.get('graph_key') != key:
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                enqueue_launches()
+            ws['graph'], ws['graph_key'] = g, key
+        graph = ws['graph']
+
     def enqueue_chunk():
-        if not multi:
-            check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
-                                         stream_ptr()), 'iamx_ba_lsmr_iterate')
+        if graph is not None:
+            graph.replay()
+        elif not multi:
+            enqueue_launches()
         else:
             xr, tbuf = ws['xr'], ws['tbuf']
             tail = (_ptr(xr), _ptr(tbuf))

@@ -226,7 +226,9 @@ __device__ __forceinline__ void half_wave_min16(const int (&r)[16], int &m0, int
 // VARIANT != 0: timing ablations, compiled only with -DIAMX_ABLATE (tools/knn2sym_ablate.py):
 // bit0 no column direction, bit1 no row direction, bit2 row direction without the cross-lane
 // butterfly, bit3 no MFMA.  Results are meaningless.
-template <int QW, int NW, int VARIANT = 0>
+// PIPE: the MFMAs of a pair of query blocks are issued while the minima of the previous pair are
+// taken (software pipeline across the 8 steps of a chunk, sched_group_barrier interleave).
+template <int QW, int NW, int VARIANT = 0, int PIPE = 0>
 __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 {
     constexpr int WGROWS = NW * QW * 32;
@@ -351,11 +353,78 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                 for (int k = 0; k < 4; ++k)
                     tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
             };
-            v4i a[4], tbv[4];
-            load_ops(0, a, tbv);
             int *row_dst = (lane & 3) == 0
                 ? lds_row + (buf * NW + wave) * CHUNK + 8 * ((lane >> 4) & 1) + 4 * g + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1)
                 : lds_dump + wave * 256 + lane;                 // + tile*32 (+16) stays inside [0, 256)
+            if constexpr (PIPE != 0) {
+                constexpr int PP = QW / 2, NS = (CHUNK / 32) * PP;
+                v4i aop[2][4], tbop[2][4];
+                v16i accs[2][2];
+                int r[16];
+                auto issue = [&](int t, int qp, v16i &acc0, v16i &acc1) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc0[reg] = acc1[reg] = tbop[t & 1][reg >> 2][reg & 3];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t & 1][s], bq[qp][s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t & 1][s], bq[qp + 1][s], acc1, 0, 0, 0);
+                    }
+                };
+                load_ops(0, aop[0], tbop[0]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tbop[0][k] += lo_lane;
+                issue(0, 0, accs[0][0], accs[0][1]);
+                load_ops(1, aop[1], tbop[1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    const int t = st / PP, qp = 2 * (st % PP), cur = st & 1;
+                    if (st + 1 < NS) {
+                        const int t1 = (st + 1) / PP, qp1 = 2 * ((st + 1) % PP);
+                        if (t1 != t) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) tbop[t1 & 1][k] += lo_lane;
+                        }
+                        issue(t1, qp1, accs[cur ^ 1][0], accs[cur ^ 1][1]);
+                        if (t1 != t && t1 + 1 < CHUNK / 32) load_ops(t1 + 1, aop[t & 1], tbop[t & 1]);
+                    }
+                    const v16i acc0 = accs[cur][0], acc1 = accs[cur][1];
+                    int t0 = min(min(m[qp][t], acc0[0]), acc0[1]);
+                    int t1m = min(min(m[qp + 1][t], acc1[0]), acc1[1]);
+#pragma unroll
+                    for (int reg = 2; reg < 16; reg += 2) {
+                        t0 = min(min(t0, acc0[reg]), acc0[reg + 1]);
+                        t1m = min(min(t1m, acc1[reg]), acc1[reg + 1]);
+                    }
+                    m[qp][t] = t0;
+                    m[qp + 1][t] = t1m;
+                    if (qp == 0) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) r[reg] = min(acc0[reg], acc1[reg]);
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) r[reg] = min(min(r[reg], acc0[reg]), acc1[reg]);
+                    }
+                    if (qp == QW - 2) {
+                        int m0, m1;
+                        half_wave_min16(r, m0, m1);
+                        int *dst = row_dst + t * 32;
+                        dst[0] = m0;
+                        dst[16] = m1;
+                    }
+                    if (st + 1 < NS) {
+                        // one MFMA, then the VALU work that fits beside it
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, PIPE, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+            v4i a[4], tbv[4];
+            load_ops(0, a, tbv);
 #pragma unroll
             for (int tile = 0; tile < CHUNK / 32; ++tile) {
                 v4i a_nx[4], tb_nx[4];
@@ -432,6 +501,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     for (int s = 0; s < 4; ++s) { a[s] = a_nx[s]; tbv[s] = tb_nx[s]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);     // keep tiles apart (no hoisting -> no spills)
+            }
             }
         }
         wait_direct();
@@ -828,9 +898,11 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     SymArgs a{sdesc, sn2, sct, img_off, img_n, upairs, wg_off, col_off, rowp_off, col, rowp, n_u, total_wg};
     const dim3 g((unsigned)total_wg);
     hipStream_t st = iamx::as_stream(stream);
-    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8>), g, dim3(512), 0, st, a);
-    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4>), g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((knn2sym_kernel<2, 4>), g, dim3(256), 0, st, a);
+    // PIPE = 6: six epilogue VALU instructions beside every MFMA of the next pair of query
+    // blocks (profiles/r2_knn2sym_ablate.txt: 1.83 -> 1.78 us per image pair)
+    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6>), g, dim3(512), 0, st, a);
+    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4, 0, 6>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((knn2sym_kernel<2, 4, 0, 6>), g, dim3(256), 0, st, a);
     return iamx::check_launch("iamx_knn2sym_sweep");
 }
 
@@ -900,6 +972,9 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 100: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 4>), g, dim3(512), 0, st, a); break;
+    case 101: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6>), g, dim3(512), 0, st, a); break;
+    case 102: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 8>), g, dim3(512), 0, st, a); break;
     default: return iamx::fail(IAMX_EINVAL, "unknown variant");
     }
     return iamx::check_launch("iamxdbg_knn2sym_variant");

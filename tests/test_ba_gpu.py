@@ -136,3 +136,59 @@ def test_residual_prepared_equals_plain():
     plain = kernels.ba_residual(t(p['cams0']), t(p['pts0']), t(p['cam_idx']), t(p['pt_idx']),
                                 t(p['uv']), t(np.array(calib))).cpu().numpy()
     assert np.abs(prob.download_m(prob.r) - plain).max() <= 1e-9 * np.abs(plain).max()
+
+
+def test_config3_full_size_residual_and_operator():
+    """BASELINE configs[3] at its full size (2812 cameras, ~270 k points, ~1.96 M observations):
+    the residual against the plain-C oracle, and J v / J^T u of the device kernels against a SciPy
+    CSR matrix assembled from the analytic blocks, plus one fused (matrix-free) LSMR iteration
+    count against the stepwise form -- the sizes bench.py times, checked."""
+    import scipy.sparse as sp
+    import torch
+    from imageanalysis_amd import ba_solver, synth
+    from oracle import cpu_ref
+    p = synth.make_ba_problem()
+    C, P, O = len(p['cams0']), len(p['pts0']), len(p['cam_idx'])
+    assert C == 2812 and O > 1900000
+    K = p['K']
+    calib = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2], *p['dist']])
+    prob = ba_solver.DeviceBA(C, P, p['cam_idx'], p['pt_idx'], p['uv'], False, fixed_calib=calib)
+    x0 = np.hstack([p['cams0'].ravel(), p['pts0'].ravel()])
+    prob.set_x(x0)
+    r = prob.download_m(prob.residual())
+    rr = cpu_ref.ba_residual(p['cams0'], p['pts0'], p['cam_idx'], p['pt_idx'], p['uv'],
+                             calib[:4], calib[4:])
+    assert np.abs(r - rr).max() / np.abs(rr).max() < TIGHT
+    # J in the reference's row / column order from the blocks of the plain C-ABI entry point
+    from imageanalysis_amd import kernels
+    rj, Jc, Jp, _ = kernels.ba_residual_jac(_dev(p['cams0']), _dev(p['pts0']), _dev(p['cam_idx']),
+                                            _dev(p['pt_idx']), _dev(p['uv']), _dev(calib))
+    assert np.abs(rj.cpu().numpy() - rr).max() / np.abs(rr).max() < TIGHT
+    Jc, Jp = Jc.cpu().numpy(), Jp.cpu().numpy()
+    rows = np.repeat(np.arange(2 * O), 10)
+    ci, pi = p['cam_idx'].astype(np.int64), p['pt_idx'].astype(np.int64)
+    cols = np.concatenate([ci[:, None] * 7 + np.arange(7), C * 7 + pi[:, None] * 3 + np.arange(3)], 1)
+    cols = np.repeat(cols, 2, axis=0).reshape(-1)            # both rows of an observation
+    vals = np.concatenate([Jc, Jp], 2).reshape(-1)
+    J = sp.csr_matrix((vals, (rows, cols)), shape=(2 * O, prob.n))
+    rng = np.random.default_rng(11)
+    v = rng.normal(size=prob.n)
+    u = rng.normal(size=2 * O)
+    prob.residual_jac()
+    y = torch.empty(prob.m, dtype=torch.float64, device='cuda')
+    prob.jv(prob.upload_n(v), y)
+    want = J @ v
+    assert np.abs(prob.download_m(y) - want).max() / np.abs(want).max() < 1e-11
+    out = torch.empty(prob.n, dtype=torch.float64, device='cuda')
+    prob.jtv(prob.upload_m(u), out)
+    want = J.T @ u
+    assert np.abs(prob.download_n(out) - want).max() / np.abs(want).max() < 1e-11
+    # matrix-free fused LSMR == the stepwise LSMR on the stored blocks (same iterates, same stop)
+    d = 1.0 / np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel())
+    d_dev = prob.upload_n(d).clone()
+    dreg = prob.upload_n(np.full(prob.n, 1e-3)).clone()
+    xa, istop_a, itn_a, nr_a, nar_a = ba_solver.lsmr_device_fused(prob, d_dev, dreg, maxiter=12)
+    xb, istop_b, itn_b, nr_b, nar_b = ba_solver.lsmr_device(prob, d_dev, dreg, maxiter=12)
+    assert itn_a == itn_b == 12
+    assert np.abs(xa - xb).max() <= 1e-9 * np.abs(xb).max()
+    assert abs(nr_a - nr_b) <= 1e-10 * nr_b

@@ -34,7 +34,8 @@ fn = L.iamxdbg_knn2sym_variant
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
 st = store
-names = {0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
+ref = None
+names = {100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
          4: 'row direction without butterfly', 5: 'row min tree only', 8: 'no MFMA',
          11: 'staging + barriers only'}
 for v in variants:
@@ -49,5 +50,10 @@ for v in variants:
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / reps)
     t = min(ts[1:])
+    if v == 0:
+        ref = (ws.col[:b.sym_col_rows].clone(), ws.rowp[:b.sym_rowp_rows].clone())
+    elif v >= 100 and ref is not None:          # alternative schedules of the same arithmetic
+        assert torch.equal(ref[0], ws.col[:b.sym_col_rows]), 'variant %d: column bounds differ' % v
+        assert torch.equal(ref[1][:, :3], ws.rowp[:b.sym_rowp_rows, :3]), 'variant %d: row bounds differ' % v
     print("sym variant %2d (%s): %.3f ms for %d image pairs -> %.3f us / unordered pair"
           % (v, names.get(v, '?'), t, b.n_u, t * 1e3 / b.n_u))
