@@ -526,7 +526,11 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 }
 
 // ---------------------------------------------------------------------------------
-// candidates: one workgroup per ORDERED pair, rows in the query image's original order
+// candidates: one workgroup per ORDERED pair.  Pass 1 visits the rows in SORTED order (the order
+// the sweep wrote its bounds in: coalesced reads) and drops a flag at the row's original
+// position; pass 2 lists the flagged rows in ascending original order at the pair's own slice
+// of cand_q (first entry out_off[p]: a pair cannot have more candidates than rows, so no scan
+// over the pairs is needed) and appends the pair's 32-candidate tasks to the exact stage's list.
 // ---------------------------------------------------------------------------------
 struct CandArgs {
     const int32_t *sn2, *sperm, *img_off, *img_n;
@@ -537,15 +541,16 @@ struct CandArgs {
     const int32_t *col, *rowp;
     double thresh;
     uint8_t *keep;
-    int32_t *seg_count;
-    int32_t *seg_tasks;          // ceil(seg_count / 32): 32-candidate tasks of symexact_kernel
+    int32_t *cand_cnt;
+    int32_t *cand_q;
+    int32_t *task_total;         // [1] tasks appended so far (zeroed by symcompact_kernel)
+    int32_t *tasks;              // [..][2] (ordered pair, block of 32 candidates)
 };
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
 {
-    // rows are visited in SORTED order (the order the sweep wrote its bounds in: coalesced
-    // reads); the flag goes to the row's original position
-    __shared__ int wsum[4];
+    __shared__ int wcnt[4];
+    __shared__ int s_base;
     const int p = blockIdx.x;
     const int qimg = A.pairs[2 * p];
     const int u = A.osrc[2 * p], role = A.osrc[2 * p + 1];
@@ -555,7 +560,6 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
     const int64_t ob = A.out_off[p];
     const int32_t *colp = A.col + 2 * A.col_off[u];
     const int32_t *rowq = A.rowp + 4 * A.rowp_off[u];
-    int cnt = 0;
     for (int pos = threadIdx.x; pos < n; pos += 256) {
         const int n2 = A.sn2[soff + pos], par = n2 & 1;
         long long Lb, Ub;
@@ -582,33 +586,13 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         const float f1 = (float)sqrt((double)Ub);
         const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
         A.keep[ob + A.sperm[soff + pos]] = k ? 1 : 0;
-        cnt += k ? 1 : 0;
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        A.seg_count[p] = tot;
-        A.seg_tasks[p] = (tot + 31) >> 5;
-    }
-}
-
-// order-preserving list of the candidate rows of every ordered pair
-__global__ __launch_bounds__(256) void symlist_kernel(const uint8_t *__restrict__ keep,
-                                                      const int64_t *__restrict__ seg_off,
-                                                      const int64_t *__restrict__ cand_off,
-                                                      int32_t *__restrict__ cand_q)
-{
-    __shared__ int wcnt[4];
-    const int seg = blockIdx.x;
-    const int64_t b = seg_off[seg], e = seg_off[seg + 1];
-    int64_t out = cand_off[seg];
+    __syncthreads();             // (workgroup-scope fence: the flags are read back below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = b; base < e; base += 256) {
-        const int64_t i = base + threadIdx.x;
-        const bool k = i < e && keep[i];
+    int out = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool k = i < n && A.keep[ob + i];
         const unsigned long long mask = __ballot(k);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));
         if (lane == 0) wcnt[wave] = __popcll(mask);
@@ -619,10 +603,18 @@ __global__ __launch_bounds__(256) void symlist_kernel(const uint8_t *__restrict_
             if (w < wave) woff += wcnt[w];
             tot += wcnt[w];
         }
-        if (k) cand_q[out + woff + before] = (int32_t)(i - b);
+        if (k) A.cand_q[ob + out + woff + before] = i;
         out += tot;
         __syncthreads();
     }
+    const int ntask = (out + 31) >> 5;
+    if (threadIdx.x == 0) {
+        A.cand_cnt[p] = out;
+        s_base = ntask ? atomicAdd(A.task_total, ntask) : 0;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntask; t += 256)
+        *reinterpret_cast<v2i *>(A.tasks + 2 * (s_base + t)) = v2i{p, t};
 }
 
 // ---------------------------------------------------------------------------------
@@ -632,7 +624,8 @@ __global__ __launch_bounds__(256) void symlist_kernel(const uint8_t *__restrict_
 // v_med3 / v_min, lowest train row wins ties), run by ONE wave on its own: the candidates are
 // the B operand, the train rows come straight from L2 (16 bytes per lane and 32-row tile; all
 // tasks of a pair read the same 512 KiB).  Survivors cluster in the few overlapping image pairs
-// of a launch, so the tasks of all pairs form one flat list that a persistent grid walks.
+// of a launch, so the tasks of all pairs form one flat list (appended to by symcand_kernel) that
+// a persistent grid walks.
 // ---------------------------------------------------------------------------------
 struct ExactArgs {
     const int8_t *desc;          // original-order store (iamx_desc_pack_*)
@@ -640,9 +633,10 @@ struct ExactArgs {
     const int32_t *norm_t;       // |s|^2 + 2 sum(s) per row
     const int32_t *img_off, *img_n;
     const int32_t *pairs;
-    const int64_t *out_off, *cand_off, *task_off;
+    const int64_t *out_off;      // first row of a pair in d2 AND first entry of its candidate list
+    const int32_t *cand_cnt;
     const int32_t *cand_q;
-    int n_pairs;
+    const int32_t *task_total, *tasks;
     double thresh;
     int32_t *d2;                 // [rows][2]: exact (best, second) written for the candidates
     int32_t *cand_t;
@@ -663,20 +657,16 @@ __device__ __forceinline__ int med3_key(int a, int b, int c)
 __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
 {
     constexpr int KEY_INVALID = 0x7FFFFFFF;
-    const int64_t total = A.task_off[A.n_pairs];
+    const int total = *A.task_total;
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, g = lane >> 5;
-    const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
-        int lo = 0, hi = A.n_pairs;                        // pair p: task_off[p] <= t < task_off[p+1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (A.task_off[mid] <= t) lo = mid; else hi = mid;
-        }
-        const int p = lo;
-        const int64_t cb = A.cand_off[p];
-        const int cnt = (int)(A.cand_off[p + 1] - cb);
-        const int k = (int)(t - A.task_off[p]) * 32 + c;
+    const int nwaves = gridDim.x * 4;
+    for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
+        const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * t);
+        const int p = task.x;
+        const int64_t cb = A.out_off[p];
+        const int cnt = A.cand_cnt[p];
+        const int k = task.y * 32 + c;
         const int q = A.cand_q[cb + (k < cnt ? k : cnt - 1)];
         const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
         const int qoff = A.img_off[qimg], toff = A.img_off[timg], nt = A.img_n[timg];
@@ -776,7 +766,8 @@ __global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restri
                                                          const uint8_t *__restrict__ cand_keep,
                                                          int32_t *__restrict__ q, int32_t *__restrict__ t,
                                                          double *__restrict__ metric,
-                                                         int32_t *__restrict__ surv_cnt)
+                                                         int32_t *__restrict__ surv_cnt,
+                                                         int32_t *__restrict__ task_total)
 {
     __shared__ int wcnt[4];
     const int p = blockIdx.x;
@@ -807,7 +798,10 @@ __global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restri
         out += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) surv_cnt[p] = out;
+    if (threadIdx.x == 0) {
+        surv_cnt[p] = out;
+        if (p == 0) *task_total = 0;           // the exact stage has consumed the list
+    }
 }
 
 }  // namespace
@@ -913,46 +907,38 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int64_t *rowp_off, const int64_t *out_off,
                                        const int32_t *col, const int32_t *rowp, int n_pairs,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
-                                       int64_t *cand_off, int32_t *cand_q, int32_t *task_cnt,
-                                       int64_t *task_off, void *stream)
+                                       int32_t *cand_q, int32_t *task_total, int32_t *tasks,
+                                       void *stream)
 {
     IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
-                     out_off && col && rowp && keep && cand_cnt && cand_off && cand_q && task_cnt &&
-                     task_off,
+                     out_off && col && rowp && keep && cand_cnt && cand_q && task_total && tasks,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
-    hipStream_t st = iamx::as_stream(stream);
     CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
-               thresh, keep, cand_cnt, task_cnt};
-    hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, a);
-    int rc = iamx_exclusive_scan_i32(cand_cnt, n_pairs, cand_off, stream);
-    if (rc != IAMX_OK) return rc;
-    rc = iamx_exclusive_scan_i32(task_cnt, n_pairs, task_off, stream);
-    if (rc != IAMX_OK) return rc;
-    hipLaunchKernelGGL(symlist_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, keep, out_off,
-                       cand_off, cand_q);
+               thresh, keep, cand_cnt, cand_q, task_total, tasks};
+    hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
 
 extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
                                   const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
-                                  const int64_t *out_off, const int64_t *cand_off,
-                                  const int32_t *cand_cnt, const int64_t *task_off, int32_t *cand_q,
+                                  const int64_t *out_off, const int32_t *cand_cnt,
+                                  int32_t *task_total, const int32_t *tasks, int32_t *cand_q,
                                   int n_pairs, double thresh, int32_t *d2, int32_t *cand_t,
                                   double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
                                   int32_t *zero_div, void *stream)
 {
-    IAMX_REQUIRE(desc && norm_q && norm_t && img_off && img_n && pairs && out_off && cand_off &&
-                     cand_cnt && task_off && cand_q && d2 && cand_t && cand_metric && cand_keep &&
+    IAMX_REQUIRE(desc && norm_q && norm_t && img_off && img_n && pairs && out_off && cand_cnt &&
+                     task_total && tasks && cand_q && d2 && cand_t && cand_metric && cand_keep &&
                      surv_cnt && zero_div,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     hipStream_t st = iamx::as_stream(stream);
-    ExactArgs a{desc, norm_q, norm_t, img_off, img_n, pairs, out_off, cand_off, task_off, cand_q,
-                n_pairs, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
+    ExactArgs a{desc, norm_q, norm_t, img_off, img_n, pairs, out_off, cand_cnt, cand_q, task_total,
+                tasks, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
     hipLaunchKernelGGL(symexact_kernel, dim3(1024), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, cand_off,
-                       cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt);
+    hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,
+                       cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total);
     return iamx::check_launch("iamx_knn2sym_exact");
 }
 

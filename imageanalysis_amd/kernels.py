@@ -325,8 +325,8 @@ class PairWorkspace(object):
         # symmetric sweep: bounds per row (allocated on first use, grown when a batch needs more)
         self.col = self.rowp = None
         self.cand_keep = torch.empty(r, dtype=U8, device=dev)
-        self.task_cnt = torch.zeros(p, dtype=I32, device=dev)
-        self.task_off = torch.zeros(p + 1, dtype=I64, device=dev)
+        self.task_total = torch.zeros(1, dtype=I32, device=dev)
+        self.tasks = torch.empty((p + r // 32 + 1, 2), dtype=I32, device=dev)
 
     def ensure_sym(self, col_rows, rowp_rows):
         dev = self.d2.device
@@ -424,15 +424,17 @@ class PairBatch(object):
                                         _ptr(self.d_pairs), _ptr(self.d_osrc), _ptr(self.d_sym_wg),
                                         _ptr(self.d_col_off), _ptr(self.d_rowp_off), _ptr(self.d_out),
                                         _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),
-                                        _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_off),
-                                        _ptr(ws.surv_q), _ptr(ws.task_cnt), _ptr(ws.task_off), s),
+                                        _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_q),
+                                        _ptr(ws.task_total), _ptr(ws.tasks), s),
               'iamx_knn2sym_candidates')
         check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.img_off),
                                    _ptr(st.img_n), _ptr(self.d_pairs), _ptr(self.d_out),
-                                   _ptr(ws.surv_off), _ptr(ws.seg_count), _ptr(ws.task_off),
+                                   _ptr(ws.seg_count), _ptr(ws.task_total), _ptr(ws.tasks),
                                    _ptr(ws.surv_q), self.n_pairs, float(thresh), _ptr(ws.d2),
                                    _ptr(ws.surv_t), _ptr(ws.surv_metric), _ptr(ws.cand_keep),
                                    _ptr(ws.surv_cnt), _ptr(ws.zero_div), s), 'iamx_knn2sym_exact')
+        # pair p's survivors sit at the start of its own row range
+        ws.surv_off[:self.n_pairs + 1].copy_(self.d_out, non_blocking=True)
 
     def run_knn2(self, ws):
         st = self.store

@@ -202,14 +202,16 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  * Candidates: pairs DEV [n_pairs][2] ordered (query image, train image); osrc DEV [n_pairs][2] =
  *   (index u of its unordered pair, role: 0 if the query image is B, 1 if it is A);
  *   out_off DEV [n_pairs+1] int64 rows of each ordered pair; keep DEV [rows] uint8 scratch;
- *   cand_cnt DEV [n_pairs], cand_off DEV [n_pairs+1] (written), cand_q DEV [rows]: candidate
- *   query rows (original numbering, ascending) of pair p at cand_off[p] .. + cand_cnt[p];
- *   task_cnt DEV [n_pairs] / task_off DEV [n_pairs+1] (written): 32-candidate tasks of the
- *   exact stage (one wave each: 32 candidates x the whole train image on the MFMA).
- * Exact: desc / norm_q / norm_t / img_off = the ORIGINAL-order store of iamx_desc_pack_*.  Writes d2 DEV
- *   [rows][2] for the candidate rows, then compacts every pair's list in place to its survivors:
- *   pair p owns cand_q / cand_t / cand_metric [cand_off[p] .. + surv_cnt[p]); zero_div is
- *   incremented for every row whose exact second distance is 0 (matcher.py:255 divides by it).
+ *   cand_cnt DEV [n_pairs] (written); cand_q DEV [rows]: the candidate query rows (original
+ *   numbering, ascending) of pair p at out_off[p] .. + cand_cnt[p] -- a pair's list lives in
+ *   its own slice of the row range, no scan over the pairs;
+ *   task_total DEV [1] (must be 0 on entry; iamx_knn2sym_exact leaves it 0), tasks DEV
+ *   [n_pairs + rows/32][2]: the 32-candidate tasks (ordered pair, block) of the exact stage.
+ * Exact: desc / norm_q / norm_t / img_off = the ORIGINAL-order store of iamx_desc_pack_*.  One
+ *   wave per task: 32 candidates x the whole train image on the MFMA.  Writes d2 DEV [rows][2]
+ *   for the candidate rows, then compacts every pair's list in place to its survivors: pair p
+ *   owns cand_q / cand_t / cand_metric [out_off[p] .. + surv_cnt[p]); zero_div is incremented
+ *   for every row whose exact second distance is 0 (matcher.py:255 divides by it).
  * ------------------------------------------------------------------------------------ */
 int64_t iamx_desc3_rows_cap(int64_t n_rows);
 int iamx_knn2sym_rows_per_wg(int form);
@@ -232,12 +234,11 @@ int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int3
                             const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
                             const int64_t *out_off, const int32_t *col, const int32_t *rowp,
                             int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
-                            int64_t *cand_off, int32_t *cand_q, int32_t *task_cnt,
-                            int64_t *task_off, void *stream);
+                            int32_t *cand_q, int32_t *task_total, int32_t *tasks, void *stream);
 int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
                        const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
-                       const int64_t *out_off, const int64_t *cand_off, const int32_t *cand_cnt,
-                       const int64_t *task_off, int32_t *cand_q, int n_pairs, double thresh,
+                       const int64_t *out_off, const int32_t *cand_cnt, int32_t *task_total,
+                       const int32_t *tasks, int32_t *cand_q, int n_pairs, double thresh,
                        int32_t *d2, int32_t *cand_t, double *cand_metric, uint8_t *cand_keep,
                        int32_t *surv_cnt, int32_t *zero_div, void *stream);
 

@@ -355,7 +355,8 @@ def test_fast_path_ragged_ties_and_tiny_classes():
         assert np.array_equal(a['st'][lo:hi], ridx[keep, 0]), (i, j)
 
 
-def test_overlapped_sweeps_equal_sequential_runs():
+@pytest.mark.parametrize('sym', [True, False], ids=['symmetric', 'one-direction'])
+def test_overlapped_sweeps_equal_sequential_runs(sym):
     """kernels.OverlappedSweeps (filter kernels of launch k on a second stream beside the sweep
     of launch k+1, two workspaces) leaves exactly what the one-stream sequence leaves"""
     import torch
@@ -367,15 +368,25 @@ def test_overlapped_sweeps_equal_sequential_runs():
         m = min(len(imgs[k]), len(imgs[k - 1])) // 3
         imgs[k][:m] = np.clip(imgs[k - 1][:m].astype(int) + rng.integers(-4, 5, (m, 128)), 0, 255)
     store = kernels.DescriptorStore.from_arrays(imgs)
-    pairs = np.array([(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j], np.int32)
-    batches = [kernels.PairBatch(store, pairs[s:s + 6]) for s in range(0, len(pairs), 6)]   # 5 launches
+    und = np.array([(i, j) for j in range(len(sizes)) for i in range(j)], np.int32)
+    batches = [kernels.PairBatch(store, np.concatenate([und[s:s + 3], und[s:s + 3, ::-1]]), sym=sym)
+               for s in range(0, len(und), 3)]                                      # 5 launches
+    assert all(b.sym == sym for b in batches)
     rows, npairs = max(b.rows for b in batches), max(b.n_pairs for b in batches)
     thresh = 270.0 * 0.75
 
     def snapshot(b, w):
-        n = int(w.surv_off[b.n_pairs].item())
         return (w.surv_cnt[:b.n_pairs].clone(), w.surv_off[:b.n_pairs + 1].clone(),
-                w.surv_q[:n].clone(), w.surv_t[:n].clone(), w.surv_metric[:n].clone())
+                w.surv_q.clone(), w.surv_t.clone(), w.surv_metric.clone())
+
+    def segments(snap):
+        """the survivor slices of every pair (what lies between them is scratch)"""
+        cnt, off, q, t, m = snap
+        out = []
+        for p in range(len(cnt)):
+            lo, hi = int(off[p]), int(off[p]) + int(cnt[p])
+            out.append((q[lo:hi].cpu().numpy(), t[lo:hi].cpu().numpy(), m[lo:hi].cpu().numpy()))
+        return out
 
     ws = kernels.PairWorkspace(rows, npairs)
     want = []
@@ -383,19 +394,19 @@ def test_overlapped_sweeps_equal_sequential_runs():
         b.run_knn2_fast(ws)
         b.run_filter_fast(ws, thresh)
         torch.cuda.synchronize()
-        want.append(snapshot(b, ws))
-    got = []
+        want.append(segments(snapshot(b, ws)))
     runner = kernels.OverlappedSweeps(rows, npairs)
     # snapshots are taken on the side stream right behind each launch's filter kernels
     lazy = []
-    runner.run(batches, thresh, after_filter=lambda b, w: lazy.append(
-        (w.surv_cnt[:b.n_pairs].clone(), w.surv_off[:b.n_pairs + 1].clone(), w.surv_q.clone(),
-         w.surv_t.clone(), w.surv_metric.clone())))
+    runner.run(batches, thresh, after_filter=lambda b, w: lazy.append(snapshot(b, w)))
     torch.cuda.synchronize()
     assert len(lazy) == len(batches)
-    for (cnt, off, q, t, m), (wc, wo, wq, wt, wm) in zip(lazy, want):
-        n = int(off[-1].item())
-        assert n == len(wq) > 0
-        assert torch.equal(cnt, wc) and torch.equal(off, wo)
-        assert torch.equal(q[:n], wq) and torch.equal(t[:n], wt) and torch.equal(m[:n], wm)
+    n_surv = 0
+    for snap, ref in zip(lazy, want):
+        got = segments(snap)
+        assert len(got) == len(ref)
+        for (q, t, m), (wq, wt, wm) in zip(got, ref):
+            assert np.array_equal(q, wq) and np.array_equal(t, wt) and np.array_equal(m, wm)
+            n_surv += len(q)
+    assert n_surv > 0
     assert sum(int(w.unresolved.item()) for w in runner.ws) == 0

@@ -25,6 +25,7 @@ def _configure(match_ratio=0.75, min_pairs=25, w=5472, h=3648):
     matcher.matcher_node.setInt('min_pairs', min_pairs)
     matcher.matcher_node.__dict__.pop('schedule', None)
     camera.set_image_params(w, h)
+    camera.set_K(3666.6665, 3666.6665, 2736.0, 1824.0)     # (the surface triangulation inverts K)
     matcher.configure()
     return matcher
 
