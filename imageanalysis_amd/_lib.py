@@ -84,8 +84,8 @@ SIGNATURES = {
     'iamx_ba_lsmr_prepare': (c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 3),
     'iamx_ba_lsmr_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 11
                              + [c_int, c_void_p]),
-    'iamx_ba_lsmr_phase': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 11
-                           + [c_int, c_int, c_void_p]),
+    'iamx_ba_lsmr_phase': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int]
+                           + [c_void_p] * 11 + [c_int, c_int, c_void_p]),
     'iamx_vec_axpby': (c_int, [c_int64, c_double, c_void_p, c_double, c_void_p, c_void_p]),
     'iamx_vec_mul2': (c_int, [c_int64] + [c_void_p] * 6),
     'iamx_vec_dot': (c_int, [c_int64] + [c_void_p] * 5),

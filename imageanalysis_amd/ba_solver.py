@@ -93,8 +93,12 @@ class DeviceBA(object):
                               (self.C * 7 + 3 * old_of_new[:, None] + np.arange(3)).ravel(), tail])
         i2h = np.concatenate([np.arange(self.C * 7),
                               (self.C * 7 + 3 * new_of_old[:, None] + np.arange(3)).ravel(), tail])
+        # several ranks: observations AND the point part of the LSMR n-vectors are sharded by
+        # point -- this rank owns the contiguous block [pt_lo, pt_hi) of the internal point order
+        self.pt_lo, self.pt_hi = 0, self.P
         if world > 1:
             sel = _dist.shard_observations_by_point(pt, self.P, rank, world)
+            self.pt_lo, self.pt_hi = _dist.point_range(pt, self.P, rank, world)
         else:
             sel = np.arange(cam.size)
         # Internal observation order: camera-major like the reference, but inside a camera by the
@@ -136,6 +140,7 @@ class DeviceBA(object):
         self._state_pin = None
         self.profile = None
         self.force_stepwise_lsmr = False
+        self.fused_phase_iterations = 0     # iterations run through iamx_ba_lsmr_phase (tests)
         # fused single-rank LSMR: replay a captured HIP graph per 64-iteration chunk
         self.use_graph = os.environ.get('IAMX_BA_GRAPH', '1') != '0'
         self.host_logic = False          # True: the O(n) TRF vector logic in numpy (_trf_host)
@@ -538,7 +543,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
                                  ctab=z(prob.C * 32), ptab=z(prob.P * 6),
                                  state=z(L.iamx_ba_lsmr_state_size()),
                                  part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
-                                 xr=z(2), tbuf=z(n))
+                                 xr=z(4), tbuf=z(n))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
     if 'dreg' not in ws:
         ws['dreg'] = torch.zeros(max(n, 1), dtype=F64, device=dev)
@@ -585,6 +590,8 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
               _ptr(prob.cam_ptr), _ptr(prob.pt_ptr), _ptr(prob.pt_obs), _ptr(prob.slot_cp), prob.O,
               prob.C, prob.P, _ptr(dreg_dev), _ptr(u1), _ptr(u2), _ptr(vt), _ptr(h), _ptr(hbar),
               _ptr(x), _ptr(ws['state']), _ptr(ws['part']))
+    mcommon = common[:11] + (prob.pt_lo, prob.pt_hi) + common[11:]
+
     def enqueue_launches():
         check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
                                      stream_ptr()), 'iamx_ba_lsmr_iterate')
@@ -609,15 +616,21 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
         elif not multi:
             enqueue_launches()
         else:
+            # two small all-reduces per iteration: 2 scalars, then the raw camera part of
+            # J^T ut' + one scalar (7 C + 1 doubles = 157 KB at configs[3]); the point part of
+            # every n-vector stays on the rank that owns the points
             xr, tbuf = ws['xr'], ws['tbuf']
-            tail = (_ptr(xr), _ptr(tbuf))
+            ncam = prob.C * 7
             for it in range(chunk):
                 par = it & 1
-                check(L.iamx_ba_lsmr_phase(*common, *tail, 0, par, stream_ptr()), 'iamx_ba_lsmr_phase')
-                _dist.allreduce_sum_(xr[:1])        # xr[1] (replicated part) is not summed
-                check(L.iamx_ba_lsmr_phase(*common, *tail, 1, par, stream_ptr()), 'iamx_ba_lsmr_phase')
-                _dist.allreduce_sum_(tbuf[:n])
-                check(L.iamx_ba_lsmr_phase(*common, *tail, 2, par, stream_ptr()), 'iamx_ba_lsmr_phase')
+                for phase in (0, 1, 2):
+                    check(L.iamx_ba_lsmr_phase(*mcommon, _ptr(xr), _ptr(tbuf), phase, par,
+                                               stream_ptr()), 'iamx_ba_lsmr_phase')
+                    if phase == 0:
+                        _dist.allreduce_sum_(xr[:2])
+                    elif phase == 1:
+                        _dist.allreduce_sum_(tbuf[:ncam + 1])
+            prob.fused_phase_iterations += chunk
 
     # The state block is copied out behind every chunk into its own pinned slot; the NEXT chunk
     # is enqueued before the host waits for that copy, so the device never idles while the host
@@ -645,6 +658,9 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
         cur ^= 1
     else:
         raise _lib.IamxError('fused LSMR did not latch a stop condition')
+    if multi:
+        # the point entries of x live on their owners (the others never left 0): complete x
+        _dist.allreduce_sum_(x[prob.C * 7:n])
     ph.__exit__()
     if st[_R['ISTOP']] == 8:
         raise _lib.IamxError('fused LSMR broke down (NaN in the recurrence)')

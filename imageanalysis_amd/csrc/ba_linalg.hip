@@ -384,16 +384,41 @@ struct LsmrArgs {
     double *partU, *partV, *partX;
     int n_partV;
     double *partU2;
-    // xr[0] = |ut1'|^2 (rank local), tbuf = raw J^T ut1' (camera part always; with multi != 0
-    // also the point part).  Multi-rank form (observations sharded by point, n-vectors
-    // replicated): the caller all-reduces xr[0] and tbuf[0..n) between the phases.
+    // Sums that cross kernels: xr[0] + xr[2] = |ut'|^2, xr[1] + xr[3] = |x|^2 (several ranks
+    // only).  tbuf[0 .. 7C) = raw camera part of J^T ut1'.
+    // Multi-rank form: observations AND the point part of every n-vector are sharded by point
+    // (this rank owns points [pt_lo, pt_hi)); only the camera part (7C entries) is replicated.
+    // xr[0] / xr[1] hold the rank-local parts (observations + owned points), xr[2] / xr[3] the
+    // replicated camera parts; tbuf[7C] carries the rank's sum of squares of the point part of
+    // vt'.  The caller all-reduces xr[0..2) after phase 0 and tbuf[0 .. 7C] after phase 1.
     double *xr, *tbuf;
     int multi;
+    int pt_lo, pt_hi;
 };
 
 
 constexpr int LS_U2_BLOCKS = 256;     // fixed grids => fixed reduction trees
 constexpr int LS_UPD_BLOCKS = 1024;
+// the first blocks of the n-vector grids take the (replicated) camera entries, the others the
+// point entries of the points this rank owns: the two kinds of partial sums stay apart
+constexpr int LS_U2_CAM = 16;
+constexpr int LS_UPD_CAM = 32;
+
+// n-vector entries of block b (of nb, the first ncam on camera entries): i = first; i < end; i += step
+struct NvecRange { int64_t first, end, step; };
+__device__ __forceinline__ NvecRange nvec_range(const LsmrArgs &A, int b, int nb, int ncam)
+{
+    NvecRange r;
+    const int64_t ncam_e = (int64_t)A.n_cams * 7;
+    if (b < ncam) {
+        r.first = (int64_t)b * 256 + threadIdx.x; r.end = ncam_e; r.step = (int64_t)ncam * 256;
+    } else {
+        r.first = ncam_e + 3 * (int64_t)A.pt_lo + (int64_t)(b - ncam) * 256 + threadIdx.x;
+        r.end = ncam_e + 3 * (int64_t)A.pt_hi;
+        r.step = (int64_t)(nb - ncam) * 256;
+    }
+    return r;
+}
 
 struct Givens { double c, s, r; };
 
@@ -431,7 +456,7 @@ __device__ __forceinline__ double sum_partials(const double *__restrict__ part, 
 __device__ __forceinline__ double beta_new(const LsmrArgs &A, double *sh)
 {
     (void)sh;
-    return sqrt(A.xr[0] + A.xr[1]);
+    return sqrt(A.xr[0] + A.xr[2]);
 }
 
 // a wave-uniform double that the compiler computed with vector instructions: move it to scalar
@@ -523,10 +548,10 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
     if (S[R_ISTOP] != 0.0) return;
     const double *in = S + parity * S_NBUF;
     const double ia = uniform(1.0 / in[S_ALPHA]), ab = uniform(in[S_ALPHA] / in[S_BETA]);
-    if ((int)blockIdx.x >= A.n_cams) {       // the replicated n-vector part of ut'
-        const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    if ((int)blockIdx.x >= A.n_cams) {       // the n-vector part of ut' (camera + owned points)
+        const NvecRange R = nvec_range(A, blockIdx.x - A.n_cams, LS_U2_BLOCKS, LS_U2_CAM);
         double acc2 = 0.0;
-        for (int64_t i = (int64_t)(blockIdx.x - A.n_cams) * 256 + threadIdx.x; i < n; i += (int64_t)LS_U2_BLOCKS * 256) {
+        for (int64_t i = R.first; i < R.end; i += R.step) {
             const double v = ia * A.dreg[i] * A.vt[i] - ab * A.u2[i];
             A.u2[i] = v;
             acc2 += v * v;
@@ -667,67 +692,52 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
     }
 }
 
-// Several ranks only -- one workgroup between the forward kernel and the all-reduce of xr[0]
-// (a single rank does the same in the prologue of every adjoint workgroup):
-//   * lsmr.py "Test for convergence" of the PREVIOUS iteration (state buffer `parity`, |x|^2
-//     partials of its update kernel); a latched R_ISTOP turns everything enqueued behind this
-//     launch into no-ops
-//   * xr[0] = this rank's |ut1'|^2 (all-reduced by the caller on several ranks),
-//     xr[1] = |ut2'|^2 (replicated part), so that beta' is two loads for everybody else.
+// Several ranks only -- one workgroup between the forward kernel and the all-reduce of xr[0..2):
+//   xr[0] = this rank's part of |ut'|^2 (its observations + the owned point entries of ut2'),
+//   xr[1] = its part of |x|^2 (owned point entries),  xr[2] / xr[3] = the camera parts of the two
+//   (replicated: every rank computes the same numbers, they are NOT summed over ranks).
+// The stopping tests of the previous iteration need the reduced |x|^2 and run in the prologue of
+// the adjoint kernel, like on a single rank.
 // A separate launch on purpose: letting the last forward workgroup do it ("threadfence
 // reduction") needs device-scope fences, and on this 8-XCD part every such fence writes the
 // XCD's L2 back -- measured 48 -> 297 us for the forward kernel.
 __global__ __launch_bounds__(256) void lsmr_sumU_kernel(LsmrArgs A, int parity)
 {
-    double *S = A.S;
-    if (S[R_ISTOP] != 0.0) return;
-    const double *in = S + parity * S_NBUF;
-    const double itn = in[S_ITN];
-    // the three sums in one pass: all loads in flight together, one reduction
-    double aX = 0.0, aU = 0.0, aU2 = 0.0;
-    for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) aX += A.partX[i];
-    for (int i = threadIdx.x; i < A.n_cams; i += 256) aU += A.partU[i];
-    for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) aU2 += A.partU2[i];
+    (void)parity;
+    if (A.S[R_ISTOP] != 0.0) return;
+    double v[5] = {0, 0, 0, 0, 0};                 // U obs, U2 cam, U2 pts, X cam, X pts
+    for (int i = threadIdx.x; i < A.n_cams; i += 256) v[0] += A.partU[i];
+    for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) v[i < LS_U2_CAM ? 1 : 2] += A.partU2[i];
+    for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) v[i < LS_UPD_CAM ? 3 : 4] += A.partX[i];
+    __shared__ double sh5[4][5];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        aX += __shfl_xor(aX, m);
-        aU += __shfl_xor(aU, m);
-        aU2 += __shfl_xor(aU2, m);
-    }
-    __shared__ double sh3[4][3];
-    if ((threadIdx.x & 63) == 0) {
-        sh3[threadIdx.x >> 6][0] = aX; sh3[threadIdx.x >> 6][1] = aU; sh3[threadIdx.x >> 6][2] = aU2;
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
+        if ((threadIdx.x & 63) == 0) sh5[threadIdx.x >> 6][k] = v[k];
     }
     __syncthreads();
-    const double sumX = sh3[0][0] + sh3[1][0] + sh3[2][0] + sh3[3][0];
-    const double s = sh3[0][1] + sh3[1][1] + sh3[2][1] + sh3[3][1];
-    const double s2 = sh3[0][2] + sh3[1][2] + sh3[2][2] + sh3[3][2];
-    if (itn > 0.0) {             // lsmr.py: "Test for convergence" of iteration itn
-        const double normx = sqrt(sumX);
-        const double normb = S[R_NORMB], normA = in[S_NORMA], normr = in[S_NORMR];
-        const double normar = in[S_NORMAR], condA = in[S_CONDA];
-        const double test1 = normr / normb;
-        const double test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY;
-        const double test3 = 1.0 / condA;
-        const double t1 = test1 / (1 + normA * normx / normb);
-        const double rtol = S[R_BTOL] + S[R_ATOL] * normA * normx / normb;
-        double istop = 0;
-        if (itn >= S[R_MAXITER]) istop = 7;
-        if (1 + test3 <= 1) istop = 6;
-        if (1 + test2 <= 1) istop = 5;
-        if (1 + t1 <= 1) istop = 4;
-        if (test3 <= S[R_CTOL]) istop = 3;
-        if (test2 <= S[R_ATOL]) istop = 2;
-        if (test1 <= rtol) istop = 1;
-        if (!(test1 == test1) || !(normx == normx)) istop = 8;     // breakdown (NaN)
-        if (threadIdx.x == 0) {
-            S[R_ITN] = itn; S[R_NORMR] = normr; S[R_NORMAR] = normar; S[R_NORMA] = normA;
-            S[R_CONDA] = condA; S[R_NORMX] = normx;
-            if (istop != 0) S[R_ISTOP] = istop;
-        }
-        if (istop != 0) return;
+    if (threadIdx.x == 0) {
+        double t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] = sh5[0][k] + sh5[1][k] + sh5[2][k] + sh5[3][k];
+        A.xr[0] = t[0] + t[2];
+        A.xr[1] = t[4];
+        A.xr[2] = t[1];
+        A.xr[3] = t[3];
     }
-    if (threadIdx.x == 0) { A.xr[0] = s; A.xr[1] = s2; }
+}
+
+// Several ranks only -- behind the adjoint kernel: this rank's sum of squares of the point part
+// of vt' goes to tbuf[7C], right behind the raw camera part, so that ONE all-reduce of
+// tbuf[0 .. 7C] delivers both
+__global__ __launch_bounds__(256) void lsmr_sumV_kernel(LsmrArgs A)
+{
+    __shared__ double sh[4];
+    if (A.S[R_ISTOP] != 0.0) return;
+    const int npb = (A.pt_hi - A.pt_lo + 255) / 256;
+    const double s = sum_partials(A.partV, npb, sh);
+    if (threadIdx.x == 0) A.tbuf[(int64_t)A.n_cams * 7] = s;
 }
 
 // ---- kernel B: beta', point part of J^T ut', vt' --------------------------------------------
@@ -743,34 +753,42 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
     __shared__ double prod[3][ADJ_CH];
-    const bool raw = A.multi != 0;
     if (A.S[R_ISTOP] != 0.0) return;             // (tbuf keeps stale values: nobody reads them)
     const double *in = A.S + parity * S_NBUF;
     double ib = 0.0, ba = 0.0;
-    if (!raw) {
-        // Single rank: no launch between the forward and this kernel.  Every workgroup sums
-        // |x|^2, |ut1'|^2, |ut2'|^2 partials itself (same code, same order => bit-identical
-        // decisions everywhere), runs the stopping tests of the previous iteration and derives
-        // beta'; workgroup 0 records them.  (Several ranks: lsmr_sumU_kernel + all-reduce.)
+    {
+        // No launch between the forward kernel (+ the all-reduce on several ranks) and this one:
+        // every workgroup derives |x|^2 and |ut'|^2 itself -- from the partial sums on a single
+        // rank, from the reduced xr on several (same code, same order => bit-identical decisions
+        // everywhere) --, runs the stopping tests of the previous iteration and derives beta';
+        // workgroup 0 records them.
         double *S = A.S;
-        double aX = 0.0, aU = 0.0, aU2 = 0.0;
-        for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) aX += A.partX[i];
-        for (int i = threadIdx.x; i < A.n_cams; i += 256) aU += A.partU[i];
-        for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) aU2 += A.partU2[i];
+        double sumX, sUU;
+        if (A.multi) {
+            sumX = A.xr[1] + A.xr[3];
+            sUU = A.xr[0] + A.xr[2];
+        } else {
+            double aX = 0.0, aU = 0.0, aU2 = 0.0;
+            for (int i = threadIdx.x; i < LS_UPD_BLOCKS; i += 256) aX += A.partX[i];
+            for (int i = threadIdx.x; i < A.n_cams; i += 256) aU += A.partU[i];
+            for (int i = threadIdx.x; i < LS_U2_BLOCKS; i += 256) aU2 += A.partU2[i];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            aX += __shfl_xor(aX, m);
-            aU += __shfl_xor(aU, m);
-            aU2 += __shfl_xor(aU2, m);
+            for (int m = 32; m >= 1; m >>= 1) {
+                aX += __shfl_xor(aX, m);
+                aU += __shfl_xor(aU, m);
+                aU2 += __shfl_xor(aU2, m);
+            }
+            __shared__ double sh3[4][3];
+            if ((threadIdx.x & 63) == 0) {
+                sh3[threadIdx.x >> 6][0] = aX; sh3[threadIdx.x >> 6][1] = aU; sh3[threadIdx.x >> 6][2] = aU2;
+            }
+            __syncthreads();
+            sumX = sh3[0][0] + sh3[1][0] + sh3[2][0] + sh3[3][0];
+            const double sU = sh3[0][1] + sh3[1][1] + sh3[2][1] + sh3[3][1];
+            const double sU2 = sh3[0][2] + sh3[1][2] + sh3[2][2] + sh3[3][2];
+            sUU = sU + sU2;
+            if (blockIdx.x == 0 && threadIdx.x == 0) { A.xr[0] = sUU; A.xr[2] = 0.0; }
         }
-        __shared__ double sh3[4][3];
-        if ((threadIdx.x & 63) == 0) {
-            sh3[threadIdx.x >> 6][0] = aX; sh3[threadIdx.x >> 6][1] = aU; sh3[threadIdx.x >> 6][2] = aU2;
-        }
-        __syncthreads();
-        const double sumX = sh3[0][0] + sh3[1][0] + sh3[2][0] + sh3[3][0];
-        const double sU = sh3[0][1] + sh3[1][1] + sh3[2][1] + sh3[3][1];
-        const double sU2 = sh3[0][2] + sh3[1][2] + sh3[2][2] + sh3[3][2];
         const double itn = in[S_ITN];
         if (itn > 0.0) {             // lsmr.py: "Test for convergence" of iteration itn
             const double normx = sqrt(sumX);
@@ -797,8 +815,7 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
             }
             if (istop != 0) return;
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { A.xr[0] = sU; A.xr[1] = sU2; }
-        const double bn = sqrt(sU + sU2);
+        const double bn = sqrt(sUU);
         if (!(bn > 0)) {         // exact solution reached: v keeps its value (lsmr.py "if beta > 0")
             if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
             return;
@@ -806,14 +823,14 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
         ib = 1.0 / bn;
         ba = bn / in[S_ALPHA];
     }
-    const int n_pt_blocks = (A.n_pts + 255) / 256;
+    const int n_pt_blocks = (A.pt_hi - A.pt_lo + 255) / 256;
     double sq = 0.0;
     if ((int)blockIdx.x < n_pt_blocks) {
         double cal[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) cal[i] = A.calib[i];
-        const int p0 = blockIdx.x * 256;
-        const int p1 = min(p0 + 256, A.n_pts);
+        const int p0 = A.pt_lo + blockIdx.x * 256;
+        const int p1 = min(p0 + 256, A.pt_hi);
         const int p = p0 + threadIdx.x;
         const int e0 = A.pt_ptr[p0], e1 = A.pt_ptr[p1];
         const int my_lo = p < p1 ? A.pt_ptr[p] : e1, my_hi = p < p1 ? A.pt_ptr[p + 1] : e1;
@@ -853,7 +870,6 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int64_t i = (int64_t)A.n_cams * 7 + (int64_t)p * 3 + k;
-                if (raw) { A.tbuf[i] = acc[k]; continue; }
                 const double v = (acc[k] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
                 A.vt[i] = v;
                 sq += v * v;
@@ -867,32 +883,33 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
             sq = v * v;
         }
     }
-    if (raw) return;
     const double s = block_sum_256(sq, sh);
     if (threadIdx.x == 0) A.partV[blockIdx.x] = s;
 }
 
-// multi-rank: vt' from the all-reduced J^T ut1 (tbuf), squared-norm partials
+// multi-rank: the camera part of vt' from the all-reduced raw camera part of J^T ut1' (tbuf);
+// LS_UPD_CAM workgroups, their squared-norm partials behind those of the point workgroups
 __global__ __launch_bounds__(256) void lsmr_vt_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
     if (A.S[R_ISTOP] != 0.0) return;
     const double *in = A.S + parity * S_NBUF;
+    const int npb = (A.pt_hi - A.pt_lo + 255) / 256;
     const double bn = beta_new(A, sh);
     if (!(bn > 0)) {
-        if (threadIdx.x == 0) A.partV[blockIdx.x] = 0.0;
+        if (threadIdx.x == 0) A.partV[npb + blockIdx.x] = 0.0;
         return;
     }
     const double ib = 1.0 / bn, ba = bn / in[S_ALPHA];
-    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    const int64_t n = (int64_t)A.n_cams * 7;
     double sq = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_UPD_BLOCKS * 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_UPD_CAM * 256) {
         const double v = (A.tbuf[i] + A.dreg[i] * A.u2[i]) * ib - ba * A.vt[i];
         A.vt[i] = v;
         sq += v * v;
     }
     const double s = block_sum_256(sq, sh);
-    if (threadIdx.x == 0) A.partV[blockIdx.x] = s;
+    if (threadIdx.x == 0) A.partV[npb + blockIdx.x] = s;
 }
 
 // ---- kernel C: alpha', plane rotations (lsmr.py main loop), then h / hbar / x -------------
@@ -904,7 +921,13 @@ __global__ __launch_bounds__(256) void lsmr_update3_kernel(LsmrArgs A, int parit
     const double *in = S + parity * S_NBUF;
     double *out = S + (1 - parity) * S_NBUF;
     const double beta = beta_new(A, sh);
-    const double s2 = sum_partials(A.partV, A.n_partV, sh);
+    double s2;
+    if (A.multi) {       // camera part (replicated partials) + the all-reduced point part
+        const int npb = (A.pt_hi - A.pt_lo + 255) / 256;
+        s2 = sum_partials(A.partV + npb, LS_UPD_CAM, sh) + A.tbuf[(int64_t)A.n_cams * 7];
+    } else {
+        s2 = sum_partials(A.partV, A.n_partV, sh);
+    }
     const double alpha = beta > 0 ? sqrt(s2) : in[S_ALPHA];
 
     const Givens g1 = sym_ortho(in[S_ALPHABAR], 0.0);
@@ -957,9 +980,9 @@ __global__ __launch_bounds__(256) void lsmr_update3_kernel(LsmrArgs A, int parit
     }
 
     const double ia = alpha > 0 ? 1.0 / alpha : 0.0;
-    const int64_t n = (int64_t)A.n_cams * 7 + (int64_t)A.n_pts * 3;
+    const NvecRange R = nvec_range(A, blockIdx.x, LS_UPD_BLOCKS, LS_UPD_CAM);
     double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)LS_UPD_BLOCKS * 256) {
+    for (int64_t i = R.first; i < R.end; i += R.step) {
         const double hb = A.h[i] + chb * A.hbar[i];
         A.hbar[i] = hb;
         const double xv = A.x[i] + cx * hb;
@@ -1031,7 +1054,7 @@ extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, cons
                reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
                partials, partials + L.off_V, partials + L.off_X, L.n_adj, partials + L.off_U2,
-               xr, tbuf, 0};
+               xr, tbuf, 0, 0, n_pts};
     hipStream_t st = iamx::as_stream(stream);
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
@@ -1042,40 +1065,47 @@ extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, cons
     return iamx::check_launch("iamx_ba_lsmr_iterate");
 }
 
-// One phase of one iteration of the multi-rank form (the caller all-reduces xr[0] after phase 0
-// and tbuf[0..n) after phase 1, on the same stream):
-//   phase 0: stopping tests of the previous iteration, ut', raw camera part of J^T ut1' -> tbuf,
-//            xr[0] = local |ut1'|^2
-//   phase 1: raw point part of J^T ut1' -> tbuf
-//   phase 2: vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
+// One phase of one iteration of the multi-rank form: observations and the point part of every
+// n-vector sharded by point (this rank owns the points [pt_lo, pt_hi) of the internal order), the
+// camera part (7 n_cams entries) replicated.  The caller all-reduces (sum) xr[0..2) after phase
+// 0 and tbuf[0 .. 7 n_cams] (7 n_cams + 1 doubles) after phase 1, on the same stream:
+//   phase 0: ut', raw camera part of J^T ut1' -> tbuf, local / replicated sums -> xr[0..4)
+//   phase 1: stopping tests of the previous iteration (reduced |x|^2), beta', point part of vt'
+//            (rank local), its sum of squares -> tbuf[7 n_cams]
+//   phase 2: camera part of vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
+// Afterwards the point part of x is complete on its owner only (the entries of the other ranks
+// are untouched: all-reduce x[7 n_cams ..) once per solve if x started as zero).
 extern "C" int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *calib,
                                   const int32_t *pt_idx, const int32_t *cam_ptr,
                                   const int32_t *pt_ptr, const int32_t *pt_obs,
                                   const int32_t *slot_cp, int64_t n_obs, int n_cams, int n_pts,
-                                  const double *dreg, double *u1, double *u2, double *vt, double *h,
-                                  double *hbar, double *x, double *state, double *partials,
-                                  double *xr, double *tbuf, int phase, int parity, void *stream)
+                                  int pt_lo, int pt_hi, const double *dreg, double *u1, double *u2,
+                                  double *vt, double *h, double *hbar, double *x, double *state,
+                                  double *partials, double *xr, double *tbuf, int phase, int parity,
+                                  void *stream)
 {
     IAMX_REQUIRE(ctab && ptab && calib && pt_idx && cam_ptr && pt_ptr && pt_obs && slot_cp && dreg &&
                      u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
                  "null pointer");
     IAMX_REQUIRE(n_obs >= 0 && n_cams > 0 && n_pts > 0 && phase >= 0 && phase <= 2 &&
-                     (parity == 0 || parity == 1),
-                 "bad size / phase / parity");
+                     (parity == 0 || parity == 1) && pt_lo >= 0 && pt_lo <= pt_hi && pt_hi <= n_pts,
+                 "bad size / phase / parity / point range");
     const PartLayout L = part_layout(n_cams, n_pts);
     LsmrArgs A{ctab, ptab, calib, pt_idx, cam_ptr, pt_ptr, pt_obs,
                reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
-               partials, partials + L.off_V, partials + L.off_X, LS_UPD_BLOCKS, partials + L.off_U2,
-               xr, tbuf, 1};
+               partials, partials + L.off_V, partials + L.off_X, 0, partials + L.off_U2,
+               xr, tbuf, 1, pt_lo, pt_hi};
     hipStream_t st = iamx::as_stream(stream);
+    const int npb = (pt_hi - pt_lo + 255) / 256;
     if (phase == 0) {
         hipLaunchKernelGGL(lsmr_fwd_kernel, dim3(n_cams + LS_U2_BLOCKS), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_sumU_kernel, dim3(1), dim3(256), 0, st, A, parity);
     } else if (phase == 1) {
-        hipLaunchKernelGGL(lsmr_adj_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, A, parity);
+        if (npb > 0) hipLaunchKernelGGL(lsmr_adj_kernel, dim3(npb), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_sumV_kernel, dim3(1), dim3(256), 0, st, A);
     } else {
-        hipLaunchKernelGGL(lsmr_vt_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
+        hipLaunchKernelGGL(lsmr_vt_kernel, dim3(LS_UPD_CAM), dim3(256), 0, st, A, parity);
         hipLaunchKernelGGL(lsmr_update3_kernel, dim3(LS_UPD_BLOCKS), dim3(256), 0, st, A, parity);
     }
     return iamx::check_launch("iamx_ba_lsmr_phase");

@@ -120,16 +120,31 @@ def allreduce_sum_(tensor, group=None):
     return tensor
 
 
+def point_owner(point_indices, n_points, world_size):
+    """rank that owns each point (contiguous blocks of point ids, balanced by observation
+    count): point p belongs to rank floor(world * (observations of points < p) / total)."""
+    point_indices = np.asarray(point_indices)
+    per_point = np.bincount(point_indices, minlength=n_points)
+    csum = np.cumsum(per_point)
+    total = int(csum[-1]) if len(csum) else 0
+    before = csum - per_point
+    return np.minimum((before * world_size) // max(total, 1), world_size - 1)
+
+
+def point_range(point_indices, n_points, rank, world_size):
+    """[lo, hi): the contiguous block of point ids owned by `rank` (the blocks of all ranks
+    partition range(n_points))."""
+    owner = point_owner(point_indices, n_points, world_size)
+    lo = int(np.searchsorted(owner, rank, side='left'))
+    hi = int(np.searchsorted(owner, rank, side='right'))
+    return lo, hi
+
+
 def shard_observations_by_point(point_indices, n_points, rank, world_size):
     """BA: all observations of a point live on one rank (point blocks and point elimination
     stay rank-local; only camera-side sums are reduced).  Points are dealt in contiguous
     blocks balanced by observation count.  Returns the indices (into the camera-major
     observation list) owned by `rank`, in ascending order (camera-major order is preserved)."""
     point_indices = np.asarray(point_indices)
-    per_point = np.bincount(point_indices, minlength=n_points)
-    csum = np.cumsum(per_point)
-    total = int(csum[-1]) if len(csum) else 0
-    # point p belongs to rank floor(world * (obs before p) / total)
-    before = csum - per_point
-    owner = np.minimum((before * world_size) // max(total, 1), world_size - 1)
+    owner = point_owner(point_indices, n_points, world_size)
     return np.nonzero(owner[point_indices] == rank)[0]

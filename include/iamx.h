@@ -417,7 +417,7 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
  *   buffered scalar recurrences, the tolerances and the latched results (layout and
  *   initialisation: imageanalysis_amd/ba_solver.py); once istop is latched the remaining
  *   iterations are no-ops.  u1 [2 n_obs], u2/vt/h/hbar/x [n] DEV work vectors; partials DEV
- *   [iamx_ba_lsmr_partials_size]; xr DEV [2] (|ut1|^2, |ut2|^2), tbuf DEV [n] (raw J^T ut1).
+ *   [iamx_ba_lsmr_partials_size]; xr DEV [4] (sums that cross kernels), tbuf DEV [n] (raw J^T ut1).
  *   pt_idx [n_obs] camera-major; cam_ptr / pt_ptr / pt_obs as for iamx_ba_jtv; slot_cp DEV
  *   [n_obs][2] int32 = (camera, point) of the observation in point-sorted slot e = pt_obs[e].
  *   Deterministic (fixed reduction trees, no atomics). */
@@ -432,18 +432,26 @@ int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, const double *c
                          double *h, double *hbar, double *x, double *state, double *partials,
                          double *xr, double *tbuf, int n_iter, void *stream);
 
-/* Multi-rank form of the same iteration (observations sharded by point, n-vectors replicated):
- * one call per phase; the caller all-reduces (sum) xr[0] (not xr[1]) after phase 0 and tbuf[0..n) after
- * phase 1 on the same stream (RCCL).  phase 0: stopping tests of the previous iteration, ut',
- * camera part of tbuf, xr[0] = local |ut1'|^2;  phase 1: point part of tbuf = local J^T ut1';
- * phase 2: vt' from the reduced tbuf,
- * alpha', plane rotations, h / hbar / x.  parity = iteration & 1.  xr DEV [2] (only xr[0] is reduced), tbuf DEV [n]. */
+/* Multi-rank form of the same iteration: observations AND the point part of every n-vector are
+ * sharded by point (this rank owns the points [pt_lo, pt_hi) of the internal order and every
+ * observation of them); only the camera part (7 n_cams entries) is replicated.  One call per
+ * phase; the caller all-reduces (sum, RCCL, same stream) xr[0..2) after phase 0 and
+ * tbuf[0 .. 7 n_cams] (7 n_cams + 1 doubles: 157 KB at BASELINE configs[3]) after phase 1.
+ *   phase 0: ut', raw camera part of J^T ut1' -> tbuf; xr[0] / xr[1] = this rank's parts of
+ *            |ut'|^2 / |x|^2, xr[2] / xr[3] = their replicated camera parts
+ *   phase 1: stopping tests of the previous iteration, beta', point part of vt' (rank local),
+ *            tbuf[7 n_cams] = its sum of squares
+ *   phase 2: camera part of vt' from the reduced tbuf, alpha', plane rotations, h / hbar / x
+ * parity = iteration & 1.  xr DEV [4], tbuf DEV [n].  The point entries of x that belong to
+ * other ranks are never touched (all-reduce x[7 n_cams ..) once per solve when x started 0).
+ * In iamx_ba_lsmr_iterate (single rank) xr is DEV [4] as well. */
 int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *calib,
                        const int32_t *pt_idx, const int32_t *cam_ptr, const int32_t *pt_ptr,
                        const int32_t *pt_obs, const int32_t *slot_cp, int64_t n_obs, int n_cams,
-                       int n_pts, const double *dreg, double *u1, double *u2, double *vt, double *h,
-                       double *hbar, double *x, double *state, double *partials, double *xr,
-                       double *tbuf, int phase, int parity, void *stream);
+                       int n_pts, int pt_lo, int pt_hi, const double *dreg, double *u1, double *u2,
+                       double *vt, double *h, double *hbar, double *x, double *state,
+                       double *partials, double *xr, double *tbuf, int phase, int parity,
+                       void *stream);
 
 /* float64 vector kernels used by the device LSMR (scipy/sparse/linalg/_isolve/lsmr.py):
  *   axpby: y = a*x + b*y (b == 0 ignores y's old content)

@@ -199,9 +199,32 @@ def _two_rank_solve(rank, world, port, path, outdir):
     opt = optimizer.Optimizer('/nonexistent')
     opt.solver = 'device'
     opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    # record what the solve all-reduces (element counts) and that it runs the fused phase path
+    from imageanalysis_amd import ba_solver, dist as D
+    sizes = []
+    plain = D.allreduce_sum_
+
+    def counting(t, group=None):
+        sizes.append(int(t.numel()))
+        return plain(t, group)
+    D.allreduce_sum_ = ba_solver._dist.allreduce_sum_ = counting
+    phases = []
+    real_phase = ba_solver.lib().iamx_ba_lsmr_phase
+
+    class _Lib(object):                               # ctypes functions cannot be patched in place
+        def __getattr__(self, name):
+            if name == 'iamx_ba_lsmr_phase':
+                def call(*a):
+                    phases.append(int(a[-3]))
+                    return real_phase(*a)
+                return call
+            return getattr(ba_solver._lib.lib(), name)
+    ba_solver.lib = lambda: _Lib()
     opt.run()
     np.save(os.path.join(outdir, 'x_r%d.npy' % rank), opt.result.x)
     np.save(os.path.join(outdir, 'f_r%d.npy' % rank), opt.result.fun)
+    np.save(os.path.join(outdir, 'red_r%d.npy' % rank), np.array(sizes, np.int64))
+    np.save(os.path.join(outdir, 'ph_r%d.npy' % rank), np.array(phases, np.int64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -228,5 +251,17 @@ def test_device_trf_two_ranks_point_sharded(tmp_path):
     f0 = np.load(tmp_path / 'f_r0.npy')
     assert f0.shape == opt.result.fun.shape
     c1, c2 = 0.5 * f0 @ f0, 0.5 * opt.result.fun @ opt.result.fun
-    assert abs(c1 - c2) / c2 < 1e-5      # 1 rank runs the fused LSMR, 2 ranks the stepwise form
+    assert abs(c1 - c2) / c2 < 1e-5      # (the partial sums of 1 and 2 ranks round differently)
     assert np.abs(x0 - opt.result.x).max() < 1e-5 * np.abs(opt.result.x).max()
+    # the two ranks ran the fused LSMR through iamx_ba_lsmr_phase: phases 0, 1, 2 in turn, and per
+    # iteration exactly two all-reduces -- 2 scalars and the camera part of J^T u + 1 scalar; the
+    # point part of the n-vectors is never reduced inside the iteration
+    C, n = opt.n_cameras, opt.result.x.size
+    for r in range(2):
+        ph = np.load(tmp_path / ('ph_r%d.npy' % r))
+        assert len(ph) >= 3 * 64 and np.array_equal(ph, np.tile([0, 1, 2], len(ph) // 3))
+        red = np.load(tmp_path / ('red_r%d.npy' % r))
+        iters = len(ph) // 3
+        assert (red == 2).sum() == iters and (red == 7 * C + 1).sum() == iters
+        # full n-vectors are reduced only O(1) times per outer iteration (gradient, init, x)
+        assert (red >= n - 7 * C).sum() <= 8 * (opt.result.njev + 2)
