@@ -60,6 +60,7 @@ SIGNATURES = {
     'iamx_triangulate_ground': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int64]
                                 + [c_void_p] * 3),
     'iamx_triangulate_pairs': (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p, c_void_p]),
+    'iamx_similarity_pairs': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_void_p, c_void_p, c_void_p]),
@@ -86,6 +87,11 @@ SIGNATURES = {
                              + [c_int, c_void_p]),
     'iamx_ba_lsmr_phase': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int]
                            + [c_void_p] * 11 + [c_int, c_int, c_void_p]),
+    'iamx_comm_unique_id': (c_int, [c_void_p]),
+    'iamx_comm_init': (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    'iamx_comm_destroy': (c_int, [c_void_p]),
+    'iamx_comm_allgather': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'iamx_comm_allreduce_f64': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'iamx_vec_axpby': (c_int, [c_int64, c_double, c_void_p, c_double, c_void_p, c_void_p]),
     'iamx_vec_mul2': (c_int, [c_int64] + [c_void_p] * 6),
     'iamx_vec_dot': (c_int, [c_int64] + [c_void_p] * 5),

@@ -163,7 +163,108 @@ __global__ __launch_bounds__(256) void triangulate_pairs_kernel(
     out_z[(int64_t)p * clip + k] = X[2] / X[3];
 }
 
+// ---------------------------------------------------------------------------------
+// 4-DOF similarity (rotation, uniform scale, translation) between the matched keypoints of an
+// image pair -- the matrix the reference asks cv2.estimateAffinePartial2D for
+// (scripts/lib/smart.py:66-89 find_affine), with a DETERMINISTIC robust fit in place of
+// OpenCV's RANSAC: least squares on all matches, then nine re-fits on the matches whose
+// residual is at most 200, 50, 10, 3, 3, ... px under the current model.
+// grid = (pairs, 2): direction 0 maps image b's pixels onto image a's (find_affine(a, b)),
+// direction 1 the other way (find_affine(b, a) on the mirrored list).  Fixed reduction trees.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum5(double (&v)[5], double (*sh)[5])
+{
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v[k] += __shfl_xor(v[k], m);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sh[threadIdx.x >> 6][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+}
+
+__global__ __launch_bounds__(256) void similarity_pairs_kernel(
+    const int32_t *__restrict__ pair_img, const int64_t *__restrict__ kp_off,
+    const float *__restrict__ xy, const int32_t *__restrict__ m_cnt,
+    const int32_t *__restrict__ m_pairs, int clip, double *__restrict__ out_aff,
+    int32_t *__restrict__ out_ok)
+{
+    __shared__ double sh[4][5];
+    const int p = blockIdx.x, dir = blockIdx.y;
+    const int n = m_cnt[p];
+    const int ima = pair_img[2 * p], imb = pair_img[2 * p + 1];
+    const float *xa = xy + 2 * kp_off[ima], *xb = xy + 2 * kp_off[imb];
+    const int32_t *mp = m_pairs + (int64_t)p * clip * 2;
+    double M[6] = {0, 0, 0, 0, 0, 0};
+    bool have = false;
+    const double thr[10] = {-1.0, 200.0, 50.0, 10.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0};
+    for (int it = 0; it < 10; ++it) {
+        const double t2 = thr[it] * thr[it];
+        auto weight = [&](double px, double py, double qx, double qy) {
+            if (it == 0) return true;
+            const double rx = M[0] * px + M[1] * py + M[2] - qx, ry = M[3] * px + M[4] * py + M[5] - qy;
+            return sqrt(rx * rx + ry * ry) <= thr[it];
+        };
+        (void)t2;
+        // pass 1: count and centroids of the matches in the fit
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const float *a = xa + 2 * mp[2 * k], *b = xb + 2 * mp[2 * k + 1];
+            const double px = dir == 0 ? b[0] : a[0], py = dir == 0 ? b[1] : a[1];      // from
+            const double qx = dir == 0 ? a[0] : b[0], qy = dir == 0 ? a[1] : b[1];      // to
+            if (weight(px, py, qx, qy)) { s[0] += 1.0; s[1] += px; s[2] += py; s[3] += qx; s[4] += qy; }
+        }
+        block_sum5(s, sh);
+        if (s[0] < 2.0) break;
+        const double cnt = s[0], cpx = s[1] / cnt, cpy = s[2] / cnt, cqx = s[3] / cnt, cqy = s[4] / cnt;
+        // pass 2: centred second moments
+        double c[5] = {0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const float *a = xa + 2 * mp[2 * k], *b = xb + 2 * mp[2 * k + 1];
+            const double px = dir == 0 ? b[0] : a[0], py = dir == 0 ? b[1] : a[1];
+            const double qx = dir == 0 ? a[0] : b[0], qy = dir == 0 ? a[1] : b[1];
+            if (weight(px, py, qx, qy)) {
+                const double ux = px - cpx, uy = py - cpy, vx = qx - cqx, vy = qy - cqy;
+                c[0] += ux * ux + uy * uy;
+                c[1] += ux * vx + uy * vy;
+                c[2] += ux * vy - uy * vx;
+            }
+        }
+        block_sum5(c, sh);
+        if (c[0] == 0.0) break;
+        const double a_ = c[1] / c[0], b_ = c[2] / c[0];
+        M[0] = a_; M[1] = -b_; M[2] = cqx - (a_ * cpx - b_ * cpy);
+        M[3] = b_; M[4] = a_;  M[5] = cqy - (b_ * cpx + a_ * cpy);
+        have = true;
+    }
+    if (threadIdx.x == 0) {
+        double *o = out_aff + ((int64_t)p * 2 + dir) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = M[k];
+        out_ok[p * 2 + dir] = have ? 1 : 0;
+    }
+}
+
 }  // namespace
+
+extern "C" int iamx_similarity_pairs(const int32_t *pair_img, const int64_t *kp_off, const float *xy,
+                                     const int32_t *m_cnt, const int32_t *m_pairs, int n_pairs,
+                                     int clip, double *out_aff, int32_t *out_ok, void *stream)
+{
+    IAMX_REQUIRE(pair_img && kp_off && xy && m_cnt && m_pairs && out_aff && out_ok, "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && clip > 0, "bad size");
+    if (n_pairs == 0) return IAMX_OK;
+    hipLaunchKernelGGL(similarity_pairs_kernel, dim3((unsigned)n_pairs, 2), dim3(256), 0,
+                       iamx::as_stream(stream), pair_img, kp_off, xy, m_cnt, m_pairs, clip, out_aff,
+                       out_ok);
+    return iamx::check_launch("iamx_similarity_pairs");
+}
 
 extern "C" int iamx_triangulate_pairs(const int32_t *pair_img, const double *PROJ, const double *IK,
                                       const int64_t *kp_off, const float *xy, const int32_t *m_cnt,

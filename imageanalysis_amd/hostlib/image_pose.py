@@ -51,6 +51,25 @@ class PoseImage(object):
         ned, ypr, quat = self.get_camera_pose(opt)
         return tf.quaternion_matrix(np.array(quat))[:3, :3]
 
+    def set_aircraft_pose(self, lat_deg, lon_deg, alt_m, yaw_deg, pitch_deg, roll_deg,
+                          flight_time=-1.0):
+        """scripts/lib/image.py:415-432 (the values find_matches' yaw estimate reads back)"""
+        node = self.node.getChild('aircraft_pose', True)
+        for k, v in (('lat_deg', lat_deg), ('lon_deg', lon_deg), ('alt_m', alt_m),
+                     ('yaw_deg', yaw_deg), ('pitch_deg', pitch_deg), ('roll_deg', roll_deg)):
+            node.setFloat(k, v)
+        quat = tf.quaternion_from_euler(yaw_deg * d2r, pitch_deg * d2r, roll_deg * d2r, 'rzyx')
+        node.setLen('quat', 4)
+        for i in range(4):
+            node.setFloatEnum('quat', i, quat[i])
+
+    def get_aircraft_pose(self):
+        node = self.node.getChild('aircraft_pose', True)
+        lla = [node.getFloat('lat_deg'), node.getFloat('lon_deg'), node.getFloat('alt_m')]
+        ypr = [node.getFloat('yaw_deg'), node.getFloat('pitch_deg'), node.getFloat('roll_deg')]
+        quat = [node.getFloatEnum('quat', i) for i in range(4)]
+        return lla, ypr, quat
+
     def set_aircraft_yaw_error_estimate(self, yaw_error_deg):
         self.node.getChild('aircraft_pose', True).setFloat("yaw_error_deg", yaw_error_deg)
 

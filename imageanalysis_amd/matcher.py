@@ -402,6 +402,8 @@ def _host_set(n, clip, surface):
                   pairs=pin((n, clip, 2), torch.int32))
         if surface:
             hs['z'] = pin((n, clip), torch.float64)
+            hs['aff'] = pin((n, 2, 6), torch.float64)
+            hs['aff_ok'] = pin((n, 2), torch.int32)
     return hs
 
 
@@ -473,6 +475,13 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                                            _ptr(xy), _ptr(post['tri_cnt']), _ptr(post['pairs']), n,
                                            clip, _ptr(post['z']), stream_ptr()),
                   'iamx_triangulate_pairs')
+            # the similarity between the two images' keypoints, both ways (yaw-error estimate)
+            post['aff'] = torch.empty((n, 2, 6), dtype=torch.float64, device=dev)
+            post['aff_ok'] = torch.empty((n, 2), dtype=torch.int32, device=dev)
+            check(L.iamx_similarity_pairs(_ptr(pb.d_pairs), _ptr(kp_off), _ptr(xy),
+                                          _ptr(post['tri_cnt']), _ptr(post['pairs']), n, clip,
+                                          _ptr(post['aff']), _ptr(post['aff_ok']), stream_ptr()),
+                  'iamx_similarity_pairs')
     hs = _host_set(n, clip, surface and post is not None)
     hs['zero_div'].copy_(ws.zero_div, non_blocking=True)
     hs['count'].copy_(ws.surv_cnt[:2 * n], non_blocking=True)
@@ -482,6 +491,8 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
         hs['pairs'].copy_(post['pairs'], non_blocking=True)
         if 'z' in post:
             hs['z'].copy_(post['z'], non_blocking=True)
+            hs['aff'].copy_(post['aff'], non_blocking=True)
+            hs['aff_ok'].copy_(post['aff_ok'], non_blocking=True)
     done_ev = torch.cuda.Event()
     done_ev.record()
     return dict(batch=batch, n=n, ws=ws, pb=pb, post=post, host=hs, done=done_ev, surface=surface)
@@ -505,7 +516,11 @@ def _finish_batch(h):
             cnt, status, lists = hs['cnt'].numpy(), hs['status'].numpy(), hs['pairs'].numpy()
             if 'z' in hs and 'z' in post:
                 z = hs['z'].numpy()
-                z_rows = {int(k): z[k, :cnt[k]] for k in np.nonzero((status == 0) & (cnt > 0))[0]}
+                aff, aff_ok = hs['aff'].numpy(), hs['aff_ok'].numpy()
+                z_rows = {int(k): (z[k, :cnt[k]],
+                                   aff[k, 0].reshape(2, 3).copy() if aff_ok[k, 0] else None,
+                                   aff[k, 1].reshape(2, 3).copy() if aff_ok[k, 1] else None)
+                          for k in np.nonzero((status == 0) & (cnt > 0))[0]}
         if post is None or status.any():
             # survivor arrays: only the host filter path reads them (blocking copies)
             first, count, sq, st, sm = ws.survivors(h['pb'].n_pairs)
@@ -553,9 +568,10 @@ def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, c
         if have_post and status[k] == 0:
             i1, i2 = batch[k]
             if i1 == i2 or k not in z_rows:
-                surf = (None, None, 0.0)         # nothing to record (smart.py:200-201)
+                surf = (None, None, 0.0, None, None)    # nothing to record (smart.py:200-201)
             else:
-                surf = (-np.average(z_rows[k]), np.std(z_rows[k]), _smart._pair_distance(i1, i2))
+                zk, aff_fwd, aff_rev = z_rows[k]
+                surf = (-np.average(zk), np.std(zk), _smart._pair_distance(i1, i2), aff_fwd, aff_rev)
         out.append((fwd, rev, n_fwd, n_rev, surf))
 
 
@@ -653,7 +669,6 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
         if pending else 0
     n_done = 0
-    yaw_set = set()
 
     # ---- images this rank will have to detect / load, in the order the rounds reach them:
     # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
@@ -716,7 +731,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 avg = std = None
                 if smart is not None:
                     if surf is not None:
-                        avg, std = smart.record_surface_estimate(i1, i2, *surf)
+                        avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
                     else:
                         # the reference's lib.smart reads kp_list / uv_list of both images; the
                         # flush at the end of an earlier round, or a non-owning rank, may not
@@ -726,13 +741,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                         avg, std = smart.update_surface_estimate(i1, i2)
                     if avg and std:
                         _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
-                    if batched_surface:
-                        # our smart mirror has no yaw estimate (constant 0): once per image
-                        for im in (i1, i2):
-                            if im.name not in yaw_set:
-                                yaw_set.add(im.name)
-                                im.set_aircraft_yaw_error_estimate(
-                                    smart.update_yaw_error_estimate(im, im))
+                    if batched_surface and surf is not None:
+                        # the similarity fits of the batch's one launch (both directions)
+                        i1.set_aircraft_yaw_error_estimate(
+                            smart.record_yaw_error_estimate(i1, i2, surf[3]))
+                        i2.set_aircraft_yaw_error_estimate(
+                            smart.record_yaw_error_estimate(i2, i1, surf[4]))
                     else:
                         i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
                         i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))

@@ -7,12 +7,18 @@ and its discard policy depends on.
     update_surface_estimate(i1, i2)     smart.py:196-250  /smart/<image>/tri_surface_pairs/...
     get_surface_estimate, load, save    smart.py:283-340
 
-The triangulation runs on the GPU (csrc/triangulate.hip iamx_triangulate_pairs; find_matches
-does a whole batch of pairs in one launch and hands the statistics to record_surface_estimate).
-NOT here: estimate_yaw_error / update_yaw_error_estimate (smart.py:138-281) rest on
-cv2.estimateAffinePartial2D, a RANSAC fit that is not reproducible; update_yaw_error_estimate
-returns 0 and records nothing.  Inside the reference environment lib.smart itself is used
-(_deps.smart())."""
+    find_affine / decompose_affine      smart.py:66-115   similarity between a pair's keypoints
+    estimate_yaw_error(i1, i2)          smart.py:138-192  yaw error from that matrix + poses
+    update_yaw_error_estimate(i1, i2)   smart.py:251-283  /smart/<image>/yaw_pairs/... + average
+
+The triangulation and the similarity fit run on the GPU (csrc/triangulate.hip:
+iamx_triangulate_pairs, iamx_similarity_pairs; find_matches does a whole batch of pairs in one
+launch each and hands the results to record_surface_estimate / record_yaw_error_estimate).
+The reference obtains the matrix from cv2.estimateAffinePartial2D (RANSAC); here it is a
+deterministic robust fit (least squares, then re-fits on the matches within 200, 50, 10, 3, ...
+px), so yaw estimates agree with the reference's to the extent the two fits do (both see
+GMS-filtered, cross-checked matches).  Inside the reference environment lib.smart itself is
+used (_deps.smart())."""
 import json
 import os
 
@@ -134,8 +140,111 @@ def update_surface_estimate(i1, i2):
     return record_surface_estimate(i1, i2, avg, std, dist_m)
 
 
+# ---- yaw error (smart.py:66-115, 138-192, 251-283) --------------------------------------------
+def find_affine(i1, i2):
+    """2x3 similarity from i2's pixels to i1's over the pair's matches (None without matches)"""
+    import torch
+    from . import kernels
+    from .kernels import _ptr, check, lib, stream_ptr
+    from .matcher import _kp_xy
+    if i1 == i2 or i2.name not in i1.match_list or len(i1.match_list[i2.name]) == 0:
+        return None
+    dev = kernels.require_gpu()
+    pairs = np.asarray(i1.match_list[i2.name], np.int32).reshape(-1, 2)
+    xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    aff = torch.empty((1, 2, 6), dtype=torch.float64, device=dev)
+    ok = torch.empty((1, 2), dtype=torch.int32, device=dev)
+    args = (t(np.array([[0, 1]]), torch.int32), t(np.array([0, len(xy1)]), torch.int64),
+            t(np.concatenate([xy1, xy2]), torch.float32), t(np.array([len(pairs)]), torch.int32),
+            t(pairs, torch.int32))
+    check(lib().iamx_similarity_pairs(*[_ptr(a) for a in args], 1, len(pairs), _ptr(aff), _ptr(ok),
+                                      stream_ptr()), 'iamx_similarity_pairs')
+    if not int(ok[0, 0].item()):
+        return None
+    return aff[0, 0].cpu().numpy().reshape(2, 3)
+
+
+def decompose_affine(affine):
+    """(rotation deg, tx, ty, sx, sy) of a 2x3 matrix"""
+    a, b, tx = affine[0]
+    c, d, ty = affine[1]
+    sx = np.sqrt(a * a + b * b) * (-1.0 if a < 0.0 else 1.0)
+    sy = np.sqrt(c * c + d * d) * (-1.0 if d < 0.0 else 1.0)
+    angle_deg = np.arctan2(-b, a) * 180.0 / np.pi
+    if angle_deg < -180.0:
+        angle_deg += 360.0
+    if angle_deg > 180.0:
+        angle_deg -= 360.0
+    return angle_deg, tx, ty, sx, sy
+
+
+def yaw_error_from_affine(i1, i2, affine):
+    """estimate_yaw_error with the matrix given: (yaw_error, dist_m, relative course, weight)"""
+    if affine is None:
+        return None, None, None, None
+    r2d = 180.0 / np.pi
+    _rot, tx, ty, _sx, _sy = decompose_affine(affine)
+    weight = abs(ty / tx) if abs(ty) > 0 else abs(tx)
+    ned1, _, _ = i1.get_camera_pose()
+    ned2, _, _ = i2.get_camera_pose()
+    diff = np.array(ned2) - np.array(ned1)
+    dist = np.linalg.norm(diff)
+    direction = diff / dist
+    crs_gps = 90 - np.arctan2(direction[0], direction[1]) * r2d
+    if crs_gps < 0:
+        crs_gps += 360
+    if crs_gps > 360:
+        crs_gps -= 360
+    # centre pixel of i2 in i1's pixel coordinates
+    w, h = _deps.camera().get_image_params()
+    cx, cy = int(w * 0.5), int(h * 0.5)
+    newc = np.asarray(affine).dot(np.float32([cx, cy, 1.0]))[:2]
+    cdiff = [newc[0] - cx, cy - newc[1]]
+    crs_aff = 90 - np.arctan2(cdiff[1], cdiff[0]) * r2d
+    _, air_ypr1, _ = i1.get_aircraft_pose()
+    yaw_error = crs_gps - (air_ypr1[0] + crs_aff)
+    if yaw_error < -180:
+        yaw_error += 360
+    if yaw_error > 180:
+        yaw_error -= 360
+    return yaw_error, dist, crs_aff, weight
+
+
+def estimate_yaw_error(i1, i2):
+    return yaw_error_from_affine(i1, i2, find_affine(i1, i2))
+
+
+def record_yaw_error_estimate(i1, i2, affine):
+    """the property-tree bookkeeping of update_yaw_error_estimate (smart.py:251-283): the pair's
+    entry under /smart/<i1>/yaw_pairs and the weighted average over the image's pairs (pairs
+    closer than 0.5 m or with more than 30 deg of error do not count; weights are truncated to
+    integers exactly like the reference's getInt)"""
+    yaw_error, dist, crs_affine, weight = yaw_error_from_affine(i1, i2, affine)
+    if yaw_error is None:
+        return 0
+    i1_node = smart_node.getChild(i1.name, True)
+    yaw_node = i1_node.getChild("yaw_pairs", True)
+    pair_node = yaw_node.getChild(i2.name, True)
+    pair_node.setFloat("yaw_error", "%.1f" % yaw_error)
+    pair_node.setFloat("dist_m", "%.1f" % dist)
+    pair_node.setFloat("relative_crs", "%.1f" % crs_affine)
+    pair_node.setFloat("weight", "%.1f" % weight)
+    total, count = 0, 0
+    for child in yaw_node.getChildren():
+        pn = yaw_node.getChild(child)
+        err, w, dist_m = pn.getFloat("yaw_error"), pn.getInt("weight"), pn.getFloat("dist_m")
+        if dist_m >= 0.5 and abs(err) <= 30:
+            total += err * w
+            count += w
+    if count > 0:
+        i1_node.setFloat("yaw_error", float("%.1f" % (total / count)))
+        return total / count
+    return 0
+
+
 def update_yaw_error_estimate(i1, i2):
-    return 0                     # RANSAC affine fit of the reference: not reproduced (see above)
+    return record_yaw_error_estimate(i1, i2, find_affine(i1, i2))
 
 
 def get_yaw_error_estimate(i1):

@@ -312,6 +312,19 @@ int iamx_triangulate_pairs(const int32_t *pair_img, const double *PROJ, const do
                            const int32_t *m_pairs, int n_pairs, int clip, double *out_z,
                            void *stream);
 
+/* iamx_similarity_pairs -- scripts/lib/smart.py:66-89 find_affine(): the 2x3 similarity
+ * (rotation, uniform scale, translation) between the matched keypoints of every pair of a batch,
+ * for estimate_yaw_error() (:138-192).  The reference asks cv2.estimateAffinePartial2D (RANSAC);
+ * this is a deterministic robust fit instead: least squares on all matches, then nine re-fits on
+ * the matches within 200, 50, 10, 3, 3, ... px of the current model.
+ *   pair_img / kp_off / xy / m_cnt / m_pairs / clip as for iamx_triangulate_pairs
+ *   out_aff DEV [n_pairs][2][6] float64 row major: [p][0] maps image b's pixels onto image a's
+ *   (find_affine(a, b)), [p][1] the other way; out_ok DEV [n_pairs][2]: 1 = a fit exists
+ *   (>= 2 matches that do not coincide) */
+int iamx_similarity_pairs(const int32_t *pair_img, const int64_t *kp_off, const float *xy,
+                          const int32_t *m_cnt, const int32_t *m_pairs, int n_pairs, int clip,
+                          double *out_aff, int32_t *out_ok, void *stream);
+
 /* out[i] = sum_{j<i} in[j], out[n] = total; in DEV [n] int32, out DEV [n+1] int64 */
 int iamx_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *stream);
 
@@ -452,6 +465,28 @@ int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *cal
                        double *vt, double *h, double *hbar, double *x, double *state,
                        double *partials, double *xr, double *tbuf, int phase, int parity,
                        void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Collectives of the hot path for callers that are not python: RCCL over
+ * xGMI, bound at run time (a process that already holds an RCCL -- torch bundles one -- re-uses
+ * it).  The python layer does the same two exchanges through torch.distributed.
+ *   iamx_comm_unique_id: HOST id128 [128 bytes], created by one rank and handed to the others by
+ *     whatever channel the caller has (file, MPI, torch store)
+ *   iamx_comm_init: one communicator per process / GPU (the current HIP device); *comm out
+ *   iamx_comm_allgather: rank r contributes bytes_per_rank bytes at `send`; recv DEV
+ *     [n_ranks * bytes_per_rank]; in place when send == recv + rank * bytes_per_rank -- the packed
+ *     descriptor store of the images a rank detected (iamx_desc_pack_* / iamx_desc3_pack_*) in
+ *     front of the pair-sharded matching: one large transfer per buffer, never per image
+ *   iamx_comm_allreduce_f64: in-place sum -- xr[0..2) and tbuf[0 .. 7 n_cams] between the phases
+ *     of iamx_ba_lsmr_phase, the gradient / column norms once per outer iteration
+ * All enqueue on `stream`; errors come back as IAMX_ELAUNCH with RCCL's message.
+ * ------------------------------------------------------------------------------------ */
+int iamx_comm_unique_id(void *id128);
+int iamx_comm_init(int n_ranks, int rank, const void *id128, void **comm);
+int iamx_comm_destroy(void *comm);
+int iamx_comm_allgather(void *comm, const void *send, void *recv, int64_t bytes_per_rank,
+                        void *stream);
+int iamx_comm_allreduce_f64(void *comm, double *buf, int64_t n, void *stream);
 
 /* float64 vector kernels used by the device LSMR (scipy/sparse/linalg/_isolve/lsmr.py):
  *   axpby: y = a*x + b*y (b == 0 ignores y's old content)

@@ -466,7 +466,11 @@ def run_smart_case(name, seed, n_img, n_kp):
                -110.0 + rng.normal(0, 1.0)]
         ypr = [rng.normal(0, 15.0), -90.0 + rng.normal(0, 2.0), rng.normal(0, 2.0)]
         im.set_camera_pose(ned, *ypr)
-        poses.append(dict(ned=ned, ypr=ypr))
+        # the aircraft's own yaw estimate is off by a few degrees: what the yaw-error estimate
+        # (smart.py:138-192) is there to find
+        air_yaw = ypr[0] + rng.normal(0, 4.0)
+        im.set_aircraft_pose(45.0, -93.0, 300.0, air_yaw, 0.0, 0.0)
+        poses.append(dict(ned=ned, ypr=ypr, air_yaw=air_yaw))
         rvec, tvec = im.get_proj()
         uvp, _ = cv2.projectPoints(pts.reshape(-1, 1, 3), rvec, np.asarray(tvec).reshape(3, 1), K,
                                    np.zeros(5))
@@ -492,13 +496,29 @@ def run_smart_case(name, seed, n_img, n_kp):
             b.match_list[a.name] = [[q, p_] for p_, q in lst]
             with quiet():
                 avg, std = ref_smart.update_surface_estimate(a, b)
-            out_pairs.append(dict(i=i, j=j, matches=lst, avg=float(avg), std=float(std)))
+                yaw_ab = ref_smart.update_yaw_error_estimate(a, b)
+                yaw_ba = ref_smart.update_yaw_error_estimate(b, a)
+                aff_ab = ref_smart.find_affine(a, b)
+                aff_ba = ref_smart.find_affine(b, a)
+            out_pairs.append(dict(i=i, j=j, matches=lst, avg=float(avg), std=float(std),
+                                  yaw_ab=float(yaw_ab), yaw_ba=float(yaw_ba),
+                                  affine_ab=np.asarray(aff_ab, np.float64),
+                                  affine_ba=np.asarray(aff_ba, np.float64)))
     tri = {im.name: (ref_smart.smart_node.getChild(im.name, True).getFloat('tri_surface_m')
                      if ref_smart.smart_node.getChild(im.name, True).hasChild('tri_surface_m') else None)
            for im in proj.image_list}
+    yaw = {}
+    for im in proj.image_list:
+        node = ref_smart.smart_node.getChild(im.name, True)
+        yp = node.getChild('yaw_pairs', True)
+        yaw[im.name] = dict(
+            yaw_error=node.getFloat('yaw_error') if node.hasChild('yaw_error') else None,
+            pairs={c: tuple(yp.getChild(c).getFloat(k) for k in
+                            ('yaw_error', 'dist_m', 'relative_crs', 'weight'))
+                   for c in yp.getChildren()})
     with open(os.path.join(GOLD, 'smart_%s.pkl' % name), 'wb') as f:
         pickle.dump(dict(names=names, poses=poses, xy=xy, K=K_FC6310S, pairs=out_pairs,
-                         tri_surface_m=tri, ground=float(ground)), f, protocol=4)
+                         tri_surface_m=tri, ground=float(ground), yaw=yaw), f, protocol=4)
     print('smart_%s: %d pairs, surface truth %.1f m, estimates %s'
           % (name, len(out_pairs), ground, sorted(set(v for v in tri.values() if v is not None))))
 

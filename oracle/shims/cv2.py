@@ -20,6 +20,15 @@ here (oracle/gen_golden.py) to produce golden vectors.  What it restates:
   implements: per point the 4x4 system [x*P3-P1; y*P3-P2] of both views, solution = right
   singular vector of the smallest singular value (homogeneous, not normalised).
 
+* ``estimateAffinePartial2D`` -> a DETERMINISTIC robust 4-DOF (rotation, uniform scale,
+  translation) fit, NOT OpenCV's RANSAC (whose sampling cannot be reproduced without OpenCV):
+  closed-form least-squares similarity on all correspondences, then nine re-fits on the
+  correspondences whose residual is at most 200, 50, 10, 3, 3, 3, 3, 3, 3 px under the
+  current model (a re-fit needs >= 2 of them, else the loop stops).  This pins what the
+  reference does WITH the matrix (scripts/lib/smart.py:66-115,138-192,251-283: decomposition,
+  course arithmetic, property-tree weighting); the fit itself is this documented stand-in,
+  implemented a second time, independently, by iamx_similarity_pairs.
+
 Anything else raises AttributeError on purpose.
 """
 import math
@@ -196,3 +205,41 @@ def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2):
             A[2 * j + 1] = x[j][1, i] * P[j][2] - P[j][1]
         out[:, i] = np.linalg.svd(A)[2][3]
     return out
+
+
+SIMILARITY_THRESHOLDS = (200.0, 50.0, 10.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0)
+
+
+def _fit_similarity(P, Q, w):
+    n = w.sum()
+    if n < 2:
+        return None
+    cp = (P * w[:, None]).sum(0) / n
+    cq = (Q * w[:, None]).sum(0) / n
+    Pc, Qc = P - cp, Q - cq
+    den = (w * (Pc * Pc).sum(1)).sum()
+    if den == 0:
+        return None
+    a = (w * (Pc * Qc).sum(1)).sum() / den
+    b = (w * (Pc[:, 0] * Qc[:, 1] - Pc[:, 1] * Qc[:, 0])).sum() / den
+    A = np.array([[a, -b], [b, a]])
+    t = cq - A.dot(cp)
+    return np.hstack([A, t.reshape(2, 1)])
+
+
+def estimateAffinePartial2D(from_pts, to_pts, *args, **kwargs):
+    """(2x3 float64 matrix or None, inlier mask [N,1] uint8) -- see the module docstring."""
+    P = np.asarray(from_pts, np.float64).reshape(-1, 2)
+    Q = np.asarray(to_pts, np.float64).reshape(-1, 2)
+    w = np.ones(len(P))
+    M = _fit_similarity(P, Q, w)
+    if M is None:
+        return None, None
+    for thr in SIMILARITY_THRESHOLDS:
+        res = np.sqrt((((P.dot(M[:, :2].T) + M[:, 2]) - Q) ** 2).sum(1))
+        w2 = (res <= thr).astype(np.float64)
+        new = _fit_similarity(P, Q, w2)
+        if new is None:
+            break
+        M, w = new, w2
+    return M, w.astype(np.uint8).reshape(-1, 1)

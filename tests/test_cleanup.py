@@ -186,3 +186,52 @@ def test_surface_estimate_equals_reference():
         want = g['tri_surface_m'][im.name]
         assert (node.getFloat('tri_surface_m') if node.hasChild('tri_surface_m') else None) == want
     assert abs(g['tri_surface_m'][g['names'][0]] - g['ground']) < 0.5
+
+
+@pytest.mark.gpu
+def test_yaw_error_estimate_equals_reference():
+    """imageanalysis_amd.smart's yaw-error estimate (device similarity fit + the reference's
+    course arithmetic and property-tree weighting, scripts/lib/smart.py:66-115,138-192,251-283)
+    against the outputs of the reference's own lib/smart.py (oracle/gen_golden.py G8, whose
+    cv2.estimateAffinePartial2D is the documented deterministic stand-in of oracle/shims/cv2.py:
+    the fit is float64 with different summation orders on the two sides -> 1e-9)."""
+    from imageanalysis_amd import smart
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    with open(os.path.join(GOLDEN, 'smart_grid.pkl'), 'rb') as f:
+        g = pickle.load(f)
+    proj = PoseProject(g['names'])
+    K = g['K']
+    camera.set_K(K[0], K[4], K[2], K[5])
+    camera.set_image_params(5472, 3648)
+    for im, pose, xy in zip(proj.image_list, g['poses'], g['xy']):
+        im.set_camera_pose(pose['ned'], *pose['ypr'])
+        im.set_aircraft_pose(45.0, -93.0, 300.0, pose['air_yaw'], 0.0, 0.0)
+        im.kp_list = [KP(x, y) for x, y in xy]
+        smart.smart_node.__dict__.pop(im.name, None)
+    n_nonzero = 0
+    for rec in g['pairs']:
+        a, b = proj.image_list[rec['i']], proj.image_list[rec['j']]
+        a.match_list[b.name] = rec['matches']
+        b.match_list[a.name] = [[q, p] for p, q in rec['matches']]
+        for (x, y, key) in ((a, b, 'ab'), (b, a, 'ba')):
+            aff = smart.find_affine(x, y)
+            want = rec['affine_' + key]
+            assert np.abs(aff - want).max() <= 1e-9 * max(1.0, np.abs(want).max()), (rec['i'], key)
+            got = smart.record_yaw_error_estimate(x, y, aff)
+            assert abs(got - rec['yaw_' + key]) <= 1e-6, (rec['i'], rec['j'], key)
+            n_nonzero += rec['yaw_' + key] != 0
+    assert n_nonzero >= 4
+    for im in proj.image_list:
+        node = smart.smart_node.getChild(im.name, True)
+        want = g['yaw'][im.name]
+        assert (node.getFloat('yaw_error') if node.hasChild('yaw_error') else None) == want['yaw_error']
+        yp = node.getChild('yaw_pairs', True)
+        assert sorted(yp.getChildren()) == sorted(want['pairs'])
+        for c, vals in want['pairs'].items():
+            got = tuple(yp.getChild(c).getFloat(k) for k in ('yaw_error', 'dist_m', 'relative_crs', 'weight'))
+            assert got == vals, (im.name, c)
+    # a pair without matches records nothing and resets the estimate to 0 like the reference
+    a, b = proj.image_list[0], proj.image_list[1]
+    a.match_list[b.name] = []
+    assert smart.update_yaw_error_estimate(a, b) == 0
