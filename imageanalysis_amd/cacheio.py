@@ -73,6 +73,32 @@ def _write_job(path, payload, on_error=None):
         on_error(e)
 
 
+def _write_raw_job(path, payload, on_error=None):
+    try:
+        raw = payload() if callable(payload) else payload
+        tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
+        with open(tmp, 'wb') as f:
+            f.write(raw)
+        os.replace(tmp, path)
+    except Exception as e:                                    # noqa: BLE001
+        if on_error is None:
+            raise
+        on_error(e)
+
+
+def write_raw(path, payload, background=True, on_error=None):
+    """uncompressed twin of write_gzip (same ordering / wait() / atomic-replace rules)"""
+    if not background:
+        _write_raw_job(path, payload, on_error)
+        return None
+    jobs, _w = _pools()
+    wait(path)
+    fut = jobs.submit(_write_raw_job, path, payload, on_error)
+    with _lock:
+        _pending[path] = fut
+    return fut
+
+
 def write_gzip(path, payload, background=True, on_error=None):
     """payload: bytes or a callable returning bytes (run on the job thread, e.g. np.save into a
     buffer).  Errors go to `on_error(exc)` if given, else surface in wait()."""

@@ -82,6 +82,8 @@ def make_keypoints(x, y, size, angle, response, octave, class_id=None):
 
 
 ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
+USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
+WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
 PREFETCH_DEPTH = 6             # decoded / cache-loaded images held ahead of the detector
 
 
@@ -118,7 +120,42 @@ def load_features(self):
     return False
 
 
+def _sidecar(desc_file):
+    """<image>.desc.u8.npy next to the reference's <image>.desc: the same descriptors as raw
+    uint8 (SIFT values are integers 0..255): 1/4 of the bytes and no gzip on either side --
+    6 MB and a few milliseconds instead of 25 MB float32 through zlib.
+    The reference's own readers keep using the .desc file."""
+    return desc_file + '.u8.npy'
+
+
+def _load_sidecar(self):
+    """float32 [N,128] from the uint8 sidecar if it is there and not older than the .desc"""
+    side = _sidecar(self.desc_file)
+    cacheio.wait(side)
+    try:
+        if not os.path.exists(side):
+            return None
+        # a .desc that is much newer was written by someone else (the reference re-detecting):
+        # our own background gzip of the same array finishes seconds after the sidecar
+        if os.path.exists(self.desc_file) and \
+                os.path.getmtime(self.desc_file) > os.path.getmtime(side) + 120.0:
+            return None
+        u8 = np.load(side)
+        if u8.dtype != np.uint8 or u8.ndim != 2 or u8.shape[1] != 128:
+            return None
+        if self.kp_list is not None and len(self.kp_list) and len(self.kp_list) != len(u8):
+            return None                                   # not the descriptors of these keypoints
+        return u8.astype(np.float32)
+    except Exception:                     # noqa: BLE001  (fall back to the .desc file)
+        return None
+
+
 def load_descriptors(self):
+    if USE_DESC_SIDECAR and self.des_list is None:
+        des = _load_sidecar(self)
+        if des is not None:
+            self.des_list = des
+            return True
     cacheio.wait(self.desc_file)
     if os.path.exists(self.desc_file):
         if self.des_list is None:
@@ -159,8 +196,16 @@ def _npy_bytes(arr):
 
 def save_descriptors(self):
     des = self.des_list                    # the array as it is now (a later flush drops only the name)
-    cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
-                       on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)))
+    if WRITE_REFERENCE_DESC:
+        cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
+                           on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)))
+    if USE_DESC_SIDECAR and des is not None and len(des):
+        u8 = np.asarray(des)
+        as_u8 = u8 if u8.dtype == np.uint8 else np.clip(np.rint(u8), 0, 255).astype(np.uint8)
+        if u8.dtype == np.uint8 or np.array_equal(as_u8, u8):          # integer valued 0..255 only
+            side = _sidecar(self.desc_file)
+            cacheio.write_raw(side, lambda: _npy_bytes(as_u8), background=ASYNC_CACHE_WRITES,
+                              on_error=lambda e: print(side + ": error saving file: " + str(e)))
 
 
 def save_matches(self):
@@ -222,6 +267,12 @@ def _prefetch_job(self):
     try:
         cacheio.wait(self.features_file)
         cacheio.wait(self.desc_file)
+        if os.path.exists(self.features_file) and USE_DESC_SIDECAR:
+            des = _load_sidecar(self)
+            if des is not None:
+                with gzip.open(self.features_file, 'rb') as fp:
+                    feat = fp.read()
+                return ('cache', feat, des)
         if os.path.exists(self.features_file) and os.path.exists(self.desc_file):
             with gzip.open(self.features_file, 'rb') as fp:
                 feat = fp.read()
@@ -254,7 +305,7 @@ def detect_features(self, scale, use_cache=True):
         if pre is not None and pre[0] == 'cache':
             try:
                 self.kp_list = _keypoints_from_tuples(pickle.loads(pre[1]))
-                self.des_list = np.load(io.BytesIO(pre[2]))
+                self.des_list = pre[2] if isinstance(pre[2], np.ndarray) else np.load(io.BytesIO(pre[2]))
                 _qlog("Loaded features/descriptors from cache:", self.name)
                 return
             except Exception:             # noqa: BLE001

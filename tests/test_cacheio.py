@@ -62,7 +62,9 @@ def test_feature_cache_roundtrip_and_reference_reader(tmp_path):
     assert np.array_equal(im.des_list, want_des) and im.des_list.dtype == np.float32
     assert [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
             for kp in im.kp_list] == want_feat
-    # ... and the files are what the reference's own loader expects
+    # ... and the files are what the reference's own loader expects (the descriptors above came
+    # from the uint8 sidecar; the 25 MB float32 .desc may still be in the background writer)
+    cacheio.wait()
     feats, des = _reference_style_read(im.features_file, im.desc_file)
     assert feats == want_feat and np.array_equal(des, want_des)
     # decompressed payloads are byte-identical to what the reference's writer produces
@@ -160,3 +162,57 @@ for k in range(6):
     for f in files:
         with gzip.open(os.path.join(str(tmp_path), f), 'rb') as fp:
             assert len(fp.read()) == 6 << 20
+
+
+def test_uint8_descriptor_sidecar(tmp_path):
+    """<image>.desc.u8.npy: written beside the reference's .desc, preferred
+    on reload, rejected when it cannot belong to the cached keypoints, never written for
+    non-integer descriptors; the .desc stays what the reference's reader expects."""
+    rng = np.random.default_rng(3)
+    getNode('/config/directories', True).setString('project_dir', str(tmp_path))
+    an = tmp_path / 'ImageAnalysis'
+    (an / 'cache').mkdir(parents=True)
+    (an / 'meta').mkdir()
+    im = iimg.Image(str(an), 'S0001')
+    n = 3000
+    im.kp_list = [iimg.make_keypoint(float(k), 2.0 * k, 3.5, 10.0, 0.02, 65793) for k in range(n)]
+    des = rng.integers(0, 256, (n, 128)).astype(np.float32)
+    im.des_list = des.copy()
+    im.save_features()
+    im.save_descriptors()
+    cacheio.wait()
+    side = im.desc_file + '.u8.npy'
+    assert os.path.exists(side) and os.path.getsize(side) < n * 128 + 256
+    assert np.array_equal(np.load(side), des.astype(np.uint8))
+    _feats, ref_des = _reference_style_read(im.features_file, im.desc_file)
+    assert ref_des.dtype == np.float32 and np.array_equal(ref_des, des)
+    # reload: the sidecar is used (make the .desc unreadable to prove it)
+    with open(im.desc_file, 'wb') as f:
+        f.write(b'not a gzip file')
+    im.des_list = None
+    assert im.load_descriptors() and im.des_list.dtype == np.float32
+    assert np.array_equal(im.des_list, des)
+    # a sidecar of another keypoint count is ignored
+    np.save(side, des[:-5].astype(np.uint8))
+    im.des_list = None
+    assert not im.load_descriptors()
+    # non-integer descriptors (another detector) get no sidecar
+    im2 = iimg.Image(str(an), 'S0002')
+    im2.kp_list = im.kp_list
+    im2.des_list = rng.normal(size=(50, 128)).astype(np.float32)
+    im2.save_descriptors()
+    cacheio.wait()
+    assert not os.path.exists(im2.desc_file + '.u8.npy') and os.path.exists(im2.desc_file)
+    # reference-format file can be switched off for caches only this package reads
+    iimg.WRITE_REFERENCE_DESC = False
+    try:
+        im3 = iimg.Image(str(an), 'S0003')
+        im3.kp_list = im.kp_list
+        im3.des_list = des.copy()
+        im3.save_descriptors()
+        cacheio.wait()
+        assert not os.path.exists(im3.desc_file) and os.path.exists(im3.desc_file + '.u8.npy')
+        im3.des_list = None
+        assert im3.load_descriptors() and np.array_equal(im3.des_list, des)
+    finally:
+        iimg.WRITE_REFERENCE_DESC = True
