@@ -72,6 +72,41 @@ def gather_store_shards(buffers, row_offsets, owner, rank, world_size, group=Non
             dist.broadcast(buf[lo * width:hi * width], src=r, group=group)
 
 
+def exchange_features(owner, own_images, rank, world_size, device=None, group=None):
+    """Sharded detection -> every rank holds every image's descriptors and keypoint positions.
+
+    owner: int [n_images] (owner_of_images: contiguous blocks); own_images: {image index:
+    (des uint8 [n,128], xy float32 [n,2])} for the images this rank detected (or loaded from
+    their cache).  Exchanges the keypoint counts (python objects, bytes), then ONE flat uint8
+    descriptor buffer and ONE flat float32 coordinate buffer covering all images, filled by
+    their owners block by block (gather_store_shards: one broadcast per owner and buffer).
+    Returns (counts int64 [n_images], desc uint8 [sum n, 128], xy float32 [sum n, 2]) as torch
+    tensors on `device` (CPU for gloo)."""
+    n_images = len(owner)
+    mine = {int(i): int(len(d)) for i, (d, _xy) in own_images.items()}
+    parts = allgather_objects(mine, group=group)
+    counts = np.zeros(n_images, np.int64)
+    for r, part in enumerate(parts):
+        for i, n in part.items():
+            if owner[i] != r:
+                raise ValueError("image %d was detected by rank %d but belongs to rank %d"
+                                 % (i, r, owner[i]))
+            counts[i] = n
+    off = np.zeros(n_images + 1, np.int64)
+    np.cumsum(counts, out=off[1:])
+    dev = device if device is not None else torch.device('cpu')
+    desc = torch.zeros((max(int(off[-1]), 1), 128), dtype=torch.uint8, device=dev)
+    xy = torch.zeros((max(int(off[-1]), 1), 2), dtype=torch.float32, device=dev)
+    for i, (d, p) in own_images.items():
+        lo, hi = int(off[i]), int(off[i + 1])
+        if hi > lo:
+            desc[lo:hi] = torch.from_numpy(np.ascontiguousarray(d, np.uint8)).to(dev)
+            xy[lo:hi] = torch.from_numpy(np.ascontiguousarray(p, np.float32)).to(dev)
+    gather_store_shards([(desc.view(-1), 128), (xy.view(-1), 2)], off, np.asarray(owner), rank,
+                        world_size, group=group)
+    return counts, desc[:int(off[-1])], xy[:int(off[-1])]
+
+
 def allgather_objects(obj, group=None):
     """Every rank contributes one picklable object; returns the list ordered by rank."""
     import torch.distributed as dist

@@ -64,6 +64,7 @@ class DeviceMatcher(object):
         self._kp = {}             # slot -> (xy float32 [n,2], key2 int32 [n,2]) host copies
         self._kp_dev = None       # (n_slots, kp_off, xy, key2) device arena of the post filter
         self._proj = {}           # slot -> (pose, [R|t] row major) for the surface triangulation
+        self._adopted = {}        # image name -> n_rows: features that arrived from another rank
 
     # cv2-style single pair call (returns numpy (idx[nq,2], dist[nq,2] float32))
     def knnMatch(self, des1, des2, k=2):
@@ -76,10 +77,14 @@ class DeviceMatcher(object):
     def slot_of(self, image):
         """Device slot of an image's descriptors; uploaded once per image (a host-side cache
         flush + reload of the same image re-uses the rows already in HBM)."""
-        n = int(image.des_list.shape[0])
         ent = self._slots.get(image.name)
+        if ent is not None and image.name in self._adopted and \
+                (image.des_list is None or not len(image.des_list)):
+            return ent[0]                       # detected on another rank (adopt())
+        n = int(image.des_list.shape[0])
         if ent is not None and ent[1] == n:
             return ent[0]
+        self._adopted.pop(image.name, None)     # (re-)detected here after all
         slot = len(self._counts)
         self._slots[image.name] = (slot, n)
         self._counts.append(n)
@@ -87,6 +92,28 @@ class DeviceMatcher(object):
         xy = _kp_xy(image)
         self._kp[slot] = (xy, kp_key2(xy))
         return slot
+
+    def adopt(self, name, des, xy):
+        """Register an image whose features were detected by ANOTHER rank (dist.exchange_features):
+        des uint8 [n,128] (device or host), xy float32 [n,2] host.  The image object itself keeps
+        no kp_list / des_list on this rank."""
+        n = int(des.shape[0])
+        slot = len(self._counts)
+        self._slots[name] = (slot, n)
+        self._adopted[name] = n
+        self._counts.append(n)
+        self._pending.append((slot, des))
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        self._kp[slot] = (xy, kp_key2(xy))
+        return slot
+
+    def rows_of(self, image):
+        """descriptor rows of an image: adopted count, else len(des_list)"""
+        n = self._adopted.get(image.name)
+        if n is not None and (image.des_list is None or not len(image.des_list)):
+            return n
+        return int(image.des_list.shape[0]) if image.des_list is not None and \
+            len(getattr(image.des_list, 'shape', ())) else 0
 
     def keypoints(self):
         """device arena of kp.pt and their "%.2f" keys for every slot (rebuilt when images
@@ -129,7 +156,8 @@ class DeviceMatcher(object):
                 for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
                     getattr(new, name)[:n_old3].copy_(getattr(old, name)[:n_old3])
             self._store = new
-        keep = [self._store.set_image(slot, np.ascontiguousarray(des), sync=False)
+        keep = [self._store.set_image(slot, des if hasattr(des, 'data_ptr') else
+                                      np.ascontiguousarray(des), sync=False)
                 for slot, des in pend]
         if keep:
             import torch
@@ -384,6 +412,65 @@ def _ensure_features(image):
         image.detect_features(detect_scale)
 
 
+def _rows_of(image):
+    dm = the_matcher
+    if isinstance(dm, DeviceMatcher):
+        return dm.rows_of(image)
+    return int(image.des_list.shape[0]) if image.des_list is not None and \
+        len(getattr(image.des_list, 'shape', ())) else 0
+
+
+def _have_features(image):
+    """True when the device matcher can match this image without touching the detector: its
+    features are on the host, or they arrived from the rank that detected it"""
+    dm = the_matcher
+    if isinstance(dm, DeviceMatcher) and image.name in dm._adopted:
+        return True
+    return not (image.kp_list is None or image.des_list is None or not len(image.kp_list)
+                or not len(image.des_list))
+
+
+def detect_features_sharded(proj, images=None):
+    """Several ranks: every image is detected (or loaded from its cache) by exactly ONE rank
+    (dist.owner_of_images: contiguous blocks), then the uint8 descriptors and the keypoint
+    positions are exchanged (dist.exchange_features: one large transfer per owner and buffer,
+    RCCL over xGMI between GPUs) and registered with the device matcher -- SURVEY.md 8e "SIFT
+    detect".  Without it every rank of an all-pairs schedule runs the detector on every image.
+    `images`: indices into proj.image_list (default: all).  Returns the keypoint counts."""
+    import torch
+    from . import dist as _dist
+    rank, ws = _dist.world()
+    if the_matcher is None:
+        configure()
+    idx = list(range(len(proj.image_list))) if images is None else [int(i) for i in images]
+    owner_local = _dist.owner_of_images(len(idx), ws)
+    own = {}
+    for k, i in enumerate(idx):
+        if owner_local[k] == rank:
+            im = proj.image_list[i]
+            _ensure_features(im)
+            des = np.asarray(im.des_list)
+            own[k] = (np.clip(np.rint(des), 0, 255).astype(np.uint8) if des.dtype != np.uint8 else des,
+                      _kp_xy(im))
+    if ws == 1:
+        return np.array([len(own[k][0]) for k in range(len(idx))], np.int64)
+    dev = None
+    if torch.distributed.get_backend() == 'nccl':
+        from . import _lib
+        dev = _lib.require_gpu()
+    counts, desc, xy = _dist.exchange_features(owner_local, own, rank, ws, device=dev)
+    off = np.zeros(len(idx) + 1, np.int64)
+    np.cumsum(counts, out=off[1:])
+    xy_host = xy.cpu().numpy()
+    dm = the_matcher
+    for k, i in enumerate(idx):
+        if owner_local[k] != rank and isinstance(dm, DeviceMatcher):
+            im = proj.image_list[i]
+            if im.name not in dm._slots:
+                dm.adopt(im.name, desc[int(off[k]):int(off[k + 1])], xy_host[int(off[k]):int(off[k + 1])])
+    return counts
+
+
 _host_sets = {}          # (n, clip, surface) -> free page-locked result buffer sets
 
 
@@ -591,7 +678,7 @@ def _camera_size():
 def _launch_lines(lines, match_ratio, surface=False):
     """lines: [(dist, i, j, i1, i2)]: enqueue the batch (see _launch_batch)"""
     batch = [(l[3], l[4]) for l in lines]
-    raw = [(len(l[3].kp_list), len(l[4].kp_list)) for l in lines]
+    raw = [(_rows_of(l[3]), _rows_of(l[4])) for l in lines]
     handle = _launch_batch(batch, match_ratio, surface=True) if surface \
         else _launch_batch(batch, match_ratio)
     return lines, raw, handle
@@ -664,6 +751,10 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     save_time = time.time()
     save_interval = 300     # seconds
     _log("Processing worklist matches:")
+    if ws > 1 and isinstance(the_matcher, DeviceMatcher) and pending:
+        # every image of the work list is detected by ONE rank; descriptors and keypoint
+        # positions are exchanged once (a collective: `pending` is the same on every rank)
+        detect_features_sharded(proj, sorted({k for _d, i, j in pending for k in (i, j)}))
     mine = _dist.shard_pairs(pending, rank, ws)
     shard_sizes = [_dist.shard_bounds(len(pending), r, ws) for r in range(ws)]
     n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
@@ -679,7 +770,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             if k not in seen:
                 seen.add(k)
                 im = proj.image_list[k]
-                if (im.kp_list is None or im.des_list is None or not len(im.kp_list)) and \
+                if not _have_features(im) and \
                         getattr(type(im), 'detect_features', None) is _image.detect_features:
                     need.append(im)
         if len(seen) == len(proj.image_list):
@@ -692,10 +783,10 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             i1, i2 = proj.image_list[i], proj.image_list[j]
             i1.desc_timestamp = time.time()
             i2.desc_timestamp = time.time()
-            _ensure_features(i1)
-            _ensure_features(i2)
             for im in (i1, i2):
-                if im.des_list is None or len(im.des_list.shape) == 0 or im.des_list.shape[0] <= 1:
+                if not _have_features(im):
+                    _ensure_features(im)
+                if _rows_of(im) <= 1:
                     # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                     raise ZeroDivisionError("float division by zero")
             lines.append((dist, i, j, i1, i2))

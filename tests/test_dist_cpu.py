@@ -187,3 +187,51 @@ def test_shard_pairs_partition():
         parts = [D.shard_pairs(pairs, r, ws) for r in range(ws)]
         assert sum(parts, []) == pairs
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _run_sharded_detect(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    _init(rank, world, port)
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from test_host_logic import _image
+    des, xy = _strip(n_img=7, seed=9)
+    names = ['E%02d' % i for i in range(len(des))]
+    proj = PoseProject(names)
+    calls = []
+
+    def fake_detect(self, scale, use_cache=True):           # TEST-ONLY stand-in for the GPU detector
+        i = names.index(self.name)
+        calls.append(i)
+        f = _image(self.name, des[i], xy[i])
+        self.des_list, self.kp_list = f.des_list, f.kp_list
+    for im in proj.image_list:
+        im.detect_features = fake_detect.__get__(im)
+        im.des_list, im.kp_list = None, None
+    matcher.detect_scale = 0.4
+    matcher.the_matcher = dm = matcher.DeviceMatcher()      # adopt() needs no GPU
+    counts = matcher.detect_features_sharded(proj)
+    assert counts.tolist() == [len(d) for d in des]
+    from imageanalysis_amd import dist as D
+    owner = D.owner_of_images(len(des), world)
+    assert sorted(calls) == np.nonzero(owner == rank)[0].tolist()      # detected once, by its owner
+    for i, im in enumerate(proj.image_list):
+        if owner[i] == rank:
+            assert im.name not in dm._adopted and len(im.des_list) == len(des[i])
+            continue
+        assert im.des_list is None and matcher._have_features(im) and matcher._rows_of(im) == len(des[i])
+        slot = dm.slot_of(im)
+        got = [d for s_, d in dm._pending if s_ == slot][0]
+        assert np.array_equal(got.numpy(), des[i])                      # uint8 rows of the owner
+        assert np.array_equal(dm._kp[slot][0], xy[i])
+        assert np.array_equal(dm._kp[slot][1], matcher.kp_key2(xy[i]))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_detection_and_feature_exchange_world2_gloo(tmp_path):
+    """SURVEY.md 8e 'SIFT detect': each image is detected by one rank, descriptors + keypoint
+    positions reach the other rank's device matcher through dist.exchange_features."""
+    mp.spawn(_run_sharded_detect, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
