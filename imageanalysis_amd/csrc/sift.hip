@@ -18,8 +18,10 @@
 //                  smoothing, peaks -> keypoints (atomic append)
 //   descriptor     one wave per keypoint: rotated 4x4x8 trilinear histogram in LDS (f64
 //                  atomics), clip/normalise/quantise
-// The per-pixel arithmetic of the pyramid uses explicit round-to-nearest mul/add (no FMA
-// contraction) in the same tap order as the CPU oracle so the pyramids are bit-identical and
+// The per-pixel arithmetic of the pyramid uses separately rounded mul and add (`#pragma clang fp
+// contract(off)` in those kernels: hipcc fuses __fmul_rn + __fadd_rn into v_fma otherwise -- round
+// 1 shipped fused taps, 1 ulp off the oracle in 40 % of the pixels, found by the config-size
+// test of round 2) in the same tap order as the CPU oracle so the pyramids are bit-identical and
 // the keypoint sets can be compared one to one; keypoints are appended in nondeterministic
 // order and put into the canonical (octave, layer, y, x, angle) order by the host wrapper.
 // Pyramid traffic: 6 Gaussian + 5 DoG f32 levels per octave written once, read once
@@ -27,6 +29,15 @@
 #include "iamx_common.h"
 
 namespace {
+
+// separately rounded float mul / add / sub for the pyramid (bit parity with the oracle): hipcc's
+// default -ffp-contract=fast fuses a * b + c -- and __fmul_rn + __fadd_rn, which are plain
+// operators underneath -- into v_fma_f32
+#pragma clang fp contract(off)
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+__device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+#pragma clang fp contract(fast)
 
 constexpr int NL = 3;                 // nOctaveLayers
 constexpr int BORDER = 5;
@@ -56,9 +67,9 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
     if (i >= (int64_t)W2 * H2) return;
     const int x = (int)(i % W2), y = (int)(i / W2);
     auto tap = [](int d, int n, int &i0, int &i1, float &t) {
-        const float f = __fsub_rn(__fmul_rn(__fadd_rn((float)d, 0.5f), 0.5f), 0.5f);
+        const float f = sub_rn(mul_rn(add_rn((float)d, 0.5f), 0.5f), 0.5f);
         i0 = (int)floorf(f);
-        t = __fsub_rn(f, (float)i0);
+        t = sub_rn(f, (float)i0);
         if (i0 < 0) { i0 = 0; t = 0.f; }
         if (i0 >= n - 1) { i0 = n - 1; t = 0.f; }
         i1 = i0 + 1 < n ? i0 + 1 : n - 1;
@@ -73,10 +84,10 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
         const int v = ((int)p[0] * 1868 + (int)p[1] * 9617 + (int)p[2] * 4899 + 8192) >> 14;
         return (float)v;
     };
-    const float omtx = __fsub_rn(1.f, tx), omty = __fsub_rn(1.f, ty);
-    const float top = __fadd_rn(__fmul_rn(gray(y0, x0), omtx), __fmul_rn(gray(y0, x1), tx));
-    const float bot = __fadd_rn(__fmul_rn(gray(y1, x0), omtx), __fmul_rn(gray(y1, x1), tx));
-    dst[i] = __fadd_rn(__fmul_rn(top, omty), __fmul_rn(bot, ty));
+    const float omtx = sub_rn(1.f, tx), omty = sub_rn(1.f, ty);
+    const float top = add_rn(mul_rn(gray(y0, x0), omtx), mul_rn(gray(y0, x1), tx));
+    const float bot = add_rn(mul_rn(gray(y1, x0), omtx), mul_rn(gray(y1, x1), tx));
+    dst[i] = add_rn(mul_rn(top, omty), mul_rn(bot, ty));
 }
 
 // Separable Gaussian.  Both passes add the taps in ascending order with separately rounded
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(256) void blur_h_kernel(const float *__restrict__ s
         const int j = threadIdx.x + 256 * p;
         if (j < n_out) {
             float acc = 0.f;
-            for (int t = 0; t <= 2 * r; ++t) acc = __fadd_rn(acc, __fmul_rn(row[j + t], sk[t]));
+            for (int t = 0; t <= 2 * r; ++t) acc = add_rn(acc, mul_rn(row[j + t], sk[t]));
             drow[j] = acc;
         }
     }
@@ -144,10 +155,10 @@ __global__ __launch_bounds__(256) void blur_v_kernel(const float *__restrict__ s
         if (y < h) {
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) acc = __fadd_rn(acc, __fmul_rn(win[j + t], T.k[t]));
+            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
             const int64_t i = (int64_t)y * w + x;
             dst[i] = acc;
-            if (dog) dog[i] = __fsub_rn(acc, prev[i]);
+            if (dog) dog[i] = sub_rn(acc, prev[i]);
         }
     }
 }
@@ -271,6 +282,126 @@ struct PyrTable {
     int n_oct;
 };
 
+// The small octaves (<= TAIL_PIXELS pixels per level) are launch bound when every blur pass is
+// its own kernel (~11 launches per octave, 12 us each for a few microseconds of work): ONE
+// workgroup builds all of them in one launch with the current level and the horizontal pass
+// held in LDS (2 x 64 KiB) -- downsample, 5 x (horizontal pass, vertical pass + DoG) per octave,
+// workgroup barriers in between.  Same taps, same tap order, same round-to-nearest mul/add as
+// blur_h_kernel / blur_v_kernel: bit-identical levels.
+constexpr int TAIL_PIXELS = 16384;
+
+struct TapSet {
+    Taps t[NL + 2];              // layers 1 .. NL+2 (sigma of the incremental blurs)
+};
+
+__global__ __launch_bounds__(1024) void pyramid_tail_kernel(PyrTable T, int o_first, TapSet TS)
+{
+    __shared__ float cur[TAIL_PIXELS];       // level l-1 of the octave
+    __shared__ float hor[TAIL_PIXELS];       // its horizontal pass
+    __shared__ float sk[MAX_TAPS];
+    for (int o = o_first; o < T.n_oct; ++o) {
+        const int H = T.oct[o].h, W = T.oct[o].w;
+        const int npx = H * W;
+        {
+            const float *src = T.oct[o - 1].g[NL];
+            const int sw = T.oct[o - 1].w;
+            float *dst = T.oct[o].g[0];
+            for (int i = threadIdx.x; i < npx; i += 1024) {
+                const int x = i % W, y = i / W;
+                const float v = src[(int64_t)(2 * y) * sw + 2 * x];
+                dst[i] = v;
+                cur[i] = v;
+            }
+        }
+        __syncthreads();
+        for (int l = 1; l < NL + 3; ++l) {
+            // the taps in LDS: indexing the kernel argument with a runtime tap number is a
+            // scalar memory load per tap
+            const int r = TS.t[l - 1].r;
+            if (threadIdx.x <= 2 * r) sk[threadIdx.x] = TS.t[l - 1].k[threadIdx.x];
+            __syncthreads();
+            float *dst = T.oct[o].g[l], *dog = T.oct[o].d[l - 1];
+            // four pixels of a thread at a time: four independent tap chains hide the LDS latency
+            // (one chain at a time ran at ~100 cycles per tap)
+            constexpr int PPT = TAIL_PIXELS / 1024;
+            // BORDER_REFLECT_101 without the modulo while the radius is smaller than the image
+            const bool simple = r < W && r < H;
+            for (int g0 = 0; g0 < PPT; g0 += 4) {
+                int base[4], pos[4];
+                bool in[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = threadIdx.x + 1024 * (g0 + j);
+                    in[j] = i < npx;
+                    const int ii = in[j] ? i : 0;
+                    pos[j] = ii % W;
+                    base[j] = ii - pos[j];
+                }
+                if (!in[0]) break;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t <= 2 * r; ++t) {
+                    const float kt = sk[t];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int xx = pos[j] - r + t;
+                        if (simple) { xx = xx < 0 ? -xx : xx; xx = xx >= W ? 2 * (W - 1) - xx : xx; }
+                        else xx = reflect101(xx, W);
+                        const float v = cur[base[j] + xx];
+                        acc[j] = add_rn(acc[j], mul_rn(v, kt));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (in[j]) hor[threadIdx.x + 1024 * (g0 + j)] = acc[j];
+            }
+            __syncthreads();
+            float out[PPT];
+            for (int g0 = 0; g0 < PPT; g0 += 4) {
+                int col[4], rowi[4];
+                bool in[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = threadIdx.x + 1024 * (g0 + j);
+                    in[j] = i < npx;
+                    const int ii = in[j] ? i : 0;
+                    col[j] = ii % W;
+                    rowi[j] = ii / W;
+                }
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if (in[0]) {
+                    for (int t = 0; t <= 2 * r; ++t) {
+                        const float kt = sk[t];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int yy = rowi[j] - r + t;
+                            if (simple) { yy = yy < 0 ? -yy : yy; yy = yy >= H ? 2 * (H - 1) - yy : yy; }
+                            else yy = reflect101(yy, H);
+                            const float v = hor[yy * W + col[j]];
+                            acc[j] = add_rn(acc[j], mul_rn(v, kt));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = threadIdx.x + 1024 * (g0 + j);
+                    out[g0 + j] = acc[j];
+                    if (in[j]) {
+                        dst[i] = acc[j];
+                        dog[i] = sub_rn(acc[j], cur[i]);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < TAIL_PIXELS / 1024; ++k) {
+                const int i = threadIdx.x + 1024 * k;
+                if (i < npx) cur[i] = out[k];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __device__ bool solve3(double A[3][3], double b[3], double x[3])
 {
     // Gaussian elimination with partial pivoting (H.solve(dD, DECOMP_LU))
@@ -322,16 +453,16 @@ __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
     for (; it < MAX_STEPS; ++it) {
         const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
         auto at = [&](const float *im, int rr, int cc) { return im[(int64_t)rr * w + cc]; };
-        const float dDx = __fmul_rn(__fsub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
-        const float dDy = __fmul_rn(__fsub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
-        const float dDs = __fmul_rn(__fsub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
-        const float v2 = __fmul_rn(at(img, r, c), 2.f);
-        const float dxx = __fmul_rn(__fsub_rn(__fadd_rn(at(img, r, c + 1), at(img, r, c - 1)), v2), second_scale);
-        const float dyy = __fmul_rn(__fsub_rn(__fadd_rn(at(img, r + 1, c), at(img, r - 1, c)), v2), second_scale);
-        const float dss = __fmul_rn(__fsub_rn(__fadd_rn(at(nxt, r, c), at(prv, r, c)), v2), second_scale);
-        const float dxy = __fmul_rn(__fadd_rn(__fsub_rn(__fsub_rn(at(img, r + 1, c + 1), at(img, r + 1, c - 1)), at(img, r - 1, c + 1)), at(img, r - 1, c - 1)), cross_scale);
-        const float dxs = __fmul_rn(__fadd_rn(__fsub_rn(__fsub_rn(at(nxt, r, c + 1), at(nxt, r, c - 1)), at(prv, r, c + 1)), at(prv, r, c - 1)), cross_scale);
-        const float dys = __fmul_rn(__fadd_rn(__fsub_rn(__fsub_rn(at(nxt, r + 1, c), at(nxt, r - 1, c)), at(prv, r + 1, c)), at(prv, r - 1, c)), cross_scale);
+        const float dDx = mul_rn(sub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
+        const float dDy = mul_rn(sub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
+        const float dDs = mul_rn(sub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
+        const float v2 = mul_rn(at(img, r, c), 2.f);
+        const float dxx = mul_rn(sub_rn(add_rn(at(img, r, c + 1), at(img, r, c - 1)), v2), second_scale);
+        const float dyy = mul_rn(sub_rn(add_rn(at(img, r + 1, c), at(img, r - 1, c)), v2), second_scale);
+        const float dss = mul_rn(sub_rn(add_rn(at(nxt, r, c), at(prv, r, c)), v2), second_scale);
+        const float dxy = mul_rn(add_rn(sub_rn(sub_rn(at(img, r + 1, c + 1), at(img, r + 1, c - 1)), at(img, r - 1, c + 1)), at(img, r - 1, c - 1)), cross_scale);
+        const float dxs = mul_rn(add_rn(sub_rn(sub_rn(at(nxt, r, c + 1), at(nxt, r, c - 1)), at(prv, r, c + 1)), at(prv, r, c - 1)), cross_scale);
+        const float dys = mul_rn(add_rn(sub_rn(sub_rn(at(nxt, r + 1, c), at(nxt, r - 1, c)), at(prv, r + 1, c)), at(prv, r - 1, c)), cross_scale);
         double A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
         double b[3] = {dDx, dDy, dDs}, X[3];
         if (!solve3(A, b, X)) return false;
@@ -350,9 +481,9 @@ __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
     {
         const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
         auto at = [&](const float *im, int rr, int cc) { return im[(int64_t)rr * w + cc]; };
-        const double dDx = (double)__fmul_rn(__fsub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
-        const double dDy = (double)__fmul_rn(__fsub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
-        const double dDs = (double)__fmul_rn(__fsub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
+        const double dDx = (double)mul_rn(sub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
+        const double dDy = (double)mul_rn(sub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
+        const double dDs = (double)mul_rn(sub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
         const double t = dDx * xc + dDy * xr + dDs * xi;
         contr = (double)at(img, r, c) * (double)img_scale + t * 0.5;
         if (fabs(contr) * NL < (double)contrast_threshold) return false;
@@ -421,7 +552,7 @@ __device__ __forceinline__ void flush_keypoints(const float *__restrict__ kbuf, 
 // (2*radius+1)^2 window (lanes stride over the pixels, f64 LDS atomics), smoothing, peaks
 __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *__restrict__ refined,
                                                      const int *__restrict__ n_refined, int cap_c,
-                                                     float sigma, float *__restrict__ kp, int cap_k,
+                                                     double sigma, float *__restrict__ kp, int cap_k,
                                                      int *__restrict__ n_kp)
 {
     __shared__ double hist_s[4][ORI_BINS];
@@ -437,7 +568,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     const Pyr &P = T.oct[R.o];
     const int h = P.h, w = P.w, o = R.o, layer = R.layer, r = R.r, c = R.c;
     const double xi = R.xi, xr = R.xr, xc = R.xc, contr = R.contr;
-    const double size = (double)sigma * exp2((layer + xi) / NL) * (double)(1 << o) * 2.0;
+    const double size = sigma * exp2((layer + xi) / NL) * (double)(1 << o) * 2.0;
     const double px = (c + xc) * (double)(1 << o), py = (r + xr) * (double)(1 << o);
     const int octave = o + (layer << 8) + (round_half_even((xi + 0.5) * 255) << 16);
     const double scl_octv = size * 0.5 / (double)(1 << o);
@@ -705,6 +836,148 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     (void)red_s;
 }
 
+// ---------------------------------------------------------------------------------
+// canonical order of the keypoint list: (octave, layer, y, x, angle, descriptor[0]) ascending
+// (the detector kernels append in a nondeterministic order).  Keypoints of different (octave,
+// layer) never compare, so: count per segment, scatter into segment-contiguous slots, rank
+// every keypoint inside its segment by counting the smaller ones (LDS-tiled, O(sum n_seg^2) =
+// a few 10^8 compares for 5 x 10^4 keypoints), gather rows to their final positions.
+// ---------------------------------------------------------------------------------
+constexpr int SORT_SEGS = 128;            // (octave index + 1) * 4 + layer < 128
+constexpr int RANK_SPLIT = 16;            // workgroups that share the comparisons of 256 keypoints
+
+struct SortKey {
+    unsigned long long a;                // (y bits << 32) | x bits
+    unsigned long long b;                // (angle bits << 32) | (descriptor[0] << 24) | row (24 bits)
+    int seg, orig;
+};
+
+__device__ __forceinline__ int seg_of(const float *kp_row)
+{
+    const int oct = __float_as_int(kp_row[5]);
+    return ((((oct & 255) + 1) & 255) << 2 | ((oct >> 8) & 3)) & (SORT_SEGS - 1);
+}
+
+// per workgroup: LDS histogram of its 256 keypoints, one global atomic per segment present
+__global__ __launch_bounds__(256) void sort_count_kernel(const float *__restrict__ kp,
+                                                         const int32_t *__restrict__ n_out, int cap,
+                                                         int32_t *__restrict__ seg_cnt)
+{
+    __shared__ int hist[SORT_SEGS];
+    const int n = min(*n_out, cap);
+    if ((int)blockIdx.x * 256 >= n) return;
+    if (threadIdx.x < SORT_SEGS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[seg_of(kp + (int64_t)i * 8)], 1);
+    __syncthreads();
+    if (threadIdx.x < SORT_SEGS && hist[threadIdx.x]) atomicAdd(&seg_cnt[threadIdx.x], hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(SORT_SEGS) void sort_offsets_kernel(int32_t *__restrict__ seg_cnt,
+                                                                 int32_t *__restrict__ seg_off,
+                                                                 int32_t *__restrict__ seg_fill)
+{
+    __shared__ int c[SORT_SEGS];
+    c[threadIdx.x] = seg_cnt[threadIdx.x];
+    __syncthreads();
+    int off = 0;
+    for (int k = 0; k < (int)threadIdx.x; ++k) off += c[k];
+    seg_off[threadIdx.x] = off;
+    if (threadIdx.x == SORT_SEGS - 1) seg_off[SORT_SEGS] = off + c[threadIdx.x];
+    seg_fill[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void sort_scatter_kernel(const float *__restrict__ kp,
+                                                           const uint8_t *__restrict__ desc,
+                                                           const int32_t *__restrict__ n_out, int cap,
+                                                           const int32_t *__restrict__ seg_off,
+                                                           int32_t *__restrict__ seg_fill,
+                                                           SortKey *__restrict__ keys,
+                                                           int32_t *__restrict__ dest)
+{
+    __shared__ int hist[SORT_SEGS], base[SORT_SEGS];
+    const int n = min(*n_out, cap);
+    if ((int)blockIdx.x * 256 >= n) return;
+    if (threadIdx.x < SORT_SEGS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int seg = 0, local = 0;
+    const float *row = kp + (int64_t)i * 8;
+    if (i < n) {
+        seg = seg_of(row);
+        local = atomicAdd(&hist[seg], 1);
+        dest[i] = 0;                                   // rank accumulator of slot i
+    }
+    __syncthreads();
+    if (threadIdx.x < SORT_SEGS && hist[threadIdx.x])
+        base[threadIdx.x] = seg_off[threadIdx.x] + atomicAdd(&seg_fill[threadIdx.x], hist[threadIdx.x]);
+    __syncthreads();
+    if (i < n) {
+        SortKey k;
+        k.a = ((unsigned long long)(unsigned)__float_as_int(row[1]) << 32) | (unsigned)__float_as_int(row[0]);
+        k.b = ((unsigned long long)(unsigned)__float_as_int(row[3]) << 32) |
+              ((unsigned long long)desc[(int64_t)i * 128] << 24) | (unsigned)(i & 0xFFFFFF);
+        k.seg = seg;
+        k.orig = i;
+        keys[base[seg] + local] = k;
+    }
+}
+
+// rank of every keypoint inside its segment = number of smaller keys there.  grid = (slots / 256,
+// RANK_SPLIT): workgroup (bx, by) compares its 256 slots with the by-th part of the segments they
+// lie in and adds its count to dest[slot]
+__global__ __launch_bounds__(256) void sort_rank_kernel(const SortKey *__restrict__ keys,
+                                                        const int32_t *__restrict__ seg_off,
+                                                        int32_t *__restrict__ dest)
+{
+    __shared__ unsigned long long ta[256], tb[256];
+    __shared__ int ts[256];
+    const int n = seg_off[SORT_SEGS];
+    const int i_lo = blockIdx.x * 256, i_hi = min(i_lo + 256, n) - 1;
+    if (i_lo >= n) return;
+    const int i = i_lo + threadIdx.x;
+    SortKey me = keys[min(i, n - 1)];
+    const int s_lo = keys[i_lo].seg, s_hi = keys[i_hi].seg;
+    const int lo = seg_off[s_lo], hi = seg_off[s_hi + 1];
+    const int part = (hi - lo + RANK_SPLIT - 1) / RANK_SPLIT;
+    const int p_lo = lo + blockIdx.y * part, p_hi = min(p_lo + part, hi);
+    int cnt = 0;
+    for (int base = p_lo; base < p_hi; base += 256) {
+        __syncthreads();
+        if (base + (int)threadIdx.x < p_hi) {
+            const SortKey o = keys[base + threadIdx.x];
+            ta[threadIdx.x] = o.a; tb[threadIdx.x] = o.b; ts[threadIdx.x] = o.seg;
+        }
+        __syncthreads();
+        const int m = min(256, p_hi - base);
+        for (int j = 0; j < m; ++j) {
+            const unsigned long long oa = ta[j], ob = tb[j];
+            cnt += (ts[j] == me.seg) & ((oa < me.a) | ((oa == me.a) & (ob < me.b)));
+        }
+    }
+    if (i < n && cnt) atomicAdd(&dest[i], cnt);
+}
+
+__global__ __launch_bounds__(256) void sort_gather_kernel(const SortKey *__restrict__ keys,
+                                                          const int32_t *__restrict__ dest,
+                                                          const int32_t *__restrict__ seg_off,
+                                                          const float *__restrict__ kp,
+                                                          const uint8_t *__restrict__ desc,
+                                                          float *__restrict__ out_kp,
+                                                          uint8_t *__restrict__ out_desc)
+{
+    const int n = seg_off[SORT_SEGS];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 3, part = t & 7;
+    if (i >= n) return;
+    const SortKey k = keys[i];
+    const int src = k.orig, dst = seg_off[k.seg] + dest[i];
+    out_kp[(int64_t)dst * 8 + part] = kp[(int64_t)src * 8 + part];
+    reinterpret_cast<uint4 *>(out_desc + (int64_t)dst * 128)[part] =
+        reinterpret_cast<const uint4 *>(desc + (int64_t)src * 128)[part];
+}
+
 inline unsigned blocks(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 void gaussian_taps(double sigma, Taps &T)
@@ -791,12 +1064,15 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     (void)hipMemsetAsync(n_cand, 0, 8, st);
     (void)hipMemsetAsync(n_out, 0, 4, st);
 
+    // OpenCV's sigma is a double (1.6); the ABI carries a float, whose widening (1.60000002...)
+    // would move every Gaussian tap in its last bits: take the parameter to 6 decimals
+    const double sigma_d = round((double)sigma * 1e6) / 1e6;
     // layer sigmas (Lowe / OpenCV buildGaussianPyramid)
     double sig[6];
-    sig[0] = sigma;
+    sig[0] = sigma_d;
     const double kf = pow(2.0, 1.0 / NL);
     for (int i = 1; i < NL + 3; ++i) {
-        const double sp = pow(kf, (double)(i - 1)) * sigma, stt = sp * kf;
+        const double sp = pow(kf, (double)(i - 1)) * sigma_d, stt = sp * kf;
         sig[i] = sqrt(stt * stt - sp * sp);
     }
     // dst = G_sigma * src; with `dog` also dog = dst - src (the DoG level between the two)
@@ -813,18 +1089,28 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         float *up = T.oct[0].d[0];             // scratch (overwritten by the DoG later)
         hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)H * W, 256)), dim3(256), 0, st,
                            image, height, width, channels, up);
-        const double sd = sqrt(fmax((double)sigma * sigma - 1.0, 0.01));
+        const double sd = sqrt(fmax(sigma_d * sigma_d - 1.0, 0.01));
         blur(up, T.oct[0].g[0], H, W, sd, nullptr);
     }
     const float threshold = floorf(0.5f * contrast_threshold / NL * 255.f);
+    // octaves from o_tail on (small images) are built by one workgroup in one launch
+    int o_tail = L.n_oct;
+    for (int o = L.n_oct - 1; o >= 1 && (int64_t)L.h[o] * L.w[o] <= TAIL_PIXELS; --o) o_tail = o;
     for (int o = 0; o < L.n_oct; ++o) {
         const int H = L.h[o], W = L.w[o];
         const int64_t npx = (int64_t)H * W;
-        if (o > 0)
-            hipLaunchKernelGGL(downsample_kernel, dim3(blocks(npx, 256)), dim3(256), 0, st,
-                               T.oct[o - 1].g[NL], L.w[o - 1], H, W, T.oct[o].g[0]);
-        for (int i = 1; i < NL + 3; ++i)
-            blur(T.oct[o].g[i - 1], T.oct[o].g[i], H, W, sig[i], T.oct[o].d[i - 1]);
+        if (o == o_tail) {
+            TapSet TS;
+            for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], TS.t[i - 1]);
+            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, st, T, o_tail, TS);
+        }
+        if (o < o_tail) {
+            if (o > 0)
+                hipLaunchKernelGGL(downsample_kernel, dim3(blocks(npx, 256)), dim3(256), 0, st,
+                                   T.oct[o - 1].g[NL], L.w[o - 1], H, W, T.oct[o].g[0]);
+            for (int i = 1; i < NL + 3; ++i)
+                blur(T.oct[o].g[i - 1], T.oct[o].g[i], H, W, sig[i], T.oct[o].d[i - 1]);
+        }
         if (H > 2 * BORDER && W > 2 * BORDER) {
             const int64_t inner = (int64_t)(H - 2 * BORDER) * (W - 2 * BORDER);
             DogStack D;
@@ -841,8 +1127,61 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,
                        CAP_CAND, contrast_threshold, edge_threshold, refined, n_refined);
     hipLaunchKernelGGL(orient_kernel, dim3(256 * 8), dim3(256), 0, st, T, refined, n_refined,
-                       CAP_CAND, sigma, kp, cap, n_out);
+                       CAP_CAND, sigma_d, kp, cap, n_out);
     hipLaunchKernelGGL(descriptor_kernel, dim3(blocks(cap, 4)), dim3(256), 0, st, T, kp, n_out, cap,
                        desc);
     return iamx::check_launch("iamx_sift_detect");
+}
+
+extern "C" int64_t iamx_sift_sort_workspace_bytes(int cap)
+{
+    if (cap < 1) return 0;
+    return (int64_t)cap * (int64_t)(sizeof(SortKey) + 4) + (3 * SORT_SEGS + 4) * 4 + 256;
+}
+
+// Canonical (octave, layer, y, x, angle, descriptor[0]) order of the lists iamx_sift_detect
+// appended (n_out DEV [1] as written by it; rows beyond cap were not stored and are ignored).
+// out_kp DEV [cap][8], out_desc DEV [cap][128]; workspace DEV iamx_sift_sort_workspace_bytes(cap).
+extern "C" int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap,
+                              void *workspace, int64_t workspace_bytes, float *out_kp,
+                              uint8_t *out_desc, void *stream)
+{
+    IAMX_REQUIRE(kp && desc && n_out && workspace && out_kp && out_desc, "null pointer");
+    IAMX_REQUIRE(cap > 0 && workspace_bytes >= iamx_sift_sort_workspace_bytes(cap), "workspace too small");
+    hipStream_t st = iamx::as_stream(stream);
+    char *ws = static_cast<char *>(workspace);
+    SortKey *keys = reinterpret_cast<SortKey *>(ws);
+    int32_t *dest = reinterpret_cast<int32_t *>(ws + (int64_t)cap * sizeof(SortKey));
+    int32_t *seg_cnt = dest + cap;
+    int32_t *seg_off = seg_cnt + SORT_SEGS;
+    int32_t *seg_fill = seg_off + SORT_SEGS + 1;
+    (void)hipMemsetAsync(seg_cnt, 0, SORT_SEGS * 4, st);
+    const unsigned g = blocks(cap, 256);
+    hipLaunchKernelGGL(sort_count_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, seg_cnt);
+    hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(SORT_SEGS), 0, st, seg_cnt, seg_off, seg_fill);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g), dim3(256), 0, st, kp, desc, n_out, cap, seg_off,
+                       seg_fill, keys, dest);
+    hipLaunchKernelGGL(sort_rank_kernel, dim3(g, RANK_SPLIT), dim3(256), 0, st, keys, seg_off, dest);
+    hipLaunchKernelGGL(sort_gather_kernel, dim3(blocks((int64_t)cap * 8, 256)), dim3(256), 0, st, keys,
+                       dest, seg_off, kp, desc, out_kp, out_desc);
+    return iamx::check_launch("iamx_sift_sort");
+}
+
+// Where a pyramid level lives inside the workspace of iamx_sift_detect (tests / diagnosis):
+// kind 0 = Gaussian level `index` (0..5), 1 = DoG level `index` (0..4) of `octave`.
+extern "C" int iamx_sift_pyramid_level(int height, int width, int octave, int kind, int index,
+                                       int64_t *byte_offset, int *level_h, int *level_w,
+                                       int *n_octaves)
+{
+    IAMX_REQUIRE(byte_offset && level_h && level_w && n_octaves, "null pointer");
+    IAMX_REQUIRE(height >= 2 && width >= 2, "bad image size");
+    const Layout L = make_layout(height, width, CAP_CAND);
+    *n_octaves = L.n_oct;
+    IAMX_REQUIRE(octave >= 0 && octave < L.n_oct && (kind == 0 || kind == 1) && index >= 0 &&
+                     index < (kind == 0 ? 6 : 5),
+                 "no such level");
+    *byte_offset = kind == 0 ? L.g_off[octave][index] : L.d_off[octave][index];
+    *level_h = L.h[octave];
+    *level_w = L.w[octave];
+    return IAMX_OK;
 }

@@ -593,30 +593,29 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     check(lib().iamx_sift_detect(_ptr(img), h, w, ch, contrast_threshold, edge_threshold, sigma,
                                  _ptr(ws), need, _ptr(kp), _ptr(desc), cap, _ptr(n), stream_ptr()),
           'iamx_sift_detect')
+    # canonical (octave, layer, y, x, angle, desc[0]) order on the device (the kernels append in a
+    # nondeterministic order): iamx_sift_sort, then one pinned download
+    sw = _sift_sort_ws.get(dev.index)
+    need_s = int(lib().iamx_sift_sort_workspace_bytes(cap))
+    if sw is None or sw[0].numel() < need_s or sw[1].shape[0] < cap:
+        sw = (torch.empty(need_s, dtype=U8, device=dev),
+              torch.empty((cap, 8), dtype=torch.float32, device=dev),
+              torch.empty((cap, 128), dtype=U8, device=dev))
+        _sift_sort_ws[dev.index] = sw
+    check(lib().iamx_sift_sort(_ptr(kp), _ptr(desc), _ptr(n), cap, _ptr(sw[0]), need_s, _ptr(sw[1]),
+                               _ptr(sw[2]), stream_ptr()), 'iamx_sift_sort')
     cnt = int(n.item())
     if cnt > cap:
         raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (cnt, cap))
-    # canonical (octave, layer, y, x, angle, desc[0]) order: the kernels append in a
-    # nondeterministic order.  Three stable device sorts on integer keys (the floats are
-    # non-negative, so their bit patterns order like their values), gather, one pinned download.
-    kpv, dv = kp[:cnt], desc[:cnt]
-    bits = kpv.view(I32).to(I64)
-    octave_d = bits[:, 5]
-    o_idx = ((octave_d & 255) + 1) & 255
-    layer = (octave_d >> 8) & 255
-    order = torch.sort((bits[:, 3] << 8) | dv[:, 0].to(I64), stable=True)[1]
-    order = order[torch.sort(((bits[:, 1] << 32) | bits[:, 0])[order], stable=True)[1]]
-    order = order[torch.sort((o_idx * 256 + layer)[order], stable=True)[1]]
-    kps = kpv.index_select(0, order)
-    ds = dv.index_select(0, order)
     hk, hd = _sift_pinned(dev, cnt)
-    hk[:cnt].copy_(kps, non_blocking=True)
-    hd[:cnt].copy_(ds, non_blocking=True)
+    hk[:cnt].copy_(sw[1][:cnt], non_blocking=True)
+    hd[:cnt].copy_(sw[2][:cnt], non_blocking=True)
     torch.cuda.current_stream().synchronize()
     k = hk[:cnt].numpy()
     return k[:, :5].copy(), k[:, 5].copy().view(np.int32), hd[:cnt].numpy().copy()
 
 
+_sift_sort_ws = {}
 _sift_pin = {}
 
 

@@ -388,14 +388,30 @@ int iamx_image_equalize_resize(const uint8_t *bgr, int height, int width, int eq
  *              packed octave (int32 bit pattern, cv2.KeyPoint.octave), 2 internal words
  *   desc       DEV [cap][128] uint8 (what cv2 returns as float32 0..255)
  *   n_out      DEV [1] int32: keypoints found (may exceed cap; only cap are stored)
- * Keypoints are appended in no particular order; sort by (octave, layer, y, x, angle) for a
- * reproducible list (imageanalysis_amd.kernels.sift_detect does).
+ * Keypoints are appended in no particular order; iamx_sift_sort puts them into the canonical
+ * (octave, layer, y, x, angle, descriptor[0]) order (imageanalysis_amd.kernels.sift_detect).
  * ------------------------------------------------------------------------------------ */
 int64_t iamx_sift_workspace_bytes(int height, int width);
 int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
                      float contrast_threshold, float edge_threshold, float sigma,
                      void *workspace, int64_t workspace_bytes, float *kp, uint8_t *desc, int cap,
                      int32_t *n_out, void *stream);
+
+/* Where a pyramid level lives inside the workspace after iamx_sift_detect (tests / diagnosis):
+ * kind 0 = Gaussian level index 0..5, kind 1 = DoG level index 0..4 of `octave` (0 = the doubled
+ * image); float32 [level_h][level_w] at workspace + byte_offset. */
+int iamx_sift_pyramid_level(int height, int width, int octave, int kind, int index,
+                            int64_t *byte_offset, int *level_h, int *level_w, int *n_octaves);
+
+/* Canonical order of the lists iamx_sift_detect appended: (octave, layer, y, x, angle,
+ * descriptor[0]) ascending -- count per (octave, layer), scatter, rank inside the segment by
+ * counting, gather.  n_out DEV [1] as written by iamx_sift_detect; out_kp DEV [cap][8],
+ * out_desc DEV [cap][128] (rows [0, min(n_out, cap))); workspace DEV
+ * iamx_sift_sort_workspace_bytes(cap) bytes. */
+int64_t iamx_sift_sort_workspace_bytes(int cap);
+int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap,
+                   void *workspace, int64_t workspace_bytes, float *out_kp, uint8_t *out_desc,
+                   void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K4: linear algebra on the device-resident block Jacobian (what SciPy's TRF/LSMR does on

@@ -75,7 +75,10 @@ def gaussian_kernel(sigma):
     r = ksize // 2
     x = np.arange(-r, r + 1, dtype=np.float64)
     k = np.exp(-(x * x) / (2.0 * sigma * sigma))
-    return (k / k.sum()).astype(np.float32)
+    total = 0.0
+    for v in k.tolist():             # sequential double sum, first tap first (np.sum is pairwise:
+        total += v                   # a different last bit would move taps by one float32 ulp)
+    return (k / total).astype(np.float32)
 
 
 def _reflect101(idx, n):
