@@ -102,6 +102,10 @@ def main():
     ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
     ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
     ap.add_argument('--ba-iters', type=int, default=3, help='TRF iterations to time')
+    ap.add_argument('--e2e', type=int, default=0, metavar='N',
+                    help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
+                         'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
+                         'points and report per-stage seconds')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -348,6 +352,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,
         }
+        if args.e2e > 0 and world == 1:
+            out["e2e"] = e2e_bench(args.e2e)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -392,6 +398,131 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
     return {"verified_pairs": int(len(ordered)), "survivors_checked": int(c.sum()),
             "against": "oracle/cpu_ref.c", "form": "symmetric sweep, form %d" % pb.sym_form
             if pb.sym else "one-direction sweep, %d-row workgroups" % pb.fast_rows}
+
+
+def e2e_bench(n_images):
+    """BASELINE configs[4] shape on one GPU: a rendered survey of n_images JPEGs on disk goes
+    through the drop-in entry points exactly as scripts/process.py:236-407 drives the reference's
+    modules -- Image.detect_features, matcher.find_matches, match_cleanup.*, groups.compute,
+    Optimizer.setup / run / update_camera_poses -- with per-stage wall seconds (host side
+    included: JPEG decode, cache files, python lists, .match pickles)."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from imageanalysis_amd import groups, image as iimg, match_cleanup, matcher, optimizer, synth
+    from imageanalysis_amd._deps import getNode
+    from imageanalysis_amd.hostlib import camera
+    cols = max(2, int(round(math.sqrt(n_images * 2.0))))
+    rows = max(2, (n_images + cols - 1) // cols)
+    tmp = tempfile.mkdtemp(prefix='iamx_e2e_')
+    out = {"images": rows * cols, "grid": [rows, cols]}
+    try:
+        t0 = time.perf_counter()
+        names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols)
+        out["render_seconds_untimed"] = round(time.perf_counter() - t0, 2)
+        W, H = int(2 * K[0, 2]), int(2 * K[1, 2])
+        an = os.path.join(tmp, 'ImageAnalysis')
+        os.makedirs(os.path.join(an, 'cache'))
+        os.makedirs(os.path.join(an, 'meta'))
+        getNode('/config/directories', True).setString('project_dir', tmp)
+        matcher.detector_node.setString('detector', 'SIFT')
+        matcher.detector_node.setFloat('scale', 1.0)
+        matcher.matcher_node.setFloat('match_ratio', 0.75)
+        matcher.matcher_node.setInt('min_pairs', 25)
+        matcher.matcher_node.setInt('min_chain_len', 0)
+        node = getNode('/config/camera', True)
+        node.__dict__.pop('K_opt', None)
+        node.__dict__.pop('dist_coeffs_opt', None)
+        camera.set_K(K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        camera.set_dist_coeffs([0.0] * 5)
+        camera.set_image_params(W, H)
+
+        class Proj(object):
+            analysis_dir = an
+
+            def findIndexByName(self, name):
+                return names.index(name) if name in names else None
+
+            def findImageByName(self, name):
+                return self.image_list[names.index(name)] if name in names else None
+
+            def save_images_info(self):
+                pass
+
+        proj = Proj()
+        proj.image_list = []
+        for name, (ned, ypr) in zip(names, logged):
+            im = iimg.Image(an, name)
+            im.set_camera_pose(ned.tolist(), *ypr.tolist())
+            im.set_aircraft_pose(45.0, -93.0, 300.0, float(ypr[0]), 0.0, 0.0)
+            getNode('/smart', True).getChild(name, True).setFloat('tri_surface_m', 0.0)
+            proj.image_list.append(im)
+        quiet = contextlib.redirect_stdout(io.StringIO())
+        stages = {}
+
+        def timed(key, fn):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            with quiet:
+                r = fn()
+            torch.cuda.synchronize()
+            stages[key] = round(time.perf_counter() - t, 3)
+            return r
+
+        matcher.configure()
+
+        def detect():
+            pf = iimg.prefetch(proj.image_list)
+            for im in proj.image_list:
+                im.detect_features(1.0)
+            pf.close()
+            iimg.cacheio.wait()
+        timed("detect", detect)
+        out["keypoints_per_image"] = int(np.mean([len(im.kp_list) for im in proj.image_list]))
+        timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
+                                                    transform='homography', sort=True))
+        out["image_pairs_with_matches"] = sum(len(v) > 0 for im in proj.image_list
+                                              for v in im.match_list.values()) // 2
+
+        def consolidate():
+            match_cleanup.merge_duplicates(proj)
+            match_cleanup.check_for_pair_dups(proj)
+            match_cleanup.check_for_1vn_dups(proj)
+            direct = match_cleanup.make_match_structure(proj)
+            return match_cleanup.link_matches(proj, direct)
+        grouped = timed("consolidate", consolidate)
+        out["chains"] = len(grouped)
+
+        def triangulate():
+            match_cleanup.triangulate_smart(proj, grouped)
+            return groups.compute(proj.image_list, grouped)
+        group_list = timed("triangulate_group", triangulate)
+        opt = optimizer.Optimizer(an)
+        timed("ba_setup", lambda: opt.setup(proj, group_list, 0, grouped, optimized=False,
+                                            cam_calib=False))
+        x0 = opt._x0()
+        args_ = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+        with quiet:
+            mre0 = float(np.mean(np.abs(opt.fun(x0, *args_))))
+        timed("ba_run", opt.run)
+        mre1 = float(np.mean(np.abs(opt.result.fun)))
+        timed("write_poses", lambda: opt.update_camera_poses(proj))
+        total = sum(stages.values())
+        out.update({"stage_seconds": stages, "total_seconds": round(total, 3),
+                    "images_per_sec_end_to_end": round(len(names) / total, 2),
+                    "ba": {"cameras": int(opt.n_cameras), "points": int(opt.n_points),
+                           "observations": int(opt.camera_indices.size),
+                           "iterations": int(opt.result.njev),
+                           "mean_abs_residual_px_before": round(mre0, 3),
+                           "mean_abs_residual_px_after": round(mre1, 3)},
+                    "image_size": [W, H],
+                    "note": "drop-in entry points, host side included; rendered %dx%d frames (the "
+                            "FC6310S field of view at a quarter of its pixels), detector scale 1.0"
+                            % (W, H)})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def host_postprocess_rate():

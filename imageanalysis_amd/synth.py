@@ -114,3 +114,73 @@ def make_survey_image(h=3648, w=5472, seed=0, device='cuda'):
     img = (img - img.min()) / (img.max() - img.min()) * 255
     img = img[0, 0]
     return torch.stack([img, img * 0.9 + 10, img * 0.8 + 20], 2).clamp(0, 255).to(torch.uint8).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# a rendered survey on disk (bench.py --e2e, BASELINE configs[4] shape): a textured ground plane
+# photographed by nadir cameras on a lawn-mower grid, every pixel ray-cast onto the plane with the
+# camera model the pipeline uses; the project is handed poses that are off by ~1 m / ~1 deg
+# --------------------------------------------------------------------------------------
+def ground_texture(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w), np.float64)
+    for s in (2, 4, 8, 16, 32):
+        g = rng.normal(size=(h // s + 2, w // s + 2))
+        img += np.kron(g, np.ones((s, s)))[:h, :w] * s ** 0.7
+    k = np.array([1, 4, 6, 4, 1.]) / 16
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, 'same'), 1, img)
+    img = np.apply_along_axis(lambda r: np.convolve(r, k, 'same'), 0, img)
+    img = (img - img.min()) / (img.max() - img.min()) * 255
+    return np.stack([img, img * 0.9 + 10, img * 0.8 + 20], 2).clip(0, 255).astype(np.uint8)
+
+
+def render_view(tex, M, ned, w, h, gsd, origin):
+    """image[v, u] = ground texture under the ray of pixel (u, v); ground plane z = 0 (NED)"""
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    ray = np.einsum('ij,jvu->ivu', M, np.stack([u, v, np.ones_like(u)]))
+    t = -ned[2] / ray[2]
+    n, e = ned[0] + ray[0] * t, ned[1] + ray[1] * t
+    r, c = (n + origin) / gsd, (e + origin) / gsd
+    r0, c0 = np.floor(r).astype(int), np.floor(c).astype(int)
+    fr, fc = (r - r0)[..., None], (c - c0)[..., None]
+    r0 = np.clip(r0, 0, tex.shape[0] - 2)
+    c0 = np.clip(c0, 0, tex.shape[1] - 2)
+    t00, t01 = tex[r0, c0].astype(float), tex[r0, c0 + 1].astype(float)
+    t10, t11 = tex[r0 + 1, c0].astype(float), tex[r0 + 1, c0 + 1].astype(float)
+    img = (t00 * (1 - fc) + t01 * fc) * (1 - fr) + (t10 * (1 - fc) + t11 * fc) * fr
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, alt=100.0,
+                         spacing=(45.0, 40.0), gsd=0.11, seed=2024):
+    """Writes <project_dir>/images/Pnnn.JPG and returns (names, truth [(ned, ypr)], logged
+    [(ned, ypr)], K).  Default camera = the FC6310S field of view at a quarter of its pixels."""
+    from PIL import Image as PILImage
+    from . import match_cleanup
+    rng = np.random.default_rng(seed)
+    os_ = __import__('os')
+    os_.makedirs(os_.path.join(project_dir, 'images'), exist_ok=True)
+    origin = 80.0
+    tex = ground_texture(int((rows * spacing[0] + 2 * origin) / gsd),
+                         int((cols * spacing[1] + 2 * origin) / gsd), seed)
+    K = np.array([[focal, 0, w / 2.0], [0, focal, h / 2.0], [0, 0, 1.0]])
+    IK = np.linalg.inv(K)
+    d2r = np.pi / 180.0
+    names, truth, logged = [], [], []
+    for row in range(rows):
+        for col in range(cols):
+            k = col if row % 2 == 0 else cols - 1 - col
+            ned = np.array([20.0 + spacing[0] * row + rng.normal(0, 0.5),
+                            25.0 + spacing[1] * k + rng.normal(0, 0.5), -alt + rng.normal(0, 0.5)])
+            ypr = np.array([(0.0 if row % 2 == 0 else 180.0) + rng.normal(0, 2.0),
+                            -90.0 + rng.normal(0, 1.5), rng.normal(0, 1.5)])
+            name = 'P%03d' % len(names)
+            q = tf.quaternion_from_euler(ypr[0] * d2r, ypr[1] * d2r, ypr[2] * d2r, 'rzyx')
+            M = tf.quaternion_matrix(q)[:3, :3].dot(match_cleanup.CAM2BODY).dot(IK)
+            bgr = render_view(tex, M, ned, w, h, gsd, origin)
+            PILImage.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(
+                os_.path.join(project_dir, 'images', name + '.JPG'), quality=95)
+            names.append(name)
+            truth.append((ned, ypr))
+            logged.append((ned + rng.normal(0, 0.8, 3), ypr + rng.normal(0, 0.7, 3)))
+    return names, truth, logged, K
