@@ -228,7 +228,9 @@ __device__ __forceinline__ void half_wave_min16(const int (&r)[16], int &m0, int
 // butterfly, bit3 no MFMA.  Results are meaningless.
 // PIPE: the MFMAs of a pair of query blocks are issued while the minima of the previous pair are
 // taken (software pipeline across the 8 steps of a chunk, sched_group_barrier interleave).
-template <int QW, int NW, int VARIANT = 0, int PIPE = 0>
+// MERGEW: waves that share the per-chunk row merge (CHUNK / MERGEW rows each); SLEEP: s_sleep
+// argument for the second half of the waves at the start of every chunk (de-phasing experiments)
+template <int QW, int NW, int VARIANT = 0, int PIPE = 0, int MERGEW = 2, int SLEEP = 0>
 __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 {
     constexpr int WGROWS = NW * QW * 32;
@@ -321,7 +323,11 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     };
     auto wait_direct = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };       // vmcnt(0)
     // per train row: the waves' group minima -> (L, U1, U2)
+    constexpr int MROWS = CHUNK / MERGEW;                // rows a merging wave takes
+    const int mrow = wave * MROWS + lane;                // (valid for wave < MERGEW, lane < MROWS)
+    const bool merger = wave < MERGEW && lane < MROWS;
     auto merge_rows = [&](int ch, int buf) {
+        const int tid = mrow;
         int L = BIG, U1 = BIG, U2 = BIG;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -340,7 +346,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks) stage_direct(ch + 1, buf ^ 1);
-        if (ch > 0 && tid < CHUNK) merge_rows(ch - 1, buf ^ 1);
+        if constexpr (SLEEP > 0)
+            if (wave >= NW / 2) __builtin_amdgcn_s_sleep(SLEEP);
+        if constexpr (!(VARIANT & 16))
+            if (ch > 0 && merger) merge_rows(ch - 1, buf ^ 1);
         if (wave_valid) {
             const int8_t *tile_base = lds_tile + buf * (CHUNK * D);
             const int *tb_base = lds_tb + buf * CHUNK;
@@ -505,9 +514,9 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
             }
         }
         wait_direct();
-        __syncthreads();
+        if constexpr (!(VARIANT & 32)) __syncthreads();
     }
-    if (tid < CHUNK) merge_rows(nchunks - 1, (nchunks - 1) & 1);
+    if (merger) merge_rows(nchunks - 1, (nchunks - 1) & 1);
 
     // ---- column results: two smallest of the 4 x 2 group minima of every query
     if (wave_valid) {
@@ -958,6 +967,13 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 200: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 4, 0>), g, dim3(512), 0, st, a); break;
+    case 201: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 2>), g, dim3(512), 0, st, a); break;
+    case 202: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 5>), g, dim3(512), 0, st, a); break;
+    case 203: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 4, 3>), g, dim3(512), 0, st, a); break;
+    case 204: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 8, 0>), g, dim3(512), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 16, 6>), g, dim3(512), 0, st, a); break;
+    case 48: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 48, 6>), g, dim3(512), 0, st, a); break;
     case 100: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 4>), g, dim3(512), 0, st, a); break;
     case 101: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6>), g, dim3(512), 0, st, a); break;
     case 102: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 8>), g, dim3(512), 0, st, a); break;

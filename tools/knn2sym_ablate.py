@@ -35,7 +35,7 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
 st = store
 ref = None
-names = {100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
+names = {200: 'merge on waves 0-3', 201: 'sleep 2 for waves 4-7', 202: 'sleep 5 for waves 4-7', 203: 'merge on waves 0-3 + sleep 3', 204: 'merge on all 8 waves', 16: 'shipped schedule without the per-chunk row merge', 48: '... and without the chunk barrier (timing only)', 100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
          4: 'row direction without butterfly', 5: 'row min tree only', 8: 'no MFMA',
          11: 'staging + barriers only'}
 for v in variants:
