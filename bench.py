@@ -242,7 +242,8 @@ def main():
         cnt = torch.tensor([n_pairs_rank], dtype=torch.int64, device=dev)
         dist.all_reduce(cnt)
         total_pairs = int(cnt.item())
-        dist.all_reduce(survivors)                 # whole-job count, like `value`
+        dist.all_reduce(survivors)                 # whole-job counts, like `value`
+        dist.all_reduce(candidates)
     else:
         total_pairs = n_pairs_rank
 
