@@ -22,6 +22,7 @@ import sys
 import numpy as np
 
 from . import _deps, cacheio
+from .matchpairs import dump_match_dict
 from .hostlib.image_pose import PoseImage
 
 try:                                     # inside the reference environment keep cv2's type
@@ -211,7 +212,9 @@ def save_descriptors(self):
 def save_matches(self):
     try:
         with open(self.match_file, 'wb') as fp:
-            pickle.dump(self.match_list, fp)
+            # same objects on load as pickle.dump(self.match_list, fp) of lists of [i, j] lists
+            # (image.py:261-268), written straight from the arrays behind the match lists
+            dump_match_dict(self.match_list, fp)
         self.matches_clean = True
     except IOError:
         print(self.match_file + ": error saving file: " + str(sys.exc_info()[1]))

@@ -23,6 +23,7 @@ import numpy as np
 
 from . import _deps
 from .matcher import _kp_xy, kp_key2
+from .matchpairs import MatchPairs
 
 CAM2BODY = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)     # lib/image.py:50-52
 
@@ -98,7 +99,8 @@ def merge_duplicates(proj):
             if j is None or len(matches) == 0:
                 continue
             p = _pairs(matches)
-            matches[:] = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1).tolist()
+            merged = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1)
+            matches[:] = merged if isinstance(matches, MatchPairs) else merged.tolist()
 
 
 def check_for_pair_dups(proj):
@@ -120,7 +122,8 @@ def check_for_pair_dups(proj):
             if count > 0:
                 print('Match:', i1.name, 'vs', proj.image_list[j].name, 'matches:', len(matches),
                       'dups:', count)
-            i1.match_list[key] = p[np.sort(first)].tolist()
+            kept = p[np.sort(first)]
+            i1.match_list[key] = MatchPairs(kept) if isinstance(matches, MatchPairs) else kept.tolist()
 
 
 def check_for_1vn_dups(proj):

@@ -27,6 +27,7 @@ from math import sqrt
 import numpy as np
 
 from . import _deps
+from .matchpairs import MatchPairs
 from ._deps import getNode
 from .gms import gms_inlier_mask
 
@@ -63,7 +64,8 @@ class DeviceMatcher(object):
         self._pending = []
         self._kp = {}             # slot -> (xy float32 [n,2], key2 int32 [n,2]) host copies
         self._kp_dev = None       # (n_slots, kp_off, xy, key2) device arena of the post filter
-        self._proj = {}           # slot -> (pose, [R|t] row major) for the surface triangulation
+        self._proj = {}           # slot -> (pose, [R|t] row major, epoch) for the surface triangulation
+        self._pose_epoch = None   # set by find_matches: camera poses do not change inside one call
         self._adopted = {}        # image name -> n_rows: features that arrived from another rank
 
     # cv2-style single pair call (returns numpy (idx[nq,2], dist[nq,2] float32))
@@ -506,7 +508,12 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     from . import kernels
     from .kernels import _ptr, check, lib, stream_ptr
     dm = the_matcher
-    slots = [(dm.slot_of(a), dm.slot_of(b)) for a, b in batch]
+    by_id = {}                                   # one slot_of() per image, not per pair
+    for pair in batch:
+        for im in pair:
+            if id(im) not in by_id:
+                by_id[id(im)] = (dm.slot_of(im), im)
+    slots = [(by_id[id(a)][0], by_id[id(b)][0]) for a, b in batch]
     store = dm.store()
     d_proj = d_ik = None
     if surface and device_filters:
@@ -514,21 +521,25 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
         # kernels go in, or the host would sit here until they have run
         from . import smart as _smart
         PROJ = np.zeros((len(dm._counts), 12))
-        done = set()
-        for (a, b), (sa, sb) in zip(batch, slots):
-            for im, s in ((a, sa), (b, sb)):
-                if s not in done:
-                    done.add(s)
-                    pose = im.get_camera_pose()
-                    hit = dm._proj.get(s)
-                    if hit is None or hit[0] != pose:
-                        hit = dm._proj[s] = (pose, _smart.projection_matrix(im).ravel())
-                    PROJ[s] = hit[1]
+        epoch = dm._pose_epoch
+        for s, im in by_id.values():
+            hit = dm._proj.get(s)
+            if hit is None or epoch is None or hit[2] is not epoch:
+                # (reading a pose back from the property tree costs more than a pair's share of
+                #  the kernels: once per image and find_matches call, else whenever it changed)
+                pose = im.get_camera_pose()
+                if hit is None or hit[0] != pose:
+                    hit = (pose, _smart.projection_matrix(im).ravel(), epoch)
+                else:
+                    hit = (hit[0], hit[1], epoch)
+                dm._proj[s] = hit
+            PROJ[s] = hit[1]
         IK = np.linalg.inv(np.asarray(_deps.camera().get_K(), float))
         dev0 = kernels.require_gpu()
         d_proj = torch.from_numpy(PROJ).to(dev0)
         d_ik = torch.from_numpy(np.ascontiguousarray(IK.ravel())).to(dev0)
-    ordered = np.array([[sa, sb] for sa, sb in slots] + [[sb, sa] for sa, sb in slots], np.int32)
+    sl = np.asarray(slots, np.int32).reshape(-1, 2)
+    ordered = np.concatenate([sl, sl[:, ::-1]])
     pb = kernels.PairBatch(store, ordered)
     ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
     if device_filters:
@@ -632,9 +643,16 @@ def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, c
     for k in range(n):
         n_fwd, n_rev = int(count[k]), int(count[n + k])
         if have_post and status[k] == 0:
+            # array-backed lists (matchpairs.py): `lists` is a page-locked buffer that the next
+            # batch reuses, the pair's rows are copied out of it once
             c = cnt[k]
-            fwd = lists[k, :c].tolist()
-            rev = lists[k, :c, ::-1].tolist()
+            if c:
+                both = np.empty((2, c, 2), np.int32)
+                both[0] = lists[k, :c]
+                both[1] = both[0, :, ::-1]
+                fwd, rev = MatchPairs(both[0]), MatchPairs(both[1])
+            else:
+                fwd, rev = [], []
         else:
             i1, i2 = batch[k]
             _ensure_features(i1)         # the keypoints may have been flushed since the launch
@@ -675,10 +693,12 @@ def _camera_size():
     return w, h
 
 
-def _launch_lines(lines, match_ratio, surface=False):
-    """lines: [(dist, i, j, i1, i2)]: enqueue the batch (see _launch_batch)"""
+def _launch_lines(lines, match_ratio, surface=False, raw=None):
+    """lines: [(dist, i, j, i1, i2)]: enqueue the batch (see _launch_batch); raw: the descriptor
+    row counts of every line's two images when the caller already has them"""
     batch = [(l[3], l[4]) for l in lines]
-    raw = [(_rows_of(l[3]), _rows_of(l[4])) for l in lines]
+    if raw is None:
+        raw = [(_rows_of(l[3]), _rows_of(l[4])) for l in lines]
     handle = _launch_batch(batch, match_ratio, surface=True) if surface \
         else _launch_batch(batch, match_ratio)
     return lines, raw, handle
@@ -717,7 +737,11 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
     (match lists, surface estimates) and writes the files -- the other ranks only record the
     pairs they matched themselves."""
     with _no_gc():
-        _find_matches(proj, K, strategy, transform, sort, review)
+        try:
+            _find_matches(proj, K, strategy, transform, sort, review)
+        finally:
+            if isinstance(the_matcher, DeviceMatcher):
+                the_matcher._pose_epoch = None
 
 
 def _find_matches(proj, K, strategy, transform, sort, review):
@@ -728,6 +752,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         quit()
     if the_matcher is None:
         configure()
+    if isinstance(the_matcher, DeviceMatcher):
+        the_matcher._pose_epoch = object()
     smart = _deps.smart()
     # our own smart mirror: the owning rank triangulates its whole batch in one launch
     batched_surface = smart is not None and hasattr(smart, 'record_surface_estimate')
@@ -777,20 +803,27 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             break
     prefetcher = _image.prefetch(need) if need else None
 
+    image_list = proj.image_list
+
     def launch_round(rnd):
-        lines = []
-        for dist, i, j in mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]:
-            i1, i2 = proj.image_list[i], proj.image_list[j]
-            i1.desc_timestamp = time.time()
-            i2.desc_timestamp = time.time()
-            for im in (i1, i2):
-                if not _have_features(im):
-                    _ensure_features(im)
-                if _rows_of(im) <= 1:
-                    # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
-                    raise ZeroDivisionError("float division by zero")
-            lines.append((dist, i, j, i1, i2))
-        return _launch_lines(lines, match_ratio, batched_surface) if lines else None
+        part = mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]
+        if not part:
+            return None
+        # per IMAGE of the round, not per pair: time stamp of the descriptor cache, detection
+        # if the features are not there, the row count the log quotes
+        now = time.time()
+        rows = {}
+        for k in {k for _d, i, j in part for k in (i, j)}:
+            im = image_list[k]
+            im.desc_timestamp = now
+            if not _have_features(im):
+                _ensure_features(im)
+            rows[k] = _rows_of(im)
+            if rows[k] <= 1:
+                # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
+                raise ZeroDivisionError("float division by zero")
+        lines = [(dist, i, j, image_list[i], image_list[j]) for dist, i, j in part]
+        return _launch_lines(lines, match_ratio, batched_surface, [(rows[i], rows[j]) for _d, i, j in part])
 
     # software pipeline: the GPU works on round r+1 while python turns round r into lists
     in_flight = launch_round(0) if n_rounds else None
@@ -807,10 +840,17 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             if ws == 1:
                 raise
             failure, results = exc, []
+        if ws > 1:
+            # arrays on the wire, not lists of lists (a MatchPairs pickles as a plain list)
+            results = [(i, j, f.array() if isinstance(f, MatchPairs) else f,
+                        r.array() if isinstance(r, MatchPairs) else r, surf)
+                       for i, j, f, r, surf in results]
         gathered = _dist.gather_results(results, failure)
 
         for part in gathered:
             for i, j, match_fwd, match_rev, surf in part:
+                if isinstance(match_fwd, np.ndarray):
+                    match_fwd, match_rev = MatchPairs(match_fwd), MatchPairs(match_rev)
                 i1, i2 = proj.image_list[i], proj.image_list[j]
                 n_done += 1
                 i1.match_list[i2.name] = match_fwd
@@ -821,6 +861,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
                 avg = std = None
                 if smart is not None:
+                    if surf is not None and surf[0] is None and surf[3] is None and surf[4] is None:
+                        # no matches: smart.py:200-201 and :258-260 record nothing, the yaw
+                        # error estimate of both images is set to the 0 they return
+                        i1.set_aircraft_yaw_error_estimate(0)
+                        i2.set_aircraft_yaw_error_estimate(0)
+                        continue
                     if surf is not None:
                         avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
                     else:

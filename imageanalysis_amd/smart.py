@@ -215,25 +215,47 @@ def estimate_yaw_error(i1, i2):
     return yaw_error_from_affine(i1, i2, find_affine(i1, i2))
 
 
+_yaw_cache = {}         # image name -> (yaw_pairs node, {other name: (yaw_error, weight, dist_m)})
+
+
+def _yaw_pairs_of(name, yaw_node):
+    """the image's yaw_pairs children as plain tuples (like _pairs_of: read from the tree once,
+    then kept in step; an image with k partners would otherwise re-read k nodes per new pair)"""
+    entry = _yaw_cache.get(name)
+    acc = entry[1] if entry is not None and entry[0] is yaw_node else None
+    if acc is None:
+        acc = {}
+        for child in yaw_node.getChildren():
+            pn = yaw_node.getChild(child)
+            if pn is not None:
+                acc[child] = (pn.getFloat("yaw_error"), pn.getInt("weight"), pn.getFloat("dist_m"))
+        _yaw_cache[name] = (yaw_node, acc)
+    return acc
+
+
 def record_yaw_error_estimate(i1, i2, affine):
     """the property-tree bookkeeping of update_yaw_error_estimate (smart.py:251-283): the pair's
     entry under /smart/<i1>/yaw_pairs and the weighted average over the image's pairs (pairs
     closer than 0.5 m or with more than 30 deg of error do not count; weights are truncated to
     integers exactly like the reference's getInt)"""
+    if affine is None:
+        return 0
     yaw_error, dist, crs_affine, weight = yaw_error_from_affine(i1, i2, affine)
     if yaw_error is None:
         return 0
     i1_node = smart_node.getChild(i1.name, True)
     yaw_node = i1_node.getChild("yaw_pairs", True)
+    acc = _yaw_pairs_of(i1.name, yaw_node)
     pair_node = yaw_node.getChild(i2.name, True)
     pair_node.setFloat("yaw_error", "%.1f" % yaw_error)
     pair_node.setFloat("dist_m", "%.1f" % dist)
     pair_node.setFloat("relative_crs", "%.1f" % crs_affine)
     pair_node.setFloat("weight", "%.1f" % weight)
+    acc[i2.name] = (pair_node.getFloat("yaw_error"), pair_node.getInt("weight"),
+                    pair_node.getFloat("dist_m"))
     total, count = 0, 0
-    for child in yaw_node.getChildren():
-        pn = yaw_node.getChild(child)
-        err, w, dist_m = pn.getFloat("yaw_error"), pn.getInt("weight"), pn.getFloat("dist_m")
+    for child in sorted(acc):                           # the tree's child order
+        err, w, dist_m = acc[child]
         if dist_m >= 0.5 and abs(err) <= 30:
             total += err * w
             count += w
@@ -263,15 +285,19 @@ def get_surface_estimate(i1, i2):
 
 # ---- smart.json (props_json inside the reference environment, plain json here) ----------------
 def _to_dict(node):
+    # (only without the props package: `node` is hostlib.props_compat.PropertyNode, whose
+    #  attributes are the children / enumerated lists / scalars themselves)
     out = {}
-    for k in node.getChildren():
-        child = node.getChild(k)
-        if child is not None:
-            out[k] = _to_dict(child)
-        elif node.getLen(k):
-            out[k] = [node.getFloatEnum(k, i) for i in range(node.getLen(k))]
+    for k, v in node.__dict__.items():
+        if isinstance(v, list):
+            if v:
+                out[k] = [float(x) for x in v]
+            else:
+                out[k] = v
+        elif hasattr(v, 'getChild'):
+            out[k] = _to_dict(v)
         else:
-            out[k] = node.__dict__[k]
+            out[k] = v
     return out
 
 
@@ -295,6 +321,7 @@ def _from_dict(node, d):
 
 def load(analysis_dir):
     _pair_cache.clear()
+    _yaw_cache.clear()
     if analysis_dir is None:
         return
     path = os.path.join(analysis_dir, "smart.json")
@@ -314,5 +341,14 @@ def save(analysis_dir):
         import props_json
         props_json.save(path, smart_node)
     else:
+        tree = _to_dict(smart_node)
         with open(path, 'w') as f:
-            json.dump(_to_dict(smart_node), f, indent=4, sort_keys=True)
+            if len(tree) <= 200:
+                json.dump(tree, f, indent=4, sort_keys=True)
+            else:
+                # python's json only has a C encoder for the compact form; a survey of
+                # thousands of images carries millions of per-pair leaves (one line per image)
+                f.write('{\n')
+                f.write(',\n'.join('%s: %s' % (json.dumps(k), json.dumps(tree[k], sort_keys=True))
+                                   for k in sorted(tree)))
+                f.write('\n}\n')

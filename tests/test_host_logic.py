@@ -253,3 +253,46 @@ def test_gather_results_reraises_single_rank():
     assert dist.gather_results([1, 2]) == [[1, 2]]
     with pytest.raises(ZeroDivisionError):
         dist.gather_results([], ZeroDivisionError("float division by zero"))
+
+
+def test_match_pairs_behave_like_the_reference_lists_and_pickle_like_them(tmp_path):
+    """image.match_list values are array-backed (matchpairs.MatchPairs): every list operation
+    the reference's readers use gives what the list of [i, j] lists would, the `.match` file
+    written from the arrays loads -- with pickle alone -- to plain lists of lists."""
+    import pickle
+    from imageanalysis_amd.matchpairs import MatchPairs, dumps_match_dict
+    rng = np.random.default_rng(5)
+    d, ref = {}, {}
+    for k in range(40):
+        n = int(rng.integers(0, 400))
+        a = rng.integers(0, 49000 if k % 3 else 200000, (n, 2)).astype(np.int32)
+        d['IMG_%04d' % k] = MatchPairs(a)
+        ref['IMG_%04d' % k] = a.tolist()
+    d['none'], ref['none'] = [], []
+    d['host path'], ref['host path'] = [[4, 5], [6, 7]], [[4, 5], [6, 7]]
+    d['neg'], ref['neg'] = MatchPairs(np.array([[-1, 70000]], np.int32)), [[-1, 70000]]
+    for blob in (dumps_match_dict(d), pickle.dumps(d), pickle.dumps(d, 2)):
+        got = pickle.loads(blob)
+        assert got == ref and all(type(v) is list for v in got.values())
+        assert all(type(p) is list and type(p[0]) is int for v in got.values() for p in v[:3])
+    assert pickle.loads(dumps_match_dict({})) == {}
+    m, r = d['IMG_0001'], ref['IMG_0001']
+    assert len(m) == len(r) and m[7] == r[7] and m[-1] == r[-1] and m[2:5] == r[2:5]
+    assert list(m) == r and m == r and r == m and not (m != r) and [p[1] for p in m] == [p[1] for p in r]
+    assert np.asarray(m, np.int64).tolist() == r and np.shares_memory(np.asarray(m), m.array())
+    assert d == ref                                   # dictionaries of them compare like lists
+    m.append([1, 2]); r.append([1, 2])
+    del m[0]; del r[0]
+    m[3] = [9, 9]; r[3] = [9, 9]
+    assert m == r and pickle.loads(dumps_match_dict({'k': m})) == {'k': r}
+    e = MatchPairs(np.zeros((3, 2), np.int32))
+    e[:] = np.array([[5, 6]])
+    assert e == [[5, 6]] and len(MatchPairs()) == 0 and not MatchPairs()
+    # through the Image object
+    from imageanalysis_amd import image as iimg
+    im = iimg.Image.__new__(iimg.Image)
+    im.match_file = str(tmp_path / 'a.match')
+    im.match_list = d
+    im.save_matches()
+    with open(im.match_file, 'rb') as fp:
+        assert pickle.load(fp) == ref
