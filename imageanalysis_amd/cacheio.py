@@ -31,8 +31,8 @@ def _pools():
     global _jobs, _workers
     with _lock:
         if _jobs is None:
-            n = max(2, min(32, os.cpu_count() or 2))
-            _jobs = ThreadPoolExecutor(max_workers=4, thread_name_prefix='iamx-cache')
+            n = max(2, min(96, os.cpu_count() or 2))
+            _jobs = ThreadPoolExecutor(max_workers=max(4, min(12, n // 8)), thread_name_prefix='iamx-cache')
             _workers = ThreadPoolExecutor(max_workers=n, thread_name_prefix='iamx-io')
     return _jobs, _workers
 
@@ -42,30 +42,41 @@ def _member(chunk, level):
     return c.compress(chunk) + c.flush()
 
 
-def gzip_members(raw, level=GZIP_LEVEL):
-    """bytes -> multi-member gzip stream of the same bytes (members compressed in parallel)"""
-    raw = memoryview(raw)
-    if len(raw) <= MEMBER_BYTES:
-        return _member(raw, level)
+def gzip_member_list(raw, level=GZIP_LEVEL):
+    """bytes-like, or a sequence of bytes-likes that are to follow each other (e.g. an .npy
+    header and the array's own memory: nothing is copied together first) -> list of gzip members
+    whose concatenation decompresses to those bytes (members compressed in parallel)"""
+    bufs = [raw] if isinstance(raw, (bytes, bytearray, memoryview)) else list(raw)
+    chunks = []
+    for b in bufs:
+        b = memoryview(b).cast('B')
+        chunks.extend(b[i:i + MEMBER_BYTES] for i in range(0, len(b), MEMBER_BYTES))
+    if not chunks:
+        chunks = [memoryview(b'')]
+    if len(chunks) == 1:
+        return [_member(chunks[0], level)]
     _j, workers = _pools()
-    chunks = [raw[i:i + MEMBER_BYTES] for i in range(0, len(raw), MEMBER_BYTES)]
     try:
-        parts = list(workers.map(lambda c: _member(c, level), chunks))
+        return list(workers.map(lambda c: _member(c, level), chunks))
     except RuntimeError:
         # "cannot schedule new futures after interpreter shutdown": the process is exiting while
         # this file is still queued -- compress it right here, the file must not be lost
-        parts = [_member(c, level) for c in chunks]
-    return b''.join(parts)
+        return [_member(c, level) for c in chunks]
+
+
+def gzip_members(raw, level=GZIP_LEVEL):
+    """... the same as ONE bytes object"""
+    return b''.join(gzip_member_list(raw, level))
 
 
 def _write_job(path, payload, on_error=None):
     try:
         raw = payload() if callable(payload) else payload
-        blob = gzip_members(raw)
+        members = gzip_member_list(raw)
         # pid + thread id: two ranks may write the same boundary image's cache at the same time
         tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
-            f.write(blob)
+            f.writelines(members)
         os.replace(tmp, path)                                 # readers never see half a file
     except Exception as e:                                    # noqa: BLE001
         if on_error is None:
@@ -78,7 +89,10 @@ def _write_raw_job(path, payload, on_error=None):
         raw = payload() if callable(payload) else payload
         tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
-            f.write(raw)
+            if isinstance(raw, (bytes, bytearray, memoryview)):
+                f.write(raw)
+            else:
+                f.writelines(raw)
         os.replace(tmp, path)
     except Exception as e:                                    # noqa: BLE001
         if on_error is None:

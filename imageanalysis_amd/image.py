@@ -24,6 +24,7 @@ import numpy as np
 from . import _deps, cacheio
 from .matchpairs import dump_match_dict
 from .hostlib.image_pose import PoseImage
+from .keypoints import KeyPointList
 
 try:                                     # inside the reference environment keep cv2's type
     from cv2 import KeyPoint as _CvKeyPoint
@@ -85,7 +86,9 @@ def make_keypoints(x, y, size, angle, response, octave, class_id=None):
 ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
 USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
 WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
-PREFETCH_DEPTH = 6             # decoded / cache-loaded images held ahead of the detector
+# decoded / cache-loaded images held ahead of the detector (one worker thread each; a 20 MP JPEG
+# takes ~0.2 s of one core to decode against ~6 ms on the GPU, 60 MB per decoded frame)
+PREFETCH_DEPTH = min(24, max(6, (os.cpu_count() or 8) // 4))
 
 
 def _log(*a):
@@ -99,21 +102,14 @@ def _qlog(*a):
 # --------------------------------------------------------------------------------------
 # cache I/O -- image.py:140-228
 # --------------------------------------------------------------------------------------
-def _keypoints_from_tuples(feature_list):
-    if not len(feature_list):
-        return []
-    pt, size, angle, response, octave, class_id = zip(*feature_list)
-    x, y = zip(*pt)
-    return make_keypoints(x, y, size, angle, response, octave, class_id)
-
-
 def load_features(self):
     cacheio.wait(self.features_file)
     if os.path.exists(self.features_file):
         try:
             with gzip.open(self.features_file, "rb") as fp:
-                feature_list = pickle.load(fp)
-            self.kp_list = _keypoints_from_tuples(feature_list)
+                blob = fp.read()
+            # (an array-backed sequence of keypoints: keypoints.py)
+            self.kp_list = KeyPointList.from_feat_bytes(blob)
             return True
         except Exception:                 # noqa: BLE001  (the reference prints and carries on)
             print(self.features_file + ":\n" + "  feature load error: "
@@ -182,17 +178,29 @@ def load_matches(self):
 def save_features(self):
     """same bytes as the reference's gzip.open(..., compresslevel=6) + pickle.dump once
     decompressed; written in the background as a multi-member gzip stream (cacheio)"""
-    feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
-                    for kp in self.kp_list]
-    cacheio.write_gzip(self.features_file, lambda: pickle.dumps(feature_list),
+    kps = self.kp_list
+    if isinstance(kps, KeyPointList):
+        payload = kps.feat_bytes                         # straight from the columns (in the writer thread)
+    else:
+        feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
+                        for kp in kps]
+        payload = lambda: pickle.dumps(feature_list)
+    cacheio.write_gzip(self.features_file, payload,
                        background=ASYNC_CACHE_WRITES,
                        on_error=lambda e: print("save_features(): I/O error: %s" % e))
 
 
 def _npy_bytes(arr):
-    buf = io.BytesIO()
-    np.save(buf, arr)
-    return buf.getbuffer()
+    """the bytes np.save() writes, as (header, the array's own memory): 25 MB of descriptors are
+    not copied (with the GIL held) just to be compressed"""
+    arr = np.asarray(arr)
+    if arr.dtype.hasobject or not arr.flags.c_contiguous or arr.size == 0:
+        buf = io.BytesIO()
+        np.save(buf, arr)
+        return buf.getbuffer()
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, np.lib.format.header_data_from_array_1_0(arr))
+    return [head.getvalue(), memoryview(arr.reshape(-1).view(np.uint8))]
 
 
 def save_descriptors(self):
@@ -202,8 +210,13 @@ def save_descriptors(self):
                            on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)))
     if USE_DESC_SIDECAR and des is not None and len(des):
         u8 = np.asarray(des)
-        as_u8 = u8 if u8.dtype == np.uint8 else np.clip(np.rint(u8), 0, 255).astype(np.uint8)
-        if u8.dtype == np.uint8 or np.array_equal(as_u8, u8):          # integer valued 0..255 only
+        known = getattr(self, '_iamx_des_u8', None)       # (float32 array, its uint8 original)
+        if known is not None and known[0] is des:
+            as_u8 = known[1]                              # straight from the detector
+        else:
+            as_u8 = u8 if u8.dtype == np.uint8 else np.clip(np.rint(u8), 0, 255).astype(np.uint8)
+        if u8.dtype == np.uint8 or (known is not None and known[0] is des) \
+                or np.array_equal(as_u8, u8):             # integer valued 0..255 only
             side = _sidecar(self.desc_file)
             cacheio.write_raw(side, lambda: _npy_bytes(as_u8), background=ASYNC_CACHE_WRITES,
                               on_error=lambda e: print(side + ": error saving file: " + str(e)))
@@ -223,11 +236,23 @@ def save_matches(self):
 # --------------------------------------------------------------------------------------
 # decode / equalise -- image.py:99-121
 # --------------------------------------------------------------------------------------
-def _decode_bgr(path):
-    from PIL import Image as PILImage      # host-side JPEG decode, EXIF orientation ignored
+def _decode_bgr(path, writable=True):
+    """host-side JPEG decode (libjpeg through Pillow), EXIF orientation ignored like cv2.imread
+    with IMREAD_ANYCOLOR | IMREAD_ANYDEPTH | IMREAD_IGNORE_ORIENTATION (image.py:101-104).
+    The decoder's RGB rows are packed as BGR in ONE pass (three 60 MB passes for convert +
+    asarray + channel flip cost as much as the decode itself); writable=False hands the packed
+    buffer over as it is (the detector only uploads it)."""
+    from PIL import Image as PILImage
     with PILImage.open(path) as im:
-        rgb = np.asarray(im.convert('RGB'))
-    return np.ascontiguousarray(rgb[:, :, ::-1])
+        if im.mode != 'RGB':
+            im = im.convert('RGB')
+        else:
+            im.load()
+        w, h = im.size
+        buf = im.tobytes('raw', 'BGR')
+    if writable:
+        return np.frombuffer(bytearray(buf), np.uint8).reshape(h, w, 3)
+    return np.frombuffer(buf, np.uint8).reshape(h, w, 3)
 
 
 def load_rgb(self, equalize=False):
@@ -250,7 +275,7 @@ def load_rgb(self, equalize=False):
 # --------------------------------------------------------------------------------------
 # detect -- image.py:287-350
 # --------------------------------------------------------------------------------------
-def features_from_bgr(bgr, scale, equalize=True):
+def features_from_bgr(bgr, scale, equalize=True, keep_u8=False):
     """full-res BGR -> (kp_list in full-res pixels, des_list float32 [N,128]); everything
     after the decode runs on the GPU."""
     from . import kernels
@@ -259,8 +284,10 @@ def features_from_bgr(bgr, scale, equalize=True):
     # kp.pt = (kp.pt[0]/scale, kp.pt[1]/scale): keypoints are cached in FULL-RES pixels (:344-346)
     kp = np.asarray(kp)
     # python-float division like `kp.pt[0] / scale` on a cv2.KeyPoint, then float32 members
-    kp_list = make_keypoints(kp[:, 0].astype(np.float64) / scale, kp[:, 1].astype(np.float64) / scale,
-                             kp[:, 2], kp[:, 3], kp[:, 4], octave)
+    kp_list = KeyPointList(kp[:, 0].astype(np.float64) / scale, kp[:, 1].astype(np.float64) / scale,
+                           kp[:, 2], kp[:, 3], kp[:, 4], octave)
+    if keep_u8:
+        return kp_list, desc.astype(np.float32), desc
     return kp_list, desc.astype(np.float32)
 
 
@@ -285,7 +312,7 @@ def _prefetch_job(self):
     except Exception:                     # noqa: BLE001  (fall through to a fresh detection)
         pass
     try:
-        return ('bgr', _decode_bgr(self.image_file))
+        return ('bgr', _decode_bgr(self.image_file, writable=False))
     except Exception:                     # noqa: BLE001  (detect_features repeats it and reports)
         return None
 
@@ -304,10 +331,12 @@ def prefetch(images, depth=None):
 def detect_features(self, scale, use_cache=True):
     pf = getattr(self, '_iamx_prefetch', None)
     pre = pf.take(self) if pf is not None and pf.pending(self) else None
+    if use_cache and pre is not None and pre[0] == 'bgr':
+        use_cache = False          # the worker looked a moment ago: no cache files (stat() is not free)
     if use_cache:
         if pre is not None and pre[0] == 'cache':
             try:
-                self.kp_list = _keypoints_from_tuples(pickle.loads(pre[1]))
+                self.kp_list = KeyPointList.from_feat_bytes(pre[1])
                 self.des_list = pre[2] if isinstance(pre[2], np.ndarray) else np.load(io.BytesIO(pre[2]))
                 _qlog("Loaded features/descriptors from cache:", self.name)
                 return
@@ -327,7 +356,7 @@ def detect_features(self, scale, use_cache=True):
         _log("Detector", detector_node.getString('detector'),
              "is not on the MI355X path (SIFT only)")
         quit()
-    bgr = pre[1] if pre is not None and pre[0] == 'bgr' else _decode_bgr(self.image_file)
+    bgr = pre[1] if pre is not None and pre[0] == 'bgr' else _decode_bgr(self.image_file, writable=False)
     h, w = bgr.shape[:2]
     self.node.setInt('height', h)
     self.node.setInt('width', w)
@@ -337,10 +366,12 @@ def detect_features(self, scale, use_cache=True):
              cam_w, cam_h, "cannot continue safely.")
         _log("Please track down and fix the camera config vs. image size issue.")
         quit()
-    self.kp_list, self.des_list = features_from_bgr(bgr, scale, equalize=True)
+    self.kp_list, self.des_list, u8 = features_from_bgr(bgr, scale, equalize=True, keep_u8=True)
+    self._iamx_des_u8 = (self.des_list, u8)
     self.num_features = len(self.kp_list)
     self.save_features()
     self.save_descriptors()
+    self._iamx_des_u8 = None       # (the writers hold what they need; a cache flush must free it)
 
 
 _METHODS = dict(load_features=load_features, load_descriptors=load_descriptors,

@@ -18,7 +18,13 @@ def _dev(x, dtype):
     dev = require_gpu()
     if isinstance(x, torch.Tensor):
         return x.to(device=dev, dtype=dtype).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(x)).to(device=dev, dtype=dtype).contiguous()
+    x = np.ascontiguousarray(x)
+    if not x.flags.writeable:
+        import warnings
+        with warnings.catch_warnings():       # a read-only source (bytes of a decoder) is only read
+            warnings.simplefilter('ignore', UserWarning)
+            return torch.from_numpy(x).to(device=dev, dtype=dtype).contiguous()
+    return torch.from_numpy(x).to(device=dev, dtype=dtype).contiguous()
 
 
 # --------------------------------------------------------------------------------------

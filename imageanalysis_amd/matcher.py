@@ -28,6 +28,7 @@ import numpy as np
 
 from . import _deps
 from .matchpairs import MatchPairs
+from .keypoints import KeyPointList
 from ._deps import getNode
 from .gms import gms_inlier_mask
 
@@ -40,7 +41,7 @@ max_distance = None
 min_pairs = 25
 
 MYMAX = 2000            # matcher.py:265
-PAIRS_PER_BATCH = 512   # unordered pairs per device batch
+PAIRS_PER_BATCH = 2048  # unordered pairs per device batch (per-batch host costs are ~2 ms)
 
 
 def _log(*a):
@@ -177,6 +178,8 @@ def _kp_xy(image):
     (scripts/lib/matcher.py:1008-1026) -- a strong reference here kept every list ever matched."""
     import weakref
     kl = image.kp_list
+    if isinstance(kl, KeyPointList):
+        return kl.xy()                                 # array backed: no objects, no cache needed
     cache = getattr(image, '_iamx_xy', None)
     if cache is not None:
         tag, xy = cache
@@ -636,12 +639,32 @@ def _match_batch(batch, match_ratio, device_filters=True, surface=False):
     return _finish_batch(_launch_batch(batch, match_ratio, device_filters, surface))
 
 
+class _Empty(list):
+    """the (shared, immutable) empty match list of a pair without matches: find_matches stores
+    a fresh [] per pair and image, like the reference"""
+    __slots__ = ()
+
+
+_NO_MATCHES = _Empty()
+_NO_SURFACE = (None, None, 0.0, None, None)      # nothing to record (smart.py:200-201)
+
+
 def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, cnt, lists, z_rows,
                    surface):
     """host side of a batch: the per-pair python lists the callers' contract asks for"""
     from . import smart as _smart
+    count = count.tolist()
+    quiet = None
+    if have_post:
+        # pairs the device filters finished with nothing left (most pairs of an all-pairs
+        # schedule): one shared result, no per-pair work beyond the counts of the log
+        quiet = ((status == 0) & (cnt == 0)).tolist()
     for k in range(n):
-        n_fwd, n_rev = int(count[k]), int(count[n + k])
+        n_fwd, n_rev = count[k], count[n + k]
+        if quiet is not None and quiet[k]:
+            out.append((_NO_MATCHES, _NO_MATCHES, n_fwd, n_rev, _NO_SURFACE) if surface
+                       else (_NO_MATCHES, _NO_MATCHES, n_fwd, n_rev))
+            continue
         if have_post and status[k] == 0:
             # array-backed lists (matchpairs.py): `lists` is a page-locked buffer that the next
             # batch reuses, the pair's rows are copied out of it once
@@ -673,7 +696,7 @@ def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, c
         if have_post and status[k] == 0:
             i1, i2 = batch[k]
             if i1 == i2 or k not in z_rows:
-                surf = (None, None, 0.0, None, None)    # nothing to record (smart.py:200-201)
+                surf = _NO_SURFACE
             else:
                 zk, aff_fwd, aff_rev = z_rows[k]
                 surf = (-np.average(zk), np.std(zk), _smart._pair_distance(i1, i2), aff_fwd, aff_rev)
@@ -742,6 +765,8 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
         finally:
             if isinstance(the_matcher, DeviceMatcher):
                 the_matcher._pose_epoch = None
+            if hasattr(_deps.smart(), 'freeze_poses'):
+                _deps.smart().freeze_poses(False)
 
 
 def _find_matches(proj, K, strategy, transform, sort, review):
@@ -755,6 +780,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     if isinstance(the_matcher, DeviceMatcher):
         the_matcher._pose_epoch = object()
     smart = _deps.smart()
+    if hasattr(smart, 'freeze_poses'):
+        smart.freeze_poses(True)
     # our own smart mirror: the owning rank triangulates its whole batch in one launch
     batched_surface = smart is not None and hasattr(smart, 'record_surface_estimate')
     rank, ws = _dist.world()
@@ -764,6 +791,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
 
     # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
     pending = []
+    if not any(im.match_list for im in proj.image_list):
+        pending, work_list = work_list, []          # a fresh survey: nothing to skip
     for dist, i, j in work_list:
         i1, i2 = proj.image_list[i], proj.image_list[j]
         if i2.name in i1.match_list and i1.name in i2.match_list:
@@ -786,6 +815,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
         if pending else 0
     n_done = 0
+    yaw_is_zero = {}        # image index -> its yaw error estimate was last set to 0 here
 
     # ---- images this rank will have to detect / load, in the order the rounds reach them:
     # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
@@ -842,31 +872,39 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             failure, results = exc, []
         if ws > 1:
             # arrays on the wire, not lists of lists (a MatchPairs pickles as a plain list)
-            results = [(i, j, f.array() if isinstance(f, MatchPairs) else f,
-                        r.array() if isinstance(r, MatchPairs) else r, surf)
+            results = [(i, j, f.array() if isinstance(f, MatchPairs) else list(f),
+                        r.array() if isinstance(r, MatchPairs) else list(r), surf)
                        for i, j, f, r, surf in results]
         gathered = _dist.gather_results(results, failure)
 
         for part in gathered:
+            n_done += len(part)
             for i, j, match_fwd, match_rev, surf in part:
-                if isinstance(match_fwd, np.ndarray):
+                i1, i2 = image_list[i], image_list[j]
+                empty = len(match_fwd) == 0 and len(match_rev) == 0
+                if empty:
+                    match_fwd, match_rev = [], []           # (never the shared _NO_MATCHES)
+                elif isinstance(match_fwd, np.ndarray):
                     match_fwd, match_rev = MatchPairs(match_fwd), MatchPairs(match_rev)
-                i1, i2 = proj.image_list[i], proj.image_list[j]
-                n_done += 1
                 i1.match_list[i2.name] = match_fwd
                 i2.match_list[i1.name] = match_rev
-                i1.matches_clean = False
-                i2.matches_clean = False
+                i1.matches_clean = i2.matches_clean = False
+                if empty and (smart is None or (surf is not None and surf[0] is None
+                                                and surf[3] is None and surf[4] is None)):
+                    # nothing matched (most pairs of an all-pairs schedule): no surface / yaw
+                    # record (smart.py:200-201, :258-260); the yaw error estimate of both images
+                    # is set to the 0 update_yaw_error_estimate returns
+                    if smart is not None:
+                        for k, im in ((i, i1), (j, i2)):
+                            if yaw_is_zero.get(k) is not True:      # (2 calls per pair add up)
+                                im.set_aircraft_yaw_error_estimate(0)
+                                yaw_is_zero[k] = True
+                    continue
 
                 # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
                 avg = std = None
                 if smart is not None:
-                    if surf is not None and surf[0] is None and surf[3] is None and surf[4] is None:
-                        # no matches: smart.py:200-201 and :258-260 record nothing, the yaw
-                        # error estimate of both images is set to the 0 they return
-                        i1.set_aircraft_yaw_error_estimate(0)
-                        i2.set_aircraft_yaw_error_estimate(0)
-                        continue
+                    yaw_is_zero[i] = yaw_is_zero[j] = False
                     if surf is not None:
                         avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
                     else:

@@ -71,10 +71,27 @@ def triangulate_features(i1, i2):
                               "down coordinate only")
 
 
+_frozen = None          # id(image) -> (ned array, aircraft yaw) while find_matches runs
+
+
+def freeze_poses(on):
+    """find_matches brackets its pair loop with this: poses do not change inside one call, and
+    reading one back from the property tree costs more than a pair's share of the kernels"""
+    global _frozen
+    _frozen = {} if on else None
+
+
+def _ned_yaw(im):
+    if _frozen is None:
+        return np.array(im.get_camera_pose()[0]), im.get_aircraft_pose()[1][0]
+    hit = _frozen.get(id(im))
+    if hit is None:
+        hit = _frozen[id(im)] = (np.array(im.get_camera_pose()[0]), im.get_aircraft_pose()[1][0])
+    return hit
+
+
 def _pair_distance(i1, i2):
-    ned1, _, _ = i1.get_camera_pose()
-    ned2, _, _ = i2.get_camera_pose()
-    return np.linalg.norm(np.array(ned2) - np.array(ned1))
+    return np.linalg.norm(_ned_yaw(i2)[0] - _ned_yaw(i1)[0])
 
 
 def estimate_surface_elevation(i1, i2):
@@ -186,9 +203,8 @@ def yaw_error_from_affine(i1, i2, affine):
     r2d = 180.0 / np.pi
     _rot, tx, ty, _sx, _sy = decompose_affine(affine)
     weight = abs(ty / tx) if abs(ty) > 0 else abs(tx)
-    ned1, _, _ = i1.get_camera_pose()
-    ned2, _, _ = i2.get_camera_pose()
-    diff = np.array(ned2) - np.array(ned1)
+    (ned1, air_yaw1), (ned2, _y2) = _ned_yaw(i1), _ned_yaw(i2)
+    diff = ned2 - ned1
     dist = np.linalg.norm(diff)
     direction = diff / dist
     crs_gps = 90 - np.arctan2(direction[0], direction[1]) * r2d
@@ -202,8 +218,7 @@ def yaw_error_from_affine(i1, i2, affine):
     newc = np.asarray(affine).dot(np.float32([cx, cy, 1.0]))[:2]
     cdiff = [newc[0] - cx, cy - newc[1]]
     crs_aff = 90 - np.arctan2(cdiff[1], cdiff[0]) * r2d
-    _, air_ypr1, _ = i1.get_aircraft_pose()
-    yaw_error = crs_gps - (air_ypr1[0] + crs_aff)
+    yaw_error = crs_gps - (air_yaw1 + crs_aff)
     if yaw_error < -180:
         yaw_error += 360
     if yaw_error > 180:

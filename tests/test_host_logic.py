@@ -296,3 +296,46 @@ def test_match_pairs_behave_like_the_reference_lists_and_pickle_like_them(tmp_pa
     im.save_matches()
     with open(im.match_file, 'rb') as fp:
         assert pickle.load(fp) == ref
+
+
+def test_keypoint_list_is_a_list_of_keypoints_and_feat_files_stay_reference_readable(tmp_path):
+    """image.kp_list is array-backed (keypoints.KeyPointList): same objects as the list the
+    reference builds, `.feat` written from the columns loads with gzip + pickle alone to the
+    reference's list of tuples, and a `.feat` written the reference's way loads back."""
+    import gzip
+    import pickle
+    from imageanalysis_amd import cacheio, image as iimg
+    from imageanalysis_amd.keypoints import KeyPointList
+    from imageanalysis_amd.matcher import _kp_xy
+    rng = np.random.default_rng(3)
+    n = 5000
+    x, y = rng.uniform(0, 5472, n), rng.uniform(0, 3648, n)
+    size, angle, resp = rng.uniform(1, 40, n), rng.uniform(0, 360, n), rng.uniform(0, 0.2, n)
+    octave = (rng.integers(0, 8, n) | (rng.integers(1, 4, n) << 8) | (rng.integers(0, 255, n) << 16))
+    kl = KeyPointList(x, y, size, angle, resp, octave)
+    ref = iimg.make_keypoints(x, y, size, angle, resp, octave)
+    want = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id) for kp in ref]
+    assert len(kl) == n and pickle.loads(kl.feat_bytes()) == want
+    assert np.array_equal(_kp_xy(type('I', (), {'kp_list': kl})()), np.array([k.pt for k in ref], np.float32))
+    # through the Image methods, read back the way the reference reads (image.py:140-160)
+    im = iimg.Image.__new__(iimg.Image)
+    im.features_file = str(tmp_path / 'a.feat')
+    im.kp_list = kl
+    im.save_features()
+    cacheio.wait()
+    with gzip.open(im.features_file, 'rb') as fp:
+        assert pickle.load(fp) == want
+    im.kp_list = None
+    assert im.load_features() and isinstance(im.kp_list, KeyPointList) and im.kp_list._objs is None
+    got = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id) for kp in im.kp_list]
+    assert got == want and im.kp_list[17].pt == ref[17].pt and im.kp_list[-1].octave == ref[-1].octave
+    # a file written by the reference's writer (default pickle protocol, memoised tuples)
+    with gzip.open(im.features_file, 'wb') as fp:
+        pickle.dump(want, fp)
+    assert im.load_features()
+    assert [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id) for kp in im.kp_list] == want
+    # objects persist once created; an empty file gives an empty list
+    im.kp_list[5].size = 99.0
+    assert im.kp_list[5].size == 99.0 and pickle.loads(im.kp_list.feat_bytes())[5][1] == 99.0
+    assert KeyPointList.from_feat_bytes(pickle.dumps([])) == [] and \
+        pickle.loads(KeyPointList([], [], [], [], [], []).feat_bytes()) == []

@@ -22,7 +22,8 @@ from imageanalysis_amd.hostlib import camera  # noqa: E402
 
 def main():
     from PIL import Image as PILImage
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    n = int(args[0]) if args else 12
     tmp = tempfile.mkdtemp(prefix='iamx_det_')
     os.makedirs(os.path.join(tmp, 'images'))
     getNode('/config/directories', True).setString('project_dir', tmp)
@@ -68,6 +69,32 @@ def main():
     tb = time.perf_counter() - t0
     pf.close()
     print('overlapped: %.2f s = %.2f images/s (detector loop done after %.2f s)' % (tb, n / tb, t_det))
+
+    # (b2) the same without the reference's float32 .desc (uint8 sidecar only: a cache only this
+    # package reads)
+    imgs2 = project('sidecar_only')
+    iimg.WRITE_REFERENCE_DESC = False
+    prof = None
+    if '--profile' in sys.argv:
+        import cProfile
+        prof = cProfile.Profile()
+    t0 = time.perf_counter()
+    pf = iimg.prefetch(imgs2)
+    if prof:
+        prof.enable()
+    for im in imgs2:
+        im.detect_features(0.4)
+    if prof:
+        prof.disable()
+        import pstats
+        pstats.Stats(prof).sort_stats('cumulative').print_stats(30)
+    t_det = time.perf_counter() - t0
+    cacheio.wait()
+    tb2 = time.perf_counter() - t0
+    pf.close()
+    iimg.WRITE_REFERENCE_DESC = True
+    print('overlapped, no float32 .desc: %.2f s = %.2f images/s (detector loop done after %.2f s)'
+          % (tb2, n / tb2, t_det))
 
     # (c) reload from the cache just written (what a second run of the pipeline does)
     for im in imgs:
