@@ -191,22 +191,68 @@ struct SymArgs {
 // -> 4 -> 2 registers); only the two levels inside a quad run on every remaining register.
 // On return every lane of quad (b4 = lane bit 4, b3, b2) holds
 //     m0 = min over the half wave of r[4*b4 + 2*b2 + b3],   m1 = ... of r[8 + 4*b4 + 2*b2 + b3].
-__device__ __forceinline__ void half_wave_min16(const int (&r)[16], int &m0, int &m1)
+// FUSED: the two masked levels as v_min_i32_dpp (DPP source and minimum in ONE instruction, the
+// bank mask leaves the other quads' value in place: 2 instead of 3 instructions per register
+// pair and no copies), written as inline assembly -- the compiler only forms v_min_dpp where
+// the mask is full.  A DPP read needs two wait states after a VALU write of the register; the
+// hazard recogniser does not look into inline assembly, hence the s_nop in front of each level
+// (inside a level no instruction reads through DPP what an earlier one of the level wrote).
+// `lo`: added to the four registers that are left after the two levels inside a 16-lane row
+// (lanes l, l^4, l^8, l^12 hold the same `lo`, see GROUPLO in the sweep): 4 adds instead of 16.
+template <bool FUSED>
+__device__ __forceinline__ void half_wave_min16(int (&r)[16], int lo, int &m0, int &m1)
 {
-    int s[8], u[4], w[2];
+    int u[4], w[2];
+    if constexpr (FUSED) {
+        asm("s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_min_i32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_min_i32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc"
+            : "+v"(r[0]), "+v"(r[2]), "+v"(r[4]), "+v"(r[6]), "+v"(r[8]), "+v"(r[10]), "+v"(r[12]), "+v"(r[14])
+            : "v"(r[1]), "v"(r[3]), "v"(r[5]), "v"(r[7]), "v"(r[9]), "v"(r[11]), "v"(r[13]), "v"(r[15]));
+        // (quads 0,1 now hold min r[2k], quads 2,3 min r[2k+1], in the register of r[2k])
+        asm("s_nop 1\n\t"
+            "v_min_i32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_i32_dpp %0, %4, %4 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_min_i32_dpp %1, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_i32_dpp %1, %5, %5 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_min_i32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_i32_dpp %2, %6, %6 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_min_i32_dpp %3, %3, %3 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_i32_dpp %3, %7, %7 row_ror:4 row_mask:0xf bank_mask:0xa"
+            : "+v"(r[0]), "+v"(r[4]), "+v"(r[8]), "+v"(r[12])
+            : "v"(r[2]), "v"(r[6]), "v"(r[10]), "v"(r[14]));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {          // lanes xor 8: quads 0,1 keep r[2k], quads 2,3 r[2k+1]
-        const int a = r[2 * k], b = r[2 * k + 1];
-        const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);   // row_ror:8
-        const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);
-        s[k] = min(t1, t2);
-    }
+        for (int k = 0; k < 4; ++k) u[k] = r[4 * k] + lo;
+    } else {
+        int s[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {          // lanes xor 4: quads 0,2 keep s[2k], quads 1,3 s[2k+1]
-        const int a = s[2 * k], b = s[2 * k + 1];
-        const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x12C, 0xF, 0x5, false);   // row_ror:12 = lane+4
-        const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x124, 0xF, 0xA, false);   // row_ror:4  = lane-4
-        u[k] = min(t1, t2);
+        for (int k = 0; k < 8; ++k) {          // lanes xor 8: quads 0,1 keep r[2k], quads 2,3 r[2k+1]
+            const int a = r[2 * k], b = r[2 * k + 1];
+            const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xF, 0x3, false);   // row_ror:8
+            const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xF, 0xC, false);
+            s[k] = min(t1, t2);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {          // lanes xor 4: quads 0,2 keep s[2k], quads 1,3 s[2k+1]
+            const int a = s[2 * k], b = s[2 * k + 1];
+            const int t1 = __builtin_amdgcn_update_dpp(b, a, 0x12C, 0xF, 0x5, false);   // row_ror:12 = lane+4
+            const int t2 = __builtin_amdgcn_update_dpp(a, b, 0x124, 0xF, 0xA, false);   // row_ror:4  = lane-4
+            u[k] = min(t1, t2) + lo;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {          // lanes xor 16: v_permlane16_swap exchanges the odd rows
@@ -230,9 +276,14 @@ __device__ __forceinline__ void half_wave_min16(const int (&r)[16], int &m0, int
 // taken (software pipeline across the 8 steps of a chunk, sched_group_barrier interleave).
 // MERGEW: waves that share the per-chunk row merge (CHUNK / MERGEW rows each); SLEEP: s_sleep
 // argument for the second half of the waves at the start of every chunk (de-phasing experiments)
-template <int QW, int NW, int VARIANT = 0, int PIPE = 0, int MERGEW = 2, int SLEEP = 0>
+// GROUPLO: the Cq floor is shared by the four lanes l, l^4, l^8, l^12 (they hold 4 QW consecutive
+// sorted rows) and added after the two butterfly levels inside a 16-lane row instead of riding in
+// the C operand; with it the fused butterfly (half_wave_min16<true>).
+template <int QW, int NW, int VARIANT = 0, int PIPE = 0, int MERGEW = 2, int SLEEP = 0, bool GROUPLO = false,
+          int CH = 128>
 __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 {
+    constexpr int CHUNK = CH;        // train rows per LDS stage (experiments: 256)
     constexpr int WGROWS = NW * QW * 32;
     constexpr int NT = NW * 64;
     constexpr int PIECES = CHUNK * D / 16 / NT;
@@ -272,10 +323,13 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     // group minimum is unchanged).  Cq of a lane's rows lies in [lo_lane, lo_lane + spread]:
     // lo_lane rides into the sweep with the C operand, the wave's largest spread S_w (a few
     // hundred for SIFT-like rows, the rows are sorted) widens the upper bound afterwards.
+    // (GROUPLO: lane c holds the row quadruple rc, c's bits 3:2 moved to the bottom, so that
+    //  the lanes that differ in bits 3:2 hold 4 QW CONSECUTIVE rows)
+    const int rc = GROUPLO ? ((c & 16) | ((c & 3) << 2) | ((c >> 2) & 3)) : c;
     v4i bq[QW][4];
 #pragma unroll
     for (int qb = 0; qb < QW; ++qb) {
-        int row = q0 + QW * c + qb;
+        int row = q0 + QW * rc + qb;
         row = row < nb ? row : nb - 1;
         const v4i *src = reinterpret_cast<const v4i *>(A.sdesc + (int64_t)(boff + row) * D);
 #pragma unroll
@@ -285,8 +339,9 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     {
         int spread = 0;
         if (wave_valid) {
-            const int r_lo = q0 + QW * c < nb ? q0 + QW * c : nb - 1;
-            const int r_hi = q0 + QW * c + QW - 1 < nb ? q0 + QW * c + QW - 1 : nb - 1;
+            const int g_lo = GROUPLO ? (rc & ~3) : rc, g_hi = GROUPLO ? (rc | 3) : rc;
+            const int r_lo = q0 + QW * g_lo < nb ? q0 + QW * g_lo : nb - 1;
+            const int r_hi = q0 + QW * g_hi + QW - 1 < nb ? q0 + QW * g_hi + QW - 1 : nb - 1;
             lo_lane = A.sn2[boff + r_lo] >> 1;
             spread = (A.sn2[boff + r_hi] >> 1) - lo_lane;
         }
@@ -380,8 +435,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     }
                 };
                 load_ops(0, aop[0], tbop[0]);
+                if constexpr (!GROUPLO) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) tbop[0][k] += lo_lane;
+                    for (int k = 0; k < 4; ++k) tbop[0][k] += lo_lane;
+                }
                 issue(0, 0, accs[0][0], accs[0][1]);
                 load_ops(1, aop[1], tbop[1]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -390,7 +447,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     const int t = st / PP, qp = 2 * (st % PP), cur = st & 1;
                     if (st + 1 < NS) {
                         const int t1 = (st + 1) / PP, qp1 = 2 * ((st + 1) % PP);
-                        if (t1 != t) {
+                        if (!GROUPLO && t1 != t) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k) tbop[t1 & 1][k] += lo_lane;
                         }
@@ -398,15 +455,15 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                         if (t1 != t && t1 + 1 < CHUNK / 32) load_ops(t1 + 1, aop[t & 1], tbop[t & 1]);
                     }
                     const v16i acc0 = accs[cur][0], acc1 = accs[cur][1];
-                    int t0 = min(min(m[qp][t], acc0[0]), acc0[1]);
-                    int t1m = min(min(m[qp + 1][t], acc1[0]), acc1[1]);
+                    int t0 = min(min(m[qp][t & 3], acc0[0]), acc0[1]);
+                    int t1m = min(min(m[qp + 1][t & 3], acc1[0]), acc1[1]);
 #pragma unroll
                     for (int reg = 2; reg < 16; reg += 2) {
                         t0 = min(min(t0, acc0[reg]), acc0[reg + 1]);
                         t1m = min(min(t1m, acc1[reg]), acc1[reg + 1]);
                     }
-                    m[qp][t] = t0;
-                    m[qp + 1][t] = t1m;
+                    m[qp][t & 3] = t0;
+                    m[qp + 1][t & 3] = t1m;
                     if (qp == 0) {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) r[reg] = min(acc0[reg], acc1[reg]);
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     }
                     if (qp == QW - 2) {
                         int m0, m1;
-                        half_wave_min16(r, m0, m1);
+                        half_wave_min16<GROUPLO>(r, GROUPLO ? lo_lane : 0, m0, m1);
                         int *dst = row_dst + t * 32;
                         dst[0] = m0;
                         dst[16] = m1;
@@ -442,7 +499,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                 static_assert(QW % 2 == 0, "query blocks are processed in pairs");
                 int cl[16];                    // C operand: Ct of the 16 rows + the lane's Cq floor
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) cl[reg] = tbv[reg >> 2][reg & 3] + lo_lane;
+                for (int reg = 0; reg < 16; ++reg) cl[reg] = tbv[reg >> 2][reg & 3] + (GROUPLO ? 0 : lo_lane);
 #pragma unroll
                 for (int qp = 0; qp < QW; qp += 2) {
                     // two independent accumulator chains in flight (C operand = Ct of the rows)
@@ -463,15 +520,15 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                         asm volatile("" ::"v"(acc0), "v"(acc1));
                     } else {
                         // column direction: one of four interleaved running minima per query
-                        int t0 = min(min(m[qp][tile], acc0[0]), acc0[1]);
-                        int t1 = min(min(m[qp + 1][tile], acc1[0]), acc1[1]);
+                        int t0 = min(min(m[qp][tile & 3], acc0[0]), acc0[1]);
+                        int t1 = min(min(m[qp + 1][tile & 3], acc1[0]), acc1[1]);
 #pragma unroll
                         for (int reg = 2; reg < 16; reg += 2) {
                             t0 = min(min(t0, acc0[reg]), acc0[reg + 1]);
                             t1 = min(min(t1, acc1[reg]), acc1[reg + 1]);
                         }
-                        m[qp][tile] = t0;
-                        m[qp + 1][tile] = t1;
+                        m[qp][tile & 3] = t0;
+                        m[qp + 1][tile & 3] = t1;
                     }
                     // row direction: minimum over the wave's query blocks, per accumulator register
                     if constexpr (VARIANT & 2) {
@@ -493,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     m0 = r[0];
                     m1 = r[1];
                 } else {
-                    half_wave_min16(r, m0, m1);
+                    half_wave_min16<GROUPLO>(r, GROUPLO ? lo_lane : 0, m0, m1);
                 }
                 {
                     // accumulator register reg of lane half g is tile row 8*(reg>>2) + 4*g + (reg&3);
@@ -527,9 +584,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
             const int a1 = min(lo01, lo23), a2 = min(max(lo01, lo23), min(hi01, hi23));
             const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
             const int v1 = min(a1, b1), v2 = min(max(a1, b1), min(a2, b2));
-            const int row = q0 + QW * c + qb;
+            const int row = q0 + QW * rc + qb;
+            const int sub = GROUPLO ? 0 : lo_lane;       // (GROUPLO: the accumulators never saw it)
             if (g == 0 && row < nb)
-                *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1 - lo_lane, v2 - lo_lane};
+                *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1 - sub, v2 - sub};
         }
     }
 }
@@ -903,9 +961,9 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     hipStream_t st = iamx::as_stream(stream);
     // PIPE = 6: six epilogue VALU instructions beside every MFMA of the next pair of query
     // blocks (profiles/r2_knn2sym_ablate.txt: 1.83 -> 1.78 us per image pair)
-    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6>), g, dim3(512), 0, st, a);
-    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4, 0, 6>), g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((knn2sym_kernel<2, 4, 0, 6>), g, dim3(256), 0, st, a);
+    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a);
+    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4, 0, 6, 2, 0, true>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((knn2sym_kernel<2, 4, 0, 6, 2, 0, true>), g, dim3(256), 0, st, a);
     return iamx::check_launch("iamx_knn2sym_sweep");
 }
 
@@ -967,6 +1025,12 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 310: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 256>), g, dim3(512), 0, st, a); break;
+    case 311: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 128>), g, dim3(512), 0, st, a); break;
+    case 300: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 301: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 302: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 4, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 303: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 200: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 4, 0>), g, dim3(512), 0, st, a); break;
     case 201: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 2>), g, dim3(512), 0, st, a); break;
     case 202: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 5>), g, dim3(512), 0, st, a); break;
