@@ -400,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
-        if (ch + 1 < nchunks) stage_direct(ch + 1, buf ^ 1);
+        if (ch + 1 < nchunks && (!(VARIANT & 64) || ch == 0)) stage_direct(ch + 1, buf ^ 1);
         if constexpr (SLEEP > 0)
             if (wave >= NW / 2) __builtin_amdgcn_s_sleep(SLEEP);
         if constexpr (!(VARIANT & 16))
@@ -1025,6 +1025,11 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 400: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 401: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 32, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 402: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 32 + 16, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 403: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 3, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 404: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 3, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 310: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 256>), g, dim3(512), 0, st, a); break;
     case 311: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 128>), g, dim3(512), 0, st, a); break;
     case 300: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
