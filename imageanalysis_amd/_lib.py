@@ -100,6 +100,21 @@ SIGNATURES = {
     'iamx_vec_mul2': (c_int, [c_int64] + [c_void_p] * 6),
     'iamx_vec_dot': (c_int, [c_int64] + [c_void_p] * 5),
     'iamx_vec_lsmr_update': (c_int, [c_int64] + [c_void_p] * 4 + [c_double] * 3 + [c_void_p]),
+    'iamx_vec_lincomb': (c_int, [c_int64, c_double, c_void_p, c_double, c_void_p, c_double, c_void_p,
+                                 c_void_p, c_void_p]),
+    'iamx_vec_mul': (c_int, [c_int64, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'iamx_vec_sqrt_shift': (c_int, [c_int64, c_void_p, c_double, c_void_p, c_void_p]),
+    'iamx_vec_scratch_doubles': (c_int, []),
+    'iamx_vec_dots': (c_int, [c_int64, c_int] + [c_void_p] * 6),
+    'iamx_vec_absmax_prod': (c_int, [c_int64] + [c_void_p] * 5),
+    'iamx_trf_cl_scaling': (c_int, [c_int64] + [c_void_p] * 7),
+    'iamx_trf_scale': (c_int, [c_int64] + [c_void_p] * 9),
+    'iamx_trf_jac_scale': (c_int, [c_int64, c_void_p, c_void_p, c_int, c_void_p]),
+    'iamx_trf_step_to_bound': (c_int, [c_int64] + [c_void_p] * 7),
+    'iamx_trf_reflect': (c_int, [c_int64] + [c_void_p] * 4 + [c_double] + [c_void_p] * 4),
+    'iamx_trf_count_outside': (c_int, [c_int64] + [c_void_p] * 7),
+    'iamx_trf_strictly_feasible': (c_int, [c_int64] + [c_void_p] * 6),
+    'iamx_trf_active': (c_int, [c_int64] + [c_void_p] * 3 + [c_double] + [c_void_p] * 2),
 }
 
 

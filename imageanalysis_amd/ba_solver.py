@@ -322,24 +322,36 @@ class DeviceBA(object):
         self.jtv(self.r, self.tmp_n)
         return self.tmp_n[:self.n].clone()
 
-    def colnorm_dev(self):
+    def colsq_dev(self):
+        """column sums of J.^2 as a device n-vector (a view of the scratch vector: use it
+        before the next operator application)"""
         self.jtv(self.r, self.tmp_n, square=True)
-        return torch.sqrt(self.tmp_n[:self.n])
+        return self.tmp_n[:self.n]
+
+    def vec_ops(self):
+        if getattr(self, '_vec_ops', None) is None:
+            self._vec_ops = VecOps(self.dev)
+        return self._vec_ops
 
     def gram_dev(self, d_dev, vectors):
         """gram() for device n-vectors (internal order); one host read for the whole matrix"""
         k = len(vectors)
+        V = self.vec_ops()
         ys = []
         for s in vectors:
-            torch.mul(d_dev[:self.n], s[:self.n], out=self.tmp_n2[:self.n])
+            V.mul(d_dev[:self.n], s[:self.n], out=self.tmp_n2[:self.n])
             y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
             self.jv(self.tmp_n2, y)
             ys.append(y[:self.m])
-        vals = [torch.dot(ys[i], ys[j]) for i in range(k) for j in range(i, k)]
-        g = torch.stack(vals)
+        pairs = [(ys[i], ys[j]) for i in range(k) for j in range(i, k)]
+        if self.m == 0:
+            g = [0.0] * len(pairs)
+        else:
+            g = V.dots(*pairs, n=self.m)                 # (k <= 3: at most 6 products)
         if self.world > 1:
-            _dist.allreduce_sum_(g)
-        g = g.tolist()
+            t = torch.tensor(g, dtype=F64, device=self.dev)
+            _dist.allreduce_sum_(t)
+            g = t.tolist()
         G = np.zeros((k, k))
         it = iter(g)
         for i in range(k):
@@ -890,79 +902,137 @@ def _trf_host(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, 
 # --------------------------------------------------------------------------------------
 # the same outer iteration with every n-vector resident on the device (internal order)
 # --------------------------------------------------------------------------------------
-_INF = float('inf')
+class VecOps(object):
+    """The n-vector kernels of the TRF outer loop (csrc/trf_vec.hip) on float64 device tensors:
+    torch holds the memory, libiamx does the arithmetic.  Scalars come back through one small
+    read per call (`dots` returns up to 8 inner products at once)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.scratch = torch.empty(int(lib().iamx_vec_scratch_doubles()), dtype=F64, device=dev)
+        self.out = torch.empty(8, dtype=F64, device=dev)
+
+    def new(self, like):
+        return torch.empty(like.numel(), dtype=F64, device=self.dev)
+
+    def lincomb(self, a, x, b=0.0, y=None, c=0.0, z=None, out=None):
+        out = self.new(x) if out is None else out
+        check(lib().iamx_vec_lincomb(x.numel(), float(a), _ptr(x), float(b), _ptr(y), float(c),
+                                     _ptr(z), _ptr(out), stream_ptr()), 'iamx_vec_lincomb')
+        return out
+
+    def mul(self, x, y=None, s=1.0, out=None):
+        out = self.new(x) if out is None else out
+        check(lib().iamx_vec_mul(x.numel(), float(s), _ptr(x), _ptr(y), _ptr(out), stream_ptr()),
+              'iamx_vec_mul')
+        return out
+
+    def sqrt_shift(self, x, shift):
+        out = self.new(x)
+        check(lib().iamx_vec_sqrt_shift(x.numel(), _ptr(x), float(shift), _ptr(out), stream_ptr()),
+              'iamx_vec_sqrt_shift')
+        return out
+
+    def dots(self, *terms, n=None):
+        """terms: (a, b) or (a, w, b) -> [sum a.*b (.*w)] as python floats, one host read"""
+        import ctypes
+        k = len(terms)
+        A = (ctypes.c_void_p * k)(*[t[0].data_ptr() for t in terms])
+        B = (ctypes.c_void_p * k)(*[t[-1].data_ptr() for t in terms])
+        W = (ctypes.c_void_p * k)(*[(t[1].data_ptr() if len(t) == 3 and t[1] is not None else None)
+                                    for t in terms])
+        n = terms[0][0].numel() if n is None else n
+        check(lib().iamx_vec_dots(n, k, A, B, W, _ptr(self.out), _ptr(self.scratch), stream_ptr()),
+              'iamx_vec_dots')
+        return self.out[:k].tolist()
+
+    def absmax(self, x, y=None):
+        check(lib().iamx_vec_absmax_prod(x.numel(), _ptr(x), _ptr(y), _ptr(self.out),
+                                         _ptr(self.scratch), stream_ptr()), 'iamx_vec_absmax_prod')
+        return float(self.out[0].item())
+
+    # ---- scipy/optimize/_lsq/common.py on device vectors
+    def cl_scaling(self, x, g, lb, ub):
+        """CL_scaling_vector"""
+        v, dv = self.new(x), self.new(x)
+        check(lib().iamx_trf_cl_scaling(x.numel(), _ptr(x), _ptr(g), _ptr(lb), _ptr(ub), _ptr(v),
+                                        _ptr(dv), stream_ptr()), 'iamx_trf_cl_scaling')
+        return v, dv
+
+    def trf_scale(self, v, dv, g, scale_inv, want_v=False):
+        """trf.py: v[dv != 0] *= scale_inv; d = sqrt(v) * scale; diag_h = g dv scale; g_h = d g"""
+        d, diag_h, g_h = self.new(v), self.new(v), self.new(v)
+        v_out = self.new(v) if want_v else None
+        check(lib().iamx_trf_scale(v.numel(), _ptr(v), _ptr(dv), _ptr(g), _ptr(scale_inv),
+                                   _ptr(v_out), _ptr(d), _ptr(diag_h), _ptr(g_h), stream_ptr()),
+              'iamx_trf_scale')
+        return (d, diag_h, g_h, v_out) if want_v else (d, diag_h, g_h)
+
+    def jac_scale(self, colsq, scale_inv, first):
+        """compute_jac_scale from the column sums of J.^2 (in place on scale_inv)"""
+        check(lib().iamx_trf_jac_scale(scale_inv.numel(), _ptr(colsq), _ptr(scale_inv),
+                                       1 if first else 0, stream_ptr()), 'iamx_trf_jac_scale')
+        return scale_inv
+
+    def step_size_to_bound(self, x, s, lb, ub, want_hits=False):
+        """step_size_to_bound: (min step, hits in {-1, 0, 1} when asked for)"""
+        check(lib().iamx_trf_step_to_bound(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub),
+                                           _ptr(self.out), _ptr(self.scratch), stream_ptr()),
+              'iamx_trf_step_to_bound')
+        step = float(self.out[0].item())
+        if not want_hits:
+            return step, None
+        hits = self.new(x)
+        check(lib().iamx_trf_reflect(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub), step, None,
+                                     None, _ptr(hits), stream_ptr()), 'iamx_trf_reflect')
+        return step, hits
+
+    def reflect(self, x, s, lb, ub, min_step, p_h):
+        """trf.py select_step: p_h with the components that hit a bound first negated"""
+        r_h = self.new(x)
+        check(lib().iamx_trf_reflect(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub), float(min_step),
+                                     _ptr(p_h), _ptr(r_h), None, stream_ptr()), 'iamx_trf_reflect')
+        return r_h
+
+    def in_bounds(self, x, lb, ub, p=None):
+        """in_bounds(x (+ p), lb, ub)"""
+        check(lib().iamx_trf_count_outside(x.numel(), _ptr(x), _ptr(p), _ptr(lb), _ptr(ub),
+                                           _ptr(self.out), _ptr(self.scratch), stream_ptr()),
+              'iamx_trf_count_outside')
+        return float(self.out[0].item()) == 0.0
+
+    def strictly_feasible(self, x, lb, ub, step=None):
+        """make_strictly_feasible(x (+ step), lb, ub, rstep=0)"""
+        out = self.new(x)
+        check(lib().iamx_trf_strictly_feasible(x.numel(), _ptr(x), _ptr(step), _ptr(lb), _ptr(ub),
+                                               _ptr(out), stream_ptr()), 'iamx_trf_strictly_feasible')
+        return out
+
+    def active_constraints(self, x, lb, ub, rtol):
+        """find_active_constraints (rtol > 0) as -1 / 0 / +1"""
+        out = self.new(x)
+        check(lib().iamx_trf_active(x.numel(), _ptr(x), _ptr(lb), _ptr(ub), float(rtol), _ptr(out),
+                                    stream_ptr()), 'iamx_trf_active')
+        return out
 
 
-def _cl_scaling_dev(x, g, lb, ub, fin_lb, fin_ub):
-    """scipy/optimize/_lsq/common.py CL_scaling_vector"""
-    one, zero = torch.ones_like(x), torch.zeros_like(x)
-    up = (g < 0) & fin_ub
-    lo = (g > 0) & fin_lb
-    v = torch.where(up, ub - x, one)
-    v = torch.where(lo, x - lb, v)
-    dv = torch.where(up, -one, zero)
-    dv = torch.where(lo, one, dv)
-    return v, dv
-
-
-def _step_size_to_bound_dev(x, s, lb, ub):
-    """common.py step_size_to_bound: (min step, hits) with hits in {-1, 0, 1}"""
-    steps = torch.maximum((lb - x) / s, (ub - x) / s)
-    steps = torch.where(s != 0, steps, torch.full_like(steps, _INF))
-    min_step = steps.min()
-    hits = (steps == min_step).to(s.dtype) * torch.sign(s)
-    return float(min_step), hits
-
-
-def _in_bounds_dev(x, lb, ub):
-    return bool(((x >= lb) & (x <= ub)).all())
-
-
-def _strictly_feasible_dev(x, lb, ub, fin_lb, fin_ub):
-    """common.py make_strictly_feasible(x, lb, ub, rstep=0) with find_active_constraints
-    (rtol = 0): points on a bound move one ulp inside"""
-    lower, upper = x <= lb, x >= ub
-    x_new = torch.where(lower, torch.nextafter(lb, ub), x)
-    x_new = torch.where(upper, torch.nextafter(ub, lb), x_new)
-    tight = (x_new < lb) | (x_new > ub)
-    return torch.where(tight, 0.5 * (lb + ub), x_new)
-
-
-def _active_constraints_dev(x, lb, ub, fin_lb, fin_ub, rtol):
-    """common.py find_active_constraints (rtol > 0)"""
-    lower_dist, upper_dist = x - lb, ub - x
-    lower_thr = rtol * torch.clamp(lb.abs(), min=1.0)
-    upper_thr = rtol * torch.clamp(ub.abs(), min=1.0)
-    active = torch.zeros_like(x)
-    active = torch.where(fin_lb & (lower_dist <= torch.minimum(upper_dist, lower_thr)),
-                         -torch.ones_like(x), active)
-    active = torch.where(fin_ub & (upper_dist <= torch.minimum(lower_dist, upper_thr)),
-                         torch.ones_like(x), active)
-    return active
-
-
-def _dots(*pairs):
-    """several inner products, one host read"""
-    return torch.stack([torch.dot(a, b) for a, b in pairs]).tolist()
-
-
-def _select_step_dev(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
+def _select_step_dev(prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     """trf.py select_step on device vectors; the J products go through Gram matrices"""
     from scipy.optimize._lsq.common import minimize_quadratic_1d
 
-    if _in_bounds_dev(x + p, lb, ub):
+    if V.in_bounds(x, lb, ub, p):
         G = prob.gram_dev(d, [p_h])
-        ph_d_ph, g_ph = _dots((p_h * diag_h, p_h), (g_h, p_h))
+        ph_d_ph, g_ph = V.dots((p_h, diag_h, p_h), (g_h, p_h))
         return p, p_h, -(0.5 * (G[0, 0] + ph_d_ph) + g_ph)
 
-    p_stride, hits = _step_size_to_bound_dev(x, p, lb, ub)
-    r_h = torch.where(hits != 0, -p_h, p_h)
-    r = d * r_h
-    p = p * p_stride
-    p_h = p_h * p_stride
-    x_on_bound = x + p
+    p_stride, _ = V.step_size_to_bound(x, p, lb, ub)
+    r_h = V.reflect(x, p, lb, ub, p_stride, p_h)
+    r = V.mul(d, r_h)
+    p = V.mul(p, s=p_stride)
+    p_h = V.mul(p_h, s=p_stride)
+    x_on_bound = V.lincomb(1.0, x, 1.0, p)
     # intersect_trust_region(p_h, r_h, Delta): positive root of |p_h + t r_h| = Delta
-    a, b, c = _dots((r_h, r_h), (p_h, r_h), (p_h, p_h))
+    a, b, c = V.dots((r_h, r_h), (p_h, r_h), (p_h, p_h))
     c -= Delta * Delta
     if a == 0:
         raise ValueError("`s` is zero.")
@@ -972,7 +1042,7 @@ def _select_step_dev(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     q = -(b + np.copysign(disc, b))
     t1, t2 = q / a, c / q
     to_tr = max(t1, t2)
-    to_bound, _ = _step_size_to_bound_dev(x_on_bound, r, lb, ub)
+    to_bound, _ = V.step_size_to_bound(x_on_bound, r, lb, ub)
     r_stride = min(to_bound, to_tr)
     if r_stride > 0:
         r_stride_l = (1 - theta) * p_stride / r_stride
@@ -980,33 +1050,33 @@ def _select_step_dev(prob, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     else:
         r_stride_l, r_stride_u = 0, -1
 
-    ag_h = -g_h
+    ag_h = V.mul(g_h, s=-1.0)
     G = prob.gram_dev(d, [p_h, r_h, ag_h])          # all three model directions in one go
-    (rh_d_rh, g_rh, ph_d_rh, ph_d_ph, g_ph, ag_d_ag, g_ag, ag_ag) = _dots(
-        (r_h * diag_h, r_h), (g_h, r_h), (p_h * diag_h, r_h), (p_h * diag_h, p_h), (g_h, p_h),
-        (ag_h * diag_h, ag_h), (g_h, ag_h), (ag_h, ag_h))
+    (rh_d_rh, g_rh, ph_d_rh, ph_d_ph, g_ph, ag_d_ag, g_ag, ag_ag) = V.dots(
+        (r_h, diag_h, r_h), (g_h, r_h), (p_h, diag_h, r_h), (p_h, diag_h, p_h), (g_h, p_h),
+        (ag_h, diag_h, ag_h), (g_h, ag_h), (ag_h, ag_h))
     if r_stride_l <= r_stride_u:
         qa = 0.5 * (G[1, 1] + rh_d_rh)
         qb = g_rh + G[0, 1] + ph_d_rh
         c0 = 0.5 * (G[0, 0] + ph_d_ph) + g_ph
         r_stride, r_value = minimize_quadratic_1d(qa, qb, r_stride_l, r_stride_u, c=c0)
-        r_h = r_h * r_stride + p_h
-        r = r_h * d
+        r_h = V.lincomb(r_stride, r_h, 1.0, p_h)
+        r = V.mul(r_h, d)
     else:
         r_value = np.inf
 
-    p = p * theta
-    p_h_t = p_h * theta
+    p = V.mul(p, s=theta)
+    p_h_t = V.mul(p_h, s=theta)
     p_value = 0.5 * theta * theta * (G[0, 0] + ph_d_ph) + theta * g_ph
 
-    ag = d * ag_h
+    ag = V.mul(d, ag_h)
     to_tr = Delta / np.sqrt(ag_ag)
-    to_bound, _ = _step_size_to_bound_dev(x, ag, lb, ub)
+    to_bound, _ = V.step_size_to_bound(x, ag, lb, ub)
     ag_stride = theta * to_bound if to_bound < to_tr else to_tr
     qa = 0.5 * (G[2, 2] + ag_d_ag)
     ag_stride, ag_value = minimize_quadratic_1d(qa, g_ag, 0, ag_stride)
-    ag_h = ag_h * ag_stride
-    ag = ag * ag_stride
+    ag_h = V.mul(ag_h, s=ag_stride)
+    ag = V.mul(ag, s=ag_stride)
 
     if p_value < r_value and p_value < ag_value:
         return p, p_h_t, -p_value
@@ -1019,7 +1089,8 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
                 callback=None, lsmr_opts=None):
     """scipy/optimize/_lsq/trf.py trf_bounds, n-vectors on the device in the internal order:
     x, g, the Coleman-Li vectors, the scaled Gauss-Newton step and the candidate steps never
-    cross PCIe; per outer iteration the host sees a few dozen scalars."""
+    cross PCIe and are only touched by libiamx kernels (VecOps); per outer iteration the host
+    sees a few dozen scalars."""
     from scipy.optimize import OptimizeResult
     from scipy.optimize._lsq.common import (check_termination, make_strictly_feasible,
                                             minimize_quadratic_1d, print_header_nonlinear,
@@ -1028,24 +1099,23 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     lsmr_opts = dict(lsmr_opts or {})
     lsmr_opts['to_host'] = False
     n = prob.n
-    vnorm = torch.linalg.vector_norm
+    V = prob.vec_ops()
     x_host = make_strictly_feasible(np.asarray(x0, np.float64).copy(), lb, ub)
     lb_d = prob.upload_n(np.broadcast_to(np.asarray(lb, np.float64), (n,)))[:n].clone()
     ub_d = prob.upload_n(np.broadcast_to(np.asarray(ub, np.float64), (n,)))[:n].clone()
-    fin_lb, fin_ub = torch.isfinite(lb_d), torch.isfinite(ub_d)
     x = prob.upload_n(x_host)[:n].clone()
     prob.set_x_dev(x)
     prob.residual_jac()
     nfev = njev = 1
     cost = prob.cost_of_r(prob.r)
     g = prob.grad_dev()
-    scale_inv = prob.colnorm_dev().clone()
-    scale_inv = torch.where(scale_inv == 0, torch.ones_like(scale_inv), scale_inv)
-    scale = 1 / scale_inv
+    scale_inv = V.jac_scale(prob.colsq_dev(), torch.empty(n, dtype=F64, device=prob.dev), first=True)
 
-    v, dv = _cl_scaling_dev(x, g, lb_d, ub_d, fin_lb, fin_ub)
-    v = torch.where(dv != 0, v * scale_inv, v)
-    Delta = float(vnorm(x * scale_inv / v ** 0.5))
+    v, dv = V.cl_scaling(x, g, lb_d, ub_d)
+    # Delta = norm(x0 * scale_inv / v**0.5) with v[dv != 0] *= scale_inv (one-off: on the host)
+    v_h, dv_h, si_h = prob.download_n(v), prob.download_n(dv), prob.download_n(scale_inv)
+    v_h[dv_h != 0] *= si_h[dv_h != 0]
+    Delta = float(np.linalg.norm(prob.download_n(x) * si_h / v_h ** 0.5))
     if Delta == 0:
         Delta = 1.0
     if max_nfev is None:
@@ -1059,8 +1129,8 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
         print_header_nonlinear()
 
     while True:
-        v, dv = _cl_scaling_dev(x, g, lb_d, ub_d, fin_lb, fin_ub)
-        g_norm = float((g * v).abs().max())
+        v, dv = V.cl_scaling(x, g, lb_d, ub_d)
+        g_norm = V.absmax(g, v)
         if g_norm < gtol:
             termination_status = 1
         if verbose == 2 and prob.rank == 0:
@@ -1069,33 +1139,31 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             break
 
         with _Phase(prob, 'scaling+reg'):
-            v = torch.where(dv != 0, v * scale_inv, v)
-            d = v ** 0.5 * scale
-            diag_h = g * dv * scale
-            g_h = d * g
+            d, diag_h, g_h = V.trf_scale(v, dv, g, scale_inv)
             # regularisation term (trf.py: build_quadratic_1d along -g_h)
             G = prob.gram_dev(d, [g_h])
-            gdg, gg = _dots((g_h * diag_h, g_h), (g_h, g_h))
+            gdg, gg = V.dots((g_h, diag_h, g_h), (g_h, g_h))
             a = 0.5 * (G[0, 0] + gdg)
             to_tr = Delta / np.sqrt(gg)
             ag_value = minimize_quadratic_1d(a, -gg, 0, to_tr)[1]
             reg_term = -ag_value / Delta ** 2
 
         with _Phase(prob, 'lsmr'):
-            dreg = (diag_h + reg_term) ** 0.5
+            dreg = V.sqrt_shift(diag_h, reg_term)
             gn_h, _istop, itn, _nr, _nar = lsmr(prob, d, dreg, **lsmr_opts)
+            gn_h = gn_h[:n]
             lsmr_iters += itn
         with _Phase(prob, 'subspace'):
             # orthonormal basis of span{g_h, gn_h} (SciPy: economic QR; the step S p_S does not
             # depend on which orthonormal basis is used): Gram-Schmidt with re-orthogonalisation
-            s0 = g_h / np.sqrt(gg)
-            w = gn_h - torch.dot(s0, gn_h) * s0
-            w = w - torch.dot(s0, w) * s0
-            wn = float(vnorm(w))
-            s1 = w / wn if wn > 0 else torch.zeros_like(w)
+            s0 = V.mul(g_h, s=1.0 / np.sqrt(gg))
+            w = V.lincomb(1.0, gn_h, -V.dots((s0, gn_h))[0], s0)
+            w = V.lincomb(1.0, w, -V.dots((s0, w))[0], s0)
+            wn = float(np.sqrt(V.dots((w, w))[0]))
+            s1 = V.mul(w, s=1.0 / wn) if wn > 0 else V.new(w).zero_()
             GS = prob.gram_dev(d, [s0, s1])
-            e00, e01, e11, gs0, gs1 = _dots((s0 * diag_h, s0), (s0 * diag_h, s1), (s1 * diag_h, s1),
-                                            (s0, g_h), (s1, g_h))
+            e00, e01, e11, gs0, gs1 = V.dots((s0, diag_h, s0), (s0, diag_h, s1), (s1, diag_h, s1),
+                                             (s0, g_h), (s1, g_h))
             B_S = GS + np.array([[e00, e01], [e01, e11]])
             g_S = np.array([gs0, gs1])
 
@@ -1104,16 +1172,16 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
         while actual_reduction <= 0 and nfev < max_nfev:
             with _Phase(prob, 'select_step'):
                 p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
-                p_h = float(p_S[0]) * s0 + float(p_S[1]) * s1
-                p = d * p_h
+                p_h = V.lincomb(float(p_S[0]), s0, float(p_S[1]), s1)
+                p = V.mul(d, p_h)
                 step, step_h, predicted_reduction = _select_step_dev(
-                    prob, x, d, diag_h, g_h, p, p_h, Delta, lb_d, ub_d, theta)
+                    prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb_d, ub_d, theta)
             with _Phase(prob, 'fun'):
-                x_new = _strictly_feasible_dev(x + step, lb_d, ub_d, fin_lb, fin_ub)
+                x_new = V.strictly_feasible(x, lb_d, ub_d, step)
                 prob.set_x_dev(x_new)
                 prob.residual(out=r_new)
                 nfev += 1
-                step_h_norm = float(vnorm(step_h))
+                step_h_norm = float(np.sqrt(V.dots((step_h, step_h))[0]))
                 cost_new = prob.cost_of_r(r_new)
             if not np.isfinite(cost_new):
                 Delta = 0.25 * step_h_norm
@@ -1121,7 +1189,7 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             actual_reduction = cost - cost_new
             Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
                                                 step_h_norm, step_h_norm > 0.95 * Delta)
-            step_norm, x_norm = torch.stack([vnorm(step), vnorm(x)]).tolist()
+            step_norm, x_norm = np.sqrt(V.dots((step, step), (x, x))).tolist()
             termination_status = check_termination(actual_reduction, cost, step_norm, x_norm,
                                                    ratio, ftol, xtol)
             if termination_status is not None:
@@ -1135,8 +1203,7 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
                 prob.residual_jac()               #  trial was the last one evaluated)
                 njev += 1
                 g = prob.grad_dev()
-                scale_inv = torch.maximum(scale_inv, prob.colnorm_dev())   # compute_jac_scale
-                scale = 1 / scale_inv
+                V.jac_scale(prob.colsq_dev(), scale_inv, first=False)       # compute_jac_scale
             if callback is not None:
                 callback(prob.download_n(x), cost)
         else:
@@ -1148,7 +1215,7 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
 
     if termination_status is None:
         termination_status = 0
-    active = _active_constraints_dev(x, lb_d, ub_d, fin_lb, fin_ub, xtol)
+    active = V.active_constraints(x, lb_d, ub_d, xtol)
     return OptimizeResult(x=prob.download_n(x), cost=cost, grad=prob.download_n(g),
                           optimality=g_norm,
                           active_mask=prob.download_n(active).astype(int), nfev=nfev, njev=njev,

@@ -13,13 +13,16 @@ if [ -n "$IAMX_ABLATE" ]; then
     OBJDIR="$HERE/obj_ablate"
     FLAGS="$FLAGS -DIAMX_ABLATE"
 fi
-SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_knn2sym.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/comm.hip $HERE/sift.hip $HERE/image_prep.hip"
+SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_knn2sym.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/trf_vec.hip $HERE/comm.hip $HERE/sift.hip $HERE/image_prep.hip"
 mkdir -p "$OBJDIR"
 OBJS=""
 for f in $SRCS; do
     o="$OBJDIR/$(basename ${f%.hip}).o"
     if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/iamx_common.h" -nt "$o" ] || [ "$HERE/../../include/iamx.h" -nt "$o" ]; then
-        $HIPCC $FLAGS ${IAMX_EXTRA_FLAGS} -c "$f" -o "$o" &
+        EXTRA=""
+        # the TRF helpers restate numpy expressions: separately rounded multiply and add
+        [ "$(basename $f)" = "trf_vec.hip" ] && EXTRA="-ffp-contract=off"
+        $HIPCC $FLAGS $EXTRA ${IAMX_EXTRA_FLAGS} -c "$f" -o "$o" &
     fi
     OBJS="$OBJS $o"
 done

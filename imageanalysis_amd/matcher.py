@@ -569,8 +569,7 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                                       _ptr(post['pairs']), _ptr(post['scratch']), _ptr(post['stat']),
                                       _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
         if surface:
-            post['tri_cnt'] = torch.where(post['status'] == 0, post['cnt'],
-                                          torch.zeros_like(post['cnt']))
+            post['tri_cnt'] = post['cnt']           # (0 for the pairs left to the host filters)
             post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
             check(L.iamx_triangulate_pairs(_ptr(pb.d_pairs), _ptr(d_proj), _ptr(d_ik), _ptr(kp_off),
                                            _ptr(xy), _ptr(post['tri_cnt']), _ptr(post['pairs']), n,

@@ -517,6 +517,50 @@ int iamx_vec_dot(int64_t n, const double *x, const double *y, double *out, doubl
 int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *x, const double *v,
                          double c_hbar, double c_x, double c_h, void *stream);
 
+/* n-vector kernels of the trust-region-reflective outer loop (csrc/trf_vec.hip), float64, all
+ * pointers DEV unless noted.  They restate the O(n) helpers of scipy.optimize.least_squares
+ * (method='trf'), which the reference calls at scripts/lib/optimizer.py:352-399:
+ *   lincomb: out = a*x + b*y + c*z (y, z may be NULL);  mul: out = s*x.*y (y NULL: s*x)
+ *   sqrt_shift: out = sqrt(x + shift)
+ *   dots: out[i] = sum a[i].*b[i] (.*w[i] when w and w[i] are not NULL), 1 <= k <= 8; a, b, w are
+ *         HOST arrays of k device pointers; scratch: DEV [iamx_vec_scratch_doubles()] float64
+ *   absmax_prod: out[0] = max |x.*y| (y NULL: max |x|), NaN if any product is
+ *   trf_cl_scaling:  _lsq/common.py CL_scaling_vector -> v, dv
+ *   trf_scale:       trf.py trf_bounds: v[dv != 0] *= scale_inv; d = sqrt(v)/scale_inv;
+ *                    diag_h = g.*dv./scale_inv; g_h = d.*g   (v_out may be NULL)
+ *   trf_jac_scale:   common.py compute_jac_scale from the column sums of J.^2
+ *   trf_step_to_bound: common.py step_size_to_bound -> out[0] = min step
+ *   trf_reflect:     its `hits` (equal(steps, min_step) * sign(s)) and r_h = p_h with the hit
+ *                    components negated (either output may be NULL)
+ *   trf_count_outside: out[0] = number of components of x (+ p) outside [lb, ub] (in_bounds)
+ *   trf_strictly_feasible: common.py make_strictly_feasible(x (+ step), lb, ub, rstep=0)
+ *   trf_active:      common.py find_active_constraints(x, lb, ub, rtol > 0) as -1 / 0 / +1 */
+int iamx_vec_lincomb(int64_t n, double a, const double *x, double b, const double *y, double c,
+                     const double *z, double *out, void *stream);
+int iamx_vec_mul(int64_t n, double s, const double *x, const double *y, double *out, void *stream);
+int iamx_vec_sqrt_shift(int64_t n, const double *x, double shift, double *out, void *stream);
+int iamx_vec_scratch_doubles(void);
+int iamx_vec_dots(int64_t n, int k, const double *const *a, const double *const *b,
+                  const double *const *w, double *out, double *scratch, void *stream);
+int iamx_vec_absmax_prod(int64_t n, const double *x, const double *y, double *out, double *scratch,
+                         void *stream);
+int iamx_trf_cl_scaling(int64_t n, const double *x, const double *g, const double *lb,
+                        const double *ub, double *v, double *dv, void *stream);
+int iamx_trf_scale(int64_t n, const double *v, const double *dv, const double *g,
+                   const double *scale_inv, double *v_out, double *d, double *diag_h, double *g_h,
+                   void *stream);
+int iamx_trf_jac_scale(int64_t n, const double *colsq, double *scale_inv, int first, void *stream);
+int iamx_trf_step_to_bound(int64_t n, const double *x, const double *s, const double *lb,
+                           const double *ub, double *out, double *scratch, void *stream);
+int iamx_trf_reflect(int64_t n, const double *x, const double *s, const double *lb, const double *ub,
+                     double min_step, const double *p_h, double *r_h, double *hits, void *stream);
+int iamx_trf_count_outside(int64_t n, const double *x, const double *p, const double *lb,
+                           const double *ub, double *out, double *scratch, void *stream);
+int iamx_trf_strictly_feasible(int64_t n, const double *x, const double *step, const double *lb,
+                               const double *ub, double *out, void *stream);
+int iamx_trf_active(int64_t n, const double *x, const double *lb, const double *ub, double rtol,
+                    double *active, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
