@@ -255,3 +255,64 @@ def test_one_direction_fast_forms_at_their_sizes(sizes, rows):
             assert np.array_equal(a['sq'][lo:hi], keep) and np.array_equal(a['st'][lo:hi], tr)
             assert np.array_equal(a['sm'][lo:hi], mt)
             assert np.array_equal(a['d2'][a['off'][p] + keep], d2)
+
+
+def test_config2_arena_pairs_at_both_ends_of_the_store():
+    """BASELINE configs[2] store: 2812 images x 4096 descriptors resident in HBM (1.5 GB per
+    layout, row offsets up to 11.5 M).  The shipped symmetric form on image pairs that touch the
+    first, the middle and the last images of the arena, both directions: bit-equal to
+    oracle/cpu_ref.c on 12 ordered pairs; planted overlaps (image j repeats 30 % of image j-1 with
+    +-6 noise) show up as hundreds of survivors, unrelated pairs as a handful."""
+    import torch
+    from imageanalysis_amd import kernels
+    dev = kernels.require_gpu()
+    n_img, kpts = 2812, 4096
+    store = kernels.DescriptorStore([kpts] * n_img)
+    alpha = torch.full((kpts, 128), 0.6, device=dev)
+    named = [(0, 1), (1, 2811), (2810, 2811), (1405, 1406), (0, 2811), (7, 1406)]
+    keep_ids = sorted({i for p in named for i in p})
+    kept, prev, pending = {}, None, []
+    for j in range(n_img):
+        g = torch.Generator(device=dev)
+        g.manual_seed(5000 + j)
+        x = torch._standard_gamma(alpha, generator=g)
+        x = x / x.norm(dim=1, keepdim=True)
+        x = x.clamp(max=0.2)
+        x = x / x.norm(dim=1, keepdim=True)
+        cur = (x * 512.0).round().clamp(0, 255)
+        base = cur.clone()
+        if prev is not None:
+            k = int(0.3 * kpts)
+            src = torch.randperm(kpts, generator=g, device=dev)[:k]
+            dst = torch.randperm(kpts, generator=g, device=dev)[:k]
+            cur[dst] = (prev[src] + torch.randint(-6, 7, (k, 128), generator=g, device=dev)).clamp(0, 255)
+        prev = base
+        u8 = cur.to(torch.uint8)
+        if j in keep_ids:
+            kept[j] = u8.cpu().numpy()
+        pending.append(store.set_image(j, u8, sync=False))
+        if len(pending) >= 64:
+            torch.cuda.synchronize()
+            pending = []
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(11)
+    und = list(named)
+    while len(und) < 1500:
+        a, b = (int(v) for v in rng.integers(0, n_img, 2))
+        if a != b and (a, b) not in und and (b, a) not in und:
+            und.append((min(a, b), max(a, b)))
+    ordered = np.array(und + [(b, a) for a, b in und], np.int32)
+    thresh = 270.0 * 0.75
+    res = _run(store, ordered, thresh, sym=True)
+    assert res['pb'].sym and res['pb'].sym_form == 2 and res['unresolved'] == 0
+    count = np.diff(res['soff'])
+    for p, (a, b) in enumerate(ordered):
+        if (int(a), int(b)) in named or (int(b), int(a)) in named:
+            keep, tidx, metric, rd2, _z = _oracle_survivors(kept[int(a)], kept[int(b)], thresh)
+            lo, hi = res['soff'][p], res['soff'][p + 1]
+            assert np.array_equal(res['sq'][lo:hi], keep), (a, b)
+            assert np.array_equal(res['st'][lo:hi], tidx) and np.array_equal(res['sm'][lo:hi], metric), (a, b)
+            assert np.array_equal(res['d2'][res['off'][p] + keep], rd2), (a, b)
+    adjacent = np.abs(ordered[:, 0] - ordered[:, 1]) == 1
+    assert adjacent.sum() >= 6 and count[adjacent].min() > 300          # the planted 30 %
+    assert count[~adjacent].max() < 60
