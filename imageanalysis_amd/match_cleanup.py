@@ -154,9 +154,10 @@ def make_match_structure(proj):
             p = _pairs(matches)
             blocks.append(np.stack([np.full(len(p), i), p[:, 0], np.full(len(p), j), p[:, 1]], 1))
     flat = np.concatenate(blocks) if blocks else np.zeros((0, 4), np.int64)
-    with _no_gc():
-        matches_direct = [[None, -1, [i, a], [j, b]] for i, a, j, b in flat.tolist()]
-    # link_matches() normally receives this very list: keep the array form beside it
+    # the reference's [[None, -1, [i, a], [j, b]], ...] (match_cleanup.py:190-215), as a list
+    # that is only built when somebody other than link_matches() looks into it
+    matches_direct = DirectMatches(flat)
+    # link_matches() normally receives this very object: the array form goes with it
     n = len(flat)
     proj._iamx_direct = (matches_direct, n,
                          np.ascontiguousarray(flat[:, [0, 2]].ravel(), np.int32),
@@ -166,6 +167,43 @@ def make_match_structure(proj):
         _log("Total feature pairs in image set:", n)
         _log("Keypoint average instances = %.1f (should be 2.0 here)" % 2.0)
     return matches_direct
+
+
+class DirectMatches(object):
+    """make_match_structure()'s result: a sequence of [None, -1, [i, a], [j, b]] lists -- one
+    python list of four objects per pair match, millions on a survey -- backed by the [n, 4]
+    array it was computed as.  The lists are created (all of them, once) when an element is
+    asked for; len() and link_matches() do not need them."""
+
+    def __init__(self, flat):
+        self._flat = flat
+        self._rows = None
+
+    def rows(self):
+        if self._rows is None:
+            with _no_gc():
+                self._rows = [[None, -1, [i, a], [j, b]] for i, a, j, b in self._flat.tolist()]
+        return self._rows
+
+    def __len__(self):
+        return len(self._flat) if self._rows is None else len(self._rows)
+
+    def __getitem__(self, k):
+        return self.rows()[k]
+
+    def __iter__(self):
+        return iter(self.rows())
+
+    def __eq__(self, other):
+        return self.rows() == (other.rows() if isinstance(other, DirectMatches) else other)
+
+    __hash__ = None
+
+    def __reduce_ex__(self, protocol):
+        return (list, (self.rows(),))
+
+    def untouched(self):
+        return self._rows is None
 
 
 def _flatten(matches):
@@ -185,7 +223,8 @@ def link_matches(proj, matches_direct):
     _log("Linking common matches together into chains:")
     n = len(matches_direct)
     cached = getattr(proj, '_iamx_direct', None)
-    if cached is not None and cached[0] is matches_direct and cached[1] == n:
+    if cached is not None and cached[0] is matches_direct and cached[1] == n \
+            and matches_direct.untouched():
         img, kp, ptr = cached[2:]                 # untouched output of make_match_structure()
     else:
         img, kp, ptr = _flatten(matches_direct)
