@@ -506,6 +506,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                     v16i acc0, acc1;
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) acc0[reg] = acc1[reg] = cl[reg];
+                    if constexpr (VARIANT & 128) {      // (experiment: MFMA bursts at raised priority)
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(3);
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         if constexpr (VARIANT & 8) {
@@ -515,6 +519,10 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qp][s], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[qp + 1][s], acc1, 0, 0, 0);
                         }
+                    }
+                    if constexpr (VARIANT & 128) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_setprio(0);
                     }
                     if constexpr (VARIANT & 1) {
                         asm volatile("" ::"v"(acc0), "v"(acc1));
@@ -1025,6 +1033,7 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 320: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 128, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 400: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 401: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 32, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 402: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 32 + 16, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
