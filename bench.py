@@ -908,7 +908,7 @@ def ba_bench(rank, world, dev, dist, args):
                          # tools/hbm_copy_bw.py), so this is a cache-level, not an HBM, fraction
                          "working_set": "Infinity-Cache resident (125 MB per evaluation)",
                          "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
-                                   "kernel: profiles/, ~20 % longer per launch)"},
+                                   "kernel, ba_residual_lds_kernel: profiles/r2_kernel_stats.txt)"},
             "residual_jac": {"bound": "hbm",
                              "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
                              "peak": HBM, "unit": "GB/s",

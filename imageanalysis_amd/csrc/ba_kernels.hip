@@ -103,9 +103,9 @@ __device__ __forceinline__ double2 residual_rt(const double *__restrict__ R,
     return make_double2(obs.x - (cal[0] * xd + cal[2]), obs.y - (cal[1] * yd + cal[3]));
 }
 
-// One launch: every workgroup (512 observations) first builds the camera blocks of the camera
-// range it touches in LDS (camera-major observations: 1-2 cameras), then evaluates from LDS.
-// A workgroup that spans more than RES_MAXCAM cameras (any observation order is legal) builds
+// One launch: every WAVE (128 observations) first builds the camera blocks of the camera range
+// it touches in its slice of LDS (camera-major observations: 1-2 cameras), then evaluates from
+// LDS.  A wave that spans more than RES_MAXCAM cameras (any observation order is legal) builds
 // the block per observation in registers instead.
 constexpr int RES_MAXCAM = 16;
 
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
     const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
     double *__restrict__ r)
 {
-    __shared__ double Rs[RES_MAXCAM][12];
-    __shared__ int range[2];
+    __shared__ double Rs_all[4][RES_MAXCAM][12];        // one set of camera blocks per WAVE
+    double (*Rs)[12] = Rs_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
     const bool two = o + 1 < n_obs, one = o < n_obs;
     int2 ci = make_int2(0, 0), pi = make_int2(0, 0);
@@ -150,14 +151,14 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
         lo = min(lo, __shfl_xor(lo, m));
         hi = max(hi, __shfl_xor(hi, m));
     }
-    if (threadIdx.x == 0) { range[0] = 0x7FFFFFFF; range[1] = -1; }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { atomicMin(&range[0], lo); atomicMax(&range[1], hi); }
-    __syncthreads();
-    const int c_lo = range[0], ncam = range[1] - c_lo + 1;
+    // (per wave, wave-synchronous: no workgroup barrier anywhere in this kernel; a wave whose
+    //  128 observations are all past the end has hi = -1 and builds nothing)
+    const int c_lo = lo, ncam = hi - lo + 1;
     const bool in_lds = ncam <= RES_MAXCAM;
-    if (in_lds && (int)threadIdx.x < ncam) cam_block(cams + (int64_t)(c_lo + threadIdx.x) * 7, Rs[threadIdx.x]);
-    __syncthreads();
+    if (in_lds && lane < ncam) cam_block(cams + (int64_t)(c_lo + lane) * 7, Rs[lane]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!one) return;
     double cal[9];
 #pragma unroll
