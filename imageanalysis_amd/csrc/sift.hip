@@ -183,6 +183,97 @@ void blur_v(hipStream_t st, const float *src, int h, int w, const Taps &tp, floa
     }
 }
 
+// Both passes in ONE launch for the big octaves (the two-pass form above moves 7.5 floats per
+// pixel and level through memory -- tmp written and re-read 1 + 2R/8 times, prev re-read for the
+// DoG --, this one 3: source in, level and DoG out).  A workgroup owns a FB_TW x FB_TH tile:
+//   1. the source tile with its R-pixel frame goes to LDS (reflect-101 at the image borders, in
+//      x and in y: a frame row outside the image IS the row the vertical pass of the two-pass
+//      form would have read),
+//   2. horizontal pass over all FB_TH + 2R rows into a second LDS tile: a thread takes strips of
+//      8 consecutive outputs with the 8 + 2R inputs in registers,
+//   3. vertical pass: a thread owns one column and 8 rows, window in registers as in
+//      blur_v_kernel; writes the level and, fused, DoG = level - source.
+// Same taps, same ascending order, separately rounded multiply and add => bit-identical levels.
+constexpr int FB_TW = 64, FB_TH = 32, FB_STRIP = 8;
+
+template <int R>
+__global__ __launch_bounds__(256) void blur_fused_kernel(const float *__restrict__ src, int h, int w,
+                                                         Taps T, float *__restrict__ dst,
+                                                         float *__restrict__ dog)
+{
+    constexpr int SW = FB_TW + 2 * R + 1;                 // (+1: odd row pitch)
+    constexpr int SH = FB_TH + 2 * R;
+    constexpr int HW = FB_TW + 1;
+    __shared__ float S[SH * SW];
+    __shared__ float Hb[SH * HW];
+    const int x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * FB_TH;
+    // 1. source tile + frame
+    for (int e = threadIdx.x; e < SH * (FB_TW + 2 * R); e += 256) {
+        const int ry = e / (FB_TW + 2 * R), rx = e - ry * (FB_TW + 2 * R);
+        int yy = y0 - R + ry, xx = x0 - R + rx;
+        yy = (yy >= 0 && yy < h) ? yy : reflect101(yy, h);
+        xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
+        S[ry * SW + rx] = src[(int64_t)yy * w + xx];
+    }
+    __syncthreads();
+    // 2. horizontal pass: strips of FB_STRIP outputs
+    constexpr int STRIPS_PER_ROW = FB_TW / FB_STRIP;
+    for (int sidx = threadIdx.x; sidx < SH * STRIPS_PER_ROW; sidx += 256) {
+        const int ry = sidx / STRIPS_PER_ROW, sx = (sidx - ry * STRIPS_PER_ROW) * FB_STRIP;
+        float win[FB_STRIP + 2 * R];
+#pragma unroll
+        for (int i = 0; i < FB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
+#pragma unroll
+        for (int j = 0; j < FB_STRIP; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
+            Hb[ry * HW + sx + j] = acc;
+        }
+    }
+    __syncthreads();
+    // 3. vertical pass: column cx, rows [8 g, 8 g + 8) of the tile
+    const int cx = threadIdx.x & (FB_TW - 1), g = threadIdx.x / FB_TW;
+    const int x = x0 + cx;
+    if (x >= w) return;
+    float win[FB_STRIP + 2 * R];
+#pragma unroll
+    for (int i = 0; i < FB_STRIP + 2 * R; ++i) win[i] = Hb[(g * FB_STRIP + i) * HW + cx];
+#pragma unroll
+    for (int j = 0; j < FB_STRIP; ++j) {
+        const int y = y0 + g * FB_STRIP + j;
+        if (y < h) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
+            const int64_t i = (int64_t)y * w + x;
+            dst[i] = acc;
+            if (dog) dog[i] = sub_rn(acc, S[(g * FB_STRIP + j + R) * SW + cx + R]);
+        }
+    }
+}
+
+template <int R>
+void launch_blur_fused(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
+                       float *dog)
+{
+    static_assert(256 / FB_TW * FB_STRIP == FB_TH, "the vertical pass covers the tile");
+    hipLaunchKernelGGL(blur_fused_kernel<R>, dim3((w + FB_TW - 1) / FB_TW, (h + FB_TH - 1) / FB_TH),
+                       dim3(256), 0, st, src, h, w, tp, dst, dog);
+}
+
+// false: this radius has no fused instantiation (the caller runs the two passes)
+bool blur_fused(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst, float *dog)
+{
+    switch (tp.r) {
+#define IAMX_BF(r) case r: launch_blur_fused<r>(st, src, h, w, tp, dst, dog); return true;
+        IAMX_BF(1) IAMX_BF(2) IAMX_BF(3) IAMX_BF(4) IAMX_BF(5) IAMX_BF(6) IAMX_BF(7) IAMX_BF(8)
+        IAMX_BF(9) IAMX_BF(10) IAMX_BF(11) IAMX_BF(12) IAMX_BF(13) IAMX_BF(14) IAMX_BF(15) IAMX_BF(16)
+#undef IAMX_BF
+    default: return false;
+    }
+}
+
 __global__ __launch_bounds__(256) void downsample_kernel(const float *__restrict__ src, int sw,
                                                          int dh, int dw, float *__restrict__ dst)
 {
@@ -1079,6 +1170,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     auto blur = [&](const float *src, float *dst, int h, int w, double s, float *dog) {
         Taps tp;
         gaussian_taps(s, tp);
+        if (blur_fused(st, src, h, w, tp, dst, dog)) return;
         hipLaunchKernelGGL(blur_h_kernel, dim3((w + BLUR_TW - 1) / BLUR_TW, h), dim3(256), 0, st, src,
                            h, w, tp, tmp);
         blur_v(st, tmp, h, w, tp, dst, src, dog);
