@@ -27,6 +27,7 @@
 // Pyramid traffic: 6 Gaussian + 5 DoG f32 levels per octave written once, read once
 // (~469 B per detect-resolution pixel).
 #include "iamx_common.h"
+#include <mutex>
 
 namespace {
 
@@ -1127,6 +1128,37 @@ extern "C" int64_t iamx_sift_workspace_bytes(int height, int width)
     return make_layout(height, width, CAP_CAND).total;
 }
 
+// second stream + fork / join events of iamx_sift_detect, one set per device, created on first
+// use and kept for the life of the process (nullptr if the runtime refuses: single-stream order)
+namespace {
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+
+SideStream *side_stream()
+{
+    static SideStream slots[64];
+    static bool ready[64], failed[64];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (failed[dev]) return nullptr;
+    if (!ready[dev]) {
+        SideStream &S = slots[dev];
+        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess) {
+            failed[dev] = true;
+            return nullptr;
+        }
+        ready[dev] = true;
+    }
+    return &slots[dev];
+}
+}  // namespace
+
 extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
                                 float contrast_threshold, float edge_threshold, float sigma,
                                 void *workspace, int64_t workspace_bytes, float *kp, uint8_t *desc,
@@ -1188,32 +1220,48 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     // octaves from o_tail on (small images) are built by one workgroup in one launch
     int o_tail = L.n_oct;
     for (int o = L.n_oct - 1; o >= 1 && (int64_t)L.h[o] * L.w[o] <= TAIL_PIXELS; --o) o_tail = o;
-    for (int o = 0; o < L.n_oct; ++o) {
+    auto extrema = [&](int o) {
         const int H = L.h[o], W = L.w[o];
-        const int64_t npx = (int64_t)H * W;
-        if (o == o_tail) {
-            TapSet TS;
-            for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], TS.t[i - 1]);
-            hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, st, T, o_tail, TS);
-        }
-        if (o < o_tail) {
-            if (o > 0)
-                hipLaunchKernelGGL(downsample_kernel, dim3(blocks(npx, 256)), dim3(256), 0, st,
-                                   T.oct[o - 1].g[NL], L.w[o - 1], H, W, T.oct[o].g[0]);
-            for (int i = 1; i < NL + 3; ++i)
-                blur(T.oct[o].g[i - 1], T.oct[o].g[i], H, W, sig[i], T.oct[o].d[i - 1]);
-        }
         if (H > 2 * BORDER && W > 2 * BORDER) {
-            const int64_t inner = (int64_t)(H - 2 * BORDER) * (W - 2 * BORDER);
             DogStack D;
             for (int i = 0; i < NL + 2; ++i) D.d[i] = T.oct[o].d[i];
-            (void)inner;
             hipLaunchKernelGGL(extrema_kernel,
                                dim3((unsigned)((W - 2 * BORDER + 61) / 62),
                                     (unsigned)((H - 2 * BORDER + 4 * EXT_RPT - 1) / (4 * EXT_RPT))),
                                dim3(256), 0, st, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
         }
+    };
+    // Issue order: the chain that leads to the small octaves first -- levels 1..NL of every big
+    // octave (level NL is the next octave's source) --, then the one-workgroup tail kernel on a
+    // second stream, and beside it the remaining two levels and the extrema scans of the big
+    // octaves on the caller's stream (the tail is a 0.5 ms latency chain on one CU).
+    for (int o = 0; o < o_tail; ++o) {
+        if (o > 0)
+            hipLaunchKernelGGL(downsample_kernel, dim3(blocks((int64_t)L.h[o] * L.w[o], 256)), dim3(256), 0, st,
+                               T.oct[o - 1].g[NL], L.w[o - 1], L.h[o], L.w[o], T.oct[o].g[0]);
+        for (int i = 1; i <= NL; ++i)
+            blur(T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], sig[i], T.oct[o].d[i - 1]);
     }
+    SideStream *side = nullptr;
+    if (o_tail < L.n_oct) {
+        TapSet TS;
+        for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], TS.t[i - 1]);
+        side = side_stream();
+        hipStream_t ts = side ? side->stream : st;
+        if (side) {
+            (void)hipEventRecord(side->fork, st);
+            (void)hipStreamWaitEvent(ts, side->fork, 0);
+        }
+        hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, ts, T, o_tail, TS);
+        if (side) (void)hipEventRecord(side->join, ts);
+    }
+    for (int o = 0; o < o_tail; ++o) {
+        for (int i = NL + 1; i < NL + 3; ++i)
+            blur(T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], sig[i], T.oct[o].d[i - 1]);
+        extrema(o);
+    }
+    if (side) (void)hipStreamWaitEvent(st, side->join, 0);
+    for (int o = o_tail; o < L.n_oct; ++o) extrema(o);
     // the number of candidates is only known on the device: launch for the capacity in slabs
     // sized by the largest plausible count (threads beyond *n_cand exit immediately)
     hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,
