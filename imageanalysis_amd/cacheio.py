@@ -69,10 +69,10 @@ def gzip_members(raw, level=GZIP_LEVEL):
     return b''.join(gzip_member_list(raw, level))
 
 
-def _write_job(path, payload, on_error=None):
+def _write_job(path, payload, on_error=None, level=GZIP_LEVEL):
     try:
         raw = payload() if callable(payload) else payload
-        members = gzip_member_list(raw)
+        members = gzip_member_list(raw, level)
         # pid + thread id: two ranks may write the same boundary image's cache at the same time
         tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
@@ -113,15 +113,16 @@ def write_raw(path, payload, background=True, on_error=None):
     return fut
 
 
-def write_gzip(path, payload, background=True, on_error=None):
+def write_gzip(path, payload, background=True, on_error=None, level=GZIP_LEVEL):
     """payload: bytes or a callable returning bytes (run on the job thread, e.g. np.save into a
-    buffer).  Errors go to `on_error(exc)` if given, else surface in wait()."""
+    buffer).  Errors go to `on_error(exc)` if given, else surface in wait().  `level`: zlib level
+    of the members (any level reads back the same bytes)."""
     if not background:
-        _write_job(path, payload, on_error)
+        _write_job(path, payload, on_error, level)
         return None
     jobs, _w = _pools()
     wait(path)                                                # keep two writes of a path ordered
-    fut = jobs.submit(_write_job, path, payload, on_error)
+    fut = jobs.submit(_write_job, path, payload, on_error, level)
     with _lock:
         _pending[path] = fut
     return fut

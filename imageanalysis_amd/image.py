@@ -86,6 +86,10 @@ def make_keypoints(x, y, size, angle, response, octave, class_id=None):
 ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
 USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
 WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
+# zlib level of the float32 .desc (the reference passes compresslevel=6, image.py:213; every level
+# decompresses to the same bytes).  On integer-valued float32 descriptors level 6 runs at 9 MB/s
+# per core for a 0.32 ratio, level 1 at 50 MB/s for 0.38: the file is what a fresh detection costs
+DESC_GZIP_LEVEL = 1
 # decoded / cache-loaded images held ahead of the detector (one worker thread each; a 20 MP JPEG
 # takes ~0.2 s of one core to decode against ~6 ms on the GPU, 60 MB per decoded frame)
 PREFETCH_DEPTH = min(24, max(6, (os.cpu_count() or 8) // 4))
@@ -207,7 +211,8 @@ def save_descriptors(self):
     des = self.des_list                    # the array as it is now (a later flush drops only the name)
     if WRITE_REFERENCE_DESC:
         cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
-                           on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)))
+                           on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)),
+                           level=DESC_GZIP_LEVEL)
     if USE_DESC_SIDECAR and des is not None and len(des):
         u8 = np.asarray(des)
         known = getattr(self, '_iamx_des_u8', None)       # (float32 array, its uint8 original)
