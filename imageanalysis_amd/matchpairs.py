@@ -4,8 +4,8 @@ The reference keeps `image.match_list[other_name]` as a python list of `[i, j]` 
 (scripts/lib/matcher.py:978-979; pickled as they are by image.py:261-268) -- tens of millions of
 two-element lists on a dense survey.  `MatchPairs` holds the same pairs as ONE int32 [n, 2]
 array (what the device hands back) and behaves like that list for every reader: len(),
-indexing (an item is a fresh `[i, j]` list), iteration, slicing, comparison with lists,
-in-place edits (the first edit turns it into a real list), `np.asarray()` without a copy.  It
+indexing, iteration, slicing, comparison with lists, in-place edits (the first element access
+turns it into the real list of lists, once), `np.asarray()` without a copy while untouched.  It
 pickles as a plain list of lists, so `.match` files written from it load in the reference
 (and anywhere else) without this module.
 
@@ -56,15 +56,14 @@ class MatchPairs(MutableSequence):
     def __len__(self):
         return len(self._a) if self._a is not None else len(self._l)
 
+    # Element access turns the object into the real list of lists, once: a reader that keeps or
+    # edits a pair it was handed (`pair[0] = ...`, `matches[k] is matches[k]`) then sees plain
+    # list semantics.  len(), np.asarray(), comparison and pickling never need the lists.
     def __getitem__(self, k):
-        if self._a is None:
-            return self._l[k]
-        if isinstance(k, slice):
-            return self._a[k].tolist()
-        return self._a[k].tolist()
+        return self._as_list()[k]
 
     def __iter__(self):
-        return iter(self._a.tolist() if self._a is not None else self._l)
+        return iter(self._as_list())
 
     def __setitem__(self, k, value):
         if self._a is not None and isinstance(k, slice) and k == slice(None) \

@@ -277,9 +277,10 @@ def test_match_pairs_behave_like_the_reference_lists_and_pickle_like_them(tmp_pa
         assert all(type(p) is list and type(p[0]) is int for v in got.values() for p in v[:3])
     assert pickle.loads(dumps_match_dict({})) == {}
     m, r = d['IMG_0001'], ref['IMG_0001']
+    assert np.shares_memory(np.asarray(m), m.array()) and len(m) == len(r)      # (untouched: a view)
     assert len(m) == len(r) and m[7] == r[7] and m[-1] == r[-1] and m[2:5] == r[2:5]
     assert list(m) == r and m == r and r == m and not (m != r) and [p[1] for p in m] == [p[1] for p in r]
-    assert np.asarray(m, np.int64).tolist() == r and np.shares_memory(np.asarray(m), m.array())
+    assert np.asarray(m, np.int64).tolist() == r and m[7] is m[7]
     assert d == ref                                   # dictionaries of them compare like lists
     m.append([1, 2]); r.append([1, 2])
     del m[0]; del r[0]
