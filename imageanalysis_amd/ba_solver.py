@@ -547,7 +547,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     multi = prob.world > 1
     if maxiter is None:
         maxiter = n
-    chunk = max(2, int(chunk) & ~1)
+    chunk = max(2, int(os.environ.get('IAMX_LSMR_CHUNK', chunk)) & ~1)
     ws = prob.lsmr_ws
     if ws is None:
         z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
