@@ -163,6 +163,7 @@ def main():
                                                  _ptr(store.sinv), _ptr(pack_scratch), sp),
                       'iamx_desc3_pack_batch_u8')
         bufs = [(store.desc, rows_per * DIM), (store.norm_q, rows_per),
+                (store.norm_t, rows_per),          # (the exact stage reads the TRAIN image's norms)
                 (store.desc3, rows_per3 * DIM), (store.sn2, rows_per3),
                 (store.sct, rows_per3), (store.sperm, rows_per3)]
         if args.one_direction:       # parity-partitioned train layout of the one-direction form
@@ -172,7 +173,7 @@ def main():
                                                      _ptr(store.perm), _ptr(store.meta[first]),
                                                      _ptr(pack_scratch), sp), 'iamx_desc2_pack_batch_u8')
             rows_per2 = int(store.offsets2[1] - store.offsets2[0])
-            bufs = bufs[:2] + [(store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),
+            bufs = bufs[:3] + [(store.desc2, rows_per2 * DIM), (store.norm2, rows_per2),
                                (store.cinit, rows_per2), (store.perm, rows_per2), (store.meta, 4)]
         if dist is not None:
             for buf, width in bufs:
@@ -367,7 +368,13 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
     hi = min(first + mine, n_img)
     cand = [(first, first + 1), (first + 1, first), (first + 1, first + 2), (first + 2, first + 1),
             (first, hi - 1), (hi - 1, first), (first + 3, hi - 2), (hi - 2, first + 3)]
-    cand = [(a, b) for a, b in cand if first <= a < hi and first <= b < hi and a != b]
+    if hi < n_img or first > 0:
+        # several ranks: also pairs whose other image was packed by ANOTHER rank and arrived
+        # through the all-gather (its descriptors are regenerated here from the seed)
+        other = hi if hi < n_img else first - 1
+        cand = cand[:4] + [(first, other), (other, first)] + cand[4:]
+    cand = [(a, b) for a, b in cand if 0 <= a < n_img and 0 <= b < n_img and a != b
+            and (first <= a < hi or first <= b < hi)]
     und = []
     for a, b in cand:
         if (a, b) not in und and (b, a) not in und:
@@ -383,7 +390,8 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
     for p, (a, b) in enumerate(ordered):
         for i in (a, b):
             if i not in host:
-                host[i] = raw[i - first].cpu().numpy()
+                host[i] = (raw[i - first] if first <= i < hi else
+                           synth_descriptors(n_img, int(i), 1, raw.device)[0]).cpu().numpy()
         ridx, rd2 = cpu_ref.knn2_l2_u8(host[a], host[b])
         d = np.sqrt(rd2.astype(np.float32)).astype(np.float64)
         with np.errstate(divide='ignore', invalid='ignore'):
