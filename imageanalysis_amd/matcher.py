@@ -42,6 +42,30 @@ min_pairs = 25
 
 MYMAX = 2000            # matcher.py:265
 PAIRS_PER_BATCH = 2048  # unordered pairs per device batch (per-batch host costs are ~2 ms)
+BATCH_BYTES = 6 << 30   # ... as far as one batch's device workspace stays below this
+
+
+def _workspace_bytes_per_pair(rows):
+    """device workspace one unordered image pair of `rows`-descriptor images needs in a batch:
+    the per-row partial bounds of the symmetric sweep (workgroups of the register-resident image
+    x padded rows of the streamed one x 16 B) dominate -- 0.26 MB at 4096 rows, 39 MB at 50 k --,
+    then ~48 B per query row and direction (distances, candidates, survivors) and the per-pair
+    result slots of the filters"""
+    rows = max(int(rows), 1)
+    wg_rows = 1024 if rows >= 4096 else (512 if rows >= 2048 else 256)
+    cap = (rows + 127) // 128 * 128
+    return ((rows + wg_rows - 1) // wg_rows) * cap * 16 + 2 * rows * 48 + 96 * 1024
+
+
+def _pairs_per_batch(rows):
+    """largest power of two <= PAIRS_PER_BATCH (at least 16) whose batch fits BATCH_BYTES"""
+    if PAIRS_PER_BATCH < 16:
+        return PAIRS_PER_BATCH
+    n = max(16, min(PAIRS_PER_BATCH, BATCH_BYTES // _workspace_bytes_per_pair(rows)))
+    p = 16
+    while p * 2 <= n:
+        p *= 2
+    return p
 
 
 def _log(*a):
@@ -811,8 +835,20 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         detect_features_sharded(proj, sorted({k for _d, i, j in pending for k in (i, j)}))
     mine = _dist.shard_pairs(pending, rank, ws)
     shard_sizes = [_dist.shard_bounds(len(pending), r, ws) for r in range(ws)]
-    n_rounds = max((hi - lo + PAIRS_PER_BATCH - 1) // PAIRS_PER_BATCH for lo, hi in shard_sizes) \
-        if pending else 0
+    # pairs per device batch: bounded by the workspace a batch needs at this survey's keypoint
+    # counts (the images of a survey carry similar numbers: the largest count known so far, or
+    # that of the first image of this rank's share, stands for all); the ranks agree on the
+    # smallest value so that they run the same number of rounds (the gather is a collective)
+    ppb = PAIRS_PER_BATCH
+    if mine and isinstance(the_matcher, DeviceMatcher):
+        known = [_rows_of(im) for im in proj.image_list if _have_features(im)]
+        if not known:
+            _ensure_features(proj.image_list[mine[0][1]])
+            known = [_rows_of(proj.image_list[mine[0][1]])]
+        ppb = _pairs_per_batch(1.25 * max(known))
+    if ws > 1:
+        ppb = min(_dist.allgather_objects(ppb))
+    n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if pending else 0
     n_done = 0
     yaw_is_zero = {}        # image index -> its yaw error estimate was last set to 0 here
 
@@ -835,7 +871,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     image_list = proj.image_list
 
     def launch_round(rnd):
-        part = mine[rnd * PAIRS_PER_BATCH:(rnd + 1) * PAIRS_PER_BATCH]
+        part = mine[rnd * ppb:(rnd + 1) * ppb]
         if not part:
             return None
         # per IMAGE of the round, not per pair: time stamp of the descriptor cache, detection

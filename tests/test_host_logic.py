@@ -340,3 +340,21 @@ def test_keypoint_list_is_a_list_of_keypoints_and_feat_files_stay_reference_read
     assert im.kp_list[5].size == 99.0 and pickle.loads(im.kp_list.feat_bytes())[5][1] == 99.0
     assert KeyPointList.from_feat_bytes(pickle.dumps([])) == [] and \
         pickle.loads(KeyPointList([], [], [], [], [], []).feat_bytes()) == []
+
+
+def test_pairs_per_batch_is_bounded_by_the_device_workspace():
+    """find_matches sizes its device batches by what a batch needs at the survey's keypoint
+    count: the per-row partial bounds of the symmetric sweep grow with rows^2 per image pair"""
+    from imageanalysis_amd import matcher
+    old = matcher.PAIRS_PER_BATCH
+    try:
+        matcher.PAIRS_PER_BATCH = 2048                   # (the shipped value; other tests shrink it)
+        assert matcher._pairs_per_batch(4096) == 2048 and matcher._pairs_per_batch(50000) == 128
+        for rows in (100, 4096, 20000, 50000, 200000):
+            n = matcher._pairs_per_batch(rows)
+            assert n >= 16 and n & (n - 1) == 0
+            assert n == 16 or n * matcher._workspace_bytes_per_pair(rows) <= matcher.BATCH_BYTES
+        matcher.PAIRS_PER_BATCH = 3                      # (tests force tiny batches)
+        assert matcher._pairs_per_batch(50000) == 3
+    finally:
+        matcher.PAIRS_PER_BATCH = old
