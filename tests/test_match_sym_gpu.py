@@ -316,3 +316,25 @@ def test_config2_arena_pairs_at_both_ends_of_the_store():
     adjacent = np.abs(ordered[:, 0] - ordered[:, 1]) == 1
     assert adjacent.sum() >= 6 and count[adjacent].min() > 300          # the planted 30 %
     assert count[~adjacent].max() < 60
+
+
+def test_sym_keypoint_counts_of_full_resolution_frames():
+    """20 MP frames at detect scale 0.4 carry ~50 k keypoints: images of 20 000 and 17 777 rows
+    (20 / 18 workgroups per pair, 157 chunks per sweep, ragged tail) through the symmetric form,
+    both directions, against oracle/cpu_ref.c."""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(77)
+    a, b = _sift_like(rng, 20000), _sift_like(rng, 17777)
+    b[rng.permutation(17777)[:3000]] = np.clip(
+        a[rng.permutation(20000)[:3000]].astype(int) + rng.integers(-5, 6, (3000, 128)), 0, 255)
+    store = kernels.DescriptorStore.from_arrays([a, b])
+    thresh = 270.0 * 0.75
+    res = _run(store, [[0, 1], [1, 0]], thresh, sym=True)
+    assert res['pb'].sym and res['pb'].sym_form == 2 and res['unresolved'] == 0
+    for p, (q, t) in enumerate(((a, b), (b, a))):
+        keep, tidx, metric, rd2, _z = _oracle_survivors(q, t, thresh)
+        lo, hi = res['soff'][p], res['soff'][p + 1]
+        assert len(keep) > 2000
+        assert np.array_equal(res['sq'][lo:hi], keep) and np.array_equal(res['st'][lo:hi], tidx)
+        assert np.array_equal(res['sm'][lo:hi], metric)
+        assert np.array_equal(res['d2'][res['off'][p] + keep], rd2)
