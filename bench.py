@@ -871,7 +871,8 @@ def ba_bench(rank, world, dev, dist, args):
     #   point adjoint             O*(48 Jp + 16 ut gather + 4 idx) + n*40
     #   update                    n*56
     # The shipped kernels are matrix free (they re-derive the blocks from camera and point), so
-    # they MOVE fewer bytes than that: O*(4 + 32) + O*(12 + 16) + gathers that stay in the
+    # they MOVE fewer bytes than that: forward O*(4 idx + 32 ut r/w + 24 point-side products out),
+    # adjoint O*(4 idx + 24 products gathered) + the point / camera table gathers that stay in the
     # Infinity Cache + n*128 ("executed_bytes_per_iteration", compulsory traffic only).
     lsmr = None
     if world == 1:
@@ -888,7 +889,7 @@ def ba_bench(rank, world, dev, dist, args):
         sync()
         t_it = (time.perf_counter() - t1) / its
         by = O * (200.0 + 68.0) + prob.n * 128.0
-        ex = O * 64.0 + prob.n * 128.0
+        ex = O * 88.0 + prob.n * 128.0
         lsmr = {"bound": "hbm", "kernels": "lsmr_fwd (+camera adjoint) + lsmr_adj (+sums, stopping tests) + lsmr_update3",
                 "achieved": round(by / t_it / 1e9, 1), "peak": HBM, "unit": "GB/s",
                 "frac": round(by / t_it / 1e9 / HBM, 4), "us_per_iteration": round(t_it * 1e6, 1),

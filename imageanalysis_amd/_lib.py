@@ -87,10 +87,10 @@ SIGNATURES = {
     'iamx_ba_lsmr_state_size': (c_int, []),
     'iamx_ba_lsmr_partials_size': (c_int64, [c_int, c_int]),
     'iamx_ba_lsmr_prepare': (c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 3),
-    'iamx_ba_lsmr_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 11
+    'iamx_ba_lsmr_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 12
                              + [c_int, c_void_p]),
     'iamx_ba_lsmr_phase': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_int]
-                           + [c_void_p] * 11 + [c_int, c_int, c_void_p]),
+                           + [c_void_p] * 12 + [c_int, c_int, c_void_p]),
     'iamx_comm_unique_id': (c_int, [c_void_p]),
     'iamx_comm_init': (c_int, [c_int, c_int, c_void_p, c_void_p]),
     'iamx_comm_destroy': (c_int, [c_void_p]),

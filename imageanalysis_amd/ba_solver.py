@@ -555,7 +555,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
                                  ctab=z(prob.C * 32), ptab=z(prob.P * 6),
                                  state=z(L.iamx_ba_lsmr_state_size()),
                                  part=z(L.iamx_ba_lsmr_partials_size(prob.C, prob.P)),
-                                 xr=z(4), tbuf=z(n))
+                                 xr=z(4), tbuf=z(n), eprod=z(3 * prob.O))
     u1, u2, vt, h, hbar, x = (ws[k] for k in ('u1', 'u2', 'vt', 'h', 'hbar', 'x'))
     if 'dreg' not in ws:
         ws['dreg'] = torch.zeros(max(n, 1), dtype=F64, device=dev)
@@ -605,8 +605,8 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
     mcommon = common[:11] + (prob.pt_lo, prob.pt_hi) + common[11:]
 
     def enqueue_launches():
-        check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), chunk,
-                                     stream_ptr()), 'iamx_ba_lsmr_iterate')
+        check(L.iamx_ba_lsmr_iterate(*common, _ptr(ws['xr']), _ptr(ws['tbuf']), _ptr(ws['eprod']),
+                                     chunk, stream_ptr()), 'iamx_ba_lsmr_iterate')
 
     # Single rank: the 3 x chunk launches of a chunk are captured once into a HIP graph (every
     # pointer they take lives in prob.lsmr_ws; dreg is copied into it) and replayed per chunk:
@@ -636,8 +636,8 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
             for it in range(chunk):
                 par = it & 1
                 for phase in (0, 1, 2):
-                    check(L.iamx_ba_lsmr_phase(*mcommon, _ptr(xr), _ptr(tbuf), phase, par,
-                                               stream_ptr()), 'iamx_ba_lsmr_phase')
+                    check(L.iamx_ba_lsmr_phase(*mcommon, _ptr(xr), _ptr(tbuf), _ptr(ws['eprod']),
+                                               phase, par, stream_ptr()), 'iamx_ba_lsmr_phase')
                     if phase == 0:
                         _dist.allreduce_sum_(xr[:2])
                     elif phase == 1:

@@ -394,6 +394,10 @@ struct LsmrArgs {
     double *xr, *tbuf;
     int multi;
     int pt_lo, pt_hi;
+    // eprod [n_obs][3]: the point part of J^T ut' per observation (camera-major order), written by
+    // the forward kernel -- which has the observation's geometry and the new ut' in registers
+    // anyway -- and summed per point by the adjoint kernel
+    double *eprod;
 };
 
 
@@ -541,7 +545,11 @@ __global__ __launch_bounds__(256) void lsmr_prepare_mf_kernel(
 // (the stopping tests of the previous iteration run behind this kernel -- adjoint prologue on a
 // single rank, lsmr_sumU_kernel on several: if they latch a stop, this launch has only touched
 // ut / tbuf, which nobody reads any more, and x is final)
-__global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
+// Three workgroups per CU on purpose (amdgpu_waves_per_eu): every observation gathers its
+// point's 72 bytes, and with four resident workgroups per CU those gathers evict each other --
+// measured 70 us at four (the register count would allow it), 57 at three, 66 at two.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void lsmr_fwd_kernel(LsmrArgs A, int parity)
 {
     __shared__ double sh[4];
     double *S = A.S;
@@ -636,13 +644,22 @@ __global__ __launch_bounds__(256) void lsmr_fwd_kernel(LsmrArgs A, int parity)
             u.y = b * ia - ab * u.y;
             *reinterpret_cast<double2 *>(A.u1 + 2 * (int64_t)o) = u;
             acc += u.x * u.x + u.y * u.y;
+            double e0 = 0.0, e1 = 0.0, e2 = 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const double w = G.du[i] * u.x + G.dv[i] * u.y;
                 sw[i] += w;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) Mo[i][j] += w * G.dX[j];
+                e0 += ct[3 * i] * w;
+                e1 += ct[3 * i + 1] * w;
+                e2 += ct[3 * i + 2] * w;
             }
+            // point part of J^T ut' of this observation (J_point = -B in the body frame): the
+            // adjoint kernel only gathers and sums these (a 24-byte record per observation: one
+            // gather per slot there; three planes cost it 8 us more)
+            double *ep = A.eprod + 3 * (int64_t)o;
+            ep[0] = -e0; ep[1] = -e1; ep[2] = -e2;
         }
     }
     __shared__ double red[4][13];
@@ -826,9 +843,6 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
     const int n_pt_blocks = (A.pt_hi - A.pt_lo + 255) / 256;
     double sq = 0.0;
     if ((int)blockIdx.x < n_pt_blocks) {
-        double cal[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) cal[i] = A.calib[i];
         const int p0 = A.pt_lo + blockIdx.x * 256;
         const int p1 = min(p0 + 256, A.pt_hi);
         const int p = p0 + threadIdx.x;
@@ -842,17 +856,10 @@ __global__ __launch_bounds__(256) void lsmr_adj_kernel(LsmrArgs A, int parity)
                 const int jx = threadIdx.x + 256 * i;
                 if (jx < cnt) {
                     const int64_t e = base + jx;
-                    const int2 cp = A.slot_cp[e];
-                    const double2 uu = *reinterpret_cast<const double2 *>(A.u1 + 2 * (int64_t)A.pt_obs[e]);
-                    const double *ct = A.ctab + (int64_t)cp.x * CT;
-                    ObsGeom G;
-                    obs_geom(ct, A.ptab + (int64_t)cp.y * 6, cal, G);
-                    const double w0 = G.du[0] * uu.x + G.dv[0] * uu.y;
-                    const double w1 = G.du[1] * uu.x + G.dv[1] * uu.y;
-                    const double w2 = G.du[2] * uu.x + G.dv[2] * uu.y;
-                    prod[0][jx] = -(ct[0] * w0 + ct[3] * w1 + ct[6] * w2);      // J_point = -B
-                    prod[1][jx] = -(ct[1] * w0 + ct[4] * w1 + ct[7] * w2);
-                    prod[2][jx] = -(ct[2] * w0 + ct[5] * w1 + ct[8] * w2);
+                    const int64_t oe = A.pt_obs[e];
+                    prod[0][jx] = A.eprod[3 * oe];
+                    prod[1][jx] = A.eprod[3 * oe + 1];
+                    prod[2][jx] = A.eprod[3 * oe + 2];
                 }
             }
             __syncthreads();
@@ -1041,8 +1048,8 @@ extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, cons
                                     const int32_t *slot_cp, int64_t n_obs, int n_cams, int n_pts,
                                     const double *dreg, double *u1, double *u2, double *vt,
                                     double *h, double *hbar, double *x, double *state,
-                                    double *partials, double *xr, double *tbuf, int n_iter,
-                                    void *stream)
+                                    double *partials, double *xr, double *tbuf, double *eprod,
+                                    int n_iter, void *stream)
 {
     IAMX_REQUIRE(ctab && ptab && calib && pt_idx && cam_ptr && pt_ptr && pt_obs && slot_cp && dreg &&
                      u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
@@ -1054,7 +1061,7 @@ extern "C" int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, cons
                reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
                partials, partials + L.off_V, partials + L.off_X, L.n_adj, partials + L.off_U2,
-               xr, tbuf, 0, 0, n_pts};
+               xr, tbuf, 0, 0, n_pts, eprod};
     hipStream_t st = iamx::as_stream(stream);
     for (int it = 0; it < n_iter; ++it) {
         const int parity = it & 1;
@@ -1081,8 +1088,8 @@ extern "C" int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const 
                                   const int32_t *slot_cp, int64_t n_obs, int n_cams, int n_pts,
                                   int pt_lo, int pt_hi, const double *dreg, double *u1, double *u2,
                                   double *vt, double *h, double *hbar, double *x, double *state,
-                                  double *partials, double *xr, double *tbuf, int phase, int parity,
-                                  void *stream)
+                                  double *partials, double *xr, double *tbuf, double *eprod, int phase,
+                                  int parity, void *stream)
 {
     IAMX_REQUIRE(ctab && ptab && calib && pt_idx && cam_ptr && pt_ptr && pt_obs && slot_cp && dreg &&
                      u1 && u2 && vt && h && hbar && x && state && partials && xr && tbuf,
@@ -1095,7 +1102,7 @@ extern "C" int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const 
                reinterpret_cast<const int2 *>(slot_cp), n_obs, n_cams, n_pts,
                dreg, u1, u2, vt, h, hbar, x, state,
                partials, partials + L.off_V, partials + L.off_X, 0, partials + L.off_U2,
-               xr, tbuf, 1, pt_lo, pt_hi};
+               xr, tbuf, 1, pt_lo, pt_hi, eprod};
     hipStream_t st = iamx::as_stream(stream);
     const int npb = (pt_hi - pt_lo + 255) / 256;
     if (phase == 0) {

@@ -449,6 +449,9 @@ int iamx_ba_jtv(const double *Jc, const double *Jp, const double *Jk, const int3
  *   [iamx_ba_lsmr_partials_size]; xr DEV [4] (sums that cross kernels), tbuf DEV [n] (raw J^T ut1).
  *   pt_idx [n_obs] camera-major; cam_ptr / pt_ptr / pt_obs as for iamx_ba_jtv; slot_cp DEV
  *   [n_obs][2] int32 = (camera, point) of the observation in point-sorted slot e = pt_obs[e].
+ *   eprod DEV [n_obs][3] float64 work buffer: the point part of J^T ut' per observation, written
+ *   by the forward kernel (which has the observation's geometry and the new ut' in registers) and
+ *   summed per point by the adjoint kernel.
  *   Deterministic (fixed reduction trees, no atomics). */
 int iamx_ba_lsmr_state_size(void);
 int64_t iamx_ba_lsmr_partials_size(int n_cams, int n_pts);
@@ -459,7 +462,7 @@ int iamx_ba_lsmr_iterate(const double *ctab, const double *ptab, const double *c
                          const int32_t *pt_obs, const int32_t *slot_cp, int64_t n_obs, int n_cams,
                          int n_pts, const double *dreg, double *u1, double *u2, double *vt,
                          double *h, double *hbar, double *x, double *state, double *partials,
-                         double *xr, double *tbuf, int n_iter, void *stream);
+                         double *xr, double *tbuf, double *eprod, int n_iter, void *stream);
 
 /* Multi-rank form of the same iteration: observations AND the point part of every n-vector are
  * sharded by point (this rank owns the points [pt_lo, pt_hi) of the internal order and every
@@ -479,8 +482,8 @@ int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *cal
                        const int32_t *pt_obs, const int32_t *slot_cp, int64_t n_obs, int n_cams,
                        int n_pts, int pt_lo, int pt_hi, const double *dreg, double *u1, double *u2,
                        double *vt, double *h, double *hbar, double *x, double *state,
-                       double *partials, double *xr, double *tbuf, int phase, int parity,
-                       void *stream);
+                       double *partials, double *xr, double *tbuf, double *eprod, int phase,
+                       int parity, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Collectives of the hot path for callers that are not python: RCCL over

@@ -215,7 +215,7 @@ def _two_rank_solve(rank, world, port, path, outdir):
         def __getattr__(self, name):
             if name == 'iamx_ba_lsmr_phase':
                 def call(*a):
-                    phases.append(int(a[-3]))
+                    phases.append(int(a[-3]))        # (..., phase, parity, stream)
                     return real_phase(*a)
                 return call
             return getattr(ba_solver._lib.lib(), name)
