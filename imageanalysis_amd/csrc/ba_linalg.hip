@@ -569,7 +569,13 @@ void lsmr_fwd_kernel(LsmrArgs A, int parity)
         return;
     }
     // one camera: its table row and its 7 entries of vt are wave-uniform (scalar loads)
-    const int c = blockIdx.x;
+    // workgroups are dealt to the 8 XCDs round robin: give every XCD a CONTIGUOUS run of cameras
+    // (neighbouring cameras of a survey see the same points, and each XCD has its own L2)
+    int c;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, k = bid >> 3, q = A.n_cams >> 3, r = A.n_cams & 7;
+        c = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const double *ct = A.ctab + (int64_t)c * CT;
     const double *vc = A.vt + (int64_t)c * 7;
     const double *xp = A.vt + (int64_t)A.n_cams * 7;
