@@ -109,6 +109,14 @@ __device__ __forceinline__ double2 residual_rt(const double *__restrict__ R,
 // the block per observation in registers instead.
 constexpr int RES_MAXCAM = 16;
 
+// Workgroups are dealt to the 8 XCDs round robin; consecutive blocks of camera-major observations
+// gather neighbouring points.  Give every XCD a contiguous run of blocks (each has its own L2).
+__device__ __forceinline__ int xcd_contiguous_block(int bid, int n)
+{
+    const int xcd = bid & 7, k = bid >> 3, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
     const double *__restrict__ cams, const double *__restrict__ pts,
     const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
     __shared__ double Rs_all[4][RES_MAXCAM][12];        // one set of camera blocks per WAVE
     double (*Rs)[12] = Rs_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
-    const int64_t o = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const int64_t o = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) * 2;
     const bool two = o + 1 < n_obs, one = o < n_obs;
     int2 ci = make_int2(0, 0), pi = make_int2(0, 0);
     double4 ob = make_double4(0, 0, 0, 0);
@@ -219,7 +227,8 @@ __global__ __launch_bounds__(256) void ba_residual_jac_kernel(
     constexpr int SC = WITH_CALIB ? 1 : 15, SP = WITH_CALIB ? 1 : 7;      // padded LDS strides
     __shared__ double sJc[WITH_CALIB ? 1 : 256 * SC];
     __shared__ double sJp[WITH_CALIB ? 1 : 256 * SP];
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < n_obs; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = (int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * 256; base < n_obs;
+         base += (int64_t)gridDim.x * 256) {
         const int64_t o = base + threadIdx.x;
         const bool valid = o < n_obs;
         if (valid) {
