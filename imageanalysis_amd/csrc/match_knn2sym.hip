@@ -494,7 +494,14 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
 #pragma unroll
             for (int tile = 0; tile < CHUNK / 32; ++tile) {
                 v4i a_nx[4], tb_nx[4];
-                if (tile + 1 < CHUNK / 32) load_ops(tile + 1, a_nx, tb_nx);
+                if (tile + 1 < CHUNK / 32) {
+                    if constexpr (VARIANT & 256) {      // (timing only: operands reused, no LDS reads)
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2) { a_nx[s2] = a[s2]; a_nx[s2][0] += 1; tb_nx[s2] = tbv[s2]; }
+                    } else {
+                        load_ops(tile + 1, a_nx, tb_nx);
+                    }
+                }
                 int r[16];
                 static_assert(QW % 2 == 0, "query blocks are processed in pairs");
                 int cl[16];                    // C operand: Ct of the 16 rows + the lane's Cq floor
@@ -1033,6 +1040,9 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
 #define V(id) case id: hipLaunchKernelGGL((knn2sym_kernel<4, 8, id>), g, dim3(512), 0, st, a); break;
         V(0) V(1) V(2) V(3) V(4) V(5) V(8) V(11)
 #undef V
+    case 330: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 256 + 3, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 331: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 256 + 64 + 3, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    case 332: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 256 + 64 + 32 + 16 + 3, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 320: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 128, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 400: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 401: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 64 + 32, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
