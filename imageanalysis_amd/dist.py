@@ -1,14 +1,20 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI on the node; "gloo" in the CPU tests).  The path shards by *pair* (matching) and by
-*point* (BA); the only data-path exchanges are
+xGMI on the node; "gloo" in the CPU tests).  The path shards by *image* (detection), by *pair*
+(matching) and by *point* (BA); the data-path exchanges are
 
-  * descriptors: every rank packs the images it detected, then the packed store
-    (int8 rows + two int32 norms) is gathered so that every rank holds all images
-    (`gather_store_shards`), 1.57 GB in total for the 2812-image survey;
-  * match lists: variable-length per-pair results are gathered on rank 0 as python objects
-    (`gather_results`) -- kilobytes per round;
-  * BA: one all-reduce of the camera-side accumulators per operator application
-    (`allreduce_sum_`), see ba_solver.py.
+  * features: every image is detected by ONE rank (`owner_of_images`), then the uint8
+    descriptors and float32 keypoint positions of all images are exchanged once
+    (`exchange_features`: keypoint counts as objects, then one broadcast per owner and buffer
+    through `gather_store_shards`); bench.py all-gathers the packed stores in place instead
+    (`all_gather_into_tensor`, 1.47 GB per layout for the 2812-image survey);
+  * match lists: the variable-length per-pair results of a round go to rank 0 ONLY
+    (`gather_results`), which keeps the survey's bookkeeping and writes the files; a failure on
+    one rank is re-raised on every rank first (`raise_on_any_rank`), and rank 0's list of
+    pending pairs is what every rank shards (`broadcast_object`);
+  * BA: observations AND the point part of every n-vector are sharded by point
+    (`point_range`, `shard_observations_by_point`); per inner iteration the ranks all-reduce the
+    camera-side part only (7 C + 1 doubles), per outer iteration the camera blocks of the
+    normal equations (`allreduce_sum_`), see ba_solver.py.
 
 xGMI is point to point (7 links x ~153 GB/s per GPU): the store exchange is done as a few
 large transfers (one per owner per buffer), never per image.
@@ -118,6 +124,42 @@ def allgather_objects(obj, group=None):
     return out
 
 
+def broadcast_object(obj, src=0, group=None):
+    """rank `src`'s picklable object on every rank"""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
+
+
+def _raise_note(r, n):
+    if n[0] == 'ZeroDivisionError':
+        raise ZeroDivisionError(n[1])
+    if n[0] == 'SystemExit':
+        raise SystemExit("rank %d quit: %s" % (r, n[1]))
+    raise RuntimeError("rank %d failed: %s: %s" % (r, n[0], n[1]))
+
+
+def raise_on_any_rank(failure, group=None):
+    """A collective: all-gathers a one-line note of `failure` (an exception raised on this rank,
+    or None) and re-raises the first one on EVERY rank -- the rank that failed raises its own
+    exception -- so that no rank is left waiting in the collective that would follow."""
+    rank, ws = world()
+    if ws == 1:
+        if failure is not None:
+            raise failure
+        return
+    note = None if failure is None else (type(failure).__name__, str(failure))
+    for r, n in enumerate(allgather_objects(note, group=group)):
+        if n is not None:
+            if r == rank and failure is not None:
+                raise failure
+            _raise_note(r, n)
+
+
 def gather_results(results, failure=None, dst=0, group=None):
     """find_matches' per-round exchange.  The per-pair match lists go to rank `dst` ONLY (it
     keeps the survey's bookkeeping and writes the files; match consolidation and everything after
@@ -131,17 +173,7 @@ def gather_results(results, failure=None, dst=0, group=None):
         if failure is not None:
             raise failure
         return [results]
-    note = None if failure is None else (type(failure).__name__, str(failure))
-    notes = allgather_objects(note, group=group)
-    for r, n in enumerate(notes):
-        if n is not None:
-            if r == rank and failure is not None:
-                raise failure
-            if n[0] == 'ZeroDivisionError':
-                raise ZeroDivisionError(n[1])
-            if n[0] == 'SystemExit':
-                raise SystemExit("rank %d quit: %s" % (r, n[1]))
-            raise RuntimeError("rank %d failed: %s: %s" % (r, n[0], n[1]))
+    raise_on_any_rank(failure, group=group)
     parts = [None] * ws if rank == dst else None
     dist.gather_object(results, parts, dst=dst, group=group)
     return parts if rank == dst else [results]

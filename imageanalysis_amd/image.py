@@ -85,6 +85,7 @@ def make_keypoints(x, y, size, angle, response, octave, class_id=None):
 
 ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
 USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
+SIDECAR_MARGIN_S = 30.0        # a .desc / .feat newer than the sidecar by more than this is not ours
 WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
 # zlib level of the float32 .desc (the reference passes compresslevel=6, image.py:213; every level
 # decompresses to the same bytes).  On integer-valued float32 descriptors level 6 runs at 9 MB/s
@@ -136,11 +137,13 @@ def _load_sidecar(self):
     try:
         if not os.path.exists(side):
             return None
-        # a .desc that is much newer was written by someone else (the reference re-detecting):
-        # our own background gzip of the same array finishes seconds after the sidecar
-        if os.path.exists(self.desc_file) and \
-                os.path.getmtime(self.desc_file) > os.path.getmtime(side) + 120.0:
-            return None
+        # a .desc / .feat that is newer was written by someone else (the reference
+        # re-detecting); our own background gzip of the same arrays finishes seconds after the
+        # sidecar (SIDECAR_MARGIN_S covers the slowest writer queue measured, 20 MP frames)
+        t_side = os.path.getmtime(side)
+        for other in (self.desc_file, self.features_file):
+            if os.path.exists(other) and os.path.getmtime(other) > t_side + SIDECAR_MARGIN_S:
+                return None
         u8 = np.load(side)
         if u8.dtype != np.uint8 or u8.ndim != 2 or u8.shape[1] != 128:
             return None
@@ -225,6 +228,15 @@ def save_descriptors(self):
             side = _sidecar(self.desc_file)
             cacheio.write_raw(side, lambda: _npy_bytes(as_u8), background=ASYNC_CACHE_WRITES,
                               on_error=lambda e: print(side + ": error saving file: " + str(e)))
+            return
+    # no sidecar written for these descriptors (non-integer values, none at all, sidecars
+    # off): one left over from an earlier detection must not answer the next load
+    side = _sidecar(self.desc_file)
+    cacheio.wait(side)
+    try:
+        os.remove(side)
+    except OSError:
+        pass
 
 
 def save_matches(self):

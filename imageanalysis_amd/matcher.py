@@ -474,15 +474,24 @@ def detect_features_sharded(proj, images=None):
     idx = list(range(len(proj.image_list))) if images is None else [int(i) for i in images]
     owner_local = _dist.owner_of_images(len(idx), ws)
     own = {}
-    for k, i in enumerate(idx):
-        if owner_local[k] == rank:
-            im = proj.image_list[i]
-            _ensure_features(im)
-            des = np.asarray(im.des_list)
-            own[k] = (np.clip(np.rint(des), 0, 255).astype(np.uint8) if des.dtype != np.uint8 else des,
-                      _kp_xy(im))
+    failure = None
+    try:
+        for k, i in enumerate(idx):
+            if owner_local[k] == rank:
+                im = proj.image_list[i]
+                _ensure_features(im)
+                des = np.asarray(im.des_list)
+                own[k] = (np.clip(np.rint(des), 0, 255).astype(np.uint8) if des.dtype != np.uint8 else des,
+                          _kp_xy(im))
+    except (Exception, SystemExit) as exc:
+        if ws == 1:
+            raise
+        failure = exc
     if ws == 1:
         return np.array([len(own[k][0]) for k in range(len(idx))], np.int64)
+    # a detector failure on one rank (quit() on an image-size mismatch, an unreadable file) is
+    # re-raised on every rank before the exchange: the others would wait in it forever
+    _dist.raise_on_any_rank(failure)
     dev = None
     if torch.distributed.get_backend() == 'nccl':
         from . import _lib
@@ -663,9 +672,15 @@ def _match_batch(batch, match_ratio, device_filters=True, surface=False):
 
 
 class _Empty(list):
-    """the (shared, immutable) empty match list of a pair without matches: find_matches stores
-    a fresh [] per pair and image, like the reference"""
+    """the shared empty match list of a pair without matches; its mutators raise (one object
+    stands for every quiet pair of a batch).  find_matches stores a fresh [] per pair and image,
+    like the reference."""
     __slots__ = ()
+
+    def _immutable(self, *a, **k):
+        raise TypeError("the shared empty match list is immutable: copy it (list(x)) first")
+
+    append = extend = insert = __iadd__ = __imul__ = __setitem__ = _immutable
 
 
 _NO_MATCHES = _Empty()
@@ -826,6 +841,13 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 continue
         pending.append((dist, i, j))
 
+    if ws > 1:
+        # Results are gathered on rank 0 only, so after an earlier find_matches call in this
+        # process the other ranks' match lists are incomplete and their skip rule would keep a
+        # different list: rank 0's list is THE list (every collective below assumes the ranks
+        # agree on it -- sharded detection, the batch size, the rounds, the shard bounds)
+        pending = _dist.broadcast_object(pending if rank == 0 else None, src=0)
+
     save_time = time.time()
     save_interval = 300     # seconds
     _log("Processing worklist matches:")
@@ -840,12 +862,18 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # that of the first image of this rank's share, stands for all); the ranks agree on the
     # smallest value so that they run the same number of rounds (the gather is a collective)
     ppb = PAIRS_PER_BATCH
-    if mine and isinstance(the_matcher, DeviceMatcher):
-        known = [_rows_of(im) for im in proj.image_list if _have_features(im)]
-        if not known:
-            _ensure_features(proj.image_list[mine[0][1]])
-            known = [_rows_of(proj.image_list[mine[0][1]])]
-        ppb = _pairs_per_batch(1.25 * max(known))
+    early_failure = None
+    try:
+        if mine and isinstance(the_matcher, DeviceMatcher):
+            known = [_rows_of(im) for im in proj.image_list if _have_features(im)]
+            if not known:
+                _ensure_features(proj.image_list[mine[0][1]])
+                known = [_rows_of(proj.image_list[mine[0][1]])]
+            ppb = _pairs_per_batch(1.25 * max(known))
+    except (Exception, SystemExit) as exc:
+        if ws == 1:
+            raise
+        early_failure = exc           # re-raised on every rank by the first gather below
     if ws > 1:
         ppb = min(_dist.allgather_objects(ppb))
     n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if pending else 0
@@ -890,17 +918,27 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         lines = [(dist, i, j, image_list[i], image_list[j]) for dist, i, j in part]
         return _launch_lines(lines, match_ratio, batched_surface, [(rows[i], rows[j]) for _d, i, j in part])
 
-    # software pipeline: the GPU works on round r+1 while python turns round r into lists
-    in_flight = launch_round(0) if n_rounds else None
-    for rnd in range(n_rounds):
-        # an exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
-        # image-size mismatch) travels with the results and is re-raised on EVERY rank: the
-        # others would otherwise wait in the collective forever
-        failure = None
+    # software pipeline: the GPU works on round r+1 while python turns round r into lists.
+    # An exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
+    # image-size mismatch) -- in the batch-size estimate above, in the launch of round 0 or
+    # inside a round -- travels with the results and is re-raised on EVERY rank: the others
+    # would otherwise wait in the collective forever
+    in_flight = None
+    failure = early_failure
+    if n_rounds and failure is None:
         try:
-            coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
-            results = _finish_lines(in_flight) if in_flight is not None else []
-            in_flight = coming
+            in_flight = launch_round(0)
+        except (Exception, SystemExit) as exc:
+            if ws == 1:
+                raise
+            failure = exc
+    for rnd in range(n_rounds):
+        results = []
+        try:
+            if failure is None:
+                coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
+                results = _finish_lines(in_flight) if in_flight is not None else []
+                in_flight = coming
         except (Exception, SystemExit) as exc:
             if ws == 1:
                 raise
@@ -968,7 +1006,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                     i2.match_list[i1.name] = []
 
         t_elapsed = time.time() - t_start
-        percent = n_done / float(max(len(pending), 1))
+        # (ranks != 0 only see their own pairs: their progress is that of their own shard)
+        percent = n_done / float(max(len(pending) if rank == 0 else len(mine), 1))
         t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
         _qlog("%.1f%% done: %.1f (min) remaining" % (percent * 100.0, t_remain / 60.0))
 

@@ -66,10 +66,15 @@ class MatchPairs(MutableSequence):
         return iter(self._as_list())
 
     def __setitem__(self, k, value):
-        if self._a is not None and isinstance(k, slice) and k == slice(None) \
-                and isinstance(value, (np.ndarray, MatchPairs)):
-            self._a = np.ascontiguousarray(np.asarray(value), np.int32).reshape(-1, 2)
+        if isinstance(k, slice) and k == slice(None) and isinstance(value, (np.ndarray, MatchPairs)):
+            # a full-slice assignment of an array (match_cleanup.merge_duplicates) resets the
+            # object to its array form whatever it was before: storing the array's rows as the
+            # elements of the list form would hand out ndarrays where `pair == [a, b]` is expected
+            self._a = np.ascontiguousarray(np.asarray(value), np.int32).reshape(-1, 2).copy()
+            self._l = None
             return
+        if isinstance(value, np.ndarray):
+            value = value.tolist()
         self._as_list()[k] = value
 
     def __delitem__(self, k):

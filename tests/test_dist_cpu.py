@@ -235,3 +235,124 @@ def test_sharded_detection_and_feature_exchange_world2_gloo(tmp_path):
     """SURVEY.md 8e 'SIFT detect': each image is detected by one rank, descriptors + keypoint
     positions reach the other rank's device matcher through dist.exchange_features."""
     mp.spawn(_run_sharded_detect, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _run_find_matches_again(rank, world, port, outdir):
+    """a SECOND find_matches call in the same process (results live on rank 0 only): the ranks
+    must still agree on the work list -- rank 0's -- or their collectives no longer line up"""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    _init(rank, world, port)
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from test_host_logic import _image
+    des, xy = _strip()
+    names = ['D%02d' % i for i in range(len(des))]
+    proj = PoseProject(names)
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        f = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = f.des_list, f.kp_list
+    matcher.detector_node.setString('detector', 'SIFT')
+    matcher.detector_node.setFloat('scale', 0.4)
+    matcher.matcher_node.setFloat('match_ratio', 0.75)
+    matcher.matcher_node.setInt('min_pairs', 25)
+    camera.set_image_params(5472, 3648)
+    matcher.max_distance, matcher.min_pairs = 270.0, 25.0
+    matcher.the_matcher = object()
+    calls = []
+
+    def launch(batch, ratio, **kw):
+        calls.append(len(batch))
+        return _oracle_match_batch(batch, ratio)
+    matcher._launch_batch = launch
+    matcher._finish_batch = lambda handle: handle
+    matcher._deps.smart = lambda: None
+    matcher.PAIRS_PER_BATCH = 3
+    matcher.find_matches(proj, None, strategy='traditional', sort=True)
+    first = {im.name: {k: list(map(list, v)) for k, v in im.match_list.items()}
+             for im in proj.image_list}
+    n_first = sum(calls)
+    del calls[:]
+    matcher.find_matches(proj, None, strategy='traditional', sort=True)       # must not hang
+    # the second call only retries the pairs rank 0 recorded as empty, dealt over both ranks
+    retried = sum(1 for k, im in enumerate(proj.image_list) for o, v in im.match_list.items()
+                  if len(v) == 0) // 2 if rank == 0 else None
+    import torch.distributed as dist
+    from imageanalysis_amd import dist as D
+    total = sum(D.allgather_objects(sum(calls)))
+    n_retry = D.broadcast_object(retried, src=0)
+    assert total == n_retry and total < n_first * world
+    if rank == 0:
+        again = {im.name: {k: list(map(list, v)) for k, v in im.match_list.items()}
+                 for im in proj.image_list}
+        assert again == first
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_find_matches_second_call_same_process_world2_gloo(tmp_path):
+    mp.spawn(_run_find_matches_again, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def _run_round0_failure(rank, world, port, where):
+    """an exception raised on ONE rank before the first gather (launch of round 0, the sharded
+    detection) is re-raised on every rank instead of leaving the other in a collective"""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    _init(rank, world, port)
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib import camera
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from test_host_logic import _image
+    des, xy = _strip()
+    names = ['D%02d' % i for i in range(len(des))]
+    proj = PoseProject(names)
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        f = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = f.des_list, f.kp_list
+    matcher.detector_node.setString('detector', 'SIFT')
+    matcher.detector_node.setFloat('scale', 0.4)
+    matcher.matcher_node.setFloat('match_ratio', 0.75)
+    matcher.matcher_node.setInt('min_pairs', 25)
+    camera.set_image_params(5472, 3648)
+    matcher.max_distance, matcher.min_pairs = 270.0, 25.0
+    matcher._deps.smart = lambda: None
+    matcher.PAIRS_PER_BATCH = 64                       # one round: the failure is in round 0
+    if where == 'launch':
+        matcher.the_matcher = object()
+
+        def launch(batch, ratio, **kw):
+            if rank == 1:
+                raise ZeroDivisionError("float division by zero")
+            return _oracle_match_batch(batch, ratio)
+        matcher._launch_batch = launch
+        matcher._finish_batch = lambda handle: handle
+        with pytest.raises(ZeroDivisionError):
+            matcher.find_matches(proj, None, strategy='traditional', sort=True)
+    else:
+        matcher.the_matcher = matcher.DeviceMatcher()
+
+        def bad_detect(self, scale, use_cache=True):
+            raise SystemExit("image size mismatch")
+        for k, im in enumerate(proj.image_list):
+            im.des_list, im.kp_list = None, None
+            if k >= 3:                                 # the second rank's images
+                im.detect_features = bad_detect.__get__(im)
+            else:
+                def ok(self, scale, use_cache=True, k=k):
+                    f = _image(names[k], des[k], xy[k])
+                    self.des_list, self.kp_list = f.des_list, f.kp_list
+                im.detect_features = ok.__get__(im)
+        with pytest.raises(SystemExit):
+            matcher.detect_features_sharded(proj)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('where', ['launch', 'detect'])
+def test_failure_before_first_gather_reaches_every_rank_world2_gloo(where):
+    mp.spawn(_run_round0_failure, args=(2, _free_port(), where), nprocs=2, join=True)
