@@ -101,7 +101,8 @@ def main():
                     help='filter kernels on the sweep stream (default: on a second stream)')
     ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
     ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
-    ap.add_argument('--ba-iters', type=int, default=3, help='TRF iterations to time')
+    ap.add_argument('--ba-iters', type=int, default=0,
+                    help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
     ap.add_argument('--e2e', type=int, default=0, metavar='N',
                     help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
                          'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
@@ -854,10 +855,30 @@ def ba_bench(rank, world, dev, dist, args):
     # untimed warm-up iteration (workspace allocation, code-object load), like --warmup for matching
     ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=2, verbose=0)
     sync()
+    del prob.inner_iterations[:]
     t0 = time.perf_counter()
-    res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=args.ba_iters + 1, verbose=0)
+    res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4,
+                               max_nfev=(args.ba_iters + 1) if args.ba_iters else None, verbose=0)
     sync()
     dt = time.perf_counter() - t0
+    inner_its = list(prob.inner_iterations)
+    # the same outer iteration with SciPy's subproblem formulation (LSMR on the whole system,
+    # Optimizer.solver = 'device-lsmr'), 3 iterations: what the Schur solver replaced
+    lsmr_ref = None
+    if world == 1:
+        prob.inner = 'lsmr'
+        ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=2, verbose=0)
+        sync()
+        del prob.inner_iterations[:]
+        t1 = time.perf_counter()
+        res_l = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=4, verbose=0)
+        sync()
+        dt_l = time.perf_counter() - t1
+        lsmr_ref = {"value": round(res_l.iterations / dt_l, 3), "unit": "TRF iterations/s",
+                    "iterations": int(res_l.iterations), "lsmr_iterations": int(sum(prob.inner_iterations)),
+                    "seconds": round(dt_l, 3),
+                    "rms_residual_px": round(float(np.sqrt(2.0 * res_l.cost / (2 * O))), 3)}
+        prob.inner = 'schur'
     if dist is not None:
         t = torch.tensor([dt, t_res, t_jac], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -902,10 +923,39 @@ def ba_bench(rank, world, dev, dist, args):
                 "achieved_executed": round(ex / t_it / 1e9, 1),
                 "frac_executed": round(ex / t_it / 1e9 / HBM, 4),
                 "working_set": "Infinity-Cache resident (< 256 MB)"}
+    schur_it = None
+    if world == 1:
+        # one CG iteration of the Schur solver = three passes over the stored Jacobian blocks
+        # (ALGORITHMIC bytes: forward Jc 112 + t 16, points Jp 48 + t 16 + slot 4, adjoint
+        # Jc 112 + Jp 48 + t 16 + z 24 + idx 4 = 400 B per observation) + the one-workgroup update
+        its = 64
+        ba_solver.schur_solve(prob, d_dev, dreg, eta=0.0, maxiter=8, to_host=False)
+        sync()
+        t1 = time.perf_counter()
+        _s, istop, itn, _rz, _ = ba_solver.schur_solve(prob, d_dev, dreg, eta=0.0, maxiter=its,
+                                                       to_host=False)
+        sync()
+        t_sol = time.perf_counter() - t1
+        t8 = time.perf_counter()
+        ba_solver.schur_solve(prob, d_dev, dreg, eta=0.0, maxiter=8, to_host=False)
+        sync()
+        t_sol8 = time.perf_counter() - t8
+        t_cg = (t_sol - t_sol8) / max(itn - 8, 1)             # (prepare / finish cancel)
+        by = O * 400.0 + C * 7 * 8 * 12.0
+        schur_it = {"bound": "hbm", "kernels": "schur_fwd + schur_pt + schur_adj + schur_update",
+                    "achieved": round(by / t_cg / 1e9, 1), "peak": HBM, "unit": "GB/s",
+                    "frac": round(by / t_cg / 1e9 / HBM, 4), "us_per_iteration": round(t_cg * 1e6, 1),
+                    "bytes_per_iteration": by, "form": "stored blocks",
+                    "iterations_timed": int(itn) - 8}
     cpu = None                                              # filled in by main() at the end
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
             "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),
-            "lsmr_iterations": int(res.lsmr_iterations), "seconds": round(dt, 3),
+            "status": int(res.status),
+            "inner_solver": "Schur complement + block-Jacobi CG (iamx_ba_accumulate, iamx_ba_schur_*), "
+                            "forcing term eta = %g" % prob.schur_eta,
+            "inner_iterations": int(sum(inner_its)),
+            "inner_iterations_per_solve_max": int(max(inner_its)) if inner_its else 0,
+            "seconds": round(dt, 3), "lsmr_reference": lsmr_ref,
             "cameras": C, "points": P, "observations": O, "rms_residual_px": round(mre, 3),
             "residual_evals_per_sec": round(1.0 / t_res, 1),
             "residual": {"bound": "hbm", "achieved": round(64.0 * o_local * world / t_res / 1e9, 1),
@@ -923,7 +973,7 @@ def ba_bench(rank, world, dev, dist, args):
                              "peak": HBM, "unit": "GB/s",
                              "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
                              "bytes_per_obs": 224},
-            "lsmr_iteration": lsmr, "cpu_baseline": cpu,
+            "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
 
 

@@ -136,6 +136,19 @@ class DeviceBA(object):
         self.tmp_n, self.tmp_n2, self.tmp_m, self.tmp_m2 = z(self.n), z(self.n), z(self.m), z(self.m)
         self.tmp_perm = z(self.n)
         self.lsmr_ws = None
+        self.schur_ws = None
+        # normal-equation blocks of the current Jacobian (iamx_ba_accumulate): U [C][7][7],
+        # V [P][3][3], g = (gc [C][7], gp [P][3]) -- this rank's observations only
+        self.acc = None
+        self._acc_valid = False
+        # Gauss-Newton subproblem solver: 'schur' (points eliminated, preconditioned CG on the
+        # reduced camera system; default) or 'lsmr' (SciPy's formulation, the reference's path)
+        self.inner = os.environ.get('IAMX_BA_INNER', 'schur')
+        self.schur_eta = float(os.environ.get('IAMX_BA_SCHUR_ETA', '0.1'))
+        self.schur_qtol = float(os.environ.get('IAMX_BA_SCHUR_QTOL', '0.3'))
+        self.schur_max_iter = int(os.environ.get('IAMX_BA_SCHUR_MAXIT', '500'))
+        self.inner_stops = []
+        self.inner_iterations = []        # inner iterations of every subproblem solved (tests)
         self._pin = None
         self._state_pin = None
         self.profile = None
@@ -180,12 +193,16 @@ class DeviceBA(object):
         raw = self.upload(a, out=self.tmp_perm)
         if out is None:
             out = torch.empty(max(self.n, 1), dtype=F64, device=self.dev)
-        torch.index_select(raw[:self.n], 0, self.idx_h2i, out=out[:self.n])
+        if self.n:
+            check(lib().iamx_vec_gather(self.n, _ptr(raw), _ptr(self.idx_h2i), _ptr(out),
+                                        stream_ptr()), 'iamx_vec_gather')
         return out
 
     def download_n(self, t):
         """device n-vector (internal point order) -> host n-vector (reference order)"""
-        torch.index_select(t[:self.n], 0, self.idx_i2h, out=self.tmp_perm[:self.n])
+        if self.n:
+            check(lib().iamx_vec_gather(self.n, _ptr(t), _ptr(self.idx_i2h), _ptr(self.tmp_perm),
+                                        stream_ptr()), 'iamx_vec_gather')
         return self.download(self.tmp_perm, self.n)
 
     def upload_m(self, a):
@@ -256,6 +273,7 @@ class DeviceBA(object):
 
     def residual_jac(self):
         cams, pts = self._cams_pts()
+        self._acc_valid = False
         if self.O:
             check(lib().iamx_ba_residual_jac(_ptr(cams), self.C, _ptr(pts), self.P,
                                              _ptr(self.cam_idx), _ptr(self.pt_idx), _ptr(self.uv),
@@ -317,15 +335,46 @@ class DeviceBA(object):
         self.jtv(self.r, self.tmp_n, square=True)
         return np.sqrt(self.download_n(self.tmp_n))
 
+    def accumulate(self):
+        """U, V, g_c, g_p of the Jacobian residual_jac() left in Jc / Jp, and of self.r
+        (iamx_ba_accumulate: one pass, this rank's observations).  Valid until the next
+        residual_jac()."""
+        if self._acc_valid:
+            return self.acc
+        if self.acc is None:
+            z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=self.dev)
+            self.acc = dict(U=z(self.C * 49), V=z(self.P * 9), g=z(self.C * 7 + self.P * 3))
+        a = self.acc
+        nc = self.C * 7
+        check(lib().iamx_ba_accumulate(_ptr(self.Jc), _ptr(self.Jp), _ptr(self.r), _ptr(self.cam_ptr),
+                                       _ptr(self.pt_ptr), _ptr(self.pt_obs), self.O, self.C, self.P,
+                                       _ptr(a['U']), _ptr(a['V']), _ptr(a['g']),
+                                       _lib.c_void_p(a['g'].data_ptr() + 8 * nc), stream_ptr()),
+              'iamx_ba_accumulate')
+        self._acc_valid = True
+        return a
+
     def grad_dev(self):
         """J^T r as a device n-vector (internal order)"""
-        self.jtv(self.r, self.tmp_n)
-        return self.tmp_n[:self.n].clone()
+        if self.with_calib:
+            self.jtv(self.r, self.tmp_n)
+            return self.tmp_n[:self.n].clone()
+        g = self.accumulate()['g'][:self.n].clone()
+        if self.world > 1:
+            _dist.allreduce_sum_(g)
+        return g
 
     def colsq_dev(self):
         """column sums of J.^2 as a device n-vector (a view of the scratch vector: use it
         before the next operator application)"""
-        self.jtv(self.r, self.tmp_n, square=True)
+        if self.with_calib:
+            self.jtv(self.r, self.tmp_n, square=True)
+            return self.tmp_n[:self.n]
+        a = self.accumulate()
+        check(lib().iamx_ba_block_diag(_ptr(a['U']), _ptr(a['V']), self.C, self.P,
+                                       _ptr(self.tmp_n), stream_ptr()), 'iamx_ba_block_diag')
+        if self.world > 1:
+            _dist.allreduce_sum_(self.tmp_n[:self.n])
         return self.tmp_n[:self.n]
 
     def vec_ops(self):
@@ -680,11 +729,134 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
             float(st[_R['NORMAR']]))
 
 
+def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=True, qtol=None):
+    """The Gauss-Newton step of  min || [J diag(d); diag(dreg)] p - [r; 0] ||  through the normal
+    equations (csrc/ba_schur.hip): points eliminated exactly, the reduced camera system solved by
+    block-Jacobi preconditioned conjugate gradients until the preconditioned residual has
+    dropped by the factor `eta` or the decrease of the quadratic model has levelled off
+    (iteration i lowers it by less than qtol / i of the total so far: the truncated-Newton test
+    of Nash & Sofer) -- SciPy's TRF only uses the step to span a 2-D subspace together with the
+    gradient and minimises the exact model in it (trf.py:315-327), so what the step has to
+    deliver is model decrease, not a small residual in the weakly determined (gauge-like)
+    directions --, the point part back-substituted.  J and r are what residual_jac() left on
+    the device.  Several ranks (observations sharded by point): one all-reduce of C x 35 doubles
+    per solve and one of C x 7 doubles per CG iteration; the recurrence is replicated.
+    Returns (step, istop, iterations, sqrt(r.z), 0.0) like lsmr_device()."""
+    n, C, P, O = prob.n, prob.C, prob.P, prob.O
+    dev = prob.dev
+    L = lib()
+    multi = prob.world > 1
+    if qtol is None:
+        # the solver's own settings come as a pair; an explicit eta alone means "to this residual"
+        qtol = prob.schur_qtol if eta is None else 0.0
+    eta = prob.schur_eta if eta is None else float(eta)
+    maxiter = int(prob.schur_max_iter if maxiter is None else maxiter)
+    ws = prob.schur_ws
+    if ws is None:
+        z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
+        ns = int(L.iamx_ba_schur_state_size())
+        ws = prob.schur_ws = dict(Y=z(P * 6), yg=z(P * 3), zp=z(P * 3), sraw=z(C * 35), minv=z(C * 28),
+                                  t=z(2 * O), qraw=z(C * 7), part=z(2 * C), x=z(C * 7), r=z(C * 7), z=z(C * 7),
+                                  p=z(C * 7), y=z(C * 7), state=z(ns), step=z(n),
+                                  pin=(torch.empty(ns, dtype=F64).pin_memory(),
+                                       torch.empty(ns, dtype=F64).pin_memory()),
+                                  ev=(torch.cuda.Event(), torch.cuda.Event()))
+    ph = _Phase(prob, 'schur:prepare')
+    ph.__enter__()
+    a = prob.accumulate()
+    nc = C * 7
+    gp = _lib.c_void_p(a['g'].data_ptr() + 8 * nc)
+    check(L.iamx_ba_schur_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.r), _ptr(prob.cam_ptr),
+                                  _ptr(prob.pt_idx), O, C, P, _ptr(a['V']), gp, _ptr(d_dev),
+                                  _ptr(dreg_dev), _ptr(ws['Y']), _ptr(ws['yg']), _ptr(ws['zp']),
+                                  _ptr(ws['sraw']), stream_ptr()), 'iamx_ba_schur_prepare')
+    if multi:
+        _dist.allreduce_sum_(ws['sraw'][:C * 35])
+    check(L.iamx_ba_schur_factor(_ptr(ws['sraw']), _ptr(d_dev), _ptr(dreg_dev), C, eta, qtol, maxiter,
+                                 _ptr(ws['minv']), _ptr(ws['x']), _ptr(ws['r']), _ptr(ws['z']),
+                                 _ptr(ws['p']), _ptr(ws['y']), _ptr(ws['state']), stream_ptr()),
+          'iamx_ba_schur_factor')
+    ph.__exit__()
+    ph = _Phase(prob, 'schur:iterate')
+    ph.__enter__()
+    it_args = (_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx), _ptr(prob.pt_idx), _ptr(prob.cam_ptr),
+               _ptr(prob.pt_ptr), _ptr(prob.pt_obs), O, C, P, _ptr(d_dev), _ptr(dreg_dev),
+               _ptr(ws['Y']), _ptr(ws['minv']), _ptr(ws['t']), _ptr(ws['zp']), _ptr(ws['qraw']),
+               _ptr(ws['part']), _ptr(ws['x']), _ptr(ws['r']), _ptr(ws['z']), _ptr(ws['p']), _ptr(ws['y']),
+               _ptr(ws['state']))
+
+    enqueued = [0]          # iterations enqueued since the factorisation (selects the state buffer)
+
+    def enqueue_chunk():
+        k = enqueued[0]
+        enqueued[0] += chunk
+        if not multi:
+            check(L.iamx_ba_schur_iterate(*it_args, k, chunk, -1, stream_ptr()), 'iamx_ba_schur_iterate')
+            return
+        for i in range(chunk):
+            check(L.iamx_ba_schur_iterate(*it_args, k + i, 1, 0, stream_ptr()), 'iamx_ba_schur_iterate')
+            _dist.allreduce_sum_(ws['qraw'][:nc])
+            check(L.iamx_ba_schur_iterate(*it_args, k + i, 1, 1, stream_ptr()), 'iamx_ba_schur_iterate')
+        prob.fused_phase_iterations += chunk
+
+    slots, events = ws['pin'], ws['ev']
+    ns = slots[0].numel()
+
+    half = ns // 2
+    where = [0, 0]          # which state buffer is current behind the chunk a slot snapshots
+
+    def snapshot(k):
+        slots[k].copy_(ws['state'][:ns], non_blocking=True)
+        events[k].record()
+        where[k] = enqueued[0] & 1
+
+    # the NEXT chunk is enqueued before the host waits for the state behind this one (a chunk
+    # behind a latched stop is made of no-ops)
+    enqueue_chunk()
+    snapshot(0)
+    cur = 0
+    for _ in range(maxiter // chunk + 3):
+        enqueue_chunk()
+        snapshot(cur ^ 1)
+        events[cur].synchronize()
+        st = slots[cur].numpy()[where[cur] * half:(where[cur] + 1) * half].copy()
+        if st[3] != 0:
+            break
+        cur ^= 1
+    else:
+        raise _lib.IamxError('Schur CG did not latch a stop condition')
+    ph.__exit__()
+    ph = _Phase(prob, 'schur:finish')
+    ph.__enter__()
+    check(L.iamx_ba_schur_finish(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx), _ptr(prob.pt_ptr),
+                                 _ptr(prob.pt_obs), O, C, P, prob.pt_lo, prob.pt_hi, _ptr(d_dev),
+                                 _ptr(ws['Y']), _ptr(ws['yg']), _ptr(ws['x']), _ptr(ws['y']),
+                                 _ptr(ws['t']), _ptr(ws['step']), stream_ptr()),
+          'iamx_ba_schur_finish')
+    if multi:
+        _dist.allreduce_sum_(ws['step'][nc:n])
+    ph.__exit__()
+    itn = int(st[2])
+    prob.inner_iterations.append(itn)
+    prob.inner_stops.append(int(st[3]))
+    step = ws['step']
+    result = prob.download_n(step) if to_host else step[:n].clone()
+    return result, int(st[3]), itn, float(np.sqrt(max(st[0], 0.0))), 0.0
+
+
 def lsmr(prob, d_dev, dreg_dev, **opts):
-    """fused host-free iterations when the problem allows it, else the stepwise form."""
+    """The Gauss-Newton subproblem of one outer iteration: the Schur-complement solve
+    (prob.inner == 'schur', default), else LSMR on the whole system as SciPy does it -- fused
+    host-free iterations when the problem allows it, else the stepwise form.  Calibration
+    columns (dense, shared by every observation) only have the stepwise LSMR."""
+    if prob.inner == 'schur' and not prob.with_calib and prob.C and (prob.O or prob.world > 1):
+        return schur_solve(prob, d_dev, dreg_dev, to_host=opts.get('to_host', True))
     if not prob.with_calib and not prob.force_stepwise_lsmr and (prob.O or prob.world > 1):
-        return lsmr_device_fused(prob, d_dev, dreg_dev, **opts)
-    return lsmr_device(prob, d_dev, dreg_dev, **opts)
+        r = lsmr_device_fused(prob, d_dev, dreg_dev, **opts)
+    else:
+        r = lsmr_device(prob, d_dev, dreg_dev, **opts)
+    prob.inner_iterations.append(r[2])
+    return r
 
 
 # --------------------------------------------------------------------------------------
@@ -1238,8 +1410,9 @@ def gather_residual(prob, n_obs_total):
     return prob.download(t, full.size)
 
 
-def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None):
-    """Entry point used by Optimizer.run() when opt.solver == 'device'."""
+def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None, inner=None):
+    """Entry point used by Optimizer.run() when opt.solver is 'device' (inner='schur') or
+    'device-lsmr' (inner='lsmr')."""
     rank, world = _dist.world()
     n = x0.size
     if isinstance(bounds, (list, tuple)) and np.ndim(bounds[0]) > 0:
@@ -1253,7 +1426,10 @@ def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None):
                          for a in opt.by_camera_points_2d if len(a)])
     prob = DeviceBA(opt.n_cameras, opt.n_points, opt.camera_indices, opt.point_indices, uv, wc,
                     fixed_calib=fixed, rank=rank, world=world)
+    if inner is not None:
+        prob.inner = inner
     res = trf_device(prob, x0, lb, ub, ftol=ftol, verbose=verbose, max_nfev=max_nfev)
+    res.inner_solver = prob.inner if not wc else 'lsmr'
     prob.set_x(res.x)
     prob.residual()
     res.fun = gather_residual(prob, opt.camera_indices.size)

@@ -81,6 +81,13 @@ __global__ __launch_bounds__(256) void sqrt_shift_kernel(int64_t n, const double
     GRID_STRIDE(i, n) out[i] = sqrt(x[i] + shift);
 }
 
+__global__ __launch_bounds__(256) void gather_kernel(int64_t n, const double *__restrict__ x,
+                                                     const int64_t *__restrict__ idx,
+                                                     double *__restrict__ out)
+{
+    GRID_STRIDE(i, n) out[i] = x[idx[i]];
+}
+
 // CL_scaling_vector(x, g, lb, ub) -> v, dv
 __global__ __launch_bounds__(256) void cl_scaling_kernel(int64_t n, const double *__restrict__ x,
                                                          const double *__restrict__ g,
@@ -340,6 +347,16 @@ extern "C" int iamx_vec_mul(int64_t n, double s, const double *x, const double *
     if (n <= 0) return IAMX_OK;
     LAUNCH(mul_kernel, n, n, s, x, y, out);
     return iamx::check_launch("iamx_vec_mul");
+}
+
+extern "C" int iamx_vec_gather(int64_t n, const double *x, const int64_t *idx, double *out,
+                               void *stream)
+{
+    IAMX_REQUIRE(x && idx && out, "null pointer");
+    IAMX_REQUIRE(x != out, "out must not alias x");
+    if (n <= 0) return IAMX_OK;
+    LAUNCH(gather_kernel, n, n, x, idx, out);
+    return iamx::check_launch("iamx_vec_gather");
 }
 
 extern "C" int iamx_vec_sqrt_shift(int64_t n, const double *x, double shift, double *out, void *stream)

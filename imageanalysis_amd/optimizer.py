@@ -97,8 +97,11 @@ class Optimizer():
         self.ncp = 7
         self.cam2body = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)
         self.body2cam = np.linalg.inv(self.cam2body)
-        # 'device' (default): the TRF restatement of ba_solver.py, J and LSMR resident on the
-        # GPU; 'scipy': SciPy's own TRF driven by the device residual / analytic Jacobian
+        # 'device' (default): the TRF restatement of ba_solver.py with J resident on the GPU and
+        # the Gauss-Newton subproblems solved through the Schur complement (iamx_ba_accumulate +
+        # iamx_ba_schur_*); 'device-lsmr': the same outer iteration with SciPy's subproblem
+        # solver, LSMR on the whole system (the reference's formulation, ~10x more inner
+        # iterations); 'scipy': SciPy's own TRF driven by the device residual / analytic Jacobian
         self.solver = 'device'
         self._dev = None
 
@@ -358,9 +361,10 @@ class Optimizer():
         bounds = self._bounds()
 
         t0 = time.time()
-        if self.solver == 'device':
+        if self.solver in ('device', 'device-lsmr'):
             from . import ba_solver
-            res = ba_solver.solve(self, x0, bounds, ftol=self.ftol, verbose=2)
+            res = ba_solver.solve(self, x0, bounds, ftol=self.ftol, verbose=2,
+                                  inner='schur' if self.solver == 'device' else 'lsmr')
         else:
             from scipy.optimize import least_squares
             res = least_squares(self.fun, x0, jac=self.jac, verbose=2, method='trf',

@@ -16,8 +16,8 @@ ap.add_argument('--group', type=int, default=0, help='group number')
 ap.add_argument('--refine', action='store_true', help='refine a previous optimization.')
 ap.add_argument('--cam-calibration', action='store_true',
                 help='include camera calibration in the optimization.')
-ap.add_argument('--solver', default='device', choices=['device', 'scipy'],
-                help="'device' (default, like Optimizer.solver): GPU-resident TRF; 'scipy': SciPy TRF fed with the device residual/Jacobian")
+ap.add_argument('--solver', default='device', choices=['device', 'device-lsmr', 'scipy'],
+                help="'device' (default, like Optimizer.solver): GPU-resident TRF, Schur-complement subproblem solver; 'device-lsmr': the same with SciPy's LSMR formulation; 'scipy': SciPy TRF fed with the device residual/Jacobian")
 args = ap.parse_args()
 
 proj = project.ProjectMgr(args.project)

@@ -486,6 +486,79 @@ int iamx_ba_lsmr_phase(const double *ctab, const double *ptab, const double *cal
                        int parity, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Normal-equation blocks and the Schur-complement Gauss-Newton step (csrc/ba_schur.hip).
+ *
+ * iamx_ba_accumulate (the J^T J / J^T r accumulators of BASELINE.json's north star):
+ *   one pass over the stored block Jacobian of iamx_ba_residual_jac emits
+ *     U  DEV [n_cams][7][7]  = sum over the camera's observations of Jc^T Jc
+ *     V  DEV [n_pts][3][3]   = sum over the point's observations of Jp^T Jp
+ *     gc DEV [n_cams][7]     = sum Jc^T r,     gp DEV [n_pts][3] = sum Jp^T r
+ *   i.e. the block diagonal of J^T J and the gradient J^T r that scipy's TRF derives from the
+ *   sparse J the reference gives it (scripts/lib/optimizer.py:142-169, 491-501;
+ *   scipy/optimize/_lsq/trf.py:241-247 g = compute_grad(J, f), compute_jac_scale).  diag(U),
+ *   diag(V) are the column sums of J.^2 of x_scale='jac'.  The off-diagonal blocks W = Jc^T Jp
+ *   (7x3 per observation) are never stored: the solve below applies them from Jc / Jp.
+ *   cam_ptr / pt_ptr / pt_obs as for iamx_ba_jtv.  Observations sharded by point over several
+ *   ranks: U and gc are partial sums -- all-reduce them (n_cams x 56 doubles, once per outer
+ *   iteration); V and gp are complete on the rank that owns the point.  No atomics.
+ *
+ * The trust-region subproblem  min || [J diag(d); diag(dreg)] p - [r; 0] ||  of trf.py:303-314
+ * (which SciPy hands to LSMR: iamx_ba_lsmr_* keeps that form) through its normal equations:
+ * points eliminated exactly, the reduced camera system S p_c = b solved by conjugate gradients
+ * preconditioned with the inverses of S's 7x7 diagonal blocks, then p_p back-substituted.
+ *   iamx_ba_schur_prepare: Y DEV [n_pts][6] = (D_p V D_p + Dreg_p^2)^-1 (upper triangle),
+ *     yg DEV [n_pts][3] = Y D_p gp, zp DEV [n_pts][3] work, sraw DEV [n_cams][35] = the packed
+ *     upper triangle of this rank's part of S_cc before regularisation (28) + its part of b (7)
+ *     -- all-reduce sraw over ranks.  d, dreg DEV [n] (n = 7 n_cams + 3 n_pts).
+ *   iamx_ba_schur_factor: one workgroup: M_c = (S_cc + Dreg_c^2)^-1 -> minv DEV [n_cams][28]
+ *     (Cholesky; a block that is not positive definite falls back to its diagonal), x = 0,
+ *     r = b, z = M r, p = z, y = d_c .* p, state (DEV, iamx_ba_schur_state_size() doubles = two
+ *     buffers of 16; buffer 0 is the start:
+ *     [0] r.z, [1] initial r.z, [2] iterations done, [3] stop: 0 running / 1 sqrt(r.z / r0.z0) <=
+ *     eta / 2 max_iter reached / 3 breakdown / 4 the decrease of the quadratic model
+ *     Q(x) = x.Sx/2 - b.x has levelled off: i (Q_{i-1} - Q_i) <= qtol |Q_i|, [4] eta,
+ *     [5] max_iter, [6] alpha, [7] beta, [8] p.Sp, [9] -Q, [10] qtol)
+ *   iamx_ba_schur_iterate: n_iter iterations, five launches each, no host synchronisation;
+ *     a latched stop turns everything enqueued behind it into no-ops.  The state block holds
+ *     two buffers: iteration i (first_iter = the number of iterations enqueued since
+ *     iamx_ba_schur_factor) reads buffer i & 1 and writes the other; after k iterations the
+ *     current scalars are in buffer k & 1.  phase = -1: whole iterations (one rank); several
+ *     ranks: phase 0 = the three passes of q = S y over this rank's observations -> qraw DEV
+ *     [n_cams][7], all-reduce qraw, then phase 1 = the update (scalars replicated on every
+ *     rank).  t DEV [2 n_obs], part DEV [2 n_cams] (partials of the two inner products),
+ *     x r z p y DEV [7 n_cams].
+ *   iamx_ba_schur_finish: step DEV [n] = (x, Y D_p (gp - W^T x)) in the scaled variables of the
+ *     subproblem; the point entries outside [pt_lo, pt_hi) are written as 0 (several ranks:
+ *     all-reduce the point part once).
+ * ------------------------------------------------------------------------------------ */
+int iamx_ba_accumulate(const double *Jc, const double *Jp, const double *r, const int32_t *cam_ptr,
+                       const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                       int n_pts, double *U, double *V, double *gc, double *gp, void *stream);
+/* out DEV [7 n_cams + 3 n_pts] = (diag U, diag V): the column sums of J.^2 */
+int iamx_ba_block_diag(const double *U, const double *V, int n_cams, int n_pts, double *out,
+                       void *stream);
+int iamx_ba_schur_state_size(void);
+int iamx_ba_schur_prepare(const double *Jc, const double *Jp, const double *r, const int32_t *cam_ptr,
+                          const int32_t *pt_idx, int64_t n_obs, int n_cams, int n_pts,
+                          const double *V, const double *gp, const double *d, const double *dreg,
+                          double *Y, double *yg, double *zp, double *sraw, void *stream);
+int iamx_ba_schur_factor(const double *sraw, const double *d, const double *dreg, int n_cams,
+                         double eta, double qtol, int max_iter, double *minv, double *x, double *r, double *z,
+                         double *p, double *y, double *state, void *stream);
+int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const int32_t *cam_idx,
+                          const int32_t *pt_idx, const int32_t *cam_ptr, const int32_t *pt_ptr,
+                          const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+                          const double *d, const double *dreg, const double *Y, const double *minv,
+                          double *t, double *zp, double *qraw, double *part, double *x, double *r,
+                          double *z, double *p, double *y, double *state, int first_iter,
+                          int n_iter, int phase, void *stream);
+int iamx_ba_schur_finish(const double *Jc, const double *Jp, const int32_t *cam_idx,
+                         const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                         int n_pts, int pt_lo, int pt_hi, const double *d, const double *Y,
+                         const double *yg, const double *x, double *y, double *t, double *step,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Collectives of the hot path for callers that are not python: RCCL over
  * xGMI, bound at run time (a process that already holds an RCCL -- torch bundles one -- re-uses
  * it).  The python layer does the same two exchanges through torch.distributed.
@@ -524,6 +597,8 @@ int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *x, const do
  * pointers DEV unless noted.  They restate the O(n) helpers of scipy.optimize.least_squares
  * (method='trf'), which the reference calls at scripts/lib/optimizer.py:352-399:
  *   lincomb: out = a*x + b*y + c*z (y, z may be NULL);  mul: out = s*x.*y (y NULL: s*x)
+ *   gather:  out[i] = x[idx[i]] (idx DEV int64 [n]; out must not alias x) -- the private point
+ *            order of the device problem <-> the reference's parameter order
  *   sqrt_shift: out = sqrt(x + shift)
  *   dots: out[i] = sum a[i].*b[i] (.*w[i] when w and w[i] are not NULL), 1 <= k <= 8; a, b, w are
  *         HOST arrays of k device pointers; scratch: DEV [iamx_vec_scratch_doubles()] float64
@@ -541,6 +616,7 @@ int iamx_vec_lsmr_update(int64_t n, double *h, double *hbar, double *x, const do
 int iamx_vec_lincomb(int64_t n, double a, const double *x, double b, const double *y, double c,
                      const double *z, double *out, void *stream);
 int iamx_vec_mul(int64_t n, double s, const double *x, const double *y, double *out, void *stream);
+int iamx_vec_gather(int64_t n, const double *x, const int64_t *idx, double *out, void *stream);
 int iamx_vec_sqrt_shift(int64_t n, const double *x, double shift, double *out, void *stream);
 int iamx_vec_scratch_doubles(void);
 int iamx_vec_dots(int64_t n, int k, const double *const *a, const double *const *b,

@@ -1,0 +1,223 @@
+"""GPU: iamx_ba_accumulate (U, V, g_c, g_p) and the Schur-complement subproblem solver
+(csrc/ba_schur.hip) against numpy / SciPy on the reference-derived BA goldens and at
+BASELINE configs[3] size."""
+import glob
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REPO
+from test_host_logic import _scene
+from test_ba_solver_gpu import _problem
+
+pytestmark = pytest.mark.gpu
+BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
+PLAIN = [p for p in BA_CASES if not bool(np.load(p)['cam_calib'])]
+
+
+def _blocks(prob):
+    """Jc [O,2,7], Jp [O,2,3], r [O,2], cam, pt (internal order) on the host"""
+    O = prob.O
+    Jc = prob.download(prob.Jc, O * 14).reshape(O, 2, 7)
+    Jp = prob.download(prob.Jp, O * 6).reshape(O, 2, 3)
+    r = prob.download(prob.r, 2 * O).reshape(O, 2)
+    return Jc, Jp, r, prob.cam_idx.cpu().numpy().astype(np.int64), prob.pt_idx.cpu().numpy().astype(np.int64)
+
+
+@pytest.mark.parametrize('path', PLAIN, ids=os.path.basename)
+def test_accumulate_equals_numpy_blocks(path):
+    g, opt, prob = _problem(path)
+    prob.set_x(g['x0'])
+    prob.residual_jac()
+    a = prob.accumulate()
+    C, P = prob.C, prob.P
+    Jc, Jp, r, cam, pt = _blocks(prob)
+    U = np.zeros((C, 7, 7)); V = np.zeros((P, 3, 3)); gc = np.zeros((C, 7)); gp = np.zeros((P, 3))
+    np.add.at(U, cam, np.einsum('oki,okj->oij', Jc, Jc))
+    np.add.at(V, pt, np.einsum('oki,okj->oij', Jp, Jp))
+    np.add.at(gc, cam, np.einsum('oki,ok->oi', Jc, r))
+    np.add.at(gp, pt, np.einsum('oki,ok->oi', Jp, r))
+    got_U = prob.download(a['U'], C * 49).reshape(C, 7, 7)
+    got_V = prob.download(a['V'], P * 9).reshape(P, 3, 3)
+    got_g = prob.download(a['g'], prob.n)
+    assert np.abs(got_U - U).max() <= 1e-12 * np.abs(U).max()
+    assert np.abs(got_V - V).max() <= 1e-12 * np.abs(V).max()
+    assert np.array_equal(got_U, got_U.transpose(0, 2, 1)) and np.array_equal(got_V, got_V.transpose(0, 2, 1))
+    ref_g = np.concatenate([gc.ravel(), gp.ravel()])
+    assert np.abs(got_g - ref_g).max() <= 1e-12 * np.abs(ref_g).max()
+    # ... and they are what the outer iteration reads: J^T r and the column sums of J.^2 (the
+    # reference's order) equal the products with the CSR Jacobian
+    args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+    J = opt.jac(g['x0'], *args)
+    ref = J.T @ g['f0']
+    assert np.abs(prob.download_n(prob.grad_dev()) - ref).max() <= 1e-9 * np.abs(ref).max()
+    ref = np.asarray(J.power(2).sum(axis=0)).ravel()
+    assert np.abs(prob.download_n(prob.colsq_dev()) - ref).max() <= 1e-12 * ref.max()
+
+
+@pytest.mark.parametrize('path', PLAIN, ids=os.path.basename)
+def test_schur_step_equals_direct_solve(path):
+    """the step of the Schur-complement solver, iterated to convergence, is the least-squares
+    solution of SciPy's subproblem  min ||[J D; Dreg] p - [r; 0]||  (trf.py:303-314)"""
+    from scipy.sparse import diags, vstack
+    from scipy.sparse.linalg import spsolve
+    from imageanalysis_amd import ba_solver
+    g, opt, prob = _problem(path)
+    x0 = g['x0']
+    args = (opt.n_cameras, opt.n_points, opt.by_camera_point_indices, opt.by_camera_points_2d)
+    J = opt.jac(x0, *args).tocsr()
+    prob.set_x(x0)
+    prob.residual_jac()
+    rng = np.random.default_rng(1)
+    cn = np.sqrt(np.asarray(J.power(2).sum(axis=0)).ravel())
+    d = (1.0 / cn) * rng.uniform(0.5, 2.0, prob.n)
+    dreg = rng.uniform(1e-3, 3e-2, prob.n)
+    A = vstack([J @ diags(d), diags(dreg)]).tocsc()
+    rhs = A.T @ np.concatenate([g['f0'], np.zeros(prob.n)])
+    ref = spsolve((A.T @ A).tocsc(), rhs)
+    dd, dr = prob.upload_n(d), prob.upload_n(dreg)
+    step, istop, itn, _rz, _ = ba_solver.schur_solve(prob, dd, dr, eta=1e-13, maxiter=2000)
+    assert istop in (1, 3) and itn > 0          # converged (3: p.Sp underflowed at the solution)
+    assert np.abs(step - ref).max() <= 2e-7 * np.abs(ref).max(), (itn, np.abs(step - ref).max())
+    # the forcing term bounds the work: a loose tolerance stops early with a descent direction
+    step2, istop2, itn2, _, _ = ba_solver.schur_solve(prob, dd, dr, eta=0.1)
+    assert istop2 == 1 and 0 < itn2 < itn
+    gh = d * (J.T @ g['f0'])
+    assert step2 @ gh > 0                         # (p solves A^T A p = A^T [r; 0] = g_h)
+    # bitwise reproducible (no atomics)
+    step3 = ba_solver.schur_solve(prob, dd, dr, eta=0.1)[0]
+    assert np.array_equal(step2, step3)
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+@pytest.mark.parametrize('solver', ['device', 'device-lsmr'])
+def test_both_inner_solvers_reach_reference_minimum(path, solver):
+    from imageanalysis_amd import optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = solver
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    opt.run()
+    res = opt.result
+    cost = 0.5 * float(res.fun @ res.fun)
+    ref = float(g['cost_final'])
+    assert abs(cost - ref) / ref < 2e-2, (cost, ref)
+    assert abs(np.mean(np.abs(res.fun)) - np.mean(np.abs(g['f_final']))) < 0.02
+    assert res.njev <= 3 * 8 and res.status in (1, 2, 3, 4)
+    want = 'lsmr' if (solver == 'device-lsmr' or bool(g['cam_calib'])) else 'schur'
+    assert res.inner_solver == want
+
+
+def test_config3_schur_inner_iterations_and_end_state():
+    """BASELINE configs[3] at full size: the Schur solver needs <= 80 inner iterations per outer
+    iteration (LSMR on the whole system: ~400) and both inner solvers end at the same cost"""
+    from imageanalysis_amd import ba_solver, synth
+    p = synth.make_ba_problem()
+    C, P = len(p['cams0']), len(p['pts0'])
+    K = p['K']
+    calib = [K[0, 0], K[1, 1], K[0, 2], K[1, 2], *p['dist']]
+    x0 = np.hstack([p['cams0'].ravel(), p['pts0'].ravel()])
+    lb = np.full(x0.size, -np.inf)
+    ub = np.full(x0.size, np.inf)
+    for j, dlt in ((0, 3.0), (1, 3.0), (2, 9.0)):
+        lb[j:C * 7:7] = p['cams0'][:, j] - dlt
+        ub[j:C * 7:7] = p['cams0'][:, j] + dlt
+    out = {}
+    for inner in ('schur', 'lsmr'):
+        prob = ba_solver.DeviceBA(C, P, p['cam_idx'], p['pt_idx'], p['uv'], False, fixed_calib=calib)
+        prob.inner = inner
+        res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4)
+        out[inner] = (res, list(prob.inner_iterations))
+    res, its = out['schur']
+    assert res.status in (1, 2, 3, 4)
+    assert max(its) <= 80 and np.mean(its) <= 40, its
+    mre = np.sqrt(2 * res.cost / (2 * len(p['uv'])))
+    assert mre < 0.46                                   # pixel noise 0.5 px, fitted: the noise floor
+    # the reference's formulation (LSMR on the whole system, atol = btol = 1e-6) run to its own
+    # ftol stop: ~10x the inner iterations per outer iteration, and an end state that is no better
+    res_l, its_l = out['lsmr']
+    assert res_l.status in (1, 2, 3, 4)
+    assert np.mean(its_l) > 5 * np.mean(its)
+    assert res.cost <= 1.005 * res_l.cost, (res.cost, res_l.cost)
+    assert abs(np.sqrt(res.cost / len(p['uv'])) - np.sqrt(res_l.cost / len(p['uv']))) < 0.02
+
+
+def _two_rank_schur(rank, world, port, path, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)                         # both ranks share the one GPU of the box
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imageanalysis_amd import optimizer
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = 'device'
+    opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
+    from imageanalysis_amd import ba_solver, dist as D
+    sizes = []
+    plain = D.allreduce_sum_
+
+    def counting(t, group=None):
+        sizes.append(int(t.numel()))
+        return plain(t, group)
+    D.allreduce_sum_ = ba_solver._dist.allreduce_sum_ = counting
+    inner = []
+    real = ba_solver.schur_solve
+
+    def solve(prob, *a, **k):
+        out = real(prob, *a, **k)
+        inner.append(out[2])
+        return out
+    ba_solver.schur_solve = solve
+    opt.run()
+    np.save(os.path.join(outdir, 'x_r%d.npy' % rank), opt.result.x)
+    np.save(os.path.join(outdir, 'f_r%d.npy' % rank), opt.result.fun)
+    np.save(os.path.join(outdir, 'red_r%d.npy' % rank), np.array(sizes, np.int64))
+    np.save(os.path.join(outdir, 'inner_r%d.npy' % rank), np.array(inner, np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_schur_two_ranks_point_sharded_and_its_reduce_schedule(tmp_path):
+    """observations sharded by point over 2 ranks (gloo, same GPU): same solution as 1 rank; the
+    inner solve all-reduces C x 35 doubles once and C x 7 doubles per CG iteration (chunks of 4
+    are enqueued ahead: a few no-op iterations behind the latched stop are reduced as well)"""
+    import torch.multiprocessing as mp
+    from imageanalysis_amd import optimizer
+    path = [p for p in BA_CASES if p.endswith('ba_mid.npz')][0]
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_schur, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    g = np.load(path)
+    proj, inp = _scene(path)
+    opt = optimizer.Optimizer('/nonexistent')
+    opt.solver = 'device'
+    opt.setup(proj, inp['groups'], 0, inp['matches'])
+    opt.run()
+    x0 = np.load(tmp_path / 'x_r0.npy')
+    x1 = np.load(tmp_path / 'x_r1.npy')
+    assert np.array_equal(x0, x1)
+    f0 = np.load(tmp_path / 'f_r0.npy')
+    c1, c2 = 0.5 * f0 @ f0, 0.5 * opt.result.fun @ opt.result.fun
+    assert abs(c1 - c2) / c2 < 1e-3
+    C, n = opt.n_cameras, opt.result.x.size
+    for r in range(2):
+        red = np.load(tmp_path / ('red_r%d.npy' % r))
+        inner = np.load(tmp_path / ('inner_r%d.npy' % r))
+        solves = len(inner)
+        assert solves >= 2 and (red == 35 * C).sum() == solves
+        n_q = int((red == 7 * C).sum())
+        assert inner.sum() <= n_q <= inner.sum() + 8 * solves
+        # per solve: the point part of the step once; per outer iteration: gradient + column sums
+        assert (red == n - 7 * C).sum() == solves
+        assert (red == n).sum() <= 3 * (opt.result.njev + 2)

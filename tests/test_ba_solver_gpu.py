@@ -197,7 +197,7 @@ def _two_rank_solve(rank, world, port, path, outdir):
     g = np.load(path)
     proj, inp = _scene(path)
     opt = optimizer.Optimizer('/nonexistent')
-    opt.solver = 'device'
+    opt.solver = 'device-lsmr'
     opt.setup(proj, inp['groups'], 0, inp['matches'], cam_calib=bool(g['cam_calib']))
     # record what the solve all-reduces (element counts) and that it runs the fused phase path
     from imageanalysis_amd import ba_solver, dist as D
@@ -242,7 +242,7 @@ def test_device_trf_two_ranks_point_sharded(tmp_path):
     g = np.load(path)
     proj, inp = _scene(path)
     opt = optimizer.Optimizer('/nonexistent')
-    opt.solver = 'device'
+    opt.solver = 'device-lsmr'
     opt.setup(proj, inp['groups'], 0, inp['matches'])
     opt.run()
     x0 = np.load(tmp_path / 'x_r0.npy')

@@ -13,7 +13,7 @@ def main(d, out):
     for f in sorted(glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)):
         lines.append('## %s' % os.path.relpath(f, d))
         rows = list(csv.DictReader(open(f)))
-        for r in rows[:25]:
+        for r in rows:                       # every kernel of the run (round 2 cut this to 25)
             lines.append('  %-70s calls=%-6s total_ns=%-14s avg_ns=%-12s pct=%s' % (
                 r.get('Name', '')[:70], r.get('Calls'), r.get('TotalDurationNs'),
                 r.get('AverageNs'), r.get('Percentage')))
@@ -27,7 +27,7 @@ def main(d, out):
             meta[k] = (r.get('VGPR_Count'), r.get('Accum_VGPR_Count'), r.get('SGPR_Count'),
                        r.get('LDS_Block_Size'), r.get('Scratch_Size'), r.get('Workgroup_Size'),
                        r.get('Grid_Size'))
-        for k in sorted(acc, key=lambda k: -sum(sum(v) for v in acc[k].values()))[:8]:
+        for k in sorted(acc, key=lambda k: -sum(sum(v) for v in acc[k].values())):
             lines.append('  kernel %s' % k[:100])
             lines.append('    vgpr/agpr/sgpr/lds/scratch/wg/grid = %s' % (meta[k],))
             for c, v in sorted(acc[k].items()):
