@@ -103,6 +103,8 @@ def main():
     ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
     ap.add_argument('--ba-iters', type=int, default=0,
                     help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
+    ap.add_argument('--no-e2e', action='store_true',
+                    help='skip the configs[4] slice (24 rendered 20 MP frames through the drop-in chain)')
     ap.add_argument('--e2e', type=int, default=0, metavar='N',
                     help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
                          'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
@@ -317,6 +319,14 @@ def main():
         if not args.no_sift:
             sift = sift_bench(rank, world, dev, dist, args)
         cleanup = cleanup_bench(args) if rank == 0 else None
+    # BASELINE configs[4] as a slice at its own frame size: 24 rendered 5472 x 3648 JPEGs through
+    # detect -> match -> link -> triangulate -> BA (the drop-in entry points, host side included)
+    e2e = e2e_small = None
+    if rank == 0 and world == 1:
+        if not args.no_e2e:
+            e2e = e2e_bench(24, full_frame=True)
+        if args.e2e > 0:
+            e2e_small = e2e_bench(args.e2e)
     # CPU baselines of the BA and SIFT sections run AFTER every timed GPU section: their OpenMP /
     # OpenBLAS worker threads keep spinning for a while after a parallel region and a GPU
     # section timed right behind them loses 4x (measured: 3.9 -> 20.9 ms per SIFT frame)
@@ -353,8 +363,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,
         }
-        if args.e2e > 0 and world == 1:
-            out["e2e"] = e2e_bench(args.e2e)
+        out["e2e"] = e2e
+        if e2e_small is not None:
+            out["e2e_quarter_frames"] = e2e_small
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -408,12 +419,15 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
             if pb.sym else "one-direction sweep, %d-row workgroups" % pb.fast_rows}
 
 
-def e2e_bench(n_images):
+def e2e_bench(n_images, full_frame=False):
     """BASELINE configs[4] shape on one GPU: a rendered survey of n_images JPEGs on disk goes
     through the drop-in entry points exactly as scripts/process.py:236-407 drives the reference's
     modules -- Image.detect_features, matcher.find_matches, match_cleanup.*, groups.compute,
     Optimizer.setup / run / update_camera_poses -- with per-stage wall seconds (host side
-    included: JPEG decode, cache files, python lists, .match pickles)."""
+    included: JPEG decode, cache files, python lists, .match pickles).  full_frame: the survey
+    is rendered at configs[4]'s own frame size, 5472 x 3648 (20 MP), and detected at the
+    reference's default scale 0.4 (scripts/lib/matcher.py:38); otherwise at a quarter of the pixels
+    and scale 1.0."""
     import contextlib
     import io
     import shutil
@@ -427,7 +441,12 @@ def e2e_bench(n_images):
     out = {"images": rows * cols, "grid": [rows, cols]}
     try:
         t0 = time.perf_counter()
-        names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols)
+        if full_frame:
+            names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols, device='cuda',
+                                                                 **synth.FULL_FRAME)
+        else:
+            names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols)
+        scale = 0.4 if full_frame else 1.0
         out["render_seconds_untimed"] = round(time.perf_counter() - t0, 2)
         W, H = int(2 * K[0, 2]), int(2 * K[1, 2])
         an = os.path.join(tmp, 'ImageAnalysis')
@@ -435,10 +454,12 @@ def e2e_bench(n_images):
         os.makedirs(os.path.join(an, 'meta'))
         getNode('/config/directories', True).setString('project_dir', tmp)
         matcher.detector_node.setString('detector', 'SIFT')
-        matcher.detector_node.setFloat('scale', 1.0)
+        matcher.detector_node.setFloat('scale', scale)
         matcher.matcher_node.setFloat('match_ratio', 0.75)
         matcher.matcher_node.setInt('min_pairs', 25)
         matcher.matcher_node.setInt('min_chain_len', 0)
+        if full_frame:
+            matcher.matcher_node.setString('schedule', 'all-pairs')
         node = getNode('/config/camera', True)
         node.__dict__.pop('K_opt', None)
         node.__dict__.pop('dist_coeffs_opt', None)
@@ -483,7 +504,7 @@ def e2e_bench(n_images):
         def detect():
             pf = iimg.prefetch(proj.image_list)
             for im in proj.image_list:
-                im.detect_features(1.0)
+                im.detect_features(scale)
             pf.close()
             iimg.cacheio.wait()
         timed("detect", detect)
@@ -516,6 +537,15 @@ def e2e_bench(n_images):
         timed("ba_run", opt.run)
         mre1 = float(np.mean(np.abs(opt.result.fun)))
         timed("write_poses", lambda: opt.update_camera_poses(proj))
+        # relative geometry against the truth the frames were rendered from (gauge: one scale)
+        est = np.array([im.get_camera_pose(opt=True)[0] for im in proj.image_list])
+        tru = np.array([t[0] for t in truth])
+        db_est = np.linalg.norm(est[:, None, :] - est[None, :, :], axis=2)
+        db_tru = np.linalg.norm(tru[:, None, :] - tru[None, :, :], axis=2)
+        gauge = float((db_est * db_tru).sum() / (db_tru * db_tru).sum())
+        out["groups"] = [len(g) for g in group_list]
+        out["baseline_scale"] = round(gauge, 5)
+        out["max_baseline_error_m"] = round(float(np.abs(db_est - gauge * db_tru).max()), 4)
         total = sum(stages.values())
         out.update({"stage_seconds": stages, "total_seconds": round(total, 3),
                     "images_per_sec_end_to_end": round(len(names) / total, 2),
@@ -524,11 +554,13 @@ def e2e_bench(n_images):
                            "iterations": int(opt.result.njev),
                            "mean_abs_residual_px_before": round(mre0, 3),
                            "mean_abs_residual_px_after": round(mre1, 3)},
-                    "image_size": [W, H],
-                    "note": "drop-in entry points, host side included; rendered %dx%d frames (the "
-                            "FC6310S field of view at a quarter of its pixels), detector scale 1.0"
-                            % (W, H)})
+                    "image_size": [W, H], "detect_scale": scale,
+                    "note": "drop-in entry points, host side included; rendered %dx%d frames (%s), "
+                            "detector scale %.1f"
+                            % (W, H, "configs[4]'s own FC6310S frame" if full_frame else
+                               "the FC6310S field of view at a quarter of its pixels", scale)})
     finally:
+        matcher.matcher_node.__dict__.pop('schedule', None)
         shutil.rmtree(tmp, ignore_errors=True)
     return out
 

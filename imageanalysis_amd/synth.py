@@ -151,18 +151,54 @@ def render_view(tex, M, ned, w, h, gsd, origin):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
+def render_view_device(tex, M, ned, w, h, gsd, origin):
+    """render_view() with torch on the device that holds `tex` (uint8 [H,W,3]): 20 MP frames take
+    a second each in numpy.  Data generation for tests / bench.py --e2e, never a timed path."""
+    import torch
+    dev = tex.device
+    f64 = torch.float64
+    u = torch.arange(w, device=dev, dtype=f64)[None, :]
+    v = torch.arange(h, device=dev, dtype=f64)[:, None]
+    Mt = [[float(M[i, j]) for j in range(3)] for i in range(3)]
+    ray = [Mt[i][0] * u + Mt[i][1] * v + Mt[i][2] for i in range(3)]
+    t = -float(ned[2]) / ray[2]
+    r = (float(ned[0]) + ray[0] * t + origin) / gsd
+    c = (float(ned[1]) + ray[1] * t + origin) / gsd
+    del ray, t
+    r0, c0 = torch.floor(r), torch.floor(c)
+    fr, fc = (r - r0)[..., None], (c - c0)[..., None]
+    del r, c
+    r0 = r0.long().clamp_(0, tex.shape[0] - 2)
+    c0 = c0.long().clamp_(0, tex.shape[1] - 2)
+    flat = tex.reshape(-1, 3)
+    i00 = r0 * tex.shape[1] + c0
+    del r0, c0
+    top = flat[i00].to(f64) * (1 - fc) + flat[i00 + 1].to(f64) * fc
+    i00 += tex.shape[1]
+    bot = flat[i00].to(f64) * (1 - fc) + flat[i00 + 1].to(f64) * fc
+    img = top * (1 - fr) + bot * fr
+    return torch.round(img).clamp_(0, 255).to(torch.uint8).cpu().numpy()
+
+
+FULL_FRAME = dict(w=W_PX, h=H_PX, focal=FX, gsd=0.03)       # the FC6310S frame of BASELINE configs[4]
+
+
 def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, alt=100.0,
-                         spacing=(45.0, 40.0), gsd=0.11, seed=2024):
+                         spacing=(45.0, 40.0), gsd=0.11, seed=2024, device=None):
     """Writes <project_dir>/images/Pnnn.JPG and returns (names, truth [(ned, ypr)], logged
-    [(ned, ypr)], K).  Default camera = the FC6310S field of view at a quarter of its pixels."""
+    [(ned, ypr)], K).  Default camera = the FC6310S field of view at a quarter of its pixels;
+    **FULL_FRAME = the 5472x3648 frame itself (pass `device`: texture and ray casting on the GPU)."""
     from PIL import Image as PILImage
     from . import match_cleanup
     rng = np.random.default_rng(seed)
     os_ = __import__('os')
     os_.makedirs(os_.path.join(project_dir, 'images'), exist_ok=True)
     origin = 80.0
-    tex = ground_texture(int((rows * spacing[0] + 2 * origin) / gsd),
-                         int((cols * spacing[1] + 2 * origin) / gsd), seed)
+    th, tw = int((rows * spacing[0] + 2 * origin) / gsd), int((cols * spacing[1] + 2 * origin) / gsd)
+    if device is not None:
+        tex = make_survey_image(th, tw, seed, device)
+    else:
+        tex = ground_texture(th, tw, seed)
     K = np.array([[focal, 0, w / 2.0], [0, focal, h / 2.0], [0, 0, 1.0]])
     IK = np.linalg.inv(K)
     d2r = np.pi / 180.0
@@ -177,7 +213,10 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
             name = 'P%03d' % len(names)
             q = tf.quaternion_from_euler(ypr[0] * d2r, ypr[1] * d2r, ypr[2] * d2r, 'rzyx')
             M = tf.quaternion_matrix(q)[:3, :3].dot(match_cleanup.CAM2BODY).dot(IK)
-            bgr = render_view(tex, M, ned, w, h, gsd, origin)
+            if device is not None:
+                bgr = render_view_device(tex, M, ned, w, h, gsd, origin)
+            else:
+                bgr = render_view(tex, M, ned, w, h, gsd, origin)
             PILImage.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(
                 os_.path.join(project_dir, 'images', name + '.JPG'), quality=95)
             names.append(name)
