@@ -8,8 +8,9 @@
 //
 // Stages (all enqueued on one stream, no host round trip inside):
 //   gray_up2x      BGR u8 -> gray u8 (fixed point) -> x2 bilinear -> f32                HBM
-//   blur_h/blur_v  separable Gaussian, BORDER_REFLECT_101, f32, taps in fixed order;    HBM
-//                  LDS row tiles / 8-row register windows; blur_v also writes the DoG
+//   blur_strip     separable Gaussian, BORDER_REFLECT_101, f32, fused multiply-add taps in  HBM
+//                  fixed order; one launch per level: column strips walked top to bottom with
+//                  a ring of horizontally blurred rows in LDS; also writes the DoG
 //   downsample                                                                          HBM
 //   extrema        26-neighbour test on the DoG stack -> candidate list (atomic append)
 //   refine         one thread per candidate: 3-D quadratic fit (<=5 steps), contrast/edge
@@ -18,12 +19,13 @@
 //                  smoothing, peaks -> keypoints (atomic append)
 //   descriptor     one wave per keypoint: rotated 4x4x8 trilinear histogram in LDS (f64
 //                  atomics), clip/normalise/quantise
-// The per-pixel arithmetic of the pyramid uses separately rounded mul and add (`#pragma clang fp
-// contract(off)` in those kernels: hipcc fuses __fmul_rn + __fadd_rn into v_fma otherwise -- round
-// 1 shipped fused taps, 1 ulp off the oracle in 40 % of the pixels, found by the config-size
-// test of round 2) in the same tap order as the CPU oracle so the pyramids are bit-identical and
-// the keypoint sets can be compared one to one; keypoints are appended in nondeterministic
-// order and put into the canonical (octave, layer, y, x, angle) order by the host wrapper.
+// The Gaussian taps are explicit fused multiply-adds (one rounding per tap, `fmaf` in the CPU
+// oracle) in the oracle's tap order; the other per-pixel arithmetic of the pyramid (grey scale,
+// x2 resize, DoG, derivatives) uses separately rounded mul / add / sub under `#pragma clang fp
+// contract(off)` -- nothing is left to the compiler's contraction choices, so the pyramids are
+// bit-identical to the oracle and the keypoint sets can be compared one to one; keypoints are
+// appended in nondeterministic order and put into the canonical (octave, layer, y, x, angle)
+// order by iamx_sift_sort.
 // Pyramid traffic: 6 Gaussian + 5 DoG f32 levels per octave written once, read once
 // (~469 B per detect-resolution pixel).
 #include "iamx_common.h"
@@ -91,187 +93,119 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
     dst[i] = add_rn(mul_rn(top, omty), mul_rn(bot, ty));
 }
 
-// Separable Gaussian.  Both passes add the taps in ascending order with separately rounded
-// mul and add (acc = 0; acc = acc + v*k[t], t = -r..r) -- the order the CPU oracle uses, so
-// the pyramid is bit-identical to it.
-// Horizontal: one workgroup per 1024-pixel row segment, staged (with its halo) in LDS.
-constexpr int BLUR_TW = 1024;
-
-__global__ __launch_bounds__(256) void blur_h_kernel(const float *__restrict__ src, int h, int w,
-                                                     Taps T, float *__restrict__ dst)
-{
-    __shared__ float row[BLUR_TW + 2 * (MAX_TAPS / 2) + 2];
-    __shared__ float sk[MAX_TAPS];
-    const int r = T.r, y = blockIdx.y, x0 = blockIdx.x * BLUR_TW;
-    if (threadIdx.x < 2 * r + 1) sk[threadIdx.x] = T.k[threadIdx.x];
-    const int n_out = min(BLUR_TW, w - x0);
-    const float *srow = src + (int64_t)y * w;
-    for (int i = threadIdx.x; i < n_out + 2 * r; i += 256) {
-        const int xx = x0 - r + i;
-        row[i] = srow[(xx >= 0 && xx < w) ? xx : reflect101(xx, w)];
-    }
-    __syncthreads();
-    float *drow = dst + (int64_t)y * w + x0;
-#pragma unroll
-    for (int p = 0; p < BLUR_TW / 256; ++p) {
-        const int j = threadIdx.x + 256 * p;
-        if (j < n_out) {
-            float acc = 0.f;
-            for (int t = 0; t <= 2 * r; ++t) acc = add_rn(acc, mul_rn(row[j + t], sk[t]));
-            drow[j] = acc;
-        }
-    }
-}
-
-// Vertical: one thread per column and BLUR_RV output rows.  The tap radius is a template
-// parameter so the (BLUR_RV + 2R)-row window lives in registers and the taps in SGPRs: every
-// input row is loaded once (coalesced), each output adds its taps in ascending order.
-// Optionally also writes the DoG level  dog = out - prev  (fused).
-constexpr int BLUR_RV = 8;
+// Separable Gaussian, BORDER_REFLECT_101.  Both passes start from 0 and add the taps in ascending
+// order with ONE rounding per tap: acc = fma(v, k[t], acc), t = -r..r -- what a filter engine
+// compiled for FMA hardware computes, and what the CPU oracle computes (fmaf), so the pyramid is
+// bit-identical to it.  (Rounds 1-2 rounded multiply and add separately to match a numpy
+// expression: twice the VALU instructions for no reference-derived reason.)
+//
+// One launch per level.  A workgroup owns a strip of SB_TW columns and `seg_rows` rows and walks
+// down it in blocks of SB_TH rows:
+//   H block k : SB_TH source rows (+ R columns on each side, reflect-101 in x and y) -> LDS,
+//               horizontal pass in strips of 8 outputs with the 8 + 2R inputs in registers
+//               -> a ring of SB_RING = 64 horizontally blurred rows in LDS
+//   V block b : a thread owns one column and 8 rows, its 8 + 2R ring rows in registers; writes
+//               the level and, fused, DoG = level - source
+// Every source row of a segment is blurred horizontally once (the tile form of round 2 redid
+// 2R rows per 32-row tile: 1.8x at R = 13), the source is read once (+ 2R / 64 columns of halo),
+// level and DoG are written once: 12 B per pixel and level + halo.  2R <= 32 keeps the window of
+// a V block inside the ring while the next H block is already in it.
+constexpr int SB_TW = 64, SB_TH = 32, SB_RING = 64, SB_STRIP = 8;
 
 template <int R>
-__global__ __launch_bounds__(256) void blur_v_kernel(const float *__restrict__ src, int h, int w,
-                                                     Taps T, float *__restrict__ dst,
-                                                     const float *__restrict__ prev,
-                                                     float *__restrict__ dog)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * BLUR_RV;
-    if (x >= w) return;
-    float win[BLUR_RV + 2 * R];
-    const bool interior = y0 - R >= 0 && y0 + BLUR_RV - 1 + R < h;
-    if (interior) {
-        const float *p = src + (int64_t)(y0 - R) * w + x;
-#pragma unroll
-        for (int i = 0; i < BLUR_RV + 2 * R; ++i) win[i] = p[(int64_t)i * w];
-    } else {
-#pragma unroll
-        for (int i = 0; i < BLUR_RV + 2 * R; ++i) {
-            const int yy = y0 - R + i;
-            win[i] = src[(int64_t)((yy >= 0 && yy < h) ? yy : reflect101(yy, h)) * w + x];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < BLUR_RV; ++j) {
-        const int y = y0 + j;
-        if (y < h) {
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
-            const int64_t i = (int64_t)y * w + x;
-            dst[i] = acc;
-            if (dog) dog[i] = sub_rn(acc, prev[i]);
-        }
-    }
-}
-
-template <int R>
-void launch_blur_v(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
-                   const float *prev, float *dog)
-{
-    hipLaunchKernelGGL(blur_v_kernel<R>, dim3((w + 255) / 256, (h + BLUR_RV - 1) / BLUR_RV), dim3(256),
-                       0, st, src, h, w, tp, dst, prev, dog);
-}
-
-void blur_v(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
-            const float *prev, float *dog)
-{
-    switch (tp.r) {
-#define IAMX_BV(r) case r: launch_blur_v<r>(st, src, h, w, tp, dst, prev, dog); break;
-        IAMX_BV(1) IAMX_BV(2) IAMX_BV(3) IAMX_BV(4) IAMX_BV(5) IAMX_BV(6) IAMX_BV(7) IAMX_BV(8)
-        IAMX_BV(9) IAMX_BV(10) IAMX_BV(11) IAMX_BV(12) IAMX_BV(13) IAMX_BV(14) IAMX_BV(15) IAMX_BV(16)
-#undef IAMX_BV
-    default: launch_blur_v<0>(st, src, h, w, tp, dst, prev, dog); break;
-    }
-}
-
-// Both passes in ONE launch for the big octaves (the two-pass form above moves 7.5 floats per
-// pixel and level through memory -- tmp written and re-read 1 + 2R/8 times, prev re-read for the
-// DoG --, this one 3: source in, level and DoG out).  A workgroup owns a FB_TW x FB_TH tile:
-//   1. the source tile with its R-pixel frame goes to LDS (reflect-101 at the image borders, in
-//      x and in y: a frame row outside the image IS the row the vertical pass of the two-pass
-//      form would have read),
-//   2. horizontal pass over all FB_TH + 2R rows into a second LDS tile: a thread takes strips of
-//      8 consecutive outputs with the 8 + 2R inputs in registers,
-//   3. vertical pass: a thread owns one column and 8 rows, window in registers as in
-//      blur_v_kernel; writes the level and, fused, DoG = level - source.
-// Same taps, same ascending order, separately rounded multiply and add => bit-identical levels.
-constexpr int FB_TW = 64, FB_TH = 32, FB_STRIP = 8;
-
-template <int R>
-__global__ __launch_bounds__(256) void blur_fused_kernel(const float *__restrict__ src, int h, int w,
+__global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict__ src, int h, int w,
                                                          Taps T, float *__restrict__ dst,
-                                                         float *__restrict__ dog)
+                                                         float *__restrict__ dog, int seg_rows)
 {
-    constexpr int SW = FB_TW + 2 * R + 1;                 // (+1: odd row pitch)
-    constexpr int SH = FB_TH + 2 * R;
-    constexpr int HW = FB_TW + 1;
-    __shared__ float S[SH * SW];
-    __shared__ float Hb[SH * HW];
-    const int x0 = blockIdx.x * FB_TW, y0 = blockIdx.y * FB_TH;
-    // 1. source tile + frame
-    for (int e = threadIdx.x; e < SH * (FB_TW + 2 * R); e += 256) {
-        const int ry = e / (FB_TW + 2 * R), rx = e - ry * (FB_TW + 2 * R);
-        int yy = y0 - R + ry, xx = x0 - R + rx;
-        yy = (yy >= 0 && yy < h) ? yy : reflect101(yy, h);
-        xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
-        S[ry * SW + rx] = src[(int64_t)yy * w + xx];
-    }
-    __syncthreads();
-    // 2. horizontal pass: strips of FB_STRIP outputs
-    constexpr int STRIPS_PER_ROW = FB_TW / FB_STRIP;
-    for (int sidx = threadIdx.x; sidx < SH * STRIPS_PER_ROW; sidx += 256) {
-        const int ry = sidx / STRIPS_PER_ROW, sx = (sidx - ry * STRIPS_PER_ROW) * FB_STRIP;
-        float win[FB_STRIP + 2 * R];
-#pragma unroll
-        for (int i = 0; i < FB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
-#pragma unroll
-        for (int j = 0; j < FB_STRIP; ++j) {
-            float acc = 0.f;
-#pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
-            Hb[ry * HW + sx + j] = acc;
+    static_assert(2 * R <= SB_RING - SB_TH, "the V window must fit the ring");
+    constexpr int SW = SB_TW + 2 * R + 1;                 // (+1: odd row pitch)
+    constexpr int HW = SB_TW + 1;
+    __shared__ float S[SB_TH * SW];
+    __shared__ float Hb[SB_RING * HW];
+    const int x0 = blockIdx.x * SB_TW;
+    const int y_begin = blockIdx.y * seg_rows;
+    const int y_end = min(y_begin + seg_rows, h);
+    // H block k: source rows [y_begin - R + SB_TH k, + SB_TH) -> ring rows (SB_TH k + ry) & 63
+    auto hblock = [&](int k) {
+        const int ybase = y_begin - R + SB_TH * k;
+        for (int e = threadIdx.x; e < SB_TH * (SB_TW + 2 * R); e += 256) {
+            const int ry = e / (SB_TW + 2 * R), rx = e - ry * (SB_TW + 2 * R);
+            int yy = ybase + ry, xx = x0 - R + rx;
+            yy = (yy >= 0 && yy < h) ? yy : reflect101(yy, h);
+            xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
+            S[ry * SW + rx] = src[(int64_t)yy * w + xx];
         }
-    }
-    __syncthreads();
-    // 3. vertical pass: column cx, rows [8 g, 8 g + 8) of the tile
-    const int cx = threadIdx.x & (FB_TW - 1), g = threadIdx.x / FB_TW;
+        __syncthreads();
+        {
+            const int ry = threadIdx.x / (SB_TW / SB_STRIP), sx = (threadIdx.x % (SB_TW / SB_STRIP)) * SB_STRIP;
+            float win[SB_STRIP + 2 * R];
+#pragma unroll
+            for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
+            float *hrow = Hb + ((SB_TH * k + ry) & (SB_RING - 1)) * HW + sx;
+#pragma unroll
+            for (int j = 0; j < SB_STRIP; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
+                hrow[j] = acc;
+            }
+        }
+        __syncthreads();
+    };
+    hblock(0);
+    const int cx = threadIdx.x & (SB_TW - 1), g = threadIdx.x / SB_TW;
     const int x = x0 + cx;
-    if (x >= w) return;
-    float win[FB_STRIP + 2 * R];
+    const int n_blocks = (y_end - y_begin + SB_TH - 1) / SB_TH;
+    for (int b = 0; b < n_blocks; ++b) {
+        hblock(b + 1);
+        // V block b: output rows y_begin + SB_TH b + 8 g + j; source row y' sits in ring row
+        // (y' - (y_begin - R)) & 63, so the window of output row y starts at (y - y_begin) & 63
+        const int y0 = y_begin + SB_TH * b + g * SB_STRIP;
+        if (x < w && y0 < y_end) {
+            float win[SB_STRIP + 2 * R];
 #pragma unroll
-    for (int i = 0; i < FB_STRIP + 2 * R; ++i) win[i] = Hb[(g * FB_STRIP + i) * HW + cx];
+            for (int i = 0; i < SB_STRIP + 2 * R; ++i)
+                win[i] = Hb[((SB_TH * b + g * SB_STRIP + i) & (SB_RING - 1)) * HW + cx];
 #pragma unroll
-    for (int j = 0; j < FB_STRIP; ++j) {
-        const int y = y0 + g * FB_STRIP + j;
-        if (y < h) {
-            float acc = 0.f;
+            for (int j = 0; j < SB_STRIP; ++j) {
+                const int y = y0 + j;
+                if (y < y_end) {
+                    float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) acc = add_rn(acc, mul_rn(win[j + t], T.k[t]));
-            const int64_t i = (int64_t)y * w + x;
-            dst[i] = acc;
-            if (dog) dog[i] = sub_rn(acc, S[(g * FB_STRIP + j + R) * SW + cx + R]);
+                    for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
+                    const int64_t i = (int64_t)y * w + x;
+                    dst[i] = acc;
+                    if (dog) dog[i] = sub_rn(acc, src[i]);
+                }
+            }
         }
     }
 }
 
 template <int R>
-void launch_blur_fused(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
+void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
                        float *dog)
 {
-    static_assert(256 / FB_TW * FB_STRIP == FB_TH, "the vertical pass covers the tile");
-    hipLaunchKernelGGL(blur_fused_kernel<R>, dim3((w + FB_TW - 1) / FB_TW, (h + FB_TH - 1) / FB_TH),
-                       dim3(256), 0, st, src, h, w, tp, dst, dog);
+    static_assert(256 / SB_TW * SB_STRIP == SB_TH && SB_TH * (SB_TW / SB_STRIP) == 256,
+                  "thread maps of the two passes cover a block");
+    const int strips = (w + SB_TW - 1) / SB_TW;
+    // rows per workgroup: long segments amortise the one extra H block per segment, short ones
+    // fill the chip (>= ~768 workgroups when the level is large enough)
+    int seg = (int)(((int64_t)h * strips / 768 + SB_TH - 1) / SB_TH) * SB_TH;
+    seg = seg < SB_TH ? SB_TH : (seg > 256 ? 256 : seg);
+    hipLaunchKernelGGL(blur_strip_kernel<R>, dim3(strips, (h + seg - 1) / seg), dim3(256), 0, st, src, h,
+                       w, tp, dst, dog, seg);
 }
 
-// false: this radius has no fused instantiation (the caller runs the two passes)
-bool blur_fused(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst, float *dog)
+// every radius gaussian_taps() can produce (r <= 16)
+void blur_level(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst, float *dog)
 {
     switch (tp.r) {
-#define IAMX_BF(r) case r: launch_blur_fused<r>(st, src, h, w, tp, dst, dog); return true;
-        IAMX_BF(1) IAMX_BF(2) IAMX_BF(3) IAMX_BF(4) IAMX_BF(5) IAMX_BF(6) IAMX_BF(7) IAMX_BF(8)
-        IAMX_BF(9) IAMX_BF(10) IAMX_BF(11) IAMX_BF(12) IAMX_BF(13) IAMX_BF(14) IAMX_BF(15) IAMX_BF(16)
-#undef IAMX_BF
-    default: return false;
+#define IAMX_BS(r) case r: launch_blur_strip<r>(st, src, h, w, tp, dst, dog); break;
+        IAMX_BS(1) IAMX_BS(2) IAMX_BS(3) IAMX_BS(4) IAMX_BS(5) IAMX_BS(6) IAMX_BS(7) IAMX_BS(8)
+        IAMX_BS(9) IAMX_BS(10) IAMX_BS(11) IAMX_BS(12) IAMX_BS(13) IAMX_BS(14) IAMX_BS(15)
+#undef IAMX_BS
+    default: launch_blur_strip<16>(st, src, h, w, tp, dst, dog); break;
     }
 }
 
@@ -373,126 +307,6 @@ struct PyrTable {
     Pyr oct[MAX_OCT];
     int n_oct;
 };
-
-// The small octaves (<= TAIL_PIXELS pixels per level) are launch bound when every blur pass is
-// its own kernel (~11 launches per octave, 12 us each for a few microseconds of work): ONE
-// workgroup builds all of them in one launch with the current level and the horizontal pass
-// held in LDS (2 x 64 KiB) -- downsample, 5 x (horizontal pass, vertical pass + DoG) per octave,
-// workgroup barriers in between.  Same taps, same tap order, same round-to-nearest mul/add as
-// blur_h_kernel / blur_v_kernel: bit-identical levels.
-constexpr int TAIL_PIXELS = 16384;
-
-struct TapSet {
-    Taps t[NL + 2];              // layers 1 .. NL+2 (sigma of the incremental blurs)
-};
-
-__global__ __launch_bounds__(1024) void pyramid_tail_kernel(PyrTable T, int o_first, TapSet TS)
-{
-    __shared__ float cur[TAIL_PIXELS];       // level l-1 of the octave
-    __shared__ float hor[TAIL_PIXELS];       // its horizontal pass
-    __shared__ float sk[MAX_TAPS];
-    for (int o = o_first; o < T.n_oct; ++o) {
-        const int H = T.oct[o].h, W = T.oct[o].w;
-        const int npx = H * W;
-        {
-            const float *src = T.oct[o - 1].g[NL];
-            const int sw = T.oct[o - 1].w;
-            float *dst = T.oct[o].g[0];
-            for (int i = threadIdx.x; i < npx; i += 1024) {
-                const int x = i % W, y = i / W;
-                const float v = src[(int64_t)(2 * y) * sw + 2 * x];
-                dst[i] = v;
-                cur[i] = v;
-            }
-        }
-        __syncthreads();
-        for (int l = 1; l < NL + 3; ++l) {
-            // the taps in LDS: indexing the kernel argument with a runtime tap number is a
-            // scalar memory load per tap
-            const int r = TS.t[l - 1].r;
-            if (threadIdx.x <= 2 * r) sk[threadIdx.x] = TS.t[l - 1].k[threadIdx.x];
-            __syncthreads();
-            float *dst = T.oct[o].g[l], *dog = T.oct[o].d[l - 1];
-            // four pixels of a thread at a time: four independent tap chains hide the LDS latency
-            // (one chain at a time ran at ~100 cycles per tap)
-            constexpr int PPT = TAIL_PIXELS / 1024;
-            // BORDER_REFLECT_101 without the modulo while the radius is smaller than the image
-            const bool simple = r < W && r < H;
-            for (int g0 = 0; g0 < PPT; g0 += 4) {
-                int base[4], pos[4];
-                bool in[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = threadIdx.x + 1024 * (g0 + j);
-                    in[j] = i < npx;
-                    const int ii = in[j] ? i : 0;
-                    pos[j] = ii % W;
-                    base[j] = ii - pos[j];
-                }
-                if (!in[0]) break;
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int t = 0; t <= 2 * r; ++t) {
-                    const float kt = sk[t];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        int xx = pos[j] - r + t;
-                        if (simple) { xx = xx < 0 ? -xx : xx; xx = xx >= W ? 2 * (W - 1) - xx : xx; }
-                        else xx = reflect101(xx, W);
-                        const float v = cur[base[j] + xx];
-                        acc[j] = add_rn(acc[j], mul_rn(v, kt));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (in[j]) hor[threadIdx.x + 1024 * (g0 + j)] = acc[j];
-            }
-            __syncthreads();
-            float out[PPT];
-            for (int g0 = 0; g0 < PPT; g0 += 4) {
-                int col[4], rowi[4];
-                bool in[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = threadIdx.x + 1024 * (g0 + j);
-                    in[j] = i < npx;
-                    const int ii = in[j] ? i : 0;
-                    col[j] = ii % W;
-                    rowi[j] = ii / W;
-                }
-                float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                if (in[0]) {
-                    for (int t = 0; t <= 2 * r; ++t) {
-                        const float kt = sk[t];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int yy = rowi[j] - r + t;
-                            if (simple) { yy = yy < 0 ? -yy : yy; yy = yy >= H ? 2 * (H - 1) - yy : yy; }
-                            else yy = reflect101(yy, H);
-                            const float v = hor[yy * W + col[j]];
-                            acc[j] = add_rn(acc[j], mul_rn(v, kt));
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = threadIdx.x + 1024 * (g0 + j);
-                    out[g0 + j] = acc[j];
-                    if (in[j]) {
-                        dst[i] = acc[j];
-                        dog[i] = sub_rn(acc[j], cur[i]);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < TAIL_PIXELS / 1024; ++k) {
-                const int i = threadIdx.x + 1024 * k;
-                if (i < npx) cur[i] = out[k];
-            }
-            __syncthreads();
-        }
-    }
-}
 
 __device__ bool solve3(double A[3][3], double b[3], double x[3])
 {
@@ -1090,7 +904,7 @@ struct Layout {
     int n_oct;
     int h[MAX_OCT], w[MAX_OCT];
     int64_t g_off[MAX_OCT][6], d_off[MAX_OCT][5];
-    int64_t tmp_off, cand_off, refined_off, count_off, total;
+    int64_t cand_off, refined_off, count_off, total;
 };
 
 Layout make_layout(int height, int width, int cap_c)
@@ -1110,7 +924,6 @@ Layout make_layout(int height, int width, int cap_c)
         H /= 2; W /= 2;
         if (H < 1 || W < 1) { L.n_oct = o + 1; break; }
     }
-    L.tmp_off = take((int64_t)L.h[0] * L.w[0] * 4);
     L.cand_off = take((int64_t)cap_c * sizeof(Cand));
     L.refined_off = take((int64_t)cap_c * sizeof(Refined));
     L.count_off = take(256);
@@ -1179,7 +992,6 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         for (int i = 0; i < 6; ++i) T.oct[o].g[i] = reinterpret_cast<float *>(ws + L.g_off[o][i]);
         for (int i = 0; i < 5; ++i) T.oct[o].d[i] = reinterpret_cast<float *>(ws + L.d_off[o][i]);
     }
-    float *tmp = reinterpret_cast<float *>(ws + L.tmp_off);
     Cand *cand = reinterpret_cast<Cand *>(ws + L.cand_off);
     Refined *refined = reinterpret_cast<Refined *>(ws + L.refined_off);
     int *n_cand = reinterpret_cast<int *>(ws + L.count_off);
@@ -1199,28 +1011,22 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         sig[i] = sqrt(stt * stt - sp * sp);
     }
     // dst = G_sigma * src; with `dog` also dog = dst - src (the DoG level between the two)
-    auto blur = [&](const float *src, float *dst, int h, int w, double s, float *dog) {
-        Taps tp;
-        gaussian_taps(s, tp);
-        if (blur_fused(st, src, h, w, tp, dst, dog)) return;
-        hipLaunchKernelGGL(blur_h_kernel, dim3((w + BLUR_TW - 1) / BLUR_TW, h), dim3(256), 0, st, src,
-                           h, w, tp, tmp);
-        blur_v(st, tmp, h, w, tp, dst, src, dog);
-    };
+    Taps taps[NL + 3];
+    for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], taps[i]);
+    auto blur = [&](hipStream_t q, const float *src, float *dst, int h, int w, const Taps &tp,
+                    float *dog) { blur_level(q, src, h, w, tp, dst, dog); };
     // base image: gray -> x2 -> blur(sqrt(sigma^2 - 1))
     {
         const int H = L.h[0], W = L.w[0];
         float *up = T.oct[0].d[0];             // scratch (overwritten by the DoG later)
         hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)H * W, 256)), dim3(256), 0, st,
                            image, height, width, channels, up);
-        const double sd = sqrt(fmax(sigma_d * sigma_d - 1.0, 0.01));
-        blur(up, T.oct[0].g[0], H, W, sd, nullptr);
+        Taps tb;
+        gaussian_taps(sqrt(fmax(sigma_d * sigma_d - 1.0, 0.01)), tb);
+        blur(st, up, T.oct[0].g[0], H, W, tb, nullptr);
     }
     const float threshold = floorf(0.5f * contrast_threshold / NL * 255.f);
-    // octaves from o_tail on (small images) are built by one workgroup in one launch
-    int o_tail = L.n_oct;
-    for (int o = L.n_oct - 1; o >= 1 && (int64_t)L.h[o] * L.w[o] <= TAIL_PIXELS; --o) o_tail = o;
-    auto extrema = [&](int o) {
+    auto extrema = [&](hipStream_t q, int o) {
         const int H = L.h[o], W = L.w[o];
         if (H > 2 * BORDER && W > 2 * BORDER) {
             DogStack D;
@@ -1228,40 +1034,48 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
             hipLaunchKernelGGL(extrema_kernel,
                                dim3((unsigned)((W - 2 * BORDER + 61) / 62),
                                     (unsigned)((H - 2 * BORDER + 4 * EXT_RPT - 1) / (4 * EXT_RPT))),
-                               dim3(256), 0, st, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
+                               dim3(256), 0, q, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
         }
     };
-    // Issue order: the chain that leads to the small octaves first -- levels 1..NL of every big
-    // octave (level NL is the next octave's source) --, then the one-workgroup tail kernel on a
-    // second stream, and beside it the remaining two levels and the extrema scans of the big
-    // octaves on the caller's stream (the tail is a 0.5 ms latency chain on one CU).
-    for (int o = 0; o < o_tail; ++o) {
-        if (o > 0)
-            hipLaunchKernelGGL(downsample_kernel, dim3(blocks((int64_t)L.h[o] * L.w[o], 256)), dim3(256), 0, st,
-                               T.oct[o - 1].g[NL], L.w[o - 1], L.h[o], L.w[o], T.oct[o].g[0]);
+    auto downsample = [&](hipStream_t q, int o) {
+        hipLaunchKernelGGL(downsample_kernel, dim3(blocks((int64_t)L.h[o] * L.w[o], 256)), dim3(256), 0, q,
+                           T.oct[o - 1].g[NL], L.w[o - 1], L.h[o], L.w[o], T.oct[o].g[0]);
+    };
+    // The levels of an octave depend on each other and octave o + 1 starts from level NL of octave
+    // o, so the pyramid is one dependency chain whose links get small quickly: from octave
+    // SIDE_OCTAVE on (<= 1/64 of the pixels of octave 0) a level is a few workgroups and its cost
+    // is the launch.  Issue order: levels 1..NL of the big octaves (the chain that leads to the
+    // small ones) first, then the small octaves -- all their levels and extrema scans -- on a second
+    // stream beside the remaining two levels and the extrema scans of the big octaves.
+    constexpr int SIDE_OCTAVE = 3;
+    const int o_side = L.n_oct < SIDE_OCTAVE ? L.n_oct : SIDE_OCTAVE;
+    for (int o = 0; o < o_side; ++o) {
+        if (o > 0) downsample(st, o);
         for (int i = 1; i <= NL; ++i)
-            blur(T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], sig[i], T.oct[o].d[i - 1]);
+            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
     }
     SideStream *side = nullptr;
-    if (o_tail < L.n_oct) {
-        TapSet TS;
-        for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], TS.t[i - 1]);
+    if (o_side < L.n_oct) {
         side = side_stream();
         hipStream_t ts = side ? side->stream : st;
         if (side) {
             (void)hipEventRecord(side->fork, st);
             (void)hipStreamWaitEvent(ts, side->fork, 0);
         }
-        hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, ts, T, o_tail, TS);
+        for (int o = o_side; o < L.n_oct; ++o) {
+            downsample(ts, o);
+            for (int i = 1; i < NL + 3; ++i)
+                blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+            extrema(ts, o);
+        }
         if (side) (void)hipEventRecord(side->join, ts);
     }
-    for (int o = 0; o < o_tail; ++o) {
+    for (int o = 0; o < o_side; ++o) {
         for (int i = NL + 1; i < NL + 3; ++i)
-            blur(T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], sig[i], T.oct[o].d[i - 1]);
-        extrema(o);
+            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+        extrema(st, o);
     }
     if (side) (void)hipStreamWaitEvent(st, side->join, 0);
-    for (int o = o_tail; o < L.n_oct; ++o) extrema(o);
     // the number of candidates is only known on the device: launch for the capacity in slabs
     // sized by the largest plausible count (threads beyond *n_cand exit immediately)
     hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,

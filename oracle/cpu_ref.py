@@ -13,7 +13,8 @@ _lib = None
 
 def build(force=False):
     if force or not os.path.exists(_SO) or \
-            os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, 'cpu_ref.c')):
+            os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
+                                        for f in ('cpu_ref.c', 'sift_ref.c', 'Makefile')):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle_cpu.so'],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -83,3 +84,54 @@ def ba_residual(cams, pts, cam_idx, pt_idx, uv, intr, dist, nthreads=0):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+# ---- oracle/sift_ref.c: the hot loops of sift_oracle.py
+def sift_blur(img, taps, nthreads=0):
+    img = np.ascontiguousarray(img, np.float32)
+    taps = np.ascontiguousarray(taps, np.float32)
+    out = np.empty_like(img)
+    rc = lib().oracle_sift_blur(_p(img), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]),
+                                _p(taps), ctypes.c_int(len(taps) // 2), _p(out), ctypes.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_sift_blur rc=%d" % rc)
+    return out
+
+
+def _ptr_array(arrays):
+    return (ctypes.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+
+
+def sift_keypoints(dogs, gauss, octave, cand, sigma0, nthreads=0):
+    """dogs / gauss: the float32 levels of one octave; cand int32 [n,3] (layer, r, c) ->
+    keypoints float64 [m,6] in the candidates' order"""
+    dogs = [np.ascontiguousarray(d, np.float32) for d in dogs]
+    gauss = [np.ascontiguousarray(g, np.float32) for g in gauss]
+    cand = np.ascontiguousarray(cand, np.int32).reshape(-1, 3)
+    h, w = dogs[0].shape
+    cap = max(4 * len(cand), 16)
+    L = lib()
+    L.oracle_sift_keypoints.restype = ctypes.c_int
+    while True:
+        kps = np.empty((cap, 6), np.float64)
+        n = L.oracle_sift_keypoints(_ptr_array(dogs), _ptr_array(gauss), ctypes.c_int(h),
+                                    ctypes.c_int(w), ctypes.c_int(octave), _p(cand),
+                                    ctypes.c_int(len(cand)), ctypes.c_double(sigma0), _p(kps),
+                                    ctypes.c_int(cap), ctypes.c_int(nthreads))
+        if n < 0:
+            raise ValueError("oracle_sift_keypoints rc=%d" % n)
+        if n <= cap:
+            return kps[:n]
+        cap = n
+
+
+def sift_descriptors(img, par, nthreads=0):
+    """img: one Gaussian level; par float64 [n,4] (ptx, pty, ori, scl) -> uint8 [n,128]"""
+    img = np.ascontiguousarray(img, np.float32)
+    par = np.ascontiguousarray(par, np.float64).reshape(-1, 4)
+    desc = np.empty((len(par), 128), np.uint8)
+    rc = lib().oracle_sift_descriptors(_p(img), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]),
+                                       _p(par), ctypes.c_int(len(par)), _p(desc), ctypes.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_sift_descriptors rc=%d" % rc)
+    return desc

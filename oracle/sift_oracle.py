@@ -13,6 +13,14 @@ edgeThreshold=10, sigma=1.6, first octave -1 (image doubled, assumed pre-blur 0.
 x512 u8 quantisation, keypoint `octave` packing octave | layer<<8 | round((xi+0.5)*255)<<16 --
 and is what the HIP kernels (csrc/sift.hip) are tested against.  Agreement with a real
 cv2.SIFT would have to be statistical (float filters differ in the last bits).
+
+Arithmetic conventions (this file is their definition; oracle/sift_ref.c restates the hot loops
+in C with OpenMP, and the *_py functions here are their numpy twins, compared in
+tests/test_oracle.py): the Gaussian taps are accumulated with ONE rounding per tap, acc =
+fma(v, k[t], acc) from 0 in ascending tap order -- a filter compiled for FMA hardware -- (rounds
+1-2 rounded product and sum separately, the numpy expression `acc += v * k`); everything else in
+the pyramid is separately rounded float32; refinement solves, orientation histograms and
+descriptors are float64.
 """
 import math
 
@@ -90,20 +98,49 @@ def _reflect101(idx, n):
     return np.where(idx >= n, period - idx, idx)
 
 
-def gaussian_blur(img, sigma):
-    """separable, BORDER_REFLECT_101, float32 accumulation in tap order."""
+def fma32(a, b, c):
+    """float32 fused multiply-add a * b + c with ONE rounding (v_fma_f32 / fmaf), exactly: the
+    product of two float32 is exact in float64; the float64 sum with c is rounded to 53 bits
+    first, which only matters when it lands exactly on a float32 tie -- then the exact error of
+    the sum (TwoSum) says on which side of the tie the true value lies."""
+    p = a.astype(np.float64) * np.float64(b)
+    c64 = np.asarray(c, np.float64)
+    s = p + c64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)                   # s + err = p + c exactly
+    r = s.astype(np.float32)
+    d = s - r.astype(np.float64)                        # exact
+    other = np.nextafter(r, np.where(d > 0, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32))
+    tie = (d != 0) & ((r.astype(np.float64) + other.astype(np.float64)) * 0.5 == s) & (err != 0)
+    if np.any(tie):
+        # ties-to-even picked r from s; the true value is s + err
+        toward_other = np.sign(err) == np.sign(d)
+        r = np.where(tie & toward_other, other, r)
+        # (tie & ~toward_other: the true value is on r's side of the midpoint... unless
+        #  ties-to-even had picked the far candidate, which float32(s) never does for r)
+    return r.astype(np.float32)
+
+
+def gaussian_blur_py(img, sigma):
+    """separable, BORDER_REFLECT_101, fused multiply-add taps in ascending order (numpy twin of
+    oracle/sift_ref.c blur_rows)."""
     k = gaussian_kernel(sigma)
     r = len(k) // 2
     h, w = img.shape
     xs = np.arange(w)
     tmp = np.zeros_like(img)
     for t in range(-r, r + 1):
-        tmp += img[:, _reflect101(xs + t, w)] * k[t + r]
+        tmp = fma32(img[:, _reflect101(xs + t, w)], k[t + r], tmp)
     ys = np.arange(h)
     out = np.zeros_like(img)
     for t in range(-r, r + 1):
-        out += tmp[_reflect101(ys + t, h), :] * k[t + r]
+        out = fma32(tmp[_reflect101(ys + t, h), :], k[t + r], out)
     return out
+
+
+def gaussian_blur(img, sigma):
+    from . import cpu_ref
+    return cpu_ref.sift_blur(img, gaussian_kernel(sigma))
 
 
 def layer_sigmas():
@@ -139,6 +176,34 @@ def build_pyramids(bgr_or_gray):
     return gauss, dog
 
 
+def _solve3(A, b):
+    """Gaussian elimination with partial pivoting (cv::Matx::solve(DECOMP_LU)): the operation
+    sequence sift_ref.c and the device use, so the refined offsets agree to the last bit"""
+    A = [[float(v) for v in row] for row in A]
+    b = [float(v) for v in b]
+    p = [0, 1, 2]
+    for k in range(3):
+        piv, best = k, abs(A[p[k]][k])
+        for i in range(k + 1, 3):
+            if abs(A[p[i]][k]) > best:
+                best, piv = abs(A[p[i]][k]), i
+        if best < 1e-300:
+            return None
+        p[k], p[piv] = p[piv], p[k]
+        for i in range(k + 1, 3):
+            f = A[p[i]][k] / A[p[k]][k]
+            for j in range(k, 3):
+                A[p[i]][j] -= f * A[p[k]][j]
+            b[p[i]] -= f * b[p[k]]
+    x = [0.0, 0.0, 0.0]
+    for k in (2, 1, 0):
+        s = b[p[k]]
+        for j in range(k + 1, 3):
+            s -= A[p[k]][j] * x[j]
+        x[k] = s / A[p[k]][k]
+    return x
+
+
 def _adjust_local_extrema(dogs, layer, r, c):
     """3-D quadratic refinement; returns None or (layer, r, c, xi, xr, xc, contr)."""
     img_scale = F(1.0 / 255.0)
@@ -160,9 +225,8 @@ def _adjust_local_extrema(dogs, layer, r, c):
         dxs = (nxt[r, c + 1] - nxt[r, c - 1] - prv[r, c + 1] + prv[r, c - 1]) * cross_scale
         dys = (nxt[r + 1, c] - nxt[r - 1, c] - prv[r + 1, c] + prv[r - 1, c]) * cross_scale
         H = np.array([[dxx, dxy, dxs], [dxy, dyy, dys], [dxs, dys, dss]], np.float32)
-        try:
-            X = np.linalg.solve(H.astype(np.float64), dD.astype(np.float64))
-        except np.linalg.LinAlgError:
+        X = _solve3(H.astype(np.float64), dD.astype(np.float64))
+        if X is None:
             return None
         xc, xr, xi = -X[0], -X[1], -X[2]
         if abs(xi) < 0.5 and abs(xr) < 0.5 and abs(xc) < 0.5:
@@ -227,8 +291,9 @@ def _orientation_hist(img, r, c, radius, sigma):
     return sm
 
 
-def detect(bgr_or_gray):
-    """-> (keypoints [N,6] float64: x, y, size, angle, response, octave(packed int), pyramids)"""
+def detect(bgr_or_gray, use_c=True):
+    """-> (keypoints [N,6] float64: x, y, size, angle, response, octave(packed int), pyramids).
+    use_c: refinement + orientation through oracle/sift_ref.c (OpenMP), else the numpy twin."""
     gauss, dog = build_pyramids(bgr_or_gray)
     threshold = math.floor(0.5 * CONTRAST_THRESHOLD / N_OCTAVE_LAYERS * 255)
     kps = []
@@ -236,6 +301,7 @@ def detect(bgr_or_gray):
         h, w = dogs[0].shape
         if h <= 2 * IMG_BORDER or w <= 2 * IMG_BORDER:
             continue
+        cands = []
         for layer in range(1, N_OCTAVE_LAYERS + 1):
             cur = dogs[layer]
             core = cur[IMG_BORDER:h - IMG_BORDER, IMG_BORDER:w - IMG_BORDER]
@@ -251,6 +317,9 @@ def detect(bgr_or_gray):
                         is_max &= core >= sh
                         is_min &= core <= sh
             rr, cc = np.nonzero(is_max | is_min)
+            if use_c:
+                cands.append(np.stack([np.full(len(rr), layer), rr + IMG_BORDER, cc + IMG_BORDER], 1))
+                continue
             for r, c in zip(rr + IMG_BORDER, cc + IMG_BORDER):
                 res = _adjust_local_extrema(dogs, layer, int(r), int(c))
                 if res is None:
@@ -275,6 +344,9 @@ def detect(bgr_or_gray):
                         if abs(angle - 360.0) < FLT_EPSILON:
                             angle = 0.0
                         kps.append([px, py, size, angle, abs(contr), octave])
+        if use_c and cands:
+            from . import cpu_ref
+            kps.extend(cpu_ref.sift_keypoints(dogs, gauss[o], o, np.concatenate(cands), SIGMA).tolist())
     kps = np.array(kps, np.float64).reshape(-1, 6)
     # first octave is -1: rescale to the input image (detectAndCompute)
     if len(kps):
@@ -351,20 +423,30 @@ def descriptor(img, ptx, pty, ori, scl):
     return np.clip(np.rint(dst * nrm), 0, 255).astype(np.uint8)
 
 
-def detect_and_compute(bgr_or_gray):
+def detect_and_compute(bgr_or_gray, use_c=True):
     """-> keypoints [N,6] (x, y, size, angle, response, packed octave), descriptors [N,128] u8,
-    sorted canonically by (octave, layer, y, x, angle)."""
-    kps, gauss = detect(bgr_or_gray)
+    sorted canonically by (octave, layer, y, x, angle).  use_c: the per-keypoint loops through
+    oracle/sift_ref.c (OpenMP), else their numpy twins (small images only)."""
+    kps, gauss = detect(bgr_or_gray, use_c=use_c)
     des = np.zeros((len(kps), 128), np.uint8)
     # cv2.KeyPoint fields are float32: the descriptor stage sees the rounded values
     kps[:, :5] = kps[:, :5].astype(np.float32).astype(np.float64)
+    par = np.zeros((len(kps), 4))
+    level = np.zeros((len(kps), 2), np.int64)
     for k, (x, y, size, angle, resp, packed) in enumerate(kps):
         octave, layer, scale = unpack_octave(packed)
-        img = gauss[octave + 1][layer]
         a = 360.0 - angle
         if abs(a - 360.0) < FLT_EPSILON:
             a = 0.0
-        des[k] = descriptor(img, x * scale, y * scale, a, size * scale * 0.5)
+        par[k] = (x * scale, y * scale, a, size * scale * 0.5)
+        level[k] = (octave + 1, layer)
+        if not use_c:
+            des[k] = descriptor(gauss[octave + 1][layer], *par[k])
+    if use_c and len(kps):
+        from . import cpu_ref
+        for o, layer in sorted(set(map(tuple, level.tolist()))):
+            sel = np.nonzero((level[:, 0] == o) & (level[:, 1] == layer))[0]
+            des[sel] = cpu_ref.sift_descriptors(gauss[o][layer], par[sel])
     if len(kps):
         oc = kps[:, 5].astype(np.int64)
         order = np.lexsort((des[:, 0], kps[:, 3], kps[:, 0], kps[:, 1], (oc >> 8) & 255,

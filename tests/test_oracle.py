@@ -127,3 +127,80 @@ def test_c_knn2_batch_equals_single():
     for p, (a, b) in enumerate(pairs):
         i, d = cpu_ref.knn2_l2_u8(imgs[a], imgs[b])
         assert np.array_equal(i, idx[p]) and np.array_equal(d, d2[p])
+
+
+# ---- oracle/sift_ref.c (the hot loops of sift_oracle.py in C) against its numpy twins -----------
+def _texture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = np.zeros((h, w), np.float64)
+    for s in (2, 4, 8, 16):
+        g = rng.normal(size=(h // s + 2, w // s + 2))
+        img += np.kron(g, np.ones((s, s)))[:h, :w] * s ** 0.7
+    img = (img - img.min()) / (img.max() - img.min()) * 255
+    return img.clip(0, 255).astype(np.uint8)
+
+
+def test_fma32_emulation_is_the_fused_multiply_add():
+    """sift_oracle.fma32 (the definition of the oracle's Gaussian taps in numpy) == fmaf, also
+    where the float64 sum lands exactly on a float32 tie (double rounding)"""
+    from oracle import sift_oracle as so
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=200000).astype(np.float32) * np.float32(100)
+    c = rng.normal(size=200000).astype(np.float32)
+    k = np.float32(0.12345678)
+    want = np.array([np.float32(__import__('math').fma(float(x), float(k), float(y)))
+                     for x, y in zip(a[:2000], c[:2000])]) if hasattr(__import__('math'), 'fma') else None
+    got = so.fma32(a, k, c)
+    if want is not None:
+        assert np.array_equal(got[:2000], want)
+    # against the C library's fmaf through the oracle's blur: a 1 x n image and a one-tap kernel
+    # is n independent fmaf(v, k, 0); a 3-tap kernel chains them
+    from oracle import cpu_ref
+    img = a.reshape(400, 500)
+    taps = np.array([0.25, 0.5, 0.25], np.float32)
+    assert np.array_equal(cpu_ref.sift_blur(img, taps), _blur_py(img, taps))
+    # a constructed double-rounding case: a*b exact = 1 + 2^-24 + 2^-60-ish relative to c
+    x = np.array([1.0 + 2.0 ** -12], np.float32)
+    y = np.float32(1.0 + 2.0 ** -12)
+    cc = np.array([2.0 ** -30], np.float32)
+    p = float(x[0]) * float(y) + float(cc[0])          # not representable: reference by fractions
+    from fractions import Fraction
+    exact = Fraction(float(x[0])) * Fraction(float(y)) + Fraction(float(cc[0]))
+    lo = np.float32(float(exact))
+    cands = [lo, np.nextafter(lo, np.float32(np.inf)), np.nextafter(lo, np.float32(-np.inf))]
+    best = min(cands, key=lambda v: abs(Fraction(float(v)) - exact))
+    assert so.fma32(x, y, cc)[0] == best and p == p
+
+
+def _blur_py(img, taps):
+    from oracle import sift_oracle as so
+    r = len(taps) // 2
+    h, w = img.shape
+    xs, ys = np.arange(w), np.arange(h)
+    tmp = np.zeros_like(img)
+    for t in range(-r, r + 1):
+        tmp = so.fma32(img[:, so._reflect101(xs + t, w)], taps[t + r], tmp)
+    out = np.zeros_like(img)
+    for t in range(-r, r + 1):
+        out = so.fma32(tmp[so._reflect101(ys + t, h), :], taps[t + r], out)
+    return out
+
+
+@pytest.mark.parametrize('shape', [(61, 83), (9, 40), (128, 20)])
+def test_c_blur_equals_numpy_twin(shape):
+    """BORDER_REFLECT_101 with radii larger than the image included"""
+    from oracle import sift_oracle as so
+    img = _texture(shape[0], shape[1], 3).astype(np.float32)
+    for sigma in (1.2263, 3.09, 1.6):
+        assert np.array_equal(so.gaussian_blur(img, sigma), so.gaussian_blur_py(img, sigma))
+
+
+def test_c_keypoints_and_descriptors_equal_numpy_twins():
+    from oracle import sift_oracle as so
+    img = _texture(120, 150, 7)
+    ka, da = so.detect_and_compute(img, use_c=True)
+    kb, db = so.detect_and_compute(img, use_c=False)
+    assert len(ka) == len(kb) > 150
+    assert np.array_equal(ka[:, 5], kb[:, 5])
+    assert np.abs(ka[:, :5] - kb[:, :5]).max() < 1e-9       # same operations: libm's last bits at most
+    assert (da != db).mean() < 1e-3 and np.abs(da.astype(int) - db.astype(int)).max() <= 1

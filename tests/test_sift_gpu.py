@@ -138,13 +138,39 @@ def _device_level(img_shape, ws, octave, kind, index):
     return lvl.cpu().numpy().reshape(lh.value, lw.value), no.value
 
 
-def test_config_size_pyramid_bit_equal_and_crops():
+def _match_sorted(ka, oa, kb, ob):
+    """_match() for whole frames: both lists are in the canonical (octave, layer, y, x, angle)
+    order, so a keypoint's partner is within a few positions of where a merge would put it"""
+    seg = lambda o: (((o & 255) + 1) & 255) * 4 + ((o >> 8) & 255)
+    sa, sb = seg(oa), seg(ob)
+    pairs = []
+    for s_ in np.unique(sa):
+        ia, ib = np.nonzero(sa == s_)[0], np.nonzero(sb == s_)[0]
+        if len(ib) == 0:
+            continue
+        yb = kb[ib, 1]
+        lo = np.searchsorted(yb, ka[ia, 1] - 0.02, 'left')
+        hi = np.searchsorted(yb, ka[ia, 1] + 0.02, 'right')
+        used = np.zeros(len(ib), bool)
+        for i, a, b in zip(ia, lo, hi):
+            cand = np.arange(a, b)
+            cand = cand[(~used[cand]) & (np.abs(kb[ib[cand], 0] - ka[i, 0]) < 0.02) & (ob[ib[cand]] == oa[i])]
+            if len(cand) == 0:
+                continue
+            da = np.abs(((kb[ib[cand], 3] - ka[i, 3]) + 180.0) % 360.0 - 180.0)
+            if da.min() < 0.2:
+                j = cand[np.argmin(da)]
+                used[j] = True
+                pairs.append((i, ib[j]))
+    return np.array(pairs).reshape(-1, 2)
+
+
+def test_config_size_pyramid_bit_equal_and_whole_frame():
     """BASELINE configs[1] detect size (5472x3648 at scale 0.4 -> 2189x1459): every Gaussian and
-    DoG level of every octave -- the big ones from the blur kernels, the small ones from the
-    one-workgroup tail kernel -- is BIT-identical to the oracle's float32 pyramid; keypoints and
-    descriptors are compared on four crops of the frame (the python oracle needs seconds per
-    crop), and the share of descriptor bytes the float32 exp / atan2 of the device moves is
-    reported (the oracle is float64 throughout)."""
+    DoG level of every octave is BIT-identical to the oracle's float32 pyramid; keypoints and
+    descriptors are compared on the WHOLE frame (the oracle's per-keypoint loops run in C,
+    oracle/sift_ref.c) and, as before, on four crops; the share of descriptor bytes the float32
+    exp / atan2 of the device moves is reported (the oracle is float64 throughout)."""
     from imageanalysis_amd import kernels
     from oracle import sift_oracle as so
     frame = texture(1459, 2189, 21)
@@ -175,6 +201,19 @@ def test_config_size_pyramid_bit_equal_and_crops():
             assert np.array_equal(got, dog[o][i]), ('dog', o, i)
     got, _ = _device_level(gray.shape, ws, 0, 1, 0)
     assert np.array_equal(got, dog[0][0])
+    # keypoints / descriptors of the whole frame, one to one
+    kps, des = so.detect_and_compute(gray)
+    assert len(kps) > 5000 and abs(len(kp) - len(kps)) <= len(kps) // 200
+    pairs = _match_sorted(kps, kps[:, 5].astype(np.int64), kp.astype(np.float64), octv.astype(np.int64))
+    assert len(pairs) >= 0.995 * len(kps), (len(pairs), len(kps), len(kp))
+    a, b = kps[pairs[:, 0]], kp[pairs[:, 1]].astype(np.float64)
+    assert np.abs(a[:, 0] - b[:, 0]).max() < 2e-3 and np.abs(a[:, 1] - b[:, 1]).max() < 2e-3
+    assert np.abs(a[:, 2] - b[:, 2]).max() < 1e-3 * a[:, 2].max()
+    assert np.abs(a[:, 4] - b[:, 4]).max() < 1e-5
+    diff = np.abs(des[pairs[:, 0]].astype(int) - d[pairs[:, 1]].astype(int))
+    print('whole frame: %d oracle / %d device keypoints, %d paired; descriptor bytes that differ: '
+          '%.4f %%, max %d' % (len(kps), len(kp), len(pairs), 100.0 * (diff != 0).mean(), diff.max()))
+    assert diff.max() <= 2 and (diff != 0).mean() < 0.01
     # keypoints / descriptors on crops of the frame
     moved, total = 0, 0
     for (y0, x0) in ((0, 0), (500, 900), (1159, 1888), (300, 1500)):
