@@ -333,6 +333,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if ba is not None:
             ba["cpu_baseline"] = ba_cpu_baseline()
+        if sift is not None and _SIFT_SAMPLE is not None:
+            sift["cpu_baseline"] = sift_cpu_baseline()
 
     out = None
     if rank == 0:
@@ -829,9 +831,9 @@ def sift_bench(rank, world, dev, dist, args):
     except Exception as e:                                  # noqa: BLE001 (e.g. not enough HBM left)
         full = {"error": str(e)[:200]}
     alg = 469.0 * h * w                                     # bytes per image
-    # no CPU baseline for this stage: the reference's detector is cv2.SIFT_create (absent here),
-    # and timing the numpy parity oracle would not be a baseline of anything
-    cpu = None
+    cpu = None                                              # filled in by main() at the end
+    global _SIFT_SAMPLE
+    _SIFT_SAMPLE = scaled.cpu().numpy() if rank == 0 else None
     return {"metric": "sift_images_per_sec", "value": round(n_local * world / dt, 2),
             "image": "5472x3648 synthetic, CLAHE + resize 0.4 -> %dx%d detect image" % (w, h),
             "keypoints_per_image": nkp // n_local, "ms_per_image": round(dt / n_local * 1e3, 2),
@@ -1007,6 +1009,31 @@ def ba_bench(rank, world, dev, dist, args):
                              "bytes_per_obs": 224},
             "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
+
+
+_SIFT_SAMPLE = None
+
+
+def sift_cpu_baseline():
+    """The reference's detector is cv2.SIFT_create().detectAndCompute (scripts/lib/image.py:324;
+    OpenCV is not installed here): the C / OpenMP restatement of the same published algorithm
+    (oracle/sift_ref.c, the parity oracle of the kernels) on the bench's own detect image, all
+    host cores, for ~10 s."""
+    from oracle import cpu_ref, sift_oracle
+    gray = sift_oracle.bgr_to_gray(_SIFT_SAMPLE)
+    cpu_ref.sift_detect(gray)                                # warm (thread pool, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        kps, _des = cpu_ref.sift_detect(gray)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 200:
+            break
+    return {"value": round(n / el, 3), "unit": "images/s", "cores": cpu_ref.num_threads(),
+            "kind": "port",
+            "sample": "%d x the %dx%d detect image (%d keypoints) in %.1f s with oracle/sift_ref.c "
+                      "(OpenMP; CLAHE + resize not included)" % (n, gray.shape[1], gray.shape[0],
+                                                                 len(kps), el)}
 
 
 def ba_cpu_baseline():

@@ -120,44 +120,65 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
     static_assert(2 * R <= SB_RING - SB_TH, "the V window must fit the ring");
     constexpr int SW = SB_TW + 2 * R + 1;                 // (+1: odd row pitch)
     constexpr int HW = SB_TW + 1;
+    constexpr int TILE = SB_TH * (SB_TW + 2 * R);         // source elements of an H block
+    constexpr int PER = (TILE + 255) / 256;               // ... per thread
     __shared__ float S[SB_TH * SW];
     __shared__ float Hb[SB_RING * HW];
     const int x0 = blockIdx.x * SB_TW;
     const int y_begin = blockIdx.y * seg_rows;
     const int y_end = min(y_begin + seg_rows, h);
-    // H block k: source rows [y_begin - R + SB_TH k, + SB_TH) -> ring rows (SB_TH k + ry) & 63
-    auto hblock = [&](int k) {
+    // The source rows of H block k + 1 are fetched into registers while block k is computed
+    // (global -> register -> LDS: the load latency sits behind a block's ~430 FMAs per thread).
+    float pre[PER];
+    auto fetch = [&](int k) {                             // source rows [y_begin - R + SB_TH k, + SB_TH)
         const int ybase = y_begin - R + SB_TH * k;
-        for (int e = threadIdx.x; e < SB_TH * (SB_TW + 2 * R); e += 256) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = threadIdx.x + 256 * i;
             const int ry = e / (SB_TW + 2 * R), rx = e - ry * (SB_TW + 2 * R);
             int yy = ybase + ry, xx = x0 - R + rx;
             yy = (yy >= 0 && yy < h) ? yy : reflect101(yy, h);
             xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
-            S[ry * SW + rx] = src[(int64_t)yy * w + xx];
+            pre[i] = e < TILE ? src[(int64_t)yy * w + xx] : 0.f;
         }
-        __syncthreads();
-        {
-            const int ry = threadIdx.x / (SB_TW / SB_STRIP), sx = (threadIdx.x % (SB_TW / SB_STRIP)) * SB_STRIP;
-            float win[SB_STRIP + 2 * R];
-#pragma unroll
-            for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
-            float *hrow = Hb + ((SB_TH * k + ry) & (SB_RING - 1)) * HW + sx;
-#pragma unroll
-            for (int j = 0; j < SB_STRIP; ++j) {
-                float acc = 0.f;
-#pragma unroll
-                for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
-                hrow[j] = acc;
-            }
-        }
-        __syncthreads();
     };
-    hblock(0);
+    auto stage = [&]() {                                  // registers -> S
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = threadIdx.x + 256 * i;
+            const int ry = e / (SB_TW + 2 * R), rx = e - ry * (SB_TW + 2 * R);
+            if (e < TILE) S[ry * SW + rx] = pre[i];
+        }
+    };
+    auto hpass = [&](int k) {                             // S -> ring rows (SB_TH k + ry) & 63
+        const int ry = threadIdx.x / (SB_TW / SB_STRIP), sx = (threadIdx.x % (SB_TW / SB_STRIP)) * SB_STRIP;
+        float win[SB_STRIP + 2 * R];
+#pragma unroll
+        for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
+        float *hrow = Hb + ((SB_TH * k + ry) & (SB_RING - 1)) * HW + sx;
+#pragma unroll
+        for (int j = 0; j < SB_STRIP; ++j) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
+            hrow[j] = acc;
+        }
+    };
     const int cx = threadIdx.x & (SB_TW - 1), g = threadIdx.x / SB_TW;
     const int x = x0 + cx;
     const int n_blocks = (y_end - y_begin + SB_TH - 1) / SB_TH;
+    fetch(0);
+    stage();
+    fetch(1);
+    __syncthreads();
+    hpass(0);
+    __syncthreads();
     for (int b = 0; b < n_blocks; ++b) {
-        hblock(b + 1);
+        stage();                                          // source rows of H block b + 1
+        if (b + 1 < n_blocks) fetch(b + 2);               // (in flight during the two passes below)
+        __syncthreads();
+        hpass(b + 1);
+        __syncthreads();
         // V block b: output rows y_begin + SB_TH b + 8 g + j; source row y' sits in ring row
         // (y' - (y_begin - R)) & 63, so the window of output row y starts at (y - y_begin) & 63
         const int y0 = y_begin + SB_TH * b + g * SB_STRIP;
@@ -228,12 +249,13 @@ struct DogStack {
     const float *d[NL + 2];
 };
 
-// One wave per row segment of 62 pixels (+1 halo column each side): every lane loads its own
-// column of the five DoG images on three rows (15 coalesced loads serve all NL layer tests; the
-// per-pixel form issued 27 loads per layer), takes the max / min of its 9 values per layer
-// triple, and gets the neighbouring columns' with two lane shifts.  val >= (<=) every one of
-// the 26 neighbours  <=>  val >= (<=) the max (min) over the 3x3x3 block, which contains val.
-constexpr int EXT_RPT = 4;        // row groups (of 4 rows) per workgroup
+// One wave per strip of 62 columns (+1 halo column each side) and EXT_ROWS rows: every lane keeps
+// its own column of the five DoG images on three consecutive rows in registers and loads ONE new
+// row per step (5 coalesced loads per row and lane serve all NL layer tests; a wave per row
+// issued 15), takes the max / min of its 9 values per layer triple, and gets the neighbouring
+// columns' with two lane shifts.  val >= (<=) every one of the 26 neighbours  <=>  val >= (<=)
+// the max (min) over the 3x3x3 block, which contains val.
+constexpr int EXT_ROWS = 16;      // rows per wave (4 waves of a workgroup: 64 rows)
 constexpr int EXT_LIST = 512;     // candidates a workgroup collects before its one global atomic
 
 __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, int o,
@@ -251,37 +273,45 @@ __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, 
     const int c = BORDER + blockIdx.x * 62 - 1 + lane;
     const int cl = c < w - 1 ? c : w - 1;              // clamped: only feeds masked-out lanes
     const bool out = lane >= 1 && lane <= 62 && c < w - BORDER;
-    for (int rr = 0; rr < EXT_RPT; ++rr) {
-        const int r = BORDER + (blockIdx.y * EXT_RPT + rr) * 4 + wave;
-        if (r >= h - BORDER) continue;                 // (whole wave)
-        float v[NL + 2][3];
+    const int r0 = BORDER + (blockIdx.y * 4 + wave) * EXT_ROWS;
+    const int r1 = min(r0 + EXT_ROWS, h - BORDER);
+    if (r0 < r1) {                                     // (whole wave)
+        float v[NL + 2][3];                            // rows r - 1, r, r + 1 (rolling)
 #pragma unroll
         for (int L = 0; L < NL + 2; ++L) {
-#pragma unroll
-            for (int dr = 0; dr < 3; ++dr) v[L][dr] = D.d[L][(int64_t)(r - 1 + dr) * w + cl];
+            v[L][1] = D.d[L][(int64_t)(r0 - 1) * w + cl];
+            v[L][2] = D.d[L][(int64_t)r0 * w + cl];
         }
-        float cmax[NL + 2], cmin[NL + 2];
+        for (int r = r0; r < r1; ++r) {
 #pragma unroll
-        for (int L = 0; L < NL + 2; ++L) {
-            cmax[L] = fmaxf(fmaxf(v[L][0], v[L][1]), v[L][2]);
-            cmin[L] = fminf(fminf(v[L][0], v[L][1]), v[L][2]);
-        }
+            for (int L = 0; L < NL + 2; ++L) {
+                v[L][0] = v[L][1];
+                v[L][1] = v[L][2];
+                v[L][2] = D.d[L][(int64_t)(r + 1) * w + cl];
+            }
+            float cmax[NL + 2], cmin[NL + 2];
 #pragma unroll
-        for (int layer = 1; layer <= NL; ++layer) {
-            const float val = v[layer][1];
-            float mx = fmaxf(fmaxf(cmax[layer - 1], cmax[layer]), cmax[layer + 1]);
-            float mn = fminf(fminf(cmin[layer - 1], cmin[layer]), cmin[layer + 1]);
-            mx = fmaxf(mx, fmaxf(__shfl_up(mx, 1), __shfl_down(mx, 1)));
-            mn = fminf(mn, fminf(__shfl_up(mn, 1), __shfl_down(mn, 1)));
-            if (!out || !(fabsf(val) > threshold)) continue;
-            const bool is_max = val > 0.f && val >= mx, is_min = val < 0.f && val <= mn;
-            if (is_max || is_min) {
-                const int k = atomicAdd(&s_n, 1);
-                if (k < EXT_LIST) {
-                    s_list[k] = Cand{o, layer, r, c};
-                } else {                               // (a block this dense: straight to global)
-                    const int g = atomicAdd(count, 1);
-                    if (g < cap) cand[g] = Cand{o, layer, r, c};
+            for (int L = 0; L < NL + 2; ++L) {
+                cmax[L] = fmaxf(fmaxf(v[L][0], v[L][1]), v[L][2]);
+                cmin[L] = fminf(fminf(v[L][0], v[L][1]), v[L][2]);
+            }
+#pragma unroll
+            for (int layer = 1; layer <= NL; ++layer) {
+                const float val = v[layer][1];
+                float mx = fmaxf(fmaxf(cmax[layer - 1], cmax[layer]), cmax[layer + 1]);
+                float mn = fminf(fminf(cmin[layer - 1], cmin[layer]), cmin[layer + 1]);
+                mx = fmaxf(mx, fmaxf(__shfl_up(mx, 1), __shfl_down(mx, 1)));
+                mn = fminf(mn, fminf(__shfl_up(mn, 1), __shfl_down(mn, 1)));
+                if (!out || !(fabsf(val) > threshold)) continue;
+                const bool is_max = val > 0.f && val >= mx, is_min = val < 0.f && val <= mn;
+                if (is_max || is_min) {
+                    const int k = atomicAdd(&s_n, 1);
+                    if (k < EXT_LIST) {
+                        s_list[k] = Cand{o, layer, r, c};
+                    } else {                           // (a block this dense: straight to global)
+                        const int g = atomicAdd(count, 1);
+                        if (g < cap) cand[g] = Cand{o, layer, r, c};
+                    }
                 }
             }
         }
@@ -307,6 +337,142 @@ struct PyrTable {
     Pyr oct[MAX_OCT];
     int n_oct;
 };
+
+// The smallest octaves (<= TAIL_PIXELS pixels per level) are pure launch latency as separate
+// kernels (~12 us per level for microseconds of work, ~35 launches): ONE workgroup builds all of
+// them in one launch with the current level and its horizontal pass in LDS.  Same taps, same
+// ascending fused multiply-add chains as blur_strip_kernel: bit-identical levels.  Both passes
+// work in strips of 8 outputs with the 8 + 2R inputs in registers (reflect-101 is applied when
+// the window is loaded, not per tap -- the round-2 tail kernel spent ~12 instructions per tap on
+// it and took 0.58 ms).
+constexpr int TAIL_PIXELS = 12800;
+
+struct TapSet {
+    Taps t[NL + 2];              // layers 1 .. NL+2 (sigma of the incremental blurs)
+};
+
+template <int R>
+__device__ __forceinline__ void tail_level(float *__restrict__ cur, float *__restrict__ hor,
+                                           float *__restrict__ nxt_base, int H, int W, int P, int P2,
+                                           const float *__restrict__ k /* LDS */,
+                                           float *__restrict__ dst, float *__restrict__ dog,
+                                           bool make_base)
+{
+    // horizontal: strips of 8 consecutive outputs of a row.  Consecutive lanes take the same
+    // strip of consecutive ROWS: their LDS addresses differ by the odd pitch P (conflict free;
+    // lanes side by side in a row would be 8 dwords apart = 8 lanes per bank)
+    const int spr = (W + 7) >> 3;
+    for (int s = threadIdx.x; s < H * spr; s += 1024) {
+        const int sx = (s / H) * 8, row = s - (s / H) * H;
+        float win[8 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * R; ++i) {
+            int xx = sx - R + i;
+            xx = (xx >= 0 && xx < W) ? xx : reflect101(xx, W);
+            win[i] = cur[row * P + xx];
+        }
+        // (eight chains side by side, each in ascending tap order; one LDS read per tap)
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+            const float kt = k[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(win[j + t], kt, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (sx + j < W) hor[row * P + sx + j] = acc[j];
+    }
+    __syncthreads();
+    // vertical: a thread owns one column and 8 rows (consecutive threads = consecutive columns)
+    const int gpr = (H + 7) >> 3;
+    for (int s = threadIdx.x; s < W * gpr; s += 1024) {
+        const int gy = (s / W) * 8, col = s - (s / W) * W;
+        float win[8 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * R; ++i) {
+            int yy = gy - R + i;
+            yy = (yy >= 0 && yy < H) ? yy : reflect101(yy, H);
+            win[i] = hor[yy * P + col];
+        }
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t <= 2 * R; ++t) {
+            const float kt = k[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(win[j + t], kt, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int y = gy + j;
+            if (y < H) {
+                const int i = y * W + col, il = y * P + col;
+                dst[i] = acc[j];
+                dog[i] = sub_rn(acc[j], cur[il]);
+                cur[il] = acc[j];                  // (this position is read by nobody else any more)
+                // level NL is the source of the next octave (INTER_NEAREST to half the size)
+                if (make_base && !(y & 1) && !(col & 1) && (y >> 1) < H / 2 && (col >> 1) < W / 2)
+                    nxt_base[(y >> 1) * P2 + (col >> 1)] = acc[j];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void pyramid_tail_kernel(PyrTable T, int o_first, TapSet TS)
+{
+    __shared__ float cur[TAIL_PIXELS];
+    __shared__ float hor[TAIL_PIXELS];
+    __shared__ float nxt[TAIL_PIXELS / 4 + 128];
+    __shared__ float sk[NL + 2][MAX_TAPS];
+    __shared__ int sr[NL + 2];
+    // the taps go from the kernel argument to LDS with compile-time indices (indexing the
+    // argument with a runtime level or tap number would put a copy of it in scratch memory)
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NL + 2; ++q) {
+            sr[q] = TS.t[q].r;
+#pragma unroll
+            for (int t = 0; t < MAX_TAPS; ++t) sk[q][t] = TS.t[q].k[t];
+        }
+    }
+    __syncthreads();
+    for (int o = o_first; o < T.n_oct; ++o) {
+        const int H = T.oct[o].h, W = T.oct[o].w, npx = H * W;
+        const int P = W | 1, P2 = (W / 2) | 1;            // odd LDS pitches
+        float *g0 = T.oct[o].g[0];
+        if (o == o_first) {
+            const float *src = T.oct[o - 1].g[NL];
+            const int sw = T.oct[o - 1].w;
+            for (int i = threadIdx.x; i < npx; i += 1024) {
+                const int x = i % W, y = i / W;
+                const float v = src[(int64_t)(2 * y) * sw + 2 * x];
+                g0[i] = v;
+                cur[y * P + x] = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < npx; i += 1024) {
+                const int x = i % W, y = i / W;
+                const float v = nxt[y * P + x];
+                g0[i] = v;
+                cur[y * P + x] = v;
+            }
+        }
+        __syncthreads();
+        for (int l = 1; l < NL + 3; ++l) {
+            const float *tp = sk[l - 1];
+            float *dst = T.oct[o].g[l], *dog = T.oct[o].d[l - 1];
+            const bool mb = l == NL && o + 1 < T.n_oct;
+            switch (sr[l - 1]) {
+#define IAMX_TL(r) case r: tail_level<r>(cur, hor, nxt, H, W, P, P2, tp, dst, dog, mb); break;
+                IAMX_TL(1) IAMX_TL(2) IAMX_TL(3) IAMX_TL(4) IAMX_TL(5) IAMX_TL(6) IAMX_TL(7) IAMX_TL(8)
+                IAMX_TL(9) IAMX_TL(10) IAMX_TL(11) IAMX_TL(12) IAMX_TL(13) IAMX_TL(14) IAMX_TL(15)
+#undef IAMX_TL
+            default: tail_level<16>(cur, hor, nxt, H, W, P, P2, tp, dst, dog, mb); break;
+            }
+        }
+    }
+}
 
 __device__ bool solve3(double A[3][3], double b[3], double x[3])
 {
@@ -606,39 +772,47 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         // radius <= diag of the octave image (< 2^14 for any image that fits the workspace),
         // so the window index fits 32 bits: no 64-bit division in the sample loop
         const int side = 2 * radius + 1;
+        // Per sample the geometry, the gradient and the three weights are float32 -- what
+        // OpenCV's calcSIFTDescriptor computes in (its fastAtan2 is only good to 0.3 deg, its
+        // exp a table) -- and cost half the issue slots of float64 on this part; the histogram
+        // itself stays float64 (LDS atomics in any order give the same sums to ~1e-16, so the
+        // quantised descriptor does not depend on the order the lanes arrive in).
+        const float cos_f = (float)cos_t, sin_f = (float)sin_t, ori_f = (float)ori;
+        const float bins_f = (float)bins_per_rad, exp_f = (float)exp_scale;
         auto sample = [&](int i, int j) {
-            const double c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
-            const double rbin = r_rot + d / 2 - 0.5, cbin = c_rot + d / 2 - 0.5;
+            const float fi = (float)i, fj = (float)j;
+            const float c_rot = fj * cos_f - fi * sin_f, r_rot = fj * sin_f + fi * cos_f;
+            const float rbin = r_rot + (d / 2 - 0.5f), cbin = c_rot + (d / 2 - 0.5f);
             const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1))
+            if (!(rbin > -1.f && rbin < (float)d && cbin > -1.f && cbin < (float)d && r > 0 && r < h - 1 &&
+                  c > 0 && c < w - 1))
                 return;
-            const double dx = (double)img[(int64_t)r * w + c + 1] - (double)img[(int64_t)r * w + c - 1];
-            const double dy = (double)img[(int64_t)(r - 1) * w + c] - (double)img[(int64_t)(r + 1) * w + c];
-            // the two transcendentals in float32 (what OpenCV's calcSIFTDescriptor computes in --
-            // its fastAtan2 is only good to 0.3 deg); the interpolation and sums stay float64
-            const double wgt = (double)expf((float)((c_rot * c_rot + r_rot * r_rot) * exp_scale));
-            double og = (double)atan2f((float)dy, (float)dx) * (180.0 / 3.141592653589793);
-            if (og < 0) og += 360.0;
-            if (og >= 360.0) og -= 360.0;
-            const double mag = sqrt(dx * dx + dy * dy) * wgt;
-            const double obin = (og - ori) * bins_per_rad;
-            const double fr0 = floor(rbin), fc0 = floor(cbin), fo0 = floor(obin);
+            const float *pc = img + (int64_t)r * w + c;
+            const float dx = pc[1] - pc[-1];
+            const float dy = pc[-w] - pc[w];
+            const float wgt = __expf((c_rot * c_rot + r_rot * r_rot) * exp_f);
+            float og = atan2f(dy, dx) * 57.29577951308232f;
+            if (og < 0.f) og += 360.f;
+            if (og >= 360.f) og -= 360.f;
+            const float mag = __fsqrt_rn(dx * dx + dy * dy) * wgt;
+            const float obin = (og - ori_f) * bins_f;
+            const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
             const int r0 = (int)fr0, c0 = (int)fc0;
             int o0 = (int)fo0;
-            const double fr = rbin - fr0, fc = cbin - fc0, fo = obin - fo0;
+            const float fr = rbin - fr0, fc = cbin - fc0, fo = obin - fo0;
             if (o0 < 0) o0 += n;
             if (o0 >= n) o0 -= n;
-            const double v_r1 = mag * fr, v_r0 = mag - v_r1;
-            const double v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
-            const double v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
-            const double vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
+            const float v_r1 = mag * fr, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
+            const float vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int rr = r0 + 1 + (q4 >> 1), cc = c0 + 1 + (q4 & 1);
                 const int base = (rr * (d + 2) + cc) * (n + 2) + o0;
-                const double v1 = vv[q4] * fo;
-                atomicAdd(&hist[base], vv[q4] - v1);
-                atomicAdd(&hist[base + 1], v1);
+                const float v1 = vv[q4] * fo;
+                atomicAdd(&hist[base], (double)(vv[q4] - v1));
+                atomicAdd(&hist[base + 1], (double)v1);
             }
         };
         if (side <= DESC_ROWS) {
@@ -960,7 +1134,11 @@ SideStream *side_stream()
     if (failed[dev]) return nullptr;
     if (!ready[dev]) {
         SideStream &S = slots[dev];
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess ||
+        // highest priority: the side chain is ~40 small dependent launches that must not queue
+        // behind the main stream's chip-filling levels
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess) {
             failed[dev] = true;
@@ -1033,7 +1211,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
             for (int i = 0; i < NL + 2; ++i) D.d[i] = T.oct[o].d[i];
             hipLaunchKernelGGL(extrema_kernel,
                                dim3((unsigned)((W - 2 * BORDER + 61) / 62),
-                                    (unsigned)((H - 2 * BORDER + 4 * EXT_RPT - 1) / (4 * EXT_RPT))),
+                                    (unsigned)((H - 2 * BORDER + 4 * EXT_ROWS - 1) / (4 * EXT_ROWS))),
                                dim3(256), 0, q, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
         }
     };
@@ -1047,7 +1225,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     // is the launch.  Issue order: levels 1..NL of the big octaves (the chain that leads to the
     // small ones) first, then the small octaves -- all their levels and extrema scans -- on a second
     // stream beside the remaining two levels and the extrema scans of the big octaves.
-    constexpr int SIDE_OCTAVE = 3;
+    constexpr int SIDE_OCTAVE = 4;
     const int o_side = L.n_oct < SIDE_OCTAVE ? L.n_oct : SIDE_OCTAVE;
     for (int o = 0; o < o_side; ++o) {
         if (o > 0) downsample(st, o);
@@ -1055,26 +1233,40 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
             blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
     }
     SideStream *side = nullptr;
+    hipStream_t ts = st;
     if (o_side < L.n_oct) {
         side = side_stream();
-        hipStream_t ts = side ? side->stream : st;
         if (side) {
+            ts = side->stream;
             (void)hipEventRecord(side->fork, st);
             (void)hipStreamWaitEvent(ts, side->fork, 0);
         }
-        for (int o = o_side; o < L.n_oct; ++o) {
-            downsample(ts, o);
-            for (int i = 1; i < NL + 3; ++i)
-                blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
-            extrema(ts, o);
-        }
-        if (side) (void)hipEventRecord(side->join, ts);
     }
+    // the host needs ~8 us per launch: the few big launches go in first so that the GPU works on
+    // them while the ~50 small ones of the side chain are still being enqueued (the other order
+    // left the main stream idle for 0.45 ms per frame)
     for (int o = 0; o < o_side; ++o) {
         for (int i = NL + 1; i < NL + 3; ++i)
             blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
         extrema(st, o);
     }
+    // small octaves: strip kernels down to o_tail, then ONE workgroup for the rest
+    int o_tail = L.n_oct;
+    for (int o = L.n_oct - 1; o >= (o_side > 1 ? o_side : 1) && (int64_t)L.h[o] * (L.w[o] | 1) <= TAIL_PIXELS; --o)
+        o_tail = o;
+    for (int o = o_side; o < o_tail; ++o) {
+        downsample(ts, o);
+        for (int i = 1; i < NL + 3; ++i)
+            blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+        extrema(ts, o);
+    }
+    if (o_tail < L.n_oct) {
+        TapSet TS;
+        for (int i = 1; i < NL + 3; ++i) TS.t[i - 1] = taps[i];
+        hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, ts, T, o_tail, TS);
+        for (int o = o_tail; o < L.n_oct; ++o) extrema(ts, o);
+    }
+    if (side) (void)hipEventRecord(side->join, ts);
     if (side) (void)hipStreamWaitEvent(st, side->join, 0);
     // the number of candidates is only known on the device: launch for the capacity in slabs
     // sized by the largest plausible count (threads beyond *n_cand exit immediately)

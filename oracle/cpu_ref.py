@@ -135,3 +135,20 @@ def sift_descriptors(img, par, nthreads=0):
     if rc != 0:
         raise ValueError("oracle_sift_descriptors rc=%d" % rc)
     return desc
+
+
+def sift_detect(gray, cap=None, nthreads=0):
+    """the whole detector + descriptor in C (oracle/sift_ref.c oracle_sift_detect): gray uint8
+    [h,w] -> (kps float64 [n,6], desc uint8 [n,128]) in detect()'s append order (unsorted)"""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    cap = int(cap or max(h * w // 8, 4096))
+    kps = np.empty((cap, 6), np.float64)
+    desc = np.empty((cap, 128), np.uint8)
+    L = lib()
+    L.oracle_sift_detect.restype = ctypes.c_int
+    n = L.oracle_sift_detect(_p(gray), ctypes.c_int(h), ctypes.c_int(w), _p(kps), _p(desc),
+                             ctypes.c_int(cap), ctypes.c_int(nthreads))
+    if n < 0:
+        raise ValueError("oracle_sift_detect rc=%d" % n)
+    return kps[:n].copy(), desc[:n].copy()

@@ -453,3 +453,17 @@ def detect_and_compute(bgr_or_gray, use_c=True):
                             ((oc & 255) + 1) & 255))
         kps, des = kps[order], des[order]
     return kps, des
+
+
+def detect_and_compute_c(bgr_or_gray):
+    """detect_and_compute() with nothing but oracle/sift_ref.c underneath (OpenMP): the form
+    bench.py times as the CPU baseline of the SIFT section"""
+    from . import cpu_ref
+    gray = bgr_to_gray(bgr_or_gray) if bgr_or_gray.ndim == 3 else bgr_or_gray
+    kps, des = cpu_ref.sift_detect(gray)
+    if len(kps):
+        oc = kps[:, 5].astype(np.int64)
+        order = np.lexsort((des[:, 0], kps[:, 3], kps[:, 0], kps[:, 1], (oc >> 8) & 255,
+                            ((oc & 255) + 1) & 255))
+        kps, des = kps[order], des[order]
+    return kps, des

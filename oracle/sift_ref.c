@@ -376,3 +376,186 @@ int oracle_sift_descriptors(const float *img, int h, int w, const double *par, i
                        desc + (size_t)k * 128);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The whole detector + descriptor in C (sift_oracle.detect_and_compute without its numpy glue):
+ * grey image -> x2 bilinear -> Gaussian / DoG pyramid -> 26-neighbour extrema -> refinement,
+ * orientation peaks -> descriptors.  OpenMP over rows / candidates / keypoints.  This is the CPU
+ * baseline of bench.py's SIFT section; tests/test_oracle.py checks it against the numpy oracle.
+ * Output order: octave, then layer, then row major, then peak -- the order detect() appends in.
+ * ------------------------------------------------------------------------------------------- */
+static void gaussian_taps(double sigma, float *k, int *r_out)
+{
+    int ksize = (int)lrint(sigma * 8 + 1) | 1;
+    int r = ksize / 2;
+    double kd[129], sum = 0;
+    if (r > 64) r = 64;
+    for (int i = -r; i <= r; ++i) {
+        kd[i + r] = exp(-(double)(i * i) / (2.0 * sigma * sigma));
+        sum += kd[i + r];
+    }
+    for (int i = 0; i < 2 * r + 1; ++i) k[i] = (float)(kd[i] / sum);
+    *r_out = r;
+}
+
+/* sift_oracle.resize_linear_2x (separately rounded float32 operations) */
+static void resize2x(const uint8_t *gray, int h, int w, float *dst)
+{
+    const int H2 = 2 * h, W2 = 2 * w;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H2; ++y) {
+        volatile float f = ((float)y + 0.5f) * 0.5f;
+        float fy = f - 0.5f;
+        int y0 = (int)floorf(fy);
+        float ty = fy - (float)y0;
+        if (y0 < 0) { y0 = 0; ty = 0.f; }
+        if (y0 >= h - 1) { y0 = h - 1; ty = 0.f; }
+        const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+        for (int x = 0; x < W2; ++x) {
+            volatile float g = ((float)x + 0.5f) * 0.5f;
+            float fx = g - 0.5f;
+            int x0 = (int)floorf(fx);
+            float tx = fx - (float)x0;
+            if (x0 < 0) { x0 = 0; tx = 0.f; }
+            if (x0 >= w - 1) { x0 = w - 1; tx = 0.f; }
+            const int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+            const float omtx = 1.f - tx, omty = 1.f - ty;
+            volatile float a = (float)gray[(size_t)y0 * w + x0] * omtx, b = (float)gray[(size_t)y0 * w + x1] * tx;
+            const float top = a + b;
+            a = (float)gray[(size_t)y1 * w + x0] * omtx; b = (float)gray[(size_t)y1 * w + x1] * tx;
+            const float bot = a + b;
+            a = top * omty; b = bot * ty;
+            dst[(size_t)y * W2 + x] = a + b;
+        }
+    }
+}
+
+int oracle_sift_detect(const uint8_t *gray, int h, int w, double *kps, uint8_t *desc, int cap,
+                       int nthreads)
+{
+    if (!gray || !kps || !desc || h < 2 || w < 2) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    const double sigma0 = 1.6;
+    int H = 2 * h, W = 2 * w;
+    int n_oct = (int)lrint(log((double)(H < W ? H : W)) / log(2.0) - 2) + 1;
+    if (n_oct < 1) n_oct = 1;
+    if (n_oct > 24) n_oct = 24;
+    double sig[NL + 3];
+    sig[0] = sigma0;
+    const double kf = pow(2.0, 1.0 / NL);
+    for (int i = 1; i < NL + 3; ++i) {
+        const double sp = pow(kf, (double)(i - 1)) * sigma0, st = sp * kf;
+        sig[i] = sqrt(st * st - sp * sp);
+    }
+    float **gauss = (float **)calloc((size_t)n_oct * (NL + 3), sizeof(float *));
+    float **dogs = (float **)calloc((size_t)n_oct * (NL + 2), sizeof(float *));
+    int *oh = (int *)calloc((size_t)n_oct, sizeof(int)), *ow = (int *)calloc((size_t)n_oct, sizeof(int));
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)H * W);
+    float taps[129];
+    int r;
+    int total = 0;
+    for (int o = 0; o < n_oct; ++o) {
+        oh[o] = H; ow[o] = W;
+        const size_t npx = (size_t)H * W;
+        for (int i = 0; i < NL + 3; ++i) gauss[o * (NL + 3) + i] = (float *)malloc(sizeof(float) * npx);
+        for (int i = 0; i < NL + 2; ++i) dogs[o * (NL + 2) + i] = (float *)malloc(sizeof(float) * npx);
+        float **g = gauss + o * (NL + 3), **dg = dogs + o * (NL + 2);
+        if (o == 0) {
+            float *up = (float *)malloc(sizeof(float) * npx);
+            resize2x(gray, h, w, up);
+            gaussian_taps(sqrt(fmax(sigma0 * sigma0 - 1.0, 0.01)), taps, &r);
+            blur_rows(up, H, W, taps, r, tmp, g[0]);
+            free(up);
+        } else {
+            const float *src = gauss[(o - 1) * (NL + 3) + NL];
+            const int sw = ow[o - 1];
+#pragma omp parallel for schedule(static)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) g[0][(size_t)y * W + x] = src[(size_t)(2 * y) * sw + 2 * x];
+        }
+        for (int i = 1; i < NL + 3; ++i) {
+            gaussian_taps(sig[i], taps, &r);
+            blur_rows(g[i - 1], H, W, taps, r, tmp, g[i]);
+#pragma omp parallel for schedule(static)
+            for (size_t q = 0; q < npx; ++q) dg[i - 1][q] = g[i][q] - g[i - 1][q];
+        }
+        /* extrema: candidates per (layer, row) counted, then written in order */
+        if (H > 2 * IMG_BORDER && W > 2 * IMG_BORDER) {
+            const float threshold = floorf(0.5f * 0.04f / NL * 255.f);
+            const int rows = H - 2 * IMG_BORDER;
+            int *cnt = (int *)calloc((size_t)NL * rows + 1, sizeof(int));
+            for (int pass = 0; pass < 2; ++pass) {
+                int32_t *cand = NULL;
+                if (pass == 1) {
+                    int acc = 0;
+                    for (int q = 0; q < NL * rows; ++q) { const int c = cnt[q]; cnt[q] = acc; acc += c; }
+                    cnt[NL * rows] = acc;
+                    cand = (int32_t *)malloc(sizeof(int32_t) * 3 * (size_t)(acc + 1));
+                }
+#pragma omp parallel for schedule(dynamic, 8) collapse(2)
+                for (int layer = 1; layer <= NL; ++layer)
+                    for (int rr = IMG_BORDER; rr < H - IMG_BORDER; ++rr) {
+                        const int slot = (layer - 1) * rows + (rr - IMG_BORDER);
+                        int n = 0;
+                        for (int cc = IMG_BORDER; cc < W - IMG_BORDER; ++cc) {
+                            const float val = dg[layer][(size_t)rr * W + cc];
+                            if (!(fabsf(val) > threshold)) continue;
+                            int is_max = val > 0, is_min = val < 0;
+                            for (int dl = -1; dl <= 1 && (is_max || is_min); ++dl)
+                                for (int dr = -1; dr <= 1; ++dr)
+                                    for (int dc = -1; dc <= 1; ++dc) {
+                                        const float nb = dg[layer + dl][(size_t)(rr + dr) * W + cc + dc];
+                                        is_max &= val >= nb;
+                                        is_min &= val <= nb;
+                                    }
+                            if (is_max || is_min) {
+                                if (pass == 1) {
+                                    int32_t *q = cand + 3 * (size_t)(cnt[slot] + n);
+                                    q[0] = layer; q[1] = rr; q[2] = cc;
+                                }
+                                ++n;
+                            }
+                        }
+                        if (pass == 0) cnt[slot] = n;
+                    }
+                if (pass == 1) {
+                    const int n_c = cnt[NL * rows];
+                    const int room = cap - total > 0 ? cap - total : 0;
+                    const int got = oracle_sift_keypoints((const float *const *)dg, (const float *const *)g, H, W,
+                                                          o, cand, n_c, sigma0, kps + (size_t)total * 6, room, 0);
+                    if (got > 0) total += got < room ? got : room;
+                    free(cand);
+                }
+            }
+            free(cnt);
+        }
+        H /= 2; W /= 2;
+        if (H < 1 || W < 1) { n_oct = o + 1; break; }
+    }
+    /* detectAndCompute: first octave is -1 -> input-image coordinates; KeyPoint fields are float32 */
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int k = 0; k < total; ++k) {
+        double *q = kps + (size_t)k * 6;
+        int oc = (int)q[5];
+        oc = (oc & ~255) | ((oc - 1) & 255);
+        q[5] = (double)oc;
+        q[0] = (double)(float)(q[0] * 0.5); q[1] = (double)(float)(q[1] * 0.5);
+        q[2] = (double)(float)(q[2] * 0.5); q[3] = (double)(float)q[3]; q[4] = (double)(float)q[4];
+        int octave = oc & 255, layer = (oc >> 8) & 255;
+        if (octave >= 128) octave |= -128;
+        const double scale = octave >= 0 ? 1.0 / (double)(1 << octave) : (double)(1 << -octave);
+        double a = 360.0 - q[3];
+        if (fabs(a - 360.0) < FLT_EPS) a = 0.0;
+        const int oi = octave + 1;
+        descriptor_one(gauss[oi * (NL + 3) + layer], oh[oi], ow[oi], q[0] * scale, q[1] * scale, a,
+                       q[2] * scale * 0.5, desc + (size_t)k * 128);
+    }
+    for (int q = 0; q < n_oct * (NL + 3); ++q) free(gauss[q]);
+    for (int q = 0; q < n_oct * (NL + 2); ++q) free(dogs[q]);
+    free(gauss); free(dogs); free(oh); free(ow); free(tmp);
+    return total;
+}

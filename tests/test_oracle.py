@@ -204,3 +204,16 @@ def test_c_keypoints_and_descriptors_equal_numpy_twins():
     assert np.array_equal(ka[:, 5], kb[:, 5])
     assert np.abs(ka[:, :5] - kb[:, :5]).max() < 1e-9       # same operations: libm's last bits at most
     assert (da != db).mean() < 1e-3 and np.abs(da.astype(int) - db.astype(int)).max() <= 1
+
+
+def test_all_c_sift_equals_the_oracle():
+    """oracle_sift_detect (the CPU baseline of bench.py's SIFT section: everything in C) ==
+    sift_oracle.detect_and_compute (numpy pyramid glue + the C loops), which in turn equals the
+    numpy twins (test above)"""
+    from oracle import sift_oracle as so
+    for shape, seed in (((120, 150), 7), ((97, 203), 11)):
+        img = _texture(shape[0], shape[1], seed)
+        ka, da = so.detect_and_compute(img)
+        kc, dc = so.detect_and_compute_c(img)
+        assert len(ka) == len(kc) > 100
+        assert np.array_equal(ka, kc) and np.array_equal(da, dc)
