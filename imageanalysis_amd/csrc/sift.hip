@@ -740,11 +740,12 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     const int total = *n_kp < cap_k ? *n_kp : cap_k;
     double *hist = hist_s[wave];
     // one keypoint per wave (private LDS slice, no block barriers).  A workgroup per 4 keypoints
-    // rather than persistent waves: the window size varies 10x between keypoints and the
-    // hardware's dynamic workgroup dispatch balances that (persistent waves measured 15 % slower)
-    const int k = blockIdx.x * 4 + wave;
-    if (k >= total) return;
-    {
+    // rather than a few persistent waves: the window size varies 10x between keypoints and the
+    // hardware's dynamic workgroup dispatch balances that (persistent waves measured 15 % slower).
+    // The grid is capped at 16 384 workgroups (the keypoint count is only known on the device:
+    // a grid for the whole capacity dispatched up to 375 k workgroups that exit at once); images
+    // with more than 65 536 keypoints give some waves a second one.
+    for (int k = blockIdx.x * 4 + wave; k < total; k += gridDim.x * 4) {
     for (int i = lane; i < HB; i += 64) hist[i] = 0.0;
     __builtin_amdgcn_wave_barrier();
     {
@@ -779,17 +780,20 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         // quantised descriptor does not depend on the order the lanes arrive in).
         const float cos_f = (float)cos_t, sin_f = (float)sin_t, ori_f = (float)ori;
         const float bins_f = (float)bins_per_rad, exp_f = (float)exp_scale;
-        auto sample = [&](int i, int j) {
+        // the four gradient neighbours of window position (i, j); callers guarantee that the
+        // position lies inside the image (0 < r < h - 1, 0 < c < w - 1)
+        struct Grad { float xl, xr, yu, yd; };
+        auto fetch = [&](int i, int j) -> Grad {
+            const float *pc = img + (int64_t)(py + i) * w + (px + j);
+            return Grad{pc[-1], pc[1], pc[-w], pc[w]};
+        };
+        auto accumulate = [&](int i, int j, const Grad g) {
             const float fi = (float)i, fj = (float)j;
             const float c_rot = fj * cos_f - fi * sin_f, r_rot = fj * sin_f + fi * cos_f;
             const float rbin = r_rot + (d / 2 - 0.5f), cbin = c_rot + (d / 2 - 0.5f);
-            const int r = py + i, c = px + j;
-            if (!(rbin > -1.f && rbin < (float)d && cbin > -1.f && cbin < (float)d && r > 0 && r < h - 1 &&
-                  c > 0 && c < w - 1))
-                return;
-            const float *pc = img + (int64_t)r * w + c;
-            const float dx = pc[1] - pc[-1];
-            const float dy = pc[-w] - pc[w];
+            if (!(rbin > -1.f && rbin < (float)d && cbin > -1.f && cbin < (float)d)) return;
+            const float dx = g.xr - g.xl;
+            const float dy = g.yu - g.yd;
             const float wgt = __expf((c_rot * c_rot + r_rot * r_rot) * exp_f);
             float og = atan2f(dy, dx) * 57.29577951308232f;
             if (og < 0.f) og += 360.f;
@@ -814,6 +818,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
                 atomicAdd(&hist[base], (double)(vv[q4] - v1));
                 atomicAdd(&hist[base + 1], (double)v1);
             }
+        };
+        auto sample = [&](int i, int j) {
+            const int r = py + i, c = px + j;
+            if (r > 0 && r < h - 1 && c > 0 && c < w - 1) accumulate(i, j, fetch(i, j));
         };
         if (side <= DESC_ROWS) {
             // The samples that pass the test above fill a ROTATED square, half of the upright
@@ -861,10 +869,29 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
             // different histogram cells (neighbouring samples share a cell: 8-way conflicts)
             const int chunk = (carry + 63) >> 6;
             const int s0 = lane * chunk, s1 = min(s0 + chunk, carry);
+            // Software pipeline, one sample deep: the image reads of sample s + 1 are in flight
+            // while sample s goes through its ~150 dependent instructions and 8 LDS atomics (the
+            // lanes of a wave sit in 64 different cache lines; with the loads at the head of each
+            // iteration the kernel was bound by their latency, not by any throughput).  Every
+            // listed position lies inside the image (the intervals are clipped), so the loads
+            // need no test.
             int row = 0;
-            for (int s = s0; s < s1; ++s) {
-                while (s >= rowpre[row + 1]) ++row;
-                sample(row - radius, rowlo[row] + (s - rowpre[row]));
+            if (s0 < s1) {
+                while (s0 >= rowpre[row + 1]) ++row;
+                int ci = row - radius, cj = rowlo[row] + (s0 - rowpre[row]);
+                Grad cg = fetch(ci, cj);
+                for (int s = s0; s < s1; ++s) {
+                    int ni = ci, nj = cj;
+                    Grad ng = cg;
+                    if (s + 1 < s1) {
+                        while (s + 1 >= rowpre[row + 1]) ++row;
+                        ni = row - radius;
+                        nj = rowlo[row] + (s + 1 - rowpre[row]);
+                        ng = fetch(ni, nj);
+                    }
+                    accumulate(ci, cj, cg);
+                    ci = ni; cj = nj; cg = ng;
+                }
             }
         } else {
             const int nsamp = side * side;
@@ -1274,8 +1301,11 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
                        CAP_CAND, contrast_threshold, edge_threshold, refined, n_refined);
     hipLaunchKernelGGL(orient_kernel, dim3(256 * 8), dim3(256), 0, st, T, refined, n_refined,
                        CAP_CAND, sigma_d, kp, cap, n_out);
-    hipLaunchKernelGGL(descriptor_kernel, dim3(blocks(cap, 4)), dim3(256), 0, st, T, kp, n_out, cap,
-                       desc);
+    {
+        const unsigned g = blocks(cap, 4);
+        hipLaunchKernelGGL(descriptor_kernel, dim3(g < 16384u ? g : 16384u), dim3(256), 0, st, T, kp,
+                           n_out, cap, desc);
+    }
     return iamx::check_launch("iamx_sift_detect");
 }
 
