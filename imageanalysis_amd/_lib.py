@@ -51,6 +51,7 @@ SIGNATURES = {
     'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 6),
     'iamx_knn2sym_exact': (c_int, [c_void_p] * 11 + [c_int, c_double] + [c_void_p] * 7),
     'iamx_match_postfilter_clip': (c_int, []),
+    'iamx_match_pack_results': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64] + [c_void_p] * 4),
     'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]
                               + [c_void_p] * 6),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

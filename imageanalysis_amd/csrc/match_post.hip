@@ -444,7 +444,83 @@ __global__ __launch_bounds__(NT) void postfilter_kernel(PostArgs A)
 
 }  // namespace
 
+namespace {
+// ---- results of a batch, packed -----------------------------------------------------------------
+// The per-pair result slots are [n_pairs][clip] (8 + 8 bytes per slot) and on an all-pairs
+// schedule 95-99 % of the pairs end with nothing: downloading the slots moved 130 MB per 4096
+// pairs across PCIe, behind the kernels on the same stream -- as long as the sweep itself.  The
+// pairs that have matches are packed back to back instead (exclusive scan of the counts by one
+// workgroup, then one workgroup per pair copies its rows); `off`, `out_pairs` and `out_z` may be
+// page-locked HOST memory (the device writes it directly: the size of the transfer is only known
+// here), or device memory.
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t *__restrict__ cnt,
+                                                         const int32_t *__restrict__ status, int n,
+                                                         int64_t *__restrict__ off)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + threadIdx.x;
+        const int64_t v = (k < n && status[k] == 0) ? (int64_t)cnt[k] : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int64_t y = __shfl_up(x, sft);
+            if ((threadIdx.x & 63) >= sft) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int64_t before = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += wsum[w];
+        if (k < n) off[k] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[n] = carry;
+}
+
+__global__ __launch_bounds__(256) void pack_copy_kernel(const int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ status,
+                                                        const int32_t *__restrict__ pairs,
+                                                        const double *__restrict__ z, int clip,
+                                                        int64_t cap, const int64_t *__restrict__ off,
+                                                        int32_t *__restrict__ out_pairs,
+                                                        double *__restrict__ out_z)
+{
+    const int k = blockIdx.x;
+    if (status[k] != 0) return;
+    const int c = cnt[k];
+    const int64_t o = off[k];
+    if (c <= 0 || o + c > cap) return;
+    const int2 *src = reinterpret_cast<const int2 *>(pairs) + (int64_t)k * clip;
+    int2 *dst = reinterpret_cast<int2 *>(out_pairs) + o;
+    for (int i = threadIdx.x; i < c; i += 256) dst[i] = src[i];
+    if (z && out_z) {
+        const double *zs = z + (int64_t)k * clip;
+        for (int i = threadIdx.x; i < c; i += 256) out_z[o + i] = zs[i];
+    }
+}
+
+}  // namespace
+
 extern "C" int iamx_match_postfilter_clip(void) { return CLIP; }
+
+extern "C" int iamx_match_pack_results(const int32_t *cnt, const int32_t *status, const int32_t *pairs,
+                                       const double *z, int n_pairs, int clip, int64_t cap,
+                                       int64_t *off, int32_t *out_pairs, double *out_z, void *stream)
+{
+    IAMX_REQUIRE(cnt && status && pairs && off && out_pairs, "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && clip > 0 && cap >= 0, "bad size");
+    hipStream_t st = iamx::as_stream(stream);
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, status, n_pairs, off);
+    if (n_pairs)
+        hipLaunchKernelGGL(pack_copy_kernel, dim3(n_pairs), dim3(256), 0, st, cnt, status, pairs, z,
+                           clip, cap, (const int64_t *)off, out_pairs, out_z);
+    return iamx::check_launch("iamx_match_pack_results");
+}
 
 extern "C" int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt,
                                      const int32_t *surv_q, const int32_t *surv_t,

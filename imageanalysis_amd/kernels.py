@@ -356,15 +356,72 @@ class PairWorkspace(object):
                 self.surv_t[:total].cpu().numpy(), self.surv_metric[:total].cpu().numpy())
 
 
+class UploadArena(object):
+    """Small host tables -> device without stalling the stream.  A pageable `tensor.to(device)`
+    blocks the host until everything already enqueued has run -- in find_matches' software
+    pipeline that is the previous round's 4 ms of kernels, per table, a dozen tables per round.
+    The arena packs all tables of a round into ONE page-locked buffer and issues ONE asynchronous
+    copy into a device buffer of a small ring (a slot is reused after the event behind its copy);
+    the tensors it hands out are views of that device buffer, valid in stream order."""
+
+    def __init__(self, nbytes=8 << 20, slots=4):
+        dev = require_gpu()
+        self.dev = dev
+        self.slots = [dict(pin=torch.empty(nbytes, dtype=U8).pin_memory(),
+                           dev=torch.empty(nbytes, dtype=U8, device=dev),
+                           ev=torch.cuda.Event(), used=False) for _ in range(slots)]
+        self.cur, self.off, self.k = None, 0, 0
+
+    def begin(self):
+        if self.cur is not None:
+            self.commit()
+        self.k = (self.k + 1) % len(self.slots)
+        self.cur = self.slots[self.k]
+        if self.cur['used']:
+            self.cur['ev'].synchronize()
+        self.off = 0
+
+    def put(self, a):
+        """numpy array -> device tensor (same dtype / shape) behind the arena's next commit()"""
+        a = np.ascontiguousarray(a)
+        nb = a.nbytes
+        off = (self.off + 15) & ~15
+        if self.cur is None or off + nb > self.cur['pin'].numel():
+            return torch.from_numpy(a).to(self.dev)            # (does not fit: the plain way)
+        if nb:
+            self.cur['pin'].numpy()[off:off + nb] = a.reshape(-1).view(np.uint8)
+        self.off = off + nb
+        t = self.cur['dev'][off:off + nb].view(_TORCH_OF[a.dtype.str]) if nb else \
+            torch.empty(0, dtype=_TORCH_OF[a.dtype.str], device=self.dev)
+        return t.view(a.shape) if a.ndim != 1 else t
+
+    def commit(self):
+        c = self.cur
+        if c is None:
+            return
+        if self.off:
+            c['dev'][:self.off].copy_(c['pin'][:self.off], non_blocking=True)
+        c['ev'].record()
+        c['used'] = True
+        self.cur = None
+
+
+_TORCH_OF = {'<i4': torch.int32, '<i8': torch.int64, '<f4': torch.float32, '<f8': torch.float64,
+             '|u1': torch.uint8, '|i1': torch.int8}
+
+
 class PairBatch(object):
     """Device-side launch tables of one batch of ordered (query image, train image) pairs.
     `run()` only enqueues kernels on the current stream (no host sync, no allocation)."""
 
-    def __init__(self, store, pairs, sym=None):
+    def __init__(self, store, pairs, sym=None, arena=None):
         """sym: None = use the symmetric sweep (one MFMA pass for both directions of an image
         pair) when the batch holds both directions of every pair, False = never (one sweep per
-        ordered pair), True = require it."""
+        ordered pair), True = require it.  arena: an UploadArena between begin() and commit() --
+        the launch tables go up with its one asynchronous copy."""
         dev = require_gpu()
+        up = arena.put if arena is not None else (lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev))
+        self._up = up
         self.store = store
         pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
         counts = np.asarray(store.counts, np.int64)
@@ -381,16 +438,16 @@ class PairBatch(object):
             raise ValueError("batch too large: split the pair list")
         self.rows = int(self.out_off[-1])
         self.total_wg = int(wg[-1])
-        self.d_pairs = torch.from_numpy(pairs).to(dev)
-        self.d_wg = torch.from_numpy(wg.astype(np.int32)).to(dev)
-        self.d_out = torch.from_numpy(self.out_off.copy()).to(dev)     # also the metric seg_off
+        self.d_pairs = up(pairs)
+        self.d_wg = up(wg.astype(np.int32))
+        self.d_out = up(self.out_off.copy())                           # also the metric seg_off
         # query rows per workgroup of the fast sweep (256 / 512 / 1024 by image size): bigger =
         # fewer LDS reads and barriers per MFMA
         self.fast_rows = 256 if not (P and nq.min() >= 2048) else (1024 if nq.min() >= 4096 else 512)
         wgf = np.zeros(P + 1, np.int64)
         np.cumsum((nq + self.fast_rows - 1) // self.fast_rows, out=wgf[1:])
         self.total_wg_fast = int(wgf[-1])
-        self.d_wg_fast = torch.from_numpy(wgf.astype(np.int32)).to(dev)
+        self.d_wg_fast = up(wgf.astype(np.int32))
         self.sym = False
         if sym is not False:
             self._setup_sym(dev)
@@ -407,11 +464,12 @@ class PairBatch(object):
         self.sym_form = t['form']
         self.n_u, self.sym_total_wg = len(t['upairs']), int(t['wg'][-1])
         self.sym_col_rows, self.sym_rowp_rows = int(t['col_off'][-1]), int(t['rowp_off'][-1])
-        self.d_upairs = torch.from_numpy(np.ascontiguousarray(t['upairs'])).to(dev)
-        self.d_sym_wg = torch.from_numpy(t['wg'].astype(np.int32)).to(dev)
-        self.d_col_off = torch.from_numpy(t['col_off'][:-1].copy()).to(dev)
-        self.d_rowp_off = torch.from_numpy(t['rowp_off'][:-1].copy()).to(dev)
-        self.d_osrc = torch.from_numpy(t['osrc']).to(dev)
+        up = self._up
+        self.d_upairs = up(np.ascontiguousarray(t['upairs']))
+        self.d_sym_wg = up(t['wg'].astype(np.int32))
+        self.d_col_off = up(t['col_off'][:-1].copy())
+        self.d_rowp_off = up(t['rowp_off'][:-1].copy())
+        self.d_osrc = up(t['osrc'])
 
     def run_sym_sweep(self, ws):
         st = self.store

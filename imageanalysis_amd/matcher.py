@@ -41,8 +41,9 @@ max_distance = None
 min_pairs = 25
 
 MYMAX = 2000            # matcher.py:265
-PAIRS_PER_BATCH = 2048  # unordered pairs per device batch (per-batch host costs are ~2 ms)
+PAIRS_PER_BATCH = 4096  # unordered pairs per device batch (per-batch host costs are ~1 ms)
 BATCH_BYTES = 6 << 30   # ... as far as one batch's device workspace stays below this
+PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
 
 
 def _workspace_bytes_per_pair(rows):
@@ -378,7 +379,8 @@ def bidirectional_pair_matches(i1, i2, review=False):
 # --------------------------------------------------------------------------------------
 # pair schedule -- matcher.py:852-916
 # --------------------------------------------------------------------------------------
-def _work_list(proj, sort):
+def _work_arrays(proj, sort):
+    """the pair schedule as arrays (dist float64, i int32, j int32), i < j"""
     image_list = proj.image_list
     ned = np.array([im.get_camera_pose()[0] for im in image_list], np.float64).reshape(-1, 3)
     intervals = np.linalg.norm(ned[1:] - ned[:-1], axis=1)
@@ -413,10 +415,16 @@ def _work_list(proj, sort):
     ii, jj, dist = ii[sel], jj[sel], dist[sel]
     # python's round() is round-half-even, like np.rint
     ddist = np.rint(dist / interval) * interval
-    work = [[float(d), int(i), int(j)] for d, i, j in zip(ddist, ii, jj)]
     if sort:
-        work = sorted(work, key=lambda fields: fields[0])        # stable, like the reference
-    return work
+        order = np.argsort(ddist, kind='stable')         # stable, like the reference's sorted()
+        ddist, ii, jj = ddist[order], ii[order], jj[order]
+    return ddist.astype(np.float64), ii.astype(np.int32), jj.astype(np.int32)
+
+
+def _work_list(proj, sort):
+    """[[dist, i, j], ...] -- the reference's work_list (matcher.py:886-916)"""
+    d, i, j = _work_arrays(proj, sort)
+    return [[float(a), int(b), int(c)] for a, b, c in zip(d.tolist(), i.tolist(), j.tolist())]
 
 
 # --------------------------------------------------------------------------------------
@@ -510,6 +518,58 @@ def detect_features_sharded(proj, images=None):
 
 
 _host_sets = {}          # (n, clip, surface) -> free page-locked result buffer sets
+_arena = None
+_ws_pool = []            # free kernels.PairWorkspace objects (a round's outputs; reused)
+_post_pool = {}          # (n, clip, surface) -> free device result sets of the per-pair filters
+
+
+def _upload_arena():
+    global _arena
+    from . import kernels
+    if _arena is None:
+        _arena = kernels.UploadArena()
+    return _arena
+
+
+def _workspace(rows, pairs):
+    """a PairWorkspace with room for `rows` query rows / `pairs` ordered pairs from the pool (a
+    round's workspace goes back when its results have been read)"""
+    from . import kernels
+    for k, w in enumerate(_ws_pool):
+        if w.max_rows >= rows and w.max_pairs >= pairs:
+            return _ws_pool.pop(k)
+    if len(_ws_pool) >= 3:                       # (a survey's rounds are all the same size)
+        _ws_pool.pop(0)
+    return kernels.PairWorkspace(int(rows * 1.05) + 1024, pairs)
+
+
+def _post_set(n, clip, dev, surface):
+    import torch
+    free = _post_pool.setdefault((n, clip, bool(surface)), [])
+    if free:
+        return free.pop()
+    post = dict(key=(n, clip, bool(surface)),
+                cnt=torch.empty(n, dtype=torch.int32, device=dev),
+                pairs=torch.empty((n, clip, 2), dtype=torch.int32, device=dev),
+                scratch=torch.empty((n, 2, clip, 2), dtype=torch.int32, device=dev),
+                stat=torch.empty((n, 4), dtype=torch.int32, device=dev),
+                status=torch.empty(n, dtype=torch.int32, device=dev))
+    if surface:
+        post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
+        post['aff'] = torch.empty((n, 2, 6), dtype=torch.float64, device=dev)
+        post['aff_ok'] = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    return post
+
+
+def _recycle(h):
+    """a finished round's device buffers back to their pools"""
+    if h.get('ws') is not None:
+        _ws_pool.append(h['ws'])
+        h['ws'] = None
+    post = h.get('post')
+    if post is not None and 'key' in post:
+        _post_pool[post['key']].append(post)
+        h['post'] = None
 
 
 def _host_set(n, clip, surface):
@@ -523,10 +583,13 @@ def _host_set(n, clip, surface):
     hs = dict(key=(n, clip, surface), zero_div=pin(1, torch.int32),
               count=pin(2 * n, torch.int32))
     if clip:
-        hs.update(cnt=pin(n, torch.int32), status=pin(n, torch.int32),
-                  pairs=pin((n, clip, 2), torch.int32))
+        # the matches of the pairs that have some, packed back to back by the device
+        # (iamx_match_pack_results writes these page-locked buffers directly)
+        cap = min(n * clip, PACK_CAP)
+        hs.update(cnt=pin(n, torch.int32), status=pin(n, torch.int32), cap=cap,
+                  off=pin(n + 1, torch.int64), pk_pairs=pin((cap, 2), torch.int32))
         if surface:
-            hs['z'] = pin((n, clip), torch.float64)
+            hs['pk_z'] = pin(cap, torch.float64)
             hs['aff'] = pin((n, 2, 6), torch.float64)
             hs['aff_ok'] = pin((n, 2), torch.int32)
     return hs
@@ -545,16 +608,27 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     from .kernels import _ptr, check, lib, stream_ptr
     dm = the_matcher
     by_id = {}                                   # one slot_of() per image, not per pair
-    for pair in batch:
-        for im in pair:
-            if id(im) not in by_id:
-                by_id[id(im)] = (dm.slot_of(im), im)
-    slots = [(by_id[id(a)][0], by_id[id(b)][0]) for a, b in batch]
+    if isinstance(batch, _PairView):
+        # a round of find_matches: index arrays, no tuple per pair
+        slot_of = np.zeros(len(batch.image_list), np.int32)
+        for u in batch.uniq.tolist():
+            im = batch.image_list[u]
+            slot_of[u] = dm.slot_of(im)
+            by_id[id(im)] = (int(slot_of[u]), im)
+        slots = np.stack([slot_of[batch.pi], slot_of[batch.pj]], 1)
+    else:
+        for pair in batch:
+            for im in pair:
+                if id(im) not in by_id:
+                    by_id[id(im)] = (dm.slot_of(im), im)
+        slots = [(by_id[id(a)][0], by_id[id(b)][0]) for a, b in batch]
     store = dm.store()
+    arena = _upload_arena()
+    arena.begin()
     d_proj = d_ik = None
     if surface and device_filters:
-        # pageable uploads wait for everything already enqueued: do them BEFORE this batch's
-        # kernels go in, or the host would sit here until they have run
+        # (every small table of the batch goes up with ONE asynchronous copy: a pageable upload
+        #  blocks the host until the previous batch's kernels have run)
         from . import smart as _smart
         PROJ = np.zeros((len(dm._counts), 12))
         epoch = dm._pose_epoch
@@ -571,13 +645,13 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                 dm._proj[s] = hit
             PROJ[s] = hit[1]
         IK = np.linalg.inv(np.asarray(_deps.camera().get_K(), float))
-        dev0 = kernels.require_gpu()
-        d_proj = torch.from_numpy(PROJ).to(dev0)
-        d_ik = torch.from_numpy(np.ascontiguousarray(IK.ravel())).to(dev0)
+        d_proj = arena.put(PROJ)
+        d_ik = arena.put(np.ascontiguousarray(IK.ravel()))
     sl = np.asarray(slots, np.int32).reshape(-1, 2)
     ordered = np.concatenate([sl, sl[:, ::-1]])
-    pb = kernels.PairBatch(store, ordered)
-    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb = kernels.PairBatch(store, ordered, arena=arena)
+    arena.commit()
+    ws = _workspace(pb.rows, pb.n_pairs)
     if device_filters:
         kp_off, xy, key2 = dm.keypoints()        # (may upload: before the kernels, like PROJ)
     thresh = max_distance * match_ratio
@@ -590,11 +664,7 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
         L = lib()
         clip = int(L.iamx_match_postfilter_clip())
         dev = xy.device
-        post = dict(cnt=torch.empty(n, dtype=torch.int32, device=dev),
-                    pairs=torch.empty((n, clip, 2), dtype=torch.int32, device=dev),
-                    scratch=torch.empty((n, 2, clip, 2), dtype=torch.int32, device=dev),
-                    stat=torch.empty((n, 4), dtype=torch.int32, device=dev),
-                    status=torch.empty(n, dtype=torch.int32, device=dev))
+        post = _post_set(n, clip, dev, surface)
         check(L.iamx_match_postfilter(_ptr(ws.surv_off), _ptr(ws.surv_cnt), _ptr(ws.surv_q),
                                       _ptr(ws.surv_t), _ptr(ws.surv_metric), _ptr(pb.d_pairs),
                                       _ptr(kp_off), _ptr(xy), _ptr(key2), n, float(cam_w),
@@ -603,14 +673,11 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                                       _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
         if surface:
             post['tri_cnt'] = post['cnt']           # (0 for the pairs left to the host filters)
-            post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
             check(L.iamx_triangulate_pairs(_ptr(pb.d_pairs), _ptr(d_proj), _ptr(d_ik), _ptr(kp_off),
                                            _ptr(xy), _ptr(post['tri_cnt']), _ptr(post['pairs']), n,
                                            clip, _ptr(post['z']), stream_ptr()),
                   'iamx_triangulate_pairs')
             # the similarity between the two images' keypoints, both ways (yaw-error estimate)
-            post['aff'] = torch.empty((n, 2, 6), dtype=torch.float64, device=dev)
-            post['aff_ok'] = torch.empty((n, 2), dtype=torch.int32, device=dev)
             check(L.iamx_similarity_pairs(_ptr(pb.d_pairs), _ptr(kp_off), _ptr(xy),
                                           _ptr(post['tri_cnt']), _ptr(post['pairs']), n, clip,
                                           _ptr(post['aff']), _ptr(post['aff_ok']), stream_ptr()),
@@ -621,9 +688,13 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     if post is not None:
         hs['cnt'].copy_(post['cnt'], non_blocking=True)
         hs['status'].copy_(post['status'], non_blocking=True)
-        hs['pairs'].copy_(post['pairs'], non_blocking=True)
-        if 'z' in post:
-            hs['z'].copy_(post['z'], non_blocking=True)
+        has_z = 'z' in post
+        check(lib().iamx_match_pack_results(_ptr(post['cnt']), _ptr(post['status']), _ptr(post['pairs']),
+                                            _ptr(post['z']) if has_z else None, n, clip, hs['cap'],
+                                            _ptr(hs['off']), _ptr(hs['pk_pairs']),
+                                            _ptr(hs['pk_z']) if has_z else None, stream_ptr()),
+              'iamx_match_pack_results')
+        if has_z:
             hs['aff'].copy_(post['aff'], non_blocking=True)
             hs['aff_ok'].copy_(post['aff_ok'], non_blocking=True)
     done_ev = torch.cuda.Event()
@@ -646,11 +717,11 @@ def _finish_batch(h):
         first = sq = st = sm = status = cnt = lists = None
         z_rows = {}
         if post is not None:
-            cnt, status, lists = hs['cnt'].numpy(), hs['status'].numpy(), hs['pairs'].numpy()
-            if 'z' in hs and 'z' in post:
-                z = hs['z'].numpy()
+            cnt, status = hs['cnt'].numpy(), hs['status'].numpy()
+            lists, zs = _unpacked(hs, post, n)
+            if zs is not None:
                 aff, aff_ok = hs['aff'].numpy(), hs['aff_ok'].numpy()
-                z_rows = {int(k): (z[k, :cnt[k]],
+                z_rows = {int(k): (zs(k),
                                    aff[k, 0].reshape(2, 3).copy() if aff_ok[k, 0] else None,
                                    aff[k, 1].reshape(2, 3).copy() if aff_ok[k, 1] else None)
                           for k in np.nonzero((status == 0) & (cnt > 0))[0]}
@@ -663,7 +734,163 @@ def _finish_batch(h):
                            cnt, lists, z_rows, h['surface'])
     finally:
         _host_sets[hs['key']].append(hs)
+        _recycle(h)
     return out
+
+
+def _unpacked(hs, post, n):
+    """accessors of a finished batch's packed download: (pairs_of(k) -> int32 [cnt, 2],
+    z_of(k) -> float64 [cnt] or None).  A batch with more matches than the packed buffers hold
+    has its slots copied the plain way."""
+    cnt, off = hs['cnt'].numpy(), hs['off'].numpy()
+    if int(off[n]) <= hs['cap']:
+        pk, pz = hs['pk_pairs'].numpy(), hs['pk_z'].numpy() if 'pk_z' in hs and 'z' in post else None
+        return ((lambda k: pk[off[k]:off[k] + cnt[k]]),
+                (lambda k: pz[off[k]:off[k] + cnt[k]]) if pz is not None else None)
+    full = post['pairs'].cpu().numpy()
+    fz = post['z'].cpu().numpy() if 'z' in post else None
+    return ((lambda k: full[k, :cnt[k]]), (lambda k: fz[k, :cnt[k]]) if fz is not None else None)
+
+
+class _PairView(object):
+    """the (image, image) pairs of one round of find_matches as two index arrays into
+    proj.image_list (a sequence of pairs for the code that wants one)"""
+
+    def __init__(self, image_list, pi, pj):
+        self.image_list, self.pi, self.pj = image_list, pi, pj
+        self.uniq = np.unique(np.concatenate([pi, pj]))
+
+    def __len__(self):
+        return len(self.pi)
+
+    def __getitem__(self, k):
+        return self.image_list[int(self.pi[k])], self.image_list[int(self.pj[k])]
+
+    def __iter__(self):
+        il = self.image_list
+        return ((il[a], il[b]) for a, b in zip(self.pi.tolist(), self.pj.tolist()))
+
+
+class _RoundResult(object):
+    """what a round delivers, as arrays over its pairs: n_fwd / n_rev (quality matches per
+    direction), cc (cross checked matches), quiet (nothing left after the filters), and for the
+    other pairs `hits` = [(k, fwd, rev, surf)] with array-backed match lists and surf =
+    (avg, std, dist_m, affine_fwd, affine_rev) or None"""
+    __slots__ = ('n', 'n_fwd', 'n_rev', 'cc', 'quiet', 'hits')
+
+
+def _finish_batch_arrays(h):
+    """_finish_batch() for find_matches: the same wait and the same results, but only the pairs
+    that HAVE matches become python objects -- on an all-pairs schedule 95-99 % of the pairs end
+    with nothing and are just a mask here.  h: the handle of _launch_batch(view, ...)."""
+    if isinstance(h, list):
+        # (a stand-in of _launch_batch / _finish_batch that already returns per-pair tuples:
+        #  the CPU tests of the multi-rank logic)
+        return _round_from_tuples(h)
+    from . import smart as _smart
+    h['done'].synchronize()
+    hs, n, ws, post = h['host'], h['n'], h['ws'], h['post']
+    R = _RoundResult()
+    R.n = n
+    try:
+        if int(hs['zero_div'][0]):
+            raise ZeroDivisionError("float division by zero")       # matcher.py:255
+        count = hs['count'].numpy()
+        R.n_fwd, R.n_rev = count[:n].astype(np.int64), count[n:2 * n].astype(np.int64)
+        if post is None:
+            raise ValueError("find_matches runs the device filters")
+        cnt, status = hs['cnt'].numpy(), hs['status'].numpy()
+        lists, zs = _unpacked(hs, post, n)
+        R.cc = np.where(status == 0, cnt, 0).astype(np.int64)
+        R.quiet = (status == 0) & (cnt == 0)
+        R.hits = []
+        dev_rows = np.nonzero((status == 0) & (cnt > 0))[0]
+        surface = h['surface'] and zs is not None
+        view = h['batch']
+        if len(dev_rows):
+            c = cnt[dev_rows].astype(np.int64)
+            if surface:
+                # -mean / std of the triangulated "down" of every pair in one go
+                # (smart.estimate_surface_elevation, smart.py:117-130)
+                off = hs['off'].numpy()
+                if int(off[n]) <= hs['cap']:
+                    # packed: per-pair sums over contiguous segments
+                    zcat = hs['pk_z'].numpy()[:int(off[n])]
+                    starts = off[dev_rows]
+                    mean = np.add.reduceat(zcat, starts) / c
+                    dev2 = (zcat - np.repeat(mean, c)) ** 2
+                    std = np.sqrt(np.add.reduceat(dev2, starts) / c)
+                else:
+                    Z = np.zeros((len(dev_rows), int(c.max())))
+                    for t_, k_ in enumerate(dev_rows.tolist()):
+                        Z[t_, :c[t_]] = zs(k_)
+                    m = np.arange(Z.shape[1])[None, :] < c[:, None]
+                    mean = np.where(m, Z, 0.0).sum(1) / c
+                    std = np.sqrt((np.where(m, Z - mean[:, None], 0.0) ** 2).sum(1) / c)
+                aff, aff_ok = hs['aff'].numpy()[dev_rows], hs['aff_ok'].numpy()[dev_rows]
+                ned, air_yaw = _smart.frozen_ned(view.image_list, with_yaw=True)
+                a_idx, b_idx = view.pi[dev_rows], view.pj[dev_rows]
+                dist = np.linalg.norm(ned[b_idx] - ned[a_idx], axis=1)
+                same = a_idx == b_idx
+                # the yaw error of both directions of every pair from the similarity fits
+                # (smart.yaw_error_from_affine, vectorised over the round)
+                yv_f = np.stack(_smart.yaw_errors_from_affines(ned[a_idx], air_yaw[a_idx], ned[b_idx],
+                                                               aff[:, 0]), 1).tolist()
+                yv_r = np.stack(_smart.yaw_errors_from_affines(ned[b_idx], air_yaw[b_idx], ned[a_idx],
+                                                               aff[:, 1]), 1).tolist()
+            for t, k in enumerate(dev_rows.tolist()):
+                ck = int(c[t])
+                both = np.empty((2, ck, 2), np.int32)          # (the download is a pinned buffer the
+                both[0] = lists(k)                             #  next round reuses: copied once)
+                both[1] = both[0, :, ::-1]
+                surf = None
+                if surface:
+                    surf = _NO_SURFACE if same[t] else (
+                        -float(mean[t]), float(std[t]), float(dist[t]), None, None,
+                        tuple(yv_f[t]) if aff_ok[t, 0] else None,
+                        tuple(yv_r[t]) if aff_ok[t, 1] else None)
+                R.hits.append((k, MatchPairs(both[0]), MatchPairs(both[1]), surf))
+        host_rows = np.nonzero(status != 0)[0]
+        if len(host_rows):
+            # pairs the device filters handed back (more candidates than their buffers hold):
+            # the host filters, per pair, as before
+            first, count_s, sq, st, sm = ws.survivors(h['pb'].n_pairs)
+            for k in host_rows.tolist():
+                i1, i2 = view[k]
+                _ensure_features(i1)
+                _ensure_features(i2)
+                xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
+                a, b = first[k], first[k] + count_s[k]
+                fwd = _post_filter(i1, i2, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]), (xy1, xy2))
+                rev = []
+                if len(fwd) >= min_pairs:
+                    a, b = first[n + k], first[n + k] + count_s[n + k]
+                    rev = _post_filter(i2, i1, _threshold_sort_clip(sq[a:b], st[a:b], sm[a:b]),
+                                       (xy2, xy1))
+                fwd, rev = filter_cross_check(fwd, rev)
+                R.cc[k] = len(fwd)
+                if len(fwd) == 0 and len(rev) == 0:
+                    R.quiet[k] = True
+                else:
+                    R.hits.append((k, fwd, rev, None))
+            R.hits.sort(key=lambda t: t[0])
+    finally:
+        _host_sets[hs['key']].append(hs)
+        _recycle(h)
+    return R
+
+
+def _round_from_tuples(results):
+    """per-pair tuples (fwd, rev, n_fwd, n_rev[, surf]) -> _RoundResult"""
+    R = _RoundResult()
+    R.n = n = len(results)
+    R.n_fwd = np.array([r[2] for r in results], np.int64).reshape(n)
+    R.n_rev = np.array([r[3] for r in results], np.int64).reshape(n)
+    R.cc = np.array([len(r[0]) for r in results], np.int64).reshape(n)
+    R.quiet = np.array([len(r[0]) == 0 and len(r[1]) == 0 for r in results], bool).reshape(n)
+    R.hits = [(k, r[0], r[1], r[4] if len(r) > 4 else None) for k, r in enumerate(results)
+              if not R.quiet[k]]
+    return R
 
 
 def _match_batch(batch, match_ratio, device_filters=True, surface=False):
@@ -709,7 +936,7 @@ def _collect_batch(out, batch, n, count, first, sq, st, sm, have_post, status, c
             c = cnt[k]
             if c:
                 both = np.empty((2, c, 2), np.int32)
-                both[0] = lists[k, :c]
+                both[0] = lists(k)
                 both[1] = both[0, :, ::-1]
                 fwd, rev = MatchPairs(both[0]), MatchPairs(both[1])
             else:
@@ -809,6 +1036,7 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
 
 def _find_matches(proj, K, strategy, transform, sort, review):
     from . import dist as _dist
+    from .matchpairs import MatchDict, QuietLedger
     if strategy != "traditional":
         _log("Match strategy", strategy, "is not on the MI355X path; only 'traditional'",
              "(bidirectional k=2 NN + metric + GMS + cross check) is.")
@@ -820,43 +1048,65 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     smart = _deps.smart()
     if hasattr(smart, 'freeze_poses'):
         smart.freeze_poses(True)
-    # our own smart mirror: the owning rank triangulates its whole batch in one launch
+    # our own smart mirror: the owning rank triangulates its whole batch in one launch, and the
+    # weighted averages over an image's pairs are formed once at the end instead of after every
+    # pair (begin_batch / flush_aggregates)
     batched_surface = smart is not None and hasattr(smart, 'record_surface_estimate')
     rank, ws = _dist.world()
     t_start = time.time()
-    work_list = _work_list(proj, sort)
+    image_list = proj.image_list
+    names = [im.name for im in image_list]
+    wd, wi, wj = _work_arrays(proj, sort)
     match_ratio = matcher_node.getFloat('match_ratio')
 
     # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
-    pending = []
-    if not any(im.match_list for im in proj.image_list):
-        pending, work_list = work_list, []          # a fresh survey: nothing to skip
-    for dist, i, j in work_list:
-        i1, i2 = proj.image_list[i], proj.image_list[j]
-        if i2.name in i1.match_list and i1.name in i2.match_list:
-            if len(i1.match_list[i2.name]) == 0:
-                _log("Retrying: ", i1.name, "vs", i2.name, "(no matches found previously)")
-            else:
-                _log("Skipping: ", i1.name, "vs", i2.name, "already done.")
-                continue
-        pending.append((dist, i, j))
-
+    if any(im.match_list for im in image_list):
+        index_of = {n_: k for k, n_ in enumerate(names)}
+        n_img = len(names)
+        tried = np.zeros((n_img, n_img), bool)
+        found = np.zeros((n_img, n_img), bool)
+        for k, im in enumerate(image_list):
+            for other, lst in im.match_list.items():
+                o = index_of.get(other)
+                if o is not None:
+                    tried[k, o] = True
+                    found[k, o] = len(lst) > 0
+        both = tried[wi, wj] & tried[wj, wi]
+        retry = both & ~found[wi, wj]
+        skip = both & found[wi, wj]
+        for k in np.nonzero(retry)[0][:50].tolist():
+            _log("Retrying: ", names[wi[k]], "vs", names[wj[k]], "(no matches found previously)")
+        for k in np.nonzero(skip)[0][:50].tolist():
+            _log("Skipping: ", names[wi[k]], "vs", names[wj[k]], "already done.")
+        if retry.sum() > 50 or skip.sum() > 50:
+            _log("... %d pairs retried (no matches found previously), %d skipped (already done)"
+                 % (int(retry.sum()), int(skip.sum())))
+        keep = ~skip
+        wd, wi, wj = wd[keep], wi[keep], wj[keep]
     if ws > 1:
         # Results are gathered on rank 0 only, so after an earlier find_matches call in this
         # process the other ranks' match lists are incomplete and their skip rule would keep a
         # different list: rank 0's list is THE list (every collective below assumes the ranks
         # agree on it -- sharded detection, the batch size, the rounds, the shard bounds)
-        pending = _dist.broadcast_object(pending if rank == 0 else None, src=0)
+        wd, wi, wj = _dist.broadcast_object((wd, wi, wj) if rank == 0 else None, src=0)
+    n_pending = len(wi)
+
+    # every image's match_list becomes a MatchDict tied to this call's ledger of quiet pairs
+    ledger = QuietLedger(names)
+    for k, im in enumerate(image_list):
+        if not isinstance(im.match_list, MatchDict):
+            im.match_list = MatchDict(im.match_list)
+        im.match_list.attach(ledger, k)
 
     save_time = time.time()
     save_interval = 300     # seconds
     _log("Processing worklist matches:")
-    if ws > 1 and isinstance(the_matcher, DeviceMatcher) and pending:
+    if ws > 1 and isinstance(the_matcher, DeviceMatcher) and n_pending:
         # every image of the work list is detected by ONE rank; descriptors and keypoint
-        # positions are exchanged once (a collective: `pending` is the same on every rank)
-        detect_features_sharded(proj, sorted({k for _d, i, j in pending for k in (i, j)}))
-    mine = _dist.shard_pairs(pending, rank, ws)
-    shard_sizes = [_dist.shard_bounds(len(pending), r, ws) for r in range(ws)]
+        # positions are exchanged once (a collective: the work list is the same on every rank)
+        detect_features_sharded(proj, np.unique(np.concatenate([wi, wj])).tolist())
+    lo_mine, hi_mine = _dist.shard_bounds(n_pending, rank, ws)
+    shard_sizes = [_dist.shard_bounds(n_pending, r, ws) for r in range(ws)]
     # pairs per device batch: bounded by the workspace a batch needs at this survey's keypoint
     # counts (the images of a survey carry similar numbers: the largest count known so far, or
     # that of the first image of this rank's share, stands for all); the ranks agree on the
@@ -864,11 +1114,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     ppb = PAIRS_PER_BATCH
     early_failure = None
     try:
-        if mine and isinstance(the_matcher, DeviceMatcher):
-            known = [_rows_of(im) for im in proj.image_list if _have_features(im)]
+        if hi_mine > lo_mine and isinstance(the_matcher, DeviceMatcher):
+            known = [_rows_of(im) for im in image_list if _have_features(im)]
             if not known:
-                _ensure_features(proj.image_list[mine[0][1]])
-                known = [_rows_of(proj.image_list[mine[0][1]])]
+                first = image_list[int(wi[lo_mine])]
+                _ensure_features(first)
+                known = [_rows_of(first)]
             ppb = _pairs_per_batch(1.25 * max(known))
     except (Exception, SystemExit) as exc:
         if ws == 1:
@@ -876,47 +1127,191 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         early_failure = exc           # re-raised on every rank by the first gather below
     if ws > 1:
         ppb = min(_dist.allgather_objects(ppb))
-    n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if pending else 0
+    n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if n_pending else 0
     n_done = 0
-    yaw_is_zero = {}        # image index -> its yaw error estimate was last set to 0 here
 
     # ---- images this rank will have to detect / load, in the order the rounds reach them:
     # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
     from . import image as _image
-    need, seen = [], set()
-    for _d, i, j in mine:
-        for k in (i, j):
-            if k not in seen:
-                seen.add(k)
-                im = proj.image_list[k]
-                if not _have_features(im) and \
-                        getattr(type(im), 'detect_features', None) is _image.detect_features:
-                    need.append(im)
-        if len(seen) == len(proj.image_list):
-            break
+    mine_imgs = np.stack([wi[lo_mine:hi_mine], wj[lo_mine:hi_mine]], 1).ravel()
+    _u, first_at = np.unique(mine_imgs, return_index=True)
+    need = []
+    for k in mine_imgs[np.sort(first_at)].tolist():
+        im = image_list[k]
+        if not _have_features(im) and \
+                getattr(type(im), 'detect_features', None) is _image.detect_features:
+            need.append(im)
     prefetcher = _image.prefetch(need) if need else None
 
-    image_list = proj.image_list
+    rows = np.zeros(len(image_list), np.int64)           # descriptor rows of the images seen so far
+    rows_known = np.zeros(len(image_list), bool)         # (reset by the periodic cache flush)
 
     def launch_round(rnd):
-        part = mine[rnd * ppb:(rnd + 1) * ppb]
-        if not part:
+        a = lo_mine + rnd * ppb
+        b = min(a + ppb, hi_mine)
+        if b <= a:
             return None
+        view = _PairView(image_list, wi[a:b], wj[a:b])
         # per IMAGE of the round, not per pair: time stamp of the descriptor cache, detection
         # if the features are not there, the row count the log quotes
         now = time.time()
-        rows = {}
-        for k in {k for _d, i, j in part for k in (i, j)}:
+        for k in view.uniq.tolist():
             im = image_list[k]
             im.desc_timestamp = now
+            if rows_known[k]:
+                continue
             if not _have_features(im):
                 _ensure_features(im)
             rows[k] = _rows_of(im)
+            rows_known[k] = True
             if rows[k] <= 1:
                 # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                 raise ZeroDivisionError("float division by zero")
-        lines = [(dist, i, j, image_list[i], image_list[j]) for dist, i, j in part]
-        return _launch_lines(lines, match_ratio, batched_surface, [(rows[i], rows[j]) for _d, i, j in part])
+        handle = _launch_batch(view, match_ratio, surface=True) if batched_surface \
+            else _launch_batch(view, match_ratio)
+        return view, a, rows, handle
+
+    def finish_round(launched):
+        """-> the round as picklable pieces: (first seq, pi, pj, dist, raw rows of both images,
+        n_fwd, n_rev, cc, quiet mask, hits)"""
+        view, a, rows, handle = launched
+        R = _finish_batch_arrays(handle)
+        hits = R.hits
+        if ws > 1:          # arrays on the wire, not lists of lists
+            hits = [(k, f.array() if isinstance(f, MatchPairs) else list(f),
+                     r.array() if isinstance(r, MatchPairs) else list(r), surf)
+                    for k, f, r, surf in hits]
+        return (a, view.pi, view.pj, wd[a:a + len(view)], rows[view.pi], rows[view.pj],
+                R.n_fwd, R.n_rev, R.cc, R.quiet, hits)
+
+    # per image: was its most recent pair a quiet one?  (the reference sets the aircraft yaw error
+    # estimate after EVERY pair -- to 0 when the pair had no matches, smart.py:258-260 --, so what
+    # an image ends with is decided by its last pair)
+    last_quiet = np.zeros(len(image_list), bool)
+    last_seq = np.full(len(image_list), -1, np.int64)
+    yaw_value = {}
+    if batched_surface and hasattr(smart, 'begin_batch'):
+        smart.begin_batch()
+
+    backlog = []
+
+    def drain(until=None):
+        """work the backlog off -- all of it, or while the event `until` has not happened yet"""
+        from .matchpairs import prepickle
+        while backlog and (until is None or not until.query()):
+            kind, payload = backlog.pop(0)
+            if kind == 'smart':
+                smart.record_round(payload)
+                smart.materialize_pending()
+            else:
+                prepickle(payload)
+
+    def book(part):
+        """rank 0's (or this rank's own) bookkeeping of one rank's round"""
+        a, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, quiet, hits = part
+        n = len(pi)
+        seq = a + np.arange(n, dtype=np.int64)
+        # ---- the log: the reference's seven qlog() lines per pair (matcher.py:311-343) for the
+        # pairs with matches, one summary line for the round's pairs without (at millions of
+        # pairs the per-pair lines cost more than the GPU work they describe)
+        records = []
+        nq = int(quiet.sum())
+        if nq:
+            records.append("%d pairs without matches (%s vs %s ... %s vs %s): raw matches %d..%d, "
+                           "quality matches %d + %d in total"
+                           % (nq, names[pi[0]], names[pj[0]], names[pi[-1]], names[pj[-1]],
+                              int(min(raw1.min(), raw2.min())), int(max(raw1.max(), raw2.max())),
+                              int(n_fwd[quiet].sum()), int(n_rev[quiet].sum())))
+        for k, _f, _r, _s in hits:
+            records.append("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
+                           "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
+                           "  cross checked matches: %d"
+                           % (names[pi[k]], names[pj[k]], dist[k], raw1[k], n_fwd[k], raw2[k], n_rev[k],
+                              cc[k]))
+        if records:
+            _qlog("\n".join(records))
+        # ---- pairs without matches: the ledger (two dictionary entries per pair, later)
+        if nq:
+            ledger.add(pi[quiet], pj[quiet], seq[quiet])
+        round_records = [] if (batched_surface and hasattr(smart, 'record_round')) else None
+        for k, match_fwd, match_rev, surf in hits:
+            i, j = int(pi[k]), int(pj[k])
+            i1, i2 = image_list[i], image_list[j]
+            if isinstance(match_fwd, np.ndarray):
+                match_fwd, match_rev = MatchPairs(match_fwd), MatchPairs(match_rev)
+            i1.match_list.set_in_order(i2.name, match_fwd, int(seq[k]))
+            i2.match_list.set_in_order(i1.name, match_rev, int(seq[k]))
+            i1.matches_clean = i2.matches_clean = False
+            # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
+            avg = std = None
+            if round_records is not None and surf is not None and len(surf) > 5:
+                # the round's entries go to the property tree in one pass (smart.record_round);
+                # the averages over an image's pairs are formed when the call ends
+                avg, std = surf[0], surf[1]
+                round_records.append((i1, i2, avg, std, surf[2], surf[5], surf[6]))
+                if avg and std:
+                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
+                for x, yv in ((i, surf[5]), (j, surf[6])):
+                    if x not in yaw_value or yaw_value[x][0] < seq[k]:
+                        # (no similarity fit for this direction: update_yaw_error_estimate returns 0)
+                        yaw_value[x] = (int(seq[k]), None if yv is not None else 0)
+            elif smart is not None:
+                if surf is not None:
+                    avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
+                else:
+                    # the reference's lib.smart reads kp_list / uv_list of both images; the
+                    # flush at the end of an earlier round, or a non-owning rank, may not
+                    # have them
+                    _ensure_features(i1)
+                    _ensure_features(i2)
+                    avg, std = smart.update_surface_estimate(i1, i2)
+                if avg and std:
+                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
+                if batched_surface and surf is not None and len(surf) > 5:
+                    # the similarity fits of the batch's one launch, already turned into yaw
+                    # errors for the whole round
+                    ya = smart.record_yaw_values(i1, i2, surf[5])
+                    yb = smart.record_yaw_values(i2, i1, surf[6])
+                elif batched_surface and surf is not None:
+                    ya = smart.record_yaw_error_estimate(i1, i2, surf[3])
+                    yb = smart.record_yaw_error_estimate(i2, i1, surf[4])
+                else:
+                    ya = smart.update_yaw_error_estimate(i1, i2)
+                    yb = smart.update_yaw_error_estimate(i2, i1)
+                for x, y in ((i, ya), (j, yb)):
+                    if x not in yaw_value or yaw_value[x][0] < seq[k]:
+                        yaw_value[x] = (int(seq[k]), y)
+            if std and std >= 50 and len(match_fwd) < 100:
+                _log("Std dev of surface triangulation blew up, matches are probably bad so "
+                     "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
+                     "count:", len(match_fwd))
+                i1.match_list.set_in_order(i2.name, [], int(seq[k]))
+                i2.match_list.set_in_order(i1.name, [], int(seq[k]))
+        # The tree entries of the round (smart.record_round) and the .match bytes of its lists
+        # (what saveMatches will write) are not needed before the call ends: they go to a backlog
+        # that is worked off while the host would otherwise wait for the GPU -- on a distance
+        # sorted schedule all the pairs with matches come in the first few rounds (host bound),
+        # the hundreds of rounds behind them have none (GPU bound).
+        if round_records:
+            for c0 in range(0, len(round_records), 256):
+                backlog.append(('smart', round_records[c0:c0 + 256]))
+        if hits:
+            lists = [dict.get(image_list[int(x)].match_list, image_list[int(y)].name)
+                     for k_, _f, _r, _s in hits for x, y in ((pi[k_], pj[k_]), (pj[k_], pi[k_]))]
+            for c0 in range(0, len(lists), 512):
+                backlog.append(('pickle', lists[c0:c0 + 512]))
+        # what every image's LAST pair so far was, quiet or not (the parts of several ranks do
+        # not arrive in seq order: the newest seq wins)
+        # (seq ascends inside a part: with repeated indices the LAST assignment stays)
+        newest = np.full(len(image_list), -1, np.int64)
+        newest_j = np.full(len(image_list), -1, np.int64)
+        newest[pi] = seq
+        newest_j[pj] = seq
+        np.maximum(newest, newest_j, out=newest)
+        upd = np.nonzero(newest > last_seq)[0]
+        last_seq[upd] = newest[upd]
+        last_quiet[upd] = quiet[newest[upd] - a]
+        return n
 
     # software pipeline: the GPU works on round r+1 while python turns round r into lists.
     # An exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
@@ -937,83 +1332,33 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         try:
             if failure is None:
                 coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
-                results = _finish_lines(in_flight) if in_flight is not None else []
+                if in_flight is not None and isinstance(in_flight[3], dict):
+                    drain(in_flight[3]['done'])     # instead of waiting for the round's results
+                results = [finish_round(in_flight)] if in_flight is not None else []
                 in_flight = coming
         except (Exception, SystemExit) as exc:
             if ws == 1:
                 raise
             failure, results = exc, []
-        if ws > 1:
-            # arrays on the wire, not lists of lists (a MatchPairs pickles as a plain list)
-            results = [(i, j, f.array() if isinstance(f, MatchPairs) else list(f),
-                        r.array() if isinstance(r, MatchPairs) else list(r), surf)
-                       for i, j, f, r, surf in results]
         gathered = _dist.gather_results(results, failure)
 
-        for part in gathered:
-            n_done += len(part)
-            for i, j, match_fwd, match_rev, surf in part:
-                i1, i2 = image_list[i], image_list[j]
-                empty = len(match_fwd) == 0 and len(match_rev) == 0
-                if empty:
-                    match_fwd, match_rev = [], []           # (never the shared _NO_MATCHES)
-                elif isinstance(match_fwd, np.ndarray):
-                    match_fwd, match_rev = MatchPairs(match_fwd), MatchPairs(match_rev)
-                i1.match_list[i2.name] = match_fwd
-                i2.match_list[i1.name] = match_rev
-                i1.matches_clean = i2.matches_clean = False
-                if empty and (smart is None or (surf is not None and surf[0] is None
-                                                and surf[3] is None and surf[4] is None)):
-                    # nothing matched (most pairs of an all-pairs schedule): no surface / yaw
-                    # record (smart.py:200-201, :258-260); the yaw error estimate of both images
-                    # is set to the 0 update_yaw_error_estimate returns
-                    if smart is not None:
-                        for k, im in ((i, i1), (j, i2)):
-                            if yaw_is_zero.get(k) is not True:      # (2 calls per pair add up)
-                                im.set_aircraft_yaw_error_estimate(0)
-                                yaw_is_zero[k] = True
-                    continue
-
-                # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
-                avg = std = None
-                if smart is not None:
-                    yaw_is_zero[i] = yaw_is_zero[j] = False
-                    if surf is not None:
-                        avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
-                    else:
-                        # the reference's lib.smart reads kp_list / uv_list of both images; the
-                        # flush at the end of an earlier round, or a non-owning rank, may not
-                        # have them
-                        _ensure_features(i1)
-                        _ensure_features(i2)
-                        avg, std = smart.update_surface_estimate(i1, i2)
-                    if avg and std:
-                        _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
-                    if batched_surface and surf is not None:
-                        # the similarity fits of the batch's one launch (both directions)
-                        i1.set_aircraft_yaw_error_estimate(
-                            smart.record_yaw_error_estimate(i1, i2, surf[3]))
-                        i2.set_aircraft_yaw_error_estimate(
-                            smart.record_yaw_error_estimate(i2, i1, surf[4]))
-                    else:
-                        i1.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i1, i2))
-                        i2.set_aircraft_yaw_error_estimate(smart.update_yaw_error_estimate(i2, i1))
-                if std and std >= 50 and len(i1.match_list[i2.name]) < 100:
-                    _log("Std dev of surface triangulation blew up, matches are probably bad so "
-                         "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
-                         "count:", len(match_fwd))
-                    i1.match_list[i2.name] = []
-                    i2.match_list[i1.name] = []
+        for parts in gathered:
+            for part in parts:
+                n_done += book(part)
 
         t_elapsed = time.time() - t_start
         # (ranks != 0 only see their own pairs: their progress is that of their own shard)
-        percent = n_done / float(max(len(pending) if rank == 0 else len(mine), 1))
+        percent = n_done / float(max(n_pending if rank == 0 else hi_mine - lo_mine, 1))
         t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
         _qlog("%.1f%% done: %.1f (min) remaining" % (percent * 100.0, t_remain / 60.0))
 
         # ---- periodic save + host descriptor cache flush (:1008-1026)
         if time.time() >= save_time + save_interval:
             if rank == 0:
+                drain()
+                _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
+                for k in np.nonzero(last_seq >= 0)[0].tolist():
+                    image_list[k].matches_clean = False
                 saveMatches(proj.image_list, check_if_dirty=True)
                 if smart is not None:
                     smart.save(proj.analysis_dir)
@@ -1030,14 +1375,39 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 line[1].kp_list = None
                 line[1].des_list = None
                 line[1].uv_list = None
+            rows_known[:] = False
 
     if prefetcher is not None:
         prefetcher.close()
+    drain()
+    _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
     if rank == 0:
+        # (quiet pairs dirty both images' match lists, like the reference's assignments)
+        for k in np.nonzero(last_seq >= 0)[0].tolist():
+            image_list[k].matches_clean = False
         saveMatches(proj.image_list)
         if smart is not None:
             smart.save(proj.analysis_dir)
     print('Pair-wise matches successfully saved.')
+
+
+def _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value):
+    """The aircraft yaw error estimate of every image as the reference leaves it: the value of
+    the image's LAST pair -- 0 when that pair had no matches (update_yaw_error_estimate returns 0,
+    smart.py:258-260), else the weighted average over its pairs."""
+    if smart is None:
+        return
+    if hasattr(smart, 'flush_aggregates'):
+        smart.flush_aggregates()
+    for k in np.nonzero(last_seq >= 0)[0].tolist():
+        im = image_list[k]
+        if last_quiet[k]:
+            im.set_aircraft_yaw_error_estimate(0)
+        elif k in yaw_value:
+            v = yaw_value[k][1]
+            if v is None:                       # deferred: the average over all recorded pairs
+                v = smart.current_yaw_average(im.name)
+            im.set_aircraft_yaw_error_estimate(v)
 
 
 def saveMatches(image_list, check_if_dirty=False):

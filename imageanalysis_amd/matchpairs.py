@@ -20,15 +20,22 @@ import numpy as np
 
 
 class MatchPairs(MutableSequence):
-    __slots__ = ('_a', '_l')
+    __slots__ = ('_a', '_l', '_pk')
 
     def __init__(self, pairs=()):
-        if isinstance(pairs, np.ndarray):
+        self._pk = None         # the pickled form of the array (find_matches fills it in while the
+        if isinstance(pairs, np.ndarray):       # GPU works; dropped by any edit)
             self._a = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
             self._l = None
         else:
             self._a = None
             self._l = [list(p) for p in pairs]
+
+    def pickled(self):
+        """bytes of this list inside a .match pickle (cached while the pairs are untouched)"""
+        if self._pk is None or self._a is None:
+            return _pairs_bytes(self.array())
+        return self._pk
 
     # ---- the two representations
     def array(self):
@@ -41,6 +48,7 @@ class MatchPairs(MutableSequence):
         if self._l is None:
             self._l = self._a.tolist()
             self._a = None
+            self._pk = None
         return self._l
 
     def tolist(self):
@@ -72,6 +80,7 @@ class MatchPairs(MutableSequence):
             # elements of the list form would hand out ndarrays where `pair == [a, b]` is expected
             self._a = np.ascontiguousarray(np.asarray(value), np.int32).reshape(-1, 2).copy()
             self._l = None
+            self._pk = None
             return
         if isinstance(value, np.ndarray):
             value = value.tolist()
@@ -129,7 +138,240 @@ def _pairs_bytes(a):
     return b'](' + rec.tobytes() + b'e'
 
 
+def prepickle(match_lists):
+    """fill in the cached .match bytes of several MatchPairs with one pass (find_matches: the
+    hits of a round, while the GPU works on the next one)"""
+    todo = [m for m in match_lists if isinstance(m, MatchPairs) and m._a is not None and m._pk is None]
+    for m, b in zip(todo, _pairs_bytes_many([m._a for m in todo])):
+        m._pk = b
+
+
+def _pairs_bytes_many(arrays):
+    """_pairs_bytes() of several [n, 2] arrays with ONE record array for all of them (an image
+    has ~100 partners with ~200 matches each: the numpy calls, not the bytes, are the cost)"""
+    lens = [len(a) for a in arrays]
+    total = sum(lens)
+    if total == 0:
+        return [b']'] * len(arrays)
+    cat = np.concatenate([a for a in arrays if len(a)])
+    op, dt = _int_opcode(int(cat.max()), int(cat.min()))
+    rec = np.empty(total, np.dtype([('h', 'S3'), ('i', dt), ('m', 'S1'), ('j', dt), ('t', 'S1')]))
+    rec['h'] = b'](' + op
+    rec['i'] = cat[:, 0]
+    rec['m'] = op
+    rec['j'] = cat[:, 1]
+    rec['t'] = b'e'
+    raw, size = rec.tobytes(), rec.itemsize
+    out, off = [], 0
+    for n in lens:
+        out.append(b'](' + raw[off * size:(off + n) * size] + b'e' if n else b']')
+        off += n
+    return out
+
+
 _key_bytes = {}         # image name -> its BINUNICODE record (every image lists every partner)
+
+
+def _key_record(name):
+    head = _key_bytes.get(name)
+    if head is None:
+        key = name.encode('utf-8', 'surrogatepass')
+        if len(_key_bytes) > 1 << 16:
+            _key_bytes.clear()
+        head = _key_bytes[name] = b'X' + struct.pack('<I', len(key)) + key
+    return head
+
+
+class QuietLedger(object):
+    """The image pairs of one find_matches() call that ended without matches -- on an all-pairs
+    schedule 95-99 % of several million pairs -- as index arrays instead of two dictionary
+    entries and two empty lists per pair.  Every image's MatchDict refers to the ledger and
+    turns its share into real `{other_name: []}` entries the first time somebody reads it.
+    `seq` is the position of the pair in the order find_matches processed the pairs (the
+    reference assigns match_list entries in that order, scripts/lib/matcher.py:978-979)."""
+
+    def __init__(self, names):
+        self.names = names
+        self._i, self._j, self._seq = [], [], []
+        self._index = None
+
+    def add(self, i, j, seq):
+        if len(i):
+            self._i.append(np.asarray(i, np.int64))
+            self._j.append(np.asarray(j, np.int64))
+            self._seq.append(np.asarray(seq, np.int64))
+            self._index = None
+
+    def __len__(self):
+        return int(sum(len(a) for a in self._i))
+
+    def entry_records(self):
+        """per image: the bytes of `name: []` inside a .match pickle (key record + EMPTY_LIST);
+        as one uint8 [n_images, L] table when all records have the same length (image names of
+        one camera do), else a list of bytes"""
+        rec = getattr(self, '_records', None)
+        if rec is None:
+            rec = [_key_record(n) + b']' for n in self.names]
+            if rec and len(set(map(len, rec))) == 1:
+                rec = np.frombuffer(b''.join(rec), np.uint8).reshape(len(rec), -1)
+            self._records = rec
+        return rec
+
+    def partners_of(self, k):
+        """(partner image indices, seq) of image k's quiet pairs, in processing order"""
+        if self._index is None:
+            if self._i:
+                qi, qj, sq = (np.concatenate(a) for a in (self._i, self._j, self._seq))
+            else:
+                qi = qj = sq = np.zeros(0, np.int64)
+            if len(sq) > 1 and np.any(np.diff(sq) < 0):
+                o = np.argsort(sq, kind='stable')
+                qi, qj, sq = qi[o], qj[o], sq[o]
+            # both directions of every pair, in seq order; then ONE stable sort by image keeps that
+            # order inside every image
+            m = len(sq)
+            img, other, seq = (np.empty(2 * m, np.int64) for _ in range(3))
+            img[0::2], img[1::2] = qi, qj
+            other[0::2], other[1::2] = qj, qi
+            seq[0::2], seq[1::2] = sq, sq
+            order = np.argsort(img, kind='stable')
+            img, other, seq = img[order], other[order], seq[order]
+            n = len(self.names)
+            bounds = np.searchsorted(img, np.arange(n + 1))
+            self._index = (other, seq, bounds)
+        other, seq, bounds = self._index
+        lo, hi = bounds[k], bounds[k + 1]
+        return other[lo:hi], seq[lo:hi]
+
+
+class MatchDict(dict):
+    """`image.match_list` while / after find_matches: a dict {other image name: match list} whose
+    entries for pairs WITHOUT matches live in a QuietLedger until the dict is first read.  The
+    order of the keys, once read, is the reference's: entries that were there before the call
+    keep their place, new ones follow in the order the pairs were processed."""
+
+    def __init__(self, *a, **k):
+        dict.__init__(self, *a, **k)
+        self._ledger = None
+        self._me = -1
+        self._seq = None        # name -> seq of the entries set (by find_matches) during the call
+
+    def attach(self, ledger, me):
+        if self._ledger is not None and self._ledger is not ledger:
+            self._materialize()
+        self._ledger, self._me = ledger, me
+        if self._seq is None:
+            self._seq = {}
+
+    def set_in_order(self, name, value, seq):
+        """find_matches' assignment of a pair WITH matches (no read, nothing materialised)"""
+        if self._seq is not None and not dict.__contains__(self, name):
+            self._seq[name] = seq
+        dict.__setitem__(self, name, value)
+
+    def _pending(self):
+        if self._ledger is None:
+            return None
+        other, seq = self._ledger.partners_of(self._me)
+        return (other, seq) if len(other) else None
+
+    def entries(self):
+        """[(name, value)] in the final key order WITHOUT turning the quiet pairs into dictionary
+        entries (the .match writer): value is the shared EMPTY for them"""
+        pend = self._pending()
+        items = list(dict.items(self))
+        if pend is None:
+            return items
+        other, seq = pend
+        names = self._ledger.names
+        sq = self._seq or {}
+        old = [(k, v) for k, v in items if k not in sq]
+        have = dict.__contains__
+        new = [(sq[k], k, v) for k, v in items if k in sq]
+        # a retried pair that stayed empty is already there (as []): its place does not move
+        quiet = [(s, names[o], EMPTY) for o, s in zip(other.tolist(), seq.tolist())
+                 if not have(self, names[o])]
+        merged = sorted(new + quiet, key=lambda t: t[0]) if new else quiet
+        return old + [(k, v) for _s, k, v in merged]
+
+    def pickle_body(self):
+        """the `name value` records of the .match pickle in the final key order, or None when the
+        plain walk over entries() is needed (entries from before the call).  The quiet pairs come
+        out of precomputed per-image records, a slice of them between two pairs with matches."""
+        pend = self._pending()
+        if pend is None or len(self._seq or {}) != dict.__len__(self):
+            return None
+        other, seq = pend
+        rec = self._ledger.entry_records()
+        if isinstance(rec, np.ndarray):
+            table = rec[other]                            # [n_quiet, L]: a slice of it is a run
+            run = lambda a, b: (table[a:b].tobytes(),) if b > a else ()
+        else:
+            quiet = list(map(rec.__getitem__, other.tolist()))
+            run = lambda a, b: quiet[a:b]
+        direct = sorted((s, k) for k, s in self._seq.items())
+        cut = np.searchsorted(seq, np.array([s for s, _k in direct], np.int64)).tolist() if direct else []
+        values = [dict.__getitem__(self, name) for _s, name in direct]
+        arr_bytes = {t: v._pk for t, v in enumerate(values)
+                     if isinstance(v, MatchPairs) and v._pk is not None and v._a is not None}
+        arr_at = [t for t, v in enumerate(values) if isinstance(v, MatchPairs) and t not in arr_bytes]
+        arr_bytes.update(zip(arr_at, _pairs_bytes_many([values[t].array() for t in arr_at])))
+        out, prev = [], 0
+        for t, ((s_, name), pos) in enumerate(zip(direct, cut)):
+            out.extend(run(prev, pos))
+            prev = pos
+            pairs = values[t]
+            out.append(_key_record(name))
+            if t in arr_bytes:
+                out.append(arr_bytes[t])
+            elif isinstance(pairs, list) and not pairs:
+                out.append(b']')
+            else:
+                body = pickle.dumps(pairs, 2)
+                out.append(body[2:-1])
+        out.extend(run(prev, len(other)))
+        return out
+
+    def _materialize(self):
+        if self._ledger is None:
+            return
+        ent = self.entries()
+        self._ledger, self._seq = None, None
+        dict.clear(self)
+        for k, v in ent:
+            dict.__setitem__(self, k, [] if v is EMPTY else v)
+
+    # ---- every read sees real entries
+    def _read(name):                                   # noqa: N805
+        base = getattr(dict, name)
+
+        def method(self, *a, **k):
+            self._materialize()
+            return base(self, *a, **k)
+        method.__name__ = name
+        return method
+
+    for _n in ('__getitem__', '__contains__', '__iter__', '__len__', '__eq__', '__ne__', '__repr__',
+               'get', 'keys', 'values', 'items', 'copy', 'pop', 'popitem', 'setdefault', 'update',
+               '__delitem__', '__setitem__', 'clear', '__reversed__', '__or__', '__ior__', '__ror__'):
+        locals()[_n] = _read(_n)
+    del _n, _read
+    __hash__ = None
+
+    def __bool__(self):
+        return dict.__len__(self) > 0 or self._pending() is not None
+
+    def __reduce_ex__(self, protocol):
+        self._materialize()
+        return (dict, (dict(self),))
+
+
+class _Empty(list):
+    """marker of MatchDict.entries() for a pair without matches (read only)"""
+    __slots__ = ()
+
+
+EMPTY = _Empty()
 
 
 def dumps_match_dict(match_list):
@@ -138,18 +380,22 @@ def dumps_match_dict(match_list):
     out = [b'\x80\x02}']
     if match_list:
         out.append(b'(')
-        for name, pairs in match_list.items():
-            head = _key_bytes.get(name)
-            if head is None:
-                if not isinstance(name, str):
-                    return pickle.dumps(match_list)
-                key = name.encode('utf-8', 'surrogatepass')
-                if len(_key_bytes) > 1 << 16:
-                    _key_bytes.clear()
-                head = _key_bytes[name] = b'X' + struct.pack('<I', len(key)) + key
-            out.append(head)
+        # (a MatchDict hands out its quiet pairs without creating dictionary entries for them)
+        if isinstance(match_list, MatchDict):
+            body = match_list.pickle_body()
+            if body is not None:
+                out.extend(body)
+                items = ()
+            else:
+                items = match_list.entries()
+        else:
+            items = match_list.items()
+        for name, pairs in items:
+            if not isinstance(name, str):
+                return pickle.dumps(dict(match_list))
+            out.append(_key_record(name))
             if isinstance(pairs, MatchPairs):
-                out.append(_pairs_bytes(pairs.array()))
+                out.append(pairs.pickled())
             elif isinstance(pairs, list) and not pairs:
                 out.append(b']')
             else:

@@ -74,11 +74,180 @@ def triangulate_features(i1, i2):
 _frozen = None          # id(image) -> (ned array, aircraft yaw) while find_matches runs
 
 
+_deferred = None        # set of image names whose weighted averages are due (begin_batch() ...)
+
+
+def begin_batch():
+    """find_matches' batched form: record_surface_estimate / record_yaw_error_estimate write
+    the pair entries as always, but the weighted averages over an image's pairs (a pass over all
+    of them, sorted -- O(k) per new pair, O(k^2) per image on an all-pairs schedule) are formed
+    by flush_aggregates(), once, instead of after every pair.  The averages a reader finds in
+    the tree after the flush are the reference's: they only depend on the entries."""
+    global _deferred
+    _deferred = set()
+
+
+_pending = []           # record_round() entries not yet written to the tree
+
+
+def record_round(pairs):
+    """find_matches' round form of record_surface_estimate + record_yaw_error_estimate (both
+    directions): pairs = [(i1, i2, avg, std, dist_m, yaw_values_fwd, yaw_values_rev)] with
+    yaw_values = (yaw_error, dist, relative course, weight) or None.  Nothing is written yet:
+    flush_aggregates() puts the entries into the property tree in one pass (a node per pair
+    and direction, built directly instead of through ~30 tree calls per pair) and forms the
+    weighted averages.  Needs begin_batch()."""
+    _pending.extend(pairs)
+
+
+def materialize_pending():
+    _materialize_pending()
+
+
+def _materialize_pending():
+    """the tree entries of everything record_round() was given, in order (same values as
+    record_surface_estimate / _record_yaw write, pair by pair)"""
+    global _pending
+    if not _pending:
+        return
+    pend, _pending = _pending, []
+    from .hostlib import props_compat
+    fast = type(smart_node) is props_compat.PropertyNode
+    Node = props_compat.PropertyNode
+    tri_of, yaw_of = {}, {}
+
+    def nodes(name):
+        hit = tri_of.get(name)
+        if hit is None:
+            inode = smart_node.getChild(name, True)
+            tri = inode.getChild("tri_surface_pairs", True)
+            yaw = inode.getChild("yaw_pairs", True)
+            hit = tri_of[name] = (tri, _pairs_of(name, tri))
+            yaw_of[name] = (yaw, _yaw_pairs_of(name, yaw))
+        return hit
+
+    for i1, i2, avg, std, dist_m, yv_f, yv_r in pend:
+        n1, n2 = i1.name, i2.name
+        (tri1, acc1), (tri2, acc2) = nodes(n1), nodes(n2)
+        if avg is not None:
+            surface_m, stddev = float("%.1f" % avg), float("%.1f" % std)
+            weight, dist_i = int(dist_m * dist_m), int(dist_m)
+            for tri, acc, other in ((tri1, acc1, n2), (tri2, acc2, n1)):
+                if fast:
+                    pn = tri.__dict__.get(other)
+                    if not isinstance(pn, Node):
+                        pn = tri.__dict__[other] = Node()
+                    d = pn.__dict__
+                    d["surface_m"], d["weight"], d["stddev"], d["dist_m"] = surface_m, weight, stddev, dist_i
+                else:
+                    pn = tri.getChild(other, True)
+                    pn.setFloat("surface_m", surface_m)
+                    pn.setInt("weight", weight)
+                    pn.setFloat("stddev", stddev)
+                    pn.setInt("dist_m", dist_i)
+                acc[other] = (surface_m, weight, stddev)
+            _deferred.add(n1)
+            _deferred.add(n2)
+        for me, other, yv in ((n1, n2, yv_f), (n2, n1, yv_r)):
+            if yv is None:
+                continue
+            yaw, yacc = yaw_of[me]
+            ye, yd = float("%.1f" % yv[0]), float("%.1f" % yv[1])
+            yc, yw = float("%.1f" % yv[2]), float("%.1f" % yv[3])
+            if fast:
+                pn = yaw.__dict__.get(other)
+                if not isinstance(pn, Node):
+                    pn = yaw.__dict__[other] = Node()
+                d = pn.__dict__
+                d["yaw_error"], d["dist_m"], d["relative_crs"], d["weight"] = ye, yd, yc, yw
+            else:
+                pn = yaw.getChild(other, True)
+                pn.setFloat("yaw_error", ye)
+                pn.setFloat("dist_m", yd)
+                pn.setFloat("relative_crs", yc)
+                pn.setFloat("weight", yw)
+            yacc[other] = (ye, int(yw), yd)
+            _deferred.add(me)
+
+
+def flush_aggregates():
+    """-> {image name: weighted yaw error over its pairs} for the images recorded since
+    begin_batch() / the last flush; writes the pending pair entries, tri_surface_m and yaw_error
+    of those images"""
+    global _deferred
+    out = {}
+    if _deferred is not None:
+        _materialize_pending()
+    if not _deferred:
+        return out
+    for name in sorted(_deferred):
+        node = smart_node.getChild(name, True)
+        if name in _pair_cache:
+            _surface_average(node, _pair_cache[name][1])
+        if name in _yaw_cache:
+            out[name] = _yaw_average(node, _yaw_cache[name][1])
+    _deferred = set()
+    return out
+
+
+def frozen_ned(image_list, with_yaw=False):
+    """[n, 3] camera positions of image_list (and the [n] aircraft yaw angles), cached while
+    the poses are frozen"""
+    global _frozen_ned
+    if not (_frozen is not None and _frozen_ned is not None and _frozen_ned[0] is image_list
+            and len(_frozen_ned[1]) == len(image_list)):
+        pairs = [_ned_yaw(im) for im in image_list]
+        _frozen_ned = (image_list, np.array([p[0] for p in pairs], np.float64).reshape(-1, 3),
+                       np.array([p[1] for p in pairs], np.float64))
+    return (_frozen_ned[1], _frozen_ned[2]) if with_yaw else _frozen_ned[1]
+
+
+def yaw_errors_from_affines(ned1, air_yaw1, ned2, aff):
+    """yaw_error_from_affine() for n pairs at once: ned1, ned2 [n,3], air_yaw1 [n], aff [n,6]
+    (row major 2x3) -> (yaw_error, dist, relative course, weight), each [n]"""
+    r2d = 180.0 / np.pi
+    tx, ty = aff[:, 2], aff[:, 5]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        weight = np.where(np.abs(ty) > 0, np.abs(ty / tx), np.abs(tx))
+    diff = ned2 - ned1
+    dist = np.sqrt((diff * diff).sum(1))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        direction = diff / dist[:, None]
+    crs_gps = 90 - np.arctan2(direction[:, 0], direction[:, 1]) * r2d
+    crs_gps = np.where(crs_gps < 0, crs_gps + 360, crs_gps)
+    crs_gps = np.where(crs_gps > 360, crs_gps - 360, crs_gps)
+    w, h = _deps.camera().get_image_params()
+    cx, cy = int(w * 0.5), int(h * 0.5)
+    fcx, fcy = float(np.float32(cx)), float(np.float32(cy))
+    newx = aff[:, 0] * fcx + aff[:, 1] * fcy + aff[:, 2]
+    newy = aff[:, 3] * fcx + aff[:, 4] * fcy + aff[:, 5]
+    crs_aff = 90 - np.arctan2(cy - newy, newx - cx) * r2d
+    yaw_error = crs_gps - (air_yaw1 + crs_aff)
+    yaw_error = np.where(yaw_error < -180, yaw_error + 360, yaw_error)
+    yaw_error = np.where(yaw_error > 180, yaw_error - 360, yaw_error)
+    return yaw_error, dist, crs_aff, weight
+
+
+def record_yaw_values(i1, i2, values):
+    """record_yaw_error_estimate() with the pair's (yaw_error, dist, relative course, weight)
+    already computed (find_matches does a whole round at once); values None: no fit"""
+    if values is None:
+        return 0
+    return _record_yaw(i1, i2, *values)
+
+
+_frozen_ned = None
+
+
 def freeze_poses(on):
     """find_matches brackets its pair loop with this: poses do not change inside one call, and
     reading one back from the property tree costs more than a pair's share of the kernels"""
-    global _frozen
+    global _frozen, _frozen_ned, _deferred
     _frozen = {} if on else None
+    _frozen_ned = None
+    if not on:
+        flush_aggregates()
+        _deferred = None
 
 
 def _ned_yaw(im):
@@ -140,16 +309,23 @@ def record_surface_estimate(i1, i2, avg, std, dist_m):
         acc[other.name] = (pair_node.getFloat("surface_m"), pair_node.getInt("weight"),
                            pair_node.getFloat("stddev"))
     for node, me in ((i1_node, i1), (i2_node, i2)):
-        acc = _pair_cache[me.name][1]
-        total, count = 0, 0
-        for child in sorted(acc):                       # the tree's child order
-            surface_m, w, stddev = acc[child]
-            if stddev < cutoff_std:
-                total += surface_m * w
-                count += w
-        if count > 0:
-            node.setFloat("tri_surface_m", float("%.1f" % (total / count)))
+        if _deferred is not None:
+            _deferred.add(me.name)
+        else:
+            _surface_average(node, _pair_cache[me.name][1])
     return avg, std
+
+
+def _surface_average(node, acc):
+    cutoff_std = 25
+    total, count = 0, 0
+    for child in sorted(acc):                           # the tree's child order
+        surface_m, w, stddev = acc[child]
+        if stddev < cutoff_std:
+            total += surface_m * w
+            count += w
+    if count > 0:
+        node.setFloat("tri_surface_m", float("%.1f" % (total / count)))
 
 
 def update_surface_estimate(i1, i2):
@@ -258,6 +434,10 @@ def record_yaw_error_estimate(i1, i2, affine):
     yaw_error, dist, crs_affine, weight = yaw_error_from_affine(i1, i2, affine)
     if yaw_error is None:
         return 0
+    return _record_yaw(i1, i2, yaw_error, dist, crs_affine, weight)
+
+
+def _record_yaw(i1, i2, yaw_error, dist, crs_affine, weight):
     i1_node = smart_node.getChild(i1.name, True)
     yaw_node = i1_node.getChild("yaw_pairs", True)
     acc = _yaw_pairs_of(i1.name, yaw_node)
@@ -268,6 +448,20 @@ def record_yaw_error_estimate(i1, i2, affine):
     pair_node.setFloat("weight", "%.1f" % weight)
     acc[i2.name] = (pair_node.getFloat("yaw_error"), pair_node.getInt("weight"),
                     pair_node.getFloat("dist_m"))
+    if _deferred is not None:
+        _deferred.add(i1.name)
+        return None                                     # (the caller asks flush_aggregates())
+    return _yaw_average(i1_node, acc)
+
+
+def current_yaw_average(name):
+    """the weighted yaw error over the pairs recorded for `name` so far (what
+    record_yaw_error_estimate returns when it is not deferred)"""
+    entry = _yaw_cache.get(name)
+    return _yaw_average(None, entry[1]) if entry is not None else 0
+
+
+def _yaw_average(i1_node, acc):
     total, count = 0, 0
     for child in sorted(acc):                           # the tree's child order
         err, w, dist_m = acc[child]
@@ -275,7 +469,8 @@ def record_yaw_error_estimate(i1, i2, affine):
             total += err * w
             count += w
     if count > 0:
-        i1_node.setFloat("yaw_error", float("%.1f" % (total / count)))
+        if i1_node is not None:
+            i1_node.setFloat("yaw_error", float("%.1f" % (total / count)))
         return total / count
     return 0
 
@@ -314,6 +509,18 @@ def _to_dict(node):
         else:
             out[k] = v
     return out
+
+
+def _has_enum_lists(node):
+    """enumerated lists need _to_dict's float conversion; the smart tree has none in practice"""
+    for img in node.__dict__.values():
+        if isinstance(img, list):
+            return True
+        if hasattr(img, '__dict__'):
+            for v in img.__dict__.values():
+                if isinstance(v, list):
+                    return True
+    return False
 
 
 def _from_dict(node, d):
@@ -356,6 +563,15 @@ def save(analysis_dir):
         import props_json
         props_json.save(path, smart_node)
     else:
+        if len(smart_node.__dict__) > 200 and not _has_enum_lists(smart_node):
+            # (one C-encoder pass with a callback per node instead of a python copy of the tree)
+            with open(path, 'w') as f:
+                top = smart_node.__dict__
+                f.write('{\n')
+                f.write(',\n'.join('%s: %s' % (json.dumps(k), json.dumps(
+                    top[k], sort_keys=True, default=lambda o: o.__dict__)) for k in sorted(top)))
+                f.write('\n}\n')
+            return
         tree = _to_dict(smart_node)
         with open(path, 'w') as f:
             if len(tree) <= 200:

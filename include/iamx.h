@@ -262,6 +262,16 @@ int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t 
  *   survivors and must take the host path.  clip = iamx_match_postfilter_clip() = 2000.
  * ------------------------------------------------------------------------------------ */
 int iamx_match_postfilter_clip(void);
+/* The per-pair results of a batch packed back to back (what find_matches downloads: on an
+ * all-pairs schedule almost every pair ends with nothing and the [n_pairs][clip] slots are 130 MB
+ * per 4096 pairs).  cnt / status / pairs as written by iamx_match_postfilter, z DEV
+ * [n_pairs][clip] of iamx_triangulate_pairs or NULL.  off [n_pairs + 1] int64: exclusive scan of
+ * the counts of the pairs with status 0 (off[n_pairs] = total); out_pairs [cap][2], out_z [cap]
+ * (NULL without z): pair k's rows at [off[k], off[k] + cnt[k]) when off[k] + cnt[k] <= cap.
+ * off / out_pairs / out_z may be page-locked HOST memory (written by the device directly). */
+int iamx_match_pack_results(const int32_t *cnt, const int32_t *status, const int32_t *pairs,
+                            const double *z, int n_pairs, int clip, int64_t cap, int64_t *off,
+                            int32_t *out_pairs, double *out_z, void *stream);
 int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, const int32_t *surv_q,
                           const int32_t *surv_t, const double *surv_metric, const int32_t *pairs,
                           const int64_t *kp_off, const float *xy, const int32_t *key2, int n_pairs,

@@ -4,7 +4,8 @@ a synthetic nadir survey on a lawn-mower grid, keypoints = projections of shared
 (so overlapping pairs carry geometrically consistent matches that pass GMS and feed the surface
 estimate), descriptors = a per-ground-point base vector + integer noise, clutter on top.
 
-    python tools/find_matches_rate.py [rows cols [kpts]] [--profile]
+    python tools/find_matches_rate.py [rows cols [kpts]] [--profile] [--objects]
+    (38 74 4096 = the 2812-image survey of BASELINE configs[2])
 
 Prints pairs/s through find_matches (all-pairs schedule), and where the host time goes."""
 import cProfile
@@ -107,7 +108,12 @@ def main():
                                   base_descriptor(rng.integers(10 ** 7, 10 ** 8, n_cl))]).astype(np.float32)
             order = rng.permutation(kpts)
             xy, des = xy[order].astype(np.float32), des[order]
-            im.kp_list = [iimg.make_keypoint(x, y, 3.0, 0.0, 1.0, 0) for x, y in xy.tolist()]
+            if '--objects' in sys.argv:      # a python object per keypoint, like a cv2 detector's list
+                im.kp_list = [iimg.make_keypoint(x, y, 3.0, 0.0, 1.0, 0) for x, y in xy.tolist()]
+            else:                            # the array-backed list our detector delivers
+                from imageanalysis_amd.keypoints import KeyPointList
+                im.kp_list = KeyPointList(xy[:, 0], xy[:, 1], np.full(kpts, 3.0), np.zeros(kpts),
+                                          np.ones(kpts), np.zeros(kpts, np.int32))
             im.des_list = des
             getNode('/smart', True).getChild(im.name, True).setFloat('tri_surface_m', 0.0)
             proj.image_list.append(im)
