@@ -14,7 +14,7 @@ _lib = None
 def build(force=False):
     if force or not os.path.exists(_SO) or \
             os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                        for f in ('cpu_ref.c', 'sift_ref.c', 'Makefile')):
+                                        for f in ('cpu_ref.c', 'sift_ref.c', 'knn2_simd.c', 'Makefile')):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle_cpu.so'],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -63,6 +63,29 @@ def knn2_l2_u8_batch(images, pairs, nthreads=0):
                                    ctypes.c_int(nthreads))
     if rc != 0:
         raise ValueError("oracle_knn2_l2_u8_batch rc=%d" % rc)
+    return idx, d2
+
+
+def knn2_simd_available():
+    L = lib()
+    L.oracle_knn2_simd_available.restype = ctypes.c_int
+    return bool(L.oracle_knn2_simd_available())
+
+
+def knn2_l2_u8_batch_simd(images, pairs, nthreads=0):
+    """knn2_l2_u8_batch with the AVX-512 VNNI kernel of oracle/knn2_simd.c (same results);
+    raises where the host has no AVX-512 VNNI"""
+    images = np.ascontiguousarray(images, np.uint8)
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    n_rows = images.shape[1]
+    idx = np.empty((len(pairs), n_rows, 2), np.int32)
+    d2 = np.empty((len(pairs), n_rows, 2), np.int32)
+    L = lib()
+    L.oracle_knn2_l2_u8_batch_simd.restype = ctypes.c_int
+    rc = L.oracle_knn2_l2_u8_batch_simd(_p(images), ctypes.c_int(n_rows), _p(pairs),
+                                        ctypes.c_int(len(pairs)), _p(idx), _p(d2), ctypes.c_int(nthreads))
+    if rc != 0:
+        raise ValueError("oracle_knn2_l2_u8_batch_simd rc=%d" % rc)
     return idx, d2
 
 

@@ -217,3 +217,20 @@ def test_all_c_sift_equals_the_oracle():
         kc, dc = so.detect_and_compute_c(img)
         assert len(ka) == len(kc) > 100
         assert np.array_equal(ka, kc) and np.array_equal(da, dc)
+
+
+def test_simd_knn2_equals_the_plain_c_loop():
+    """oracle/knn2_simd.c (the AVX-512 VNNI form bench.py times as cpu_baseline) == cpu_ref.c:
+    ragged row counts, duplicates (ties -> lowest train index), extreme values"""
+    if not cpu_ref.knn2_simd_available():
+        pytest.skip("no AVX-512 VNNI on this host")
+    rng = np.random.default_rng(3)
+    for n_rows in (2, 17, 63, 64, 65, 500):
+        imgs = rng.integers(0, 256, (3, n_rows, 128), dtype=np.uint8)
+        imgs[2, :n_rows // 2] = imgs[2, n_rows - n_rows // 2:]
+        imgs[0, 0] = 0
+        imgs[1, -1] = 255
+        pairs = np.array([[0, 1], [1, 0], [2, 2], [0, 2], [2, 1]], np.int32)
+        a = cpu_ref.knn2_l2_u8_batch(imgs, pairs)
+        b = cpu_ref.knn2_l2_u8_batch_simd(imgs, pairs)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), n_rows
