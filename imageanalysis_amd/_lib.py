@@ -74,6 +74,12 @@ SIGNATURES = {
     'iamx_image_resized_dims': (c_int, [c_int, c_int, c_double, c_void_p, c_void_p]),
     'iamx_image_equalize_resize': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, c_double,
                                            c_void_p, c_int64, c_void_p, c_void_p]),
+    'iamx_jpeg_info': (c_int, [c_void_p, c_int64, c_void_p]),
+    'iamx_jpeg_decode_coefficients': (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    'iamx_jpeg_workspace_bytes': (c_int64, [c_void_p]),
+    'iamx_jpeg_reconstruct': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    'iamx_gzip_f32_from_u8_bound': (c_int64, [c_int64, c_int64]),
+    'iamx_gzip_f32_from_u8': (c_int64, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     'iamx_sift_workspace_bytes': (c_int64, [c_int, c_int]),
     'iamx_sift_detect': (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, c_void_p, c_int64, c_void_p, c_void_p, c_int,

@@ -18,7 +18,8 @@ import threading
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 
-MEMBER_BYTES = 1 << 20
+MEMBER_BYTES = 1 << 22               # (few, large zlib calls: every call is a GIL hand-over for the
+                                     #  thread that drives the detector)
 GZIP_LEVEL = 6                        # the reference's compresslevel (image.py:201,213)
 
 _lock = threading.Lock()
@@ -32,7 +33,7 @@ def _pools():
     with _lock:
         if _jobs is None:
             n = max(2, min(96, os.cpu_count() or 2))
-            _jobs = ThreadPoolExecutor(max_workers=max(4, min(12, n // 8)), thread_name_prefix='iamx-cache')
+            _jobs = ThreadPoolExecutor(max_workers=max(4, min(32, n // 4)), thread_name_prefix='iamx-cache')
             _workers = ThreadPoolExecutor(max_workers=n, thread_name_prefix='iamx-io')
     return _jobs, _workers
 
@@ -42,7 +43,7 @@ def _member(chunk, level):
     return c.compress(chunk) + c.flush()
 
 
-def gzip_member_list(raw, level=GZIP_LEVEL):
+def gzip_member_list(raw, level=GZIP_LEVEL, member_bytes=None):
     """bytes-like, or a sequence of bytes-likes that are to follow each other (e.g. an .npy
     header and the array's own memory: nothing is copied together first) -> list of gzip members
     whose concatenation decompresses to those bytes (members compressed in parallel)"""
@@ -50,7 +51,8 @@ def gzip_member_list(raw, level=GZIP_LEVEL):
     chunks = []
     for b in bufs:
         b = memoryview(b).cast('B')
-        chunks.extend(b[i:i + MEMBER_BYTES] for i in range(0, len(b), MEMBER_BYTES))
+        mb = member_bytes or MEMBER_BYTES
+        chunks.extend(b[i:i + mb] for i in range(0, len(b), mb))
     if not chunks:
         chunks = [memoryview(b'')]
     if len(chunks) == 1:
@@ -69,10 +71,10 @@ def gzip_members(raw, level=GZIP_LEVEL):
     return b''.join(gzip_member_list(raw, level))
 
 
-def _write_job(path, payload, on_error=None, level=GZIP_LEVEL):
+def _write_job(path, payload, on_error=None, level=GZIP_LEVEL, member_bytes=None):
     try:
         raw = payload() if callable(payload) else payload
-        members = gzip_member_list(raw, level)
+        members = gzip_member_list(raw, level, member_bytes)
         # pid + thread id: two ranks may write the same boundary image's cache at the same time
         tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
@@ -113,16 +115,17 @@ def write_raw(path, payload, background=True, on_error=None):
     return fut
 
 
-def write_gzip(path, payload, background=True, on_error=None, level=GZIP_LEVEL):
+def write_gzip(path, payload, background=True, on_error=None, level=GZIP_LEVEL, member_bytes=None):
     """payload: bytes or a callable returning bytes (run on the job thread, e.g. np.save into a
     buffer).  Errors go to `on_error(exc)` if given, else surface in wait().  `level`: zlib level
     of the members (any level reads back the same bytes)."""
     if not background:
-        _write_job(path, payload, on_error, level)
+        # (the caller waits for this one file: many small members, all workers on it)
+        _write_job(path, payload, on_error, level, 1 << 20)
         return None
     jobs, _w = _pools()
     wait(path)                                                # keep two writes of a path ordered
-    fut = jobs.submit(_write_job, path, payload, on_error, level)
+    fut = jobs.submit(_write_job, path, payload, on_error, level, member_bytes)
     with _lock:
         _pending[path] = fut
     return fut

@@ -13,7 +13,7 @@ if [ -n "$IAMX_ABLATE" ]; then
     OBJDIR="$HERE/obj_ablate"
     FLAGS="$FLAGS -DIAMX_ABLATE"
 fi
-SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_knn2sym.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/ba_schur.hip $HERE/trf_vec.hip $HERE/comm.hip $HERE/sift.hip $HERE/image_prep.hip"
+SRCS="$HERE/common.hip $HERE/match_knn2.hip $HERE/match_knn2v2.hip $HERE/match_knn2sym.hip $HERE/match_post.hip $HERE/host_cleanup.hip $HERE/triangulate.hip $HERE/ba_kernels.hip $HERE/ba_linalg.hip $HERE/ba_schur.hip $HERE/trf_vec.hip $HERE/comm.hip $HERE/sift.hip $HERE/image_prep.hip $HERE/jpeg.hip $HERE/cache_codec.hip"
 mkdir -p "$OBJDIR"
 OBJS=""
 for f in $SRCS; do

@@ -85,6 +85,7 @@ def make_keypoints(x, y, size, angle, response, octave, class_id=None):
 
 ASYNC_CACHE_WRITES = True      # cache files are written by background threads (cacheio.wait())
 USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
+USE_DEVICE_JPEG = True         # split decoder: Huffman on the host, IDCT / upsampling / colour on the GPU
 SIDECAR_MARGIN_S = 30.0        # a .desc / .feat newer than the sidecar by more than this is not ours
 WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
 # zlib level of the float32 .desc (the reference passes compresslevel=6, image.py:213; every level
@@ -192,9 +193,11 @@ def save_features(self):
         feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
                         for kp in kps]
         payload = lambda: pickle.dumps(feature_list)
+    # (3 MB at the reference's level 6 is 0.3 s of one core: eight members, eight cores)
     cacheio.write_gzip(self.features_file, payload,
                        background=ASYNC_CACHE_WRITES,
-                       on_error=lambda e: print("save_features(): I/O error: %s" % e))
+                       on_error=lambda e: print("save_features(): I/O error: %s" % e),
+                       member_bytes=384 << 10)
 
 
 def _npy_bytes(arr):
@@ -210,25 +213,54 @@ def _npy_bytes(arr):
     return [head.getvalue(), memoryview(arr.reshape(-1).view(np.uint8))]
 
 
+def _desc_gzip_from_u8(u8):
+    """the bytes of the reference's <image>.desc -- gzip(np.save(float32 [N,128])) -- straight
+    from the uint8 descriptors (libiamx iamx_gzip_f32_from_u8: the float32 array is 256 different
+    4-byte patterns; ~10x faster than zlib level 1 on it, GIL released)"""
+    import ctypes
+    from . import _lib
+    u8 = np.ascontiguousarray(u8, np.uint8)
+    head = io.BytesIO()
+    np.lib.format.write_array_header_1_0(head, dict(descr='<f4', fortran_order=False, shape=u8.shape))
+    header = np.frombuffer(head.getvalue(), np.uint8)
+    L = _lib.lib()
+    cap = int(L.iamx_gzip_f32_from_u8_bound(len(header), u8.size))
+    out = np.empty(cap, np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = L.iamx_gzip_f32_from_u8(p(header), len(header), p(u8) if u8.size else None, u8.size, p(out), cap)
+    if n <= 0:
+        _lib.check(int(n), 'iamx_gzip_f32_from_u8')
+    return memoryview(out)[:int(n)]
+
+
 def save_descriptors(self):
     des = self.des_list                    # the array as it is now (a later flush drops only the name)
-    if WRITE_REFERENCE_DESC:
-        cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
-                           on_error=lambda e: print(self.desc_file + ": error saving file: " + str(e)),
-                           level=DESC_GZIP_LEVEL)
-    if USE_DESC_SIDECAR and des is not None and len(des):
+    as_u8 = None
+    if des is not None and len(des):
         u8 = np.asarray(des)
         known = getattr(self, '_iamx_des_u8', None)       # (float32 array, its uint8 original)
         if known is not None and known[0] is des:
             as_u8 = known[1]                              # straight from the detector
+        elif u8.dtype == np.uint8:
+            as_u8 = u8
         else:
-            as_u8 = u8 if u8.dtype == np.uint8 else np.clip(np.rint(u8), 0, 255).astype(np.uint8)
-        if u8.dtype == np.uint8 or (known is not None and known[0] is des) \
-                or np.array_equal(as_u8, u8):             # integer valued 0..255 only
-            side = _sidecar(self.desc_file)
-            cacheio.write_raw(side, lambda: _npy_bytes(as_u8), background=ASYNC_CACHE_WRITES,
-                              on_error=lambda e: print(side + ": error saving file: " + str(e)))
-            return
+            cand = np.clip(np.rint(u8), 0, 255).astype(np.uint8)
+            if np.array_equal(cand, u8):                  # integer valued 0..255 only
+                as_u8 = cand
+    if WRITE_REFERENCE_DESC:
+        on_error = lambda e: print(self.desc_file + ": error saving file: " + str(e))
+        if as_u8 is not None and as_u8.ndim == 2 and np.asarray(des).dtype == np.float32:
+            # the reference's file without the float32 bytes ever going through zlib
+            cacheio.write_raw(self.desc_file, lambda: _desc_gzip_from_u8(as_u8),
+                              background=ASYNC_CACHE_WRITES, on_error=on_error)
+        else:
+            cacheio.write_gzip(self.desc_file, lambda: _npy_bytes(des), background=ASYNC_CACHE_WRITES,
+                               on_error=on_error, level=DESC_GZIP_LEVEL)
+    if USE_DESC_SIDECAR and as_u8 is not None:
+        side = _sidecar(self.desc_file)
+        cacheio.write_raw(side, lambda: _npy_bytes(as_u8), background=ASYNC_CACHE_WRITES,
+                          on_error=lambda e: print(side + ": error saving file: " + str(e)))
+        return
     # no sidecar written for these descriptors (non-integer values, none at all, sidecars
     # off): one left over from an earlier detection must not answer the next load
     side = _sidecar(self.desc_file)
@@ -304,8 +336,25 @@ def features_from_bgr(bgr, scale, equalize=True, keep_u8=False):
     kp_list = KeyPointList(kp[:, 0].astype(np.float64) / scale, kp[:, 1].astype(np.float64) / scale,
                            kp[:, 2], kp[:, 3], kp[:, 4], octave)
     if keep_u8:
-        return kp_list, desc.astype(np.float32), desc
-    return kp_list, desc.astype(np.float32)
+        return kp_list, _to_float32(desc), desc
+    return kp_list, _to_float32(desc)
+
+
+def _to_float32(u8):
+    """uint8 [N,128] -> float32 [N,128] (the reference's des_list dtype), row blocks converted on
+    the I/O worker threads: 25 MB per frame is 2.5 ms of the detector loop on one core"""
+    n = len(u8)
+    out = np.empty(u8.shape, np.float32)
+    if n < 8192:
+        out[...] = u8
+        return out
+    _j, workers = cacheio._pools()
+    step = (n + 7) // 8
+
+    def part(a):
+        out[a:a + step] = u8[a:a + step]
+    list(workers.map(part, range(0, n, step)))
+    return out
 
 
 def _prefetch_job(self):
@@ -329,9 +378,35 @@ def _prefetch_job(self):
     except Exception:                     # noqa: BLE001  (fall through to a fresh detection)
         pass
     try:
+        # the host half of the split decoder (Huffman only, GIL released); files it does not
+        # handle are decoded whole
+        if USE_DEVICE_JPEG:
+            from . import kernels
+            jc = kernels.jpeg_host_decode(self.image_file)
+            if jc is not None:
+                # ... and the device half right behind it, on this worker's own stream: the 80 MB of
+                # coefficients go up and become pixels while the detector works on an earlier
+                # frame; the main thread receives a finished frame in HBM
+                import torch
+                with torch.cuda.stream(_worker_stream()):
+                    bgr = kernels.jpeg_reconstruct(jc)       # (synchronises this stream only)
+                return ('bgr', bgr)
         return ('bgr', _decode_bgr(self.image_file, writable=False))
     except Exception:                     # noqa: BLE001  (detect_features repeats it and reports)
         return None
+
+
+_worker_streams = __import__('threading').local()
+
+
+def _worker_stream():
+    """one HIP stream per prefetch worker thread (uploads + JPEG reconstruction off the
+    detector's stream)"""
+    import torch
+    st = getattr(_worker_streams, 'stream', None)
+    if st is None:
+        st = _worker_streams.stream = torch.cuda.Stream()
+    return st
 
 
 def prefetch(images, depth=None):
@@ -348,7 +423,7 @@ def prefetch(images, depth=None):
 def detect_features(self, scale, use_cache=True):
     pf = getattr(self, '_iamx_prefetch', None)
     pre = pf.take(self) if pf is not None and pf.pending(self) else None
-    if use_cache and pre is not None and pre[0] == 'bgr':
+    if use_cache and pre is not None and pre[0] in ('bgr', 'coef'):
         use_cache = False          # the worker looked a moment ago: no cache files (stat() is not free)
     if use_cache:
         if pre is not None and pre[0] == 'cache':
@@ -373,8 +448,23 @@ def detect_features(self, scale, use_cache=True):
         _log("Detector", detector_node.getString('detector'),
              "is not on the MI355X path (SIFT only)")
         quit()
-    bgr = pre[1] if pre is not None and pre[0] == 'bgr' else _decode_bgr(self.image_file, writable=False)
-    h, w = bgr.shape[:2]
+    if pre is not None and pre[0] == 'bgr':
+        bgr = pre[1]
+        if hasattr(bgr, 'record_stream'):
+            import torch                # (allocated on a worker's stream, used on this one)
+            bgr.record_stream(torch.cuda.current_stream())
+    else:
+        # Huffman decode on the host (already done by the prefetch worker if there is one), the
+        # rest of the JPEG decode on the device: the frame never exists in host memory
+        bgr = None
+        if USE_DEVICE_JPEG:
+            from . import kernels
+            jc = pre[1] if pre is not None and pre[0] == 'coef' else kernels.jpeg_host_decode(self.image_file)
+            if jc is not None:
+                bgr = kernels.jpeg_reconstruct(jc)
+        if bgr is None:
+            bgr = _decode_bgr(self.image_file, writable=False)
+    h, w = int(bgr.shape[0]), int(bgr.shape[1])
     self.node.setInt('height', h)
     self.node.setInt('width', w)
     cam_w, cam_h = _deps.camera().get_image_params()

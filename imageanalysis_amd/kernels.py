@@ -597,6 +597,8 @@ class PairBatch(object):
 # SIFT
 # --------------------------------------------------------------------------------------
 _sift_ws = {}
+_sift_out = {}
+_prep_ws = {}
 
 
 class OverlappedSweeps(object):
@@ -651,9 +653,12 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=U8, device=dev)
         _sift_ws[dev.index] = ws
-    kp = torch.empty((cap, 8), dtype=torch.float32, device=dev)
-    desc = torch.empty((cap, 128), dtype=U8, device=dev)
-    n = torch.zeros(1, dtype=I32, device=dev)
+    ob = _sift_out.get(dev.index)                  # (allocations cost ~0.3 ms each per frame)
+    if ob is None or ob[0].shape[0] < cap:
+        ob = (torch.empty((cap, 8), dtype=torch.float32, device=dev),
+              torch.empty((cap, 128), dtype=U8, device=dev), torch.zeros(1, dtype=I32, device=dev))
+        _sift_out[dev.index] = ob
+    kp, desc, n = ob[0][:cap], ob[1][:cap], ob[2]
     check(lib().iamx_sift_detect(_ptr(img), h, w, ch, contrast_threshold, edge_threshold, sigma,
                                  _ptr(ws), need, _ptr(kp), _ptr(desc), cap, _ptr(n), stream_ptr()),
           'iamx_sift_detect')
@@ -694,6 +699,98 @@ def _sift_pinned(dev, n):
     return cur
 
 
+# ---- split JPEG decoder (csrc/jpeg.hip): Huffman decode on the host, the rest on the device --------
+class JpegCoefficients(object):
+    """A JPEG after the host half of the decoder: info (int32 [16], iamx_jpeg_info), the
+    quantised coefficients in a page-locked buffer (int16 [blocks, 64]) and the quantisation
+    tables (uint16 [3, 64]).  release() hands the buffer back to the pool."""
+    __slots__ = ('info', 'coef', 'quant', '_slot')
+
+    def release(self):
+        if self._slot is not None:
+            with _jpeg_lock:
+                _jpeg_pool.append(self._slot)
+            self._slot = None
+            self.coef = None
+
+
+_jpeg_pool = []          # free page-locked coefficient buffers (torch int16, flat)
+_jpeg_lock = __import__('threading').Lock()
+
+
+def _jpeg_buffer(n_values):
+    with _jpeg_lock:
+        for k, b in enumerate(_jpeg_pool):
+            if b.numel() >= n_values:
+                return _jpeg_pool.pop(k)
+        if len(_jpeg_pool) >= 8:             # (a survey's frames are all the same size)
+            _jpeg_pool.pop(0)
+    return torch.empty(int(n_values), dtype=torch.int16).pin_memory()
+
+
+def jpeg_host_decode(source):
+    """The host half: file name or bytes -> JpegCoefficients, or None for a file the split
+    decoder does not handle (progressive, arithmetic, CMYK, ... -- the caller reads those the
+    host way).  No device involved; the C call releases the GIL (worker threads decode in
+    parallel).  Raises IamxError for a broken file."""
+    import ctypes
+    if isinstance(source, (bytes, bytearray, memoryview)):
+        data = bytes(source)
+    else:
+        with open(source, 'rb') as fp:
+            data = fp.read()
+    raw = np.frombuffer(data, np.uint8)
+    L = lib()
+    jc = JpegCoefficients()
+    jc.info = np.zeros(16, np.int32)
+    jc._slot = None
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = L.iamx_jpeg_info(p(raw), len(raw), p(jc.info))
+    if rc == -4:
+        return None
+    check(rc, 'iamx_jpeg_info')
+    blocks = int(jc.info[11])
+    jc._slot = _jpeg_buffer(blocks * 64)
+    jc.coef = jc._slot[:blocks * 64].view(blocks, 64)
+    jc.quant = np.zeros((3, 64), np.uint16)
+    rc = L.iamx_jpeg_decode_coefficients(p(raw), len(raw), ctypes.c_void_p(jc.coef.data_ptr()), blocks,
+                                         p(jc.quant))
+    if rc != 0:
+        jc.release()
+        if rc == -4:
+            return None
+        check(rc, 'iamx_jpeg_decode_coefficients')
+    return jc
+
+
+def jpeg_reconstruct(jc, release=True):
+    """The device half: JpegCoefficients -> BGR uint8 [h, w, 3] in HBM, bit-identical to
+    libjpeg-turbo's output (dequantisation, islow IDCT, fancy upsampling, YCbCr -> BGR)."""
+    import ctypes
+    dev = require_gpu()
+    L = lib()
+    info = jc.info
+    w, h = int(info[0]), int(info[1])
+    d_coef = torch.empty(jc.coef.shape, dtype=torch.int16, device=dev)
+    d_coef.copy_(jc.coef, non_blocking=True)
+    d_quant = torch.from_numpy(jc.quant.astype(np.int16)).to(dev)        # (bit pattern; read as uint16)
+    need = int(L.iamx_jpeg_workspace_bytes(info.ctypes.data_as(ctypes.c_void_p)))
+    ws = torch.empty(need, dtype=U8, device=dev)
+    out = torch.empty((h, w, 3), dtype=U8, device=dev)
+    check(L.iamx_jpeg_reconstruct(_ptr(d_coef), _ptr(d_quant), info.ctypes.data_as(ctypes.c_void_p),
+                                  _ptr(ws), need, _ptr(out), stream_ptr()), 'iamx_jpeg_reconstruct')
+    if release:
+        torch.cuda.current_stream().synchronize()        # the page-locked buffer has been read
+        jc.release()
+    return out
+
+
+def jpeg_decode(source):
+    """file name or bytes -> BGR uint8 [h, w, 3] on the device, or None for an unsupported file"""
+    jc = jpeg_host_decode(source)
+    return None if jc is None else jpeg_reconstruct(jc)
+
+
 def equalize_resize(bgr, scale, equalize=True, clip_limit=3.0):
     """Image.load_rgb(equalize=True) + cv2.resize(fx=fy=scale) on the device.
     bgr [h,w,3] uint8 (numpy or device) -> device tensor [round(h*s), round(w*s), 3] uint8."""
@@ -707,10 +804,13 @@ def equalize_resize(bgr, scale, equalize=True, clip_limit=3.0):
     check(lib().iamx_image_resized_dims(h, w, float(scale), ctypes.byref(oh), ctypes.byref(ow)),
           'iamx_image_resized_dims')
     need = int(lib().iamx_image_prep_workspace_bytes(h, w))
-    ws = torch.empty(need, dtype=U8, device=dev)
+    ws = _prep_ws.get(dev.index)
+    if ws is None or ws.numel() < need:
+        ws = _prep_ws[dev.index] = torch.empty(need, dtype=U8, device=dev)
     out = torch.empty((oh.value, ow.value, 3), dtype=U8, device=dev)
     check(lib().iamx_image_equalize_resize(_ptr(img), h, w, 1 if equalize else 0, float(clip_limit),
                                            float(scale), _ptr(ws), need, _ptr(out), stream_ptr()),
           'iamx_image_equalize_resize')
-    torch.cuda.current_stream().synchronize()
+    if not isinstance(bgr, torch.Tensor):
+        torch.cuda.current_stream().synchronize()      # (the upload's staging copy has been read)
     return out

@@ -25,6 +25,7 @@ extern "C" {
 #define IAMX_EINVAL       -1   /* bad argument (null pointer, size out of range)        */
 #define IAMX_ELAUNCH      -2   /* HIP reported a launch / runtime error                 */
 #define IAMX_ENODEVICE    -3   /* no gfx950 device visible                              */
+#define IAMX_EUNSUPPORTED -4   /* valid input of a kind this path does not handle       */
 
 #define IAMX_DESC_DIM      128 /* SIFT descriptor length (scripts/lib/image.py:324)      */
 #define IAMX_ROW_PAD       128 /* packed images are padded to a multiple of this many rows */
@@ -422,6 +423,43 @@ int64_t iamx_sift_sort_workspace_bytes(int cap);
 int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap,
                    void *workspace, int64_t workspace_bytes, float *out_kp, uint8_t *out_desc,
                    void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Image ingest: split JPEG decoder (csrc/jpeg.hip) in place of cv2.imread(file, ANYCOLOR |
+ * ANYDEPTH | IGNORE_ORIENTATION) of scripts/lib/image.py:99-104.  The host does the Huffman
+ * decode (serial by nature), the device dequantisation + the libjpeg "islow" integer IDCT +
+ * fancy chroma upsampling + YCbCr -> BGR: integer arithmetic throughout, pixels bit-identical to
+ * libjpeg-turbo's (what OpenCV and Pillow decode with).  8-bit baseline / extended-sequential
+ * Huffman files with one interleaved scan, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0; anything else
+ * returns IAMX_EUNSUPPORTED (the caller decodes such a file the host way).
+ *   iamx_jpeg_info: HOST.  info [16] int32: width, height, components, max h / v sampling,
+ *     blocks_w / blocks_h of components 0..2 (8x8 blocks, padded to whole MCUs), [11] total
+ *     blocks, [12] restart interval.
+ *   iamx_jpeg_decode_coefficients: HOST, no device involved, thread safe.  coef HOST
+ *     [coef_blocks >= info[11]][64] int16: the quantised coefficients of every block in natural
+ *     (row major) order, components back to back, blocks of a component in raster order;
+ *     quant HOST [3][64] uint16: the components' quantisation tables in natural order.
+ *   iamx_jpeg_reconstruct: coef / quant DEV (as written above), info HOST, workspace DEV
+ *     iamx_jpeg_workspace_bytes(info) bytes (the component planes), bgr DEV [height][width][3].
+ * ------------------------------------------------------------------------------------ */
+int iamx_jpeg_info(const uint8_t *data, int64_t len, int32_t *info);
+int iamx_jpeg_decode_coefficients(const uint8_t *data, int64_t len, int16_t *coef,
+                                  int64_t coef_blocks, uint16_t *quant);
+int64_t iamx_jpeg_workspace_bytes(const int32_t *info);
+int iamx_jpeg_reconstruct(const int16_t *coef, const uint16_t *quant, const int32_t *info,
+                          void *workspace, int64_t workspace_bytes, uint8_t *bgr, void *stream);
+
+/* The reference's descriptor cache file (gzip of np.save(float32 [N, 128]),
+ * scripts/lib/image.py:205-217) written straight from the detector's uint8 descriptors: HOST,
+ * no device involved, thread safe.  out receives ONE gzip member whose payload is `header` (the
+ * .npy header) followed by the little-endian float32 values of `values`; any gzip reader gets the
+ * bytes np.save would have written (a dynamic-Huffman DEFLATE block of literals built from the
+ * histogram of the 256 possible values: ~25 ms per 50 k-keypoint frame instead of ~0.5 s of
+ * zlib).  Returns the member's size in bytes (out_cap >= iamx_gzip_f32_from_u8_bound(...)) or a
+ * negative error code. */
+int64_t iamx_gzip_f32_from_u8_bound(int64_t n_header, int64_t n_values);
+int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header, const uint8_t *values,
+                              int64_t n_values, uint8_t *out, int64_t out_cap);
 
 /* ------------------------------------------------------------------------------------
  * K4: linear algebra on the device-resident block Jacobian (what SciPy's TRF/LSMR does on

@@ -14,7 +14,7 @@ _lib = None
 def build(force=False):
     if force or not os.path.exists(_SO) or \
             os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f))
-                                        for f in ('cpu_ref.c', 'sift_ref.c', 'knn2_simd.c', 'Makefile')):
+                                        for f in ('cpu_ref.c', 'sift_ref.c', 'knn2_simd.c', 'jpeg_ref.c', 'Makefile')):
         subprocess.check_call(['make', '-C', _HERE, '-B', 'liboracle_cpu.so'],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -175,3 +175,16 @@ def sift_detect(gray, cap=None, nthreads=0):
     if n < 0:
         raise ValueError("oracle_sift_detect rc=%d" % n)
     return kps[:n].copy(), desc[:n].copy()
+
+
+def jpeg_reconstruct(coef, quant, info):
+    """oracle/jpeg_ref.c: quantised coefficients (as iamx_jpeg_decode_coefficients writes them)
+    -> BGR uint8 [h, w, 3] the way libjpeg-turbo's defaults reconstruct them"""
+    coef = np.ascontiguousarray(coef, np.int16)
+    quant = np.ascontiguousarray(quant, np.uint16)
+    info = np.ascontiguousarray(info, np.int32)
+    out = np.empty((int(info[1]), int(info[0]), 3), np.uint8)
+    rc = lib().oracle_jpeg_reconstruct(_p(coef), _p(quant), _p(info), _p(out))
+    if rc != 0:
+        raise ValueError("oracle_jpeg_reconstruct rc=%d" % rc)
+    return out

@@ -216,3 +216,29 @@ def test_uint8_descriptor_sidecar(tmp_path):
         assert im3.load_descriptors() and np.array_equal(im3.des_list, des)
     finally:
         iimg.WRITE_REFERENCE_DESC = True
+
+
+def test_desc_file_from_uint8_is_the_reference_format(tmp_path):
+    """iamx_gzip_f32_from_u8 (host code of libiamx): the .desc file written straight from the
+    detector's uint8 descriptors decompresses to exactly the bytes np.save(float32) writes, for
+    any content -- empty, constant, all 256 values, SIFT-like -- and the reference's reader
+    (gzip.open + np.load, scripts/lib/image.py:166-177) loads it"""
+    import gzip
+    import io
+    from imageanalysis_amd import image as iimg
+    rng = np.random.default_rng(0)
+    cases = [np.zeros((0, 128), np.uint8), np.zeros((3, 128), np.uint8), np.full((5, 128), 255, np.uint8),
+             rng.integers(0, 256, (100, 128), dtype=np.uint8),
+             np.arange(256, dtype=np.uint8).reshape(2, 128),
+             (rng.gamma(0.6, 1, (3000, 128)) * 40).clip(0, 255).astype(np.uint8)]
+    for u8 in cases:
+        f32 = u8.astype(np.float32)
+        buf = io.BytesIO()
+        np.save(buf, f32)
+        z = bytes(iimg._desc_gzip_from_u8(u8))
+        assert gzip.decompress(z) == buf.getvalue()
+        path = tmp_path / 'x.desc'
+        path.write_bytes(z)
+        with gzip.open(str(path), 'rb') as fp:
+            back = np.load(fp)
+        assert back.dtype == np.float32 and np.array_equal(back, f32)

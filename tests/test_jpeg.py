@@ -1,0 +1,91 @@
+"""CPU: the host half of the split JPEG decoder (iamx_jpeg_info / iamx_jpeg_decode_coefficients,
+plain C++ in libiamx.so, no device involved) and the restatement of libjpeg's pixel
+reconstruction (oracle/jpeg_ref.c, the CPU twin of the kernels) against libjpeg-turbo itself
+(Pillow): bit-identical pixels on 4:4:4 / 4:2:2 / 4:2:0 / grey files, odd sizes, restart markers,
+optimised Huffman tables.  The GPU kernels are compared with Pillow in tests/test_jpeg_gpu.py."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+CASES = [((96, 128), 0, 95, {}), ((96, 128), 1, 95, {}), ((96, 128), 2, 95, {}),
+         ((451, 637), 1, 90, {}), ((451, 637), 2, 75, {}), ((33, 17), 2, 60, {}), ((17, 33), 1, 85, {}),
+         ((8, 8), 0, 95, {}), ((1, 1), 2, 95, {}), ((9, 15), 2, 100, {}), ((240, 321), 2, 30, {}),
+         ((200, 300), 1, 92, dict(restart_marker_rows=1)), ((200, 300), 2, 92, dict(restart_marker_blocks=7)),
+         ((130, 97), 0, 88, dict(restart_marker_blocks=1)), ((300, 200), 2, 95, dict(optimize=True)),
+         ((123, 77), 'L', 90, {}), ((64, 64), 'L', 50, dict(restart_marker_blocks=3))]
+
+
+def scene(h, w, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 120 * np.sin(x / 7.0 + seed) * np.cos(y / 11.0),
+                    127 + 120 * np.sin((x + y) / 13.0), 127 + 120 * np.cos(x / 5.0 - y / 9.0)], 2)
+    img += rng.normal(0, 25, img.shape)
+    # saturated and sharp-edged regions (out-of-range IDCT results, chroma edges)
+    img[h // 3:h // 2, w // 4:w // 2] = (255, 0, 255)
+    img[: max(h // 8, 1), : max(w // 8, 1)] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def encode(shape, sub, quality, extra, seed=0):
+    from PIL import Image
+    rgb = scene(shape[0], shape[1], seed)
+    buf = io.BytesIO()
+    if sub == 'L':
+        Image.fromarray(rgb[:, :, 0]).save(buf, 'JPEG', quality=quality, **extra)
+    else:
+        Image.fromarray(rgb).save(buf, 'JPEG', quality=quality, subsampling=sub, **extra)
+    return buf.getvalue()
+
+
+def pillow_bgr(data):
+    from PIL import Image
+    im = Image.open(io.BytesIO(data))
+    im = im.convert('RGB')
+    return np.asarray(im)[:, :, ::-1]
+
+
+def host_decode(data):
+    from imageanalysis_amd import _lib
+    L = _lib.lib()
+    raw = np.frombuffer(data, np.uint8)
+    info = np.zeros(16, np.int32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = L.iamx_jpeg_info(p(raw), len(raw), p(info))
+    if rc != 0:
+        return rc, None, None, None
+    coef = np.empty((int(info[11]), 64), np.int16)
+    quant = np.zeros((3, 64), np.uint16)
+    rc = L.iamx_jpeg_decode_coefficients(p(raw), len(raw), p(coef), len(coef), p(quant))
+    return rc, info, coef, quant
+
+
+@pytest.mark.parametrize('shape,sub,quality,extra', CASES)
+def test_host_decode_plus_reconstruction_equals_libjpeg(shape, sub, quality, extra):
+    from oracle import cpu_ref
+    data = encode(shape, sub, quality, extra, seed=quality)
+    rc, info, coef, quant = host_decode(data)
+    assert rc == 0
+    assert (info[0], info[1]) == (shape[1], shape[0])
+    got = cpu_ref.jpeg_reconstruct(coef, quant, info)
+    want = pillow_bgr(data)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), (np.abs(got.astype(int) - want.astype(int)).max(),
+                                       int((got != want).sum()))
+
+
+def test_unsupported_files_are_reported_not_guessed():
+    from PIL import Image
+    from imageanalysis_amd import _lib
+    buf = io.BytesIO()
+    Image.fromarray(scene(64, 64, 1)).save(buf, 'JPEG', quality=90, progressive=True)
+    rc, *_ = host_decode(buf.getvalue())
+    assert rc == -4 and b'progressive' in _lib.lib().iamx_last_error()
+    buf = io.BytesIO()
+    Image.fromarray(scene(64, 64, 1)).convert('CMYK').save(buf, 'JPEG', quality=90)
+    assert host_decode(buf.getvalue())[0] == -4
+    assert host_decode(b'\x89PNG\r\n\x1a\n' + b'0' * 64)[0] == -1
+    data = encode((64, 64), 2, 90, {})
+    assert host_decode(data[:len(data) // 3])[0] in (0, -1)      # truncated: zeros, like libjpeg
