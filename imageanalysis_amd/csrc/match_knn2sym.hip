@@ -607,6 +607,266 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
     }
 }
 
+#ifdef IAMX_ABLATE
+// ---------------------------------------------------------------------------------
+// EXPERIMENT (ablation build only; measured, not shipped: profiles/r3_knn2sym_crosschunk.txt --
+// 1 % with the barrier on the chunk boundary, register spills with it anywhere else).
+// The same sweep with the software pipeline carried ACROSS the chunk boundary (round 3).
+// knn2sym_kernel drains its pipeline at every chunk barrier: the last epilogue of a chunk has no
+// MFMAs beside it, the first MFMAs of the next chunk no epilogue, and the barrier puts the two
+// waves of every SIMD back into lockstep eight steps later.  Here the A rows are staged THREE
+// chunks deep, so the one barrier per chunk does not have to sit on the boundary:
+//   barrier M(ch), taken by a wave somewhere in the first steps of chunk ch (step BAR_LO for the
+//   first half of the waves, BAR_HI for the second: the two waves of a SIMD arrive from different
+//   points of their step sequence), says
+//     (1) chunk ch+1 is in LDS (every wave waited for its part of the staging it issued behind
+//         M(ch-1), a whole chunk ago),
+//     (2) nobody reads chunk ch-1 any more -> its buffer takes chunk ch+2,
+//     (3) every wave has stored its row minima of chunk ch-1 -> waves 0/1 merge them.
+//   The last step of a chunk issues the MFMAs of the next chunk's first step (operands read from
+//   the next buffer behind M(ch)), so the MFMA / epilogue interleave never stops; the step behind
+//   the last chunk computes on stale rows and is dropped.  The row minima rotate through three
+//   buffers as well (a wave may write chunk ch+2's while the merge of chunk ch is still running).
+// Arithmetic, bounds and result layout are those of knn2sym_kernel<.., GROUPLO = true>.
+// ---------------------------------------------------------------------------------
+template <int QW, int NW, int PIPE, int BAR_LO, int BAR_HI>
+__global__ __launch_bounds__(NW * 64, 2) void knn2sym_x_kernel(SymArgs A)
+{
+    constexpr int WGROWS = NW * QW * 32;
+    constexpr int NT = NW * 64;
+    constexpr int PIECES = CHUNK * D / 16 / NT;
+    constexpr int TPC = CHUNK / 32;                  // 32-row tiles per chunk
+    constexpr int PP = QW / 2, NS = TPC * PP;        // steps (pairs of query blocks) per chunk
+    static_assert(QW % 2 == 0 && (TPC % 2) == 0, "operand / accumulator parity continues across chunks");
+    static_assert(BAR_LO <= NS - PP - 1 && BAR_HI <= NS - PP - 1, "the barrier precedes the first read of the next chunk");
+    __shared__ __attribute__((aligned(16))) int8_t lds[3 * CHUNK * D + 3 * CHUNK * 4 + 3 * NW * CHUNK * 4 + 2 * NW * 4 + NW * 256 * 4];
+    int8_t *lds_tile = lds;
+    int *lds_tb = reinterpret_cast<int *>(lds + 3 * CHUNK * D);      // [3][CHUNK]     Ct
+    int *lds_row = lds_tb + 3 * CHUNK;                               // [3][NW][CHUNK] R_w
+    int *lds_cq = lds_row + 3 * NW * CHUNK;                          // [NW] (2 NW reserved) S_w
+    int *lds_dump = lds_cq + 2 * NW;                                 // [NW][256]      unused stores
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, g = lane >> 5;
+
+    int vid;
+    {
+        const int total = A.total_wg, bid = blockIdx.x;
+        const int xcd = bid & 7, k = bid >> 3, q = total >> 3, r = total & 7;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    int lo = 0, hi = A.n_u;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.wg_off[mid] <= vid) lo = mid; else hi = mid;
+    }
+    const int u = lo;
+    const int bimg = A.upairs[2 * u], aimg = A.upairs[2 * u + 1];
+    const int boff = A.img_off[bimg], nb = A.img_n[bimg];
+    const int aoff = A.img_off[aimg], na = A.img_n[aimg];
+    const int capA = (na + CHUNK - 1) / CHUNK * CHUNK;
+    const int nchunks = capA / CHUNK;
+    const int wgi = vid - A.wg_off[u];
+    const int q0 = wgi * WGROWS + wave * (QW * 32);
+    const bool wave_valid = q0 < nb;
+    const int64_t rbase = A.rowp_off[u] + (int64_t)wgi * capA;
+
+    // B operand and Cq floor as in knn2sym_kernel (GROUPLO lane -> row map)
+    const int rc = (c & 16) | ((c & 3) << 2) | ((c >> 2) & 3);
+    v4i bq[QW][4];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        int row = q0 + QW * rc + qb;
+        row = row < nb ? row : nb - 1;
+        const v4i *src = reinterpret_cast<const v4i *>(A.sdesc + (int64_t)(boff + row) * D);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[qb][s] = ~src[2 * s + g];
+    }
+    int lo_lane = 0;
+    {
+        int spread = 0;
+        if (wave_valid) {
+            const int g_lo = rc & ~3, g_hi = rc | 3;
+            const int r_lo = q0 + QW * g_lo < nb ? q0 + QW * g_lo : nb - 1;
+            const int r_hi = q0 + QW * g_hi + QW - 1 < nb ? q0 + QW * g_hi + QW - 1 : nb - 1;
+            lo_lane = A.sn2[boff + r_lo] >> 1;
+            spread = (A.sn2[boff + r_hi] >> 1) - lo_lane;
+        }
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) spread = max(spread, __shfl_xor(spread, sh));
+        if (lane == 0) lds_cq[wave] = spread;
+    }
+    if (!wave_valid) {
+#pragma unroll
+        for (int k = 0; k < 3 * CHUNK / 64; ++k)
+            lds_row[((k / (CHUNK / 64)) * NW + wave) * CHUNK + (k % (CHUNK / 64)) * 64 + lane] = BIG;
+    }
+    int m[QW][4];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[qb][k] = BIG;
+
+    const int8_t *tbase = A.sdesc + (int64_t)aoff * D;
+    const int32_t *tci = A.sct + aoff;
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    auto stage_direct = [&](int ch, int buf) {
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j) {
+            const int e = j * NT + tid, row = e >> 3, slot = (e & 7) ^ ((row >> 1) & 7);
+            const int8_t *gsrc = tbase + (int64_t)(ch * CHUNK + row) * D + slot * 16;
+            int8_t *ldst = lds_tile + buf * (CHUNK * D) + (j * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds(gsrc, (lds_ptr)ldst, 16, 0, 0);
+        }
+        if (wave < CHUNK / 64)
+            __builtin_amdgcn_global_load_lds(tci + ch * CHUNK + tid,
+                                             (lds_ptr)(lds_tb + buf * CHUNK + wave * 64), 4, 0, 0);
+    };
+    auto wait_direct = [&]() { __builtin_amdgcn_s_waitcnt(0x0F70); };       // vmcnt(0)
+    constexpr int MROWS = CHUNK / 2;                     // waves 0 and 1 merge 64 rows each
+    const int mrow = wave * MROWS + lane;
+    const bool merger = wave < 2;
+    auto merge_rows = [&](int ch, int buf) {
+        int L = BIG, U1 = BIG, U2 = BIG;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int R = lds_row[(buf * NW + w) * CHUNK + mrow];
+            const int uw = R + lds_cq[w];
+            L = min(L, R);
+            U2 = min(max(U1, uw), U2);
+            U1 = min(U1, uw);
+        }
+        *reinterpret_cast<v4i *>(A.rowp + 4 * (rbase + ch * CHUNK + mrow)) = v4i{L, U1, U2, 0};
+    };
+    // barrier M(ch): see the header.  b2 = buffer of chunk ch+2 = buffer of chunk ch-1
+    auto mid_barrier = [&](int ch, int b2) {
+        wait_direct();
+        __syncthreads();
+        if (ch + 2 < nchunks) stage_direct(ch + 2, b2);
+        if (ch > 0 && merger) merge_rows(ch - 1, b2);
+    };
+
+    stage_direct(0, 0);
+    if (nchunks > 1) stage_direct(1, 1);
+    wait_direct();
+    __syncthreads();
+
+    if (!wave_valid) {
+        int b2 = 2;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            mid_barrier(ch, b2);
+            b2 = b2 == 2 ? 0 : b2 + 1;
+        }
+    } else {
+        const int bar_st = wave < NW / 2 ? BAR_LO : BAR_HI;
+        auto load_tile = [&](const int8_t *tile_base, const int *tb_base, int tile, v4i (&a)[4], v4i (&tbv)[4]) {
+            const int r = tile * 32 + c, swz = (r >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                a[s] = *reinterpret_cast<const v4i *>(tile_base + r * D + (((2 * s + g) ^ swz) * 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                tbv[k] = *reinterpret_cast<const v4i *>(tb_base + tile * 32 + 8 * k + 4 * g);
+        };
+        v4i aop[2][4], tbop[2][4];
+        v16i accs[2][2];
+        int r[16];
+        auto issue = [&](int par, int qp, v16i &acc0, v16i &acc1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc0[reg] = acc1[reg] = tbop[par][reg >> 2][reg & 3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[par][s], bq[qp][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[par][s], bq[qp + 1][s], acc1, 0, 0, 0);
+            }
+        };
+        const int row_lane = 8 * ((lane >> 4) & 1) + 4 * g + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+        const bool row_owner = (lane & 3) == 0;
+        // prologue: the first step of chunk 0 is in flight when the loop starts
+        load_tile(lds_tile, lds_tb, 0, aop[0], tbop[0]);
+        issue(0, 0, accs[0][0], accs[0][1]);
+        load_tile(lds_tile, lds_tb, 1, aop[1], tbop[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        int b = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int b1 = b == 2 ? 0 : b + 1, b2 = b == 0 ? 2 : b - 1;
+            const int8_t *tile_cur = lds_tile + b * (CHUNK * D), *tile_nxt = lds_tile + b1 * (CHUNK * D);
+            const int *tb_cur = lds_tb + b * CHUNK, *tb_nxt = lds_tb + b1 * CHUNK;
+            int *row_dst = row_owner ? lds_row + (b * NW + wave) * CHUNK + row_lane
+                                     : lds_dump + wave * 256 + lane;     // + t*32 (+16) stays inside [0, 256)
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int t = st / PP, qp = 2 * (st % PP), cur = st & 1;
+                if (st == BAR_LO || st == BAR_HI) {
+                    if (bar_st == st) mid_barrier(ch, b2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    // the next step's MFMAs (past the last step of the chunk: the next chunk's first)
+                    const int t1 = (st + 1) / PP, qp1 = 2 * ((st + 1) % PP);
+                    issue(t1 & 1, qp1, accs[cur ^ 1][0], accs[cur ^ 1][1]);
+                    if (t1 != t) {
+                        const int T = t1 + 1;            // operands of the tile after that one
+                        if (T >= TPC) load_tile(tile_nxt, tb_nxt, T - TPC, aop[t & 1], tbop[t & 1]);
+                        else load_tile(tile_cur, tb_cur, T, aop[t & 1], tbop[t & 1]);
+                    }
+                }
+                const v16i acc0 = accs[cur][0], acc1 = accs[cur][1];
+                int t0 = min(min(m[qp][t & 3], acc0[0]), acc0[1]);
+                int t1m = min(min(m[qp + 1][t & 3], acc1[0]), acc1[1]);
+#pragma unroll
+                for (int reg = 2; reg < 16; reg += 2) {
+                    t0 = min(min(t0, acc0[reg]), acc0[reg + 1]);
+                    t1m = min(min(t1m, acc1[reg]), acc1[reg + 1]);
+                }
+                m[qp][t & 3] = t0;
+                m[qp + 1][t & 3] = t1m;
+                if (qp == 0) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) r[reg] = min(acc0[reg], acc1[reg]);
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) r[reg] = min(min(r[reg], acc0[reg]), acc1[reg]);
+                }
+                if (qp == QW - 2) {
+                    int m0, m1;
+                    half_wave_min16<true>(r, lo_lane, m0, m1);
+                    int *dst = row_dst + t * 32;
+                    dst[0] = m0;
+                    dst[16] = m1;
+                }
+                // one MFMA, then the VALU work that fits beside it
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, PIPE, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            b = b1;
+        }
+    }
+    wait_direct();
+    __syncthreads();
+    if (merger) merge_rows(nchunks - 1, (nchunks - 1) % 3);
+
+    // ---- column results: two smallest of the 4 x 2 group minima of every query
+    if (wave_valid) {
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) {
+            const int lo01 = min(m[qb][0], m[qb][1]), hi01 = max(m[qb][0], m[qb][1]);
+            const int lo23 = min(m[qb][2], m[qb][3]), hi23 = max(m[qb][2], m[qb][3]);
+            const int a1 = min(lo01, lo23), a2 = min(max(lo01, lo23), min(hi01, hi23));
+            const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
+            const int v1 = min(a1, b1), v2 = min(max(a1, b1), min(a2, b2));
+            const int row = q0 + QW * rc + qb;
+            if (g == 0 && row < nb)
+                *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1, v2};
+        }
+    }
+}
+
+#endif  // IAMX_ABLATE
+
 // ---------------------------------------------------------------------------------
 // candidates: one workgroup per ORDERED pair.  Pass 1 visits the rows in SORTED order (the order
 // the sweep wrote its bounds in: coalesced reads) and drops a flag at the row's original
@@ -1052,6 +1312,10 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
     case 310: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 256>), g, dim3(512), 0, st, a); break;
     case 311: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 128>), g, dim3(512), 0, st, a); break;
     case 300: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+#define X(id, pipe, lo, hi) case id: hipLaunchKernelGGL((knn2sym_x_kernel<4, 8, pipe, lo, hi>), g, dim3(512), 0, st, a); break;
+        X(500, 6, 4, 4) X(501, 6, 4, 0) X(502, 6, 0, 0) X(503, 6, 5, 1) X(504, 6, 2, 2) X(505, 6, 4, 1)
+        X(506, 5, 4, 0) X(507, 7, 4, 0) X(508, 6, 5, 2) X(509, 6, 3, 0)
+#undef X
     case 301: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 0, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 302: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 4, 2, 0, true>), g, dim3(512), 0, st, a); break;
     case 303: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 2, 0, true>), g, dim3(512), 0, st, a); break;

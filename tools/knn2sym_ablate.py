@@ -35,7 +35,8 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
 st = store
 ref = None
-names = {330: 'MFMA + staging, one LDS operand read per chunk', 331: '... and no staging after chunk 1', 332: '... and no barrier / merge: MFMA issue only', 320: 'PIPE 0 with the MFMA bursts at raised wave priority', 400: 'no staging after chunk 1 (timing only)', 401: '... and no chunk barrier', 402: '... and no row merge', 403: 'MFMA only, no staging after chunk 1', 404: 'MFMA + staging only (new form)', 310: '256-row chunks, merge on 4 waves, PIPE 5', 311: '128-row chunks, merge on 4 waves, PIPE 5', 300: 'fused butterfly + group Cq floor, PIPE 6', 301: '... PIPE 0', 302: '... PIPE 4', 303: '... PIPE 5', 200: 'merge on waves 0-3', 201: 'sleep 2 for waves 4-7', 202: 'sleep 5 for waves 4-7', 203: 'merge on waves 0-3 + sleep 3', 204: 'merge on all 8 waves', 16: 'shipped schedule without the per-chunk row merge', 48: '... and without the chunk barrier (timing only)', 100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
+ref300 = None
+names = {500: 'cross-chunk pipeline, barrier at step 4 / 4', 501: '... 4 / 0', 502: '... 0 / 0', 503: '... 5 / 1', 504: '... 2 / 2', 505: '... 4 / 1', 506: '... 4 / 0, PIPE 5', 507: '... 4 / 0, PIPE 7', 508: '... 5 / 2', 509: '... 3 / 0', 330: 'MFMA + staging, one LDS operand read per chunk', 331: '... and no staging after chunk 1', 332: '... and no barrier / merge: MFMA issue only', 320: 'PIPE 0 with the MFMA bursts at raised wave priority', 400: 'no staging after chunk 1 (timing only)', 401: '... and no chunk barrier', 402: '... and no row merge', 403: 'MFMA only, no staging after chunk 1', 404: 'MFMA + staging only (new form)', 310: '256-row chunks, merge on 4 waves, PIPE 5', 311: '128-row chunks, merge on 4 waves, PIPE 5', 300: 'fused butterfly + group Cq floor, PIPE 6', 301: '... PIPE 0', 302: '... PIPE 4', 303: '... PIPE 5', 200: 'merge on waves 0-3', 201: 'sleep 2 for waves 4-7', 202: 'sleep 5 for waves 4-7', 203: 'merge on waves 0-3 + sleep 3', 204: 'merge on all 8 waves', 16: 'shipped schedule without the per-chunk row merge', 48: '... and without the chunk barrier (timing only)', 100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
          4: 'row direction without butterfly', 5: 'row min tree only', 8: 'no MFMA',
          11: 'staging + barriers only'}
 for v in variants:
@@ -52,6 +53,12 @@ for v in variants:
     t = min(ts[1:])
     if v == 0:
         ref = (ws.col[:b.sym_col_rows].clone(), ws.rowp[:b.sym_rowp_rows].clone())
+    elif v == 300:
+        ref300 = (ws.col[:b.sym_col_rows].clone(), ws.rowp[:b.sym_rowp_rows].clone())
+    elif v >= 500:                              # cross-chunk pipeline: the arithmetic of variant 300
+        assert ref300 is not None, 'run variant 300 first'
+        assert torch.equal(ref300[0], ws.col[:b.sym_col_rows]), 'variant %d: column bounds differ' % v
+        assert torch.equal(ref300[1][:, :3], ws.rowp[:b.sym_rowp_rows, :3]), 'variant %d: row bounds differ' % v
     elif 100 <= v < 300 and ref is not None:    # alternative schedules of the same arithmetic
         # (300+: group-shared Cq floor -- different, equally valid bounds)
         assert torch.equal(ref[0], ws.col[:b.sym_col_rows]), 'variant %d: column bounds differ' % v
