@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--one-direction', action='store_true',
                     help='A/B: the round-1 form, one MFMA sweep per ORDERED pair (iamx_knn2v2_pairs)')
-    ap.add_argument('--verify-pairs', type=int, default=6,
+    ap.add_argument('--verify-pairs', type=int, default=64,
                     help='ordered pairs of the timed store checked against the oracle afterwards')
     ap.add_argument('--no-overlap', action='store_true',
                     help='filter kernels on the sweep stream (default: on a second stream)')
@@ -259,14 +259,20 @@ def main():
     traffic, traffic_src, mfma_busy, mfma_busy_src = None, None, None, None
     sweeps = 2 if args.one_direction else 1                # MFMA passes per distance matrix
     tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json' if args.one_direction
-                      else 'r2_knn2sym_traffic.json')
+                      else 'r3_knn2sym_traffic.json')
     if n_img == CONFIG1_IMAGES and world == 1 and os.path.exists(tf):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); PMC cannot be collected from inside
         with open(tf) as fp:
             t = json.load(fp)
-        traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
-        mfma_busy, mfma_busy_src = t.get("mfma_busy"), t.get("mfma_busy_source")
+        # ... of THIS kernel: a summary measured on another instantiation of the sweep is refused
+        kid = kernels.lib().iamx_knn2sym_kernel_id(2).decode() if not args.one_direction else None
+        if kid is None or t.get("kernel", "").startswith(kid):
+            traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
+            mfma_busy, mfma_busy_src = t.get("mfma_busy"), t.get("mfma_busy_source")
+        else:
+            traffic_src = mfma_busy_src = ("refused: %s was measured on %s, the library launches %s"
+                                           % (os.path.basename(tf), t.get("kernel", "?").split(' (')[0], kid))
     roofline = {"bound": "mfma", "kernel": "knn2v2_kernel" if args.one_direction else "knn2sym_kernel",
                 "achieved": round(achieved, 2), "peak": I8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / I8_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -387,6 +393,11 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
         # through the all-gather (its descriptors are regenerated here from the seed)
         other = hi if hi < n_img else first - 1
         cand = cand[:4] + [(first, other), (other, first)] + cand[4:]
+    # ... then more neighbours (overlapping views: most survivors) and far pairs, spread over the store
+    span = max(hi - first, 1)
+    for k in range(4, 4 + 2 * n_check):
+        a = first + (k * 7919) % span
+        cand.append((a, a + 1) if k % 2 else (a, first + (a - first + span // 2 + k) % span))
     cand = [(a, b) for a, b in cand if 0 <= a < n_img and 0 <= b < n_img and a != b
             and (first <= a < hi or first <= b < hi)]
     und = []
@@ -831,6 +842,13 @@ def sift_bench(rank, world, dev, dist, args):
     except Exception as e:                                  # noqa: BLE001 (e.g. not enough HBM left)
         full = {"error": str(e)[:200]}
     alg = 469.0 * h * w                                     # bytes per image
+    sift_tr, sift_tr_src = None, None
+    _p = os.path.join(REPO, 'profiles', AUX_TRAFFIC_FILE)
+    if os.path.exists(_p):
+        with open(_p) as fp:
+            _d = json.load(fp)
+        sift_tr = _d.get("sift", {}).get("hbm_bytes_per_frame") or None
+        sift_tr_src = "profiles/%s (%s)" % (AUX_TRAFFIC_FILE, _d.get("source", ""))
     cpu = None                                              # filled in by main() at the end
     global _SIFT_SAMPLE
     _SIFT_SAMPLE = scaled.cpu().numpy() if rank == 0 else None
@@ -840,7 +858,11 @@ def sift_bench(rank, world, dev, dist, args):
             "ms_per_image_detector_kernels": round(t_k * 1e3, 2),
             "roofline": {"bound": "hbm", "kernels": "pyramid + extrema + orientation + descriptor",
                          "achieved": round(alg / t_k / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg},
+                         "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg,
+                         "traffic": sift_tr, "traffic_source": sift_tr_src,
+                         "timing": "hipEvents around %d whole detects on the launch stream; per-kernel " % n_local +
+                                   "durations: profiles/r3_kernel_stats.txt (rocprofv3 --kernel-trace "
+                                   "--stats of the bench command), profiles/r3_sift_kernel_stats.txt"},
             "scale_1_0": full, "cpu_baseline": cpu, "dtype": "f32 pyramid, f64 histograms",
             "parallelism": "image-shard x%d" % world}
 
@@ -957,6 +979,10 @@ def ba_bench(rank, world, dev, dist, args):
                 "achieved_executed": round(ex / t_it / 1e9, 1),
                 "frac_executed": round(ex / t_it / 1e9 / HBM, 4),
                 "working_set": "Infinity-Cache resident (< 256 MB)"}
+        lsmr["traffic"], lsmr["traffic_source"] = aux_traffic(
+            ('lsmr_fwd_kernel', 'lsmr_adj_kernel', 'lsmr_update3_kernel'), 'lsmr_update3_kernel')
+        lsmr["timing"] = ("wall clock around %d fused iterations, queue kept full; per-kernel durations: "
+                          "profiles/r3_kernel_stats.txt" % its)
     schur_it = None
     if world == 1:
         # one CG iteration of the Schur solver = three passes over the stored Jacobian blocks
@@ -981,6 +1007,12 @@ def ba_bench(rank, world, dev, dist, args):
                     "frac": round(by / t_cg / 1e9 / HBM, 4), "us_per_iteration": round(t_cg * 1e6, 1),
                     "bytes_per_iteration": by, "form": "stored blocks",
                     "iterations_timed": int(itn) - 8}
+        schur_it["traffic"], schur_it["traffic_source"] = aux_traffic(
+            ('schur_fwd_kernel', 'schur_pt_kernel', 'schur_adj_kernel', 'schur_pq_kernel',
+             'schur_update1_kernel', 'schur_update2_kernel'), 'schur_fwd_kernel')
+        schur_it["timing"] = ("wall clock, difference of a %d- and an 8-iteration solve; per-kernel "
+                              "durations: profiles/r3_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
+                              % its)
     cpu = None                                              # filled in by main() at the end
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
             "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),
@@ -1000,15 +1032,42 @@ def ba_bench(rank, world, dev, dist, args):
                          # 256 MB Infinity Cache (a plain copy of that size runs at 6.9 TB/s,
                          # tools/hbm_copy_bw.py), so this is a cache-level, not an HBM, fraction
                          "working_set": "Infinity-Cache resident (125 MB per evaluation)",
+                         "traffic": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[0],
+                         "traffic_source": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[1],
                          "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
-                                   "kernel, ba_residual_lds_kernel: profiles/r2_kernel_stats.txt)"},
+                                   "kernel, ba_residual_lds_kernel: profiles/r3_kernel_stats.txt)"},
             "residual_jac": {"bound": "hbm",
                              "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
                              "peak": HBM, "unit": "GB/s",
                              "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
-                             "bytes_per_obs": 224},
+                             "bytes_per_obs": 224,
+                             "traffic": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[0],
+                             "traffic_source": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[1],
+                             "timing": "hipEvents around 50 launches (ba_residual_jac_kernel: "
+                                       "profiles/r3_kernel_stats.txt)"},
             "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
+
+
+AUX_TRAFFIC_FILE = 'r3_ba_sift_traffic.json'
+
+
+def aux_traffic(bases, per):
+    """HBM bytes per `per`-kernel launch of the kernels whose base name is in `bases`, summed
+    (an iteration = every kernel of it), from the committed PMC passes of this command
+    (profiles/r3_ba_sift_traffic.json, tools/aux_traffic_json.py); (None, reason) without it"""
+    path = os.path.join(REPO, 'profiles', AUX_TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fp:
+        doc = json.load(fp)
+    ks = doc.get("kernels", {})
+    n_per = sum(v["dispatches"] for k, v in ks.items() if k.split('<')[0] == per)
+    tot = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in ks.items()
+              if k.split('<')[0] in bases)
+    if n_per == 0 or tot == 0:
+        return None, "profiles/%s holds no %s launches" % (AUX_TRAFFIC_FILE, per)
+    return int(tot / n_per), "profiles/%s (%s)" % (AUX_TRAFFIC_FILE, doc.get("source", ""))
 
 
 _SIFT_SAMPLE = None

@@ -43,6 +43,7 @@ SIGNATURES = {
                            + [c_void_p] * 3),
     'iamx_desc3_rows_cap': (c_int64, [c_int64]),
     'iamx_knn2sym_rows_per_wg': (c_int, [c_int]),
+    'iamx_knn2sym_kernel_id': (ctypes.c_char_p, [c_int]),
     'iamx_desc3_pack_u8': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
     'iamx_desc3_pack_f32': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
     'iamx_desc3_pack_batch_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]

@@ -1219,6 +1219,23 @@ extern "C" int iamx_desc3_pack_batch_u8(const uint8_t *src, const int64_t *src_o
     return pack3_launch<uint8_t>(P, total_rows, max_rows_per_image, stream, "iamx_desc3_pack_batch_u8");
 }
 
+// template arguments of the shipped sweep, one place for the launch and for iamx_knn2sym_kernel_id()
+#define SWEEP_FORM2 4, 8, 0, 6, 2, 0, true, 128
+#define SWEEP_FORM1 4, 4, 0, 6, 2, 0, true, 128
+#define SWEEP_FORM0 2, 4, 0, 6, 2, 0, true, 128
+#define SWEEP_STR2(...) #__VA_ARGS__
+#define SWEEP_STR(...) SWEEP_STR2(__VA_ARGS__)
+
+extern "C" const char *iamx_knn2sym_kernel_id(int form)
+{
+    switch (form) {
+    case 2: return "knn2sym_kernel<" SWEEP_STR(SWEEP_FORM2) ">";
+    case 1: return "knn2sym_kernel<" SWEEP_STR(SWEEP_FORM1) ">";
+    case 0: return "knn2sym_kernel<" SWEEP_STR(SWEEP_FORM0) ">";
+    default: return "";
+    }
+}
+
 extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const int32_t *sct,
                                   const int32_t *img_off, const int32_t *img_n,
                                   const int32_t *upairs, const int32_t *wg_off,
@@ -1236,9 +1253,9 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     hipStream_t st = iamx::as_stream(stream);
     // PIPE = 6: six epilogue VALU instructions beside every MFMA of the next pair of query
     // blocks (profiles/r2_knn2sym_ablate.txt: 1.83 -> 1.78 us per image pair)
-    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a);
-    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<4, 4, 0, 6, 2, 0, true>), g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((knn2sym_kernel<2, 4, 0, 6, 2, 0, true>), g, dim3(256), 0, st, a);
+    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM2>), g, dim3(512), 0, st, a);
+    else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM1>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM0>), g, dim3(256), 0, st, a);
     return iamx::check_launch("iamx_knn2sym_sweep");
 }
 

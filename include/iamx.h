@@ -216,6 +216,9 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  * ------------------------------------------------------------------------------------ */
 int64_t iamx_desc3_rows_cap(int64_t n_rows);
 int iamx_knn2sym_rows_per_wg(int form);
+/* the sweep kernel a form launches, spelled the way rocprofv3 prints it ("knn2sym_kernel<4, 8, ...>"):
+ * profile summaries are matched against the binary that is loaded (bench.py refuses stale ones) */
+const char *iamx_knn2sym_kernel_id(int form);
 int iamx_desc3_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst, int32_t *sn2,
                        int32_t *sct, int32_t *sperm, int32_t *sinv, int32_t *scratch,
                        void *stream);

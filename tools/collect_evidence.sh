@@ -1,21 +1,23 @@
 #!/bin/bash
 # Round evidence in one go (GPU box; run from the repository root through gpurun):
-#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r2)
+#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r3)
 # Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back), the summaries that are
 # judged are copied to profiles/ afterwards.  Counter passes are separate runs with --pmc only.
-TAG="${1:-r2}"
+TAG="${1:-r3}"
 OUT="$PWD/gpurun_out"
 REPO="$PWD"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 SUM="python $REPO/tools/prof_summary.py"
-BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0"
+BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e"
+# BA + SIFT kernels (a small matching section in front of them)
+AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e"
 
 step() { echo "== $1 ($(date +%T))"; }
 
 step "gpu tests"
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
-tail -3 "$OUT/${TAG}_gpu_tests.txt"
+tail -n 3 "$OUT/${TAG}_gpu_tests.txt"
 
 step "bench"
 timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
@@ -23,7 +25,7 @@ tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
 
 step "kernel stats of the bench command"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
-    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
+    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
 $SUM /tmp/p_stats "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/prof_gaps.py" /tmp/p_stats lsmr > "$OUT/${TAG}_lsmr_gaps.txt" 2>&1
 head -8 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-160
@@ -33,6 +35,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err)
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/p_$C "$OUT/${TAG}_knn2sym_pmc_${lc}.txt" > /dev/null
+done
+step "PMC: HBM traffic of the BA and SIFT kernels (FETCH_SIZE, WRITE_SIZE: separate passes)"
+for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/a_$C -o b -- $AUX_PMC > /dev/null 2> /tmp/a_$C.err)
+    lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
+    $SUM /tmp/a_$C "$OUT/${TAG}_aux_pmc_${lc}.txt" > /dev/null
 done
 step "PMC: SQ / MFMA busy"
 (cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
@@ -52,9 +60,10 @@ step "SIFT kernel stats"
     python "$REPO/tools/sift_time.py" 0.4 > "$OUT/${TAG}_sift_time.txt" 2>&1)
 $SUM /tmp/p_sift "$OUT/${TAG}_sift_kernel_stats.txt" > /dev/null
 
+if [ -z "$NO_ENTRY" ]; then
 step "entry points"
-timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -1 "$OUT/${TAG}_fm_dense.txt"
-timeout 600 python tools/find_matches_rate.py 40 40 1024 > "$OUT/${TAG}_fm_sparse.txt" 2>&1; tail -1 "$OUT/${TAG}_fm_sparse.txt"
-timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -4 "$OUT/${TAG}_detect_rate.txt"
-timeout 900 python bench.py --e2e 100 > "$OUT/${TAG}_e2e_100.json" 2> "$OUT/${TAG}_e2e_100.err"; tail -c 400 "$OUT/${TAG}_e2e_100.json"; echo
+timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_dense.txt"
+timeout 600 python tools/find_matches_rate.py 40 40 1024 > "$OUT/${TAG}_fm_sparse.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_sparse.txt"
+timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
+fi
 step "done"
