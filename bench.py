@@ -515,7 +515,7 @@ def e2e_bench(n_images, full_frame=False):
         matcher.configure()
 
         def detect():
-            pf = iimg.prefetch(proj.image_list)
+            pf = iimg.prefetch(proj.image_list, scale=scale)
             for im in proj.image_list:
                 im.detect_features(scale)
             pf.close()

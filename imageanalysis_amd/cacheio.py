@@ -38,16 +38,49 @@ def _pools():
     return _jobs, _workers
 
 
-def _member(chunk, level):
-    c = zlib.compressobj(level, zlib.DEFLATED, 31)            # wbits 31: gzip container
+def _member(chunk, level, strategy=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)            # wbits 31: gzip container
     return c.compress(chunk) + c.flush()
 
 
-def gzip_member_list(raw, level=GZIP_LEVEL, member_bytes=None):
+NATIVE_THREADS = 8                    # zlib threads inside one iamx_gzip_members call
+
+
+def _native_members(bufs, level, member_bytes, strategy=0):
+    """all members of one file in ONE call into libiamx (zlib on threads of its own, no GIL): with
+    a python future per member the hand-overs of the interpreter lock, not the compression,
+    bounded a detection loop on a many-core host (tools/detect_stages.py).  None if the library
+    is not there (the pure-python members below are the same stream)."""
+    try:
+        import ctypes
+        import numpy as np
+        from . import _lib
+        L = _lib.lib()
+    except Exception:                                         # noqa: BLE001
+        return None
+    views = [np.frombuffer(memoryview(b).cast('B'), np.uint8) for b in bufs]
+    views = [v for v in views if len(v)]
+    lens = np.array([len(v) for v in views], np.int64)
+    ptrs = (ctypes.c_void_p * max(len(views), 1))(*[v.ctypes.data for v in views])
+    total = int(lens.sum())
+    n_members = int(sum((int(n) + member_bytes - 1) // member_bytes for n in lens)) or 1
+    cap = int(L.iamx_gzip_members_bound(total, n_members))
+    out = np.empty(cap, np.uint8)
+    n = L.iamx_gzip_members(ptrs, lens.ctypes.data_as(ctypes.c_void_p), len(views), int(member_bytes),
+                            int(level), int(strategy), NATIVE_THREADS, out.ctypes.data_as(ctypes.c_void_p), cap)
+    if n < 0:
+        _lib.check(int(n), 'iamx_gzip_members')
+    return memoryview(out)[:int(n)]
+
+
+def gzip_member_list(raw, level=GZIP_LEVEL, member_bytes=None, strategy=0):
     """bytes-like, or a sequence of bytes-likes that are to follow each other (e.g. an .npy
     header and the array's own memory: nothing is copied together first) -> list of gzip members
     whose concatenation decompresses to those bytes (members compressed in parallel)"""
     bufs = [raw] if isinstance(raw, (bytes, bytearray, memoryview)) else list(raw)
+    native = _native_members(bufs, level, member_bytes or MEMBER_BYTES, strategy)
+    if native is not None:
+        return [native]
     chunks = []
     for b in bufs:
         b = memoryview(b).cast('B')
@@ -56,14 +89,14 @@ def gzip_member_list(raw, level=GZIP_LEVEL, member_bytes=None):
     if not chunks:
         chunks = [memoryview(b'')]
     if len(chunks) == 1:
-        return [_member(chunks[0], level)]
+        return [_member(chunks[0], level, strategy)]
     _j, workers = _pools()
     try:
-        return list(workers.map(lambda c: _member(c, level), chunks))
+        return list(workers.map(lambda c: _member(c, level, strategy), chunks))
     except RuntimeError:
         # "cannot schedule new futures after interpreter shutdown": the process is exiting while
         # this file is still queued -- compress it right here, the file must not be lost
-        return [_member(c, level) for c in chunks]
+        return [_member(c, level, strategy) for c in chunks]
 
 
 def gzip_members(raw, level=GZIP_LEVEL):
@@ -71,10 +104,10 @@ def gzip_members(raw, level=GZIP_LEVEL):
     return b''.join(gzip_member_list(raw, level))
 
 
-def _write_job(path, payload, on_error=None, level=GZIP_LEVEL, member_bytes=None):
+def _write_job(path, payload, on_error=None, level=GZIP_LEVEL, member_bytes=None, strategy=0):
     try:
         raw = payload() if callable(payload) else payload
-        members = gzip_member_list(raw, level, member_bytes)
+        members = gzip_member_list(raw, level, member_bytes, strategy)
         # pid + thread id: two ranks may write the same boundary image's cache at the same time
         tmp = '%s.tmp%d.%d' % (path, os.getpid(), threading.get_ident())
         with open(tmp, 'wb') as f:
@@ -115,17 +148,18 @@ def write_raw(path, payload, background=True, on_error=None):
     return fut
 
 
-def write_gzip(path, payload, background=True, on_error=None, level=GZIP_LEVEL, member_bytes=None):
+def write_gzip(path, payload, background=True, on_error=None, level=GZIP_LEVEL, member_bytes=None,
+               strategy=0):
     """payload: bytes or a callable returning bytes (run on the job thread, e.g. np.save into a
     buffer).  Errors go to `on_error(exc)` if given, else surface in wait().  `level`: zlib level
     of the members (any level reads back the same bytes)."""
     if not background:
         # (the caller waits for this one file: many small members, all workers on it)
-        _write_job(path, payload, on_error, level, 1 << 20)
+        _write_job(path, payload, on_error, level, 1 << 20, strategy)
         return None
     jobs, _w = _pools()
     wait(path)                                                # keep two writes of a path ordered
-    fut = jobs.submit(_write_job, path, payload, on_error, level, member_bytes)
+    fut = jobs.submit(_write_job, path, payload, on_error, level, member_bytes, strategy)
     with _lock:
         _pending[path] = fut
     return fut

@@ -27,5 +27,5 @@ for f in $SRCS; do
     OBJS="$OBJS $o"
 done
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJS -lz -lpthread
 echo "built $OUT"

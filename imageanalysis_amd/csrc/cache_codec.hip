@@ -113,7 +113,7 @@ void canonical_codes(const uint8_t *len, int n_sym, uint16_t *code /* bit revers
         code[s] = len[s] ? (uint16_t)reverse_bits((uint32_t)next[len[s]]++, len[s]) : 0;
 }
 
-uint32_t g_crc[4][256];
+uint32_t g_crc[16][256];
 bool g_crc_ready = false;
 
 void crc_tables()
@@ -126,7 +126,7 @@ void crc_tables()
     }
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = g_crc[0][i];
-        for (int t = 1; t < 4; ++t) {
+        for (int t = 1; t < 16; ++t) {
             c = g_crc[0][c & 0xff] ^ (c >> 8);
             g_crc[t][i] = c;
         }
@@ -161,7 +161,17 @@ extern "C" int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header
     }
     // histogram of the values -> literal frequencies
     uint64_t hist[256] = {0};
-    for (int64_t i = 0; i < n_values; ++i) hist[values[i]]++;
+    {
+        // four interleaved counters: runs of equal values (zeros) do not serialise on one slot
+        std::vector<uint32_t> h4(4 * 256, 0);
+        uint32_t *h = h4.data();
+        int64_t i = 0;
+        for (; i + 4 <= n_values && i < (int64_t)0xFFFFFFF0; i += 4) {
+            h[values[i]]++; h[256 + values[i + 1]]++; h[512 + values[i + 2]]++; h[768 + values[i + 3]]++;
+        }
+        for (int v = 0; v < 256; ++v) hist[v] = (uint64_t)h[v] + h[256 + v] + h[512 + v] + h[768 + v];
+        for (; i < n_values; ++i) hist[values[i]]++;
+    }
     uint64_t freq[257] = {0};
     for (int64_t i = 0; i < n_header; ++i) freq[header[i]]++;
     for (int v = 0; v < 256; ++v)
@@ -208,20 +218,67 @@ extern "C" int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header
     }
     uint32_t crc = 0xFFFFFFFFu;
     for (int64_t i = 0; i < n_header; ++i) crc = g_crc[0][(crc ^ header[i]) & 0xff] ^ (crc >> 8);
-    for (int64_t i = 0; i < n_values; ++i) {
-        const int v = values[i];
-        // (a value's bits can exceed what fits behind a partly filled accumulator: two puts)
-        const uint64_t b = vbits[v];
+    // CRC-32 sixteen bytes (four values) per step.  A pattern's two low bytes are zero and
+    // table[.][0] = 0, so the words that are not mixed with the running CRC cost ONE look-up
+    // each in a per-position table of the value: u1/u2/u3[v] = slices of bytes 2, 3 of word 1/2/3.
+    uint32_t u1[256], u2[256], u3[256];
+    for (int v = 0; v < 256; ++v) {
+        u1[v] = g_crc[9][pat[v][2]] ^ g_crc[8][pat[v][3]];
+        u2[v] = g_crc[5][pat[v][2]] ^ g_crc[4][pat[v][3]];
+        u3[v] = g_crc[1][pat[v][2]] ^ g_crc[0][pat[v][3]];
+    }
+    // bits: a 64-bit accumulator stored whole (the buffer bound leaves > 8 bytes of slack past
+    // the longest possible stream: 60 bits per value), advanced by the full bytes it holds
+    uint8_t *q = bw.p;
+    uint64_t acc = bw.acc;
+    int nb = bw.n;                                       // < 8
+    auto emit = [&](uint64_t b, int l) {                 // l <= 56
+        acc |= b << nb;
+        nb += l;
+        std::memcpy(q, &acc, 8);
+        q += nb >> 3;
+        acc >>= nb & ~7;
+        nb &= 7;
+    };
+    auto emit_value = [&](int v) {
         const int l = vlen[v];
-        if (l <= 32) {
-            bw.put((uint32_t)b, l);
+        if (l <= 56) {
+            emit(vbits[v], l);
         } else {
-            bw.put((uint32_t)(b & 0xFFFFFFFFu), 32);
-            bw.put((uint32_t)(b >> 32), l - 32);
+            emit(vbits[v] & 0xFFFFFFFFull, 32);
+            emit(vbits[v] >> 32, l - 32);
         }
+    };
+    int64_t i = 0;
+    for (; i + 4 <= n_values; i += 4) {
+        const int v0 = values[i], v1 = values[i + 1], v2 = values[i + 2], v3 = values[i + 3];
+        // two values per accumulator step where their bits fit (nearly always: ~20 bits a value)
+        const int l01 = vlen[v0] + vlen[v1], l23 = vlen[v2] + vlen[v3];
+        if (l01 <= 56) {
+            emit(vbits[v0] | (vbits[v1] << vlen[v0]), l01);
+        } else {
+            emit_value(v0);
+            emit_value(v1);
+        }
+        if (l23 <= 56) {
+            emit(vbits[v2] | (vbits[v3] << vlen[v2]), l23);
+        } else {
+            emit_value(v2);
+            emit_value(v3);
+        }
+        const uint32_t x = crc ^ word[v0];
+        crc = g_crc[15][x & 0xff] ^ g_crc[14][(x >> 8) & 0xff] ^ g_crc[13][(x >> 16) & 0xff] ^ g_crc[12][x >> 24]
+              ^ u1[v1] ^ u2[v2] ^ u3[v3];
+    }
+    for (; i < n_values; ++i) {
+        const int v = values[i];
+        emit_value(v);
         const uint32_t x = crc ^ word[v];
         crc = g_crc[3][x & 0xff] ^ g_crc[2][(x >> 8) & 0xff] ^ g_crc[1][(x >> 16) & 0xff] ^ g_crc[0][x >> 24];
     }
+    bw.p = q;
+    bw.acc = acc;
+    bw.n = nb;
     bw.put(code[256], len[256]);
     bw.flush();
     if (bw.overflow) return iamx::fail(IAMX_EINVAL, "iamx_gzip_f32_from_u8: output buffer too small");
@@ -231,4 +288,152 @@ extern "C" int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header
     for (int k = 0; k < 4; ++k) *p++ = (uint8_t)(crc >> (8 * k));
     for (int k = 0; k < 4; ++k) *p++ = (uint8_t)(isize >> (8 * k));
     return (int64_t)(p - out);
+}
+
+// =====================================================================================
+// The rest of the cache writers' byte work, each as ONE call without the interpreter lock.
+// Measured on the 256-thread host of the GPU box (tools/detect_stages.py): with the members of a
+// .feat file compressed by eight python futures, the float32 conversion by eight more and the
+// pickle records assembled by numpy field assignments, a thread that wakes up needs 1-4 ms to get
+// the lock back and a fresh detection costs 11.5 ms of serialised host time per frame whatever the
+// number of workers.
+// =====================================================================================
+#include <zlib.h>
+
+#include <atomic>
+#include <thread>
+
+namespace {
+
+struct Chunk {
+    const uint8_t *src;
+    size_t len;
+    uint8_t *dst;            // its own region of the output (deflateBound of the chunk)
+    size_t cap, out;
+    int rc;
+};
+
+void deflate_chunk(Chunk &c, int level, int strategy)
+{
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    c.rc = deflateInit2(&zs, level, Z_DEFLATED, 31, 8, strategy);     // 31: gzip container
+    if (c.rc != Z_OK) return;
+    zs.next_in = const_cast<Bytef *>(c.src);
+    zs.avail_in = (uInt)c.len;
+    zs.next_out = c.dst;
+    zs.avail_out = (uInt)c.cap;
+    const int r = deflate(&zs, Z_FINISH);
+    c.out = c.cap - zs.avail_out;
+    c.rc = r == Z_STREAM_END ? Z_OK : (r == Z_OK ? Z_BUF_ERROR : r);
+    deflateEnd(&zs);
+}
+
+inline size_t member_bound(size_t len) { return len + (len >> 10) + 64; }   // >= deflateBound + gzip wrapper
+
+}  // namespace
+
+// upper bound of iamx_gzip_members' output for `total` input bytes in `n_members` members
+extern "C" int64_t iamx_gzip_members_bound(int64_t total, int64_t n_members)
+{
+    if (total < 0 || n_members < 0) return 0;
+    return total + (total >> 10) + 64 * (n_members + 1);
+}
+
+// gzip members (each at most member_bytes of input, never spanning two buffers; zlib `level` and
+// `strategy`: 0 default, 1 filtered, 2 Huffman only, 3 RLE, 4 fixed) of the buffers
+// bufs[0..n_bufs), compressed on up to `threads` threads and written back to back: a multi-member
+// gzip stream that decompresses to the concatenation of the buffers.  Returns the number of bytes
+// written or a negative error code.
+extern "C" int64_t iamx_gzip_members(const uint8_t *const *bufs, const int64_t *lens, int n_bufs,
+                                     int64_t member_bytes, int level, int strategy, int threads,
+                                     uint8_t *out, int64_t out_cap)
+{
+    if (!bufs || !lens || n_bufs < 0 || !out || member_bytes < 1 || member_bytes > (1ll << 30) || level < 0 ||
+        level > 9 || strategy < 0 || strategy > 4)
+        return iamx::fail(IAMX_EINVAL, "iamx_gzip_members: bad argument");
+    std::vector<Chunk> chunks;
+    size_t need = 0;
+    for (int b = 0; b < n_bufs; ++b) {
+        if (lens[b] < 0 || (lens[b] > 0 && !bufs[b])) return iamx::fail(IAMX_EINVAL, "iamx_gzip_members: bad buffer");
+        for (int64_t o = 0; o < lens[b]; o += member_bytes) {
+            const size_t n = (size_t)std::min<int64_t>(member_bytes, lens[b] - o);
+            chunks.push_back(Chunk{bufs[b] + o, n, nullptr, member_bound(n), 0, Z_OK});
+            need += member_bound(n);
+        }
+    }
+    if (chunks.empty()) {
+        chunks.push_back(Chunk{reinterpret_cast<const uint8_t *>(""), 0, nullptr, member_bound(0), 0, Z_OK});
+        need = member_bound(0);
+    }
+    if ((size_t)out_cap < need) return iamx::fail(IAMX_EINVAL, "iamx_gzip_members: output buffer too small");
+    size_t off = 0;
+    for (Chunk &c : chunks) {
+        c.dst = out + off;
+        off += c.cap;
+    }
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), chunks.size()));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < chunks.size(); i = next.fetch_add(1)) deflate_chunk(chunks[i], level, strategy);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    size_t w = 0;
+    for (Chunk &c : chunks) {
+        if (c.rc != Z_OK) return iamx::fail(IAMX_EINVAL, "iamx_gzip_members: zlib error %d", c.rc);
+        if (out + w != c.dst) std::memmove(out + w, c.dst, c.out);
+        w += c.out;
+    }
+    return (int64_t)w;
+}
+
+// dst[i] = (float)src[i]: the reference's float32 des_list from the detector's uint8 descriptors
+extern "C" int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) return iamx::fail(IAMX_EINVAL, "iamx_u8_to_f32: null pointer");
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(threads, 1), n >> 18));
+    auto part = [&](int t) {
+        const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+        for (int64_t i = a; i < b; ++i) dst[i] = (float)src[i];
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (std::thread &t : pool) t.join();
+    return IAMX_OK;
+}
+
+// The .feat pickle's fixed-width records (imageanalysis_amd/keypoints.py _REC: protocol-2 opcodes
+// "( G x G y TUPLE2 G size G angle G response J octave J class_id t", BINFLOAT big endian,
+// BININT little endian) from the keypoint columns: out [n][58].
+extern "C" int iamx_feat_records(const float *x, const float *y, const float *size, const float *angle,
+                                 const float *response, const int32_t *octave, const int32_t *class_id,
+                                 int64_t n, uint8_t *out)
+{
+    if (n < 0 || (n > 0 && (!x || !y || !size || !angle || !response || !octave || !class_id || !out)))
+        return iamx::fail(IAMX_EINVAL, "iamx_feat_records: null pointer");
+    auto put_f64 = [](uint8_t *p, float v) {
+        const double d = (double)v;
+        uint64_t u;
+        std::memcpy(&u, &d, 8);
+        u = __builtin_bswap64(u);
+        std::memcpy(p, &u, 8);
+    };
+    for (int64_t i = 0; i < n; ++i) {
+        uint8_t *p = out + 58 * i;
+        p[0] = '(';
+        p[1] = 'G';  put_f64(p + 2, x[i]);
+        p[10] = 'G'; put_f64(p + 11, y[i]);
+        p[19] = 0x86;
+        p[20] = 'G'; put_f64(p + 21, size[i]);
+        p[29] = 'G'; put_f64(p + 30, angle[i]);
+        p[38] = 'G'; put_f64(p + 39, response[i]);
+        p[47] = 'J'; std::memcpy(p + 48, &octave[i], 4);
+        p[52] = 'J'; std::memcpy(p + 53, &class_id[i], 4);
+        p[57] = 't';
+    }
+    return IAMX_OK;
 }

@@ -38,6 +38,33 @@ struct HuffTable {
     int32_t maxcode[18];        // largest code of length l (-1 if none), [17] sentinel
     int32_t valoffset[17];      // huffval index of the first code of length l minus that code
     uint8_t huffval[256];
+    // AC tables only: code AND magnitude bits inside the lookahead -> (value << 8) | (run << 4) |
+    // total bits (value -128 .. 127), 0 = take the two-step path
+    int16_t fast_ac[1 << LOOK];
+
+    int eob_len = HuffTable::LOOK, eob_code = -1;   // the code of symbol 0x00 if it is <= LOOK bits long
+
+    void build_fast_ac()
+    {
+        eob_len = LOOK;
+        eob_code = -1;
+        for (int i = 0; i < (1 << LOOK); ++i)
+            if (fast[i] && (fast[i] & 255) == 0) {
+                eob_len = fast[i] >> 8;
+                eob_code = i >> (LOOK - eob_len);
+                break;
+            }
+        for (int i = 0; i < (1 << LOOK); ++i) {
+            fast_ac[i] = 0;
+            const int f = fast[i];
+            if (!f) continue;
+            const int rs = f & 255, l = f >> 8, run = rs >> 4, sz = rs & 15;
+            if (sz == 0 || l + sz > LOOK) continue;
+            int v = ((i << l) & ((1 << LOOK) - 1)) >> (LOOK - sz);      // the sz bits behind the code
+            if (v < (1 << (sz - 1))) v += 1 - (1 << sz);                // (jdhuff.c HUFF_EXTEND)
+            if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)(v * 256 + run * 16 + l + sz);
+        }
+    }
 
     bool build(const uint8_t *bits /* [1..16] at [0..15] */, const uint8_t *vals, int nvals)
     {
@@ -66,6 +93,7 @@ struct HuffTable {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        build_fast_ac();
         present = true;
         return true;
     }
@@ -212,8 +240,25 @@ struct BitReader {
     int bits = 0;
     bool hit_marker = false;
 
+    // afterwards at least 32 valid bits: a Huffman code (<= 16) and its magnitude bits (<= 15)
     inline void fill()
     {
+        if (bits >= 32) return;
+        if (!hit_marker && p + 8 <= end) {
+            // eight bytes at once when none of them is 0xFF (no stuffing, no marker)
+            uint64_t w;
+            std::memcpy(&w, p, 8);
+            w = __builtin_bswap64(w);
+            const uint64_t t = ~w;
+            if (!((t - 0x0101010101010101ull) & ~t & 0x8080808080808080ull)) {
+                const int nb = (64 - bits) >> 3;                     // 1 .. 8 whole bytes fit
+                const uint64_t take = nb == 8 ? w : (w & ~((1ull << (64 - 8 * nb)) - 1));
+                acc |= take >> bits;
+                bits += 8 * nb;
+                p += nb;
+                return;
+            }
+        }
         while (bits <= 56) {
             int b = 0;
             if (!hit_marker && p < end) {
@@ -321,7 +366,6 @@ extern "C" int iamx_jpeg_decode_coefficients(const uint8_t *data, int64_t len, i
     IAMX_REQUIRE(coef_blocks >= total, "coefficient buffer too small (iamx_jpeg_info)");
     for (int c = 0; c < H.ncomp; ++c)
         for (int i = 0; i < 64; ++i) quant[c * 64 + i] = H.quant[H.comp[c].tq][i];
-    std::memset(coef, 0, sizeof(int16_t) * 64 * (size_t)total);
     BitReader br;
     br.p = H.scan;
     br.end = H.scan + H.scan_len;
@@ -340,20 +384,33 @@ extern "C" int iamx_jpeg_decode_coefficients(const uint8_t *data, int64_t len, i
                 for (int by = 0; by < C.v; ++by)
                     for (int bx = 0; bx < C.h; ++bx) {
                         int16_t *blk = coef + 64 * (base[c] + (int64_t)(my * C.v + by) * C.blocks_w + mx * C.h + bx);
+                        std::memset(blk, 0, 128);
                         int s = decode_symbol(br, DC);
                         if (s) {
-                            br.fill();
                             const int r = br.get(s);
                             s = extend(r, s);
                         }
                         pred[c] += s;
                         blk[0] = (int16_t)pred[c];
                         for (int k = 1; k < 64;) {
+                            br.fill();
+                            const int look = br.peek(HuffTable::LOOK);
+                            if (look >> (HuffTable::LOOK - AC.eob_len) == AC.eob_code) {   // end of block
+                                br.skip(AC.eob_len);
+                                break;
+                            }
+                            const int fa = AC.fast_ac[look];
+                            if (fa) {                                    // code + value in one look-up
+                                k += (fa >> 4) & 15;
+                                br.skip(fa & 15);
+                                if (k < 64) blk[kZigzag[k]] = (int16_t)(fa >> 8);
+                                ++k;
+                                continue;
+                            }
                             const int rs = decode_symbol(br, AC);
                             const int r = rs >> 4, sz = rs & 15;
                             if (sz) {
                                 k += r;
-                                br.fill();
                                 const int v = extend(br.get(sz), sz);
                                 if (k < 64) blk[kZigzag[k]] = (int16_t)v;
                                 ++k;

@@ -1142,8 +1142,9 @@ extern "C" int64_t iamx_sift_workspace_bytes(int height, int width)
     return make_layout(height, width, CAP_CAND).total;
 }
 
-// second stream + fork / join events of iamx_sift_detect, one set per device, created on first
-// use and kept for the life of the process (nullptr if the runtime refuses: single-stream order)
+// second stream + fork / join events of iamx_sift_detect, one set per device AND calling thread
+// (concurrent detections from several host threads must not share fork / join events), created on
+// first use and kept for the life of the thread (nullptr if the runtime refuses: single-stream order)
 namespace {
 struct SideStream {
     hipStream_t stream;
@@ -1152,10 +1153,8 @@ struct SideStream {
 
 SideStream *side_stream()
 {
-    static SideStream slots[64];
-    static bool ready[64], failed[64];
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
+    static thread_local SideStream slots[64];
+    static thread_local bool ready[64], failed[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     if (failed[dev]) return nullptr;

@@ -94,6 +94,12 @@ WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this p
 DESC_GZIP_LEVEL = 1
 # decoded / cache-loaded images held ahead of the detector (one worker thread each; a 20 MP JPEG
 # takes ~0.2 s of one core to decode against ~6 ms on the GPU, 60 MB per decoded frame)
+# zlib setting of the .feat members.  The reference asks for compresslevel=6 (image.py:201); on a
+# 50 k-keypoint .feat that is 270 ms of one core for 23.3 bytes per keypoint, the largest single host
+# cost of a fresh detection (tools/detect_stages.py: the GPU box's 16-core quota was spent on it).
+# Level 4 with Z_FILTERED (the records are mostly float bits: few matches, Huffman does the work) is
+# 72 ms for 24.9 bytes per keypoint -- the same bytes for every reader.  (6, 0) = the reference's.
+FEAT_GZIP_LEVEL, FEAT_GZIP_STRATEGY = 4, 1
 PREFETCH_DEPTH = min(24, max(6, (os.cpu_count() or 8) // 4))
 
 
@@ -188,7 +194,7 @@ def save_features(self):
     decompressed; written in the background as a multi-member gzip stream (cacheio)"""
     kps = self.kp_list
     if isinstance(kps, KeyPointList):
-        payload = kps.feat_bytes                         # straight from the columns (in the writer thread)
+        payload = lambda: kps.feat_bytes(as_view=True)   # straight from the columns (in the writer thread)
     else:
         feature_list = [(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
                         for kp in kps]
@@ -197,7 +203,7 @@ def save_features(self):
     cacheio.write_gzip(self.features_file, payload,
                        background=ASYNC_CACHE_WRITES,
                        on_error=lambda e: print("save_features(): I/O error: %s" % e),
-                       member_bytes=384 << 10)
+                       member_bytes=384 << 10, level=FEAT_GZIP_LEVEL, strategy=FEAT_GZIP_STRATEGY)
 
 
 def _npy_bytes(arr):
@@ -324,12 +330,18 @@ def load_rgb(self, equalize=False):
 # --------------------------------------------------------------------------------------
 # detect -- image.py:287-350
 # --------------------------------------------------------------------------------------
-def features_from_bgr(bgr, scale, equalize=True, keep_u8=False):
+def features_from_bgr(bgr, scale, equalize=True, keep_u8=False, slot=False):
     """full-res BGR -> (kp_list in full-res pixels, des_list float32 [N,128]); everything
-    after the decode runs on the GPU."""
+    after the decode runs on the GPU.  slot: take a detector slot for the device part (worker
+    threads that detect concurrently; the host part below runs outside the slot)."""
     from . import kernels
-    scaled = kernels.equalize_resize(bgr, scale, equalize=equalize)
-    kp, octave, desc = kernels.sift_detect(scaled)
+    if slot:
+        with kernels.detector_slot():
+            scaled = kernels.equalize_resize(bgr, scale, equalize=equalize)
+            kp, octave, desc = kernels.sift_detect(scaled)
+    else:
+        scaled = kernels.equalize_resize(bgr, scale, equalize=equalize)
+        kp, octave, desc = kernels.sift_detect(scaled)
     # kp.pt = (kp.pt[0]/scale, kp.pt[1]/scale): keypoints are cached in FULL-RES pixels (:344-346)
     kp = np.asarray(kp)
     # python-float division like `kp.pt[0] / scale` on a cv2.KeyPoint, then float32 members
@@ -341,19 +353,14 @@ def features_from_bgr(bgr, scale, equalize=True, keep_u8=False):
 
 
 def _to_float32(u8):
-    """uint8 [N,128] -> float32 [N,128] (the reference's des_list dtype), row blocks converted on
-    the I/O worker threads: 25 MB per frame is 2.5 ms of the detector loop on one core"""
-    n = len(u8)
+    """uint8 [N,128] -> float32 [N,128] (the reference's des_list dtype) in one call into libiamx
+    (threads of its own: 25 MB per frame is 2.5 ms of one core)"""
+    import ctypes
+    from . import _lib
+    u8 = np.ascontiguousarray(u8, np.uint8)
     out = np.empty(u8.shape, np.float32)
-    if n < 8192:
-        out[...] = u8
-        return out
-    _j, workers = cacheio._pools()
-    step = (n + 7) // 8
-
-    def part(a):
-        out[a:a + step] = u8[a:a + step]
-    list(workers.map(part, range(0, n, step)))
+    _lib.check(_lib.lib().iamx_u8_to_f32(u8.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p),
+                                         u8.size, 4), 'iamx_u8_to_f32')
     return out
 
 
@@ -388,8 +395,15 @@ def _prefetch_job(self):
                 # coefficients go up and become pixels while the detector works on an earlier
                 # frame; the main thread receives a finished frame in HBM
                 import torch
-                with torch.cuda.stream(_worker_stream()):
-                    bgr = kernels.jpeg_reconstruct(jc)       # (synchronises this stream only)
+                with torch.cuda.stream(_worker_stream()), kernels.polite_waits():
+                    bgr = kernels.jpeg_reconstruct(jc)       # (waits for this stream only)
+                    scale = getattr(self, '_iamx_prefetch_scale', None)
+                    if scale is not None:
+                        # the caller said which scale it will ask for: the whole detection runs
+                        # here, in one of the detector slots, and the loop that calls
+                        # detect_features() only collects results
+                        feats = features_from_bgr(bgr, scale, equalize=True, keep_u8=True, slot=True)
+                        return ('features', float(scale), feats, int(bgr.shape[0]), int(bgr.shape[1]))
                 return ('bgr', bgr)
         return ('bgr', _decode_bgr(self.image_file, writable=False))
     except Exception:                     # noqa: BLE001  (detect_features repeats it and reports)
@@ -409,11 +423,15 @@ def _worker_stream():
     return st
 
 
-def prefetch(images, depth=None):
+def prefetch(images, depth=None, scale=None):
     """Start decoding / cache-loading `images` (in this order) on worker threads; each image's
-    next detect_features() picks its result up.  Returns the cacheio.Prefetch (close() it)."""
+    next detect_features() picks its result up.  With `scale` (the argument detect_features()
+    is going to be called with) images without cache files are DETECTED on the workers as well
+    (kernels.DETECT_SLOTS at a time).  Returns the cacheio.Prefetch (close() it)."""
     todo = [im for im in images if getattr(im, 'image_file', None) or
             os.path.exists(getattr(im, 'features_file', '') or '')]
+    for im in todo:
+        im._iamx_prefetch_scale = scale
     pf = cacheio.Prefetch(_prefetch_job, todo, PREFETCH_DEPTH if depth is None else depth)
     for im in todo:
         im._iamx_prefetch = pf
@@ -423,8 +441,10 @@ def prefetch(images, depth=None):
 def detect_features(self, scale, use_cache=True):
     pf = getattr(self, '_iamx_prefetch', None)
     pre = pf.take(self) if pf is not None and pf.pending(self) else None
-    if use_cache and pre is not None and pre[0] in ('bgr', 'coef'):
+    if use_cache and pre is not None and pre[0] in ('bgr', 'coef', 'features'):
         use_cache = False          # the worker looked a moment ago: no cache files (stat() is not free)
+    if pre is not None and pre[0] == 'features' and pre[1] != float(scale):
+        pre = None                 # detected at another scale than the one asked for now: start over
     if use_cache:
         if pre is not None and pre[0] == 'cache':
             try:
@@ -448,7 +468,11 @@ def detect_features(self, scale, use_cache=True):
         _log("Detector", detector_node.getString('detector'),
              "is not on the MI355X path (SIFT only)")
         quit()
-    if pre is not None and pre[0] == 'bgr':
+    feats = None
+    if pre is not None and pre[0] == 'features':
+        feats, h, w = pre[2], pre[3], pre[4]
+        bgr = None
+    elif pre is not None and pre[0] == 'bgr':
         bgr = pre[1]
         if hasattr(bgr, 'record_stream'):
             import torch                # (allocated on a worker's stream, used on this one)
@@ -464,7 +488,8 @@ def detect_features(self, scale, use_cache=True):
                 bgr = kernels.jpeg_reconstruct(jc)
         if bgr is None:
             bgr = _decode_bgr(self.image_file, writable=False)
-    h, w = int(bgr.shape[0]), int(bgr.shape[1])
+    if feats is None:
+        h, w = int(bgr.shape[0]), int(bgr.shape[1])
     self.node.setInt('height', h)
     self.node.setInt('width', w)
     cam_w, cam_h = _deps.camera().get_image_params()
@@ -473,7 +498,9 @@ def detect_features(self, scale, use_cache=True):
              cam_w, cam_h, "cannot continue safely.")
         _log("Please track down and fix the camera config vs. image size issue.")
         quit()
-    self.kp_list, self.des_list, u8 = features_from_bgr(bgr, scale, equalize=True, keep_u8=True)
+    if feats is None:
+        feats = features_from_bgr(bgr, scale, equalize=True, keep_u8=True)
+    self.kp_list, self.des_list, u8 = feats
     self._iamx_des_u8 = (self.des_list, u8)
     self.num_features = len(self.kp_list)
     self.save_features()

@@ -1,5 +1,7 @@
 """Thin python bindings over the C ABI: torch tensors are device-buffer containers only,
 every number is produced by a hand-written HIP kernel in libiamx.so (csrc/*.hip)."""
+import threading
+
 import numpy as np
 import torch
 
@@ -600,6 +602,77 @@ _sift_ws = {}
 _sift_out = {}
 _prep_ws = {}
 
+# Detector slots: the workspace / output / staging caches above are keyed by (device, slot).  Slot 0
+# belongs to whoever calls without asking (one thread at a time, as before); worker threads that
+# detect concurrently take one of DETECT_SLOTS numbered slots each (image.py runs whole detections
+# on its prefetch workers): a slot is ~1 GB of workspace for a 3 MP detect image (8 of them keep the GPU fed), so the number of
+# detections in flight is bounded by the slots, not by the number of threads.
+DETECT_SLOTS = 8
+_slot_tls = threading.local()
+_slot_free = None
+_slot_lock = threading.Lock()
+
+
+def _slot_key(dev):
+    return (dev.index, getattr(_slot_tls, 'slot', 0))
+
+
+def wait_stream(polite=None):
+    """Wait for the current stream.  The HIP runtime spins on the host while it waits
+    (hipDeviceScheduleAuto: one core at 100 % per waiting thread, measured with
+    torch.cuda.Event(blocking=True) as well); a thread that holds a detector slot -- or says
+    polite=True -- polls an event with short sleeps instead: +0.2 ms of latency, no core burnt.
+    (Two dozen prefetch workers waiting for uploads and detections cost more CPU than the JPEG
+    Huffman decoding and the cache compression together on a host with a 16-core quota.)"""
+    if polite is None:
+        polite = getattr(_slot_tls, 'slot', 0) != 0 or getattr(_slot_tls, 'polite', False)
+    if not polite:
+        torch.cuda.current_stream().synchronize()
+        return
+    import time
+    ev = torch.cuda.Event()
+    ev.record()
+    pause = 0.0001
+    while not ev.query():
+        time.sleep(pause)
+        pause = min(pause * 1.5, 0.001)
+
+
+class polite_waits(object):
+    """with polite_waits(): waits of this thread inside the package's calls sleep instead of spin"""
+
+    def __enter__(self):
+        self.prev = getattr(_slot_tls, 'polite', False)
+        _slot_tls.polite = True
+        return self
+
+    def __exit__(self, *exc):
+        _slot_tls.polite = self.prev
+        return False
+
+
+class detector_slot(object):
+    """with detector_slot(): ... -- this thread's sift_detect / equalize_resize calls use a
+    private set of device buffers (blocks while all DETECT_SLOTS are taken)"""
+
+    def __enter__(self):
+        global _slot_free
+        with _slot_lock:
+            if _slot_free is None:
+                import queue
+                _slot_free = queue.Queue()
+                for k in range(1, DETECT_SLOTS + 1):
+                    _slot_free.put(k)
+        self.slot = _slot_free.get()
+        self.prev = getattr(_slot_tls, 'slot', 0)
+        _slot_tls.slot = self.slot
+        return self
+
+    def __exit__(self, *exc):
+        _slot_tls.slot = self.prev
+        _slot_free.put(self.slot)
+        return False
+
 
 class OverlappedSweeps(object):
     """Runs a sequence of PairBatch launches with the small threshold / compaction / finish
@@ -649,37 +722,40 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     else:
         h, w, ch = img.shape
     need = int(lib().iamx_sift_workspace_bytes(h, w))
-    ws = _sift_ws.get(dev.index)
+    ws = _sift_ws.get(_slot_key(dev))
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=U8, device=dev)
-        _sift_ws[dev.index] = ws
-    ob = _sift_out.get(dev.index)                  # (allocations cost ~0.3 ms each per frame)
+        _sift_ws[_slot_key(dev)] = ws
+    ob = _sift_out.get(_slot_key(dev))                  # (allocations cost ~0.3 ms each per frame)
     if ob is None or ob[0].shape[0] < cap:
         ob = (torch.empty((cap, 8), dtype=torch.float32, device=dev),
               torch.empty((cap, 128), dtype=U8, device=dev), torch.zeros(1, dtype=I32, device=dev))
-        _sift_out[dev.index] = ob
+        _sift_out[_slot_key(dev)] = ob
     kp, desc, n = ob[0][:cap], ob[1][:cap], ob[2]
     check(lib().iamx_sift_detect(_ptr(img), h, w, ch, contrast_threshold, edge_threshold, sigma,
                                  _ptr(ws), need, _ptr(kp), _ptr(desc), cap, _ptr(n), stream_ptr()),
           'iamx_sift_detect')
     # canonical (octave, layer, y, x, angle, desc[0]) order on the device (the kernels append in a
     # nondeterministic order): iamx_sift_sort, then one pinned download
-    sw = _sift_sort_ws.get(dev.index)
+    sw = _sift_sort_ws.get(_slot_key(dev))
     need_s = int(lib().iamx_sift_sort_workspace_bytes(cap))
     if sw is None or sw[0].numel() < need_s or sw[1].shape[0] < cap:
         sw = (torch.empty(need_s, dtype=U8, device=dev),
               torch.empty((cap, 8), dtype=torch.float32, device=dev),
               torch.empty((cap, 128), dtype=U8, device=dev))
-        _sift_sort_ws[dev.index] = sw
+        _sift_sort_ws[_slot_key(dev)] = sw
     check(lib().iamx_sift_sort(_ptr(kp), _ptr(desc), _ptr(n), cap, _ptr(sw[0]), need_s, _ptr(sw[1]),
                                _ptr(sw[2]), stream_ptr()), 'iamx_sift_sort')
-    cnt = int(n.item())
+    hn = _sift_pinned_count(dev)
+    hn.copy_(n, non_blocking=True)
+    wait_stream()
+    cnt = int(hn[0])
     if cnt > cap:
         raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (cnt, cap))
     hk, hd = _sift_pinned(dev, cnt)
     hk[:cnt].copy_(sw[1][:cnt], non_blocking=True)
     hd[:cnt].copy_(sw[2][:cnt], non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    wait_stream()
     k = hk[:cnt].numpy()
     return k[:, :5].copy(), k[:, 5].copy().view(np.int32), hd[:cnt].numpy().copy()
 
@@ -688,14 +764,21 @@ _sift_sort_ws = {}
 _sift_pin = {}
 
 
+def _sift_pinned_count(dev):
+    cur = _sift_pin.get((_slot_key(dev), 'n'))
+    if cur is None:
+        cur = _sift_pin[(_slot_key(dev), 'n')] = torch.zeros(1, dtype=I32).pin_memory()
+    return cur
+
+
 def _sift_pinned(dev, n):
     """page-locked staging for the keypoint / descriptor download (grown geometrically)"""
-    cur = _sift_pin.get(dev.index)
+    cur = _sift_pin.get(_slot_key(dev))
     if cur is None or cur[0].shape[0] < n:
         m = max(1 << 16, 1 << int(n - 1).bit_length())
         cur = (torch.empty((m, 8), dtype=torch.float32).pin_memory(),
                torch.empty((m, 128), dtype=U8).pin_memory())
-        _sift_pin[dev.index] = cur
+        _sift_pin[_slot_key(dev)] = cur
     return cur
 
 
@@ -771,16 +854,17 @@ def jpeg_reconstruct(jc, release=True):
     L = lib()
     info = jc.info
     w, h = int(info[0]), int(info[1])
+    # (the 384-byte table first: a pageable copy waits for what is in front of it on the stream)
+    d_quant = torch.from_numpy(jc.quant.astype(np.int16)).to(dev)        # (bit pattern; read as uint16)
     d_coef = torch.empty(jc.coef.shape, dtype=torch.int16, device=dev)
     d_coef.copy_(jc.coef, non_blocking=True)
-    d_quant = torch.from_numpy(jc.quant.astype(np.int16)).to(dev)        # (bit pattern; read as uint16)
     need = int(L.iamx_jpeg_workspace_bytes(info.ctypes.data_as(ctypes.c_void_p)))
     ws = torch.empty(need, dtype=U8, device=dev)
     out = torch.empty((h, w, 3), dtype=U8, device=dev)
     check(L.iamx_jpeg_reconstruct(_ptr(d_coef), _ptr(d_quant), info.ctypes.data_as(ctypes.c_void_p),
                                   _ptr(ws), need, _ptr(out), stream_ptr()), 'iamx_jpeg_reconstruct')
     if release:
-        torch.cuda.current_stream().synchronize()        # the page-locked buffer has been read
+        wait_stream()                                    # the page-locked buffer has been read
         jc.release()
     return out
 
@@ -804,9 +888,9 @@ def equalize_resize(bgr, scale, equalize=True, clip_limit=3.0):
     check(lib().iamx_image_resized_dims(h, w, float(scale), ctypes.byref(oh), ctypes.byref(ow)),
           'iamx_image_resized_dims')
     need = int(lib().iamx_image_prep_workspace_bytes(h, w))
-    ws = _prep_ws.get(dev.index)
+    ws = _prep_ws.get(_slot_key(dev))
     if ws is None or ws.numel() < need:
-        ws = _prep_ws[dev.index] = torch.empty(need, dtype=U8, device=dev)
+        ws = _prep_ws[_slot_key(dev)] = torch.empty(need, dtype=U8, device=dev)
     out = torch.empty((oh.value, ow.value, 3), dtype=U8, device=dev)
     check(lib().iamx_image_equalize_resize(_ptr(img), h, w, 1 if equalize else 0, float(clip_limit),
                                            float(scale), _ptr(ws), need, _ptr(out), stream_ptr()),

@@ -78,21 +78,28 @@ class KeyPointList(Sequence):
         return (list, (self.objects(),))
 
     # ---- the .feat file
-    def feat_bytes(self):
+    def feat_bytes(self, as_view=False):
+        """the .feat pickle (bytes; as_view: a memoryview of the buffer it was written into)"""
         if self._objs is not None:                       # the objects are the truth once they exist
             return pickle.dumps([(kp.pt, kp.size, kp.angle, kp.response, kp.octave, kp.class_id)
                                  for kp in self._objs])
         n = len(self)
         if n == 0:
             return _EMPTY
-        rec = np.empty(n, _REC)
-        for name, op in _OPS:
-            rec[name] = op
-        for name in _COLS:
-            rec[name] = getattr(self, name)
-        rec['octave'] = self.octave
-        rec['class_id'] = self.class_id
-        return _HEAD + rec.tobytes() + _TAIL
+        # (libiamx writes the records: numpy field assignments into the packed record type cost
+        #  11 ms per 50 k keypoints; head and tail go into the same buffer)
+        import ctypes
+        from . import _lib
+        h = len(_HEAD)
+        out = np.empty(h + n * _REC.itemsize + len(_TAIL), np.uint8)
+        out[:h] = np.frombuffer(_HEAD, np.uint8)
+        out[h + n * _REC.itemsize:] = np.frombuffer(_TAIL, np.uint8)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(_lib.lib().iamx_feat_records(p(self.x), p(self.y), p(self.size), p(self.angle),
+                                                p(self.response), p(self.octave), p(self.class_id), n,
+                                                ctypes.c_void_p(out.ctypes.data + h)),
+                   'iamx_feat_records')
+        return memoryview(out) if as_view else out.tobytes()
 
     @staticmethod
     def from_feat_bytes(blob):

@@ -1141,7 +1141,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         if not _have_features(im) and \
                 getattr(type(im), 'detect_features', None) is _image.detect_features:
             need.append(im)
-    prefetcher = _image.prefetch(need) if need else None
+    prefetcher = _image.prefetch(need, scale=detect_scale) if need else None
 
     rows = np.zeros(len(image_list), np.int64)           # descriptor rows of the images seen so far
     rows_known = np.zeros(len(image_list), bool)         # (reset by the periodic cache flush)

@@ -464,6 +464,26 @@ int64_t iamx_gzip_f32_from_u8_bound(int64_t n_header, int64_t n_values);
 int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header, const uint8_t *values,
                               int64_t n_values, uint8_t *out, int64_t out_cap);
 
+/* The other cache-file byte work of Image.save_features / save_descriptors / detect_features
+ * (scripts/lib/image.py:187-217, 324-346), HOST only, one call each so that no interpreter lock
+ * is held or handed around while the bytes are produced (threads are created inside):
+ *   iamx_gzip_members   gzip.open(..., compresslevel=level).write(...) as a multi-member gzip
+ *                       stream (members of <= member_bytes of input, compressed in parallel with
+ *                       zlib at `level`, `strategy` 0 default .. 4 fixed as in zlib.h); bufs / lens: the buffers that follow each other (an .npy header and
+ *                       the array's own memory, or one pickle).  Returns bytes written
+ *                       (out_cap >= iamx_gzip_members_bound(total, members)) or a negative code.
+ *   iamx_u8_to_f32      des_list = float32 of the detector's uint8 descriptors.
+ *   iamx_feat_records   the .feat pickle's records "( G x G y TUPLE2 G size G angle G response
+ *                       J octave J class_id t" (58 bytes per keypoint) from the columns. */
+int64_t iamx_gzip_members_bound(int64_t total_bytes, int64_t n_members);
+int64_t iamx_gzip_members(const uint8_t *const *bufs, const int64_t *lens, int n_bufs,
+                          int64_t member_bytes, int level, int strategy, int threads, uint8_t *out,
+                          int64_t out_cap);
+int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads);
+int iamx_feat_records(const float *x, const float *y, const float *size, const float *angle,
+                      const float *response, const int32_t *octave, const int32_t *class_id,
+                      int64_t n, uint8_t *out);
+
 /* ------------------------------------------------------------------------------------
  * K4: linear algebra on the device-resident block Jacobian (what SciPy's TRF/LSMR does on
  * the sparse matrix the reference gives it: scripts/lib/optimizer.py:491-501,

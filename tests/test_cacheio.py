@@ -242,3 +242,44 @@ def test_desc_file_from_uint8_is_the_reference_format(tmp_path):
         with gzip.open(str(path), 'rb') as fp:
             back = np.load(fp)
         assert back.dtype == np.float32 and np.array_equal(back, f32)
+
+
+def test_native_gzip_members_are_a_gzip_stream_of_the_buffers():
+    """iamx_gzip_members (one call, zlib on its own threads): any gzip reader gets the buffers back"""
+    rng = np.random.default_rng(5)
+    text = bytes(rng.integers(97, 105, 3_000_000, dtype=np.uint8))
+    arr = rng.integers(0, 4, (70000, 16)).astype(np.float32)
+    cases = [([text], 1 << 20), ([text[:10], memoryview(arr.reshape(-1).view(np.uint8))], 384 << 10),
+             ([b''], 1 << 20), ([b'x'], 1), ([text[:5000]], 4096), ([b'', text[:100], b''], 64)]
+    for bufs, mb in cases:
+        for level in (1, 6):
+            members = cacheio.gzip_member_list(bufs if len(bufs) > 1 else bufs[0], level, mb)
+            blob = b''.join(bytes(m) for m in members)
+            want = b''.join(bytes(memoryview(b).cast('B')) for b in bufs)
+            assert gzip.decompress(blob) == want
+            if len(want) > 100000:
+                assert len(blob) < len(want) // 2
+    # the python members (interpreter shutdown path) give the same payload
+    py = b''.join(cacheio._member(memoryview(text)[i:i + (1 << 20)], 6) for i in range(0, len(text), 1 << 20))
+    assert gzip.decompress(py) == text
+
+
+def test_native_float32_conversion_and_feat_records():
+    import pickle
+    from imageanalysis_amd.keypoints import KeyPointList
+    rng = np.random.default_rng(6)
+    for n in (0, 1, 77, 300000):
+        u8 = rng.integers(0, 256, (n, 128), dtype=np.uint8)
+        f = iimg._to_float32(u8)
+        assert f.dtype == np.float32 and f.shape == u8.shape and np.array_equal(f, u8.astype(np.float32))
+    n = 5000
+    cols = [rng.uniform(0, 5000, n), rng.uniform(0, 3000, n), rng.uniform(1, 40, n), rng.uniform(0, 360, n),
+            rng.uniform(0, 0.2, n)]
+    octv = rng.integers(-(1 << 20), 1 << 24, n).astype(np.int32)
+    kl = KeyPointList(*cols, octv)
+    f32 = [np.asarray(c, np.float64).astype(np.float32) for c in cols]
+    want = [((float(f32[0][i]), float(f32[1][i])), float(f32[2][i]), float(f32[3][i]), float(f32[4][i]),
+             int(octv[i]), -1) for i in range(n)]
+    blob = kl.feat_bytes()
+    assert isinstance(blob, bytes) and pickle.loads(blob) == want
+    assert bytes(kl.feat_bytes(as_view=True)) == blob

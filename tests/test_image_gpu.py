@@ -81,6 +81,58 @@ def test_detect_features_end_to_end(tmp_path):
         iimg.Image(str(an), 'T001').detect_features(0.5, use_cache=False)
 
 
+def test_detection_on_prefetch_workers_equals_the_serial_loop(tmp_path):
+    """prefetch(images, scale=...) runs whole detections on the worker threads, several at a
+    time in separate detector slots: keypoints, descriptors and cache files must be exactly what
+    one detect_features() after the other gives"""
+    from PIL import Image as PILImage
+    from imageanalysis_amd import cacheio, image as iimg
+    from imageanalysis_amd._deps import getNode
+    from imageanalysis_amd.hostlib import camera
+    proj = tmp_path / 'proj'
+    (proj / 'images').mkdir(parents=True)
+    getNode('/config/directories', True).setString('project_dir', str(proj))
+    getNode('/config/detector', True).setString('detector', 'SIFT')
+    camera.set_image_params(640, 480)
+    names = ['W%03d' % k for k in range(12)]
+    for k, name in enumerate(names):
+        rgb = texture(480, 640, 20 + k)[:, :, ::-1]
+        PILImage.fromarray(np.ascontiguousarray(rgb)).save(str(proj / 'images' / (name + '.JPG')), quality=93)
+
+    def project(tag):
+        an = proj / ('ImageAnalysis_' + tag)
+        (an / 'cache').mkdir(parents=True)
+        (an / 'meta').mkdir()
+        return [iimg.Image(str(an), n) for n in names]
+
+    serial = project('serial')
+    for im in serial:
+        im.detect_features(0.5)
+    workers = project('workers')
+    pf = iimg.prefetch(workers, depth=8, scale=0.5)
+    for im in workers:
+        im.detect_features(0.5)
+    pf.close()
+    cacheio.wait()
+    for a, b in zip(serial, workers):
+        assert len(a.kp_list) == len(b.kp_list) > 200
+        assert np.array_equal(a.des_list, b.des_list)
+        assert [k.pt for k in a.kp_list[:50]] == [k.pt for k in b.kp_list[:50]]
+        assert b.get_size() == (640, 480)
+        with gzip.open(b.desc_file, 'rb') as f:
+            assert np.array_equal(np.load(f), a.des_list)
+        with gzip.open(a.features_file, 'rb') as fa, gzip.open(b.features_file, 'rb') as fb:
+            assert fa.read() == fb.read()
+    # asked for at another scale than the workers were told: detected again, not reused
+    other = project('other')
+    pf = iimg.prefetch(other[:2], depth=2, scale=0.5)
+    other[0].detect_features(0.4)
+    pf.close()
+    ref = project('ref04')[0]
+    ref.detect_features(0.4)
+    assert len(other[0].kp_list) == len(ref.kp_list) and np.array_equal(other[0].des_list, ref.des_list)
+
+
 def test_full_chain_overlapping_views(tmp_path):
     """JPEG -> Image.detect_features -> matcher.bidirectional_pair_matches on two overlapping
     views of one scene, the second flown on the opposite heading (turned 180 deg): the chain

@@ -184,7 +184,7 @@ def test_config_size_pyramid_bit_equal_and_whole_frame():
     order = np.lexsort((d[:, 0], key[:, 3], key[:, 2], key[:, 1], key[:, 0]))
     assert np.array_equal(order, np.arange(len(kp)))
     import torch
-    ws = kernels._sift_ws[torch.cuda.current_device()]
+    ws = kernels._sift_ws[(torch.cuda.current_device(), 0)]
     gauss, dog = so.build_pyramids(gray)
     _lvl, n_oct = _device_level(gray.shape, ws, 0, 0, 0)
     assert n_oct == len(gauss) >= 10

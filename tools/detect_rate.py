@@ -61,7 +61,7 @@ def main():
     imgs = project('overlap')
     iimg.ASYNC_CACHE_WRITES = True
     t0 = time.perf_counter()
-    pf = iimg.prefetch(imgs)
+    pf = iimg.prefetch(imgs, scale=0.4)
     for im in imgs:
         im.detect_features(0.4)
     t_det = time.perf_counter() - t0
@@ -79,7 +79,7 @@ def main():
         import cProfile
         prof = cProfile.Profile()
     t0 = time.perf_counter()
-    pf = iimg.prefetch(imgs2)
+    pf = iimg.prefetch(imgs2, scale=0.4)
     if prof:
         prof.enable()
     for im in imgs2:
@@ -100,7 +100,7 @@ def main():
     for im in imgs:
         im.kp_list = im.des_list = None
     t0 = time.perf_counter()
-    pf = iimg.prefetch(imgs)
+    pf = iimg.prefetch(imgs, scale=0.4)
     for im in imgs:
         im.detect_features(0.4)
     tc = time.perf_counter() - t0
