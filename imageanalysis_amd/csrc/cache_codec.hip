@@ -437,3 +437,54 @@ extern "C" int iamx_feat_records(const float *x, const float *y, const float *si
     }
     return IAMX_OK;
 }
+
+// The pair lists of the .match pickles (Image.save_matches, scripts/lib/image.py:222-233: a dict
+// {other image: [[i, j], ...]}): list k = rows [off[k], off[k+1]) of `pairs` as the protocol-2
+// stream  ] ( { ] ( <int> i <int> j e }* e   (no memo entries; BININT2 'M' when every index of the
+// list fits 16 bits, else BININT 'J'), an empty list as  ] .  out_off[k] .. out_off[k+1] = the
+// bytes of list k in out (out_cap >= sum over lists of 3 + 13 rows).  Returns bytes written.
+extern "C" int64_t iamx_pickle_pair_lists(const int32_t *pairs, const int64_t *off, int64_t n_lists,
+                                          uint8_t *out, int64_t out_cap, int64_t *out_off)
+{
+    if (n_lists < 0 || (n_lists > 0 && (!off || !out || !out_off)))
+        return iamx::fail(IAMX_EINVAL, "iamx_pickle_pair_lists: null pointer");
+    uint8_t *p = out;
+    for (int64_t k = 0; k < n_lists; ++k) {
+        const int64_t a = off[k], b = off[k + 1];
+        out_off[k] = (int64_t)(p - out);
+        if (b < a || (b > a && !pairs)) return iamx::fail(IAMX_EINVAL, "iamx_pickle_pair_lists: bad offsets");
+        if ((int64_t)(p - out) + 3 + 13 * (b - a) > out_cap)
+            return iamx::fail(IAMX_EINVAL, "iamx_pickle_pair_lists: output buffer too small");
+        if (b == a) {
+            *p++ = ']';
+            continue;
+        }
+        bool narrow = true;
+        for (int64_t r = 2 * a; r < 2 * b; ++r) narrow &= (uint32_t)pairs[r] < 65536u;
+        *p++ = ']';
+        *p++ = '(';
+        if (narrow) {
+            for (int64_t r = a; r < b; ++r) {
+                const uint16_t i = (uint16_t)pairs[2 * r], j = (uint16_t)pairs[2 * r + 1];
+                p[0] = ']'; p[1] = '('; p[2] = 'M';
+                std::memcpy(p + 3, &i, 2);
+                p[5] = 'M';
+                std::memcpy(p + 6, &j, 2);
+                p[8] = 'e';
+                p += 9;
+            }
+        } else {
+            for (int64_t r = a; r < b; ++r) {
+                p[0] = ']'; p[1] = '('; p[2] = 'J';
+                std::memcpy(p + 3, &pairs[2 * r], 4);
+                p[7] = 'J';
+                std::memcpy(p + 8, &pairs[2 * r + 1], 4);
+                p[12] = 'e';
+                p += 13;
+            }
+        }
+        *p++ = 'e';
+    }
+    if (n_lists > 0) out_off[n_lists] = (int64_t)(p - out);
+    return (int64_t)(p - out);
+}

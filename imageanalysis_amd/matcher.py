@@ -1194,17 +1194,23 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         smart.begin_batch()
 
     backlog = []
+    # the .match bytes of the rounds' pair lists (what saveMatches will write) are made on ONE
+    # background thread, in libiamx without the interpreter lock (matchpairs.prepickle)
+    from concurrent.futures import ThreadPoolExecutor
+    from .matchpairs import prepickle
+    pickler = ThreadPoolExecutor(max_workers=1, thread_name_prefix='iamx-pickle')
+    pickling = []
 
     def drain(until=None):
-        """work the backlog off -- all of it, or while the event `until` has not happened yet"""
-        from .matchpairs import prepickle
+        """work the backlog off -- all of it, or while the event `until` has not happened yet;
+        all of it includes the pickles in flight"""
         while backlog and (until is None or not until.query()):
             kind, payload = backlog.pop(0)
-            if kind == 'smart':
-                smart.record_round(payload)
-                smart.materialize_pending()
-            else:
-                prepickle(payload)
+            smart.record_round(payload)
+            smart.materialize_pending()
+        if until is None:
+            while pickling:
+                pickling.pop(0).result()
 
     def book(part):
         """rank 0's (or this rank's own) bookkeeping of one rank's round"""
@@ -1298,8 +1304,9 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         if hits:
             lists = [dict.get(image_list[int(x)].match_list, image_list[int(y)].name)
                      for k_, _f, _r, _s in hits for x, y in ((pi[k_], pj[k_]), (pj[k_], pi[k_]))]
-            for c0 in range(0, len(lists), 512):
-                backlog.append(('pickle', lists[c0:c0 + 512]))
+            pickling.append(pickler.submit(prepickle, lists))
+            while len(pickling) > 64 and pickling[0].done():
+                pickling.pop(0).result()
         # what every image's LAST pair so far was, quiet or not (the parts of several ranks do
         # not arrive in seq order: the newest seq wins)
         # (seq ascends inside a part: with repeated indices the LAST assignment stays)
@@ -1385,9 +1392,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         # (quiet pairs dirty both images' match lists, like the reference's assignments)
         for k in np.nonzero(last_seq >= 0)[0].tolist():
             image_list[k].matches_clean = False
+        # (smart.json -- millions of per-pair leaves -- is encoded beside the .match writers)
+        smart_saved = pickler.submit(smart.save, proj.analysis_dir) if smart is not None else None
         saveMatches(proj.image_list)
-        if smart is not None:
-            smart.save(proj.analysis_dir)
+        if smart_saved is not None:
+            smart_saved.result()
+    pickler.shutdown(wait=True)
     print('Pair-wise matches successfully saved.')
 
 
@@ -1411,10 +1421,17 @@ def _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value):
 
 
 def saveMatches(image_list, check_if_dirty=False):
+    """matcher.py:1046-1055.  The files of a survey are a gigabyte of pair lists: a few writer
+    threads (the file writes release the interpreter lock) when the images are ours; any other
+    image class is saved one after the other like the reference does."""
     _log('saving matches and image meta data ...')
-    for image in image_list:
-        if check_if_dirty:
-            if not image.matches_clean:
-                image.save_matches()
-        else:
-            image.save_matches()
+    todo = [image for image in image_list if not (check_if_dirty and image.matches_clean)]
+    from . import image as _image
+    ours = all(getattr(type(im), 'save_matches', None) is _image.save_matches for im in todo)
+    if ours and len(todo) >= 64:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4, thread_name_prefix='iamx-match') as pool:
+            list(pool.map(lambda im: im.save_matches(), todo))
+        return
+    for image in todo:
+        image.save_matches()

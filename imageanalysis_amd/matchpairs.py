@@ -32,10 +32,12 @@ class MatchPairs(MutableSequence):
             self._l = [list(p) for p in pairs]
 
     def pickled(self):
-        """bytes of this list inside a .match pickle (cached while the pairs are untouched)"""
-        if self._pk is None or self._a is None:
+        """bytes of this list inside a .match pickle (cached while the pairs are untouched: the
+        cache entry names the array it was made from, prepickle() fills it in from another thread)"""
+        pk = self._pk
+        if pk is None or self._a is None or pk[0] is not self._a:
             return _pairs_bytes(self.array())
-        return self._pk
+        return pk[1]
 
     # ---- the two representations
     def array(self):
@@ -140,33 +142,36 @@ def _pairs_bytes(a):
 
 def prepickle(match_lists):
     """fill in the cached .match bytes of several MatchPairs with one pass (find_matches: the
-    hits of a round, while the GPU works on the next one)"""
-    todo = [m for m in match_lists if isinstance(m, MatchPairs) and m._a is not None and m._pk is None]
-    for m, b in zip(todo, _pairs_bytes_many([m._a for m in todo])):
-        m._pk = b
+    hits of a round, while the GPU works on the next one; safe to run on another thread)"""
+    todo = [(m, m._a) for m in match_lists if isinstance(m, MatchPairs) and m._a is not None and m._pk is None]
+    for (m, a), b in zip(todo, _pairs_bytes_many([a for _m, a in todo])):
+        m._pk = (a, b)
 
 
 def _pairs_bytes_many(arrays):
-    """_pairs_bytes() of several [n, 2] arrays with ONE record array for all of them (an image
-    has ~100 partners with ~200 matches each: the numpy calls, not the bytes, are the cost)"""
-    lens = [len(a) for a in arrays]
-    total = sum(lens)
-    if total == 0:
-        return [b']'] * len(arrays)
-    cat = np.concatenate([a for a in arrays if len(a)])
-    op, dt = _int_opcode(int(cat.max()), int(cat.min()))
-    rec = np.empty(total, np.dtype([('h', 'S3'), ('i', dt), ('m', 'S1'), ('j', dt), ('t', 'S1')]))
-    rec['h'] = b'](' + op
-    rec['i'] = cat[:, 0]
-    rec['m'] = op
-    rec['j'] = cat[:, 1]
-    rec['t'] = b'e'
-    raw, size = rec.tobytes(), rec.itemsize
-    out, off = [], 0
-    for n in lens:
-        out.append(b'](' + raw[off * size:(off + n) * size] + b'e' if n else b']')
-        off += n
-    return out
+    """_pairs_bytes() of several int32 [n, 2] arrays in one call into libiamx (an image has ~100
+    partners with ~200 matches each: the numpy calls, not the bytes, were the cost): memoryviews
+    into ONE buffer"""
+    import ctypes
+    from . import _lib
+    if not arrays:
+        return []
+    lens = np.fromiter((len(a) for a in arrays), np.int64, len(arrays))
+    off = np.zeros(len(arrays) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    total = int(off[-1])
+    full = [np.ascontiguousarray(a, np.int32).reshape(-1, 2) for a in arrays if len(a)]
+    cat = np.concatenate(full) if len(full) > 1 else (full[0] if full else np.zeros((0, 2), np.int32))
+    cap = 3 * len(arrays) + 13 * total
+    out = np.empty(cap, np.uint8)
+    out_off = np.zeros(len(arrays) + 1, np.int64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    n = _lib.lib().iamx_pickle_pair_lists(p(cat), p(off), len(arrays), p(out), cap, p(out_off))
+    if n < 0:
+        _lib.check(int(n), 'iamx_pickle_pair_lists')
+    view = memoryview(out)
+    oo = out_off.tolist()
+    return [view[oo[k]:oo[k + 1]] for k in range(len(arrays))]
 
 
 _key_bytes = {}         # image name -> its BINUNICODE record (every image lists every partner)
@@ -312,8 +317,9 @@ class MatchDict(dict):
         direct = sorted((s, k) for k, s in self._seq.items())
         cut = np.searchsorted(seq, np.array([s for s, _k in direct], np.int64)).tolist() if direct else []
         values = [dict.__getitem__(self, name) for _s, name in direct]
-        arr_bytes = {t: v._pk for t, v in enumerate(values)
-                     if isinstance(v, MatchPairs) and v._pk is not None and v._a is not None}
+        arr_bytes = {t: v._pk[1] for t, v in enumerate(values)
+                     if isinstance(v, MatchPairs) and v._pk is not None and v._a is not None
+                     and v._pk[0] is v._a}
         arr_at = [t for t, v in enumerate(values) if isinstance(v, MatchPairs) and t not in arr_bytes]
         arr_bytes.update(zip(arr_at, _pairs_bytes_many([values[t].array() for t in arr_at])))
         out, prev = [], 0
@@ -377,6 +383,12 @@ EMPTY = _Empty()
 def dumps_match_dict(match_list):
     """bytes of the `.match` file of {name: MatchPairs | list}; values that are not MatchPairs
     (or hold anything but integer pairs) go through pickle itself."""
+    return b''.join(_match_dict_pieces(match_list))
+
+
+def _match_dict_pieces(match_list):
+    """... as the list of byte pieces that follow each other (the file writer hands them to
+    writelines(): the pair lists of a survey are a gigabyte that need not be joined first)"""
     out = [b'\x80\x02}']
     if match_list:
         out.append(b'(')
@@ -392,7 +404,7 @@ def dumps_match_dict(match_list):
             items = match_list.items()
         for name, pairs in items:
             if not isinstance(name, str):
-                return pickle.dumps(dict(match_list))
+                return [pickle.dumps(dict(match_list))]
             out.append(_key_record(name))
             if isinstance(pairs, MatchPairs):
                 out.append(pairs.pickled())
@@ -406,8 +418,8 @@ def dumps_match_dict(match_list):
                 out.append(body[2:-1])
         out.append(b'u')
     out.append(b'.')
-    return b''.join(out)
+    return out
 
 
 def dump_match_dict(match_list, fp):
-    fp.write(dumps_match_dict(match_list))
+    fp.writelines(_match_dict_pieces(match_list))

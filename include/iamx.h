@@ -483,6 +483,12 @@ int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads);
 int iamx_feat_records(const float *x, const float *y, const float *size, const float *angle,
                       const float *response, const int32_t *octave, const int32_t *class_id,
                       int64_t n, uint8_t *out);
+/* The pair lists of the .match pickles (Image.save_matches, scripts/lib/image.py:222-233): list k =
+ * rows [off[k], off[k+1]) of pairs [.][2] as the protocol-2 stream "] ( { ] ( int int e }* e" (no
+ * memo entries), an empty list as "]"; out_off [n_lists + 1] receives where each list's bytes start
+ * (out_cap >= sum of 3 + 13 * rows).  HOST only.  Returns bytes written or a negative code. */
+int64_t iamx_pickle_pair_lists(const int32_t *pairs, const int64_t *off, int64_t n_lists, uint8_t *out,
+                               int64_t out_cap, int64_t *out_off);
 
 /* ------------------------------------------------------------------------------------
  * K4: linear algebra on the device-resident block Jacobian (what SciPy's TRF/LSMR does on

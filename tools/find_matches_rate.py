@@ -119,10 +119,35 @@ def main():
             proj.image_list.append(im)
     print('project built in %.1f s' % (time.time() - t0))
 
+    for a in sys.argv:
+        if a.startswith('--ppb='):
+            matcher.PAIRS_PER_BATCH = int(a[6:])
     matcher.configure()
     K = camera.get_K()
     torch.cuda.synchronize()
     prof = cProfile.Profile() if '--profile' in sys.argv else None
+    # phases of the call: set-up until the first launch, the rounds, the final save
+    marks = {}
+    from imageanalysis_amd import smart as _smart
+    orig_launch, orig_save, orig_ssave = matcher._launch_batch, matcher.saveMatches, _smart.save
+
+    def launch(*a, **k):
+        marks.setdefault('first launch', time.perf_counter())
+        marks['launches'] = marks.get('launches', 0) + 1
+        return orig_launch(*a, **k)
+
+    def save(*a, **k):
+        marks['rounds done'] = time.perf_counter()
+        r = orig_save(*a, **k)
+        marks['matches saved'] = time.perf_counter()
+        return r
+
+    def ssave(*a, **k):
+        r = orig_ssave(*a, **k)
+        marks['smart saved'] = time.perf_counter()
+        return r
+    matcher._launch_batch, matcher.saveMatches, _smart.save = launch, save, ssave
+    c0 = os.times()
     t0 = time.perf_counter()
     if prof:
         prof.enable()
@@ -130,6 +155,17 @@ def main():
     if prof:
         prof.disable()
     dt = time.perf_counter() - t0
+    c1 = os.times()
+    seq = [('first launch', t0)] + [(k, marks[k]) for k in ('first launch', 'rounds done', 'matches saved', 'smart saved') if k in marks]
+    print('phases: ' + ', '.join('%s +%.2f s' % (seq[i][0], seq[i][1] - seq[i - 1][1]) for i in range(1, len(seq)))
+          + '; end +%.2f s; %d launches' % (t0 + dt - seq[-1][1], marks.get('launches', 0)))
+    print('process CPU during find_matches: user %.1f s, system %.1f s in %.2f s wall'
+          % (c1.user - c0.user, c1.system - c0.system, dt))
+    try:
+        from threadpoolctl import threadpool_info
+        print('thread pools:', [(d.get('internal_api'), d.get('num_threads')) for d in threadpool_info()])
+    except Exception as e:                                  # noqa: BLE001
+        print('threadpoolctl:', e)
     n_pairs = n_img * (n_img - 1) // 2
     linked = sum(len(v) > 0 for im in proj.image_list for v in im.match_list.values()) // 2
     total = sum(len(v) for im in proj.image_list for v in im.match_list.values()) // 2
