@@ -1079,6 +1079,7 @@ def sift_cpu_baseline():
     (oracle/sift_ref.c, the parity oracle of the kernels) on the bench's own detect image, all
     host cores, for ~10 s."""
     from oracle import cpu_ref, sift_oracle
+    cpu_ref.set_num_threads(cpu_ref.host_cores())      # (a cgroup quota, not the 256 threads the box shows)
     gray = sift_oracle.bgr_to_gray(_SIFT_SAMPLE)
     cpu_ref.sift_detect(gray)                                # warm (thread pool, page faults)
     n, t0 = 0, time.perf_counter()
@@ -1106,6 +1107,7 @@ def ba_cpu_baseline():
     from scipy.sparse import csr_matrix
     from oracle import cpu_ref
     from imageanalysis_amd import synth
+    cpu_ref.set_num_threads(cpu_ref.host_cores())
     p = synth.make_ba_problem(rows=10, cols=30, n_points=32000, n_obs=195000)
     C, P, O = len(p['cams0']), len(p['pts0']), len(p['cam_idx'])
     K = p['K']
@@ -1151,7 +1153,7 @@ def cpu_baseline(sample_images):
     imgs = rng.integers(0, 256, (n_img, KPTS, DIM), dtype=np.uint8)
     if sample_images is not None:
         imgs[:len(sample_images)] = sample_images
-    threads = cpu_ref.num_threads()
+    threads = cpu_ref.set_num_threads(cpu_ref.host_cores())
     unordered = [(i, j) for i in range(n_img) for j in range(i + 1, n_img)]       # 120 pairs
     ordered = np.array(unordered + [(j, i) for i, j in unordered], np.int32)
     simd = cpu_ref.knn2_simd_available()

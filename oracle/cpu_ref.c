@@ -78,6 +78,16 @@ int oracle_knn2_l2_u8_batch(const uint8_t *images, int n_rows, const int32_t *pa
     return 0;
 }
 
+/* (a container's CPU quota is not what omp_get_max_threads() reports: the caller sets it) */
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

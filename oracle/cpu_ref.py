@@ -109,6 +109,37 @@ def num_threads():
     return lib().oracle_num_threads()
 
 
+def host_cores():
+    """cores this process may really use: the CPU affinity mask and the cgroup quota (cpu.max),
+    not the number of hardware threads the machine shows"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        p = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0 and p > 0:
+            n = min(n, max(1, q // p))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_num_threads(n):
+    """OpenMP threads of the oracle's loops from now on (bench.py: host_cores())"""
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+    return num_threads()
+
+
 # ---- oracle/sift_ref.c: the hot loops of sift_oracle.py
 def sift_blur(img, taps, nthreads=0):
     img = np.ascontiguousarray(img, np.float32)

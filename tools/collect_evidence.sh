@@ -19,17 +19,6 @@ step "gpu tests"
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
 tail -n 3 "$OUT/${TAG}_gpu_tests.txt"
 
-step "bench"
-timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
-tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
-
-step "kernel stats of the bench command"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
-    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
-$SUM /tmp/p_stats "$OUT/${TAG}_kernel_stats.txt" > /dev/null
-python "$REPO/tools/prof_gaps.py" /tmp/p_stats lsmr > "$OUT/${TAG}_lsmr_gaps.txt" 2>&1
-head -8 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-160
-
 step "PMC: HBM traffic of the matching step (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err)
@@ -54,6 +43,24 @@ $SUM /tmp/p_in "$OUT/${TAG}_knn2sym_pmc_insts.txt" > /dev/null
     SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d /tmp/p_wt -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_wt.err)
 $SUM /tmp/p_wt "$OUT/${TAG}_knn2sym_pmc_wait.txt" > /dev/null
 head -12 "$OUT/${TAG}_knn2sym_pmc_sq.txt" | cut -c1-140
+
+step "traffic summaries -> profiles/ (what bench.py quotes)"
+for f in knn2sym_pmc_fetch knn2sym_pmc_write knn2sym_pmc_sq aux_pmc_fetch aux_pmc_write; do
+    cp "$OUT/${TAG}_$f.txt" "$REPO/profiles/${TAG}_$f.txt"
+done
+python "$REPO/tools/update_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_knn2sym_traffic.json" "$OUT/"
+python "$REPO/tools/aux_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_ba_sift_traffic.json" "$OUT/"
+
+step "bench"
+timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
+tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
+
+step "kernel stats of the bench command"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
+    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
+$SUM /tmp/p_stats "$OUT/${TAG}_kernel_stats.txt" > /dev/null
+python "$REPO/tools/prof_gaps.py" /tmp/p_stats lsmr > "$OUT/${TAG}_lsmr_gaps.txt" 2>&1
+head -8 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-160
 
 step "SIFT kernel stats"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_sift -o s -- \
