@@ -15,6 +15,7 @@ AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baselin
 
 step() { echo "== $1 ($(date +%T))"; }
 
+if [ "${STAGE:-AB}" != "B" ]; then
 step "gpu tests"
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
 tail -n 3 "$OUT/${TAG}_gpu_tests.txt"
@@ -36,12 +37,6 @@ step "PMC: SQ / MFMA busy"
     SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
     --output-format csv -d /tmp/p_sq -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_sq.err)
 $SUM /tmp/p_sq "$OUT/${TAG}_knn2sym_pmc_sq.txt" > /dev/null
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM \
-    SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --output-format csv -d /tmp/p_in -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_in.err)
-$SUM /tmp/p_in "$OUT/${TAG}_knn2sym_pmc_insts.txt" > /dev/null
-(cd /tmp && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-    SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d /tmp/p_wt -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_wt.err)
-$SUM /tmp/p_wt "$OUT/${TAG}_knn2sym_pmc_wait.txt" > /dev/null
 head -12 "$OUT/${TAG}_knn2sym_pmc_sq.txt" | cut -c1-140
 
 step "traffic summaries -> profiles/ (what bench.py quotes)"
@@ -55,6 +50,8 @@ step "bench"
 timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
 tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
 
+fi
+if [ "${STAGE:-AB}" != "A" ]; then
 step "kernel stats of the bench command"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
     python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
@@ -70,7 +67,7 @@ $SUM /tmp/p_sift "$OUT/${TAG}_sift_kernel_stats.txt" > /dev/null
 if [ -z "$NO_ENTRY" ]; then
 step "entry points"
 timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_dense.txt"
-timeout 600 python tools/find_matches_rate.py 40 40 1024 > "$OUT/${TAG}_fm_sparse.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_sparse.txt"
 timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
+fi
 fi
 step "done"
