@@ -103,6 +103,8 @@ def main():
     ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
     ap.add_argument('--ba-iters', type=int, default=0,
                     help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
+    ap.add_argument('--no-sift-full', action='store_true',
+                    help='SIFT section without the scale 1.0 (20 MP) detects (counter passes: every detect the same size)')
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the configs[4] slice (24 rendered 20 MP frames through the drop-in chain)')
     ap.add_argument('--e2e', type=int, default=0, metavar='N',
@@ -832,6 +834,8 @@ def sift_bench(rank, world, dev, dist, args):
     # SURVEY.md 8d also asks for scale = 1.0 (the full 20 MP frame)
     full = None
     try:
+        if args.no_sift_full:
+            raise RuntimeError("skipped (--no-sift-full)")
         kernels.sift_detect(imgs[0], cap=1500000)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -31,7 +31,7 @@ def test_two_rank_bench_verifies_pairs_across_ranks():
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['unresolved'] == 0
-    assert d['verified_pairs'] == 6 and d['verify']['survivors_checked'] > 1000
+    assert d['verified_pairs'] == 64 and d['verify']['survivors_checked'] > 1000
     assert d['config']['pairs_per_step'] == 64 * 63 // 2
     # 30 % of every image is a noisy copy of its predecessor: ~860 survivors per adjacent pair and direction
     assert d['survivors_per_step'] > 63 * 2 * 700 and d['candidates_per_step'] >= d['survivors_per_step']

@@ -54,7 +54,7 @@ sift_total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in kernels
                  if k.split('<')[0] in SIFT)
 doc = {"source": "profiles/%s_aux_pmc_fetch.txt, profiles/%s_aux_pmc_write.txt (separate rocprofv3 --pmc "
                  "passes of bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 "
-                 "--no-e2e)" % (tag, tag),
+                 "--no-e2e --no-sift-full)" % (tag, tag),
        "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
        "kernels": kernels,
        "sift": {"frames": frames, "hbm_bytes_per_frame": int(sift_total / max(frames, 1))}}

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 SUM="python $REPO/tools/prof_summary.py"
 BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e"
 # BA + SIFT kernels (a small matching section in front of them)
-AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e"
+AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e --no-sift-full"
 
 step() { echo "== $1 ($(date +%T))"; }
 

@@ -34,6 +34,8 @@ d['kernel'] = re.sub(r'^kernel (void )?\(anonymous namespace\)::', '', kname).sp
 d['FETCH_SIZE_avg_per_launch_KB'] = round(fetch)
 d['WRITE_SIZE_avg_per_launch_KB'] = round(write)
 d['hbm_bytes_per_launch'] = int(round(fetch) * 1024 * 2 + round(write) * 1024)
+d['source'] = ('profiles/%s_knn2sym_pmc_fetch.txt, profiles/%s_knn2sym_pmc_write.txt (separate rocprofv3 --pmc passes of '
+               'bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e)' % (tag, tag))
 d['mfma_busy'] = round(busy / (gui / 8 * 1024), 4)
 d['mfma_busy_source'] = ('profiles/%s_knn2sym_pmc_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES %.4g / (GRBM_GUI_ACTIVE '
                          '%.4g / 8 XCDs x 1024 SIMDs), the same 500-image bench command; the pipe executes '
