@@ -149,17 +149,37 @@ class DeviceMatcher(object):
         import torch
         from . import _lib
         n = len(self._counts)
-        if self._kp_dev is None or self._kp_dev[0] != n:
+        cur = self._kp_dev
+        if cur is None or cur[0] != n:
+            # only the NEW slots go up (one concatenation, one copy each), into arenas that grow
+            # geometrically: find_matches meets a few new images in every round of its first
+            # stretch, and re-uploading every keypoint of every image each time was O(images^2)
             dev = _lib.require_gpu()
-            cnt = [len(self._kp[s][0]) for s in range(n)]
-            off = np.zeros(n + 1, np.int64)
-            np.cumsum(cnt, out=off[1:])
-            xy = np.concatenate([self._kp[s][0] for s in range(n)] + [np.zeros((0, 2), np.float32)])
-            k2 = np.concatenate([self._kp[s][1] for s in range(n)] + [np.zeros((0, 2), np.int32)])
-            self._kp_dev = (n, torch.from_numpy(off[:-1].copy()).to(dev),
-                            torch.from_numpy(np.ascontiguousarray(xy, np.float32)).to(dev),
-                            torch.from_numpy(np.ascontiguousarray(k2, np.int32)).to(dev))
-        return self._kp_dev[1:]
+            n0 = cur[0] if cur is not None else 0
+            rows0 = cur[4] if cur is not None else 0
+            cnt = [len(self._kp[s][0]) for s in range(n0, n)]
+            off = rows0 + np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            rows = int(off[-1])
+            if cur is None or cur[1].shape[0] < n or cur[2].shape[0] < rows:
+                cap_n = max(n, 2 * (cur[1].shape[0] if cur is not None else 0), 64)
+                cap_r = max(rows, 2 * (cur[2].shape[0] if cur is not None else 0), 1 << 16)
+                d_off = torch.zeros(cap_n, dtype=torch.int64, device=dev)
+                d_xy = torch.empty((cap_r, 2), dtype=torch.float32, device=dev)
+                d_k2 = torch.empty((cap_r, 2), dtype=torch.int32, device=dev)
+                if cur is not None:
+                    d_off[:n0].copy_(cur[1][:n0])
+                    d_xy[:rows0].copy_(cur[2][:rows0])
+                    d_k2[:rows0].copy_(cur[3][:rows0])
+            else:
+                d_off, d_xy, d_k2 = cur[1], cur[2], cur[3]
+            if n > n0:
+                xy = np.concatenate([self._kp[s][0] for s in range(n0, n)] + [np.zeros((0, 2), np.float32)])
+                k2 = np.concatenate([self._kp[s][1] for s in range(n0, n)] + [np.zeros((0, 2), np.int32)])
+                d_off[n0:n].copy_(torch.from_numpy(off[:-1].copy()))
+                d_xy[rows0:rows].copy_(torch.from_numpy(np.ascontiguousarray(xy, np.float32)))
+                d_k2[rows0:rows].copy_(torch.from_numpy(np.ascontiguousarray(k2, np.int32)))
+            self._kp_dev = (n, d_off, d_xy, d_k2, rows)
+        return self._kp_dev[1:4]
 
     def store(self):
         """(Re)build the arena when new images arrived; old rows are copied on the device."""
@@ -838,18 +858,31 @@ def _finish_batch_arrays(h):
                                                                aff[:, 0]), 1).tolist()
                 yv_r = np.stack(_smart.yaw_errors_from_affines(ned[b_idx], air_yaw[b_idx], ned[a_idx],
                                                                aff[:, 1]), 1).tolist()
+            # the round's pair rows, forward and reversed, as TWO arrays the match lists are views
+            # of (the download is a pinned buffer the next round reuses: copied once); a batch that
+            # did not fit the packed download copies pair by pair
+            off_h = hs['off'].numpy()
+            packed = int(off_h[n]) <= hs['cap']
+            if packed:
+                fwd_all = hs['pk_pairs'].numpy()[:int(off_h[n])].copy()
+                rev_all = np.ascontiguousarray(fwd_all[:, ::-1])
+                lo = off_h[dev_rows].tolist()
+                hi = (off_h[dev_rows] + c).tolist()
             for t, k in enumerate(dev_rows.tolist()):
-                ck = int(c[t])
-                both = np.empty((2, ck, 2), np.int32)          # (the download is a pinned buffer the
-                both[0] = lists(k)                             #  next round reuses: copied once)
-                both[1] = both[0, :, ::-1]
+                if packed:
+                    both = (fwd_all[lo[t]:hi[t]], rev_all[lo[t]:hi[t]])
+                else:
+                    ck = int(c[t])
+                    both = np.empty((2, ck, 2), np.int32)
+                    both[0] = lists(k)
+                    both[1] = both[0, :, ::-1]
                 surf = None
                 if surface:
                     surf = _NO_SURFACE if same[t] else (
                         -float(mean[t]), float(std[t]), float(dist[t]), None, None,
                         tuple(yv_f[t]) if aff_ok[t, 0] else None,
                         tuple(yv_r[t]) if aff_ok[t, 1] else None)
-                R.hits.append((k, MatchPairs(both[0]), MatchPairs(both[1]), surf))
+                R.hits.append((k, MatchPairs.of_array(both[0]), MatchPairs.of_array(both[1]), surf))
         host_rows = np.nonzero(status != 0)[0]
         if len(host_rows):
             # pairs the device filters handed back (more candidates than their buffers hold):
@@ -1142,6 +1175,19 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 getattr(type(im), 'detect_features', None) is _image.detect_features:
             need.append(im)
     prefetcher = _image.prefetch(need, scale=detect_scale) if need else None
+    # The images whose features are in memory already go to the device in ONE step (descriptor
+    # arena, keypoint arena): the first rounds of a distance-sorted schedule meet ~35 new images
+    # each, and growing the arenas image by image rebuilt and re-synchronised them every round
+    # (the device idled through the first ~70 rounds of a 2812-image survey: r3_fm_timeline)
+    if isinstance(the_matcher, DeviceMatcher) and early_failure is None:
+        ready = [image_list[k] for k in np.unique(mine_imgs).tolist()
+                 if image_list[k].des_list is not None and image_list[k].kp_list is not None
+                 and len(getattr(image_list[k].des_list, 'shape', ())) == 2 and len(image_list[k].des_list) > 1]
+        if len(ready) > 1:
+            for im in ready:
+                the_matcher.slot_of(im)
+            the_matcher.store()
+            the_matcher.keypoints()
 
     rows = np.zeros(len(image_list), np.int64)           # descriptor rows of the images seen so far
     rows_known = np.zeros(len(image_list), bool)         # (reset by the periodic cache flush)
@@ -1392,11 +1438,9 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         # (quiet pairs dirty both images' match lists, like the reference's assignments)
         for k in np.nonzero(last_seq >= 0)[0].tolist():
             image_list[k].matches_clean = False
-        # (smart.json -- millions of per-pair leaves -- is encoded beside the .match writers)
-        smart_saved = pickler.submit(smart.save, proj.analysis_dir) if smart is not None else None
         saveMatches(proj.image_list)
-        if smart_saved is not None:
-            smart_saved.result()
+        if smart is not None:
+            smart.save(proj.analysis_dir)
     pickler.shutdown(wait=True)
     print('Pair-wise matches successfully saved.')
 
@@ -1421,17 +1465,12 @@ def _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value):
 
 
 def saveMatches(image_list, check_if_dirty=False):
-    """matcher.py:1046-1055.  The files of a survey are a gigabyte of pair lists: a few writer
-    threads (the file writes release the interpreter lock) when the images are ours; any other
-    image class is saved one after the other like the reference does."""
+    # (writer threads and a concurrent smart.save were measured on the 2812-image survey: the
+    #  interpreter lock makes four writers take twice as long as one)
     _log('saving matches and image meta data ...')
-    todo = [image for image in image_list if not (check_if_dirty and image.matches_clean)]
-    from . import image as _image
-    ours = all(getattr(type(im), 'save_matches', None) is _image.save_matches for im in todo)
-    if ours and len(todo) >= 64:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=4, thread_name_prefix='iamx-match') as pool:
-            list(pool.map(lambda im: im.save_matches(), todo))
-        return
-    for image in todo:
-        image.save_matches()
+    for image in image_list:
+        if check_if_dirty:
+            if not image.matches_clean:
+                image.save_matches()
+        else:
+            image.save_matches()

@@ -31,6 +31,14 @@ class MatchPairs(MutableSequence):
             self._a = None
             self._l = [list(p) for p in pairs]
 
+    @classmethod
+    def of_array(cls, a):
+        """a contiguous int32 [n, 2] array as it is (no checks, no copy: find_matches makes two
+        of these per image pair with matches)"""
+        m = object.__new__(cls)
+        m._a, m._l, m._pk = a, None, None
+        return m
+
     def pickled(self):
         """bytes of this list inside a .match pickle (cached while the pairs are untouched: the
         cache entry names the array it was made from, prepickle() fills it in from another thread)"""
@@ -422,4 +430,4 @@ def _match_dict_pieces(match_list):
 
 
 def dump_match_dict(match_list, fp):
-    fp.writelines(_match_dict_pieces(match_list))
+    fp.write(dumps_match_dict(match_list))
