@@ -799,6 +799,38 @@ class _RoundResult(object):
     __slots__ = ('n', 'n_fwd', 'n_rev', 'cc', 'quiet', 'hits')
 
 
+class _LazyHits(object):
+    """the pairs WITH matches of a round -- [(k, fwd, rev, surf)] as _finish_batch_arrays()
+    documents them -- made on access from the round's arrays (len(), indexing, slicing,
+    iteration)"""
+    __slots__ = ('rows', 'fwd', 'rev', 'lo', 'hi', 'surf')
+
+    def __init__(self, rows, fwd, rev, lo, hi, surf):
+        self.rows, self.fwd, self.rev, self.lo, self.hi, self.surf = rows, fwd, rev, lo, hi, surf
+
+    def __len__(self):
+        return len(self.rows)
+
+    def _one(self, t):
+        a, b = self.lo[t], self.hi[t]
+        surf = None
+        if self.surf is not None:
+            same, mean, std, dist, yv_f, yv_r, aff_ok = self.surf
+            surf = _NO_SURFACE if same[t] else (
+                -float(mean[t]), float(std[t]), float(dist[t]), None, None,
+                tuple(yv_f[t]) if aff_ok[t, 0] else None,
+                tuple(yv_r[t]) if aff_ok[t, 1] else None)
+        return (self.rows[t], MatchPairs.of_array(self.fwd[a:b]), MatchPairs.of_array(self.rev[a:b]), surf)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self._one(t) for t in range(*k.indices(len(self.rows)))]
+        return self._one(k if k >= 0 else k + len(self.rows))
+
+    def __iter__(self):
+        return (self._one(t) for t in range(len(self.rows)))
+
+
 def _finish_batch_arrays(h):
     """_finish_batch() for find_matches: the same wait and the same results, but only the pairs
     that HAVE matches become python objects -- on an all-pairs schedule 95-99 % of the pairs end
@@ -868,14 +900,17 @@ def _finish_batch_arrays(h):
                 rev_all = np.ascontiguousarray(fwd_all[:, ::-1])
                 lo = off_h[dev_rows].tolist()
                 hi = (off_h[dev_rows] + c).tolist()
-            for t, k in enumerate(dev_rows.tolist()):
-                if packed:
-                    both = (fwd_all[lo[t]:hi[t]], rev_all[lo[t]:hi[t]])
-                else:
-                    ck = int(c[t])
-                    both = np.empty((2, ck, 2), np.int32)
-                    both[0] = lists(k)
-                    both[1] = both[0, :, ::-1]
+            if packed:
+                # (the per-pair objects are made when the pairs are booked, not here: a round of
+                #  4096 pairs with matches is 20-30 ms of object creation, and this function sits
+                #  between the device and its next round)
+                R.hits = _LazyHits(dev_rows.tolist(), fwd_all, rev_all, lo, hi,
+                                   (same, mean, std, dist, yv_f, yv_r, aff_ok) if surface else None)
+            for t, k in enumerate(() if packed else dev_rows.tolist()):
+                ck = int(c[t])
+                both = np.empty((2, ck, 2), np.int32)
+                both[0] = lists(k)
+                both[1] = both[0, :, ::-1]
                 surf = None
                 if surface:
                     surf = _NO_SURFACE if same[t] else (
@@ -888,6 +923,7 @@ def _finish_batch_arrays(h):
             # pairs the device filters handed back (more candidates than their buffers hold):
             # the host filters, per pair, as before
             first, count_s, sq, st, sm = ws.survivors(h['pb'].n_pairs)
+            R.hits = list(R.hits)
             for k in host_rows.tolist():
                 i1, i2 = view[k]
                 _ensure_features(i1)
@@ -906,7 +942,7 @@ def _finish_batch_arrays(h):
                     R.quiet[k] = True
                 else:
                     R.hits.append((k, fwd, rev, None))
-            R.hits.sort(key=lambda t: t[0])
+            R.hits = sorted(R.hits, key=lambda t: t[0])
     finally:
         _host_sets[hs['key']].append(hs)
         _recycle(h)
@@ -1239,6 +1275,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     if batched_surface and hasattr(smart, 'begin_batch'):
         smart.begin_batch()
 
+    from collections import deque
     backlog = []
     # the .match bytes of the rounds' pair lists (what saveMatches will write) are made on ONE
     # background thread, in libiamx without the interpreter lock (matchpairs.prepickle)
@@ -1247,33 +1284,70 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     pickler = ThreadPoolExecutor(max_workers=1, thread_name_prefix='iamx-pickle')
     pickling = []
 
+    # Finished rounds whose pairs with matches are not booked yet (generators of book_steps()).
+    # The schedule is sorted by distance: the pairs WITH matches -- all the per-pair host work,
+    # ~30 us each -- sit in the first rounds, where the device would idle while they are booked,
+    # and hundreds of rounds without a match follow, where the host would idle.  So a finished
+    # round is only queued; its pairs are booked a chunk at a time in the moments the host would
+    # otherwise WAIT for the device (drain(until=...)), or at the latest before a save.
+    to_book = deque()
+
     def drain(until=None):
-        """work the backlog off -- all of it, or while the event `until` has not happened yet;
-        all of it includes the pickles in flight"""
-        while backlog and (until is None or not until.query()):
-            kind, payload = backlog.pop(0)
-            smart.record_round(payload)
-            smart.materialize_pending()
+        """work the queues off -- all of it, or while the event `until` has not happened yet
+        (one ~2 ms step at a time); all of it includes the pickles in flight"""
+        while (backlog or to_book) and (until is None or not until.query()):
+            if backlog:
+                kind, payload = backlog.pop(0)
+                smart.record_round(payload)
+                smart.materialize_pending()
+            else:
+                try:
+                    next(to_book[0])
+                except StopIteration:
+                    to_book.popleft()
         if until is None:
             while pickling:
                 pickling.pop(0).result()
 
-    def book(part):
-        """rank 0's (or this rank's own) bookkeeping of one rank's round"""
+    BOOK_CHUNK = 64     # pairs with matches booked per step (~2 ms): see drain()
+
+    def book_steps(part):
+        """rank 0's (or this rank's own) bookkeeping of one rank's round, as a generator: the
+        once-per-round part first, then BOOK_CHUNK pairs with matches per step.  Nothing here
+        depends on the order in which rounds or chunks are booked: match_list entries, the ledger
+        and the yaw values carry the pair's seq and the newest seq wins."""
         a, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, quiet, hits = part
         n = len(pi)
         seq = a + np.arange(n, dtype=np.int64)
         # ---- the log: the reference's seven qlog() lines per pair (matcher.py:311-343) for the
         # pairs with matches, one summary line for the round's pairs without (at millions of
         # pairs the per-pair lines cost more than the GPU work they describe)
-        records = []
         nq = int(quiet.sum())
         if nq:
-            records.append("%d pairs without matches (%s vs %s ... %s vs %s): raw matches %d..%d, "
-                           "quality matches %d + %d in total"
-                           % (nq, names[pi[0]], names[pj[0]], names[pi[-1]], names[pj[-1]],
-                              int(min(raw1.min(), raw2.min())), int(max(raw1.max(), raw2.max())),
-                              int(n_fwd[quiet].sum()), int(n_rev[quiet].sum())))
+            _qlog("%d pairs without matches (%s vs %s ... %s vs %s): raw matches %d..%d, "
+                  "quality matches %d + %d in total"
+                  % (nq, names[pi[0]], names[pj[0]], names[pi[-1]], names[pj[-1]],
+                     int(min(raw1.min(), raw2.min())), int(max(raw1.max(), raw2.max())),
+                     int(n_fwd[quiet].sum()), int(n_rev[quiet].sum())))
+            # ---- pairs without matches: the ledger (two dictionary entries per pair, later)
+            ledger.add(pi[quiet], pj[quiet], seq[quiet])
+        # what every image's LAST pair so far was, quiet or not (the parts of several ranks do
+        # not arrive in seq order: the newest seq wins)
+        # (seq ascends inside a part: with repeated indices the LAST assignment stays)
+        newest = np.full(len(image_list), -1, np.int64)
+        newest_j = np.full(len(image_list), -1, np.int64)
+        newest[pi] = seq
+        newest_j[pj] = seq
+        np.maximum(newest, newest_j, out=newest)
+        upd = np.nonzero(newest > last_seq)[0]
+        last_seq[upd] = newest[upd]
+        last_quiet[upd] = quiet[newest[upd] - a]
+        for c0 in range(0, len(hits), BOOK_CHUNK):
+            yield
+            _book_hits(hits[c0:c0 + BOOK_CHUNK], pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq)
+
+    def _book_hits(hits, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq):
+        records = []
         for k, _f, _r, _s in hits:
             records.append("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
                            "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
@@ -1282,9 +1356,6 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                               cc[k]))
         if records:
             _qlog("\n".join(records))
-        # ---- pairs without matches: the ledger (two dictionary entries per pair, later)
-        if nq:
-            ledger.add(pi[quiet], pj[quiet], seq[quiet])
         round_records = [] if (batched_surface and hasattr(smart, 'record_round')) else None
         for k, match_fwd, match_rev, surf in hits:
             i, j = int(pi[k]), int(pj[k])
@@ -1339,32 +1410,15 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                      "count:", len(match_fwd))
                 i1.match_list.set_in_order(i2.name, [], int(seq[k]))
                 i2.match_list.set_in_order(i1.name, [], int(seq[k]))
-        # The tree entries of the round (smart.record_round) and the .match bytes of its lists
-        # (what saveMatches will write) are not needed before the call ends: they go to a backlog
-        # that is worked off while the host would otherwise wait for the GPU -- on a distance
-        # sorted schedule all the pairs with matches come in the first few rounds (host bound),
-        # the hundreds of rounds behind them have none (GPU bound).
+        # the tree entries of these pairs (smart.record_round): a backlog item of their own
         if round_records:
-            for c0 in range(0, len(round_records), 256):
-                backlog.append(('smart', round_records[c0:c0 + 256]))
-        if hits:
-            lists = [dict.get(image_list[int(x)].match_list, image_list[int(y)].name)
-                     for k_, _f, _r, _s in hits for x, y in ((pi[k_], pj[k_]), (pj[k_], pi[k_]))]
-            pickling.append(pickler.submit(prepickle, lists))
-            while len(pickling) > 64 and pickling[0].done():
-                pickling.pop(0).result()
-        # what every image's LAST pair so far was, quiet or not (the parts of several ranks do
-        # not arrive in seq order: the newest seq wins)
-        # (seq ascends inside a part: with repeated indices the LAST assignment stays)
-        newest = np.full(len(image_list), -1, np.int64)
-        newest_j = np.full(len(image_list), -1, np.int64)
-        newest[pi] = seq
-        newest_j[pj] = seq
-        np.maximum(newest, newest_j, out=newest)
-        upd = np.nonzero(newest > last_seq)[0]
-        last_seq[upd] = newest[upd]
-        last_quiet[upd] = quiet[newest[upd] - a]
-        return n
+            backlog.append(('smart', round_records))
+        # ... and the .match bytes of their lists (what saveMatches will write): background thread
+        lists = [dict.get(image_list[int(x)].match_list, image_list[int(y)].name)
+                 for k_, _f, _r, _s in hits for x, y in ((pi[k_], pj[k_]), (pj[k_], pi[k_]))]
+        pickling.append(pickler.submit(prepickle, lists))
+        while len(pickling) > 256 and pickling[0].done():
+            pickling.pop(0).result()
 
     # software pipeline: the GPU works on round r+1 while python turns round r into lists.
     # An exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
@@ -1397,7 +1451,10 @@ def _find_matches(proj, K, strategy, transform, sort, review):
 
         for parts in gathered:
             for part in parts:
-                n_done += book(part)
+                steps = book_steps(part)
+                next(steps, None)             # the once-per-round part now, the pairs with matches later
+                to_book.append(steps)
+                n_done += len(part[1])
 
         t_elapsed = time.time() - t_start
         # (ranks != 0 only see their own pairs: their progress is that of their own shard)
