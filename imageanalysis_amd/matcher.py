@@ -1347,23 +1347,23 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             _book_hits(hits[c0:c0 + BOOK_CHUNK], pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq)
 
     def _book_hits(hits, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq):
-        records = []
-        for k, _f, _r, _s in hits:
-            records.append("Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
-                           "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
-                           "  cross checked matches: %d"
-                           % (names[pi[k]], names[pj[k]], dist[k], raw1[k], n_fwd[k], raw2[k], n_rev[k],
-                              cc[k]))
-        if records:
-            _qlog("\n".join(records))
+        # (python numbers for the chunk's pairs once: numpy scalars cost ~1 us each to format)
+        ks = np.fromiter((h[0] for h in hits), np.int64, len(hits))
+        pik, pjk, sqk = pi[ks].tolist(), pj[ks].tolist(), seq[ks].tolist()
+        records = ["Matching %s vs %s\n  separation (approx) = %.0f (m)\n  raw matches: %d\n"
+                   "  quality matches: %d\n  raw matches: %d\n  quality matches: %d\n"
+                   "  cross checked matches: %d" % (names[a_], names[b_], d_, r1_, f_, r2_, r_, c_)
+                   for a_, b_, d_, r1_, f_, r2_, r_, c_ in zip(
+                       pik, pjk, dist[ks].tolist(), raw1[ks].tolist(), n_fwd[ks].tolist(),
+                       raw2[ks].tolist(), n_rev[ks].tolist(), cc[ks].tolist())]
         round_records = [] if (batched_surface and hasattr(smart, 'record_round')) else None
-        for k, match_fwd, match_rev, surf in hits:
-            i, j = int(pi[k]), int(pj[k])
+        for t_, (k, match_fwd, match_rev, surf) in enumerate(hits):
+            i, j, sq = pik[t_], pjk[t_], sqk[t_]
             i1, i2 = image_list[i], image_list[j]
             if isinstance(match_fwd, np.ndarray):
                 match_fwd, match_rev = MatchPairs(match_fwd), MatchPairs(match_rev)
-            i1.match_list.set_in_order(i2.name, match_fwd, int(seq[k]))
-            i2.match_list.set_in_order(i1.name, match_rev, int(seq[k]))
+            i1.match_list.set_in_order(i2.name, match_fwd, sq)
+            i2.match_list.set_in_order(i1.name, match_rev, sq)
             i1.matches_clean = i2.matches_clean = False
             # ---- surface / yaw bookkeeping and the discard policy (:987-1005)
             avg = std = None
@@ -1373,11 +1373,13 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 avg, std = surf[0], surf[1]
                 round_records.append((i1, i2, avg, std, surf[2], surf[5], surf[6]))
                 if avg and std:
-                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
+                    # (the pair's line of the log, in the chunk's record: one log call per chunk)
+                    records.append("  %s %s surface est: %.1f std: %.1f" % (i1.name, i2.name, avg, std))
                 for x, yv in ((i, surf[5]), (j, surf[6])):
-                    if x not in yaw_value or yaw_value[x][0] < seq[k]:
+                    cur = yaw_value.get(x)
+                    if cur is None or cur[0] < sq:
                         # (no similarity fit for this direction: update_yaw_error_estimate returns 0)
-                        yaw_value[x] = (int(seq[k]), None if yv is not None else 0)
+                        yaw_value[x] = (sq, None if yv is not None else 0)
             elif smart is not None:
                 if surf is not None:
                     avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
@@ -1402,14 +1404,16 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                     ya = smart.update_yaw_error_estimate(i1, i2)
                     yb = smart.update_yaw_error_estimate(i2, i1)
                 for x, y in ((i, ya), (j, yb)):
-                    if x not in yaw_value or yaw_value[x][0] < seq[k]:
-                        yaw_value[x] = (int(seq[k]), y)
+                    if x not in yaw_value or yaw_value[x][0] < sq:
+                        yaw_value[x] = (sq, y)
             if std and std >= 50 and len(match_fwd) < 100:
                 _log("Std dev of surface triangulation blew up, matches are probably bad so "
                      "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
                      "count:", len(match_fwd))
-                i1.match_list.set_in_order(i2.name, [], int(seq[k]))
-                i2.match_list.set_in_order(i1.name, [], int(seq[k]))
+                i1.match_list.set_in_order(i2.name, [], sq)
+                i2.match_list.set_in_order(i1.name, [], sq)
+        if records:
+            _qlog("\n".join(records))
         # the tree entries of these pairs (smart.record_round): a backlog item of their own
         if round_records:
             backlog.append(('smart', round_records))

@@ -122,8 +122,6 @@ def main():
     for a in sys.argv:
         if a.startswith('--ppb='):
             matcher.PAIRS_PER_BATCH = int(a[6:])
-        if a.startswith('--depth='):
-            matcher.ROUNDS_IN_FLIGHT = int(a[8:])
     matcher.configure()
     K = camera.get_K()
     torch.cuda.synchronize()
