@@ -386,6 +386,7 @@ extern "C" int iamx_jpeg_decode_coefficients(const uint8_t *data, int64_t len, i
                         int16_t *blk = coef + 64 * (base[c] + (int64_t)(my * C.v + by) * C.blocks_w + mx * C.h + bx);
                         std::memset(blk, 0, 128);
                         int s = decode_symbol(br, DC);
+                        if (s > 15) s = 0;                               // corrupt table entry (jdhuff.c warns)
                         if (s) {
                             const int r = br.get(s);
                             s = extend(r, s);

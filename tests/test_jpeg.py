@@ -89,3 +89,43 @@ def test_unsupported_files_are_reported_not_guessed():
     assert host_decode(b'\x89PNG\r\n\x1a\n' + b'0' * 64)[0] == -1
     data = encode((64, 64), 2, 90, {})
     assert host_decode(data[:len(data) // 3])[0] in (0, -1)      # truncated: zeros, like libjpeg
+
+
+def test_host_half_survives_damaged_files():
+    """flipped bytes, truncation and garbage in the entropy-coded segment: the Huffman stage
+    returns (an error code or coefficients), it never reads outside its buffers or hangs"""
+    import ctypes
+    import io
+    from PIL import Image as PILImage
+    from imageanalysis_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for sub, rst in ((0, 0), (2, 0), (2, 4)):
+        buf = io.BytesIO()
+        PILImage.fromarray(img).save(buf, 'JPEG', quality=85, subsampling=sub, restart_marker_blocks=rst)
+        good = np.frombuffer(buf.getvalue(), np.uint8)
+        sos = int(np.nonzero((good[:-1] == 0xFF) & (good[1:] == 0xDA))[0][0]) + 14
+        for trial in range(40):
+            raw = good.copy()
+            kind = trial % 4
+            if kind == 0:
+                idx = rng.integers(sos, len(raw) - 2, 12)
+                raw[idx] = rng.integers(0, 256, 12, dtype=np.uint8)
+            elif kind == 1:
+                raw = raw[:int(rng.integers(sos, len(raw)))].copy()
+            elif kind == 2:
+                raw[sos + 5:] = 0xFF
+            else:
+                raw[int(rng.integers(sos, len(raw) - 2))] = 0xFF
+            info = np.zeros(16, np.int32)
+            if L.iamx_jpeg_info(p(raw), len(raw), p(info)) != 0:
+                continue
+            blocks = int(info[11])
+            coef = np.zeros((blocks + 1, 64), np.int16)
+            coef[blocks] = 12345                                  # guard row behind the buffer
+            quant = np.zeros((3, 64), np.uint16)
+            rc = L.iamx_jpeg_decode_coefficients(p(raw), len(raw), p(coef), blocks, p(quant))
+            assert rc in (0, -1, -4)
+            assert (coef[blocks] == 12345).all()
