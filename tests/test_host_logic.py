@@ -358,3 +358,25 @@ def test_pairs_per_batch_is_bounded_by_the_device_workspace():
         assert matcher._pairs_per_batch(50000) == 3
     finally:
         matcher.PAIRS_PER_BATCH = old
+
+
+def test_pair_lists_pickled_in_libiamx_load_like_the_reference_lists():
+    """matchpairs._pairs_bytes_many (iamx_pickle_pair_lists): narrow and wide indices, empty
+    lists, many lists in one call -- each stream is what pickle.loads() turns into [[i, j], ...]"""
+    import pickle
+    from imageanalysis_amd import matchpairs as mp
+    rng = np.random.default_rng(3)
+    arrays = [rng.integers(0, 4096, (n, 2)).astype(np.int32) for n in (0, 1, 7, 300, 0, 2000)]
+    arrays.append(np.array([[0, 65535], [65536, 1], [2 ** 31 - 1, 70000]], np.int32))      # wide
+    arrays.append(np.array([[65535, 65535]], np.int32))                                     # still narrow
+    out = mp._pairs_bytes_many(arrays)
+    assert len(out) == len(arrays)
+    for a, b in zip(arrays, out):
+        assert pickle.loads(b'\x80\x02' + bytes(b) + b'.') == a.tolist()
+    assert bytes(out[0]) == b']' and len(bytes(out[1])) == 3 + 9 and len(bytes(out[6])) == 3 + 3 * 13
+    # through the cache of a MatchPairs: filled in by prepickle(), dropped by an edit
+    m = mp.MatchPairs(arrays[3])
+    mp.prepickle([m, mp.MatchPairs(arrays[2]), [], mp.MatchPairs()])
+    assert m._pk is not None and pickle.loads(b'\x80\x02' + bytes(m.pickled()) + b'.') == arrays[3].tolist()
+    m[:] = arrays[2]
+    assert pickle.loads(b'\x80\x02' + bytes(m.pickled()) + b'.') == arrays[2].tolist()
