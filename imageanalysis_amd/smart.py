@@ -126,6 +126,44 @@ def _materialize_pending():
             yaw_of[name] = (yaw, _yaw_pairs_of(name, yaw))
         return hit
 
+    if fast:
+        # our own tree: a pair's node is made in one go -- a fresh node whose dictionary is set
+        # at once when the pair has no entry yet (the normal case inside one find_matches call)
+        new_node = Node.__new__
+        add = _deferred.add
+        for i1, i2, avg, std, dist_m, yv_f, yv_r in pend:
+            n1, n2 = i1.name, i2.name
+            hit1 = tri_of.get(n1) or nodes(n1)
+            hit2 = tri_of.get(n2) or nodes(n2)
+            if avg is not None:
+                surface_m, stddev = float("%.1f" % avg), float("%.1f" % std)
+                weight, dist_i = int(dist_m * dist_m), int(dist_m)
+                entry = (surface_m, weight, stddev)
+                for (tri, acc), other in ((hit1, n2), (hit2, n1)):
+                    td = tri.__dict__
+                    pn = td.get(other)
+                    if type(pn) is not Node:
+                        pn = td[other] = new_node(Node)
+                    d = pn.__dict__
+                    d["surface_m"], d["weight"], d["stddev"], d["dist_m"] = surface_m, weight, stddev, dist_i
+                    acc[other] = entry
+                add(n1)
+                add(n2)
+            for me, other, yv in ((n1, n2, yv_f), (n2, n1, yv_r)):
+                if yv is None:
+                    continue
+                yaw, yacc = yaw_of[me]
+                ye, yd = float("%.1f" % yv[0]), float("%.1f" % yv[1])
+                yc, yw = float("%.1f" % yv[2]), float("%.1f" % yv[3])
+                yd_ = yaw.__dict__
+                pn = yd_.get(other)
+                if type(pn) is not Node:
+                    pn = yd_[other] = new_node(Node)
+                d = pn.__dict__
+                d["yaw_error"], d["dist_m"], d["relative_crs"], d["weight"] = ye, yd, yc, yw
+                yacc[other] = (ye, int(yw), yd)
+                add(me)
+        return
     for i1, i2, avg, std, dist_m, yv_f, yv_r in pend:
         n1, n2 = i1.name, i2.name
         (tri1, acc1), (tri2, acc2) = nodes(n1), nodes(n2)
@@ -133,18 +171,11 @@ def _materialize_pending():
             surface_m, stddev = float("%.1f" % avg), float("%.1f" % std)
             weight, dist_i = int(dist_m * dist_m), int(dist_m)
             for tri, acc, other in ((tri1, acc1, n2), (tri2, acc2, n1)):
-                if fast:
-                    pn = tri.__dict__.get(other)
-                    if not isinstance(pn, Node):
-                        pn = tri.__dict__[other] = Node()
-                    d = pn.__dict__
-                    d["surface_m"], d["weight"], d["stddev"], d["dist_m"] = surface_m, weight, stddev, dist_i
-                else:
-                    pn = tri.getChild(other, True)
-                    pn.setFloat("surface_m", surface_m)
-                    pn.setInt("weight", weight)
-                    pn.setFloat("stddev", stddev)
-                    pn.setInt("dist_m", dist_i)
+                pn = tri.getChild(other, True)
+                pn.setFloat("surface_m", surface_m)
+                pn.setInt("weight", weight)
+                pn.setFloat("stddev", stddev)
+                pn.setInt("dist_m", dist_i)
                 acc[other] = (surface_m, weight, stddev)
             _deferred.add(n1)
             _deferred.add(n2)
@@ -154,18 +185,11 @@ def _materialize_pending():
             yaw, yacc = yaw_of[me]
             ye, yd = float("%.1f" % yv[0]), float("%.1f" % yv[1])
             yc, yw = float("%.1f" % yv[2]), float("%.1f" % yv[3])
-            if fast:
-                pn = yaw.__dict__.get(other)
-                if not isinstance(pn, Node):
-                    pn = yaw.__dict__[other] = Node()
-                d = pn.__dict__
-                d["yaw_error"], d["dist_m"], d["relative_crs"], d["weight"] = ye, yd, yc, yw
-            else:
-                pn = yaw.getChild(other, True)
-                pn.setFloat("yaw_error", ye)
-                pn.setFloat("dist_m", yd)
-                pn.setFloat("relative_crs", yc)
-                pn.setFloat("weight", yw)
+            pn = yaw.getChild(other, True)
+            pn.setFloat("yaw_error", ye)
+            pn.setFloat("dist_m", yd)
+            pn.setFloat("relative_crs", yc)
+            pn.setFloat("weight", yw)
             yacc[other] = (ye, int(yw), yd)
             _deferred.add(me)
 

@@ -380,3 +380,70 @@ def test_pair_lists_pickled_in_libiamx_load_like_the_reference_lists():
     assert m._pk is not None and pickle.loads(b'\x80\x02' + bytes(m.pickled()) + b'.') == arrays[3].tolist()
     m[:] = arrays[2]
     assert pickle.loads(b'\x80\x02' + bytes(m.pickled()) + b'.') == arrays[2].tolist()
+
+
+def test_smart_round_form_equals_the_pair_by_pair_bookkeeping():
+    """smart.record_round + materialize_pending + flush_aggregates (what find_matches uses: a
+    round's entries written in one pass, averages once at the end) leaves the SAME property tree
+    and the same weighted yaw errors as record_surface_estimate / record_yaw_values pair by pair"""
+    from imageanalysis_amd import smart
+    from imageanalysis_amd.hostlib import camera
+
+    class Im(object):
+        def __init__(self, k):
+            self.name = 'Q%03d' % k
+            self.ned = [3.0 * k, 17.0 * (k % 5), -100.0 - k]
+            self.match_list = {}
+
+        def get_camera_pose(self):
+            return (self.ned, 10.0, -90.0, 0.0)
+
+        def get_aircraft_pose(self):
+            return (0.0, 0.0, 0.0), (12.0 + len(self.name), 0.0, 0.0)
+
+    camera.set_image_params(5472, 3648)
+    rng = np.random.default_rng(4)
+    imgs = [Im(k) for k in range(12)]
+    pairs = []
+    for a in range(12):
+        for b in range(a + 1, 12):
+            if rng.random() < 0.6:
+                dist = float(np.linalg.norm(np.array(imgs[b].ned) - np.array(imgs[a].ned)))
+                avg, std = float(rng.normal(-3, 8)), float(abs(rng.normal(6, 12)))
+                yf = tuple(float(v) for v in (rng.normal(0, 20), dist, rng.uniform(0, 360), rng.uniform(0, 9)))
+                yr = tuple(float(v) for v in (rng.normal(0, 20), dist, rng.uniform(0, 360), rng.uniform(0, 9)))
+                pairs.append((imgs[a], imgs[b], avg, std, dist,
+                              yf if rng.random() < 0.8 else None, yr if rng.random() < 0.8 else None))
+    assert len(pairs) > 25
+
+    def reset():
+        smart.smart_node.__dict__.clear()
+        smart.load(None)
+        for im in imgs:
+            smart.smart_node.getChild(im.name, True).setFloat('tri_surface_m', 0.0)
+
+    # (a) pair by pair, averages after every pair (the reference's order of operations)
+    reset()
+    yaw_a = {}
+    for i1, i2, avg, std, dist, yf, yr in pairs:
+        smart.record_surface_estimate(i1, i2, avg, std, dist)
+        for me, other, yv in ((i1, i2, yf), (i2, i1, yr)):
+            y = smart.record_yaw_values(me, other, yv)
+            if yv is not None:
+                yaw_a[me.name] = y
+    tree_a = smart._to_dict(smart.smart_node)
+
+    # (b) the round form: three "rounds", one flush at the end
+    reset()
+    smart.begin_batch()
+    for c0 in range(0, len(pairs), 11):
+        smart.record_round(pairs[c0:c0 + 11])
+        smart.materialize_pending()
+    yaw_b = smart.flush_aggregates()
+    tree_b = smart._to_dict(smart.smart_node)
+    smart.freeze_poses(False)
+    assert tree_b == tree_a
+    assert set(yaw_b) >= set(yaw_a)
+    for name, y in yaw_a.items():
+        assert yaw_b[name] == y
+    reset()
