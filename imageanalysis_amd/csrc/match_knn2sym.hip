@@ -280,8 +280,8 @@ __device__ __forceinline__ void half_wave_min16(int (&r)[16], int lo, int &m0, i
 // sorted rows) and added after the two butterfly levels inside a 16-lane row instead of riding in
 // the C operand; with it the fused butterfly (half_wave_min16<true>).
 template <int QW, int NW, int VARIANT = 0, int PIPE = 0, int MERGEW = 2, int SLEEP = 0, bool GROUPLO = false,
-          int CH = 128>
-__global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
+          int CH = 128, int WPE = 2>
+__global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
 {
     constexpr int CHUNK = CH;        // train rows per LDS stage (experiments: 256)
     constexpr int WGROWS = NW * QW * 32;
@@ -333,7 +333,13 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
         row = row < nb ? row : nb - 1;
         const v4i *src = reinterpret_cast<const v4i *>(A.sdesc + (int64_t)(boff + row) * D);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bq[qb][s] = ~src[2 * s + g];
+        for (int s = 0; s < 4; ++s) {
+            bq[qb][s] = ~src[2 * s + g];
+            // one wave per SIMD (512 registers): the B operand -- only ever an MFMA source -- belongs
+            // in the AGPR half, the accumulators the VALU reads in the VGPR half; left alone the
+            // allocator does the opposite and pays a v_accvgpr_read per accumulator element
+            if constexpr (WPE == 1) asm volatile("" : "+a"(bq[qb][s]));
+        }
     }
     int lo_lane = 0;
     {
@@ -433,6 +439,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_kernel(SymArgs A)
                         acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t & 1][s], bq[qp][s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(aop[t & 1][s], bq[qp + 1][s], acc1, 0, 0, 0);
                     }
+                    if constexpr (WPE == 1) asm volatile("" : "+v"(acc0), "+v"(acc1));
                 };
                 load_ops(0, aop[0], tbop[0]);
                 if constexpr (!GROUPLO) {
@@ -1329,6 +1336,12 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
     case 310: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 256>), g, dim3(512), 0, st, a); break;
     case 311: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 5, 4, 0, true, 128>), g, dim3(512), 0, st, a); break;
     case 300: hipLaunchKernelGGL((knn2sym_kernel<4, 8, 0, 6, 2, 0, true>), g, dim3(512), 0, st, a); break;
+    // 8 query blocks per wave, ONE wave per SIMD (512 registers): the butterfly and the LDS operand
+    // reads are shared by twice the MFMAs (5.3 instead of 6.3 VALU per MFMA), no second wave to
+    // hide stalls.  Same 1024 B rows per workgroup, same tables.  (round 3: compiled, not measured)
+    case 600: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 6, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
+    case 601: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 5, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
+    case 602: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 0, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
 #define X(id, pipe, lo, hi) case id: hipLaunchKernelGGL((knn2sym_x_kernel<4, 8, pipe, lo, hi>), g, dim3(512), 0, st, a); break;
         X(500, 6, 4, 4) X(501, 6, 4, 0) X(502, 6, 0, 0) X(503, 6, 5, 1) X(504, 6, 2, 2) X(505, 6, 4, 1)
         X(506, 5, 4, 0) X(507, 7, 4, 0) X(508, 6, 5, 2) X(509, 6, 3, 0)
