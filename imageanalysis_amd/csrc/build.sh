@@ -22,10 +22,10 @@ for f in $SRCS; do
         EXTRA=""
         # the TRF helpers restate numpy expressions: separately rounded multiply and add
         [ "$(basename $f)" = "trf_vec.hip" ] && EXTRA="-ffp-contract=off"
-        # ablation build only: the one-wave-per-SIMD sweep variants (600-602) need their MFMA
+        # the one-wave-per-SIMD sweep (form 2; ablation variants 600-602) needs its MFMA
         # accumulators in VGPRs (the allocator's default for > 256 registers is the AGPR half,
         # at a v_accvgpr_read per element the VALU touches)
-        [ -n "$IAMX_ABLATE" ] && [ "$(basename $f)" = "match_knn2sym.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+        [ "$(basename $f)" = "match_knn2sym.hip" ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
         $HIPCC $FLAGS $EXTRA ${IAMX_EXTRA_FLAGS} -c "$f" -o "$o" &
     fi
     OBJS="$OBJS $o"

@@ -1227,9 +1227,11 @@ extern "C" int iamx_desc3_pack_batch_u8(const uint8_t *src, const int64_t *src_o
 }
 
 // template arguments of the shipped sweep, one place for the launch and for iamx_knn2sym_kernel_id()
-#define SWEEP_FORM2 4, 8, 0, 6, 2, 0, true, 128
-#define SWEEP_FORM1 4, 4, 0, 6, 2, 0, true, 128
-#define SWEEP_FORM0 2, 4, 0, 6, 2, 0, true, 128
+// (form 2: eight query blocks per wave, ONE wave per SIMD, B operand in AGPRs -- see the kernel and
+//  profiles/r3_knn2sym_onewave.txt; compiled with -mllvm -amdgpu-mfma-vgpr-form, csrc/build.sh)
+#define SWEEP_FORM2 8, 4, 0, 5, 2, 0, true, 128, 1
+#define SWEEP_FORM1 4, 4, 0, 6, 2, 0, true, 128, 2
+#define SWEEP_FORM0 2, 4, 0, 6, 2, 0, true, 128, 2
 #define SWEEP_STR2(...) #__VA_ARGS__
 #define SWEEP_STR(...) SWEEP_STR2(__VA_ARGS__)
 
@@ -1260,7 +1262,7 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     hipStream_t st = iamx::as_stream(stream);
     // PIPE = 6: six epilogue VALU instructions beside every MFMA of the next pair of query
     // blocks (profiles/r2_knn2sym_ablate.txt: 1.83 -> 1.78 us per image pair)
-    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM2>), g, dim3(512), 0, st, a);
+    if (form == 2) hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM2>), g, dim3(256), 0, st, a);
     else if (form == 1) hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM1>), g, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((knn2sym_kernel<SWEEP_FORM0>), g, dim3(256), 0, st, a);
     return iamx::check_launch("iamx_knn2sym_sweep");
