@@ -29,6 +29,13 @@
 //   group minimum in [R_w + lo_w, R_w + hi_w]; per train row the 8 waves of a workgroup are
 //   merged through LDS into (L, U1, U2) = (min lower bound, two smallest upper bounds).
 // One sorted store serves both roles (any order is legal for the A side).
+//
+// Workgroup shapes (iamx_knn2sym_sweep `form`).  Form 2, images of >= 4096 rows: 1024 B rows per
+// workgroup as 4 waves x 8 query blocks, ONE wave per SIMD (WPE = 1, 512 registers: the B operand
+// in the AGPR half, accumulators in VGPRs -- the file is compiled with -mllvm
+// -amdgpu-mfma-vgpr-form) -- the butterfly and the LDS operand reads of a tile serve 32 MFMAs,
+// 5.2 VALU per MFMA (round 3; before: 8 waves x 4 blocks at two waves per SIMD, 6.4 per MFMA).
+// Forms 1 / 0 (512 / 256 rows per workgroup): 4 waves x 4 / 2 blocks, two waves per SIMD.
 #include "iamx_common.h"
 
 namespace {
