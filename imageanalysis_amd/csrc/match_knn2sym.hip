@@ -1351,6 +1351,10 @@ extern "C" int iamxdbg_knn2sym_variant(int variant, const int8_t *sdesc, const i
     case 600: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 6, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
     case 601: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 5, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
     case 602: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 0, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
+    case 603: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 4, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
+    case 604: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 7, 2, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
+    case 605: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 5, 4, 0, true, 256, 1>), g, dim3(256), 0, st, a); break;
+    case 606: hipLaunchKernelGGL((knn2sym_kernel<8, 4, 0, 5, 4, 0, true, 128, 1>), g, dim3(256), 0, st, a); break;
 #define X(id, pipe, lo, hi) case id: hipLaunchKernelGGL((knn2sym_x_kernel<4, 8, pipe, lo, hi>), g, dim3(512), 0, st, a); break;
         X(500, 6, 4, 4) X(501, 6, 4, 0) X(502, 6, 0, 0) X(503, 6, 5, 1) X(504, 6, 2, 2) X(505, 6, 4, 1)
         X(506, 5, 4, 0) X(507, 7, 4, 0) X(508, 6, 5, 2) X(509, 6, 3, 0)

@@ -36,7 +36,7 @@ fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_i
 st = store
 ref = None
 ref300 = None
-names = {600: '8 query blocks per wave, one wave per SIMD, B operand in AGPRs, PIPE 6', 601: '... PIPE 5', 602: '... PIPE 0', 500: 'cross-chunk pipeline, barrier at step 4 / 4', 501: '... 4 / 0', 502: '... 0 / 0', 503: '... 5 / 1', 504: '... 2 / 2', 505: '... 4 / 1', 506: '... 4 / 0, PIPE 5', 507: '... 4 / 0, PIPE 7', 508: '... 5 / 2', 509: '... 3 / 0', 330: 'MFMA + staging, one LDS operand read per chunk', 331: '... and no staging after chunk 1', 332: '... and no barrier / merge: MFMA issue only', 320: 'PIPE 0 with the MFMA bursts at raised wave priority', 400: 'no staging after chunk 1 (timing only)', 401: '... and no chunk barrier', 402: '... and no row merge', 403: 'MFMA only, no staging after chunk 1', 404: 'MFMA + staging only (new form)', 310: '256-row chunks, merge on 4 waves, PIPE 5', 311: '128-row chunks, merge on 4 waves, PIPE 5', 300: 'fused butterfly + group Cq floor, PIPE 6', 301: '... PIPE 0', 302: '... PIPE 4', 303: '... PIPE 5', 200: 'merge on waves 0-3', 201: 'sleep 2 for waves 4-7', 202: 'sleep 5 for waves 4-7', 203: 'merge on waves 0-3 + sleep 3', 204: 'merge on all 8 waves', 16: 'shipped schedule without the per-chunk row merge', 48: '... and without the chunk barrier (timing only)', 100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
+names = {600: '8 query blocks per wave, one wave per SIMD, B operand in AGPRs, PIPE 6', 601: '... PIPE 5', 602: '... PIPE 0', 603: '... PIPE 4', 604: '... PIPE 7', 605: '... PIPE 5, 256-row chunks, merge on 4 waves', 606: '... PIPE 5, merge on 4 waves', 500: 'cross-chunk pipeline, barrier at step 4 / 4', 501: '... 4 / 0', 502: '... 0 / 0', 503: '... 5 / 1', 504: '... 2 / 2', 505: '... 4 / 1', 506: '... 4 / 0, PIPE 5', 507: '... 4 / 0, PIPE 7', 508: '... 5 / 2', 509: '... 3 / 0', 330: 'MFMA + staging, one LDS operand read per chunk', 331: '... and no staging after chunk 1', 332: '... and no barrier / merge: MFMA issue only', 320: 'PIPE 0 with the MFMA bursts at raised wave priority', 400: 'no staging after chunk 1 (timing only)', 401: '... and no chunk barrier', 402: '... and no row merge', 403: 'MFMA only, no staging after chunk 1', 404: 'MFMA + staging only (new form)', 310: '256-row chunks, merge on 4 waves, PIPE 5', 311: '128-row chunks, merge on 4 waves, PIPE 5', 300: 'fused butterfly + group Cq floor, PIPE 6', 301: '... PIPE 0', 302: '... PIPE 4', 303: '... PIPE 5', 200: 'merge on waves 0-3', 201: 'sleep 2 for waves 4-7', 202: 'sleep 5 for waves 4-7', 203: 'merge on waves 0-3 + sleep 3', 204: 'merge on all 8 waves', 16: 'shipped schedule without the per-chunk row merge', 48: '... and without the chunk barrier (timing only)', 100: 'pipelined, 4 VALU per MFMA', 101: 'pipelined, 6 VALU per MFMA', 102: 'pipelined, 8 VALU per MFMA', 0: 'shipped', 1: 'no column direction', 2: 'no row direction', 3: 'MFMA + staging only',
          4: 'row direction without butterfly', 5: 'row min tree only', 8: 'no MFMA',
          11: 'staging + barriers only'}
 for v in variants:
