@@ -399,6 +399,9 @@ def bidirectional_pair_matches(i1, i2, review=False):
 # --------------------------------------------------------------------------------------
 # pair schedule -- matcher.py:852-916
 # --------------------------------------------------------------------------------------
+_WORK_MATRIX_MAX = 8192      # images up to which the schedule is built from the n x n distance matrix
+
+
 def _work_arrays(proj, sort):
     """the pair schedule as arrays (dist float64, i int32, j int32), i < j"""
     image_list = proj.image_list
@@ -424,19 +427,46 @@ def _work_arrays(proj, sort):
     _log('Generating work list for range:', min_dist, '-', max_dist)
     n = len(image_list)
     interval = median_int * 1.3
-    ii, jj = np.triu_indices(n, k=1)
-    dist = np.linalg.norm(ned[jj] - ned[ii], axis=1)
-    if schedule == "all-pairs":
-        sel = np.ones(len(ii), bool)
-    elif schedule == "distance":
-        sel = ((dist >= min_dist) & (dist <= max_dist)) | (np.abs(ii - jj) <= 4)
+    if n <= _WORK_MATRIX_MAX:
+        # the distance MATRIX, then the selected upper-triangle entries in row-major order (what
+        # triu_indices + two gathers of [pairs, 3] coordinates deliver, 3x faster; the sums are
+        # formed in np.linalg.norm's order, so the distances are bit-identical)
+        acc = None
+        for d in range(3):
+            c = ned[:, d]
+            diff = c[None, :] - c[:, None]
+            sq = diff * diff
+            acc = sq if acc is None else acc + sq
+        D = np.sqrt(acc)
+        upper = np.triu(np.ones((n, n), bool), 1)
+        if schedule == "all-pairs":
+            mask = upper
+        elif schedule == "distance":
+            mask = upper & (((D >= min_dist) & (D <= max_dist)) | ~np.triu(np.ones((n, n), bool), 5))
+        else:
+            mask = upper & ~np.triu(np.ones((n, n), bool), 5)
+        dist = D[mask]
+        idx = np.arange(n, dtype=np.int32)
+        ii = np.broadcast_to(idx[:, None], (n, n))[mask]
+        jj = np.broadcast_to(idx, (n, n))[mask]
     else:
-        sel = np.abs(ii - jj) <= 4
-    ii, jj, dist = ii[sel], jj[sel], dist[sel]
+        ii, jj = np.triu_indices(n, k=1)
+        dist = np.linalg.norm(ned[jj] - ned[ii], axis=1)
+        if schedule == "all-pairs":
+            sel = np.ones(len(ii), bool)
+        elif schedule == "distance":
+            sel = ((dist >= min_dist) & (dist <= max_dist)) | (np.abs(ii - jj) <= 4)
+        else:
+            sel = np.abs(ii - jj) <= 4
+        ii, jj, dist = ii[sel], jj[sel], dist[sel]
     # python's round() is round-half-even, like np.rint
-    ddist = np.rint(dist / interval) * interval
+    steps = np.rint(dist / interval)
+    ddist = steps * interval
     if sort:
-        order = np.argsort(ddist, kind='stable')         # stable, like the reference's sorted()
+        # stable, like the reference's sorted(); the key is a small integer (numpy radix-sorts
+        # 16-bit keys: 4x faster than the merge sort of the float64 distances, same permutation)
+        key = steps.astype(np.int16) if len(steps) and 0 <= steps.min() and steps.max() < 32767 else ddist
+        order = np.argsort(key, kind='stable')
         ddist, ii, jj = ddist[order], ii[order], jj[order]
     return ddist.astype(np.float64), ii.astype(np.int32), jj.astype(np.int32)
 

@@ -447,3 +447,54 @@ def test_smart_round_form_equals_the_pair_by_pair_bookkeeping():
     for name, y in yaw_a.items():
         assert yaw_b[name] == y
     reset()
+
+
+def test_pair_schedule_matrix_form_equals_the_gather_form():
+    """matcher._work_arrays builds the schedule from the n x n distance matrix for surveys up to
+    8192 images: same pairs, same (bit-identical) distances, same stable order as the
+    triu_indices + gather form that larger surveys still take, for all three schedules"""
+    from imageanalysis_amd import matcher
+
+    class Im(object):
+        def __init__(self, ned):
+            self.ned = ned
+
+        def get_camera_pose(self):
+            return (self.ned, 0.0, -90.0, 0.0)
+
+    class Proj(object):
+        pass
+
+    rng = np.random.default_rng(8)
+    proj = Proj()
+    proj.image_list = [Im([20.0 * (k // 9) + rng.normal(0, 2.0), 20.0 * (k % 9) + rng.normal(0, 2.0),
+                           -100.0 + rng.normal(0, 1.0)]) for k in range(70)]
+    node = matcher.matcher_node
+    try:
+        for schedule, extra in (('all-pairs', {}), ('neighbours', {}), ('distance', {'min_dist': 15.0, 'max_dist': 70.0})):
+            node.setString('schedule', schedule)
+            for k, v in extra.items():
+                node.setFloat(k, v)
+            for sort in (True, False):
+                got = matcher._work_arrays(proj, sort)
+                keep = matcher._WORK_MATRIX_MAX
+                matcher._WORK_MATRIX_MAX = 0
+                try:
+                    want = matcher._work_arrays(proj, sort)
+                finally:
+                    matcher._WORK_MATRIX_MAX = keep
+                assert len(got[0]) == len(want[0]) > 0
+                for a, b in zip(got, want):
+                    assert a.dtype == b.dtype and np.array_equal(a, b)
+                if sort:
+                    # the order python's stable sorted() gives: by rounded distance, row-major inside
+                    dd, ii, jj = got
+                    assert (np.diff(dd) >= 0).all()
+                    same = np.diff(dd) == 0
+                    rm = ii.astype(np.int64) * 100000 + jj
+                    assert (np.diff(rm)[same] > 0).all()
+    finally:
+        node.setString('schedule', 'neighbours')
+        for k in ('min_dist', 'max_dist'):
+            if node.hasChild(k):
+                node.__dict__.pop(k, None)
