@@ -399,7 +399,7 @@ def bidirectional_pair_matches(i1, i2, review=False):
 # --------------------------------------------------------------------------------------
 # pair schedule -- matcher.py:852-916
 # --------------------------------------------------------------------------------------
-_WORK_MATRIX_MAX = 8192      # images up to which the schedule is built from the n x n distance matrix
+_WORK_MATRIX_MAX = 4096      # images up to which the schedule is built from the n x n distance matrix (~0.4 GB of temporaries)
 
 
 def _work_arrays(proj, sort):

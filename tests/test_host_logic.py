@@ -451,7 +451,7 @@ def test_smart_round_form_equals_the_pair_by_pair_bookkeeping():
 
 def test_pair_schedule_matrix_form_equals_the_gather_form():
     """matcher._work_arrays builds the schedule from the n x n distance matrix for surveys up to
-    8192 images: same pairs, same (bit-identical) distances, same stable order as the
+    4096 images: same pairs, same (bit-identical) distances, same stable order as the
     triu_indices + gather form that larger surveys still take, for all three schedules"""
     from imageanalysis_amd import matcher
 
