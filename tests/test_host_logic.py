@@ -498,3 +498,48 @@ def test_pair_schedule_matrix_form_equals_the_gather_form():
         for k in ('min_dist', 'max_dist'):
             if node.hasChild(k):
                 node.__dict__.pop(k, None)
+
+
+def test_detector_slots_are_private_per_thread_and_always_returned():
+    """kernels.detector_slot: concurrent holders get distinct slots (their device buffers are
+    keyed by the slot), at most DETECT_SLOTS at a time, and a slot goes back on an exception"""
+    import threading
+    import time
+    from imageanalysis_amd import kernels
+
+    class Dev(object):
+        index = 0
+
+    assert kernels._slot_key(Dev()) == (0, 0)               # outside any slot: the shared slot 0
+    held, peak, lock = [], [0], threading.Lock()
+
+    def worker():
+        with kernels.detector_slot() as s:
+            key = kernels._slot_key(Dev())
+            assert key == (0, s.slot) and s.slot >= 1
+            with lock:
+                held.append(s.slot)
+                assert len(set(held)) == len(held)           # nobody else holds this slot now
+                peak[0] = max(peak[0], len(held))
+            time.sleep(0.02)
+            with lock:
+                held.remove(s.slot)
+        assert kernels._slot_key(Dev()) == (0, 0)
+
+    threads = [threading.Thread(target=worker) for _ in range(3 * kernels.DETECT_SLOTS)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert 1 <= peak[0] <= kernels.DETECT_SLOTS
+    with pytest.raises(RuntimeError):
+        with kernels.detector_slot():
+            raise RuntimeError('inside a slot')
+    got = []
+    for _ in range(kernels.DETECT_SLOTS):                    # every slot is back in the pool
+        s = kernels.detector_slot()
+        s.__enter__()
+        got.append(s)
+    assert sorted(x.slot for x in got) == list(range(1, kernels.DETECT_SLOTS + 1))
+    for s in got:
+        s.__exit__(None, None, None)
