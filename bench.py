@@ -32,6 +32,8 @@ KPTS = 4096
 DIM = 128
 FLOP_PER_PAIR = 2.0 * KPTS * KPTS * DIM          # one distance matrix serves both directions
 I8_DENSE_PEAK_TFLOPS = 5000.0                    # 2 x bf16 dense (MI355X_MICROARCH.md)
+I8_UBENCH_TOPS = 3944.0                          # the guide's measured i8 MFMA micro-benchmark rate
+KNN2SYM_TRAFFIC_FILE = 'r4_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
 CONFIG1_IMAGES = 500                             # configs[1]: C(500, 2) = 124 750 pairs
 CONFIG2_IMAGES = 2812                            # configs[2]: 3 952 266 pairs
 MATCH_RATIO = 0.75
@@ -85,62 +87,15 @@ def pair_schedule(n_img, rank, world, sub_batch):
     return launches, hi - lo
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--images', type=int, default=0, help='override the survey size')
-    ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--one-direction', action='store_true',
-                    help='A/B: the round-1 form, one MFMA sweep per ORDERED pair (iamx_knn2v2_pairs)')
-    ap.add_argument('--verify-pairs', type=int, default=64,
-                    help='ordered pairs of the timed store checked against the oracle afterwards')
-    ap.add_argument('--no-overlap', action='store_true',
-                    help='filter kernels on the sweep stream (default: on a second stream)')
-    ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
-    ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
-    ap.add_argument('--ba-iters', type=int, default=0,
-                    help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
-    ap.add_argument('--no-sift-full', action='store_true',
-                    help='SIFT section without the scale 1.0 (20 MP) detects (counter passes: every detect the same size)')
-    ap.add_argument('--no-e2e', action='store_true',
-                    help='skip the configs[4] slice (24 rendered 20 MP frames through the drop-in chain)')
-    ap.add_argument('--e2e', type=int, default=0, metavar='N',
-                    help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
-                         'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
-                         'points and report per-stage seconds')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # IAMX_BENCH_DEBUG_ONE_GPU=1: all ranks on device 0 over gloo -- a smoke test of the N > 1
-    # code path on a 1-GPU box (RCCL refuses two ranks on one device); never used for numbers
-    one_gpu = os.environ.get('IAMX_BENCH_DEBUG_ONE_GPU') == '1'
-    if one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        if one_gpu:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-
+def match_section(args, rank, world, dev, dist, one_gpu, n_img, steps, warmup, verify_pairs):
+    """The matching half of the metric on an `n_img`-image survey: `warmup` untimed steps, then
+    exactly `steps` timed ones between barriers (max over ranks).  Returns the figures of the
+    JSON line (seconds, pairs, survivor counts, the sweep's roofline, the oracle self-check)."""
     from imageanalysis_amd import kernels
 
     # ---- survey: configs[1] on one GPU, configs[2] (strong scaling) on several.  Image slots
     #      are dealt to the ranks in equal blocks (the last block may hold spare slots that no
     #      pair refers to), so the all-gather is one equal-sized collective per buffer
-    n_img = args.images or (CONFIG1_IMAGES if world == 1 else CONFIG2_IMAGES)
     per = (n_img + world - 1) // world
     n_slots = per * world
     first, mine = rank * per, per
@@ -231,13 +186,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     survivors.zero_()
     candidates.zero_()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(timed_events=True)
     barrier()
     dt = time.perf_counter() - t0
@@ -261,7 +216,7 @@ def main():
     traffic, traffic_src, mfma_busy, mfma_busy_src = None, None, None, None
     sweeps = 2 if args.one_direction else 1                # MFMA passes per distance matrix
     tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json' if args.one_direction
-                      else 'r3_knn2sym_traffic.json')
+                      else KNN2SYM_TRAFFIC_FILE)
     if n_img == CONFIG1_IMAGES and world == 1 and os.path.exists(tf):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); PMC cannot be collected from inside
@@ -292,20 +247,114 @@ def main():
                 "mfma_passes_per_matrix": sweeps,
                 "executed_tflops": round(sweeps * achieved, 1),
                 "executed_frac_of_peak": round(sweeps * achieved / I8_DENSE_PEAK_TFLOPS, 4),
-                "executed_frac_of_sustained_3200": round(sweeps * achieved / 3200.0, 4)}
+                # the guide's measured i8 micro-benchmark ceiling (MI355X_MICROARCH.md: >= 3944 TOPS)
+                "frac_of_guide_ubench_3944": round(achieved / I8_UBENCH_TOPS, 4)}
 
     # ---- self-check outside the timed region: a sample of ordered pairs of the store that was
     #      just timed (neighbours, which overlap, and far pairs), through the same path, against
     #      the oracle (oracle/cpu_ref.c) -- survivor rows, train rows, metrics
     verified = None
-    if rank == 0 and args.verify_pairs > 0:
+    if rank == 0 and verify_pairs > 0:
         verified = verify_sample(kernels, store, raw, first, mine, n_img, thresh,
-                                 args.verify_pairs, not args.one_direction)
+                                 verify_pairs, not args.one_direction)
 
     ws_unresolved = sum(int(w.unresolved.item()) for w in (ws_pair if overlap else [ws]))
+    cpu_sample = raw[:2].cpu().numpy() if (rank == 0 and mine >= 2) else None
+    return {"dt": dt, "total_pairs": total_pairs, "survivors": int(survivors.item()),
+            "candidates": int(candidates.item()), "unresolved": int(ws_unresolved),
+            "verified": verified, "roofline": roofline, "cpu_sample": cpu_sample,
+            "launches": len(batches)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--images', type=int, default=0, help='override the survey size')
+    ap.add_argument('--sub-batch', type=int, default=8192, help='ordered pairs per launch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--one-direction', action='store_true',
+                    help='A/B: the round-1 form, one MFMA sweep per ORDERED pair (iamx_knn2v2_pairs)')
+    ap.add_argument('--verify-pairs', type=int, default=64,
+                    help='ordered pairs of the timed store checked against the oracle afterwards')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='filter kernels on the sweep stream (default: on a second stream)')
+    ap.add_argument('--no-survey', action='store_true',
+                    help='skip the one-step 2812-image survey sub-record (N = 1 only)')
+    ap.add_argument('--no-ba', action='store_true', help='skip the bundle-adjustment section')
+    ap.add_argument('--no-sift', action='store_true', help='skip the feature-detection section')
+    ap.add_argument('--ba-iters', type=int, default=0,
+                    help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
+    ap.add_argument('--no-sift-full', action='store_true',
+                    help='SIFT section without the scale 1.0 (20 MP) detects (counter passes: every detect the same size)')
+    ap.add_argument('--no-e2e', action='store_true',
+                    help='skip the configs[4] slice (24 rendered 20 MP frames through the drop-in chain)')
+    ap.add_argument('--e2e', type=int, default=0, metavar='N',
+                    help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
+                         'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
+                         'points and report per-stage seconds')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher, one rank per GPU
+        # (the same command line the driver uses for N > 1)
+        import socket
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                  '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+                                  '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d under WORLD_SIZE=%d: the launcher's rank count and "
+                         "--gpus disagree" % (args.gpus, world))
+    # IAMX_BENCH_DEBUG_ONE_GPU=1: all ranks on device 0 over gloo -- a smoke test of the N > 1
+    # code path on a 1-GPU box (RCCL refuses two ranks on one device); never used for numbers
+    one_gpu = os.environ.get('IAMX_BENCH_DEBUG_ONE_GPU') == '1'
+    if one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
+
+    n_img = args.images or (CONFIG1_IMAGES if world == 1 else CONFIG2_IMAGES)
+    m = match_section(args, rank, world, dev, dist, one_gpu, n_img, args.steps, args.warmup,
+                      args.verify_pairs)
+    dt, total_pairs, roofline, verified = m["dt"], m["total_pairs"], m["roofline"], m["verified"]
+    cpu_sample = m["cpu_sample"]
+    # ---- the metric's own survey at N = 1: ONE step over all 3 952 266 pairs of the 2812-image
+    #      configs[2] job on this GPU (same kernels, same timed-step contents; about 7 s).  The
+    #      headline stays on configs[1], the configuration BASELINE.json quotes for one MI355X.
+    survey = None
+    if world == 1 and n_img != CONFIG2_IMAGES and not args.no_survey and not args.one_direction:
+        torch.cuda.empty_cache()
+        s = match_section(args, rank, world, dev, dist, one_gpu, CONFIG2_IMAGES, 1, 0,
+                          min(args.verify_pairs, 16))
+        survey = {"workload": "configs[2] at N = 1: %d synthetic images x %d kpts x 128-D, all %d "
+                              "pairs, one timed step (no warm-up step; the configs[1] section "
+                              "just ran the same kernels)" % (CONFIG2_IMAGES, KPTS, s["total_pairs"]),
+                  "value": round(s["total_pairs"] / s["dt"], 1), "unit": "pairs/s",
+                  "seconds_per_step": round(s["dt"], 3), "pairs_per_step": s["total_pairs"],
+                  "launches": s["launches"], "survivors_per_step": s["survivors"],
+                  "candidates_per_step": s["candidates"], "unresolved": s["unresolved"],
+                  "verify": s["verified"],
+                  "roofline": {k: s["roofline"][k] for k in ("bound", "kernel", "achieved", "peak",
+                                                             "unit", "frac", "avg_launch_ms")}}
+        del s
+        torch.cuda.empty_cache()
     # ---- second half of the metric: sparse bundle adjustment (BASELINE configs[3])
     ba = None
-    cpu_sample = raw[:2].cpu().numpy() if (rank == 0 and mine >= 2) else None
     # The GPU sections below run with the BLAS thread pool limited to one thread: after a
     # multi-threaded numpy call ~100 OpenBLAS workers keep spinning for a while and the device
     # queue of whatever is timed next stalls for tens of milliseconds (profiles/r1_ba_notes.txt;
@@ -319,9 +368,6 @@ def main():
     sift = cleanup = None
     with quiet_blas:
         if not args.no_ba:
-            del batches, ws, raw, store
-            if overlap:
-                del ws_pair, runner
             torch.cuda.empty_cache()
             ba = ba_bench(rank, world, dev, dist, args)
         if not args.no_sift:
@@ -366,11 +412,12 @@ def main():
                        "images": n_img, "kpts": KPTS, "pairs_per_step": total_pairs,
                        "parallelism": "pair-shard x%d%s" % (world, " + RCCL descriptor all-gather"
                                                             if world > 1 else "")},
-            "survivors_per_step": int(survivors.item()) // max(args.steps, 1),
-            "candidates_per_step": int(candidates.item()) // max(args.steps, 1),
-            "unresolved": int(ws_unresolved),
+            "survivors_per_step": m["survivors"] // max(args.steps, 1),
+            "candidates_per_step": m["candidates"] // max(args.steps, 1),
+            "unresolved": m["unresolved"],
             "verified_pairs": verified["verified_pairs"] if verified else 0, "verify": verified,
-            "roofline": roofline, "cpu_baseline": cpu, "host_postprocess": host_post, "ba": ba,
+            "roofline": roofline, "cpu_baseline": cpu, "survey_2812": survey,
+            "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,
         }
         out["e2e"] = e2e
@@ -865,8 +912,8 @@ def sift_bench(rank, world, dev, dist, args):
                          "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg,
                          "traffic": sift_tr, "traffic_source": sift_tr_src,
                          "timing": "hipEvents around %d whole detects on the launch stream; per-kernel " % n_local +
-                                   "durations: profiles/r3_kernel_stats.txt (rocprofv3 --kernel-trace "
-                                   "--stats of the bench command), profiles/r3_sift_kernel_stats.txt"},
+                                   "durations: profiles/r4_kernel_stats.txt (rocprofv3 --kernel-trace "
+                                   "--stats of the bench command), profiles/r4_sift_kernel_stats.txt"},
             "scale_1_0": full, "cpu_baseline": cpu, "dtype": "f32 pyramid, f64 histograms",
             "parallelism": "image-shard x%d" % world}
 
@@ -986,7 +1033,7 @@ def ba_bench(rank, world, dev, dist, args):
         lsmr["traffic"], lsmr["traffic_source"] = aux_traffic(
             ('lsmr_fwd_kernel', 'lsmr_adj_kernel', 'lsmr_update3_kernel'), 'lsmr_update3_kernel')
         lsmr["timing"] = ("wall clock around %d fused iterations, queue kept full; per-kernel durations: "
-                          "profiles/r3_kernel_stats.txt" % its)
+                          "profiles/r4_kernel_stats.txt" % its)
     schur_it = None
     if world == 1:
         # one CG iteration of the Schur solver = three passes over the stored Jacobian blocks
@@ -1015,7 +1062,7 @@ def ba_bench(rank, world, dev, dist, args):
             ('schur_fwd_kernel', 'schur_pt_kernel', 'schur_adj_kernel', 'schur_pq_kernel',
              'schur_update1_kernel', 'schur_update2_kernel'), 'schur_fwd_kernel')
         schur_it["timing"] = ("wall clock, difference of a %d- and an 8-iteration solve; per-kernel "
-                              "durations: profiles/r3_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
+                              "durations: profiles/r4_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
                               % its)
     cpu = None                                              # filled in by main() at the end
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
@@ -1039,7 +1086,7 @@ def ba_bench(rank, world, dev, dist, args):
                          "traffic": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[0],
                          "traffic_source": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[1],
                          "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
-                                   "kernel, ba_residual_lds_kernel: profiles/r3_kernel_stats.txt)"},
+                                   "kernel, ba_residual_lds_kernel: profiles/r4_kernel_stats.txt)"},
             "residual_jac": {"bound": "hbm",
                              "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
                              "peak": HBM, "unit": "GB/s",
@@ -1048,18 +1095,18 @@ def ba_bench(rank, world, dev, dist, args):
                              "traffic": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[0],
                              "traffic_source": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[1],
                              "timing": "hipEvents around 50 launches (ba_residual_jac_kernel: "
-                                       "profiles/r3_kernel_stats.txt)"},
+                                       "profiles/r4_kernel_stats.txt)"},
             "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
 
 
-AUX_TRAFFIC_FILE = 'r3_ba_sift_traffic.json'
+AUX_TRAFFIC_FILE = 'r4_ba_sift_traffic.json'
 
 
 def aux_traffic(bases, per):
     """HBM bytes per `per`-kernel launch of the kernels whose base name is in `bases`, summed
     (an iteration = every kernel of it), from the committed PMC passes of this command
-    (profiles/r3_ba_sift_traffic.json, tools/aux_traffic_json.py); (None, reason) without it"""
+    (profiles/r4_ba_sift_traffic.json, tools/aux_traffic_json.py); (None, reason) without it"""
     path = os.path.join(REPO, 'profiles', AUX_TRAFFIC_FILE)
     if not os.path.exists(path):
         return None, None

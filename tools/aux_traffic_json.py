@@ -9,7 +9,7 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
 prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 SIFT = ('gray_up2x_kernel', 'blur_strip_kernel', 'downsample_kernel', 'extrema_kernel',
         'pyramid_tail_kernel', 'refine_kernel', 'orient_kernel', 'descriptor_kernel')
@@ -54,7 +54,7 @@ sift_total = sum(v["hbm_bytes_per_launch"] * v["dispatches"] for k, v in kernels
                  if k.split('<')[0] in SIFT)
 doc = {"source": "profiles/%s_aux_pmc_fetch.txt, profiles/%s_aux_pmc_write.txt (separate rocprofv3 --pmc "
                  "passes of bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 "
-                 "--no-e2e --no-sift-full)" % (tag, tag),
+                 "--no-e2e --no-sift-full --no-survey)" % (tag, tag),
        "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
        "kernels": kernels,
        "sift": {"frames": frames, "hbm_bytes_per_frame": int(sift_total / max(frames, 1))}}

@@ -1,24 +1,36 @@
 #!/bin/bash
 # Round evidence in one go (GPU box; run from the repository root through gpurun):
-#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r3)
+#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r4)
 # Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back), the summaries that are
 # judged are copied to profiles/ afterwards.  Counter passes are separate runs with --pmc only.
-TAG="${1:-r3}"
+TAG="${1:-r4}"
 OUT="$PWD/gpurun_out"
 REPO="$PWD"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 SUM="python $REPO/tools/prof_summary.py"
-BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e"
+BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey"
 # BA + SIFT kernels (a small matching section in front of them)
-AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e --no-sift-full"
+AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e --no-sift-full --no-survey"
 
 step() { echo "== $1 ($(date +%T))"; }
+# The instantiation the library launches: every summary below must name it, or the run fails
+# (round 3 shipped a kernel swapped in after the last evidence pass).
+export IAMX_EXPECT_KERNEL="$(python -c 'from imageanalysis_amd import kernels; print(kernels.lib().iamx_knn2sym_kernel_id(2).decode())')"
+echo "shipped sweep: $IAMX_EXPECT_KERNEL"
+check_kernel() {   # $1 = summary file that has to contain the launched template string
+    if ! grep -qF "$IAMX_EXPECT_KERNEL" "$1"; then
+        echo "EVIDENCE MISMATCH: $1 does not mention $IAMX_EXPECT_KERNEL"; FAILED=1
+    fi
+}
+FAILED=0
 
 if [ "${STAGE:-AB}" != "B" ]; then
+if [ -z "$NO_TESTS" ]; then
 step "gpu tests"
 timeout 1500 python -m pytest tests -m gpu -q > "$OUT/${TAG}_gpu_tests.txt" 2>&1
 tail -n 3 "$OUT/${TAG}_gpu_tests.txt"
+fi
 
 step "PMC: HBM traffic of the matching step (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
@@ -26,12 +38,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/p_$C "$OUT/${TAG}_knn2sym_pmc_${lc}.txt" > /dev/null
 done
+if [ -z "$NO_AUX" ]; then
 step "PMC: HBM traffic of the BA and SIFT kernels (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/a_$C -o b -- $AUX_PMC > /dev/null 2> /tmp/a_$C.err)
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/a_$C "$OUT/${TAG}_aux_pmc_${lc}.txt" > /dev/null
+    cp "$OUT/${TAG}_aux_pmc_${lc}.txt" "$REPO/profiles/${TAG}_aux_pmc_${lc}.txt"
 done
+python "$REPO/tools/aux_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_ba_sift_traffic.json" "$OUT/"
+fi
 step "PMC: SQ / MFMA busy"
 (cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
@@ -40,11 +56,12 @@ $SUM /tmp/p_sq "$OUT/${TAG}_knn2sym_pmc_sq.txt" > /dev/null
 head -12 "$OUT/${TAG}_knn2sym_pmc_sq.txt" | cut -c1-140
 
 step "traffic summaries -> profiles/ (what bench.py quotes)"
-for f in knn2sym_pmc_fetch knn2sym_pmc_write knn2sym_pmc_sq aux_pmc_fetch aux_pmc_write; do
+for f in knn2sym_pmc_fetch knn2sym_pmc_write knn2sym_pmc_sq; do
     cp "$OUT/${TAG}_$f.txt" "$REPO/profiles/${TAG}_$f.txt"
 done
-python "$REPO/tools/update_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_knn2sym_traffic.json" "$OUT/"
-python "$REPO/tools/aux_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_ba_sift_traffic.json" "$OUT/"
+for f in knn2sym_pmc_fetch knn2sym_pmc_write knn2sym_pmc_sq; do check_kernel "$REPO/profiles/${TAG}_$f.txt"; done
+python "$REPO/tools/update_traffic_json.py" "$TAG" || FAILED=1
+[ -f "$REPO/profiles/${TAG}_knn2sym_traffic.json" ] && cp "$REPO/profiles/${TAG}_knn2sym_traffic.json" "$OUT/"
 
 step "bench"
 timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
@@ -54,15 +71,18 @@ fi
 if [ "${STAGE:-AB}" != "A" ]; then
 step "kernel stats of the bench command"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
-    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
+    python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-survey > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
 $SUM /tmp/p_stats "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/prof_gaps.py" /tmp/p_stats lsmr > "$OUT/${TAG}_lsmr_gaps.txt" 2>&1
 head -8 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-160
+check_kernel "$OUT/${TAG}_kernel_stats.txt"
+cp "$OUT/${TAG}_kernel_stats.txt" "$REPO/profiles/${TAG}_kernel_stats.txt"
 
 step "SIFT kernel stats"
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_sift -o s -- \
     python "$REPO/tools/sift_time.py" 0.4 > "$OUT/${TAG}_sift_time.txt" 2>&1)
 $SUM /tmp/p_sift "$OUT/${TAG}_sift_kernel_stats.txt" > /dev/null
+cp "$OUT/${TAG}_sift_kernel_stats.txt" "$OUT/${TAG}_sift_time.txt" "$REPO/profiles/"
 
 if [ -z "$NO_ENTRY" ]; then
 step "entry points"
@@ -71,3 +91,4 @@ timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1;
 fi
 fi
 step "done"
+[ "$FAILED" = 0 ] || { echo "collect_evidence: FAILED (kernel mismatch)"; exit 1; }
