@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence in one go (GPU box; run from the repository root through gpurun):
 #   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r4)
-# Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back), the summaries that are
-# judged are copied to profiles/ afterwards.  Counter passes are separate runs with --pmc only.
+# Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back); the summaries come back
+# under gpurun_out/ -- copy the judged ones to profiles/ afterwards (tools/pull_evidence.sh).  Counter passes are separate runs with --pmc only.
 TAG="${1:-r4}"
 OUT="$PWD/gpurun_out"
 REPO="$PWD"

@@ -14,8 +14,8 @@ def main(d, out):
         lines.append('## %s' % os.path.relpath(f, d))
         rows = list(csv.DictReader(open(f)))
         for r in rows:                       # every kernel of the run (round 2 cut this to 25)
-            lines.append('  %-70s calls=%-6s total_ns=%-14s avg_ns=%-12s pct=%s' % (
-                r.get('Name', '')[:70], r.get('Calls'), r.get('TotalDurationNs'),
+            lines.append('  %-110s calls=%-6s total_ns=%-14s avg_ns=%-12s pct=%s' % (
+                r.get('Name', '')[:110], r.get('Calls'), r.get('TotalDurationNs'),
                 r.get('AverageNs'), r.get('Percentage')))
     for f in sorted(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)):
         lines.append('## %s' % os.path.relpath(f, d))
