@@ -92,8 +92,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     'iamx_sift_pyramid_level': (c_int, [c_int] * 5 + [c_void_p] * 4),
     'iamx_sift_sort_workspace_bytes': (c_int64, [c_int]),
-    'iamx_sift_sort': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p,
-                               c_void_p, c_void_p]),
+    'iamx_sift_sort': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                               c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'iamx_ba_jv': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_ba_jtv': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p]),

@@ -13,19 +13,20 @@
 //                  a ring of horizontally blurred rows in LDS; also writes the DoG
 //   downsample                                                                          HBM
 //   extrema        26-neighbour test on the DoG stack -> candidate list (atomic append)
-//   refine         one thread per candidate: 3-D quadratic fit (<=5 steps), contrast/edge
-//                  tests -> refined list (atomic append)
-//   orient         one wave per refined candidate: orientation histogram (f64 LDS atomics),
-//                  smoothing, peaks -> keypoints (atomic append)
-//   descriptor     one wave per keypoint: rotated 4x4x8 trilinear histogram in LDS (f64
-//                  atomics), clip/normalise/quantise
+//   refine         one thread per candidate: adjustLocalExtrema in float32 (<=5 steps, Cramer
+//                  solve, contrast/edge tests) -> refined list (atomic append)
+//   orient         one wave per refined candidate: calcOrientationHist (float32 terms, exact
+//                  f64 LDS-atomic sums), smoothing, peaks -> keypoints (atomic append)
+//   descriptor     one wave per keypoint: calcSIFTDescriptor, rotated 4x4x8 trilinear histogram
+//                  in LDS (float32 terms, f64 atomics), clip/normalise/quantise
+//   sort           removeDuplicatedSorted: OpenCV's output order, duplicates dropped
 // The Gaussian taps are explicit fused multiply-adds (one rounding per tap, `fmaf` in the CPU
 // oracle) in the oracle's tap order; the other per-pixel arithmetic of the pyramid (grey scale,
 // x2 resize, DoG, derivatives) uses separately rounded mul / add / sub under `#pragma clang fp
 // contract(off)` -- nothing is left to the compiler's contraction choices, so the pyramids are
 // bit-identical to the oracle and the keypoint sets can be compared one to one; keypoints are
-// appended in nondeterministic order and put into the canonical (octave, layer, y, x, angle)
-// order by iamx_sift_sort.
+// appended in nondeterministic order; iamx_sift_sort removes duplicates and puts them into
+// OpenCV's output order (KeyPointsFilter::removeDuplicatedSorted).
 // Pyramid traffic: 6 Gaussian + 5 DoG f32 levels per octave written once, read once
 // (~469 B per detect-resolution pixel).
 #include "iamx_common.h"
@@ -474,43 +475,83 @@ __global__ __launch_bounds__(1024) void pyramid_tail_kernel(PyrTable T, int o_fi
     }
 }
 
-__device__ bool solve3(double A[3][3], double b[3], double x[3])
+// -----------------------------------------------------------------------------------------------
+// Behind the pyramid everything follows OpenCV's float32 scalar code (sift.simd.hpp
+// adjustLocalExtrema / calcOrientationHist / calcSIFTDescriptor, mathfuncs' fastAtan2) operation
+// by operation, exactly as oracle/sift_ref.c restates it: the functions below are compiled with
+// contraction OFF, every float operator is one IEEE float32 operation (division and square root
+// correctly rounded: hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).  The stated
+// departures from OpenCV: exp32() instead of hal::exp32f's table, correctly
+// rounded cosf / sinf / powf, and histogram bins that are the exact sum of OpenCV's float32 terms
+// (float64 LDS atomics, order independent) rounded to float32 once.
+// -----------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+
+// cv::fastAtan2, scalar form: degrees in [0, 360], 7th-order polynomial (~0.3 deg)
+__device__ __forceinline__ float fast_atan2_cv(float y, float x)
 {
-    // Gaussian elimination with partial pivoting (H.solve(dD, DECOMP_LU))
-    int p[3] = {0, 1, 2};
-    for (int k = 0; k < 3; ++k) {
-        int piv = k;
-        double best = fabs(A[p[k]][k]);
-        for (int i = k + 1; i < 3; ++i)
-            if (fabs(A[p[i]][k]) > best) { best = fabs(A[p[i]][k]); piv = i; }
-        if (best < 1e-300) return false;
-        const int t = p[k]; p[k] = p[piv]; p[piv] = t;
-        for (int i = k + 1; i < 3; ++i) {
-            const double f = A[p[i]][k] / A[p[k]][k];
-            for (int j = k; j < 3; ++j) A[p[i]][j] -= f * A[p[k]][j];
-            b[p[i]] -= f * b[p[k]];
-        }
-    }
-    for (int k = 2; k >= 0; --k) {
-        double s = b[p[k]];
-        for (int j = k + 1; j < 3; ++j) s -= A[p[k]][j] * x[j];
-        x[k] = s / A[p[k]][k];
-    }
-    return true;
+    constexpr float P1 = 0.9997878412794807f * 57.29577951308232f, P3 = -0.3258083974640975f * 57.29577951308232f,
+                    P5 = 0.1555786518463281f * 57.29577951308232f, P7 = -0.04432655554792128f * 57.29577951308232f;
+    const float eps = 2.220446049250313e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool steep = !(ax >= ay);
+    const float num = steep ? ax : ay, den = (steep ? ay : ax) + eps;
+    const float c = num / den;
+    const float c2 = c * c;
+    float a = (((P7 * c2 + P5) * c2 + P3) * c2 + P1) * c;
+    if (steep) a = 90.f - a;
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
 }
 
-__device__ __forceinline__ int round_half_even(double v)
+// oracle exp32(): float64 range reduction, degree-7 float32 Horner polynomial for 2^f, x <= 0
+__device__ __forceinline__ float exp32(float x)
 {
-    return (int)rint(v);
+    if (x < -87.f) return 0.f;
+    const double t = (double)x * 1.4426950408889634;
+    const double n = rint(t);
+    const float f = (float)(t - n);
+    float p = 1.5252733804059841e-05f;
+    p = p * f + 0.00015403530393381608f;
+    p = p * f + 0.0013333558146428443f;
+    p = p * f + 0.009618129107628477f;
+    p = p * f + 0.05550410866482158f;
+    p = p * f + 0.2402265069591007f;
+    p = p * f + 0.6931471805599453f;
+    p = p * f + 1.0f;
+    return ldexpf(p, (int)n);
+}
+
+// Matx33f::solve(Vec3f, DECOMP_LU) = Cramer's rule in float32 (Matx_FastSolveOp<float, 3, 3, 1>);
+// determinant exactly 0 -> the zero vector
+__device__ __forceinline__ void solve3_cramer(const float a[3][3], const float b[3], float x[3])
+{
+    const float det = a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) -
+                      a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2]) +
+                      a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    if (det == 0) { x[0] = x[1] = x[2] = 0.f; return; }
+    const float d = 1.f / det;
+    x[0] = d * (b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+                a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2]) +
+                a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * (a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) -
+                b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * (a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) -
+                a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0]) +
+                b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
 }
 
 // a candidate that passed the sub-pixel fit and the contrast / edge tests
 struct Refined {
     int o, layer, r, c;
-    double xi, xr, xc, contr;
+    float xi, xr, xc, contr;
 };
 
-// one thread per candidate: 3-D quadratic fit (<= 5 steps), contrast and edge tests
+// one thread per candidate: adjustLocalExtrema (<= 5 steps, contrast and edge tests), float32
 __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
                                            float contrast_threshold, float edge_threshold,
                                            Refined &R)
@@ -520,54 +561,54 @@ __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
     int layer = cd.layer, r = cd.r, c = cd.c;
     const float img_scale = 1.f / 255.f;
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
-    double xi = 0, xr = 0, xc = 0;
+    float xi = 0, xr = 0, xc = 0;
     int it = 0;
+#define AT(im, rr, cc) ((im)[(int64_t)(rr) * w + (cc)])
     for (; it < MAX_STEPS; ++it) {
         const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
-        auto at = [&](const float *im, int rr, int cc) { return im[(int64_t)rr * w + cc]; };
-        const float dDx = mul_rn(sub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
-        const float dDy = mul_rn(sub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
-        const float dDs = mul_rn(sub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
-        const float v2 = mul_rn(at(img, r, c), 2.f);
-        const float dxx = mul_rn(sub_rn(add_rn(at(img, r, c + 1), at(img, r, c - 1)), v2), second_scale);
-        const float dyy = mul_rn(sub_rn(add_rn(at(img, r + 1, c), at(img, r - 1, c)), v2), second_scale);
-        const float dss = mul_rn(sub_rn(add_rn(at(nxt, r, c), at(prv, r, c)), v2), second_scale);
-        const float dxy = mul_rn(add_rn(sub_rn(sub_rn(at(img, r + 1, c + 1), at(img, r + 1, c - 1)), at(img, r - 1, c + 1)), at(img, r - 1, c - 1)), cross_scale);
-        const float dxs = mul_rn(add_rn(sub_rn(sub_rn(at(nxt, r, c + 1), at(nxt, r, c - 1)), at(prv, r, c + 1)), at(prv, r, c - 1)), cross_scale);
-        const float dys = mul_rn(add_rn(sub_rn(sub_rn(at(nxt, r + 1, c), at(nxt, r - 1, c)), at(prv, r + 1, c)), at(prv, r - 1, c)), cross_scale);
-        double A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-        double b[3] = {dDx, dDy, dDs}, X[3];
-        if (!solve3(A, b, X)) return false;
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
+        const float v2 = AT(img, r, c) * 2.f;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+        const float dss = (AT(nxt, r, c) + AT(prv, r, c) - v2) * second_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+        const float dxs = (AT(nxt, r, c + 1) - AT(nxt, r, c - 1) - AT(prv, r, c + 1) + AT(prv, r, c - 1)) * cross_scale;
+        const float dys = (AT(nxt, r + 1, c) - AT(nxt, r - 1, c) - AT(prv, r + 1, c) + AT(prv, r - 1, c)) * cross_scale;
+        const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float X[3];
+        solve3_cramer(H, dD, X);
         xc = -X[0]; xr = -X[1]; xi = -X[2];
-        if (fabs(xi) < 0.5 && fabs(xr) < 0.5 && fabs(xc) < 0.5) break;
-        if (fabs(xi) > 2147483647.0 / 3 || fabs(xr) > 2147483647.0 / 3 || fabs(xc) > 2147483647.0 / 3)
-            return false;
-        c += round_half_even(xc);
-        r += round_half_even(xr);
-        layer += round_half_even(xi);
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        const float big = (float)(2147483647 / 3);
+        if (fabsf(xi) > big || fabsf(xr) > big || fabsf(xc) > big) return false;
+        c += cv_round(xc);
+        r += cv_round(xr);
+        layer += cv_round(xi);
         if (layer < 1 || layer > NL || c < BORDER || c >= w - BORDER || r < BORDER || r >= h - BORDER)
             return false;
     }
     if (it >= MAX_STEPS) return false;
-    double contr;
+    float contr;
     {
         const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
-        auto at = [&](const float *im, int rr, int cc) { return im[(int64_t)rr * w + cc]; };
-        const double dDx = (double)mul_rn(sub_rn(at(img, r, c + 1), at(img, r, c - 1)), deriv_scale);
-        const double dDy = (double)mul_rn(sub_rn(at(img, r + 1, c), at(img, r - 1, c)), deriv_scale);
-        const double dDs = (double)mul_rn(sub_rn(at(nxt, r, c), at(prv, r, c)), deriv_scale);
-        const double t = dDx * xc + dDy * xr + dDs * xi;
-        contr = (double)at(img, r, c) * (double)img_scale + t * 0.5;
-        if (fabs(contr) * NL < (double)contrast_threshold) return false;
-        const double v2 = (double)at(img, r, c) * 2.0;
-        const double dxx = ((double)at(img, r, c + 1) + (double)at(img, r, c - 1) - v2) * (double)second_scale;
-        const double dyy = ((double)at(img, r + 1, c) + (double)at(img, r - 1, c) - v2) * (double)second_scale;
-        const double dxy = ((double)at(img, r + 1, c + 1) - (double)at(img, r + 1, c - 1)
-                            - (double)at(img, r - 1, c + 1) + (double)at(img, r - 1, c - 1)) * (double)cross_scale;
-        const double tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
-        const double e = edge_threshold;
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
+        float t = 0.f;                                    // Matx::dot
+        t += dD[0] * xc; t += dD[1] * xr; t += dD[2] * xi;
+        contr = AT(img, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * (float)NL < contrast_threshold) return false;
+        const float v2 = AT(img, r, c) * 2.f;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        const float e = edge_threshold;
         if (det <= 0 || tr * tr * e >= (e + 1) * (e + 1) * det) return false;
     }
+#undef AT
     R.o = cd.o; R.layer = layer; R.r = r; R.c = c;
     R.xi = xi; R.xr = xr; R.xc = xc; R.contr = contr;
     return true;
@@ -598,8 +639,6 @@ __global__ __launch_bounds__(256) void refine_kernel(PyrTable T, const Cand *__r
     }
 }
 
-
-
 constexpr int ORI_BUF = 72;       // keypoints a wave collects before it touches the global counter
 
 // wave-wide: copy `n` buffered keypoints (8 floats each) behind one atomicAdd
@@ -620,15 +659,17 @@ __device__ __forceinline__ void flush_keypoints(const float *__restrict__ kbuf, 
     __builtin_amdgcn_wave_barrier();
 }
 
-// one wave per refined candidate: 36-bin gradient orientation histogram over the
-// (2*radius+1)^2 window (lanes stride over the pixels, f64 LDS atomics), smoothing, peaks
+// one wave per refined candidate: the KeyPoint fields of adjustLocalExtrema, then
+// calcOrientationHist over the (2*radius+1)^2 window (lanes stride over the pixels; float32
+// terms W * Mag summed exactly by float64 LDS atomics, each bin rounded to float32 once),
+// float32 smoothing and peak interpolation
 __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *__restrict__ refined,
                                                      const int *__restrict__ n_refined, int cap_c,
-                                                     double sigma, float *__restrict__ kp, int cap_k,
+                                                     float sigma, float *__restrict__ kp, int cap_k,
                                                      int *__restrict__ n_kp)
 {
     __shared__ double hist_s[4][ORI_BINS];
-    __shared__ double sm_s[4][ORI_BINS];
+    __shared__ float sm_s[4][ORI_BINS];
     __shared__ float kbuf_s[4][ORI_BUF * 8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int total = *n_refined < cap_c ? *n_refined : cap_c;
@@ -639,17 +680,20 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     const Refined R = refined[idx];
     const Pyr &P = T.oct[R.o];
     const int h = P.h, w = P.w, o = R.o, layer = R.layer, r = R.r, c = R.c;
-    const double xi = R.xi, xr = R.xr, xc = R.xc, contr = R.contr;
-    const double size = sigma * exp2((layer + xi) / NL) * (double)(1 << o) * 2.0;
-    const double px = (c + xc) * (double)(1 << o), py = (r + xr) * (double)(1 << o);
-    const int octave = o + (layer << 8) + (round_half_even((xi + 0.5) * 255) << 16);
-    const double scl_octv = size * 0.5 / (double)(1 << o);
+    const float xi = R.xi, xr = R.xr, xc = R.xc, contr = R.contr;
+    const float oscale = (float)(1 << o);
+    const float e3 = ((float)layer + xi) / (float)NL;
+    const float size = sigma * (float)exp2((double)e3) * oscale * 2.f;       // powf(2.f, e3)
+    const float px = ((float)c + xc) * oscale, py = ((float)r + xr) * oscale;
+    const int octave = o + (layer << 8) + ((int)rint(((double)xi + 0.5) * 255) << 16);
+    const float scl_octv = size * 0.5f / oscale;
 
     const float *g = P.g[layer];
-    const int radius = round_half_even(4.5 * scl_octv);
-    const double osig = 1.5 * scl_octv;
-    const double expf_scale = -1.0 / (2.0 * osig * osig);
-    double *hist = hist_s[wave], *sm = sm_s[wave];
+    const int radius = cv_round(4.5f * scl_octv);
+    const float osig = 1.5f * scl_octv;
+    const float expf_scale = -1.f / (2.f * osig * osig);
+    double *hist = hist_s[wave];
+    float *sm = sm_s[wave];
     if (lane < ORI_BINS) hist[lane] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int side = 2 * radius + 1;
@@ -657,43 +701,40 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
         const int i = e / side - radius, j = e % side - radius;
         const int y = r + i, x = c + j;
         if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
-        const double dx = (double)g[(int64_t)y * w + x + 1] - (double)g[(int64_t)y * w + x - 1];
-        const double dy = (double)g[(int64_t)(y - 1) * w + x] - (double)g[(int64_t)(y + 1) * w + x];
-        // float32 transcendentals like OpenCV's calcOrientationHist (see descriptor_kernel)
-        const double wgt = (double)expf((float)((double)(i * i + j * j) * expf_scale));
-        double ori = (double)atan2f((float)dy, (float)dx) * (180.0 / 3.141592653589793);
-        if (ori < 0) ori += 360.0;
-        if (ori >= 360.0) ori -= 360.0;
-        const double mag = sqrt(dx * dx + dy * dy);
-        int b = round_half_even((ORI_BINS / 360.0) * ori);
+        const float dx = g[(int64_t)y * w + x + 1] - g[(int64_t)y * w + x - 1];
+        const float dy = g[(int64_t)(y - 1) * w + x] - g[(int64_t)(y + 1) * w + x];
+        const float wgt = exp32((float)(i * i + j * j) * expf_scale);
+        const float ori = fast_atan2_cv(dy, dx);
+        const float mag = sqrtf(dx * dx + dy * dy);
+        int b = cv_round((float)(ORI_BINS / 360.f) * ori);
         if (b >= ORI_BINS) b -= ORI_BINS;
         if (b < 0) b += ORI_BINS;
-        atomicAdd(&hist[b], wgt * mag);
+        atomicAdd(&hist[b], (double)(wgt * mag));
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): LDS atomics landed
     if (lane < ORI_BINS) {
         const int k = lane;
-        const double m2 = hist[(k + ORI_BINS - 2) % ORI_BINS], p2 = hist[(k + 2) % ORI_BINS];
-        const double m1 = hist[(k + ORI_BINS - 1) % ORI_BINS], p1 = hist[(k + 1) % ORI_BINS];
-        sm[k] = (m2 + p2) * (1.0 / 16) + (m1 + p1) * (4.0 / 16) + hist[k] * (6.0 / 16);
+        const float m2 = (float)hist[(k + ORI_BINS - 2) % ORI_BINS], p2 = (float)hist[(k + 2) % ORI_BINS];
+        const float m1 = (float)hist[(k + ORI_BINS - 1) % ORI_BINS], p1 = (float)hist[(k + 1) % ORI_BINS];
+        sm[k] = (m2 + p2) * (1.f / 16.f) + (m1 + p1) * (4.f / 16.f) + (float)hist[k] * (6.f / 16.f);
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
-    double omax = lane < ORI_BINS ? sm[lane] : 0.0;
+    float omax = lane < ORI_BINS ? sm[lane] : 0.f;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) omax = fmax(omax, __shfl_xor(omax, m));
-    const double mag_thr = omax * 0.8;
+    for (int m = 32; m >= 1; m >>= 1) omax = fmaxf(omax, __shfl_xor(omax, m));
+    const float mag_thr = omax * 0.8f;
     bool peak = false;
-    double angle = 0.0;
+    float angle = 0.f;
     if (lane < ORI_BINS) {
         const int j = lane;
-        const double lft = sm[(j + ORI_BINS - 1) % ORI_BINS], rgt = sm[(j + 1) % ORI_BINS];
+        const float lft = sm[(j + ORI_BINS - 1) % ORI_BINS], rgt = sm[(j + 1) % ORI_BINS];
         if (sm[j] > lft && sm[j] > rgt && sm[j] >= mag_thr) {
-            double bin = j + 0.5 * (lft - rgt) / (lft - 2 * sm[j] + rgt);
-            bin = bin < 0 ? ORI_BINS + bin : (bin >= ORI_BINS ? bin - ORI_BINS : bin);
-            angle = 360.0 - (360.0 / ORI_BINS) * bin;
-            if (fabs(angle - 360.0) < 1.1920929e-07) angle = 0.0;
+            float bin = (float)j + 0.5f * (lft - rgt) / (lft - 2 * sm[j] + rgt);
+            bin = bin < 0 ? (float)ORI_BINS + bin : (bin >= ORI_BINS ? bin - (float)ORI_BINS : bin);
+            angle = 360.f - (360.f / ORI_BINS) * bin;
+            if (fabsf(angle - 360.f) < 1.1920929e-07f) angle = 0.f;
             peak = true;
         }
     }
@@ -707,12 +748,12 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     }
     if (peak) {
         float *q = kbuf + (n_buf + __popcll(pm & ((1ull << lane) - 1))) * 8;
-        // first octave is -1: report in input-image pixels (detectAndCompute)
-        q[0] = (float)(px * 0.5);
-        q[1] = (float)(py * 0.5);
-        q[2] = (float)(size * 0.5);
-        q[3] = (float)angle;
-        q[4] = (float)fabs(contr);
+        // first octave is -1: report in input-image pixels (detectAndCompute; x 0.5 is exact)
+        q[0] = px * 0.5f;
+        q[1] = py * 0.5f;
+        q[2] = size * 0.5f;
+        q[3] = angle;
+        q[4] = fabsf(contr);
         const int oct_out = (octave & ~255) | ((octave - 1) & 255);
         q[5] = __int_as_float(oct_out);
         q[6] = __int_as_float(o * 256 + layer);        // pyramid address for the descriptor
@@ -724,7 +765,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     flush_keypoints(kbuf, n_buf, kp, cap_k, n_kp, lane);
 }
 
-// one wave per keypoint
+// one wave per keypoint: calcSIFTDescriptor
 __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
                                                          const int *__restrict__ n_kp, int cap_k,
                                                          uint8_t *__restrict__ desc)
@@ -732,13 +773,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     constexpr int d = 4, n = 8;
     constexpr int HB = (d + 2) * (d + 2) * (n + 2);       // 360
     __shared__ double hist_s[4][HB];
-    __shared__ double red_s[4][2];
+    __shared__ float raw_s[4][d * d * n + 2];
     constexpr int DESC_ROWS = 160;                        // window rows handled by the interval walk
     __shared__ int rowlo_s[4][DESC_ROWS];
     __shared__ int rowpre_s[4][DESC_ROWS + 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int total = *n_kp < cap_k ? *n_kp : cap_k;
     double *hist = hist_s[wave];
+    float *raw = raw_s[wave];
     // one keypoint per wave (private LDS slice, no block barriers).  A workgroup per 4 keypoints
     // rather than a few persistent waves: the window size varies 10x between keypoints and the
     // hardware's dynamic workgroup dispatch balances that (persistent waves measured 15 % slower).
@@ -755,17 +797,18 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         const Pyr &P = T.oct[o];
         const float *img = P.g[layer];
         const int h = P.h, w = P.w;
-        // keypoint in the coordinates of its octave: x * scale with scale = 2^-(o-1)
-        const double scale = o >= 1 ? 1.0 / (double)(1 << (o - 1)) : 2.0;
-        const double ptx = (double)q[0] * scale, pty = (double)q[1] * scale;
-        double ori = 360.0 - (double)q[3];
-        if (fabs(ori - 360.0) < 1.1920929e-07) ori = 0.0;
-        const double scl = (double)q[2] * scale * 0.5;
-        const int px = round_half_even(ptx), py = round_half_even(pty);
-        double cos_t = cos(ori * (3.141592653589793 / 180.0)), sin_t = sin(ori * (3.141592653589793 / 180.0));
-        const double bins_per_rad = n / 360.0, exp_scale = -1.0 / (d * d * 0.5);
-        const double hist_width = 3.0 * scl;
-        int radius = round_half_even(hist_width * 1.4142135623730951 * (d + 1) * 0.5);
+        // calcDescriptors: keypoint in the coordinates of its octave, scale = 2^-(o-1) (exact)
+        const float scale = o >= 1 ? 1.f / (float)(1 << (o - 1)) : 2.f;
+        const float ptx = q[0] * scale, pty = q[1] * scale;
+        float ori = 360.f - q[3];
+        if (fabsf(ori - 360.f) < 1.1920929e-07f) ori = 0.f;
+        const float scl = q[2] * scale * 0.5f;
+        const int px = cv_round(ptx), py = cv_round(pty);
+        const float ang = ori * (float)(3.141592653589793 / 180.0);
+        float cos_t = (float)cos((double)ang), sin_t = (float)sin((double)ang);   // cosf / sinf, correctly rounded
+        const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
+        const float hist_width = 3.f * scl;
+        int radius = cv_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
         const int diag = (int)sqrt((double)w * w + (double)h * h);
         radius = radius < diag ? radius : diag;
         cos_t /= hist_width;
@@ -773,13 +816,6 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
         // radius <= diag of the octave image (< 2^14 for any image that fits the workspace),
         // so the window index fits 32 bits: no 64-bit division in the sample loop
         const int side = 2 * radius + 1;
-        // Per sample the geometry, the gradient and the three weights are float32 -- what
-        // OpenCV's calcSIFTDescriptor computes in (its fastAtan2 is only good to 0.3 deg, its
-        // exp a table) -- and cost half the issue slots of float64 on this part; the histogram
-        // itself stays float64 (LDS atomics in any order give the same sums to ~1e-16, so the
-        // quantised descriptor does not depend on the order the lanes arrive in).
-        const float cos_f = (float)cos_t, sin_f = (float)sin_t, ori_f = (float)ori;
-        const float bins_f = (float)bins_per_rad, exp_f = (float)exp_scale;
         // the four gradient neighbours of window position (i, j); callers guarantee that the
         // position lies inside the image (0 < r < h - 1, 0 < c < w - 1)
         struct Grad { float xl, xr, yu, yd; };
@@ -788,18 +824,15 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
             return Grad{pc[-1], pc[1], pc[-w], pc[w]};
         };
         auto accumulate = [&](int i, int j, const Grad g) {
-            const float fi = (float)i, fj = (float)j;
-            const float c_rot = fj * cos_f - fi * sin_f, r_rot = fj * sin_f + fi * cos_f;
-            const float rbin = r_rot + (d / 2 - 0.5f), cbin = c_rot + (d / 2 - 0.5f);
-            if (!(rbin > -1.f && rbin < (float)d && cbin > -1.f && cbin < (float)d)) return;
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d)) return;
             const float dx = g.xr - g.xl;
             const float dy = g.yu - g.yd;
-            const float wgt = __expf((c_rot * c_rot + r_rot * r_rot) * exp_f);
-            float og = atan2f(dy, dx) * 57.29577951308232f;
-            if (og < 0.f) og += 360.f;
-            if (og >= 360.f) og -= 360.f;
-            const float mag = __fsqrt_rn(dx * dx + dy * dy) * wgt;
-            const float obin = (og - ori_f) * bins_f;
+            const float wgt = exp32((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            const float og = fast_atan2_cv(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const float obin = (og - ori) * bins_per_rad;
             const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
             const int r0 = (int)fr0, c0 = (int)fc0;
             int o0 = (int)fo0;
@@ -830,6 +863,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
             // concatenated intervals instead of the whole window.
             int *rowlo = rowlo_s[wave], *rowpre = rowpre_s[wave];
             int carry = 0;
+            const double cos_d = (double)cos_t, sin_d = (double)sin_t;
             for (int base = 0; base < side; base += 64) {
                 const int row = base + lane;
                 int jl = 0, cnt = 0;
@@ -839,8 +873,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
                         double lo = fmax((double)-radius, (double)(1 - px));
                         double hi = fmin((double)radius, (double)(w - 2 - px));
                         // -1 < j*a + b < d  for (a, b) = (sin_t, i*cos_t + 1.5) and (cos_t, -i*sin_t + 1.5)
-                        const double aa[2] = {sin_t, cos_t};
-                        const double bb[2] = {i * cos_t + d / 2 - 0.5, -i * sin_t + d / 2 - 0.5};
+                        const double aa[2] = {sin_d, cos_d};
+                        const double bb[2] = {i * cos_d + d / 2 - 0.5, -i * sin_d + d / 2 - 0.5};
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             if (fabs(aa[e]) < 1e-9) continue;          // no usable bound: keep all
@@ -904,182 +938,234 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the LDS atomics have landed
     {
-        // circular orientation bins, then the 128 values: lanes 0..63 hold 2 each
-        double v[2];
-        double sq = 0.0;
+        // bins -> float32 (one rounding each), circular orientation bins folded in float32, then
+        // the 128 values: lanes 0..63 hold 2 each
+        float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int t = lane * 2 + e;             // (i*d + j)*n + kk
             const int cell = t / n, kk = t % n;
             const int i = cell / d, j = cell % d;
             const int base = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            double x = hist[base + kk];
-            if (kk == 0) x += hist[base + n];
-            if (kk == 1) x += hist[base + n + 1];
+            float x = (float)hist[base + kk];
+            if (kk == 0) x = x + (float)hist[base + n];
+            if (kk == 1) x = x + (float)hist[base + n + 1];
             v[e] = x;
-            sq += x * x;
+            raw[t] = x;
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m);
-        const double thr = sqrt(sq) * 0.2;
-        double sq2 = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // the two norms are OpenCV's scalar loops: sequential float32 sums over k = 0 .. 127
+        if (lane == 0) {
+            float nrm2 = 0.f;
+            for (int t = 0; t < d * d * n; ++t) nrm2 += raw[t] * raw[t];
+            const float thr = sqrtf(nrm2) * 0.2f;
+            nrm2 = 0.f;
+            for (int t = 0; t < d * d * n; ++t) {
+                const float val = raw[t] < thr ? raw[t] : thr;
+                nrm2 += val * val;
+            }
+            const float s2 = sqrtf(nrm2);
+            raw[d * d * n] = thr;
+            raw[d * d * n + 1] = 512.f / (s2 > 1.1920929e-07f ? s2 : 1.1920929e-07f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        const float thr = raw[d * d * n], nrm = raw[d * d * n + 1];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            v[e] = v[e] < thr ? v[e] : thr;
-            sq2 += v[e] * v[e];
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sq2 += __shfl_xor(sq2, m);
-        const double nrm = 512.0 / fmax(sqrt(sq2), 1.1920929e-07);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            double x = rint(v[e] * nrm);
+            const float val = v[e] < thr ? v[e] : thr;
+            float x = rintf(val * nrm);
             x = x < 0 ? 0 : (x > 255 ? 255 : x);
             desc[(int64_t)k * 128 + lane * 2 + e] = (uint8_t)x;
         }
     }
     __builtin_amdgcn_wave_barrier();
     }   // keypoint loop
-    (void)red_s;
 }
+#pragma clang fp contract(fast)
 
 // ---------------------------------------------------------------------------------
-// canonical order of the keypoint list: (octave, layer, y, x, angle, descriptor[0]) ascending
-// (the detector kernels append in a nondeterministic order).  Keypoints of different (octave,
-// layer) never compare, so: count per segment, scatter into segment-contiguous slots, rank
-// every keypoint inside its segment by counting the smaller ones (LDS-tiled, O(sum n_seg^2) =
-// a few 10^8 compares for 5 x 10^4 keypoints), gather rows to their final positions.
+// Output order and duplicate removal (detectAndCompute -> KeyPointsFilter::removeDuplicatedSorted,
+// features2d/keypoint.cpp): the detector kernels append in a nondeterministic order.
+//   order 1 (OpenCV's): x, y ascending, size DESCENDING, angle ascending, response DESCENDING,
+//            packed octave (before the first-octave adjustment) DESCENDING
+//   order 0 (pyramid-local, rounds 1-3): octave, layer, y, x, angle ascending, then size /
+//            response / octave descending
+// then every keypoint equal to its predecessor in (x, y, size, angle) is dropped -- the first of
+// such a run (the highest response) stays, as in OpenCV's loop.
+// All fields are non-negative floats, so their bit patterns order like the values; a key is six
+// 32-bit words compared lexicographically (descending fields complemented) + the row as a tie
+// break.  Keys are dealt to SORT_BUCKETS buckets by a monotone function of the leading field(s)
+// (the x range, or (octave, layer) x the y range), so bucket order is key order; inside its
+// bucket every key is ranked by counting the smaller ones (a few dozen per bucket for an
+// evenly textured image; correct, only slower, if they all fall into one), duplicates are
+// flagged in the same pass, an exclusive scan of the flags closes the gaps.
 // ---------------------------------------------------------------------------------
-constexpr int SORT_SEGS = 128;            // (octave index + 1) * 4 + layer < 128
-constexpr int RANK_SPLIT = 16;            // workgroups that share the comparisons of 256 keypoints
+constexpr int SORT_BUCKETS = 4096;
+constexpr int SORT_SEGS = 128;            // (octave index + 1) * 4 + layer < 128  (order 0)
 
 struct SortKey {
-    unsigned long long a;                // (y bits << 32) | x bits
-    unsigned long long b;                // (angle bits << 32) | (descriptor[0] << 24) | row (24 bits)
-    int seg, orig;
+    unsigned w[6];
+    int bucket, orig;
 };
 
-__device__ __forceinline__ int seg_of(const float *kp_row)
+struct SortParams {
+    int order;
+    float ext_x, ext_y;                  // image width / height in pixels (bucket scale)
+};
+
+__device__ __forceinline__ SortKey make_key(const float *row, int i, const SortParams P)
 {
-    const int oct = __float_as_int(kp_row[5]);
-    return ((((oct & 255) + 1) & 255) << 2 | ((oct >> 8) & 3)) & (SORT_SEGS - 1);
+    SortKey k;
+    const unsigned x = (unsigned)__float_as_int(row[0]), y = (unsigned)__float_as_int(row[1]);
+    const unsigned size = ~(unsigned)__float_as_int(row[2]), angle = (unsigned)__float_as_int(row[3]);
+    const unsigned resp = ~(unsigned)__float_as_int(row[4]);
+    const int oct = __float_as_int(row[5]);
+    const unsigned oct_pre = ~(unsigned)((oct & ~255) | ((oct + 1) & 255));
+    if (P.order == 1) {
+        int b = (int)(row[0] / P.ext_x * (float)SORT_BUCKETS);
+        k.bucket = b < 0 ? 0 : (b >= SORT_BUCKETS ? SORT_BUCKETS - 1 : b);
+        k.w[0] = x; k.w[1] = y; k.w[2] = size; k.w[3] = angle;
+    } else {
+        const int seg = ((((oct & 255) + 1) & 255) << 2 | ((oct >> 8) & 3)) & (SORT_SEGS - 1);
+        constexpr int PER = SORT_BUCKETS / SORT_SEGS;
+        int b = (int)(row[1] / P.ext_y * (float)PER);
+        b = b < 0 ? 0 : (b >= PER ? PER - 1 : b);
+        k.bucket = seg * PER + b;
+        k.w[0] = y; k.w[1] = x; k.w[2] = angle; k.w[3] = size;
+    }
+    k.w[4] = resp; k.w[5] = oct_pre;
+    k.orig = i;
+    return k;
 }
 
-// per workgroup: LDS histogram of its 256 keypoints, one global atomic per segment present
 __global__ __launch_bounds__(256) void sort_count_kernel(const float *__restrict__ kp,
                                                          const int32_t *__restrict__ n_out, int cap,
-                                                         int32_t *__restrict__ seg_cnt)
+                                                         SortParams P, int32_t *__restrict__ bucket_cnt)
 {
-    __shared__ int hist[SORT_SEGS];
     const int n = min(*n_out, cap);
-    if ((int)blockIdx.x * 256 >= n) return;
-    if (threadIdx.x < SORT_SEGS) hist[threadIdx.x] = 0;
-    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&hist[seg_of(kp + (int64_t)i * 8)], 1);
-    __syncthreads();
-    if (threadIdx.x < SORT_SEGS && hist[threadIdx.x]) atomicAdd(&seg_cnt[threadIdx.x], hist[threadIdx.x]);
+    if (i < n) atomicAdd(&bucket_cnt[make_key(kp + (int64_t)i * 8, i, P).bucket], 1);
 }
 
-__global__ __launch_bounds__(SORT_SEGS) void sort_offsets_kernel(int32_t *__restrict__ seg_cnt,
-                                                                 int32_t *__restrict__ seg_off,
-                                                                 int32_t *__restrict__ seg_fill)
+// exclusive scan of the bucket counts (one workgroup); also clears the fill counters
+__global__ __launch_bounds__(1024) void sort_offsets_kernel(const int32_t *__restrict__ bucket_cnt,
+                                                            int32_t *__restrict__ bucket_off,
+                                                            int32_t *__restrict__ bucket_fill)
 {
-    __shared__ int c[SORT_SEGS];
-    c[threadIdx.x] = seg_cnt[threadIdx.x];
+    constexpr int PER = SORT_BUCKETS / 1024;
+    __shared__ int part[1024];
+    int c[PER], sum = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) { c[e] = bucket_cnt[threadIdx.x * PER + e]; sum += c[e]; }
+    part[threadIdx.x] = sum;
     __syncthreads();
-    int off = 0;
-    for (int k = 0; k < (int)threadIdx.x; ++k) off += c[k];
-    seg_off[threadIdx.x] = off;
-    if (threadIdx.x == SORT_SEGS - 1) seg_off[SORT_SEGS] = off + c[threadIdx.x];
-    seg_fill[threadIdx.x] = 0;
+    for (int sft = 1; sft < 1024; sft <<= 1) {
+        const int v = threadIdx.x >= sft ? part[threadIdx.x - sft] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int off = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        bucket_off[threadIdx.x * PER + e] = off;
+        bucket_fill[threadIdx.x * PER + e] = 0;
+        off += c[e];
+    }
+    if (threadIdx.x == 1023) bucket_off[SORT_BUCKETS] = off;
 }
 
 __global__ __launch_bounds__(256) void sort_scatter_kernel(const float *__restrict__ kp,
-                                                           const uint8_t *__restrict__ desc,
                                                            const int32_t *__restrict__ n_out, int cap,
-                                                           const int32_t *__restrict__ seg_off,
-                                                           int32_t *__restrict__ seg_fill,
-                                                           SortKey *__restrict__ keys,
-                                                           int32_t *__restrict__ dest)
+                                                           SortParams P,
+                                                           const int32_t *__restrict__ bucket_off,
+                                                           int32_t *__restrict__ bucket_fill,
+                                                           SortKey *__restrict__ keys)
 {
-    __shared__ int hist[SORT_SEGS], base[SORT_SEGS];
     const int n = min(*n_out, cap);
-    if ((int)blockIdx.x * 256 >= n) return;
-    if (threadIdx.x < SORT_SEGS) hist[threadIdx.x] = 0;
-    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int seg = 0, local = 0;
-    const float *row = kp + (int64_t)i * 8;
-    if (i < n) {
-        seg = seg_of(row);
-        local = atomicAdd(&hist[seg], 1);
-        dest[i] = 0;                                   // rank accumulator of slot i
-    }
-    __syncthreads();
-    if (threadIdx.x < SORT_SEGS && hist[threadIdx.x])
-        base[threadIdx.x] = seg_off[threadIdx.x] + atomicAdd(&seg_fill[threadIdx.x], hist[threadIdx.x]);
-    __syncthreads();
-    if (i < n) {
-        SortKey k;
-        k.a = ((unsigned long long)(unsigned)__float_as_int(row[1]) << 32) | (unsigned)__float_as_int(row[0]);
-        k.b = ((unsigned long long)(unsigned)__float_as_int(row[3]) << 32) |
-              ((unsigned long long)desc[(int64_t)i * 128] << 24) | (unsigned)(i & 0xFFFFFF);
-        k.seg = seg;
-        k.orig = i;
-        keys[base[seg] + local] = k;
-    }
+    if (i >= n) return;
+    const SortKey k = make_key(kp + (int64_t)i * 8, i, P);
+    keys[bucket_off[k.bucket] + atomicAdd(&bucket_fill[k.bucket], 1)] = k;
 }
 
-// rank of every keypoint inside its segment = number of smaller keys there.  grid = (slots / 256,
-// RANK_SPLIT): workgroup (bx, by) compares its 256 slots with the by-th part of the segments they
-// lie in and adds its count to dest[slot]
+// one thread per key: rank inside its bucket = number of smaller keys there; dup = one of them is
+// equal in the four leading words (x, y, size, angle in either order)
 __global__ __launch_bounds__(256) void sort_rank_kernel(const SortKey *__restrict__ keys,
-                                                        const int32_t *__restrict__ seg_off,
-                                                        int32_t *__restrict__ dest)
+                                                        const int32_t *__restrict__ bucket_off,
+                                                        int32_t *__restrict__ rank,
+                                                        int32_t *__restrict__ dup_at)
 {
-    __shared__ unsigned long long ta[256], tb[256];
-    __shared__ int ts[256];
-    const int n = seg_off[SORT_SEGS];
-    const int i_lo = blockIdx.x * 256, i_hi = min(i_lo + 256, n) - 1;
-    if (i_lo >= n) return;
-    const int i = i_lo + threadIdx.x;
-    SortKey me = keys[min(i, n - 1)];
-    const int s_lo = keys[i_lo].seg, s_hi = keys[i_hi].seg;
-    const int lo = seg_off[s_lo], hi = seg_off[s_hi + 1];
-    const int part = (hi - lo + RANK_SPLIT - 1) / RANK_SPLIT;
-    const int p_lo = lo + blockIdx.y * part, p_hi = min(p_lo + part, hi);
+    const int n = bucket_off[SORT_BUCKETS];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const SortKey me = keys[i];
+    const int lo = bucket_off[me.bucket], hi = bucket_off[me.bucket + 1];
     int cnt = 0;
-    for (int base = p_lo; base < p_hi; base += 256) {
-        __syncthreads();
-        if (base + (int)threadIdx.x < p_hi) {
-            const SortKey o = keys[base + threadIdx.x];
-            ta[threadIdx.x] = o.a; tb[threadIdx.x] = o.b; ts[threadIdx.x] = o.seg;
+    bool dup = false;
+    for (int j = lo; j < hi; ++j) {
+        const SortKey o = keys[j];
+        bool less = false, eq = true, eq4 = true;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            if (eq && o.w[e] != me.w[e]) { less = o.w[e] < me.w[e]; eq = false; }
+            if (e == 3) eq4 = eq;
         }
-        __syncthreads();
-        const int m = min(256, p_hi - base);
-        for (int j = 0; j < m; ++j) {
-            const unsigned long long oa = ta[j], ob = tb[j];
-            cnt += (ts[j] == me.seg) & ((oa < me.a) | ((oa == me.a) & (ob < me.b)));
-        }
+        if (eq) less = o.orig < me.orig;
+        cnt += less;
+        dup |= less && eq4;
     }
-    if (i < n && cnt) atomicAdd(&dest[i], cnt);
+    rank[i] = lo + cnt;
+    dup_at[lo + cnt] = dup ? 1 : 0;
+}
+
+// exclusive scan of the duplicate flags in sorted order (one workgroup, a contiguous chunk per
+// thread); n_sorted = keys kept
+__global__ __launch_bounds__(1024) void sort_compact_kernel(const int32_t *__restrict__ bucket_off,
+                                                            int32_t *__restrict__ dup_at,
+                                                            int32_t *__restrict__ n_sorted)
+{
+    __shared__ int part[1024];
+    const int n = bucket_off[SORT_BUCKETS];
+    const int chunk = (n + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    int sum = 0;
+    for (int j = lo; j < hi; ++j) sum += dup_at[j];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int sft = 1; sft < 1024; sft <<= 1) {
+        const int v = threadIdx.x >= sft ? part[threadIdx.x - sft] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int j = lo; j < hi; ++j) {
+        const int f = dup_at[j];
+        dup_at[j] = f ? -1 : run;                      // dropped, or the number of drops before j
+        run += f;
+    }
+    if (threadIdx.x == 1023) *n_sorted = n - part[1023];
 }
 
 __global__ __launch_bounds__(256) void sort_gather_kernel(const SortKey *__restrict__ keys,
-                                                          const int32_t *__restrict__ dest,
-                                                          const int32_t *__restrict__ seg_off,
+                                                          const int32_t *__restrict__ rank,
+                                                          const int32_t *__restrict__ dup_at,
+                                                          const int32_t *__restrict__ bucket_off,
                                                           const float *__restrict__ kp,
                                                           const uint8_t *__restrict__ desc,
                                                           float *__restrict__ out_kp,
                                                           uint8_t *__restrict__ out_desc)
 {
-    const int n = seg_off[SORT_SEGS];
+    const int n = bucket_off[SORT_BUCKETS];
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 3, part = t & 7;
     if (i >= n) return;
-    const SortKey k = keys[i];
-    const int src = k.orig, dst = seg_off[k.seg] + dest[i];
+    const int r = rank[i], before = dup_at[r];
+    if (before < 0) return;
+    const int src = keys[i].orig, dst = r - before;
     out_kp[(int64_t)dst * 8 + part] = kp[(int64_t)src * 8 + part];
     reinterpret_cast<uint4 *>(out_desc + (int64_t)dst * 128)[part] =
         reinterpret_cast<const uint4 *>(desc + (int64_t)src * 128)[part];
@@ -1299,7 +1385,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,
                        CAP_CAND, contrast_threshold, edge_threshold, refined, n_refined);
     hipLaunchKernelGGL(orient_kernel, dim3(256 * 8), dim3(256), 0, st, T, refined, n_refined,
-                       CAP_CAND, sigma_d, kp, cap, n_out);
+                       CAP_CAND, (float)sigma_d, kp, cap, n_out);
     {
         const unsigned g = blocks(cap, 4);
         hipLaunchKernelGGL(descriptor_kernel, dim3(g < 16384u ? g : 16384u), dim3(256), 0, st, T, kp,
@@ -1311,34 +1397,41 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
 extern "C" int64_t iamx_sift_sort_workspace_bytes(int cap)
 {
     if (cap < 1) return 0;
-    return (int64_t)cap * (int64_t)(sizeof(SortKey) + 4) + (3 * SORT_SEGS + 4) * 4 + 256;
+    return (int64_t)cap * (int64_t)(sizeof(SortKey) + 8) + (3 * SORT_BUCKETS + 4) * 4 + 256;
 }
 
-// Canonical (octave, layer, y, x, angle, descriptor[0]) order of the lists iamx_sift_detect
-// appended (n_out DEV [1] as written by it; rows beyond cap were not stored and are ignored).
-// out_kp DEV [cap][8], out_desc DEV [cap][128]; workspace DEV iamx_sift_sort_workspace_bytes(cap).
+// detectAndCompute's removeDuplicatedSorted on the lists iamx_sift_detect appended (n_out DEV [1]
+// as written by it; rows beyond cap were not stored and are ignored): duplicates dropped, rows in
+// OpenCV's output order (order 1) or the pyramid-local order (order 0).  width / height: the
+// detect image's size in pixels (bucket scale only).  out_kp DEV [cap][8], out_desc DEV
+// [cap][128], n_sorted DEV [1] = rows kept; workspace DEV iamx_sift_sort_workspace_bytes(cap).
 extern "C" int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap,
-                              void *workspace, int64_t workspace_bytes, float *out_kp,
-                              uint8_t *out_desc, void *stream)
+                              int order, int width, int height, void *workspace,
+                              int64_t workspace_bytes, float *out_kp, uint8_t *out_desc,
+                              int32_t *n_sorted, void *stream)
 {
-    IAMX_REQUIRE(kp && desc && n_out && workspace && out_kp && out_desc, "null pointer");
+    IAMX_REQUIRE(kp && desc && n_out && workspace && out_kp && out_desc && n_sorted, "null pointer");
     IAMX_REQUIRE(cap > 0 && workspace_bytes >= iamx_sift_sort_workspace_bytes(cap), "workspace too small");
+    IAMX_REQUIRE((order == 0 || order == 1) && width > 0 && height > 0, "bad order / image size");
     hipStream_t st = iamx::as_stream(stream);
     char *ws = static_cast<char *>(workspace);
     SortKey *keys = reinterpret_cast<SortKey *>(ws);
-    int32_t *dest = reinterpret_cast<int32_t *>(ws + (int64_t)cap * sizeof(SortKey));
-    int32_t *seg_cnt = dest + cap;
-    int32_t *seg_off = seg_cnt + SORT_SEGS;
-    int32_t *seg_fill = seg_off + SORT_SEGS + 1;
-    (void)hipMemsetAsync(seg_cnt, 0, SORT_SEGS * 4, st);
+    int32_t *rank = reinterpret_cast<int32_t *>(ws + (int64_t)cap * sizeof(SortKey));
+    int32_t *dup_at = rank + cap;
+    int32_t *bucket_cnt = dup_at + cap;
+    int32_t *bucket_off = bucket_cnt + SORT_BUCKETS;
+    int32_t *bucket_fill = bucket_off + SORT_BUCKETS + 1;
+    const SortParams P{order, (float)width, (float)height};
+    (void)hipMemsetAsync(bucket_cnt, 0, SORT_BUCKETS * 4, st);
     const unsigned g = blocks(cap, 256);
-    hipLaunchKernelGGL(sort_count_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, seg_cnt);
-    hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(SORT_SEGS), 0, st, seg_cnt, seg_off, seg_fill);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g), dim3(256), 0, st, kp, desc, n_out, cap, seg_off,
-                       seg_fill, keys, dest);
-    hipLaunchKernelGGL(sort_rank_kernel, dim3(g, RANK_SPLIT), dim3(256), 0, st, keys, seg_off, dest);
+    hipLaunchKernelGGL(sort_count_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, P, bucket_cnt);
+    hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(1024), 0, st, bucket_cnt, bucket_off, bucket_fill);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, P, bucket_off,
+                       bucket_fill, keys);
+    hipLaunchKernelGGL(sort_rank_kernel, dim3(g), dim3(256), 0, st, keys, bucket_off, rank, dup_at);
+    hipLaunchKernelGGL(sort_compact_kernel, dim3(1), dim3(1024), 0, st, bucket_off, dup_at, n_sorted);
     hipLaunchKernelGGL(sort_gather_kernel, dim3(blocks((int64_t)cap * 8, 256)), dim3(256), 0, st, keys,
-                       dest, seg_off, kp, desc, out_kp, out_desc);
+                       rank, dup_at, bucket_off, kp, desc, out_kp, out_desc);
     return iamx::check_launch("iamx_sift_sort");
 }
 

@@ -711,10 +711,13 @@ class OverlappedSweeps(object):
         main.wait_stream(self.side)
 
 
-def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6):
-    """image: [h,w,3] BGR or [h,w] gray uint8 (numpy or device tensor).  Returns numpy
-    (kp [N,5] float32: x, y, size, angle, response; octave [N] int32 (cv2 packing);
-    desc [N,128] uint8), in the canonical (octave, layer, y, x, angle) order."""
+def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0, sigma=1.6,
+                order='opencv'):
+    """cv2.SIFT_create().detectAndCompute(image, None): image [h,w,3] BGR or [h,w] gray uint8
+    (numpy or device tensor).  Returns numpy (kp [N,5] float32: x, y, size, angle, response;
+    octave [N] int32 (cv2 packing); desc [N,128] uint8), duplicates removed, in OpenCV's output
+    order (KeyPointsFilter::removeDuplicatedSorted) -- or, order='canonical', in the pyramid-local
+    (octave, layer, y, x, angle) order."""
     dev = require_gpu()
     img = _dev(image, U8)
     if img.dim() == 2:
@@ -735,23 +738,29 @@ def sift_detect(image, cap=200000, contrast_threshold=0.04, edge_threshold=10.0,
     check(lib().iamx_sift_detect(_ptr(img), h, w, ch, contrast_threshold, edge_threshold, sigma,
                                  _ptr(ws), need, _ptr(kp), _ptr(desc), cap, _ptr(n), stream_ptr()),
           'iamx_sift_detect')
-    # canonical (octave, layer, y, x, angle, desc[0]) order on the device (the kernels append in a
-    # nondeterministic order): iamx_sift_sort, then one pinned download
+    # removeDuplicatedSorted on the device (the kernels append in a nondeterministic order, with
+    # duplicates): iamx_sift_sort, then one pinned download
     sw = _sift_sort_ws.get(_slot_key(dev))
     need_s = int(lib().iamx_sift_sort_workspace_bytes(cap))
     if sw is None or sw[0].numel() < need_s or sw[1].shape[0] < cap:
         sw = (torch.empty(need_s, dtype=U8, device=dev),
               torch.empty((cap, 8), dtype=torch.float32, device=dev),
-              torch.empty((cap, 128), dtype=U8, device=dev))
+              torch.empty((cap, 128), dtype=U8, device=dev),
+              torch.zeros(2, dtype=I32, device=dev))
         _sift_sort_ws[_slot_key(dev)] = sw
-    check(lib().iamx_sift_sort(_ptr(kp), _ptr(desc), _ptr(n), cap, _ptr(sw[0]), need_s, _ptr(sw[1]),
-                               _ptr(sw[2]), stream_ptr()), 'iamx_sift_sort')
+    if order not in ('opencv', 'canonical'):
+        raise ValueError("sift_detect: order must be 'opencv' or 'canonical'")
+    check(lib().iamx_sift_sort(_ptr(kp), _ptr(desc), _ptr(n), cap, 1 if order == 'opencv' else 0,
+                               w, h, _ptr(sw[0]), need_s, _ptr(sw[1]), _ptr(sw[2]), _ptr(sw[3]),
+                               stream_ptr()), 'iamx_sift_sort')
+    sw[3][1:2].copy_(n, non_blocking=True)                # [kept, appended]
     hn = _sift_pinned_count(dev)
-    hn.copy_(n, non_blocking=True)
+    hn.copy_(sw[3], non_blocking=True)
     wait_stream()
-    cnt = int(hn[0])
-    if cnt > cap:
-        raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (cnt, cap))
+    cnt, found = int(hn[0]), int(hn[1])
+    if found > cap:
+        raise _lib.IamxError("sift_detect: %d keypoints exceed the capacity %d" % (found, cap))
+    sift_detect.last_removed = found - cnt               # duplicates dropped (diagnosis / tests)
     hk, hd = _sift_pinned(dev, cnt)
     hk[:cnt].copy_(sw[1][:cnt], non_blocking=True)
     hd[:cnt].copy_(sw[2][:cnt], non_blocking=True)
@@ -767,7 +776,7 @@ _sift_pin = {}
 def _sift_pinned_count(dev):
     cur = _sift_pin.get((_slot_key(dev), 'n'))
     if cur is None:
-        cur = _sift_pin[(_slot_key(dev), 'n')] = torch.zeros(1, dtype=I32).pin_memory()
+        cur = _sift_pin[(_slot_key(dev), 'n')] = torch.zeros(2, dtype=I32).pin_memory()
     return cur
 
 

@@ -402,8 +402,11 @@ int iamx_image_equalize_resize(const uint8_t *bgr, int height, int width, int eq
  *              packed octave (int32 bit pattern, cv2.KeyPoint.octave), 2 internal words
  *   desc       DEV [cap][128] uint8 (what cv2 returns as float32 0..255)
  *   n_out      DEV [1] int32: keypoints found (may exceed cap; only cap are stored)
- * Keypoints are appended in no particular order; iamx_sift_sort puts them into the canonical
- * (octave, layer, y, x, angle, descriptor[0]) order (imageanalysis_amd.kernels.sift_detect).
+ * Keypoints are appended in no particular order and still hold duplicates; iamx_sift_sort is the
+ * rest of detectAndCompute: KeyPointsFilter::removeDuplicatedSorted (duplicates dropped, OpenCV's
+ * output order).  Behind the float32 pyramid the arithmetic follows OpenCV's sift.simd.hpp scalar
+ * code in float32 (adjustLocalExtrema with Matx33f::solve, calcOrientationHist,
+ * calcSIFTDescriptor, hal::fastAtan2); oracle/sift_oracle.py states the three departures.
  * ------------------------------------------------------------------------------------ */
 int64_t iamx_sift_workspace_bytes(int height, int width);
 int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
@@ -417,15 +420,19 @@ int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
 int iamx_sift_pyramid_level(int height, int width, int octave, int kind, int index,
                             int64_t *byte_offset, int *level_h, int *level_w, int *n_octaves);
 
-/* Canonical order of the lists iamx_sift_detect appended: (octave, layer, y, x, angle,
- * descriptor[0]) ascending -- count per (octave, layer), scatter, rank inside the segment by
- * counting, gather.  n_out DEV [1] as written by iamx_sift_detect; out_kp DEV [cap][8],
- * out_desc DEV [cap][128] (rows [0, min(n_out, cap))); workspace DEV
- * iamx_sift_sort_workspace_bytes(cap) bytes. */
+/* KeyPointsFilter::removeDuplicatedSorted of detectAndCompute (OpenCV features2d/keypoint.cpp;
+ * cv2.SIFT.detectAndCompute at scripts/lib/image.py:324 returns its result) on the lists
+ * iamx_sift_detect appended: sort by KeyPoint12_LessThan -- x, y ascending, size descending, angle
+ * ascending, response descending, octave descending -- and drop every keypoint equal to its
+ * predecessor in (x, y, size, angle).  order 1 = that order (what cv2 returns); order 0 = the
+ * pyramid-local (octave, layer, y, x, angle) order with the same duplicates dropped.
+ * n_out DEV [1] as written by iamx_sift_detect; width, height: the detect image's size in pixels;
+ * out_kp DEV [cap][8], out_desc DEV [cap][128] (rows [0, n_sorted)); n_sorted DEV [1] int32 =
+ * rows kept; workspace DEV iamx_sift_sort_workspace_bytes(cap) bytes. */
 int64_t iamx_sift_sort_workspace_bytes(int cap);
-int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap,
-                   void *workspace, int64_t workspace_bytes, float *out_kp, uint8_t *out_desc,
-                   void *stream);
+int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_t *n_out, int cap, int order,
+                   int width, int height, void *workspace, int64_t workspace_bytes, float *out_kp,
+                   uint8_t *out_desc, int32_t *n_sorted, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Image ingest: split JPEG decoder (csrc/jpeg.hip) in place of cv2.imread(file, ANYCOLOR |

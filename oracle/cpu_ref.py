@@ -180,9 +180,9 @@ def sift_keypoints(dogs, gauss, octave, cand, sigma0, nthreads=0):
 
 
 def sift_descriptors(img, par, nthreads=0):
-    """img: one Gaussian level; par float64 [n,4] (ptx, pty, ori, scl) -> uint8 [n,128]"""
+    """img: one Gaussian level; par float32 [n,4] (ptx, pty, ori, scl) -> uint8 [n,128]"""
     img = np.ascontiguousarray(img, np.float32)
-    par = np.ascontiguousarray(par, np.float64).reshape(-1, 4)
+    par = np.ascontiguousarray(par, np.float32).reshape(-1, 4)
     desc = np.empty((len(par), 128), np.uint8)
     rc = lib().oracle_sift_descriptors(_p(img), ctypes.c_int(img.shape[0]), ctypes.c_int(img.shape[1]),
                                        _p(par), ctypes.c_int(len(par)), _p(desc), ctypes.c_int(nthreads))
@@ -193,7 +193,7 @@ def sift_descriptors(img, par, nthreads=0):
 
 def sift_detect(gray, cap=None, nthreads=0):
     """the whole detector + descriptor in C (oracle/sift_ref.c oracle_sift_detect): gray uint8
-    [h,w] -> (kps float64 [n,6], desc uint8 [n,128]) in detect()'s append order (unsorted)"""
+    [h,w] -> (kps float64 [n,6], desc uint8 [n,128]), duplicates removed, OpenCV's output order"""
     gray = np.ascontiguousarray(gray, np.uint8)
     h, w = gray.shape
     cap = int(cap or max(h * w // 8, 4096))

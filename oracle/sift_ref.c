@@ -86,74 +86,102 @@ int oracle_sift_blur(const float *src, int h, int w, const float *k, int r, floa
     return 0;
 }
 
-/* Gaussian elimination with partial pivoting on a 3 x 3 system (what H.solve(dD, DECOMP_LU)
- * does; the same sequence as sift_oracle._solve3 and the device's solve3) */
-static int solve3(double A[3][3], double b[3], double x[3])
+/* ---- float32 scalar conventions of OpenCV's sift.simd.hpp / mathfuncs, twins of the functions of
+ * the same names in sift_oracle.py.  The file is compiled with -ffp-contract=off: every float
+ * operator below is one IEEE float32 operation. */
+static float fast_atan2f_cv(float y, float x)
 {
-    int p[3] = {0, 1, 2};
-    for (int k = 0; k < 3; ++k) {
-        int piv = k;
-        double best = fabs(A[p[k]][k]);
-        for (int i = k + 1; i < 3; ++i)
-            if (fabs(A[p[i]][k]) > best) { best = fabs(A[p[i]][k]); piv = i; }
-        if (best < 1e-300) return 0;
-        const int t = p[k]; p[k] = p[piv]; p[piv] = t;
-        for (int i = k + 1; i < 3; ++i) {
-            const double f = A[p[i]][k] / A[p[k]][k];
-            for (int j = k; j < 3; ++j) A[p[i]][j] -= f * A[p[k]][j];
-            b[p[i]] -= f * b[p[k]];
-        }
+    /* cv::fastAtan2, scalar form (mathfuncs_core): degrees in [0, 360] */
+    static const float P1 = 0.9997878412794807f * 57.29577951308232f, P3 = -0.3258083974640975f * 57.29577951308232f,
+                       P5 = 0.1555786518463281f * 57.29577951308232f, P7 = -0.04432655554792128f * 57.29577951308232f;
+    const float eps = 2.220446049250313e-16f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((P7 * c2 + P5) * c2 + P3) * c2 + P1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((P7 * c2 + P5) * c2 + P3) * c2 + P1) * c;
     }
-    for (int k = 2; k >= 0; --k) {
-        double s = b[p[k]];
-        for (int j = k + 1; j < 3; ++j) s -= A[p[k]][j] * x[j];
-        x[k] = s / A[p[k]][k];
-    }
-    return 1;
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+static float exp32(float x)
+{
+    /* sift_oracle.exp32: float64 range reduction, degree-7 float32 Horner polynomial for 2^f */
+    static const float C[8] = {1.0f, 0.6931471805599453f, 0.2402265069591007f, 0.05550410866482158f,
+                               0.009618129107628477f, 0.0013333558146428443f, 0.00015403530393381608f,
+                               1.5252733804059841e-05f};
+    if (x < -87.f) return 0.f;
+    const double t = (double)x * 1.4426950408889634;
+    const double n = rint(t);
+    const float f = (float)(t - n);
+    float p = C[7];
+    for (int k = 6; k >= 0; --k) p = p * f + C[k];
+    return ldexpf(p, (int)n);
+}
+
+/* Matx33f::solve(Vec3f, DECOMP_LU) = Cramer's rule in float32 (Matx_FastSolveOp<float, 3, 3, 1>);
+ * determinant exactly 0 -> the zero vector */
+static void solve3_cramer(const float a[3][3], const float b[3], float x[3])
+{
+    const float det = a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) -
+                      a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2]) +
+                      a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    if (det == 0) { x[0] = x[1] = x[2] = 0.f; return; }
+    const float d = 1.f / det;
+    x[0] = d * (b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+                a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2]) +
+                a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * (a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) -
+                b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * (a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) -
+                a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0]) +
+                b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
 }
 
 typedef struct {
     int layer, r, c;
-    double xi, xr, xc, contr;
+    float xi, xr, xc, contr;
 } refined_t;
 
-/* sift_oracle._adjust_local_extrema (float32 derivative arithmetic with separately rounded
- * operations, float64 solve / contrast / edge tests) */
-/* (compiled with -ffp-contract=off: oracle/Makefile) */
+/* sift_oracle._adjust_local_extrema = adjustLocalExtrema of sift.simd.hpp (float32 throughout) */
 static int adjust_local_extrema(const float *const *dogs, int h, int w, int layer, int r, int c,
                                 refined_t *out)
 {
     const float img_scale = 1.f / 255.f;
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
-    double xi = 0, xr = 0, xc = 0;
+    float xi = 0, xr = 0, xc = 0;
     int it = 0;
 #define AT(im, rr, cc) ((im)[(size_t)(rr) * w + (cc)])
     for (; it < MAX_INTERP_STEPS; ++it) {
         const float *img = dogs[layer], *prv = dogs[layer - 1], *nxt = dogs[layer + 1];
-        volatile float t0;
-        t0 = AT(img, r, c + 1) - AT(img, r, c - 1); const float dDx = t0 * deriv_scale;
-        t0 = AT(img, r + 1, c) - AT(img, r - 1, c); const float dDy = t0 * deriv_scale;
-        t0 = AT(nxt, r, c) - AT(prv, r, c);         const float dDs = t0 * deriv_scale;
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
         const float v2 = AT(img, r, c) * 2.f;
-        t0 = AT(img, r, c + 1) + AT(img, r, c - 1); t0 = t0 - v2; const float dxx = t0 * second_scale;
-        t0 = AT(img, r + 1, c) + AT(img, r - 1, c); t0 = t0 - v2; const float dyy = t0 * second_scale;
-        t0 = AT(nxt, r, c) + AT(prv, r, c);         t0 = t0 - v2; const float dss = t0 * second_scale;
-        t0 = AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1); t0 = t0 - AT(img, r - 1, c + 1);
-        t0 = t0 + AT(img, r - 1, c - 1); const float dxy = t0 * cross_scale;
-        t0 = AT(nxt, r, c + 1) - AT(nxt, r, c - 1); t0 = t0 - AT(prv, r, c + 1);
-        t0 = t0 + AT(prv, r, c - 1); const float dxs = t0 * cross_scale;
-        t0 = AT(nxt, r + 1, c) - AT(nxt, r - 1, c); t0 = t0 - AT(prv, r + 1, c);
-        t0 = t0 + AT(prv, r - 1, c); const float dys = t0 * cross_scale;
-        double A[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
-        double b[3] = {dDx, dDy, dDs}, X[3];
-        if (!solve3(A, b, X)) return 0;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+        const float dss = (AT(nxt, r, c) + AT(prv, r, c) - v2) * second_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+        const float dxs = (AT(nxt, r, c + 1) - AT(nxt, r, c - 1) - AT(prv, r, c + 1) + AT(prv, r, c - 1)) * cross_scale;
+        const float dys = (AT(nxt, r + 1, c) - AT(nxt, r - 1, c) - AT(prv, r + 1, c) + AT(prv, r - 1, c)) * cross_scale;
+        const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float X[3];
+        solve3_cramer(H, dD, X);
         xc = -X[0]; xr = -X[1]; xi = -X[2];
-        if (fabs(xi) < 0.5 && fabs(xr) < 0.5 && fabs(xc) < 0.5) break;
-        if (fabs(xi) > 2147483647.0 / 3 || fabs(xr) > 2147483647.0 / 3 || fabs(xc) > 2147483647.0 / 3)
-            return 0;
-        c += (int)rint(xc);
-        r += (int)rint(xr);
-        layer += (int)rint(xi);
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        const float big = (float)(2147483647 / 3);
+        if (fabsf(xi) > big || fabsf(xr) > big || fabsf(xc) > big) return 0;
+        c += (int)lrintf(xc);
+        r += (int)lrintf(xr);
+        layer += (int)lrintf(xi);
         if (layer < 1 || layer > NL || c < IMG_BORDER || c >= w - IMG_BORDER || r < IMG_BORDER ||
             r >= h - IMG_BORDER)
             return 0;
@@ -161,20 +189,19 @@ static int adjust_local_extrema(const float *const *dogs, int h, int w, int laye
     if (it >= MAX_INTERP_STEPS) return 0;
     {
         const float *img = dogs[layer], *prv = dogs[layer - 1], *nxt = dogs[layer + 1];
-        volatile float t0;
-        t0 = AT(img, r, c + 1) - AT(img, r, c - 1); const double dDx = (double)(float)(t0 * deriv_scale);
-        t0 = AT(img, r + 1, c) - AT(img, r - 1, c); const double dDy = (double)(float)(t0 * deriv_scale);
-        t0 = AT(nxt, r, c) - AT(prv, r, c);         const double dDs = (double)(float)(t0 * deriv_scale);
-        const double t = dDx * xc + dDy * xr + dDs * xi;
-        const double contr = (double)AT(img, r, c) * (double)img_scale + t * 0.5;
-        if (fabs(contr) * NL < 0.04) return 0;
-        const double v2 = (double)AT(img, r, c) * 2.0;
-        const double dxx = ((double)AT(img, r, c + 1) + (double)AT(img, r, c - 1) - v2) * (double)second_scale;
-        const double dyy = ((double)AT(img, r + 1, c) + (double)AT(img, r - 1, c) - v2) * (double)second_scale;
-        const double dxy = ((double)AT(img, r + 1, c + 1) - (double)AT(img, r + 1, c - 1)
-                            - (double)AT(img, r - 1, c + 1) + (double)AT(img, r - 1, c - 1)) * (double)cross_scale;
-        const double tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
-        const double e = 10.0;
+        const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
+                             (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
+                             (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
+        float t = 0.f;                                   /* Matx::dot */
+        t += dD[0] * xc; t += dD[1] * xr; t += dD[2] * xi;
+        const float contr = AT(img, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * (float)NL < 0.04f) return 0;
+        const float v2 = AT(img, r, c) * 2.f;
+        const float dxx = (AT(img, r, c + 1) + AT(img, r, c - 1) - v2) * second_scale;
+        const float dyy = (AT(img, r + 1, c) + AT(img, r - 1, c) - v2) * second_scale;
+        const float dxy = (AT(img, r + 1, c + 1) - AT(img, r + 1, c - 1) - AT(img, r - 1, c + 1) + AT(img, r - 1, c - 1)) * cross_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        const float e = 10.f;
         if (det <= 0 || tr * tr * e >= (e + 1) * (e + 1) * det) return 0;
         out->layer = layer; out->r = r; out->c = c;
         out->xi = xi; out->xr = xr; out->xc = xc; out->contr = contr;
@@ -183,49 +210,51 @@ static int adjust_local_extrema(const float *const *dogs, int h, int w, int laye
     return 1;
 }
 
-/* sift_oracle._orientation_hist (float64 throughout) + the peak search of detect() */
-static int orientation_peaks(const float *img, int h, int w, int r, int c, int radius, double sigma,
-                             double *angles /* [ORI_BINS] */)
+/* sift_oracle._orientation_hist + _orientation_peaks (calcOrientationHist and the peak search of
+ * findScaleSpaceExtrema): float32 terms W * Mag, every bin the exact sum of its terms rounded to
+ * float32 once (float64 accumulation), float32 smoothing / peak interpolation */
+static int orientation_peaks(const float *img, int h, int w, int r, int c, int radius, float sigma,
+                             float *angles /* [ORI_BINS] */)
 {
     const int n = ORI_BINS;
-    const double expf_scale = -1.0 / (2.0 * sigma * sigma);
-    double hist[ORI_BINS], sm[ORI_BINS];
-    for (int k = 0; k < n; ++k) hist[k] = 0.0;
+    const float expf_scale = -1.f / (2.f * sigma * sigma);
+    double acc[ORI_BINS];
+    float t[ORI_BINS], sm[ORI_BINS];
+    for (int k = 0; k < n; ++k) acc[k] = 0.0;
     for (int i = -radius; i <= radius; ++i) {
         const int y = r + i;
         if (y <= 0 || y >= h - 1) continue;
         for (int j = -radius; j <= radius; ++j) {
             const int x = c + j;
             if (x <= 0 || x >= w - 1) continue;
-            const double dx = (double)img[(size_t)y * w + x + 1] - (double)img[(size_t)y * w + x - 1];
-            const double dy = (double)img[(size_t)(y - 1) * w + x] - (double)img[(size_t)(y + 1) * w + x];
-            const double wgt = exp((double)(i * i + j * j) * expf_scale);
-            double ori = fmod(atan2(dy, dx) * (180.0 / 3.141592653589793), 360.0);
-            if (ori < 0) ori += 360.0;
-            if (ori >= 360.0) ori -= 360.0;
-            const double mag = sqrt(dx * dx + dy * dy);
-            int b = (int)rint((n / 360.0) * ori);
+            const float dx = img[(size_t)y * w + x + 1] - img[(size_t)y * w + x - 1];
+            const float dy = img[(size_t)(y - 1) * w + x] - img[(size_t)(y + 1) * w + x];
+            const float wgt = exp32((float)(i * i + j * j) * expf_scale);
+            const float ori = fast_atan2f_cv(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy);
+            int b = (int)lrintf((float)(n / 360.f) * ori);
             if (b >= n) b -= n;
             if (b < 0) b += n;
-            hist[b] += wgt * mag;
+            acc[b] += (double)(wgt * mag);
         }
     }
-    double omax = 0.0;
+    for (int k = 0; k < n; ++k) t[k] = (float)acc[k];
+    float omax = 0.f;
     for (int k = 0; k < n; ++k) {
-        const double m2 = hist[(k + n - 2) % n], p2 = hist[(k + 2) % n];
-        const double m1 = hist[(k + n - 1) % n], p1 = hist[(k + 1) % n];
-        sm[k] = (m2 + p2) * (1.0 / 16) + (m1 + p1) * (4.0 / 16) + hist[k] * (6.0 / 16);
+        const float m2 = t[(k + n - 2) % n], p2 = t[(k + 2) % n];
+        const float m1 = t[(k + n - 1) % n], p1 = t[(k + 1) % n];
+        sm[k] = (m2 + p2) * (1.f / 16.f) + (m1 + p1) * (4.f / 16.f) + t[k] * (6.f / 16.f);
         if (k == 0 || sm[k] > omax) omax = sm[k];
     }
-    const double mag_thr = omax * 0.8;
+    const float mag_thr = omax * 0.8f;
     int np = 0;
     for (int j = 0; j < n; ++j) {
-        const double lft = sm[(j + n - 1) % n], rgt = sm[(j + 1) % n];
+        const float lft = sm[(j + n - 1) % n], rgt = sm[(j + 1) % n];
         if (sm[j] > lft && sm[j] > rgt && sm[j] >= mag_thr) {
-            double bin = j + 0.5 * (lft - rgt) / (lft - 2 * sm[j] + rgt);
-            bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
-            double angle = 360.0 - (360.0 / n) * bin;
-            if (fabs(angle - 360.0) < FLT_EPS) angle = 0.0;
+            float bin = (float)j + 0.5f * (lft - rgt) / (lft - 2 * sm[j] + rgt);
+            bin = bin < 0 ? (float)n + bin : (bin >= n ? bin - (float)n : bin);
+            float angle = 360.f - (360.f / n) * bin;
+            if (fabsf(angle - 360.f) < (float)FLT_EPS) angle = 0.f;
             angles[np++] = angle;
         }
     }
@@ -235,8 +264,9 @@ static int orientation_peaks(const float *img, int h, int w, int r, int c, int r
 /* detect() of sift_oracle.py for the candidates of one octave, in the order given (layer,
  * then row major): refinement, contrast / edge tests, orientation peaks.  dogs: NL+2 levels,
  * gauss: NL+3 levels of the octave, cand [n][3] = (layer, r, c).  kps [cap][6] = x, y, size,
- * angle, |contrast|, packed octave in the coordinates of the DOUBLED image (detect() halves them
- * afterwards).  Returns the number of keypoints (may exceed cap: only cap are stored). */
+ * angle, |contrast| (float32 values), packed octave in the coordinates of the DOUBLED image
+ * (detect() halves them afterwards).  Returns the number of keypoints (may exceed cap: only cap
+ * are stored). */
 int oracle_sift_keypoints(const float *const *dogs, const float *const *gauss, int h, int w, int o,
                           const int32_t *cand, int n, double sigma0, double *kps, int cap, int nthreads)
 {
@@ -251,17 +281,20 @@ int oracle_sift_keypoints(const float *const *dogs, const float *const *gauss, i
     double *loc = (double *)malloc(sizeof(double) * (size_t)n * 6 * 4);     /* 4 peaks inline */
     double **more = (double **)calloc((size_t)n, sizeof(double *));
     if (!cnt || !loc || !more) return -2;
+    const float sigma = (float)sigma0;                   /* adjustLocalExtrema takes float sigma */
 #pragma omp parallel for schedule(dynamic, 64)
     for (int k = 0; k < n; ++k) {
         refined_t R;
         if (!adjust_local_extrema(dogs, h, w, cand[3 * k], cand[3 * k + 1], cand[3 * k + 2], &R)) continue;
-        const double size = sigma0 * pow(2.0, (R.layer + R.xi) / NL) * (double)(1 << o) * 2.0;
-        const double px = (R.c + R.xc) * (double)(1 << o), py = (R.r + R.xr) * (double)(1 << o);
-        const int octave = o + (R.layer << 8) + ((int)rint((R.xi + 0.5) * 255) << 16);
-        const double scl_octv = size * 0.5 / (double)(1 << o);
-        double angles[ORI_BINS];
-        const int np = orientation_peaks(gauss[R.layer], h, w, R.r, R.c, (int)rint(4.5 * scl_octv),
-                                         1.5 * scl_octv, angles);
+        const float scale = (float)(1 << o);
+        const float e = ((float)R.layer + R.xi) / (float)NL;
+        const float size = sigma * (float)exp2((double)e) * scale * 2.f;     /* powf(2.f, e) */
+        const float px = ((float)R.c + R.xc) * scale, py = ((float)R.r + R.xr) * scale;
+        const int octave = o + (R.layer << 8) + ((int)lrint(((double)R.xi + 0.5) * 255) << 16);
+        const float scl_octv = size * 0.5f / scale;
+        float angles[ORI_BINS];
+        const int np = orientation_peaks(gauss[R.layer], h, w, R.r, R.c, (int)lrintf(4.5f * scl_octv),
+                                         1.5f * scl_octv, angles);
         double *dstp = loc + (size_t)k * 24;
         if (np > 4) {
             more[k] = (double *)malloc(sizeof(double) * 6 * (size_t)np);
@@ -269,7 +302,7 @@ int oracle_sift_keypoints(const float *const *dogs, const float *const *gauss, i
         }
         for (int j = 0; j < np; ++j) {
             double *q = dstp + 6 * j;
-            q[0] = px; q[1] = py; q[2] = size; q[3] = angles[j]; q[4] = fabs(R.contr); q[5] = (double)octave;
+            q[0] = px; q[1] = py; q[2] = size; q[3] = angles[j]; q[4] = fabsf(R.contr); q[5] = (double)octave;
         }
         cnt[k] = np;
     }
@@ -284,84 +317,86 @@ int oracle_sift_keypoints(const float *const *dogs, const float *const *gauss, i
     return total;
 }
 
-/* sift_oracle.descriptor (float64 throughout) */
-static void descriptor_one(const float *img, int h, int w, double ptx, double pty, double ori, double scl,
+/* sift_oracle.descriptor = calcSIFTDescriptor (float32 throughout; bins = exact sums rounded once) */
+static void descriptor_one(const float *img, int h, int w, float ptx, float pty, float ori, float scl,
                            uint8_t *out)
 {
     const int d = DESCR_W, n = DESCR_N;
-    const int px = (int)rint(ptx), py = (int)rint(pty);
-    double cos_t = cos(ori * (3.141592653589793 / 180.0)), sin_t = sin(ori * (3.141592653589793 / 180.0));
-    const double bins_per_rad = n / 360.0, exp_scale = -1.0 / (d * d * 0.5);
-    const double hist_width = 3.0 * scl;
-    int radius = (int)rint(hist_width * 1.4142135623730951 * (d + 1) * 0.5);
+    const int px = (int)lrintf(ptx), py = (int)lrintf(pty);
+    const float ang = ori * (float)(3.141592653589793 / 180.0);
+    float cos_t = (float)cos((double)ang), sin_t = (float)sin((double)ang);   /* cosf / sinf, correctly rounded */
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
+    const float hist_width = 3.f * scl;
+    int radius = (int)lrintf(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
     const int diag = (int)sqrt((double)w * w + (double)h * h);
     radius = radius < diag ? radius : diag;
     cos_t /= hist_width;
     sin_t /= hist_width;
-    double hist[(DESCR_W + 2) * (DESCR_W + 2) * (DESCR_N + 2)];
-    memset(hist, 0, sizeof(hist));
+    double acc[(DESCR_W + 2) * (DESCR_W + 2) * (DESCR_N + 2)];
+    float hist[(DESCR_W + 2) * (DESCR_W + 2) * (DESCR_N + 2)];
+    memset(acc, 0, sizeof(acc));
     for (int i = -radius; i <= radius; ++i) {
         for (int j = -radius; j <= radius; ++j) {
-            const double c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
-            const double rbin = r_rot + d / 2 - 0.5, cbin = c_rot + d / 2 - 0.5;
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
             if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1))
                 continue;
-            const double dx = (double)img[(size_t)r * w + c + 1] - (double)img[(size_t)r * w + c - 1];
-            const double dy = (double)img[(size_t)(r - 1) * w + c] - (double)img[(size_t)(r + 1) * w + c];
-            const double wgt = exp((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            double og = fmod(atan2(dy, dx) * (180.0 / 3.141592653589793), 360.0);
-            if (og < 0) og += 360.0;
-            if (og >= 360.0) og -= 360.0;
-            const double mag = sqrt(dx * dx + dy * dy) * wgt;
-            const double obin = (og - ori) * bins_per_rad;
-            const double fr0 = floor(rbin), fc0 = floor(cbin), fo0 = floor(obin);
+            const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
+            const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
+            const float wgt = exp32((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            const float og = fast_atan2f_cv(dy, dx);
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const float obin = (og - ori) * bins_per_rad;
+            const float fr0 = floorf(rbin), fc0 = floorf(cbin), fo0 = floorf(obin);
             const int r0 = (int)fr0, c0 = (int)fc0;
             int o0 = (int)fo0;
-            const double fr = rbin - fr0, fc = cbin - fc0, fo = obin - fo0;
+            const float fr = rbin - fr0, fc = cbin - fc0, fo = obin - fo0;
             if (o0 < 0) o0 += n;
             if (o0 >= n) o0 -= n;
-            const double v_r1 = mag * fr, v_r0 = mag - v_r1;
-            const double v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
-            const double v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
-            const double vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
+            const float v_r1 = mag * fr, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
+            const float vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int rr = r0 + 1 + (q4 >> 1), cc = c0 + 1 + (q4 & 1);
                 const int base = (rr * (d + 2) + cc) * (n + 2) + o0;
-                const double v1 = vv[q4] * fo;
-                hist[base] += vv[q4] - v1;
-                hist[base + 1] += v1;
+                const float v1 = vv[q4] * fo;
+                acc[base] += (double)(vv[q4] - v1);
+                acc[base + 1] += (double)v1;
             }
         }
     }
-    double dst[DESCR_W * DESCR_W * DESCR_N], sq = 0.0;
+    for (int k = 0; k < (d + 2) * (d + 2) * (n + 2); ++k) hist[k] = (float)acc[k];
+    float dst[DESCR_W * DESCR_W * DESCR_N];
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) {
-            double *cell = hist + ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
+            float *cell = hist + ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
             cell[0] += cell[n];
             cell[1] += cell[n + 1];
-            for (int k = 0; k < n; ++k) {
-                dst[(i * d + j) * n + k] = cell[k];
-                sq += cell[k] * cell[k];
-            }
+            for (int k = 0; k < n; ++k) dst[(i * d + j) * n + k] = cell[k];
         }
-    const double thr = sqrt(sq) * 0.2;
-    double sq2 = 0.0;
+    float nrm2 = 0.f;
+    for (int k = 0; k < d * d * n; ++k) nrm2 += dst[k] * dst[k];
+    const float thr = sqrtf(nrm2) * 0.2f;
+    nrm2 = 0.f;
     for (int k = 0; k < d * d * n; ++k) {
-        dst[k] = dst[k] < thr ? dst[k] : thr;
-        sq2 += dst[k] * dst[k];
+        const float val = dst[k] < thr ? dst[k] : thr;
+        dst[k] = val;
+        nrm2 += val * val;
     }
-    const double nrm = 512.0 / fmax(sqrt(sq2), FLT_EPS);
+    const float s2 = sqrtf(nrm2);
+    const float nrm = 512.f / (s2 > (float)FLT_EPS ? s2 : (float)FLT_EPS);
     for (int k = 0; k < d * d * n; ++k) {
-        double x = rint(dst[k] * nrm);
+        float x = rintf(dst[k] * nrm);
         x = x < 0 ? 0 : (x > 255 ? 255 : x);
         out[k] = (uint8_t)x;
     }
 }
 
-/* descriptors of n keypoints that live on one Gaussian level: par [n][4] = ptx, pty, ori, scl in
- * the coordinates of that level; desc [n][128] */
-int oracle_sift_descriptors(const float *img, int h, int w, const double *par, int n, uint8_t *desc,
+/* descriptors of n keypoints that live on one Gaussian level: par [n][4] = ptx, pty, ori, scl
+ * (float32) in the coordinates of that level; desc [n][128] */
+int oracle_sift_descriptors(const float *img, int h, int w, const float *par, int n, uint8_t *desc,
                             int nthreads)
 {
     if (!img || !par || !desc) return -1;
@@ -377,12 +412,43 @@ int oracle_sift_descriptors(const float *img, int h, int w, const double *par, i
     return 0;
 }
 
+/* KeyPoint12_LessThan of KeyPointsFilter::removeDuplicatedSorted on rows x, y, size, angle,
+ * response, packed octave (before the first-octave adjustment; class_id is -1 everywhere) */
+static int kp12_less(const void *pa, const void *pb)
+{
+    const double *a = (const double *)pa, *b = (const double *)pb;
+    if (a[0] != b[0]) return a[0] < b[0] ? -1 : 1;
+    if (a[1] != b[1]) return a[1] < b[1] ? -1 : 1;
+    if (a[2] != b[2]) return a[2] > b[2] ? -1 : 1;
+    if (a[3] != b[3]) return a[3] < b[3] ? -1 : 1;
+    if (a[4] != b[4]) return a[4] > b[4] ? -1 : 1;
+    if (a[5] != b[5]) return a[5] > b[5] ? -1 : 1;
+    return 0;
+}
+
+/* sift_oracle.remove_duplicated_sorted: sorts kps [n][6] in place, returns the number kept */
+int oracle_sift_remove_duplicated_sorted(double *kps, int n)
+{
+    if (!kps || n < 0) return -1;
+    if (n < 2) return n;
+    qsort(kps, (size_t)n, 6 * sizeof(double), kp12_less);
+    int i = 0;
+    for (int j = 1; j < n; ++j) {
+        const double *k1 = kps + (size_t)i * 6, *k2 = kps + (size_t)j * 6;
+        if (k1[0] != k2[0] || k1[1] != k2[1] || k1[2] != k2[2] || k1[3] != k2[3]) {
+            ++i;
+            if (i != j) memcpy(kps + (size_t)i * 6, k2, 6 * sizeof(double));
+        }
+    }
+    return i + 1;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * The whole detector + descriptor in C (sift_oracle.detect_and_compute without its numpy glue):
  * grey image -> x2 bilinear -> Gaussian / DoG pyramid -> 26-neighbour extrema -> refinement,
  * orientation peaks -> descriptors.  OpenMP over rows / candidates / keypoints.  This is the CPU
  * baseline of bench.py's SIFT section; tests/test_oracle.py checks it against the numpy oracle.
- * Output order: octave, then layer, then row major, then peak -- the order detect() appends in.
+ * Output: duplicates removed and in OpenCV's order (KeyPointsFilter::removeDuplicatedSorted).
  * ------------------------------------------------------------------------------------------- */
 static void gaussian_taps(double sigma, float *k, int *r_out)
 {
@@ -536,23 +602,25 @@ int oracle_sift_detect(const uint8_t *gray, int h, int w, double *kps, uint8_t *
         H /= 2; W /= 2;
         if (H < 1 || W < 1) { n_oct = o + 1; break; }
     }
-    /* detectAndCompute: first octave is -1 -> input-image coordinates; KeyPoint fields are float32 */
+    /* detectAndCompute: removeDuplicatedSorted (also fixes the output order), then first octave
+     * is -1 -> input-image coordinates, then the descriptors in that order */
+    total = oracle_sift_remove_duplicated_sorted(kps, total);
 #pragma omp parallel for schedule(dynamic, 16)
     for (int k = 0; k < total; ++k) {
         double *q = kps + (size_t)k * 6;
         int oc = (int)q[5];
         oc = (oc & ~255) | ((oc - 1) & 255);
         q[5] = (double)oc;
-        q[0] = (double)(float)(q[0] * 0.5); q[1] = (double)(float)(q[1] * 0.5);
-        q[2] = (double)(float)(q[2] * 0.5); q[3] = (double)(float)q[3]; q[4] = (double)(float)q[4];
+        q[0] = (double)((float)q[0] * 0.5f); q[1] = (double)((float)q[1] * 0.5f);
+        q[2] = (double)((float)q[2] * 0.5f);
         int octave = oc & 255, layer = (oc >> 8) & 255;
         if (octave >= 128) octave |= -128;
-        const double scale = octave >= 0 ? 1.0 / (double)(1 << octave) : (double)(1 << -octave);
-        double a = 360.0 - q[3];
-        if (fabs(a - 360.0) < FLT_EPS) a = 0.0;
+        const float scale = octave >= 0 ? 1.f / (float)(1 << octave) : (float)(1 << -octave);
+        float a = 360.f - (float)q[3];
+        if (fabsf(a - 360.f) < (float)FLT_EPS) a = 0.f;
         const int oi = octave + 1;
-        descriptor_one(gauss[oi * (NL + 3) + layer], oh[oi], ow[oi], q[0] * scale, q[1] * scale, a,
-                       q[2] * scale * 0.5, desc + (size_t)k * 128);
+        descriptor_one(gauss[oi * (NL + 3) + layer], oh[oi], ow[oi], (float)q[0] * scale, (float)q[1] * scale, a,
+                       (float)q[2] * scale * 0.5f, desc + (size_t)k * 128);
     }
     for (int q = 0; q < n_oct * (NL + 3); ++q) free(gauss[q]);
     for (int q = 0; q < n_oct * (NL + 2); ++q) free(dogs[q]);

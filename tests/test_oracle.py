@@ -201,9 +201,67 @@ def test_c_keypoints_and_descriptors_equal_numpy_twins():
     ka, da = so.detect_and_compute(img, use_c=True)
     kb, db = so.detect_and_compute(img, use_c=False)
     assert len(ka) == len(kb) > 150
-    assert np.array_equal(ka[:, 5], kb[:, 5])
-    assert np.abs(ka[:, :5] - kb[:, :5]).max() < 1e-9       # same operations: libm's last bits at most
-    assert (da != db).mean() < 1e-3 and np.abs(da.astype(int) - db.astype(int)).max() <= 1
+    assert np.array_equal(ka, kb) and np.array_equal(da, db)   # the same float32 operations
+
+
+def test_opencv_float32_helpers():
+    """the scalar conventions the oracle restates: cv::fastAtan2's polynomial (good to ~0.3 deg,
+    45 deg comes out as 44.99...), exp32 (an expf within ~1 ulp), Matx33f::solve = Cramer's rule
+    (zero vector for a singular matrix)"""
+    import math
+    from oracle import sift_oracle as so
+    rng = np.random.default_rng(5)
+    for y, x in rng.normal(size=(2000, 2)) * 10:
+        want = math.degrees(math.atan2(np.float32(y), np.float32(x))) % 360.0
+        got = float(so.fast_atan2(y, x))
+        assert abs(((got - want) + 180.0) % 360.0 - 180.0) < 0.3
+    assert so.fast_atan2(0, 0) == 0 and so.fast_atan2(1, 0) == 90 and so.fast_atan2(0, -1) == 180
+    assert abs(float(so.fast_atan2(1, 1)) - 44.99046) < 1e-4       # the published value of the polynomial
+    for x in np.concatenate([-rng.uniform(0, 12, 3000), [0.0, -1e-8, -86.9, -88.0]]):
+        x = np.float32(x)
+        want = math.exp(float(x))
+        got = float(so.exp32(x))
+        assert got == 0.0 if x < -87 else abs(got - want) <= 1.5 * float(np.spacing(np.float32(want)))
+    A = rng.normal(size=(3, 3)).astype(np.float32)
+    b = rng.normal(size=3).astype(np.float32)
+    x = np.array(so._solve3_cramer(A.tolist() and [[np.float32(v) for v in r] for r in A],
+                                   [np.float32(v) for v in b]), np.float64)
+    assert np.allclose(x, np.linalg.solve(A.astype(np.float64), b.astype(np.float64)), rtol=1e-3, atol=1e-4)
+    sing = [[np.float32(1), np.float32(2), np.float32(3)]] * 3
+    assert [float(v) for v in so._solve3_cramer(sing, [np.float32(1)] * 3)] == [0.0, 0.0, 0.0]
+
+
+def test_remove_duplicated_sorted_semantics():
+    """KeyPointsFilter::removeDuplicatedSorted: KeyPoint12_LessThan order (x, y up; size down;
+    angle up; response down; octave down, compared BEFORE the first-octave adjustment), then
+    everything equal to the last kept row in (x, y, size, angle) goes -- numpy twin == C"""
+    import ctypes
+    from oracle import sift_oracle as so
+    oc = lambda o, layer: ((o - 1) & 255) | (layer << 8)          # as detectAndCompute reports it
+    rows = np.array([
+        [5.0, 1.0, 2.0, 30.0, 0.02, oc(0, 1)],
+        [5.0, 1.0, 2.0, 30.0, 0.05, oc(0, 1)],      # duplicate of row 0 with the HIGHER response: survives
+        [5.0, 1.0, 2.0, 10.0, 0.01, oc(0, 1)],      # same point, smaller angle: before both
+        [5.0, 1.0, 3.0, 10.0, 0.01, oc(0, 2)],      # larger size first
+        [4.0, 9.0, 2.0, 0.0, 0.01, oc(1, 1)],       # smaller x first of all
+        [5.0, 1.0, 2.0, 30.0, 0.05, oc(1, 1)],      # ties to row 1 up to the octave: higher octave first
+    ])
+    kept, idx, removed = so.remove_duplicated_sorted(rows)
+    assert idx.tolist() == [4, 3, 2, 5] and removed == 2
+    rng = np.random.default_rng(1)
+    big = rng.integers(0, 6, (4000, 6)).astype(np.float64)
+    big[:, 5] = [oc(int(a) % 4, 1 + int(b) % 3) for a, b in zip(big[:, 5], big[:, 4])]
+    big[:, 4] = (big[:, 4] + 1) / 64
+    kept, idx, removed = so.remove_duplicated_sorted(big)
+    buf = np.ascontiguousarray(big.copy())
+    # (the C comparator sees the packed octave the way findScaleSpaceExtrema wrote it)
+    pre = buf[:, 5].astype(np.int64)
+    buf[:, 5] = (pre & ~255) | ((pre + 1) & 255)
+    L = cpu_ref.lib()
+    L.oracle_sift_remove_duplicated_sorted.restype = ctypes.c_int
+    n = L.oracle_sift_remove_duplicated_sorted(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(len(buf)))
+    assert n == len(kept) and removed == len(big) - n
+    assert np.array_equal(buf[:n, :5], kept[:, :5])
 
 
 def test_all_c_sift_equals_the_oracle():
