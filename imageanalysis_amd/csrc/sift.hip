@@ -54,6 +54,18 @@ struct Taps {
     float k[MAX_TAPS];
 };
 
+// Workgroup b is observed to run on XCD b % 8, each XCD with its own 4 MB L2 (MI355X_MICROARCH.md,
+// workgroup dispatch): the bijective remap that hands every XCD a CONTIGUOUS range of tile numbers,
+// so that tiles side by side -- which share halo columns and the 128-byte lines a tile edge cuts
+// through -- are fetched into one L2 instead of two.  A placement guess: slower if wrong, never
+// incorrect.  IAMX_SIFT_NO_XCD=1 (read once) switches it off for A/B measurements.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg, int enabled)
+{
+    if (!enabled) return orig;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 __device__ __forceinline__ int reflect101(int p, int n)
 {
     if (n == 1) return 0;
@@ -116,17 +128,19 @@ constexpr int SB_TW = 64, SB_TH = 32, SB_RING = 64, SB_STRIP = 8;
 template <int R>
 __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict__ src, int h, int w,
                                                          Taps T, float *__restrict__ dst,
-                                                         float *__restrict__ dog, int seg_rows)
+                                                         float *__restrict__ dog, int seg_rows, int xcd)
 {
     static_assert(2 * R <= SB_RING - SB_TH, "the V window must fit the ring");
+    const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
+    const int tile_x = tile % (int)gridDim.x, tile_y = tile / (int)gridDim.x;
     constexpr int SW = SB_TW + 2 * R + 1;                 // (+1: odd row pitch)
     constexpr int HW = SB_TW + 1;
     constexpr int TILE = SB_TH * (SB_TW + 2 * R);         // source elements of an H block
     constexpr int PER = (TILE + 255) / 256;               // ... per thread
     __shared__ float S[SB_TH * SW];
     __shared__ float Hb[SB_RING * HW];
-    const int x0 = blockIdx.x * SB_TW;
-    const int y_begin = blockIdx.y * seg_rows;
+    const int x0 = tile_x * SB_TW;
+    const int y_begin = tile_y * seg_rows;
     const int y_end = min(y_begin + seg_rows, h);
     // The source rows of H block k + 1 are fetched into registers while block k is computed
     // (global -> register -> LDS: the load latency sits behind a block's ~430 FMAs per thread).
@@ -204,6 +218,12 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
     }
 }
 
+inline int xcd_enabled()
+{
+    static const int on = [] { const char *e = getenv("IAMX_SIFT_NO_XCD"); return (e && e[0] == '1') ? 0 : 1; }();
+    return on;
+}
+
 template <int R>
 void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
                        float *dog)
@@ -216,7 +236,7 @@ void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Tap
     int seg = (int)(((int64_t)h * strips / 768 + SB_TH - 1) / SB_TH) * SB_TH;
     seg = seg < SB_TH ? SB_TH : (seg > 256 ? 256 : seg);
     hipLaunchKernelGGL(blur_strip_kernel<R>, dim3(strips, (h + seg - 1) / seg), dim3(256), 0, st, src, h,
-                       w, tp, dst, dog, seg);
+                       w, tp, dst, dog, seg, xcd_enabled());
 }
 
 // every radius gaussian_taps() can produce (r <= 16)
@@ -261,8 +281,10 @@ constexpr int EXT_LIST = 512;     // candidates a workgroup collects before its 
 
 __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, int o,
                                                       float threshold, Cand *__restrict__ cand,
-                                                      int cap, int *__restrict__ count)
+                                                      int cap, int *__restrict__ count, int xcd)
 {
+    const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
+    const int tile_x = tile % (int)gridDim.x, tile_y = tile / (int)gridDim.x;
     // Candidates are ~1 % of the pixels; one global atomicAdd each on the single counter was the
     // whole cost of this kernel (~150 k same-address device-scope atomics per image = 0.75 ms).
     // A workgroup collects its candidates in LDS and reserves their slots with ONE atomic.
@@ -271,10 +293,10 @@ __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, 
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = BORDER + blockIdx.x * 62 - 1 + lane;
+    const int c = BORDER + tile_x * 62 - 1 + lane;
     const int cl = c < w - 1 ? c : w - 1;              // clamped: only feeds masked-out lanes
     const bool out = lane >= 1 && lane <= 62 && c < w - BORDER;
-    const int r0 = BORDER + (blockIdx.y * 4 + wave) * EXT_ROWS;
+    const int r0 = BORDER + (tile_y * 4 + wave) * EXT_ROWS;
     const int r1 = min(r0 + EXT_ROWS, h - BORDER);
     if (r0 < r1) {                                     // (whole wave)
         float v[NL + 2][3];                            // rows r - 1, r, r + 1 (rolling)
@@ -666,7 +688,7 @@ __device__ __forceinline__ void flush_keypoints(const float *__restrict__ kbuf, 
 __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *__restrict__ refined,
                                                      const int *__restrict__ n_refined, int cap_c,
                                                      float sigma, float *__restrict__ kp, int cap_k,
-                                                     int *__restrict__ n_kp)
+                                                     int *__restrict__ n_kp, int xcd)
 {
     __shared__ double hist_s[4][ORI_BINS];
     __shared__ float sm_s[4][ORI_BINS];
@@ -675,8 +697,19 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     const int total = *n_refined < cap_c ? *n_refined : cap_c;
     float *kbuf = kbuf_s[wave];
     int n_buf = 0;
-    // persistent waves (wave-uniform control flow; no block-level barriers below)
-    for (int idx = blockIdx.x * 4 + wave; idx < total; idx += gridDim.x * 4) {
+    // persistent waves (wave-uniform control flow; no block-level barriers below).  A wave takes
+    // runs of ORI_RUN consecutive candidates (the list is in the extrema scan's tile order:
+    // neighbours in the list are neighbours in the image, and so are the keypoints a wave appends
+    // together); the runs of one XCD's workgroups form a contiguous part of the list.
+    constexpr int ORI_RUN = 4;
+    const int n_runs = (total + ORI_RUN - 1) / ORI_RUN;
+    const int xcds = xcd ? 8 : 1;
+    const int my_xcd = xcd ? (int)(blockIdx.x & 7) : 0;
+    const int runs_per = (n_runs + xcds - 1) / xcds;
+    const int run_end = min((my_xcd + 1) * runs_per, n_runs);
+    const int wave_here = (int)(blockIdx.x / xcds) * 4 + wave, waves_here = (int)(gridDim.x / xcds) * 4;
+    for (int run = my_xcd * runs_per + wave_here; run < run_end; run += waves_here)
+    for (int idx = run * ORI_RUN; idx < min(run * ORI_RUN + ORI_RUN, total); ++idx) {
     const Refined R = refined[idx];
     const Pyr &P = T.oct[R.o];
     const int h = P.h, w = P.w, o = R.o, layer = R.layer, r = R.r, c = R.c;
@@ -768,7 +801,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 // one wave per keypoint: calcSIFTDescriptor
 __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
                                                          const int *__restrict__ n_kp, int cap_k,
-                                                         uint8_t *__restrict__ desc)
+                                                         uint8_t *__restrict__ desc, int xcd)
 {
     constexpr int d = 4, n = 8;
     constexpr int HB = (d + 2) * (d + 2) * (n + 2);       // 360
@@ -787,7 +820,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float
     // The grid is capped at 16 384 workgroups (the keypoint count is only known on the device:
     // a grid for the whole capacity dispatched up to 375 k workgroups that exit at once); images
     // with more than 65 536 keypoints give some waves a second one.
-    for (int k = blockIdx.x * 4 + wave; k < total; k += gridDim.x * 4) {
+    // The workgroups of one XCD walk a contiguous part of the list (appended by orient_kernel in
+    // runs of image neighbours): the windows an XCD's L2 sees overlap instead of being spread over
+    // the whole pyramid.
+    const int xcds = xcd ? 8 : 1;
+    const int my_xcd = xcd ? (int)(blockIdx.x & 7) : 0;
+    const int slab = ((total + xcds - 1) / xcds + 3) & ~3;
+    const int k_end = min((my_xcd + 1) * slab, total);
+    for (int k = my_xcd * slab + (int)(blockIdx.x / xcds) * 4 + wave; k < k_end; k += (int)(gridDim.x / xcds) * 4) {
     for (int i = lane; i < HB; i += 64) hist[i] = 0.0;
     __builtin_amdgcn_wave_barrier();
     {
@@ -1324,7 +1364,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
             hipLaunchKernelGGL(extrema_kernel,
                                dim3((unsigned)((W - 2 * BORDER + 61) / 62),
                                     (unsigned)((H - 2 * BORDER + 4 * EXT_ROWS - 1) / (4 * EXT_ROWS))),
-                               dim3(256), 0, q, D, H, W, o, threshold, cand, CAP_CAND, n_cand);
+                               dim3(256), 0, q, D, H, W, o, threshold, cand, CAP_CAND, n_cand, xcd_enabled());
         }
     };
     auto downsample = [&](hipStream_t q, int o) {
@@ -1384,12 +1424,12 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     // sized by the largest plausible count (threads beyond *n_cand exit immediately)
     hipLaunchKernelGGL(refine_kernel, dim3(blocks(CAP_CAND, 256)), dim3(256), 0, st, T, cand, n_cand,
                        CAP_CAND, contrast_threshold, edge_threshold, refined, n_refined);
-    hipLaunchKernelGGL(orient_kernel, dim3(256 * 8), dim3(256), 0, st, T, refined, n_refined,
-                       CAP_CAND, (float)sigma_d, kp, cap, n_out);
+    hipLaunchKernelGGL(orient_kernel, dim3(512 * 8), dim3(256), 0, st, T, refined, n_refined,
+                       CAP_CAND, (float)sigma_d, kp, cap, n_out, xcd_enabled());
     {
-        const unsigned g = blocks(cap, 4);
+        const unsigned g = (blocks(cap, 4) + 7u) & ~7u;     // (a multiple of 8: the XCD slabs)
         hipLaunchKernelGGL(descriptor_kernel, dim3(g < 16384u ? g : 16384u), dim3(256), 0, st, T, kp,
-                           n_out, cap, desc);
+                           n_out, cap, desc, xcd_enabled());
     }
     return iamx::check_launch("iamx_sift_detect");
 }
