@@ -1136,7 +1136,8 @@ __global__ __launch_bounds__(256) void sort_scatter_kernel(const float *__restri
 __global__ __launch_bounds__(256) void sort_rank_kernel(const SortKey *__restrict__ keys,
                                                         const int32_t *__restrict__ bucket_off,
                                                         int32_t *__restrict__ rank,
-                                                        int32_t *__restrict__ dup_at)
+                                                        unsigned *__restrict__ dup_bits,
+                                                        int32_t *__restrict__ tile_cnt)
 {
     const int n = bucket_off[SORT_BUCKETS];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1157,22 +1158,27 @@ __global__ __launch_bounds__(256) void sort_rank_kernel(const SortKey *__restric
         cnt += less;
         dup |= less && eq4;
     }
-    rank[i] = lo + cnt;
-    dup_at[lo + cnt] = dup ? 1 : 0;
+    const int r = lo + cnt;
+    rank[i] = r;
+    if (dup) {                                           // (rare: a handful per frame)
+        atomicOr(&dup_bits[r >> 5], 1u << (r & 31));
+        atomicAdd(&tile_cnt[r >> 8], 1);
+    }
 }
 
-// exclusive scan of the duplicate flags in sorted order (one workgroup, a contiguous chunk per
-// thread); n_sorted = keys kept
+// duplicates are flagged as bits at their sorted position (dup_bits) and counted per tile of 256
+// positions (tile_cnt): exclusive scan of the tile counts (one workgroup); n_sorted = rows kept
 __global__ __launch_bounds__(1024) void sort_compact_kernel(const int32_t *__restrict__ bucket_off,
-                                                            int32_t *__restrict__ dup_at,
+                                                            int32_t *__restrict__ tile_cnt,
                                                             int32_t *__restrict__ n_sorted)
 {
     __shared__ int part[1024];
     const int n = bucket_off[SORT_BUCKETS];
-    const int chunk = (n + 1023) / 1024;
-    const int lo = min((int)threadIdx.x * chunk, n), hi = min(lo + chunk, n);
+    const int tiles = (n + 255) >> 8;
+    const int chunk = (tiles + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * chunk, tiles), hi = min(lo + chunk, tiles);
     int sum = 0;
-    for (int j = lo; j < hi; ++j) sum += dup_at[j];
+    for (int j = lo; j < hi; ++j) sum += tile_cnt[j];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int sft = 1; sft < 1024; sft <<= 1) {
@@ -1183,16 +1189,17 @@ __global__ __launch_bounds__(1024) void sort_compact_kernel(const int32_t *__res
     }
     int run = part[threadIdx.x] - sum;
     for (int j = lo; j < hi; ++j) {
-        const int f = dup_at[j];
-        dup_at[j] = f ? -1 : run;                      // dropped, or the number of drops before j
-        run += f;
+        const int c = tile_cnt[j];
+        tile_cnt[j] = run;                             // drops before the tile
+        run += c;
     }
     if (threadIdx.x == 1023) *n_sorted = n - part[1023];
 }
 
 __global__ __launch_bounds__(256) void sort_gather_kernel(const SortKey *__restrict__ keys,
                                                           const int32_t *__restrict__ rank,
-                                                          const int32_t *__restrict__ dup_at,
+                                                          const unsigned *__restrict__ dup_bits,
+                                                          const int32_t *__restrict__ tile_off,
                                                           const int32_t *__restrict__ bucket_off,
                                                           const float *__restrict__ kp,
                                                           const uint8_t *__restrict__ desc,
@@ -1203,8 +1210,11 @@ __global__ __launch_bounds__(256) void sort_gather_kernel(const SortKey *__restr
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int i = t >> 3, part = t & 7;
     if (i >= n) return;
-    const int r = rank[i], before = dup_at[r];
-    if (before < 0) return;
+    const int r = rank[i];
+    const unsigned word = dup_bits[r >> 5];
+    if ((word >> (r & 31)) & 1u) return;               // a duplicate: dropped
+    int before = tile_off[r >> 8] + __popc(word & ((1u << (r & 31)) - 1u));
+    for (int w = (r >> 8) << 3; w < (r >> 5); ++w) before += __popc(dup_bits[w]);
     const int src = keys[i].orig, dst = r - before;
     out_kp[(int64_t)dst * 8 + part] = kp[(int64_t)src * 8 + part];
     reinterpret_cast<uint4 *>(out_desc + (int64_t)dst * 128)[part] =
@@ -1429,7 +1439,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     {
         const unsigned g = (blocks(cap, 4) + 7u) & ~7u;     // (a multiple of 8: the XCD slabs)
         hipLaunchKernelGGL(descriptor_kernel, dim3(g < 16384u ? g : 16384u), dim3(256), 0, st, T, kp,
-                           n_out, cap, desc, xcd_enabled());
+                           n_out, cap, desc, 0);     // (XCD slabs: -21 % traffic but +6 % time, profiles/r4_sift_ab.txt)
     }
     return iamx::check_launch("iamx_sift_detect");
 }
@@ -1437,7 +1447,8 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
 extern "C" int64_t iamx_sift_sort_workspace_bytes(int cap)
 {
     if (cap < 1) return 0;
-    return (int64_t)cap * (int64_t)(sizeof(SortKey) + 8) + (3 * SORT_BUCKETS + 4) * 4 + 256;
+    return (int64_t)cap * (int64_t)(sizeof(SortKey) + 4) + ((int64_t)cap / 32 + cap / 256 + 4) * 4 +
+           (3 * SORT_BUCKETS + 4) * 4 + 256;
 }
 
 // detectAndCompute's removeDuplicatedSorted on the lists iamx_sift_detect appended (n_out DEV [1]
@@ -1457,21 +1468,23 @@ extern "C" int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_
     char *ws = static_cast<char *>(workspace);
     SortKey *keys = reinterpret_cast<SortKey *>(ws);
     int32_t *rank = reinterpret_cast<int32_t *>(ws + (int64_t)cap * sizeof(SortKey));
-    int32_t *dup_at = rank + cap;
-    int32_t *bucket_cnt = dup_at + cap;
+    // [dup_bits | tile_cnt | bucket_cnt] are zeroed together
+    unsigned *dup_bits = reinterpret_cast<unsigned *>(rank + cap);
+    int32_t *tile_cnt = reinterpret_cast<int32_t *>(dup_bits + cap / 32 + 1);
+    int32_t *bucket_cnt = tile_cnt + cap / 256 + 1;
     int32_t *bucket_off = bucket_cnt + SORT_BUCKETS;
     int32_t *bucket_fill = bucket_off + SORT_BUCKETS + 1;
     const SortParams P{order, (float)width, (float)height};
-    (void)hipMemsetAsync(bucket_cnt, 0, SORT_BUCKETS * 4, st);
+    (void)hipMemsetAsync(dup_bits, 0, ((size_t)cap / 32 + 1 + cap / 256 + 1 + SORT_BUCKETS) * 4, st);
     const unsigned g = blocks(cap, 256);
     hipLaunchKernelGGL(sort_count_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, P, bucket_cnt);
     hipLaunchKernelGGL(sort_offsets_kernel, dim3(1), dim3(1024), 0, st, bucket_cnt, bucket_off, bucket_fill);
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(g), dim3(256), 0, st, kp, n_out, cap, P, bucket_off,
                        bucket_fill, keys);
-    hipLaunchKernelGGL(sort_rank_kernel, dim3(g), dim3(256), 0, st, keys, bucket_off, rank, dup_at);
-    hipLaunchKernelGGL(sort_compact_kernel, dim3(1), dim3(1024), 0, st, bucket_off, dup_at, n_sorted);
+    hipLaunchKernelGGL(sort_rank_kernel, dim3(g), dim3(256), 0, st, keys, bucket_off, rank, dup_bits, tile_cnt);
+    hipLaunchKernelGGL(sort_compact_kernel, dim3(1), dim3(1024), 0, st, bucket_off, tile_cnt, n_sorted);
     hipLaunchKernelGGL(sort_gather_kernel, dim3(blocks((int64_t)cap * 8, 256)), dim3(256), 0, st, keys,
-                       rank, dup_at, bucket_off, kp, desc, out_kp, out_desc);
+                       rank, dup_bits, tile_cnt, bucket_off, kp, desc, out_kp, out_desc);
     return iamx::check_launch("iamx_sift_sort");
 }
 
