@@ -13,6 +13,7 @@
 // size zlib level 1 gives.  Any gzip reader (gzip.open + np.load in the reference) gets the bytes
 // np.save would have written.
 #include "iamx_common.h"
+#include <mutex>
 
 #include <algorithm>
 #include <cstring>
@@ -114,11 +115,12 @@ void canonical_codes(const uint8_t *len, int n_sym, uint16_t *code /* bit revers
 }
 
 uint32_t g_crc[16][256];
-bool g_crc_ready = false;
+std::once_flag g_crc_once;
 
-void crc_tables()
+// (called with the GIL released from many writer threads: built exactly once, with the ordering
+//  std::call_once gives between the table stores and every later reader)
+void crc_tables_build()
 {
-    if (g_crc_ready) return;
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
@@ -131,8 +133,9 @@ void crc_tables()
             g_crc[t][i] = c;
         }
     }
-    g_crc_ready = true;
 }
+
+void crc_tables() { std::call_once(g_crc_once, crc_tables_build); }
 
 }  // namespace
 

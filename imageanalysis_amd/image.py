@@ -395,7 +395,11 @@ def _prefetch_job(self):
                 # coefficients go up and become pixels while the detector works on an earlier
                 # frame; the main thread receives a finished frame in HBM
                 import torch
-                with torch.cuda.stream(_worker_stream()), kernels.polite_waits():
+                # the current HIP device is per host thread: a fresh worker starts on device 0,
+                # not on the device prefetch() was called under (a rank with LOCAL_RANK != 0)
+                dev = getattr(self, '_iamx_prefetch_device', None)
+                with torch.cuda.device(dev if dev is not None else torch.cuda.current_device()), \
+                        torch.cuda.stream(_worker_stream()), kernels.polite_waits():
                     bgr = kernels.jpeg_reconstruct(jc)       # (waits for this stream only)
                     scale = getattr(self, '_iamx_prefetch_scale', None)
                     if scale is not None:
@@ -414,12 +418,16 @@ _worker_streams = __import__('threading').local()
 
 
 def _worker_stream():
-    """one HIP stream per prefetch worker thread (uploads + JPEG reconstruction off the
-    detector's stream)"""
+    """one HIP stream per prefetch worker thread AND device (uploads + JPEG reconstruction off the
+    detector's stream); created on the thread's current device"""
     import torch
-    st = getattr(_worker_streams, 'stream', None)
+    streams = getattr(_worker_streams, 'streams', None)
+    if streams is None:
+        streams = _worker_streams.streams = {}
+    dev = torch.cuda.current_device()
+    st = streams.get(dev)
     if st is None:
-        st = _worker_streams.stream = torch.cuda.Stream()
+        st = streams[dev] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -430,8 +438,16 @@ def prefetch(images, depth=None, scale=None):
     (kernels.DETECT_SLOTS at a time).  Returns the cacheio.Prefetch (close() it)."""
     todo = [im for im in images if getattr(im, 'image_file', None) or
             os.path.exists(getattr(im, 'features_file', '') or '')]
+    dev = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            dev = torch.cuda.current_device()          # the workers run their device half THERE
+    except ImportError:                                # pragma: no cover
+        pass
     for im in todo:
         im._iamx_prefetch_scale = scale
+        im._iamx_prefetch_device = dev
     pf = cacheio.Prefetch(_prefetch_job, todo, PREFETCH_DEPTH if depth is None else depth)
     for im in todo:
         im._iamx_prefetch = pf

@@ -94,10 +94,23 @@ class KeyPointList(Sequence):
         out = np.empty(h + n * _REC.itemsize + len(_TAIL), np.uint8)
         out[:h] = np.frombuffer(_HEAD, np.uint8)
         out[h + n * _REC.itemsize:] = np.frombuffer(_TAIL, np.uint8)
+        try:
+            L = _lib.lib()
+        except (OSError, _lib.IamxError):
+            # no libiamx.so (a CPU-only tool re-saving a .feat): the same bytes from numpy -- this
+            # is file formatting, not the compute path, which has no fallback
+            rec = out[h:h + n * _REC.itemsize].view(_REC)
+            for name, op in _OPS:
+                rec[name] = op
+            for name in _COLS:
+                rec[name] = getattr(self, name)
+            rec['octave'] = self.octave
+            rec['class_id'] = self.class_id
+            return memoryview(out) if as_view else out.tobytes()
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        _lib.check(_lib.lib().iamx_feat_records(p(self.x), p(self.y), p(self.size), p(self.angle),
-                                                p(self.response), p(self.octave), p(self.class_id), n,
-                                                ctypes.c_void_p(out.ctypes.data + h)),
+        _lib.check(L.iamx_feat_records(p(self.x), p(self.y), p(self.size), p(self.angle),
+                                       p(self.response), p(self.octave), p(self.class_id), n,
+                                       ctypes.c_void_p(out.ctypes.data + h)),
                    'iamx_feat_records')
         return memoryview(out) if as_view else out.tobytes()
 

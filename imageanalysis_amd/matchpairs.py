@@ -300,10 +300,13 @@ class MatchDict(dict):
         other, seq = pend
         names = self._ledger.names
         sq = self._seq or {}
-        old = [(k, v) for k, v in items if k not in sq]
         have = dict.__contains__
+        # a quiet pair whose key was there before the call keeps its place but NOT its value: the
+        # reference assigns match_list[name] = [] unconditionally (lib/matcher.py:978-979), so a
+        # stale one-sided entry (an interrupted save) does not survive the retry
+        redone = set(names[o] for o in other.tolist() if have(self, names[o]) and names[o] not in sq)
+        old = [(k, EMPTY if k in redone else v) for k, v in items if k not in sq]
         new = [(sq[k], k, v) for k, v in items if k in sq]
-        # a retried pair that stayed empty is already there (as []): its place does not move
         quiet = [(s, names[o], EMPTY) for o, s in zip(other.tolist(), seq.tolist())
                  if not have(self, names[o])]
         merged = sorted(new + quiet, key=lambda t: t[0]) if new else quiet

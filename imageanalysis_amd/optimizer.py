@@ -392,6 +392,11 @@ class Optimizer():
         _log("Starting mean reprojection error: %.2f" % mre_start)
         _log("Final mean reprojection error: %.2f" % mre_final)
         _log("Iterations:", res.njev)
+        if getattr(res, 'inner_solver', None):
+            # which linear solver produced the Gauss-Newton steps (the reference's least_squares
+            # uses LSMR on the full system; the default here is the Schur complement form, see
+            # INTEGRATION.md "Solver")
+            _log("Inner solver:", res.inner_solver)
         _log("Elapsed time = %.1f sec" % (t1 - t0))
         if self.optimize_calib == 'global':
             _log("Final camera calib:\n", camera_calib)

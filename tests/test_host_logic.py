@@ -543,3 +543,43 @@ def test_detector_slots_are_private_per_thread_and_always_returned():
     assert sorted(x.slot for x in got) == list(range(1, kernels.DETECT_SLOTS + 1))
     for s in got:
         s.__exit__(None, None, None)
+
+
+def test_quiet_pair_overwrites_a_stale_entry():
+    """the reference assigns match_list[name] = [] for a pair without matches
+    unconditionally (scripts/lib/matcher.py:978-979).  A one-sided non-empty entry left by an
+    interrupted save must not survive the retry: value replaced in place, key order kept."""
+    from imageanalysis_amd.matchpairs import MatchDict, QuietLedger
+    names = ['a', 'b', 'c']
+    led = QuietLedger(names)
+    da, db = MatchDict({'c': [[5, 6]], 'b': [[1, 2]]}), MatchDict()
+    da.attach(led, 0)
+    db.attach(led, 1)
+    led.add([0], [1], [7])                               # pair (a, b) ended without matches
+    assert da.entries() == [('c', [[5, 6]]), ('b', [])] or \
+        [(k, list(v)) for k, v in da.entries()] == [('c', [[5, 6]]), ('b', [])]
+    assert [(k, list(v)) for k, v in db.entries()] == [('a', [])]
+    import pickle
+    assert pickle.loads(pickle.dumps(da)) == {'c': [[5, 6]], 'b': []}
+    assert list(pickle.loads(pickle.dumps(da)).keys()) == ['c', 'b']
+    assert dict(db) == {'a': []}
+
+
+def test_feat_bytes_without_the_library(monkeypatch):
+    """KeyPointList.feat_bytes() is file formatting; without libiamx.so (a CPU-only
+    tool re-saving a .feat) it writes the same bytes from numpy instead of raising"""
+    import pickle
+    from imageanalysis_amd import _lib
+    from imageanalysis_amd.keypoints import KeyPointList
+    rng = np.random.default_rng(4)
+    n = 300
+    kl = KeyPointList(rng.uniform(0, 5000, n), rng.uniform(0, 3000, n), rng.uniform(1, 9, n),
+                      rng.uniform(0, 360, n), rng.uniform(0, 0.1, n), rng.integers(0, 1 << 24, n))
+    with_lib = kl.feat_bytes()
+
+    def no_lib():
+        raise _lib.IamxError("libiamx.so not found (test)")
+    monkeypatch.setattr(_lib, 'lib', no_lib)
+    assert kl.feat_bytes() == with_lib
+    rows = pickle.loads(with_lib)
+    assert len(rows) == n and rows[7][0] == (float(kl.x[7]), float(kl.y[7])) and rows[7][5] == -1
