@@ -107,11 +107,12 @@ SIGNATURES = {
     'iamx_ba_accumulate': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int] + [c_void_p] * 5),
     'iamx_ba_block_diag': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'iamx_ba_schur_state_size': (c_int, []),
-    'iamx_ba_schur_prepare': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int] + [c_void_p] * 9),
-    'iamx_ba_schur_factor': (c_int, [c_void_p] * 3 + [c_int, c_double, c_double, c_int] + [c_void_p] * 8),
-    'iamx_ba_schur_iterate': (c_int, [c_void_p] * 7 + [c_int64, c_int, c_int] + [c_void_p] * 14
+    'iamx_ba_schur_prepare': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int] + [c_void_p] * 10),
+    'iamx_ba_schur_factor': (c_int, [c_void_p] * 3 + [c_int, c_int, c_int, c_double, c_double, c_int]
+                             + [c_void_p] * 8),
+    'iamx_ba_schur_iterate': (c_int, [c_void_p] * 8 + [c_int64, c_int, c_int] + [c_void_p] * 15
                               + [c_int, c_int, c_int, c_void_p]),
-    'iamx_ba_schur_finish': (c_int, [c_void_p] * 5 + [c_int64, c_int, c_int, c_int, c_int]
+    'iamx_ba_schur_finish': (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int, c_int, c_int]
                              + [c_void_p] * 8),
     'iamx_comm_unique_id': (c_int, [c_void_p]),
     'iamx_comm_init': (c_int, [c_int, c_int, c_void_p, c_void_p]),

@@ -752,37 +752,43 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
     eta = prob.schur_eta if eta is None else float(eta)
     maxiter = int(prob.schur_max_iter if maxiter is None else maxiter)
     ws = prob.schur_ws
+    wc = prob.with_calib
+    nq = C * 7 + (8 if wc else 0)        # the reduced system: cameras (+ the calibration block)
+    Jk = _ptr(prob.Jk) if wc else None
     if ws is None:
         z = lambda k: torch.zeros(max(int(k), 1), dtype=F64, device=dev)
         ns = int(L.iamx_ba_schur_state_size())
-        ws = prob.schur_ws = dict(Y=z(P * 6), yg=z(P * 3), zp=z(P * 3), sraw=z(C * 35), minv=z(C * 28),
-                                  t=z(2 * O), qraw=z(C * 7), part=z(2 * C), x=z(C * 7), r=z(C * 7), z=z(C * 7),
-                                  p=z(C * 7), y=z(C * 7), state=z(ns), step=z(n),
+        ws = prob.schur_ws = dict(Y=z(P * 6), yg=z(P * 3), zp=z(P * 3), sraw=z(C * 35 + 44), minv=z(C * 28 + 36),
+                                  t=z(2 * O), qraw=z(C * 7 + 8), part=z(2 * C + 2), x=z(C * 7 + 8), r=z(C * 7 + 8),
+                                  z=z(C * 7 + 8), p=z(C * 7 + 8), y=z(C * 7 + 8), state=z(ns), step=z(n),
+                                  ck=z(C * 44) if wc else None,
                                   pin=(torch.empty(ns, dtype=F64).pin_memory(),
                                        torch.empty(ns, dtype=F64).pin_memory()),
                                   ev=(torch.cuda.Event(), torch.cuda.Event()))
+    ck = _ptr(ws['ck']) if wc else None
     ph = _Phase(prob, 'schur:prepare')
     ph.__enter__()
     a = prob.accumulate()
     nc = C * 7
     gp = _lib.c_void_p(a['g'].data_ptr() + 8 * nc)
-    check(L.iamx_ba_schur_prepare(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.r), _ptr(prob.cam_ptr),
+    check(L.iamx_ba_schur_prepare(_ptr(prob.Jc), _ptr(prob.Jp), Jk, _ptr(prob.r), _ptr(prob.cam_ptr),
                                   _ptr(prob.pt_idx), O, C, P, _ptr(a['V']), gp, _ptr(d_dev),
                                   _ptr(dreg_dev), _ptr(ws['Y']), _ptr(ws['yg']), _ptr(ws['zp']),
-                                  _ptr(ws['sraw']), stream_ptr()), 'iamx_ba_schur_prepare')
+                                  _ptr(ws['sraw']), ck, stream_ptr()), 'iamx_ba_schur_prepare')
     if multi:
-        _dist.allreduce_sum_(ws['sraw'][:C * 35])
-    check(L.iamx_ba_schur_factor(_ptr(ws['sraw']), _ptr(d_dev), _ptr(dreg_dev), C, eta, qtol, maxiter,
+        _dist.allreduce_sum_(ws['sraw'][:C * 35 + (44 if wc else 0)])
+    check(L.iamx_ba_schur_factor(_ptr(ws['sraw']), _ptr(d_dev), _ptr(dreg_dev), C, P, 1 if wc else 0,
+                                 eta, qtol, maxiter,
                                  _ptr(ws['minv']), _ptr(ws['x']), _ptr(ws['r']), _ptr(ws['z']),
                                  _ptr(ws['p']), _ptr(ws['y']), _ptr(ws['state']), stream_ptr()),
           'iamx_ba_schur_factor')
     ph.__exit__()
     ph = _Phase(prob, 'schur:iterate')
     ph.__enter__()
-    it_args = (_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx), _ptr(prob.pt_idx), _ptr(prob.cam_ptr),
+    it_args = (_ptr(prob.Jc), _ptr(prob.Jp), Jk, _ptr(prob.cam_idx), _ptr(prob.pt_idx), _ptr(prob.cam_ptr),
                _ptr(prob.pt_ptr), _ptr(prob.pt_obs), O, C, P, _ptr(d_dev), _ptr(dreg_dev),
                _ptr(ws['Y']), _ptr(ws['minv']), _ptr(ws['t']), _ptr(ws['zp']), _ptr(ws['qraw']),
-               _ptr(ws['part']), _ptr(ws['x']), _ptr(ws['r']), _ptr(ws['z']), _ptr(ws['p']), _ptr(ws['y']),
+               _ptr(ws['part']), ck, _ptr(ws['x']), _ptr(ws['r']), _ptr(ws['z']), _ptr(ws['p']), _ptr(ws['y']),
                _ptr(ws['state']))
 
     enqueued = [0]          # iterations enqueued since the factorisation (selects the state buffer)
@@ -795,7 +801,7 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
             return
         for i in range(chunk):
             check(L.iamx_ba_schur_iterate(*it_args, k + i, 1, 0, stream_ptr()), 'iamx_ba_schur_iterate')
-            _dist.allreduce_sum_(ws['qraw'][:nc])
+            _dist.allreduce_sum_(ws['qraw'][:nq])
             check(L.iamx_ba_schur_iterate(*it_args, k + i, 1, 1, stream_ptr()), 'iamx_ba_schur_iterate')
         prob.fused_phase_iterations += chunk
 
@@ -828,13 +834,13 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
     ph.__exit__()
     ph = _Phase(prob, 'schur:finish')
     ph.__enter__()
-    check(L.iamx_ba_schur_finish(_ptr(prob.Jc), _ptr(prob.Jp), _ptr(prob.cam_idx), _ptr(prob.pt_ptr),
+    check(L.iamx_ba_schur_finish(_ptr(prob.Jc), _ptr(prob.Jp), Jk, _ptr(prob.cam_idx), _ptr(prob.pt_ptr),
                                  _ptr(prob.pt_obs), O, C, P, prob.pt_lo, prob.pt_hi, _ptr(d_dev),
                                  _ptr(ws['Y']), _ptr(ws['yg']), _ptr(ws['x']), _ptr(ws['y']),
                                  _ptr(ws['t']), _ptr(ws['step']), stream_ptr()),
           'iamx_ba_schur_finish')
     if multi:
-        _dist.allreduce_sum_(ws['step'][nc:n])
+        _dist.allreduce_sum_(ws['step'][nc:nc + 3 * P])      # (the calibration entries are replicated)
     ph.__exit__()
     itn = int(st[2])
     prob.inner_iterations.append(itn)
@@ -847,9 +853,10 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
 def lsmr(prob, d_dev, dreg_dev, **opts):
     """The Gauss-Newton subproblem of one outer iteration: the Schur-complement solve
     (prob.inner == 'schur', default), else LSMR on the whole system as SciPy does it -- fused
-    host-free iterations when the problem allows it, else the stepwise form.  Calibration
-    columns (dense, shared by every observation) only have the stepwise LSMR."""
-    if prob.inner == 'schur' and not prob.with_calib and prob.C and (prob.O or prob.world > 1):
+    host-free iterations when the problem allows it, else the stepwise form (the only LSMR form
+    with calibration columns)."""
+    if prob.inner == 'schur' and prob.C and (prob.O or prob.world > 1):
+        # (with calibration columns: the bordered form, csrc/ba_schur.hip)
         return schur_solve(prob, d_dev, dreg_dev, to_host=opts.get('to_host', True))
     if not prob.with_calib and not prob.force_stepwise_lsmr and (prob.O or prob.world > 1):
         r = lsmr_device_fused(prob, d_dev, dreg_dev, **opts)
@@ -1429,7 +1436,7 @@ def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None, inner=None):
     if inner is not None:
         prob.inner = inner
     res = trf_device(prob, x0, lb, ub, ftol=ftol, verbose=verbose, max_nfev=max_nfev)
-    res.inner_solver = prob.inner if not wc else 'lsmr'
+    res.inner_solver = prob.inner
     prob.set_x(res.x)
     prob.residual()
     res.fun = gather_residual(prob, opt.camera_indices.size)

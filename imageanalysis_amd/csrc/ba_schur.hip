@@ -25,6 +25,15 @@
 // (U, g_c, the diagonal blocks of S, its right-hand side, q) is a partial sum the caller
 // all-reduces -- C x (49 + 7) and C x 35 doubles once per outer iteration, C x 7 doubles per CG
 // iteration; the scalars of the recurrence are replicated.  No atomics: bitwise reproducible.
+//
+// optimize_calib='global' (scripts/lib/optimizer.py:142-169,181-189: 8 calibration columns shared
+// by every observation) is the BORDERED form of the same system: the calibration block k joins the
+// camera side, q = [p_c; p_k], S q = [Jc Jk]^T (I - Jp V'^-1 Jp^T) [Jc Jk] q + Dreg^2 q.  The
+// passes above carry the extra term (t += Jk (D_k y_k) in schur_fwd, q_k = D_k sum_o Jk_o^T e_o as
+// per-camera partials of schur_adj + one small reduction), the preconditioner gets an 8x8 block
+// (D_k (sum Jk^T Jk) D_k + Dreg_k^2)^-1 -- the calibration block of the normal equations, without
+// its Schur correction, which couples all observations of a point --, and the recurrence treats
+// the block as one more "camera" of 8 parameters stored behind the 7 C camera entries.
 #include "iamx_common.h"
 
 namespace {
@@ -34,6 +43,9 @@ constexpr int ST_RZ = 0, ST_RZ0 = 1, ST_ITER = 2, ST_STOP = 3, ST_ETA = 4, ST_MA
 
 // index of (i, j), i <= j, in the packed upper triangle of a 7x7 symmetric matrix
 __host__ __device__ constexpr int tri7(int i, int j) { return i * 7 - i * (i - 1) / 2 + (j - i); }
+// ... of an 8x8 one (the calibration block): 36 entries
+__host__ __device__ constexpr int tri8(int i, int j) { return i * 8 - i * (i - 1) / 2 + (j - i); }
+constexpr int NK = 8, NK_TRI = 36;
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -167,13 +179,22 @@ __global__ __launch_bounds__(256) void schur_points_kernel(const double *__restr
 }
 
 // ---- the three passes of  q = S y ----------------------------------------------------------------
+// Jk / yk: the calibration columns [O][2][8] and the 8 scaled calibration entries of y (nullptr
+// without them)
 __global__ __launch_bounds__(256) void schur_fwd_kernel(const double *__restrict__ Jc,
+                                                        const double *__restrict__ Jk,
                                                         const int32_t *__restrict__ cam_idx,
                                                         int64_t n_obs, const double *__restrict__ yv,
+                                                        const double *__restrict__ yk,
                                                         const double *__restrict__ state,
                                                         double *__restrict__ t)
 {
     if (state && state[ST_STOP] != 0.0) return;
+    double ykr[NK];
+    if (Jk) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) ykr[k] = yk[k];
+    }
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n_obs;
          o += (int64_t)gridDim.x * 256) {
         const double *y = yv + (int64_t)cam_idx[o] * 7;
@@ -184,6 +205,14 @@ __global__ __launch_bounds__(256) void schur_fwd_kernel(const double *__restrict
             const double v = y[k];
             a += jc[k] * v;
             b += jc[7 + k] * v;
+        }
+        if (Jk) {
+            const double *jk = Jk + o * 16;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                a += jk[k] * ykr[k];
+                b += jk[NK + k] * ykr[k];
+            }
         }
         *reinterpret_cast<double2 *>(t + 2 * o) = make_double2(a, b);
     }
@@ -241,9 +270,12 @@ __global__ __launch_bounds__(256) void schur_pt_kernel(const double *__restrict_
 // BLOCKS = true : the same with t = r (the right-hand side of the reduced system) and the
 //                 camera's diagonal block of S before regularisation,
 //                 d_c d_c^T .* sum Jc^T (I - Jp (D_p Y D_p) Jp^T) Jc   (28 unique)  -> sraw[c][35]
-template <bool BLOCKS>
+// CALIB: additionally the camera's partial sums of the calibration block, unscaled, to
+//         ckpart[c][KC]: sum Jk^T e (8); with BLOCKS in front of them sum Jk^T Jk (36 unique)
+template <bool BLOCKS, bool CALIB>
 __global__ __launch_bounds__(256) void schur_adj_kernel(const double *__restrict__ Jc,
                                                         const double *__restrict__ Jp,
+                                                        const double *__restrict__ Jk,
                                                         const int32_t *__restrict__ cam_ptr,
                                                         const int32_t *__restrict__ pt_idx,
                                                         const double *__restrict__ t,
@@ -255,9 +287,12 @@ __global__ __launch_bounds__(256) void schur_adj_kernel(const double *__restrict
                                                         const double *__restrict__ pv,
                                                         const double *__restrict__ dreg_c,
                                                         double *__restrict__ pqpart,
-                                                        double *__restrict__ out)
+                                                        double *__restrict__ out,
+                                                        double *__restrict__ ckpart)
 {
-    constexpr int K = BLOCKS ? 35 : 7;
+    constexpr int KB = BLOCKS ? 35 : 7;                  // camera sums
+    constexpr int KC = CALIB ? (BLOCKS ? NK_TRI + NK : NK) : 0;
+    constexpr int K = KB + KC;
     __shared__ double sh[4 * K];
     if (!BLOCKS && state && state[ST_STOP] != 0.0) return;
     const int c = blockIdx.x;
@@ -307,9 +342,29 @@ __global__ __launch_bounds__(256) void schur_adj_kernel(const double *__restrict
         constexpr int B = BLOCKS ? 28 : 0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) acc[B + k] += j0[k] * e0 + j1[k] * e1;
+        if (CALIB) {
+            const double *jk = Jk + (int64_t)o * 16;
+            double k0[NK], k1[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { k0[k] = jk[k]; k1[k] = jk[NK + k]; }
+            constexpr int BK = KB + (BLOCKS ? NK_TRI : 0);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[BK + k] += k0[k] * e0 + k1[k] * e1;
+            if (BLOCKS) {
+#pragma unroll
+                for (int i = 0; i < NK; ++i) {
+#pragma unroll
+                    for (int j = i; j < NK; ++j) acc[KB + tri8(i, j)] += k0[i] * k0[j] + k1[i] * k1[j];
+                }
+            }
+        }
     }
     block_sum_k<K>(acc, sh);
     if (threadIdx.x == 0) {
+        if (CALIB) {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) ckpart[(int64_t)c * KC + k] = acc[KB + k];
+        }
         const double *dc = d_c + (int64_t)c * 7;
         if (BLOCKS) {
             double *s = out + (int64_t)c * 35;
@@ -333,6 +388,120 @@ __global__ __launch_bounds__(256) void schur_adj_kernel(const double *__restrict
             if (pqpart) pqpart[c] = s;
         }
     }
+}
+
+// The calibration partials of schur_adj summed over the cameras (one workgroup), scaled:
+// KC = 8 : qk[k] = d_k[k] * sum_c ckpart[c][k]; with pqslot also p_k . (q_k + Dreg_k^2 p_k)
+// KC = 44: sk[tri8(i,j)] = d_k[i] d_k[j] * sum (36), sk[36 + k] = d_k[k] * sum (the right-hand side)
+template <int KC>
+__global__ __launch_bounds__(256) void schur_calib_reduce_kernel(const double *__restrict__ ckpart,
+                                                                 int n_cams,
+                                                                 const double *__restrict__ d_k,
+                                                                 const double *__restrict__ dreg_k,
+                                                                 const double *__restrict__ pk,
+                                                                 const double *__restrict__ state,
+                                                                 double *__restrict__ outk,
+                                                                 double *__restrict__ pqslot)
+{
+    __shared__ double sh[4 * KC];
+    if (state && state[ST_STOP] != 0.0) return;
+    double acc[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc[k] = 0.0;
+    for (int c = threadIdx.x; c < n_cams; c += 256) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) acc[k] += ckpart[(int64_t)c * KC + k];
+    }
+    block_sum_k<KC>(acc, sh);
+    if (threadIdx.x == 0) {
+        if (KC == NK) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const double q = d_k[k] * acc[k];
+                outk[k] = q;
+                if (pqslot) s += pk[k] * (q + dreg_k[k] * dreg_k[k] * pk[k]);
+            }
+            if (pqslot) *pqslot = s;
+        } else {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+#pragma unroll
+                for (int j = i; j < NK; ++j) outk[tri8(i, j)] = d_k[i] * d_k[j] * acc[tri8(i, j)];
+                outk[NK_TRI + i] = d_k[i] * acc[NK_TRI + i];
+            }
+        }
+    }
+}
+
+// symmetric 8x8 (packed upper triangle) times vector
+__device__ __forceinline__ void sym8_apply(const double *__restrict__ m /* 36 */, const double *v,
+                                           double *out)
+{
+    for (int i = 0; i < NK; ++i) out[i] = 0.0;
+    for (int i = 0; i < NK; ++i) {
+        for (int j = i; j < NK; ++j) {
+            const double a = m[tri8(i, j)];
+            out[i] += a * v[j];
+            if (j != i) out[j] += a * v[i];
+        }
+    }
+}
+
+// the calibration block of the preconditioner and of the start of the recurrence (one thread):
+// a = sk (scaled) + Dreg_k^2, M_k = a^-1 through a Cholesky factorisation (diagonal fallback),
+// x_k = 0, r_k = rhs_k, z_k = p_k = M_k r_k, y_k = d_k .* p_k.  Returns r_k . z_k.
+__device__ double calib_factor(const double *__restrict__ sk, const double *__restrict__ d_k,
+                               const double *__restrict__ dreg_k, double *__restrict__ mk,
+                               double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                               double *__restrict__ pv, double *__restrict__ yv)
+{
+    double a[NK][NK], L[NK][NK], Li[NK][NK];
+    for (int i = 0; i < NK; ++i)
+        for (int j = i; j < NK; ++j) a[i][j] = a[j][i] = sk[tri8(i, j)] + (i == j ? dreg_k[i] * dreg_k[i] : 0.0);
+    bool ok = true;
+    for (int j = 0; j < NK; ++j) {
+        double dsum = a[j][j];
+        for (int k = 0; k < j; ++k) dsum -= L[j][k] * L[j][k];
+        if (!(dsum > 1e-14 * a[j][j]) || !(a[j][j] > 0.0)) { ok = false; dsum = 1.0; }
+        L[j][j] = sqrt(dsum);
+        for (int i = j + 1; i < NK; ++i) {
+            double v = a[i][j];
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+            L[i][j] = v / L[j][j];
+        }
+    }
+    if (ok) {
+        for (int j = 0; j < NK; ++j) {                 // Li = L^-1 (lower)
+            Li[j][j] = 1.0 / L[j][j];
+            for (int i = j + 1; i < NK; ++i) {
+                double v = 0.0;
+                for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
+                Li[i][j] = v / L[i][i];
+            }
+        }
+        for (int i = 0; i < NK; ++i)
+            for (int j = i; j < NK; ++j) {             // M = Li^T Li
+                double v = 0.0;
+                for (int k = j; k < NK; ++k) v += Li[k][i] * Li[k][j];
+                mk[tri8(i, j)] = v;
+            }
+    } else {
+        for (int i = 0; i < NK; ++i)
+            for (int j = i; j < NK; ++j) mk[tri8(i, j)] = (i == j) ? (a[i][i] > 0.0 ? 1.0 / a[i][i] : 1.0) : 0.0;
+    }
+    double rc[NK], zc[NK], rz = 0.0;
+    for (int k = 0; k < NK; ++k) rc[k] = sk[NK_TRI + k];
+    sym8_apply(mk, rc, zc);
+    for (int k = 0; k < NK; ++k) {
+        x[k] = 0.0;
+        r[k] = rc[k];
+        z[k] = zc[k];
+        pv[k] = zc[k];
+        yv[k] = d_k[k] * zc[k];
+        rz += rc[k] * zc[k];
+    }
+    return rz;
 }
 
 // sum over the 1024 threads of the single update workgroup (all threads get the result)
@@ -370,6 +539,8 @@ __device__ __forceinline__ void sym7_apply(const double *__restrict__ m /* 28 */
 __global__ __launch_bounds__(1024) void schur_factor_kernel(const double *__restrict__ sraw,
                                                             const double *__restrict__ d_c,
                                                             const double *__restrict__ dreg_c,
+                                                            const double *__restrict__ d_k,
+                                                            const double *__restrict__ dreg_k,
                                                             int n_cams, double eta, double qtol,
                                                             double maxiter,
                                                             double *__restrict__ minv,
@@ -458,6 +629,12 @@ __global__ __launch_bounds__(1024) void schur_factor_kernel(const double *__rest
             rz += rc[k] * zc[k];
         }
     }
+    if (d_k && threadIdx.x == 0) {
+        // the calibration block sits behind the cameras in every vector of the recurrence
+        const int64_t nc = (int64_t)n_cams * 7;
+        rz += calib_factor(sraw + (int64_t)n_cams * 35, d_k, dreg_k, minv + (int64_t)n_cams * 28,
+                           x + nc, r + nc, z + nc, pv + nc, yv + nc);
+    }
     rz = block_sum_1024(rz, sh);
     if (threadIdx.x == 0) {
         for (int k = 0; k < 2 * ST_COUNT; ++k) state[k] = 0.0;
@@ -497,12 +674,22 @@ __device__ __forceinline__ double sum_partials_256(const double *__restrict__ pa
 
 __global__ __launch_bounds__(256) void schur_pq_kernel(const double *__restrict__ qraw,
                                                        const double *__restrict__ dreg_c,
+                                                       const double *__restrict__ dreg_k,
                                                        const double *__restrict__ pv, int n_cams,
                                                        const double *__restrict__ state,
                                                        double *__restrict__ pqpart)
 {
     if (state[ST_STOP] != 0.0) return;
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (dreg_k && c == n_cams) {                       // the calibration block: slot n_cams
+        double s = 0.0;
+        for (int k = 0; k < NK; ++k) {
+            const int64_t i = (int64_t)n_cams * 7 + k;
+            s += pv[i] * (qraw[i] + dreg_k[k] * dreg_k[k] * pv[i]);
+        }
+        pqpart[c] = s;
+        return;
+    }
     if (c >= n_cams) return;
     double s = 0.0;
 #pragma unroll
@@ -516,6 +703,7 @@ __global__ __launch_bounds__(256) void schur_pq_kernel(const double *__restrict_
 
 __global__ __launch_bounds__(256) void schur_update1_kernel(const double *__restrict__ qraw,
                                                             const double *__restrict__ dreg_c,
+                                                            const double *__restrict__ dreg_k,
                                                             const double *__restrict__ minv,
                                                             int n_cams, double *__restrict__ x,
                                                             double *__restrict__ r,
@@ -527,10 +715,28 @@ __global__ __launch_bounds__(256) void schur_update1_kernel(const double *__rest
 {
     __shared__ double sh[4];
     if (state[ST_STOP] != 0.0) return;
-    const double pq = sum_partials_256(pqpart, n_cams, sh);
+    const int n_part = n_cams + (dreg_k ? 1 : 0);
+    const double pq = sum_partials_256(pqpart, n_part, sh);
     if (!(pq > 0.0)) return;                       // update2 latches the breakdown
     const double alpha = state[ST_RZ] / pq;
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (dreg_k && c == n_cams) {                       // the calibration block
+        const int64_t nc = (int64_t)n_cams * 7;
+        double rk[NK], zk[NK], s = 0.0;
+        for (int k = 0; k < NK; ++k) {
+            const double l = dreg_k[k], p = pv[nc + k];
+            x[nc + k] += alpha * p;
+            rk[k] = r[nc + k] - alpha * (qraw[nc + k] + l * l * p);
+            r[nc + k] = rk[k];
+        }
+        sym8_apply(minv + (int64_t)n_cams * 28, rk, zk);
+        for (int k = 0; k < NK; ++k) {
+            z[nc + k] = zk[k];
+            s += rk[k] * zk[k];
+        }
+        rzpart[c] = s;
+        return;
+    }
     if (c >= n_cams) return;
     double rc[7], zc[7];
 #pragma unroll
@@ -551,7 +757,8 @@ __global__ __launch_bounds__(256) void schur_update1_kernel(const double *__rest
     rzpart[c] = s;
 }
 
-__global__ __launch_bounds__(256) void schur_update2_kernel(const double *__restrict__ d_c, int n_cams,
+__global__ __launch_bounds__(256) void schur_update2_kernel(const double *__restrict__ d_c,
+                                                            const double *__restrict__ d_k, int n_cams,
                                                             const double *__restrict__ z,
                                                             double *__restrict__ pv,
                                                             double *__restrict__ yv,
@@ -565,7 +772,8 @@ __global__ __launch_bounds__(256) void schur_update2_kernel(const double *__rest
         if (blockIdx.x == 0 && threadIdx.x < ST_COUNT) next[threadIdx.x] = state[threadIdx.x];
         return;
     }
-    const double pq = sum_partials_256(pqpart, n_cams, sh);
+    const int n_part = n_cams + (d_k ? 1 : 0);
+    const double pq = sum_partials_256(pqpart, n_part, sh);
     if (!(pq > 0.0)) {
         if (blockIdx.x == 0 && threadIdx.x < ST_COUNT)
             next[threadIdx.x] = threadIdx.x == ST_STOP ? 3.0 : (threadIdx.x == ST_PQ ? pq : state[threadIdx.x]);
@@ -573,7 +781,7 @@ __global__ __launch_bounds__(256) void schur_update2_kernel(const double *__rest
     }
     const double rz = state[ST_RZ];
     const double alpha = rz / pq;
-    const double rzn = sum_partials_256(rzpart, n_cams, sh);
+    const double rzn = sum_partials_256(rzpart, n_part, sh);
     const double beta = rzn / rz;
     const double iter = state[ST_ITER] + 1.0;
     const double eta = state[ST_ETA];
@@ -594,6 +802,13 @@ __global__ __launch_bounds__(256) void schur_update2_kernel(const double *__rest
                 const double p = z[i] + beta * pv[i];
                 pv[i] = p;
                 yv[i] = d_c[i] * p;
+            }
+        } else if (d_k && c == n_cams) {
+            for (int k = 0; k < NK; ++k) {
+                const int64_t i = (int64_t)n_cams * 7 + k;
+                const double p = z[i] + beta * pv[i];
+                pv[i] = p;
+                yv[i] = d_k[k] * p;
             }
         }
     }
@@ -674,82 +889,123 @@ extern "C" int iamx_ba_block_diag(const double *U, const double *V, int n_cams, 
 
 extern "C" int iamx_ba_schur_state_size(void) { return 2 * ST_COUNT; }
 
-extern "C" int iamx_ba_schur_prepare(const double *Jc, const double *Jp, const double *r,
-                                     const int32_t *cam_ptr, const int32_t *pt_idx, int64_t n_obs,
-                                     int n_cams, int n_pts, const double *V, const double *gp,
-                                     const double *d, const double *dreg, double *Y, double *yg,
-                                     double *zp, double *sraw, void *stream)
+// Jk (DEV [O][2][8], the calibration columns of iamx_ba_residual_jac) selects the bordered form
+// (optimize_calib='global'); nullptr: cameras and points only.  With Jk: d / dreg carry the 8
+// calibration entries behind the points, every vector of the recurrence (x, r, z, p, y, qraw) has
+// 7 C + 8 entries, minv 28 C + 36, part 2 (C + 1), sraw 35 C + 44 (the calibration block + its
+// right-hand side behind the cameras'), ckpart [C][44] scratch.
+extern "C" int iamx_ba_schur_prepare(const double *Jc, const double *Jp, const double *Jk,
+                                     const double *r, const int32_t *cam_ptr, const int32_t *pt_idx,
+                                     int64_t n_obs, int n_cams, int n_pts, const double *V,
+                                     const double *gp, const double *d, const double *dreg, double *Y,
+                                     double *yg, double *zp, double *sraw, double *ckpart,
+                                     void *stream)
 {
     IAMX_REQUIRE(Jc && Jp && r && cam_ptr && pt_idx && V && gp && d && dreg && Y && yg && zp && sraw,
                  "null pointer");
+    IAMX_REQUIRE(!Jk || ckpart, "ckpart is required with calibration columns");
     IAMX_REQUIRE(n_obs >= 0 && n_cams > 0 && n_pts >= 0, "bad size");
     hipStream_t st = iamx::as_stream(stream);
     const double *d_p = d + (int64_t)n_cams * 7, *dreg_p = dreg + (int64_t)n_cams * 7;
     if (n_pts)
         hipLaunchKernelGGL(schur_points_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, st, V, gp,
                            d_p, dreg_p, n_pts, Y, yg, zp);
-    hipLaunchKernelGGL(schur_adj_kernel<true>, dim3(n_cams), dim3(256), 0, st, Jc, Jp, cam_ptr,
-                       pt_idx, r, zp, d, d_p, Y, (const double *)nullptr, (const double *)nullptr,
-                       (const double *)nullptr, (double *)nullptr, sraw);
+    if (Jk) {
+        const double *d_k = d_p + (int64_t)n_pts * 3;
+        hipLaunchKernelGGL((schur_adj_kernel<true, true>), dim3(n_cams), dim3(256), 0, st, Jc, Jp, Jk,
+                           cam_ptr, pt_idx, r, zp, d, d_p, Y, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, (double *)nullptr, sraw,
+                           ckpart);
+        hipLaunchKernelGGL(schur_calib_reduce_kernel<NK_TRI + NK>, dim3(1), dim3(256), 0, st,
+                           (const double *)ckpart, n_cams, d_k, (const double *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr,
+                           sraw + (int64_t)n_cams * 35, (double *)nullptr);
+    } else {
+        hipLaunchKernelGGL((schur_adj_kernel<true, false>), dim3(n_cams), dim3(256), 0, st, Jc, Jp,
+                           (const double *)nullptr, cam_ptr, pt_idx, r, zp, d, d_p, Y,
+                           (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                           (double *)nullptr, sraw, (double *)nullptr);
+    }
     return iamx::check_launch("iamx_ba_schur_prepare");
 }
 
+// n_pts: only used to find the calibration entries of d / dreg (with_calib != 0)
 extern "C" int iamx_ba_schur_factor(const double *sraw, const double *d, const double *dreg,
-                                    int n_cams, double eta, double qtol, int max_iter, double *minv,
-                                    double *x,
-                                    double *r, double *z, double *p, double *y, double *state,
-                                    void *stream)
+                                    int n_cams, int n_pts, int with_calib, double eta, double qtol,
+                                    int max_iter, double *minv, double *x, double *r, double *z,
+                                    double *p, double *y, double *state, void *stream)
 {
     IAMX_REQUIRE(sraw && d && dreg && minv && x && r && z && p && y && state, "null pointer");
-    IAMX_REQUIRE(n_cams > 0 && eta >= 0 && qtol >= 0 && max_iter > 0, "bad size");
+    IAMX_REQUIRE(n_cams > 0 && n_pts >= 0 && eta >= 0 && qtol >= 0 && max_iter > 0, "bad size");
+    const int64_t nk = (int64_t)n_cams * 7 + (int64_t)n_pts * 3;
     hipLaunchKernelGGL(schur_factor_kernel, dim3(1), dim3(1024), 0, iamx::as_stream(stream), sraw, d,
-                       dreg, n_cams, eta, qtol, (double)max_iter, minv, x, r, z, p, y, state);
+                       dreg, with_calib ? d + nk : (const double *)nullptr,
+                       with_calib ? dreg + nk : (const double *)nullptr, n_cams, eta, qtol,
+                       (double)max_iter, minv, x, r, z, p, y, state);
     return iamx::check_launch("iamx_ba_schur_factor");
 }
 
-extern "C" int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                                     const int32_t *pt_idx, const int32_t *cam_ptr,
-                                     const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs,
-                                     int n_cams, int n_pts, const double *d, const double *dreg,
-                                     const double *Y, const double *minv, double *t, double *zp,
-                                     double *qraw, double *part, double *x, double *r, double *z,
+extern "C" int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const double *Jk,
+                                     const int32_t *cam_idx, const int32_t *pt_idx,
+                                     const int32_t *cam_ptr, const int32_t *pt_ptr,
+                                     const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+                                     const double *d, const double *dreg, const double *Y,
+                                     const double *minv, double *t, double *zp, double *qraw,
+                                     double *part, double *ckpart, double *x, double *r, double *z,
                                      double *p, double *y, double *state, int first_iter, int n_iter,
                                      int phase, void *stream)
 {
     IAMX_REQUIRE(Jc && Jp && cam_idx && pt_idx && cam_ptr && pt_ptr && pt_obs && d && dreg && Y &&
                      minv && t && zp && qraw && part && x && r && z && p && y && state,
                  "null pointer");
+    IAMX_REQUIRE(!Jk || ckpart, "ckpart is required with calibration columns");
     IAMX_REQUIRE(n_cams > 0 && n_pts >= 0 && n_obs >= 0 && n_iter >= 1 && first_iter >= 0, "bad size");
     IAMX_REQUIRE(phase >= -1 && phase <= 1, "phase is -1 (whole iterations), 0 or 1");
     hipStream_t st = iamx::as_stream(stream);
-    const double *d_p = d + (int64_t)n_cams * 7;
-    double *pqpart = part, *rzpart = part + n_cams;
-    const unsigned gc = (unsigned)((n_cams + 255) / 256);
+    const int64_t nc = (int64_t)n_cams * 7;
+    const double *d_p = d + nc;
+    const double *d_k = Jk ? d_p + (int64_t)n_pts * 3 : nullptr;
+    const double *dreg_k = Jk ? dreg + nc + (int64_t)n_pts * 3 : nullptr;
+    const int n_part = n_cams + (Jk ? 1 : 0);
+    double *pqpart = part, *rzpart = part + n_part;
+    const unsigned gc = (unsigned)((n_part + 255) / 256);
     for (int it = 0; it < n_iter; ++it) {
         const int par = (first_iter + it) & 1;
         const double *cur = state + par * ST_COUNT;
         double *next = state + (par ^ 1) * ST_COUNT;
         if (phase != 1) {
             if (n_obs)
-                hipLaunchKernelGGL(schur_fwd_kernel, dim3(grid_for(n_obs)), dim3(256), 0, st, Jc,
-                                   cam_idx, n_obs, (const double *)y, cur, t);
+                hipLaunchKernelGGL(schur_fwd_kernel, dim3(grid_for(n_obs)), dim3(256), 0, st, Jc, Jk,
+                                   cam_idx, n_obs, (const double *)y, (const double *)(y + nc), cur, t);
             if (n_pts)
                 hipLaunchKernelGGL(schur_pt_kernel<false>, dim3((n_pts + 255) / 256), dim3(256), 0,
                                    st, Jp, pt_ptr, pt_obs, n_pts, 0, n_pts, (const double *)t, d_p, Y,
                                    (const double *)nullptr, cur, zp);
             // one rank: q is complete, the adjoint kernel also emits the partials of p.q
-            hipLaunchKernelGGL(schur_adj_kernel<false>, dim3(n_cams), dim3(256), 0, st, Jc, Jp,
-                               cam_ptr, pt_idx, (const double *)t, (const double *)zp, d, d_p, Y, cur,
-                               (const double *)p, dreg, phase == -1 ? pqpart : (double *)nullptr, qraw);
+            if (Jk) {
+                hipLaunchKernelGGL((schur_adj_kernel<false, true>), dim3(n_cams), dim3(256), 0, st, Jc,
+                                   Jp, Jk, cam_ptr, pt_idx, (const double *)t, (const double *)zp, d,
+                                   d_p, Y, cur, (const double *)p, dreg,
+                                   phase == -1 ? pqpart : (double *)nullptr, qraw, ckpart);
+                hipLaunchKernelGGL(schur_calib_reduce_kernel<NK>, dim3(1), dim3(256), 0, st,
+                                   (const double *)ckpart, n_cams, d_k, dreg_k,
+                                   (const double *)(p + nc), cur, qraw + nc,
+                                   phase == -1 ? pqpart + n_cams : (double *)nullptr);
+            } else {
+                hipLaunchKernelGGL((schur_adj_kernel<false, false>), dim3(n_cams), dim3(256), 0, st, Jc,
+                                   Jp, (const double *)nullptr, cam_ptr, pt_idx, (const double *)t,
+                                   (const double *)zp, d, d_p, Y, cur, (const double *)p, dreg,
+                                   phase == -1 ? pqpart : (double *)nullptr, qraw, (double *)nullptr);
+            }
         }
         if (phase != 0) {
             if (phase == 1)
                 hipLaunchKernelGGL(schur_pq_kernel, dim3(gc), dim3(256), 0, st, (const double *)qraw,
-                                   dreg, (const double *)p, n_cams, cur, pqpart);
+                                   dreg, dreg_k, (const double *)p, n_cams, cur, pqpart);
             hipLaunchKernelGGL(schur_update1_kernel, dim3(gc), dim3(256), 0, st, (const double *)qraw,
-                               dreg, minv, n_cams, x, r, z, (const double *)p, cur,
+                               dreg, dreg_k, minv, n_cams, x, r, z, (const double *)p, cur,
                                (const double *)pqpart, rzpart);
-            hipLaunchKernelGGL(schur_update2_kernel, dim3(gc), dim3(256), 0, st, d, n_cams,
+            hipLaunchKernelGGL(schur_update2_kernel, dim3(gc), dim3(256), 0, st, d, d_k, n_cams,
                                (const double *)z, p, y, cur, next, (const double *)pqpart,
                                (const double *)rzpart);
         }
@@ -757,22 +1013,27 @@ extern "C" int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const i
     return iamx::check_launch("iamx_ba_schur_iterate");
 }
 
-extern "C" int iamx_ba_schur_finish(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                                    const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs,
-                                    int n_cams, int n_pts, int pt_lo, int pt_hi, const double *d,
-                                    const double *Y, const double *yg, const double *x, double *y,
-                                    double *t, double *step, void *stream)
+// step = (d_c .* x_c, point part by back-substitution, d_k .* x_k behind the points with Jk)
+extern "C" int iamx_ba_schur_finish(const double *Jc, const double *Jp, const double *Jk,
+                                    const int32_t *cam_idx, const int32_t *pt_ptr,
+                                    const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
+                                    int pt_lo, int pt_hi, const double *d, const double *Y,
+                                    const double *yg, const double *x, double *y, double *t,
+                                    double *step, void *stream)
 {
     IAMX_REQUIRE(Jc && Jp && cam_idx && pt_ptr && pt_obs && d && Y && yg && x && y && t && step,
                  "null pointer");
     IAMX_REQUIRE(n_cams > 0 && n_pts >= 0 && n_obs >= 0 && 0 <= pt_lo && pt_lo <= pt_hi &&
                      pt_hi <= n_pts, "bad size");
     hipStream_t st = iamx::as_stream(stream);
-    const int64_t nc = (int64_t)n_cams * 7;
+    const int64_t nc = (int64_t)n_cams * 7, np3 = (int64_t)n_pts * 3;
     hipLaunchKernelGGL(schur_scale_kernel, dim3(grid_for(nc)), dim3(256), 0, st, nc, d, x, y, step);
+    if (Jk)
+        hipLaunchKernelGGL(schur_scale_kernel, dim3(1), dim3(256), 0, st, (int64_t)NK, d + nc + np3,
+                           x + nc, y + nc, step + nc + np3);
     if (n_obs)
-        hipLaunchKernelGGL(schur_fwd_kernel, dim3(grid_for(n_obs)), dim3(256), 0, st, Jc, cam_idx,
-                           n_obs, (const double *)y, (const double *)nullptr, t);
+        hipLaunchKernelGGL(schur_fwd_kernel, dim3(grid_for(n_obs)), dim3(256), 0, st, Jc, Jk, cam_idx,
+                           n_obs, (const double *)y, (const double *)(y + nc), (const double *)nullptr, t);
     if (n_pts)
         hipLaunchKernelGGL(schur_pt_kernel<true>, dim3((n_pts + 255) / 256), dim3(256), 0, st, Jp,
                            pt_ptr, pt_obs, n_pts, pt_lo, pt_hi, (const double *)t,

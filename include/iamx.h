@@ -622,25 +622,37 @@ int iamx_ba_accumulate(const double *Jc, const double *Jp, const double *r, cons
 int iamx_ba_block_diag(const double *U, const double *V, int n_cams, int n_pts, double *out,
                        void *stream);
 int iamx_ba_schur_state_size(void);
-int iamx_ba_schur_prepare(const double *Jc, const double *Jp, const double *r, const int32_t *cam_ptr,
-                          const int32_t *pt_idx, int64_t n_obs, int n_cams, int n_pts,
-                          const double *V, const double *gp, const double *d, const double *dreg,
-                          double *Y, double *yg, double *zp, double *sraw, void *stream);
+/* optimize_calib='global' (scripts/lib/optimizer.py:142-169,181-189: 8 calibration columns that
+ * every observation shares; `process.py --cam-calibration`, scripts/process.py:384): pass Jk DEV
+ * [n_obs][2][8] (iamx_ba_residual_jac) to all four calls for the BORDERED form -- the calibration
+ * block joins the camera side of the reduced system as one more block of 8 parameters, with the
+ * inverse of its own normal-equation block (D_k sum Jk^T Jk D_k + Dreg_k^2) as preconditioner.
+ * Then n = 7 n_cams + 3 n_pts + 8 (calibration entries of d / dreg / step behind the points),
+ * x r z p y qraw DEV [7 n_cams + 8], minv DEV [28 n_cams + 36], part DEV [2 (n_cams + 1)], sraw DEV
+ * [35 n_cams + 44] (all-reduce all of it), ckpart DEV [n_cams][44] scratch; several ranks
+ * all-reduce qraw [7 n_cams + 8] per iteration.  Jk = NULL: cameras and points only, sizes as
+ * documented above, ckpart unused. */
+int iamx_ba_schur_prepare(const double *Jc, const double *Jp, const double *Jk, const double *r,
+                          const int32_t *cam_ptr, const int32_t *pt_idx, int64_t n_obs, int n_cams,
+                          int n_pts, const double *V, const double *gp, const double *d,
+                          const double *dreg, double *Y, double *yg, double *zp, double *sraw,
+                          double *ckpart, void *stream);
 int iamx_ba_schur_factor(const double *sraw, const double *d, const double *dreg, int n_cams,
-                         double eta, double qtol, int max_iter, double *minv, double *x, double *r, double *z,
-                         double *p, double *y, double *state, void *stream);
-int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                          const int32_t *pt_idx, const int32_t *cam_ptr, const int32_t *pt_ptr,
-                          const int32_t *pt_obs, int64_t n_obs, int n_cams, int n_pts,
-                          const double *d, const double *dreg, const double *Y, const double *minv,
-                          double *t, double *zp, double *qraw, double *part, double *x, double *r,
-                          double *z, double *p, double *y, double *state, int first_iter,
-                          int n_iter, int phase, void *stream);
-int iamx_ba_schur_finish(const double *Jc, const double *Jp, const int32_t *cam_idx,
-                         const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
-                         int n_pts, int pt_lo, int pt_hi, const double *d, const double *Y,
-                         const double *yg, const double *x, double *y, double *t, double *step,
-                         void *stream);
+                         int n_pts, int with_calib, double eta, double qtol, int max_iter,
+                         double *minv, double *x, double *r, double *z, double *p, double *y,
+                         double *state, void *stream);
+int iamx_ba_schur_iterate(const double *Jc, const double *Jp, const double *Jk,
+                          const int32_t *cam_idx, const int32_t *pt_idx, const int32_t *cam_ptr,
+                          const int32_t *pt_ptr, const int32_t *pt_obs, int64_t n_obs, int n_cams,
+                          int n_pts, const double *d, const double *dreg, const double *Y,
+                          const double *minv, double *t, double *zp, double *qraw, double *part,
+                          double *ckpart, double *x, double *r, double *z, double *p, double *y,
+                          double *state, int first_iter, int n_iter, int phase, void *stream);
+int iamx_ba_schur_finish(const double *Jc, const double *Jp, const double *Jk,
+                         const int32_t *cam_idx, const int32_t *pt_ptr, const int32_t *pt_obs,
+                         int64_t n_obs, int n_cams, int n_pts, int pt_lo, int pt_hi, const double *d,
+                         const double *Y, const double *yg, const double *x, double *y, double *t,
+                         double *step, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Collectives of the hot path for callers that are not python: RCCL over

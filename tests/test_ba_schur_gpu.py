@@ -58,10 +58,11 @@ def test_accumulate_equals_numpy_blocks(path):
     assert np.abs(prob.download_n(prob.colsq_dev()) - ref).max() <= 1e-12 * ref.max()
 
 
-@pytest.mark.parametrize('path', PLAIN, ids=os.path.basename)
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
 def test_schur_step_equals_direct_solve(path):
     """the step of the Schur-complement solver, iterated to convergence, is the least-squares
-    solution of SciPy's subproblem  min ||[J D; Dreg] p - [r; 0]||  (trf.py:303-314)"""
+    solution of SciPy's subproblem  min ||[J D; Dreg] p - [r; 0]||  (trf.py:303-314) -- also with
+    the 8 calibration columns of optimize_calib='global' (the bordered form)"""
     from scipy.sparse import diags, vstack
     from scipy.sparse.linalg import spsolve
     from imageanalysis_amd import ba_solver
@@ -108,8 +109,8 @@ def test_both_inner_solvers_reach_reference_minimum(path, solver):
     assert abs(cost - ref) / ref < 2e-2, (cost, ref)
     assert abs(np.mean(np.abs(res.fun)) - np.mean(np.abs(g['f_final']))) < 0.02
     assert res.njev <= 3 * 8 and res.status in (1, 2, 3, 4)
-    want = 'lsmr' if (solver == 'device-lsmr' or bool(g['cam_calib'])) else 'schur'
-    assert res.inner_solver == want
+    # (the calibration mode has the Schur path too: the bordered form)
+    assert res.inner_solver == ('lsmr' if solver == 'device-lsmr' else 'schur')
 
 
 def test_config3_schur_inner_iterations_and_end_state():
