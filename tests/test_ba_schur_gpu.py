@@ -147,6 +147,40 @@ def test_config3_schur_inner_iterations_and_end_state():
     assert abs(np.sqrt(res.cost / len(p['uv'])) - np.sqrt(res_l.cost / len(p['uv']))) < 0.02
 
 
+def test_config3_with_calibration_columns_bordered_schur():
+    """`process.py --cam-calibration` at BASELINE configs[3] size: optimize_calib='global' adds 8
+    dense columns (scripts/lib/optimizer.py:142-169,181-189).  The bordered Schur solve takes a
+    fraction of the inner iterations of LSMR on the whole system and ends at least as low."""
+    from imageanalysis_amd import ba_solver, synth
+    p = synth.make_ba_problem()
+    C, P = len(p['cams0']), len(p['pts0'])
+    K = p['K']
+    cal0 = np.array([K[0, 0] * 1.015, K[0, 2] + 6.0, K[1, 2] - 4.0, *(np.asarray(p['dist']) * 0.7)])
+    x0 = np.hstack([p['cams0'].ravel(), p['pts0'].ravel(), cal0])
+    lb = np.full(x0.size, -np.inf)
+    ub = np.full(x0.size, np.inf)
+    for j, dlt in ((0, 3.0), (1, 3.0), (2, 9.0)):
+        lb[j:C * 7:7] = p['cams0'][:, j] - dlt
+        ub[j:C * 7:7] = p['cams0'][:, j] + dlt
+    k0 = C * 7 + P * 3
+    lb[k0:k0 + 3] = [K[0, 0] * 0.8, K[0, 2] * 0.8, K[1, 2] * 0.8]
+    ub[k0:k0 + 3] = [K[0, 0] * 1.2, K[0, 2] * 1.2, K[1, 2] * 1.2]
+    lb[k0 + 5:k0 + 7], ub[k0 + 5:k0 + 7] = -0.2, 0.2
+    out = {}
+    for inner in ('schur', 'lsmr'):
+        prob = ba_solver.DeviceBA(C, P, p['cam_idx'], p['pt_idx'], p['uv'], True)
+        prob.inner = inner
+        res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=40 if inner == 'lsmr' else None)
+        out[inner] = (res, list(prob.inner_iterations))
+    res, its = out['schur']
+    res_l, its_l = out['lsmr']
+    assert res.status in (1, 2, 3, 4) and max(its) <= 150 and res.iterations <= 25, (its, res.iterations)
+    assert np.sqrt(res.cost / len(p['uv'])) < 0.46              # the 0.5 px noise floor, fitted
+    assert np.mean(its_l) > 3 * np.mean(its)
+    assert res.cost <= 1.005 * res_l.cost, (res.cost, res_l.cost)
+    assert np.all(res.x >= lb) and np.all(res.x <= ub)
+
+
 def _two_rank_schur(rank, world, port, path, outdir):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, 'tests'))
