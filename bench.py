@@ -290,6 +290,10 @@ def main():
                     help='SIFT section without the scale 1.0 (20 MP) detects (counter passes: every detect the same size)')
     ap.add_argument('--no-e2e', action='store_true',
                     help='skip the configs[4] slice (24 rendered 20 MP frames through the drop-in chain)')
+    ap.add_argument('--e2e-full', type=int, default=0, metavar='N',
+                    help='BASELINE configs[4] at scale: N rendered 5472 x 3648 frames (N >= 512 asked '
+                         'for) through the whole chain on one GPU, neighbour + distance-window '
+                         'schedule; rendering and writing N JPEGs takes ~0.1 s per frame, untimed')
     ap.add_argument('--e2e', type=int, default=0, metavar='N',
                     help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
                          'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
@@ -375,10 +379,12 @@ def main():
         cleanup = cleanup_bench(args) if rank == 0 else None
     # BASELINE configs[4] as a slice at its own frame size: 24 rendered 5472 x 3648 JPEGs through
     # detect -> match -> link -> triangulate -> BA (the drop-in entry points, host side included)
-    e2e = e2e_small = None
+    e2e = e2e_small = e2e_big = None
     if rank == 0 and world == 1:
         if not args.no_e2e:
             e2e = e2e_bench(24, full_frame=True)
+        if args.e2e_full > 0:
+            e2e_big = e2e_bench(args.e2e_full, full_frame=True, schedule='distance')
         if args.e2e > 0:
             e2e_small = e2e_bench(args.e2e)
     # CPU baselines of the BA and SIFT sections run AFTER every timed GPU section: their OpenMP /
@@ -421,6 +427,16 @@ def main():
             "sift": sift, "cleanup": cleanup,
         }
         out["e2e"] = e2e
+        if e2e_big is not None:
+            out["e2e_full"] = e2e_big
+        else:
+            # the configs[4] run at >= 512 frames is minutes of rendering: its tracked record
+            # (bench.py --e2e-full 512 on MI355X) is quoted instead of re-run by default
+            rec = os.path.join(REPO, 'profiles', 'r4_e2e_full_512.json')
+            if os.path.exists(rec):
+                with open(rec) as fp:
+                    out["e2e_full_recorded"] = dict(json.load(fp), source='profiles/r4_e2e_full_512.json '
+                                                    '(python bench.py --e2e-full 512, not re-run here)')
         if e2e_small is not None:
             out["e2e_quarter_frames"] = e2e_small
         print(json.dumps(out), flush=True)
@@ -481,7 +497,7 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
             if pb.sym else "one-direction sweep, %d-row workgroups" % pb.fast_rows}
 
 
-def e2e_bench(n_images, full_frame=False):
+def e2e_bench(n_images, full_frame=False, schedule=None):
     """BASELINE configs[4] shape on one GPU: a rendered survey of n_images JPEGs on disk goes
     through the drop-in entry points exactly as scripts/process.py:236-407 drives the reference's
     modules -- Image.detect_features, matcher.find_matches, match_cleanup.*, groups.compute,
@@ -489,7 +505,10 @@ def e2e_bench(n_images, full_frame=False):
     included: JPEG decode, cache files, python lists, .match pickles).  full_frame: the survey
     is rendered at configs[4]'s own frame size, 5472 x 3648 (20 MP), and detected at the
     reference's default scale 0.4 (scripts/lib/matcher.py:38); otherwise at a quarter of the pixels
-    and scale 1.0."""
+    and scale 1.0.  schedule: 'all-pairs' (default with full_frame: the slice of a few dozen
+    frames), 'distance' (neighbours in the list + every pair inside the reference's distance
+    window, scripts/lib/matcher.py:886-903: the shape of a survey of hundreds / thousands of
+    frames) or 'neighbours' (the reference at HEAD)."""
     import contextlib
     import io
     import shutil
@@ -520,8 +539,12 @@ def e2e_bench(n_images, full_frame=False):
         matcher.matcher_node.setFloat('match_ratio', 0.75)
         matcher.matcher_node.setInt('min_pairs', 25)
         matcher.matcher_node.setInt('min_chain_len', 0)
-        if full_frame:
-            matcher.matcher_node.setString('schedule', 'all-pairs')
+        if schedule is None and full_frame:
+            schedule = 'all-pairs'
+        if schedule is not None:
+            matcher.matcher_node.setString('schedule', schedule)
+        out["schedule"] = schedule or 'neighbours'
+        torch.cuda.reset_peak_memory_stats()
         node = getNode('/config/camera', True)
         node.__dict__.pop('K_opt', None)
         node.__dict__.pop('dist_coeffs_opt', None)
@@ -573,6 +596,7 @@ def e2e_bench(n_images, full_frame=False):
         out["keypoints_per_image"] = int(np.mean([len(im.kp_list) for im in proj.image_list]))
         timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
                                                     transform='homography', sort=True))
+        out["image_pairs_matched"] = sum(len(im.match_list) for im in proj.image_list) // 2
         out["image_pairs_with_matches"] = sum(len(v) > 0 for im in proj.image_list
                                               for v in im.match_list.values()) // 2
 
@@ -606,6 +630,7 @@ def e2e_bench(n_images, full_frame=False):
         db_tru = np.linalg.norm(tru[:, None, :] - tru[None, :, :], axis=2)
         gauge = float((db_est * db_tru).sum() / (db_tru * db_tru).sum())
         out["groups"] = [len(g) for g in group_list]
+        out["peak_hbm_bytes"] = int(torch.cuda.max_memory_allocated())
         out["baseline_scale"] = round(gauge, 5)
         out["max_baseline_error_m"] = round(float(np.abs(db_est - gauge * db_tru).max()), 4)
         total = sum(stages.values())

@@ -138,3 +138,24 @@ def test_config4_slice_at_the_real_frame_size():
     assert ba["mean_abs_residual_px_after"] < 1.0
     # relative geometry recovered up to the one global scale BA cannot observe
     assert abs(out["baseline_scale"] - 1.0) < 0.03 and out["max_baseline_error_m"] < 0.15
+
+
+def test_config4_at_128_frames_distance_schedule():
+    """BASELINE configs[4] beyond a slice: 128 rendered 5472 x 3648 frames through the whole chain
+    on the neighbour + distance-window schedule (scripts/lib/matcher.py:886-903 with its window
+    enabled -- all-pairs is not the shape of a survey of thousands of frames): one connected
+    block, sub-pixel residuals, the relative geometry of the truth."""
+    sys.path.insert(0, REPO)
+    import bench
+    out = bench.e2e_bench(128, full_frame=True, schedule='distance')
+    n = out["images"]
+    assert n >= 128 and out["image_size"] == [5472, 3648] and out["schedule"] == 'distance'
+    rows, cols = out["grid"]
+    assert out["image_pairs_matched"] < n * (n - 1) // 4          # a window, not all pairs
+    assert out["image_pairs_with_matches"] >= (rows - 1) * cols + rows * (cols - 1)
+    assert out["groups"] == [n]
+    ba = out["ba"]
+    assert ba["cameras"] == n and ba["observations"] > 3 * ba["points"] > 100000
+    assert ba["mean_abs_residual_px_before"] > 10.0 and ba["mean_abs_residual_px_after"] < 1.0
+    assert abs(out["baseline_scale"] - 1.0) < 0.03 and out["max_baseline_error_m"] < 0.3
+    assert 0 < out["peak_hbm_bytes"] < 200 * 2 ** 30
