@@ -575,11 +575,21 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         quiet = contextlib.redirect_stdout(io.StringIO())
         stages = {}
 
+        profile_stages = os.environ.get('IAMX_E2E_PROFILE', '').split(',')
+
         def timed(key, fn):
             torch.cuda.synchronize()
             t = time.perf_counter()
-            with quiet:
-                r = fn()
+            if key in profile_stages:              # (diagnosis: cProfile of the named stages to stderr)
+                import cProfile
+                import pstats
+                pr = cProfile.Profile()
+                with quiet:
+                    r = pr.runcall(fn)
+                pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(22)
+            else:
+                with quiet:
+                    r = fn()
             torch.cuda.synchronize()
             stages[key] = round(time.perf_counter() - t, 3)
             return r
