@@ -44,9 +44,16 @@ def compute(image_list, matches):
 
     n = len(matches)
     ptr = np.zeros(n + 1, np.int64)
-    if n:
-        np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
-    img = np.array([p[0] for m in matches for p in m[2:]], np.int32)
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()               # (millions of small lists alive: see match_cleanup.triangulate_smart)
+    try:
+        if n:
+            np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
+        img = np.fromiter((p[0] for m in matches for p in m[2:]), np.int32, int(ptr[-1]))
+    finally:
+        if gc_was:
+            gc.enable()
     level = np.full(n, -1, np.int32)
     placed_images = set()
     placed_flag = np.zeros(max(n_img, 1), np.uint8)

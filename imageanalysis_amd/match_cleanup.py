@@ -243,9 +243,13 @@ def link_matches(proj, matches_direct):
     total = int(o_ptr[-1])
     # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt))
     uv = np.zeros((total, 2), np.float64)
-    for i in np.unique(o_img[:total]):
-        sel = np.nonzero(o_img[:total] == i)[0]
-        uv[sel] = _kp_xy(proj.image_list[int(i)])[o_kp[sel]].astype(np.float64)
+    # (chain members grouped by image with ONE stable sort: a mask per image is O(images x
+    #  members), 3 s of the 9 s this stage took on a 512-frame survey)
+    by_img = np.argsort(o_img[:total], kind='stable')
+    cuts = np.searchsorted(o_img[:total][by_img], np.arange(len(proj.image_list) + 1))
+    for i in np.nonzero(np.diff(cuts))[0].tolist():
+        sel = by_img[cuts[i]:cuts[i + 1]]
+        uv[sel] = _kp_xy(proj.image_list[i])[o_kp[sel]].astype(np.float64)
     _log("Sorting matches by longest chain first.")
     lens = np.diff(o_ptr)
     order = np.argsort(-lens, kind='stable')          # list.sort(key=len, reverse=True) is stable
@@ -313,10 +317,16 @@ def triangulate_smart(proj, matches):
     n = len(matches)
     if n == 0:
         return
-    ptr = np.zeros(n + 1, np.int64)
-    np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
-    obs_img = np.array([p[0] for m in matches for p in m[2:]], np.int32)
-    obs_uv = np.array([p[1] for m in matches for p in m[2:]], np.float64).reshape(-1, 2)
+    # (millions of small lists are alive here -- the matches_grouped contract --: every
+    #  generation-2 pass of the cyclic collector walks them all again, and the list-building
+    #  calls below trigger many)
+    with _no_gc():
+        ptr = np.zeros(n + 1, np.int64)
+        np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
+        flat = [p for m in matches for p in m[2:]]
+        obs_img = np.fromiter((p[0] for p in flat), np.int32, len(flat))
+        obs_uv = np.array([p[1] for p in flat], np.float64).reshape(-1, 2)
+        del flat
     dev = kernels.require_gpu()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     d_M, d_ned, d_base, d_img, d_uv, d_ptr = (t(a) for a in (M, ned, base, obs_img, obs_uv, ptr))
@@ -325,8 +335,9 @@ def triangulate_smart(proj, matches):
     check(lib().iamx_triangulate_ground(_ptr(d_M), _ptr(d_ned), _ptr(d_base), n_img, _ptr(d_img),
                                         _ptr(d_uv), _ptr(d_ptr), n, _ptr(out), _ptr(n_sky),
                                         stream_ptr()), 'iamx_triangulate_ground')
-    res = out.cpu().numpy().tolist()
     for _ in range(int(n_sky.item())):
         _log('vector projected above horizon.')
-    for m, p in zip(matches, res):
-        m[0] = p
+    with _no_gc():
+        res = out.cpu().numpy().tolist()
+        for m, p in zip(matches, res):
+            m[0] = p
