@@ -260,6 +260,14 @@ def link_matches(proj, matches_direct):
     if n_chain:
         _log("Total unique features in image set:", n_chain)
         _log("Keypoint average instances:", "%.2f" % (total / float(n_chain)))
+    if n_chain > 100000 and hasattr(gc, 'freeze'):
+        # The chains are millions of small lists that live until the process ends and hold no
+        # reference cycles.  Left in the collector's youngest generations they make the next
+        # full collection -- triggered by whatever allocates next: the triangulation, the
+        # optimizer's setup -- walk all of them (seconds on a survey of hundreds of frames).
+        # gc.freeze() moves everything alive now to the permanent generation; reference counting
+        # still frees it.
+        gc.freeze()
     return out
 
 
