@@ -157,6 +157,10 @@ class DeviceBA(object):
         # fused single-rank LSMR: replay a captured HIP graph per 64-iteration chunk
         self.use_graph = os.environ.get('IAMX_BA_GRAPH', '1') != '0'
         self.host_logic = False          # True: the O(n) TRF vector logic in numpy (_trf_host)
+        # several ranks, device-resident outer iteration, no calibration columns: the point part
+        # of every n-vector stays on the rank that owns the points (zeros elsewhere), only the
+        # camera part and scalars are reduced inside the outer loop (set by _trf_device)
+        self.local_points = False
         self._calib_idx = None
         self._fixed_calib_up = False
 
@@ -361,7 +365,8 @@ class DeviceBA(object):
             return self.tmp_n[:self.n].clone()
         g = self.accumulate()['g'][:self.n].clone()
         if self.world > 1:
-            _dist.allreduce_sum_(g)
+            # (the point entries are complete on the rank that owns the point and zero elsewhere)
+            _dist.allreduce_sum_(g[:self.C * 7] if self.local_points else g)
         return g
 
     def colsq_dev(self):
@@ -374,7 +379,7 @@ class DeviceBA(object):
         check(lib().iamx_ba_block_diag(_ptr(a['U']), _ptr(a['V']), self.C, self.P,
                                        _ptr(self.tmp_n), stream_ptr()), 'iamx_ba_block_diag')
         if self.world > 1:
-            _dist.allreduce_sum_(self.tmp_n[:self.n])
+            _dist.allreduce_sum_(self.tmp_n[:self.C * 7] if self.local_points else self.tmp_n[:self.n])
         return self.tmp_n[:self.n]
 
     def vec_ops(self):
@@ -396,7 +401,7 @@ class DeviceBA(object):
         if self.m == 0:
             g = [0.0] * len(pairs)
         else:
-            g = V.dots(*pairs, n=self.m)                 # (k <= 3: at most 6 products)
+            g = V.dots(*pairs, n=self.m, n_vectors=False)     # (k <= 3: at most 6 products)
         if self.world > 1:
             t = torch.tensor(g, dtype=F64, device=self.dev)
             _dist.allreduce_sum_(t)
@@ -839,7 +844,7 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
                                  _ptr(ws['Y']), _ptr(ws['yg']), _ptr(ws['x']), _ptr(ws['y']),
                                  _ptr(ws['t']), _ptr(ws['step']), stream_ptr()),
           'iamx_ba_schur_finish')
-    if multi:
+    if multi and not prob.local_points:
         _dist.allreduce_sum_(ws['step'][nc:nc + 3 * P])      # (the calibration entries are replicated)
     ph.__exit__()
     itn = int(st[2])
@@ -1090,6 +1095,16 @@ class VecOps(object):
         self.dev = dev
         self.scratch = torch.empty(int(lib().iamx_vec_scratch_doubles()), dtype=F64, device=dev)
         self.out = torch.empty(8, dtype=F64, device=dev)
+        # several ranks with rank-local point parts (_trf_device): (rank, first point entry,
+        # number of point entries).  An n-vector then holds the camera part (replicated), this
+        # rank's points, and ZEROS for the points of the other ranks; a sum over the entries is
+        # rank 0's whole vector + the point part of the others, all-reduced as a scalar.
+        self.part = None
+
+    def _reduce(self, k, op):
+        """the first k scalars of self.out over the ranks (identity on one rank)"""
+        if self.part is not None:
+            _dist.allreduce_(self.out[:k], op)
 
     def new(self, like):
         return torch.empty(like.numel(), dtype=F64, device=self.dev)
@@ -1112,8 +1127,9 @@ class VecOps(object):
               'iamx_vec_sqrt_shift')
         return out
 
-    def dots(self, *terms, n=None):
-        """terms: (a, b) or (a, w, b) -> [sum a.*b (.*w)] as python floats, one host read"""
+    def dots(self, *terms, n=None, n_vectors=True):
+        """terms: (a, b) or (a, w, b) -> [sum a.*b (.*w)] as python floats, one host read.
+        n_vectors=False: the operands are not n-vectors (observation space: the caller reduces)"""
         import ctypes
         k = len(terms)
         A = (ctypes.c_void_p * k)(*[t[0].data_ptr() for t in terms])
@@ -1121,13 +1137,22 @@ class VecOps(object):
         W = (ctypes.c_void_p * k)(*[(t[1].data_ptr() if len(t) == 3 and t[1] is not None else None)
                                     for t in terms])
         n = terms[0][0].numel() if n is None else n
+        if self.part is not None and n_vectors and self.part[0] > 0:
+            # this rank's share of a sum over n-vector entries: the point part only
+            off, n = 8 * self.part[1], self.part[2]
+            A = (ctypes.c_void_p * k)(*[a + off for a in A])
+            B = (ctypes.c_void_p * k)(*[b + off for b in B])
+            W = (ctypes.c_void_p * k)(*[(w + off if w else None) for w in W])
         check(lib().iamx_vec_dots(n, k, A, B, W, _ptr(self.out), _ptr(self.scratch), stream_ptr()),
               'iamx_vec_dots')
+        if n_vectors:
+            self._reduce(k, 'sum')
         return self.out[:k].tolist()
 
     def absmax(self, x, y=None):
         check(lib().iamx_vec_absmax_prod(x.numel(), _ptr(x), _ptr(y), _ptr(self.out),
                                          _ptr(self.scratch), stream_ptr()), 'iamx_vec_absmax_prod')
+        self._reduce(1, 'max')
         return float(self.out[0].item())
 
     # ---- scipy/optimize/_lsq/common.py on device vectors
@@ -1158,6 +1183,7 @@ class VecOps(object):
         check(lib().iamx_trf_step_to_bound(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub),
                                            _ptr(self.out), _ptr(self.scratch), stream_ptr()),
               'iamx_trf_step_to_bound')
+        self._reduce(1, 'min')
         step = float(self.out[0].item())
         if not want_hits:
             return step, None
@@ -1178,6 +1204,7 @@ class VecOps(object):
         check(lib().iamx_trf_count_outside(x.numel(), _ptr(x), _ptr(p), _ptr(lb), _ptr(ub),
                                            _ptr(self.out), _ptr(self.scratch), stream_ptr()),
               'iamx_trf_count_outside')
+        self._reduce(1, 'sum')
         return float(self.out[0].item()) == 0.0
 
     def strictly_feasible(self, x, lb, ub, step=None):
@@ -1283,6 +1310,21 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     lb_d = prob.upload_n(np.broadcast_to(np.asarray(lb, np.float64), (n,)))[:n].clone()
     ub_d = prob.upload_n(np.broadcast_to(np.asarray(ub, np.float64), (n,)))[:n].clone()
     x = prob.upload_n(x_host)[:n].clone()
+    # Several ranks (observations sharded by point): the point part of x, g, the step and every
+    # other n-vector lives on the rank that owns the points -- zeros elsewhere --, the TRF scalars
+    # are sums / maxima of per-rank shares (VecOps.part).  Inside the loop only the camera blocks
+    # and scalars cross ranks; the point parts are put together once, at the end.
+    nc, np3 = prob.C * 7, prob.P * 3
+    prob.local_points = prob.world > 1 and not prob.with_calib and prob.inner == 'schur'
+    own = None
+    if prob.local_points:
+        own = torch.zeros(n, dtype=F64, device=prob.dev)
+        own[:nc] = 1.0
+        own[nc + 3 * prob.pt_lo:nc + 3 * prob.pt_hi] = 1.0
+        x = V.mul(x, own)
+        V.part = (prob.rank, nc, np3)
+    else:
+        V.part = None
     prob.set_x_dev(x)
     prob.residual_jac()
     nfev = njev = 1
@@ -1294,7 +1336,17 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     # Delta = norm(x0 * scale_inv / v**0.5) with v[dv != 0] *= scale_inv (one-off: on the host)
     v_h, dv_h, si_h = prob.download_n(v), prob.download_n(dv), prob.download_n(scale_inv)
     v_h[dv_h != 0] *= si_h[dv_h != 0]
-    Delta = float(np.linalg.norm(prob.download_n(x) * si_h / v_h ** 0.5))
+    t_h = prob.download_n(x) * si_h / v_h ** 0.5
+    if prob.local_points:
+        # this rank's share of the sum of squares: its own entries, the camera part on rank 0 only
+        share = prob.download_n(own) != 0
+        if prob.rank > 0:
+            share[:nc] = False
+        sq = torch.tensor([float(np.dot(t_h[share], t_h[share]))], dtype=F64, device=prob.dev)
+        _dist.allreduce_sum_(sq)
+        Delta = float(np.sqrt(sq.item()))
+    else:
+        Delta = float(np.linalg.norm(t_h))
     if Delta == 0:
         Delta = 1.0
     if max_nfev is None:
@@ -1395,6 +1447,13 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     if termination_status is None:
         termination_status = 0
     active = V.active_constraints(x, lb_d, ub_d, xtol)
+    if prob.local_points:
+        # the point parts, put together once (zeros outside a rank's own block)
+        active = V.mul(active, own)
+        for vec in (x, g, active):
+            _dist.allreduce_sum_(vec[nc:nc + np3])
+        V.part = None
+        prob.local_points = False
     return OptimizeResult(x=prob.download_n(x), cost=cost, grad=prob.download_n(g),
                           optimality=g_norm,
                           active_mask=prob.download_n(active).astype(int), nfev=nfev, njev=njev,
@@ -1404,17 +1463,24 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
 
 
 def gather_residual(prob, n_obs_total):
-    """full camera-major residual vector in the reference's observation order (all ranks)."""
+    """full camera-major residual vector in the reference's observation order (all ranks): every
+    rank's slice travels once (all-gather of the residuals and of their positions), not a
+    zero-padded vector of all observations through an all-reduce."""
     r = prob.download(prob.r, prob.m)
     full = np.zeros(2 * n_obs_total)
     sel = prob.local_obs
-    full[2 * sel] = r[0::2]
-    full[2 * sel + 1] = r[1::2]
     if prob.world == 1:
+        full[2 * sel] = r[0::2]
+        full[2 * sel + 1] = r[1::2]
         return full
-    t = prob.upload(full)
-    _dist.allreduce_sum_(t)
-    return prob.download(t, full.size)
+    pos = torch.from_numpy(np.ascontiguousarray(sel, np.int64)).to(prob.dev)
+    parts_r = _dist.allgather_padded(prob.r, prob.m)
+    parts_p = _dist.allgather_padded(pos, pos.numel())
+    for rr, pp in zip(parts_r, parts_p):
+        rr, pp = rr.cpu().numpy(), pp.cpu().numpy()
+        full[2 * pp] = rr[0::2]
+        full[2 * pp + 1] = rr[1::2]
+    return full
 
 
 def solve(opt, x0, bounds, ftol=1e-4, verbose=0, max_nfev=None, inner=None):

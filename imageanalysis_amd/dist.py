@@ -187,6 +187,32 @@ def allreduce_sum_(tensor, group=None):
     return tensor
 
 
+def allreduce_(tensor, op, group=None):
+    """op: 'sum' | 'max' | 'min' (the scalars of the BA outer iteration)"""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws > 1:
+        dist.all_reduce(tensor, op={'sum': dist.ReduceOp.SUM, 'max': dist.ReduceOp.MAX,
+                                    'min': dist.ReduceOp.MIN}[op], group=group)
+    return tensor
+
+
+def allgather_padded(tensor, count, group=None):
+    """every rank's first `count` (its own) entries of a 1-D tensor -> (list of per-rank tensors).
+    Slices of different length travel padded to the longest one."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return [tensor[:count]]
+    counts = allgather_objects(int(count))
+    longest = max(counts)
+    buf = torch.zeros(longest, dtype=tensor.dtype, device=tensor.device)
+    buf[:count].copy_(tensor[:count])
+    parts = [torch.empty_like(buf) for _ in range(ws)]
+    dist.all_gather(parts, buf, group=group)
+    return [p_[:c] for p_, c in zip(parts, counts)]
+
+
 def point_owner(point_indices, n_points, world_size):
     """rank that owns each point (contiguous blocks of point ids, balanced by observation
     count): point p belongs to rank floor(world * (observations of points < p) / total)."""

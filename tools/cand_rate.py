@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""How selective is the symmetric sweep's bound test on REAL descriptors?  Renders a 2 x 3 survey
+of 5472 x 3648 frames, detects, matches every pair through the shipped batch path and prints per
+ordered pair: rows, candidates (rows that passed the (L, U) bound test and are re-scanned exactly
+by symexact_kernel), survivors of the exact metric test -- next to the synthetic descriptors of
+bench.py, where candidates ~= survivors.        python tools/cand_rate.py"""
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from imageanalysis_amd import image as iimg, kernels, synth  # noqa: E402
+
+tmp = tempfile.mkdtemp(prefix='iamx_cand_')
+names, truth, logged, K = synth.make_rendered_survey(tmp, 2, 3, device='cuda', **synth.FULL_FRAME)
+des = []
+for n in names:
+    bgr = iimg._decode_bgr(os.path.join(tmp, 'images', n + '.JPG'))
+    kp, d32, d8 = iimg.features_from_bgr(bgr, 0.4, equalize=True, keep_u8=True)
+    des.append(np.ascontiguousarray(d8))
+    print(n, len(d8), 'keypoints')
+store = kernels.DescriptorStore.from_arrays(des)
+und = [(a, b) for a in range(len(des)) for b in range(a + 1, len(des))]
+ordered = np.array(und + [(b, a) for a, b in und], np.int32)
+pb = kernels.PairBatch(store, ordered, sym=True)
+ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+thresh = 270.0 * 0.75
+for it in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pb.run(ws, thresh)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+cand = ws.seg_count[:pb.n_pairs].cpu().numpy()
+surv = ws.surv_cnt[:pb.n_pairs].cpu().numpy()
+rows = np.array([len(des[a]) for a, _b in ordered])
+print('%d ordered pairs in %.1f ms' % (len(ordered), dt * 1e3))
+for (a, b), r, c, s in zip(ordered.tolist(), rows, cand, surv):
+    print('  %d -> %d: rows %6d  candidates %6d (%.1f %%)  survivors %5d' % (a, b, r, c, 100.0 * c / r, s))
+print('total: rows %d, candidates %d (%.1f %%), survivors %d' % (rows.sum(), cand.sum(), 100.0 * cand.sum() / rows.sum(), surv.sum()))
