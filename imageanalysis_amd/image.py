@@ -91,7 +91,10 @@ WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this p
 # zlib level of the float32 .desc (the reference passes compresslevel=6, image.py:213; every level
 # decompresses to the same bytes).  On integer-valued float32 descriptors level 6 runs at 9 MB/s
 # per core for a 0.32 ratio, level 1 at 50 MB/s for 0.38: the file is what a fresh detection costs
-DESC_GZIP_LEVEL = 1
+# IAMX_REFERENCE_GZIP=1: both cache files at the reference's own zlib setting (level 6, default
+# strategy) -- byte sizes like the reference's, at ~4x the host time per fresh detection
+_REF_GZIP = os.environ.get('IAMX_REFERENCE_GZIP') == '1'
+DESC_GZIP_LEVEL = 6 if _REF_GZIP else 1
 # decoded / cache-loaded images held ahead of the detector (one worker thread each; a 20 MP JPEG
 # takes ~0.2 s of one core to decode against ~6 ms on the GPU, 60 MB per decoded frame)
 # zlib setting of the .feat members.  The reference asks for compresslevel=6 (image.py:201); on a
@@ -99,7 +102,7 @@ DESC_GZIP_LEVEL = 1
 # cost of a fresh detection (tools/detect_stages.py: the GPU box's 16-core quota was spent on it).
 # Level 4 with Z_FILTERED (the records are mostly float bits: few matches, Huffman does the work) is
 # 72 ms for 24.9 bytes per keypoint -- the same bytes for every reader.  (6, 0) = the reference's.
-FEAT_GZIP_LEVEL, FEAT_GZIP_STRATEGY = 4, 1
+FEAT_GZIP_LEVEL, FEAT_GZIP_STRATEGY = (6, 0) if _REF_GZIP else (4, 1)
 PREFETCH_DEPTH = min(24, max(6, (os.cpu_count() or 8) // 4))
 
 
