@@ -886,7 +886,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_x_kernel(SymArgs A)
 // the sweep wrote its bounds in: coalesced reads) and drops a flag at the row's original
 // position; pass 2 lists the flagged rows in ascending original order at the pair's own slice
 // of cand_q (first entry out_off[p]: a pair cannot have more candidates than rows, so no scan
-// over the pairs is needed) and appends the pair's 32-candidate tasks to the exact stage's list.
+// over the pairs is needed) and appends the pair's 64-candidate tasks to the exact stage's list.
 // ---------------------------------------------------------------------------------
 struct CandArgs {
     const int32_t *sn2, *sperm, *img_off, *img_n;
@@ -899,8 +899,8 @@ struct CandArgs {
     uint8_t *keep;
     int32_t *cand_cnt;
     int32_t *cand_q;
-    int32_t *task_total;         // [1] tasks appended so far (zeroed by symcompact_kernel)
-    int32_t *tasks;              // [..][2] (ordered pair, block of 32 candidates)
+    int32_t *task_total;         // [2] wave tasks / workgroup tasks appended so far (zeroed by symcompact_kernel)
+    int32_t *tasks;              // [..][2] (ordered pair, block): wave tasks from entry 0, workgroup tasks from entry n_pairs
 };
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
@@ -963,10 +963,14 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         out += tot;
         __syncthreads();
     }
-    const int ntask = (out + 31) >> 5;
+    // two task lists in one buffer: a pair with <= 64 candidates is ONE wave's task (entries
+    // [0, n_pairs): at most one per pair), a pair with more gets workgroup tasks of 256 candidates
+    // whose four waves share every train tile through LDS (entries from n_pairs on)
+    const bool small = out <= 64;
+    const int ntask = small ? (out > 0 ? 1 : 0) : (out + 255) >> 8;
     if (threadIdx.x == 0) {
         A.cand_cnt[p] = out;
-        s_base = ntask ? atomicAdd(A.task_total, ntask) : 0;
+        s_base = ntask ? atomicAdd(A.task_total + (small ? 0 : 1), ntask) + (small ? 0 : (int)gridDim.x) : 0;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < ntask; t += 256)
@@ -987,6 +991,8 @@ struct ExactArgs {
     const int8_t *desc;          // original-order store (iamx_desc_pack_*)
     const int32_t *norm_q;       // |s|^2 per row
     const int32_t *norm_t;       // |s|^2 + 2 sum(s) per row
+    const int32_t *key_t;        // norm_t * 256 + (store row & 255) per row (symexact_keys_kernel)
+    int n_pairs;                 // (the workgroup tasks start at entry n_pairs of `tasks`)
     const int32_t *img_off, *img_n;
     const int32_t *pairs;
     const int64_t *out_off;      // first row of a pair in d2 AND first entry of its candidate list
@@ -1010,109 +1016,302 @@ __device__ __forceinline__ int med3_key(int a, int b, int c)
     return r;
 }
 
+// key_t[g] = norm_t[g] * 256 + (g & 255) for every row g of the store: the per-row constant of
+// the packed key, so that the scan below builds a key with ONE v_lshl_add_u32 per entry
+__global__ __launch_bounds__(256) void symexact_keys_kernel(const int32_t *__restrict__ norm_t,
+                                                            int64_t total_rows,
+                                                            int32_t *__restrict__ key_t)
+{
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total_rows;
+         g += (int64_t)gridDim.x * 256)
+        key_t[g] = norm_t[g] * 256 + (int)(g & 255);
+}
+
+__device__ __forceinline__ int lshl9_add(int a, int b)
+{
+    // (a << 9) + b in one instruction; `a` is a raw MFMA accumulator here: the compiler sees a
+    // plain VALU use of it and inserts the MFMA -> VALU wait states itself
+    return (int)(((unsigned)a << 9) + (unsigned)b);
+}
+
+// the end of a candidate's scan: merge the two lane halves (rows +4) lexicographically by
+// (distance, row), write the exact squared distances, the train row, the metric and the keep flag
+__device__ __forceinline__ void exact_finish(const ExactArgs &A, int p, int64_t cb, int cnt, int qoff,
+                                             int q, int k, int g, int bd1, int bi1, int bd2, int bi2)
+{
+    const int od1 = __shfl_xor(bd1, 32), oi1 = __shfl_xor(bi1, 32);
+    const int od2 = __shfl_xor(bd2, 32), oi2 = __shfl_xor(bi2, 32);
+    auto less = [](int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); };
+    int f_d, f_i, s_d;
+    if (less(od1, oi1, bd1, bi1)) {
+        f_d = od1; f_i = oi1;
+        s_d = less(bd1, bi1, od2, oi2) ? bd1 : od2;
+    } else {
+        f_d = bd1; f_i = bi1;
+        s_d = less(od1, oi1, bd2, bi2) ? od1 : bd2;
+    }
+    if (g == 0 && k < cnt) {
+        const int na = A.norm_q[qoff + q];
+        const int d1 = f_d + na, d2 = s_d + na;
+        *reinterpret_cast<v2i *>(A.d2 + 2 * (A.out_off[p] + q)) = v2i{d1, d2};
+        // cv2 L2 distance = float32 sqrt; the rest in float64 like python (matcher.py:253-263)
+        const float f0 = (float)sqrt((double)d1);
+        const float f1 = (float)sqrt((double)d2);
+        double mt;
+        bool ok = false;
+        if (f1 == 0.0f) {
+            mt = __longlong_as_double(0x7FF8000000000000LL);    // python raises ZeroDivisionError
+            atomicAdd(A.zero_div, 1);
+        } else {
+            mt = (double)f0 * ((double)f0 / (double)f1);
+            ok = mt < A.thresh;
+        }
+        A.cand_t[cb + k] = f_i;
+        A.cand_metric[cb + k] = mt;
+        A.cand_keep[cb + k] = ok ? 1 : 0;
+    }
+}
+
+// A TASK = up to 64 candidate rows of one ordered pair (two B operands: every train tile that
+// comes up from L2 serves both) against every row of its train image.  The scan is written for
+// the VALU, which bounds it: per 32 x 32 tile and candidate set 4 MFMAs and 16 x (key, med3, min)
+// = 48 VALU instructions -- the first version spent ~200 (key from three terms, a select for the
+// ragged last tile in every tile, 32 register copies for the one-tile-ahead prefetch) and ran at
+// 0.5 PFLOP/s, a third of the sweep's time on synthetic descriptors but THREE TIMES the sweep on
+// real frames, where a third to two thirds of a pair's rows are candidates.
+// Epochs of the packed keys follow the store's row numbers (images start on multiples of 128).
 __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
 {
     constexpr int KEY_INVALID = 0x7FFFFFFF;
-    const int total = *A.task_total;
+    const int total = A.task_total[0];
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, g = lane >> 5;
     const int nwaves = gridDim.x * 4;
     for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += nwaves) {
+        // (a task is the whole wave's: its numbers live in scalar registers, the tile loop's tests
+        //  are scalar branches)
         const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * t);
-        const int p = task.x;
+        const int p = __builtin_amdgcn_readfirstlane(task.x);
+        const int tblk = __builtin_amdgcn_readfirstlane(task.y);
         const int64_t cb = A.out_off[p];
-        const int cnt = A.cand_cnt[p];
-        const int k = task.y * 32 + c;
-        const int q = A.cand_q[cb + (k < cnt ? k : cnt - 1)];
+        const int cnt = __builtin_amdgcn_readfirstlane(A.cand_cnt[p]);
         const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
-        const int qoff = A.img_off[qimg], toff = A.img_off[timg], nt = A.img_n[timg];
-        v4i bq[4];
-        {
-            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q) * D);
+        const int qoff = __builtin_amdgcn_readfirstlane(A.img_off[qimg]);
+        const int toff = __builtin_amdgcn_readfirstlane(A.img_off[timg]);
+        const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
+        int kq[2], q[2];
+        v4i bq[2][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bq[s] = ~src[2 * s + g];
+        for (int h = 0; h < 2; ++h) {
+            kq[h] = tblk * 64 + h * 32 + c;
+            q[h] = A.cand_q[cb + (kq[h] < cnt ? kq[h] : cnt - 1)];
+            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q[h]) * D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[h][s] = ~src[2 * s + g];
         }
         const int8_t *tbase = A.desc + (int64_t)toff * D;
-        const int32_t *tnorm = A.norm_t + toff;
+        const int32_t *tkey = A.key_t + toff;
         const int ntiles = (nt + 31) / 32;
-        auto load_tile = [&](int tile, v4i (&a)[4], v4i (&tb)[4]) {
+        auto load_tile = [&](int tile, v4i (&a)[4], v4i (&tk)[4]) {
             // rows past the end stay inside the image's 128-row padding; their keys are masked
             const v4i *src = reinterpret_cast<const v4i *>(tbase + (int64_t)(tile * 32 + c) * D);
 #pragma unroll
             for (int s = 0; s < 4; ++s) a[s] = src[2 * s + g];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                tb[kk] = *reinterpret_cast<const v4i *>(tnorm + tile * 32 + 8 * kk + 4 * g);
+                tk[kk] = *reinterpret_cast<const v4i *>(tkey + tile * 32 + 8 * kk + 4 * g);
         };
-        int m1 = KEY_INVALID, m2 = KEY_INVALID;
-        int bd1 = KEY_INVALID, bi1 = 0, bd2 = KEY_INVALID, bi2 = 0;
-        v4i a[4], tb[4];
-        load_tile(0, a, tb);
-        for (int tile = 0; tile < ntiles; ++tile) {
-            v4i a_nx[4], tb_nx[4];
-            load_tile(tile + 1 < ntiles ? tile + 1 : tile, a_nx, tb_nx);
-            v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int m1[2] = {KEY_INVALID, KEY_INVALID}, m2[2] = {KEY_INVALID, KEY_INVALID};
+        int bd1[2] = {KEY_INVALID, KEY_INVALID}, bi1[2] = {0, 0};
+        int bd2[2] = {KEY_INVALID, KEY_INVALID}, bi2[2] = {0, 0};
+        // a task at the end of a pair's list (or the only one of a pair with a few candidates --
+        // every pair of bench.py's synthetic surveys) fills one candidate set only
+        const bool two_sets = cnt - tblk * 64 > 32;
+        auto scan_tile = [&](int tile, const v4i (&a)[4], const v4i (&tk)[4]) {
+            const bool ragged = tile * 32 + 32 > nt;              // (wave uniform: the last tile only)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[s], acc, 0, 0, 0);
-            const bool ragged = tile * 32 + 32 > nt;
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two_sets) break;
+                v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = tile * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3);
-                int key = tb[reg >> 2][reg & 3] * 256 + (row & 255) + (acc[reg] << 9);
-                if (ragged) key = row < nt ? key : KEY_INVALID;
-                m2 = med3_key(m1, m2, key);
-                m1 = min(m1, key);
-            }
-            // fold the packed keys of this 256-row epoch into (distance, index) pairs
-            if ((tile & 7) == 7 || tile == ntiles - 1) {
-                const int sbase = (tile >> 3) * 256;
-                const int d1k = m1 >> 8, i1k = sbase + (m1 & 255);
-                const int d2k = m2 >> 8, i2k = sbase + (m2 & 255);
-                if (d1k < bd1) {
-                    if (d2k < bd1) { bd2 = d2k; bi2 = i2k; }
-                    else           { bd2 = bd1; bi2 = bi1; }
-                    bd1 = d1k; bi1 = i1k;
-                } else if (d1k < bd2) {
-                    bd2 = d1k; bi2 = i1k;
+                for (int s = 0; s < 4; ++s)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                if (!ragged) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int key = lshl9_add(acc[reg], tk[reg >> 2][reg & 3]);
+                        m2[h] = med3_key(m1[h], m2[h], key);
+                        m1[h] = min(m1[h], key);
+                    }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = tile * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3);
+                        int key = lshl9_add(acc[reg], tk[reg >> 2][reg & 3]);
+                        key = row < nt ? key : KEY_INVALID;
+                        m2[h] = med3_key(m1[h], m2[h], key);
+                        m1[h] = min(m1[h], key);
+                    }
                 }
-                m1 = m2 = KEY_INVALID;
             }
+            // fold the packed keys of this 256-row epoch of the STORE into (distance, row) pairs
+            const int grow = toff + tile * 32;                    // first store row of the tile
+            if (((grow + 32) & 255) == 0 || tile == ntiles - 1) {
+                const int sbase = (grow & ~255) - toff;           // epoch start as a row of the image
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { a[s] = a_nx[s]; tb[s] = tb_nx[s]; }
-        }
-        // merge the two lane halves (rows +4) lexicographically by (distance, row)
-        const int od1 = __shfl_xor(bd1, 32), oi1 = __shfl_xor(bi1, 32);
-        const int od2 = __shfl_xor(bd2, 32), oi2 = __shfl_xor(bi2, 32);
-        auto less = [](int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); };
-        int f_d, f_i, s_d;
-        if (less(od1, oi1, bd1, bi1)) {
-            f_d = od1; f_i = oi1;
-            s_d = less(bd1, bi1, od2, oi2) ? bd1 : od2;
-        } else {
-            f_d = bd1; f_i = bi1;
-            s_d = less(od1, oi1, bd2, bi2) ? od1 : bd2;
-        }
-        if (g == 0 && k < cnt) {
-            const int na = A.norm_q[qoff + q];
-            const int d1 = f_d + na, d2 = s_d + na;
-            *reinterpret_cast<v2i *>(A.d2 + 2 * (A.out_off[p] + q)) = v2i{d1, d2};
-            // cv2 L2 distance = float32 sqrt; the rest in float64 like python (matcher.py:253-263)
-            const float f0 = (float)sqrt((double)d1);
-            const float f1 = (float)sqrt((double)d2);
-            double mt;
-            bool ok = false;
-            if (f1 == 0.0f) {
-                mt = __longlong_as_double(0x7FF8000000000000LL);    // python raises ZeroDivisionError
-                atomicAdd(A.zero_div, 1);
-            } else {
-                mt = (double)f0 * ((double)f0 / (double)f1);
-                ok = mt < A.thresh;
+                for (int h = 0; h < 2; ++h) {
+                    const int d1k = m1[h] >> 8, i1k = sbase + (m1[h] & 255);
+                    const int d2k = m2[h] >> 8, i2k = sbase + (m2[h] & 255);
+                    if (d1k < bd1[h]) {
+                        if (d2k < bd1[h]) { bd2[h] = d2k; bi2[h] = i2k; }
+                        else              { bd2[h] = bd1[h]; bi2[h] = bi1[h]; }
+                        bd1[h] = d1k; bi1[h] = i1k;
+                    } else if (d1k < bd2[h]) {
+                        bd2[h] = d1k; bi2[h] = i1k;
+                    }
+                    m1[h] = m2[h] = KEY_INVALID;
+                }
             }
-            A.cand_t[cb + k] = f_i;
-            A.cand_metric[cb + k] = mt;
-            A.cand_keep[cb + k] = ok ? 1 : 0;
+        };
+        // two register sets, tiles alternate between them: the loads of tile + 1 are in flight
+        // while tile is scanned, without copying a set into the other
+        v4i a0[4], k0[4], a1[4], k1[4];
+        load_tile(0, a0, k0);
+        for (int tile = 0; tile < ntiles; tile += 2) {
+            load_tile(tile + 1 < ntiles ? tile + 1 : tile, a1, k1);
+            scan_tile(tile, a0, k0);
+            if (tile + 1 < ntiles) {
+                load_tile(tile + 2 < ntiles ? tile + 2 : tile + 1, a0, k0);
+                scan_tile(tile + 1, a1, k1);
+            }
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            exact_finish(A, p, cb, cnt, qoff, q[h], kq[h], g, bd1[h], bi1[h], bd2[h], bi2[h]);
+    }
+}
+
+// Workgroup form of the exact stage for pairs with MANY candidates (real frames: a third to two
+// thirds of a pair's rows): a task = 256 candidates of one ordered pair, 64 per wave as two B
+// operands; the four waves share every 32-row train tile through LDS -- fetched once per
+// workgroup, coalesced (thread = 16 bytes of a row, a wave = 8 whole rows) instead of once per wave
+// as 64 scattered 16-byte pieces (what bounded the wave form: the CU's texture addresser, not the
+// VALU).  LDS rows are XOR-swizzled by 16-byte chunk (chunk j of row r sits at j ^ (r & 7)): the
+// MFMA operand reads of 32 lanes x one chunk column spread over the banks.  Two tile buffers, one
+// barrier per tile; tile T + 1 is in flight from L2 while tile T is scanned.
+__global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
+{
+    constexpr int KEY_INVALID = 0x7FFFFFFF;
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][32 * D];
+    __shared__ __attribute__((aligned(16))) int32_t s_key[2][32];
+    const int total = A.task_total[1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;      // staging: 16 bytes per thread
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * ((int64_t)A.n_pairs + t));
+        const int p = __builtin_amdgcn_readfirstlane(task.x);
+        const int tblk = __builtin_amdgcn_readfirstlane(task.y);
+        const int64_t cb = A.out_off[p];
+        const int cnt = __builtin_amdgcn_readfirstlane(A.cand_cnt[p]);
+        const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
+        const int qoff = __builtin_amdgcn_readfirstlane(A.img_off[qimg]);
+        const int toff = __builtin_amdgcn_readfirstlane(A.img_off[timg]);
+        const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
+        const int k_wave = tblk * 256 + wave * 64;                     // first candidate of this wave
+        const int n_sets = cnt - k_wave > 32 ? 2 : (cnt - k_wave > 0 ? 1 : 0);
+        int kq[2], q[2];
+        v4i bq[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            kq[h] = k_wave + h * 32 + c;
+            q[h] = A.cand_q[cb + (kq[h] < cnt ? kq[h] : cnt - 1)];
+            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q[h]) * D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[h][s] = ~src[2 * s + g];
+        }
+        const int8_t *tbase = A.desc + (int64_t)toff * D;
+        const int32_t *tkey = A.key_t + toff;
+        const int ntiles = (nt + 31) / 32;
+        int m1[2] = {KEY_INVALID, KEY_INVALID}, m2[2] = {KEY_INVALID, KEY_INVALID};
+        int bd1[2] = {KEY_INVALID, KEY_INVALID}, bi1[2] = {0, 0};
+        int bd2[2] = {KEY_INVALID, KEY_INVALID}, bi2[2] = {0, 0};
+        // (rows past the end stay inside the image's 128-row padding; their keys are masked)
+        auto fetch = [&](int tile, v4i &row16, int &key) {
+            row16 = *reinterpret_cast<const v4i *>(tbase + (int64_t)(tile * 32 + lrow) * D + 16 * lchunk);
+            key = threadIdx.x < 32 ? tkey[tile * 32 + threadIdx.x] : 0;
+        };
+        auto stage = [&](int buf, const v4i row16, int key) {
+            *reinterpret_cast<v4i *>(&s_tile[buf][lrow * D + 16 * (lchunk ^ (lrow & 7))]) = row16;
+            if (threadIdx.x < 32) s_key[buf][threadIdx.x] = key;
+        };
+        v4i pre;
+        int pre_key;
+        __syncthreads();                               // (the previous task's last tile is consumed)
+        fetch(0, pre, pre_key);
+        stage(0, pre, pre_key);
+        __syncthreads();
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int buf = tile & 1;
+            if (tile + 1 < ntiles) fetch(tile + 1, pre, pre_key);
+            if (n_sets > 0) {
+                v4i a[4], tk[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    a[s] = *reinterpret_cast<const v4i *>(&s_tile[buf][c * D + 16 * ((2 * s + g) ^ (c & 7))]);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    tk[kk] = *reinterpret_cast<const v4i *>(&s_key[buf][8 * kk + 4 * g]);
+                const bool ragged = tile * 32 + 32 > nt;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && n_sets < 2) break;
+                    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                    if (!ragged) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int key = lshl9_add(acc[reg], tk[reg >> 2][reg & 3]);
+                            m2[h] = med3_key(m1[h], m2[h], key);
+                            m1[h] = min(m1[h], key);
+                        }
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int row = tile * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3);
+                            int key = lshl9_add(acc[reg], tk[reg >> 2][reg & 3]);
+                            key = row < nt ? key : KEY_INVALID;
+                            m2[h] = med3_key(m1[h], m2[h], key);
+                            m1[h] = min(m1[h], key);
+                        }
+                    }
+                }
+                const int grow = toff + tile * 32;
+                if (((grow + 32) & 255) == 0 || tile == ntiles - 1) {
+                    const int sbase = (grow & ~255) - toff;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d1k = m1[h] >> 8, i1k = sbase + (m1[h] & 255);
+                        const int d2k = m2[h] >> 8, i2k = sbase + (m2[h] & 255);
+                        if (d1k < bd1[h]) {
+                            if (d2k < bd1[h]) { bd2[h] = d2k; bi2[h] = i2k; }
+                            else              { bd2[h] = bd1[h]; bi2[h] = bi1[h]; }
+                            bd1[h] = d1k; bi1[h] = i1k;
+                        } else if (d1k < bd2[h]) {
+                            bd2[h] = d1k; bi2[h] = i1k;
+                        }
+                        m1[h] = m2[h] = KEY_INVALID;
+                    }
+                }
+            }
+            if (tile + 1 < ntiles) stage(buf ^ 1, pre, pre_key);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            exact_finish(A, p, cb, cnt, qoff, q[h], kq[h], g, bd1[h], bi1[h], bd2[h], bi2[h]);
     }
 }
 
@@ -1156,7 +1355,7 @@ __global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restri
     }
     if (threadIdx.x == 0) {
         surv_cnt[p] = out;
-        if (p == 0) *task_total = 0;           // the exact stage has consumed the list
+        if (p == 0) task_total[0] = task_total[1] = 0;   // the exact stage has consumed the lists
     }
 }
 
@@ -1296,6 +1495,7 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
 }
 
 extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
+                                  int32_t *key_t, int64_t total_rows,
                                   const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
                                   const int64_t *out_off, const int32_t *cand_cnt,
                                   int32_t *task_total, const int32_t *tasks, int32_t *cand_q,
@@ -1303,15 +1503,24 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
                                   double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
                                   int32_t *zero_div, void *stream)
 {
-    IAMX_REQUIRE(desc && norm_q && norm_t && img_off && img_n && pairs && out_off && cand_cnt &&
+    IAMX_REQUIRE(desc && norm_q && norm_t && key_t && img_off && img_n && pairs && out_off && cand_cnt &&
                      task_total && tasks && cand_q && d2 && cand_t && cand_metric && cand_keep &&
                      surv_cnt && zero_div,
                  "null pointer");
+    IAMX_REQUIRE(total_rows >= 0, "negative row count");
     if (n_pairs <= 0) return IAMX_OK;
     hipStream_t st = iamx::as_stream(stream);
-    ExactArgs a{desc, norm_q, norm_t, img_off, img_n, pairs, out_off, cand_cnt, cand_q, task_total,
-                tasks, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
-    hipLaunchKernelGGL(symexact_kernel, dim3(1024), dim3(256), 0, st, a);
+    // (46 MB each way for the 2812-image store of configs[2]: ~20 us beside a 7 ms round; rebuilt
+    //  every call, so the keys can never be stale against a re-packed store)
+    if (total_rows > 0) {
+        int64_t gk = (total_rows + 255) / 256;
+        hipLaunchKernelGGL(symexact_keys_kernel, dim3((unsigned)(gk > 4096 ? 4096 : gk)), dim3(256), 0, st,
+                           norm_t, total_rows, key_t);
+    }
+    ExactArgs a{desc, norm_q, norm_t, key_t, n_pairs, img_off, img_n, pairs, out_off, cand_cnt, cand_q,
+                task_total, tasks, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
+    hipLaunchKernelGGL(symexact_kernel, dim3(1024), dim3(256), 0, st, a);       // pairs with <= 64 candidates
+    hipLaunchKernelGGL(symexact_wg_kernel, dim3(2048), dim3(256), 0, st, a);    // the others, 256 per workgroup
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,
                        cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total);
     return iamx::check_launch("iamx_knn2sym_exact");

@@ -51,6 +51,7 @@ class DescriptorStore(object):
         self.desc = torch.empty((total, 128), dtype=I8, device=dev)
         self.norm_q = torch.empty(total, dtype=I32, device=dev)
         self.norm_t = torch.empty(total, dtype=I32, device=dev)
+        self.key_t = torch.empty(total, dtype=I32, device=dev)      # scratch of iamx_knn2sym_exact
         self.img_off = torch.from_numpy(offs[:-1].astype(np.int32)).to(dev)
         self.img_n = torch.tensor(self.counts, dtype=I32, device=dev) if self.counts else \
             torch.zeros(0, dtype=I32, device=dev)
@@ -333,8 +334,10 @@ class PairWorkspace(object):
         # symmetric sweep: bounds per row (allocated on first use, grown when a batch needs more)
         self.col = self.rowp = None
         self.cand_keep = torch.empty(r, dtype=U8, device=dev)
-        self.task_total = torch.zeros(1, dtype=I32, device=dev)
-        self.tasks = torch.empty((p + r // 32 + 1, 2), dtype=I32, device=dev)
+        # exact stage of the symmetric form: two task lists in one buffer (wave tasks from entry
+        # 0, workgroup tasks from entry n_pairs) and their two counters
+        self.task_total = torch.zeros(2, dtype=I32, device=dev)
+        self.tasks = torch.empty((2 * p + r // 32 + 2, 2), dtype=I32, device=dev)
 
     def ensure_sym(self, col_rows, rowp_rows):
         dev = self.d2.device
@@ -493,7 +496,8 @@ class PairBatch(object):
                                         _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_q),
                                         _ptr(ws.task_total), _ptr(ws.tasks), s),
               'iamx_knn2sym_candidates')
-        check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.img_off),
+        check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.key_t),
+                                   st.norm_t.numel(), _ptr(st.img_off),
                                    _ptr(st.img_n), _ptr(self.d_pairs), _ptr(self.d_out),
                                    _ptr(ws.seg_count), _ptr(ws.task_total), _ptr(ws.tasks),
                                    _ptr(ws.surv_q), self.n_pairs, float(thresh), _ptr(ws.d2),

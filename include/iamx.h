@@ -206,10 +206,15 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  *   cand_cnt DEV [n_pairs] (written); cand_q DEV [rows]: the candidate query rows (original
  *   numbering, ascending) of pair p at out_off[p] .. + cand_cnt[p] -- a pair's list lives in
  *   its own slice of the row range, no scan over the pairs;
- *   task_total DEV [1] (must be 0 on entry; iamx_knn2sym_exact leaves it 0), tasks DEV
- *   [n_pairs + rows/32][2]: the 32-candidate tasks (ordered pair, block) of the exact stage.
- * Exact: desc / norm_q / norm_t / img_off = the ORIGINAL-order store of iamx_desc_pack_*.  One
- *   wave per task: 32 candidates x the whole train image on the MFMA.  Writes d2 DEV [rows][2]
+ *   task_total DEV [2] (must be 0 on entry; iamx_knn2sym_exact leaves it 0), tasks DEV
+ *   [2 n_pairs + rows/32 + 2][2]: the tasks (ordered pair, block) of the exact stage -- wave
+ *   tasks (pairs with <= 64 candidates) from entry 0, workgroup tasks (256 candidates) from
+ *   entry n_pairs.
+ * Exact: desc / norm_q / norm_t / img_off = the ORIGINAL-order store of iamx_desc_pack_*.  A
+ *   wave task: <= 64 candidates x the whole train image on the MFMA, train tiles straight from
+ *   L2; a workgroup task: 4 x 64 candidates, every train tile staged once in LDS for the four
+ *   waves (the form real frames need: a third to two thirds of a pair's rows are candidates
+ *   there, against 0.1 % on uncorrelated synthetic descriptors).  Writes d2 DEV [rows][2]
  *   for the candidate rows, then compacts every pair's list in place to its survivors: pair p
  *   owns cand_q / cand_t / cand_metric [out_off[p] .. + surv_cnt[p]); zero_div is incremented
  *   for every row whose exact second distance is 0 (matcher.py:255 divides by it).
@@ -239,7 +244,14 @@ int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int3
                             const int64_t *out_off, const int32_t *col, const int32_t *rowp,
                             int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
                             int32_t *cand_q, int32_t *task_total, int32_t *tasks, void *stream);
+/* key_t DEV [total_rows] int32 scratch beside norm_t (total_rows = rows of the whole original-
+ * order store): rewritten by every call with the per-row constant of the packed (distance, row)
+ * key.  task_total DEV [2], tasks DEV [2 n_pairs + rows / 32 + 2][2] (iamx_knn2sym_candidates
+ * fills them: a pair with <= 64 candidates is one WAVE task, entries from 0; a pair with more
+ * gets WORKGROUP tasks of 256 candidates, entries from n_pairs -- four waves share every train
+ * tile through LDS; both counters are reset by this call). */
 int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
+                       int32_t *key_t, int64_t total_rows,
                        const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
                        const int64_t *out_off, const int32_t *cand_cnt, int32_t *task_total,
                        const int32_t *tasks, int32_t *cand_q, int n_pairs, double thresh,
