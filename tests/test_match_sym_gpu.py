@@ -338,3 +338,44 @@ def test_sym_keypoint_counts_of_full_resolution_frames():
         assert np.array_equal(res['sq'][lo:hi], keep) and np.array_equal(res['st'][lo:hi], tidx)
         assert np.array_equal(res['sm'][lo:hi], metric)
         assert np.array_equal(res['d2'][res['off'][p] + keep], rd2)
+
+
+@pytest.mark.parametrize('sizes', [(5000, 4097), (700, 20000), (4096, 4096, 333)])
+def test_exact_stage_with_many_candidates(sizes):
+    """Pairs whose rows mostly MATCH (real frames of one scene: a third to two thirds of a pair's
+    rows are candidates) go through the workgroup form of the exact stage -- 256 candidates per
+    task, train tiles shared through LDS -- and pairs with <= 64 candidates through the wave form;
+    both against oracle/cpu_ref.c: survivor rows, train rows, metrics, squared distances.  Ragged
+    sizes (last tile masked, images starting at odd multiples of 128 rows in the store), planted
+    exact duplicates (ties -> lowest train row), a candidate count that is not a multiple of 32."""
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(sum(sizes))
+    imgs = [_sift_like(rng, sizes[0])]
+    for n in sizes[1:]:
+        # most rows of the next image are noisy copies of rows of the first one
+        src = rng.integers(0, sizes[0], n)
+        im = np.clip(imgs[0][src].astype(int) + rng.integers(-3, 4, (n, 128)), 0, 255).astype(np.uint8)
+        fresh = rng.random(n) < 0.35
+        im[fresh] = _sift_like(rng, int(fresh.sum()))
+        imgs.append(im)
+    imgs[1][10] = imgs[0][7]                 # an exact copy: distance 0
+    imgs[1][11] = imgs[1][10]                # ... twice: the lower train row wins, second distance 0
+    imgs.append(_sift_like(rng, 200))        # an unrelated small image: few or no candidates (wave form)
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    k = len(imgs)
+    pairs = [(a, b) for a in range(k) for b in range(k) if a != b]
+    thresh = 270.0 * 0.75
+    got = _run(store, pairs, thresh, sym=True)
+    assert got['pb'].sym and got['unresolved'] == 0
+    many = 0
+    zero_div = 0
+    for p, (a, b) in enumerate(pairs):
+        keep, t, m, d2, zd = _oracle_survivors(imgs[a], imgs[b], thresh)
+        zero_div += zd
+        lo, hi = got['soff'][p], got['soff'][p + 1]
+        assert np.array_equal(got['sq'][lo:hi], keep), (a, b)
+        assert np.array_equal(got['st'][lo:hi], t), (a, b)
+        assert np.array_equal(got['sm'][lo:hi], m), (a, b)
+        assert np.array_equal(got['d2'][got['off'][p] + keep], d2), (a, b)
+        many += len(keep) > 256
+    assert many >= 2 and got['zero_div'] == zero_div
