@@ -43,17 +43,22 @@ def compute(image_list, matches):
     print("Notice: I should really work on this formula ...")
 
     n = len(matches)
-    ptr = np.zeros(n + 1, np.int64)
-    import gc
-    gc_was = gc.isenabled()
-    gc.disable()               # (millions of small lists alive: see match_cleanup.triangulate_smart)
-    try:
-        if n:
-            np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
-        img = np.fromiter((p[0] for m in matches for p in m[2:]), np.int32, int(ptr[-1]))
-    finally:
-        if gc_was:
-            gc.enable()
+    from .match_cleanup import Chains
+    fast = isinstance(matches, Chains) and matches.untouched()
+    if fast:
+        ptr, img = matches.ptr, matches.img           # the arrays link_matches() linked
+    else:
+        ptr = np.zeros(n + 1, np.int64)
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()           # (millions of small lists alive: see match_cleanup.triangulate_smart)
+        try:
+            if n:
+                np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
+            img = np.fromiter((p[0] for m in matches for p in m[2:]), np.int32, int(ptr[-1]))
+        finally:
+            if gc_was:
+                gc.enable()
     level = np.full(n, -1, np.int32)
     placed_images = set()
     placed_flag = np.zeros(max(n_img, 1), np.uint8)
@@ -87,6 +92,9 @@ def compute(image_list, matches):
             groups.append(group_list)
         if len(group_images) < 3:
             done = True
+    if fast and matches.untouched():
+        matches.group[:] = level
+        return groups
     for m, lv in zip(matches, level.tolist()):
         m[1] = lv
     return groups

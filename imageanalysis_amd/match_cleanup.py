@@ -216,6 +216,95 @@ def _flatten(matches):
             ptr)
 
 
+class Chains(object):
+    """link_matches()'s result -- the `matches_grouped` of scripts/process.py:305-405 -- as a
+    sequence of `[ned | None, group, [image, [u, v]], ...]` lists backed by flat arrays: ptr int64
+    [n + 1], img int32 [total], uv float64 [total, 2] (chain c owns [ptr[c], ptr[c + 1])), ned
+    float64 [n, 3] + has_ned, group int32 [n].  A survey of hundreds of frames links millions of
+    chains (2.2 M at 512 frames of 20 MP): as python lists they are tens of millions of objects that
+    every consumer re-flattened, and at BASELINE configs[4]'s 10 k frames they do not fit.  This
+    package's own consumers (triangulate_smart, groups.compute, Optimizer.setup / refit) read and
+    write the arrays; `pickle.dump` writes the reference's plain list of lists WITHOUT keeping it;
+    anybody who indexes or iterates gets real lists -- all of them, built once, and from then on
+    they are the truth (`untouched()` is False and every consumer takes its list path), because
+    the caller may edit what it was handed."""
+
+    def __init__(self, img, uv, ptr):
+        self.img = np.ascontiguousarray(img, np.int32)
+        self.uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        self.ptr = np.ascontiguousarray(ptr, np.int64)
+        n = len(self.ptr) - 1
+        self.ned = np.zeros((n, 3), np.float64)
+        self.has_ned = np.zeros(n, bool)
+        self.group = np.full(n, -1, np.int32)
+        self._rows = None
+
+    @classmethod
+    def from_lists(cls, rows):
+        """a loaded `matches_grouped` pickle (plain lists) as the array-backed form"""
+        ptr = np.zeros(len(rows) + 1, np.int64)
+        if len(rows):
+            np.cumsum([len(m) - 2 for m in rows], out=ptr[1:])
+        flat = [p for m in rows for p in m[2:]]
+        self = cls(np.fromiter((p[0] for p in flat), np.int32, len(flat)),
+                   np.array([p[1] for p in flat], np.float64).reshape(-1, 2), ptr)
+        for c, m in enumerate(rows):
+            if m[0] is not None:
+                self.ned[c] = m[0]
+                self.has_ned[c] = True
+            self.group[c] = m[1]
+        return self
+
+    def untouched(self):
+        return self._rows is None
+
+    def _build(self):
+        with _no_gc():
+            pts = [[i, p] for i, p in zip(self.img.tolist(), self.uv.tolist())]
+            lo, hi = self.ptr[:-1].tolist(), self.ptr[1:].tolist()
+            ned = self.ned.tolist()
+            return [[ned[c] if h else None, g] + pts[a:b]
+                    for c, (a, b, h, g) in enumerate(zip(lo, hi, self.has_ned.tolist(), self.group.tolist()))]
+
+    def rows(self):
+        if self._rows is None:
+            self._rows = self._build()
+            if len(self._rows) > 100000 and hasattr(gc, 'freeze'):
+                gc.freeze()                    # (see link_matches)
+        return self._rows
+
+    def __len__(self):
+        return len(self.ptr) - 1 if self._rows is None else len(self._rows)
+
+    def __getitem__(self, k):
+        return self.rows()[k]
+
+    def __iter__(self):
+        return iter(self.rows())
+
+    def __eq__(self, other):
+        return self.rows() == (other.rows() if isinstance(other, Chains) else other)
+
+    __hash__ = None
+
+    def __reduce_ex__(self, protocol):
+        # the matches_grouped pickle: a plain list of lists (not kept when the arrays are the truth)
+        return (list, (self._rows if self._rows is not None else self._build(),))
+
+    # list methods the reference's scripts use on matches_grouped
+    def __delitem__(self, k):
+        del self.rows()[k]
+
+    def __setitem__(self, k, v):
+        self.rows()[k] = v
+
+    def append(self, v):
+        self.rows().append(v)
+
+    def sort(self, *a, **k):
+        self.rows().sort(*a, **k)
+
+
 def link_matches(proj, matches_direct):
     """Chains of [img, kp] per feature by the reference's order-dependent rules (native code),
     keypoint indices replaced by [u, v], longest chains first (stable)."""
@@ -253,21 +342,15 @@ def link_matches(proj, matches_direct):
     _log("Sorting matches by longest chain first.")
     lens = np.diff(o_ptr)
     order = np.argsort(-lens, kind='stable')          # list.sort(key=len, reverse=True) is stable
-    with _no_gc():
-        pts = [[i, p] for i, p in zip(o_img[:total].tolist(), uv.tolist())]
-        lo, hi = o_ptr[:-1].tolist(), o_ptr[1:].tolist()
-        out = [[None, -1] + pts[lo[c]:hi[c]] for c in order.tolist()]
+    # the chains in that order, as arrays (Chains builds the reference's lists only on demand)
+    new_ptr = np.zeros(n_chain + 1, np.int64)
+    np.cumsum(lens[order], out=new_ptr[1:])
+    take = (np.repeat(o_ptr[:-1][order] - new_ptr[:-1], lens[order]) + np.arange(total)) if total else \
+        np.zeros(0, np.int64)
+    out = Chains(o_img[:total][take], uv[take], new_ptr)
     if n_chain:
         _log("Total unique features in image set:", n_chain)
         _log("Keypoint average instances:", "%.2f" % (total / float(n_chain)))
-    if n_chain > 100000 and hasattr(gc, 'freeze'):
-        # The chains are millions of small lists that live until the process ends and hold no
-        # reference cycles.  Left in the collector's youngest generations they make the next
-        # full collection -- triggered by whatever allocates next: the triangulation, the
-        # optimizer's setup -- walk all of them (seconds on a survey of hundreds of frames).
-        # gc.freeze() moves everything alive now to the permanent generation; reference counting
-        # still frees it.
-        gc.freeze()
     return out
 
 
@@ -325,10 +408,14 @@ def triangulate_smart(proj, matches):
     n = len(matches)
     if n == 0:
         return
+    fast = isinstance(matches, Chains) and matches.untouched()
     # (millions of small lists are alive here -- the matches_grouped contract --: every
     #  generation-2 pass of the cyclic collector walks them all again, and the list-building
     #  calls below trigger many)
-    with _no_gc():
+    if fast:
+        ptr, obs_img, obs_uv = matches.ptr, matches.img, matches.uv
+    else:
+      with _no_gc():
         ptr = np.zeros(n + 1, np.int64)
         np.cumsum([len(m) - 2 for m in matches], out=ptr[1:])
         flat = [p for m in matches for p in m[2:]]
@@ -345,6 +432,10 @@ def triangulate_smart(proj, matches):
                                         stream_ptr()), 'iamx_triangulate_ground')
     for _ in range(int(n_sky.item())):
         _log('vector projected above horizon.')
+    if fast and matches.untouched():
+        matches.ned[:] = out.cpu().numpy()
+        matches.has_ned[:] = True
+        return
     with _no_gc():
         res = out.cpu().numpy().tolist()
         for m, p in zip(matches, res):

@@ -275,6 +275,9 @@ class Optimizer():
             self.camera_params[cam_idx * self.ncp:cam_idx * self.ncp + self.ncp] = \
                 np.append(ned, quat)
 
+        from .match_cleanup import Chains
+        if isinstance(matches_list, Chains) and matches_list.untouched():
+            return self._setup_from_arrays(matches_list, placed_images, group_index)
         # one pass over the matches (the reference makes three with the same test)
         pts, obs_cam, obs_feat, obs_uv = [], [], [], []
         cam_rev = self.camera_map_rev
@@ -305,6 +308,45 @@ class Optimizer():
         obs_cam = np.asarray(obs_cam, np.int64)
         obs_feat = np.asarray(obs_feat, np.int64)
         obs_uv = np.asarray(obs_uv, np.float64).reshape(-1, 2)
+        order = np.argsort(obs_cam, kind='stable')
+        counts = np.bincount(obs_cam, minlength=self.n_cameras) if n_observations else \
+            np.zeros(self.n_cameras, np.int64)
+        splits = np.cumsum(counts)[:-1]
+        self.by_camera_point_indices = [np.array(a) for a in np.split(obs_feat[order], splits)]
+        self.by_camera_points_2d = [a.reshape(len(a), 1, 2)
+                                    for a in np.split(obs_uv[order], splits)]
+        self.camera_indices = obs_cam[order].astype(int)
+        self.point_indices = obs_feat[order].astype(int)
+        self._dev = None
+        _log("num observations:", n_observations)
+
+    def _setup_from_arrays(self, chains, placed_images, group_index):
+        """the match pass of setup() on link_matches()'s arrays (match_cleanup.Chains): the same
+        selections in the same order, without a python object per chain member"""
+        ptr, img, uv = chains.ptr, chains.img, chains.uv
+        n = len(ptr) - 1
+        n_img = int(img.max()) + 1 if len(img) else 0
+        placed = np.zeros(max(n_img, max(placed_images, default=-1) + 1, 1), bool)
+        placed[list(placed_images)] = True
+        cam_of = np.full(len(placed), -1, np.int64)
+        for i, index in self.camera_map_fwd.items():
+            cam_of[index] = i
+        chain_of = np.repeat(np.arange(n), np.diff(ptr))
+        ok_obs = placed[img] & (chains.group[chain_of] == group_index)
+        per_chain = np.bincount(chain_of[ok_obs], minlength=n)
+        use = np.nonzero(per_chain >= self.min_chain_len)[0]          # ascending = the loop's order
+        feat_of = np.full(n, -1, np.int64)
+        feat_of[use] = np.arange(len(use))
+        self.feat_map_fwd = dict(zip(use.tolist(), range(len(use))))
+        self.feat_map_rev = dict(zip(range(len(use)), use.tolist()))
+        self.n_points = len(use)
+        pts = np.where(chains.has_ned[use, None], chains.ned[use], np.nan)   # (None -> nan, as np.asarray does)
+        for k in np.nonzero(np.isnan(pts).any(axis=1))[0]:       # optimizer.py:352-353
+            print(self.feat_map_rev[int(k)], pts[k])
+        self.points_3d = pts.reshape(-1).copy() if self.n_points else np.empty(0)
+        sel = np.nonzero(ok_obs & (feat_of[chain_of] >= 0))[0]         # chain order, member order
+        obs_cam, obs_feat, obs_uv = cam_of[img[sel]], feat_of[chain_of[sel]], uv[sel]
+        n_observations = len(sel)
         order = np.argsort(obs_cam, kind='stable')
         counts = np.bincount(obs_cam, minlength=self.n_cameras) if n_observations else \
             np.zeros(self.n_cameras, np.int64)
@@ -427,7 +469,10 @@ class Optimizer():
     # optimizer.py:583-683
     # ---------------------------------------------------------------------------------
     def refit(self, proj, matches, groups, group_index):
-        matches_opt = list(matches)
+        from .match_cleanup import Chains
+        # (list(matches): a shallow copy whose members are the caller's chains; the array-backed
+        #  form is edited through its arrays below)
+        matches_opt = matches if (isinstance(matches, Chains) and matches.untouched()) else list(matches)
         group = groups[group_index]
         _log('refitting group size:', len(group))
         src_list, dst_list = [], []
@@ -487,6 +532,16 @@ class Optimizer():
 
         new_feats = transform_points(A, self.points_3d)
         name_in_group = [image.name in in_group for image in proj.image_list]
+        if isinstance(matches_opt, Chains) and matches_opt.untouched():
+            # the same rule on the arrays: a chain with a member in the group takes its new point
+            ch = matches_opt
+            rows = np.array([self.feat_map_rev[i] for i in range(len(new_feats))], np.int64)
+            in_grp = np.asarray(name_in_group, bool)[ch.img]
+            csum = np.concatenate([[0], np.cumsum(in_grp)])
+            hit = (csum[ch.ptr[rows + 1]] - csum[ch.ptr[rows]]) > 0
+            ch.ned[rows[hit]] = np.asarray(new_feats, np.float64).reshape(-1, 3)[hit]
+            ch.has_ned[rows[hit]] = True
+            return
         for i, feat in enumerate(new_feats):
             match = matches_opt[self.feat_map_rev[i]]
             if any(name_in_group[m[0]] for m in match[2:]):

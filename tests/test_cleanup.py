@@ -125,6 +125,37 @@ def test_groups_compute_equals_reference(path, min_chain_len):
     assert [m[1] for m in matches] == want['levels']
 
 
+@pytest.mark.parametrize('path', CASES, ids=os.path.basename)
+def test_chains_array_form_equals_the_lists(path):
+    """link_matches() returns match_cleanup.Chains: arrays behind the reference's list of lists.
+    Its own consumers read / write the arrays (groups.compute here; triangulate_smart and
+    Optimizer.setup / refit in the GPU tests), pickling does not turn it into lists, indexing does
+    -- and from then on the lists are the truth."""
+    from imageanalysis_amd import groups, match_cleanup
+    with open(path, 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    match_cleanup.merge_duplicates(proj)
+    match_cleanup.check_for_pair_dups(proj)
+    chains = match_cleanup.link_matches(proj, match_cleanup.make_match_structure(proj))
+    assert isinstance(chains, match_cleanup.Chains) and chains.untouched()
+    assert len(chains) == len(g['matches_grouped'])
+    assert pickle.loads(pickle.dumps(chains)) == g['matches_grouped'] and chains.untouched()
+    # grouping on the arrays == grouping on the lists
+    tri = match_cleanup.Chains.from_lists(g['matches_triangulated'])
+    assert pickle.loads(pickle.dumps(tri)) == g['matches_triangulated']
+    got = groups.compute(proj.image_list, tri)
+    assert tri.untouched()
+    want = g['groups'][0]
+    assert got == want['groups'] and tri.group.tolist() == want['levels']
+    assert [m[1] for m in pickle.loads(pickle.dumps(tri))] == want['levels']
+    # a reader that indexes gets lists it may edit; the edit is seen by everybody afterwards
+    first = tri[0]
+    assert not tri.untouched() and first[1] == want['levels'][0]
+    first[1] = 99
+    assert pickle.loads(pickle.dumps(tri))[0][1] == 99 and list(tri)[0][1] == 99
+
+
 def test_groups_save_load_roundtrip(tmp_path):
     from imageanalysis_amd import groups
     gl = [['b', 'a', 'c'], ['z']]
@@ -153,6 +184,12 @@ def test_triangulate_smart_equals_reference(path):
     assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())     # f64, same formulas
     assert all(m[2:] == w[2:] for m, w in zip(matches, want))
     assert all(type(m[0]) is list and type(m[0][0]) is float for m in matches)
+    # the array-backed form: same points, written into the arrays, no lists built
+    chains = match_cleanup.Chains.from_lists(g['matches_grouped'])
+    match_cleanup.triangulate_smart(proj, chains)
+    assert chains.untouched() and chains.has_ned.all()
+    assert np.array_equal(chains.ned, got)
+    assert pickle.loads(pickle.dumps(chains)) == matches
 
 
 @pytest.mark.gpu

@@ -583,3 +583,46 @@ def test_feat_bytes_without_the_library(monkeypatch):
     assert kl.feat_bytes() == with_lib
     rows = pickle.loads(with_lib)
     assert len(rows) == n and rows[7][0] == (float(kl.x[7]), float(kl.y[7])) and rows[7][5] == -1
+
+
+@pytest.mark.parametrize('path', BA_CASES, ids=os.path.basename)
+def test_optimizer_setup_and_refit_on_the_array_backed_chains(path):
+    """Optimizer.setup() / refit() on match_cleanup.Chains (the arrays link_matches() returns) ==
+    the same calls on the reference's list of lists: every array of the setup, the feature maps,
+    the points refit() writes back"""
+    import copy
+    from imageanalysis_amd import match_cleanup, optimizer
+    g = np.load(path)
+    out = {}
+    for form in ('lists', 'arrays'):
+        proj, inp = _scene(path)
+        matches = copy.deepcopy(inp['matches'])
+        if form == 'arrays':
+            matches = match_cleanup.Chains.from_lists(matches)
+        opt = optimizer.Optimizer('/nonexistent')
+        opt.setup(proj, inp['groups'], 0, matches, cam_calib=bool(g['cam_calib']))
+        C, P = opt.n_cameras, opt.n_points
+        xf = g['x_final']
+        setup = dict(ci=opt.camera_indices.copy(), pi=opt.point_indices.copy(), p3=np.array(opt.points_3d),
+                     bi=[a.copy() for a in opt.by_camera_point_indices],
+                     b2=[a.copy() for a in opt.by_camera_points_2d],
+                     fwd=dict(opt.feat_map_fwd), rev=dict(opt.feat_map_rev), cp=np.array(opt.camera_params))
+        opt.camera_params = xf[:C * 7].reshape(C, 7)
+        opt.points_3d = xf[C * 7:C * 7 + P * 3].reshape(P, 3)
+        opt.update_camera_poses(proj)
+        opt.refit(proj, matches, inp['groups'], 0)
+        if form == 'arrays':
+            assert matches.untouched()
+        out[form] = (setup, pickle.loads(pickle.dumps(matches)))
+    (a, ma), (b, mb) = out['lists'], out['arrays']
+    for k in ('ci', 'pi', 'p3', 'cp'):
+        assert np.array_equal(a[k], b[k]), k
+    assert a['fwd'] == b['fwd'] and a['rev'] == b['rev']
+    for x, y in zip(a['bi'] + a['b2'], b['bi'] + b['b2']):
+        assert np.array_equal(x, y)
+    assert len(ma) == len(mb)
+    for x, y in zip(ma, mb):
+        assert x[1:] == y[1:]
+        assert (x[0] is None) == (y[0] is None)
+        if x[0] is not None:
+            assert np.allclose(x[0], y[0], rtol=0, atol=0)
