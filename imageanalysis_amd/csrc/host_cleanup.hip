@@ -10,6 +10,7 @@
 // GPU matching; here it is flat arrays + one hash map, O(points) per pass.
 #include "iamx_common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -75,50 +76,111 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     // chains under construction: singly linked nodes in insertion order
     std::vector<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_next((size_t)n_pts);
     std::vector<int32_t> head, tail;
-    PointMap map((size_t)n_pts);
+    // the images of a chain's first INL points, side by side: the "image already in the chain?"
+    // test of a join reads one cache line instead of walking the chain's scattered nodes
+    constexpr int INL = 7;
+    struct ChainImgs { int32_t n; int32_t img[INL]; };
+    std::vector<ChainImgs> cimg;
+    // (image, keypoint) -> chain: a DENSE table over the keypoints that occur (image i owns
+    // [base[i], base[i] + max keypoint index of i + 1)) -- one 4-byte access per look-up where
+    // the hash map of rounds 1-3 paid two cache misses (key, value) and the mixing; the entries
+    // of the matches a few steps ahead are prefetched, since the walk order is known: the pass
+    // is bound by memory latency (6.4 M points on a 128-frame survey, several passes).
+    // A negative index or more than 2^31 table entries fall back to the hash map.
+    int32_t n_img = 0;
+    bool dense = getenv("IAMX_LINK_HASH") == nullptr;      // (A/B switch: the hash map of rounds 1-3)
+    for (int64_t j = 0; j < n_pts; ++j) {
+        if (img[j] < 0 || kp[j] < 0) { dense = false; break; }
+        if (img[j] >= n_img) n_img = img[j] + 1;
+    }
+    std::vector<int64_t> base;
+    std::vector<int32_t> table;
+    if (dense) {
+        base.assign((size_t)n_img + 1, 0);
+        for (int64_t j = 0; j < n_pts; ++j)
+            if (kp[j] + 1 > base[(size_t)img[j] + 1]) base[(size_t)img[j] + 1] = kp[j] + 1;
+        for (int32_t i = 0; i < n_img; ++i) base[(size_t)i + 1] += base[(size_t)i];
+        if (base[(size_t)n_img] >= (1LL << 31)) dense = false;
+        else table.assign((size_t)base[(size_t)n_img], -1);
+    }
+    PointMap map(dense ? 0 : (size_t)n_pts);
+    constexpr int64_t AHEAD = 48;                         // points of look-ahead for the prefetch
     int passes = 0;
     int64_t n_cur = n_matches;
     while (true) {
         ++passes;
-        map.clear();
+        if (dense) { if (passes > 1) std::fill(table.begin(), table.end(), -1); }
+        else map.clear();
         head.clear();
         tail.clear();
+        cimg.clear();
         int32_t n_nodes = 0;
         auto append = [&](int32_t chain, int32_t pi, int32_t pk) {
             const int32_t nd = n_nodes++;
             node_img[nd] = pi; node_kp[nd] = pk; node_next[nd] = -1;
             if (head[chain] < 0) head[chain] = nd; else node_next[tail[chain]] = nd;
             tail[chain] = nd;
+            ChainImgs &ci = cimg[(size_t)chain];
+            if (ci.n < INL) ci.img[ci.n] = pi;
+            ++ci.n;
         };
+        auto in_chain = [&](int32_t chain, int32_t pi) -> bool {
+            const ChainImgs &ci = cimg[(size_t)chain];
+            const int32_t k = ci.n < INL ? ci.n : INL;
+            for (int32_t t = 0; t < k; ++t)
+                if (ci.img[t] == pi) return true;
+            if (ci.n > INL) {                               // a long chain: the rest through its nodes
+                int32_t nd = head[chain];
+                for (int32_t t = 0; t < INL; ++t) nd = node_next[nd];
+                for (; nd >= 0; nd = node_next[nd])
+                    if (node_img[nd] == pi) return true;
+            }
+            return false;
+        };
+        auto lookup = [&](int32_t pi, int32_t pk) -> int32_t {
+            if (dense) return table[(size_t)(base[(size_t)pi] + pk)];
+            const size_t h = map.slot(PointMap::code(pi, pk));
+            return map.key[h] != 0 ? map.val[h] : -1;
+        };
+        auto store = [&](int32_t pi, int32_t pk, int32_t chain) {
+            if (dense) { table[(size_t)(base[(size_t)pi] + pk)] = chain; return; }
+            const uint64_t c = PointMap::code(pi, pk);
+            const size_t h = map.slot(c);
+            map.key[h] = c;
+            map.val[h] = chain;
+        };
+        const int64_t n_pts_cur = c_ptr[(size_t)n_cur];
         for (int64_t m = 0; m < n_cur; ++m) {
             const int64_t b = c_ptr[m], e = c_ptr[m + 1];
+            if (dense) {
+                for (int64_t j = b + AHEAD; j < e + AHEAD && j < n_pts_cur; ++j)
+                    __builtin_prefetch(&table[(size_t)(base[(size_t)c_img[j]] + c_kp[j])], 1, 1);
+                // ... and, half way, the chain a point will most likely join (a hint: the entry
+                // may still change before its turn)
+                for (int64_t j = b + AHEAD / 2; j < e + AHEAD / 2 && j < n_pts_cur; ++j) {
+                    const int32_t guess = table[(size_t)(base[(size_t)c_img[j]] + c_kp[j])];
+                    if (guess >= 0) __builtin_prefetch(&cimg[(size_t)guess], 1, 1);
+                }
+            }
             int32_t index = -1;
             for (int64_t j = b; j < e; ++j) {               // first point seen before decides
-                const size_t h = map.slot(PointMap::code(c_img[j], c_kp[j]));
-                if (map.key[h] != 0) { index = map.val[h]; break; }
+                index = lookup(c_img[j], c_kp[j]);
+                if (index >= 0) break;
             }
             if (index < 0) {                                // new chain: register every point
                 index = (int32_t)head.size();
                 head.push_back(-1);
                 tail.push_back(-1);
+                cimg.push_back(ChainImgs{0, {0}});
                 for (int64_t j = b; j < e; ++j) {
-                    const uint64_t c = PointMap::code(c_img[j], c_kp[j]);
-                    const size_t h = map.slot(c);
-                    map.key[h] = c;
-                    map.val[h] = index;
+                    store(c_img[j], c_kp[j], index);
                     append(index, c_img[j], c_kp[j]);
                 }
             } else {                                        // join: only images new to the chain
                 for (int64_t j = b; j < e; ++j) {
-                    bool found = false;
-                    for (int32_t nd = head[index]; nd >= 0; nd = node_next[nd])
-                        if (node_img[nd] == c_img[j]) { found = true; break; }
-                    if (!found) {
+                    if (!in_chain(index, c_img[j])) {
                         append(index, c_img[j], c_kp[j]);
-                        const uint64_t c = PointMap::code(c_img[j], c_kp[j]);
-                        const size_t h = map.slot(c);
-                        map.key[h] = c;
-                        map.val[h] = index;
+                        store(c_img[j], c_kp[j], index);
                     }
                 }
             }
