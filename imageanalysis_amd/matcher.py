@@ -672,6 +672,10 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
                 if id(im) not in by_id:
                     by_id[id(im)] = (dm.slot_of(im), im)
         slots = [(by_id[id(a)][0], by_id[id(b)][0]) for a, b in batch]
+    if dm._pending or dm._kp_dev is None or dm._kp_dev[0] != len(dm._counts):
+        # new images: the descriptor / keypoint arenas are about to be rebuilt, and the previous
+        # round's side-stream kernels may still be reading the old ones
+        torch.cuda.current_stream().wait_stream(_side_stream())
     store = dm.store()
     arena = _upload_arena()
     arena.begin()
@@ -705,7 +709,42 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     if device_filters:
         kp_off, xy, key2 = dm.keypoints()        # (may upload: before the kernels, like PROJ)
     thresh = max_distance * match_ratio
-    pb.run(ws, thresh)
+    # The sweep fills the machine for ~95 % of a round; everything behind it -- candidate test,
+    # exact stage, per-pair filters, triangulation, packing, the downloads -- is small, latency
+    # bound work that runs on a SECOND stream beside the next round's sweep (each round has its
+    # own workspace / result set from the pools, handed back only after the host has read them).
+    main = torch.cuda.current_stream()
+    side = _side_stream()
+    if pb.rows and pb.n_pairs:
+        pb.run_knn2_fast(ws)
+    swept = torch.cuda.Event()
+    swept.record(main)
+    side.wait_event(swept)
+    with torch.cuda.stream(side):
+        return _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d_ik,
+                                  kp_off if device_filters else None, xy if device_filters else None,
+                                  key2 if device_filters else None)
+
+
+_side = {}
+
+
+def _side_stream():
+    """the second stream of _launch_batch, one per device"""
+    import torch
+    dev = torch.cuda.current_device()
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d_ik, kp_off, xy, key2):
+    """the part of _launch_batch() behind the sweep (enqueued on the side stream)"""
+    import torch
+    from .kernels import _ptr, check, lib, stream_ptr
+    if pb.rows and pb.n_pairs:
+        pb.run_filter_fast(ws, thresh)
     n = len(batch)
     post = None
     clip = 0
@@ -1155,7 +1194,34 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     t_start = time.time()
     image_list = proj.image_list
     names = [im.name for im in image_list]
-    wd, wi, wj = _work_arrays(proj, sort)
+    # One rank: the images whose features are in memory go to the device (descriptor arena,
+    # keypoint arena: ~0.3 ms of host time each) on a helper thread WHILE the schedule is built
+    # and sorted below -- both are seconds on a survey of thousands of images, and the first round
+    # of a distance-sorted schedule needs nearly every image.  Joined before the first launch.
+    early = None
+    if ws == 1 and isinstance(the_matcher, DeviceMatcher) and len(image_list) > 64:
+        import threading
+        import torch as _torch
+        _dev = _torch.cuda.current_device()
+        _stream = _torch.cuda.current_stream()
+        _ready = [im for im in image_list
+                  if im.des_list is not None and im.kp_list is not None
+                  and len(getattr(im.des_list, 'shape', ())) == 2 and len(im.des_list) > 1]
+
+        def _register():
+            with _torch.cuda.device(_dev), _torch.cuda.stream(_stream):
+                for im in _ready:
+                    the_matcher.slot_of(im)
+                the_matcher.store()
+                the_matcher.keypoints()
+        if len(_ready) > 1:
+            early = threading.Thread(target=_register, name='iamx-register')
+            early.start()
+    try:
+        wd, wi, wj = _work_arrays(proj, sort)
+    finally:
+        if early is not None:
+            early.join()
     match_ratio = matcher_node.getFloat('match_ratio')
 
     # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
@@ -1529,9 +1595,17 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         # (quiet pairs dirty both images' match lists, like the reference's assignments)
         for k in np.nonzero(last_seq >= 0)[0].tolist():
             image_list[k].matches_clean = False
-        saveMatches(proj.image_list)
+        # smart.json is written beside the .match files (file writes release the interpreter)
+        saver = None
         if smart is not None:
-            smart.save(proj.analysis_dir)
+            import threading
+            saver = threading.Thread(target=smart.save, args=(proj.analysis_dir,), name='iamx-smart-save')
+            saver.start()
+        try:
+            saveMatches(proj.image_list)
+        finally:
+            if saver is not None:
+                saver.join()
     pickler.shutdown(wait=True)
     print('Pair-wise matches successfully saved.')
 
