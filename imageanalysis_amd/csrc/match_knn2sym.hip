@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256) void pack3_rows_kernel(Pack3Args P, int64_t to
     }
 }
 
+// rank of every row inside its image = rows with a smaller key (ties: the earlier row), by
+// counting.  blockIdx.z splits the comparisons of a 256-row group over `gridDim.z` workgroups
+// (each adds its part to pos[], zeroed by the caller): one 38 k-row frame is 150 groups x 38 k
+// compares -- 150 workgroups leave most of the chip idle (1.55 ms per frame, a fifth of the
+// match stage of a 128-frame survey); split 16 ways it is 0.15 ms.
 __global__ __launch_bounds__(256) void pack3_rank_kernel(Pack3Args P)
 {
     __shared__ __attribute__((aligned(16))) int keys[1024];
@@ -117,8 +122,10 @@ __global__ __launch_bounds__(256) void pack3_rank_kernel(Pack3Args P)
     if ((int)blockIdx.x * 256 >= n) return;
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int mine = r < n ? P.n2[r0 + r] : 0;
+    const int tiles = (n + 1023) / 1024, per = (tiles + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int b_lo = (int)blockIdx.z * per * 1024, b_hi = min(n, b_lo + per * 1024);
     int cnt = 0;
-    for (int base = 0; base < n; base += 1024) {
+    for (int base = b_lo; base < b_hi; base += 1024) {
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -136,7 +143,10 @@ __global__ __launch_bounds__(256) void pack3_rank_kernel(Pack3Args P)
             cnt += (k.w < mine) || (k.w == mine && base + j + 3 < r);
         }
     }
-    if (r < n) P.pos[r0 + r] = cnt;
+    if (r < n) {
+        if (gridDim.z == 1) P.pos[r0 + r] = cnt;
+        else if (cnt) atomicAdd(&P.pos[r0 + r], cnt);
+    }
 }
 
 template <typename SRC>
@@ -1383,7 +1393,13 @@ static int pack3_launch(Pack3Args P, int64_t total_rows, int max_rows, void *str
     const int cap = (max_rows + CHUNK - 1) / CHUNK * CHUNK;
     hipLaunchKernelGGL(pack3_rows_kernel<SRC>, dim3((unsigned)((total_rows * 8 + 255) / 256)),
                        dim3(256), 0, st, P, total_rows);
-    hipLaunchKernelGGL(pack3_rank_kernel, dim3((unsigned)((max_rows + 255) / 256), (unsigned)P.n_img),
+    // (few, large images: split every row group's comparisons so that the launch fills the chip)
+    const int64_t groups = (int64_t)((max_rows + 255) / 256) * P.n_img;
+    int split = 1;
+    while (split < 32 && groups * split < 2048 && max_rows > 1024 * split) split *= 2;
+    if (split > 1) (void)hipMemsetAsync(P.pos, 0, (size_t)total_rows * sizeof(int32_t), st);
+    hipLaunchKernelGGL(pack3_rank_kernel,
+                       dim3((unsigned)((max_rows + 255) / 256), (unsigned)P.n_img, (unsigned)split),
                        dim3(256), 0, st, P);
     hipLaunchKernelGGL(pack3_scatter_kernel<SRC>,
                        dim3((unsigned)(((int64_t)cap * 8 + 255) / 256), (unsigned)P.n_img),

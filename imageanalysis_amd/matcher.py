@@ -41,8 +41,10 @@ max_distance = None
 min_pairs = 25
 
 MYMAX = 2000            # matcher.py:265
-PAIRS_PER_BATCH = 4096  # unordered pairs per device batch (per-batch host costs are ~1 ms)
-BATCH_BYTES = 6 << 30   # ... as far as one batch's device workspace stays below this
+PAIRS_PER_BATCH = 16384 # unordered pairs per device batch (per-batch host costs are ~3 ms: 4096 -> 16384
+                        # took 0.5 s off the 2812-image all-pairs survey, profiles/r4_fm_config2.txt)
+BATCH_BYTES = 24 << 30  # ... as far as one batch's device workspace stays below this (three are pooled:
+                        # 72 GB of the 288 GB; 512 instead of 128 pairs per batch at 50 k keypoints)
 PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
 
 
@@ -635,7 +637,7 @@ def _host_set(n, clip, surface):
     if clip:
         # the matches of the pairs that have some, packed back to back by the device
         # (iamx_match_pack_results writes these page-locked buffers directly)
-        cap = min(n * clip, PACK_CAP)
+        cap = min(n * clip, max(PACK_CAP, n * 1024))   # (grows with the batch: ~800 matches per pair that has some)
         hs.update(cnt=pin(n, torch.int32), status=pin(n, torch.int32), cap=cap,
                   off=pin(n + 1, torch.int64), pk_pairs=pin((cap, 2), torch.int32))
         if surface:

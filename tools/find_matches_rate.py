@@ -122,6 +122,8 @@ def main():
     for a in sys.argv:
         if a.startswith('--ppb='):
             matcher.PAIRS_PER_BATCH = int(a[6:])
+        if a.startswith('--batch-gb='):
+            matcher.BATCH_BYTES = int(float(a[11:]) * (1 << 30))
     matcher.configure()
     K = camera.get_K()
     torch.cuda.synchronize()
