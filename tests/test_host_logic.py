@@ -348,8 +348,11 @@ def test_pairs_per_batch_is_bounded_by_the_device_workspace():
     from imageanalysis_amd import matcher
     old = matcher.PAIRS_PER_BATCH
     try:
-        matcher.PAIRS_PER_BATCH = 2048                   # (the shipped value; other tests shrink it)
-        assert matcher._pairs_per_batch(4096) == 2048 and matcher._pairs_per_batch(50000) == 128
+        assert matcher.BATCH_BYTES == 24 << 30
+        matcher.PAIRS_PER_BATCH = 2048                   # (other tests shrink it)
+        assert matcher._pairs_per_batch(4096) == 2048 and matcher._pairs_per_batch(50000) == 512
+        matcher.PAIRS_PER_BATCH = 16384
+        assert matcher._pairs_per_batch(4096) == 16384 and matcher._pairs_per_batch(50000) == 512
         for rows in (100, 4096, 20000, 50000, 200000):
             n = matcher._pairs_per_batch(rows)
             assert n >= 16 and n & (n - 1) == 0
