@@ -57,6 +57,7 @@ SIGNATURES = {
                               + [c_void_p] * 6),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'iamx_ledger_index': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'iamx_group_level': (c_int64, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_void_p]),
     'iamx_triangulate_ground': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int64]

@@ -277,3 +277,32 @@ extern "C" int64_t iamx_group_level(const int32_t *img, const int64_t *ptr, int6
     }
     return seed;
 }
+
+// The per-image index of find_matches' ledger of pairs WITHOUT matches (matchpairs.QuietLedger):
+// m pairs (qi, qj) with their processing positions seq, ASCENDING in seq; every pair belongs to
+// both of its images.  One counting sort by image (O(m + n_images)) writes, per image k, its
+// partners and their seq in processing order at [bounds[k], bounds[k + 1]).  The numpy form (three
+// gathers of 2 m entries through a radix argsort) was 1.0 s of the 2.0 s that writing the .match
+// files of the 2812-image all-pairs survey took.
+extern "C" int iamx_ledger_index(const int64_t *qi, const int64_t *qj, const int64_t *seq, int64_t m,
+                                 int64_t n_images, int64_t *other, int64_t *seq_out, int64_t *bounds)
+{
+    if (m < 0 || n_images < 0 || !bounds || (m > 0 && (!qi || !qj || !seq || !other || !seq_out)))
+        return iamx::fail(IAMX_EINVAL, "iamx_ledger_index: null pointer or negative count");
+    for (int64_t k = 0; k <= n_images; ++k) bounds[k] = 0;
+    for (int64_t e = 0; e < m; ++e) {
+        if (qi[e] < 0 || qi[e] >= n_images || qj[e] < 0 || qj[e] >= n_images)
+            return iamx::fail(IAMX_EINVAL, "iamx_ledger_index: image index out of range");
+        ++bounds[qi[e] + 1];
+        ++bounds[qj[e] + 1];
+    }
+    for (int64_t k = 0; k < n_images; ++k) bounds[k + 1] += bounds[k];
+    std::vector<int64_t> fill(bounds, bounds + n_images);
+    for (int64_t e = 0; e < m; ++e) {           // (the order of the numpy form: i's entry, then j's)
+        int64_t p = fill[(size_t)qi[e]]++;
+        other[p] = qj[e]; seq_out[p] = seq[e];
+        p = fill[(size_t)qj[e]]++;
+        other[p] = qi[e]; seq_out[p] = seq[e];
+    }
+    return IAMX_OK;
+}

@@ -312,6 +312,15 @@ int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, cons
 int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
                           int64_t n_matches, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                           int32_t *n_passes);
+/* iamx_ledger_index -- HOST arrays.  matcher.find_matches (scripts/lib/matcher.py:978-979) gives
+ * BOTH images of every processed pair a match_list entry, in processing order; for the pairs
+ * without matches -- 95-99 % of an all-pairs schedule -- this package keeps index arrays (qi, qj,
+ * seq ascending) and this routine turns them into the per-image lists the .match writer walks:
+ * image k's partners and their seq at [bounds[k], bounds[k+1]) of other / seq_out (2 m entries),
+ * bounds [n_images + 1].  One counting sort. */
+int iamx_ledger_index(const int64_t *qi, const int64_t *qj, const int64_t *seq, int64_t m,
+                      int64_t n_images, int64_t *other, int64_t *seq_out, int64_t *bounds);
+
 /* iamx_group_level -- one group level of scripts/lib/groups.py:59-118 compute() (HOST arrays):
  * seed chain + sweeps until nothing can be added.  level [n_matches] in/out (-1 = unused),
  * placed_images [n_images] 0/1 from earlier levels, placed_matches [n_images] out.  Returns the
