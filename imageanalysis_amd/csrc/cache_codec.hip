@@ -409,6 +409,43 @@ extern "C" int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int thr
     return IAMX_OK;
 }
 
+// Many images' float32 descriptors (the reference's des_list: integer valued 0..255) -> uint8,
+// back to back in dst: round-half-even + clamp like the device pack kernels' own conversion
+// (csrc/match_knn2*.hip load_value).  srcs HOST [n] pointers, rows HOST [n] elements per image.
+// The threads split the total evenly (an image may be shared by two threads).
+extern "C" int iamx_f32_to_u8_many(const float *const *srcs, const int64_t *counts, int n, uint8_t *dst,
+                                   int threads)
+{
+    if (n < 0 || (n > 0 && (!srcs || !counts || !dst))) return iamx::fail(IAMX_EINVAL, "iamx_f32_to_u8_many: null pointer");
+    std::vector<int64_t> off((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (counts[i] < 0 || (counts[i] > 0 && !srcs[i])) return iamx::fail(IAMX_EINVAL, "iamx_f32_to_u8_many: bad image");
+        off[(size_t)i + 1] = off[(size_t)i] + counts[i];
+    }
+    const int64_t total = off[(size_t)n];
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(threads, 1), total >> 18));
+    auto part = [&](int t) {
+        const int64_t a = total * t / nt, b = total * (t + 1) / nt;
+        int img = (int)(std::upper_bound(off.begin(), off.end(), a) - off.begin()) - 1;
+        for (int64_t e = a; e < b;) {
+            while (off[(size_t)img + 1] <= e) ++img;
+            const int64_t stop = std::min(b, off[(size_t)img + 1]);
+            const float *s = srcs[img] + (e - off[(size_t)img]);
+            uint8_t *d = dst + e;
+            for (int64_t i = 0; i < stop - e; ++i) {
+                const float v = rintf(s[i]);
+                d[i] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+            }
+            e = stop;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (std::thread &t : pool) t.join();
+    return IAMX_OK;
+}
+
 // The .feat pickle's fixed-width records (imageanalysis_amd/keypoints.py _REC: protocol-2 opcodes
 // "( G x G y TUPLE2 G size G angle G response J octave J class_id t", BINFLOAT big endian,
 // BININT little endian) from the keypoint columns: out [n][58].

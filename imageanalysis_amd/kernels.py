@@ -1,5 +1,6 @@
 """Thin python bindings over the C ABI: torch tensors are device-buffer containers only,
 every number is produced by a hand-written HIP kernel in libiamx.so (csrc/*.hip)."""
+import os
 import threading
 
 import numpy as np
@@ -122,6 +123,61 @@ class DescriptorStore(object):
             torch.cuda.current_stream().synchronize()
             return ()
         return (src, scratch, scratch3)
+
+    def set_images(self, first, arrays):
+        """Pack the descriptors of the consecutive images first .. first + len(arrays) - 1 in one
+        go: host arrays ([n,128] float32 or uint8) are turned into ONE uint8 block (float32 by
+        libiamx's threads), uploaded once and packed by the batched kernels -- 0.1 ms per image
+        where set_image() image by image costs 0.3 ms (a float32 upload and ~10 launches each:
+        0.85 s for the 2812 images of BASELINE configs[2]).  Enqueues on the current stream and
+        returns the temporaries the kernels read (keep them until the stream is synchronised)."""
+        import ctypes
+        k = len(arrays)
+        if k == 0:
+            return ()
+        counts = [self.counts[first + i] for i in range(k)]
+        for i, a in enumerate(arrays):
+            if not isinstance(a, np.ndarray) or a.dtype not in (np.float32, np.uint8) \
+                    or tuple(a.shape) != (counts[i], 128):
+                raise ValueError("set_images: image %d is not a host [n,128] float32 / uint8 array" % (first + i))
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        rows = int(sum(counts))
+        if rows == 0:
+            return ()
+        u8 = np.empty((rows, 128), np.uint8)
+        off = np.zeros(k + 1, np.int64)
+        np.cumsum(counts, out=off[1:])
+        f32 = [i for i, a in enumerate(arrays) if a.dtype == np.float32]
+        if len(f32) == k:
+            srcs = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
+            cnt = (ctypes.c_int64 * k)(*[a.size for a in arrays])
+            check(lib().iamx_f32_to_u8_many(srcs, cnt, k, u8.ctypes.data_as(ctypes.c_void_p),
+                                            min(16, os.cpu_count() or 1)), 'iamx_f32_to_u8_many')
+        else:
+            for i, a in enumerate(arrays):
+                u8[off[i]:off[i + 1]] = a if a.dtype == np.uint8 else \
+                    np.clip(np.rint(a), 0, 255).astype(np.uint8)
+        dev = self.desc.device
+        src = torch.from_numpy(u8).to(dev)
+        L, sp = lib(), stream_ptr()
+        # original-order store: image by image (one launch each: images are padded to 128 rows)
+        for i in range(k):
+            if counts[i]:
+                o = int(self.offsets[first + i])
+                check(L.iamx_desc_pack_u8(_ptr(src[int(off[i]):]), counts[i], _ptr(self.desc[o:]),
+                                          _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]), sp), 'iamx_desc_pack_u8')
+        src_off = torch.from_numpy(off).to(dev)
+        scratch = torch.empty(3 * rows, dtype=I32, device=dev)
+        mx = int(max(counts))
+        check(L.iamx_desc2_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off2[first:]), k, rows, mx,
+                                         _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
+                                         _ptr(self.perm), _ptr(self.meta[first]), _ptr(scratch), sp),
+              'iamx_desc2_pack_batch_u8')
+        scratch3 = torch.empty(3 * rows, dtype=I32, device=dev)
+        check(L.iamx_desc3_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off3[first:]), k, rows, mx,
+                                         _ptr(self.desc3), _ptr(self.sn2), _ptr(self.sct), _ptr(self.sperm),
+                                         _ptr(self.sinv), _ptr(scratch3), sp), 'iamx_desc3_pack_batch_u8')
+        return (src, src_off, scratch, scratch3)
 
     @classmethod
     def from_arrays(cls, arrays):

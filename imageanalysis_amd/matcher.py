@@ -206,9 +206,22 @@ class DeviceMatcher(object):
                 for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
                     getattr(new, name)[:n_old3].copy_(getattr(old, name)[:n_old3])
             self._store = new
-        keep = [self._store.set_image(slot, des if hasattr(des, 'data_ptr') else
-                                      np.ascontiguousarray(des), sync=False)
-                for slot, des in pend]
+        # a run of consecutive new slots whose descriptors are host arrays goes up in ONE step
+        # (DescriptorStore.set_images); anything else image by image
+        keep = []
+        bulk = []
+        if len(pend) >= 8:
+            k = 0
+            while k < len(pend) and pend[k][0] == pend[0][0] + k and isinstance(pend[k][1], np.ndarray) \
+                    and pend[k][1].dtype in (np.float32, np.uint8) and pend[k][1].ndim == 2 \
+                    and pend[k][1].shape[1] == 128:
+                k += 1
+            if k >= 8:
+                bulk, pend = pend[:k], pend[k:]
+                keep.append(self._store.set_images(bulk[0][0], [d for _s, d in bulk]))
+        keep += [self._store.set_image(slot, des if hasattr(des, 'data_ptr') else
+                                       np.ascontiguousarray(des), sync=False)
+                 for slot, des in pend]
         if keep:
             import torch
             torch.cuda.current_stream().synchronize()        # one sync for the whole batch

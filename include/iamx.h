@@ -508,6 +508,11 @@ int64_t iamx_gzip_members(const uint8_t *const *bufs, const int64_t *lens, int n
                           int64_t member_bytes, int level, int strategy, int threads, uint8_t *out,
                           int64_t out_cap);
 int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads);
+/* the other way for a whole survey: the float32 des_list of n images (scripts/lib/image.py:324,
+ * integer valued) -> uint8 back to back in dst (HOST), threads of its own; srcs HOST [n] pointers,
+ * counts HOST [n] elements per image.  Feeds ONE upload + the batched pack kernels. */
+int iamx_f32_to_u8_many(const float *const *srcs, const int64_t *counts, int n, uint8_t *dst,
+                        int threads);
 int iamx_feat_records(const float *x, const float *y, const float *size, const float *angle,
                       const float *response, const int32_t *octave, const int32_t *class_id,
                       int64_t n, uint8_t *out);

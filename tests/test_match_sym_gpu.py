@@ -379,3 +379,32 @@ def test_exact_stage_with_many_candidates(sizes):
         assert np.array_equal(got['d2'][got['off'][p] + keep], d2), (a, b)
         many += len(keep) > 256
     assert many >= 2 and got['zero_div'] == zero_div
+
+
+def test_bulk_ingest_equals_image_by_image():
+    """DescriptorStore.set_images (one uint8 block from libiamx's threads, one upload, the batched
+    pack kernels) fills every layout of the store exactly like set_image() image by image: ragged
+    row counts, float32 (the reference's des_list) and uint8 sources"""
+    import torch
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(12)
+    counts = [4096, 4097, 130, 5000, 2, 3333, 4096, 257, 1024, 700]
+    for dtype in (np.float32, np.uint8):
+        arrays = [_sift_like(rng, n).astype(dtype) for n in counts]
+        a = kernels.DescriptorStore(counts)
+        for i, d in enumerate(arrays):
+            a.set_image(i, d)
+        b = kernels.DescriptorStore(counts)
+        keep = b.set_images(0, arrays)
+        torch.cuda.synchronize()
+        del keep
+        for i, n in enumerate(counts):
+            o, o2, o3 = int(a.offsets[i]), int(a.offsets2[i]), int(a.offsets3[i])
+            for name, lo, m in (('desc', o, n), ('norm_q', o, n), ('norm_t', o, n),
+                                ('desc3', o3, int(a.caps3[i])), ('sn2', o3, n), ('sct', o3, n),
+                                ('sperm', o3, n), ('sinv', o3, n)):
+                assert torch.equal(getattr(a, name)[lo:lo + m], getattr(b, name)[lo:lo + m]), (name, i)
+            n2 = int(a.offsets2[i + 1]) - o2
+            for name in ('desc2', 'norm2', 'cinit', 'perm'):
+                assert torch.equal(getattr(a, name)[o2:o2 + n2], getattr(b, name)[o2:o2 + n2]), (name, i)
+        assert torch.equal(a.meta, b.meta)
