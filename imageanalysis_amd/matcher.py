@@ -1223,12 +1223,17 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                   if im.des_list is not None and im.kp_list is not None
                   and len(getattr(im.des_list, 'shape', ())) == 2 and len(im.des_list) > 1]
 
+        _failed = []
+
         def _register():
-            with _torch.cuda.device(_dev), _torch.cuda.stream(_stream):
-                for im in _ready:
-                    the_matcher.slot_of(im)
-                the_matcher.store()
-                the_matcher.keypoints()
+            try:
+                with _torch.cuda.device(_dev), _torch.cuda.stream(_stream):
+                    for im in _ready:
+                        the_matcher.slot_of(im)
+                    the_matcher.store()
+                    the_matcher.keypoints()
+            except BaseException as exc:          # noqa: BLE001  (re-raised on the calling thread)
+                _failed.append(exc)
         if len(_ready) > 1:
             early = threading.Thread(target=_register, name='iamx-register')
             early.start()
@@ -1237,6 +1242,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     finally:
         if early is not None:
             early.join()
+    if early is not None and _failed:
+        raise _failed[0]
     match_ratio = matcher_node.getFloat('match_ratio')
 
     # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
