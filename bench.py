@@ -1077,9 +1077,14 @@ def ba_bench(rank, world, dev, dist, args):
     t_res = timed(f_res, 100)
     t_jac = timed(f_jac, 50)
     o_local = prob.O
-    # untimed warm-up iteration (workspace allocation, code-object load), like --warmup for matching
-    ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=2, verbose=0)
+    # untimed warm-up solve (workspace and allocator blocks of every branch of the step selection,
+    # code-object load), like --warmup for matching; the collector has the matching section's heap
+    # behind it before the clock starts
+    ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4,
+                         max_nfev=(args.ba_iters + 1) if args.ba_iters else None, verbose=0)
     sync()
+    import gc
+    gc.collect()
     del prob.inner_iterations[:]
     t0 = time.perf_counter()
     res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4,

@@ -5,8 +5,10 @@ asked to run without a GPU, this raises.  torch is imported first so that the HI
 runtime already mapped by torch (its bundled libamdhip64, soname libamdhip64.so.7) is
 the one libiamx.so binds to -- one runtime per process, device pointers interchangeable.
 """
+import contextlib
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('IAMX_LIB') or os.path.join(_HERE, 'libiamx.so')   # IAMX_LIB: A/B builds
@@ -141,6 +143,8 @@ SIGNATURES = {
     'iamx_trf_count_outside': (c_int, [c_int64] + [c_void_p] * 7),
     'iamx_trf_strictly_feasible': (c_int, [c_int64] + [c_void_p] * 6),
     'iamx_trf_active': (c_int, [c_int64] + [c_void_p] * 3 + [c_double] + [c_void_p] * 2),
+    'iamx_trf_feasible_start': (c_int, [c_int64] + [c_void_p] * 3 + [c_double] + [c_void_p] * 2),
+    'iamx_trf_scaled_start': (c_int, [c_int64] + [c_void_p] * 6),
 }
 
 
@@ -182,6 +186,28 @@ def require_gpu():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+_held = threading.local()
+
+
 def stream_ptr():
+    held = getattr(_held, 'ptr', None)
+    if held is not None:
+        return held
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@contextlib.contextmanager
+def hold_stream(fresh=False):
+    """Inside the block stream_ptr() answers with the stream that was current on entry (per
+    thread) instead of asking torch each time -- torch.cuda.current_stream() costs ~8 us, more
+    than many of the kernels the TRF loop launches.  Code that switches streams inside (a graph
+    capture) wraps its launches in hold_stream(fresh=True): the stream current THERE."""
+    import torch
+    prev = getattr(_held, 'ptr', None)
+    if fresh or prev is None:
+        _held.ptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        yield
+    finally:
+        _held.ptr = prev

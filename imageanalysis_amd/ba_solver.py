@@ -135,6 +135,7 @@ class DeviceBA(object):
         self.out1 = z(4)
         self.tmp_n, self.tmp_n2, self.tmp_m, self.tmp_m2 = z(self.n), z(self.n), z(self.m), z(self.m)
         self.tmp_perm = z(self.n)
+        self._tmp_many = None
         self.lsmr_ws = None
         self.schur_ws = None
         # normal-equation blocks of the current Jacobian (iamx_ba_accumulate): U [C][7][7],
@@ -171,7 +172,7 @@ class DeviceBA(object):
     # (measured: one such stall per LSMR solve, profiles/r1_ba_notes.txt).
     def _stage(self, k):
         if self._pin is None or self._pin.numel() < k:
-            self._pin = torch.empty(max(int(k), self.n, self.m, 64), dtype=F64).pin_memory()
+            self._pin = torch.empty(max(int(k), 3 * self.n, self.m, 64), dtype=F64).pin_memory()
         return self._pin[:k]
 
     def upload(self, a, out=None):
@@ -208,6 +209,51 @@ class DeviceBA(object):
             check(lib().iamx_vec_gather(self.n, _ptr(t), _ptr(self.idx_i2h), _ptr(self.tmp_perm),
                                         stream_ptr()), 'iamx_vec_gather')
         return self.download(self.tmp_perm, self.n)
+
+    def upload_n_many(self, arrays):
+        """upload_n of several host n-vectors (a scalar stands for a constant vector): one staging
+        copy, one transfer, one wait"""
+        n, out, full = self.n, [None] * len(arrays), []
+        for k, a in enumerate(arrays):
+            if np.ndim(a) == 0:
+                out[k] = torch.full((max(n, 1),), float(a), dtype=F64, device=self.dev)
+            else:
+                full.append(k)
+        if full and n:
+            st = self._stage(len(full) * n)
+            for j, k in enumerate(full):
+                st.numpy()[j * n:(j + 1) * n] = np.asarray(arrays[k], np.float64).ravel()
+            raw = self._many(len(full))
+            raw[:len(full) * n].copy_(st, non_blocking=True)
+            for j, k in enumerate(full):
+                out[k] = torch.empty(n, dtype=F64, device=self.dev)
+                check(lib().iamx_vec_gather(n, _ptr(raw[j * n:]), _ptr(self.idx_h2i), _ptr(out[k]),
+                                            stream_ptr()), 'iamx_vec_gather')
+            torch.cuda.current_stream().synchronize()      # the staging buffer is reused
+        else:
+            for k in full:
+                out[k] = torch.empty(1, dtype=F64, device=self.dev)
+        return out
+
+    def download_n_many(self, vectors):
+        """download_n of several device n-vectors: one transfer, one wait"""
+        n, k = self.n, len(vectors)
+        if not n:
+            return [np.empty(0) for _ in vectors]
+        raw = self._many(k)
+        for j, t in enumerate(vectors):
+            check(lib().iamx_vec_gather(n, _ptr(t), _ptr(self.idx_i2h), _ptr(raw[j * n:]), stream_ptr()),
+                  'iamx_vec_gather')
+        st = self._stage(k * n)
+        st.copy_(raw[:k * n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = st.numpy().copy()
+        return [host[j * n:(j + 1) * n] for j in range(k)]
+
+    def _many(self, k):
+        if self._tmp_many is None or self._tmp_many.numel() < k * self.n:
+            self._tmp_many = torch.empty(max(k * self.n, 1), dtype=F64, device=self.dev)
+        return self._tmp_many
 
     def upload_m(self, a):
         """host m-vector in the order of this rank's slice of the reference's observation list
@@ -387,31 +433,48 @@ class DeviceBA(object):
             self._vec_ops = VecOps(self.dev)
         return self._vec_ops
 
-    def gram_dev(self, d_dev, vectors):
-        """gram() for device n-vectors (internal order); one host read for the whole matrix"""
-        k = len(vectors)
+    def jd(self, d_dev, s):
+        """y = J diag(d) s for a device n-vector s (this rank's observations)"""
         V = self.vec_ops()
-        ys = []
-        for s in vectors:
-            V.mul(d_dev[:self.n], s[:self.n], out=self.tmp_n2[:self.n])
-            y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
-            self.jv(self.tmp_n2, y)
-            ys.append(y[:self.m])
-        pairs = [(ys[i], ys[j]) for i in range(k) for j in range(i, k)]
-        if self.m == 0:
-            g = [0.0] * len(pairs)
-        else:
-            g = V.dots(*pairs, n=self.m, n_vectors=False)     # (k <= 3: at most 6 products)
+        V.mul(d_dev[:self.n], s[:self.n], out=self.tmp_n2[:self.n])
+        y = torch.empty(max(self.m, 1), dtype=F64, device=self.dev)
+        self.jv(self.tmp_n2, y)
+        return y[:self.m]
+
+    def q_pairs(self, *pairs):
+        """queue inner products of observation-space vectors (this rank's share, summed over the
+        ranks); the slot of the first (at most 8 per call)"""
+        V = self.vec_ops()
+        at = V.q_dots(*pairs, n=self.m, n_vectors=False) if self.m else V.q_zero(len(pairs))
         if self.world > 1:
-            t = torch.tensor(g, dtype=F64, device=self.dev)
-            _dist.allreduce_sum_(t)
-            g = t.tolist()
+            _dist.allreduce_sum_(V.out[at:at + len(pairs)])
+        return at
+
+    def q_gram(self, ys):
+        """queue the upper triangle (row by row) of the Gram matrix of observation-space vectors;
+        the slot of its first entry (k <= 3 vectors: at most 6 products)"""
+        k = len(ys)
+        return self.q_pairs(*[(ys[i], ys[j]) for i in range(k) for j in range(i, k)])
+
+    def q_cost(self, r):
+        """queue r.r over this rank's observations, summed over the ranks (cost = half of it)"""
+        return self.q_gram([r[:self.m]])
+
+    @staticmethod
+    def gram_of(vals, at, k):
         G = np.zeros((k, k))
-        it = iter(g)
+        it = iter(vals[at:])
         for i in range(k):
             for j in range(i, k):
                 G[i, j] = G[j, i] = next(it)
         return G
+
+    def gram_dev(self, d_dev, vectors):
+        """gram() for device n-vectors (internal order); one host read for the whole matrix"""
+        V = self.vec_ops()
+        V.begin()
+        at = self.q_gram([self.jd(d_dev, s) for s in vectors])
+        return self.gram_of(V.fetch(), at, len(vectors))
 
     def gram(self, d_host, vectors, d_dev=None):
         """G[i][j] = (J diag(d) s_i) . (J diag(d) s_j), summed over ranks.  With `d_dev` (d
@@ -671,7 +734,7 @@ def lsmr_device_fused(prob, d_dev, dreg_dev, atol=1e-6, btol=1e-6, conlim=1e8, m
         if ws.get('graph_key') != key:
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g), _lib.hold_stream(fresh=True):     # (the capture stream)
                 enqueue_launches()
             ws['graph'], ws['graph_key'] = g, key
         graph = ws['graph']
@@ -943,13 +1006,14 @@ def trf_device(prob, x0, lb, ub, **kw):
     multi-threaded np.dot/norm leaves ~100 OpenBLAS workers spinning for a while, and the
     device queue then stalls 60-90 ms in the next LSMR solve (measured, tools/diag_stall2.py;
     profiles/r1_ba_notes.txt).  The vectors are memory-bound; one thread loses nothing."""
-    try:
-        from threadpoolctl import threadpool_limits
-    except ImportError:                   # pragma: no cover
-        return (_trf_host if prob.host_logic else _trf_device)(prob, x0, lb, ub, **kw)
     fn = _trf_host if prob.host_logic else _trf_device
-    with threadpool_limits(limits=1, user_api='blas'):
-        return fn(prob, x0, lb, ub, **kw)
+    with _lib.hold_stream():              # (one stream for the whole solve; see _lib.hold_stream)
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:               # pragma: no cover
+            return fn(prob, x0, lb, ub, **kw)
+        with threadpool_limits(limits=1, user_api='blas'):
+            return fn(prob, x0, lb, ub, **kw)
 
 
 def _trf_host(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
@@ -1094,17 +1158,42 @@ class VecOps(object):
     def __init__(self, dev):
         self.dev = dev
         self.scratch = torch.empty(int(lib().iamx_vec_scratch_doubles()), dtype=F64, device=dev)
-        self.out = torch.empty(8, dtype=F64, device=dev)
+        # scalar results: SLOTS doubles read by the host in ONE transfer (begin / q_* / fetch)
+        self.out = torch.empty(self.SLOTS, dtype=F64, device=dev)
+        self._q = 0
         # several ranks with rank-local point parts (_trf_device): (rank, first point entry,
         # number of point entries).  An n-vector then holds the camera part (replicated), this
         # rank's points, and ZEROS for the points of the other ranks; a sum over the entries is
         # rank 0's whole vector + the point part of the others, all-reduced as a scalar.
         self.part = None
 
-    def _reduce(self, k, op):
-        """the first k scalars of self.out over the ranks (identity on one rank)"""
+    SLOTS = 32
+
+    def _reduce(self, k, op, at=0):
+        """k scalars of self.out over the ranks (identity on one rank)"""
         if self.part is not None:
-            _dist.allreduce_(self.out[:k], op)
+            _dist.allreduce_(self.out[at:at + k], op)
+
+    # ---- queued scalars: every q_* launch writes its results into the next free slots of
+    # self.out and returns the index of the first; fetch() is the one host read for all of them
+    # (each read drains the queue: the TRF loop pays for round trips, not for arithmetic)
+    def begin(self):
+        self._q = 0
+
+    def _take(self, k):
+        at = self._q
+        if at + k > self.SLOTS:
+            raise _lib.IamxError('VecOps: more than %d queued scalars' % self.SLOTS)
+        self._q = at + k
+        return at
+
+    def _slot_ptr(self, at):
+        return _lib.c_void_p(self.out.data_ptr() + 8 * at)
+
+    def fetch(self):
+        vals = self.out[:self._q].tolist()
+        self._q = 0
+        return vals
 
     def new(self, like):
         return torch.empty(like.numel(), dtype=F64, device=self.dev)
@@ -1130,8 +1219,20 @@ class VecOps(object):
     def dots(self, *terms, n=None, n_vectors=True):
         """terms: (a, b) or (a, w, b) -> [sum a.*b (.*w)] as python floats, one host read.
         n_vectors=False: the operands are not n-vectors (observation space: the caller reduces)"""
+        self.begin()
+        self.q_dots(*terms, n=n, n_vectors=n_vectors)
+        return self.fetch()
+
+    def q_zero(self, k):
+        at = self._take(k)
+        self.out[at:at + k].zero_()
+        return at
+
+    def q_dots(self, *terms, n=None, n_vectors=True):
+        """dots() without the host read: the slot of the first of the len(terms) results"""
         import ctypes
         k = len(terms)
+        at = self._take(k)
         A = (ctypes.c_void_p * k)(*[t[0].data_ptr() for t in terms])
         B = (ctypes.c_void_p * k)(*[t[-1].data_ptr() for t in terms])
         W = (ctypes.c_void_p * k)(*[(t[1].data_ptr() if len(t) == 3 and t[1] is not None else None)
@@ -1143,17 +1244,23 @@ class VecOps(object):
             A = (ctypes.c_void_p * k)(*[a + off for a in A])
             B = (ctypes.c_void_p * k)(*[b + off for b in B])
             W = (ctypes.c_void_p * k)(*[(w + off if w else None) for w in W])
-        check(lib().iamx_vec_dots(n, k, A, B, W, _ptr(self.out), _ptr(self.scratch), stream_ptr()),
+        check(lib().iamx_vec_dots(n, k, A, B, W, self._slot_ptr(at), _ptr(self.scratch), stream_ptr()),
               'iamx_vec_dots')
         if n_vectors:
-            self._reduce(k, 'sum')
-        return self.out[:k].tolist()
+            self._reduce(k, 'sum', at)
+        return at
 
     def absmax(self, x, y=None):
-        check(lib().iamx_vec_absmax_prod(x.numel(), _ptr(x), _ptr(y), _ptr(self.out),
+        self.begin()
+        self.q_absmax(x, y)
+        return float(self.fetch()[0])
+
+    def q_absmax(self, x, y=None):
+        at = self._take(1)
+        check(lib().iamx_vec_absmax_prod(x.numel(), _ptr(x), _ptr(y), self._slot_ptr(at),
                                          _ptr(self.scratch), stream_ptr()), 'iamx_vec_absmax_prod')
-        self._reduce(1, 'max')
-        return float(self.out[0].item())
+        self._reduce(1, 'max', at)
+        return at
 
     # ---- scipy/optimize/_lsq/common.py on device vectors
     def cl_scaling(self, x, g, lb, ub):
@@ -1180,17 +1287,23 @@ class VecOps(object):
 
     def step_size_to_bound(self, x, s, lb, ub, want_hits=False):
         """step_size_to_bound: (min step, hits in {-1, 0, 1} when asked for)"""
-        check(lib().iamx_trf_step_to_bound(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub),
-                                           _ptr(self.out), _ptr(self.scratch), stream_ptr()),
-              'iamx_trf_step_to_bound')
-        self._reduce(1, 'min')
-        step = float(self.out[0].item())
+        self.begin()
+        self.q_step_to_bound(x, s, lb, ub)
+        step = float(self.fetch()[0])
         if not want_hits:
             return step, None
         hits = self.new(x)
         check(lib().iamx_trf_reflect(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub), step, None,
                                      None, _ptr(hits), stream_ptr()), 'iamx_trf_reflect')
         return step, hits
+
+    def q_step_to_bound(self, x, s, lb, ub):
+        at = self._take(1)
+        check(lib().iamx_trf_step_to_bound(x.numel(), _ptr(x), _ptr(s), _ptr(lb), _ptr(ub),
+                                           self._slot_ptr(at), _ptr(self.scratch), stream_ptr()),
+              'iamx_trf_step_to_bound')
+        self._reduce(1, 'min', at)
+        return at
 
     def reflect(self, x, s, lb, ub, min_step, p_h):
         """trf.py select_step: p_h with the components that hit a bound first negated"""
@@ -1201,17 +1314,38 @@ class VecOps(object):
 
     def in_bounds(self, x, lb, ub, p=None):
         """in_bounds(x (+ p), lb, ub)"""
+        self.begin()
+        self.q_count_outside(x, lb, ub, p)
+        return self.fetch()[0] == 0.0
+
+    def q_count_outside(self, x, lb, ub, p=None):
+        """number of components of x (+ p) outside [lb, ub] (0 <=> in_bounds)"""
+        at = self._take(1)
         check(lib().iamx_trf_count_outside(x.numel(), _ptr(x), _ptr(p), _ptr(lb), _ptr(ub),
-                                           _ptr(self.out), _ptr(self.scratch), stream_ptr()),
+                                           self._slot_ptr(at), _ptr(self.scratch), stream_ptr()),
               'iamx_trf_count_outside')
-        self._reduce(1, 'sum')
-        return float(self.out[0].item()) == 0.0
+        self._reduce(1, 'sum', at)
+        return at
 
     def strictly_feasible(self, x, lb, ub, step=None):
         """make_strictly_feasible(x (+ step), lb, ub, rstep=0)"""
         out = self.new(x)
         check(lib().iamx_trf_strictly_feasible(x.numel(), _ptr(x), _ptr(step), _ptr(lb), _ptr(ub),
                                                _ptr(out), stream_ptr()), 'iamx_trf_strictly_feasible')
+        return out
+
+    def feasible_start(self, x, lb, ub, rstep):
+        """make_strictly_feasible(x, lb, ub, rstep) for rstep > 0"""
+        out = self.new(x)
+        check(lib().iamx_trf_feasible_start(x.numel(), _ptr(x), _ptr(lb), _ptr(ub), float(rstep),
+                                            _ptr(out), stream_ptr()), 'iamx_trf_feasible_start')
+        return out
+
+    def scaled_start(self, x, scale_inv, v, dv):
+        """x * scale_inv / sqrt(v') with v' = v * scale_inv where dv != 0 (trf.py:243-246)"""
+        out = self.new(x)
+        check(lib().iamx_trf_scaled_start(x.numel(), _ptr(x), _ptr(scale_inv), _ptr(v), _ptr(dv),
+                                          _ptr(out), stream_ptr()), 'iamx_trf_scaled_start')
         return out
 
     def active_constraints(self, x, lb, ub, rtol):
@@ -1222,24 +1356,93 @@ class VecOps(object):
         return out
 
 
-def _select_step_dev(prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
-    """trf.py select_step on device vectors; the J products go through Gram matrices"""
+_COMPANION4 = np.zeros((4, 4))
+_COMPANION4[1, 0] = _COMPANION4[2, 1] = _COMPANION4[3, 2] = 1.0
+
+
+def solve_tr_2d(B, g, Delta):
+    """scipy/optimize/_lsq/common.py solve_trust_region_2d -- min 0.5 p^T B p + g^T p over
+    |p| <= Delta for a symmetric 2 x 2 B -- with the same two cases (the Newton step when B is
+    positive definite and the step fits, else the best real root of the same quartic in
+    t = tan(phi / 2), found as the eigenvalues of its companion matrix like np.roots does), in
+    scalar arithmetic: SciPy's version spends 0.3 ms per call in array plumbing, which the
+    device-resident loop would wait for with an idle GPU.  Returns (p, newton_step)."""
+    a, b, c = float(B[0][0]), float(B[0][1]), float(B[1][1])
+    g0, g1 = float(g[0]), float(g[1])
+    if a > 0.0:
+        l10 = b / a
+        s = c - l10 * b
+        if s > 0.0:                                   # B = L diag(a, s) L^T
+            y1 = -g1 + l10 * g0
+            p1 = y1 / s
+            p0 = -g0 / a - l10 * p1
+            if p0 * p0 + p1 * p1 <= Delta * Delta:
+                return np.array([p0, p1]), True
+    D2 = Delta * Delta
+    A, Bq, C = a * D2, b * D2, c * D2
+    d, f = g0 * Delta, g1 * Delta
+    co = (-Bq + d, 2 * (A - C + f), 6 * Bq, 2 * (-A + C + f), -Bq - d)
+    if co[0] == 0.0 or co[4] == 0.0 or not all(np.isfinite(co)):
+        # (np.roots strips zero end coefficients; leave the rare case to it)
+        from scipy.optimize._lsq.common import solve_trust_region_2d
+        return solve_trust_region_2d(np.array([[a, b], [b, c]]), np.array([g0, g1]), Delta)
+    M = _COMPANION4.copy()
+    M[0, 0], M[0, 1], M[0, 2], M[0, 3] = -co[1] / co[0], -co[2] / co[0], -co[3] / co[0], -co[4] / co[0]
+    best = None
+    for t in np.linalg.eigvals(M):
+        if t.imag != 0.0:
+            continue
+        t = t.real
+        q = 1.0 + t * t
+        p0, p1 = Delta * 2.0 * t / q, Delta * (1.0 - t * t) / q
+        val = 0.5 * (p0 * (a * p0 + b * p1) + p1 * (b * p0 + c * p1)) + g0 * p0 + g1 * p1
+        if best is None or val < best[0]:
+            best = (val, p0, p1)
+    if best is None:
+        from scipy.optimize._lsq.common import solve_trust_region_2d
+        return solve_trust_region_2d(np.array([[a, b], [b, c]]), np.array([g0, g1]), Delta)
+    return np.array([best[1], best[2]]), False
+
+
+def _select_step_dev(prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta, Ggg, gdg, gg):
+    """trf.py select_step on device vectors; the J products go through Gram matrices.  Two host
+    reads at most: the first brings the in_bounds test together with the model value of a step
+    that stays inside (the common case) and the distance to the bounds; the second everything the
+    reflected and the anti-gradient candidates need.  (Ggg, gdg, gg: |J d g_h|^2, g_h.diag_h.g_h
+    and g_h.g_h, known since the regularisation term -- the anti-gradient direction is -g_h.)"""
     from scipy.optimize._lsq.common import minimize_quadratic_1d
 
-    if V.in_bounds(x, lb, ub, p):
-        G = prob.gram_dev(d, [p_h])
-        ph_d_ph, g_ph = V.dots((p_h, diag_h, p_h), (g_h, p_h))
-        return p, p_h, -(0.5 * (G[0, 0] + ph_d_ph) + g_ph)
+    y_p = prob.jd(d, p_h)
+    V.begin()
+    i_out = V.q_count_outside(x, lb, ub, p)
+    i_sb = V.q_step_to_bound(x, p, lb, ub)
+    i_G = prob.q_pairs((y_p, y_p))
+    i_d = V.q_dots((p_h, diag_h, p_h), (g_h, p_h), (p_h, p_h))
+    S = V.fetch()
+    Gpp, ph_d_ph, g_ph, ph_ph = S[i_G], S[i_d], S[i_d + 1], S[i_d + 2]
+    if S[i_out] == 0.0:
+        return p, p_h, -(0.5 * (Gpp + ph_d_ph) + g_ph)
 
-    p_stride, _ = V.step_size_to_bound(x, p, lb, ub)
+    p_stride = S[i_sb]
     r_h = V.reflect(x, p, lb, ub, p_stride, p_h)
     r = V.mul(d, r_h)
     p = V.mul(p, s=p_stride)
     p_h = V.mul(p_h, s=p_stride)
     x_on_bound = V.lincomb(1.0, x, 1.0, p)
+    ag = V.mul(d, g_h, s=-1.0)                      # d .* ag_h with ag_h = -g_h
+    y_r = prob.jd(d, r_h)
+    V.begin()
+    i_1 = V.q_dots((r_h, r_h), (p_h, r_h), (r_h, diag_h, r_h), (g_h, r_h), (p_h, diag_h, r_h))
+    i_2 = prob.q_pairs((y_r, y_r), (y_p, y_r))
+    i_3 = V.q_step_to_bound(x_on_bound, r, lb, ub)
+    i_4 = V.q_step_to_bound(x, ag, lb, ub)
+    S = V.fetch()
+    # the products with the scaled p_h (and with y_p, computed before the scaling)
+    G00, ph_d_ph, g_ph = p_stride * p_stride * Gpp, p_stride * p_stride * ph_d_ph, p_stride * g_ph
+    G11, G01 = S[i_2], p_stride * S[i_2 + 1]
+    rh_d_rh, g_rh, ph_d_rh = S[i_1 + 2], S[i_1 + 3], S[i_1 + 4]
     # intersect_trust_region(p_h, r_h, Delta): positive root of |p_h + t r_h| = Delta
-    a, b, c = V.dots((r_h, r_h), (p_h, r_h), (p_h, p_h))
-    c -= Delta * Delta
+    a, b, c = S[i_1], S[i_1 + 1], p_stride * p_stride * ph_ph - Delta * Delta
     if a == 0:
         raise ValueError("`s` is zero.")
     if c > 0:
@@ -1248,7 +1451,7 @@ def _select_step_dev(prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     q = -(b + np.copysign(disc, b))
     t1, t2 = q / a, c / q
     to_tr = max(t1, t2)
-    to_bound, _ = V.step_size_to_bound(x_on_bound, r, lb, ub)
+    to_bound = S[i_3]
     r_stride = min(to_bound, to_tr)
     if r_stride > 0:
         r_stride_l = (1 - theta) * p_stride / r_stride
@@ -1256,39 +1459,28 @@ def _select_step_dev(prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb, ub, theta):
     else:
         r_stride_l, r_stride_u = 0, -1
 
-    ag_h = V.mul(g_h, s=-1.0)
-    G = prob.gram_dev(d, [p_h, r_h, ag_h])          # all three model directions in one go
-    (rh_d_rh, g_rh, ph_d_rh, ph_d_ph, g_ph, ag_d_ag, g_ag, ag_ag) = V.dots(
-        (r_h, diag_h, r_h), (g_h, r_h), (p_h, diag_h, r_h), (p_h, diag_h, p_h), (g_h, p_h),
-        (ag_h, diag_h, ag_h), (g_h, ag_h), (ag_h, ag_h))
     if r_stride_l <= r_stride_u:
-        qa = 0.5 * (G[1, 1] + rh_d_rh)
-        qb = g_rh + G[0, 1] + ph_d_rh
-        c0 = 0.5 * (G[0, 0] + ph_d_ph) + g_ph
+        qa = 0.5 * (G11 + rh_d_rh)
+        qb = g_rh + G01 + ph_d_rh
+        c0 = 0.5 * (G00 + ph_d_ph) + g_ph
         r_stride, r_value = minimize_quadratic_1d(qa, qb, r_stride_l, r_stride_u, c=c0)
-        r_h = V.lincomb(r_stride, r_h, 1.0, p_h)
-        r = V.mul(r_h, d)
     else:
         r_value = np.inf
 
-    p = V.mul(p, s=theta)
-    p_h_t = V.mul(p_h, s=theta)
-    p_value = 0.5 * theta * theta * (G[0, 0] + ph_d_ph) + theta * g_ph
+    p_value = 0.5 * theta * theta * (G00 + ph_d_ph) + theta * g_ph
 
-    ag = V.mul(d, ag_h)
-    to_tr = Delta / np.sqrt(ag_ag)
-    to_bound, _ = V.step_size_to_bound(x, ag, lb, ub)
+    to_tr = Delta / np.sqrt(gg)
+    to_bound = S[i_4]
     ag_stride = theta * to_bound if to_bound < to_tr else to_tr
-    qa = 0.5 * (G[2, 2] + ag_d_ag)
-    ag_stride, ag_value = minimize_quadratic_1d(qa, g_ag, 0, ag_stride)
-    ag_h = V.mul(ag_h, s=ag_stride)
-    ag = V.mul(ag, s=ag_stride)
+    ag_stride, ag_value = minimize_quadratic_1d(0.5 * (Ggg + gdg), -gg, 0, ag_stride)
 
+    # (only the chosen candidate is formed)
     if p_value < r_value and p_value < ag_value:
-        return p, p_h_t, -p_value
+        return V.mul(p, s=theta), V.mul(p_h, s=theta), -p_value
     elif r_value < p_value and r_value < ag_value:
-        return r, r_h, -r_value
-    return ag, ag_h, -ag_value
+        r_h = V.lincomb(r_stride, r_h, 1.0, p_h)
+        return V.mul(r_h, d), r_h, -r_value
+    return V.mul(ag, s=ag_stride), V.mul(g_h, s=-ag_stride), -ag_value
 
 
 def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None, verbose=0,
@@ -1298,18 +1490,15 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     cross PCIe and are only touched by libiamx kernels (VecOps); per outer iteration the host
     sees a few dozen scalars."""
     from scipy.optimize import OptimizeResult
-    from scipy.optimize._lsq.common import (check_termination, make_strictly_feasible,
+    from scipy.optimize._lsq.common import (check_termination,
                                             minimize_quadratic_1d, print_header_nonlinear,
-                                            print_iteration_nonlinear, solve_trust_region_2d,
-                                            update_tr_radius)
+                                            print_iteration_nonlinear, update_tr_radius)
     lsmr_opts = dict(lsmr_opts or {})
     lsmr_opts['to_host'] = False
     n = prob.n
     V = prob.vec_ops()
-    x_host = make_strictly_feasible(np.asarray(x0, np.float64).copy(), lb, ub)
-    lb_d = prob.upload_n(np.broadcast_to(np.asarray(lb, np.float64), (n,)))[:n].clone()
-    ub_d = prob.upload_n(np.broadcast_to(np.asarray(ub, np.float64), (n,)))[:n].clone()
-    x = prob.upload_n(x_host)[:n].clone()
+    x_raw, lb_d, ub_d = (t[:n] for t in prob.upload_n_many([np.asarray(x0, np.float64), lb, ub]))
+    x = V.feasible_start(x_raw, lb_d, ub_d, 1e-10)        # make_strictly_feasible(x0, lb, ub)
     # Several ranks (observations sharded by point): the point part of x, g, the step and every
     # other n-vector lives on the rank that owns the points -- zeros elsewhere --, the TRF scalars
     # are sums / maxima of per-rank shares (VecOps.part).  Inside the loop only the camera blocks
@@ -1328,25 +1517,22 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     prob.set_x_dev(x)
     prob.residual_jac()
     nfev = njev = 1
-    cost = prob.cost_of_r(prob.r)
+    V.begin()
+    prob.q_cost(prob.r)
+    cost = 0.5 * V.fetch()[0]
     g = prob.grad_dev()
     scale_inv = V.jac_scale(prob.colsq_dev(), torch.empty(n, dtype=F64, device=prob.dev), first=True)
 
     v, dv = V.cl_scaling(x, g, lb_d, ub_d)
-    # Delta = norm(x0 * scale_inv / v**0.5) with v[dv != 0] *= scale_inv (one-off: on the host)
-    v_h, dv_h, si_h = prob.download_n(v), prob.download_n(dv), prob.download_n(scale_inv)
-    v_h[dv_h != 0] *= si_h[dv_h != 0]
-    t_h = prob.download_n(x) * si_h / v_h ** 0.5
+    # Delta = norm(x0 * scale_inv / v**0.5) with v[dv != 0] *= scale_inv
     if prob.local_points:
-        # this rank's share of the sum of squares: its own entries, the camera part on rank 0 only
-        share = prob.download_n(own) != 0
-        if prob.rank > 0:
-            share[:nc] = False
-        sq = torch.tensor([float(np.dot(t_h[share], t_h[share]))], dtype=F64, device=prob.dev)
-        _dist.allreduce_sum_(sq)
-        Delta = float(np.sqrt(sq.item()))
+        # (entries of other ranks' points: x is 0 there; keep the divisor away from 0 as well)
+        v0 = V.lincomb(1.0, V.mul(v, own), 1.0, 1.0 - own)
     else:
-        Delta = float(np.linalg.norm(t_h))
+        v0 = v
+    t0 = V.scaled_start(x, scale_inv, v0, dv)
+    Delta = float(np.sqrt(V.dots((t0, t0))[0]))
+    del t0, v0
     if Delta == 0:
         Delta = 1.0
     if max_nfev is None:
@@ -1359,9 +1545,20 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
     if verbose == 2 and prob.rank == 0:
         print_header_nonlinear()
 
+    # Host reads per outer iteration (each one drains the queue): the gradient norm with the
+    # regularisation scalars, the Schur solve's stop tests, one projection and one batch for the
+    # 2-D subspace, one for the step, one for the trial point.
     while True:
-        v, dv = V.cl_scaling(x, g, lb_d, ub_d)
-        g_norm = V.absmax(g, v)
+        with _Phase(prob, 'scaling+reg'):
+            v, dv = V.cl_scaling(x, g, lb_d, ub_d)
+            d, diag_h, g_h = V.trf_scale(v, dv, g, scale_inv)
+            y_g = prob.jd(d, g_h)
+            V.begin()
+            i_n = V.q_absmax(g, v)
+            i_G = prob.q_gram([y_g])
+            i_d = V.q_dots((g_h, diag_h, g_h), (g_h, g_h))
+            S = V.fetch()
+            g_norm, Ggg, gdg, gg = S[i_n], S[i_G], S[i_d], S[i_d + 1]
         if g_norm < gtol:
             termination_status = 1
         if verbose == 2 and prob.rank == 0:
@@ -1369,15 +1566,11 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
         if termination_status is not None or nfev == max_nfev:
             break
 
-        with _Phase(prob, 'scaling+reg'):
-            d, diag_h, g_h = V.trf_scale(v, dv, g, scale_inv)
-            # regularisation term (trf.py: build_quadratic_1d along -g_h)
-            G = prob.gram_dev(d, [g_h])
-            gdg, gg = V.dots((g_h, diag_h, g_h), (g_h, g_h))
-            a = 0.5 * (G[0, 0] + gdg)
-            to_tr = Delta / np.sqrt(gg)
-            ag_value = minimize_quadratic_1d(a, -gg, 0, to_tr)[1]
-            reg_term = -ag_value / Delta ** 2
+        # regularisation term (trf.py: build_quadratic_1d along -g_h)
+        a = 0.5 * (Ggg + gdg)
+        to_tr = Delta / np.sqrt(gg)
+        ag_value = minimize_quadratic_1d(a, -gg, 0, to_tr)[1]
+        reg_term = -ag_value / Delta ** 2
 
         with _Phase(prob, 'lsmr'):
             dreg = V.sqrt_shift(diag_h, reg_term)
@@ -1385,42 +1578,61 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             gn_h = gn_h[:n]
             lsmr_iters += itn
         with _Phase(prob, 'subspace'):
-            # orthonormal basis of span{g_h, gn_h} (SciPy: economic QR; the step S p_S does not
-            # depend on which orthonormal basis is used): Gram-Schmidt with re-orthogonalisation
-            s0 = V.mul(g_h, s=1.0 / np.sqrt(gg))
-            w = V.lincomb(1.0, gn_h, -V.dots((s0, gn_h))[0], s0)
-            w = V.lincomb(1.0, w, -V.dots((s0, w))[0], s0)
-            wn = float(np.sqrt(V.dots((w, w))[0]))
-            s1 = V.mul(w, s=1.0 / wn) if wn > 0 else V.new(w).zero_()
-            GS = prob.gram_dev(d, [s0, s1])
-            e00, e01, e11, gs0, gs1 = V.dots((s0, diag_h, s0), (s0, diag_h, s1), (s1, diag_h, s1),
-                                             (s0, g_h), (s1, g_h))
-            B_S = GS + np.array([[e00, e01], [e01, e11]])
-            g_S = np.array([gs0, gs1])
+            # orthonormal basis {s0, s1} of span{g_h, gn_h} (SciPy: economic QR; the step S p_S
+            # does not depend on which orthonormal basis is used): s0 = g_h / |g_h|, and
+            # Gram-Schmidt with one re-orthogonalisation for s1.  The first projection is carried
+            # out on the vectors (w = gn_h - (s0.gn_h) s0 cancels when the two are nearly
+            # parallel); the second one, c = s0.w, is of round-off size and is applied to the
+            # scalars: with w' = w - c s0, every product with w' is a combination of the products
+            # with w and s0 that one batch returns.  s0 and s1 are never formed.
+            sg = np.sqrt(gg)
+            w = V.lincomb(1.0, gn_h, -V.dots((g_h, gn_h))[0] / gg, g_h)
+            y_w = prob.jd(d, w)
+            V.begin()
+            i_G = prob.q_pairs((y_g, y_w), (y_w, y_w))
+            i_d = V.q_dots((g_h, w), (w, w), (g_h, diag_h, w), (w, diag_h, w))
+            S = V.fetch()
+            G00, G0w, Gww = Ggg / gg, S[i_G] / sg, S[i_G + 1]
+            c, ww = S[i_d] / sg, S[i_d + 1]
+            e00, e0w, eww = gdg / gg, S[i_d + 2] / sg, S[i_d + 3]
+            wn = float(np.sqrt(max(ww - c * c, 0.0)))
+            if wn > 0:
+                G01, G11 = (G0w - c * G00) / wn, (Gww - 2 * c * G0w + c * c * G00) / wn ** 2
+                e01, e11 = (e0w - c * e00) / wn, (eww - 2 * c * e0w + c * c * e00) / wn ** 2
+            else:
+                G01 = G11 = e01 = e11 = 0.0
+            B_S = np.array([[G00 + e00, G01 + e01], [G01 + e01, G11 + e11]])
+            g_S = np.array([sg, 0.0])                   # s0.g_h = |g_h|, s1.g_h = 0
 
         theta = max(0.995, 1 - g_norm)
         actual_reduction = -1
         while actual_reduction <= 0 and nfev < max_nfev:
             with _Phase(prob, 'select_step'):
-                p_S, _ = solve_trust_region_2d(B_S, g_S, Delta)
-                p_h = V.lincomb(float(p_S[0]), s0, float(p_S[1]), s1)
+                p_S, _ = solve_tr_2d(B_S, g_S, Delta)
+                # p_h = p_S[0] s0 + p_S[1] s1 in terms of g_h and w
+                cw = float(p_S[1]) / wn if wn > 0 else 0.0
+                p_h = V.lincomb((float(p_S[0]) - cw * c) / sg, g_h, cw, w)
                 p = V.mul(d, p_h)
                 step, step_h, predicted_reduction = _select_step_dev(
-                    prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb_d, ub_d, theta)
+                    prob, V, x, d, diag_h, g_h, p, p_h, Delta, lb_d, ub_d, theta, Ggg, gdg, gg)
             with _Phase(prob, 'fun'):
                 x_new = V.strictly_feasible(x, lb_d, ub_d, step)
                 prob.set_x_dev(x_new)
                 prob.residual(out=r_new)
                 nfev += 1
-                step_h_norm = float(np.sqrt(V.dots((step_h, step_h))[0]))
-                cost_new = prob.cost_of_r(r_new)
+                V.begin()
+                i_s = V.q_dots((step_h, step_h), (step, step), (x, x))
+                i_c = prob.q_cost(r_new)
+                S = V.fetch()
+                step_h_norm = float(np.sqrt(S[i_s]))
+                cost_new = 0.5 * S[i_c]
             if not np.isfinite(cost_new):
                 Delta = 0.25 * step_h_norm
                 continue
             actual_reduction = cost - cost_new
             Delta_new, ratio = update_tr_radius(Delta, actual_reduction, predicted_reduction,
                                                 step_h_norm, step_h_norm > 0.95 * Delta)
-            step_norm, x_norm = np.sqrt(V.dots((step, step), (x, x))).tolist()
+            step_norm, x_norm = float(np.sqrt(S[i_s + 1])), float(np.sqrt(S[i_s + 2]))
             termination_status = check_termination(actual_reduction, cost, step_norm, x_norm,
                                                    ratio, ftol, xtol)
             if termination_status is not None:
@@ -1454,9 +1666,9 @@ def _trf_device(prob, x0, lb, ub, ftol=1e-4, xtol=1e-8, gtol=1e-8, max_nfev=None
             _dist.allreduce_sum_(vec[nc:nc + np3])
         V.part = None
         prob.local_points = False
-    return OptimizeResult(x=prob.download_n(x), cost=cost, grad=prob.download_n(g),
-                          optimality=g_norm,
-                          active_mask=prob.download_n(active).astype(int), nfev=nfev, njev=njev,
+    x_out, g_out, active_out = prob.download_n_many([x, g, active])
+    return OptimizeResult(x=x_out, cost=cost, grad=g_out, optimality=g_norm,
+                          active_mask=active_out.astype(int), nfev=nfev, njev=njev,
                           status=termination_status, lsmr_iterations=lsmr_iters,
                           iterations=iteration)
 

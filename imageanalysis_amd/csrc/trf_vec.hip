@@ -242,6 +242,41 @@ __global__ __launch_bounds__(256) void strictly_feasible_kernel(int64_t n, const
     }
 }
 
+// make_strictly_feasible(x, lb, ub, rstep) with rstep > 0 (trf.py: the start point): a component
+// within rstep * max(1, |bound|) of a finite bound moves that far inside it (the upper bound wins
+// where both tests hold, as find_active_constraints writes +1 last); a box too tight for that
+// takes its midpoint
+__global__ __launch_bounds__(256) void feasible_start_kernel(int64_t n, const double *__restrict__ x,
+                                                             const double *__restrict__ lb,
+                                                             const double *__restrict__ ub, double rstep,
+                                                             double *__restrict__ out)
+{
+    GRID_STRIDE(i, n) {
+        const double t = x[i];
+        const double ld = t - lb[i], ud = ub[i] - t;
+        const double lt = rstep * fmax(1.0, fabs(lb[i])), ut = rstep * fmax(1.0, fabs(ub[i]));
+        double r = t;
+        if (isfinite(lb[i]) && ld <= (ud < lt ? ud : lt)) r = lb[i] + lt;
+        if (isfinite(ub[i]) && ud <= (ld < ut ? ld : ut)) r = ub[i] - ut;
+        if (r < lb[i] || r > ub[i]) r = 0.5 * (lb[i] + ub[i]);
+        out[i] = r;
+    }
+}
+
+// trf.py, before the loop: x * scale_inv / v**0.5 with v[dv != 0] *= scale_inv -- the vector whose
+// norm is the first trust-region radius
+__global__ __launch_bounds__(256) void scaled_start_kernel(int64_t n, const double *__restrict__ x,
+                                                           const double *__restrict__ scale_inv,
+                                                           const double *__restrict__ v,
+                                                           const double *__restrict__ dv,
+                                                           double *__restrict__ out)
+{
+    GRID_STRIDE(i, n) {
+        const double vv = dv[i] != 0.0 ? v[i] * scale_inv[i] : v[i];
+        out[i] = x[i] * scale_inv[i] / sqrt(vv);
+    }
+}
+
 // find_active_constraints(x, lb, ub, rtol) with rtol > 0
 __global__ __launch_bounds__(256) void active_kernel(int64_t n, const double *__restrict__ x,
                                                      const double *__restrict__ lb,
@@ -464,6 +499,25 @@ extern "C" int iamx_trf_strictly_feasible(int64_t n, const double *x, const doub
     if (n <= 0) return IAMX_OK;
     LAUNCH(strictly_feasible_kernel, n, n, x, step, lb, ub, out);
     return iamx::check_launch("iamx_trf_strictly_feasible");
+}
+
+extern "C" int iamx_trf_feasible_start(int64_t n, const double *x, const double *lb, const double *ub,
+                                       double rstep, double *out, void *stream)
+{
+    IAMX_REQUIRE(x && lb && ub && out, "null pointer");
+    IAMX_REQUIRE(rstep > 0, "rstep > 0 (rstep = 0 is iamx_trf_strictly_feasible)");
+    if (n <= 0) return IAMX_OK;
+    LAUNCH(feasible_start_kernel, n, n, x, lb, ub, rstep, out);
+    return iamx::check_launch("iamx_trf_feasible_start");
+}
+
+extern "C" int iamx_trf_scaled_start(int64_t n, const double *x, const double *scale_inv,
+                                     const double *v, const double *dv, double *out, void *stream)
+{
+    IAMX_REQUIRE(x && scale_inv && v && dv && out, "null pointer");
+    if (n <= 0) return IAMX_OK;
+    LAUNCH(scaled_start_kernel, n, n, x, scale_inv, v, dv, out);
+    return iamx::check_launch("iamx_trf_scaled_start");
 }
 
 extern "C" int iamx_trf_active(int64_t n, const double *x, const double *lb, const double *ub,

@@ -761,6 +761,14 @@ int iamx_trf_strictly_feasible(int64_t n, const double *x, const double *step, c
                                const double *ub, double *out, void *stream);
 int iamx_trf_active(int64_t n, const double *x, const double *lb, const double *ub, double rtol,
                     double *active, void *stream);
+/* make_strictly_feasible(x, lb, ub, rstep) for rstep > 0: the start point of trf_bounds
+ * (scipy/optimize/_lsq/trf.py:214 through common.py:440) */
+int iamx_trf_feasible_start(int64_t n, const double *x, const double *lb, const double *ub, double rstep,
+                            double *out, void *stream);
+/* out = x * scale_inv / sqrt(v') with v' = v * scale_inv where dv != 0: the vector whose norm is the
+ * first trust-region radius (trf.py:243-246) */
+int iamx_trf_scaled_start(int64_t n, const double *x, const double *scale_inv, const double *v,
+                          const double *dv, double *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -629,3 +629,32 @@ def test_optimizer_setup_and_refit_on_the_array_backed_chains(path):
         assert (x[0] is None) == (y[0] is None)
         if x[0] is not None:
             assert np.allclose(x[0], y[0], rtol=0, atol=0)
+
+
+def test_2d_trust_region_solver_equals_scipys():
+    """ba_solver.solve_tr_2d against scipy/optimize/_lsq/common.py solve_trust_region_2d -- the
+    subproblem trf.py solves per trial step (trf.py:328) --: the same case (Newton step or
+    boundary) and the same model value, over definite, singular and badly scaled B."""
+    from scipy.optimize._lsq.common import solve_trust_region_2d
+    from imageanalysis_amd.ba_solver import solve_tr_2d
+    rng = np.random.default_rng(3)
+    newton = boundary = 0
+    for k in range(2000):
+        Q = rng.normal(size=(2, 2))
+        B = Q @ Q.T * 10 ** rng.uniform(-4, 4)
+        if k % 7 == 0:                          # s1 = 0: the second row and column vanish
+            B[1, :] = 0
+            B[:, 1] = 0
+        g = np.array([10 ** rng.uniform(-4, 4), 0.0 if k % 2 else rng.normal()])
+        Delta = 10 ** rng.uniform(-4, 4)
+        want, want_newton = solve_trust_region_2d(B, g, Delta)
+        got, got_newton = solve_tr_2d(B, g, Delta)
+        assert got_newton == want_newton
+        value = lambda p: 0.5 * p @ B @ p + g @ p          # noqa: E731
+        assert abs(value(got) - value(want)) <= 1e-10 * abs(value(want))
+        assert np.linalg.norm(got) <= Delta * (1 + 1e-12)
+        if not np.allclose(B[1], 0):            # (a unique minimiser)
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-9 * Delta)
+        newton += got_newton
+        boundary += not got_newton
+    assert newton > 100 and boundary > 100

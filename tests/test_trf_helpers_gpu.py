@@ -113,6 +113,38 @@ def test_make_strictly_feasible_and_in_bounds(V, seed):
 
 
 @pytest.mark.parametrize('seed', range(4))
+def test_start_point_and_first_radius(V, seed):
+    """trf_bounds before its loop: make_strictly_feasible(x0, lb, ub) with the default rstep, and
+    Delta = norm(x0 * scale_inv / v**0.5)"""
+    from scipy.optimize._lsq import common
+    x, lb, ub, g, _ = _case(seed)
+    rng = np.random.default_rng(50 + seed)
+    # points on, just inside (within rstep) and outside their bounds
+    ubf = np.where(np.isfinite(ub), ub, 0.0)
+    x = np.where((rng.random(len(x)) < 0.1) & np.isfinite(ub),
+                 ubf - rng.uniform(0, 2e-10, len(x)) * np.maximum(1, np.abs(ubf)), x)
+    x = np.where(rng.random(len(x)) < 0.05, x + 10.0, x)
+    k = int(np.nonzero(np.isfinite(ub) & np.isfinite(lb))[0][0])
+    lb[k] = ub[k] = x[k] = -2.5                                    # a degenerate box
+    want = common.make_strictly_feasible(x, lb, ub)
+    tx, tlb, tub, tg = _t(V, x, lb, ub, g)
+    got = V.feasible_start(tx, tlb, tub, 1e-10)
+    assert np.array_equal(_h(got), want)
+    assert (want != x).sum() > 100
+    v, dv = common.CL_scaling_vector(want, g, lb, ub)
+    scale_inv = rng.uniform(0.1, 30, len(x))
+    v[dv != 0] *= scale_inv[dv != 0]
+    t = want * scale_inv / v ** 0.5
+    tv, tdv = V.cl_scaling(got, tg, tlb, tub)
+    tt = V.scaled_start(got, _t(V, scale_inv)[0], tv, tdv)
+    assert np.array_equal(_h(tt), t, equal_nan=True)
+    fin = np.isfinite(t)                     # (the degenerate box has v = 0)
+    tf = _t(V, np.where(fin, t, 0.0))[0]
+    assert fin.sum() >= len(t) - 1
+    assert np.isclose(np.sqrt(V.dots((tf, tf))[0]), np.linalg.norm(t[fin]), rtol=1e-13)
+
+
+@pytest.mark.parametrize('seed', range(4))
 def test_find_active_constraints(V, seed):
     from scipy.optimize._lsq import common
     x, lb, ub, _, _ = _case(seed)

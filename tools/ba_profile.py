@@ -35,3 +35,15 @@ for profile in (None, {}):
     if profile:
         for k, v in sorted(profile.items(), key=lambda kv: -kv[1]):
             print('   %-14s %8.1f ms  (%.1f %%)' % (k, v * 1e3, 100 * v / dt))
+
+if os.environ.get('IAMX_BA_CPROFILE'):
+    # where the host spends the solve (the GPU is busy for well under half of it)
+    import cProfile
+    import pstats
+    prob.profile = None
+    pr = cProfile.Profile()
+    pr.enable()
+    res = ba_solver.trf_device(prob, x0, lb, ub, ftol=1e-4, max_nfev=iters + 1)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(28)
