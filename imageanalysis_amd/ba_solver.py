@@ -138,6 +138,7 @@ class DeviceBA(object):
         self._tmp_many = None
         self.lsmr_ws = None
         self.schur_ws = None
+        self.schur_last_itn = 0
         # normal-equation blocks of the current Jacobian (iamx_ba_accumulate): U [C][7][7],
         # V [P][3][3], g = (gc [C][7], gp [P][3]) -- this rank's observations only
         self.acc = None
@@ -861,8 +862,15 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
 
     enqueued = [0]          # iterations enqueued since the factorisation (selects the state buffer)
 
+    # Chunk sizes: the first one is as long as the previous solve took (the counts drift slowly
+    # from one outer iteration to the next; at most 6), the following ones short -- whatever is
+    # enqueued behind the latched stop is launched as no-ops, 5 per iteration (and, on several
+    # ranks, all-reduced).
+    plan = [max(2, min(int(prob.schur_last_itn or chunk), 6, maxiter)), 2, 2, 2, 2]
+
     def enqueue_chunk():
         k = enqueued[0]
+        chunk = plan.pop(0) if plan else 4
         enqueued[0] += chunk
         if not multi:
             check(L.iamx_ba_schur_iterate(*it_args, k, chunk, -1, stream_ptr()), 'iamx_ba_schur_iterate')
@@ -889,7 +897,7 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
     enqueue_chunk()
     snapshot(0)
     cur = 0
-    for _ in range(maxiter // chunk + 3):
+    for _ in range(maxiter // 2 + 8):
         enqueue_chunk()
         snapshot(cur ^ 1)
         events[cur].synchronize()
@@ -911,6 +919,7 @@ def schur_solve(prob, d_dev, dreg_dev, eta=None, maxiter=None, chunk=4, to_host=
         _dist.allreduce_sum_(ws['step'][nc:nc + 3 * P])      # (the calibration entries are replicated)
     ph.__exit__()
     itn = int(st[2])
+    prob.schur_last_itn = itn
     prob.inner_iterations.append(itn)
     prob.inner_stops.append(int(st[3]))
     step = ws['step']
