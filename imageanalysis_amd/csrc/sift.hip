@@ -75,13 +75,11 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p >= n ? period - p : p;
 }
 
-__global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restrict__ src, int h,
-                                                        int w, int ch, float *__restrict__ dst)
+// pixel (y, x) of the doubled gray image (cv::resize INTER_LINEAR x2 of cvtColor BGR2GRAY), from
+// the h x w x ch 8-bit source
+__device__ __forceinline__ float gray_up2x_at(const uint8_t *__restrict__ src, int h, int w, int ch,
+                                              int y, int x)
 {
-    const int W2 = 2 * w, H2 = 2 * h;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)W2 * H2) return;
-    const int x = (int)(i % W2), y = (int)(i / W2);
     auto tap = [](int d, int n, int &i0, int &i1, float &t) {
         const float f = sub_rn(mul_rn(add_rn((float)d, 0.5f), 0.5f), 0.5f);
         i0 = (int)floorf(f);
@@ -103,7 +101,19 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
     const float omtx = sub_rn(1.f, tx), omty = sub_rn(1.f, ty);
     const float top = add_rn(mul_rn(gray(y0, x0), omtx), mul_rn(gray(y0, x1), tx));
     const float bot = add_rn(mul_rn(gray(y1, x0), omtx), mul_rn(gray(y1, x1), tx));
-    dst[i] = add_rn(mul_rn(top, omty), mul_rn(bot, ty));
+    return add_rn(mul_rn(top, omty), mul_rn(bot, ty));
+}
+
+// (Doubling inside the base blur's loads -- the doubled image never stored -- was measured in
+// round 4: 126 MB less traffic per 2189x1459 frame but 190 us instead of 60 + 38 us, four byte
+// gathers per source element in the blur's prefetch registers.  Not kept.)
+__global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restrict__ src, int h,
+                                                        int w, int ch, float *__restrict__ dst)
+{
+    const int W2 = 2 * w, H2 = 2 * h;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)W2 * H2) return;
+    dst[i] = gray_up2x_at(src, h, w, ch, (int)(i / W2), (int)(i % W2));
 }
 
 // Separable Gaussian, BORDER_REFLECT_101.  Both passes start from 0 and add the taps in ascending
@@ -118,17 +128,18 @@ __global__ __launch_bounds__(256) void gray_up2x_kernel(const uint8_t *__restric
 //               horizontal pass in strips of 8 outputs with the 8 + 2R inputs in registers
 //               -> a ring of SB_RING = 64 horizontally blurred rows in LDS
 //   V block b : a thread owns one column and 8 rows, its 8 + 2R ring rows in registers; writes
-//               the level and, fused, DoG = level - source
+//               the level
 // Every source row of a segment is blurred horizontally once (the tile form of round 2 redid
 // 2R rows per 32-row tile: 1.8x at R = 13), the source is read once (+ 2R / 64 columns of halo),
-// level and DoG are written once: 12 B per pixel and level + halo.  2R <= 32 keeps the window of
-// a V block inside the ring while the next H block is already in it.
+// the level is written once: 8 B per pixel and level + halo (the DoG levels are not stored:
+// extrema_kernel and refine_one subtract two levels where they need one).  2R <= 32 keeps the
+// window of a V block inside the ring while the next H block is already in it.
 constexpr int SB_TW = 64, SB_TH = 32, SB_RING = 64, SB_STRIP = 8;
 
 template <int R>
 __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict__ src, int h, int w,
                                                          Taps T, float *__restrict__ dst,
-                                                         float *__restrict__ dog, int seg_rows, int xcd)
+                                                         int seg_rows, int xcd)
 {
     static_assert(2 * R <= SB_RING - SB_TH, "the V window must fit the ring");
     const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
@@ -211,7 +222,6 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
                     for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
                     const int64_t i = (int64_t)y * w + x;
                     dst[i] = acc;
-                    if (dog) dog[i] = sub_rn(acc, src[i]);
                 }
             }
         }
@@ -225,8 +235,7 @@ inline int xcd_enabled()
 }
 
 template <int R>
-void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst,
-                       float *dog)
+void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst)
 {
     static_assert(256 / SB_TW * SB_STRIP == SB_TH && SB_TH * (SB_TW / SB_STRIP) == 256,
                   "thread maps of the two passes cover a block");
@@ -236,18 +245,18 @@ void launch_blur_strip(hipStream_t st, const float *src, int h, int w, const Tap
     int seg = (int)(((int64_t)h * strips / 768 + SB_TH - 1) / SB_TH) * SB_TH;
     seg = seg < SB_TH ? SB_TH : (seg > 256 ? 256 : seg);
     hipLaunchKernelGGL(blur_strip_kernel<R>, dim3(strips, (h + seg - 1) / seg), dim3(256), 0, st, src, h,
-                       w, tp, dst, dog, seg, xcd_enabled());
+                       w, tp, dst, seg, xcd_enabled());
 }
 
 // every radius gaussian_taps() can produce (r <= 16)
-void blur_level(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst, float *dog)
+void blur_level(hipStream_t st, const float *src, int h, int w, const Taps &tp, float *dst)
 {
     switch (tp.r) {
-#define IAMX_BS(r) case r: launch_blur_strip<r>(st, src, h, w, tp, dst, dog); break;
+#define IAMX_BS(r) case r: launch_blur_strip<r>(st, src, h, w, tp, dst); break;
         IAMX_BS(1) IAMX_BS(2) IAMX_BS(3) IAMX_BS(4) IAMX_BS(5) IAMX_BS(6) IAMX_BS(7) IAMX_BS(8)
         IAMX_BS(9) IAMX_BS(10) IAMX_BS(11) IAMX_BS(12) IAMX_BS(13) IAMX_BS(14) IAMX_BS(15)
 #undef IAMX_BS
-    default: launch_blur_strip<16>(st, src, h, w, tp, dst, dog); break;
+    default: launch_blur_strip<16>(st, src, h, w, tp, dst); break;
     }
 }
 
@@ -264,10 +273,12 @@ struct Cand {
     int o, layer, r, c;
 };
 
-// one launch per octave: every interior pixel is tested on the NL middle DoG layers (the five
-// DoG images are read once instead of up to three times)
-struct DogStack {
-    const float *d[NL + 2];
+// one launch per octave: every interior pixel is tested on the NL middle DoG layers.  The DoG
+// images are never stored: D_l = G_(l+1) - G_l is one float subtraction of two levels the scan
+// reads anyway (six Gaussian levels once, instead of five DoG levels that the blur passes would
+// have had to write first: 4 B per pixel and level less traffic, and 5 of 11 pyramid buffers less)
+struct GaussStack {
+    const float *g[NL + 3];
 };
 
 // One wave per strip of 62 columns (+1 halo column each side) and EXT_ROWS rows: every lane keeps
@@ -279,7 +290,7 @@ struct DogStack {
 constexpr int EXT_ROWS = 16;      // rows per wave (4 waves of a workgroup: 64 rows)
 constexpr int EXT_LIST = 512;     // candidates a workgroup collects before its one global atomic
 
-__global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, int o,
+__global__ __launch_bounds__(256) void extrema_kernel(GaussStack G, int h, int w, int o,
                                                       float threshold, Cand *__restrict__ cand,
                                                       int cap, int *__restrict__ count, int xcd)
 {
@@ -300,18 +311,23 @@ __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, 
     const int r1 = min(r0 + EXT_ROWS, h - BORDER);
     if (r0 < r1) {                                     // (whole wave)
         float v[NL + 2][3];                            // rows r - 1, r, r + 1 (rolling)
+        float gl[NL + 3];
+        // the NL + 2 DoG values of one pixel from its NL + 3 Gaussian values
+        auto dog_row = [&](int row, int slot) {
 #pragma unroll
-        for (int L = 0; L < NL + 2; ++L) {
-            v[L][1] = D.d[L][(int64_t)(r0 - 1) * w + cl];
-            v[L][2] = D.d[L][(int64_t)r0 * w + cl];
-        }
+            for (int L = 0; L < NL + 3; ++L) gl[L] = G.g[L][(int64_t)row * w + cl];
+#pragma unroll
+            for (int L = 0; L < NL + 2; ++L) v[L][slot] = sub_rn(gl[L + 1], gl[L]);
+        };
+        dog_row(r0 - 1, 1);
+        dog_row(r0, 2);
         for (int r = r0; r < r1; ++r) {
 #pragma unroll
             for (int L = 0; L < NL + 2; ++L) {
                 v[L][0] = v[L][1];
                 v[L][1] = v[L][2];
-                v[L][2] = D.d[L][(int64_t)(r + 1) * w + cl];
             }
+            dog_row(r + 1, 2);
             float cmax[NL + 2], cmin[NL + 2];
 #pragma unroll
             for (int L = 0; L < NL + 2; ++L) {
@@ -350,9 +366,8 @@ __global__ __launch_bounds__(256) void extrema_kernel(DogStack D, int h, int w, 
 }
 
 struct Pyr {
-    // per octave: pointers of the 6 Gaussian and 5 DoG levels, dims
+    // per octave: pointers of the 6 Gaussian levels, dims
     float *g[6];
-    float *d[5];
     int h, w;
 };
 constexpr int MAX_OCT = 16;
@@ -378,8 +393,7 @@ template <int R>
 __device__ __forceinline__ void tail_level(float *__restrict__ cur, float *__restrict__ hor,
                                            float *__restrict__ nxt_base, int H, int W, int P, int P2,
                                            const float *__restrict__ k /* LDS */,
-                                           float *__restrict__ dst, float *__restrict__ dog,
-                                           bool make_base)
+                                           float *__restrict__ dst, bool make_base)
 {
     // horizontal: strips of 8 consecutive outputs of a row.  Consecutive lanes take the same
     // strip of consecutive ROWS: their LDS addresses differ by the odd pitch P (conflict free;
@@ -431,7 +445,6 @@ __device__ __forceinline__ void tail_level(float *__restrict__ cur, float *__res
             if (y < H) {
                 const int i = y * W + col, il = y * P + col;
                 dst[i] = acc[j];
-                dog[i] = sub_rn(acc[j], cur[il]);
                 cur[il] = acc[j];                  // (this position is read by nobody else any more)
                 // level NL is the source of the next octave (INTER_NEAREST to half the size)
                 if (make_base && !(y & 1) && !(col & 1) && (y >> 1) < H / 2 && (col >> 1) < W / 2)
@@ -484,14 +497,14 @@ __global__ __launch_bounds__(1024) void pyramid_tail_kernel(PyrTable T, int o_fi
         __syncthreads();
         for (int l = 1; l < NL + 3; ++l) {
             const float *tp = sk[l - 1];
-            float *dst = T.oct[o].g[l], *dog = T.oct[o].d[l - 1];
+            float *dst = T.oct[o].g[l];
             const bool mb = l == NL && o + 1 < T.n_oct;
             switch (sr[l - 1]) {
-#define IAMX_TL(r) case r: tail_level<r>(cur, hor, nxt, H, W, P, P2, tp, dst, dog, mb); break;
+#define IAMX_TL(r) case r: tail_level<r>(cur, hor, nxt, H, W, P, P2, tp, dst, mb); break;
                 IAMX_TL(1) IAMX_TL(2) IAMX_TL(3) IAMX_TL(4) IAMX_TL(5) IAMX_TL(6) IAMX_TL(7) IAMX_TL(8)
                 IAMX_TL(9) IAMX_TL(10) IAMX_TL(11) IAMX_TL(12) IAMX_TL(13) IAMX_TL(14) IAMX_TL(15)
 #undef IAMX_TL
-            default: tail_level<16>(cur, hor, nxt, H, W, P, P2, tp, dst, dog, mb); break;
+            default: tail_level<16>(cur, hor, nxt, H, W, P, P2, tp, dst, mb); break;
             }
         }
     }
@@ -585,9 +598,11 @@ __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
     const float deriv_scale = img_scale * 0.5f, second_scale = img_scale, cross_scale = img_scale * 0.25f;
     float xi = 0, xr = 0, xc = 0;
     int it = 0;
-#define AT(im, rr, cc) ((im)[(int64_t)(rr) * w + (cc)])
+    // DoG layer `im` at (rr, cc): the difference of two Gaussian levels, as the pyramid defines it
+    // (img / prv / nxt are the DoG layer indices layer, layer - 1, layer + 1)
+#define AT(im, rr, cc) sub_rn(P.g[(im) + 1][(int64_t)(rr) * w + (cc)], P.g[(im)][(int64_t)(rr) * w + (cc)])
     for (; it < MAX_STEPS; ++it) {
-        const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
+        const int img = layer, prv = layer - 1, nxt = layer + 1;
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
@@ -614,7 +629,7 @@ __device__ __forceinline__ bool refine_one(const PyrTable &T, const Cand cd,
     if (it >= MAX_STEPS) return false;
     float contr;
     {
-        const float *img = P.d[layer], *prv = P.d[layer - 1], *nxt = P.d[layer + 1];
+        const int img = layer, prv = layer - 1, nxt = layer + 1;
         const float dD[3] = {(AT(img, r, c + 1) - AT(img, r, c - 1)) * deriv_scale,
                              (AT(img, r + 1, c) - AT(img, r - 1, c)) * deriv_scale,
                              (AT(nxt, r, c) - AT(prv, r, c)) * deriv_scale};
@@ -1240,8 +1255,8 @@ void gaussian_taps(double sigma, Taps &T)
 struct Layout {
     int n_oct;
     int h[MAX_OCT], w[MAX_OCT];
-    int64_t g_off[MAX_OCT][6], d_off[MAX_OCT][5];
-    int64_t cand_off, refined_off, count_off, total;
+    int64_t g_off[MAX_OCT][6];
+    int64_t up_off, cand_off, refined_off, count_off, total;
 };
 
 Layout make_layout(int height, int width, int cap_c)
@@ -1257,10 +1272,10 @@ Layout make_layout(int height, int width, int cap_c)
     for (int o = 0; o < n_oct; ++o) {
         L.h[o] = H; L.w[o] = W;
         for (int i = 0; i < 6; ++i) L.g_off[o][i] = take((int64_t)H * W * 4);
-        for (int i = 0; i < 5; ++i) L.d_off[o][i] = take((int64_t)H * W * 4);
         H /= 2; W /= 2;
         if (H < 1 || W < 1) { L.n_oct = o + 1; break; }
     }
+    L.up_off = take((int64_t)L.h[0] * L.w[0] * 4);          // the 2x image before the base blur
     L.cand_off = take((int64_t)cap_c * sizeof(Cand));
     L.refined_off = take((int64_t)cap_c * sizeof(Refined));
     L.count_off = take(256);
@@ -1330,7 +1345,6 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         T.oct[o].h = L.h[o];
         T.oct[o].w = L.w[o];
         for (int i = 0; i < 6; ++i) T.oct[o].g[i] = reinterpret_cast<float *>(ws + L.g_off[o][i]);
-        for (int i = 0; i < 5; ++i) T.oct[o].d[i] = reinterpret_cast<float *>(ws + L.d_off[o][i]);
     }
     Cand *cand = reinterpret_cast<Cand *>(ws + L.cand_off);
     Refined *refined = reinterpret_cast<Refined *>(ws + L.refined_off);
@@ -1350,31 +1364,32 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
         const double sp = pow(kf, (double)(i - 1)) * sigma_d, stt = sp * kf;
         sig[i] = sqrt(stt * stt - sp * sp);
     }
-    // dst = G_sigma * src; with `dog` also dog = dst - src (the DoG level between the two)
+    // dst = G_sigma * src
     Taps taps[NL + 3];
     for (int i = 1; i < NL + 3; ++i) gaussian_taps(sig[i], taps[i]);
-    auto blur = [&](hipStream_t q, const float *src, float *dst, int h, int w, const Taps &tp,
-                    float *dog) { blur_level(q, src, h, w, tp, dst, dog); };
+    auto blur = [&](hipStream_t q, const float *src, float *dst, int h, int w, const Taps &tp) {
+        blur_level(q, src, h, w, tp, dst);
+    };
     // base image: gray -> x2 -> blur(sqrt(sigma^2 - 1))
     {
         const int H = L.h[0], W = L.w[0];
-        float *up = T.oct[0].d[0];             // scratch (overwritten by the DoG later)
+        float *up = reinterpret_cast<float *>(ws + L.up_off);
         hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)H * W, 256)), dim3(256), 0, st,
                            image, height, width, channels, up);
         Taps tb;
         gaussian_taps(sqrt(fmax(sigma_d * sigma_d - 1.0, 0.01)), tb);
-        blur(st, up, T.oct[0].g[0], H, W, tb, nullptr);
+        blur(st, up, T.oct[0].g[0], H, W, tb);
     }
     const float threshold = floorf(0.5f * contrast_threshold / NL * 255.f);
     auto extrema = [&](hipStream_t q, int o) {
         const int H = L.h[o], W = L.w[o];
         if (H > 2 * BORDER && W > 2 * BORDER) {
-            DogStack D;
-            for (int i = 0; i < NL + 2; ++i) D.d[i] = T.oct[o].d[i];
+            GaussStack G;
+            for (int i = 0; i < NL + 3; ++i) G.g[i] = T.oct[o].g[i];
             hipLaunchKernelGGL(extrema_kernel,
                                dim3((unsigned)((W - 2 * BORDER + 61) / 62),
                                     (unsigned)((H - 2 * BORDER + 4 * EXT_ROWS - 1) / (4 * EXT_ROWS))),
-                               dim3(256), 0, q, D, H, W, o, threshold, cand, CAP_CAND, n_cand, xcd_enabled());
+                               dim3(256), 0, q, G, H, W, o, threshold, cand, CAP_CAND, n_cand, xcd_enabled());
         }
     };
     auto downsample = [&](hipStream_t q, int o) {
@@ -1392,7 +1407,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     for (int o = 0; o < o_side; ++o) {
         if (o > 0) downsample(st, o);
         for (int i = 1; i <= NL; ++i)
-            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i]);
     }
     SideStream *side = nullptr;
     hipStream_t ts = st;
@@ -1409,7 +1424,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     // left the main stream idle for 0.45 ms per frame)
     for (int o = 0; o < o_side; ++o) {
         for (int i = NL + 1; i < NL + 3; ++i)
-            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+            blur(st, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i]);
         extrema(st, o);
     }
     // small octaves: strip kernels down to o_tail, then ONE workgroup for the rest
@@ -1419,7 +1434,7 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     for (int o = o_side; o < o_tail; ++o) {
         downsample(ts, o);
         for (int i = 1; i < NL + 3; ++i)
-            blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i], T.oct[o].d[i - 1]);
+            blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i]);
         extrema(ts, o);
     }
     if (o_tail < L.n_oct) {
@@ -1489,7 +1504,8 @@ extern "C" int iamx_sift_sort(const float *kp, const uint8_t *desc, const int32_
 }
 
 // Where a pyramid level lives inside the workspace of iamx_sift_detect (tests / diagnosis):
-// kind 0 = Gaussian level `index` (0..5), 1 = DoG level `index` (0..4) of `octave`.
+// kind 0 = Gaussian level `index` (0..5) of `octave`.  (kind 1, the DoG levels of rounds 1-3, is
+// gone with the buffers: DoG level i is level i + 1 minus level i, taken where it is needed.)
 extern "C" int iamx_sift_pyramid_level(int height, int width, int octave, int kind, int index,
                                        int64_t *byte_offset, int *level_h, int *level_w,
                                        int *n_octaves)
@@ -1498,10 +1514,9 @@ extern "C" int iamx_sift_pyramid_level(int height, int width, int octave, int ki
     IAMX_REQUIRE(height >= 2 && width >= 2, "bad image size");
     const Layout L = make_layout(height, width, CAP_CAND);
     *n_octaves = L.n_oct;
-    IAMX_REQUIRE(octave >= 0 && octave < L.n_oct && (kind == 0 || kind == 1) && index >= 0 &&
-                     index < (kind == 0 ? 6 : 5),
-                 "no such level");
-    *byte_offset = kind == 0 ? L.g_off[octave][index] : L.d_off[octave][index];
+    IAMX_REQUIRE(kind == 0, "only the Gaussian levels (kind 0) are stored");
+    IAMX_REQUIRE(octave >= 0 && octave < L.n_oct && index >= 0 && index < 6, "no such level");
+    *byte_offset = L.g_off[octave][index];
     *level_h = L.h[octave];
     *level_w = L.w[octave];
     return IAMX_OK;

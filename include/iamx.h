@@ -436,8 +436,9 @@ int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
                      int32_t *n_out, void *stream);
 
 /* Where a pyramid level lives inside the workspace after iamx_sift_detect (tests / diagnosis):
- * kind 0 = Gaussian level index 0..5, kind 1 = DoG level index 0..4 of `octave` (0 = the doubled
- * image); float32 [level_h][level_w] at workspace + byte_offset. */
+ * kind 0 = Gaussian level index 0..5 of `octave` (0 = the doubled image); float32
+ * [level_h][level_w] at workspace + byte_offset.  Other kinds fail: the DoG levels are not
+ * stored (level i + 1 minus level i is taken where the scan and the sub-pixel fit need it). */
 int iamx_sift_pyramid_level(int height, int width, int octave, int kind, int index,
                             int64_t *byte_offset, int *level_h, int *level_w, int *n_octaves);
 

@@ -158,6 +158,11 @@ def test_sift_rotation_invariance(k):
     assert ratio_ok > 0.6
 
 
+def _lib_error():
+    from imageanalysis_amd import _lib
+    return _lib.IamxError
+
+
 def _device_level(img_shape, ws, octave, kind, index):
     import ctypes
     from imageanalysis_amd import _lib
@@ -189,16 +194,17 @@ def test_config_size_pyramid_bit_equal_and_whole_frame():
     _lvl, n_oct = _device_level(gray.shape, ws, 0, 0, 0)
     assert n_oct == len(gauss) >= 10
     for o in range(n_oct):
+        levels = []
         for i in range(6):
             got, _ = _device_level(gray.shape, ws, o, 0, i)
             assert got.shape == gauss[o][i].shape and np.array_equal(got, gauss[o][i]), ('gauss', o, i)
+            levels.append(got)
+        # the DoG levels are not stored on the device: the scan and the sub-pixel fit take
+        # level i + 1 minus level i (one float32 subtraction) -- the oracle's DoG images
         for i in range(5):
-            if o == 0 and i == 0:
-                continue                               # DoG 0 of octave 0 doubles as scratch before it is written
-            got, _ = _device_level(gray.shape, ws, o, 1, i)
-            assert np.array_equal(got, dog[o][i]), ('dog', o, i)
-    got, _ = _device_level(gray.shape, ws, 0, 1, 0)
-    assert np.array_equal(got, dog[0][0])
+            assert np.array_equal(levels[i + 1] - levels[i], dog[o][i]), ('dog', o, i)
+    with pytest.raises(_lib_error()):
+        _device_level(gray.shape, ws, 0, 1, 0)
     # keypoints / descriptors of the whole frame, row by row
     kps, des, removed = so.detect_and_compute(gray, return_removed=True)
     assert len(kps) > 5000 and removed >= 1 and dropped == removed
@@ -215,3 +221,21 @@ def test_config_size_pyramid_bit_equal_and_whole_frame():
         ck, co, cd = kernels.sift_detect(crop)
         assert len(kps) > 100 and kernels.sift_detect.last_removed == removed
         assert _rows_equal(kps, des, ck, co, cd)[0] == 0 and _rows_equal(kps, des, ck, co, cd)[2] <= 1
+
+
+def test_base_level_for_two_sigmas():
+    """The base level is the blur of the doubled gray image: the oracle's level bit for bit, on a
+    colour image too (cvtColor inside the doubling), for the default sigma and for one whose base
+    blur has another radius (5 and 12)."""
+    import torch
+    from imageanalysis_amd import kernels
+    from oracle import sift_oracle as so
+    frame = texture(150, 211, 5)
+    for image in (frame, so.bgr_to_gray(frame)):
+        gray = so.bgr_to_gray(frame).astype(np.float32)
+        for sigma in (1.6, 3.0):
+            kernels.sift_detect(image, sigma=sigma)
+            ws = kernels._sift_ws[(torch.cuda.current_device(), 0)]
+            got, _ = _device_level(gray.shape, ws, 0, 0, 0)
+            want = so.gaussian_blur(so.resize_linear_2x(gray), np.sqrt(sigma * sigma - 1.0))
+            assert np.array_equal(got, want), sigma

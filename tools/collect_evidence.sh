@@ -88,6 +88,18 @@ if [ -z "$NO_ENTRY" ]; then
 step "entry points"
 timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_dense.txt"
 timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
+# configs[2] through matcher.find_matches (2812 x 4096, 3.95 M pairs)
+timeout 600 python tools/find_matches_rate.py 38 74 4096 > "$OUT/${TAG}_fm_config2_run.txt" 2>&1; tail -n 3 "$OUT/${TAG}_fm_config2_run.txt"
+# configs[4] at 512 rendered 20 MP frames (what bench.py quotes as e2e_full_recorded)
+timeout 900 python bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey \
+    --images 64 --e2e-full 512 > "$OUT/${TAG}_e2e_full_run.json" 2> "$OUT/${TAG}_e2e_full_run.err"
+python - "$OUT/${TAG}_e2e_full_run.json" "$OUT/${TAG}_e2e_full_512.json" <<'PY'
+import json, sys
+rec = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]).get("e2e_full")
+if rec:
+    json.dump(rec, open(sys.argv[2], "w"), indent=1)
+    print("e2e_full:", rec.get("images"), "frames,", rec.get("seconds_total", rec.get("seconds")), "s")
+PY
 fi
 fi
 step "done"
