@@ -175,6 +175,7 @@ def main():
           % (n_pairs, dt, n_pairs / dt, linked, total))
     if prof:
         pstats.Stats(prof).sort_stats('cumulative').print_stats(28)
+        pstats.Stats(prof).sort_stats('tottime').print_stats(40)
 
 
 if __name__ == '__main__':
