@@ -87,7 +87,7 @@ cp "$OUT/${TAG}_sift_kernel_stats.txt" "$OUT/${TAG}_sift_time.txt" "$REPO/profil
 if [ -z "$NO_ENTRY" ]; then
 step "entry points"
 timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_dense.txt"
-timeout 600 python tools/detect_rate.py 64 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
+timeout 900 python tools/detect_rate.py 256 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
 # configs[2] through matcher.find_matches (2812 x 4096, 3.95 M pairs)
 timeout 600 python tools/find_matches_rate.py 38 74 4096 > "$OUT/${TAG}_fm_config2_run.txt" 2>&1; tail -n 3 "$OUT/${TAG}_fm_config2_run.txt"
 # configs[4] at 512 rendered 20 MP frames (what bench.py quotes as e2e_full_recorded)
