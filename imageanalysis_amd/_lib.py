@@ -60,6 +60,9 @@ SIGNATURES = {
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     'iamx_ledger_index': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    'iamx_pairs_fwd_rev': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int]),
+    'iamx_touch_pages': (c_int, [c_void_p, c_int64, c_int]),
+    'iamx_segment_mean_std': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int]),
     'iamx_group_level': (c_int64, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_void_p]),
     'iamx_triangulate_ground': (c_int, [c_void_p] * 3 + [c_int] + [c_void_p] * 3 + [c_int64]

@@ -11,7 +11,9 @@
 #include "iamx_common.h"
 
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -306,3 +308,119 @@ extern "C" int iamx_ledger_index(const int64_t *qi, const int64_t *qj, const int
     }
     return IAMX_OK;
 }
+
+// ---- a round of find_matches: the bulk work between the device and the python lists -----------
+// A round that holds pairs WITH matches hands back millions of (query, train) rows in one packed,
+// page-locked buffer that the next round reuses.  What python did with them per round -- one copy,
+// one column-swapped copy (the reversed direction's list), the mean / standard deviation of every
+// pair's triangulated heights through three temporaries of the size of the round -- cost 70-100 ms
+// in numpy, most of it first-touch page faults of fresh arrays on ONE thread, while the device
+// idled (profiles/r4_fm_timeline_c2.txt: the first 24 rounds of the 2812-image survey took 102 ms
+// each against 29 ms of sweep).  Here: a few threads, every byte touched once.
+namespace {
+template <class F>
+void run_threads(int64_t n, int threads, int64_t grain, F body)          // body(lo, hi) on [0, n)
+{
+    int t = threads < 1 ? 1 : (threads > 16 ? 16 : threads);
+    if ((int64_t)t > (n + grain - 1) / grain) t = (int)((n + grain - 1) / grain);
+    if (t <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + t - 1) / t;
+    for (int k = 1; k < t; ++k) {
+        const int64_t lo = per * k, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) pool.emplace_back([=] { body(lo, hi); });
+    }
+    body((int64_t)0, per < n ? per : n);
+    for (auto &th : pool) th.join();
+}
+
+// numpy's float64 add.reduce (loops_utils.h.src DOUBLE_pairwise_sum): straight below 8 terms,
+// eight interleaved partial sums up to 128, halves (multiples of 8) above
+double pairwise_sum(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+}  // namespace
+
+// fwd[k] = src[k], rev[k] = (src[k][1], src[k][0]) for n rows of two int32
+extern "C" int iamx_pairs_fwd_rev(const int32_t *src, int64_t n, int32_t *fwd, int32_t *rev, int threads)
+{
+    if (n < 0 || (n > 0 && (!src || !fwd || !rev)))
+        return iamx::fail(IAMX_EINVAL, "iamx_pairs_fwd_rev: null pointer or negative count");
+    run_threads(n, threads, (int64_t)1 << 16, [=](int64_t lo, int64_t hi) {
+        for (int64_t k = lo; k < hi; ++k) {
+            const int32_t a = src[2 * k], b = src[2 * k + 1];
+            fwd[2 * k] = a; fwd[2 * k + 1] = b;
+            rev[2 * k] = b; rev[2 * k + 1] = a;
+        }
+    });
+    return IAMX_OK;
+}
+
+// per segment s (z[starts[s] .. + counts[s]), counts >= 1): mean = np.add.reduceat(z, starts) / c
+// and std = sqrt(np.add.reduceat((z - mean)**2, starts) / c) -- numpy's own summation order (the
+// first term, then the pairwise sum of the rest), so the values are the ones the numpy form gave
+extern "C" int iamx_segment_mean_std(const double *z, const int64_t *starts, const int64_t *counts,
+                                     int64_t n_seg, int64_t n_z, double *mean, double *std, int threads)
+{
+    if (n_seg < 0 || n_z < 0 || (n_seg > 0 && (!z || !starts || !counts || !mean || !std)))
+        return iamx::fail(IAMX_EINVAL, "iamx_segment_mean_std: null pointer or negative count");
+    for (int64_t s = 0; s < n_seg; ++s)
+        if (counts[s] < 1 || starts[s] < 0 || starts[s] + counts[s] > n_z)
+            return iamx::fail(IAMX_EINVAL, "iamx_segment_mean_std: segment out of range or empty");
+    run_threads(n_seg, threads, 64, [=](int64_t lo, int64_t hi) {
+        std::vector<double> d2;
+        for (int64_t s = lo; s < hi; ++s) {
+            const double *a = z + starts[s];
+            const int64_t c = counts[s];
+            const double m = (a[0] + pairwise_sum(a + 1, c - 1)) / (double)c;
+            d2.resize((size_t)c);
+            for (int64_t i = 0; i < c; ++i) {
+                const double d = a[i] - m;
+                d2[(size_t)i] = d * d;
+            }
+            mean[s] = m;
+            std[s] = sqrt((d2[0] + pairwise_sum(d2.data() + 1, c - 1)) / (double)c);
+        }
+    });
+    return IAMX_OK;
+}
+
+// Reads one byte of every 4 KiB page of [p, p + bytes) on `threads` threads: the first touch of a
+// fresh page-locked (or plain) buffer costs microseconds per page, and a round's landing buffers
+// are hundreds of megabytes (find_matches pays it once per buffer set, 0.45 s each on one thread:
+// matcher._prewarm_pools does it beside the schedule bookkeeping instead of inside round 0-2).
+extern "C" int iamx_touch_pages(const void *p, int64_t bytes, int threads)
+{
+    if (bytes < 0 || (bytes > 0 && !p))
+        return iamx::fail(IAMX_EINVAL, "iamx_touch_pages: null pointer or negative size");
+    const volatile unsigned char *b = static_cast<const volatile unsigned char *>(p);
+    const int64_t pages = (bytes + 4095) / 4096;
+    run_threads(pages, threads, 1024, [=](int64_t lo, int64_t hi) {
+        unsigned acc = 0;
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t at = k * 4096;
+            acc += b[at < bytes ? at : bytes - 1];
+        }
+        (void)acc;
+    });
+    return IAMX_OK;
+}
+

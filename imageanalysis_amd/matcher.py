@@ -20,17 +20,22 @@ Only the 'traditional' strategy (the default of process.py / 3a-matching.py) and
 descriptors (integer valued 0..255) are on this path.
 """
 import contextlib
+import ctypes
 import gc
 import time
 from math import sqrt
 
 import numpy as np
 
-from . import _deps
-from .matchpairs import MatchPairs
+from . import _deps, _lib
+from .matchpairs import MatchPairs, empty_huge
 from .keypoints import KeyPointList
 from ._deps import getNode
 from .gms import gms_inlier_mask
+
+# host threads of the bulk routines between a round's packed results and its match lists
+# (libiamx: iamx_pairs_fwd_rev, iamx_segment_mean_std); the GPU box grants a process 16 cores
+_HOST_THREADS = 6
 
 detector_node = getNode('/config/detector', True)
 matcher_node = getNode('/config/matcher', True)
@@ -45,6 +50,8 @@ PAIRS_PER_BATCH = 16384 # unordered pairs per device batch (per-batch host costs
                         # took 0.5 s off the 2812-image all-pairs survey, profiles/r4_fm_config2.txt)
 BATCH_BYTES = 24 << 30  # ... as far as one batch's device workspace stays below this (three are pooled:
                         # 72 GB of the 288 GB; 512 instead of 128 pairs per batch at 50 k keypoints)
+EARLY_SMART_ROUNDS = 8  # rounds in a row without a match before smart.json is written ahead of time
+early_smart_stats = {'written': 0, 'current_at_end': 0}     # (tests / diagnosis)
 PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
 
 
@@ -505,6 +512,9 @@ def _no_gc():
         yield
     finally:
         if was:
+            # (the lists made inside are acyclic and stay: out of the collector's generations, or
+            #  the first allocation after enable() pays a full pass over all of them, ~0.3 s)
+            gc.freeze()
             gc.enable()
 
 
@@ -650,7 +660,11 @@ def _host_set(n, clip, surface):
     if clip:
         # the matches of the pairs that have some, packed back to back by the device
         # (iamx_match_pack_results writes these page-locked buffers directly)
-        cap = min(n * clip, max(PACK_CAP, n * 1024))   # (grows with the batch: ~800 matches per pair that has some)
+        # (grows with the batch.  The closest pairs of a survey carry ~1700 matches each and a
+        #  distance-sorted schedule puts 16 384 of them into ONE round: with room for 1024 per pair
+        #  the first three rounds of the 2812-image survey overflowed into the slot-by-slot path,
+        #  0.45 s each -- tools/find_matches_rate.py --trace)
+        cap = min(n * clip, max(PACK_CAP, n * 2048))
         hs.update(cnt=pin(n, torch.int32), status=pin(n, torch.int32), cap=cap,
                   off=pin(n + 1, torch.int64), pk_pairs=pin((cap, 2), torch.int32))
         if surface:
@@ -658,6 +672,39 @@ def _host_set(n, clip, surface):
             hs['aff'] = pin((n, 2, 6), torch.float64)
             hs['aff_ok'] = pin((n, 2), torch.int32)
     return hs
+
+
+def _prewarm_pools(n, rows, surface, dev, stream, sets=3):
+    """The first rounds of a survey each met an empty pool: a workspace of gigabytes, the device
+    result set of the filters, the page-locked landing buffers (hundreds of megabytes whose pages
+    are mapped on first touch) -- 0.4-0.5 s per round and set, with the device idle
+    (tools/find_matches_rate.py --trace).  This allocates what `sets` rounds of n pairs with
+    `rows`-descriptor images rotate through and touches the host buffers, on a helper thread beside
+    the bookkeeping between the schedule and the first launch; everything goes through the pools'
+    own constructors, so a round that asks for another size simply allocates as before."""
+    import torch
+    clip = int(_lib.lib().iamx_match_postfilter_clip())
+    with torch.cuda.device(dev), torch.cuda.stream(stream):
+        host = [_host_set(n, clip, surface) for _ in range(sets)]
+        for hs in host:
+            for t in hs.values():
+                if isinstance(t, torch.Tensor) and t.numel() * t.element_size() >= (1 << 20):
+                    _lib.check(_lib.lib().iamx_touch_pages(ctypes.c_void_p(t.data_ptr()),
+                                                           t.numel() * t.element_size(), _HOST_THREADS),
+                               'iamx_touch_pages')
+        for hs in host:
+            _host_sets[hs['key']].append(hs)
+        post = [_post_set(n, clip, torch.device('cuda', dev), surface) for _ in range(2)]
+        for p_ in post:
+            _post_pool[p_['key']].append(p_)
+        work = [_workspace(2 * n * int(rows), 2 * n) for _ in range(2)]
+        # the bound tables of the symmetric sweep (kernels.sym_tables: a column table of the padded
+        # row count per pair, the per-row partial bounds of every workgroup of the other image)
+        cap3 = (int(rows) + 127) // 128 * 128
+        wg_rows = 1024 if rows >= 4096 else (512 if rows >= 2048 else 256)
+        for w in work:
+            w.ensure_sym(n * cap3, n * ((int(rows) + wg_rows - 1) // wg_rows) * cap3)
+        _ws_pool.extend(work)
 
 
 def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
@@ -924,7 +971,9 @@ def _finish_batch_arrays(h):
         #  the CPU tests of the multi-rank logic)
         return _round_from_tuples(h)
     from . import smart as _smart
+    _t0 = time.perf_counter()
     h['done'].synchronize()
+    _t1 = time.perf_counter()
     hs, n, ws, post = h['host'], h['n'], h['ws'], h['post']
     R = _RoundResult()
     R.n = n
@@ -951,11 +1000,15 @@ def _finish_batch_arrays(h):
                 off = hs['off'].numpy()
                 if int(off[n]) <= hs['cap']:
                     # packed: per-pair sums over contiguous segments
+                    # (iamx_segment_mean_std: np.add.reduceat(z) / c and the same of the squared
+                    #  deviations in numpy's summation order, without the round-sized temporaries)
                     zcat = hs['pk_z'].numpy()[:int(off[n])]
-                    starts = off[dev_rows]
-                    mean = np.add.reduceat(zcat, starts) / c
-                    dev2 = (zcat - np.repeat(mean, c)) ** 2
-                    std = np.sqrt(np.add.reduceat(dev2, starts) / c)
+                    starts = np.ascontiguousarray(off[dev_rows], np.int64)
+                    mean, std = np.empty(len(c)), np.empty(len(c))
+                    _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+                    _lib.check(_lib.lib().iamx_segment_mean_std(_hp(zcat), _hp(starts), _hp(c), len(c),
+                                                                len(zcat), _hp(mean), _hp(std),
+                                                                _HOST_THREADS), 'iamx_segment_mean_std')
                 else:
                     Z = np.zeros((len(dev_rows), int(c.max())))
                     for t_, k_ in enumerate(dev_rows.tolist()):
@@ -980,8 +1033,12 @@ def _finish_batch_arrays(h):
             off_h = hs['off'].numpy()
             packed = int(off_h[n]) <= hs['cap']
             if packed:
-                fwd_all = hs['pk_pairs'].numpy()[:int(off_h[n])].copy()
-                rev_all = np.ascontiguousarray(fwd_all[:, ::-1])
+                # (one threaded pass writes both: the copy and its column-swapped twin)
+                src = hs['pk_pairs'].numpy()[:int(off_h[n])]
+                fwd_all, rev_all = empty_huge(src.shape, np.int32), empty_huge(src.shape, np.int32)
+                _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+                _lib.check(_lib.lib().iamx_pairs_fwd_rev(_hp(src), len(src), _hp(fwd_all), _hp(rev_all),
+                                                         _HOST_THREADS), 'iamx_pairs_fwd_rev')
                 lo = off_h[dev_rows].tolist()
                 hi = (off_h[dev_rows] + c).tolist()
             if packed:
@@ -1030,7 +1087,12 @@ def _finish_batch_arrays(h):
     finally:
         _host_sets[hs['key']].append(hs)
         _recycle(h)
+    if _round_trace is not None:        # (tools/find_matches_rate.py --trace)
+        _round_trace.append(('finish', _t1 - _t0, time.perf_counter() - _t1, len(R.hits)))
     return R
+
+
+_round_trace = None
 
 
 def _round_from_tuples(results):
@@ -1237,11 +1299,17 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         if len(_ready) > 1:
             early = threading.Thread(target=_register, name='iamx-register')
             early.start()
+    if _round_trace is not None:
+        _round_trace.append(('pre', 'helper started', time.perf_counter()))
     try:
         wd, wi, wj = _work_arrays(proj, sort)
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'schedule built', time.perf_counter()))
     finally:
         if early is not None:
             early.join()
+    if _round_trace is not None:
+        _round_trace.append(('pre', 'registration joined', time.perf_counter()))
     if early is not None and _failed:
         raise _failed[0]
     match_ratio = matcher_node.getFloat('match_ratio')
@@ -1279,12 +1347,14 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     n_pending = len(wi)
 
     # every image's match_list becomes a MatchDict tied to this call's ledger of quiet pairs
-    ledger = QuietLedger(names)
+    ledger = QuietLedger(names, capacity=n_pending)
     for k, im in enumerate(image_list):
         if not isinstance(im.match_list, MatchDict):
             im.match_list = MatchDict(im.match_list)
         im.match_list.attach(ledger, k)
 
+    if _round_trace is not None:
+        _round_trace.append(('pre', 'ledger attached', time.perf_counter()))
     save_time = time.time()
     save_interval = 300     # seconds
     _log("Processing worklist matches:")
@@ -1300,6 +1370,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # smallest value so that they run the same number of rounds (the gather is a collective)
     ppb = PAIRS_PER_BATCH
     early_failure = None
+    known = []
     try:
         if hi_mine > lo_mine and isinstance(the_matcher, DeviceMatcher):
             known = [_rows_of(im) for im in image_list if _have_features(im)]
@@ -1316,12 +1387,33 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         ppb = min(_dist.allgather_objects(ppb))
     n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if n_pending else 0
     n_done = 0
+    # a survey of many full rounds: the pools its rounds rotate through are filled (and the
+    # page-locked buffers touched) on a helper thread while the bookkeeping below runs
+    warm = None
+    if ws == 1 and isinstance(the_matcher, DeviceMatcher) and early_failure is None and known \
+            and (hi_mine - lo_mine) >= 4 * ppb:
+        import threading
+        import torch as _torch
+
+        def _warm(n_=ppb, rows_=max(known), dev_=_torch.cuda.current_device(),
+                  stream_=_torch.cuda.current_stream()):
+            try:
+                _prewarm_pools(n_, rows_, bool(batched_surface), dev_, stream_)
+            except Exception:             # noqa: BLE001  (best effort: a round allocates what it misses)
+                pass
+        warm = threading.Thread(target=_warm, name='iamx-prewarm')
+        warm.start()
 
     # ---- images this rank will have to detect / load, in the order the rounds reach them:
     # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
     from . import image as _image
     mine_imgs = np.stack([wi[lo_mine:hi_mine], wj[lo_mine:hi_mine]], 1).ravel()
-    _u, first_at = np.unique(mine_imgs, return_index=True)
+    # (first occurrence of every image without sorting the 2 x pairs entries: assigning positions
+    #  in reverse order leaves the smallest one; np.unique took 0.2 s on the 2812-image survey)
+    first_pos = np.full(len(image_list), -1, np.int64)
+    first_pos[mine_imgs[::-1]] = np.arange(len(mine_imgs) - 1, -1, -1, dtype=np.int64)
+    mine_uniq = np.nonzero(first_pos >= 0)[0]
+    first_at = first_pos[mine_uniq]
     need = []
     for k in mine_imgs[np.sort(first_at)].tolist():
         im = image_list[k]
@@ -1334,7 +1426,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # each, and growing the arenas image by image rebuilt and re-synchronised them every round
     # (the device idled through the first ~70 rounds of a 2812-image survey: r3_fm_timeline)
     if isinstance(the_matcher, DeviceMatcher) and early_failure is None:
-        ready = [image_list[k] for k in np.unique(mine_imgs).tolist()
+        ready = [image_list[k] for k in mine_uniq.tolist()
                  if image_list[k].des_list is not None and image_list[k].kp_list is not None
                  and len(getattr(image_list[k].des_list, 'shape', ())) == 2 and len(image_list[k].des_list) > 1]
         if len(ready) > 1:
@@ -1410,19 +1502,65 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # otherwise WAIT for the device (drain(until=...)), or at the latest before a save.
     to_book = deque()
 
+    # smart.json ahead of time.  Its content only changes when a pair WITH matches is booked; on a
+    # distance-sorted schedule those all sit in the first rounds, and the host then idles through
+    # hundreds of quiet ones.  Once everything seen is booked and several rounds in a row brought
+    # nothing, the file is written on a helper thread beside the waits; the end of the call writes
+    # it again only if a pair with matches was booked after that (booking first waits for a
+    # writer that is still reading the tree).
+    hits_booked = [0]
+    rounds_without_hits = [0]
+    early_smart = {'thread': None, 'hits': -1, 'error': None}
+
+    def _early_smart_join():
+        t = early_smart['thread']
+        if t is not None and t.is_alive():
+            t.join()
+
+    def maybe_save_smart_early():
+        if rank != 0 or smart is None or early_smart['thread'] is not None \
+                or not batched_surface or not hasattr(smart, 'flush_aggregates') \
+                or rounds_without_hits[0] < EARLY_SMART_ROUNDS:
+            return
+        # (quiet rounds: the host has time -- a few booking steps if any are left, ~2 ms each)
+        for _ in range(4):
+            if backlog or to_book:
+                drain_step()
+        if backlog or to_book or hits_booked[0] == 0:
+            return
+        import threading
+        smart.flush_aggregates()
+        early_smart['hits'] = hits_booked[0]
+
+        def _write():
+            try:
+                try:
+                    smart.save(proj.analysis_dir, polite=True)
+                except TypeError:                 # (the reference's lib.smart.save has one argument)
+                    smart.save(proj.analysis_dir)
+            except BaseException as exc:          # noqa: BLE001  (the end of the call writes it again)
+                early_smart['error'] = exc
+        early_smart['thread'] = threading.Thread(target=_write, name='iamx-smart-save-early')
+        early_smart['thread'].start()
+        early_smart_stats['written'] += 1
+
+    def drain_step():
+        _early_smart_join()
+        if backlog:
+            kind, payload = backlog.pop(0)
+            smart.record_round(payload)
+            smart.materialize_pending()
+        elif to_book:
+            try:
+                next(to_book[0])
+            except StopIteration:
+                to_book.popleft()
+
     def drain(until=None):
         """work the queues off -- all of it, or while the event `until` has not happened yet
         (one ~2 ms step at a time); all of it includes the pickles in flight"""
         while (backlog or to_book) and (until is None or not until.query()):
-            if backlog:
-                kind, payload = backlog.pop(0)
-                smart.record_round(payload)
-                smart.materialize_pending()
-            else:
-                try:
-                    next(to_book[0])
-                except StopIteration:
-                    to_book.popleft()
+            drain_step()
         if until is None:
             while pickling:
                 pickling.pop(0).result()
@@ -1465,6 +1603,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             _book_hits(hits[c0:c0 + BOOK_CHUNK], pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq)
 
     def _book_hits(hits, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq):
+        _early_smart_join()
+        hits_booked[0] += len(hits)
         # (python numbers for the chunk's pairs once: numpy scalars cost ~1 us each to format)
         ks = np.fromiter((h[0] for h in hits), np.int64, len(hits))
         pik, pjk, sqk = pi[ks].tolist(), pj[ks].tolist(), seq[ks].tolist()
@@ -1549,6 +1689,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # would otherwise wait in the collective forever
     in_flight = None
     failure = early_failure
+    if _round_trace is not None:
+        _round_trace.append(('pre', 'ready to launch', time.perf_counter()))
+    if warm is not None:
+        warm.join()
+    if _round_trace is not None:
+        _round_trace.append(('pre', 'pools warm', time.perf_counter()))
     if n_rounds and failure is None:
         try:
             in_flight = launch_round(0)
@@ -1575,8 +1721,11 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             for part in parts:
                 steps = book_steps(part)
                 next(steps, None)             # the once-per-round part now, the pairs with matches later
-                to_book.append(steps)
+                if len(part[10]):
+                    to_book.append(steps)
                 n_done += len(part[1])
+                rounds_without_hits[0] = 0 if len(part[10]) else rounds_without_hits[0] + 1
+        maybe_save_smart_early()
 
         t_elapsed = time.time() - t_start
         # (ranks != 0 only see their own pairs: their progress is that of their own shard)
@@ -1588,6 +1737,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         if time.time() >= save_time + save_interval:
             if rank == 0:
                 drain()
+                _early_smart_join()
                 _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
                 for k in np.nonzero(last_seq >= 0)[0].tolist():
                     image_list[k].matches_clean = False
@@ -1612,14 +1762,19 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     if prefetcher is not None:
         prefetcher.close()
     drain()
+    _early_smart_join()
     _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
     if rank == 0:
         # (quiet pairs dirty both images' match lists, like the reference's assignments)
         for k in np.nonzero(last_seq >= 0)[0].tolist():
             image_list[k].matches_clean = False
-        # smart.json is written beside the .match files (file writes release the interpreter)
+        # smart.json is written beside the .match files (file writes release the interpreter),
+        # unless the copy written ahead of time is still current
         saver = None
-        if smart is not None:
+        smart_current = early_smart['thread'] is not None and early_smart['error'] is None \
+            and early_smart['hits'] == hits_booked[0]
+        early_smart_stats['current_at_end'] += bool(smart_current)
+        if smart is not None and not smart_current:
             import threading
             saver = threading.Thread(target=smart.save, args=(proj.analysis_dir,), name='iamx-smart-save')
             saver.start()

@@ -126,6 +126,37 @@ class MatchPairs(MutableSequence):
         return (list, (self.tolist(),))
 
 
+_HUGE = 2 << 20
+_libc = None
+
+
+def empty_huge(shape, dtype):
+    """np.empty() for arrays of many megabytes that are written once: anonymous memory with
+    MADV_HUGEPAGE, so that the first touch maps 2 MiB at a time where the kernel grants
+    transparent huge pages (a fresh 4 KiB page costs microseconds of kernel time, and a heavy
+    round of find_matches writes ~10^5 of them: 0.45 s per round on the GPU box, 1.6 s per
+    268 MB in the build container; 10x less with huge pages).  Plain np.empty() below 8 MiB or
+    when mmap / madvise are not to be had."""
+    import ctypes
+    import mmap
+    global _libc
+    dtype = np.dtype(dtype)
+    shape = (int(shape),) if np.ndim(shape) == 0 else tuple(int(x) for x in shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if n < (8 << 20):
+        return np.empty(shape, dtype)
+    try:
+        m = mmap.mmap(-1, n + _HUGE)
+        raw = np.frombuffer(m, np.uint8)
+        off = (-raw.ctypes.data) % _HUGE
+        if _libc is None:
+            _libc = ctypes.CDLL(None, use_errno=True)
+        _libc.madvise(ctypes.c_void_p(raw.ctypes.data + off), ctypes.c_size_t(n), 14)   # MADV_HUGEPAGE
+        return raw[off:off + n].view(dtype).reshape(shape)
+    except (OSError, ValueError, AttributeError):
+        return np.empty(shape, dtype)
+
+
 def _int_opcode(max_value, min_value):
     """(opcode, numpy dtype) of the narrowest fixed-width pickle integer that holds the range"""
     if min_value >= 0 and max_value < 65536:
@@ -169,9 +200,13 @@ def _pairs_bytes_many(arrays):
     np.cumsum(lens, out=off[1:])
     total = int(off[-1])
     full = [np.ascontiguousarray(a, np.int32).reshape(-1, 2) for a in arrays if len(a)]
-    cat = np.concatenate(full) if len(full) > 1 else (full[0] if full else np.zeros((0, 2), np.int32))
+    if len(full) > 1:
+        cat = empty_huge((total, 2), np.int32)
+        np.concatenate(full, out=cat)
+    else:
+        cat = full[0] if full else np.zeros((0, 2), np.int32)
     cap = 3 * len(arrays) + 13 * total
-    out = np.empty(cap, np.uint8)
+    out = empty_huge(cap, np.uint8)
     out_off = np.zeros(len(arrays) + 1, np.int64)
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     n = _lib.lib().iamx_pickle_pair_lists(p(cat), p(off), len(arrays), p(out), cap, p(out_off))
@@ -203,20 +238,29 @@ class QuietLedger(object):
     `seq` is the position of the pair in the order find_matches processed the pairs (the
     reference assigns match_list entries in that order, scripts/lib/matcher.py:978-979)."""
 
-    def __init__(self, names):
+    def __init__(self, names, capacity=0):
+        """capacity: the number of pairs the call will process at most (the three columns then
+        never move: rounds append into them as they finish, nothing is joined at the end)"""
         self.names = names
-        self._i, self._j, self._seq = [], [], []
+        self._cols = np.empty((3, max(int(capacity), 1024)), np.int64)      # i, j, seq
+        self._n = 0
         self._index = None
 
     def add(self, i, j, seq):
-        if len(i):
-            self._i.append(np.asarray(i, np.int64))
-            self._j.append(np.asarray(j, np.int64))
-            self._seq.append(np.asarray(seq, np.int64))
+        k = len(i)
+        if k:
+            if self._n + k > self._cols.shape[1]:
+                grown = np.empty((3, max(2 * self._cols.shape[1], self._n + k)), np.int64)
+                grown[:, :self._n] = self._cols[:, :self._n]
+                self._cols = grown
+            self._cols[0, self._n:self._n + k] = i
+            self._cols[1, self._n:self._n + k] = j
+            self._cols[2, self._n:self._n + k] = seq
+            self._n += k
             self._index = None
 
     def __len__(self):
-        return int(sum(len(a) for a in self._i))
+        return self._n
 
     def entry_records(self):
         """per image: the bytes of `name: []` inside a .match pickle (key record + EMPTY_LIST);
@@ -233,10 +277,7 @@ class QuietLedger(object):
     def partners_of(self, k):
         """(partner image indices, seq) of image k's quiet pairs, in processing order"""
         if self._index is None:
-            if self._i:
-                qi, qj, sq = (np.concatenate(a) for a in (self._i, self._j, self._seq))
-            else:
-                qi = qj = sq = np.zeros(0, np.int64)
+            qi, qj, sq = (self._cols[r, :self._n] for r in range(3))
             if len(sq) > 1 and np.any(np.diff(sq) < 0):
                 o = np.argsort(sq, kind='stable')
                 qi, qj, sq = qi[o], qj[o], sq[o]

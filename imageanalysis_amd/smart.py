@@ -579,7 +579,11 @@ def load(analysis_dir):
             _from_dict(smart_node, json.load(f))
 
 
-def save(analysis_dir):
+def save(analysis_dir, polite=False):
+    """polite: called on a helper thread beside a loop that launches device work (find_matches
+    writes the file ahead of time): give the interpreter lock up after every image's record -- a
+    thread that holds it for 0.3 ms at a time and never sleeps makes the launching thread wait up
+    to the 5 ms switch interval at each of its own dozens of lock hand-overs per round."""
     if analysis_dir is None:
         return
     path = os.path.join(analysis_dir, "smart.json")
@@ -589,11 +593,17 @@ def save(analysis_dir):
     else:
         if len(smart_node.__dict__) > 200 and not _has_enum_lists(smart_node):
             # (one C-encoder pass with a callback per node instead of a python copy of the tree)
+            import time
+
+            def records(top):
+                for k in sorted(top):
+                    yield '%s: %s' % (json.dumps(k), json.dumps(top[k], sort_keys=True,
+                                                                default=lambda o: o.__dict__))
+                    if polite:
+                        time.sleep(0.0002)
             with open(path, 'w') as f:
-                top = smart_node.__dict__
                 f.write('{\n')
-                f.write(',\n'.join('%s: %s' % (json.dumps(k), json.dumps(
-                    top[k], sort_keys=True, default=lambda o: o.__dict__)) for k in sorted(top)))
+                f.write(',\n'.join(records(smart_node.__dict__)))
                 f.write('\n}\n')
             return
         tree = _to_dict(smart_node)

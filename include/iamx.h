@@ -320,6 +320,20 @@ int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *
  * bounds [n_images + 1].  One counting sort. */
 int iamx_ledger_index(const int64_t *qi, const int64_t *qj, const int64_t *seq, int64_t m,
                       int64_t n_images, int64_t *other, int64_t *seq_out, int64_t *bounds);
+/* iamx_pairs_fwd_rev, iamx_segment_mean_std -- HOST arrays, `threads` host threads.  The bulk
+ * work of one round of find_matches between the device's packed result buffer and the match
+ * lists of scripts/lib/matcher.py:978-979: fwd = the n (query, train) int32 rows copied out of the
+ * page-locked buffer, rev = the same rows with the columns swapped (the list of the reversed
+ * direction); and, per pair, the mean and standard deviation of its triangulated heights
+ * (lib/smart.py:117-130 estimate_surface_elevation: np.mean / np.std of the pair's values) over
+ * the segments z[starts[s] .. + counts[s]) of the round's packed heights, summed in numpy's
+ * order. */
+int iamx_pairs_fwd_rev(const int32_t *src, int64_t n, int32_t *fwd, int32_t *rev, int threads);
+/* reads one byte of every 4 KiB page of a HOST buffer on `threads` threads (first touch of the
+ * page-locked landing buffers of find_matches' rounds, off the critical path) */
+int iamx_touch_pages(const void *p, int64_t bytes, int threads);
+int iamx_segment_mean_std(const double *z, const int64_t *starts, const int64_t *counts,
+                          int64_t n_seg, int64_t n_z, double *mean, double *std, int threads);
 
 /* iamx_group_level -- one group level of scripts/lib/groups.py:59-118 compute() (HOST arrays):
  * seed chain + sweeps until nothing can be added.  level [n_matches] in/out (-1 = unused),

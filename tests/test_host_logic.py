@@ -658,3 +658,38 @@ def test_2d_trust_region_solver_equals_scipys():
         newton += got_newton
         boundary += not got_newton
     assert newton > 100 and boundary > 100
+
+
+def test_round_bulk_routines_equal_numpy():
+    """libiamx host routines of a find_matches round (lib/matcher.py:978-979 lists, lib/smart.py:
+    117-130 statistics): the threaded copy + column swap, and per-pair mean / std of the packed
+    heights BIT-equal to the numpy expressions they replace (np.add.reduceat sums)."""
+    import ctypes
+    from imageanalysis_amd import _lib
+    L = _lib.lib()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)          # noqa: E731
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 5, 70000, 300001):
+        src = rng.integers(0, 50000, (n, 2)).astype(np.int32)
+        fwd, rev = np.full_like(src, -1), np.full_like(src, -1)
+        _lib.check(L.iamx_pairs_fwd_rev(P(src), n, P(fwd), P(rev), 5), 'iamx_pairs_fwd_rev')
+        assert np.array_equal(fwd, src) and np.array_equal(rev, src[:, ::-1])
+    # segments of 1 .. 3000 values: below 8, up to 128, and the recursive halves of numpy's sum
+    c = np.concatenate([np.arange(1, 300), rng.integers(1, 3000, 400), [1, 1, 7, 8, 9, 127, 128, 129, 2999]])
+    c = c.astype(np.int64)
+    z = np.ascontiguousarray(rng.normal(-120.0, 35.0, int(c.sum())))
+    z[::97] *= 1e6
+    starts = np.ascontiguousarray(np.concatenate([[0], np.cumsum(c)[:-1]]), np.int64)
+    mean_np = np.add.reduceat(z, starts) / c
+    std_np = np.sqrt(np.add.reduceat((z - np.repeat(mean_np, c)) ** 2, starts) / c)
+    for threads in (1, 4):
+        mean, std = np.empty(len(c)), np.empty(len(c))
+        _lib.check(L.iamx_segment_mean_std(P(z), P(starts), P(c), len(c), len(z), P(mean), P(std), threads),
+                   'iamx_segment_mean_std')
+        assert np.array_equal(mean, mean_np) and np.array_equal(std, std_np)
+    # and what the reference computes per pair: np.mean / np.std of the pair's values
+    k = 431
+    seg = z[starts[k]:starts[k] + c[k]]
+    assert np.isclose(mean[k], np.mean(seg), rtol=1e-14) and np.isclose(std[k], np.std(seg), rtol=1e-12)
+    bad = np.array([0], np.int64)
+    assert L.iamx_segment_mean_std(P(z), P(starts), P(bad), 1, len(z), P(mean), P(std), 1) != 0

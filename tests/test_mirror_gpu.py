@@ -303,3 +303,67 @@ def test_optimizer_fun_jac_run_against_reference(path, solver):
                        opt.K[1, 2], opt.distCoeffs))
         e = opt.fun(x, *args)
         assert np.abs(e - opt.result.fun).max() < 1e-9
+
+
+@pytest.mark.parametrize('sort', [True, False], ids=['sorted', 'unsorted'])
+def test_smart_json_written_ahead_of_time_equals_the_final_one(tmp_path, sort):
+    """find_matches writes smart.json on a helper thread once several rounds in a row brought no
+    match (the host idles through the quiet rounds of a distance-sorted survey) and only writes
+    it again at the end when a pair with matches was booked later.  Either way the file is the
+    one a call without the early write leaves (scripts/lib/matcher.py:1020-1031 writes it at the
+    end): sorted schedule = every hit first, the early copy stands; unsorted (image order) =
+    hits keep arriving, the end rewrites."""
+    import json
+    from imageanalysis_amd import smart
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from test_match_gpu import _sift_like
+    matcher = _configure(0.75, 25)
+    n_img, W, H = 20, 5472, 3648
+    rng = np.random.default_rng(23)
+    des, xy = [], []
+    for i in range(n_img):
+        n = 600
+        d = _sift_like(rng, n)
+        p = np.stack([rng.uniform(600, W - 600, n), rng.uniform(400, H - 400, n)], 1)
+        if i:
+            # rows 0..299 of image i = rows 300..599 of image i - 1 (its own fresh rows: only
+            # neighbours share features, no chains across three images)
+            k = 300
+            src, dst = np.arange(k, 2 * k), np.arange(k)
+            d[dst] = np.clip(des[i - 1][src].astype(int) + rng.integers(-5, 6, (k, 128)), 0, 255)
+            p[dst] = xy[i - 1][src] + [250.0, -120.0] + rng.normal(0, 0.6, (k, 2))
+        des.append(d)
+        xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
+    files = {}
+    old = matcher.PAIRS_PER_BATCH, matcher.EARLY_SMART_ROUNDS
+    try:
+        for mode, after in (('early', 1), ('plain', 10 ** 9)):
+            tag = ('E' if mode == 'early' else 'P') + ('s' if sort else 'u')
+            names = ['%s%02d' % (tag, i) for i in range(n_img)]
+            out = tmp_path / mode
+            out.mkdir()
+            proj = PoseProject(names, analysis_dir=str(out))
+            for i, im in enumerate(proj.image_list):
+                im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+                fresh = _image(names[i], des[i], xy[i])
+                im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
+            matcher.PAIRS_PER_BATCH, matcher.EARLY_SMART_ROUNDS = 2, after
+            before = dict(matcher.early_smart_stats)
+            matcher.find_matches(proj, None, strategy='traditional', sort=sort)
+            written = matcher.early_smart_stats['written'] - before['written']
+            stands = matcher.early_smart_stats['current_at_end'] - before['current_at_end']
+            if mode == 'early':
+                assert written == 1 and stands == (1 if sort else 0), matcher.early_smart_stats
+            else:
+                assert written == 0 and stands == 0
+            tree = json.load(open(out / 'smart.json'))
+            mine = {k.replace(tag, 'X'): json.loads(json.dumps(v).replace(tag, 'X'))
+                    for k, v in tree.items() if k.startswith(tag)}
+            assert len(mine) >= n_img - 1
+            files[mode] = mine
+            hits = sum(len(v) > 0 for im in proj.image_list for v in im.match_list.values()) // 2
+            assert hits >= n_img - 2
+    finally:
+        matcher.PAIRS_PER_BATCH, matcher.EARLY_SMART_ROUNDS = old
+    assert files['early'] == files['plain']
+    assert any('yaw_pairs' in v or 'tri_surface_pairs' in v for v in files['early'].values())

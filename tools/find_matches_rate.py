@@ -133,10 +133,17 @@ def main():
     from imageanalysis_amd import smart as _smart
     orig_launch, orig_save, orig_ssave = matcher._launch_batch, matcher.saveMatches, _smart.save
 
+    trace = [] if '--trace' in sys.argv else None
+    matcher._round_trace = trace
+
     def launch(*a, **k):
         marks.setdefault('first launch', time.perf_counter())
         marks['launches'] = marks.get('launches', 0) + 1
-        return orig_launch(*a, **k)
+        t = time.perf_counter()
+        r = orig_launch(*a, **k)
+        if trace is not None:
+            trace.append(('launch', time.perf_counter() - t, time.perf_counter() - marks['first launch']))
+        return r
 
     def save(*a, **k):
         marks['rounds done'] = time.perf_counter()
@@ -173,6 +180,15 @@ def main():
     total = sum(len(v) for im in proj.image_list for v in im.match_list.values()) // 2
     print('find_matches: %d pairs in %.2f s = %.0f pairs/s; %d pairs with matches, %d matches'
           % (n_pairs, dt, n_pairs / dt, linked, total))
+    if trace is not None:
+        # per round: host time of the launch, wait for the device, host time of the finish, pairs with matches
+        ln = [t for t in trace if t[0] == 'launch']
+        fn = [t for t in trace if t[0] == 'finish']
+        print('before the first launch: ' + ', '.join('%s +%.3f s' % (t[1], t[2] - t0) for t in trace if t[0] == 'pre'))
+        print('round  at s   launch ms   wait ms  finish ms  hits')
+        for r in list(range(0, min(40, len(fn)))) + list(range(40, len(fn), 40)):
+            print('%5d %6.2f %9.1f %9.1f %9.1f %6d' % (r, ln[r][2], ln[r][1] * 1e3, fn[r][1] * 1e3, fn[r][2] * 1e3, fn[r][3]), *fn[r][4:])
+        print('sums: launch %.2f s, wait %.2f s, finish %.2f s' % (sum(t[1] for t in ln), sum(t[1] for t in fn), sum(t[2] for t in fn)))
     if prof:
         pstats.Stats(prof).sort_stats('cumulative').print_stats(28)
         pstats.Stats(prof).sort_stats('tottime').print_stats(40)
