@@ -22,6 +22,7 @@ descriptors (integer valued 0..255) are on this path.
 import contextlib
 import ctypes
 import gc
+import os
 import time
 from math import sqrt
 
@@ -50,6 +51,7 @@ PAIRS_PER_BATCH = 16384 # unordered pairs per device batch (per-batch host costs
                         # took 0.5 s off the 2812-image all-pairs survey, profiles/r4_fm_config2.txt)
 BATCH_BYTES = 24 << 30  # ... as far as one batch's device workspace stays below this (three are pooled:
                         # 72 GB of the 288 GB; 512 instead of 128 pairs per batch at 50 k keypoints)
+PREWARM_ROUNDS = 32     # a call with at least this many rounds fills its buffer pools on a helper thread first
 EARLY_SMART_ROUNDS = 8  # rounds in a row without a match before smart.json is written ahead of time
 early_smart_stats = {'written': 0, 'current_at_end': 0}     # (tests / diagnosis)
 PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
@@ -1391,7 +1393,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     # page-locked buffers touched) on a helper thread while the bookkeeping below runs
     warm = None
     if ws == 1 and isinstance(the_matcher, DeviceMatcher) and early_failure is None and known \
-            and (hi_mine - lo_mine) >= 4 * ppb:
+            and n_rounds >= PREWARM_ROUNDS:
         import threading
         import torch as _torch
 

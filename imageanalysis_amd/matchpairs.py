@@ -16,6 +16,8 @@ import pickle
 import struct
 from collections.abc import MutableSequence
 
+import os
+
 import numpy as np
 
 
