@@ -770,6 +770,9 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     pb = kernels.PairBatch(store, ordered, arena=arena)
     arena.commit()
     ws = _workspace(pb.rows, pb.n_pairs)
+    # (the kernels only ever RAISE this flag: a pooled workspace that reported a zero distance --
+    #  the ZeroDivisionError of matcher.py:255 -- would fail every later batch that draws it)
+    ws.zero_div.zero_()
     if device_filters:
         kp_off, xy, key2 = dm.keypoints()        # (may upload: before the kernels, like PROJ)
     thresh = max_distance * match_ratio

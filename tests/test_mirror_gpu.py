@@ -265,6 +265,17 @@ def test_find_matches_zero_division_like_reference():
         im.des_list, im.kp_list = f.des_list, f.kp_list
     with pytest.raises(ZeroDivisionError):       # all distances 0 -> d0/d1 = 0/0 (matcher.py:255)
         matcher.find_matches(proj, None, strategy='traditional')
+    # ... and the call after it is not affected: the device flag behind the exception lives in a
+    # POOLED workspace that the next batch of the same size draws (it stayed raised until round 4)
+    from test_match_gpu import _sift_like
+    rng = np.random.default_rng(3)
+    ok = PoseProject(['Y0', 'Y1'])
+    for i, im in enumerate(ok.image_list):
+        im.set_camera_pose([0.0, 10.0 * i, -100.0], 0.0, -90.0, 0.0)
+        f = _image(im.name, _sift_like(rng, 40), rng.uniform(100, 3000, (40, 2)).astype(np.float32))
+        im.des_list, im.kp_list = f.des_list, f.kp_list
+    matcher.find_matches(ok, None, strategy='traditional')
+    assert 'Y1' in ok.image_list[0].match_list
 
 
 @pytest.mark.parametrize('solver', ['device', 'scipy'])
