@@ -93,14 +93,24 @@ def merge_duplicates(proj):
         remaps.append(remap)
     _log("Merging keypoints with duplicate uv coordinates:")
     index = _index_by_name(proj)
+    # (an image without two used keypoints on one pixel maps every index onto itself)
+    same = [bool((r == np.arange(len(r))).all()) for r in remaps]
     for i, i1 in enumerate(proj.image_list):
         for key, matches in i1.match_list.items():
             j = index.get(key)
             if j is None or len(matches) == 0:
                 continue
-            p = _pairs(matches)
-            merged = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1)
-            matches[:] = merged if isinstance(matches, MatchPairs) else merged.tolist()
+            if same[i] and same[j]:
+                continue                      # nothing to merge: the list stays as it is
+            if isinstance(matches, MatchPairs):
+                p = matches.array()
+                merged = np.empty((len(p), 2), np.int32)
+                merged[:, 0] = remaps[i][p[:, 0]]
+                merged[:, 1] = remaps[j][p[:, 1]]
+                matches[:] = merged
+            else:
+                p = _pairs(matches)
+                matches[:] = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1).tolist()
 
 
 def check_for_pair_dups(proj):
@@ -117,6 +127,11 @@ def check_for_pair_dups(proj):
                 continue
             p = _pairs(matches)
             code = (p[:, 0] << 32) | p[:, 1]
+            # (the usual case -- no pair twice -- is settled by a plain sort: a third of the cost
+            #  of the index-returning unique)
+            srt = np.sort(code)
+            if not (srt[1:] == srt[:-1]).any():
+                continue
             _u, first = np.unique(code, return_index=True)
             count = len(p) - len(first)
             if count > 0:
@@ -145,24 +160,29 @@ def check_for_1vn_dups(proj):
 def make_match_structure(proj):
     _log("Constructing unified match structure:")
     index = _index_by_name(proj)
-    blocks = []
+    # the pairs (i < j) with matches, in the reference's order, and their [n, 2] keypoint arrays
+    ij, blocks = [], []
     for i, img in enumerate(proj.image_list):
         for key, matches in img.match_list.items():
             j = index.get(key)
             if j is None or j <= i or len(matches) == 0:
                 continue
-            p = _pairs(matches)
-            blocks.append(np.stack([np.full(len(p), i), p[:, 0], np.full(len(p), j), p[:, 1]], 1))
-    flat = np.concatenate(blocks) if blocks else np.zeros((0, 4), np.int64)
+            ij.append((i, j))
+            blocks.append(np.asarray(matches, np.int32).reshape(-1, 2))
+    counts = np.fromiter((len(b) for b in blocks), np.int64, len(blocks))
+    n = int(counts.sum())
+    # what link_matches() reads: (image, keypoint) of both ends of every pair match, interleaved
+    # -- the keypoint side IS the concatenated pair arrays, the image side a repeat of (i, j) per
+    # pair.  (Round 3 built an int64 [n, 4] table pair by pair and sliced it apart again.)
+    kp = np.concatenate(blocks).ravel() if blocks else np.zeros(0, np.int32)
+    img = np.repeat(np.asarray(ij, np.int32).reshape(-1, 2), counts, axis=0).ravel() if blocks \
+        else np.zeros(0, np.int32)
     # the reference's [[None, -1, [i, a], [j, b]], ...] (match_cleanup.py:190-215), as a list
     # that is only built when somebody other than link_matches() looks into it
-    matches_direct = DirectMatches(flat)
+    matches_direct = DirectMatches(img, kp)
     # link_matches() normally receives this very object: the array form goes with it
-    n = len(flat)
-    proj._iamx_direct = (matches_direct, n,
-                         np.ascontiguousarray(flat[:, [0, 2]].ravel(), np.int32),
-                         np.ascontiguousarray(flat[:, [1, 3]].ravel(), np.int32),
-                         np.arange(n + 1, dtype=np.int64) * 2)
+    proj._iamx_direct = (matches_direct, n, np.ascontiguousarray(img, np.int32),
+                         np.ascontiguousarray(kp, np.int32), np.arange(n + 1, dtype=np.int64) * 2)
     if n:
         _log("Total feature pairs in image set:", n)
         _log("Keypoint average instances = %.1f (should be 2.0 here)" % 2.0)
@@ -171,22 +191,24 @@ def make_match_structure(proj):
 
 class DirectMatches(object):
     """make_match_structure()'s result: a sequence of [None, -1, [i, a], [j, b]] lists -- one
-    python list of four objects per pair match, millions on a survey -- backed by the [n, 4]
-    array it was computed as.  The lists are created (all of them, once) when an element is
-    asked for; len() and link_matches() do not need them."""
+    python list of four objects per pair match, millions on a survey -- backed by the interleaved
+    (image, image) and (keypoint, keypoint) arrays it was computed as.  The lists are created
+    (all of them, once) when an element is asked for; len() and link_matches() do not need them."""
 
-    def __init__(self, flat):
-        self._flat = flat
+    def __init__(self, img, kp):
+        self._img = np.asarray(img).reshape(-1, 2)
+        self._kp = np.asarray(kp).reshape(-1, 2)
         self._rows = None
 
     def rows(self):
         if self._rows is None:
             with _no_gc():
-                self._rows = [[None, -1, [i, a], [j, b]] for i, a, j, b in self._flat.tolist()]
+                self._rows = [[None, -1, [i, a], [j, b]] for (i, j), (a, b)
+                              in zip(self._img.tolist(), self._kp.tolist())]
         return self._rows
 
     def __len__(self):
-        return len(self._flat) if self._rows is None else len(self._rows)
+        return len(self._img) if self._rows is None else len(self._rows)
 
     def __getitem__(self, k):
         return self.rows()[k]
@@ -330,24 +352,29 @@ def link_matches(proj, matches_direct):
     _log('Replacing keypoint indices with uv coordinates:')
     o_ptr = o_ptr[:n_chain + 1]
     total = int(o_ptr[-1])
-    # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt))
-    uv = np.zeros((total, 2), np.float64)
-    # (chain members grouped by image with ONE stable sort: a mask per image is O(images x
-    #  members), 3 s of the 9 s this stage took on a 512-frame survey)
-    by_img = np.argsort(o_img[:total], kind='stable')
-    cuts = np.searchsorted(o_img[:total][by_img], np.arange(len(proj.image_list) + 1))
-    for i in np.nonzero(np.diff(cuts))[0].tolist():
-        sel = by_img[cuts[i]:cuts[i + 1]]
-        uv[sel] = _kp_xy(proj.image_list[i])[o_kp[sel]].astype(np.float64)
     _log("Sorting matches by longest chain first.")
     lens = np.diff(o_ptr)
-    order = np.argsort(-lens, kind='stable')          # list.sort(key=len, reverse=True) is stable
+    # list.sort(key=len, reverse=True) is stable (16-bit keys: numpy's stable argsort is a radix
+    # sort for them)
+    order = np.argsort((-lens).astype(np.int16) if total and lens.max() < 32768 else -lens, kind='stable')
     # the chains in that order, as arrays (Chains builds the reference's lists only on demand)
     new_ptr = np.zeros(n_chain + 1, np.int64)
     np.cumsum(lens[order], out=new_ptr[1:])
     take = (np.repeat(o_ptr[:-1][order] - new_ptr[:-1], lens[order]) + np.arange(total)) if total else \
         np.zeros(0, np.int64)
-    out = Chains(o_img[:total][take], uv[take], new_ptr)
+    f_img, f_kp = o_img[:total][take], o_kp[:total][take]
+    # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt)): ONE
+    # gather from the images' keypoint positions laid end to end, in the final order (a scatter
+    # per image behind a sort of the members by image was 1 s of a 512-frame survey's 3.9 s)
+    seen = np.zeros(len(proj.image_list), bool)
+    seen[f_img] = True
+    xy_of = [(_kp_xy(im) if seen[i] else np.zeros((0, 2), np.float32))
+             for i, im in enumerate(proj.image_list)]
+    first = np.zeros(len(xy_of) + 1, np.int64)
+    np.cumsum([len(x) for x in xy_of], out=first[1:])
+    xy_all = np.concatenate(xy_of) if xy_of else np.zeros((0, 2), np.float32)
+    uv = xy_all[first[f_img] + f_kp].astype(np.float64) if total else np.zeros((0, 2), np.float64)
+    out = Chains(f_img, uv, new_ptr)
     if n_chain:
         _log("Total unique features in image set:", n_chain)
         _log("Keypoint average instances:", "%.2f" % (total / float(n_chain)))
