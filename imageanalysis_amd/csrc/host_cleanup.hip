@@ -13,10 +13,37 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <sys/mman.h>
 #include <thread>
 #include <vector>
 
 namespace {
+
+// A fixed-size array in anonymous memory with MADV_HUGEPAGE (where the kernel grants transparent
+// huge pages: a first touch per 2 MiB instead of per 4 KiB).  The linking pass of a 512-frame
+// survey touches ~1 GB of fresh arrays once; as std::vectors their page faults cost more than the
+// pass itself.  Falls back to plain pages silently; contents are zero after construction.
+template <class T>
+struct HugeBuf {
+    T *p = nullptr;
+    size_t n = 0, bytes = 0;
+    explicit HugeBuf(size_t count) : n(count)
+    {
+        const size_t huge = (size_t)2 << 20;
+        bytes = ((count * sizeof(T) + huge - 1) / huge + 1) * huge;
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        p = static_cast<T *>(m);
+    }
+    ~HugeBuf() { if (p) munmap(p, bytes); }
+    HugeBuf(const HugeBuf &) = delete;
+    HugeBuf &operator=(const HugeBuf &) = delete;
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    T *data() { return p; }
+};
 
 // open-addressing map (img, kp) -> chain index, cleared per pass
 struct PointMap {
@@ -72,17 +99,23 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         iamx::fail(IAMX_EINVAL, "iamx_link_matches: more than 2^31 matches / points");
         return IAMX_EINVAL;
     }
-    // current pass input: flat points + offsets (two buffers, swapped per pass)
-    std::vector<int32_t> c_img(img, img + n_pts), c_kp(kp, kp + n_pts);
-    std::vector<int64_t> c_ptr(ptr, ptr + n_matches + 1);
+    try {
+    // current pass input: flat points + offsets (rewritten in place per pass)
+    HugeBuf<int32_t> c_img((size_t)n_pts), c_kp((size_t)n_pts);
+    HugeBuf<int64_t> c_ptr((size_t)n_matches + 1);
+    std::memcpy(c_img.data(), img, (size_t)n_pts * sizeof(int32_t));
+    std::memcpy(c_kp.data(), kp, (size_t)n_pts * sizeof(int32_t));
+    std::memcpy(c_ptr.data(), ptr, (size_t)(n_matches + 1) * sizeof(int64_t));
     // chains under construction: singly linked nodes in insertion order
-    std::vector<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_next((size_t)n_pts);
-    std::vector<int32_t> head, tail;
+    HugeBuf<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_next((size_t)n_pts);
+    // (a pass never makes more chains than it reads: n_matches bounds all of them)
+    HugeBuf<int32_t> head((size_t)n_matches + 1), tail((size_t)n_matches + 1);
+    int64_t n_chains = 0;
     // the images of a chain's first INL points, side by side: the "image already in the chain?"
     // test of a join reads one cache line instead of walking the chain's scattered nodes
     constexpr int INL = 7;
     struct ChainImgs { int32_t n; int32_t img[INL]; };
-    std::vector<ChainImgs> cimg;
+    HugeBuf<ChainImgs> cimg((size_t)n_matches + 1);
     // (image, keypoint) -> chain: a DENSE table over the keypoints that occur (image i owns
     // [base[i], base[i] + max keypoint index of i + 1)) -- one 4-byte access per look-up where
     // the hash map of rounds 1-3 paid two cache misses (key, value) and the mixing; the entries
@@ -96,26 +129,25 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         if (img[j] >= n_img) n_img = img[j] + 1;
     }
     std::vector<int64_t> base;
-    std::vector<int32_t> table;
+    size_t table_n = 0;
     if (dense) {
         base.assign((size_t)n_img + 1, 0);
         for (int64_t j = 0; j < n_pts; ++j)
             if (kp[j] + 1 > base[(size_t)img[j] + 1]) base[(size_t)img[j] + 1] = kp[j] + 1;
         for (int32_t i = 0; i < n_img; ++i) base[(size_t)i + 1] += base[(size_t)i];
         if (base[(size_t)n_img] >= (1LL << 31)) dense = false;
-        else table.assign((size_t)base[(size_t)n_img], -1);
+        else table_n = (size_t)base[(size_t)n_img];
     }
+    HugeBuf<int32_t> table(dense ? table_n : 1);
     PointMap map(dense ? 0 : (size_t)n_pts);
     constexpr int64_t AHEAD = 48;                         // points of look-ahead for the prefetch
     int passes = 0;
     int64_t n_cur = n_matches;
     while (true) {
         ++passes;
-        if (dense) { if (passes > 1) std::fill(table.begin(), table.end(), -1); }
+        if (dense) std::memset(table.data(), 0xff, table_n * sizeof(int32_t));      // every entry -1
         else map.clear();
-        head.clear();
-        tail.clear();
-        cimg.clear();
+        n_chains = 0;
         int32_t n_nodes = 0;
         auto append = [&](int32_t chain, int32_t pi, int32_t pk) {
             const int32_t nd = n_nodes++;
@@ -170,10 +202,10 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
                 if (index >= 0) break;
             }
             if (index < 0) {                                // new chain: register every point
-                index = (int32_t)head.size();
-                head.push_back(-1);
-                tail.push_back(-1);
-                cimg.push_back(ChainImgs{0, {0}});
+                index = (int32_t)n_chains++;
+                head[(size_t)index] = -1;
+                tail[(size_t)index] = -1;
+                cimg[(size_t)index] = ChainImgs{0, {0}};
                 for (int64_t j = b; j < e; ++j) {
                     store(c_img[j], c_kp[j], index);
                     append(index, c_img[j], c_kp[j]);
@@ -188,9 +220,8 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
             }
         }
         // next pass input = the chains in creation order, points in insertion order
-        const int64_t n_new = (int64_t)head.size();
+        const int64_t n_new = n_chains;
         int64_t o = 0;
-        c_ptr.resize((size_t)n_new + 1);
         for (int64_t i = 0; i < n_new; ++i) {
             c_ptr[(size_t)i] = o;
             for (int32_t nd = head[(size_t)i]; nd >= 0; nd = node_next[nd]) {
@@ -210,6 +241,10 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     std::memcpy(out_ptr, c_ptr.data(), (size_t)(n_cur + 1) * sizeof(int64_t));
     if (n_passes) *n_passes = passes;
     return n_cur;
+    } catch (const std::bad_alloc &) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_matches: out of memory");
+        return IAMX_EINVAL;
+    }
 }
 
 // One group level of scripts/lib/groups.py:59-118 compute() (HOST): pick the seed feature (the
