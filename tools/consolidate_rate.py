@@ -4,7 +4,7 @@ check_for_1vn_dups, make_match_structure, link_matches) on a synthetic survey of
 512-frame configs[4] run -- a grid of frames, every world point seen by the frames around it,
 every overlapping pair's matches as find_matches leaves them (array-backed MatchPairs) -- HOST
 code only, no GPU needed: per-function seconds (and a cProfile with --profile).
-    python tools/consolidate_rate.py [rows cols [points_per_frame]] [--profile]"""
+    python tools/consolidate_rate.py [rows cols [points_per_frame]] [--profile] [--dup=0.15]"""
 import cProfile
 import os
 import pstats
@@ -20,7 +20,7 @@ from imageanalysis_amd.keypoints import KeyPointList  # noqa: E402
 from imageanalysis_amd.matchpairs import MatchPairs  # noqa: E402
 
 
-def build(rows, cols, per_frame, seed=0):
+def build(rows, cols, per_frame, seed=0, dup=0.0):
     """frames on a grid with 70 % overlap along a row and 60 % between rows: a world point falls
     into ~8 frames; a pair of frames keeps ~55 % of its common points as matches"""
     rng = np.random.default_rng(seed)
@@ -43,6 +43,11 @@ def build(rows, cols, per_frame, seed=0):
         im = proj.image_list[k]
         im.set_camera_pose([origin[k, 1] * 0.05, origin[k, 0] * 0.05, -100.0], 0.0, -90.0, 0.0)
         xy = (pts[inside] - origin[k]).astype(np.float32)
+        if dup > 0 and len(xy) > 1:
+            # SIFT gives a location with several dominant orientations several keypoints: the same
+            # pixel more than once (what merge_duplicates is for)
+            twins = rng.random(len(xy)) < dup
+            xy[twins] = xy[rng.integers(0, len(xy), int(twins.sum()))]
         z = np.zeros(len(xy), np.float32)
         im.kp_list = KeyPointList(xy[:, 0].copy(), xy[:, 1].copy(), z + 3.0, z, z + 0.05, z.astype(np.int32))
         im.uv_list = xy
@@ -74,7 +79,8 @@ def main():
     rows, cols = (int(args[0]), int(args[1])) if len(args) >= 2 else (16, 32)
     per_frame = int(args[2]) if len(args) >= 3 else 37000
     t0 = time.time()
-    proj, n_pairs, n_matches = build(rows, cols, per_frame)
+    dup = max([float(a[6:]) for a in sys.argv if a.startswith('--dup=')] or [0.15])
+    proj, n_pairs, n_matches = build(rows, cols, per_frame, dup=dup)
     print('%d frames, %d pairs with matches, %d matches (built in %.1f s)'
           % (rows * cols, n_pairs, n_matches, time.time() - t0))
     prof = cProfile.Profile() if '--profile' in sys.argv else None
