@@ -693,3 +693,55 @@ def test_round_bulk_routines_equal_numpy():
     assert np.isclose(mean[k], np.mean(seg), rtol=1e-14) and np.isclose(std[k], np.std(seg), rtol=1e-12)
     bad = np.array([0], np.int64)
     assert L.iamx_segment_mean_std(P(z), P(starts), P(bad), 1, len(z), P(mean), P(std), 1) != 0
+
+
+def test_quiet_ledger_grows_and_indexes_like_the_naive_form():
+    """QuietLedger appends a round's quiet pairs into preallocated columns (growing them when the
+    announced capacity was too small) and hands every image its partners in processing order --
+    what a dictionary entry per pair and direction, assigned pair after pair
+    (scripts/lib/matcher.py:978-979), would hold."""
+    from imageanalysis_amd.matchpairs import QuietLedger
+    rng = np.random.default_rng(5)
+    names = ['q%02d' % k for k in range(37)]
+    for capacity in (0, 10, 5000):
+        led = QuietLedger(names, capacity=capacity)
+        want = {k: [] for k in range(len(names))}
+        seq = 0
+        for _round in range(40):
+            m = int(rng.integers(0, 90))
+            i = rng.integers(0, len(names), m)
+            j = (i + 1 + rng.integers(0, len(names) - 1, m)) % len(names)
+            s = np.arange(seq, seq + m)
+            seq += m
+            led.add(i, j, s)
+            for a, b, t in zip(i.tolist(), j.tolist(), s.tolist()):
+                want[a].append((b, t))
+                want[b].append((a, t))
+        assert len(led) == seq
+        for k in range(len(names)):
+            other, sq = led.partners_of(k)
+            assert list(zip(other.tolist(), sq.tolist())) == want[k]
+        led.add([0], [1], [seq])                        # an add after the index was built
+        other, sq = led.partners_of(1)
+        assert (int(other[-1]), int(sq[-1])) == (0, seq)
+
+
+def test_huge_page_backed_arrays_behave_like_numpy_arrays():
+    """matchpairs.empty_huge: the arrays a round's match lists are views of -- shape, dtype,
+    contiguity, writability, a view keeping the memory alive, the plain fallback below 8 MiB"""
+    import gc
+    from imageanalysis_amd.matchpairs import empty_huge
+    small = empty_huge((100, 2), np.int32)
+    assert small.shape == (100, 2) and small.dtype == np.int32 and small.flags['OWNDATA']
+    big = empty_huge((3_000_000, 2), np.int32)           # 24 MB
+    assert big.shape == (3_000_000, 2) and big.dtype == np.int32
+    assert big.flags['C_CONTIGUOUS'] and big.flags['WRITEABLE'] and big.ctypes.data % 4096 == 0
+    big[:] = np.arange(6_000_000, dtype=np.int32).reshape(-1, 2)
+    view = big[1_000_000:1_000_005]
+    del big
+    gc.collect()
+    assert view[:, 0].tolist() == [2_000_000, 2_000_002, 2_000_004, 2_000_006, 2_000_008]
+    flat = empty_huge(9_000_000, np.uint8)
+    assert flat.shape == (9_000_000,) and flat.dtype == np.uint8
+    flat[-1] = 7
+    assert int(flat[-1]) == 7
