@@ -59,6 +59,8 @@ SIGNATURES = {
                               + [c_void_p] * 6),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'iamx_chains_longest_first': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
+    'iamx_first_occurrence': (c_int, [c_void_p, c_int64, c_void_p]),
     'iamx_ledger_index': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     'iamx_pairs_fwd_rev': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int]),
     'iamx_touch_pages': (c_int, [c_void_p, c_int64, c_int]),

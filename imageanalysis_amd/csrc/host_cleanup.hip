@@ -459,3 +459,72 @@ extern "C" int iamx_touch_pages(const void *p, int64_t bytes, int threads)
     return IAMX_OK;
 }
 
+// ---- consolidation helpers (HOST) ----------------------------------------------------------
+// first[k] = the smallest j with key[j] == key[k]: what np.unique(key, return_index=True,
+// return_inverse=True) delivers as first[inverse] for merge_duplicates (match_cleanup.py:19-104:
+// keypoints of one image with the same "%.2f-%.2f" pixel collapse onto the first one), by one
+// pass over an open-addressing table instead of a stable argsort.
+extern "C" int iamx_first_occurrence(const int64_t *key, int64_t n, int64_t *first)
+{
+    if (n < 0 || (n > 0 && (!key || !first)))
+        return iamx::fail(IAMX_EINVAL, "iamx_first_occurrence: null pointer or negative count");
+    size_t cap = 16;
+    while (cap < (size_t)(2 * n + 16)) cap <<= 1;
+    std::vector<int64_t> slot(cap, -1);
+    const size_t mask = cap - 1;
+    for (int64_t k = 0; k < n; ++k) {
+        uint64_t h = (uint64_t)key[k];
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+        size_t at = (size_t)(h & mask);
+        while (slot[at] >= 0 && key[slot[at]] != key[k]) at = (at + 1) & mask;
+        if (slot[at] < 0) slot[at] = k;
+        first[k] = slot[at];
+    }
+    return IAMX_OK;
+}
+
+// The chains of iamx_link_matches, longest first, chains of equal length in their given order
+// (list.sort(key=len, reverse=True) of match_cleanup.py:291-292 is stable): a counting sort of
+// the chains by length, then the members copied chain by chain on `threads` threads.  out_ptr
+// [n_chains + 1]; out_img / out_kp sized like the input.
+extern "C" int iamx_chains_longest_first(const int32_t *img, const int32_t *kp, const int64_t *ptr,
+                                         int64_t n_chains, int32_t *out_img, int32_t *out_kp,
+                                         int64_t *out_ptr, int threads)
+{
+    if (n_chains < 0 || !ptr || !out_ptr || (n_chains > 0 && (!img || !kp || !out_img || !out_kp)))
+        return iamx::fail(IAMX_EINVAL, "iamx_chains_longest_first: null pointer or negative count");
+    int64_t longest = 0;
+    for (int64_t c = 0; c < n_chains; ++c) {
+        const int64_t len = ptr[c + 1] - ptr[c];
+        if (len < 0) return iamx::fail(IAMX_EINVAL, "iamx_chains_longest_first: offsets not monotone");
+        if (len > longest) longest = len;
+    }
+    // chains with length L start at rank[L] in the output order (longer lengths first)
+    std::vector<int64_t> rank((size_t)longest + 2, 0);
+    for (int64_t c = 0; c < n_chains; ++c) ++rank[(size_t)(ptr[c + 1] - ptr[c])];
+    int64_t at = 0;
+    for (int64_t len = longest; len >= 0; --len) {
+        const int64_t cnt = rank[(size_t)len];
+        rank[(size_t)len] = at;
+        at += cnt;
+    }
+    std::vector<int64_t> order((size_t)n_chains);
+    for (int64_t c = 0; c < n_chains; ++c) order[(size_t)rank[(size_t)(ptr[c + 1] - ptr[c])]++] = c;
+    out_ptr[0] = 0;
+    for (int64_t r = 0; r < n_chains; ++r) {
+        const int64_t c = order[(size_t)r];
+        out_ptr[r + 1] = out_ptr[r] + (ptr[c + 1] - ptr[c]);
+    }
+    const int64_t *ord = order.data();
+    run_threads(n_chains, threads, (int64_t)1 << 14, [=](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t c = ord[r], len = ptr[c + 1] - ptr[c], src = ptr[c], dst = out_ptr[r];
+            for (int64_t t = 0; t < len; ++t) {
+                out_img[dst + t] = img[src + t];
+                out_kp[dst + t] = kp[src + t];
+            }
+        }
+    });
+    return IAMX_OK;
+}
+

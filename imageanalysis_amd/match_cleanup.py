@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _deps
 from .matcher import _kp_xy, kp_key2
-from .matchpairs import MatchPairs
+from .matchpairs import MatchPairs, empty_huge
 
 CAM2BODY = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)     # lib/image.py:50-52
 
@@ -77,6 +77,22 @@ def compute_kp_usage(proj):
             proj.image_list[j].kp_used[p[:, 1]] = True
 
 
+def _first_occurrence(key):
+    """index of the first element equal to key[k], for every k (one hashing pass in libiamx; the
+    numpy form -- a stable argsort inside np.unique -- without the library)"""
+    import ctypes
+    from . import _lib
+    try:
+        first = np.empty(len(key), np.int64)
+        _lib.check(_lib.lib().iamx_first_occurrence(key.ctypes.data_as(ctypes.c_void_p), len(key),
+                                                    first.ctypes.data_as(ctypes.c_void_p)),
+                   'iamx_first_occurrence')
+        return first
+    except (OSError, _lib.IamxError):
+        _uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+        return first[inv]
+
+
 def merge_duplicates(proj):
     compute_kp_usage(proj)
     _log("Indexing features by unique uv coordinates:")
@@ -86,9 +102,8 @@ def merge_duplicates(proj):
         used = np.nonzero(im.kp_used)[0]
         if len(used):
             k2 = kp_key2(_kp_xy(im)[used]).astype(np.int64)
-            key = (k2[:, 0] << 32) | k2[:, 1]
-            _uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
-            remap[used] = used[first[inv]]    # first used keypoint (lowest index) with that pixel
+            key = np.ascontiguousarray((k2[:, 0] << 32) | k2[:, 1])
+            remap[used] = used[_first_occurrence(key)]   # first used keypoint (lowest index) with that pixel
         im.kp_remap_index = remap             # (the reference keeps a {"x-y": index} dict here)
         remaps.append(remap)
     _log("Merging keypoints with duplicate uv coordinates:")
@@ -353,16 +368,16 @@ def link_matches(proj, matches_direct):
     o_ptr = o_ptr[:n_chain + 1]
     total = int(o_ptr[-1])
     _log("Sorting matches by longest chain first.")
-    lens = np.diff(o_ptr)
-    # list.sort(key=len, reverse=True) is stable (16-bit keys: numpy's stable argsort is a radix
-    # sort for them)
-    order = np.argsort((-lens).astype(np.int16) if total and lens.max() < 32768 else -lens, kind='stable')
-    # the chains in that order, as arrays (Chains builds the reference's lists only on demand)
+    # list.sort(key=len, reverse=True) is stable: a counting sort of the chains by length and the
+    # members copied chain by chain, in libiamx (the numpy form -- argsort, repeat, two gathers
+    # over all members -- was a third of this function)
+    f_img, f_kp = empty_huge(total, np.int32), empty_huge(total, np.int32)
     new_ptr = np.zeros(n_chain + 1, np.int64)
-    np.cumsum(lens[order], out=new_ptr[1:])
-    take = (np.repeat(o_ptr[:-1][order] - new_ptr[:-1], lens[order]) + np.arange(total)) if total else \
-        np.zeros(0, np.int64)
-    f_img, f_kp = o_img[:total][take], o_kp[:total][take]
+    rc = lib().iamx_chains_longest_first(P(o_img), P(o_kp), P(o_ptr), n_chain, P(f_img), P(f_kp),
+                                         P(new_ptr), 4)
+    if rc != 0:
+        raise RuntimeError("iamx_chains_longest_first failed (%d): %s"
+                           % (rc, (lib().iamx_last_error() or b'?').decode()))
     # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt)): ONE
     # gather from the images' keypoint positions laid end to end, in the final order (a scatter
     # per image behind a sort of the members by image was 1 s of a 512-frame survey's 3.9 s)

@@ -312,6 +312,15 @@ int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, cons
 int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
                           int64_t n_matches, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                           int32_t *n_passes);
+/* HOST helpers of the same stage.  iamx_chains_longest_first: the chains of iamx_link_matches in
+ * the order match_cleanup.py:291-292 leaves them (stable sort by length, longest first), members
+ * copied on `threads` threads; out arrays sized like the input, out_ptr [n_chains + 1].
+ * iamx_first_occurrence: first[k] = smallest j with key[j] == key[k] (merge_duplicates,
+ * match_cleanup.py:19-104: keypoints of an image on the same pixel collapse onto the first). */
+int iamx_chains_longest_first(const int32_t *img, const int32_t *kp, const int64_t *ptr,
+                              int64_t n_chains, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
+                              int threads);
+int iamx_first_occurrence(const int64_t *key, int64_t n, int64_t *first);
 /* iamx_ledger_index -- HOST arrays.  matcher.find_matches (scripts/lib/matcher.py:978-979) gives
  * BOTH images of every processed pair a match_list entry, in processing order; for the pairs
  * without matches -- 95-99 % of an all-pairs schedule -- this package keeps index arrays (qi, qj,

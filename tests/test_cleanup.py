@@ -272,3 +272,41 @@ def test_yaw_error_estimate_equals_reference():
     a, b = proj.image_list[0], proj.image_list[1]
     a.match_list[b.name] = []
     assert smart.update_yaw_error_estimate(a, b) == 0
+
+
+def test_consolidation_host_helpers_equal_numpy():
+    """libiamx host helpers of the consolidation stage against the numpy expressions they
+    replace: first occurrence per key (merge_duplicates, match_cleanup.py:19-104) and the stable
+    longest-first order of the linked chains (match_cleanup.py:291-292)."""
+    import ctypes
+    from imageanalysis_amd import _lib
+    L = _lib.lib()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)          # noqa: E731
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 17, 40000):
+        key = np.ascontiguousarray(rng.integers(-50, 50 + n // 3, n) * 4294967297, np.int64)
+        first = np.full(n, -7, np.int64)
+        _lib.check(L.iamx_first_occurrence(P(key), n, P(first)), 'iamx_first_occurrence')
+        _u, idx, inv = np.unique(key, return_index=True, return_inverse=True)
+        assert np.array_equal(first, idx[inv] if n else first)
+    for n_chains in (0, 1, 5, 30000):
+        lens = rng.integers(2, 9, n_chains)
+        if n_chains > 10:
+            lens[rng.integers(0, n_chains, 5)] = 40                # a few long ones
+        ptr = np.zeros(n_chains + 1, np.int64)
+        np.cumsum(lens, out=ptr[1:])
+        total = int(ptr[-1])
+        img = rng.integers(0, 500, total).astype(np.int32)
+        kp = rng.integers(0, 40000, total).astype(np.int32)
+        o_img, o_kp = np.full(total, -1, np.int32), np.full(total, -1, np.int32)
+        o_ptr = np.full(n_chains + 1, -1, np.int64)
+        for threads in (1, 3):
+            _lib.check(L.iamx_chains_longest_first(P(img), P(kp), P(ptr), n_chains, P(o_img), P(o_kp),
+                                                   P(o_ptr), threads), 'iamx_chains_longest_first')
+            order = np.argsort(-lens, kind='stable')
+            want_ptr = np.zeros(n_chains + 1, np.int64)
+            np.cumsum(lens[order], out=want_ptr[1:])
+            take = np.concatenate([np.arange(ptr[c], ptr[c + 1]) for c in order]) if n_chains else \
+                np.zeros(0, np.int64)
+            assert np.array_equal(o_ptr, want_ptr)
+            assert np.array_equal(o_img, img[take]) and np.array_equal(o_kp, kp[take])

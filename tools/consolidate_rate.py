@@ -83,6 +83,8 @@ def main():
     proj, n_pairs, n_matches = build(rows, cols, per_frame, dup=dup)
     print('%d frames, %d pairs with matches, %d matches (built in %.1f s)'
           % (rows * cols, n_pairs, n_matches, time.time() - t0))
+    from imageanalysis_amd import _lib
+    _lib.lib()                          # (loading the library is not part of the stage)
     prof = cProfile.Profile() if '--profile' in sys.argv else None
     if prof:
         prof.enable()
