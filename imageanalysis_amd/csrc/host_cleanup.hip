@@ -143,8 +143,15 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     constexpr int64_t AHEAD = 48;                         // points of look-ahead for the prefetch
     int passes = 0;
     int64_t n_cur = n_matches;
+    // The reference repeats the pass until one changes nothing.  A pass can only join chains that
+    // SHARE a point, and a chain it builds shares a point with another one only when a join
+    // appends a point that is already registered to a different chain (every other point of a
+    // pass is registered once).  A pass that never did that leaves pairwise disjoint chains: the
+    // next one would copy them unchanged -- it is counted, not run.  (IAMX_LINK_VERIFY=1 runs it.)
+    const bool verify = getenv("IAMX_LINK_VERIFY") != nullptr;
     while (true) {
         ++passes;
+        bool shared = false;
         if (dense) std::memset(table.data(), 0xff, table_n * sizeof(int32_t));      // every entry -1
         else map.clear();
         n_chains = 0;
@@ -213,6 +220,8 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
             } else {                                        // join: only images new to the chain
                 for (int64_t j = b; j < e; ++j) {
                     if (!in_chain(index, c_img[j])) {
+                        const int32_t owner = lookup(c_img[j], c_kp[j]);
+                        if (owner >= 0 && owner != index) shared = true;
                         append(index, c_img[j], c_kp[j]);
                         store(c_img[j], c_kp[j], index);
                     }
@@ -234,6 +243,10 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         const bool done = n_new == n_cur;
         n_cur = n_new;
         if (done) break;
+        if (!shared && !verify) {
+            ++passes;                                       // the pass that would change nothing
+            break;
+        }
     }
     const int64_t total = c_ptr[(size_t)n_cur];
     std::memcpy(out_img, c_img.data(), (size_t)total * sizeof(int32_t));

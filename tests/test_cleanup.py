@@ -310,3 +310,50 @@ def test_consolidation_host_helpers_equal_numpy():
                 np.zeros(0, np.int64)
             assert np.array_equal(o_ptr, want_ptr)
             assert np.array_equal(o_img, img[take]) and np.array_equal(o_kp, kp[take])
+
+
+def test_link_matches_skips_only_the_pass_that_changes_nothing():
+    """iamx_link_matches stops after a pass that left pairwise disjoint chains instead of running
+    the reference's final no-change pass (match_cleanup.py:223-274 loops until the count stays):
+    same chains, same order, same reported pass count as with IAMX_LINK_VERIFY=1, on random
+    surveys whose pair matches need several passes."""
+    import ctypes
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys, numpy as np
+sys.path.insert(0, %r)
+from imageanalysis_amd import _lib
+L = _lib.lib()
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+out = []
+for seed in range(6):
+    rng = np.random.default_rng(seed)
+    n_img, n_kp, n = 12, 300, 4000 + 500 * seed
+    img = np.empty(2 * n, np.int32); kp = np.empty(2 * n, np.int32)
+    a = rng.integers(0, n_img, n); b = (a + 1 + rng.integers(0, n_img - 1, n)) %% n_img
+    img[0::2], img[1::2] = a, b
+    # keypoints tied to a small set of world points, with mismatches: chains that meet late
+    world = rng.integers(0, 500, n)
+    kp[0::2] = (world * 7 + a) %% n_kp
+    kp[1::2] = np.where(rng.random(n) < 0.9, (world * 7 + b) %% n_kp, rng.integers(0, n_kp, n))
+    ptr = np.arange(n + 1, dtype=np.int64) * 2
+    o_img, o_kp = np.empty_like(img), np.empty_like(kp)
+    o_ptr = np.zeros(n + 1, np.int64); passes = np.zeros(1, np.int32)
+    nc = int(L.iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr), P(passes)))
+    tot = int(o_ptr[nc])
+    out.append((nc, int(passes[0]), o_ptr[:nc + 1].tobytes(), o_img[:tot].tobytes(), o_kp[:tot].tobytes()))
+import pickle
+sys.stdout.buffer.write(pickle.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import pickle
+    runs = []
+    for verify in (False, True):
+        env = dict(os.environ)
+        env.pop('IAMX_LINK_VERIFY', None)
+        if verify:
+            env['IAMX_LINK_VERIFY'] = '1'
+        runs.append(pickle.loads(subprocess.run([sys.executable, '-c', code], env=env, check=True,
+                                                capture_output=True).stdout))
+    assert runs[0] == runs[1]
+    assert max(r[1] for r in runs[0]) >= 3                # several passes were needed somewhere
