@@ -2,6 +2,8 @@
 # Builds libiamx.so (gfx950 only) next to the python package.  Cross-compiles without a GPU.
 # IAMX_ABLATE=1 builds libiamx_ablate.so instead: the same library plus the iamxdbg_* timing
 # variants used by tools/*_ablate.py (never loaded by the product; select it with IAMX_LIB).
+# IAMX_REBUILD=1 ignores the object cache: every source is compiled (what __graft_entry__.build()
+# asks for, so that a build check proves the SOURCES build, not that stale objects link).
 set -e
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -18,7 +20,7 @@ mkdir -p "$OBJDIR"
 OBJS=""
 for f in $SRCS; do
     o="$OBJDIR/$(basename ${f%.hip}).o"
-    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/iamx_common.h" -nt "$o" ] || [ "$HERE/../../include/iamx.h" -nt "$o" ]; then
+    if [ -n "$IAMX_REBUILD" ] || [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/iamx_common.h" -nt "$o" ] || [ "$HERE/../../include/iamx.h" -nt "$o" ]; then
         EXTRA=""
         # the TRF helpers restate numpy expressions: separately rounded multiply and add
         [ "$(basename $f)" = "trf_vec.hip" ] && EXTRA="-ffp-contract=off"

@@ -255,8 +255,8 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     if (n_passes) *n_passes = passes;
     return n_cur;
     } catch (const std::bad_alloc &) {
-        iamx::fail(IAMX_EINVAL, "iamx_link_matches: out of memory");
-        return IAMX_EINVAL;
+        iamx::fail(IAMX_ENOMEM, "iamx_link_matches: out of memory");
+        return IAMX_ENOMEM;
     }
 }
 

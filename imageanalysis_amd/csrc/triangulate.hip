@@ -132,6 +132,7 @@ __device__ void null_vector_4x4(double A[4][4], double v_out[4])
     }
 }
 
+template <bool XYZ>
 __global__ __launch_bounds__(256) void triangulate_pairs_kernel(
     const int32_t *__restrict__ pair_img, const double *__restrict__ PROJ, const double *__restrict__ IK,
     const int64_t *__restrict__ kp_off, const float *__restrict__ xy,
@@ -160,7 +161,15 @@ __global__ __launch_bounds__(256) void triangulate_pairs_kernel(
     }
     double X[4];
     null_vector_4x4(A, X);
-    out_z[(int64_t)p * clip + k] = X[2] / X[3];
+    if (XYZ) {
+        // (points /= points[3] of smart.py:62: north, east, down)
+        double *o = out_z + ((int64_t)p * clip + k) * 3;
+        o[0] = X[0] / X[3];
+        o[1] = X[1] / X[3];
+        o[2] = X[2] / X[3];
+    } else {
+        out_z[(int64_t)p * clip + k] = X[2] / X[3];
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -274,8 +283,22 @@ extern "C" int iamx_triangulate_pairs(const int32_t *pair_img, const double *PRO
     IAMX_REQUIRE(pair_img && PROJ && IK && kp_off && xy && m_cnt && m_pairs && out_z, "null pointer");
     IAMX_REQUIRE(n_pairs >= 0 && clip > 0, "bad size");
     if (n_pairs == 0) return IAMX_OK;
-    hipLaunchKernelGGL(triangulate_pairs_kernel, dim3((unsigned)((clip + 255) / 256), (unsigned)n_pairs),
+    hipLaunchKernelGGL(triangulate_pairs_kernel<false>, dim3((unsigned)((clip + 255) / 256), (unsigned)n_pairs),
                        dim3(256), 0, iamx::as_stream(stream), pair_img, PROJ, IK, kp_off, xy, m_cnt,
                        m_pairs, clip, out_z);
     return iamx::check_launch("iamx_triangulate_pairs");
+}
+
+extern "C" int iamx_triangulate_pairs_xyz(const int32_t *pair_img, const double *PROJ, const double *IK,
+                                          const int64_t *kp_off, const float *xy, const int32_t *m_cnt,
+                                          const int32_t *m_pairs, int n_pairs, int clip,
+                                          double *out_xyz, void *stream)
+{
+    IAMX_REQUIRE(pair_img && PROJ && IK && kp_off && xy && m_cnt && m_pairs && out_xyz, "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && clip > 0, "bad size");
+    if (n_pairs == 0) return IAMX_OK;
+    hipLaunchKernelGGL(triangulate_pairs_kernel<true>, dim3((unsigned)((clip + 255) / 256), (unsigned)n_pairs),
+                       dim3(256), 0, iamx::as_stream(stream), pair_img, PROJ, IK, kp_off, xy, m_cnt,
+                       m_pairs, clip, out_xyz);
+    return iamx::check_launch("iamx_triangulate_pairs_xyz");
 }

@@ -25,6 +25,15 @@ def _log(*a):
     _deps.logger().log(*a)
 
 
+def my_add(placed_matches, matches, group_level, i):
+    """groups.py:18-22, kept for callers that drive the grouping by hand: chain i joins
+    `group_level`, and every image it is seen in has one more placed feature.  (compute() does
+    this for whole sweeps inside iamx_group_level.)"""
+    for obs in matches[i][2:]:
+        placed_matches[obs[0]] += 1
+    matches[i][1] = group_level
+
+
 def compute(image_list, matches):
     """notice: matches are assumed sorted longest chain first (link_matches does that)."""
     from ._lib import c_void_p, lib

@@ -383,9 +383,12 @@ class PairWorkspace(object):
         self.surv_q = torch.empty(r, dtype=I32, device=dev)
         self.surv_t = torch.empty(r, dtype=I32, device=dev)
         self.surv_metric = torch.empty(r, dtype=F64, device=dev)
-        self.zero_div = torch.zeros(1, dtype=I32, device=dev)
+        # [0] a zero second distance was met (ZeroDivisionError of matcher.py:255), [1] rows the
+        # bound form could not resolve exactly (must stay 0: find_matches refuses the batch)
+        self.flags = torch.zeros(2, dtype=I32, device=dev)
+        self.zero_div = self.flags[0:1]
         self.tile = torch.empty(r, dtype=I32, device=dev)
-        self.unresolved = torch.zeros(1, dtype=I32, device=dev)
+        self.unresolved = self.flags[1:2]
         self.surv_cnt = torch.zeros(p, dtype=I32, device=dev)
         # symmetric sweep: bounds per row (allocated on first use, grown when a batch needs more)
         self.col = self.rowp = None

@@ -388,7 +388,21 @@ def link_matches(proj, matches_direct):
     first = np.zeros(len(xy_of) + 1, np.int64)
     np.cumsum([len(x) for x in xy_of], out=first[1:])
     xy_all = np.concatenate(xy_of) if xy_of else np.zeros((0, 2), np.float32)
-    uv = xy_all[first[f_img] + f_kp].astype(np.float64) if total else np.zeros((0, 2), np.float64)
+    if total:
+        # (the reference's kp_list[m[1]] raises IndexError for a keypoint index its image does not
+        #  have -- a .match file that is stale against its .feat; the flat gather would read a
+        #  NEIGHBOURING image's keypoint instead.  Negative indices wrap inside the image, as there.)
+        n_kp = np.diff(first)[f_img]
+        kp = np.where(f_kp < 0, f_kp + n_kp, f_kp)
+        bad = (kp < 0) | (kp >= n_kp)
+        if bad.any():
+            k = int(np.nonzero(bad)[0][0])
+            raise IndexError("list index out of range: keypoint %d of %s (%d keypoints); is its "
+                             ".match file stale against the .feat?"
+                             % (int(f_kp[k]), proj.image_list[int(f_img[k])].name, int(n_kp[k])))
+        uv = xy_all[first[f_img] + kp].astype(np.float64)
+    else:
+        uv = np.zeros((0, 2), np.float64)
     out = Chains(f_img, uv, new_ptr)
     if n_chain:
         _log("Total unique features in image set:", n_chain)
@@ -417,10 +431,8 @@ def _base_elevations(proj):
             b = image_node.getFloat("tri_surface_m")
         else:
             if srtm is None:
-                import importlib
-                try:
-                    srtm = importlib.import_module('lib.srtm')
-                except Exception:
+                srtm = _deps.srtm()
+                if srtm is None:
                     raise RuntimeError("no /smart/%s/tri_surface_m estimate and no lib.srtm to "
                                        "look the ground elevation up" % image.name)
             b = srtm.ned_interp([ned[0], ned[1]])[0]

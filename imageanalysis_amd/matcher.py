@@ -69,11 +69,23 @@ def _workspace_bytes_per_pair(rows):
     return ((rows + wg_rows - 1) // wg_rows) * cap * 16 + 2 * rows * 48 + 96 * 1024
 
 
+def _batch_bytes():
+    """BATCH_BYTES on the 288 GB part it was chosen for; on a device with less free memory a
+    twelfth of what is free (three workspaces are pooled, and the descriptor / keypoint arenas,
+    result sets and the caller's own tensors need the rest), never below 256 MB"""
+    try:
+        import torch
+        free, _total = torch.cuda.mem_get_info()
+    except Exception:                     # noqa: BLE001  (no device yet: the 288 GB figure)
+        return BATCH_BYTES
+    return int(max(256 << 20, min(BATCH_BYTES, free // 12)))
+
+
 def _pairs_per_batch(rows):
     """largest power of two <= PAIRS_PER_BATCH (at least 16) whose batch fits BATCH_BYTES"""
     if PAIRS_PER_BATCH < 16:
         return PAIRS_PER_BATCH
-    n = max(16, min(PAIRS_PER_BATCH, BATCH_BYTES // _workspace_bytes_per_pair(rows)))
+    n = max(16, min(PAIRS_PER_BATCH, _batch_bytes() // _workspace_bytes_per_pair(rows)))
     p = 16
     while p * 2 <= n:
         p *= 2
@@ -504,19 +516,35 @@ def _work_list(proj, sort):
 # --------------------------------------------------------------------------------------
 # the batched pair loop -- matcher.py:918-1031
 # --------------------------------------------------------------------------------------
+FREEZE_MIN_OBJECTS = 2_000_000     # tracked objects a find_matches call must leave before gc.freeze()
+
+
+def _tracked_objects():
+    # (with the collector disabled the young generation's counter just accumulates: container
+    #  allocations minus deallocations since the last collection, O(1) to read)
+    return gc.get_count()[0]
+
+
 @contextlib.contextmanager
 def _no_gc():
     """find_matches keeps tens of millions of 2-element lists alive (the match_list contract);
     every generation-2 pass of the cyclic collector would walk all of them again"""
     was = gc.isenabled()
     gc.disable()
+    before = _tracked_objects() if was else 0
     try:
         yield
     finally:
         if was:
-            # (the lists made inside are acyclic and stay: out of the collector's generations, or
-            #  the first allocation after enable() pays a full pass over all of them, ~0.3 s)
-            gc.freeze()
+            # The lists made inside are acyclic and stay: out of the collector's generations, or
+            # the first allocation after enable() pays a full pass over all of them (~0.3 s).
+            # freeze() also pins whatever garbage CYCLES exist at that moment -- exception
+            # tracebacks, objects holding device or page-locked buffers -- for the life of the
+            # process, so: only a call that left a survey's worth of objects freezes (a small
+            # call's walk is cheap anyway), and the young generations are collected first.
+            if hasattr(gc, 'freeze') and _tracked_objects() - before > FREEZE_MIN_OBJECTS:
+                gc.collect(1)
+                gc.freeze()
             gc.enable()
 
 
@@ -657,7 +685,7 @@ def _host_set(n, clip, surface):
     if free:
         return free.pop()
     pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
-    hs = dict(key=(n, clip, surface), zero_div=pin(1, torch.int32),
+    hs = dict(key=(n, clip, surface), zero_div=pin(2, torch.int32),
               count=pin(2 * n, torch.int32))
     if clip:
         # the matches of the pairs that have some, packed back to back by the device
@@ -772,7 +800,7 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     ws = _workspace(pb.rows, pb.n_pairs)
     # (the kernels only ever RAISE this flag: a pooled workspace that reported a zero distance --
     #  the ZeroDivisionError of matcher.py:255 -- would fail every later batch that draws it)
-    ws.zero_div.zero_()
+    ws.flags.zero_()
     if device_filters:
         kp_off, xy, key2 = dm.keypoints()        # (may upload: before the kernels, like PROJ)
     thresh = max_distance * match_ratio
@@ -788,9 +816,15 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
     swept.record(main)
     side.wait_event(swept)
     with torch.cuda.stream(side):
-        return _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d_ik,
-                                  kp_off if device_filters else None, xy if device_filters else None,
-                                  key2 if device_filters else None)
+        h = _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d_ik,
+                               kp_off if device_filters else None, xy if device_filters else None,
+                               key2 if device_filters else None)
+    # (the side stream reads these tables; the caching allocator knows them by the stream they were
+    #  made on, so a table that outgrew the upload arena's slot -- a fresh main-stream tensor --
+    #  must stay referenced until the host has seen the batch's `done` event)
+    h['tables'] = (d_proj, d_ik, kp_off if device_filters else None,
+                   xy if device_filters else None, key2 if device_filters else None)
+    return h
 
 
 _side = {}
@@ -839,7 +873,7 @@ def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d
                                           _ptr(post['aff']), _ptr(post['aff_ok']), stream_ptr()),
                   'iamx_similarity_pairs')
     hs = _host_set(n, clip, surface and post is not None)
-    hs['zero_div'].copy_(ws.zero_div, non_blocking=True)
+    hs['zero_div'].copy_(ws.flags, non_blocking=True)
     hs['count'].copy_(ws.surv_cnt[:2 * n], non_blocking=True)
     if post is not None:
         hs['cnt'].copy_(post['cnt'], non_blocking=True)
@@ -869,6 +903,11 @@ def _finish_batch(h):
     try:
         if int(hs['zero_div'][0]):
             raise ZeroDivisionError("float division by zero")       # matcher.py:255
+        if int(hs['zero_div'][1]):
+            # (never seen: the bound forms' exact stage covers every candidate row by
+            #  construction; a .match file written past this would be silently wrong)
+            raise RuntimeError("libiamx: %d query rows left unresolved by the exact stage"
+                               % int(hs['zero_div'][1]))
         count = hs['count'].numpy().astype(np.int64)
         first = sq = st = sm = status = cnt = lists = None
         z_rows = {}
@@ -985,6 +1024,11 @@ def _finish_batch_arrays(h):
     try:
         if int(hs['zero_div'][0]):
             raise ZeroDivisionError("float division by zero")       # matcher.py:255
+        if int(hs['zero_div'][1]):
+            # (never seen: the bound forms' exact stage covers every candidate row by
+            #  construction; a .match file written past this would be silently wrong)
+            raise RuntimeError("libiamx: %d query rows left unresolved by the exact stage"
+                               % int(hs['zero_div'][1]))
         count = hs['count'].numpy()
         R.n_fwd, R.n_rev = count[:n].astype(np.int64), count[n:2 * n].astype(np.int64)
         if post is None:
@@ -1405,7 +1449,11 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             try:
                 _prewarm_pools(n_, rows_, bool(batched_surface), dev_, stream_)
             except Exception:             # noqa: BLE001  (best effort: a round allocates what it misses)
-                pass
+                # (out of memory half way: give back what the pools hold so that the first real
+                #  round starts from a clean allocator instead of failing where this did)
+                _ws_pool.clear()
+                _post_pool.clear()
+                _torch.cuda.empty_cache()
         warm = threading.Thread(target=_warm, name='iamx-prewarm')
         warm.start()
 
@@ -1781,13 +1829,22 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         early_smart_stats['current_at_end'] += bool(smart_current)
         if smart is not None and not smart_current:
             import threading
-            saver = threading.Thread(target=smart.save, args=(proj.analysis_dir,), name='iamx-smart-save')
+            saver_error = []
+
+            def _save_smart():
+                try:
+                    smart.save(proj.analysis_dir)
+                except BaseException as exc:       # re-raised below, where the reference's call sits
+                    saver_error.append(exc)
+            saver = threading.Thread(target=_save_smart, name='iamx-smart-save')
             saver.start()
         try:
             saveMatches(proj.image_list)
         finally:
             if saver is not None:
                 saver.join()
+        if saver is not None and saver_error:
+            raise saver_error[0]
     pickler.shutdown(wait=True)
     print('Pair-wise matches successfully saved.')
 

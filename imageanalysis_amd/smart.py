@@ -1,6 +1,8 @@
-"""MI355X-path stand-in for the deterministic half of the reference's scripts/lib/smart.py:
-the per-pair ground-surface estimate find_matches() keeps while it runs (lib/matcher.py:987-1005)
-and its discard policy depends on.
+"""MI355X-path replacement of the reference's scripts/lib/smart.py -- the whole module surface
+(`from imageanalysis_amd.smart import *` is the shim file): the per-pair
+ground-surface and yaw-error estimates find_matches() keeps while it runs
+(lib/matcher.py:987-1005) and its discard policy depends on, and what process.py asks of the
+module around it.
 
     triangulate_features(i1, i2)        smart.py:26-63    two-view DLT of the pair's matches
     estimate_surface_elevation(i1, i2)  smart.py:117-130  -mean / std of the "down" coordinate
@@ -10,6 +12,9 @@ and its discard policy depends on.
     find_affine / decompose_affine      smart.py:66-115   similarity between a pair's keypoints
     estimate_yaw_error(i1, i2)          smart.py:138-192  yaw error from that matrix + poses
     update_yaw_error_estimate(i1, i2)   smart.py:251-283  /smart/<image>/yaw_pairs/... + average
+    get_yaw_error_estimate(i1)          smart.py:285-290
+    update_srtm_elevations(proj)        smart.py:319-324  process.py:220 (delegates to lib.srtm)
+    set_yaw_error_estimates(proj)       smart.py:326-331  process.py:240
 
 The triangulation and the similarity fit run on the GPU (csrc/triangulate.hip:
 iamx_triangulate_pairs, iamx_similarity_pairs; find_matches does a whole batch of pairs in one
@@ -17,8 +22,10 @@ launch each and hands the results to record_surface_estimate / record_yaw_error_
 The reference obtains the matrix from cv2.estimateAffinePartial2D (RANSAC); here it is a
 deterministic robust fit (least squares, then re-fits on the matches within 200, 50, 10, 3, ...
 px), so yaw estimates agree with the reference's to the extent the two fits do (both see
-GMS-filtered, cross-checked matches).  Inside the reference environment lib.smart itself is
-used (_deps.smart())."""
+GMS-filtered, cross-checked matches).  Inside the reference environment this module works on the
+reference's own /smart tree (props.getNode) and smart.json goes through props_json, so the rest
+of process.py shares its state; lib.srtm (tile download + interpolation, out of scope here) is
+used where the reference uses it."""
 import json
 import os
 
@@ -65,10 +72,35 @@ def triangulate_down(i1, i2, pairs):
 
 
 def triangulate_features(i1, i2):
-    """only the row the callers use is produced: a [1, N] array of "down" coordinates is NOT
-    the reference's 4xN; use estimate_surface_elevation()."""
-    raise NotImplementedError("use estimate_surface_elevation(); the device kernel returns the "
-                              "down coordinate only")
+    """smart.py:26-63: the [4, N] homogeneous NED points of the pair's matches after
+    `points /= points[3]` (rows north, east, down, 1), None where the reference returns None.
+    (iamx_triangulate_pairs_xyz; find_matches itself uses the batched down-only form.)"""
+    import torch
+    from . import kernels
+    from .kernels import _ptr, check, lib, stream_ptr
+    from .matcher import _kp_xy
+    if i1 == i2 or i2.name not in i1.match_list or len(i1.match_list[i2.name]) == 0:
+        return None
+    if not i1.kp_list or not len(i1.kp_list):
+        i1.load_features()
+    if not i2.kp_list or not len(i2.kp_list):
+        i2.load_features()
+    dev = kernels.require_gpu()
+    pairs = np.asarray(i1.match_list[i2.name], np.int32).reshape(-1, 2)
+    n = len(pairs)
+    xy1, xy2 = _kp_xy(i1), _kp_xy(i2)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+    PROJ = np.stack([projection_matrix(i1).ravel(), projection_matrix(i2).ravel()])
+    IK = np.linalg.inv(_deps.camera().get_K())
+    out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    args = (t(np.array([[0, 1]]), torch.int32), t(PROJ, torch.float64), t(IK.ravel(), torch.float64),
+            t(np.array([0, len(xy1)]), torch.int64), t(np.concatenate([xy1, xy2]), torch.float32),
+            t(np.array([n]), torch.int32), t(pairs, torch.int32))
+    check(lib().iamx_triangulate_pairs_xyz(*[_ptr(a) for a in args], 1, n, _ptr(out), stream_ptr()),
+          'iamx_triangulate_pairs_xyz')
+    points = np.ones((4, n))
+    points[:3] = out.cpu().numpy().T
+    return points
 
 
 _frozen = None          # id(image) -> (ned array, aircraft yaw) while find_matches runs
@@ -515,6 +547,37 @@ def get_surface_estimate(i1, i2):
     if vals:
         return sum(vals) / len(vals)
     return (i1_node.getFloat("srtm_surface_m") + i2_node.getFloat("srtm_surface_m")) * 0.5
+
+
+# ---- what process.py asks of the module around find_matches (smart.py:319-331) ----------------
+def update_srtm_elevations(proj, ned_interp=None):
+    """smart.py:319-324 (process.py:220): /smart/<image>/srtm_surface_m = the SRTM ground under
+    every camera, to 0.1 m.  The lookup is lib.srtm's (tile download + interpolation, out of
+    scope here), which process.py:218 initialises itself; `ned_interp` replaces it for callers
+    without the reference tree."""
+    if ned_interp is None:
+        srtm = _deps.srtm()
+        if srtm is None:
+            raise RuntimeError("update_srtm_elevations: lib.srtm is not importable (it is the "
+                               "reference's SRTM tile reader); pass ned_interp=")
+        ned_interp = srtm.ned_interp
+    for image in proj.image_list:
+        ned, _ypr, _quat = image.get_camera_pose()
+        surface = np.asarray(ned_interp([ned[0], ned[1]]), float).ravel()[0]
+        image_node = smart_node.getChild(image.name, True)
+        image_node.setFloat("srtm_surface_m", float("%.1f" % surface))
+
+
+def set_yaw_error_estimates(proj):
+    """smart.py:326-331 (process.py:240), as written there: the value is read from the image's
+    `yaw_pairs` node -- the per-partner table, where a key "yaw_error" only exists for an image of
+    that name -- not from /smart/<image>/yaw_error where update_yaw_error_estimate() puts the
+    average; so the reference applies 0.0 to every image, and so does this."""
+    for image in proj.image_list:
+        image_node = smart_node.getChild(image.name, True)
+        yaw_node = image_node.getChild("yaw_pairs", True)
+        yaw_error_deg = yaw_node.getFloat("yaw_error")
+        image.set_aircraft_yaw_error_estimate(yaw_error_deg)
 
 
 # ---- smart.json (props_json inside the reference environment, plain json here) ----------------

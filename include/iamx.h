@@ -26,6 +26,7 @@ extern "C" {
 #define IAMX_ELAUNCH      -2   /* HIP reported a launch / runtime error                 */
 #define IAMX_ENODEVICE    -3   /* no gfx950 device visible                              */
 #define IAMX_EUNSUPPORTED -4   /* valid input of a kind this path does not handle       */
+#define IAMX_ENOMEM       -5   /* a host routine could not allocate its work arrays     */
 
 #define IAMX_DESC_DIM      128 /* SIFT descriptor length (scripts/lib/image.py:324)      */
 #define IAMX_ROW_PAD       128 /* packed images are padded to a multiple of this many rows */
@@ -369,6 +370,14 @@ int iamx_triangulate_pairs(const int32_t *pair_img, const double *PROJ, const do
                            const int64_t *kp_off, const float *xy, const int32_t *m_cnt,
                            const int32_t *m_pairs, int n_pairs, int clip, double *out_z,
                            void *stream);
+
+/* iamx_triangulate_pairs_xyz -- the same triangulation with all three w-normalised NED components,
+ * what `points /= points[3]` leaves in rows 0..2 of triangulate_features()'s 4xN return value
+ * (scripts/lib/smart.py:61-63); out_xyz DEV [n_pairs][clip][3] */
+int iamx_triangulate_pairs_xyz(const int32_t *pair_img, const double *PROJ, const double *IK,
+                               const int64_t *kp_off, const float *xy, const int32_t *m_cnt,
+                               const int32_t *m_pairs, int n_pairs, int clip, double *out_xyz,
+                               void *stream);
 
 /* iamx_similarity_pairs -- scripts/lib/smart.py:66-89 find_affine(): the 2x3 similarity
  * (rotation, uniform scale, translation) between the matched keypoints of every pair of a batch,

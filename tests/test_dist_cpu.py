@@ -14,6 +14,21 @@ import torch.multiprocessing as mp
 from conftest import REPO
 
 
+@pytest.fixture(autouse=True)
+def _restore_matcher_injections():
+    """the helpers below replace the device halves of find_matches (and _deps.smart) by assignment
+    -- they also run in spawned workers, where monkeypatch is not at hand; the world-1 runs happen
+    in THIS process, so what they replaced is put back for the tests that follow"""
+    from imageanalysis_amd import _deps, matcher
+    names = ('_launch_batch', '_finish_batch', 'the_matcher', 'PAIRS_PER_BATCH', 'max_distance', 'min_pairs')
+    saved = {n: getattr(matcher, n) for n in names}
+    smart = _deps.smart
+    yield
+    for n, v in saved.items():
+        setattr(matcher, n, v)
+    _deps.smart = smart
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
