@@ -36,6 +36,7 @@ I8_UBENCH_TOPS = 3944.0                          # the guide's measured i8 MFMA 
 KNN2SYM_TRAFFIC_FILE = 'r4_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
 CONFIG1_IMAGES = 500                             # configs[1]: C(500, 2) = 124 750 pairs
 CONFIG2_IMAGES = 2812                            # configs[2]: 3 952 266 pairs
+E2E_FRAMES = 128                                 # configs[4] slice of the default run (rendered 20 MP frames)
 MATCH_RATIO = 0.75
 MAX_DISTANCE = 270.0
 
@@ -386,7 +387,9 @@ def main():
     e2e = e2e_small = e2e_big = None
     if rank == 0 and world == 1:
         if not args.no_e2e:
-            e2e = e2e_bench(24, full_frame=True)
+            # 128 rendered 20 MP frames (13 s of untimed rendering), the distance-window schedule
+            # of a real survey; `--e2e-full N` runs the same at N >= 512
+            e2e = e2e_bench(E2E_FRAMES, full_frame=True, schedule='distance')
         if args.e2e_full > 0:
             e2e_big = e2e_bench(args.e2e_full, full_frame=True, schedule='distance')
         if args.e2e > 0:
@@ -434,16 +437,31 @@ def main():
         out["e2e"] = e2e
         if e2e_big is not None:
             out["e2e_full"] = e2e_big
-        else:
-            # the configs[4] run at >= 512 frames is minutes of rendering: its tracked record
-            # (bench.py --e2e-full 512 on MI355X) is quoted instead of re-run by default
-            rec = os.path.join(REPO, 'profiles', 'r4_e2e_full_512.json')
-            if os.path.exists(rec):
-                with open(rec) as fp:
-                    out["e2e_full_recorded"] = dict(json.load(fp), source='profiles/r4_e2e_full_512.json '
-                                                    '(python bench.py --e2e-full 512, not re-run here)')
         if e2e_small is not None:
             out["e2e_quarter_frames"] = e2e_small
+        # LAST key, short: the driver keeps the tail of this line -- every headline figure of the
+        # sections above in one place (same numbers, nothing new)
+        g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+        out["summary"] = {
+            "match_pairs_per_sec": out["value"], "match_frac_i8_peak": g(roofline, "frac"),
+            "mfma_busy": g(roofline, "mfma_busy"), "match_traffic_bytes": g(roofline, "traffic"),
+            "survey_2812_pairs_per_sec": g(survey, "value"), "survey_2812_seconds": g(survey, "seconds_per_step"),
+            "dense_overlap_pairs_per_sec": g(dense, "pairs_per_sec"),
+            "ba_seconds_to_ftol": g(ba, "seconds_to_ftol"), "ba_trf_it_per_sec": g(ba, "value"),
+            "ba_residual_frac_cache": g(ba, "residual", "frac"),
+            "ba_residual_frac_out_of_cache": g(ba, "residual", "out_of_cache", "frac"),
+            "ba_jac_frac_cache": g(ba, "residual_jac", "frac"),
+            "ba_jac_frac_out_of_cache": g(ba, "residual_jac", "out_of_cache", "frac"),
+            "ba_schur_iteration_frac": g(ba, "schur_iteration", "frac"),
+            "sift_frames_per_sec": g(sift, "value"), "sift_frac_hbm": g(sift, "roofline", "frac"),
+            "sift_traffic_bytes": g(sift, "roofline", "traffic"),
+            "sift_ms_per_detect_on_stream": g(sift, "ms_per_image_detector_kernels"),
+            "e2e_stage_seconds": g(e2e, "stage_seconds"),
+            "e2e_images": g(e2e, "images"), "e2e_images_per_sec": g(e2e, "images_per_sec_end_to_end"),
+            "e2e_total_seconds": g(e2e, "total_seconds"), "e2e_peak_hbm_bytes": g(e2e, "peak_hbm_bytes"),
+            "e2e_mre_px": g(e2e, "ba", "mean_abs_residual_px_after"),
+            "cpu_baseline_pairs_per_sec": g(cpu, "value"), "cpu_cores": g(cpu, "cores"),
+        }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -628,6 +646,11 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
             matcher.matcher_node.setString('schedule', schedule)
         out["schedule"] = schedule or 'neighbours'
         torch.cuda.reset_peak_memory_stats()
+        # (at >= 1024 frames the float32 des_list of the reference's contract is tens of GB of
+        #  host memory: image.DES_LIST_U8 keeps the same values as uint8; cache files unchanged)
+        des_u8_was = iimg.DES_LIST_U8
+        iimg.DES_LIST_U8 = n_images >= 1024
+        out["des_list_dtype"] = 'uint8' if iimg.DES_LIST_U8 else 'float32'
         node = getNode('/config/camera', True)
         node.__dict__.pop('K_opt', None)
         node.__dict__.pop('dist_coeffs_opt', None)
@@ -690,6 +713,10 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
                                                     transform='homography', sort=True))
         out["image_pairs_matched"] = sum(len(im.match_list) for im in proj.image_list) // 2
+        out["hbm_after_match"] = dict(matcher.device_memory_report(),
+                                      allocated_bytes=int(torch.cuda.memory_allocated()),
+                                      peak_allocated_bytes=int(torch.cuda.max_memory_allocated()))
+        out["hbm_model"] = matcher.device_memory_model(len(names), out["keypoints_per_image"])
         out["image_pairs_with_matches"] = sum(len(v) > 0 for im in proj.image_list
                                               for v in im.match_list.values()) // 2
 
@@ -724,6 +751,8 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         gauge = float((db_est * db_tru).sum() / (db_tru * db_tru).sum())
         out["groups"] = [len(g) for g in group_list]
         out["peak_hbm_bytes"] = int(torch.cuda.max_memory_allocated())
+        import resource
+        out["host_peak_rss_bytes"] = int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss) * 1024
         out["baseline_scale"] = round(gauge, 5)
         out["max_baseline_error_m"] = round(float(np.abs(db_est - gauge * db_tru).max()), 4)
         total = sum(stages.values())
@@ -741,6 +770,10 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
                                "the FC6310S field of view at a quarter of its pixels", scale)})
     finally:
         matcher.matcher_node.__dict__.pop('schedule', None)
+        try:
+            iimg.DES_LIST_U8 = des_u8_was
+        except NameError:
+            pass
         shutil.rmtree(tmp, ignore_errors=True)
     return out
 
@@ -1077,6 +1110,32 @@ def ba_bench(rank, world, dev, dist, args):
     t_res = timed(f_res, 100)
     t_jac = timed(f_jac, 50)
     o_local = prob.O
+    # The same two kernels on a working set that cannot sit in the 256 MiB Infinity Cache: six
+    # copies of the problem (6 x 125 MB for the residual, 6 x 439 MB with the Jacobian blocks) in
+    # rotation, so that every launch finds its inputs evicted by the five launches before it.
+    # (`timed` above re-launches ONE problem back to back: its 125 MB come out of the cache.)
+    t_res_cold = t_jac_cold = None
+    n_rot = 6
+    if world == 1:
+        rot = [prob]
+        for _ in range(n_rot - 1):
+            q = ba_solver.DeviceBA(C, P, p['cam_idx'], p['pt_idx'], p['uv'], False, fixed_calib=calib,
+                                   rank=rank, world=world)
+            q.set_x(x0)
+            rot.append(q)
+        launch = [q.bound_launchers() for q in rot]
+
+        def rot_res():
+            for fr, _fj in launch:
+                fr()
+
+        def rot_jac():
+            for _fr, fj in launch:
+                fj()
+        t_res_cold = timed(rot_res, 20) / n_rot
+        t_jac_cold = timed(rot_jac, 10) / n_rot
+        del launch, rot
+        torch.cuda.empty_cache()
     # untimed warm-up solve (workspace and allocator blocks of every branch of the step selection,
     # code-object load), like --warmup for matching; the collector has the matching section's heap
     # behind it before the clock starts
@@ -1188,7 +1247,19 @@ def ba_bench(rank, world, dev, dist, args):
                               "durations: profiles/r4_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
                               % its)
     cpu = None                                              # filled in by main() at the end
+    def cold(t, bytes_per_obs):
+        if t is None:
+            return None
+        bw = bytes_per_obs * o_local / t / 1e9
+        return {"achieved": round(bw, 1), "frac": round(bw / HBM, 4),
+                "frac_of_achievable_6300": round(bw / 6300.0, 4), "us_per_launch": round(t * 1e6, 2),
+                "working_set": "%d problem copies in rotation (%.0f MB > the 256 MiB Infinity Cache)"
+                               % (n_rot, n_rot * bytes_per_obs * o_local / 1e6),
+                "timing": "hipEvents around %d rotations" % (20 if bytes_per_obs == 64 else 10)}
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
+            # time to the reference's stopping rule (ftol = 1e-4) is the figure that compares with
+            # another inner solver: the Schur path takes more, cheaper outer iterations than LSMR
+            "seconds_to_ftol": round(dt, 4),
             "iterations": int(res.iterations), "njev": int(res.njev), "nfev": int(res.nfev),
             "status": int(res.status),
             "inner_solver": "Schur complement + block-Jacobi CG (iamx_ba_accumulate, iamx_ba_schur_*), "
@@ -1206,6 +1277,7 @@ def ba_bench(rank, world, dev, dist, args):
                          # 256 MB Infinity Cache (a plain copy of that size runs at 6.9 TB/s,
                          # tools/hbm_copy_bw.py), so this is a cache-level, not an HBM, fraction
                          "working_set": "Infinity-Cache resident (125 MB per evaluation)",
+                         "out_of_cache": cold(t_res_cold, 64.0),
                          "traffic": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[0],
                          "traffic_source": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[1],
                          "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
@@ -1215,6 +1287,7 @@ def ba_bench(rank, world, dev, dist, args):
                              "peak": HBM, "unit": "GB/s",
                              "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
                              "bytes_per_obs": 224,
+                             "out_of_cache": cold(t_jac_cold, 224.0),
                              "traffic": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[0],
                              "traffic_source": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[1],
                              "timing": "hipEvents around 50 launches (ba_residual_jac_kernel: "

@@ -31,6 +31,7 @@
 // (~469 B per detect-resolution pixel).
 #include "iamx_common.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 
@@ -1327,6 +1328,43 @@ SideStream *side_stream()
 }
 }  // namespace
 
+// Everything of a detection behind the first kernel (which reads the caller's image), enqueued on
+// `st` and, for the small octaves, on this thread's side stream -- ~65 launches for a 3 MP frame.
+static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float edge_threshold,
+                                float sigma, char *ws, float *kp, uint8_t *desc, int cap,
+                                int32_t *n_out, hipStream_t st);
+
+// The launch sequence of a frame size never changes (grids are sized by capacity, counts live
+// on the device) and every pointer in it belongs to the caller's per-detector workspace / output
+// buffers, so it is CAPTURED ONCE into a HIP graph per (frame size, parameters, buffers) and
+// replayed: one submission instead of ~65, no per-launch host cost between dependent kernels.
+// The first kernel (gray_up2x: the only reader of the image, whose address changes from frame to
+// frame) stays a plain launch in front of the graph.  IAMX_SIFT_NO_GRAPH=1: plain launches.
+namespace {
+struct GraphKey {
+    int height, width, cap, xcd;
+    float ct, et, sigma;
+    void *ws, *kp, *desc, *n_out;
+    int device;
+};
+struct GraphSlot {
+    GraphKey key;
+    hipGraphExec_t exec;
+    uint64_t stamp;
+    bool used;
+};
+constexpr int GRAPH_SLOTS = 12;
+
+inline bool graph_enabled()
+{
+    static const bool on = []() {
+        const char *e = getenv("IAMX_SIFT_NO_GRAPH");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+}  // namespace
+
 extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int channels,
                                 float contrast_threshold, float edge_threshold, float sigma,
                                 void *workspace, int64_t workspace_bytes, float *kp, uint8_t *desc,
@@ -1339,6 +1377,68 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     IAMX_REQUIRE(workspace_bytes >= L.total, "workspace too small (iamx_sift_workspace_bytes)");
     hipStream_t st = iamx::as_stream(stream);
     char *ws = static_cast<char *>(workspace);
+    // base image, part 1: gray -> x2 (reads the caller's image: outside the graph)
+    hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)L.h[0] * L.w[0], 256)), dim3(256), 0, st,
+                       image, height, width, channels, reinterpret_cast<float *>(ws + L.up_off));
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    if (!graph_enabled() || hipStreamIsCapturing(st, &cap_status) != hipSuccess ||
+        cap_status != hipStreamCaptureStatusNone)
+        return sift_enqueue_pyramid(L, contrast_threshold, edge_threshold, sigma, ws, kp, desc, cap,
+                                    n_out, st);
+    static thread_local GraphSlot slots[GRAPH_SLOTS];
+    static thread_local uint64_t clock_ = 0;
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.height = height; key.width = width; key.cap = cap; key.xcd = xcd_enabled();
+    key.ct = contrast_threshold; key.et = edge_threshold; key.sigma = sigma;
+    key.ws = workspace; key.kp = kp; key.desc = desc; key.n_out = n_out;
+    (void)hipGetDevice(&key.device);
+    GraphSlot *hit = nullptr, *victim = &slots[0];
+    for (GraphSlot &g : slots) {
+        if (g.used && memcmp(&g.key, &key, sizeof(key)) == 0) { hit = &g; break; }
+        if (!g.used || (victim->used && g.stamp < victim->stamp)) victim = &g;
+    }
+    if (!hit) {
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return sift_enqueue_pyramid(L, contrast_threshold, edge_threshold, sigma, ws, kp, desc,
+                                        cap, n_out, st);
+        }
+        const int rc = sift_enqueue_pyramid(L, contrast_threshold, edge_threshold, sigma, ws, kp, desc,
+                                            cap, n_out, st);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        const hipError_t e1 = hipStreamEndCapture(st, &graph);
+        if (rc != IAMX_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e1 != hipSuccess || !graph ||
+            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            // the runtime refused (the capture left nothing on the stream): plain launches
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            return sift_enqueue_pyramid(L, contrast_threshold, edge_threshold, sigma, ws, kp, desc,
+                                        cap, n_out, st);
+        }
+        (void)hipGraphDestroy(graph);
+        if (victim->used) (void)hipGraphExecDestroy(victim->exec);
+        victim->key = key;
+        victim->exec = exec;
+        victim->used = true;
+        hit = victim;
+    }
+    hit->stamp = ++clock_;
+    if (hipGraphLaunch(hit->exec, st) != hipSuccess)
+        return iamx::fail(IAMX_ELAUNCH, "iamx_sift_detect: hipGraphLaunch: %s",
+                          hipGetErrorString(hipGetLastError()));
+    return iamx::check_launch("iamx_sift_detect");
+}
+
+static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float edge_threshold,
+                                float sigma, char *ws, float *kp, uint8_t *desc, int cap,
+                                int32_t *n_out, hipStream_t st)
+{
     PyrTable T;
     T.n_oct = L.n_oct;
     for (int o = 0; o < L.n_oct; ++o) {
@@ -1370,12 +1470,10 @@ extern "C" int iamx_sift_detect(const uint8_t *image, int height, int width, int
     auto blur = [&](hipStream_t q, const float *src, float *dst, int h, int w, const Taps &tp) {
         blur_level(q, src, h, w, tp, dst);
     };
-    // base image: gray -> x2 -> blur(sqrt(sigma^2 - 1))
+    // base image, part 2: blur(sqrt(sigma^2 - 1)) of the doubled image
     {
         const int H = L.h[0], W = L.w[0];
         float *up = reinterpret_cast<float *>(ws + L.up_off);
-        hipLaunchKernelGGL(gray_up2x_kernel, dim3(blocks((int64_t)H * W, 256)), dim3(256), 0, st,
-                           image, height, width, channels, up);
         Taps tb;
         gaussian_taps(sqrt(fmax(sigma_d * sigma_d - 1.0, 0.01)), tb);
         blur(st, up, T.oct[0].g[0], H, W, tb);

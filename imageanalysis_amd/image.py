@@ -87,6 +87,10 @@ ASYNC_CACHE_WRITES = True      # cache files are written by background threads (
 USE_DESC_SIDECAR = True        # <image>.desc.u8.npy: raw uint8 descriptors beside the reference's .desc
 USE_DEVICE_JPEG = True         # split decoder: Huffman on the host, IDCT / upsampling / colour on the GPU
 SIDECAR_MARGIN_S = 30.0        # a .desc / .feat newer than the sidecar by more than this is not ours
+DES_LIST_U8 = False            # True: image.des_list stays uint8 [N,128] (the same integer values; 6 MB
+                               # instead of 25 MB per 50 k-keypoint frame -- 47 GB instead of 190 GB of host
+                               # memory for 10 000 frames).  The cache files are unchanged (float32 .desc);
+                               # only code that needs des_list.dtype == float32 would notice.
 WRITE_REFERENCE_DESC = True    # False: skip the 25 MB float32 gzip (only this package reads the cache then)
 # zlib level of the float32 .desc (the reference passes compresslevel=6, image.py:213; every level
 # decompresses to the same bytes).  On integer-valued float32 descriptors level 6 runs at 9 MB/s
@@ -159,7 +163,7 @@ def _load_sidecar(self):
             return None
         if self.kp_list is not None and len(self.kp_list) and len(self.kp_list) != len(u8):
             return None                                   # not the descriptors of these keypoints
-        return u8.astype(np.float32)
+        return u8 if DES_LIST_U8 else u8.astype(np.float32)
     except Exception:                     # noqa: BLE001  (fall back to the .desc file)
         return None
 
@@ -258,7 +262,7 @@ def save_descriptors(self):
                 as_u8 = cand
     if WRITE_REFERENCE_DESC:
         on_error = lambda e: print(self.desc_file + ": error saving file: " + str(e))
-        if as_u8 is not None and as_u8.ndim == 2 and np.asarray(des).dtype == np.float32:
+        if as_u8 is not None and as_u8.ndim == 2 and np.asarray(des).dtype in (np.float32, np.uint8):
             # the reference's file without the float32 bytes ever going through zlib
             cacheio.write_raw(self.desc_file, lambda: _desc_gzip_from_u8(as_u8),
                               background=ASYNC_CACHE_WRITES, on_error=on_error)
@@ -350,9 +354,10 @@ def features_from_bgr(bgr, scale, equalize=True, keep_u8=False, slot=False):
     # python-float division like `kp.pt[0] / scale` on a cv2.KeyPoint, then float32 members
     kp_list = KeyPointList(kp[:, 0].astype(np.float64) / scale, kp[:, 1].astype(np.float64) / scale,
                            kp[:, 2], kp[:, 3], kp[:, 4], octave)
+    des = np.ascontiguousarray(desc, np.uint8) if DES_LIST_U8 else _to_float32(desc)
     if keep_u8:
-        return kp_list, _to_float32(desc), desc
-    return kp_list, _to_float32(desc)
+        return kp_list, des, desc
+    return kp_list, des
 
 
 def _to_float32(u8):

@@ -38,9 +38,15 @@ class DescriptorStore(object):
     store'): int8 rows (value-128), each image zero-padded to 128 rows, + two int32 norms
     per row.  288 GB of HBM hold > 10^9 descriptors, so a whole survey stays resident."""
 
-    def __init__(self, counts):
+    def __init__(self, counts, train_layout=True):
+        """train_layout=False: the parity-partitioned copy `desc2` (a third of the arena) is not
+        kept.  Only the ONE-direction fast sweep reads it; a store that serves batches holding
+        both directions of every pair (find_matches: the symmetric sweep reads `desc3`, the exact
+        stage `desc`) does without, and a batch the symmetric sweep refuses (an image of < 2 rows)
+        then takes the general kernel, which reads `desc` only."""
         dev = require_gpu()
         L = lib()
+        self.has_train_layout = bool(train_layout)
         self.counts = [int(c) for c in counts]
         pads = [int(L.iamx_desc_padded_rows(c)) for c in self.counts]
         offs = np.zeros(len(pads) + 1, np.int64)
@@ -63,7 +69,7 @@ class DescriptorStore(object):
         if offs2[-1] >= 2 ** 31:
             raise ValueError("descriptor store limited to 2^31 rows")
         self.offsets2 = offs2
-        total2 = max(int(offs2[-1]), 1)
+        total2 = max(int(offs2[-1]), 1) if train_layout else 1
         self.desc2 = torch.empty((total2, 128), dtype=I8, device=dev)
         self.norm2 = torch.empty(total2, dtype=I32, device=dev)
         self.cinit = torch.empty(total2, dtype=I32, device=dev)
@@ -106,12 +112,14 @@ class DescriptorStore(object):
         fn = lib().iamx_desc_pack_u8 if is_u8 else lib().iamx_desc_pack_f32
         check(fn(_ptr(src), n, _ptr(self.desc[o:]), _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]),
                  stream_ptr()), 'iamx_desc_pack')
-        o2 = int(self.offsets2[i])
-        fn2 = lib().iamx_desc2_pack_u8 if is_u8 else lib().iamx_desc2_pack_f32
-        scratch = torch.empty(3 * n, dtype=I32, device=src.device)
-        check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
-                  _ptr(self.perm[o2:]), _ptr(self.meta[i]), _ptr(scratch), stream_ptr()),
-              'iamx_desc2_pack')
+        scratch = None
+        if self.has_train_layout:
+            o2 = int(self.offsets2[i])
+            fn2 = lib().iamx_desc2_pack_u8 if is_u8 else lib().iamx_desc2_pack_f32
+            scratch = torch.empty(3 * n, dtype=I32, device=src.device)
+            check(fn2(_ptr(src), n, _ptr(self.desc2[o2:]), _ptr(self.norm2[o2:]), _ptr(self.cinit[o2:]),
+                      _ptr(self.perm[o2:]), _ptr(self.meta[i]), _ptr(scratch), stream_ptr()),
+                  'iamx_desc2_pack')
         o3 = int(self.offsets3[i])
         fn3 = lib().iamx_desc3_pack_u8 if is_u8 else lib().iamx_desc3_pack_f32
         scratch3 = torch.empty(3 * n, dtype=I32, device=src.device)
@@ -167,12 +175,14 @@ class DescriptorStore(object):
                 check(L.iamx_desc_pack_u8(_ptr(src[int(off[i]):]), counts[i], _ptr(self.desc[o:]),
                                           _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]), sp), 'iamx_desc_pack_u8')
         src_off = torch.from_numpy(off).to(dev)
-        scratch = torch.empty(3 * rows, dtype=I32, device=dev)
+        scratch = None
         mx = int(max(counts))
-        check(L.iamx_desc2_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off2[first:]), k, rows, mx,
-                                         _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
-                                         _ptr(self.perm), _ptr(self.meta[first]), _ptr(scratch), sp),
-              'iamx_desc2_pack_batch_u8')
+        if self.has_train_layout:
+            scratch = torch.empty(3 * rows, dtype=I32, device=dev)
+            check(L.iamx_desc2_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off2[first:]), k, rows, mx,
+                                             _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
+                                             _ptr(self.perm), _ptr(self.meta[first]), _ptr(scratch), sp),
+                  'iamx_desc2_pack_batch_u8')
         scratch3 = torch.empty(3 * rows, dtype=I32, device=dev)
         check(L.iamx_desc3_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off3[first:]), k, rows, mx,
                                          _ptr(self.desc3), _ptr(self.sn2), _ptr(self.sct), _ptr(self.sperm),
@@ -590,6 +600,9 @@ class PairBatch(object):
         st = self.store
         if self.sym and not exact_second:
             return self.run_sym_sweep(ws)
+        if not st.has_train_layout:
+            # (no parity-partitioned copy in this store: the general kernel, exact as well)
+            return self.run_knn2(ws)
         if exact_second and self.fast_rows == 1024:          # the exact-second form stops at 512
             self._use_rows(512)
         check(lib().iamx_knn2v2_pairs(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.img_off),
@@ -612,6 +625,10 @@ class PairBatch(object):
         threshold keeps a superset; iamx_knn2v2_finish makes it exact (include/iamx.h)."""
         if self.sym and not exact_second:
             return self.run_sym_filter(ws, thresh)
+        if not self.store.has_train_layout:
+            self.run_filter(ws, thresh)
+            ws.surv_cnt[:self.n_pairs].copy_(ws.seg_count[:self.n_pairs])
+            return
         L, s, st = lib(), stream_ptr(), self.store
         check(L.iamx_match_metric(_ptr(ws.d2), _ptr(self.d_out), self.n_pairs, float(thresh),
                                   _ptr(ws.metric), _ptr(ws.keep), _ptr(ws.seg_count),

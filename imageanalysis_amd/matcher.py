@@ -209,7 +209,9 @@ class DeviceMatcher(object):
         from . import kernels
         pend = self._pending
         if self._store is None or len(self._store.counts) != len(self._counts):
-            new = kernels.DescriptorStore(self._counts)
+            # (no parity-partitioned copy: find_matches' batches hold both directions of every
+            #  pair -- a third less arena, 104 instead of 155 GB for 10 000 frames of 37 k keypoints)
+            new = kernels.DescriptorStore(self._counts, train_layout=False)
             if self._store is not None and len(self._store.counts):
                 old = self._store
                 n_old, n_old2, k = int(old.offsets[-1]), int(old.offsets2[-1]), len(old.counts)
@@ -217,11 +219,12 @@ class DeviceMatcher(object):
                 new.norm_q[:n_old].copy_(old.norm_q[:n_old])
                 new.norm_t[:n_old].copy_(old.norm_t[:n_old])
                 # ... and the train-side (parity partitioned) form the fast kernel reads
-                new.desc2[:n_old2].copy_(old.desc2[:n_old2])
-                new.norm2[:n_old2].copy_(old.norm2[:n_old2])
-                new.cinit[:n_old2].copy_(old.cinit[:n_old2])
-                new.perm[:n_old2].copy_(old.perm[:n_old2])
-                new.meta[:k].copy_(old.meta[:k])
+                if old.has_train_layout and new.has_train_layout:
+                    new.desc2[:n_old2].copy_(old.desc2[:n_old2])
+                    new.norm2[:n_old2].copy_(old.norm2[:n_old2])
+                    new.cinit[:n_old2].copy_(old.cinit[:n_old2])
+                    new.perm[:n_old2].copy_(old.perm[:n_old2])
+                    new.meta[:k].copy_(old.meta[:k])
                 # ... and the sorted form of the symmetric sweep
                 n_old3 = int(old.offsets3[-1])
                 for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
@@ -664,6 +667,54 @@ def _post_set(n, clip, dev, surface):
         post['aff'] = torch.empty((n, 2, 6), dtype=torch.float64, device=dev)
         post['aff_ok'] = torch.empty((n, 2), dtype=torch.int32, device=dev)
     return post
+
+
+def _tensor_bytes(obj):
+    import torch
+    vals = obj.values() if isinstance(obj, dict) else vars(obj).values()
+    seen, total = set(), 0
+    for t in vals:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            key = t.untyped_storage().data_ptr()
+            if key not in seen:
+                seen.add(key)
+                total += t.untyped_storage().nbytes()
+    return total
+
+
+def device_memory_report():
+    """bytes of HBM this module holds right now: the descriptor arena (what grows with the
+    survey), the keypoint arena, and the pooled per-round buffers (what does not)"""
+    dm = the_matcher if isinstance(the_matcher, DeviceMatcher) else None
+    arena = _tensor_bytes(dm._store) if dm is not None and dm._store is not None else 0
+    kp = sum(t.untyped_storage().nbytes() for t in dm._kp_dev[1:4]) if dm is not None and dm._kp_dev else 0
+    pooled = sum(_tensor_bytes(w) for w in _ws_pool)
+    post = sum(_tensor_bytes(p_) for lst in _post_pool.values() for p_ in lst)
+    return dict(descriptor_arena_bytes=int(arena), keypoint_arena_bytes=int(kp),
+                pooled_workspace_bytes=int(pooled), pooled_result_set_bytes=int(post),
+                images=len(dm._counts) if dm is not None else 0,
+                descriptor_rows=int(sum(dm._counts)) if dm is not None else 0)
+
+
+def device_memory_model(n_images, rows_per_image, train_layout=False):
+    """HBM the matching stage needs for a survey of n_images x rows_per_image descriptors, bytes:
+      arena      per row: 128 B int8 + 3 x 4 B (norms, key scratch) in the original order, 128 B +
+                 4 x 4 B in the sorted order (+ 128 B + 3 x 4 B parity partitioned with
+                 train_layout; find_matches does without), rows padded to 128 per image;
+                 keypoints 16 B per row (kp.pt float32 x 2, "%.2f" keys int32 x 2)
+      per round  a workspace of <= BATCH_BYTES (the per-row partial bounds of the symmetric sweep
+                 dominate), TWO of them pooled + a third while a round is in flight, and the
+                 per-pair result slots of the filters (clip x 56 B per pair)
+    Only the arena grows with the survey; the rest is bounded by BATCH_BYTES whatever N is."""
+    rows = (int(rows_per_image) + 127) // 128 * 128
+    per_row = (128 + 12) + (128 + 16) + ((128 + 12) if train_layout else 0)
+    arena = n_images * rows * per_row + n_images * int(rows_per_image) * 16
+    ppb = _pairs_per_batch(1.25 * rows_per_image)
+    ws = ppb * _workspace_bytes_per_pair(1.25 * rows_per_image)
+    clip = 2000
+    return dict(arena_bytes=int(arena), workspace_bytes_each=int(ws), pairs_per_batch=int(ppb),
+                result_set_bytes_each=int(ppb * clip * (8 + 16 + 8) + ppb * 200),
+                peak_bytes=int(arena + 3 * ws + 2 * ppb * clip * 32))
 
 
 def _recycle(h):

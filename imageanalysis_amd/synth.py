@@ -203,6 +203,14 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
     IK = np.linalg.inv(K)
     d2r = np.pi / 180.0
     names, truth, logged = [], [], []
+    # (the JPEG encoder releases the interpreter: frames are encoded on a few threads while the
+    #  next ones are rendered -- 2048 frames of 20 MP take a minute instead of four)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=min(12, max(2, (os_.cpu_count() or 4) - 2)))
+    saves = []
+
+    def _save(rgb, path):
+        PILImage.fromarray(rgb).save(path, quality=95)
     for row in range(rows):
         for col in range(cols):
             k = col if row % 2 == 0 else cols - 1 - col
@@ -217,9 +225,14 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
                 bgr = render_view_device(tex, M, ned, w, h, gsd, origin)
             else:
                 bgr = render_view(tex, M, ned, w, h, gsd, origin)
-            PILImage.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(
-                os_.path.join(project_dir, 'images', name + '.JPG'), quality=95)
+            saves.append(pool.submit(_save, np.ascontiguousarray(bgr[:, :, ::-1]),
+                                     os_.path.join(project_dir, 'images', name + '.JPG')))
+            while len(saves) > 24:                       # (bounded: 60 MB per frame in flight)
+                saves.pop(0).result()
             names.append(name)
             truth.append((ned, ypr))
             logged.append((ned + rng.normal(0, 0.8, 3), ypr + rng.normal(0, 0.7, 3)))
+    for f in saves:
+        f.result()
+    pool.shutdown()
     return names, truth, logged, K
