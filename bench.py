@@ -456,6 +456,7 @@ def main():
             "sift_frames_per_sec": g(sift, "value"), "sift_frac_hbm": g(sift, "roofline", "frac"),
             "sift_traffic_bytes": g(sift, "roofline", "traffic"),
             "sift_ms_per_detect_on_stream": g(sift, "ms_per_image_detector_kernels"),
+            "sift_frac_hbm_8_in_flight": g(sift, "concurrent_8", "frac"),
             "e2e_stage_seconds": g(e2e, "stage_seconds"),
             "e2e_images": g(e2e, "images"), "e2e_images_per_sec": g(e2e, "images_per_sec_end_to_end"),
             "e2e_total_seconds": g(e2e, "total_seconds"), "e2e_peak_hbm_bytes": g(e2e, "peak_hbm_bytes"),
@@ -1016,15 +1017,49 @@ def sift_bench(rank, world, dev, dist, args):
     kpd = torch.empty((400000, 8), dtype=torch.float32, device=dev)
     dd = torch.empty((400000, 128), dtype=torch.uint8, device=dev)
     nn = torch.zeros(1, dtype=torch.int32, device=dev)
-    e0.record()
-    for _ in range(n_local):
+    def enqueue(b=None):
+        b = b or (ws, kpd, dd, nn)
         kernels.check(L.iamx_sift_detect(kernels._ptr(scaled), h, w, 3, 0.04, 10.0, 1.6,
-                                         kernels._ptr(ws), need, kernels._ptr(kpd), kernels._ptr(dd),
-                                         400000, kernels._ptr(nn), kernels.stream_ptr()),
+                                         kernels._ptr(b[0]), need, kernels._ptr(b[1]), kernels._ptr(b[2]),
+                                         400000, kernels._ptr(b[3]), torch.cuda.current_stream().cuda_stream),
                       'iamx_sift_detect')
+    # steady state: 3 untimed detections on these buffers, then N_K back to back.  (Rounds 1-4
+    # timed FOUR detections behind a synchronize: 2.8 ms each where the same kernels take 1.8 ms
+    # once the queue is full and the clocks are up -- tools/sift_stream_time.py.)
+    N_K = 20
+    for _ in range(3):
+        enqueue()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(N_K):
+        enqueue()
     e1.record()
     torch.cuda.synchronize()
-    t_k = e0.elapsed_time(e1) / n_local * 1e-3
+    t_k = e0.elapsed_time(e1) / N_K * 1e-3
+    # ... and what image.prefetch runs: 8 detector threads in flight, a buffer set and stream each
+    # (whole-job rate, wall clock: the frames' small kernels fill each other's dependency stalls)
+    t_conc = None
+    if dist is None:
+        import threading
+        K_DET = 8
+        sets = [(torch.empty(need, dtype=torch.uint8, device=dev), torch.empty((400000, 8), dtype=torch.float32, device=dev),
+                 torch.empty((400000, 128), dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+                for _ in range(K_DET)]
+        streams = [torch.cuda.Stream() for _ in range(K_DET)]
+
+        def worker(k, reps):
+            with torch.cuda.stream(streams[k]):
+                for _ in range(reps):
+                    enqueue(sets[k])
+        for reps in (2, N_K):
+            torch.cuda.synchronize()
+            t0c = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(k, reps)) for k in range(K_DET)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            torch.cuda.synchronize()
+            t_conc = (time.perf_counter() - t0c) / (K_DET * reps)
+        del sets, streams
     if dist is not None:
         t = torch.tensor([dt, t_k], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1062,9 +1097,13 @@ def sift_bench(rank, world, dev, dist, args):
                          "achieved": round(alg / t_k / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg,
                          "traffic": sift_tr, "traffic_source": sift_tr_src,
-                         "timing": "hipEvents around %d whole detects on the launch stream; per-kernel " % n_local +
-                                   "durations: profiles/r4_kernel_stats.txt (rocprofv3 --kernel-trace "
-                                   "--stats of the bench command), profiles/r4_sift_kernel_stats.txt"},
+                         "timing": "hipEvents around %d whole detects on the launch stream, steady state "
+                                   "(3 untimed before); per-kernel durations: profiles/r5_kernel_stats.txt "
+                                   "(rocprofv3 --kernel-trace --stats of the bench command)" % N_K},
+            "concurrent_8": None if t_conc is None else {
+                "ms_per_image": round(t_conc * 1e3, 3), "achieved": round(alg / t_conc / 1e9, 1), "peak": 8000.0,
+                "unit": "GB/s", "frac": round(alg / t_conc / 1e9 / 8000.0, 4),
+                "timing": "wall clock, 8 threads x %d detections, one stream and buffer set per thread" % N_K},
             "scale_1_0": full, "cpu_baseline": cpu, "dtype": "f32 pyramid, f64 histograms",
             "parallelism": "image-shard x%d" % world}
 
@@ -1114,7 +1153,7 @@ def ba_bench(rank, world, dev, dist, args):
     # copies of the problem (6 x 125 MB for the residual, 6 x 439 MB with the Jacobian blocks) in
     # rotation, so that every launch finds its inputs evicted by the five launches before it.
     # (`timed` above re-launches ONE problem back to back: its 125 MB come out of the cache.)
-    t_res_cold = t_jac_cold = None
+    t_res_cold = t_jac_cold = copy_bw = None
     n_rot = 6
     if world == 1:
         rot = [prob]
@@ -1135,6 +1174,18 @@ def ba_bench(rank, world, dev, dist, args):
         t_res_cold = timed(rot_res, 20) / n_rot
         t_jac_cold = timed(rot_jac, 10) / n_rot
         del launch, rot
+        torch.cuda.empty_cache()
+        # yardstick on the same box, same moment: a plain device copy over the same kind of
+        # rotating working set (6 x 62.5 MB read + 62.5 MB written = the residual's byte count)
+        n_el = int(62.5e6 // 8)
+        srcs = [torch.empty(n_el, dtype=torch.float64, device=dev).normal_() for _ in range(n_rot)]
+        dsts = [torch.empty(n_el, dtype=torch.float64, device=dev) for _ in range(n_rot)]
+
+        def rot_copy():
+            for a_, b_ in zip(srcs, dsts):
+                b_.copy_(a_)
+        copy_bw = 2 * n_el * 8 / (timed(rot_copy, 20) / n_rot) / 1e9
+        del srcs, dsts
         torch.cuda.empty_cache()
     # untimed warm-up solve (workspace and allocator blocks of every branch of the step selection,
     # code-object load), like --warmup for matching; the collector has the matching section's heap
@@ -1253,6 +1304,8 @@ def ba_bench(rank, world, dev, dist, args):
         bw = bytes_per_obs * o_local / t / 1e9
         return {"achieved": round(bw, 1), "frac": round(bw / HBM, 4),
                 "frac_of_achievable_6300": round(bw / 6300.0, 4), "us_per_launch": round(t * 1e6, 2),
+                "plain_copy_same_working_set_gbs": None if copy_bw is None else round(copy_bw, 1),
+                "frac_of_plain_copy": None if copy_bw is None else round(bw / copy_bw, 4),
                 "working_set": "%d problem copies in rotation (%.0f MB > the 256 MiB Infinity Cache)"
                                % (n_rot, n_rot * bytes_per_obs * o_local / 1e6),
                 "timing": "hipEvents around %d rotations" % (20 if bytes_per_obs == 64 else 10)}

@@ -57,6 +57,7 @@ SIGNATURES = {
     'iamx_match_pack_results': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64] + [c_void_p] * 4),
     'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]
                               + [c_void_p] * 6),
+    'iamx_thp_pays': (c_int, []),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     'iamx_chains_longest_first': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int]),

@@ -9,6 +9,7 @@
 // at 2812-10 k images this serial python is the wall-clock bottleneck after
 // GPU matching; here it is flat arrays + one hash map, O(points) per pass.
 #include "iamx_common.h"
+#include <chrono>
 
 #include <cstdlib>
 #include <cmath>
@@ -24,6 +25,41 @@ namespace {
 // huge pages: a first touch per 2 MiB instead of per 4 KiB).  The linking pass of a 512-frame
 // survey touches ~1 GB of fresh arrays once; as std::vectors their page faults cost more than the
 // pass itself.  Falls back to plain pages silently; contents are zero after construction.
+// Whether MADV_HUGEPAGE pays on THIS host, decided once per process by touching 32 MiB each way.
+// With free huge pages a first touch maps 2 MiB at a time (10x fewer faults: measured in round 4 on
+// the GPU box and in the build container).  On a host whose memory is fragmented the same advice
+// makes every fault wait for the kernel's direct compaction (defrag = madvise): round 5's build
+// container took 0.9 s to copy 144 MB into such a mapping, 0.1 s into plain pages, and ran the
+// linking pass 2.3x slower on top.  IAMX_THP=0 / 1 overrides the probe.
+inline double seconds_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline double touch_probe(bool huge_advice)
+{
+    const size_t huge = (size_t)2 << 20, bytes = (size_t)32 << 20;
+    void *m = mmap(nullptr, bytes + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return 1e9;
+    char *p = reinterpret_cast<char *>(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+    (void)madvise(p, bytes, huge_advice ? MADV_HUGEPAGE : MADV_NOHUGEPAGE);
+    const double t0 = seconds_now();
+    for (size_t o = 0; o < bytes; o += 4096) p[o] = 1;
+    const double dt = seconds_now() - t0;
+    munmap(m, bytes + huge);
+    return dt;
+}
+
+inline bool thp_pays()
+{
+    static const bool v = []() {
+        if (const char *e = getenv("IAMX_THP")) return e[0] == '1';
+        const double plain = touch_probe(false), huge = touch_probe(true);
+        return huge <= 1.5 * plain;
+    }();
+    return v;
+}
+
 template <class T>
 struct HugeBuf {
     T *p = nullptr;
@@ -34,7 +70,7 @@ struct HugeBuf {
         bytes = ((count * sizeof(T) + huge - 1) / huge + 1) * huge;
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) throw std::bad_alloc();
-        (void)madvise(m, bytes, MADV_HUGEPAGE);
+        if (thp_pays()) (void)madvise(m, bytes, MADV_HUGEPAGE);
         p = static_cast<T *>(m);
     }
     ~HugeBuf() { if (p) munmap(p, bytes); }
@@ -77,6 +113,10 @@ struct PointMap {
 
 }  // namespace
 
+// 1 when transparent huge pages speed up first-touch on this host right now (probed once per
+// process; what HugeBuf and matchpairs.empty_huge() go by), else 0
+extern "C" int iamx_thp_pays(void) { return thp_pays() ? 1 : 0; }
+
 // in : n_matches chains, chain i = points [ptr[i], ptr[i+1]) of (img[], kp[])
 // out: linked chains in the reference's order (NOT yet sorted by length), same flat layout;
 //      out arrays must hold ptr[n_matches] points / n_matches + 1 offsets.
@@ -100,22 +140,31 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         return IAMX_EINVAL;
     }
     try {
+    const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // current pass input: flat points + offsets (rewritten in place per pass)
     HugeBuf<int32_t> c_img((size_t)n_pts), c_kp((size_t)n_pts);
     HugeBuf<int64_t> c_ptr((size_t)n_matches + 1);
     std::memcpy(c_img.data(), img, (size_t)n_pts * sizeof(int32_t));
     std::memcpy(c_kp.data(), kp, (size_t)n_pts * sizeof(int32_t));
     std::memcpy(c_ptr.data(), ptr, (size_t)(n_matches + 1) * sizeof(int64_t));
-    // chains under construction: singly linked nodes in insertion order
-    HugeBuf<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_next((size_t)n_pts);
-    // (a pass never makes more chains than it reads: n_matches bounds all of them)
-    HugeBuf<int32_t> head((size_t)n_matches + 1), tail((size_t)n_matches + 1);
+    if (getenv("IAMX_LINK_TIMING")) fprintf(stderr, "  copies: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
+    // chains under construction: every appended point is a NODE (image, keypoint, chain) written
+    // sequentially in append order; a pass ends with a stable counting sort of the nodes by chain
+    // (the chains in creation order, their points in insertion order).  Rounds 2-4 linked a
+    // chain's nodes through next pointers and rebuilt the flat form by walking every list: one
+    // DEPENDENT cache miss per point and pass (12 M on a 512-frame survey's first pass, a second
+    // of the stage); the scatter's misses are independent of each other and overlap.
+    HugeBuf<int32_t> node_img((size_t)n_pts), node_kp((size_t)n_pts), node_chain((size_t)n_pts);
     int64_t n_chains = 0;
-    // the images of a chain's first INL points, side by side: the "image already in the chain?"
-    // test of a join reads one cache line instead of walking the chain's scattered nodes
-    constexpr int INL = 7;
+    // the images of a chain's first INL points, side by side (one cache line): the "image already
+    // in the chain?" test of a join reads it instead of the chain's scattered nodes; the rare
+    // longer chain keeps the rest of its images on an overflow list
+    constexpr int INL = 15;
     struct ChainImgs { int32_t n; int32_t img[INL]; };
+    static_assert(sizeof(ChainImgs) == 64, "one cache line per chain");
     HugeBuf<ChainImgs> cimg((size_t)n_matches + 1);
+    HugeBuf<int32_t> ovf_head((size_t)n_matches + 1), ovf_next((size_t)n_pts);
+    HugeBuf<int64_t> cursor((size_t)n_matches + 2);
     // (image, keypoint) -> chain: a DENSE table over the keypoints that occur (image i owns
     // [base[i], base[i] + max keypoint index of i + 1)) -- one 4-byte access per look-up where
     // the hash map of rounds 1-3 paid two cache misses (key, value) and the mixing; the entries
@@ -138,6 +187,7 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         if (base[(size_t)n_img] >= (1LL << 31)) dense = false;
         else table_n = (size_t)base[(size_t)n_img];
     }
+    if (getenv("IAMX_LINK_TIMING")) fprintf(stderr, "  dense scan: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
     HugeBuf<int32_t> table(dense ? table_n : 1);
     PointMap map(dense ? 0 : (size_t)n_pts);
     constexpr int64_t AHEAD = 48;                         // points of look-ahead for the prefetch
@@ -149,8 +199,12 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
     // pass is registered once).  A pass that never did that leaves pairwise disjoint chains: the
     // next one would copy them unchanged -- it is counted, not run.  (IAMX_LINK_VERIFY=1 runs it.)
     const bool verify = getenv("IAMX_LINK_VERIFY") != nullptr;
+    const bool timing = getenv("IAMX_LINK_TIMING") != nullptr;        // per-pass seconds on stderr
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (timing) fprintf(stderr, "iamx_link_matches setup: %.3f s\n", now() - t_enter);
     while (true) {
         ++passes;
+        const double t_pass = now();
         bool shared = false;
         if (dense) std::memset(table.data(), 0xff, table_n * sizeof(int32_t));      // every entry -1
         else map.clear();
@@ -158,11 +212,14 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         int32_t n_nodes = 0;
         auto append = [&](int32_t chain, int32_t pi, int32_t pk) {
             const int32_t nd = n_nodes++;
-            node_img[nd] = pi; node_kp[nd] = pk; node_next[nd] = -1;
-            if (head[chain] < 0) head[chain] = nd; else node_next[tail[chain]] = nd;
-            tail[chain] = nd;
+            node_img[nd] = pi; node_kp[nd] = pk; node_chain[nd] = chain;
             ChainImgs &ci = cimg[(size_t)chain];
-            if (ci.n < INL) ci.img[ci.n] = pi;
+            if (ci.n < INL) {
+                ci.img[ci.n] = pi;
+            } else {                                        // overflow list, newest first
+                ovf_next[nd] = ci.n == INL ? -1 : ovf_head[(size_t)chain];
+                ovf_head[(size_t)chain] = nd;
+            }
             ++ci.n;
         };
         auto in_chain = [&](int32_t chain, int32_t pi) -> bool {
@@ -170,12 +227,9 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
             const int32_t k = ci.n < INL ? ci.n : INL;
             for (int32_t t = 0; t < k; ++t)
                 if (ci.img[t] == pi) return true;
-            if (ci.n > INL) {                               // a long chain: the rest through its nodes
-                int32_t nd = head[chain];
-                for (int32_t t = 0; t < INL; ++t) nd = node_next[nd];
-                for (; nd >= 0; nd = node_next[nd])
+            if (ci.n > INL)                                 // a long chain: the rest through its nodes
+                for (int32_t nd = ovf_head[(size_t)chain]; nd >= 0; nd = ovf_next[nd])
                     if (node_img[nd] == pi) return true;
-            }
             return false;
         };
         auto lookup = [&](int32_t pi, int32_t pk) -> int32_t {
@@ -210,9 +264,7 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
             }
             if (index < 0) {                                // new chain: register every point
                 index = (int32_t)n_chains++;
-                head[(size_t)index] = -1;
-                tail[(size_t)index] = -1;
-                cimg[(size_t)index] = ChainImgs{0, {0}};
+                cimg[(size_t)index].n = 0;
                 for (int64_t j = b; j < e; ++j) {
                     store(c_img[j], c_kp[j], index);
                     append(index, c_img[j], c_kp[j]);
@@ -228,18 +280,27 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
                 }
             }
         }
-        // next pass input = the chains in creation order, points in insertion order
+        // next pass input = the chains in creation order, points in insertion order: a stable
+        // counting sort of the nodes by chain (the counts are the chains' lengths)
+        const double t_walk = now();
         const int64_t n_new = n_chains;
         int64_t o = 0;
         for (int64_t i = 0; i < n_new; ++i) {
             c_ptr[(size_t)i] = o;
-            for (int32_t nd = head[(size_t)i]; nd >= 0; nd = node_next[nd]) {
-                c_img[(size_t)o] = node_img[nd];
-                c_kp[(size_t)o] = node_kp[nd];
-                ++o;
-            }
+            cursor[(size_t)i] = o;
+            o += cimg[(size_t)i].n;
         }
         c_ptr[(size_t)n_new] = o;
+        constexpr int32_t SCATTER_AHEAD = 24;
+        for (int32_t nd = 0; nd < n_nodes; ++nd) {
+            if (nd + SCATTER_AHEAD < n_nodes) __builtin_prefetch(&cursor[(size_t)node_chain[nd + SCATTER_AHEAD]], 1, 1);
+            const int64_t dst = cursor[(size_t)node_chain[nd]]++;
+            c_img[(size_t)dst] = node_img[nd];
+            c_kp[(size_t)dst] = node_kp[nd];
+        }
+        if (timing)
+            fprintf(stderr, "iamx_link_matches pass %d: %lld -> %lld chains, %d nodes, walk %.3f s, regroup %.3f s\n",
+                    passes, (long long)n_cur, (long long)n_new, n_nodes, t_walk - t_pass, now() - t_walk);
         const bool done = n_new == n_cur;
         n_cur = n_new;
         if (done) break;
@@ -249,6 +310,7 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         }
     }
     const int64_t total = c_ptr[(size_t)n_cur];
+    if (timing) fprintf(stderr, "iamx_link_matches total: %.3f s\n", now() - t_enter);
     std::memcpy(out_img, c_img.data(), (size_t)total * sizeof(int32_t));
     std::memcpy(out_kp, c_kp.data(), (size_t)total * sizeof(int32_t));
     std::memcpy(out_ptr, c_ptr.data(), (size_t)(n_cur + 1) * sizeof(int64_t));

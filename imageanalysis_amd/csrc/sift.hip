@@ -145,54 +145,88 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
     static_assert(2 * R <= SB_RING - SB_TH, "the V window must fit the ring");
     const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
     const int tile_x = tile % (int)gridDim.x, tile_y = tile / (int)gridDim.x;
-    constexpr int SW = SB_TW + 2 * R + 1;                 // (+1: odd row pitch)
+    constexpr int ROW = SB_TW + 2 * R;                    // source elements per row of an H block
+    constexpr int SW = ROW + 1;                           // (+1: odd row pitch)
     constexpr int HW = SB_TW + 1;
-    constexpr int TILE = SB_TH * (SB_TW + 2 * R);         // source elements of an H block
-    constexpr int PER = (TILE + 255) / 256;               // ... per thread
+    // the ring holds its first SB_MIRROR rows a second time behind row SB_RING - 1, so that the
+    // 8 + 2R rows a thread of the V pass reads never wrap: constant LDS offsets from one base
+    constexpr int SB_MIRROR = SB_STRIP + 2 * R;
     __shared__ float S[SB_TH * SW];
-    __shared__ float Hb[SB_RING * HW];
+    __shared__ float Hb[(SB_RING + SB_MIRROR) * HW];
     const int x0 = tile_x * SB_TW;
     const int y_begin = tile_y * seg_rows;
     const int y_end = min(y_begin + seg_rows, h);
+    // Fetch map of an H block: thread t takes rows (t >> 4) and (t >> 4) + 16, columns (t & 15) +
+    // 16 c -- one per-thread offset, everything else constants of the unrolled loops (round 4 dealt
+    // the elements out linearly, e = t + 256 i, and redid a division by ROW and two reflect-101
+    // tests per element and block: about as many VALU instructions as the taps themselves).
+    constexpr int NC = (ROW + 15) / 16;                   // column steps (the last one partial)
+    constexpr int PER_ = 2 * NC;
+    static_assert(SB_TH == 32, "two rows per thread");
+    const int f_ry = threadIdx.x >> 4, f_l = threadIdx.x & 15;
+    const bool cols_inside = x0 - R >= 0 && x0 + SB_TW + R <= w;        // (uniform)
     // The source rows of H block k + 1 are fetched into registers while block k is computed
     // (global -> register -> LDS: the load latency sits behind a block's ~430 FMAs per thread).
-    float pre[PER];
+    float pre[PER_];
     auto fetch = [&](int k) {                             // source rows [y_begin - R + SB_TH k, + SB_TH)
         const int ybase = y_begin - R + SB_TH * k;
+        if (cols_inside && ybase >= 0 && ybase + SB_TH <= h) {
+            // the whole rectangle lies inside the image
+            const float *base = src + (int64_t)(ybase + f_ry) * w + (x0 - R + f_l);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            const int ry = e / (SB_TW + 2 * R), rx = e - ry * (SB_TW + 2 * R);
-            int yy = ybase + ry, xx = x0 - R + rx;
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    pre[ri * NC + c] = (16 * c + 15 < ROW || f_l + 16 * c < ROW)
+                                           ? base[(int64_t)(16 * ri) * w + 16 * c] : 0.f;
+            return;
+        }
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+            int yy = ybase + f_ry + 16 * ri;
             yy = (yy >= 0 && yy < h) ? yy : reflect101(yy, h);
-            xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
-            pre[i] = e < TILE ? src[(int64_t)yy * w + xx] : 0.f;
+            const float *row = src + (int64_t)yy * w;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                int xx = x0 - R + f_l + 16 * c;
+                xx = (xx >= 0 && xx < w) ? xx : reflect101(xx, w);
+                pre[ri * NC + c] = (16 * c + 15 < ROW || f_l + 16 * c < ROW) ? row[xx] : 0.f;
+            }
         }
     };
     auto stage = [&]() {                                  // registers -> S
+        float *sp = S + f_ry * SW + f_l;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = threadIdx.x + 256 * i;
-            const int ry = e / (SB_TW + 2 * R), rx = e - ry * (SB_TW + 2 * R);
-            if (e < TILE) S[ry * SW + rx] = pre[i];
-        }
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                if (16 * c + 15 < ROW || f_l + 16 * c < ROW) sp[16 * ri * SW + 16 * c] = pre[ri * NC + c];
     };
+    const int h_ry = threadIdx.x / (SB_TW / SB_STRIP), h_sx = (threadIdx.x % (SB_TW / SB_STRIP)) * SB_STRIP;
     auto hpass = [&](int k) {                             // S -> ring rows (SB_TH k + ry) & 63
-        const int ry = threadIdx.x / (SB_TW / SB_STRIP), sx = (threadIdx.x % (SB_TW / SB_STRIP)) * SB_STRIP;
         float win[SB_STRIP + 2 * R];
 #pragma unroll
-        for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = S[ry * SW + sx + i];
-        float *hrow = Hb + ((SB_TH * k + ry) & (SB_RING - 1)) * HW + sx;
+        for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = S[h_ry * SW + h_sx + i];
+        const int ring_row = (SB_TH * k + h_ry) & (SB_RING - 1);
+        float *hrow = Hb + ring_row * HW + h_sx;
+        const bool mirror = ring_row < SB_MIRROR;
+        float acc[SB_STRIP];
 #pragma unroll
         for (int j = 0; j < SB_STRIP; ++j) {
-            float acc = 0.f;
+            acc[j] = 0.f;
 #pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
-            hrow[j] = acc;
+            for (int t = 0; t <= 2 * R; ++t) acc[j] = __builtin_fmaf(win[j + t], T.k[t], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < SB_STRIP; ++j) hrow[j] = acc[j];
+        if (mirror) {
+#pragma unroll
+            for (int j = 0; j < SB_STRIP; ++j) hrow[SB_RING * HW + j] = acc[j];
         }
     };
     const int cx = threadIdx.x & (SB_TW - 1), g = threadIdx.x / SB_TW;
     const int x = x0 + cx;
+    const float *vbase = Hb + (g * SB_STRIP) * HW + cx;   // ring row g * 8 of this thread's column
     const int n_blocks = (y_end - y_begin + SB_TH - 1) / SB_TH;
     fetch(0);
     stage();
@@ -200,32 +234,36 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
     __syncthreads();
     hpass(0);
     __syncthreads();
+    auto vpass = [&](int b, const float *vb) {
+        // V block b: output rows y_begin + SB_TH b + 8 g + j; source row y' sits in ring row
+        // (y' - (y_begin - R)) & 63, so the window of output row y starts at (y - y_begin) & 63
+        // = vb's row (SB_TH b & 63, a constant of the unrolled body) + 8 g
+        const int y0 = y_begin + SB_TH * b + g * SB_STRIP;
+        if (x < w && y0 < y_end) {
+            float win[SB_STRIP + 2 * R];
+#pragma unroll
+            for (int i = 0; i < SB_STRIP + 2 * R; ++i) win[i] = vb[i * HW];
+            float *out = dst + (int64_t)y0 * w + x;
+            float acc[SB_STRIP];
+#pragma unroll
+            for (int j = 0; j < SB_STRIP; ++j) {
+                acc[j] = 0.f;
+#pragma unroll
+                for (int t = 0; t <= 2 * R; ++t) acc[j] = __builtin_fmaf(win[j + t], T.k[t], acc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < SB_STRIP; ++j)
+                if (y0 + j < y_end) out[(int64_t)j * w] = acc[j];
+        }
+    };
+    static_assert(SB_RING == 2 * SB_TH, "the ring start of a V block alternates between two rows");
     for (int b = 0; b < n_blocks; ++b) {
         stage();                                          // source rows of H block b + 1
         if (b + 1 < n_blocks) fetch(b + 2);               // (in flight during the two passes below)
         __syncthreads();
         hpass(b + 1);
         __syncthreads();
-        // V block b: output rows y_begin + SB_TH b + 8 g + j; source row y' sits in ring row
-        // (y' - (y_begin - R)) & 63, so the window of output row y starts at (y - y_begin) & 63
-        const int y0 = y_begin + SB_TH * b + g * SB_STRIP;
-        if (x < w && y0 < y_end) {
-            float win[SB_STRIP + 2 * R];
-#pragma unroll
-            for (int i = 0; i < SB_STRIP + 2 * R; ++i)
-                win[i] = Hb[((SB_TH * b + g * SB_STRIP + i) & (SB_RING - 1)) * HW + cx];
-#pragma unroll
-            for (int j = 0; j < SB_STRIP; ++j) {
-                const int y = y0 + j;
-                if (y < y_end) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int t = 0; t <= 2 * R; ++t) acc = __builtin_fmaf(win[j + t], T.k[t], acc);
-                    const int64_t i = (int64_t)y * w + x;
-                    dst[i] = acc;
-                }
-            }
-        }
+        if (b & 1) vpass(b, vbase + SB_TH * HW); else vpass(b, vbase);
     }
 }
 
@@ -1336,10 +1374,15 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
 
 // The launch sequence of a frame size never changes (grids are sized by capacity, counts live
 // on the device) and every pointer in it belongs to the caller's per-detector workspace / output
-// buffers, so it is CAPTURED ONCE into a HIP graph per (frame size, parameters, buffers) and
-// replayed: one submission instead of ~65, no per-launch host cost between dependent kernels.
-// The first kernel (gray_up2x: the only reader of the image, whose address changes from frame to
-// frame) stays a plain launch in front of the graph.  IAMX_SIFT_NO_GRAPH=1: plain launches.
+// buffers, so it CAN be captured once into a HIP graph per (frame size, parameters, buffers) and
+// replayed: one submission instead of ~65.  The first kernel (gray_up2x: the only reader of the
+// image, whose address changes from frame to frame) stays a plain launch in front of the graph.
+// OPT-IN (IAMX_SIFT_GRAPH=1), because it does not pay on MI355X / ROCm 7 (round 5,
+// profiles/r5_sift_graph_ab.txt): in steady state the ~65 plain launches cost the host 0.12 ms per
+// frame and the stream is kernel bound either way -- 1.773 ms per detection replayed against
+// 1.781 ms launched --, and with eight detector threads in flight the replayed graphs serialise
+// where plain launches of different frames interleave: 2.02 against 1.51 ms per detection.  (The
+// "0.6 ms of launch gaps per frame" of round 4 was an artefact of timing four cold detections.)
 namespace {
 struct GraphKey {
     int height, width, cap, xcd;
@@ -1358,8 +1401,8 @@ constexpr int GRAPH_SLOTS = 12;
 inline bool graph_enabled()
 {
     static const bool on = []() {
-        const char *e = getenv("IAMX_SIFT_NO_GRAPH");
-        return !(e && e[0] == '1');
+        const char *e = getenv("IAMX_SIFT_GRAPH");
+        return e && e[0] == '1';
     }();
     return on;
 }

@@ -132,6 +132,20 @@ _HUGE = 2 << 20
 _libc = None
 
 
+_thp = None
+
+
+def _thp_pays():
+    global _thp
+    if _thp is None:
+        try:
+            from . import _lib
+            _thp = bool(_lib.lib().iamx_thp_pays())
+        except Exception:                 # noqa: BLE001  (no library: plain pages)
+            _thp = False
+    return _thp
+
+
 def empty_huge(shape, dtype):
     """np.empty() for arrays of many megabytes that are written once: anonymous memory with
     MADV_HUGEPAGE, so that the first touch maps 2 MiB at a time where the kernel grants
@@ -153,7 +167,10 @@ def empty_huge(shape, dtype):
         off = (-raw.ctypes.data) % _HUGE
         if _libc is None:
             _libc = ctypes.CDLL(None, use_errno=True)
-        _libc.madvise(ctypes.c_void_p(raw.ctypes.data + off), ctypes.c_size_t(n), 14)   # MADV_HUGEPAGE
+        # (only where huge pages pay on this host today: libiamx probes once per process -- on a
+        #  fragmented host the advice makes every first touch wait for compaction, 9x slower)
+        if _thp_pays():
+            _libc.madvise(ctypes.c_void_p(raw.ctypes.data + off), ctypes.c_size_t(n), 14)   # MADV_HUGEPAGE
         return raw[off:off + n].view(dtype).reshape(shape)
     except (OSError, ValueError, AttributeError):
         return np.empty(shape, dtype)

@@ -116,6 +116,89 @@ def make_survey_image(h=3648, w=5472, seed=0, device='cuda'):
     return torch.stack([img, img * 0.9 + 10, img * 0.8 + 20], 2).clamp(0, 255).to(torch.uint8).contiguous()
 
 
+def make_survey_gray_big(h, w, seed=0, device='cuda', band=2048):
+    """The grey channel of make_survey_image() for ground textures beyond 2^31 pixels (a survey
+    of thousands of 20 MP frames at 3 cm: 53 k x 91 k for 2048 frames), where one
+    interpolate() call over the whole plane is past the framework's 32-bit indexing: the same
+    seeded noise grids, upsampled band by band with the bilinear weights of
+    interpolate(align_corners=False) written out, accumulated in float32, normalised by the
+    global extrema like the small form.  uint8 [h, w] on the device."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    acc = torch.zeros((h, w), device=device)
+    xs = torch.arange(w, device=device, dtype=torch.float32)
+    for s in (2, 4, 8, 16, 32, 64):
+        gh, gw = h // s + 2, w // s + 2
+        if gh * gw < (1 << 30):
+            n = torch.randn((1, 1, gh, gw), generator=g, device=device)[0, 0]    # (= the small form's grid)
+        else:
+            n = torch.empty((gh, gw), device=device)
+            step = max(1, (1 << 30) // gw)
+            for a in range(0, gh, step):
+                n[a:a + step].normal_(generator=g)
+        sx = ((xs + 0.5) / s - 0.5).clamp_(min=0)
+        x0 = sx.floor().long().clamp_(max=gw - 1)
+        x1 = (x0 + 1).clamp_(max=gw - 1)
+        wx = (sx - x0.to(sx.dtype))[None, :]
+        for a in range(0, h, band):
+            b = min(a + band, h)
+            sy = ((torch.arange(a, b, device=device, dtype=torch.float32) + 0.5) / s - 0.5).clamp_(min=0)
+            y0 = sy.floor().long().clamp_(max=gh - 1)
+            y1 = (y0 + 1).clamp_(max=gh - 1)
+            wy = (sy - y0.to(sy.dtype))[:, None]
+            top, bot = n[y0], n[y1]                           # [band, gw]
+            up = (top[:, x0] * (1 - wx) + top[:, x1] * wx) * (1 - wy) + \
+                 (bot[:, x0] * (1 - wx) + bot[:, x1] * wx) * wy
+            acc[a:b] += up * s ** 0.7
+            del top, bot, up
+        del n
+    lo, hi = float(acc.min()), float(acc.max())
+    out = torch.empty((h, w), dtype=torch.uint8, device=device)
+    for a in range(0, h, band):
+        b = min(a + band, h)
+        out[a:b] = ((acc[a:b] - lo) / (hi - lo) * 255).clamp_(0, 255).to(torch.uint8)
+    return out
+
+
+def render_view_device_gray(tex, M, ned, w, h, gsd, origin):
+    """render_view_device() over the single-channel texture of make_survey_gray_big(): the texels
+    under the frame are cut out first (indices inside the cut-out fit 32 bits), the grey value is
+    interpolated and the three channels derived from it as make_survey_image() does."""
+    import torch
+    dev = tex.device
+    f64 = torch.float64
+    u = torch.arange(w, device=dev, dtype=f64)[None, :]
+    v = torch.arange(h, device=dev, dtype=f64)[:, None]
+    Mt = [[float(M[i, j]) for j in range(3)] for i in range(3)]
+    ray = [Mt[i][0] * u + Mt[i][1] * v + Mt[i][2] for i in range(3)]
+    t = -float(ned[2]) / ray[2]
+    r = (float(ned[0]) + ray[0] * t + origin) / gsd
+    c = (float(ned[1]) + ray[1] * t + origin) / gsd
+    del ray, t
+    r.clamp_(0, tex.shape[0] - 2)
+    c.clamp_(0, tex.shape[1] - 2)
+    r_lo, c_lo = int(r.min()), int(c.min())
+    r_hi, c_hi = min(int(r.max()) + 2, tex.shape[0]), min(int(c.max()) + 2, tex.shape[1])
+    sub = tex[r_lo:r_hi, c_lo:c_hi].contiguous()
+    r -= r_lo
+    c -= c_lo
+    r0, c0 = torch.floor(r), torch.floor(c)
+    fr, fc = r - r0, c - c0
+    del r, c
+    r0 = r0.long().clamp_(0, sub.shape[0] - 2)
+    c0 = c0.long().clamp_(0, sub.shape[1] - 2)
+    flat = sub.reshape(-1)
+    i00 = r0 * sub.shape[1] + c0
+    del r0, c0
+    top = flat[i00].to(f64) * (1 - fc) + flat[i00 + 1].to(f64) * fc
+    i00 += sub.shape[1]
+    bot = flat[i00].to(f64) * (1 - fc) + flat[i00 + 1].to(f64) * fc
+    gray = top * (1 - fr) + bot * fr
+    img = torch.stack([gray, gray * 0.9 + 10, gray * 0.8 + 20], 2)
+    return torch.round(img).clamp_(0, 255).to(torch.uint8).cpu().numpy()
+
+
 # --------------------------------------------------------------------------------------
 # a rendered survey on disk (bench.py --e2e, BASELINE configs[4] shape): a textured ground plane
 # photographed by nadir cameras on a lawn-mower grid, every pixel ray-cast onto the plane with the
@@ -180,6 +263,7 @@ def render_view_device(tex, M, ned, w, h, gsd, origin):
     return torch.round(img).clamp_(0, 255).to(torch.uint8).cpu().numpy()
 
 
+BIG_TEXTURE_PIXELS = 1500 * 1000 * 1000     # ground textures above this are built band by band (grey only)
 FULL_FRAME = dict(w=W_PX, h=H_PX, focal=FX, gsd=0.03)       # the FC6310S frame of BASELINE configs[4]
 
 
@@ -195,7 +279,10 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
     os_.makedirs(os_.path.join(project_dir, 'images'), exist_ok=True)
     origin = 80.0
     th, tw = int((rows * spacing[0] + 2 * origin) / gsd), int((cols * spacing[1] + 2 * origin) / gsd)
-    if device is not None:
+    big = device is not None and th * tw > BIG_TEXTURE_PIXELS
+    if big:
+        tex = make_survey_gray_big(th, tw, seed, device)     # (beyond one interpolate() call)
+    elif device is not None:
         tex = make_survey_image(th, tw, seed, device)
     else:
         tex = ground_texture(th, tw, seed)
@@ -221,7 +308,9 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
             name = 'P%03d' % len(names)
             q = tf.quaternion_from_euler(ypr[0] * d2r, ypr[1] * d2r, ypr[2] * d2r, 'rzyx')
             M = tf.quaternion_matrix(q)[:3, :3].dot(match_cleanup.CAM2BODY).dot(IK)
-            if device is not None:
+            if big:
+                bgr = render_view_device_gray(tex, M, ned, w, h, gsd, origin)
+            elif device is not None:
                 bgr = render_view_device(tex, M, ned, w, h, gsd, origin)
             else:
                 bgr = render_view(tex, M, ned, w, h, gsd, origin)

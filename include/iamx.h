@@ -296,6 +296,13 @@ int iamx_match_postfilter(const int64_t *surv_off, const int32_t *surv_cnt, cons
                           int32_t *out_cnt, int32_t *out_pairs, int32_t *scratch,
                           int32_t *out_stat, int32_t *status, void *stream);
 
+/* iamx_thp_pays -- HOST.  1 when MADV_HUGEPAGE speeds up the first touch of fresh anonymous memory
+ * on this host right now, 0 when it slows it down (a fragmented host makes every such fault wait
+ * for the kernel's compaction); probed once per process with 2 x 32 MiB, IAMX_THP=0 / 1 overrides.
+ * The work arrays of iamx_link_matches and the package's result arrays (matchpairs.empty_huge,
+ * what find_matches' rounds land in: scripts/lib/matcher.py:918-1031) go by it. */
+int iamx_thp_pays(void);
+
 /* ------------------------------------------------------------------------------------
  * match consolidation (host) and initial triangulation (device).
  *

@@ -280,12 +280,20 @@ def main():
         ok('lib/smart.py (original) update_srtm_elevations / set_yaw_error_estimates leave the tree and '
            'the images as the mirror does')
         tri = []
+        # (set_aircraft_yaw_error_estimate above re-derived every camera pose from the aircraft
+        #  pose and the mount, lib/image.py:434-460: back to the golden's poses first)
+        for im, pose in zip(sproj.image_list, g['poses']):
+            im.set_camera_pose(pose['ned'], *pose['ypr'])
         for rec in g['pairs'][:4]:
             a, b = sproj.image_list[rec['i']], sproj.image_list[rec['j']]
             a.match_list[b.name] = [list(p) for p in rec['matches']]
             with quiet():
                 pts = orig_smart.triangulate_features(a, b)
-            tri.append(dict(i=rec['i'], j=rec['j'], points=np.asarray(pts, np.float64)))
+            pts = np.asarray(pts, np.float64)
+            # the same call chain produced the golden's surface estimate: -mean / std of "down"
+            assert abs(-np.average(pts[2]) - rec['avg']) < 1e-9 * max(1.0, abs(rec['avg']))
+            assert abs(np.std(pts[2]) - rec['std']) < 1e-9 * max(1.0, rec['std'])
+            tri.append(dict(i=rec['i'], j=rec['j'], points=pts))
         result['triangulate_features'] = tri
         ok('lib/smart.py (original) triangulate_features: %d pairs recorded for tests/test_dropin.py'
            % len(tri))

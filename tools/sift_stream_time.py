@@ -1,7 +1,7 @@
 """Device time of whole SIFT detections on the launch stream (GPU box): hipEvents around N calls of
 iamx_sift_detect on one resident detect image (what bench.py's sift.roofline is timed on), and
 the same with 8 detector threads in flight (what image.prefetch does).
-    python tools/sift_stream_time.py [n]            IAMX_SIFT_NO_GRAPH=1 for the plain-launch form"""
+    python tools/sift_stream_time.py [n]            IAMX_SIFT_GRAPH=1 for the captured-graph form"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -44,7 +44,7 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 alg = 469.0 * h * w
 print("graph=%s  one stream: %.3f ms per detect on the stream (host enqueue %.3f ms), %d keypoints, "
-      "%.1f GB/s algorithmic = %.4f of 8 TB/s" % (os.environ.get('IAMX_SIFT_NO_GRAPH') != '1', ms, t_host / n * 1e3,
+      "%.1f GB/s algorithmic = %.4f of 8 TB/s" % (os.environ.get('IAMX_SIFT_GRAPH') == '1', ms, t_host / n * 1e3,
                                                  int(b0[3].item()), alg / ms / 1e6, alg / ms / 1e6 / 8000.0))
 # 8 detectors in flight, one thread + stream + buffer set each
 K = 8
@@ -67,5 +67,5 @@ for reps in (2, n):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 print("graph=%s  %d streams: %.3f ms per detect (wall, %d detects), %.1f GB/s algorithmic = %.4f of 8 TB/s"
-      % (os.environ.get('IAMX_SIFT_NO_GRAPH') != '1', K, dt / (K * n) * 1e3, K * n, alg / (dt / (K * n)) / 1e9,
+      % (os.environ.get('IAMX_SIFT_GRAPH') == '1', K, dt / (K * n) * 1e3, K * n, alg / (dt / (K * n)) / 1e9,
          alg / (dt / (K * n)) / 1e9 / 8000.0))
