@@ -714,6 +714,9 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
                                                     transform='homography', sort=True))
         out["image_pairs_matched"] = sum(len(im.match_list) for im in proj.image_list) // 2
+        out["route_rounds"] = {"mode": matcher.DENSE_ROUTE, "symmetric": matcher._route['rounds'][0],
+                               "one_direction": matcher._route['rounds'][1],
+                               "last_candidate_share": matcher._route['share']}
         out["hbm_after_match"] = dict(matcher.device_memory_report(),
                                       allocated_bytes=int(torch.cuda.memory_allocated()),
                                       peak_allocated_bytes=int(torch.cuda.max_memory_allocated()))

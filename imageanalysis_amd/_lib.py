@@ -27,6 +27,7 @@ SIGNATURES = {
     'iamx_desc_padded_rows': (c_int64, [c_int64]),
     'iamx_desc_pack_u8': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'iamx_desc_pack_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'iamx_desc_unpack_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'iamx_knn2_wg_per_pair': (c_int, [c_int]),
     'iamx_knn2_l2_pairs': (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_knn2_l2_u8': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
@@ -60,6 +61,7 @@ SIGNATURES = {
     'iamx_thp_pays': (c_int, []),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'iamx_link_pair_blocks': (c_int64, [c_void_p] * 3 + [c_int64] + [c_void_p] * 4),
     'iamx_chains_longest_first': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int]),
     'iamx_first_occurrence': (c_int, [c_void_p, c_int64, c_void_p]),
     'iamx_ledger_index': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -93,6 +95,8 @@ SIGNATURES = {
     'iamx_gzip_f32_from_u8': (c_int64, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     'iamx_gzip_members_bound': (c_int64, [c_int64, c_int64]),
     'iamx_gzip_members': (c_int64, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int64]),
+    'iamx_gzip_records_bound': (c_int64, [c_int64, c_int64]),
+    'iamx_gzip_records': (c_int64, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int64]),
     'iamx_u8_to_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     'iamx_f32_to_u8_many': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
     'iamx_feat_records': (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),

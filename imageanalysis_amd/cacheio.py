@@ -64,8 +64,17 @@ def _native_members(bufs, level, member_bytes, strategy=0):
     ptrs = (ctypes.c_void_p * max(len(views), 1))(*[v.ctypes.data for v in views])
     total = int(lens.sum())
     n_members = int(sum((int(n) + member_bytes - 1) // member_bytes for n in lens)) or 1
-    cap = int(L.iamx_gzip_members_bound(total, n_members))
+    cap = int(L.iamx_gzip_records_bound(total, n_members) if isinstance(strategy, tuple)
+              else L.iamx_gzip_members_bound(total, n_members))
     out = np.empty(cap, np.uint8)
+    if isinstance(strategy, tuple):
+        # ('records', width): streams of fixed-width records (the .feat pickle) through libiamx's
+        # own DEFLATE encoder, which only looks one record back (iamx_gzip_records)
+        n = L.iamx_gzip_records(ptrs, lens.ctypes.data_as(ctypes.c_void_p), len(views), int(member_bytes),
+                                int(strategy[1]), NATIVE_THREADS, out.ctypes.data_as(ctypes.c_void_p), cap)
+        if n < 0:
+            _lib.check(int(n), 'iamx_gzip_records')
+        return memoryview(out)[:int(n)]
     n = L.iamx_gzip_members(ptrs, lens.ctypes.data_as(ctypes.c_void_p), len(views), int(member_bytes),
                             int(level), int(strategy), NATIVE_THREADS, out.ctypes.data_as(ctypes.c_void_p), cap)
     if n < 0:
@@ -81,6 +90,8 @@ def gzip_member_list(raw, level=GZIP_LEVEL, member_bytes=None, strategy=0):
     native = _native_members(bufs, level, member_bytes or MEMBER_BYTES, strategy)
     if native is not None:
         return [native]
+    if isinstance(strategy, tuple):
+        strategy = 1                          # (no library: zlib's filtered strategy, the same payload)
     chunks = []
     for b in bufs:
         b = memoryview(b).cast('B')

@@ -393,6 +393,244 @@ extern "C" int64_t iamx_gzip_members(const uint8_t *const *bufs, const int64_t *
     return (int64_t)w;
 }
 
+// =====================================================================================
+// DEFLATE for streams of fixed-width records (the .feat pickle: 58 bytes per keypoint,
+// keypoints.py _REC).  Such a stream has one kind of redundancy -- a byte equals the byte one
+// record earlier (the pickle opcodes, the zero tails of float32 values widened to float64, class_id
+// = -1, exponent bytes) -- and zlib finds it through hash chains over every 3-byte window: 50-70 ms
+// of one core per 50 k-keypoint frame at level 4, the largest host cost of a fresh detection (more
+// than the JPEG's Huffman decode).  This encoder looks at distance `record_bytes` ONLY: one compare
+// pass makes the tokens (literal | match of length >= 4 at that distance), a dynamic Huffman code is
+// built from their histogram, one more pass writes the bits.  Valid gzip members (any reader
+// inflates them to the same payload); smaller than zlib's level 4 output and ~5x faster.
+// =====================================================================================
+namespace {
+
+inline uint32_t crc32_bytes(const uint8_t *p, size_t n)
+{
+    uint32_t crc = 0xFFFFFFFFu;
+    while (n >= 8) {
+        uint32_t a, b;
+        std::memcpy(&a, p, 4);
+        std::memcpy(&b, p + 4, 4);
+        a ^= crc;
+        crc = g_crc[7][a & 0xff] ^ g_crc[6][(a >> 8) & 0xff] ^ g_crc[5][(a >> 16) & 0xff] ^ g_crc[4][a >> 24] ^
+              g_crc[3][b & 0xff] ^ g_crc[2][(b >> 8) & 0xff] ^ g_crc[1][(b >> 16) & 0xff] ^ g_crc[0][b >> 24];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = g_crc[0][(crc ^ *p++) & 0xff] ^ (crc >> 8);
+    return crc ^ 0xFFFFFFFFu;
+}
+
+// length symbol / extra bits of a match length 3..258 (RFC 1951 3.2.5)
+struct LenCode { uint16_t sym; uint8_t extra_bits; uint16_t extra; };
+inline LenCode length_code(int len)
+{
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31,
+                                      35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const uint8_t ebits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2,
+                                      3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    int k = 28;
+    while (base[k] > len) --k;
+    return LenCode{(uint16_t)(257 + k), ebits[k], (uint16_t)(len - base[k])};
+}
+
+struct DistCode { int sym, extra_bits, extra; };
+inline DistCode distance_code(int dist)              // 1..32768
+{
+    static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513,
+                                      769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint8_t ebits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8,
+                                      9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    int k = 29;
+    while (base[k] > dist) --k;
+    return DistCode{k, ebits[k], dist - base[k]};
+}
+
+// one gzip member of src[0, len) with matches at distance D only; returns bytes written or -1
+int64_t record_member(const uint8_t *src, size_t len, int D, uint8_t *out, size_t cap)
+{
+    constexpr int MIN_MATCH = 4, MAX_MATCH = 258;
+    // tokens: < 256 literal, >= 256: match of length (tok - 256 + MIN_MATCH - ... ) -- kept as
+    // 0x8000 | length
+    std::vector<uint16_t> tok;
+    tok.reserve(len / 2 + 16);
+    uint64_t freq[286] = {0};
+    size_t n_match = 0;
+    {
+        size_t i = 0;
+        const size_t first = std::min<size_t>((size_t)D, len);
+        for (; i < first; ++i) { tok.push_back(src[i]); freq[src[i]]++; }
+        while (i < len) {
+            // run of bytes equal to the ones D earlier, 8 at a time
+            size_t L = 0;
+            const size_t maxl = std::min<size_t>((size_t)MAX_MATCH, len - i);
+            while (L + 8 <= maxl) {
+                uint64_t a, b;
+                std::memcpy(&a, src + i + L, 8);
+                std::memcpy(&b, src + i + L - D, 8);
+                const uint64_t x = a ^ b;
+                if (x) { L += (size_t)(__builtin_ctzll(x) >> 3); goto counted; }
+                L += 8;
+            }
+            while (L < maxl && src[i + L] == src[i + L - D]) ++L;
+        counted:
+            if (L >= (size_t)MIN_MATCH) {
+                tok.push_back((uint16_t)(0x8000u | L));
+                freq[length_code((int)L).sym]++;
+                ++n_match;
+                i += L;
+            } else {
+                // (the bytes up to the mismatch become literals too: a short run does not pay)
+                const size_t lit = L + 1 <= len - i ? L + 1 : len - i;
+                for (size_t k = 0; k < lit; ++k) { tok.push_back(src[i + k]); freq[src[i + k]]++; }
+                i += lit;
+            }
+        }
+    }
+    freq[256] = 1;
+    uint8_t llen[286];
+    uint16_t lcode[286];
+    code_lengths(freq, 286, llen);
+    canonical_codes(llen, 286, lcode);
+    const DistCode dc = distance_code(D);
+    if (cap < 18 + 400) return -1;
+    uint8_t *p = out;
+    const uint8_t gz[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+    std::memcpy(p, gz, 10);
+    p += 10;
+    BitWriter bw;
+    bw.p = p;
+    bw.end = out + cap - 8;
+    const int n_dist = n_match ? dc.sym + 1 : 1;
+    bw.put(1, 1);                                        // BFINAL
+    bw.put(2, 2);                                        // BTYPE = dynamic Huffman
+    bw.put(286 - 257, 5);                                // HLIT
+    bw.put((uint32_t)(n_dist - 1), 5);                   // HDIST
+    bw.put(15, 4);                                       // HCLEN: all 19 code length codes
+    // code-length alphabet: symbols 0..15 with 4-bit codes (complete), 16..18 unused; order
+    // 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    bw.put(0, 3); bw.put(0, 3); bw.put(0, 3);
+    for (int k = 0; k < 16; ++k) bw.put(4, 3);
+    for (int sy = 0; sy < 286; ++sy) bw.put(reverse_bits(llen[sy], 4), 4);
+    // distance code lengths: the one distance in use has a 1-bit code ("0"), the others none
+    for (int d = 0; d < n_dist; ++d) bw.put(reverse_bits((n_match && d == dc.sym) ? 1u : 0u, 4), 4);
+    // a 64-bit accumulator stored whole (slack past the end is guaranteed by the bound)
+    uint8_t *q = bw.p;
+    uint8_t *const qend = out + cap - 16;
+    uint64_t acc = bw.acc;
+    int nb = bw.n;
+    auto emit = [&](uint64_t b, int l) {                 // l <= 56
+        acc |= b << nb;
+        nb += l;
+        std::memcpy(q, &acc, 8);
+        q += nb >> 3;
+        acc >>= nb & ~7;
+        nb &= 7;
+    };
+    // per match length: the whole bit string (length code + extra, distance code "0" + extra)
+    uint64_t mbits[MAX_MATCH + 1];
+    uint8_t mlen[MAX_MATCH + 1];
+    for (int L = MIN_MATCH; L <= MAX_MATCH; ++L) {
+        const LenCode lc = length_code(L);
+        uint64_t b = lcode[lc.sym];
+        int l = llen[lc.sym];
+        b |= (uint64_t)lc.extra << l;
+        l += lc.extra_bits;
+        l += 1;                                          // the distance code: one 0 bit
+        b |= (uint64_t)dc.extra << l;
+        l += dc.extra_bits;
+        mbits[L] = b;
+        mlen[L] = (uint8_t)l;                            // <= 15 + 5 + 1 + 13
+    }
+    for (size_t k = 0; k < tok.size(); ++k) {
+        if (q >= qend) return -1;
+        const uint16_t t = tok[k];
+        if (t & 0x8000u) emit(mbits[t & 0x7FFF], mlen[t & 0x7FFF]);
+        else emit(lcode[t], llen[t]);
+    }
+    emit(lcode[256], llen[256]);
+    bw.p = q;
+    bw.acc = acc;
+    bw.n = nb;
+    bw.flush();
+    if (bw.overflow) return -1;
+    p = bw.p;
+    const uint32_t crc = crc32_bytes(src, len);
+    const uint32_t isize = (uint32_t)(len & 0xFFFFFFFFu);
+    for (int k = 0; k < 4; ++k) *p++ = (uint8_t)(crc >> (8 * k));
+    for (int k = 0; k < 4; ++k) *p++ = (uint8_t)(isize >> (8 * k));
+    return (int64_t)(p - out);
+}
+
+}  // namespace
+
+// upper bound of iamx_gzip_records' output: a Huffman code spends less than 9 bits on a byte of
+// its own histogram, a member carries a 150-byte code table and 18 bytes of gzip wrapper
+extern "C" int64_t iamx_gzip_records_bound(int64_t total, int64_t n_members)
+{
+    if (total < 0 || n_members < 0) return 0;
+    return total + (total >> 3) + 256 * (n_members + 1);
+}
+
+// gzip members of the buffers bufs[0..n_bufs) (as iamx_gzip_members: each member at most
+// member_bytes of input, never spanning two buffers, compressed on up to `threads` threads, written
+// back to back) with the record encoder above: matches at distance record_bytes only.  Returns the
+// number of bytes written or a negative error code; out_cap >= iamx_gzip_records_bound().
+extern "C" int64_t iamx_gzip_records(const uint8_t *const *bufs, const int64_t *lens, int n_bufs,
+                                     int64_t member_bytes, int record_bytes, int threads, uint8_t *out,
+                                     int64_t out_cap)
+{
+    if (!bufs || !lens || n_bufs < 0 || !out || member_bytes < 1 || member_bytes > (1ll << 30) ||
+        record_bytes < 1 || record_bytes > 32768)
+        return iamx::fail(IAMX_EINVAL, "iamx_gzip_records: bad argument");
+    crc_tables();
+    struct Part { const uint8_t *src; size_t len; uint8_t *dst; size_t cap; int64_t out; };
+    std::vector<Part> parts;
+    // (a literal costs at most 15 bits: twice the input + the 150-byte code table is a safe bound;
+    //  the parts are compacted afterwards)
+    auto bound = [](size_t n) { return 2 * n + 1024; };
+    size_t need = 0;
+    for (int b = 0; b < n_bufs; ++b) {
+        if (lens[b] < 0 || (lens[b] > 0 && !bufs[b])) return iamx::fail(IAMX_EINVAL, "iamx_gzip_records: bad buffer");
+        for (int64_t o = 0; o < lens[b]; o += member_bytes) {
+            const size_t n = (size_t)std::min<int64_t>(member_bytes, lens[b] - o);
+            parts.push_back(Part{bufs[b] + o, n, nullptr, bound(n), 0});
+            need += bound(n);
+        }
+    }
+    if (parts.empty()) {
+        parts.push_back(Part{reinterpret_cast<const uint8_t *>(""), 0, nullptr, bound(0), 0});
+        need = bound(0);
+    }
+    // the members are encoded into a scratch area of the worst-case size and copied together
+    std::vector<uint8_t> scratch(need);
+    size_t off = 0;
+    for (Part &c : parts) {
+        c.dst = scratch.data() + off;
+        off += c.cap;
+    }
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), parts.size()));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < parts.size(); i = next.fetch_add(1))
+            parts[i].out = record_member(parts[i].src, parts[i].len, record_bytes, parts[i].dst, parts[i].cap);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    size_t w = 0;
+    for (Part &c : parts) {
+        if (c.out < 0) return iamx::fail(IAMX_EINVAL, "iamx_gzip_records: member overflow");
+        if (w + (size_t)c.out > (size_t)out_cap) return iamx::fail(IAMX_EINVAL, "iamx_gzip_records: output buffer too small");
+        std::memcpy(out + w, c.dst, (size_t)c.out);
+        w += (size_t)c.out;
+    }
+    return (int64_t)w;
+}
+
 // dst[i] = (float)src[i]: the reference's float32 des_list from the detector's uint8 descriptors
 extern "C" int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads)
 {

@@ -117,37 +117,50 @@ struct PointMap {
 // process; what HugeBuf and matchpairs.empty_huge() go by), else 0
 extern "C" int iamx_thp_pays(void) { return thp_pays() ? 1 : 0; }
 
-// in : n_matches chains, chain i = points [ptr[i], ptr[i+1]) of (img[], kp[])
-// out: linked chains in the reference's order (NOT yet sorted by length), same flat layout;
-//      out arrays must hold ptr[n_matches] points / n_matches + 1 offsets.
-// returns the number of chains (>= 0) or a negative error code; *n_passes = passes executed.
-extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
-                                     int64_t n_matches, int32_t *out_img, int32_t *out_kp,
-                                     int64_t *out_ptr, int32_t *n_passes)
+namespace {
+// what fills the first pass's input: either the caller's flat chains, or blocks of pair matches
+struct LinkInput {
+    // form A: chains [ptr[i], ptr[i+1]) of (img[], kp[])
+    const int32_t *img = nullptr, *kp = nullptr;
+    const int64_t *ptr = nullptr;
+    // form B: n_blocks blocks of pair matches; block b = counts[b] rows [kp of image ij[2b],
+    // kp of image ij[2b+1]] (int32 [counts[b]][2], the arrays behind the images' match lists)
+    const int32_t *const *blocks = nullptr;
+    const int64_t *counts = nullptr;
+    const int32_t *ij = nullptr;
+    int64_t n_blocks = 0;
+};
+
+int64_t link_impl(const LinkInput &in, int64_t n_matches, int64_t n_pts, int32_t *out_img,
+                  int32_t *out_kp, int64_t *out_ptr, int32_t *n_passes)
 {
-    if (n_matches < 0 || !ptr || !out_ptr || (n_matches > 0 && (!img || !kp || !out_img || !out_kp))) {
-        iamx::fail(IAMX_EINVAL, "iamx_link_matches: null pointer or negative count");
-        return IAMX_EINVAL;
-    }
-    for (int64_t i = 0; i < n_matches; ++i)
-        if (ptr[i + 1] < ptr[i]) {
-            iamx::fail(IAMX_EINVAL, "iamx_link_matches: offsets not monotone");
-            return IAMX_EINVAL;
-        }
-    const int64_t n_pts = n_matches ? ptr[n_matches] : 0;
-    if (n_matches >= (1LL << 31) || n_pts >= (1LL << 31)) {
-        iamx::fail(IAMX_EINVAL, "iamx_link_matches: more than 2^31 matches / points");
-        return IAMX_EINVAL;
-    }
     try {
     const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // current pass input: flat points + offsets (rewritten in place per pass)
     HugeBuf<int32_t> c_img((size_t)n_pts), c_kp((size_t)n_pts);
     HugeBuf<int64_t> c_ptr((size_t)n_matches + 1);
-    std::memcpy(c_img.data(), img, (size_t)n_pts * sizeof(int32_t));
-    std::memcpy(c_kp.data(), kp, (size_t)n_pts * sizeof(int32_t));
-    std::memcpy(c_ptr.data(), ptr, (size_t)(n_matches + 1) * sizeof(int64_t));
-    if (getenv("IAMX_LINK_TIMING")) fprintf(stderr, "  copies: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
+    if (in.blocks) {
+        // pair matches: chain m = points 2m, 2m + 1; written straight into the work arrays (the
+        // python side used to concatenate the blocks, repeat (i, j) per match and build the
+        // offsets 0, 2, 4, ...: three fresh arrays of the size of these, then copied here)
+        int64_t m = 0;
+        for (int64_t b = 0; b < in.n_blocks; ++b) {
+            const int32_t i = in.ij[2 * b], j = in.ij[2 * b + 1];
+            const int32_t *blk = in.blocks[b];
+            for (int64_t k = 0; k < in.counts[b]; ++k, ++m) {
+                c_img[(size_t)(2 * m)] = i;
+                c_img[(size_t)(2 * m + 1)] = j;
+                c_kp[(size_t)(2 * m)] = blk[2 * k];
+                c_kp[(size_t)(2 * m + 1)] = blk[2 * k + 1];
+            }
+        }
+        for (int64_t q = 0; q <= n_matches; ++q) c_ptr[(size_t)q] = 2 * q;
+    } else {
+        std::memcpy(c_img.data(), in.img, (size_t)n_pts * sizeof(int32_t));
+        std::memcpy(c_kp.data(), in.kp, (size_t)n_pts * sizeof(int32_t));
+        std::memcpy(c_ptr.data(), in.ptr, (size_t)(n_matches + 1) * sizeof(int64_t));
+    }
+    const int32_t *img = c_img.data(), *kp = c_kp.data();   // (the scans below read the first pass's input)
     // chains under construction: every appended point is a NODE (image, keypoint, chain) written
     // sequentially in append order; a pass ends with a stable counting sort of the nodes by chain
     // (the chains in creation order, their points in insertion order).  Rounds 2-4 linked a
@@ -187,7 +200,6 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         if (base[(size_t)n_img] >= (1LL << 31)) dense = false;
         else table_n = (size_t)base[(size_t)n_img];
     }
-    if (getenv("IAMX_LINK_TIMING")) fprintf(stderr, "  dense scan: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_enter);
     HugeBuf<int32_t> table(dense ? table_n : 1);
     PointMap map(dense ? 0 : (size_t)n_pts);
     constexpr int64_t AHEAD = 48;                         // points of look-ahead for the prefetch
@@ -320,6 +332,62 @@ extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, cons
         iamx::fail(IAMX_ENOMEM, "iamx_link_matches: out of memory");
         return IAMX_ENOMEM;
     }
+}
+}  // namespace
+
+// in : n_matches chains, chain i = points [ptr[i], ptr[i+1]) of (img[], kp[])
+// out: linked chains in the reference's order (NOT yet sorted by length), same flat layout;
+//      out arrays must hold ptr[n_matches] points / n_matches + 1 offsets.
+// returns the number of chains (>= 0) or a negative error code; *n_passes = passes executed.
+extern "C" int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
+                                     int64_t n_matches, int32_t *out_img, int32_t *out_kp,
+                                     int64_t *out_ptr, int32_t *n_passes)
+{
+    if (n_matches < 0 || !ptr || !out_ptr || (n_matches > 0 && (!img || !kp || !out_img || !out_kp))) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_matches: null pointer or negative count");
+        return IAMX_EINVAL;
+    }
+    for (int64_t i = 0; i < n_matches; ++i)
+        if (ptr[i + 1] < ptr[i]) {
+            iamx::fail(IAMX_EINVAL, "iamx_link_matches: offsets not monotone");
+            return IAMX_EINVAL;
+        }
+    const int64_t n_pts = n_matches ? ptr[n_matches] : 0;
+    if (n_matches >= (1LL << 31) || n_pts >= (1LL << 31)) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_matches: more than 2^31 matches / points");
+        return IAMX_EINVAL;
+    }
+    LinkInput in;
+    in.img = img; in.kp = kp; in.ptr = ptr;
+    return link_impl(in, n_matches, n_pts, out_img, out_kp, out_ptr, n_passes);
+}
+
+// iamx_link_matches for the pair matches of make_match_structure() without the flat copies:
+// blocks[b] = int32 [counts[b]][2] (keypoint of image ij[2b], keypoint of image ij[2b + 1]), in
+// the reference's order of pairs; out arrays must hold 2 * sum(counts) points.
+extern "C" int64_t iamx_link_pair_blocks(const int32_t *const *blocks, const int64_t *counts,
+                                         const int32_t *ij, int64_t n_blocks, int32_t *out_img,
+                                         int32_t *out_kp, int64_t *out_ptr, int32_t *n_passes)
+{
+    if (n_blocks < 0 || !out_ptr || (n_blocks > 0 && (!blocks || !counts || !ij || !out_img || !out_kp))) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_pair_blocks: null pointer or negative count");
+        return IAMX_EINVAL;
+    }
+    int64_t n_matches = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        if (counts[b] < 0 || (counts[b] > 0 && !blocks[b])) {
+            iamx::fail(IAMX_EINVAL, "iamx_link_pair_blocks: negative count or null block");
+            return IAMX_EINVAL;
+        }
+        n_matches += counts[b];
+    }
+    if (2 * n_matches >= (1LL << 31)) {
+        iamx::fail(IAMX_EINVAL, "iamx_link_pair_blocks: more than 2^31 points");
+        return IAMX_EINVAL;
+    }
+    LinkInput in;
+    in.blocks = blocks; in.counts = counts; in.ij = ij; in.n_blocks = n_blocks;
+    return link_impl(in, n_matches, 2 * n_matches, out_img, out_kp, out_ptr, n_passes);
 }
 
 // One group level of scripts/lib/groups.py:59-118 compute() (HOST): pick the seed feature (the

@@ -495,6 +495,36 @@ extern "C" int iamx_desc_pack_f32(const float *src, int64_t n_rows, int8_t *dst,
     return pack_impl(src, n_rows, dst, norm_q, norm_t, stream, "iamx_desc_pack_f32");
 }
 
+// rows of `n_img` images of the original-order store back as uint8, laid back to back (image i:
+// rows [dst_off[i], dst_off[i + 1]) of dst): value = stored + 128.  What rebuilds another layout of
+// images whose source descriptors are no longer on the device (DescriptorStore.ensure_train_layout).
+namespace {
+__global__ __launch_bounds__(256) void unpack_u8_kernel(const int8_t *__restrict__ desc,
+                                                        const int32_t *__restrict__ img_off,
+                                                        const int64_t *__restrict__ dst_off,
+                                                        uint8_t *__restrict__ dst)
+{
+    const int img = blockIdx.y;
+    const int64_t n = dst_off[img + 1] - dst_off[img];
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;          // 16 bytes per thread
+    if (t >= n * 8) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(desc + (int64_t)img_off[img] * D)[t];
+    reinterpret_cast<uint4 *>(dst + dst_off[img] * D)[t] =
+        make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+}
+}  // namespace
+
+extern "C" int iamx_desc_unpack_u8(const int8_t *desc, const int32_t *img_off, const int64_t *dst_off,
+                                   int n_img, int max_rows_per_image, uint8_t *dst, void *stream)
+{
+    IAMX_REQUIRE(desc && img_off && dst_off && dst, "null pointer");
+    IAMX_REQUIRE(n_img >= 0 && max_rows_per_image >= 0, "bad count");
+    if (n_img == 0 || max_rows_per_image == 0) return IAMX_OK;
+    hipLaunchKernelGGL(unpack_u8_kernel, dim3((unsigned)(((int64_t)max_rows_per_image * 8 + 255) / 256), (unsigned)n_img),
+                       dim3(256), 0, iamx::as_stream(stream), desc, img_off, dst_off, dst);
+    return iamx::check_launch("iamx_desc_unpack_u8");
+}
+
 extern "C" int iamx_knn2_wg_per_pair(int n_query_rows)
 {
     return n_query_rows <= 0 ? 0 : (n_query_rows + QB - 1) / QB;

@@ -106,7 +106,12 @@ DESC_GZIP_LEVEL = 6 if _REF_GZIP else 1
 # cost of a fresh detection (tools/detect_stages.py: the GPU box's 16-core quota was spent on it).
 # Level 4 with Z_FILTERED (the records are mostly float bits: few matches, Huffman does the work) is
 # 72 ms for 24.9 bytes per keypoint -- the same bytes for every reader.  (6, 0) = the reference's.
-FEAT_GZIP_LEVEL, FEAT_GZIP_STRATEGY = (6, 0) if _REF_GZIP else (4, 1)
+# Round 5: the .feat members no longer go through zlib at all.  The pickle is a stream of 58-byte
+# records whose only redundancy is "same byte as one record earlier"; libiamx's record encoder
+# (iamx_gzip_records: matches at distance 58 only, dynamic Huffman code) writes valid gzip members
+# of the REFERENCE's size (28.5 bytes per keypoint, level 6 gives 28.4) in 18 ms of one core where
+# level 4 / Z_FILTERED took 99 ms -- more than the Huffman decode of the frame's JPEG (43 ms).
+FEAT_GZIP_LEVEL, FEAT_GZIP_STRATEGY = (6, 0) if _REF_GZIP else (4, ('records', 58))
 PREFETCH_DEPTH = min(24, max(6, (os.cpu_count() or 8) // 4))
 
 

@@ -93,6 +93,47 @@ class DescriptorStore(object):
     def __len__(self):
         return len(self.counts)
 
+    def ensure_train_layout(self, chunk_rows=4 << 20):
+        """Builds the parity-partitioned copy `desc2` of a store made without it, from the
+        original-order rows already on the device (iamx_desc_unpack_u8 -> iamx_desc2_pack_batch_u8,
+        a few million rows at a time).  Enqueued on the current stream; find_matches asks for it the
+        first time a round is routed to the one-direction sweep."""
+        if self.has_train_layout:
+            return
+        dev = self.desc.device
+        L, sp = lib(), stream_ptr()
+        total2 = max(int(self.offsets2[-1]), 1)
+        self.desc2 = torch.empty((total2, 128), dtype=I8, device=dev)
+        self.norm2 = torch.empty(total2, dtype=I32, device=dev)
+        self.cinit = torch.empty(total2, dtype=I32, device=dev)
+        self.perm = torch.empty(total2, dtype=I32, device=dev)
+        counts = np.asarray(self.counts, np.int64)
+        keep = []
+        first = 0
+        while first < len(counts):
+            k, rows = 0, 0
+            while first + k < len(counts) and (k == 0 or rows + counts[first + k] <= chunk_rows):
+                rows += int(counts[first + k])
+                k += 1
+            if rows:
+                off = np.zeros(k + 1, np.int64)
+                np.cumsum(counts[first:first + k], out=off[1:])
+                d_off = torch.from_numpy(off).to(dev)
+                u8 = torch.empty((rows, 128), dtype=U8, device=dev)
+                mx = int(counts[first:first + k].max())
+                check(L.iamx_desc_unpack_u8(_ptr(self.desc), _ptr(self.img_off[first:]), _ptr(d_off), k, mx,
+                                            _ptr(u8), sp), 'iamx_desc_unpack_u8')
+                scratch = torch.empty(3 * rows, dtype=I32, device=dev)
+                check(L.iamx_desc2_pack_batch_u8(_ptr(u8), _ptr(d_off), _ptr(self.img_off2[first:]), k, rows, mx,
+                                                 _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
+                                                 _ptr(self.perm), _ptr(self.meta[first]), _ptr(scratch), sp),
+                      'iamx_desc2_pack_batch_u8')
+                keep.append((d_off, u8, scratch))
+            first += k
+        torch.cuda.current_stream().synchronize()          # (the temporaries above)
+        del keep
+        self.has_train_layout = True
+
     def set_image(self, i, des, sync=True):
         """Pack descriptors of image i.  `des`: [n,128] float32 (cv2/reference layout, integer
         valued) or uint8, numpy or device tensor.  With sync=False the kernels are only

@@ -186,18 +186,16 @@ def make_match_structure(proj):
             blocks.append(np.asarray(matches, np.int32).reshape(-1, 2))
     counts = np.fromiter((len(b) for b in blocks), np.int64, len(blocks))
     n = int(counts.sum())
-    # what link_matches() reads: (image, keypoint) of both ends of every pair match, interleaved
-    # -- the keypoint side IS the concatenated pair arrays, the image side a repeat of (i, j) per
-    # pair.  (Round 3 built an int64 [n, 4] table pair by pair and sliced it apart again.)
-    kp = np.concatenate(blocks).ravel() if blocks else np.zeros(0, np.int32)
-    img = np.repeat(np.asarray(ij, np.int32).reshape(-1, 2), counts, axis=0).ravel() if blocks \
-        else np.zeros(0, np.int32)
+    blocks = [np.ascontiguousarray(b, np.int32) for b in blocks]
+    ij_arr = np.asarray(ij, np.int32).reshape(-1, 2)
     # the reference's [[None, -1, [i, a], [j, b]], ...] (match_cleanup.py:190-215), as a list
-    # that is only built when somebody other than link_matches() looks into it
-    matches_direct = DirectMatches(img, kp)
-    # link_matches() normally receives this very object: the array form goes with it
-    proj._iamx_direct = (matches_direct, n, np.ascontiguousarray(img, np.int32),
-                         np.ascontiguousarray(kp, np.int32), np.arange(n + 1, dtype=np.int64) * 2)
+    # that is only built when somebody other than link_matches() looks into it -- and so are the
+    # flat (image, keypoint) arrays behind it: link_matches() hands the blocks themselves to
+    # libiamx (round 4 concatenated them, repeated (i, j) per match and built the offsets
+    # 0, 2, 4, ...: three fresh arrays of 8 bytes per match each)
+    matches_direct = DirectMatches.from_blocks(ij_arr, counts, blocks)
+    # link_matches() normally receives this very object: the block form goes with it
+    proj._iamx_direct = (matches_direct, n, ij_arr, counts, blocks)
     if n:
         _log("Total feature pairs in image set:", n)
         _log("Keypoint average instances = %.1f (should be 2.0 here)" % 2.0)
@@ -214,16 +212,37 @@ class DirectMatches(object):
         self._img = np.asarray(img).reshape(-1, 2)
         self._kp = np.asarray(kp).reshape(-1, 2)
         self._rows = None
+        self._blocks = None
+        self._n = len(self._img)
+
+    @classmethod
+    def from_blocks(cls, ij, counts, blocks):
+        """pair (ij[b, 0], ij[b, 1]) contributes the rows of blocks[b] ([n, 2] keypoint indices);
+        the flat arrays are made when somebody asks for them"""
+        self = object.__new__(cls)
+        self._img = self._kp = self._rows = None
+        self._blocks = (np.asarray(ij, np.int32).reshape(-1, 2), np.asarray(counts, np.int64), blocks)
+        self._n = int(self._blocks[1].sum())
+        return self
+
+    def arrays(self):
+        """(img, kp): int32 [n, 2] each"""
+        if self._img is None:
+            ij, counts, blocks = self._blocks
+            self._kp = np.concatenate(blocks).reshape(-1, 2) if blocks else np.zeros((0, 2), np.int32)
+            self._img = np.repeat(ij, counts, axis=0) if blocks else np.zeros((0, 2), np.int32)
+        return self._img, self._kp
 
     def rows(self):
         if self._rows is None:
+            img, kp = self.arrays()
             with _no_gc():
                 self._rows = [[None, -1, [i, a], [j, b]] for (i, j), (a, b)
-                              in zip(self._img.tolist(), self._kp.tolist())]
+                              in zip(img.tolist(), kp.tolist())]
         return self._rows
 
     def __len__(self):
-        return len(self._img) if self._rows is None else len(self._rows)
+        return self._n if self._rows is None else len(self._rows)
 
     def __getitem__(self, k):
         return self.rows()[k]
@@ -349,17 +368,24 @@ def link_matches(proj, matches_direct):
     _log("Linking common matches together into chains:")
     n = len(matches_direct)
     cached = getattr(proj, '_iamx_direct', None)
-    if cached is not None and cached[0] is matches_direct and cached[1] == n \
-            and matches_direct.untouched():
-        img, kp, ptr = cached[2:]                 # untouched output of make_match_structure()
-    else:
-        img, kp, ptr = _flatten(matches_direct)
-    o_img, o_kp = np.empty_like(img), np.empty_like(kp)
-    o_ptr = np.zeros(n + 1, np.int64)
     passes = np.zeros(1, np.int32)
     P = lambda a: c_void_p(a.ctypes.data)
-    n_chain = int(lib().iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr),
-                                          P(passes)))
+    if cached is not None and cached[0] is matches_direct and cached[1] == n \
+            and matches_direct.untouched():
+        # untouched output of make_match_structure(): the pair blocks as they lie
+        import ctypes
+        ij, counts, blocks = cached[2:]
+        o_img, o_kp = empty_huge(2 * n, np.int32), empty_huge(2 * n, np.int32)
+        o_ptr = np.zeros(n + 1, np.int64)
+        ptrs = (ctypes.c_void_p * max(len(blocks), 1))(*[b.ctypes.data for b in blocks])
+        n_chain = int(lib().iamx_link_pair_blocks(ptrs, P(counts), P(np.ascontiguousarray(ij)), len(blocks),
+                                                  P(o_img), P(o_kp), P(o_ptr), P(passes)))
+    else:
+        img, kp, ptr = _flatten(matches_direct)
+        o_img, o_kp = np.empty_like(img), np.empty_like(kp)
+        o_ptr = np.zeros(n + 1, np.int64)
+        n_chain = int(lib().iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr),
+                                              P(passes)))
     if n_chain < 0:
         raise RuntimeError("iamx_link_matches failed (%d): %s"
                            % (n_chain, (lib().iamx_last_error() or b'?').decode()))

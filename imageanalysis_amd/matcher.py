@@ -55,6 +55,38 @@ PREWARM_ROUNDS = 32     # a call with at least this many rounds fills its buffer
 EARLY_SMART_ROUNDS = 8  # rounds in a row without a match before smart.json is written ahead of time
 early_smart_stats = {'written': 0, 'current_at_end': 0}     # (tests / diagnosis)
 PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
+# Which sweep a round of find_matches takes.  The symmetric sweep (one MFMA pass per image pair)
+# leaves the rows whose bounds pass the metric test to an exact stage that runs at half the sweep's
+# rate: 0.47 + 1.9 f units of time per pair for a candidate share f of the rows.  On unrelated or
+# barely overlapping frames f is ~0.001; on overlapping frames of real imagery it is 0.3-0.6 (typical
+# nearest-neighbour distances of SIFT descriptors sit right at the reference's 270 x ratio threshold)
+# and the one-direction bound form -- two sweeps per pair, best exact, nothing left for an exact
+# stage but the few survivors -- is faster: 0.74 units whatever f is.  'auto': a round takes the
+# one-direction form when the last symmetric round it knows of had f above DENSE_SHARE; every
+# DENSE_PROBE-th such round is symmetric again and measures f anew (a distance-sorted schedule
+# goes from dense to sparse once).  'never' / 'always' pin the choice (tests, A/B).  Results are
+# identical either way -- both forms end in exact top-2 distances (tests/test_mirror_gpu.py).
+DENSE_ROUTE = os.environ.get('IAMX_DENSE_ROUTE', 'auto')
+DENSE_SHARE = 0.15
+DENSE_PROBE = 4
+_route = {'share': None, 'since_probe': 0, 'rounds': [0, 0]}     # rounds: [symmetric, one-direction]
+
+
+def _route_reset():
+    _route.update(share=None, since_probe=0, rounds=[0, 0])
+
+
+def _route_next():
+    """True: the next round takes the one-direction form"""
+    if DENSE_ROUTE == 'always':
+        return True
+    if DENSE_ROUTE != 'auto' or _route['share'] is None or _route['share'] < DENSE_SHARE:
+        return False
+    _route['since_probe'] += 1
+    if _route['since_probe'] >= DENSE_PROBE:
+        _route['since_probe'] = 0
+        return False
+    return True
 
 
 def _workspace_bytes_per_pair(rows):
@@ -204,14 +236,19 @@ class DeviceMatcher(object):
             self._kp_dev = (n, d_off, d_xy, d_k2, rows)
         return self._kp_dev[1:4]
 
+    def want_train_layout(self):
+        """from now on the arena carries the parity-partitioned copy the one-direction sweep reads"""
+        self._train_layout = True
+
     def store(self):
         """(Re)build the arena when new images arrived; old rows are copied on the device."""
         from . import kernels
         pend = self._pending
+        want_train = getattr(self, '_train_layout', False)
         if self._store is None or len(self._store.counts) != len(self._counts):
             # (no parity-partitioned copy: find_matches' batches hold both directions of every
             #  pair -- a third less arena, 104 instead of 155 GB for 10 000 frames of 37 k keypoints)
-            new = kernels.DescriptorStore(self._counts, train_layout=False)
+            new = kernels.DescriptorStore(self._counts, train_layout=want_train)
             if self._store is not None and len(self._store.counts):
                 old = self._store
                 n_old, n_old2, k = int(old.offsets[-1]), int(old.offsets2[-1]), len(old.counts)
@@ -219,6 +256,8 @@ class DeviceMatcher(object):
                 new.norm_q[:n_old].copy_(old.norm_q[:n_old])
                 new.norm_t[:n_old].copy_(old.norm_t[:n_old])
                 # ... and the train-side (parity partitioned) form the fast kernel reads
+                if new.has_train_layout and not old.has_train_layout:
+                    old.ensure_train_layout()
                 if old.has_train_layout and new.has_train_layout:
                     new.desc2[:n_old2].copy_(old.desc2[:n_old2])
                     new.norm2[:n_old2].copy_(old.norm2[:n_old2])
@@ -251,6 +290,8 @@ class DeviceMatcher(object):
             torch.cuda.current_stream().synchronize()        # one sync for the whole batch
         del keep
         self._pending = []
+        if want_train and not self._store.has_train_layout:
+            self._store.ensure_train_layout()
         return self._store
 
 
@@ -737,7 +778,7 @@ def _host_set(n, clip, surface):
         return free.pop()
     pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)
     hs = dict(key=(n, clip, surface), zero_div=pin(2, torch.int32),
-              count=pin(2 * n, torch.int32))
+              count=pin(2 * n, torch.int32), cand=pin(2 * n, torch.int32))
     if clip:
         # the matches of the pairs that have some, packed back to back by the device
         # (iamx_match_pack_results writes these page-locked buffers directly)
@@ -788,7 +829,7 @@ def _prewarm_pools(n, rows, surface, dev, stream, sets=3):
         _ws_pool.extend(work)
 
 
-def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
+def _launch_batch(batch, match_ratio, device_filters=True, surface=False, one_direction=False):
     """batch: list of (i1, i2) image objects.  ENQUEUES, on the current stream, the device k=2
     NN + metric threshold for both directions of every pair, the per-pair filters (sort/clip,
     GMS, de-dup, gates, cross check: iamx_match_postfilter) unless `device_filters` is False,
@@ -819,6 +860,8 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
         # new images: the descriptor / keypoint arenas are about to be rebuilt, and the previous
         # round's side-stream kernels may still be reading the old ones
         torch.cuda.current_stream().wait_stream(_side_stream())
+    if one_direction:
+        dm.want_train_layout()            # (the parity-partitioned copy, built on first use)
     store = dm.store()
     arena = _upload_arena()
     arena.begin()
@@ -846,8 +889,9 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False):
         d_ik = arena.put(np.ascontiguousarray(IK.ravel()))
     sl = np.asarray(slots, np.int32).reshape(-1, 2)
     ordered = np.concatenate([sl, sl[:, ::-1]])
-    pb = kernels.PairBatch(store, ordered, arena=arena)
+    pb = kernels.PairBatch(store, ordered, sym=False if one_direction else None, arena=arena)
     arena.commit()
+    _route['rounds'][0 if pb.sym else 1] += 1
     ws = _workspace(pb.rows, pb.n_pairs)
     # (the kernels only ever RAISE this flag: a pooled workspace that reported a zero distance --
     #  the ZeroDivisionError of matcher.py:255 -- would fail every later batch that draws it)
@@ -926,6 +970,8 @@ def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d
     hs = _host_set(n, clip, surface and post is not None)
     hs['zero_div'].copy_(ws.flags, non_blocking=True)
     hs['count'].copy_(ws.surv_cnt[:2 * n], non_blocking=True)
+    if pb.sym and pb.rows and pb.n_pairs:
+        hs['cand'].copy_(ws.seg_count[:2 * n], non_blocking=True)     # candidate rows per ordered pair
     if post is not None:
         hs['cnt'].copy_(post['cnt'], non_blocking=True)
         hs['status'].copy_(post['status'], non_blocking=True)
@@ -940,7 +986,8 @@ def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d
             hs['aff_ok'].copy_(post['aff_ok'], non_blocking=True)
     done_ev = torch.cuda.Event()
     done_ev.record()
-    return dict(batch=batch, n=n, ws=ws, pb=pb, post=post, host=hs, done=done_ev, surface=surface)
+    return dict(batch=batch, n=n, ws=ws, pb=pb, post=post, host=hs, done=done_ev, surface=surface,
+                sym=bool(pb.sym and pb.rows and pb.n_pairs), rows=int(pb.rows))
 
 
 def _finish_batch(h):
@@ -959,6 +1006,8 @@ def _finish_batch(h):
             #  construction; a .match file written past this would be silently wrong)
             raise RuntimeError("libiamx: %d query rows left unresolved by the exact stage"
                                % int(hs['zero_div'][1]))
+        if h.get('sym'):
+            _route['share'] = float(hs['cand'].numpy()[:2 * n].sum(dtype=np.int64)) / max(h['rows'], 1)
         count = hs['count'].numpy().astype(np.int64)
         first = sq = st = sm = status = cnt = lists = None
         z_rows = {}
@@ -1080,6 +1129,8 @@ def _finish_batch_arrays(h):
             #  construction; a .match file written past this would be silently wrong)
             raise RuntimeError("libiamx: %d query rows left unresolved by the exact stage"
                                % int(hs['zero_div'][1]))
+        if h.get('sym'):
+            _route['share'] = float(hs['cand'].numpy()[:2 * n].sum(dtype=np.int64)) / max(h['rows'], 1)
         count = hs['count'].numpy()
         R.n_fwd, R.n_rev = count[:n].astype(np.int64), count[n:2 * n].astype(np.int64)
         if post is None:
@@ -1360,6 +1411,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
         configure()
     if isinstance(the_matcher, DeviceMatcher):
         the_matcher._pose_epoch = object()
+    _route_reset()
     smart = _deps.smart()
     if hasattr(smart, 'freeze_poses'):
         smart.freeze_poses(True)
@@ -1563,8 +1615,8 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             if rows[k] <= 1:
                 # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                 raise ZeroDivisionError("float division by zero")
-        handle = _launch_batch(view, match_ratio, surface=True) if batched_surface \
-            else _launch_batch(view, match_ratio)
+        handle = _launch_batch(view, match_ratio, surface=bool(batched_surface),
+                               one_direction=_route_next())
         return view, a, rows, handle
 
     def finish_round(launched):

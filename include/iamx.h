@@ -54,6 +54,12 @@ int iamx_desc_pack_u8(const uint8_t *src, int64_t n_rows, int8_t *dst,
                       int32_t *norm_q, int32_t *norm_t, void *stream);
 int iamx_desc_pack_f32(const float *src, int64_t n_rows, int8_t *dst,
                        int32_t *norm_q, int32_t *norm_t, void *stream);
+/* the inverse for n_img images of a packed store: image i's rows (first stored row img_off[i]) as
+ * uint8 at rows [dst_off[i], dst_off[i+1]) of dst -- the source a different layout of the same
+ * images is packed from once their descriptors have left the host (scripts/lib/matcher.py:1012-1026
+ * drops them from memory on a timer).  img_off DEV [n_img] int32, dst_off DEV [n_img+1] int64. */
+int iamx_desc_unpack_u8(const int8_t *desc, const int32_t *img_off, const int64_t *dst_off, int n_img,
+                        int max_rows_per_image, uint8_t *dst, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * K2: exact 2-nearest-neighbour search in L2 -- replaces
@@ -320,6 +326,13 @@ int iamx_thp_pays(void);
 int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *ptr,
                           int64_t n_matches, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                           int32_t *n_passes);
+/* iamx_link_pair_blocks -- the same for the pair matches of make_match_structure()
+ * (match_cleanup.py:190-215) handed over as they lie in the images' match lists: blocks[b] = HOST
+ * int32 [counts[b]][2] (keypoint of image ij[2b], keypoint of image ij[2b+1]), pairs in the
+ * reference's order; out arrays hold 2 * sum(counts) points / sum(counts) + 1 offsets. */
+int64_t iamx_link_pair_blocks(const int32_t *const *blocks, const int64_t *counts, const int32_t *ij,
+                              int64_t n_blocks, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
+                              int32_t *n_passes);
 /* HOST helpers of the same stage.  iamx_chains_longest_first: the chains of iamx_link_matches in
  * the order match_cleanup.py:291-292 leaves them (stable sort by length, longest first), members
  * copied on `threads` threads; out arrays sized like the input, out_ptr [n_chains + 1].
@@ -546,6 +559,16 @@ int64_t iamx_gzip_f32_from_u8(const uint8_t *header, int64_t n_header, const uin
 int64_t iamx_gzip_members_bound(int64_t total_bytes, int64_t n_members);
 int64_t iamx_gzip_members(const uint8_t *const *bufs, const int64_t *lens, int n_bufs,
                           int64_t member_bytes, int level, int strategy, int threads, uint8_t *out,
+                          int64_t out_cap);
+/* iamx_gzip_records -- HOST.  iamx_gzip_members for streams of fixed-width records (the .feat
+ * pickle of scripts/lib/image.py:192-203: 58 bytes per keypoint): a DEFLATE encoder that only
+ * looks for matches at distance record_bytes (one compare pass, dynamic Huffman code, no hash
+ * chains) -- valid gzip members, the same payload for every reader, smaller than zlib's level 4
+ * output on such streams and several times faster.  out_cap >= iamx_gzip_records_bound(total
+ * input bytes, number of members). */
+int64_t iamx_gzip_records_bound(int64_t total, int64_t n_members);
+int64_t iamx_gzip_records(const uint8_t *const *bufs, const int64_t *lens, int n_bufs,
+                          int64_t member_bytes, int record_bytes, int threads, uint8_t *out,
                           int64_t out_cap);
 int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads);
 /* the other way for a whole survey: the float32 des_list of n images (scripts/lib/image.py:324,

@@ -283,3 +283,36 @@ def test_native_float32_conversion_and_feat_records():
     blob = kl.feat_bytes()
     assert isinstance(blob, bytes) and pickle.loads(blob) == want
     assert bytes(kl.feat_bytes(as_view=True)) == blob
+
+
+def test_record_deflate_members_are_plain_gzip_and_small():
+    """iamx_gzip_records (the .feat writer since round 5): DEFLATE with matches one record back
+    only.  Any gzip reader inflates the members to the payload -- python's gzip / zlib here, the
+    reference's `pickle.load(gzip.open(...))` (scripts/lib/image.py:140-150) on a real .feat -- and
+    the file is no larger than zlib's level 4 / Z_FILTERED output it replaces."""
+    import pickle
+    import zlib
+    from imageanalysis_amd.keypoints import KeyPointList
+    rng = np.random.default_rng(12)
+    n = 30000
+    kl = KeyPointList(rng.uniform(0, 5472, n), rng.uniform(0, 3648, n),
+                      2.0 * 1.6 * 2 ** rng.uniform(0, 5, n), rng.uniform(0, 360, n), rng.uniform(0.02, 0.1, n),
+                      (rng.integers(0, 6, n) | (rng.integers(1, 4, n) << 8) | (rng.integers(0, 256, n) << 16)))
+    payload = bytes(kl.feat_bytes())
+    members = cacheio.gzip_member_list(payload, 4, 384 << 10, ('records', 58))
+    blob = b''.join(bytes(m) for m in members)
+    assert gzip.decompress(blob) == payload
+    assert pickle.load(gzip.GzipFile(fileobj=io.BytesIO(blob))) == pickle.loads(payload)
+    zl = b''.join(bytes(m) for m in cacheio.gzip_member_list(payload, 4, 384 << 10, 1))
+    assert len(blob) <= len(zl)
+    # the first member alone is a complete gzip stream of the first 384 KiB
+    d = zlib.decompressobj(47)
+    assert d.decompress(blob) == payload[:384 << 10] and d.eof
+    # degenerate inputs, record widths, member sizes
+    cases = [b'', b'a', b'abc' * 5, bytes(range(256)) * 3, b'\x00' * 100000,
+             rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), payload[:57], payload[:59]]
+    for pl in cases:
+        for mb in (1000, 384 << 10):
+            for rec in (58, 1, 7, 32768):
+                out = b''.join(bytes(m) for m in cacheio.gzip_member_list(pl, 4, mb, ('records', rec)))
+                assert gzip.decompress(out) == pl, (len(pl), mb, rec)

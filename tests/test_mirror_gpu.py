@@ -378,3 +378,62 @@ def test_smart_json_written_ahead_of_time_equals_the_final_one(tmp_path, sort):
         matcher.PAIRS_PER_BATCH, matcher.EARLY_SMART_ROUNDS = old
     assert files['early'] == files['plain']
     assert any('yaw_pairs' in v or 'tri_surface_pairs' in v for v in files['early'].values())
+
+
+@pytest.mark.parametrize('route', ['never', 'always', 'auto'])
+def test_find_matches_dense_routing_gives_the_same_lists(route):
+    """A round of find_matches may take the symmetric sweep or the one-direction bound form
+    (matcher.DENSE_ROUTE): every match list == the oracle's bidirectional pipeline either way, with
+    the arena growing in between (the parity-partitioned copy is rebuilt from the rows already on
+    the device) and, in 'auto', rounds of both kinds in one call."""
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from oracle import match_oracle as mo
+    from test_match_gpu import _sift_like
+    matcher = _configure(0.75, 25)
+    rng = np.random.default_rng(53)
+    n_img, W, H = 8, 5472, 3648
+    names = ['R%02d' % i for i in range(n_img)]
+    proj = PoseProject(names)
+    des, xy = [], []
+    for i in range(n_img):
+        n = 2100 + 130 * i
+        d = _sift_like(rng, n)
+        p = np.stack([rng.uniform(600, W - 600, n), rng.uniform(400, H - 400, n)], 1)
+        if i:
+            # the first images overlap heavily (and their unmatched rows sit close to the metric
+            # threshold: many candidate rows), the last ones barely
+            k = int((0.6 if i < 5 else 0.03) * min(n, len(des[i - 1])))
+            src, dst = rng.permutation(len(des[i - 1]))[:k], rng.permutation(n)[:k]
+            d[dst] = np.clip(des[i - 1][src].astype(int) + rng.integers(-5, 6, (k, 128)), 0, 255)
+            p[dst] = xy[i - 1][src] + [250.0, -120.0] + rng.normal(0, 0.6, (k, 2))
+        des.append(d)
+        xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
+    for i, im in enumerate(proj.image_list):
+        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        fresh = _image(names[i], des[i], xy[i])
+        im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
+    old = (matcher.PAIRS_PER_BATCH, matcher.DENSE_ROUTE, matcher.DENSE_SHARE, matcher.DENSE_PROBE)
+    matcher.PAIRS_PER_BATCH, matcher.DENSE_ROUTE = 3, route
+    if route == 'auto':
+        matcher.DENSE_SHARE, matcher.DENSE_PROBE = 0.0005, 3      # (any candidates at all: dense)
+    try:
+        matcher.find_matches(proj, None, strategy='traditional', sort=True)
+        rounds = list(matcher._route['rounds'])
+    finally:
+        matcher.PAIRS_PER_BATCH, matcher.DENSE_ROUTE, matcher.DENSE_SHARE, matcher.DENSE_PROBE = old
+    assert sum(rounds) >= 6
+    if route == 'never':
+        assert rounds[1] == 0
+    elif route == 'always':
+        assert rounds[0] == 0
+    else:
+        assert rounds[0] >= 2 and rounds[1] >= 2, rounds
+    n_nonempty = 0
+    for i in range(n_img):
+        for j in range(i + 1, min(i + 5, n_img)):
+            f, r = mo.bidirectional_pair_matches(des[i], xy[i], des[j], xy[j], 0.75, 25, (W, H))
+            a, b = proj.image_list[i], proj.image_list[j]
+            assert np.array_equal(np.array(a.match_list[names[j]]).reshape(-1, 2), f), (route, i, j)
+            assert np.array_equal(np.array(b.match_list[names[i]]).reshape(-1, 2), r), (route, i, j)
+            n_nonempty += len(f) > 0
+    assert n_nonempty >= 4

@@ -30,11 +30,21 @@ def main():
     getNode('/config/detector', True).setString('detector', 'SIFT')
     camera.set_image_params(5472, 3648)
     t0 = time.time()
-    for k in range(n):
-        bgr = synth.make_survey_image(seed=k).cpu().numpy()
-        PILImage.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(
-            os.path.join(tmp, 'images', 'D%04d.JPG' % k), quality=92)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=12) as pool:           # (the encoder releases the interpreter)
+        futs = []
+        for k in range(n):
+            bgr = synth.make_survey_image(seed=k).cpu().numpy()
+            futs.append(pool.submit(PILImage.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save,
+                                    os.path.join(tmp, 'images', 'D%04d.JPG' % k), quality=92))
+            while len(futs) > 24:
+                futs.pop(0).result()
+        for f in futs:
+            f.result()
     print('%d synthetic 5472x3648 JPEGs written in %.1f s' % (n, time.time() - t0))
+    if '--feat-zlib' in sys.argv:
+        iimg.FEAT_GZIP_STRATEGY = 1                            # round 4's .feat members: zlib level 4, Z_FILTERED
+        print('.feat through zlib (level %d, Z_FILTERED)' % iimg.FEAT_GZIP_LEVEL)
 
     def project(tag):
         an = os.path.join(tmp, 'ImageAnalysis_' + tag)
@@ -47,15 +57,16 @@ def main():
     cacheio.wait()
 
     # (a) serial, synchronous cache writes
-    imgs = project('serial')
-    iimg.ASYNC_CACHE_WRITES = False
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for im in imgs:
-        im.detect_features(0.4)
-    ta = time.perf_counter() - t0
-    nk = sum(len(im.kp_list) for im in imgs) / float(n)
-    print('serial    : %.2f s = %.2f images/s (%.0f keypoints/image)' % (ta, n / ta, nk))
+    if '--no-serial' not in sys.argv:
+        imgs = project('serial')
+        iimg.ASYNC_CACHE_WRITES = False
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for im in imgs:
+            im.detect_features(0.4)
+        ta = time.perf_counter() - t0
+        nk = sum(len(im.kp_list) for im in imgs) / float(n)
+        print('serial    : %.2f s = %.2f images/s (%.0f keypoints/image)' % (ta, n / ta, nk))
 
     # (b) prefetch + background writes; the files must be complete when the clock stops
     imgs = project('overlap')
