@@ -447,6 +447,7 @@ def main():
             "mfma_busy": g(roofline, "mfma_busy"), "match_traffic_bytes": g(roofline, "traffic"),
             "survey_2812_pairs_per_sec": g(survey, "value"), "survey_2812_seconds": g(survey, "seconds_per_step"),
             "dense_overlap_pairs_per_sec": g(dense, "pairs_per_sec"),
+            "dense_overlap_routed_pairs_per_sec": g(dense, "routed_pairs_per_sec"),
             "ba_seconds_to_ftol": g(ba, "seconds_to_ftol"), "ba_trf_it_per_sec": g(ba, "value"),
             "ba_residual_frac_cache": g(ba, "residual", "frac"),
             "ba_residual_frac_out_of_cache": g(ba, "residual", "out_of_cache", "frac"),
@@ -583,6 +584,34 @@ def dense_overlap_bench(dev, oracle_pairs=4):
                 and np.array_equal(sm[lo:hi], metric[keep])):
             raise RuntimeError("dense-overlap self-check: pair (%d, %d) differs from the oracle" % (a, b))
         checked += 1
+    # the same pairs through the one-direction bound form (what find_matches routes a dense round
+    # to, matcher.DENSE_ROUTE): two sweeps per pair, survivors finished exactly; same survivors
+    pb1 = kernels.PairBatch(store, ordered, sym=False)
+    ws1 = kernels.PairWorkspace(pb1.rows, pb1.n_pairs)
+    best1 = None
+    for _ in range(3):
+        ev[0].record()
+        pb1.run_knn2_fast(ws1)
+        ev[1].record()
+        pb1.run_filter_fast(ws1, thresh)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t = (ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
+        best1 = t if best1 is None or sum(t) < sum(best1) else best1
+    f1, c1, sq1, st1, sm1 = ws1.survivors(pb1.n_pairs)
+    for p_ in range(pb.n_pairs):
+        lo, hi, lo1, hi1 = first[p_], first[p_] + count[p_], f1[p_], f1[p_] + c1[p_]
+        if not (np.array_equal(sq[lo:hi], sq1[lo1:hi1]) and np.array_equal(st[lo:hi], st1[lo1:hi1])
+                and np.array_equal(sm[lo:hi], sm1[lo1:hi1])):
+            raise RuntimeError("dense-overlap self-check: the two forms differ on ordered pair %d" % p_)
+    if int(ws1.unresolved.item()):
+        raise RuntimeError("dense-overlap: unresolved rows in the one-direction form")
+    one_dir = {"sweeps_ms": round(best1[0], 3), "filter_and_finish_ms": round(best1[1], 3),
+               "pairs_per_sec": round(len(und) / (sum(best1) * 1e-3), 1),
+               "pairs_per_sec_in_4096_row_units": round(len(und) * (rows / float(KPTS)) ** 2 / (sum(best1) * 1e-3), 1),
+               "speedup_over_symmetric": round(sum(best) / sum(best1), 3),
+               "survivors_equal_symmetric_form": True}
+    del pb1, ws1
     flop_exact = 2.0 * cand * rows * DIM
     flop_sweep = 2.0 * len(und) * rows * rows * DIM
     return {"workload": "%d images x %d rows, 55 %% of every image's rows are noisy copies of rows of "
@@ -596,6 +625,8 @@ def dense_overlap_bench(dev, oracle_pairs=4):
             "exact_stage_tflops": round(flop_exact / (best[1] * 1e-3) / 1e12, 1),
             "exact_stage": "symexact_wg_kernel: 256 candidates per workgroup, train tiles shared through "
                            "LDS (+ candidate test, compaction in the same interval)",
+            "one_direction_form": one_dir,
+            "routed_pairs_per_sec": round(max(len(und) / (sum(best) * 1e-3), one_dir["pairs_per_sec"]), 1),
             "verified_pairs": checked, "against": "oracle/cpu_ref.c"}
 
 

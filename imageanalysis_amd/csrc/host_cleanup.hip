@@ -9,6 +9,8 @@
 // at 2812-10 k images this serial python is the wall-clock bottleneck after
 // GPU matching; here it is flat arrays + one hash map, O(points) per pass.
 #include "iamx_common.h"
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 
 #include <cstdlib>
@@ -623,6 +625,83 @@ extern "C" int iamx_first_occurrence(const int64_t *key, int64_t n, int64_t *fir
         if (slot[at] < 0) slot[at] = k;
         first[k] = slot[at];
     }
+    return IAMX_OK;
+}
+
+// One pass over the images' match lists for the three per-list loops in front of link_matches
+// (scripts/lib/match_cleanup.py:19-188 + lib/project.py:331-350): list b = int32 [cnt[b]][2],
+// column 0 keypoints of image ia[b], column 1 of image ib[b]; keypoints of image i live at
+// [kp_base[i], kp_base[i + 1]) of the flat per-keypoint arrays.
+//   mode & 1  compute_kp_usage:   used[kp_base[ia] + a] = used[kp_base[ib] + b] = 1
+//   mode & 2  merge_duplicates:   a <- remap[kp_base[ia] + a], b <- remap[kp_base[ib] + b], IN PLACE
+//   mode & 4  check_for_pair_dups / check_for_1vn_dups: dup_pairs[b] = rows that repeat an earlier
+//             row of the list, dup_first[b] = rows whose column 0 repeats an earlier row's
+// A python loop over the lists did each of these with two or three numpy calls per list: 64 k lists
+// of ~2 k rows on a 2048-frame survey, 6 s of the consolidation stage in np.sort / np.unique.
+// Lists are independent; `threads` of them are scanned at a time.
+extern "C" int iamx_match_lists_scan(int32_t *const *lists, const int64_t *cnt, const int32_t *ia,
+                                     const int32_t *ib, int64_t n_lists, const int64_t *kp_base,
+                                     int32_t n_images, uint8_t *used, const int32_t *remap, int mode,
+                                     int32_t *dup_pairs, int32_t *dup_first, int threads)
+{
+    if (n_lists < 0 || !kp_base || n_images < 0 ||
+        (n_lists > 0 && (!lists || !cnt || !ia || !ib)) || ((mode & 1) && !used) ||
+        ((mode & 2) && !remap) || ((mode & 4) && (!dup_pairs || !dup_first)))
+        return iamx::fail(IAMX_EINVAL, "iamx_match_lists_scan: null pointer or negative count");
+    for (int64_t b = 0; b < n_lists; ++b)
+        if (cnt[b] < 0 || (cnt[b] > 0 && !lists[b]) || ia[b] < 0 || ia[b] >= n_images || ib[b] < 0 ||
+            ib[b] >= n_images)
+            return iamx::fail(IAMX_EINVAL, "iamx_match_lists_scan: bad list %lld", (long long)b);
+    std::atomic<int64_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        std::vector<uint64_t> slot;                       // open addressing, 0 = empty (codes are + 1)
+        std::vector<uint32_t> slot1;
+        for (int64_t b = next.fetch_add(1); b < n_lists; b = next.fetch_add(1)) {
+            int32_t *p = lists[b];
+            const int64_t n = cnt[b];
+            const int64_t ba = kp_base[ia[b]], bb = kp_base[ib[b]];
+            const int64_t na = kp_base[ia[b] + 1] - ba, nb = kp_base[ib[b] + 1] - bb;
+            if (mode & 3) {
+                for (int64_t k = 0; k < n; ++k) {
+                    const int64_t a = p[2 * k], c = p[2 * k + 1];
+                    if (a < 0 || a >= na || c < 0 || c >= nb) { bad.store(1); break; }
+                    if (mode & 1) { used[ba + a] = 1; used[bb + c] = 1; }
+                    if (mode & 2) { p[2 * k] = remap[ba + a]; p[2 * k + 1] = remap[bb + c]; }
+                }
+            }
+            if (mode & 4) {
+                size_t cap = 16;
+                while (cap < (size_t)(2 * n + 16)) cap <<= 1;
+                slot.assign(cap, 0);
+                slot1.assign(cap, 0);
+                const size_t mask = cap - 1;
+                int32_t dp = 0, d1 = 0;
+                for (int64_t k = 0; k < n; ++k) {
+                    const uint64_t code = (((uint64_t)(uint32_t)p[2 * k] << 32) | (uint32_t)p[2 * k + 1]) + 1;
+                    uint64_t h = code;
+                    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33;
+                    size_t at = (size_t)(h & mask);
+                    while (slot[at] != 0 && slot[at] != code) at = (at + 1) & mask;
+                    if (slot[at] == code) ++dp; else slot[at] = code;
+                    const uint32_t c1 = (uint32_t)p[2 * k] + 1u;
+                    uint64_t g = c1;
+                    g *= 0x9E3779B97F4A7C15ULL; g ^= g >> 29;
+                    size_t a1 = (size_t)(g & mask);
+                    while (slot1[a1] != 0 && slot1[a1] != c1) a1 = (a1 + 1) & mask;
+                    if (slot1[a1] == c1) ++d1; else slot1[a1] = c1;
+                }
+                dup_pairs[b] = dp;
+                dup_first[b] = d1;
+            }
+        }
+    };
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(threads, 1), n_lists));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    if (bad.load()) return iamx::fail(IAMX_EINVAL, "iamx_match_lists_scan: keypoint index out of range");
     return IAMX_OK;
 }
 

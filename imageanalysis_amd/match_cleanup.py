@@ -63,18 +63,70 @@ def _pairs(matches):
 # --------------------------------------------------------------------------------------
 # duplicates -- match_cleanup.py:19-188 (+ project.py:331-350 compute_kp_usage)
 # --------------------------------------------------------------------------------------
-def compute_kp_usage(proj):
-    index = _index_by_name(proj)
-    for im in proj.image_list:
-        im.kp_used = np.zeros(len(im.kp_list), np.bool_)
-    for i1 in proj.image_list:
+SCAN_THREADS = 8
+
+
+def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None):
+    """iamx_match_lists_scan over the match lists that are array backed (what find_matches leaves:
+    matchpairs.MatchPairs in their array form).  -> (entries, dup_pairs, dup_first, rest): entries =
+    [(i, key, j, matches)] of the lists scanned, rest = the same for the lists that are plain
+    python lists (the caller's per-list numpy path).  wanted(i, j): scan this pair at all?"""
+    import ctypes
+    from ._lib import check, lib
+    entries, rest, arrays = [], [], []
+    for i, i1 in enumerate(proj.image_list):
         for key, matches in i1.match_list.items():
             j = index.get(key)
             if j is None or len(matches) == 0:
-                continue                      # pairs outside our area set
-            p = _pairs(matches)
-            i1.kp_used[p[:, 0]] = True
-            proj.image_list[j].kp_used[p[:, 1]] = True
+                continue
+            if wanted is not None and not wanted(i, j):
+                continue
+            a = matches._a if isinstance(matches, MatchPairs) else None
+            if a is not None and a.dtype == np.int32 and a.flags.c_contiguous and a.flags.writeable:
+                entries.append((i, key, j, matches))
+                arrays.append(a)
+            else:
+                rest.append((i, key, j, matches))
+    n = len(entries)
+    dup_pairs, dup_first = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    if n:
+        if base is None:
+            base = _kp_base(proj)
+        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        cnt = np.fromiter((len(a) for a in arrays), np.int64, n)
+        ia = np.fromiter((e[0] for e in entries), np.int32, n)
+        ib = np.fromiter((e[2] for e in entries), np.int32, n)
+        P = lambda x: None if x is None else x.ctypes.data_as(ctypes.c_void_p)
+        rc = lib().iamx_match_lists_scan(ptrs, P(cnt), P(ia), P(ib), n, P(base), len(proj.image_list),
+                                         P(used), P(remap), mode, P(dup_pairs), P(dup_first), SCAN_THREADS)
+        if rc != 0:
+            msg = (lib().iamx_last_error() or b'?').decode()
+            if 'out of range' in msg:
+                raise IndexError("index out of range in a match list (%s)" % msg)
+            check(rc, 'iamx_match_lists_scan')
+        if mode & 2:
+            for _i, _k, _j, m in entries:
+                m._pk = None                      # (the pickled form was made from the old pairs)
+    return entries, dup_pairs, dup_first, rest
+
+
+def _kp_base(proj):
+    base = np.zeros(len(proj.image_list) + 1, np.int64)
+    np.cumsum([len(im.kp_list) for im in proj.image_list], out=base[1:])
+    return base
+
+
+def compute_kp_usage(proj):
+    index = _index_by_name(proj)
+    base = _kp_base(proj)
+    used = np.zeros(int(base[-1]), np.uint8)
+    _e, _dp, _d1, rest = _scan_lists(proj, index, 1, used=used, base=base)
+    for i, im in enumerate(proj.image_list):
+        im.kp_used = used[base[i]:base[i + 1]].view(np.bool_)
+    for i, _key, j, matches in rest:
+        p = _pairs(matches)
+        proj.image_list[i].kp_used[p[:, 0]] = True
+        proj.image_list[j].kp_used[p[:, 1]] = True
 
 
 def _first_occurrence(key):
@@ -110,22 +162,28 @@ def merge_duplicates(proj):
     index = _index_by_name(proj)
     # (an image without two used keypoints on one pixel maps every index onto itself)
     same = [bool((r == np.arange(len(r))).all()) for r in remaps]
-    for i, i1 in enumerate(proj.image_list):
-        for key, matches in i1.match_list.items():
-            j = index.get(key)
-            if j is None or len(matches) == 0:
-                continue
-            if same[i] and same[j]:
-                continue                      # nothing to merge: the list stays as it is
-            if isinstance(matches, MatchPairs):
-                p = matches.array()
-                merged = np.empty((len(p), 2), np.int32)
-                merged[:, 0] = remaps[i][p[:, 0]]
-                merged[:, 1] = remaps[j][p[:, 1]]
-                matches[:] = merged
-            else:
-                p = _pairs(matches)
-                matches[:] = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1).tolist()
+    if all(same):
+        return
+    base = _kp_base(proj)
+    flat = np.concatenate(remaps).astype(np.int32) if remaps else np.zeros(0, np.int32)
+    # the array-backed lists in one native pass (in place), the rest list by list
+    _e, _dp, _d1, rest = _scan_lists(proj, index, 2, wanted=lambda i, j: not (same[i] and same[j]),
+                                     remap=flat, base=base)
+    for i, _key, j, matches in rest:
+        p = _pairs(matches)
+        matches[:] = np.stack([remaps[i][p[:, 0]], remaps[j][p[:, 1]]], 1).tolist()
+
+
+def _drop_pair_dups(proj, i1, key, j, matches):
+    p = _pairs(matches)
+    code = (p[:, 0] << 32) | p[:, 1]
+    _u, first = np.unique(code, return_index=True)
+    count = len(p) - len(first)
+    if count > 0:
+        print('Match:', i1.name, 'vs', proj.image_list[j].name, 'matches:', len(matches),
+              'dups:', count)
+        kept = p[np.sort(first)]
+        i1.match_list[key] = MatchPairs(kept) if isinstance(matches, MatchPairs) else kept.tolist()
 
 
 def check_for_pair_dups(proj):
@@ -133,40 +191,32 @@ def check_for_pair_dups(proj):
     index = _index_by_name(proj)
     for i1 in proj.image_list:
         for key in list(i1.match_list):
-            matches = i1.match_list[key]
-            j = index.get(key)
-            if j is None:
-                continue
-            if len(matches) == 0:
+            if index.get(key) is not None and len(i1.match_list[key]) == 0:
                 i1.match_list[key] = []
-                continue
-            p = _pairs(matches)
-            code = (p[:, 0] << 32) | p[:, 1]
-            # (the usual case -- no pair twice -- is settled by a plain sort: a third of the cost
-            #  of the index-returning unique)
-            srt = np.sort(code)
-            if not (srt[1:] == srt[:-1]).any():
-                continue
-            _u, first = np.unique(code, return_index=True)
-            count = len(p) - len(first)
-            if count > 0:
-                print('Match:', i1.name, 'vs', proj.image_list[j].name, 'matches:', len(matches),
-                      'dups:', count)
-            kept = p[np.sort(first)]
-            i1.match_list[key] = MatchPairs(kept) if isinstance(matches, MatchPairs) else kept.tolist()
+    entries, dup_pairs, _d1, rest = _scan_lists(proj, index, 4)
+    # (the usual case -- no pair twice in any list -- ends here)
+    for k in np.nonzero(dup_pairs)[0].tolist():
+        i, key, j, matches = entries[k]
+        _drop_pair_dups(proj, proj.image_list[i], key, j, matches)
+    for i, key, j, matches in rest:
+        p = _pairs(matches)
+        srt = np.sort((p[:, 0] << 32) | p[:, 1])
+        if (srt[1:] == srt[:-1]).any():
+            _drop_pair_dups(proj, proj.image_list[i], key, j, matches)
 
 
 def check_for_1vn_dups(proj):
     _log("Testing for 1 vs. n keypoint duplicates (there never should be any):")
     index = _index_by_name(proj)
-    for i, i1 in enumerate(proj.image_list):
-        for key, matches in i1.match_list.items():
-            if index.get(key) is None or len(matches) == 0:
-                continue
-            p = _pairs(matches)
-            count = len(p) - len(np.unique(p[:, 0]))
-            if count > 0:
-                _qlog('Match:', i, 'vs', len(matches) - 1, 'matches:', len(matches), 'dups:', count)
+    entries, _dp, dup_first, rest = _scan_lists(proj, index, 4)
+    for k in np.nonzero(dup_first)[0].tolist():
+        i, _key, _j, matches = entries[k]
+        _qlog('Match:', i, 'vs', len(matches) - 1, 'matches:', len(matches), 'dups:', int(dup_first[k]))
+    for i, _key, _j, matches in rest:
+        p = _pairs(matches)
+        count = len(p) - len(np.unique(p[:, 0]))
+        if count > 0:
+            _qlog('Match:', i, 'vs', len(matches) - 1, 'matches:', len(matches), 'dups:', count)
 
 
 # --------------------------------------------------------------------------------------

@@ -333,6 +333,18 @@ int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *
 int64_t iamx_link_pair_blocks(const int32_t *const *blocks, const int64_t *counts, const int32_t *ij,
                               int64_t n_blocks, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                               int32_t *n_passes);
+/* iamx_match_lists_scan -- HOST.  One pass over the images' match lists for the per-list loops in
+ * front of link_matches (scripts/lib/match_cleanup.py:19-188, lib/project.py:331-350
+ * compute_kp_usage): list b = int32 [cnt[b]][2] (keypoint of image ia[b], keypoint of image ib[b]),
+ * keypoints of image i at [kp_base[i], kp_base[i+1]) of the flat arrays `used` (uint8) / `remap`.
+ * mode & 1: mark both keypoints used; & 2: replace both by remap[...] in place (merge_duplicates);
+ * & 4: dup_pairs[b] = rows equal to an earlier row, dup_first[b] = rows whose first keypoint
+ * occurred before (check_for_pair_dups / check_for_1vn_dups).  A keypoint index outside its image
+ * is IAMX_EINVAL (the reference raises IndexError there). */
+int iamx_match_lists_scan(int32_t *const *lists, const int64_t *cnt, const int32_t *ia,
+                          const int32_t *ib, int64_t n_lists, const int64_t *kp_base, int32_t n_images,
+                          uint8_t *used, const int32_t *remap, int mode, int32_t *dup_pairs,
+                          int32_t *dup_first, int threads);
 /* HOST helpers of the same stage.  iamx_chains_longest_first: the chains of iamx_link_matches in
  * the order match_cleanup.py:291-292 leaves them (stable sort by length, longest first), members
  * copied on `threads` threads; out arrays sized like the input, out_ptr [n_chains + 1].
