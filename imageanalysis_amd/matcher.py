@@ -66,8 +66,12 @@ PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that ba
 # DENSE_PROBE-th such round is symmetric again and measures f anew (a distance-sorted schedule
 # goes from dense to sparse once).  'never' / 'always' pin the choice (tests, A/B).  Results are
 # identical either way -- both forms end in exact top-2 distances (tests/test_mirror_gpu.py).
+# Measured (profiles/r5_e2e_full_512_{never,auto}.json: 512 rendered 20 MP frames, candidate share
+# 0.17 in the dense rounds): 3.36 s symmetric against 3.44 s routed -- break-even, as the cost model
+# says for f = 0.14-0.17 -- so the threshold sits where the model promises 1.4x (f = 0.30: the
+# dense-overlap workload of bench.py, f = 0.28, runs 1.3x faster in the one-direction form).
 DENSE_ROUTE = os.environ.get('IAMX_DENSE_ROUTE', 'auto')
-DENSE_SHARE = 0.15
+DENSE_SHARE = 0.30
 DENSE_PROBE = 4
 _route = {'share': None, 'since_probe': 0, 'rounds': [0, 0]}     # rounds: [symmetric, one-direction]
 
