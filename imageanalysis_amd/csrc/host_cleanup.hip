@@ -628,6 +628,82 @@ extern "C" int iamx_first_occurrence(const int64_t *key, int64_t n, int64_t *fir
     return IAMX_OK;
 }
 
+// key2[k] = round-half-even(100 * xy[k]) computed exactly (matcher.kp_key2: two keypoints have the
+// same "%.2f-%.2f" % kp.pt string, scripts/lib/matcher.py:166-167 / match_cleanup.py:36-38, iff
+// their key pairs are equal): x * 2^40 is an exact integer for every float32 in [2^-16, 2^14),
+// smaller values print as 0.00 either way.  IAMX_EINVAL for a coordinate outside [0, 16384).
+namespace {
+inline bool key_of(float x, int32_t &key)
+{
+    if (!(x >= 0.f) || x >= 16384.f) return false;
+    const int64_t m = (int64_t)((double)x * 1099511627776.0) * 100;
+    int64_t q = m >> 40;
+    const int64_t rem = m & ((1ll << 40) - 1), half = 1ll << 39;
+    q += (rem > half) | ((rem == half) & ((q & 1) == 1));
+    key = (int32_t)q;
+    return true;
+}
+}  // namespace
+
+extern "C" int iamx_kp_key2(const float *xy, int64_t n, int32_t *key2)
+{
+    if (n < 0 || (n > 0 && (!xy || !key2))) return iamx::fail(IAMX_EINVAL, "iamx_kp_key2: null pointer or negative count");
+    for (int64_t k = 0; k < 2 * n; ++k)
+        if (!key_of(xy[k], key2[k])) return iamx::fail(IAMX_EINVAL, "iamx_kp_key2: keypoint coordinates outside [0, 16384)");
+    return IAMX_OK;
+}
+
+// merge_duplicates' per-image index (scripts/lib/match_cleanup.py:19-60): remap[k] = the first USED
+// keypoint (lowest index) of the image whose pixel has the same "%.2f-%.2f" key as keypoint k, k
+// itself for an unused keypoint.  Images image_lo .. image_hi - 1 of the flat arrays (keypoints of
+// image i at [kp_base[i], kp_base[i + 1]): xy float32 [..][2], used uint8, remap int32 holding the
+// index INSIDE the image); identity[i] = 1 when image i maps every keypoint onto itself.
+extern "C" int iamx_kp_dup_remap(const float *xy, const uint8_t *used, const int64_t *kp_base,
+                                 int32_t n_images, int32_t *remap, uint8_t *identity, int threads)
+{
+    if (n_images < 0 || !kp_base || (n_images > 0 && (!xy || !used || !remap || !identity)))
+        return iamx::fail(IAMX_EINVAL, "iamx_kp_dup_remap: null pointer or negative count");
+    std::atomic<int32_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        std::vector<uint64_t> keys;
+        std::vector<int32_t> slot;
+        for (int32_t i = next.fetch_add(1); i < n_images; i = next.fetch_add(1)) {
+            const int64_t b = kp_base[i], n = kp_base[i + 1] - b;
+            size_t cap = 16;
+            while (cap < (size_t)(2 * n + 16)) cap <<= 1;
+            keys.assign(cap, 0);
+            slot.assign(cap, -1);
+            const size_t mask = cap - 1;
+            bool same = true;
+            for (int64_t k = 0; k < n; ++k) {
+                int32_t r = (int32_t)k;
+                if (used[b + k]) {
+                    int32_t kx, ky;
+                    if (!key_of(xy[2 * (b + k)], kx) || !key_of(xy[2 * (b + k) + 1], ky)) { bad.store(1); break; }
+                    const uint64_t code = (((uint64_t)(uint32_t)kx << 32) | (uint32_t)ky) + 1;
+                    uint64_t h = code;
+                    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
+                    size_t at = (size_t)(h & mask);
+                    while (keys[at] != 0 && keys[at] != code) at = (at + 1) & mask;
+                    if (keys[at] == 0) { keys[at] = code; slot[at] = (int32_t)k; }
+                    r = slot[at];
+                    same = same && r == (int32_t)k;
+                }
+                remap[b + k] = r;
+            }
+            identity[i] = same ? 1 : 0;
+        }
+    };
+    const int nt = std::max(1, std::min(std::max(threads, 1), (int)n_images));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    if (bad.load()) return iamx::fail(IAMX_EINVAL, "iamx_kp_dup_remap: keypoint coordinates outside [0, 16384)");
+    return IAMX_OK;
+}
+
 // One pass over the images' match lists for the three per-list loops in front of link_matches
 // (scripts/lib/match_cleanup.py:19-188 + lib/project.py:331-350): list b = int32 [cnt[b]][2],
 // column 0 keypoints of image ia[b], column 1 of image ib[b]; keypoints of image i live at

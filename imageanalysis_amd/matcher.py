@@ -241,8 +241,22 @@ class DeviceMatcher(object):
         return self._kp_dev[1:4]
 
     def want_train_layout(self):
-        """from now on the arena carries the parity-partitioned copy the one-direction sweep reads"""
+        """From now on the arena carries the parity-partitioned copy the one-direction sweep reads
+        (+50 % of the arena: 140 B per descriptor row).  -> False when that copy would take more
+        than a quarter of the free device memory -- the round then stays on the symmetric sweep,
+        which needs nothing extra (a 10 000-frame survey's arena is 104 GB without it)."""
+        if getattr(self, '_train_layout', False):
+            return True
+        try:
+            import torch
+            free, _total = torch.cuda.mem_get_info()
+        except Exception:                 # noqa: BLE001
+            return False
+        need = (sum(self._counts) + 128 * len(self._counts)) * 140
+        if need > free // 4:
+            return False
         self._train_layout = True
+        return True
 
     def store(self):
         """(Re)build the arena when new images arrived; old rows are copied on the device."""
@@ -333,6 +347,19 @@ def kp_key2(xy):
     "%.2f-%.2f" % kp.pt string (matcher.py:166-167) iff their key pairs are equal.  kp.pt holds
     float32 values; x * 2**40 is an exact integer for every float32 in [2**-16, 2**14) and
     smaller values print as 0.00 either way."""
+    if isinstance(xy, np.ndarray) and xy.dtype == np.float32 and xy.ndim == 2 and xy.shape[1] == 2 \
+            and xy.flags.c_contiguous and len(xy) >= 256:
+        # (one pass in libiamx: the numpy form below is six temporaries of the array's size)
+        try:
+            key = np.empty(xy.shape, np.int32)
+            rc = _lib.lib().iamx_kp_key2(xy.ctypes.data_as(ctypes.c_void_p), len(xy),
+                                         key.ctypes.data_as(ctypes.c_void_p))
+        except OSError:
+            rc = None
+        if rc == 0:
+            return key
+        if rc is not None:
+            raise ValueError("keypoint coordinates outside [0, 16384)")
     x = np.asarray(xy, np.float64).reshape(-1, 2)
     if x.size and (x.min() < 0 or x.max() >= 16384.0):
         raise ValueError("keypoint coordinates outside [0, 16384)")
@@ -864,8 +891,8 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False, one_di
         # new images: the descriptor / keypoint arenas are about to be rebuilt, and the previous
         # round's side-stream kernels may still be reading the old ones
         torch.cuda.current_stream().wait_stream(_side_stream())
-    if one_direction:
-        dm.want_train_layout()            # (the parity-partitioned copy, built on first use)
+    if one_direction and not dm.want_train_layout():      # (the parity-partitioned copy, built on first use)
+        one_direction = False
     store = dm.store()
     arena = _upload_arena()
     arena.begin()

@@ -333,6 +333,16 @@ int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *
 int64_t iamx_link_pair_blocks(const int32_t *const *blocks, const int64_t *counts, const int32_t *ij,
                               int64_t n_blocks, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                               int32_t *n_passes);
+/* iamx_kp_key2 -- HOST.  key2[k] = round-half-even(100 * xy[k]) in exact integer arithmetic: the
+ * "%.2f-%.2f" % kp.pt keys of scripts/lib/matcher.py:166-167 and match_cleanup.py:36-38 as integer
+ * pairs (xy float32 [n][2] in [0, 16384), key2 int32 [n][2]).
+ * iamx_kp_dup_remap -- HOST.  merge_duplicates' per-image table (match_cleanup.py:19-60) for
+ * n_images images at once: remap[k] (index inside the image) = the first USED keypoint of the
+ * image with keypoint k's key, k itself when k is unused; identity[i] = 1 when image i has no two
+ * used keypoints on one pixel.  Flat arrays, image i at [kp_base[i], kp_base[i+1]). */
+int iamx_kp_key2(const float *xy, int64_t n, int32_t *key2);
+int iamx_kp_dup_remap(const float *xy, const uint8_t *used, const int64_t *kp_base, int32_t n_images,
+                      int32_t *remap, uint8_t *identity, int threads);
 /* iamx_match_lists_scan -- HOST.  One pass over the images' match lists for the per-list loops in
  * front of link_matches (scripts/lib/match_cleanup.py:19-188, lib/project.py:331-350
  * compute_kp_usage): list b = int32 [cnt[b]][2] (keypoint of image ia[b], keypoint of image ib[b]),

@@ -745,3 +745,53 @@ def test_huge_page_backed_arrays_behave_like_numpy_arrays():
     assert flat.shape == (9_000_000,) and flat.dtype == np.uint8
     flat[-1] = 7
     assert int(flat[-1]) == 7
+
+
+def test_native_kp_keys_and_dup_remap_equal_the_numpy_form():
+    """iamx_kp_key2 / iamx_kp_dup_remap (round 5: merge_duplicates' per-image tables in one native
+    call) against the numpy statement of the same integers, on random positions, on exact halves
+    (x.xx5 values that are float32-representable: round-half-even decides) and on shared pixels"""
+    import ctypes
+    from imageanalysis_amd import _lib, matcher
+    rng = np.random.default_rng(77)
+    n = 5000
+    x = rng.uniform(0, 5472, (n, 2)).astype(np.float32)
+    x[:200] = (rng.integers(0, 40000, (200, 2)) * 0.125).astype(np.float32)         # k/8: many exact .125 / .375 / .625 / .875
+    x[200:300] = np.float32(2 ** -17) * rng.integers(0, 3, (100, 2))              # below 2^-16: prints as 0.00
+    x[300:320] = [[0.005, 0.015], [0.025, 1.005]] * 10
+    def numpy_key(xy):
+        v = np.asarray(xy, np.float64)
+        m = (v * float(1 << 40)).astype(np.int64) * 100
+        q, rem = m >> 40, m & ((1 << 40) - 1)
+        half = 1 << 39
+        return (q + ((rem > half) | ((rem == half) & ((q & 1) == 1)))).astype(np.int32)
+    want = numpy_key(x)
+    got = matcher.kp_key2(x)
+    assert got.dtype == np.int32 and np.array_equal(got, want)
+    # ... and the strings they stand for
+    for k in rng.integers(0, n, 300):
+        assert ("%.2f-%.2f" % (float(x[k, 0]), float(x[k, 1]))) == "%d.%02d-%d.%02d" % (
+            want[k, 0] // 100, want[k, 0] % 100, want[k, 1] // 100, want[k, 1] % 100)
+    with pytest.raises(ValueError):
+        matcher.kp_key2(np.full((300, 2), 20000.0, np.float32))
+    # duplicate remap: three "images" back to back
+    counts = [1500, 0, 3500]
+    base = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    xy = x.copy()
+    twins = rng.permutation(1500)[:300]
+    xy[twins] = xy[(twins + 7) % 1500]                     # shared pixels inside image 0
+    used = (rng.random(n) < 0.7).astype(np.uint8)
+    remap = np.empty(n, np.int32)
+    ident = np.zeros(3, np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(_lib.lib().iamx_kp_dup_remap(P(xy), P(used), P(base), 3, P(remap), P(ident), 2), 'iamx_kp_dup_remap')
+    for i, (b, e) in enumerate(zip(base[:-1], base[1:])):
+        want_r = np.arange(e - b)
+        u = np.nonzero(used[b:e])[0]
+        if len(u):
+            k2 = numpy_key(xy[b:e][u]).astype(np.int64)
+            _uq, first, inv = np.unique((k2[:, 0] << 32) | k2[:, 1], return_index=True, return_inverse=True)
+            want_r[u] = u[first[inv]]
+        assert np.array_equal(remap[b:e], want_r), i
+        assert bool(ident[i]) == bool((want_r == np.arange(e - b)).all())
+    assert not ident[0] and ident[1]
