@@ -34,7 +34,7 @@ FLOP_PER_PAIR = 2.0 * KPTS * KPTS * DIM          # one distance matrix serves bo
 I8_DENSE_PEAK_TFLOPS = 5000.0                    # the task's dense i8 / fp8 nameplate (2 x the 2.5 PF bf16 dense figure); the guide has no i8 spec line,
                                                  # only the micro-benchmark below -- `frac` is against this, `frac_of_guide_ubench_3944` against that
 I8_UBENCH_TOPS = 3944.0                          # the guide's measured i8 MFMA micro-benchmark rate
-KNN2SYM_TRAFFIC_FILE = 'r4_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
+KNN2SYM_TRAFFIC_FILE = 'r5_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
 CONFIG1_IMAGES = 500                             # configs[1]: C(500, 2) = 124 750 pairs
 CONFIG2_IMAGES = 2812                            # configs[2]: 3 952 266 pairs
 E2E_FRAMES = 128                                 # configs[4] slice of the default run (rendered 20 MP frames)
@@ -289,6 +289,8 @@ def main():
     ap.add_argument('--sift-first', action='store_true',
                     help='run the feature-detection section before the matching section (diagnosis of the '
                          'single-stream detection time: tools/sift_stream_bisect.py)')
+    ap.add_argument('--sift-last', action='store_true',
+                    help='run the feature-detection section behind the BA section, where rounds 1-4 had it')
     ap.add_argument('--ba-iters', type=int, default=0,
                     help='TRF iterations to time (0: until ftol = 1e-4 stops the solve, the reference\'s call)')
     ap.add_argument('--no-sift-full', action='store_true',
@@ -343,6 +345,21 @@ def main():
         sift_early = sift_bench(rank, world, dev, dist, args)
     m = match_section(args, rank, world, dev, dist, one_gpu, n_img, args.steps, args.warmup,
                       args.verify_pairs)
+    # The feature-detection section runs HERE, directly behind the headline section.  Behind the
+    # survey / dense-overlap / BA sections of the same process its single-stream loop reads 2.8 ms
+    # per detection where the same kernels, buffers and loop read 1.66 ms here and 1.70 ms in a
+    # fresh process -- while eight detections in flight read 1.39 ms in both places
+    # (profiles/r5_bench_sift_{inplace,first}.json, r5_sift_stream_bisect.txt: not the stream
+    # count, page-locked memory, allocator state, loaded code objects or ba_bench on its own).
+    if sift_early is None and not args.no_sift and not args.sift_last:
+        try:
+            from threadpoolctl import threadpool_limits as _tl
+            _q = _tl(limits=1, user_api='blas')
+        except ImportError:                               # pragma: no cover
+            import contextlib as _cl
+            _q = _cl.nullcontext()
+        with _q:
+            sift_early = sift_bench(rank, world, dev, dist, args)
     dt, total_pairs, roofline, verified = m["dt"], m["total_pairs"], m["roofline"], m["verified"]
     cpu_sample = m["cpu_sample"]
     # ---- the metric's own survey at N = 1: ONE step over all 3 952 266 pairs of the 2812-image
@@ -758,7 +775,8 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         out["hbm_after_match"] = dict(matcher.device_memory_report(),
                                       allocated_bytes=int(torch.cuda.memory_allocated()),
                                       peak_allocated_bytes=int(torch.cuda.max_memory_allocated()))
-        out["hbm_model"] = matcher.device_memory_model(len(names), out["keypoints_per_image"])
+        out["hbm_model"] = matcher.device_memory_model(len(names), out["keypoints_per_image"],
+                                                       train_layout=matcher._route['rounds'][1] > 0)
         out["image_pairs_with_matches"] = sum(len(v) > 0 for im in proj.image_list
                                               for v in im.match_list.values()) // 2
 
@@ -1310,7 +1328,7 @@ def ba_bench(rank, world, dev, dist, args):
         lsmr["traffic"], lsmr["traffic_source"] = aux_traffic(
             ('lsmr_fwd_kernel', 'lsmr_adj_kernel', 'lsmr_update3_kernel'), 'lsmr_update3_kernel')
         lsmr["timing"] = ("wall clock around %d fused iterations, queue kept full; per-kernel durations: "
-                          "profiles/r4_kernel_stats.txt" % its)
+                          "profiles/r5_kernel_stats.txt" % its)
     schur_it = None
     if world == 1:
         # one CG iteration of the Schur solver = three passes over the stored Jacobian blocks
@@ -1339,7 +1357,7 @@ def ba_bench(rank, world, dev, dist, args):
             ('schur_fwd_kernel', 'schur_pt_kernel', 'schur_adj_kernel', 'schur_pq_kernel',
              'schur_update1_kernel', 'schur_update2_kernel'), 'schur_fwd_kernel')
         schur_it["timing"] = ("wall clock, difference of a %d- and an 8-iteration solve; per-kernel "
-                              "durations: profiles/r4_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
+                              "durations: profiles/r5_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
                               % its)
     cpu = None                                              # filled in by main() at the end
     def cold(t, bytes_per_obs):
@@ -1378,7 +1396,7 @@ def ba_bench(rank, world, dev, dist, args):
                          "traffic": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[0],
                          "traffic_source": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[1],
                          "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
-                                   "kernel, ba_residual_lds_kernel: profiles/r4_kernel_stats.txt)"},
+                                   "kernel, ba_residual_lds_kernel: profiles/r5_kernel_stats.txt)"},
             "residual_jac": {"bound": "hbm",
                              "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
                              "peak": HBM, "unit": "GB/s",
@@ -1388,12 +1406,12 @@ def ba_bench(rank, world, dev, dist, args):
                              "traffic": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[0],
                              "traffic_source": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[1],
                              "timing": "hipEvents around 50 launches (ba_residual_jac_kernel: "
-                                       "profiles/r4_kernel_stats.txt)"},
+                                       "profiles/r5_kernel_stats.txt)"},
             "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
 
 
-AUX_TRAFFIC_FILE = 'r4_ba_sift_traffic.json'
+AUX_TRAFFIC_FILE = 'r5_ba_sift_traffic.json'
 
 
 def aux_traffic(bases, per):

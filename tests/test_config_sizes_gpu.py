@@ -184,8 +184,10 @@ def test_config4_at_512_frames_bounded_device_memory():
     assert rep["images"] == n and rep["descriptor_rows"] == pytest.approx(n * out["keypoints_per_image"], rel=0.01)
     assert 0.9 * model["arena_bytes"] <= rep["descriptor_arena_bytes"] + rep["keypoint_arena_bytes"] \
         <= 1.05 * model["arena_bytes"]
-    # per row of the arena: 128 + 12 (original order) + 128 + 16 (sorted order) bytes, padded
-    assert rep["descriptor_arena_bytes"] / float(rep["descriptor_rows"]) < 300.0
+    # per row of the arena: 128 + 12 (original order) + 128 + 16 (sorted order) bytes, padded; + 128
+    # + 12 when a dense round of this run asked for the one-direction sweep's layout
+    routed = out["route_rounds"]["one_direction"] > 0
+    assert rep["descriptor_arena_bytes"] / float(rep["descriptor_rows"]) < (440.0 if routed else 300.0)
     assert rep["pooled_workspace_bytes"] <= 3 * matcher.BATCH_BYTES
     assert out["peak_hbm_bytes"] <= model["peak_bytes"] + 24 * 2 ** 30     # (+ 8 SIFT slots, BA)
     print({k: out[k] for k in ("stage_seconds", "total_seconds", "peak_hbm_bytes", "hbm_after_match", "hbm_model")})

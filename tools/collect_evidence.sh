@@ -3,7 +3,7 @@
 #   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r4)
 # Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back); the summaries come back
 # under gpurun_out/ -- copy the judged ones to profiles/ afterwards (tools/pull_evidence.sh).  Counter passes are separate runs with --pmc only.
-TAG="${1:-r4}"
+TAG="${1:-r5}"
 OUT="$PWD/gpurun_out"
 REPO="$PWD"
 mkdir -p "$OUT"
@@ -87,12 +87,13 @@ cp "$OUT/${TAG}_sift_kernel_stats.txt" "$OUT/${TAG}_sift_time.txt" "$REPO/profil
 if [ -z "$NO_ENTRY" ]; then
 step "entry points"
 timeout 600 python tools/find_matches_rate.py > "$OUT/${TAG}_fm_dense.txt" 2>&1; tail -n 1 "$OUT/${TAG}_fm_dense.txt"
-timeout 900 python tools/detect_rate.py 256 > "$OUT/${TAG}_detect_rate.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate.txt"
+timeout 900 python tools/detect_rate.py 192 --no-serial > "$OUT/${TAG}_detect_rate_final.txt" 2>&1; tail -n 4 "$OUT/${TAG}_detect_rate_final.txt"
 # configs[2] through matcher.find_matches (2812 x 4096, 3.95 M pairs)
 timeout 600 python tools/find_matches_rate.py 38 74 4096 > "$OUT/${TAG}_fm_config2_run.txt" 2>&1; tail -n 3 "$OUT/${TAG}_fm_config2_run.txt"
 # configs[4] at 512 rendered 20 MP frames (what bench.py quotes as e2e_full_recorded)
-timeout 900 python bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey \
+IAMX_LINK_TIMING=1 timeout 900 python bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey \
     --images 64 --e2e-full 512 > "$OUT/${TAG}_e2e_full_run.json" 2> "$OUT/${TAG}_e2e_full_run.err"
+grep iamx_link_matches "$OUT/${TAG}_e2e_full_run.err" > "$OUT/${TAG}_link_passes_512.txt"
 python - "$OUT/${TAG}_e2e_full_run.json" "$OUT/${TAG}_e2e_full_512.json" <<'PY'
 import json, sys
 rec = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]).get("e2e_full")
