@@ -64,7 +64,7 @@ python "$REPO/tools/update_traffic_json.py" "$TAG" || FAILED=1
 [ -f "$REPO/profiles/${TAG}_knn2sym_traffic.json" ] && cp "$REPO/profiles/${TAG}_knn2sym_traffic.json" "$OUT/"
 
 step "bench"
-timeout 900 python bench.py > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
 tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
 
 fi
