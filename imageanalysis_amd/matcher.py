@@ -57,20 +57,18 @@ early_smart_stats = {'written': 0, 'current_at_end': 0}     # (tests / diagnosis
 PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that batch's slots are copied)
 # Which sweep a round of find_matches takes.  The symmetric sweep (one MFMA pass per image pair)
 # leaves the rows whose bounds pass the metric test to an exact stage that runs at half the sweep's
-# rate: 0.47 + 1.9 f units of time per pair for a candidate share f of the rows.  On unrelated or
-# barely overlapping frames f is ~0.001; on overlapping frames of real imagery it is 0.3-0.6 (typical
-# nearest-neighbour distances of SIFT descriptors sit right at the reference's 270 x ratio threshold)
-# and the one-direction bound form -- two sweeps per pair, best exact, nothing left for an exact
-# stage but the few survivors -- is faster: 0.74 units whatever f is.  'auto': a round takes the
-# one-direction form when the last symmetric round it knows of had f above DENSE_SHARE; every
-# DENSE_PROBE-th such round is symmetric again and measures f anew (a distance-sorted schedule
-# goes from dense to sparse once).  'never' / 'always' pin the choice (tests, A/B).  Results are
-# identical either way -- both forms end in exact top-2 distances (tests/test_mirror_gpu.py).
-# Measured (profiles/r5_e2e_full_512_{never,auto}.json: 512 rendered 20 MP frames, candidate share
-# 0.17 in the dense rounds): 3.36 s symmetric against 3.44 s routed -- break-even, as the cost model
-# says for f = 0.14-0.17 -- so the threshold sits where the model promises 1.4x (f = 0.30: the
-# dense-overlap workload of bench.py, f = 0.28, runs 1.3x faster in the one-direction form).
-DENSE_ROUTE = os.environ.get('IAMX_DENSE_ROUTE', 'auto')
+# rate; on overlapping frames of real imagery 15-30 % of the rows are such candidates.  Round 5
+# built the route the round-4 review proposed -- a round whose last measured candidate share exceeds
+# DENSE_SHARE takes the one-direction bound form (two sweeps per pair, survivors finished exactly),
+# every DENSE_PROBE-th routed round measures again -- and MEASURED it (profiles/r5_*): break-even on
+# 512 rendered frames (3.36 s symmetric, 3.44 s routed, f = 0.17), SLOWER on the workloads with many
+# true survivors: the dense-overlap workload of bench.py (f = 0.28) runs 0.63x as fast in the
+# one-direction form (its per-survivor finish costs more than the exact stage it replaces), the
+# dense 400-image survey 76 k instead of 87 k pairs/s, configs[2] 394 k instead of 420 k -- and the
+# parity-partitioned layout it needs is another 140 B per descriptor row.  So the default is
+# 'never'; 'auto' / 'always' remain for A/B runs (IAMX_DENSE_ROUTE).  Results are identical in all
+# modes (tests/test_mirror_gpu.py).
+DENSE_ROUTE = os.environ.get('IAMX_DENSE_ROUTE', 'never')
 DENSE_SHARE = 0.30
 DENSE_PROBE = 4
 _route = {'share': None, 'since_probe': 0, 'rounds': [0, 0]}     # rounds: [symmetric, one-direction]

@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 5, final GPU call on the shipped defaults: tests, entry points, bench, configs[4] at 512 and 4186 frames
+OUT="$PWD/gpurun_out"; mkdir -p "$OUT"; export TMPDIR=/tmp
+echo "== gpu tests $(date +%T)"
+timeout 1500 python -m pytest tests -m gpu -q > "$OUT/r5_gpu_tests.txt" 2>&1; grep -E "passed|failed" "$OUT/r5_gpu_tests.txt" | tail -2; grep -E "^FAILED|^ERROR" "$OUT/r5_gpu_tests.txt" | head
+echo "== entry points $(date +%T)"
+timeout 600 python tools/find_matches_rate.py > "$OUT/r5_fm_dense_final.txt" 2>&1; tail -n 1 "$OUT/r5_fm_dense_final.txt"
+timeout 600 python tools/find_matches_rate.py 38 74 4096 > "$OUT/r5_fm_config2_final.txt" 2>&1; tail -n 3 "$OUT/r5_fm_config2_final.txt"
+echo "== bench $(date +%T)"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/r5_bench_latest.json" 2> "$OUT/r5_bench_latest.err"; tail -c 1800 "$OUT/r5_bench_latest.json"; echo
+for N in 512 4096; do
+echo "== e2e-full $N $(date +%T)"
+IAMX_LINK_TIMING=1 timeout 1700 python bench.py --images 64 --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey --e2e-full $N > "$OUT/r5_e2e_final_$N.raw" 2> "$OUT/r5_e2e_final_$N.err"
+python - "$N" <<'PY'
+import json, sys
+try:
+    d = json.loads(open('gpurun_out/r5_e2e_final_%s.raw' % sys.argv[1]).read().strip().splitlines()[-1])
+    e = d.get('e2e_full')
+    json.dump(e, open('gpurun_out/r5_e2e_full_%d_final.json' % e['images'], 'w'), indent=1)
+    print(json.dumps({k: e.get(k) for k in ('images', 'stage_seconds', 'total_seconds', 'images_per_sec_end_to_end', 'peak_hbm_bytes', 'host_peak_rss_bytes', 'hbm_after_match', 'hbm_model', 'ba', 'image_pairs_matched', 'image_pairs_with_matches', 'keypoints_per_image', 'render_seconds_untimed', 'max_baseline_error_m', 'route_rounds')}))
+except Exception as ex:
+    print('no result', ex)
+PY
+grep iamx_link_matches "$OUT/r5_e2e_final_$N.err" > "$OUT/r5_link_passes_$N.txt"; tail -3 "$OUT/r5_link_passes_$N.txt"
+done
+echo "== done $(date +%T)"
