@@ -61,6 +61,7 @@ SIGNATURES = {
     'iamx_thp_pays': (c_int, []),
     'iamx_link_matches': (c_int64, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
+    'iamx_chain_members_uv': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'iamx_kp_key2': (c_int, [c_void_p, c_int64, c_void_p]),
     'iamx_kp_dup_remap': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     'iamx_match_lists_scan': (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),

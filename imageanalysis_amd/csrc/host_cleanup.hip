@@ -781,6 +781,55 @@ extern "C" int iamx_match_lists_scan(int32_t *const *lists, const int64_t *cnt, 
     return IAMX_OK;
 }
 
+// uv[k] = (double) kp.pt of member k of the chains: keypoint f_kp[k] of image f_img[k], read from
+// the images' own keypoint arrays (xy[i] = float32 [n_kp[i]][2]) -- the "replace keypoint indices
+// with uv coordinates" step of scripts/lib/match_cleanup.py:277-287.  A negative index counts from
+// the end of the image's list like python's kp_list[m[1]]; an index outside the list is
+// IAMX_EINVAL with *bad_member = the first offending member (the reference raises IndexError).
+// The numpy form (a concatenation of every image's positions, five index passes and a gather over
+// all members) was a third of link_matches' time on a survey of thousands of frames.
+extern "C" int iamx_chain_members_uv(const int32_t *f_img, const int32_t *f_kp, int64_t n_members,
+                                     const float *const *xy, const int64_t *n_kp, int32_t n_images,
+                                     double *uv, int64_t *bad_member, int threads)
+{
+    if (n_members < 0 || n_images < 0 || (n_members > 0 && (!f_img || !f_kp || !xy || !n_kp || !uv)))
+        return iamx::fail(IAMX_EINVAL, "iamx_chain_members_uv: null pointer or negative count");
+    std::atomic<int64_t> first_bad{-1};
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(threads, 1), n_members >> 16));
+    auto work = [&](int t) {
+        const int64_t lo = n_members * t / nt, hi = n_members * (t + 1) / nt;
+        constexpr int64_t AHEAD = 16;
+        for (int64_t k = lo; k < hi; ++k) {
+            if (k + AHEAD < hi) {
+                const int32_t ia = f_img[k + AHEAD];
+                if (ia >= 0 && ia < n_images && xy[ia]) {
+                    int64_t ka = f_kp[k + AHEAD];
+                    if (ka < 0) ka += n_kp[ia];
+                    if (ka >= 0 && ka < n_kp[ia]) __builtin_prefetch(xy[ia] + 2 * ka, 0, 1);
+                }
+            }
+            const int32_t i = f_img[k];
+            int64_t kp = f_kp[k];
+            if (i < 0 || i >= n_images) { kp = -1; } else { if (kp < 0) kp += n_kp[i]; if (kp >= n_kp[i]) kp = -1; }
+            if (kp < 0) {
+                int64_t cur = first_bad.load();
+                while ((cur < 0 || k < cur) && !first_bad.compare_exchange_weak(cur, k)) {}
+                uv[2 * k] = uv[2 * k + 1] = 0.0;
+                continue;
+            }
+            uv[2 * k] = (double)xy[i][2 * kp];
+            uv[2 * k + 1] = (double)xy[i][2 * kp + 1];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread &t : pool) t.join();
+    if (bad_member) *bad_member = first_bad.load();
+    if (first_bad.load() >= 0) return iamx::fail(IAMX_EINVAL, "iamx_chain_members_uv: keypoint index out of range");
+    return IAMX_OK;
+}
+
 // The chains of iamx_link_matches, longest first, chains of equal length in their given order
 // (list.sort(key=len, reverse=True) of match_cleanup.py:291-292 is stable): a counting sort of
 // the chains by length, then the members copied chain by chain on `threads` threads.  out_ptr

@@ -73,29 +73,46 @@ def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None
     python lists (the caller's per-list numpy path).  wanted(i, j): scan this pair at all?"""
     import ctypes
     from ._lib import check, lib
-    entries, rest, arrays = [], [], []
-    for i, i1 in enumerate(proj.image_list):
-        for key, matches in i1.match_list.items():
-            j = index.get(key)
-            if j is None or len(matches) == 0:
-                continue
-            if wanted is not None and not wanted(i, j):
-                continue
-            a = matches._a if isinstance(matches, MatchPairs) else None
-            if a is not None and a.dtype == np.int32 and a.flags.c_contiguous and a.flags.writeable:
-                entries.append((i, key, j, matches))
-                arrays.append(a)
-            else:
-                rest.append((i, key, j, matches))
+    # the four scans of a consolidation walk the same lists: their tables (which lists are array
+    # backed, the pointers, counts and image pairs) are made once and kept on the project while
+    # no list object or backing array has been replaced
+    sig_n, sig_h = 0, 0
+    for i1 in proj.image_list:
+        for m in i1.match_list.values():
+            sig_n += 1
+            sig_h = (sig_h * 1000003) ^ id(m) ^ (id(m._a) if isinstance(m, MatchPairs) else 0)
+    sig_h &= (1 << 62) - 1
+    cached = getattr(proj, '_iamx_scan', None) if wanted is None else None
+    if cached is not None and cached[0] == (sig_n, sig_h, len(proj.image_list)):
+        entries, rest, arrays, tables = cached[1:]
+    else:
+        entries, rest, arrays, tables = [], [], [], None
+        for i, i1 in enumerate(proj.image_list):
+            for key, matches in i1.match_list.items():
+                j = index.get(key)
+                if j is None or len(matches) == 0:
+                    continue
+                if wanted is not None and not wanted(i, j):
+                    continue
+                a = matches._a if isinstance(matches, MatchPairs) else None
+                if a is not None and a.dtype == np.int32 and a.flags.c_contiguous and a.flags.writeable:
+                    entries.append((i, key, j, matches))
+                    arrays.append(a)
+                else:
+                    rest.append((i, key, j, matches))
     n = len(entries)
     dup_pairs, dup_first = np.zeros(n, np.int32), np.zeros(n, np.int32)
     if n:
         if base is None:
             base = _kp_base(proj)
-        ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
-        cnt = np.fromiter((len(a) for a in arrays), np.int64, n)
-        ia = np.fromiter((e[0] for e in entries), np.int32, n)
-        ib = np.fromiter((e[2] for e in entries), np.int32, n)
+        if tables is None:
+            tables = ((ctypes.c_void_p * n)(*[a.__array_interface__['data'][0] for a in arrays]),
+                      np.fromiter((len(a) for a in arrays), np.int64, n),
+                      np.fromiter((e[0] for e in entries), np.int32, n),
+                      np.fromiter((e[2] for e in entries), np.int32, n))
+        ptrs, cnt, ia, ib = tables
+        if wanted is None:
+            proj._iamx_scan = ((sig_n, sig_h, len(proj.image_list)), entries, rest, arrays, tables)
         P = lambda x: None if x is None else x.ctypes.data_as(ctypes.c_void_p)
         rc = lib().iamx_match_lists_scan(ptrs, P(cnt), P(ia), P(ib), n, P(base), len(proj.image_list),
                                          P(used), P(remap), mode, P(dup_pairs), P(dup_first), SCAN_THREADS)
@@ -467,31 +484,33 @@ def link_matches(proj, matches_direct):
     if rc != 0:
         raise RuntimeError("iamx_chains_longest_first failed (%d): %s"
                            % (rc, (lib().iamx_last_error() or b'?').decode()))
-    # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt)): ONE
-    # gather from the images' keypoint positions laid end to end, in the final order (a scatter
-    # per image behind a sort of the members by image was 1 s of a 512-frame survey's 3.9 s)
-    seen = np.zeros(len(proj.image_list), bool)
-    seen[f_img] = True
-    xy_of = [(_kp_xy(im) if seen[i] else np.zeros((0, 2), np.float32))
-             for i, im in enumerate(proj.image_list)]
-    first = np.zeros(len(xy_of) + 1, np.int64)
-    np.cumsum([len(x) for x in xy_of], out=first[1:])
-    xy_all = np.concatenate(xy_of) if xy_of else np.zeros((0, 2), np.float32)
+    # kp.pt of every chain member (python floats of the float32 values, like list(kp.pt)), in the
+    # final order: one native pass over the members that reads the images' own position arrays
+    # (iamx_chain_members_uv).  The reference's kp_list[m[1]] raises IndexError for a keypoint
+    # index its image does not have -- a .match file that is stale against its .feat --, negative
+    # indices wrap inside the image: both are kept.
+    import ctypes
+    n_img = len(proj.image_list)
+    xy_of, n_kp = [None] * n_img, np.zeros(max(n_img, 1), np.int64)
+    uv = empty_huge((total, 2), np.float64) if total else np.zeros((0, 2), np.float64)
     if total:
-        # (the reference's kp_list[m[1]] raises IndexError for a keypoint index its image does not
-        #  have -- a .match file that is stale against its .feat; the flat gather would read a
-        #  NEIGHBOURING image's keypoint instead.  Negative indices wrap inside the image, as there.)
-        n_kp = np.diff(first)[f_img]
-        kp = np.where(f_kp < 0, f_kp + n_kp, f_kp)
-        bad = (kp < 0) | (kp >= n_kp)
-        if bad.any():
-            k = int(np.nonzero(bad)[0][0])
-            raise IndexError("list index out of range: keypoint %d of %s (%d keypoints); is its "
-                             ".match file stale against the .feat?"
-                             % (int(f_kp[k]), proj.image_list[int(f_img[k])].name, int(n_kp[k])))
-        uv = xy_all[first[f_img] + kp].astype(np.float64)
-    else:
-        uv = np.zeros((0, 2), np.float64)
+        # positions of every image that occurs (a missing one shows up as an out-of-range index)
+        occurs = np.zeros(n_img, bool)
+        occurs[f_img] = True
+        for i in np.nonzero(occurs)[0].tolist():
+            xy_of[i] = np.ascontiguousarray(_kp_xy(proj.image_list[i]), np.float32).reshape(-1, 2)
+            n_kp[i] = len(xy_of[i])
+        ptrs = (ctypes.c_void_p * max(n_img, 1))(*[(a.ctypes.data if a is not None and len(a) else None) for a in xy_of])
+        bad = np.full(1, -1, np.int64)
+        rc = lib().iamx_chain_members_uv(P(f_img), P(f_kp), total, ptrs, P(n_kp), n_img, P(uv), P(bad), SCAN_THREADS)
+        if rc != 0:
+            k = int(bad[0])
+            if k >= 0:
+                raise IndexError("list index out of range: keypoint %d of %s (%d keypoints); is its "
+                                 ".match file stale against the .feat?"
+                                 % (int(f_kp[k]), proj.image_list[int(f_img[k])].name, int(n_kp[int(f_img[k])])))
+            raise RuntimeError("iamx_chain_members_uv failed (%d): %s"
+                               % (rc, (lib().iamx_last_error() or b'?').decode()))
     out = Chains(f_img, uv, new_ptr)
     if n_chain:
         _log("Total unique features in image set:", n_chain)

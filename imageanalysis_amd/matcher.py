@@ -613,10 +613,12 @@ def _no_gc():
             # the first allocation after enable() pays a full pass over all of them (~0.3 s).
             # freeze() also pins whatever garbage CYCLES exist at that moment -- exception
             # tracebacks, objects holding device or page-locked buffers -- for the life of the
-            # process, so: only a call that left a survey's worth of objects freezes (a small
-            # call's walk is cheap anyway), and the young generations are collected first.
+            # process, so only a call that left a survey's worth of objects freezes (a small
+            # call's walk is cheap anyway).  (Collecting the young generations first, as was tried
+            # in round 5, IS the walk over everything the call made -- the collector was off, all of
+            # it sits in generation 0: 0.3 s at the end of the 2812-image survey,
+            # profiles/r5_fm_config2_final.txt against r4_fm_config2_run.txt.)
             if hasattr(gc, 'freeze') and _tracked_objects() - before > FREEZE_MIN_OBJECTS:
-                gc.collect(1)
                 gc.freeze()
             gc.enable()
 

@@ -333,6 +333,14 @@ int64_t iamx_link_matches(const int32_t *img, const int32_t *kp, const int64_t *
 int64_t iamx_link_pair_blocks(const int32_t *const *blocks, const int64_t *counts, const int32_t *ij,
                               int64_t n_blocks, int32_t *out_img, int32_t *out_kp, int64_t *out_ptr,
                               int32_t *n_passes);
+/* iamx_chain_members_uv -- HOST.  The "replace keypoint indices with uv coordinates" step of
+ * link_matches (scripts/lib/match_cleanup.py:277-287) for all chain members at once: uv[k] =
+ * (double) kp.pt of keypoint f_kp[k] of image f_img[k], from the images' own position arrays
+ * (xy[i] float32 [n_kp[i]][2]).  Negative indices count from the end like a python list's; an index
+ * outside the image's list -> IAMX_EINVAL, *bad_member = the first such member. */
+int iamx_chain_members_uv(const int32_t *f_img, const int32_t *f_kp, int64_t n_members,
+                          const float *const *xy, const int64_t *n_kp, int32_t n_images, double *uv,
+                          int64_t *bad_member, int threads);
 /* iamx_kp_key2 -- HOST.  key2[k] = round-half-even(100 * xy[k]) in exact integer arithmetic: the
  * "%.2f-%.2f" % kp.pt keys of scripts/lib/matcher.py:166-167 and match_cleanup.py:36-38 as integer
  * pairs (xy float32 [n][2] in [0, 16384), key2 int32 [n][2]).

@@ -357,3 +357,59 @@ sys.stdout.buffer.write(pickle.dumps(out))
                                                 capture_output=True).stdout))
     assert runs[0] == runs[1]
     assert max(r[1] for r in runs[0]) >= 3                # several passes were needed somewhere
+
+
+@pytest.mark.parametrize('path', CASES, ids=os.path.basename)
+def test_consolidation_of_array_backed_lists_equals_reference(path):
+    """the same goldens with the match lists as find_matches leaves them (matchpairs.MatchPairs over
+    int32 arrays): compute_kp_usage, the remap of merge_duplicates and the two duplicate checks run
+    as native passes over the arrays (iamx_match_lists_scan, iamx_kp_dup_remap), the chains are
+    linked from the pair blocks as they lie (iamx_link_pair_blocks) and get their pixel positions
+    in one native pass (iamx_chain_members_uv)"""
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd.keypoints import KeyPointList
+    from imageanalysis_amd.matchpairs import MatchPairs
+    with open(path, 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    for im, xy in zip(proj.image_list, g['inputs']['xy']):
+        xy = np.asarray(xy, np.float32)
+        z = np.zeros(len(xy), np.float32)
+        im.kp_list = KeyPointList(xy[:, 0].copy(), xy[:, 1].copy(), z + 3.0, z, z, z.astype(np.int32))
+        im.match_list = {k: (MatchPairs(np.asarray(v, np.int32).reshape(-1, 2)) if len(v) else [])
+                         for k, v in im.match_list.items()}
+    match_cleanup.merge_duplicates(proj)
+    match_cleanup.check_for_pair_dups(proj)
+    match_cleanup.check_for_1vn_dups(proj)
+    for im, want, used in zip(proj.image_list, g['match_lists_after'], g['kp_used']):
+        assert list(im.match_list.keys()) == list(want.keys())
+        for k in want:
+            assert im.match_list[k] == want[k], (im.name, k)
+        assert np.array_equal(im.kp_used, used)
+    direct = match_cleanup.make_match_structure(proj)
+    grouped = match_cleanup.link_matches(proj, direct)
+    assert direct.untouched()                               # (linked from the blocks: no lists were built)
+    assert grouped == g['matches_grouped']
+    assert direct == g['matches_direct']
+
+
+def test_link_matches_reports_a_stale_keypoint_index():
+    """a match list that refers to a keypoint its image does not have (a .match file stale against
+    the .feat): the reference's kp_list[m[1]] raises IndexError; the native passes do too instead of
+    reading a neighbouring image's keypoint"""
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd.matchpairs import MatchPairs
+    with open(CASES[0], 'rb') as f:
+        g = pickle.load(f)
+    proj = _project(g)
+    a, b = proj.image_list[0], proj.image_list[1]
+    n_b = len(b.kp_list)
+    a.match_list = {b.name: MatchPairs(np.array([[0, 1], [2, n_b + 5]], np.int32))}
+    b.match_list = {a.name: MatchPairs(np.array([[1, 0], [n_b + 5, 2]], np.int32))}
+    for im in proj.image_list[2:]:
+        im.match_list = {}
+    with pytest.raises(IndexError):
+        match_cleanup.merge_duplicates(proj)
+    direct = match_cleanup.make_match_structure(proj)
+    with pytest.raises(IndexError):
+        match_cleanup.link_matches(proj, direct)
