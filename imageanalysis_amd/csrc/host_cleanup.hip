@@ -216,10 +216,120 @@ int64_t link_impl(const LinkInput &in, int64_t n_matches, int64_t n_pts, int32_t
     const bool timing = getenv("IAMX_LINK_TIMING") != nullptr;        // per-pass seconds on stderr
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (timing) fprintf(stderr, "iamx_link_matches setup: %.3f s\n", now() - t_enter);
+    // chains of a pass's OUTPUT that share a point with another one (ids = creation order = the
+    // next pass's input order): the two ends of every join that appended a point already
+    // registered elsewhere.  When they are few the next pass only has to look at them (below).
+    std::vector<int32_t> touched;
+    bool touched_complete = true;
+    const bool full_only = verify || getenv("IAMX_LINK_FULL") != nullptr;    // (A/B: every pass the full walk)
     while (true) {
         ++passes;
         const double t_pass = now();
         bool shared = false;
+        // ---- incremental pass: a chain that shares no point with any other chain is copied by a
+        // full pass exactly as it is (nothing it looks up is registered, nothing it registers is
+        // looked up by anybody else), so only the chains named in `touched` are walked -- in input
+        // order, against a small hash map over THEIR points -- and the result is assembled by one
+        // sequential copy.  Same output as the full walk (IAMX_LINK_FULL=1 / IAMX_LINK_VERIFY=1 run
+        // that one; tests compare); the late passes of a survey merge a handful of chains and
+        // cost a full walk over ~10^8 points each.
+        if (!full_only && passes > 1 && touched_complete && (int64_t)touched.size() * 8 < n_cur) {
+            std::sort(touched.begin(), touched.end());
+            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+            const size_t nt_ = touched.size();
+            struct Root { std::vector<int32_t> ex_img, ex_kp, imgs; };
+            std::vector<int32_t> root_of(nt_, -1);           // per touched chain: its root (itself or the chain it joined)
+            std::vector<uint8_t> is_root(nt_, 0);
+            std::vector<Root> roots(nt_);
+            size_t pts_t = 0;
+            for (size_t k = 0; k < nt_; ++k) pts_t += (size_t)(c_ptr[(size_t)touched[k] + 1] - c_ptr[(size_t)touched[k]]);
+            PointMap H(pts_t);
+            std::vector<int32_t> next_touched;               // (root positions among `touched`, mapped below)
+            for (size_t k = 0; k < nt_; ++k) {
+                const int64_t b = c_ptr[(size_t)touched[k]], e = c_ptr[(size_t)touched[k] + 1];
+                int32_t index = -1;
+                for (int64_t j = b; j < e; ++j) {
+                    const size_t h = H.slot(PointMap::code(c_img[j], c_kp[j]));
+                    if (H.key[h] != 0) { index = H.val[h]; break; }
+                }
+                if (index < 0) {
+                    is_root[k] = 1;
+                    root_of[k] = (int32_t)k;
+                    Root &R = roots[k];
+                    for (int64_t j = b; j < e; ++j) {
+                        const uint64_t c = PointMap::code(c_img[j], c_kp[j]);
+                        const size_t h = H.slot(c);
+                        H.key[h] = c;
+                        H.val[h] = (int32_t)k;
+                        R.imgs.push_back(c_img[j]);
+                    }
+                } else {
+                    root_of[k] = index;
+                    Root &R = roots[(size_t)index];
+                    for (int64_t j = b; j < e; ++j) {
+                        const int32_t pi = c_img[j], pk = c_kp[j];
+                        bool have = false;
+                        for (int32_t im : R.imgs) if (im == pi) { have = true; break; }
+                        if (have) continue;
+                        const uint64_t c = PointMap::code(pi, pk);
+                        const size_t h = H.slot(c);
+                        if (H.key[h] != 0 && H.val[h] != index) {
+                            shared = true;
+                            next_touched.push_back(index);
+                            next_touched.push_back(H.val[h]);
+                        }
+                        R.ex_img.push_back(pi);
+                        R.ex_kp.push_back(pk);
+                        R.imgs.push_back(pi);
+                        H.key[h] = c;
+                        H.val[h] = index;
+                    }
+                }
+            }
+            // assemble: every input chain in order -- untouched ones and roots (with what joined
+            // them) stay, the touched chains that joined a root are gone
+            std::vector<int32_t> out_pos(nt_, -1);
+            int64_t o = 0, n_new = 0;
+            size_t tk = 0;
+            int32_t *d_img = node_img.data(), *d_kp = node_kp.data();
+            for (int64_t i = 0; i < n_cur; ++i) {
+                const int64_t b = c_ptr[(size_t)i], e = c_ptr[(size_t)i + 1];
+                const bool is_t = tk < nt_ && touched[tk] == (int32_t)i;
+                if (is_t && !is_root[tk]) { ++tk; continue; }
+                cursor[(size_t)n_new] = o;
+                std::memcpy(d_img + o, c_img.data() + b, (size_t)(e - b) * sizeof(int32_t));
+                std::memcpy(d_kp + o, c_kp.data() + b, (size_t)(e - b) * sizeof(int32_t));
+                o += e - b;
+                if (is_t) {
+                    const Root &R = roots[tk];
+                    std::memcpy(d_img + o, R.ex_img.data(), R.ex_img.size() * sizeof(int32_t));
+                    std::memcpy(d_kp + o, R.ex_kp.data(), R.ex_kp.size() * sizeof(int32_t));
+                    o += (int64_t)R.ex_img.size();
+                    out_pos[tk] = (int32_t)n_new;
+                    ++tk;
+                }
+                ++n_new;
+            }
+            cursor[(size_t)n_new] = o;
+            std::memcpy(c_img.data(), d_img, (size_t)o * sizeof(int32_t));
+            std::memcpy(c_kp.data(), d_kp, (size_t)o * sizeof(int32_t));
+            std::memcpy(c_ptr.data(), cursor.data(), (size_t)(n_new + 1) * sizeof(int64_t));
+            touched.clear();
+            for (int32_t r : next_touched) touched.push_back(out_pos[(size_t)r]);
+            if (timing)
+                fprintf(stderr, "iamx_link_matches pass %d: %lld -> %lld chains, incremental over %zu chains, %.3f s\n",
+                        passes, (long long)n_cur, (long long)n_new, nt_, now() - t_pass);
+            const bool done_i = n_new == n_cur;
+            n_cur = n_new;
+            if (done_i) break;
+            if (!shared) {
+                ++passes;                                   // the pass that would change nothing
+                break;
+            }
+            continue;
+        }
+        touched.clear();
+        touched_complete = true;
         if (dense) std::memset(table.data(), 0xff, table_n * sizeof(int32_t));      // every entry -1
         else map.clear();
         n_chains = 0;
@@ -287,7 +397,18 @@ int64_t link_impl(const LinkInput &in, int64_t n_matches, int64_t n_pts, int32_t
                 for (int64_t j = b; j < e; ++j) {
                     if (!in_chain(index, c_img[j])) {
                         const int32_t owner = lookup(c_img[j], c_kp[j]);
-                        if (owner >= 0 && owner != index) shared = true;
+                        if (owner >= 0 && owner != index) {
+                            shared = true;
+                            if (touched_complete) {
+                                if ((int64_t)touched.size() * 4 < n_cur + 1024) {
+                                    touched.push_back(index);
+                                    touched.push_back(owner);
+                                } else {
+                                    touched_complete = false;   // (too many to be worth it)
+                                    touched.clear();
+                                }
+                            }
+                        }
                         append(index, c_img[j], c_kp[j]);
                         store(c_img[j], c_kp[j], index);
                     }

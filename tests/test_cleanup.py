@@ -413,3 +413,115 @@ def test_link_matches_reports_a_stale_keypoint_index():
     direct = match_cleanup.make_match_structure(proj)
     with pytest.raises(IndexError):
         match_cleanup.link_matches(proj, direct)
+
+
+def test_consolidation_scans_stay_linear_in_the_number_of_lists():
+    """(round 5 regression) the table signature of match_cleanup._scan_lists once multiplied an
+    unmasked python integer per list: 133 k lists of a 4186-frame survey cost 6 s per scan.  120 k
+    one-row lists must go through the four scans in a few seconds."""
+    import time
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from imageanalysis_amd.keypoints import KeyPointList
+    from imageanalysis_amd.matchpairs import MatchPairs
+    n_img, fan = 1200, 50
+    proj = PoseProject(['L%04d' % i for i in range(n_img)])
+    z = np.zeros(4, np.float32)
+    for i, im in enumerate(proj.image_list):
+        im.kp_list = KeyPointList(z + [1, 2, 3, 4], z + [5, 6, 7, 8], z + 3, z, z, z.astype(np.int32))
+        im.match_list = {}
+    for i in range(n_img):
+        for d in range(1, fan + 1):
+            j = (i + d) % n_img
+            proj.image_list[i].match_list[proj.image_list[j].name] = MatchPairs(np.array([[d % 4, (d + 1) % 4]], np.int32))
+            proj.image_list[j].match_list[proj.image_list[i].name] = MatchPairs(np.array([[(d + 1) % 4, d % 4]], np.int32))
+    t0 = time.perf_counter()
+    match_cleanup.merge_duplicates(proj)
+    match_cleanup.check_for_pair_dups(proj)
+    match_cleanup.check_for_1vn_dups(proj)
+    dt = time.perf_counter() - t0
+    assert sum(len(im.match_list) for im in proj.image_list) == 2 * n_img * fan
+    assert dt < 8.0, dt
+
+
+def test_link_matches_incremental_passes_equal_the_full_walk(capfd):
+    """Late passes of iamx_link_matches only walk the chains that share a point with another chain
+    (round 5).  Same chains, same order, same number of passes as the full walk (IAMX_LINK_FULL=1) and
+    as a literal python transcription of the reference's loop, on surveys whose conflicting matches
+    (two keypoints of one image in one chain's reach) force several passes."""
+    import ctypes
+    from imageanalysis_amd import _lib
+
+    def python_rules(ptr, img, kp):
+        matches = [[(int(img[j]), int(kp[j])) for j in range(ptr[m], ptr[m + 1])] for m in range(len(ptr) - 1)]
+        passes = 0
+        while True:
+            passes += 1
+            new, lookup = [], {}
+            for match in matches:
+                index = -1
+                for p in match:
+                    if p in lookup:
+                        index = lookup[p]
+                        break
+                if index < 0:
+                    for p in match:
+                        lookup[p] = len(new)
+                    new.append(list(match))
+                else:
+                    existing = new[index]
+                    for p in match:
+                        if not any(p[0] == e[0] for e in existing):
+                            existing.append(p)
+                            lookup[p] = index
+            if len(new) == len(matches):
+                return new, passes
+            matches = new
+
+    def native(img, kp, ptr):
+        n = len(ptr) - 1
+        o_img, o_kp = np.empty_like(img), np.empty_like(kp)
+        o_ptr = np.zeros(n + 1, np.int64)
+        passes = np.zeros(1, np.int32)
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        nc = int(_lib.lib().iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr), P(passes)))
+        assert nc >= 0
+        o_ptr = o_ptr[:nc + 1]
+        return [[(int(o_img[j]), int(o_kp[j])) for j in range(o_ptr[c], o_ptr[c + 1])] for c in range(nc)], int(passes[0])
+
+    used_incremental = 0
+    for seed, n_img, n_kp, n_tracks in ((1, 30, 400, 3000), (2, 60, 150, 6000), (3, 12, 60, 900)):
+        rng = np.random.default_rng(seed)
+        pairs = []
+        for _ in range(n_tracks):
+            # a track seen by a run of images; now and then the "same" feature is matched through
+            # ANOTHER keypoint of an image (a conflict the linking resolves over several passes)
+            length = int(rng.integers(2, 8))
+            start = int(rng.integers(0, n_img - length + 1))
+            kps = rng.integers(0, n_kp, length)
+            for a in range(length):
+                for b in range(a + 1, min(a + 3, length)):
+                    ka, kb = int(kps[a]), int(kps[b])
+                    if rng.random() < 0.15:
+                        kb = int(rng.integers(0, n_kp))
+                    pairs.append((start + a, ka, start + b, kb))
+        order = rng.permutation(len(pairs))
+        img = np.array([[pairs[k][0], pairs[k][2]] for k in order], np.int32).ravel()
+        kp = np.array([[pairs[k][1], pairs[k][3]] for k in order], np.int32).ravel()
+        ptr = np.arange(len(pairs) + 1, dtype=np.int64) * 2
+        want, want_passes = python_rules(ptr, img, kp)
+        os.environ['IAMX_LINK_TIMING'] = '1'
+        try:
+            got, got_passes = native(img, kp, ptr)
+            err = capfd.readouterr().err
+            os.environ['IAMX_LINK_FULL'] = '1'
+            full, full_passes = native(img, kp, ptr)
+            capfd.readouterr()
+        finally:
+            os.environ.pop('IAMX_LINK_TIMING', None)
+            os.environ.pop('IAMX_LINK_FULL', None)
+        assert got == want and full == want, seed
+        assert got_passes == want_passes == full_passes, (seed, got_passes, want_passes, full_passes)
+        used_incremental += err.count('incremental over')
+        assert want_passes >= 3
+    assert used_incremental >= 2                          # the path under test did run
