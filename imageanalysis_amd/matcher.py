@@ -64,8 +64,9 @@ PACK_CAP = 4 << 20      # matches a batch's packed download holds (more: that ba
 # 512 rendered frames (3.36 s symmetric, 3.44 s routed, f = 0.17), SLOWER on the workloads with many
 # true survivors: the dense-overlap workload of bench.py (f = 0.28) runs 0.63x as fast in the
 # one-direction form (its per-survivor finish costs more than the exact stage it replaces), the
-# dense 400-image survey 76 k instead of 87 k pairs/s, configs[2] 394 k instead of 420 k -- and the
-# parity-partitioned layout it needs is another 140 B per descriptor row.  So the default is
+# dense 400-image survey 76 k instead of 80 k pairs/s through find_matches (same code otherwise;
+# configs[2], whose dense rounds are few, is unaffected) -- and the parity-partitioned layout it
+# needs is another 140 B per descriptor row.  So the default is
 # 'never'; 'auto' / 'always' remain for A/B runs (IAMX_DENSE_ROUTE).  Results are identical in all
 # modes (tests/test_mirror_gpu.py).
 DENSE_ROUTE = os.environ.get('IAMX_DENSE_ROUTE', 'never')
