@@ -795,3 +795,20 @@ def test_native_kp_keys_and_dup_remap_equal_the_numpy_form():
         assert np.array_equal(remap[b:e], want_r), i
         assert bool(ident[i]) == bool((want_r == np.arange(e - b)).all())
     assert not ident[0] and ident[1]
+
+
+def test_device_memory_model_of_the_matching_stage():
+    """matcher.device_memory_model (DESIGN section 3 "memory at scale"): only the arena grows with
+    the survey; the figures quoted for BASELINE configs[4]'s 10 000 frames"""
+    from imageanalysis_amd import matcher
+    m = matcher.device_memory_model(10000, 37000)
+    rows = (37000 + 127) // 128 * 128
+    assert m['arena_bytes'] == 10000 * rows * 284 + 10000 * 37000 * 16
+    assert 100e9 < m['arena_bytes'] < 112e9
+    assert m['workspace_bytes_each'] <= matcher.BATCH_BYTES
+    assert m['peak_bytes'] < 288e9                                  # fits one MI355X
+    with_copy = matcher.device_memory_model(10000, 37000, train_layout=True)
+    assert with_copy['arena_bytes'] - m['arena_bytes'] == 10000 * rows * 140
+    small = matcher.device_memory_model(128, 38000)
+    assert small['workspace_bytes_each'] == m['workspace_bytes_each'] or small['pairs_per_batch'] >= m['pairs_per_batch']
+    assert small['arena_bytes'] < 1.6e9
