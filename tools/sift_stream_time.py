@@ -46,6 +46,8 @@ alg = 469.0 * h * w
 print("graph=%s  one stream: %.3f ms per detect on the stream (host enqueue %.3f ms), %d keypoints, "
       "%.1f GB/s algorithmic = %.4f of 8 TB/s" % (os.environ.get('IAMX_SIFT_GRAPH') == '1', ms, t_host / n * 1e3,
                                                  int(b0[3].item()), alg / ms / 1e6, alg / ms / 1e6 / 8000.0))
+if os.environ.get('IAMX_SIFT_SINGLE') == '1':
+    sys.exit(0)
 # 8 detectors in flight, one thread + stream + buffer set each
 K = 8
 bufs = [buffers() for _ in range(K)]
