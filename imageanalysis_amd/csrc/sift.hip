@@ -30,6 +30,7 @@
 // Pyramid traffic: 6 Gaussian + 5 DoG f32 levels per octave written once, read once
 // (~469 B per detect-resolution pixel).
 #include "iamx_common.h"
+#include <algorithm>
 #include <mutex>
 #include <stdlib.h>
 
@@ -329,12 +330,10 @@ struct GaussStack {
 constexpr int EXT_ROWS = 16;      // rows per wave (4 waves of a workgroup: 64 rows)
 constexpr int EXT_LIST = 512;     // candidates a workgroup collects before its one global atomic
 
-__global__ __launch_bounds__(256) void extrema_kernel(GaussStack G, int h, int w, int o,
-                                                      float threshold, Cand *__restrict__ cand,
-                                                      int cap, int *__restrict__ count, int xcd)
+__device__ __forceinline__ void extrema_tile(const GaussStack &G, int h, int w, int o, float threshold,
+                                             Cand *__restrict__ cand, int cap, int *__restrict__ count,
+                                             int tile_x, int tile_y)
 {
-    const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
-    const int tile_x = tile % (int)gridDim.x, tile_y = tile / (int)gridDim.x;
     // Candidates are ~1 % of the pixels; one global atomicAdd each on the single counter was the
     // whole cost of this kernel (~150 k same-address device-scope atomics per image = 0.75 ms).
     // A workgroup collects its candidates in LDS and reserves their slots with ONE atomic.
@@ -404,6 +403,14 @@ __global__ __launch_bounds__(256) void extrema_kernel(GaussStack G, int h, int w
     }
 }
 
+__global__ __launch_bounds__(256) void extrema_kernel(GaussStack G, int h, int w, int o,
+                                                      float threshold, Cand *__restrict__ cand,
+                                                      int cap, int *__restrict__ count, int xcd)
+{
+    const int tile = xcd_remap(blockIdx.x + blockIdx.y * gridDim.x, gridDim.x * gridDim.y, xcd);
+    extrema_tile(G, h, w, o, threshold, cand, cap, count, tile % (int)gridDim.x, tile / (int)gridDim.x);
+}
+
 struct Pyr {
     // per octave: pointers of the 6 Gaussian levels, dims
     float *g[6];
@@ -414,6 +421,25 @@ struct PyrTable {
     Pyr oct[MAX_OCT];
     int n_oct;
 };
+
+// the extrema scans of SEVERAL small octaves in one launch (blockIdx.z = octave - o_first; a block
+// beyond its octave's tile range exits): the four octaves behind the one-workgroup tail of the
+// pyramid were four dependent launches of a few microseconds of work each, on the critical path
+__global__ __launch_bounds__(256) void extrema_multi_kernel(PyrTable T, int o_first, float threshold,
+                                                            Cand *__restrict__ cand, int cap,
+                                                            int *__restrict__ count)
+{
+    const int o = o_first + (int)blockIdx.z;
+    const Pyr &P = T.oct[o];
+    const int h = P.h, w = P.w;
+    if (!(h > 2 * BORDER && w > 2 * BORDER)) return;
+    const int tiles_x = (w - 2 * BORDER + 61) / 62, tiles_y = (h - 2 * BORDER + 4 * EXT_ROWS - 1) / (4 * EXT_ROWS);
+    if ((int)blockIdx.x >= tiles_x || (int)blockIdx.y >= tiles_y) return;
+    GaussStack G;
+#pragma unroll
+    for (int i = 0; i < NL + 3; ++i) G.g[i] = P.g[i];
+    extrema_tile(G, h, w, o, threshold, cand, cap, count, (int)blockIdx.x, (int)blockIdx.y);
+}
 
 // The smallest octaves (<= TAIL_PIXELS pixels per level) are pure launch latency as separate
 // kernels (~12 us per level for microseconds of work, ~35 launches): ONE workgroup builds all of
@@ -1339,6 +1365,8 @@ namespace {
 struct SideStream {
     hipStream_t stream;
     hipEvent_t fork, join;
+    hipStream_t stream2;          // the one-workgroup tail of the pyramid beside the last strip octave
+    hipEvent_t fork2, join2;
 };
 
 SideStream *side_stream()
@@ -1355,8 +1383,11 @@ SideStream *side_stream()
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (hipStreamCreateWithPriority(&S.stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&S.stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
             hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.fork2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.join2, hipEventDisableTiming) != hipSuccess) {
             failed[dev] = true;
             return nullptr;
         }
@@ -1572,18 +1603,41 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
     int o_tail = L.n_oct;
     for (int o = L.n_oct - 1; o >= (o_side > 1 ? o_side : 1) && (int64_t)L.h[o] * (L.w[o] | 1) <= TAIL_PIXELS; --o)
         o_tail = o;
-    for (int o = o_side; o < o_tail; ++o) {
-        downsample(ts, o);
-        for (int i = 1; i < NL + 3; ++i)
-            blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i]);
-        extrema(ts, o);
-    }
-    if (o_tail < L.n_oct) {
+    // The one-workgroup tail (0.25 ms) only needs level NL of the last strip octave: it starts on a
+    // THIRD stream as soon as that level exists, beside the octave's two remaining levels and its
+    // extrema scan, and the scans of its own octaves are one launch (round 5: the chain tail ->
+    // four small scans used to END 0.1 ms after the main stream had run out of work,
+    // profiles/r5_sift_single_timeline.txt).
+    auto launch_tail = [&](hipStream_t q) {
         TapSet TS;
         for (int i = 1; i < NL + 3; ++i) TS.t[i - 1] = taps[i];
-        hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, ts, T, o_tail, TS);
-        for (int o = o_tail; o < L.n_oct; ++o) extrema(ts, o);
+        hipLaunchKernelGGL(pyramid_tail_kernel, dim3(1), dim3(1024), 0, q, T, o_tail, TS);
+        int mx = 1, my = 1;
+        for (int o = o_tail; o < L.n_oct; ++o) {
+            if (!(L.h[o] > 2 * BORDER && L.w[o] > 2 * BORDER)) continue;
+            mx = std::max(mx, (L.w[o] - 2 * BORDER + 61) / 62);
+            my = std::max(my, (L.h[o] - 2 * BORDER + 4 * EXT_ROWS - 1) / (4 * EXT_ROWS));
+        }
+        hipLaunchKernelGGL(extrema_multi_kernel, dim3((unsigned)mx, (unsigned)my, (unsigned)(L.n_oct - o_tail)),
+                           dim3(256), 0, q, T, o_tail, threshold, cand, CAP_CAND, n_cand);
+    };
+    bool tail_forked = false;
+    for (int o = o_side; o < o_tail; ++o) {
+        downsample(ts, o);
+        for (int i = 1; i < NL + 3; ++i) {
+            blur(ts, T.oct[o].g[i - 1], T.oct[o].g[i], L.h[o], L.w[o], taps[i]);
+            if (side && o == o_tail - 1 && i == NL && o_tail < L.n_oct) {
+                (void)hipEventRecord(side->fork2, ts);
+                (void)hipStreamWaitEvent(side->stream2, side->fork2, 0);
+                launch_tail(side->stream2);
+                (void)hipEventRecord(side->join2, side->stream2);
+                tail_forked = true;
+            }
+        }
+        extrema(ts, o);
     }
+    if (o_tail < L.n_oct && !tail_forked) launch_tail(ts);
+    if (tail_forked) (void)hipStreamWaitEvent(st, side->join2, 0);
     if (side) (void)hipEventRecord(side->join, ts);
     if (side) (void)hipStreamWaitEvent(st, side->join, 0);
     // the number of candidates is only known on the device: launch for the capacity in slabs
