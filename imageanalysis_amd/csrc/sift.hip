@@ -765,6 +765,7 @@ __device__ __forceinline__ void flush_keypoints(const float *__restrict__ kbuf, 
 // calcOrientationHist over the (2*radius+1)^2 window (lanes stride over the pixels; float32
 // terms W * Mag summed exactly by float64 LDS atomics, each bin rounded to float32 once),
 // float32 smoothing and peak interpolation
+// (96 VGPRs, 5 waves per SIMD: forcing 6 / 8 costs 64 / 132 B of scratch and measured 0 / +2 %)
 __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *__restrict__ refined,
                                                      const int *__restrict__ n_refined, int cap_c,
                                                      float sigma, float *__restrict__ kp, int cap_k,
@@ -879,7 +880,13 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 }
 
 // one wave per keypoint: calcSIFTDescriptor
-__global__ __launch_bounds__(256) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
+// (8 waves per SIMD: 64 VGPRs and 32 B of scratch instead of 86 VGPRs / 5 waves -- the kernel waits
+//  on LDS atomics and image gathers more than it issues; 1.645 / 1.626 / 1.596 ms per detection at
+//  5 / 6 / 8 waves on one box, round 5)
+#ifndef IAMX_DESC_WAVES
+#define IAMX_DESC_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_WAVES, IAMX_DESC_WAVES))) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
                                                          const int *__restrict__ n_kp, int cap_k,
                                                          uint8_t *__restrict__ desc, int xcd)
 {
