@@ -550,7 +550,7 @@ def verify_sample(kernels, store, raw, first, mine, n_img, thresh, n_check, sym)
             if pb.sym else "one-direction sweep, %d-row workgroups" % pb.fast_rows}
 
 
-def dense_overlap_bench(dev, oracle_pairs=4):
+def dense_overlap_bench(dev, oracle_pairs=4, n_img=12, rows=16384):
     """The regime `value` does not see: image pairs that really overlap.  bench.py's survey copies
     30 % of an image's rows from its predecessor only, so 0.1 % of the rows of an average pair are
     candidates of the sweep's bound test and the exact stage (symexact_*) is a rounding error; on
@@ -559,7 +559,6 @@ def dense_overlap_bench(dev, oracle_pairs=4):
     all 66 pairs both ways in one launch; sweep and filter / exact stage timed with events on the
     launch stream; a few ordered pairs checked against oracle/cpu_ref.c afterwards."""
     from imageanalysis_amd import kernels
-    n_img, rows = 12, 16384
     g = torch.Generator(device=dev)
     g.manual_seed(77)
     alpha = torch.full((rows, DIM), 0.6, device=dev)

@@ -52,7 +52,7 @@ SIGNATURES = {
     'iamx_desc3_pack_batch_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]
                                  + [c_void_p] * 7),
     'iamx_knn2sym_sweep': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int] + [c_void_p] * 3),
-    'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 6),
+    'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 7),
     'iamx_knn2sym_exact': (c_int, [c_void_p] * 4 + [c_int64] + [c_void_p] * 8 + [c_int, c_double] + [c_void_p] * 7),
     'iamx_match_postfilter_clip': (c_int, []),
     'iamx_match_pack_results': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64] + [c_void_p] * 4),

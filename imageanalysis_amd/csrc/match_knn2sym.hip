@@ -911,6 +911,7 @@ struct CandArgs {
     int32_t *cand_q;
     int32_t *task_total;         // [2] wave tasks / workgroup tasks appended so far (zeroed by symcompact_kernel)
     int32_t *tasks;              // [..][2] (ordered pair, block): wave tasks from entry 0, workgroup tasks from entry n_pairs
+    int32_t *d2;                 // [rows][2]: [.][1] of a candidate row = upper bound of its exact second distance
 };
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
@@ -951,7 +952,11 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         const float f0 = (float)sqrt((double)Lb);
         const float f1 = (float)sqrt((double)Ub);
         const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
-        A.keep[ob + A.sperm[soff + pos]] = k ? 1 : 0;
+        const int orig = A.sperm[soff + pos];
+        A.keep[ob + orig] = k ? 1 : 0;
+        // what the exact stage prunes its scan with: no row farther than this can be the best or
+        // the second of the candidate (replaced by the exact pair of distances there)
+        if (k) A.d2[2 * (ob + orig) + 1] = (int)(Ub < 0x7FFFFFFFll ? Ub : 0x7FFFFFFFll);
     }
     __syncthreads();             // (workgroup-scope fence: the flags are read back below)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1206,14 +1211,31 @@ __global__ __launch_bounds__(256) void symexact_kernel(ExactArgs A)
 // operands; the four waves share every 32-row train tile through LDS -- fetched once per
 // workgroup, coalesced (thread = 16 bytes of a row, a wave = 8 whole rows) instead of once per wave
 // as 64 scattered 16-byte pieces (what bounded the wave form: the CU's texture addresser, not the
-// VALU).  LDS rows are XOR-swizzled by 16-byte chunk (chunk j of row r sits at j ^ (r & 7)): the
-// MFMA operand reads of 32 lanes x one chunk column spread over the banks.  Two tile buffers, one
+// VALU).  LDS rows are XOR-swizzled by 16-byte chunk (chunk j of row r sits at j ^ ((r >> 1) & 7)):
+// a ds_read_b128 is served in four groups of 16 lanes -- rows {0-3, 12-15, 20-27} and {4-11, 16-19,
+// 28-31} of a lane half -- and two rows share the 64 banks, so the eight row PAIRS of a group must
+// land on eight different chunks; r & 7 left them two-way conflicted (26 % of the LDS cycles).  Two tile buffers, one
 // barrier per tile; tile T + 1 is in flight from L2 while tile T is scanned.
-__global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
+//
+// PRUNE: the scan is bound by the VALU (SQ counters on overlapping frames: 126 VALU instructions
+// per wave and tile, 78 % of the SIMD's issue slots; profiles/r5_exact_pmc_unpruned_*.txt), and 96 of the
+// 126 keep a best and a second over rows that cannot be either: symcand_kernel knows an upper
+// bound U of the candidate's exact second distance (d2[.][1]).  With c = norm_t >> 1 of the train
+// row as the MFMA's C operand the accumulator IS the halved distance term h (distance - norm_q =
+// 2 h + parity of norm_t), a row with h > (U - norm_q) >> 1 is out, and a tile is scanned the old
+// way only if some lane's minimum over its 16 accumulators (8 x v_min3) is not: ~2 rows per
+// candidate, ~60 of a wave's ~1150 tiles.  Keys, ties and the result are the unpruned scan's.
+//
+// SUB tiles are staged per barrier (a PHASE): the waves run that many tiles on their own between
+// two workgroup rendezvous.
+template <bool PRUNE, int SUB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void symexact_wg_kernel(ExactArgs A)
 {
     constexpr int KEY_INVALID = 0x7FFFFFFF;
-    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][32 * D];
-    __shared__ __attribute__((aligned(16))) int32_t s_key[2][32];
+    constexpr int PR = 32 * SUB;                                           // rows per phase
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][PR * D];
+    __shared__ __attribute__((aligned(16))) int32_t s_key[2][PR];      // PRUNE: key_t & 511
+    __shared__ __attribute__((aligned(16))) int32_t s_half[2][PR];     // PRUNE: key_t >> 9 = norm_t >> 1
     const int total = A.task_total[1];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, g = lane >> 5;
@@ -1230,7 +1252,7 @@ __global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
         const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
         const int k_wave = tblk * 256 + wave * 64;                     // first candidate of this wave
         const int n_sets = cnt - k_wave > 32 ? 2 : (cnt - k_wave > 0 ? 1 : 0);
-        int kq[2], q[2];
+        int kq[2], q[2], hmax[2];
         v4i bq[2][4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1239,7 +1261,11 @@ __global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
             const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q[h]) * D);
 #pragma unroll
             for (int s = 0; s < 4; ++s) bq[h][s] = ~src[2 * s + g];
+            // (read before this task's exact_finish replaces it; a padding lane repeats the
+            //  pair's last candidate, which is this task's)
+            hmax[h] = PRUNE ? (A.d2[2 * (cb + q[h]) + 1] - A.norm_q[qoff + q[h]]) >> 1 : 0;
         }
+        bool dirty = false;                            // (wave-uniform: keys since the last fold)
         const int8_t *tbase = A.desc + (int64_t)toff * D;
         const int32_t *tkey = A.key_t + toff;
         const int ntiles = (nt + 31) / 32;
@@ -1247,39 +1273,71 @@ __global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
         int bd1[2] = {KEY_INVALID, KEY_INVALID}, bi1[2] = {0, 0};
         int bd2[2] = {KEY_INVALID, KEY_INVALID}, bi2[2] = {0, 0};
         // (rows past the end stay inside the image's 128-row padding; their keys are masked)
-        auto fetch = [&](int tile, v4i &row16, int &key) {
-            row16 = *reinterpret_cast<const v4i *>(tbase + (int64_t)(tile * 32 + lrow) * D + 16 * lchunk);
-            key = threadIdx.x < 32 ? tkey[tile * 32 + threadIdx.x] : 0;
+        // (a phase may reach past the last tile: still inside the padding, never scanned)
+        auto fetch = [&](int ph, v4i (&row16)[SUB], int &key) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j)
+                row16[j] = *reinterpret_cast<const v4i *>(tbase + (int64_t)(ph * PR + j * 32 + lrow) * D + 16 * lchunk);
+            key = threadIdx.x < PR ? tkey[ph * PR + threadIdx.x] : 0;
         };
-        auto stage = [&](int buf, const v4i row16, int key) {
-            *reinterpret_cast<v4i *>(&s_tile[buf][lrow * D + 16 * (lchunk ^ (lrow & 7))]) = row16;
-            if (threadIdx.x < 32) s_key[buf][threadIdx.x] = key;
+        auto stage = [&](int buf, const v4i (&row16)[SUB], int key) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j)
+                *reinterpret_cast<v4i *>(&s_tile[buf][(j * 32 + lrow) * D + 16 * (lchunk ^ ((lrow >> 1) & 7))]) = row16[j];
+            if (threadIdx.x < PR) {
+                s_key[buf][threadIdx.x] = PRUNE ? key & 511 : key;
+                if (PRUNE) s_half[buf][threadIdx.x] = key >> 9;
+            }
         };
-        v4i pre;
+        v4i pre[SUB];
         int pre_key;
+        const int nph = (ntiles + SUB - 1) / SUB;
         __syncthreads();                               // (the previous task's last tile is consumed)
         fetch(0, pre, pre_key);
         stage(0, pre, pre_key);
         __syncthreads();
-        for (int tile = 0; tile < ntiles; ++tile) {
-            const int buf = tile & 1;
-            if (tile + 1 < ntiles) fetch(tile + 1, pre, pre_key);
-            if (n_sets > 0) {
+        for (int ph = 0; ph < nph; ++ph) {
+            const int buf = ph & 1;
+            if (ph + 1 < nph) fetch(ph + 1, pre, pre_key);
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+            const int tile = ph * SUB + j;
+            if (n_sets > 0 && tile < ntiles) {
                 v4i a[4], tk[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    a[s] = *reinterpret_cast<const v4i *>(&s_tile[buf][c * D + 16 * ((2 * s + g) ^ (c & 7))]);
+                    a[s] = *reinterpret_cast<const v4i *>(&s_tile[buf][(j * 32 + c) * D + 16 * ((2 * s + g) ^ ((c >> 1) & 7))]);
+                v16i cin = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (PRUNE) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    tk[kk] = *reinterpret_cast<const v4i *>(&s_key[buf][8 * kk + 4 * g]);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const v4i t = *reinterpret_cast<const v4i *>(&s_half[buf][j * 32 + 8 * kk + 4 * g]);
+                        cin[4 * kk] = t.x; cin[4 * kk + 1] = t.y; cin[4 * kk + 2] = t.z; cin[4 * kk + 3] = t.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        tk[kk] = *reinterpret_cast<const v4i *>(&s_key[buf][j * 32 + 8 * kk + 4 * g]);
+                }
                 const bool ragged = tile * 32 + 32 > nt;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (h == 1 && n_sets < 2) break;
-                    v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[h][0], cin, 0, 0, 0);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
+                    for (int s = 1; s < 4; ++s)
                         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                    if (PRUNE) {
+                        const int t0 = min(min(acc[0], acc[1]), acc[2]), t1 = min(min(acc[3], acc[4]), acc[5]);
+                        const int t2 = min(min(acc[6], acc[7]), acc[8]), t3 = min(min(acc[9], acc[10]), acc[11]);
+                        const int t4 = min(min(acc[12], acc[13]), acc[14]);
+                        const int lo = min(min(min(t0, t1), t2), min(min(t3, t4), acc[15]));
+                        if (__ballot(lo <= hmax[h]) == 0ull) continue;
+                        dirty = true;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            tk[kk] = *reinterpret_cast<const v4i *>(&s_key[buf][j * 32 + 8 * kk + 4 * g]);
+                    }
                     if (!ragged) {
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
@@ -1299,7 +1357,8 @@ __global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
                     }
                 }
                 const int grow = toff + tile * 32;
-                if (((grow + 32) & 255) == 0 || tile == ntiles - 1) {
+                if ((!PRUNE || dirty) && (((grow + 32) & 255) == 0 || tile == ntiles - 1)) {
+                    dirty = false;
                     const int sbase = (grow & ~255) - toff;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1316,7 +1375,8 @@ __global__ __launch_bounds__(256) void symexact_wg_kernel(ExactArgs A)
                     }
                 }
             }
-            if (tile + 1 < ntiles) stage(buf ^ 1, pre, pre_key);
+            }
+            if (ph + 1 < nph) stage(buf ^ 1, pre, pre_key);
             __syncthreads();
         }
 #pragma unroll
@@ -1498,14 +1558,14 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int32_t *col, const int32_t *rowp, int n_pairs,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
                                        int32_t *cand_q, int32_t *task_total, int32_t *tasks,
-                                       void *stream)
+                                       int32_t *d2, void *stream)
 {
     IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
-                     out_off && col && rowp && keep && cand_cnt && cand_q && task_total && tasks,
+                     out_off && col && rowp && keep && cand_cnt && cand_q && task_total && tasks && d2,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
-               thresh, keep, cand_cnt, cand_q, task_total, tasks};
+               thresh, keep, cand_cnt, cand_q, task_total, tasks, d2};
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
@@ -1536,7 +1596,17 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
     ExactArgs a{desc, norm_q, norm_t, key_t, n_pairs, img_off, img_n, pairs, out_off, cand_cnt, cand_q,
                 task_total, tasks, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
     hipLaunchKernelGGL(symexact_kernel, dim3(1024), dim3(256), 0, st, a);       // pairs with <= 64 candidates
-    hipLaunchKernelGGL(symexact_wg_kernel, dim3(2048), dim3(256), 0, st, a);    // the others, 256 per workgroup
+    // the others, 256 per workgroup (IAMX_EXACT_PRUNE=0: the unpruned scan, for A/B and tests)
+    const char *prune = getenv("IAMX_EXACT_PRUNE"), *sub = getenv("IAMX_EXACT_SUB");
+    const int nsub = sub ? atoi(sub) : 2;
+    if (prune && prune[0] == '0')
+        hipLaunchKernelGGL((symexact_wg_kernel<false, 1>), dim3(2048), dim3(256), 0, st, a);
+    else if (nsub == 1)
+        hipLaunchKernelGGL((symexact_wg_kernel<true, 1>), dim3(2048), dim3(256), 0, st, a);
+    else if (nsub == 4)
+        hipLaunchKernelGGL((symexact_wg_kernel<true, 4>), dim3(2048), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((symexact_wg_kernel<true, 2>), dim3(2048), dim3(256), 0, st, a);
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,
                        cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total);
     return iamx::check_launch("iamx_knn2sym_exact");

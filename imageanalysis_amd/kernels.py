@@ -604,7 +604,7 @@ class PairBatch(object):
                                         _ptr(self.d_col_off), _ptr(self.d_rowp_off), _ptr(self.d_out),
                                         _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),
                                         _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_q),
-                                        _ptr(ws.task_total), _ptr(ws.tasks), s),
+                                        _ptr(ws.task_total), _ptr(ws.tasks), _ptr(ws.d2), s),
               'iamx_knn2sym_candidates')
         check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.key_t),
                                    st.norm_t.numel(), _ptr(st.img_off),

@@ -213,6 +213,9 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  *   cand_cnt DEV [n_pairs] (written); cand_q DEV [rows]: the candidate query rows (original
  *   numbering, ascending) of pair p at out_off[p] .. + cand_cnt[p] -- a pair's list lives in
  *   its own slice of the row range, no scan over the pairs;
+ *   d2 DEV [rows][2] int32 (the array iamx_knn2sym_exact fills): entry [r][1] of a candidate row
+ *   receives an upper bound of its exact second squared distance, which the exact stage prunes its
+ *   scan with before it replaces the pair of values.
  *   task_total DEV [2] (must be 0 on entry; iamx_knn2sym_exact leaves it 0), tasks DEV
  *   [2 n_pairs + rows/32 + 2][2]: the tasks (ordered pair, block) of the exact stage -- wave
  *   tasks (pairs with <= 64 candidates) from entry 0, workgroup tasks (256 candidates) from
@@ -250,7 +253,8 @@ int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int3
                             const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
                             const int64_t *out_off, const int32_t *col, const int32_t *rowp,
                             int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
-                            int32_t *cand_q, int32_t *task_total, int32_t *tasks, void *stream);
+                            int32_t *cand_q, int32_t *task_total, int32_t *tasks, int32_t *d2,
+                            void *stream);
 /* key_t DEV [total_rows] int32 scratch beside norm_t (total_rows = rows of the whole original-
  * order store): rewritten by every call with the per-row constant of the packed (distance, row)
  * key.  task_total DEV [2], tasks DEV [2 n_pairs + rows / 32 + 2][2] (iamx_knn2sym_candidates
