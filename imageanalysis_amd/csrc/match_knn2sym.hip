@@ -912,6 +912,7 @@ struct CandArgs {
     int32_t *task_total;         // [2] wave tasks / workgroup tasks appended so far (zeroed by symcompact_kernel)
     int32_t *tasks;              // [..][2] (ordered pair, block): wave tasks from entry 0, workgroup tasks from entry n_pairs
     int32_t *d2;                 // [rows][2]: [.][1] of a candidate row = upper bound of its exact second distance
+    int wg_shift;                // log2 of the candidates of a workgroup task (8, or 9 for the four-set form)
 };
 
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
@@ -979,10 +980,10 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         __syncthreads();
     }
     // two task lists in one buffer: a pair with <= 64 candidates is ONE wave's task (entries
-    // [0, n_pairs): at most one per pair), a pair with more gets workgroup tasks of 256 candidates
+    // [0, n_pairs): at most one per pair), a pair with more gets workgroup tasks of 256 or 512 candidates
     // whose four waves share every train tile through LDS (entries from n_pairs on)
     const bool small = out <= 64;
-    const int ntask = small ? (out > 0 ? 1 : 0) : (out + 255) >> 8;
+    const int ntask = small ? (out > 0 ? 1 : 0) : (out + (1 << A.wg_shift) - 1) >> A.wg_shift;
     if (threadIdx.x == 0) {
         A.cand_cnt[p] = out;
         s_base = ntask ? atomicAdd(A.task_total + (small ? 0 : 1), ntask) + (small ? 0 : (int)gridDim.x) : 0;
@@ -1385,6 +1386,166 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// The same scan with FOUR candidate sets per wave (a task = 512 candidates) at two waves per SIMD:
+// a train tile read from LDS feeds 16 MFMAs instead of 8, and the four accumulator chains are
+// independent, so the matrix pipe is kept busy by one wave where the two-set form needs its
+// neighbours (47 % MFMA busy there: waves parked on the tile barrier and LDS reads).
+template <int SUB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void symexact_wg4_kernel(ExactArgs A)
+{
+    constexpr int KEY_INVALID = 0x7FFFFFFF;
+    constexpr int NSET = 4;
+    constexpr int PR = 32 * SUB;
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][PR * D];
+    __shared__ __attribute__((aligned(16))) int32_t s_key[2][PR];      // key_t & 511
+    __shared__ __attribute__((aligned(16))) int32_t s_half[2][PR];     // key_t >> 9 = norm_t >> 1
+    const int total = A.task_total[1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * ((int64_t)A.n_pairs + t));
+        const int p = __builtin_amdgcn_readfirstlane(task.x);
+        const int tblk = __builtin_amdgcn_readfirstlane(task.y);
+        const int64_t cb = A.out_off[p];
+        const int cnt = __builtin_amdgcn_readfirstlane(A.cand_cnt[p]);
+        const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
+        const int qoff = __builtin_amdgcn_readfirstlane(A.img_off[qimg]);
+        const int toff = __builtin_amdgcn_readfirstlane(A.img_off[timg]);
+        const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
+        const int k_wave = tblk * (64 * NSET * 4) + wave * (32 * NSET);
+        const int left = cnt - k_wave;
+        const int n_sets = left <= 0 ? 0 : (left >= 32 * NSET ? NSET : (left + 31) >> 5);
+        int kq[NSET], q[NSET], hmax[NSET];
+        v4i bq[NSET][4];
+#pragma unroll
+        for (int h = 0; h < NSET; ++h) {
+            kq[h] = k_wave + h * 32 + c;
+            q[h] = A.cand_q[cb + (kq[h] < cnt ? kq[h] : cnt - 1)];
+            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q[h]) * D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[h][s] = ~src[2 * s + g];
+            hmax[h] = (A.d2[2 * (cb + q[h]) + 1] - A.norm_q[qoff + q[h]]) >> 1;
+        }
+        bool dirty = false;
+        const int8_t *tbase = A.desc + (int64_t)toff * D;
+        const int32_t *tkey = A.key_t + toff;
+        const int ntiles = (nt + 31) / 32;
+        int m1[NSET], m2[NSET], bd1[NSET], bi1[NSET], bd2[NSET], bi2[NSET];
+#pragma unroll
+        for (int h = 0; h < NSET; ++h) {
+            m1[h] = m2[h] = bd1[h] = bd2[h] = KEY_INVALID;
+            bi1[h] = bi2[h] = 0;
+        }
+        auto fetch = [&](int ph, v4i (&row16)[SUB], int &key) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j)
+                row16[j] = *reinterpret_cast<const v4i *>(tbase + (int64_t)(ph * PR + j * 32 + lrow) * D + 16 * lchunk);
+            key = threadIdx.x < PR ? tkey[ph * PR + threadIdx.x] : 0;
+        };
+        auto stage = [&](int buf, const v4i (&row16)[SUB], int key) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j)
+                *reinterpret_cast<v4i *>(&s_tile[buf][(j * 32 + lrow) * D + 16 * (lchunk ^ ((lrow >> 1) & 7))]) = row16[j];
+            if (threadIdx.x < PR) {
+                s_key[buf][threadIdx.x] = key & 511;
+                s_half[buf][threadIdx.x] = key >> 9;
+            }
+        };
+        v4i pre[SUB];
+        int pre_key;
+        const int nph = (ntiles + SUB - 1) / SUB;
+        __syncthreads();
+        fetch(0, pre, pre_key);
+        stage(0, pre, pre_key);
+        __syncthreads();
+        for (int ph = 0; ph < nph; ++ph) {
+            const int buf = ph & 1;
+            if (ph + 1 < nph) fetch(ph + 1, pre, pre_key);
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                const int tile = ph * SUB + j;
+                if (n_sets == 0 || tile >= ntiles) continue;
+                v4i a[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    a[s] = *reinterpret_cast<const v4i *>(&s_tile[buf][(j * 32 + c) * D + 16 * ((2 * s + g) ^ ((c >> 1) & 7))]);
+                v16i cin;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const v4i th = *reinterpret_cast<const v4i *>(&s_half[buf][j * 32 + 8 * kk + 4 * g]);
+                    cin[4 * kk] = th.x; cin[4 * kk + 1] = th.y; cin[4 * kk + 2] = th.z; cin[4 * kk + 3] = th.w;
+                }
+                // (a set past n_sets repeats the pair's last candidate: computed, never used)
+                v16i acc[NSET];
+#pragma unroll
+                for (int h = 0; h < NSET; ++h)
+                    acc[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[h][0], cin, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 4; ++s)
+#pragma unroll
+                    for (int h = 0; h < NSET; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc[h], 0, 0, 0);
+                const bool ragged = tile * 32 + 32 > nt;
+#pragma unroll
+                for (int h = 0; h < NSET; ++h) {
+                    const v16i &x = acc[h];
+                    const int t0 = min(min(x[0], x[1]), x[2]), t1 = min(min(x[3], x[4]), x[5]);
+                    const int t2 = min(min(x[6], x[7]), x[8]), t3 = min(min(x[9], x[10]), x[11]);
+                    const int t4 = min(min(x[12], x[13]), x[14]);
+                    const int lo = min(min(min(t0, t1), t2), min(min(t3, t4), x[15]));
+                    if (h >= n_sets || __ballot(lo <= hmax[h]) == 0ull) continue;
+                    dirty = true;
+                    v4i tk[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        tk[kk] = *reinterpret_cast<const v4i *>(&s_key[buf][j * 32 + 8 * kk + 4 * g]);
+                    if (!ragged) {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int key = lshl9_add(x[reg], tk[reg >> 2][reg & 3]);
+                            m2[h] = med3_key(m1[h], m2[h], key);
+                            m1[h] = min(m1[h], key);
+                        }
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int row = tile * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3);
+                            int key = lshl9_add(x[reg], tk[reg >> 2][reg & 3]);
+                            key = row < nt ? key : KEY_INVALID;
+                            m2[h] = med3_key(m1[h], m2[h], key);
+                            m1[h] = min(m1[h], key);
+                        }
+                    }
+                }
+                const int grow = toff + tile * 32;
+                if (dirty && (((grow + 32) & 255) == 0 || tile == ntiles - 1)) {
+                    dirty = false;
+                    const int sbase = (grow & ~255) - toff;
+#pragma unroll
+                    for (int h = 0; h < NSET; ++h) {
+                        const int d1k = m1[h] >> 8, i1k = sbase + (m1[h] & 255);
+                        const int d2k = m2[h] >> 8, i2k = sbase + (m2[h] & 255);
+                        if (d1k < bd1[h]) {
+                            if (d2k < bd1[h]) { bd2[h] = d2k; bi2[h] = i2k; }
+                            else              { bd2[h] = bd1[h]; bi2[h] = bi1[h]; }
+                            bd1[h] = d1k; bi1[h] = i1k;
+                        } else if (d1k < bd2[h]) {
+                            bd2[h] = d1k; bi2[h] = i1k;
+                        }
+                        m1[h] = m2[h] = KEY_INVALID;
+                    }
+                }
+            }
+            if (ph + 1 < nph) stage(buf ^ 1, pre, pre_key);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < NSET; ++h)
+            exact_finish(A, p, cb, cnt, qoff, q[h], kq[h], g, bd1[h], bi1[h], bd2[h], bi2[h]);
+    }
+}
+
 // in-place, order-preserving compaction of every pair's candidate list to its survivors
 __global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restrict__ cand_off,
                                                          const int32_t *__restrict__ cand_cnt,
@@ -1550,6 +1711,15 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     return iamx::check_launch("iamx_knn2sym_sweep");
 }
 
+// the workgroup form of the exact stage the two entry points below agree on
+// (IAMX_EXACT_SETS=2: two candidate sets per wave, tasks of 256; default four, tasks of 512)
+static bool exact_four_sets()
+{
+    const char *e = getenv("IAMX_EXACT_SETS"), *pr = getenv("IAMX_EXACT_PRUNE");
+    if (pr && pr[0] == '0') return false;
+    return !(e && e[0] == '2');
+}
+
 extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int32_t *img_off, const int32_t *img_n,
                                        const int32_t *pairs, const int32_t *osrc,
@@ -1565,7 +1735,7 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                  "null pointer");
     if (n_pairs <= 0) return IAMX_OK;
     CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
-               thresh, keep, cand_cnt, cand_q, task_total, tasks, d2};
+               thresh, keep, cand_cnt, cand_q, task_total, tasks, d2, exact_four_sets() ? 9 : 8};
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
@@ -1599,7 +1769,12 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
     // the others, 256 per workgroup (IAMX_EXACT_PRUNE=0: the unpruned scan, for A/B and tests)
     const char *prune = getenv("IAMX_EXACT_PRUNE"), *sub = getenv("IAMX_EXACT_SUB");
     const int nsub = sub ? atoi(sub) : 2;
-    if (prune && prune[0] == '0')
+    if (exact_four_sets()) {
+        if (nsub == 1)
+            hipLaunchKernelGGL((symexact_wg4_kernel<1>), dim3(2048), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((symexact_wg4_kernel<2>), dim3(2048), dim3(256), 0, st, a);
+    } else if (prune && prune[0] == '0')
         hipLaunchKernelGGL((symexact_wg_kernel<false, 1>), dim3(2048), dim3(256), 0, st, a);
     else if (nsub == 1)
         hipLaunchKernelGGL((symexact_wg_kernel<true, 1>), dim3(2048), dim3(256), 0, st, a);

@@ -340,19 +340,22 @@ def test_sym_keypoint_counts_of_full_resolution_frames():
         assert np.array_equal(res['d2'][res['off'][p] + keep], rd2)
 
 
-@pytest.mark.parametrize('prune', ['1', '0'], ids=['pruned', 'unpruned'])
+@pytest.mark.parametrize('prune,sets', [('1', '4'), ('1', '2'), ('0', '2')],
+                         ids=['pruned-4-sets', 'pruned-2-sets', 'unpruned'])
 @pytest.mark.parametrize('sizes', [(5000, 4097), (700, 20000), (4096, 4096, 333)])
-def test_exact_stage_with_many_candidates(sizes, prune, monkeypatch):
+def test_exact_stage_with_many_candidates(sizes, prune, sets, monkeypatch):
     """Pairs whose rows mostly MATCH (real frames of one scene: a third to two thirds of a pair's
     rows are candidates) go through the workgroup form of the exact stage -- 256 candidates per
     task, train tiles shared through LDS -- and pairs with <= 64 candidates through the wave form;
     both against oracle/cpu_ref.c: survivor rows, train rows, metrics, squared distances.  Ragged
     sizes (last tile masked, images starting at odd multiples of 128 rows in the store), planted
     exact duplicates (ties -> lowest train row), a candidate count that is not a multiple of 32.
-    Both scans of the workgroup form: the one that skips tiles no lane can have its best or second
-    in (the candidate test's upper bound of the second distance, shipped) and the full one."""
+    All scans of the workgroup form: the one that skips tiles no lane can have its best or second
+    in (the candidate test's upper bound of the second distance) with four candidate sets per wave
+    and tasks of 512 (shipped) or two and 256, and the full scan."""
     from imageanalysis_amd import kernels
     monkeypatch.setenv('IAMX_EXACT_PRUNE', prune)
+    monkeypatch.setenv('IAMX_EXACT_SETS', sets)
     rng = np.random.default_rng(sum(sizes))
     imgs = [_sift_like(rng, sizes[0])]
     for n in sizes[1:]:

@@ -12,6 +12,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
 prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 SIFT = ('gray_up2x_kernel', 'blur_strip_kernel', 'downsample_kernel', 'extrema_kernel',
+        'extrema_multi_kernel',
         'pyramid_tail_kernel', 'refine_kernel', 'orient_kernel', 'descriptor_kernel',
         'sort_count_kernel', 'sort_offsets_kernel', 'sort_scatter_kernel', 'sort_rank_kernel',
         'sort_compact_kernel', 'sort_gather_kernel')
