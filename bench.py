@@ -650,7 +650,7 @@ def dense_overlap_bench(dev, oracle_pairs=4, n_img=12, rows=16384):
             "pairs_per_sec_in_4096_row_units": round(len(und) * (rows / float(KPTS)) ** 2 / (sum(best) * 1e-3), 1),
             "sweep_tflops": round(flop_sweep / (best[0] * 1e-3) / 1e12, 1),
             "exact_stage_tflops": round(flop_exact / (best[1] * 1e-3) / 1e12, 1),
-            "exact_stage": "symexact_wg4_kernel: 512 candidates per workgroup, train tiles shared through "
+            "exact_stage": "symexact_wg_kernel: 256 candidates per workgroup, train tiles shared through "
                            "LDS, tiles that cannot hold a candidate's best or second skipped on the "
                            "candidate test's bound (+ candidate test, compaction in the same interval)",
             "one_direction_form": one_dir,

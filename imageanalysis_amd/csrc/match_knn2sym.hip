@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int qoff = __builtin_amdgcn_readfirstlane(A.img_off[qimg]);
         const int toff = __builtin_amdgcn_readfirstlane(A.img_off[timg]);
         const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
-        const int k_wave = tblk * (64 * NSET * 4) + wave * (32 * NSET);
+        const int k_wave = (tblk * 4 + wave) * (32 * NSET);      // 4 waves x NSET sets of 32
         const int left = cnt - k_wave;
         const int n_sets = left <= 0 ? 0 : (left >= 32 * NSET ? NSET : (left + 31) >> 5);
         int kq[NSET], q[NSET], hmax[NSET];
@@ -1712,12 +1712,12 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
 }
 
 // the workgroup form of the exact stage the two entry points below agree on
-// (IAMX_EXACT_SETS=2: two candidate sets per wave, tasks of 256; default four, tasks of 512)
+// (default: two candidate sets per wave, tasks of 256; IAMX_EXACT_SETS=4: four, tasks of 512)
 static bool exact_four_sets()
 {
     const char *e = getenv("IAMX_EXACT_SETS"), *pr = getenv("IAMX_EXACT_PRUNE");
     if (pr && pr[0] == '0') return false;
-    return !(e && e[0] == '2');
+    return e && e[0] == '4';
 }
 
 extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,

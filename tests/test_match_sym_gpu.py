@@ -351,8 +351,8 @@ def test_exact_stage_with_many_candidates(sizes, prune, sets, monkeypatch):
     sizes (last tile masked, images starting at odd multiples of 128 rows in the store), planted
     exact duplicates (ties -> lowest train row), a candidate count that is not a multiple of 32.
     All scans of the workgroup form: the one that skips tiles no lane can have its best or second
-    in (the candidate test's upper bound of the second distance) with four candidate sets per wave
-    and tasks of 512 (shipped) or two and 256, and the full scan."""
+    in (the candidate test's upper bound of the second distance) with two candidate sets per wave
+    and tasks of 256 (shipped) or four and 512, and the full scan."""
     from imageanalysis_amd import kernels
     monkeypatch.setenv('IAMX_EXACT_PRUNE', prune)
     monkeypatch.setenv('IAMX_EXACT_SETS', sets)
