@@ -717,6 +717,7 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         camera.set_K(K[0, 0], K[1, 1], K[0, 2], K[1, 2])
         camera.set_dist_coeffs([0.0] * 5)
         camera.set_image_params(W, H)
+        camera.set_mount_params(0.0, -90.0, 0.0)
 
         class Proj(object):
             analysis_dir = an
@@ -734,8 +735,9 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         proj.image_list = []
         for name, (ned, ypr) in zip(names, logged):
             im = iimg.Image(an, name)
-            im.set_camera_pose(ned.tolist(), *ypr.tolist())
-            im.set_aircraft_pose(45.0, -93.0, 300.0, float(ypr[0]), 0.0, 0.0)
+            # (camera pose + the aircraft attitude that leads to it under the nadir mount:
+            #  find_matches re-derives the camera pose whenever it updates an image's yaw error)
+            im.set_pose_from_camera(ned.tolist(), *ypr.tolist())
             getNode('/smart', True).getChild(name, True).setFloat('tri_surface_m', 0.0)
             proj.image_list.append(im)
         quiet = contextlib.redirect_stdout(io.StringIO())

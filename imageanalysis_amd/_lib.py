@@ -78,6 +78,7 @@ SIGNATURES = {
                                 + [c_void_p] * 3),
     'iamx_triangulate_pairs': (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p, c_void_p]),
     'iamx_triangulate_pairs_xyz': (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p, c_void_p]),
+    'iamx_triangulate_packed': (c_int, [c_void_p] * 7 + [c_int, c_int64, c_void_p, c_void_p]),
     'iamx_similarity_pairs': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'iamx_exclusive_scan_i32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     'iamx_ba_residual': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -172,6 +172,49 @@ __global__ __launch_bounds__(256) void triangulate_pairs_kernel(
     }
 }
 
+// The same triangulation over PACKED match lists with one pair of projection matrices PER PAIR:
+// find_matches' surface stage.  The reference rewrites both images' camera poses after every
+// pair (scripts/lib/matcher.py:990-993 -> lib/image.py:434-457), so the matrices a pair
+// triangulates with depend on the pairs before it; the host replays that chain
+// (smart.PoseFeedback) and hands every pair its own [R | t] x 2.
+//   pair_img [n_pairs][2] image slots (keypoint arena), pair_proj [n_pairs][2][12],
+//   m_off [n_pairs + 1] first match of every pair in m_pairs [total][2]; out_z [total].
+__global__ __launch_bounds__(256) void triangulate_packed_kernel(
+    const int32_t *__restrict__ pair_img, const double *__restrict__ pair_proj,
+    const double *__restrict__ IK, const int64_t *__restrict__ kp_off, const float *__restrict__ xy,
+    const int64_t *__restrict__ m_off, const int32_t *__restrict__ m_pairs, int n_pairs,
+    int64_t total, double *__restrict__ out_z)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    // the pair this match belongs to: last p with m_off[p] <= k
+    int lo = 0, hi = n_pairs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (m_off[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    const int p = lo;
+    const int im1 = pair_img[2 * p], im2 = pair_img[2 * p + 1];
+    const int q = m_pairs[2 * k], t = m_pairs[2 * k + 1];
+    const float *p1 = xy + 2 * (kp_off[im1] + q), *p2 = xy + 2 * (kp_off[im2] + t);
+    const double uv[2][2] = {{(double)p1[0], (double)p1[1]}, {(double)p2[0], (double)p2[1]}};
+    const double *P[2] = {pair_proj + (int64_t)p * 24, pair_proj + (int64_t)p * 24 + 12};
+    double A[4][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double x = IK[0] * uv[j][0] + IK[1] * uv[j][1] + IK[2];
+        const double y = IK[3] * uv[j][0] + IK[4] * uv[j][1] + IK[5];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            A[2 * j][c] = x * P[j][8 + c] - P[j][c];
+            A[2 * j + 1][c] = y * P[j][8 + c] - P[j][4 + c];
+        }
+    }
+    double X[4];
+    null_vector_4x4(A, X);
+    out_z[k] = X[2] / X[3];
+}
+
 // ---------------------------------------------------------------------------------
 // 4-DOF similarity (rotation, uniform scale, translation) between the matched keypoints of an
 // image pair -- the matrix the reference asks cv2.estimateAffinePartial2D for
@@ -301,4 +344,18 @@ extern "C" int iamx_triangulate_pairs_xyz(const int32_t *pair_img, const double 
                        dim3(256), 0, iamx::as_stream(stream), pair_img, PROJ, IK, kp_off, xy, m_cnt,
                        m_pairs, clip, out_xyz);
     return iamx::check_launch("iamx_triangulate_pairs_xyz");
+}
+
+extern "C" int iamx_triangulate_packed(const int32_t *pair_img, const double *pair_proj, const double *IK,
+                                       const int64_t *kp_off, const float *xy, const int64_t *m_off,
+                                       const int32_t *m_pairs, int n_pairs, int64_t total,
+                                       double *out_z, void *stream)
+{
+    IAMX_REQUIRE(pair_img && pair_proj && IK && kp_off && xy && m_off && m_pairs && out_z, "null pointer");
+    IAMX_REQUIRE(n_pairs >= 0 && total >= 0, "bad size");
+    if (n_pairs == 0 || total == 0) return IAMX_OK;
+    hipLaunchKernelGGL(triangulate_packed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       iamx::as_stream(stream), pair_img, pair_proj, IK, kp_off, xy, m_off, m_pairs,
+                       n_pairs, total, out_z);
+    return iamx::check_launch("iamx_triangulate_packed");
 }

@@ -7,10 +7,15 @@ xGMI on the node; "gloo" in the CPU tests).  The path shards by *image* (detecti
     (`exchange_features`: keypoint counts as objects, then one broadcast per owner and buffer
     through `gather_store_shards`); bench.py all-gathers the packed stores in place instead
     (`all_gather_into_tensor`, 1.47 GB per layout for the 2812-image survey);
-  * match lists: the variable-length per-pair results of a round go to rank 0 ONLY
-    (`gather_results`), which keeps the survey's bookkeeping and writes the files; a failure on
-    one rank is re-raised on every rank first (`raise_on_any_rank`), and rank 0's list of
-    pending pairs is what every rank shards (`broadcast_object`);
+  * match lists: the pairs of a round are dealt round-robin (`round_slice`: rank r takes pairs
+    r, r + W, ... of the round's stretch of the schedule, so every rank sees the same mix of near
+    and far pairs); the variable-length per-pair results go to rank 0 ONLY as ONE flat byte
+    tensor per rank (`pack_arrays` / `gather_arrays`: a fixed layout of arrays -- counts, packed
+    match rows, similarity fits --, gathered with `torch.distributed.gather`; on RCCL the bytes
+    travel GPU to GPU and rank 0's surface stage reads the match rows where they land), which
+    keeps the survey's bookkeeping and writes the files; a failure on one rank is re-raised on
+    every rank first (`raise_on_any_rank`), and rank 0's list of pending pairs is what every
+    rank shards (`broadcast_object`);
   * BA: observations AND the point part of every n-vector are sharded by point
     (`point_range`, `shard_observations_by_point`); per inner iteration the ranks all-reduce the
     camera-side part only (7 C + 1 doubles), per outer iteration the camera blocks of the
@@ -177,6 +182,97 @@ def gather_results(results, failure=None, dst=0, group=None):
     parts = [None] * ws if rank == dst else None
     dist.gather_object(results, parts, dst=dst, group=group)
     return parts if rank == dst else [results]
+
+
+def round_slice(n_items, rnd, per_rank, rank, world_size):
+    """find_matches' deal: round `rnd` covers items [rnd * W * per_rank, (rnd + 1) * W * per_rank)
+    of the schedule and rank r takes every W-th of them starting at r.  A distance-sorted schedule
+    puts the overlapping pairs (all the exact-stage, filter and match-list work) first: contiguous
+    blocks gave all of them to rank 0.  -> the item indices of `rank` (ascending int64)."""
+    base = rnd * world_size * per_rank
+    end = min(base + world_size * per_rank, n_items)
+    return np.arange(base + rank, end, world_size, dtype=np.int64)
+
+
+_WIRE_DTYPES = [np.dtype(t) for t in ('uint8', 'int32', 'int64', 'float64', 'bool', 'float32')]
+
+
+def pack_arrays(arrays):
+    """list of numpy arrays (<= 2-D, dtypes of _WIRE_DTYPES) -> ONE uint8 array: an int64 header
+    (count, then per array: dtype code, rows, columns or -1, byte offset) and the arrays' bytes,
+    each 16-byte aligned.  unpack_arrays() gives views of the same bytes back."""
+    k = len(arrays)
+    head = np.zeros(1 + 4 * k, np.int64)
+    head[0] = k
+    off = (head.nbytes + 15) & ~15
+    arrs = []
+    for t, a in enumerate(arrays):
+        a = np.ascontiguousarray(a)
+        code = _WIRE_DTYPES.index(a.dtype)
+        if a.ndim == 0 or a.ndim > 2:
+            raise ValueError("pack_arrays: 1-D or 2-D arrays only")
+        head[1 + 4 * t:5 + 4 * t] = (code, a.shape[0], a.shape[1] if a.ndim == 2 else -1, off)
+        arrs.append((off, a))
+        off = (off + a.nbytes + 15) & ~15
+    buf = np.zeros(max(off, 16), np.uint8)
+    buf[:head.nbytes] = head.view(np.uint8)
+    for o, a in arrs:
+        if a.nbytes:
+            buf[o:o + a.nbytes] = a.reshape(-1).view(np.uint8)
+    return buf
+
+
+def unpack_arrays(buf):
+    """-> (list of array views into buf, list of their byte offsets)"""
+    buf = np.asarray(buf, np.uint8)
+    k = int(buf[:8].view(np.int64)[0])
+    head = buf[:8 * (1 + 4 * k)].view(np.int64)
+    out, offs = [], []
+    for t in range(k):
+        code, d0, d1, off = (int(v) for v in head[1 + 4 * t:5 + 4 * t])
+        dt = _WIRE_DTYPES[code]
+        n = d0 * (d1 if d1 >= 0 else 1)
+        a = buf[off:off + n * dt.itemsize].view(dt)
+        out.append(a.reshape(d0, d1) if d1 >= 0 else a)
+        offs.append(off)
+    return out, offs
+
+
+def gather_arrays(buf, failure=None, dst=0, group=None, device=None):
+    """find_matches' per-round exchange: every rank's pack_arrays() buffer -> rank `dst`, as ONE
+    tensor gather (sizes and failure notes travel in the small object all-gather before it; a
+    failure on any rank is re-raised on EVERY rank, like gather_results).  `device`: where the
+    bytes travel (the GPU for RCCL, None = host for gloo).
+    -> on dst: [(host uint8 array, device uint8 tensor or None)] per rank; elsewhere None."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        if failure is not None:
+            raise failure
+        return [(buf, None)]
+    note = None if failure is None else (type(failure).__name__, str(failure))
+    infos = allgather_objects((note, 0 if buf is None else int(len(buf))), group=group)
+    for r, (n, _size) in enumerate(infos):
+        if n is not None:
+            if r == rank and failure is not None:
+                raise failure
+            _raise_note(r, n)
+    sizes = [sz for _n, sz in infos]
+    longest = max(max(sizes), 16)
+    dev = device if device is not None else torch.device('cpu')
+    mine = torch.zeros(longest, dtype=torch.uint8, device=dev)
+    if len(buf):
+        mine[:len(buf)].copy_(torch.from_numpy(buf))
+    parts = [torch.empty(longest, dtype=torch.uint8, device=dev) for _ in range(ws)] \
+        if rank == dst else None
+    dist.gather(mine, parts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = []
+    for r, t in enumerate(parts):
+        host = buf if r == rank else t[:sizes[r]].cpu().numpy()
+        out.append((host, t[:sizes[r]] if device is not None else None))
+    return out
 
 
 def allreduce_sum_(tensor, group=None):

@@ -1,8 +1,10 @@
 """Camera calibration accessors on /config/camera -- same names and meaning as the
-reference's scripts/lib/camera.py:58-121 (get_K, get_dist_coeffs, get_image_params + setters)."""
+reference's scripts/lib/camera.py:58-139 (get_K, get_dist_coeffs, get_image_params, the mount
+angles and get_body2cam + setters)."""
 import numpy as np
 
 from .._deps import getNode
+from . import transforms as tf
 
 camera_node = getNode('/config/camera', True)
 
@@ -42,3 +44,24 @@ def set_image_params(width_px, height_px):
 
 def get_image_params():
     return camera_node.getInt('width_px'), camera_node.getInt('height_px')
+
+
+def set_mount_params(yaw_deg, pitch_deg, roll_deg):
+    """camera.py:123-127"""
+    mount_node = camera_node.getChild('mount', True)
+    mount_node.setFloat('yaw_deg', yaw_deg)
+    mount_node.setFloat('pitch_deg', pitch_deg)
+    mount_node.setFloat('roll_deg', roll_deg)
+
+
+def get_mount_params():
+    mount_node = camera_node.getChild('mount', True)
+    return [mount_node.getFloat('yaw_deg'), mount_node.getFloat('pitch_deg'),
+            mount_node.getFloat('roll_deg')]
+
+
+def get_body2cam():
+    """the mount offset as a (w,x,y,z) quaternion -- camera.py:136-139"""
+    d2r = np.pi / 180.0
+    yaw_deg, pitch_deg, roll_deg = get_mount_params()
+    return tf.quaternion_from_euler(yaw_deg * d2r, pitch_deg * d2r, roll_deg * d2r, 'rzyx')

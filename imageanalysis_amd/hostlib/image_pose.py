@@ -9,6 +9,7 @@ from .._deps import getNode
 from . import transforms as tf
 
 d2r = np.pi / 180.0
+r2d = 180.0 / np.pi
 
 
 class PoseImage(object):
@@ -23,6 +24,8 @@ class PoseImage(object):
         self.num_features = 0
         self.placed = False
         self.desc_timestamp = 0.0
+        self.cam2body = np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], dtype=float)   # image.py:50-54
+        self.body2cam = np.linalg.inv(self.cam2body)
 
     def set_camera_pose(self, ned, yaw_deg, pitch_deg, roll_deg, opt=False):
         quat = tf.quaternion_from_euler(yaw_deg * d2r, pitch_deg * d2r, roll_deg * d2r, 'rzyx')
@@ -71,7 +74,47 @@ class PoseImage(object):
         return lla, ypr, quat
 
     def set_aircraft_yaw_error_estimate(self, yaw_error_deg):
-        self.node.getChild('aircraft_pose', True).setFloat("yaw_error_deg", yaw_error_deg)
+        """scripts/lib/image.py:434-457: the aircraft quaternion with the yaw bias added, and the
+        CAMERA pose that follows from it (mount offset applied) -- what the next pair of
+        find_matches triangulates with"""
+        from . import camera
+        ac = self.node.getChild('aircraft_pose', True)
+        ac.setFloat("yaw_error_deg", yaw_error_deg)
+        yaw_deg, pitch_deg, roll_deg = ac.getFloat('yaw_deg'), ac.getFloat('pitch_deg'), ac.getFloat('roll_deg')
+        ned2body = tf.quaternion_from_euler((yaw_deg + yaw_error_deg) * d2r, pitch_deg * d2r,
+                                            roll_deg * d2r, 'rzyx')
+        ac.setLen('quat', 4)
+        for i in range(4):
+            ac.setFloatEnum('quat', i, ned2body[i])
+        ned2cam = tf.quaternion_multiply(ned2body, camera.get_body2cam())
+        yaw_rad, pitch_rad, roll_rad = tf.euler_from_quaternion(ned2cam, 'rzyx')
+        cp = self.node.getChild('camera_pose', True)
+        cp.setFloat('yaw_deg', yaw_rad * r2d)
+        cp.setFloat('pitch_deg', pitch_rad * r2d)
+        cp.setFloat('roll_deg', roll_rad * r2d)
+        cp.setLen('quat', 4)
+        for i in range(4):
+            cp.setFloatEnum('quat', i, ned2cam[i])
+
+    def set_pose_from_camera(self, ned, yaw_deg, pitch_deg, roll_deg, lla=(45.0, -93.0, 300.0)):
+        """Synthetic projects (tests, bench) log a CAMERA pose; the reference derives the camera
+        pose from the AIRCRAFT pose and the mount offset (lib/pose.py:125-152) and re-derives it
+        whenever find_matches updates an image's yaw-error estimate (lib/image.py:434-457).  This
+        stores the camera pose and the aircraft attitude that leads to it under the configured
+        mount, so that the re-derivation lands on the same pose (plus the estimated yaw error)."""
+        from . import camera
+        self.set_camera_pose(ned, yaw_deg, pitch_deg, roll_deg)
+        ned2cam = tf.quaternion_from_euler(yaw_deg * d2r, pitch_deg * d2r, roll_deg * d2r, 'rzyx')
+        b = camera.get_body2cam()
+        inv = np.array([b[0], -b[1], -b[2], -b[3]]) / float(np.dot(b, b))
+        y, p, r = tf.euler_from_quaternion(tf.quaternion_multiply(ned2cam, inv), 'rzyx')
+        self.set_aircraft_pose(lla[0], lla[1], lla[2], y * r2d, p * r2d, r * r2d)
+
+    def get_cam2body(self):
+        return self.cam2body
+
+    def get_body2cam(self):
+        return self.body2cam
 
     def detect_features(self, scale, use_cache=True):
         raise RuntimeError("PoseImage carries no pixels: attach kp_list/des_list yourself")

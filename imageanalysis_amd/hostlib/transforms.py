@@ -9,7 +9,7 @@ optimizer module does not depend on that package.  Pinned by tests/golden/ba_*_r
 Citations: scripts/lib/archive/transformations.py
   quaternion_matrix :1395-1420, quaternion_from_euler :1276-1330, euler_from_matrix :1115-1170,
   euler_matrix :1051-1112, decompose_matrix :730-815, affine_matrix_from_points :889-995,
-  superimposition_matrix :998-1046.
+  superimposition_matrix :998-1046, quaternion_multiply :1499-1512.
 """
 import math
 
@@ -58,6 +58,16 @@ def quaternion_from_euler(ai, aj, ak, axes='sxyz'):
     if parity:
         q[j] *= -1.0
     return q
+
+
+def quaternion_multiply(quaternion1, quaternion0):
+    """Hamilton product q1 * q0 of (w,x,y,z) quaternions, term order as the reference's."""
+    w0, x0, y0, z0 = quaternion0
+    w1, x1, y1, z1 = quaternion1
+    return np.array([-x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0,
+                     x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
+                     -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                     x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0], dtype=np.float64)
 
 
 def euler_from_matrix(matrix, axes='sxyz'):

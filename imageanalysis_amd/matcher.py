@@ -179,6 +179,16 @@ class DeviceMatcher(object):
         self._kp[slot] = (xy, kp_key2(xy))
         return slot
 
+    def slot_known(self, image):
+        """the image's slot without looking at its features when it is registered already (the
+        host copy of an image's features may have been flushed since): the surface stage of the
+        booking rank asks for images other ranks matched"""
+        ent = self._slots.get(image.name)
+        if ent is not None:
+            return ent[0]
+        _ensure_features(image)
+        return self.slot_of(image)
+
     def adopt(self, name, des, xy):
         """Register an image whose features were detected by ANOTHER rank (dist.exchange_features):
         des uint8 [n,128] (device or host), xy float32 [n,2] host.  The image object itself keeps
@@ -725,18 +735,20 @@ def _workspace(rows, pairs):
 
 
 def _post_set(n, clip, dev, surface):
+    """surface: False, True (triangulated heights + similarity fits) or 'fit' (the fits only)"""
     import torch
-    free = _post_pool.setdefault((n, clip, bool(surface)), [])
+    free = _post_pool.setdefault((n, clip, surface), [])
     if free:
         return free.pop()
-    post = dict(key=(n, clip, bool(surface)),
+    post = dict(key=(n, clip, surface),
                 cnt=torch.empty(n, dtype=torch.int32, device=dev),
                 pairs=torch.empty((n, clip, 2), dtype=torch.int32, device=dev),
                 scratch=torch.empty((n, 2, clip, 2), dtype=torch.int32, device=dev),
                 stat=torch.empty((n, 4), dtype=torch.int32, device=dev),
                 status=torch.empty(n, dtype=torch.int32, device=dev))
-    if surface:
+    if surface is True:
         post['z'] = torch.empty((n, clip), dtype=torch.float64, device=dev)
+    if surface:
         post['aff'] = torch.empty((n, 2, 6), dtype=torch.float64, device=dev)
         post['aff_ok'] = torch.empty((n, 2), dtype=torch.int32, device=dev)
     return post
@@ -898,7 +910,7 @@ def _launch_batch(batch, match_ratio, device_filters=True, surface=False, one_di
     arena = _upload_arena()
     arena.begin()
     d_proj = d_ik = None
-    if surface and device_filters:
+    if surface is True and device_filters:
         # (every small table of the batch goes up with ONE asynchronous copy: a pageable upload
         #  blocks the host until the previous batch's kernels have run)
         from . import smart as _smart
@@ -990,16 +1002,18 @@ def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d
                                       _ptr(post['status']), stream_ptr()), 'iamx_match_postfilter')
         if surface:
             post['tri_cnt'] = post['cnt']           # (0 for the pairs left to the host filters)
+        if surface is True:
             check(L.iamx_triangulate_pairs(_ptr(pb.d_pairs), _ptr(d_proj), _ptr(d_ik), _ptr(kp_off),
                                            _ptr(xy), _ptr(post['tri_cnt']), _ptr(post['pairs']), n,
                                            clip, _ptr(post['z']), stream_ptr()),
                   'iamx_triangulate_pairs')
+        if surface:
             # the similarity between the two images' keypoints, both ways (yaw-error estimate)
             check(L.iamx_similarity_pairs(_ptr(pb.d_pairs), _ptr(kp_off), _ptr(xy),
                                           _ptr(post['tri_cnt']), _ptr(post['pairs']), n, clip,
                                           _ptr(post['aff']), _ptr(post['aff_ok']), stream_ptr()),
                   'iamx_similarity_pairs')
-    hs = _host_set(n, clip, surface and post is not None)
+    hs = _host_set(n, clip, surface if post is not None else False)
     hs['zero_div'].copy_(ws.flags, non_blocking=True)
     hs['count'].copy_(ws.surv_cnt[:2 * n], non_blocking=True)
     if pb.sym and pb.rows and pb.n_pairs:
@@ -1013,7 +1027,7 @@ def _launch_batch_tail(batch, pb, ws, thresh, device_filters, surface, d_proj, d
                                             _ptr(hs['off']), _ptr(hs['pk_pairs']),
                                             _ptr(hs['pk_z']) if has_z else None, stream_ptr()),
               'iamx_match_pack_results')
-        if has_z:
+        if 'aff' in post:
             hs['aff'].copy_(post['aff'], non_blocking=True)
             hs['aff_ok'].copy_(post['aff_ok'], non_blocking=True)
     done_ev = torch.cuda.Event()
@@ -1099,49 +1113,102 @@ class _PairView(object):
 
 
 class _RoundResult(object):
-    """what a round delivers, as arrays over its pairs: n_fwd / n_rev (quality matches per
-    direction), cc (cross checked matches), quiet (nothing left after the filters), and for the
-    other pairs `hits` = [(k, fwd, rev, surf)] with array-backed match lists and surf =
-    (avg, std, dist_m, affine_fwd, affine_rev) or None"""
-    __slots__ = ('n', 'n_fwd', 'n_rev', 'cc', 'quiet', 'hits')
+    """what a round delivers, as arrays over its n pairs: n_fwd / n_rev (quality matches per
+    direction), cc (cross checked matches), quiet (nothing left after the filters); for the h
+    pairs WITH matches hit_rows (ascending) and their match rows fwd_all[lo[t]:hi[t]] (rev_all:
+    the same rows with the columns swapped); with `fit` the pair distances and, per direction,
+    the yaw values of the similarity fit (yaw_error, dist, relative course, weight) / whether a
+    fit exists; mean / std of the triangulated "down" are filled in by the surface stage.
+    `src`: where the surface stage finds the match rows without another copy (the page-locked
+    buffer the device packed them into, or the device buffer a gather landed in), `release`
+    hands the round's landing buffers back to their pool."""
+    __slots__ = ('n', 'n_fwd', 'n_rev', 'cc', 'quiet', 'hit_rows', 'lo', 'hi', 'fwd_all', 'rev_all',
+                 'fit', 'dist', 'same', 'yv_f', 'yv_r', 'aff_ok', 'mean', 'std', 'src', 'release')
+
+    def __init__(self, n=0):
+        self.n = n
+        self.hit_rows = np.zeros(0, np.int64)
+        self.lo = self.hi = np.zeros(0, np.int64)
+        self.fwd_all = self.rev_all = np.zeros((0, 2), np.int32)
+        self.fit = False
+        self.dist = self.same = self.yv_f = self.yv_r = self.aff_ok = self.mean = self.std = None
+        self.src = None
+        self.release = None
+
+    @property
+    def hits(self):
+        return _LazyHits(self)
+
+    def done(self):
+        if self.release is not None:
+            self.release()
+            self.release = None
+        self.src = None
 
 
 class _LazyHits(object):
-    """the pairs WITH matches of a round -- [(k, fwd, rev, surf)] as _finish_batch_arrays()
-    documents them -- made on access from the round's arrays (len(), indexing, slicing,
-    iteration)"""
-    __slots__ = ('rows', 'fwd', 'rev', 'lo', 'hi', 'surf')
+    """the pairs WITH matches of a round as [(k, fwd, rev, surf)] -- k the pair's row, fwd / rev
+    array-backed match lists, surf = (avg, std, dist_m, None, None, yaw values fwd, rev) or None
+    -- made on access from the round's arrays (len(), indexing, slicing, iteration)"""
+    __slots__ = ('R',)
 
-    def __init__(self, rows, fwd, rev, lo, hi, surf):
-        self.rows, self.fwd, self.rev, self.lo, self.hi, self.surf = rows, fwd, rev, lo, hi, surf
+    def __init__(self, R):
+        self.R = R
 
     def __len__(self):
-        return len(self.rows)
+        return len(self.R.hit_rows)
 
     def _one(self, t):
-        a, b = self.lo[t], self.hi[t]
+        R = self.R
+        a, b = int(R.lo[t]), int(R.hi[t])
         surf = None
-        if self.surf is not None:
-            same, mean, std, dist, yv_f, yv_r, aff_ok = self.surf
-            surf = _NO_SURFACE if same[t] else (
-                -float(mean[t]), float(std[t]), float(dist[t]), None, None,
-                tuple(yv_f[t]) if aff_ok[t, 0] else None,
-                tuple(yv_r[t]) if aff_ok[t, 1] else None)
-        return (self.rows[t], MatchPairs.of_array(self.fwd[a:b]), MatchPairs.of_array(self.rev[a:b]), surf)
+        if R.fit:
+            if R.same[t] or R.mean is None:
+                surf = _NO_SURFACE
+            else:
+                surf = (-float(R.mean[t]), float(R.std[t]), float(R.dist[t]), None, None,
+                        tuple(R.yv_f[t].tolist()) if R.aff_ok[t, 0] else None,
+                        tuple(R.yv_r[t].tolist()) if R.aff_ok[t, 1] else None)
+        return (int(R.hit_rows[t]), MatchPairs.of_array(R.fwd_all[a:b]), MatchPairs.of_array(R.rev_all[a:b]), surf)
 
     def __getitem__(self, k):
         if isinstance(k, slice):
-            return [self._one(t) for t in range(*k.indices(len(self.rows)))]
-        return self._one(k if k >= 0 else k + len(self.rows))
+            return [self._one(t) for t in range(*k.indices(len(self)))]
+        return self._one(k if k >= 0 else k + len(self))
 
     def __iter__(self):
-        return (self._one(t) for t in range(len(self.rows)))
+        return (self._one(t) for t in range(len(self)))
+
+
+def _similarity_of_lists(view, rows, lists):
+    """similarity fits of a few pairs whose match lists were made on the host (pairs the device
+    filters handed back): [(aff [2, 6], ok [2])] through iamx_similarity_pairs"""
+    import torch
+    from .kernels import _ptr, check, lib, stream_ptr
+    dm = the_matcher
+    kp_off, xy, _k2 = dm.keypoints()
+    dev = xy.device
+    out = []
+    for k, fwd in zip(rows, lists):
+        i1, i2 = view[k]
+        pairs = np.ascontiguousarray(np.asarray(fwd, np.int32).reshape(-1, 2))
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)
+        aff = torch.empty((1, 2, 6), dtype=torch.float64, device=dev)
+        ok = torch.empty((1, 2), dtype=torch.int32, device=dev)
+        d_img = t(np.array([[dm.slot_of(i1), dm.slot_of(i2)]]), torch.int32)
+        d_cnt, d_pairs = t(np.array([len(pairs)]), torch.int32), t(pairs, torch.int32)
+        check(lib().iamx_similarity_pairs(_ptr(d_img), _ptr(kp_off), _ptr(xy), _ptr(d_cnt), _ptr(d_pairs),
+                                          1, max(len(pairs), 1), _ptr(aff), _ptr(ok), stream_ptr()),
+              'iamx_similarity_pairs')
+        out.append((aff[0].cpu().numpy(), ok[0].cpu().numpy()))
+    return out
 
 
 def _finish_batch_arrays(h):
     """_finish_batch() for find_matches: the same wait and the same results, but only the pairs
-    that HAVE matches become python objects -- on an all-pairs schedule 95-99 % of the pairs end
-    with nothing and are just a mask here.  h: the handle of _launch_batch(view, ...)."""
+    that HAVE matches become python objects (and only when they are booked) -- on an all-pairs
+    schedule 95-99 % of the pairs end with nothing and are just a mask here.  h: the handle of
+    _launch_batch(view, ...).  -> _RoundResult"""
     if isinstance(h, list):
         # (a stand-in of _launch_batch / _finish_batch that already returns per-pair tuples:
         #  the CPU tests of the multi-rank logic)
@@ -1151,8 +1218,8 @@ def _finish_batch_arrays(h):
     h['done'].synchronize()
     _t1 = time.perf_counter()
     hs, n, ws, post = h['host'], h['n'], h['ws'], h['post']
-    R = _RoundResult()
-    R.n = n
+    R = _RoundResult(n)
+    keep_host = False
     try:
         if int(hs['zero_div'][0]):
             raise ZeroDivisionError("float division by zero")       # matcher.py:255
@@ -1168,86 +1235,47 @@ def _finish_batch_arrays(h):
         if post is None:
             raise ValueError("find_matches runs the device filters")
         cnt, status = hs['cnt'].numpy(), hs['status'].numpy()
-        lists, zs = _unpacked(hs, post, n)
         R.cc = np.where(status == 0, cnt, 0).astype(np.int64)
         R.quiet = (status == 0) & (cnt == 0)
-        R.hits = []
         dev_rows = np.nonzero((status == 0) & (cnt > 0))[0]
-        surface = h['surface'] and zs is not None
-        view = h['batch']
-        if len(dev_rows):
-            c = cnt[dev_rows].astype(np.int64)
-            if surface:
-                # -mean / std of the triangulated "down" of every pair in one go
-                # (smart.estimate_surface_elevation, smart.py:117-130)
-                off = hs['off'].numpy()
-                if int(off[n]) <= hs['cap']:
-                    # packed: per-pair sums over contiguous segments
-                    # (iamx_segment_mean_std: np.add.reduceat(z) / c and the same of the squared
-                    #  deviations in numpy's summation order, without the round-sized temporaries)
-                    zcat = hs['pk_z'].numpy()[:int(off[n])]
-                    starts = np.ascontiguousarray(off[dev_rows], np.int64)
-                    mean, std = np.empty(len(c)), np.empty(len(c))
-                    _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
-                    _lib.check(_lib.lib().iamx_segment_mean_std(_hp(zcat), _hp(starts), _hp(c), len(c),
-                                                                len(zcat), _hp(mean), _hp(std),
-                                                                _HOST_THREADS), 'iamx_segment_mean_std')
-                else:
-                    Z = np.zeros((len(dev_rows), int(c.max())))
-                    for t_, k_ in enumerate(dev_rows.tolist()):
-                        Z[t_, :c[t_]] = zs(k_)
-                    m = np.arange(Z.shape[1])[None, :] < c[:, None]
-                    mean = np.where(m, Z, 0.0).sum(1) / c
-                    std = np.sqrt((np.where(m, Z - mean[:, None], 0.0) ** 2).sum(1) / c)
-                aff, aff_ok = hs['aff'].numpy()[dev_rows], hs['aff_ok'].numpy()[dev_rows]
-                ned, air_yaw = _smart.frozen_ned(view.image_list, with_yaw=True)
-                a_idx, b_idx = view.pi[dev_rows], view.pj[dev_rows]
-                dist = np.linalg.norm(ned[b_idx] - ned[a_idx], axis=1)
-                same = a_idx == b_idx
-                # the yaw error of both directions of every pair from the similarity fits
-                # (smart.yaw_error_from_affine, vectorised over the round)
-                yv_f = np.stack(_smart.yaw_errors_from_affines(ned[a_idx], air_yaw[a_idx], ned[b_idx],
-                                                               aff[:, 0]), 1).tolist()
-                yv_r = np.stack(_smart.yaw_errors_from_affines(ned[b_idx], air_yaw[b_idx], ned[a_idx],
-                                                               aff[:, 1]), 1).tolist()
-            # the round's pair rows, forward and reversed, as TWO arrays the match lists are views
-            # of (the download is a pinned buffer the next round reuses: copied once); a batch that
-            # did not fit the packed download copies pair by pair
-            off_h = hs['off'].numpy()
-            packed = int(off_h[n]) <= hs['cap']
-            if packed:
-                # (one threaded pass writes both: the copy and its column-swapped twin)
-                src = hs['pk_pairs'].numpy()[:int(off_h[n])]
-                fwd_all, rev_all = empty_huge(src.shape, np.int32), empty_huge(src.shape, np.int32)
-                _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
-                _lib.check(_lib.lib().iamx_pairs_fwd_rev(_hp(src), len(src), _hp(fwd_all), _hp(rev_all),
-                                                         _HOST_THREADS), 'iamx_pairs_fwd_rev')
-                lo = off_h[dev_rows].tolist()
-                hi = (off_h[dev_rows] + c).tolist()
-            if packed:
-                # (the per-pair objects are made when the pairs are booked, not here: a round of
-                #  4096 pairs with matches is 20-30 ms of object creation, and this function sits
-                #  between the device and its next round)
-                R.hits = _LazyHits(dev_rows.tolist(), fwd_all, rev_all, lo, hi,
-                                   (same, mean, std, dist, yv_f, yv_r, aff_ok) if surface else None)
-            for t, k in enumerate(() if packed else dev_rows.tolist()):
-                ck = int(c[t])
-                both = np.empty((2, ck, 2), np.int32)
-                both[0] = lists(k)
-                both[1] = both[0, :, ::-1]
-                surf = None
-                if surface:
-                    surf = _NO_SURFACE if same[t] else (
-                        -float(mean[t]), float(std[t]), float(dist[t]), None, None,
-                        tuple(yv_f[t]) if aff_ok[t, 0] else None,
-                        tuple(yv_r[t]) if aff_ok[t, 1] else None)
-                R.hits.append((k, MatchPairs.of_array(both[0]), MatchPairs.of_array(both[1]), surf))
         host_rows = np.nonzero(status != 0)[0]
+        R.fit = bool(h['surface']) and 'aff' in hs
+        view = h['batch']
+        off_h = hs['off'].numpy()
+        packed = int(off_h[n]) <= hs['cap']
+        _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+        c = cnt[dev_rows].astype(np.int64)
+        if len(dev_rows) and packed:
+            # the round's pair rows, forward and reversed, as TWO arrays the match lists are views
+            # of (the download is a pinned buffer the next round reuses: copied once, one threaded
+            # pass writes the copy and its column-swapped twin)
+            src = hs['pk_pairs'].numpy()[:int(off_h[n])]
+            R.fwd_all, R.rev_all = empty_huge(src.shape, np.int32), empty_huge(src.shape, np.int32)
+            _lib.check(_lib.lib().iamx_pairs_fwd_rev(_hp(src), len(src), _hp(R.fwd_all), _hp(R.rev_all),
+                                                     _HOST_THREADS), 'iamx_pairs_fwd_rev')
+            lo = off_h[dev_rows].astype(np.int64)
+            if R.fit:
+                # (the surface stage reads the rows where the device packed them and writes the
+                #  triangulated heights beside them: the landing buffers stay out of the pool
+                #  until R.done())
+                R.src = dict(kind='pinned', pairs=hs['pk_pairs'], z=hs['pk_z'], total=int(off_h[n]))
+                keep_host = True
+        elif len(dev_rows):
+            # a batch whose matches did not fit the packed download: the slots, copied plainly
+            full = post['pairs'].cpu().numpy()
+            R.fwd_all = np.concatenate([full[k, :cnt[k]] for k in dev_rows.tolist()])
+            R.rev_all = np.ascontiguousarray(R.fwd_all[:, ::-1])
+            lo = np.concatenate([[0], np.cumsum(c)[:-1]]).astype(np.int64)
+        else:
+            lo = np.zeros(0, np.int64)
+        R.hit_rows, R.lo, R.hi = dev_rows.astype(np.int64), lo, lo + c
+        aff = hs['aff'].numpy()[dev_rows] if R.fit else None
+        aff_ok = hs['aff_ok'].numpy()[dev_rows] if R.fit else None
         if len(host_rows):
             # pairs the device filters handed back (more candidates than their buffers hold):
-            # the host filters, per pair, as before
+            # the host filters, per pair, as before; their rows go behind the packed ones
             first, count_s, sq, st, sm = ws.survivors(h['pb'].n_pairs)
-            R.hits = list(R.hits)
+            extra_rows, extra = [], []
             for k in host_rows.tolist():
                 i1, i2 = view[k]
                 _ensure_features(i1)
@@ -1265,13 +1293,53 @@ def _finish_batch_arrays(h):
                 if len(fwd) == 0 and len(rev) == 0:
                     R.quiet[k] = True
                 else:
-                    R.hits.append((k, fwd, rev, None))
-            R.hits = sorted(R.hits, key=lambda t: t[0])
+                    extra_rows.append(k)
+                    extra.append(np.asarray(fwd, np.int32).reshape(-1, 2))
+            if extra_rows:
+                base = len(R.fwd_all)
+                R.fwd_all = np.concatenate([R.fwd_all] + extra)
+                R.rev_all = np.ascontiguousarray(R.fwd_all[:, ::-1])
+                ec = np.array([len(e) for e in extra], np.int64)
+                elo = base + np.concatenate([[0], np.cumsum(ec)[:-1]]).astype(np.int64)
+                rows_all = np.concatenate([R.hit_rows, np.array(extra_rows, np.int64)])
+                lo_all, hi_all = np.concatenate([R.lo, elo]), np.concatenate([R.hi, elo + ec])
+                if R.fit:
+                    fits = _similarity_of_lists(view, extra_rows, extra)
+                    aff = np.concatenate([aff, np.stack([f[0] for f in fits])])
+                    aff_ok = np.concatenate([aff_ok, np.stack([f[1] for f in fits])])
+                order = np.argsort(rows_all, kind='stable')
+                R.hit_rows, R.lo, R.hi = rows_all[order], lo_all[order], hi_all[order]
+                if R.fit:
+                    aff, aff_ok = aff[order], aff_ok[order]
+                if R.src is not None:
+                    # (the device-packed rows no longer cover every pair with matches: the surface
+                    #  stage uploads the round's rows instead)
+                    R.src = None
+        if R.fit and len(R.hit_rows):
+            ned, air_yaw = _smart.frozen_ned(view.image_list, with_yaw=True)
+            a_idx, b_idx = view.pi[R.hit_rows], view.pj[R.hit_rows]
+            R.dist = np.linalg.norm(ned[b_idx] - ned[a_idx], axis=1)
+            R.same = a_idx == b_idx
+            # the yaw error of both directions of every pair from the similarity fits
+            # (smart.yaw_error_from_affine, vectorised over the round)
+            R.yv_f = np.stack(_smart.yaw_errors_from_affines(ned[a_idx], air_yaw[a_idx], ned[b_idx],
+                                                             aff[:, 0]), 1)
+            R.yv_r = np.stack(_smart.yaw_errors_from_affines(ned[b_idx], air_yaw[b_idx], ned[a_idx],
+                                                             aff[:, 1]), 1)
+            R.aff_ok = aff_ok.astype(bool)
+        elif R.fit:
+            R.dist, R.same = np.zeros(0), np.zeros(0, bool)
+            R.yv_f = R.yv_r = np.zeros((0, 4))
+            R.aff_ok = np.zeros((0, 2), bool)
     finally:
-        _host_sets[hs['key']].append(hs)
+        if keep_host and R.src is not None:
+            R.release = lambda hs_=hs: _host_sets[hs_['key']].append(hs_)
+        else:
+            R.src = None
+            _host_sets[hs['key']].append(hs)
         _recycle(h)
     if _round_trace is not None:        # (tools/find_matches_rate.py --trace)
-        _round_trace.append(('finish', _t1 - _t0, time.perf_counter() - _t1, len(R.hits)))
+        _round_trace.append(('finish', _t1 - _t0, time.perf_counter() - _t1, len(R.hit_rows)))
     return R
 
 
@@ -1279,15 +1347,31 @@ _round_trace = None
 
 
 def _round_from_tuples(results):
-    """per-pair tuples (fwd, rev, n_fwd, n_rev[, surf]) -> _RoundResult"""
-    R = _RoundResult()
-    R.n = n = len(results)
+    """per-pair tuples (fwd, rev, n_fwd, n_rev[, fit]) -> _RoundResult; fit = (dist_m, yaw values
+    fwd or None, yaw values rev or None) where a stand-in of the device step supplies them"""
+    n = len(results)
+    R = _RoundResult(n)
     R.n_fwd = np.array([r[2] for r in results], np.int64).reshape(n)
     R.n_rev = np.array([r[3] for r in results], np.int64).reshape(n)
     R.cc = np.array([len(r[0]) for r in results], np.int64).reshape(n)
     R.quiet = np.array([len(r[0]) == 0 and len(r[1]) == 0 for r in results], bool).reshape(n)
-    R.hits = [(k, r[0], r[1], r[4] if len(r) > 4 else None) for k, r in enumerate(results)
-              if not R.quiet[k]]
+    rows = np.nonzero(~R.quiet)[0]
+    lists = [np.asarray(results[k][0], np.int32).reshape(-1, 2) for k in rows.tolist()]
+    c = np.array([len(a) for a in lists], np.int64)
+    R.hit_rows = rows.astype(np.int64)
+    R.lo = np.concatenate([[0], np.cumsum(c)[:-1]]).astype(np.int64) if len(c) else np.zeros(0, np.int64)
+    R.hi = R.lo + c
+    R.fwd_all = np.concatenate(lists + [np.zeros((0, 2), np.int32)])
+    R.rev_all = np.ascontiguousarray(R.fwd_all[:, ::-1])
+    R.fit = bool(results) and all(len(r) > 4 and r[4] is not None for r in results)
+    if R.fit:
+        fits = [results[k][4] for k in rows.tolist()]
+        zero = (0.0, 0.0, 0.0, 0.0)
+        R.dist = np.array([f[0] for f in fits], np.float64).reshape(len(fits))
+        R.same = np.zeros(len(fits), bool)
+        R.yv_f = np.array([f[1] if f[1] is not None else zero for f in fits], np.float64).reshape(len(fits), 4)
+        R.yv_r = np.array([f[2] if f[2] is not None else zero for f in fits], np.float64).reshape(len(fits), 4)
+        R.aff_ok = np.array([[f[1] is not None, f[2] is not None] for f in fits], bool).reshape(len(fits), 2)
     return R
 
 
@@ -1433,8 +1517,6 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
 
 
 def _find_matches(proj, K, strategy, transform, sort, review):
-    from . import dist as _dist
-    from .matchpairs import MatchDict, QuietLedger
     if strategy != "traditional":
         _log("Match strategy", strategy, "is not on the MI355X path; only 'traditional'",
              "(bidirectional k=2 NN + metric + GMS + cross check) is.")
@@ -1444,194 +1526,402 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     if isinstance(the_matcher, DeviceMatcher):
         the_matcher._pose_epoch = object()
     _route_reset()
-    smart = _deps.smart()
-    if hasattr(smart, 'freeze_poses'):
-        smart.freeze_poses(True)
-    # our own smart mirror: the owning rank triangulates its whole batch in one launch, and the
-    # weighted averages over an image's pairs are formed once at the end instead of after every
-    # pair (begin_batch / flush_aggregates)
-    batched_surface = smart is not None and hasattr(smart, 'record_surface_estimate')
-    rank, ws = _dist.world()
-    t_start = time.time()
-    image_list = proj.image_list
-    names = [im.name for im in image_list]
-    # One rank: the images whose features are in memory go to the device (descriptor arena,
-    # keypoint arena: ~0.3 ms of host time each) on a helper thread WHILE the schedule is built
-    # and sorted below -- both are seconds on a survey of thousands of images, and the first round
-    # of a distance-sorted schedule needs nearly every image.  Joined before the first launch.
-    early = None
-    if ws == 1 and isinstance(the_matcher, DeviceMatcher) and len(image_list) > 64:
+    run = _MatchRun(proj, sort)
+    run.schedule()
+    run.prepare()
+    run.rounds()
+    run.finish()
+    print('Pair-wise matches successfully saved.')
+
+
+# the wire layout of one rank's share of a round (dist.pack_arrays order)
+_PART_FIELDS = ('seq', 'pi', 'pj', 'dist', 'raw1', 'raw2', 'n_fwd', 'n_rev', 'cc', 'quiet',
+                'hit_rows', 'lo', 'hi', 'fwd_all', 'fit', 'hit_dist', 'same', 'yv_f', 'yv_r', 'aff_ok')
+_PART_FWD = _PART_FIELDS.index('fwd_all')
+
+
+class _Part(object):
+    """one rank's share of one round on the booking rank: the pairs (seq = position in the
+    schedule, image indices, log figures) and their _RoundResult"""
+    __slots__ = ('seq', 'pi', 'pj', 'dist', 'raw1', 'raw2', 'R')
+
+    def __init__(self, seq, pi, pj, dist, raw1, raw2, R):
+        self.seq, self.pi, self.pj, self.dist, self.raw1, self.raw2, self.R = seq, pi, pj, dist, raw1, raw2, R
+
+    def to_wire(self):
+        from . import dist as _dist
+        R = self.R
+        h = len(R.hit_rows)
+        z1, z4, z2 = np.zeros(h), np.zeros((h, 4)), np.zeros((h, 2), bool)
+        fit = R.fit and R.dist is not None
+        # (only the rows of pairs with matches, back to back in hit order)
+        if h and not (R.lo[0] == 0 and np.array_equal(R.lo[1:], R.hi[:-1]) and R.hi[-1] == len(R.fwd_all)):
+            fwd = np.concatenate([R.fwd_all[a:b] for a, b in zip(R.lo.tolist(), R.hi.tolist())])
+            c = R.hi - R.lo
+            lo = np.concatenate([[0], np.cumsum(c)[:-1]]).astype(np.int64)
+            hi = lo + c
+        else:
+            fwd, lo, hi = R.fwd_all, R.lo, R.hi
+        return _dist.pack_arrays([
+            np.asarray(self.seq, np.int64), np.asarray(self.pi, np.int32), np.asarray(self.pj, np.int32),
+            np.asarray(self.dist, np.float64), np.asarray(self.raw1, np.int64), np.asarray(self.raw2, np.int64),
+            np.asarray(R.n_fwd, np.int64), np.asarray(R.n_rev, np.int64), np.asarray(R.cc, np.int64),
+            np.asarray(R.quiet, bool), np.asarray(R.hit_rows, np.int64), np.asarray(lo, np.int64),
+            np.asarray(hi, np.int64), np.ascontiguousarray(fwd, np.int32).reshape(-1, 2),
+            np.array([bool(R.fit)]), np.asarray(R.dist if fit else z1, np.float64),
+            np.asarray(R.same if fit else np.zeros(h, bool), bool),
+            np.asarray(R.yv_f if fit else z4, np.float64).reshape(h, 4),
+            np.asarray(R.yv_r if fit else z4, np.float64).reshape(h, 4),
+            np.asarray(R.aff_ok if fit else z2, bool).reshape(h, 2)])
+
+    @classmethod
+    def from_wire(cls, host, dev):
+        """host: the uint8 buffer of to_wire(); dev: the same bytes on the device (RCCL gather)
+        or None"""
+        from . import dist as _dist
+        arrs, offs = _dist.unpack_arrays(host)
+        f = dict(zip(_PART_FIELDS, arrs))
+        R = _RoundResult(len(f['seq']))
+        R.n_fwd, R.n_rev, R.cc, R.quiet = f['n_fwd'], f['n_rev'], f['cc'], f['quiet']
+        R.hit_rows, R.lo, R.hi = f['hit_rows'], f['lo'], f['hi']
+        R.fwd_all = f['fwd_all']
+        R.rev_all = np.ascontiguousarray(R.fwd_all[:, ::-1])
+        R.fit = bool(f['fit'][0])
+        if R.fit:
+            R.dist, R.same, R.yv_f, R.yv_r, R.aff_ok = f['hit_dist'], f['same'], f['yv_f'], f['yv_r'], f['aff_ok']
+            if dev is not None and len(R.fwd_all):
+                import torch
+                o = offs[_PART_FWD]
+                R.src = dict(kind='device', total=len(R.fwd_all),
+                             pairs=dev[o:o + R.fwd_all.nbytes].view(torch.int32).view(-1, 2))
+        return cls(f['seq'], f['pi'], f['pj'], f['dist'], f['raw1'], f['raw2'], R)
+
+
+_surface = {}
+
+
+def _surface_stream():
+    """the stream of the surface stage's triangulation, one per device: beside the next round's
+    sweep (main stream) and its tail (side stream, queued behind that sweep)"""
+    import torch
+    dev = torch.cuda.current_device()
+    st = _surface.get(dev)
+    if st is None:
+        st = _surface[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+_z_pool = []             # page-locked float64 landing buffers of the surface stage
+
+
+def _z_buffer(total):
+    import torch
+    for k, t in enumerate(_z_pool):
+        if t.numel() >= total:
+            return _z_pool.pop(k)
+    return torch.empty(max(int(total * 1.25), 1 << 16), dtype=torch.float64, pin_memory=True)
+
+
+def _surface_device(image_list, jobs, waiter=None):
+    """The device half of the surface stage: jobs = [dict(pi, pj [h] image indices, proj
+    [h, 2, 12], m_off [h + 1], pairs = host int32 [T, 2], src = _RoundResult.src or None)] ->
+    per job the float64 [T] NED "down" of every match (iamx_triangulate_packed: every pair with
+    its own two projection matrices).  Match rows are read where they already are -- the
+    page-locked buffer the device packed them into, the device buffer of the round's gather --
+    and uploaded only when they are in neither; heights land in page-locked memory directly.
+    waiter(event): what the host does until the event has happened (default: wait)."""
+    import torch
+    from . import kernels
+    from .kernels import _ptr, check, lib
+    dm = the_matcher
+    dev = kernels.require_gpu()
+    slots = []
+    for job in jobs:
+        sl = np.empty((len(job['pi']), 2), np.int32)
+        for c, col in enumerate((job['pi'], job['pj'])):
+            for t, x in enumerate(col.tolist()):
+                sl[t, c] = dm.slot_known(image_list[x])
+        slots.append(sl)
+    kp_off, xy, _k2 = dm.keypoints()
+    IK = np.ascontiguousarray(np.linalg.inv(np.asarray(_deps.camera().get_K(), float)).ravel())
+    st = _surface_stream()
+    outs, keep = [], []
+    with torch.cuda.stream(st):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
+        d_ik = up(IK)
+        for job, sl in zip(jobs, slots):
+            total = int(job['m_off'][-1])
+            src = job.get('src')
+            if src is not None and src['kind'] == 'pinned':
+                d_pairs, z = src['pairs'], src['z']
+                own_z = False
+            else:
+                d_pairs = src['pairs'] if src is not None else up(job['pairs'])
+                z, own_z = _z_buffer(total), True
+            tabs = (up(sl), up(job['proj']), up(job['m_off']))
+            keep.append((tabs, d_pairs))
+            check(lib().iamx_triangulate_packed(_ptr(tabs[0]), _ptr(tabs[1]), _ptr(d_ik), _ptr(kp_off),
+                                                _ptr(xy), _ptr(tabs[2]), _ptr(d_pairs), len(sl), total,
+                                                _ptr(z), ctypes.c_void_p(st.cuda_stream)),
+                  'iamx_triangulate_packed')
+            outs.append((z, total, own_z))
+        ev = torch.cuda.Event()
+        ev.record(st)
+    if waiter is not None:
+        waiter(ev)
+    ev.synchronize()
+    res = []
+    for z, total, own_z in outs:
+        zz = z.numpy()[:total]
+        if own_z:
+            zz = zz.copy()
+            _z_pool.append(z)
+        res.append(zz)
+    del keep
+    return res
+
+
+def _segment_mean_std(z, starts, counts):
+    """per segment np.mean / np.std of z[start : start + count] (smart.py:117-130), summed in
+    numpy's order (iamx_segment_mean_std)"""
+    mean, std = np.empty(len(counts)), np.empty(len(counts))
+    if len(counts):
+        _hp = lambda a_: a_.ctypes.data_as(ctypes.c_void_p)
+        z = np.ascontiguousarray(z, np.float64)
+        starts, counts = np.ascontiguousarray(starts, np.int64), np.ascontiguousarray(counts, np.int64)
+        _lib.check(_lib.lib().iamx_segment_mean_std(_hp(z), _hp(starts), _hp(counts), len(counts), len(z),
+                                                    _hp(mean), _hp(std), _HOST_THREADS),
+                   'iamx_segment_mean_std')
+    return mean, std
+
+
+class _MatchRun(object):
+    """One find_matches() call -- scripts/lib/matcher.py:852-1031 -- as its stages:
+        schedule()   the work list (:856-916), the skip rule (:946-951), rank 0's list on every rank
+        prepare()    sharded detection, pairs per round, pools, prefetch, the images already in memory
+        rounds()     per round: launch (this rank's pairs of the round, dist.round_slice) ->
+                     finish (arrays) -> exchange (one byte tensor per rank to rank 0) ->
+                     surface stage (rank 0: pose feedback in schedule order + triangulation) ->
+                     bookkeeping (queued, worked off while the host would wait for the device)
+        finish()     the images' final poses, .match files, smart.json
+    """
+    BOOK_CHUNK = 64     # pairs with matches booked per step (~2 ms): see drain()
+
+    def __init__(self, proj, sort):
+        from . import dist as _dist
+        self.proj, self.sort = proj, sort
+        self.image_list = proj.image_list
+        self.names = [im.name for im in self.image_list]
+        self.rank, self.ws = _dist.world()
+        self.smart = _deps.smart()
+        self.surface = self.smart is not None
+        self.t_start = time.time()
+        self.device = isinstance(the_matcher, DeviceMatcher)
+        self.failure = None
+        self.prefetcher = None
+        self.feedback = None
+        self.seen = np.zeros(len(self.image_list), bool)      # images with a pair processed in this call
+        self.n_done = 0
+        self._stored_proj = {}
+
+    # ---- the schedule ------------------------------------------------------------------------
+    def _register_early(self):
+        """One rank: the images whose features are in memory go to the device (descriptor arena,
+        keypoint arena: ~0.3 ms of host time each) on a helper thread WHILE the schedule is built
+        and sorted -- both are seconds on a survey of thousands of images, and the first round of
+        a distance-sorted schedule needs nearly every image.  -> (thread, failures) or None"""
+        image_list = self.image_list
+        if not (self.ws == 1 and self.device and len(image_list) > 64):
+            return None
         import threading
         import torch as _torch
         _dev = _torch.cuda.current_device()
         _stream = _torch.cuda.current_stream()
-        _ready = [im for im in image_list
-                  if im.des_list is not None and im.kp_list is not None
-                  and len(getattr(im.des_list, 'shape', ())) == 2 and len(im.des_list) > 1]
-
-        _failed = []
+        ready = [im for im in image_list
+                 if im.des_list is not None and im.kp_list is not None
+                 and len(getattr(im.des_list, 'shape', ())) == 2 and len(im.des_list) > 1]
+        failed = []
 
         def _register():
             try:
                 with _torch.cuda.device(_dev), _torch.cuda.stream(_stream):
-                    for im in _ready:
+                    for im in ready:
                         the_matcher.slot_of(im)
                     the_matcher.store()
                     the_matcher.keypoints()
             except BaseException as exc:          # noqa: BLE001  (re-raised on the calling thread)
-                _failed.append(exc)
-        if len(_ready) > 1:
-            early = threading.Thread(target=_register, name='iamx-register')
-            early.start()
-    if _round_trace is not None:
-        _round_trace.append(('pre', 'helper started', time.perf_counter()))
-    try:
-        wd, wi, wj = _work_arrays(proj, sort)
-        if _round_trace is not None:
-            _round_trace.append(('pre', 'schedule built', time.perf_counter()))
-    finally:
-        if early is not None:
-            early.join()
-    if _round_trace is not None:
-        _round_trace.append(('pre', 'registration joined', time.perf_counter()))
-    if early is not None and _failed:
-        raise _failed[0]
-    match_ratio = matcher_node.getFloat('match_ratio')
-
-    # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
-    if any(im.match_list for im in image_list):
-        index_of = {n_: k for k, n_ in enumerate(names)}
-        n_img = len(names)
-        tried = np.zeros((n_img, n_img), bool)
-        found = np.zeros((n_img, n_img), bool)
-        for k, im in enumerate(image_list):
-            for other, lst in im.match_list.items():
-                o = index_of.get(other)
-                if o is not None:
-                    tried[k, o] = True
-                    found[k, o] = len(lst) > 0
-        both = tried[wi, wj] & tried[wj, wi]
-        retry = both & ~found[wi, wj]
-        skip = both & found[wi, wj]
-        for k in np.nonzero(retry)[0][:50].tolist():
-            _log("Retrying: ", names[wi[k]], "vs", names[wj[k]], "(no matches found previously)")
-        for k in np.nonzero(skip)[0][:50].tolist():
-            _log("Skipping: ", names[wi[k]], "vs", names[wj[k]], "already done.")
-        if retry.sum() > 50 or skip.sum() > 50:
-            _log("... %d pairs retried (no matches found previously), %d skipped (already done)"
-                 % (int(retry.sum()), int(skip.sum())))
-        keep = ~skip
-        wd, wi, wj = wd[keep], wi[keep], wj[keep]
-    if ws > 1:
-        # Results are gathered on rank 0 only, so after an earlier find_matches call in this
-        # process the other ranks' match lists are incomplete and their skip rule would keep a
-        # different list: rank 0's list is THE list (every collective below assumes the ranks
-        # agree on it -- sharded detection, the batch size, the rounds, the shard bounds)
-        wd, wi, wj = _dist.broadcast_object((wd, wi, wj) if rank == 0 else None, src=0)
-    n_pending = len(wi)
-
-    # every image's match_list becomes a MatchDict tied to this call's ledger of quiet pairs
-    ledger = QuietLedger(names, capacity=n_pending)
-    for k, im in enumerate(image_list):
-        if not isinstance(im.match_list, MatchDict):
-            im.match_list = MatchDict(im.match_list)
-        im.match_list.attach(ledger, k)
-
-    if _round_trace is not None:
-        _round_trace.append(('pre', 'ledger attached', time.perf_counter()))
-    save_time = time.time()
-    save_interval = 300     # seconds
-    _log("Processing worklist matches:")
-    if ws > 1 and isinstance(the_matcher, DeviceMatcher) and n_pending:
-        # every image of the work list is detected by ONE rank; descriptors and keypoint
-        # positions are exchanged once (a collective: the work list is the same on every rank)
-        detect_features_sharded(proj, np.unique(np.concatenate([wi, wj])).tolist())
-    lo_mine, hi_mine = _dist.shard_bounds(n_pending, rank, ws)
-    shard_sizes = [_dist.shard_bounds(n_pending, r, ws) for r in range(ws)]
-    # pairs per device batch: bounded by the workspace a batch needs at this survey's keypoint
-    # counts (the images of a survey carry similar numbers: the largest count known so far, or
-    # that of the first image of this rank's share, stands for all); the ranks agree on the
-    # smallest value so that they run the same number of rounds (the gather is a collective)
-    ppb = PAIRS_PER_BATCH
-    early_failure = None
-    known = []
-    try:
-        if hi_mine > lo_mine and isinstance(the_matcher, DeviceMatcher):
-            known = [_rows_of(im) for im in image_list if _have_features(im)]
-            if not known:
-                first = image_list[int(wi[lo_mine])]
-                _ensure_features(first)
-                known = [_rows_of(first)]
-            ppb = _pairs_per_batch(1.25 * max(known))
-    except (Exception, SystemExit) as exc:
-        if ws == 1:
-            raise
-        early_failure = exc           # re-raised on every rank by the first gather below
-    if ws > 1:
-        ppb = min(_dist.allgather_objects(ppb))
-    n_rounds = max((hi - lo + ppb - 1) // ppb for lo, hi in shard_sizes) if n_pending else 0
-    n_done = 0
-    # a survey of many full rounds: the pools its rounds rotate through are filled (and the
-    # page-locked buffers touched) on a helper thread while the bookkeeping below runs
-    warm = None
-    if ws == 1 and isinstance(the_matcher, DeviceMatcher) and early_failure is None and known \
-            and n_rounds >= PREWARM_ROUNDS:
-        import threading
-        import torch as _torch
-
-        def _warm(n_=ppb, rows_=max(known), dev_=_torch.cuda.current_device(),
-                  stream_=_torch.cuda.current_stream()):
-            try:
-                _prewarm_pools(n_, rows_, bool(batched_surface), dev_, stream_)
-            except Exception:             # noqa: BLE001  (best effort: a round allocates what it misses)
-                # (out of memory half way: give back what the pools hold so that the first real
-                #  round starts from a clean allocator instead of failing where this did)
-                _ws_pool.clear()
-                _post_pool.clear()
-                _torch.cuda.empty_cache()
-        warm = threading.Thread(target=_warm, name='iamx-prewarm')
-        warm.start()
-
-    # ---- images this rank will have to detect / load, in the order the rounds reach them:
-    # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
-    from . import image as _image
-    mine_imgs = np.stack([wi[lo_mine:hi_mine], wj[lo_mine:hi_mine]], 1).ravel()
-    # (first occurrence of every image without sorting the 2 x pairs entries: assigning positions
-    #  in reverse order leaves the smallest one; np.unique took 0.2 s on the 2812-image survey)
-    first_pos = np.full(len(image_list), -1, np.int64)
-    first_pos[mine_imgs[::-1]] = np.arange(len(mine_imgs) - 1, -1, -1, dtype=np.int64)
-    mine_uniq = np.nonzero(first_pos >= 0)[0]
-    first_at = first_pos[mine_uniq]
-    need = []
-    for k in mine_imgs[np.sort(first_at)].tolist():
-        im = image_list[k]
-        if not _have_features(im) and \
-                getattr(type(im), 'detect_features', None) is _image.detect_features:
-            need.append(im)
-    prefetcher = _image.prefetch(need, scale=detect_scale) if need else None
-    # The images whose features are in memory already go to the device in ONE step (descriptor
-    # arena, keypoint arena): the first rounds of a distance-sorted schedule meet ~35 new images
-    # each, and growing the arenas image by image rebuilt and re-synchronised them every round
-    # (the device idled through the first ~70 rounds of a 2812-image survey: r3_fm_timeline)
-    if isinstance(the_matcher, DeviceMatcher) and early_failure is None:
-        ready = [image_list[k] for k in mine_uniq.tolist()
-                 if image_list[k].des_list is not None and image_list[k].kp_list is not None
-                 and len(getattr(image_list[k].des_list, 'shape', ())) == 2 and len(image_list[k].des_list) > 1]
-        if len(ready) > 1:
-            for im in ready:
-                the_matcher.slot_of(im)
-            the_matcher.store()
-            the_matcher.keypoints()
-
-    rows = np.zeros(len(image_list), np.int64)           # descriptor rows of the images seen so far
-    rows_known = np.zeros(len(image_list), bool)         # (reset by the periodic cache flush)
-
-    def launch_round(rnd):
-        a = lo_mine + rnd * ppb
-        b = min(a + ppb, hi_mine)
-        if b <= a:
+                failed.append(exc)
+        if len(ready) <= 1:
             return None
-        view = _PairView(image_list, wi[a:b], wj[a:b])
+        th = threading.Thread(target=_register, name='iamx-register')
+        th.start()
+        return th, failed
+
+    def schedule(self):
+        from . import dist as _dist
+        from .matchpairs import MatchDict, QuietLedger
+        image_list, names = self.image_list, self.names
+        early = self._register_early()
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'helper started', time.perf_counter()))
+        try:
+            wd, wi, wj = _work_arrays(self.proj, self.sort)
+            if _round_trace is not None:
+                _round_trace.append(('pre', 'schedule built', time.perf_counter()))
+        finally:
+            if early is not None:
+                early[0].join()
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'registration joined', time.perf_counter()))
+        if early is not None and early[1]:
+            raise early[1][0]
+        self.match_ratio = matcher_node.getFloat('match_ratio')
+        # ---- skip rule (:946-951), evaluated up front: a pair's state is only changed by itself
+        if any(im.match_list for im in image_list):
+            index_of = {n_: k for k, n_ in enumerate(names)}
+            n_img = len(names)
+            tried = np.zeros((n_img, n_img), bool)
+            found = np.zeros((n_img, n_img), bool)
+            for k, im in enumerate(image_list):
+                for other, lst in im.match_list.items():
+                    o = index_of.get(other)
+                    if o is not None:
+                        tried[k, o] = True
+                        found[k, o] = len(lst) > 0
+            both = tried[wi, wj] & tried[wj, wi]
+            retry = both & ~found[wi, wj]
+            skip = both & found[wi, wj]
+            for k in np.nonzero(retry)[0][:50].tolist():
+                _log("Retrying: ", names[wi[k]], "vs", names[wj[k]], "(no matches found previously)")
+            for k in np.nonzero(skip)[0][:50].tolist():
+                _log("Skipping: ", names[wi[k]], "vs", names[wj[k]], "already done.")
+            if retry.sum() > 50 or skip.sum() > 50:
+                _log("... %d pairs retried (no matches found previously), %d skipped (already done)"
+                     % (int(retry.sum()), int(skip.sum())))
+            keep = ~skip
+            wd, wi, wj = wd[keep], wi[keep], wj[keep]
+        if self.ws > 1:
+            # Results are gathered on rank 0 only, so after an earlier find_matches call in this
+            # process the other ranks' match lists are incomplete and their skip rule would keep a
+            # different list: rank 0's list is THE list (every collective below assumes the ranks
+            # agree on it -- sharded detection, the batch size, the rounds, the deal)
+            wd, wi, wj = _dist.broadcast_object((wd, wi, wj) if self.rank == 0 else None, src=0)
+        self.wd, self.wi, self.wj = wd, wi, wj
+        self.n_pending = len(wi)
+        # every image's match_list becomes a MatchDict tied to this call's ledger of quiet pairs
+        self.ledger = QuietLedger(names, capacity=self.n_pending)
+        for k, im in enumerate(image_list):
+            if not isinstance(im.match_list, MatchDict):
+                im.match_list = MatchDict(im.match_list)
+            im.match_list.attach(self.ledger, k)
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'ledger attached', time.perf_counter()))
+
+    # ---- before the first launch -------------------------------------------------------------
+    def _mine(self, rnd):
+        from . import dist as _dist
+        return _dist.round_slice(self.n_pending, rnd, self.ppb, self.rank, self.ws)
+
+    def prepare(self):
+        from . import dist as _dist
+        from . import image as _image
+        image_list, wi, wj = self.image_list, self.wi, self.wj
+        rank, ws, n_pending = self.rank, self.ws, self.n_pending
+        self.save_time = time.time()
+        self.save_interval = 300     # seconds
+        _log("Processing worklist matches:")
+        if ws > 1 and self.device and n_pending:
+            # every image of the work list is detected by ONE rank; descriptors and keypoint
+            # positions are exchanged once (a collective: the work list is the same on every rank)
+            detect_features_sharded(self.proj, np.unique(np.concatenate([wi, wj])).tolist())
+        # pairs per device batch: bounded by the workspace a batch needs at this survey's keypoint
+        # counts (the images of a survey carry similar numbers: the largest count known so far, or
+        # that of the first image of this rank's share, stands for all); the ranks agree on the
+        # smallest value so that they run the same number of rounds (the gather is a collective)
+        ppb = PAIRS_PER_BATCH
+        known = []
+        try:
+            if n_pending > rank and self.device:
+                known = [_rows_of(im) for im in image_list if _have_features(im)]
+                if not known:
+                    first = image_list[int(wi[rank])]
+                    _ensure_features(first)
+                    known = [_rows_of(first)]
+                ppb = _pairs_per_batch(1.25 * max(known))
+        except (Exception, SystemExit) as exc:
+            if ws == 1:
+                raise
+            self.failure = exc           # re-raised on every rank by the first exchange
+        if ws > 1:
+            ppb = min(_dist.allgather_objects(ppb))
+        self.ppb = ppb
+        self.n_rounds = (n_pending + ws * ppb - 1) // (ws * ppb) if n_pending else 0
+        # a survey of many full rounds: the pools its rounds rotate through are filled (and the
+        # page-locked buffers touched) on a helper thread while the bookkeeping below runs
+        self.warm = None
+        if ws == 1 and self.device and self.failure is None and known and self.n_rounds >= PREWARM_ROUNDS:
+            import threading
+            import torch as _torch
+
+            def _warm(n_=ppb, rows_=max(known), dev_=_torch.cuda.current_device(),
+                      stream_=_torch.cuda.current_stream(), surface_='fit' if self.surface else False):
+                try:
+                    _prewarm_pools(n_, rows_, surface_, dev_, stream_)
+                except Exception:             # noqa: BLE001  (best effort: a round allocates what it misses)
+                    # (out of memory half way: give back what the pools hold so that the first real
+                    #  round starts from a clean allocator instead of failing where this did)
+                    _ws_pool.clear()
+                    _post_pool.clear()
+                    _torch.cuda.empty_cache()
+            self.warm = threading.Thread(target=_warm, name='iamx-prewarm')
+            self.warm.start()
+        # ---- images this rank will have to detect / load, in the order the rounds reach them:
+        # their JPEG decode or cache load runs ahead on worker threads (image.prefetch)
+        if ws == 1:
+            mine_imgs = np.stack([wi, wj], 1).ravel()
+        else:
+            sel = np.concatenate([self._mine(r) for r in range(self.n_rounds)] + [np.zeros(0, np.int64)])
+            mine_imgs = np.stack([wi[sel], wj[sel]], 1).ravel()
+        # (first occurrence of every image without sorting the 2 x pairs entries: assigning positions
+        #  in reverse order leaves the smallest one; np.unique took 0.2 s on the 2812-image survey)
+        first_pos = np.full(len(image_list), -1, np.int64)
+        first_pos[mine_imgs[::-1]] = np.arange(len(mine_imgs) - 1, -1, -1, dtype=np.int64)
+        mine_uniq = np.nonzero(first_pos >= 0)[0]
+        first_at = first_pos[mine_uniq]
+        need = []
+        for k in mine_imgs[np.sort(first_at)].tolist():
+            im = image_list[k]
+            if not _have_features(im) and \
+                    getattr(type(im), 'detect_features', None) is _image.detect_features:
+                need.append(im)
+        self.prefetcher = _image.prefetch(need, scale=detect_scale) if need else None
+        # The images whose features are in memory already go to the device in ONE step (descriptor
+        # arena, keypoint arena): the first rounds of a distance-sorted schedule meet ~35 new images
+        # each, and growing the arenas image by image rebuilt and re-synchronised them every round
+        # (the device idled through the first ~70 rounds of a 2812-image survey: r3_fm_timeline)
+        if self.device and self.failure is None:
+            ready = [image_list[k] for k in mine_uniq.tolist()
+                     if image_list[k].des_list is not None and image_list[k].kp_list is not None
+                     and len(getattr(image_list[k].des_list, 'shape', ())) == 2 and len(image_list[k].des_list) > 1]
+            if len(ready) > 1:
+                for im in ready:
+                    the_matcher.slot_of(im)
+                the_matcher.store()
+                the_matcher.keypoints()
+        self.rows = np.zeros(len(image_list), np.int64)           # descriptor rows of the images seen so far
+        self.rows_known = np.zeros(len(image_list), bool)         # (reset by the periodic cache flush)
+        if self.surface and self.rank == 0:
+            self.smart.begin_batch()
+            self.feedback = self.smart.PoseFeedback(image_list)
+        self._init_booking()
+
+    # ---- one round on this rank ----------------------------------------------------------------
+    def launch_round(self, rnd):
+        sl = self._mine(rnd)
+        if not len(sl):
+            return None
+        image_list, rows, rows_known = self.image_list, self.rows, self.rows_known
+        view = _PairView(image_list, self.wi[sl], self.wj[sl])
         # per IMAGE of the round, not per pair: time stamp of the descriptor cache, detection
         # if the features are not there, the row count the log quotes
         now = time.time()
@@ -1647,122 +1937,224 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             if rows[k] <= 1:
                 # raw_matches() returns [] and basic_pair_matches divides by len([]) (:232)
                 raise ZeroDivisionError("float division by zero")
-        handle = _launch_batch(view, match_ratio, surface=bool(batched_surface),
+        handle = _launch_batch(view, self.match_ratio, surface='fit' if self.surface else False,
                                one_direction=_route_next())
-        return view, a, rows, handle
+        return view, sl, handle
 
-    def finish_round(launched):
-        """-> the round as picklable pieces: (first seq, pi, pj, dist, raw rows of both images,
-        n_fwd, n_rev, cc, quiet mask, hits)"""
-        view, a, rows, handle = launched
+    def finish_round(self, launched):
+        """-> _Part: the round's pairs of this rank and their results as arrays"""
+        view, sl, handle = launched
         R = _finish_batch_arrays(handle)
-        hits = R.hits
-        if ws > 1:          # arrays on the wire, not lists of lists
-            hits = [(k, f.array() if isinstance(f, MatchPairs) else list(f),
-                     r.array() if isinstance(r, MatchPairs) else list(r), surf)
-                    for k, f, r, surf in hits]
-        return (a, view.pi, view.pj, wd[a:a + len(view)], rows[view.pi], rows[view.pj],
-                R.n_fwd, R.n_rev, R.cc, R.quiet, hits)
+        return _Part(sl, view.pi, view.pj, self.wd[sl], self.rows[view.pi], self.rows[view.pj], R)
 
-    # per image: was its most recent pair a quiet one?  (the reference sets the aircraft yaw error
-    # estimate after EVERY pair -- to 0 when the pair had no matches, smart.py:258-260 --, so what
-    # an image ends with is decided by its last pair)
-    last_quiet = np.zeros(len(image_list), bool)
-    last_seq = np.full(len(image_list), -1, np.int64)
-    yaw_value = {}
-    if batched_surface and hasattr(smart, 'begin_batch'):
-        smart.begin_batch()
+    def exchange(self, part):
+        """every rank's part of the round on rank 0 (one byte tensor per rank, dist.gather_arrays);
+        a failure on one rank is re-raised on every rank.  -> [_Part] on rank 0, [] elsewhere"""
+        from . import dist as _dist
+        if self.ws == 1:
+            if self.failure is not None:
+                raise self.failure
+            return [part] if part is not None else []
+        dev = None
+        if self.device:
+            import torch
+            if torch.distributed.get_backend() == 'nccl':
+                dev = _lib.require_gpu()
+        buf = part.to_wire() if part is not None and self.failure is None else np.zeros(0, np.uint8)
+        got = _dist.gather_arrays(buf, self.failure, device=dev)
+        if part is not None:
+            self.n_done_own = getattr(self, 'n_done_own', 0) + len(part.seq)
+        if got is None:
+            if part is not None:
+                part.R.done()
+            return []
+        parts = []
+        for r, (host, d) in enumerate(got):
+            if r == self.rank:
+                if part is not None:
+                    parts.append(part)
+            elif len(host):
+                parts.append(_Part.from_wire(host, d))
+        return parts
 
-    from collections import deque
-    backlog = []
-    # the .match bytes of the rounds' pair lists (what saveMatches will write) are made on ONE
-    # background thread, in libiamx without the interpreter lock (matchpairs.prepickle)
-    from concurrent.futures import ThreadPoolExecutor
-    from .matchpairs import prepickle
-    pickler = ThreadPoolExecutor(max_workers=1, thread_name_prefix='iamx-pickle')
-    pickling = []
+    # ---- the surface stage (booking rank) ------------------------------------------------------
+    def _projection(self, x):
+        hit = self._stored_proj.get(x)
+        if hit is None:
+            hit = self._stored_proj[x] = self.smart.projection_matrix(self.image_list[x]).ravel()
+        return hit
 
-    # Finished rounds whose pairs with matches are not booked yet (generators of book_steps()).
-    # The schedule is sorted by distance: the pairs WITH matches -- all the per-pair host work,
-    # ~30 us each -- sit in the first rounds, where the device would idle while they are booked,
-    # and hundreds of rounds without a match follow, where the host would idle.  So a finished
-    # round is only queued; its pairs are booked a chunk at a time in the moments the host would
-    # otherwise WAIT for the device (drain(until=...)), or at the latest before a save.
-    to_book = deque()
+    def surface_stage(self, parts):
+        """lib/matcher.py:987-993 for the whole round: the pose feedback replayed in schedule order
+        (smart.PoseFeedback), then every pair with matches triangulated with the two camera poses
+        the reference's loop would hold when it reaches the pair; fills mean / std of the parts"""
+        if self.feedback is None or not parts:
+            for p_ in parts:
+                p_.R.done()
+            return
+        fit_parts = [p_ for p_ in parts if p_.R.fit]
+        if len(fit_parts) != len(parts):
+            raise RuntimeError("find_matches: a rank delivered a round without similarity fits")
+        # the round in schedule order (the ranks' shares interleave: seq = base + r + W t)
+        if len(parts) == 1:
+            p0 = parts[0]
+            seq, pi, pj, quiet = p0.seq, p0.pi, p0.pj, p0.R.quiet
+            hit_pos = p0.R.hit_rows
+            part_of = np.zeros(len(hit_pos), np.int64)
+            hit_t = np.arange(len(hit_pos), dtype=np.int64)
+            yv_f, yv_r, ok = p0.R.yv_f, p0.R.yv_r, p0.R.aff_ok
+        else:
+            seq = np.concatenate([p_.seq for p_ in parts])
+            order = np.argsort(seq, kind='stable')
+            inv = np.empty(len(order), np.int64)
+            inv[order] = np.arange(len(order))
+            seq = seq[order]
+            pi = np.concatenate([p_.pi for p_ in parts])[order]
+            pj = np.concatenate([p_.pj for p_ in parts])[order]
+            quiet = np.concatenate([p_.R.quiet for p_ in parts])[order]
+            starts = np.concatenate([[0], np.cumsum([len(p_.seq) for p_ in parts])])
+            pos = np.concatenate([inv[starts[k] + p_.R.hit_rows] for k, p_ in enumerate(parts)]
+                                 + [np.zeros(0, np.int64)]).astype(np.int64)
+            part_id = np.concatenate([np.full(len(p_.R.hit_rows), k, np.int64) for k, p_ in enumerate(parts)]
+                                     + [np.zeros(0, np.int64)])
+            t_in = np.concatenate([np.arange(len(p_.R.hit_rows), dtype=np.int64) for p_ in parts]
+                                  + [np.zeros(0, np.int64)])
+            o2 = np.argsort(pos, kind='stable')
+            hit_pos, part_of, hit_t = pos[o2], part_id[o2], t_in[o2]
+            cat = lambda name, shape: np.concatenate(
+                [np.asarray(getattr(p_.R, name)).reshape((-1,) + shape) for p_ in parts])[o2]
+            yv_f, yv_r, ok = cat('yv_f', (4,)), cat('yv_r', (4,)), cat('aff_ok', (2,))
+        e1, e2, f1, f2 = self.feedback.feed(seq, pi, pj, quiet, hit_pos, yv_f, yv_r, ok)
+        h = len(hit_pos)
+        if h:
+            hi_, hj_ = pi[hit_pos], pj[hit_pos]
+            proj = np.empty((h, 2, 12))
+            for side, (imgs, est, fresh) in enumerate(((hi_, e1, f1), (hj_, e2, f2))):
+                moved = np.nonzero(~fresh)[0]
+                if len(moved):
+                    proj[moved, side] = self.feedback.projections(imgs[moved].tolist(),
+                                                                  [est[t] for t in moved.tolist()])
+                for t in np.nonzero(fresh)[0].tolist():
+                    proj[t, side] = self._projection(int(imgs[t]))
+            jobs, where = [], []
+            for k, p_ in enumerate(parts):
+                R = p_.R
+                mine = np.nonzero(part_of == k)[0]            # ascending hit_t: the part's hit order
+                if not len(mine):
+                    continue
+                lo, hi2 = R.lo, R.hi
+                contiguous = bool(np.array_equal(lo[1:], hi2[:-1]))
+                src = R.src if contiguous else None
+                if contiguous:
+                    base = int(lo[0]) if src is None else 0
+                    m_off = np.concatenate([lo, hi2[-1:]]).astype(np.int64) - base
+                    if src is not None and src['kind'] == 'pinned':
+                        m_off[-1] = int(hi2[-1])              # (the packed buffer: offsets as they are)
+                    pairs = R.fwd_all[int(lo[0]):int(hi2[-1])] if src is None else None
+                else:
+                    c = hi2 - lo
+                    m_off = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+                    pairs = np.concatenate([R.fwd_all[a:b] for a, b in zip(lo.tolist(), hi2.tolist())])
+                jobs.append(dict(pi=hi_[mine], pj=hj_[mine], proj=proj[mine], m_off=m_off,
+                                 pairs=pairs, src=src))
+                where.append((k, m_off))
+            zs = _surface_device(self.image_list, jobs, waiter=self.drain_until)
+            for (k, m_off), z in zip(where, zs):
+                R = parts[k].R
+                R.mean, R.std = _segment_mean_std(z, m_off[:-1], np.diff(m_off))
+        for p_ in parts:
+            if p_.R.mean is None and p_.R.fit:
+                p_.R.mean = p_.R.std = np.zeros(len(p_.R.hit_rows))
+            p_.R.done()
 
-    # smart.json ahead of time.  Its content only changes when a pair WITH matches is booked; on a
-    # distance-sorted schedule those all sit in the first rounds, and the host then idles through
-    # hundreds of quiet ones.  Once everything seen is booked and several rounds in a row brought
-    # nothing, the file is written on a helper thread beside the waits; the end of the call writes
-    # it again only if a pair with matches was booked after that (booking first waits for a
-    # writer that is still reading the tree).
-    hits_booked = [0]
-    rounds_without_hits = [0]
-    early_smart = {'thread': None, 'hits': -1, 'error': None}
+    # ---- bookkeeping (booking rank) ------------------------------------------------------------
+    def _init_booking(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        self.backlog = []
+        # the .match bytes of the rounds' pair lists (what saveMatches will write) are made on ONE
+        # background thread, in libiamx without the interpreter lock (matchpairs.prepickle)
+        self.pickler = ThreadPoolExecutor(max_workers=1, thread_name_prefix='iamx-pickle')
+        self.pickling = []
+        # Finished rounds whose pairs with matches are not booked yet (generators of book_steps()).
+        # The schedule is sorted by distance: the pairs WITH matches -- all the per-pair host work,
+        # ~30 us each -- sit in the first rounds, where the device would idle while they are booked,
+        # and hundreds of rounds without a match follow, where the host would idle.  So a finished
+        # round is only queued; its pairs are booked a chunk at a time in the moments the host would
+        # otherwise WAIT for the device (drain(until=...)), or at the latest before a save.
+        self.to_book = deque()
+        # smart.json ahead of time.  Its content only changes when a pair WITH matches is booked; on a
+        # distance-sorted schedule those all sit in the first rounds, and the host then idles through
+        # hundreds of quiet ones.  Once everything seen is booked and several rounds in a row brought
+        # nothing, the file is written on a helper thread beside the waits; the end of the call writes
+        # it again only if a pair with matches was booked after that (booking first waits for a
+        # writer that is still reading the tree).
+        self.hits_booked = 0
+        self.rounds_without_hits = 0
+        self.early_smart = {'thread': None, 'hits': -1, 'error': None}
 
-    def _early_smart_join():
-        t = early_smart['thread']
+    def _early_smart_join(self):
+        t = self.early_smart['thread']
         if t is not None and t.is_alive():
             t.join()
 
-    def maybe_save_smart_early():
-        if rank != 0 or smart is None or early_smart['thread'] is not None \
-                or not batched_surface or not hasattr(smart, 'flush_aggregates') \
-                or rounds_without_hits[0] < EARLY_SMART_ROUNDS:
+    def maybe_save_smart_early(self):
+        smart = self.smart
+        if self.rank != 0 or smart is None or self.early_smart['thread'] is not None \
+                or self.rounds_without_hits < EARLY_SMART_ROUNDS:
             return
         # (quiet rounds: the host has time -- a few booking steps if any are left, ~2 ms each)
         for _ in range(4):
-            if backlog or to_book:
-                drain_step()
-        if backlog or to_book or hits_booked[0] == 0:
+            if self.backlog or self.to_book:
+                self.drain_step()
+        if self.backlog or self.to_book or self.hits_booked == 0:
             return
         import threading
         smart.flush_aggregates()
-        early_smart['hits'] = hits_booked[0]
+        self.early_smart['hits'] = self.hits_booked
+        early_smart, proj = self.early_smart, self.proj
 
         def _write():
             try:
-                try:
-                    smart.save(proj.analysis_dir, polite=True)
-                except TypeError:                 # (the reference's lib.smart.save has one argument)
-                    smart.save(proj.analysis_dir)
+                smart.save(proj.analysis_dir, polite=True)
             except BaseException as exc:          # noqa: BLE001  (the end of the call writes it again)
                 early_smart['error'] = exc
         early_smart['thread'] = threading.Thread(target=_write, name='iamx-smart-save-early')
         early_smart['thread'].start()
         early_smart_stats['written'] += 1
 
-    def drain_step():
-        _early_smart_join()
-        if backlog:
-            kind, payload = backlog.pop(0)
-            smart.record_round(payload)
-            smart.materialize_pending()
-        elif to_book:
+    def drain_step(self):
+        self._early_smart_join()
+        if self.backlog:
+            _kind, payload = self.backlog.pop(0)
+            self.smart.record_round(payload)
+            self.smart.materialize_pending()
+        elif self.to_book:
             try:
-                next(to_book[0])
+                next(self.to_book[0])
             except StopIteration:
-                to_book.popleft()
+                self.to_book.popleft()
 
-    def drain(until=None):
+    def drain_until(self, event):
+        self.drain(event)
+
+    def drain(self, until=None):
         """work the queues off -- all of it, or while the event `until` has not happened yet
         (one ~2 ms step at a time); all of it includes the pickles in flight"""
-        while (backlog or to_book) and (until is None or not until.query()):
-            drain_step()
+        while (self.backlog or self.to_book) and (until is None or not until.query()):
+            self.drain_step()
         if until is None:
-            while pickling:
-                pickling.pop(0).result()
+            while self.pickling:
+                self.pickling.pop(0).result()
 
-    BOOK_CHUNK = 64     # pairs with matches booked per step (~2 ms): see drain()
-
-    def book_steps(part):
-        """rank 0's (or this rank's own) bookkeeping of one rank's round, as a generator: the
-        once-per-round part first, then BOOK_CHUNK pairs with matches per step.  Nothing here
-        depends on the order in which rounds or chunks are booked: match_list entries, the ledger
-        and the yaw values carry the pair's seq and the newest seq wins."""
-        a, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, quiet, hits = part
-        n = len(pi)
-        seq = a + np.arange(n, dtype=np.int64)
+    def book_steps(self, part):
+        """the bookkeeping of one rank's round, as a generator: the once-per-round part first, then
+        BOOK_CHUNK pairs with matches per step.  Nothing here depends on the order in which rounds
+        or chunks are booked: match_list entries and the ledger carry the pair's seq and the newest
+        seq wins; what DOES depend on the order -- the poses -- was settled by the surface stage."""
+        names = self.names
+        seq, pi, pj, quiet = part.seq, part.pi, part.pj, part.R.quiet
+        raw1, raw2, n_fwd, n_rev = part.raw1, part.raw2, part.R.n_fwd, part.R.n_rev
         # ---- the log: the reference's seven qlog() lines per pair (matcher.py:311-343) for the
         # pairs with matches, one summary line for the round's pairs without (at millions of
         # pairs the per-pair lines cost more than the GPU work they describe)
@@ -1774,25 +2166,21 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                      int(min(raw1.min(), raw2.min())), int(max(raw1.max(), raw2.max())),
                      int(n_fwd[quiet].sum()), int(n_rev[quiet].sum())))
             # ---- pairs without matches: the ledger (two dictionary entries per pair, later)
-            ledger.add(pi[quiet], pj[quiet], seq[quiet])
-        # what every image's LAST pair so far was, quiet or not (the parts of several ranks do
-        # not arrive in seq order: the newest seq wins)
-        # (seq ascends inside a part: with repeated indices the LAST assignment stays)
-        newest = np.full(len(image_list), -1, np.int64)
-        newest_j = np.full(len(image_list), -1, np.int64)
-        newest[pi] = seq
-        newest_j[pj] = seq
-        np.maximum(newest, newest_j, out=newest)
-        upd = np.nonzero(newest > last_seq)[0]
-        last_seq[upd] = newest[upd]
-        last_quiet[upd] = quiet[newest[upd] - a]
-        for c0 in range(0, len(hits), BOOK_CHUNK):
+            self.ledger.add(pi[quiet], pj[quiet], seq[quiet])
+        self.seen[pi] = True
+        self.seen[pj] = True
+        hits = part.R.hits
+        for c0 in range(0, len(hits), self.BOOK_CHUNK):
             yield
-            _book_hits(hits[c0:c0 + BOOK_CHUNK], pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq)
+            self._book_hits(hits[c0:c0 + self.BOOK_CHUNK], part)
 
-    def _book_hits(hits, pi, pj, dist, raw1, raw2, n_fwd, n_rev, cc, seq):
-        _early_smart_join()
-        hits_booked[0] += len(hits)
+    def _book_hits(self, hits, part):
+        from .matchpairs import prepickle
+        names, image_list = self.names, self.image_list
+        pi, pj, seq, dist = part.pi, part.pj, part.seq, part.dist
+        raw1, raw2, n_fwd, n_rev, cc = part.raw1, part.raw2, part.R.n_fwd, part.R.n_rev, part.R.cc
+        self._early_smart_join()
+        self.hits_booked += len(hits)
         # (python numbers for the chunk's pairs once: numpy scalars cost ~1 us each to format)
         ks = np.fromiter((h[0] for h in hits), np.int64, len(hits))
         pik, pjk, sqk = pi[ks].tolist(), pj[ks].tolist(), seq[ks].tolist()
@@ -1802,7 +2190,7 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                    for a_, b_, d_, r1_, f_, r2_, r_, c_ in zip(
                        pik, pjk, dist[ks].tolist(), raw1[ks].tolist(), n_fwd[ks].tolist(),
                        raw2[ks].tolist(), n_rev[ks].tolist(), cc[ks].tolist())]
-        round_records = [] if (batched_surface and hasattr(smart, 'record_round')) else None
+        round_records = [] if self.surface else None
         for t_, (k, match_fwd, match_rev, surf) in enumerate(hits):
             i, j, sq = pik[t_], pjk[t_], sqk[t_]
             i1, i2 = image_list[i], image_list[j]
@@ -1821,37 +2209,6 @@ def _find_matches(proj, K, strategy, transform, sort, review):
                 if avg and std:
                     # (the pair's line of the log, in the chunk's record: one log call per chunk)
                     records.append("  %s %s surface est: %.1f std: %.1f" % (i1.name, i2.name, avg, std))
-                for x, yv in ((i, surf[5]), (j, surf[6])):
-                    cur = yaw_value.get(x)
-                    if cur is None or cur[0] < sq:
-                        # (no similarity fit for this direction: update_yaw_error_estimate returns 0)
-                        yaw_value[x] = (sq, None if yv is not None else 0)
-            elif smart is not None:
-                if surf is not None:
-                    avg, std = smart.record_surface_estimate(i1, i2, *surf[:3])
-                else:
-                    # the reference's lib.smart reads kp_list / uv_list of both images; the
-                    # flush at the end of an earlier round, or a non-owning rank, may not
-                    # have them
-                    _ensure_features(i1)
-                    _ensure_features(i2)
-                    avg, std = smart.update_surface_estimate(i1, i2)
-                if avg and std:
-                    _qlog(" ", i1.name, i2.name, "surface est: %.1f" % avg, "std: %.1f" % std)
-                if batched_surface and surf is not None and len(surf) > 5:
-                    # the similarity fits of the batch's one launch, already turned into yaw
-                    # errors for the whole round
-                    ya = smart.record_yaw_values(i1, i2, surf[5])
-                    yb = smart.record_yaw_values(i2, i1, surf[6])
-                elif batched_surface and surf is not None:
-                    ya = smart.record_yaw_error_estimate(i1, i2, surf[3])
-                    yb = smart.record_yaw_error_estimate(i2, i1, surf[4])
-                else:
-                    ya = smart.update_yaw_error_estimate(i1, i2)
-                    yb = smart.update_yaw_error_estimate(i2, i1)
-                for x, y in ((i, ya), (j, yb)):
-                    if x not in yaw_value or yaw_value[x][0] < sq:
-                        yaw_value[x] = (sq, y)
             if std and std >= 50 and len(match_fwd) < 100:
                 _log("Std dev of surface triangulation blew up, matches are probably bad so "
                      "discarding them!", i1.name, i2.name, "avg:", avg, "std:", std,
@@ -1862,145 +2219,139 @@ def _find_matches(proj, K, strategy, transform, sort, review):
             _qlog("\n".join(records))
         # the tree entries of these pairs (smart.record_round): a backlog item of their own
         if round_records:
-            backlog.append(('smart', round_records))
+            self.backlog.append(('smart', round_records))
         # ... and the .match bytes of their lists (what saveMatches will write): background thread
         lists = [dict.get(image_list[int(x)].match_list, image_list[int(y)].name)
                  for k_, _f, _r, _s in hits for x, y in ((pi[k_], pj[k_]), (pj[k_], pi[k_]))]
-        pickling.append(pickler.submit(prepickle, lists))
-        while len(pickling) > 256 and pickling[0].done():
-            pickling.pop(0).result()
+        self.pickling.append(self.pickler.submit(prepickle, lists))
+        while len(self.pickling) > 256 and self.pickling[0].done():
+            self.pickling.pop(0).result()
 
-    # software pipeline: the GPU works on round r+1 while python turns round r into lists.
-    # An exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
-    # image-size mismatch) -- in the batch-size estimate above, in the launch of round 0 or
-    # inside a round -- travels with the results and is re-raised on EVERY rank: the others
-    # would otherwise wait in the collective forever
-    in_flight = None
-    failure = early_failure
-    if _round_trace is not None:
-        _round_trace.append(('pre', 'ready to launch', time.perf_counter()))
-    if warm is not None:
-        warm.join()
-    if _round_trace is not None:
-        _round_trace.append(('pre', 'pools warm', time.perf_counter()))
-    if n_rounds and failure is None:
-        try:
-            in_flight = launch_round(0)
-        except (Exception, SystemExit) as exc:
-            if ws == 1:
-                raise
-            failure = exc
-    for rnd in range(n_rounds):
-        results = []
-        try:
-            if failure is None:
-                coming = launch_round(rnd + 1) if rnd + 1 < n_rounds else None
-                if in_flight is not None and isinstance(in_flight[3], dict):
-                    drain(in_flight[3]['done'])     # instead of waiting for the round's results
-                results = [finish_round(in_flight)] if in_flight is not None else []
-                in_flight = coming
-        except (Exception, SystemExit) as exc:
-            if ws == 1:
-                raise
-            failure, results = exc, []
-        gathered = _dist.gather_results(results, failure)
+    # ---- the loop ------------------------------------------------------------------------------
+    def rounds(self):
+        """software pipeline: the GPU works on round r+1 while python turns round r into lists.
+        An exception on one rank (ZeroDivisionError of a <= 1-descriptor image, quit() on an
+        image-size mismatch) -- in the batch-size estimate, in the launch of round 0 or inside a
+        round -- travels with the results and is re-raised on EVERY rank: the others would
+        otherwise wait in the collective forever"""
+        ws = self.ws
+        in_flight = None
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'ready to launch', time.perf_counter()))
+        if self.warm is not None:
+            self.warm.join()
+        if _round_trace is not None:
+            _round_trace.append(('pre', 'pools warm', time.perf_counter()))
+        if self.n_rounds and self.failure is None:
+            try:
+                in_flight = self.launch_round(0)
+            except (Exception, SystemExit) as exc:
+                if ws == 1:
+                    raise
+                self.failure = exc
+        for rnd in range(self.n_rounds):
+            part = None
+            try:
+                if self.failure is None:
+                    coming = self.launch_round(rnd + 1) if rnd + 1 < self.n_rounds else None
+                    if in_flight is not None and isinstance(in_flight[2], dict):
+                        self.drain(in_flight[2]['done'])     # instead of waiting for the round's results
+                    part = self.finish_round(in_flight) if in_flight is not None else None
+                    in_flight = coming
+            except (Exception, SystemExit) as exc:
+                if ws == 1:
+                    raise
+                self.failure, part = exc, None
+            parts = self.exchange(part)
+            if self.rank == 0:
+                self.surface_stage(parts)
+                for p_ in parts:
+                    steps = self.book_steps(p_)
+                    next(steps, None)             # the once-per-round part now, the pairs with matches later
+                    nh = len(p_.R.hit_rows)
+                    if nh:
+                        self.to_book.append(steps)
+                    self.n_done += len(p_.seq)
+                    self.rounds_without_hits = 0 if nh else self.rounds_without_hits + 1
+                self.maybe_save_smart_early()
+            elif part is not None:
+                self.n_done += len(part.seq)
+            t_elapsed = time.time() - self.t_start
+            # (ranks != 0 only see their own pairs: their progress is that of their own share)
+            total = self.n_pending if self.rank == 0 else max(self.n_pending // ws, 1)
+            percent = self.n_done / float(max(total, 1))
+            t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
+            _qlog("%.1f%% done: %.1f (min) remaining" % (percent * 100.0, t_remain / 60.0))
+            # ---- periodic save + host descriptor cache flush (:1008-1026)
+            if time.time() >= self.save_time + self.save_interval:
+                self.periodic_save()
 
-        for parts in gathered:
-            for part in parts:
-                steps = book_steps(part)
-                next(steps, None)             # the once-per-round part now, the pairs with matches later
-                if len(part[10]):
-                    to_book.append(steps)
-                n_done += len(part[1])
-                rounds_without_hits[0] = 0 if len(part[10]) else rounds_without_hits[0] + 1
-        maybe_save_smart_early()
+    def periodic_save(self):
+        proj = self.proj
+        if self.rank == 0:
+            self.drain()
+            self._early_smart_join()
+            if self.smart is not None:
+                self.smart.flush_aggregates()
+            for k in np.nonzero(self.seen)[0].tolist():
+                self.image_list[k].matches_clean = False
+            saveMatches(proj.image_list, check_if_dirty=True)
+            if self.smart is not None:
+                self.smart.save(proj.analysis_dir)
+        self.save_time = time.time()
+        time_list = [[i3.desc_timestamp, i3] for i3 in proj.image_list if i3.des_list is not None]
+        time_list = sorted(time_list, key=lambda fields: fields[0], reverse=True)
+        cache_size = 20 + 5 * (int(sqrt(len(proj.image_list))) + 1)
+        flush_list = time_list[cache_size:]
+        _qlog("flushing keypoint/descriptor cache - size: %d (over by: %d)"
+              % (cache_size, len(flush_list)))
+        for line in flush_list:
+            _qlog('  clearing descriptors for:', line[1].name)
+            line[1].kp_list = None
+            line[1].des_list = None
+            line[1].uv_list = None
+        self.rows_known[:] = False
 
-        t_elapsed = time.time() - t_start
-        # (ranks != 0 only see their own pairs: their progress is that of their own shard)
-        percent = n_done / float(max(n_pending if rank == 0 else hi_mine - lo_mine, 1))
-        t_remain = (t_elapsed / percent - t_elapsed) if percent > 0 else 0.0
-        _qlog("%.1f%% done: %.1f (min) remaining" % (percent * 100.0, t_remain / 60.0))
+    def finish(self):
+        proj, smart = self.proj, self.smart
+        if self.prefetcher is not None:
+            self.prefetcher.close()
+        self.drain()
+        self._early_smart_join()
+        if self.rank == 0:
+            if smart is not None:
+                smart.flush_aggregates()
+            if self.feedback is not None:
+                # every image's pose as its LAST pair of the call left it (lib/matcher.py:990-993)
+                self.feedback.settle()
+            # (quiet pairs dirty both images' match lists, like the reference's assignments)
+            for k in np.nonzero(self.seen)[0].tolist():
+                self.image_list[k].matches_clean = False
+            # smart.json is written beside the .match files (file writes release the interpreter),
+            # unless the copy written ahead of time is still current
+            saver = None
+            es = self.early_smart
+            smart_current = es['thread'] is not None and es['error'] is None and es['hits'] == self.hits_booked
+            early_smart_stats['current_at_end'] += bool(smart_current)
+            if smart is not None and not smart_current:
+                import threading
+                saver_error = []
 
-        # ---- periodic save + host descriptor cache flush (:1008-1026)
-        if time.time() >= save_time + save_interval:
-            if rank == 0:
-                drain()
-                _early_smart_join()
-                _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
-                for k in np.nonzero(last_seq >= 0)[0].tolist():
-                    image_list[k].matches_clean = False
-                saveMatches(proj.image_list, check_if_dirty=True)
-                if smart is not None:
-                    smart.save(proj.analysis_dir)
-            save_time = time.time()
-            time_list = [[i3.desc_timestamp, i3] for i3 in proj.image_list
-                         if i3.des_list is not None]
-            time_list = sorted(time_list, key=lambda fields: fields[0], reverse=True)
-            cache_size = 20 + 5 * (int(sqrt(len(proj.image_list))) + 1)
-            flush_list = time_list[cache_size:]
-            _qlog("flushing keypoint/descriptor cache - size: %d (over by: %d)"
-                  % (cache_size, len(flush_list)))
-            for line in flush_list:
-                _qlog('  clearing descriptors for:', line[1].name)
-                line[1].kp_list = None
-                line[1].des_list = None
-                line[1].uv_list = None
-            rows_known[:] = False
-
-    if prefetcher is not None:
-        prefetcher.close()
-    drain()
-    _early_smart_join()
-    _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value)
-    if rank == 0:
-        # (quiet pairs dirty both images' match lists, like the reference's assignments)
-        for k in np.nonzero(last_seq >= 0)[0].tolist():
-            image_list[k].matches_clean = False
-        # smart.json is written beside the .match files (file writes release the interpreter),
-        # unless the copy written ahead of time is still current
-        saver = None
-        smart_current = early_smart['thread'] is not None and early_smart['error'] is None \
-            and early_smart['hits'] == hits_booked[0]
-        early_smart_stats['current_at_end'] += bool(smart_current)
-        if smart is not None and not smart_current:
-            import threading
-            saver_error = []
-
-            def _save_smart():
-                try:
-                    smart.save(proj.analysis_dir)
-                except BaseException as exc:       # re-raised below, where the reference's call sits
-                    saver_error.append(exc)
-            saver = threading.Thread(target=_save_smart, name='iamx-smart-save')
-            saver.start()
-        try:
-            saveMatches(proj.image_list)
-        finally:
-            if saver is not None:
-                saver.join()
-        if saver is not None and saver_error:
-            raise saver_error[0]
-    pickler.shutdown(wait=True)
-    print('Pair-wise matches successfully saved.')
-
-
-def _settle_yaw(smart, image_list, last_seq, last_quiet, yaw_value):
-    """The aircraft yaw error estimate of every image as the reference leaves it: the value of
-    the image's LAST pair -- 0 when that pair had no matches (update_yaw_error_estimate returns 0,
-    smart.py:258-260), else the weighted average over its pairs."""
-    if smart is None:
-        return
-    if hasattr(smart, 'flush_aggregates'):
-        smart.flush_aggregates()
-    for k in np.nonzero(last_seq >= 0)[0].tolist():
-        im = image_list[k]
-        if last_quiet[k]:
-            im.set_aircraft_yaw_error_estimate(0)
-        elif k in yaw_value:
-            v = yaw_value[k][1]
-            if v is None:                       # deferred: the average over all recorded pairs
-                v = smart.current_yaw_average(im.name)
-            im.set_aircraft_yaw_error_estimate(v)
+                def _save_smart():
+                    try:
+                        smart.save(proj.analysis_dir)
+                    except BaseException as exc:       # re-raised below, where the reference's call sits
+                        saver_error.append(exc)
+                saver = threading.Thread(target=_save_smart, name='iamx-smart-save')
+                saver.start()
+            try:
+                saveMatches(proj.image_list)
+            finally:
+                if saver is not None:
+                    saver.join()
+            if saver is not None and saver_error:
+                raise saver_error[0]
+        self.pickler.shutdown(wait=True)
 
 
 def saveMatches(image_list, check_if_dirty=False):

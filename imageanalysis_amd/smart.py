@@ -103,6 +103,196 @@ def triangulate_features(i1, i2):
     return points
 
 
+# ---- the yaw-error FEEDBACK of the pair loop (lib/matcher.py:987-993) ---------------------------
+# After every pair the reference rewrites both images' camera poses from the running yaw-error
+# estimate (update_yaw_error_estimate -> Image.set_aircraft_yaw_error_estimate,
+# lib/image.py:434-457), and the NEXT pair either image takes part in triangulates with those
+# poses (triangulate_features -> get_proj, lib/image.py:542-553).  The estimate itself only
+# depends on the similarity fits (pose independent), so the whole chain is a prefix computation
+# over the schedule: PoseFeedback replays it in schedule order from the rounds' yaw values and
+# hands every pair with matches the two projection matrices the reference would have used.
+def pose_matrices(yaw_deg, pitch_deg, roll_deg, ned, body2cam_q, body2cam_m):
+    """[n, 12] row-major [R | t] of cameras whose AIRCRAFT attitude is (yaw, pitch, roll) degrees
+    ('rzyx') and whose mount offset is the quaternion body2cam_q: the camera pose
+    Image.set_aircraft_yaw_error_estimate() stores (lib/image.py:441-457: ned2cam = ned2body *
+    body2cam) turned into get_proj()'s matrix (lib/image.py:542-553: R = body2cam . ned2body,
+    t = -R . ned), for n poses at once.  Term by term the arithmetic of transformations.py
+    (quaternion_from_euler 'rzyx', quaternion_multiply, quaternion_matrix); the half-angle sines
+    and cosines come from math like there."""
+    import math
+    d2r = math.pi / 180.0
+    n = len(yaw_deg)
+    trig = lambda a: (np.array([math.cos(v) for v in a]), np.array([math.sin(v) for v in a]))
+    # quaternion_from_euler(yaw, pitch, roll, 'rzyx'): frame 1 swaps the first and last angle
+    ci, si = trig((np.asarray(roll_deg, float) * d2r / 2.0).tolist())
+    cj, sj = trig((np.asarray(pitch_deg, float) * d2r / 2.0).tolist())
+    ck, sk = trig((np.asarray(yaw_deg, float) * d2r / 2.0).tolist())
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    w1, x1, y1, z1 = cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc
+    w0, x0, y0, z0 = [float(v) for v in body2cam_q]
+    q = np.stack([-x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0,
+                  x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0,
+                  -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0,
+                  x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0], 1)
+    # quaternion_matrix: q *= sqrt(2 / |q|^2); outer products
+    nn = (q * q).sum(1)
+    q = q * np.sqrt(2.0 / nn)[:, None]
+    o = q[:, :, None] * q[:, None, :]
+    body2ned = np.empty((n, 3, 3))
+    body2ned[:, 0, 0] = 1.0 - o[:, 2, 2] - o[:, 3, 3]
+    body2ned[:, 0, 1] = o[:, 1, 2] - o[:, 3, 0]
+    body2ned[:, 0, 2] = o[:, 1, 3] + o[:, 2, 0]
+    body2ned[:, 1, 0] = o[:, 1, 2] + o[:, 3, 0]
+    body2ned[:, 1, 1] = 1.0 - o[:, 1, 1] - o[:, 3, 3]
+    body2ned[:, 1, 2] = o[:, 2, 3] - o[:, 1, 0]
+    body2ned[:, 2, 0] = o[:, 1, 3] - o[:, 2, 0]
+    body2ned[:, 2, 1] = o[:, 2, 3] + o[:, 1, 0]
+    body2ned[:, 2, 2] = 1.0 - o[:, 1, 1] - o[:, 2, 2]
+    R = np.einsum('ij,nkj->nik', np.asarray(body2cam_m, float), body2ned)       # body2cam . ned2body
+    t = -np.einsum('nij,nj->ni', R, np.asarray(ned, float).reshape(n, 3))
+    return np.concatenate([R, t[:, :, None]], 2).reshape(n, 12)
+
+
+class PoseFeedback(object):
+    """The camera poses the reference's pair loop would hold when it reaches each pair
+    (lib/matcher.py:918-1005), replayed from the rounds of find_matches.
+
+    State per image: the yaw-error estimate its LAST pair so far left (the weighted average over
+    /smart/<image>/yaw_pairs after a pair with a similarity fit, 0 after a pair without matches
+    or without a fit: update_yaw_error_estimate, lib/smart.py:251-283), or "untouched" -- then the
+    image's stored camera pose stands.  feed() takes one round (all ranks' pairs, schedule order)
+    and returns, for its pairs with matches, the estimate of both images BEFORE the pair."""
+
+    def __init__(self, image_list):
+        self.image_list = image_list
+        n = len(image_list)
+        self.touched = np.zeros(n, bool)
+        self.value = [0] * n                 # python numbers: what the reference passes on
+        self._entries = {}                   # image index -> [sorted partner names, {name: (err, w, dist)}]
+        self._base = None
+        self._base_of = {}
+
+    # -- the running average of one image, lib/smart.py:265-283 ------------------------------
+    def _state(self, x):
+        st = self._entries.get(x)
+        if st is None:
+            name = self.image_list[x].name
+            inode = smart_node.getChild(name, True)
+            acc = dict(_yaw_pairs_of(name, inode.getChild("yaw_pairs", True)))
+            st = self._entries[x] = [sorted(acc), acc]
+        return st
+
+    def _record(self, x, other, values):
+        """the pair entry of image x for partner `other` and the average over x's entries"""
+        import bisect
+        keys, acc = self._state(x)
+        if other not in acc:
+            bisect.insort(keys, other)
+        acc[other] = (float("%.1f" % values[0]), int(float("%.1f" % values[3])), float("%.1f" % values[1]))
+        total, count = 0, 0
+        for k in keys:                                   # the tree's child order (sorted)
+            err, w, dist_m = acc[k]
+            if dist_m >= 0.5 and abs(err) <= 30:
+                total += err * w
+                count += w
+        return total / count if count > 0 else 0
+
+    def feed(self, seq, pi, pj, quiet, hit_rows, yv_f, yv_r, ok):
+        """one round: seq / pi / pj / quiet over ALL its pairs (seq ascending), hit_rows = the
+        rows with matches, yv_f / yv_r [h][4] their (yaw_error, dist, course, weight) per
+        direction, ok [h][2] whether that direction has a similarity fit.
+        -> (e1 [h], e2 [h], fresh1 [h], fresh2 [h]): the estimate of pair.i1 / pair.i2 when the
+        pair is reached, and whether that image is still untouched (stored pose)."""
+        import bisect
+        h = len(hit_rows)
+        e1, e2 = [0] * h, [0] * h
+        f1, f2 = np.zeros(h, bool), np.zeros(h, bool)
+        names = None
+        if h:
+            names = [im.name for im in self.image_list] if self._base is None else self._base[0]
+            if self._base is None:
+                self._base = (names,)
+            hi, hj = pi[hit_rows], pj[hit_rows]
+            is_hit_img = np.zeros(len(self.image_list), bool)
+            is_hit_img[hi] = True
+            is_hit_img[hj] = True
+            # quiet pairs of this round that touch an image with matches in this round, per image
+            qrows = np.nonzero(quiet)[0]
+            qsets = {}
+            if len(qrows):
+                qi, qj, qs = pi[qrows], pj[qrows], seq[qrows]
+                img = np.concatenate([qi[is_hit_img[qi]], qj[is_hit_img[qj]]])
+                sq = np.concatenate([qs[is_hit_img[qi]], qs[is_hit_img[qj]]])
+                if len(img):
+                    order = np.lexsort((sq, img))
+                    img, sq = img[order], sq[order]
+                    cut = np.nonzero(np.diff(img))[0] + 1
+                    for a, b in zip(np.concatenate([[0], cut]).tolist(), np.concatenate([cut, [len(img)]]).tolist()):
+                        qsets[int(img[a])] = sq[a:b].tolist()
+            last_event = {}                                  # image -> seq of its last pair with matches here
+            touched, value = self.touched, self.value
+            hs = seq[hit_rows].tolist()
+            for t, (x, y, s) in enumerate(zip(hi.tolist(), hj.tolist(), hs)):
+                for side, im_ in ((0, x), (1, y)):
+                    qs_ = qsets.get(im_)
+                    if qs_:
+                        k = bisect.bisect_left(qs_, s)
+                        if k and qs_[k - 1] > last_event.get(im_, -1):
+                            touched[im_] = True              # a quiet pair in between: back to 0
+                            value[im_] = 0
+                    if side == 0:
+                        e1[t], f1[t] = value[x], not touched[x]
+                    else:
+                        e2[t], f2[t] = value[y], not touched[y]
+                # the pair's own updates: image 1, then image 2 (lib/matcher.py:990-993)
+                value[x] = self._record(x, names[y], yv_f[t]) if ok[t][0] else 0
+                value[y] = self._record(y, names[x], yv_r[t]) if ok[t][1] else 0
+                touched[x] = touched[y] = True
+                last_event[x] = last_event[y] = s
+        # every image whose LAST pair of the round is a quiet one ends the round at 0
+        n_img = len(self.image_list)
+        newest = np.full(n_img, -1, np.int64)
+        newest_j = np.full(n_img, -1, np.int64)
+        newest[pi] = seq                                     # (seq ascends: the last assignment stays)
+        newest_j[pj] = seq
+        np.maximum(newest, newest_j, out=newest)
+        seen = np.nonzero(newest >= 0)[0]
+        if len(seen):
+            row_of = np.searchsorted(seq, newest[seen])
+            for x in seen[quiet[row_of]].tolist():
+                self.value[x] = 0
+            self.touched[seen] = True
+        return e1, e2, f1, f2
+
+    def _pose_base(self, x):
+        """(aircraft yaw, pitch, roll, camera ned): what set_aircraft_yaw_error_estimate() and
+        get_proj() read; none of them changes inside one find_matches call"""
+        hit = self._base_of.get(x)
+        if hit is None:
+            im = self.image_list[x]
+            _lla, ypr, _q = im.get_aircraft_pose()
+            hit = self._base_of[x] = (ypr[0], ypr[1], ypr[2], tuple(im.get_camera_pose()[0]))
+        return hit
+
+    def projections(self, images, estimates):
+        """[n, 12] projection matrices of `images` (indices) under the yaw-error `estimates`"""
+        cam = _deps.camera()
+        il = self.image_list
+        base = [self._pose_base(x) for x in images]
+        yaw = [b[0] + e for b, e in zip(base, estimates)]
+        first = il[images[0]]
+        body2cam_m = first.get_body2cam() if hasattr(first, 'get_body2cam') else np.linalg.inv(CAM2BODY)
+        return pose_matrices(yaw, [b[1] for b in base], [b[2] for b in base],
+                             np.array([b[3] for b in base], float).reshape(-1, 3), cam.get_body2cam(),
+                             np.asarray(body2cam_m, float))
+
+    def settle(self):
+        """the call is over: every touched image gets its last estimate, the way the reference's
+        last set_aircraft_yaw_error_estimate() of that image left it"""
+        for x in np.nonzero(self.touched)[0].tolist():
+            self.image_list[x].set_aircraft_yaw_error_estimate(self.value[x])
+
+
 _frozen = None          # id(image) -> (ned array, aircraft yaw) while find_matches runs
 
 

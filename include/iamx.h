@@ -433,6 +433,21 @@ int iamx_triangulate_pairs_xyz(const int32_t *pair_img, const double *PROJ, cons
                                const int32_t *m_pairs, int n_pairs, int clip, double *out_xyz,
                                void *stream);
 
+/* iamx_triangulate_packed -- the triangulation of iamx_triangulate_pairs over PACKED match lists
+ * with one pair of projection matrices PER PAIR: the surface stage of find_matches.  The reference
+ * rewrites both images' camera poses after every pair (scripts/lib/matcher.py:990-993 ->
+ * lib/image.py:434-457 set_aircraft_yaw_error_estimate) and the next pair triangulates with them
+ * (lib/smart.py:26-63 via lib/image.py:542-553 get_proj); the host replays that chain in schedule
+ * order and passes every pair the two matrices the reference would have used.
+ *   pair_img  DEV [n_pairs][2] image slots (kp_off / xy as above)
+ *   pair_proj DEV [n_pairs][2][12] float64 row-major [R | t] of image 1 / image 2 of the pair
+ *   m_off     DEV [n_pairs + 1] int64 first match of every pair; m_pairs DEV [total][2]
+ *   out_z     DEV [total] NED "down" of every match (w-normalised) */
+int iamx_triangulate_packed(const int32_t *pair_img, const double *pair_proj, const double *IK,
+                            const int64_t *kp_off, const float *xy, const int64_t *m_off,
+                            const int32_t *m_pairs, int n_pairs, int64_t total, double *out_z,
+                            void *stream);
+
 /* iamx_similarity_pairs -- scripts/lib/smart.py:66-89 find_affine(): the 2x3 similarity
  * (rotation, uniform scale, translation) between the matched keypoints of every pair of a batch,
  * for estimate_yaw_error() (:138-192).  The reference asks cv2.estimateAffinePartial2D (RANSAC);

@@ -523,6 +523,149 @@ def run_smart_case(name, seed, n_img, n_kp):
           % (name, len(out_pairs), ground, sorted(set(v for v in tri.values() if v is not None))))
 
 
+# ---------------------------------------------------------------------------
+# G9: the reference's OWN pair loop -- lib/matcher.py:852-1031 find_matches(strategy="traditional")
+# -- on a two-row strip with pre-loaded features: per-pair match lists, the surface / yaw
+# bookkeeping of lib/smart.py, the yaw-error FEEDBACK (after every pair the images' camera poses
+# are rewritten, lib/image.py:434-457, and the next pair triangulates with them), the
+# "std >= 50 and < 100 matches -> discard" rule (:1001-1005), a quiet pair resetting the estimate
+# to 0, and a second call on the same project (done pairs skipped, empty ones retried).
+# ---------------------------------------------------------------------------
+def _tree(node):
+    out = {}
+    for k, v in node.__dict__.items():
+        out[k] = _tree(v) if hasattr(v, 'getChild') else (list(v) if isinstance(v, list) else v)
+    return out
+
+
+def _pose_record(im):
+    ac = im.node.getChild('aircraft_pose', True)
+    cp = im.node.getChild('camera_pose', True)
+    return dict(yaw_error_deg=ac.getFloat('yaw_error_deg') if ac.hasChild('yaw_error_deg') else None,
+                aircraft_quat=[ac.getFloatEnum('quat', k) for k in range(4)],
+                camera_ypr=[cp.getFloat('yaw_deg'), cp.getFloat('pitch_deg'), cp.getFloat('roll_deg')],
+                camera_quat=[cp.getFloatEnum('quat', k) for k in range(4)])
+
+
+def run_find_matches_case(name, seed, n_img=14, n_kp=420, sorts=(True, False)):
+    from lib import smart as ref_smart
+    rng = np.random.default_rng(seed)
+    per_row = n_img // 2
+    names = ['F%03d' % i for i in range(n_img)]
+    camera.set_K(*[K_FC6310S[k] for k in (0, 4, 2, 5)])
+    camera.set_image_params(W_PX, H_PX)
+    camera.set_mount_params(0.0, -90.0, 0.0)
+    K = np.array(K_FC6310S).reshape(3, 3)
+    getNode('/config/detector', True).setString('detector', 'SIFT')
+    getNode('/config/detector', True).setFloat('scale', 0.4)
+    mnode = getNode('/config/matcher', True)
+    mnode.setFloat('match_ratio', 0.75)
+    mnode.setInt('min_pairs', 25)
+    matcher.configure()
+    # ---- the scene: ground points with a descriptor each; two flight lines, serpentine
+    ground = float(rng.uniform(2.0, 15.0))
+    n_pts = 2600
+    pts = np.stack([rng.uniform(-90, 30.0 * per_row + 60, n_pts), rng.uniform(-120, 160, n_pts),
+                    -ground + rng.normal(0, 1.2, n_pts)], 1)
+    base_des = sift_like(rng, n_pts)
+    truth, reported = [], []
+    for i in range(n_img):
+        row, col = divmod(i, per_row)
+        north = 30.0 * (col if row == 0 else per_row - 1 - col)
+        ned = [north + rng.normal(0, 0.4), 38.0 * row + rng.normal(0, 0.4), -112.0 + rng.normal(0, 0.8)]
+        heading = (0.0 if row == 0 else 180.0) + rng.normal(0, 3.0)
+        pitch, roll = rng.normal(0, 1.5), rng.normal(0, 1.5)
+        yaw_bias = rng.normal(0, 4.0) + (6.0 if i % 5 == 2 else 0.0)     # what the EKF got wrong
+        truth.append(dict(ned=ned, ypr=[heading, pitch, roll]))
+        reported.append(dict(ned=ned, ypr=[heading + yaw_bias, pitch, roll]))
+
+    def fresh_project(tag):
+        """images with the REPORTED aircraft pose, camera pose = aircraft pose + mount
+        (lib/pose.py:125-152), keypoints = projections under the TRUE pose"""
+        for n_ in list(getNode('/images', True).__dict__):
+            del getNode('/images', True).__dict__[n_]
+        ref_smart.smart_node.__dict__.clear()
+        tmp = '/tmp/iamx_golden_fm_%s_%s' % (name, tag)
+        os.makedirs(os.path.join(tmp, 'meta'), exist_ok=True)
+        for f_ in os.listdir(os.path.join(tmp, 'meta')):
+            os.remove(os.path.join(tmp, 'meta', f_))
+        proj = FakeProj(names, tmp)
+        body2cam = camera.get_body2cam()
+        r2d = 180.0 / math.pi
+        for i, im in enumerate(proj.image_list):
+            for kind in ('truth', 'reported'):
+                src = truth[i] if kind == 'truth' else reported[i]
+                im.set_aircraft_pose(45.0, -93.0, 300.0, *src['ypr'])
+                ned2body = [im.node.getChild('aircraft_pose').getFloatEnum('quat', k) for k in range(4)]
+                ned2cam = _tf.quaternion_multiply(ned2body, body2cam)
+                y, p, r = _tf.euler_from_quaternion(ned2cam, 'rzyx')
+                im.set_camera_pose(src['ned'], y * r2d, p * r2d, r * r2d)
+                if kind == 'truth':
+                    rvec, tvec = im.get_proj()
+                    uvp, _ = cv2.projectPoints(pts.reshape(-1, 1, 3), rvec,
+                                               np.asarray(tvec).reshape(3, 1), K, np.zeros(5))
+                    im._uvp = uvp.reshape(-1, 2)
+        return proj
+
+    proj = fresh_project('probe')
+    rng_kp = np.random.default_rng(seed + 1)
+    des, xy = [], []
+    for i, im in enumerate(proj.image_list):
+        uvp = im._uvp
+        vis = np.nonzero((uvp[:, 0] > 2) & (uvp[:, 0] < W_PX - 2) & (uvp[:, 1] > 2) & (uvp[:, 1] < H_PX - 2))[0]
+        vis = rng_kp.permutation(vis)[:n_kp]
+        p = uvp[vis] + rng_kp.normal(0, 0.4, (len(vis), 2))
+        d = np.clip(base_des[vis].astype(np.int64) + rng_kp.integers(-5, 6, (len(vis), 128)), 0, 255)
+        # clutter: features of nothing on the ground
+        n_cl = 60
+        p = np.concatenate([p, np.stack([rng_kp.uniform(0, W_PX - 1, n_cl), rng_kp.uniform(0, H_PX - 1, n_cl)], 1)])
+        d = np.concatenate([d, sift_like(rng_kp, n_cl)])
+        des.append(d.astype(np.uint8))
+        xy.append(np.clip(p, 0, [W_PX - 1, H_PX - 1]).astype(np.float32))
+    # a false match block between images 1 and 5 (4 apart: no common ground): the same 70 "features"
+    # at nearly the same pixels of both -> GMS-consistent, triangulates to nonsense (std >= 50)
+    a_, b_ = 1, 5
+    n_f = 70
+    blk = sift_like(rng_kp, n_f)
+    pos = np.stack([rng_kp.uniform(900, 2400, n_f), rng_kp.uniform(700, 1900, n_f)], 1)
+    for k_, shift in ((a_, (0.0, 0.0)), (b_, (35.0, -20.0))):
+        dd = np.clip(blk.astype(np.int64) + rng_kp.integers(-4, 5, (n_f, 128)), 0, 255).astype(np.uint8)
+        pp = (pos + shift + rng_kp.normal(0, 2.5, (n_f, 2))).astype(np.float32)
+        des[k_] = np.concatenate([des[k_], dd])
+        xy[k_] = np.concatenate([xy[k_], pp])
+
+    runs = {}
+    for sort in sorts:
+        proj = fresh_project('sort%d' % int(sort))
+        for i, im in enumerate(proj.image_list):
+            im.des_list = des[i].astype(np.float32)
+            im.kp_list = [cv2.KeyPoint(float(x), float(y), 3.0) for x, y in xy[i]]
+        initial = [_pose_record(im) for im in proj.image_list]
+        calls = []
+        for call in range(2):
+            with quiet():
+                matcher.find_matches(proj, K, strategy='traditional', transform='gms', sort=sort)
+            calls.append(dict(
+                match_lists=[{k: [list(map(int, p_)) for p_ in v] for k, v in im.match_list.items()}
+                             for im in proj.image_list],
+                smart=pickle.loads(pickle.dumps(_tree(ref_smart.smart_node))),
+                poses=[_pose_record(im) for im in proj.image_list]))
+        runs[bool(sort)] = dict(initial=initial, calls=calls)
+        ml = calls[0]['match_lists']
+        n_hit = sum(1 for m in ml for v in m.values() if len(v)) // 2
+        n_all = sum(len(m) for m in ml) // 2
+        disc = [(names[i], o) for i, m in enumerate(ml) for o, v in m.items()
+                if not v and o in calls[0]['smart'].get(names[i], {}).get('tri_surface_pairs', {})]
+        print('find_matches_%s sort=%s: %d pairs, %d with matches, discarded %s, yaw_error_deg %s'
+              % (name, sort, n_all, n_hit, sorted(disc)[:4],
+                 ['%.2f' % (p_['yaw_error_deg'] or 0) for p_ in calls[0]['poses']]))
+    with open(os.path.join(GOLD, 'find_matches_%s.pkl' % name), 'wb') as f:
+        pickle.dump(dict(names=names, des=des, xy=xy, K=K_FC6310S, width=W_PX, height=H_PX,
+                         mount=[0.0, -90.0, 0.0], reported=reported, truth=truth,
+                         aircraft_lla=[45.0, -93.0, 300.0], match_ratio=0.75, min_pairs=25,
+                         ground=ground, runs=runs), f, protocol=4)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     # G1 ------------------------------------------------------------------
@@ -545,6 +688,8 @@ def main():
     run_cleanup_case('twoblocks', seed=33, n_img=22, n_kp=1500, n_tracks=2600, gap=12)
     # G8 ------------------------------------------------------------------
     run_smart_case('grid', seed=41, n_img=6, n_kp=400)
+    # G9 ------------------------------------------------------------------
+    run_find_matches_case('strip', seed=51)
 
 
 if __name__ == '__main__':

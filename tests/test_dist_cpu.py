@@ -128,17 +128,12 @@ def test_find_matches_two_ranks_equals_one_rank():
         _run_find_matches(0, 1, 0, d)
         mp.spawn(_run_find_matches, args=(2, _free_port(), d), nprocs=2, join=True)
         one = pickle.load(open(os.path.join(d, 'r0_of_1.pkl'), 'rb'))
-        # rank 0 holds the whole survey's bookkeeping, the other rank the pairs it matched itself
+        # rank 0 holds the whole survey's bookkeeping; the other rank is a worker (its share of every
+        # round travels to rank 0 as one byte tensor, nothing is booked there)
         two = pickle.load(open(os.path.join(d, 'r0_of_2.pkl'), 'rb'))
         assert two == one
         part = pickle.load(open(os.path.join(d, 'r1_of_2.pkl'), 'rb'))
-        seen = 0
-        for name, ml in part.items():
-            for other, lst in ml.items():
-                assert lst == one[name][other]
-                seen += 1
-        assert 0 < seen < sum(len(m) for m in one.values())
-        assert sum(len(v) > 0 for m in one.values() for v in m.values()) >= 8
+        assert all(len(ml) == 0 for ml in part.values())
 
 
 def _run_helpers(rank, world, port):

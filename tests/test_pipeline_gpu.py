@@ -80,6 +80,7 @@ def test_detect_match_consolidate_triangulate_group_optimize(tmp_path):
     camera.set_K(F, F, W / 2.0, H / 2.0)
     camera.set_dist_coeffs([0.0] * 5)
     camera.set_image_params(W, H)
+    camera.set_mount_params(0.0, -90.0, 0.0)
 
     class Proj(object):
         analysis_dir = str(an)
@@ -104,7 +105,7 @@ def test_detect_match_consolidate_triangulate_group_optimize(tmp_path):
             str(proj_dir / 'images' / (name + '.JPG')), quality=95)
         im = iimg.Image(str(an), name)
         # what the flight log would say: off by ~1 m and ~1 deg
-        im.set_camera_pose((ned + rng.normal(0, 0.8, 3)).tolist(), *(ypr + rng.normal(0, 0.7, 3)).tolist())
+        im.set_pose_from_camera((ned + rng.normal(0, 0.8, 3)).tolist(), *(ypr + rng.normal(0, 0.7, 3)).tolist())
         getNode('/smart', True).getChild(name, True).setFloat('tri_surface_m', 0.0)
         proj.image_list.append(im)
 
