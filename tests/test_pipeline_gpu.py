@@ -118,17 +118,18 @@ def test_detect_match_consolidate_triangulate_group_optimize(tmp_path):
     assert n_pairs >= 12                                   # neighbours overlap, far pairs do not
     assert all(len(im.kp_list) > 1000 for im in proj.image_list)
     assert os.path.exists(os.path.join(str(an), 'meta', 'P00.match'))
-    # the surface statistics find_matches recorded came from ONE triangulation launch per batch;
-    # they equal what the per-pair entry point computes from the stored match lists
+    # the surface statistics find_matches recorded: every pair was triangulated with the camera
+    # poses the reference's loop holds when it reaches the pair (tests/test_find_matches_loop.py
+    # pins that against the reference's own loop) -- on these frames, rendered from the plane
+    # z = 0 with ~1 m / ~1 deg of pose error, that is a surface within a few metres of 0 for every pair
+    # (40 m baselines seen from 100 m: a degree of attitude error moves a pair's surface by metres)
     from imageanalysis_amd import smart
     n_checked = 0
     for a in proj.image_list:
         for b in proj.image_list:
             if a is not b and len(a.match_list.get(b.name, [])):
-                avg, std, _d = smart.estimate_surface_elevation(a, b)
                 rec = smart.smart_node.getChild(a.name).getChild('tri_surface_pairs').getChild(b.name)
-                assert rec.getFloat('surface_m') == float('%.1f' % avg)
-                assert rec.getFloat('stddev') == float('%.1f' % std)
+                assert abs(rec.getFloat('surface_m')) < 10.0 and rec.getFloat('stddev') < 8.0
                 n_checked += 1
     assert n_checked >= 24
 
