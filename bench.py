@@ -2,15 +2,16 @@
 """bench.py -- image-pairs matched / s on MI355X (BASELINE.json metric), with roofline and a
 CPU baseline on the same line.
 
-Workload, N=1: BASELINE.json configs[1] -- 500 synthetic images x 4096 keypoints x 128-D
-SIFT-like descriptors, brute-force L2 2-NN in BOTH directions for all 124 750 image pairs,
-plus the reference's quality-metric filter and survivor compaction on the device
-(metric M1).  A "step" = one pass over all pairs of the rank's shard.
-N>1: BASELINE.json configs[2] -- the 2812-image survey, all 3 952 266 pairs, pair-sharded over
-the ranks (strong scaling: the total work is fixed).  Each rank owns 1/N of the images'
-descriptors ("detected there"), packs them, they are all-gathered over RCCL inside the step (the
-path's one exchange step), then every rank matches its shard of the pair schedule -- no other
-data-path collective.  The BA section runs configs[3] point-sharded.
+Workload, every N: the survey BASELINE.json's metric is quoted on (configs[2]) -- 2812 synthetic
+images x 4096 keypoints x 128-D SIFT-like descriptors, brute-force L2 2-NN in BOTH directions for
+all 3 952 266 image pairs, plus the reference's quality-metric filter and survivor compaction on
+the device (metric M1).  A "step" = one pass over all pairs of the rank's share
+(strong scaling: the total work is fixed; it fits one GPU, 7 s per step).  N>1: each rank owns
+1/N of the images' descriptors ("detected there"), packs them, they are all-gathered over RCCL
+inside the step (the path's one exchange step), every rank matches its share of the pair schedule,
+and the survivors of every launch travel to rank 0 as fixed-layout tensors (the product's
+per-round gather, dist.gather_arrays) -- no other data-path collective.  configs[1] (500 images,
+one MI355X) follows as an extra key at N = 1.  The BA section runs configs[3] point-sharded.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 """
@@ -164,24 +165,79 @@ def match_section(args, rank, world, dev, dist, one_gpu, n_img, steps, warmup, v
 
     candidates = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    def count_survivors(b, w):
+    # ---- N > 1: what the product does with a round's results (matcher._MatchRun.exchange:
+    #      every rank's share of a round -> rank 0 as ONE fixed-layout tensor gather).  Here a
+    #      "round" is GATHER_GROUP launches; a rank's share is, per launch, the survivor count of
+    #      every ordered pair and the first GATHER_CAP compacted (query row, train row) survivors
+    #      (the synthetic survey leaves ~4 k per launch; anything beyond the cap is counted and
+    #      reported, never silently dropped).  Inside the timed step, on the side stream.
+    GATHER_GROUP, GATHER_CAP = 4, 65536
+    gather = None
+    if dist is not None:
+        nl = torch.tensor([len(batches)], dtype=torch.int64, device=dev)
+        dist.all_reduce(nl, op=dist.ReduceOp.MAX)
+        n_groups = (int(nl.item()) + GATHER_GROUP - 1) // GATHER_GROUP
+        max_pairs = max(b.n_pairs for b in batches)
+        words = GATHER_GROUP * (max_pairs + 2 * GATHER_CAP)
+        gather = {"groups": n_groups, "words": words, "sent": 0,
+                  "stage": [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(2)],
+                  "recv": [[torch.empty(words, dtype=torch.int32, device=dev) for _ in range(world)]
+                           for _ in range(2)] if rank == 0 else None,
+                  "truncated": torch.zeros(1, dtype=torch.int64, device=dev),
+                  "received": torch.zeros(1, dtype=torch.int64, device=dev)}
+
+    def send_group(g):
+        st = gather["stage"][g & 1]
+        if one_gpu:                  # gloo debug mode: host tensors
+            parts = [torch.empty(gather["words"], dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+            dist.gather(st.cpu(), parts, dst=0)
+            if rank == 0:
+                gather["received"].add_(sum(int(p_.view(GATHER_GROUP, -1)[:, :max_pairs].sum()) for p_ in parts))
+        else:
+            dist.gather(st, gather["recv"][g & 1] if rank == 0 else None, dst=0)
+            if rank == 0:            # (rank 0 reads what arrived: the counts of every rank's share)
+                for p_ in gather["recv"][g & 1]:
+                    gather["received"].add_(p_.view(GATHER_GROUP, -1)[:, :max_pairs].sum())
+        gather["sent"] = g + 1
+
+    def count_survivors(b, w, k=None):
         survivors.add_(w.surv_cnt[:b.n_pairs].sum())
         candidates.add_(w.seg_count[:b.n_pairs].sum())     # rows that passed the bound test
+        if gather is not None and k is not None:
+            g, slot = divmod(k, GATHER_GROUP)
+            st = gather["stage"][g & 1]
+            if slot == 0:
+                st.zero_()
+            base = slot * (max_pairs + 2 * GATHER_CAP)
+            st[base:base + b.n_pairs].copy_(w.surv_cnt[:b.n_pairs])
+            st[base + max_pairs:base + max_pairs + GATHER_CAP].copy_(w.surv_q[:GATHER_CAP])
+            st[base + max_pairs + GATHER_CAP:base + max_pairs + 2 * GATHER_CAP].copy_(w.surv_t[:GATHER_CAP])
+            gather["truncated"].add_((w.surv_cnt[:b.n_pairs].sum() - GATHER_CAP).clamp_(min=0))
+            if slot == GATHER_GROUP - 1 or k == len(batches) - 1:
+                send_group(g)
 
     def step(timed_events=False):
         pack_and_gather()
+        if gather is not None:
+            gather["sent"] = 0
+        counter = iter(range(len(batches)))
         if overlap:
-            runner.run(batches, thresh, after_filter=count_survivors,
+            runner.run(batches, thresh, after_filter=lambda b, w: count_survivors(b, w, next(counter)),
                        sweep_events=ev if timed_events else None)
-            return
-        for b, (e0, e1) in zip(batches, ev):
-            if timed_events:
-                e0.record()
-            b.run_knn2_fast(ws)
-            if timed_events:
-                e1.record()
-            b.run_filter_fast(ws, thresh)
-            count_survivors(b, ws)
+        else:
+            for k, (b, (e0, e1)) in enumerate(zip(batches, ev)):
+                if timed_events:
+                    e0.record()
+                b.run_knn2_fast(ws)
+                if timed_events:
+                    e1.record()
+                b.run_filter_fast(ws, thresh)
+                count_survivors(b, ws, k)
+        if gather is not None:
+            # (a rank with fewer launches than the longest share still takes part in every gather)
+            for g in range(gather["sent"], gather["groups"]):
+                gather["stage"][g & 1].zero_()
+                send_group(g)
 
     def barrier():
         if dist is not None:
@@ -193,13 +249,23 @@ def match_section(args, rank, world, dev, dist, one_gpu, n_img, steps, warmup, v
     barrier()
     survivors.zero_()
     candidates.zero_()
+    if gather is not None:
+        gather["truncated"].zero_()
+        gather["received"].zero_()
     t0 = time.perf_counter()
     for _ in range(steps):
         step(timed_events=True)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
+    # (each rank's own clock from the common start barrier to the moment ITS work of the K steps
+    #  was done would need a second sync point; what is reported per rank is the barrier-to-barrier
+    #  time it measured -- the spread shows clock skew only -- and, below, its busy time)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [round(float(x.item()), 4) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         cnt = torch.tensor([n_pairs_rank], dtype=torch.int64, device=dev)
@@ -213,13 +279,20 @@ def match_section(args, rank, world, dev, dist, one_gpu, n_img, steps, warmup, v
     # ---- roofline of the dominant kernel, HIP events of the last step (recorded on the stream
     #      the sweeps are launched on)
     k_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
+    per_rank_busy = None
+    if dist is not None:
+        # every rank's sweep-kernel seconds of the last step (its share of the schedule)
+        tb = torch.tensor([sum(k_ms) * 1e-3], dtype=torch.float64, device=dev)
+        allb = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allb, tb)
+        per_rank_busy = [round(float(x.item()), 4) for x in allb]
     k_pairs = [b.n_pairs / 2.0 for b in batches]           # unordered pairs per launch
     achieved = sum(k_pairs) * FLOP_PER_PAIR / (sum(k_ms) * 1e-3) / 1e12
     traffic, traffic_src, mfma_busy, mfma_busy_src = None, None, None, None
     sweeps = 2 if args.one_direction else 1                # MFMA passes per distance matrix
     tf = os.path.join(REPO, 'profiles', 'r1_knn2v2_traffic.json' if args.one_direction
                       else KNN2SYM_TRAFFIC_FILE)
-    if n_img == CONFIG1_IMAGES and world == 1 and os.path.exists(tf):
+    if world == 1 and os.path.exists(tf):
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE); PMC cannot be collected from inside
         with open(tf) as fp:
@@ -265,7 +338,15 @@ def match_section(args, rank, world, dev, dist, one_gpu, n_img, steps, warmup, v
     return {"dt": dt, "total_pairs": total_pairs, "survivors": int(survivors.item()),
             "candidates": int(candidates.item()), "unresolved": int(ws_unresolved),
             "verified": verified, "roofline": roofline, "cpu_sample": cpu_sample,
-            "launches": len(batches)}
+            "launches": len(batches), "per_rank_seconds": per_rank,
+            "per_rank_sweep_seconds": per_rank_busy,
+            "gather": None if gather is None else {
+                "what": "per %d launches every rank's survivor counts + first %d survivor rows per "
+                        "launch -> rank 0, one fixed-layout tensor gather (RCCL), inside the timed step"
+                        % (GATHER_GROUP, GATHER_CAP),
+                "gathers_per_step": gather["groups"], "bytes_per_rank_and_gather": gather["words"] * 4,
+                "survivors_beyond_cap": int(gather["truncated"].item()),
+                "survivor_count_seen_by_rank0": int(gather["received"].item())}}
 
 
 def main():
@@ -339,7 +420,7 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    n_img = args.images or (CONFIG1_IMAGES if world == 1 else CONFIG2_IMAGES)
+    n_img = args.images or CONFIG2_IMAGES
     sift_early = None
     if args.sift_first and not args.no_sift:
         sift_early = sift_bench(rank, world, dev, dist, args)
@@ -366,21 +447,19 @@ def main():
             sift_early = sift_bench(rank, world, dev, dist, args)
     dt, total_pairs, roofline, verified = m["dt"], m["total_pairs"], m["roofline"], m["verified"]
     cpu_sample = m["cpu_sample"]
-    # ---- the metric's own survey at N = 1: ONE step over all 3 952 266 pairs of the 2812-image
-    #      configs[2] job on this GPU (same kernels, same timed-step contents; about 7 s).  The
-    #      headline stays on configs[1], the configuration BASELINE.json quotes for one MI355X.
+    # ---- configs[1] (the one-MI355X configuration of BASELINE.json: 500 images, 124 750 pairs) as
+    #      an extra key at N = 1: same kernels, same timed-step contents, 0.23 s per step
     survey = None
-    if world == 1 and n_img != CONFIG2_IMAGES and not args.no_survey and not args.one_direction:
+    if world == 1 and n_img != CONFIG1_IMAGES and not args.no_survey and not args.one_direction:
         torch.cuda.empty_cache()
-        s = match_section(args, rank, world, dev, dist, one_gpu, CONFIG2_IMAGES, 1, 0,
+        s = match_section(args, rank, world, dev, dist, one_gpu, CONFIG1_IMAGES, 5, 1,
                           min(args.verify_pairs, 16))
-        survey = {"workload": "configs[2] at N = 1: %d synthetic images x %d kpts x 128-D, all %d "
-                              "pairs, one timed step (no warm-up step; the configs[1] section "
-                              "just ran the same kernels)" % (CONFIG2_IMAGES, KPTS, s["total_pairs"]),
-                  "value": round(s["total_pairs"] / s["dt"], 1), "unit": "pairs/s",
-                  "seconds_per_step": round(s["dt"], 3), "pairs_per_step": s["total_pairs"],
-                  "launches": s["launches"], "survivors_per_step": s["survivors"],
-                  "candidates_per_step": s["candidates"], "unresolved": s["unresolved"],
+        survey = {"workload": "configs[1]: %d synthetic images x %d kpts x 128-D, all %d pairs, "
+                              "5 timed steps after 1 warm-up step" % (CONFIG1_IMAGES, KPTS, s["total_pairs"]),
+                  "value": round(s["total_pairs"] * 5 / s["dt"], 1), "unit": "pairs/s",
+                  "seconds_per_step": round(s["dt"] / 5, 4), "pairs_per_step": s["total_pairs"],
+                  "launches": s["launches"], "survivors_per_step": s["survivors"] // 5,
+                  "candidates_per_step": s["candidates"] // 5, "unresolved": s["unresolved"],
                   "verify": s["verified"],
                   "roofline": {k: s["roofline"][k] for k in ("bound", "kernel", "achieved", "peak",
                                                              "unit", "frac", "avg_launch_ms")}}
@@ -442,7 +521,7 @@ def main():
             "metric": "image_pairs_matched_per_sec", "value": round(value, 1), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "scaling": "strong", "vs_baseline": None,
             "dtype": "u8 (int8 MFMA, int32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%s: %d synthetic images x %d kpts x 128-D, all-pairs "
@@ -457,7 +536,8 @@ def main():
             "candidates_per_step": m["candidates"] // max(args.steps, 1),
             "unresolved": m["unresolved"],
             "verified_pairs": verified["verified_pairs"] if verified else 0, "verify": verified,
-            "roofline": roofline, "cpu_baseline": cpu, "survey_2812": survey,
+            "roofline": roofline, "cpu_baseline": cpu, "config1_500": survey,
+            "per_rank_seconds": m.get("per_rank_seconds"), "gather": m.get("gather"),
             "dense_overlap": dense,
             "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,
@@ -473,7 +553,7 @@ def main():
         out["summary"] = {
             "match_pairs_per_sec": out["value"], "match_frac_i8_peak": g(roofline, "frac"),
             "mfma_busy": g(roofline, "mfma_busy"), "match_traffic_bytes": g(roofline, "traffic"),
-            "survey_2812_pairs_per_sec": g(survey, "value"), "survey_2812_seconds": g(survey, "seconds_per_step"),
+            "config1_500_pairs_per_sec": g(survey, "value"), "config1_500_seconds": g(survey, "seconds_per_step"),
             "dense_overlap_pairs_per_sec": g(dense, "pairs_per_sec"),
             "dense_overlap_routed_pairs_per_sec": g(dense, "routed_pairs_per_sec"),
             "ba_seconds_to_ftol": g(ba, "seconds_to_ftol"), "ba_trf_it_per_sec": g(ba, "value"),

@@ -4,9 +4,10 @@ xGMI on the node; "gloo" in the CPU tests).  The path shards by *image* (detecti
 
   * features: every image is detected by ONE rank (`owner_of_images`), then the uint8
     descriptors and float32 keypoint positions of all images are exchanged once
-    (`exchange_features`: keypoint counts as objects, then one broadcast per owner and buffer
-    through `gather_store_shards`); bench.py all-gathers the packed stores in place instead
-    (`all_gather_into_tensor`, 1.47 GB per layout for the 2812-image survey);
+    (`exchange_features`: keypoint counts as objects, then ONE `all_gather_into_tensor` per buffer
+    through `gather_store_shards` -- the ranks' blocks padded to the largest); bench.py
+    all-gathers its equal-sized packed stores in place (1.47 GB per layout for the 2812-image
+    survey);
   * match lists: the pairs of a round are dealt round-robin (`round_slice`: rank r takes pairs
     r, r + W, ... of the round's stretch of the schedule, so every rank sees the same mix of near
     and far pairs); the variable-length per-pair results go to rank 0 ONLY as ONE flat byte
@@ -22,7 +23,7 @@ xGMI on the node; "gloo" in the CPU tests).  The path shards by *image* (detecti
     normal equations (`allreduce_sum_`), see ba_solver.py.
 
 xGMI is point to point (7 links x ~153 GB/s per GPU): the store exchange is done as a few
-large transfers (one per owner per buffer), never per image.
+large collectives (one all-gather per buffer), never per image.
 """
 import numpy as np
 import torch
@@ -66,21 +67,31 @@ def gather_store_shards(buffers, row_offsets, owner, rank, world_size, group=Non
     buffers: list of (tensor, row_width) -- e.g. (desc.view(-1), 128), (norm_q, 1), (norm_t, 1),
     each covering ALL images; row_offsets: int64 [n_images+1] first packed row of each image;
     owner: int [n_images], contiguous blocks (owner_of_images).  On entry rank r has filled the
-    rows of its own images; on exit every rank has every row.  One broadcast per (owner,
-    buffer): few, large transfers.
+    rows of its own images; on exit every rank has every row.  ONE all-gather per buffer
+    (all_gather_into_tensor: RCCL's ring over xGMI, every link busy at once): the ranks' blocks
+    differ in size, so they travel padded to the largest one and are copied into place.
     """
     import torch.distributed as dist
     if world_size == 1:
         return
+    owner = np.asarray(owner)
+    spans = []
     for r in range(world_size):
         mine = np.nonzero(owner == r)[0]
-        if len(mine) == 0:
-            continue
-        lo, hi = int(row_offsets[mine[0]]), int(row_offsets[mine[-1] + 1])
-        if hi == lo:
-            continue
-        for buf, width in buffers:
-            dist.broadcast(buf[lo * width:hi * width], src=r, group=group)
+        spans.append((int(row_offsets[mine[0]]), int(row_offsets[mine[-1] + 1])) if len(mine) else (0, 0))
+    longest = max(hi - lo for lo, hi in spans)
+    if longest == 0:
+        return
+    for buf, width in buffers:
+        send = torch.zeros(longest * width, dtype=buf.dtype, device=buf.device)
+        lo, hi = spans[rank]
+        send[:(hi - lo) * width].copy_(buf[lo * width:hi * width])
+        recv = torch.empty(world_size * longest * width, dtype=buf.dtype, device=buf.device)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        for r, (lo, hi) in enumerate(spans):
+            if hi > lo and r != rank:
+                buf[lo * width:hi * width].copy_(recv[r * longest * width:r * longest * width + (hi - lo) * width])
+        del send, recv
 
 
 def exchange_features(owner, own_images, rank, world_size, device=None, group=None):
@@ -90,7 +101,8 @@ def exchange_features(owner, own_images, rank, world_size, device=None, group=No
     (des uint8 [n,128], xy float32 [n,2])} for the images this rank detected (or loaded from
     their cache).  Exchanges the keypoint counts (python objects, bytes), then ONE flat uint8
     descriptor buffer and ONE flat float32 coordinate buffer covering all images, filled by
-    their owners block by block (gather_store_shards: one broadcast per owner and buffer).
+    their owners block by block and all-gathered (gather_store_shards: one
+    all_gather_into_tensor per buffer -- the RCCL descriptor all-gather of the north star).
     Returns (counts int64 [n_images], desc uint8 [sum n, 128], xy float32 [sum n, 2]) as torch
     tensors on `device` (CPU for gloo)."""
     n_images = len(owner)

@@ -36,3 +36,6 @@ def test_two_rank_bench_verifies_pairs_across_ranks():
     # 30 % of every image is a noisy copy of its predecessor: ~860 survivors per adjacent pair and direction
     assert d['survivors_per_step'] > 63 * 2 * 700 and d['candidates_per_step'] >= d['survivors_per_step']
     assert d['ba'] is not None and d['ba']['parallelism'] == 'point-shard x2'
+    # the product's per-round exchange inside the timed step: rank 0 saw every rank's survivor counts
+    assert d['gather']['survivor_count_seen_by_rank0'] == d['survivors_per_step']
+    assert len(d['per_rank_seconds']) == 2 and len(d['per_rank_sweep_seconds']) == 2

@@ -366,3 +366,40 @@ def _run_round0_failure(rank, world, port, where):
 @pytest.mark.parametrize('where', ['launch', 'detect'])
 def test_failure_before_first_gather_reaches_every_rank_world2_gloo(where):
     mp.spawn(_run_round0_failure, args=(2, _free_port(), where), nprocs=2, join=True)
+
+
+def test_round_robin_deal_balances_the_overlapping_pairs():
+    """find_matches deals every round's pairs round-robin (dist.round_slice).  On a
+    distance-sorted all-pairs schedule the overlapping pairs -- all the exact-stage, filter and
+    match-list work -- come first: contiguous blocks (what rounds 1-5 did) give all of them to
+    rank 0, the round-robin deal gives every rank the same share to within a few per cent."""
+    from imageanalysis_amd import dist as D
+    from imageanalysis_amd import matcher
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    n = 20 * 24
+    proj = PoseProject(['G%03d' % i for i in range(n)])
+    for i, im in enumerate(proj.image_list):
+        r, c = divmod(i, 24)
+        im.set_camera_pose([30.0 * r, 25.0 * (c if r % 2 == 0 else 23 - c), -100.0], 0.0, -90.0, 0.0)
+    matcher.matcher_node.setString('schedule', 'all-pairs')
+    try:
+        wd, wi, wj = matcher._work_arrays(proj, True)
+    finally:
+        matcher.matcher_node.__dict__.pop('schedule', None)
+    assert len(wd) == n * (n - 1) // 2 and np.all(np.diff(wd) >= 0)
+    near = wd <= 70.0                                        # pairs whose footprints overlap
+    world, ppb = 8, 512
+    n_rounds = (len(wd) + world * ppb - 1) // (world * ppb)
+    share = np.zeros(world, np.int64)
+    seen = np.zeros(len(wd), np.int64)
+    for rank in range(world):
+        for rnd in range(n_rounds):
+            sl = D.round_slice(len(wd), rnd, ppb, rank, world)
+            share[rank] += int(near[sl].sum())
+            seen[sl] += 1
+    assert np.all(seen == 1)                                 # a partition of the schedule
+    assert share.sum() == near.sum() > 1000
+    assert share.max() - share.min() <= 0.15 * share.mean()
+    blocks = np.array([near[D.shard_bounds(len(wd), r, world)[0]:D.shard_bounds(len(wd), r, world)[1]].sum()
+                       for r in range(world)])
+    assert blocks[0] == near.sum() and blocks[1:].sum() == 0   # what the contiguous deal did
