@@ -996,3 +996,172 @@ extern "C" int iamx_chains_longest_first(const int32_t *img, const int32_t *kp, 
     return IAMX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The yaw-error feedback of the reference's pair loop as a prefix computation over the schedule
+// (HOST code) -- scripts/lib/matcher.py:987-993: after every pair
+//     yaw1 = smart.update_yaw_error_estimate(i1, i2); i1.set_aircraft_yaw_error_estimate(yaw1)
+//     yaw2 = smart.update_yaw_error_estimate(i2, i1); i2.set_aircraft_yaw_error_estimate(yaw2)
+// where update_yaw_error_estimate (scripts/lib/smart.py:251-283) returns 0 for a pair without
+// matches / without a similarity fit, else writes the pair's entry (values rounded through
+// "%.1f", the weight read back with getInt) under /smart/<image>/yaw_pairs and returns the
+// weighted average over the image's entries in the tree's child order (sorted by partner name)
+// that are at least 0.5 m apart and at most 30 degrees off.  The NEXT pair an image takes part in
+// triangulates with the pose that estimate gives (lib/image.py:434-457), so find_matches needs,
+// for every pair with matches, the estimate of both images as they stand when the loop reaches
+// the pair.  State per image: entries sorted by partner rank, current value, touched flag.
+// smart.PoseFeedback drives this; the python form of the same replay stays beside it for partner
+// names outside the project.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct YawEntry {
+    int32_t partner;     // rank of the partner's name among the project's image names
+    double err;          // yaw error, rounded to 0.1
+    double w;            // weight: trunc of the value rounded to 0.1 (what getInt returns)
+    double dist;         // pair distance, rounded to 0.1
+};
+
+struct YawFeedback {
+    int n_images;
+    std::vector<int32_t> rank;                 // image index -> rank of its name
+    std::vector<std::vector<YawEntry>> entries;
+    std::vector<double> value;
+    std::vector<uint8_t> touched;
+};
+
+// float("%.1f" % x): both sides print the correctly rounded decimal and read it back exactly
+inline double round_tenth(double x)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "%.1f", x);
+    return strtod(buf, nullptr);
+}
+
+#pragma clang fp contract(off)
+double yaw_average(const std::vector<YawEntry> &es)
+{
+    // total / count as python forms them: total a float sum of separately rounded products,
+    // count an exact integer sum, one division
+    double total = 0.0;
+    __int128 count = 0;
+    for (const YawEntry &e : es) {
+        if (e.dist >= 0.5 && std::fabs(e.err) <= 30.0) {
+            total = total + e.err * e.w;
+            count += (__int128)e.w;
+        }
+    }
+    if (count > 0) return total / (double)count;
+    return 0.0;
+}
+
+int yaw_record(YawFeedback *fb, int x, int y, const double *v)
+{
+    // v = (yaw_error, dist, relative course, weight)
+    const double w = std::trunc(round_tenth(v[3]));
+    if (!(std::fabs(w) < 1e37)) return -1;     // python: int(inf) / int(nan) raises
+    YawEntry e{fb->rank[(size_t)y], round_tenth(v[0]), w, round_tenth(v[1])};
+    std::vector<YawEntry> &es = fb->entries[(size_t)x];
+    auto at = std::lower_bound(es.begin(), es.end(), e.partner,
+                               [](const YawEntry &a, int32_t p) { return a.partner < p; });
+    if (at != es.end() && at->partner == e.partner) *at = e; else es.insert(at, e);
+    fb->value[(size_t)x] = yaw_average(es);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" void *iamx_yaw_feedback_new(int n_images, const int32_t *name_rank)
+{
+    if (n_images <= 0 || !name_rank) return nullptr;
+    YawFeedback *fb = new (std::nothrow) YawFeedback();
+    if (!fb) return nullptr;
+    fb->n_images = n_images;
+    fb->rank.assign(name_rank, name_rank + n_images);
+    fb->entries.resize((size_t)n_images);
+    fb->value.assign((size_t)n_images, 0.0);
+    fb->touched.assign((size_t)n_images, 0);
+    return fb;
+}
+
+extern "C" void iamx_yaw_feedback_free(void *h) { delete static_cast<YawFeedback *>(h); }
+
+// entries an image's yaw_pairs node holds before the call (an earlier find_matches run)
+extern "C" int iamx_yaw_feedback_seed(void *h, int image, int n, const int32_t *partner_image,
+                                      const double *err, const double *weight, const double *dist)
+{
+    YawFeedback *fb = static_cast<YawFeedback *>(h);
+    if (!fb || image < 0 || image >= fb->n_images || n < 0 || (n && (!partner_image || !err || !weight || !dist)))
+        return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_seed: bad argument");
+    std::vector<YawEntry> &es = fb->entries[(size_t)image];
+    es.clear();
+    for (int k = 0; k < n; ++k) {
+        if (partner_image[k] < 0 || partner_image[k] >= fb->n_images)
+            return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_seed: partner index out of range");
+        es.push_back(YawEntry{fb->rank[(size_t)partner_image[k]], err[k], weight[k], dist[k]});
+    }
+    std::sort(es.begin(), es.end(), [](const YawEntry &a, const YawEntry &b) { return a.partner < b.partner; });
+    return IAMX_OK;
+}
+
+// One round, pairs in schedule order: pi / pj [n] image indices, quiet [n] 1 = no matches; the
+// h pairs with matches are the rows hit_rows [h] (ascending) with yv_f / yv_r [h][4] (yaw_error,
+// dist, relative course, weight per direction) and ok [h][2] (1 = that direction has a fit).
+// Out per pair with matches: e1 / e2 = the estimate of pair.i1 / pair.i2 BEFORE the pair,
+// fresh1 / fresh2 = 1 while that image has not been part of any pair of the call yet (its stored
+// camera pose stands).
+extern "C" int iamx_yaw_feedback_feed(void *h_, int64_t n, const int32_t *pi, const int32_t *pj,
+                                      const uint8_t *quiet, int64_t h, const int64_t *hit_rows,
+                                      const double *yv_f, const double *yv_r, const uint8_t *ok,
+                                      double *e1, double *e2, uint8_t *fresh1, uint8_t *fresh2)
+{
+    YawFeedback *fb = static_cast<YawFeedback *>(h_);
+    if (!fb || n < 0 || h < 0 || (n && (!pi || !pj || !quiet)) ||
+        (h && (!hit_rows || !yv_f || !yv_r || !ok || !e1 || !e2 || !fresh1 || !fresh2)))
+        return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: bad argument");
+    int64_t t = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        const int x = pi[k], y = pj[k];
+        if (x < 0 || x >= fb->n_images || y < 0 || y >= fb->n_images)
+            return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: image index out of range");
+        if (t < h && hit_rows[t] == k) {
+            if (quiet[k]) return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: a quiet pair among the hits");
+            e1[t] = fb->value[(size_t)x];
+            e2[t] = fb->value[(size_t)y];
+            fresh1[t] = !fb->touched[(size_t)x];
+            fresh2[t] = !fb->touched[(size_t)y];
+            // image 1, then image 2 (matcher.py:990-993)
+            if (ok[2 * t]) {
+                if (yaw_record(fb, x, y, yv_f + 4 * t))
+                    return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: cannot convert float infinity to integer");
+            } else {
+                fb->value[(size_t)x] = 0.0;
+            }
+            if (ok[2 * t + 1]) {
+                if (yaw_record(fb, y, x, yv_r + 4 * t))
+                    return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: cannot convert float infinity to integer");
+            } else {
+                fb->value[(size_t)y] = 0.0;
+            }
+            ++t;
+        } else if (quiet[k]) {
+            fb->value[(size_t)x] = 0.0;
+            fb->value[(size_t)y] = 0.0;
+        } else {
+            return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: a pair with matches is missing from hit_rows");
+        }
+        fb->touched[(size_t)x] = 1;
+        fb->touched[(size_t)y] = 1;
+    }
+    if (t != h) return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_feed: hit_rows not ascending rows of the round");
+    return IAMX_OK;
+}
+
+extern "C" int iamx_yaw_feedback_state(void *h, double *value, uint8_t *touched)
+{
+    YawFeedback *fb = static_cast<YawFeedback *>(h);
+    if (!fb || !value || !touched) return iamx::fail(IAMX_EINVAL, "iamx_yaw_feedback_state: bad argument");
+    std::copy(fb->value.begin(), fb->value.end(), value);
+    std::copy(fb->touched.begin(), fb->touched.end(), touched);
+    return IAMX_OK;
+}

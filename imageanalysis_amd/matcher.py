@@ -1622,6 +1622,9 @@ def _z_buffer(total):
     return torch.empty(max(int(total * 1.25), 1 << 16), dtype=torch.float64, pin_memory=True)
 
 
+_surface_up = None       # kernels.UploadArena of the surface stage's tables (its own stream)
+
+
 def _surface_device(image_list, jobs, waiter=None):
     """The device half of the surface stage: jobs = [dict(pi, pj [h] image indices, proj
     [h, 2, 12], m_off [h + 1], pairs = host int32 [T, 2], src = _RoundResult.src or None)] ->
@@ -1630,25 +1633,36 @@ def _surface_device(image_list, jobs, waiter=None):
     page-locked buffer the device packed them into, the device buffer of the round's gather --
     and uploaded only when they are in neither; heights land in page-locked memory directly.
     waiter(event): what the host does until the event has happened (default: wait)."""
+    global _surface_up
     import torch
     from . import kernels
     from .kernels import _ptr, check, lib
     dm = the_matcher
     dev = kernels.require_gpu()
+    # image index -> slot of the keypoint arena, once per image of the round
+    slot_of = {}
     slots = []
     for job in jobs:
-        sl = np.empty((len(job['pi']), 2), np.int32)
-        for c, col in enumerate((job['pi'], job['pj'])):
-            for t, x in enumerate(col.tolist()):
-                sl[t, c] = dm.slot_known(image_list[x])
-        slots.append(sl)
+        both = np.stack([job['pi'], job['pj']], 1)
+        for x in np.unique(both).tolist():
+            if x not in slot_of:
+                slot_of[x] = dm.slot_known(image_list[x])
+        table = np.zeros(int(both.max()) + 1 if both.size else 1, np.int32)
+        for x, s_ in slot_of.items():
+            if x < len(table):
+                table[x] = s_
+        slots.append(table[both].astype(np.int32))
     kp_off, xy, _k2 = dm.keypoints()
     IK = np.ascontiguousarray(np.linalg.inv(np.asarray(_deps.camera().get_K(), float)).ravel())
     st = _surface_stream()
     outs, keep = [], []
     with torch.cuda.stream(st):
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True)
+        if _surface_up is None:
+            _surface_up = kernels.UploadArena(nbytes=16 << 20, slots=3)
+        _surface_up.begin()
+        up = _surface_up.put
         d_ik = up(IK)
+        launches = []
         for job, sl in zip(jobs, slots):
             total = int(job['m_off'][-1])
             src = job.get('src')
@@ -1656,15 +1670,18 @@ def _surface_device(image_list, jobs, waiter=None):
                 d_pairs, z = src['pairs'], src['z']
                 own_z = False
             else:
-                d_pairs = src['pairs'] if src is not None else up(job['pairs'])
+                d_pairs = src['pairs'] if src is not None else \
+                    torch.from_numpy(np.ascontiguousarray(job['pairs'])).to(dev, non_blocking=True)
                 z, own_z = _z_buffer(total), True
-            tabs = (up(sl), up(job['proj']), up(job['m_off']))
+            launches.append(((up(sl), up(job['proj']), up(job['m_off'])), d_pairs, z, len(sl), total))
+            outs.append((z, total, own_z))
+        _surface_up.commit()
+        for tabs, d_pairs, z, h, total in launches:
             keep.append((tabs, d_pairs))
             check(lib().iamx_triangulate_packed(_ptr(tabs[0]), _ptr(tabs[1]), _ptr(d_ik), _ptr(kp_off),
-                                                _ptr(xy), _ptr(tabs[2]), _ptr(d_pairs), len(sl), total,
+                                                _ptr(xy), _ptr(tabs[2]), _ptr(d_pairs), h, total,
                                                 _ptr(z), ctypes.c_void_p(st.cuda_stream)),
                   'iamx_triangulate_packed')
-            outs.append((z, total, own_z))
         ev = torch.cuda.Event()
         ev.record(st)
     if waiter is not None:

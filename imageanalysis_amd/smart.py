@@ -111,7 +111,10 @@ def triangulate_features(i1, i2):
 # depends on the similarity fits (pose independent), so the whole chain is a prefix computation
 # over the schedule: PoseFeedback replays it in schedule order from the rounds' yaw values and
 # hands every pair with matches the two projection matrices the reference would have used.
-def pose_matrices(yaw_deg, pitch_deg, roll_deg, ned, body2cam_q, body2cam_m):
+NATIVE_FEEDBACK = True      # False: PoseFeedback replays in python (tests compare the two)
+
+
+def pose_matrices(yaw_deg, pitch_deg, roll_deg, ned, body2cam_q, body2cam_m, half_trig=None):
     """[n, 12] row-major [R | t] of cameras whose AIRCRAFT attitude is (yaw, pitch, roll) degrees
     ('rzyx') and whose mount offset is the quaternion body2cam_q: the camera pose
     Image.set_aircraft_yaw_error_estimate() stores (lib/image.py:441-457: ned2cam = ned2body *
@@ -122,10 +125,13 @@ def pose_matrices(yaw_deg, pitch_deg, roll_deg, ned, body2cam_q, body2cam_m):
     import math
     d2r = math.pi / 180.0
     n = len(yaw_deg)
-    trig = lambda a: (np.array([math.cos(v) for v in a]), np.array([math.sin(v) for v in a]))
+    trig = lambda a: (np.array(list(map(math.cos, a))), np.array(list(map(math.sin, a))))
     # quaternion_from_euler(yaw, pitch, roll, 'rzyx'): frame 1 swaps the first and last angle
-    ci, si = trig((np.asarray(roll_deg, float) * d2r / 2.0).tolist())
-    cj, sj = trig((np.asarray(pitch_deg, float) * d2r / 2.0).tolist())
+    if half_trig is not None:      # (cos, sin of roll / 2 and pitch / 2 per pose, formed once per image)
+        ci, si, cj, sj = half_trig
+    else:
+        ci, si = trig((np.asarray(roll_deg, float) * d2r / 2.0).tolist())
+        cj, sj = trig((np.asarray(pitch_deg, float) * d2r / 2.0).tolist())
     ck, sk = trig((np.asarray(yaw_deg, float) * d2r / 2.0).tolist())
     cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
     w1, x1, y1, z1 = cj * cc + sj * ss, cj * sc - sj * cs, cj * ss + sj * cc, cj * cs - sj * sc
@@ -163,7 +169,7 @@ class PoseFeedback(object):
     image's stored camera pose stands.  feed() takes one round (all ranks' pairs, schedule order)
     and returns, for its pairs with matches, the estimate of both images BEFORE the pair."""
 
-    def __init__(self, image_list):
+    def __init__(self, image_list, native=None):
         self.image_list = image_list
         n = len(image_list)
         self.touched = np.zeros(n, bool)
@@ -171,6 +177,53 @@ class PoseFeedback(object):
         self._entries = {}                   # image index -> [sorted partner names, {name: (err, w, dist)}]
         self._base = None
         self._base_of = {}
+        native = NATIVE_FEEDBACK if native is None else native
+        self._native = self._native_state(image_list) if native and n else None
+
+    def __del__(self):
+        h, self._native = getattr(self, '_native', None), None
+        free = getattr(self, '_free', None)
+        if h is not None and free is not None:
+            free(h)
+
+    def _native_state(self, image_list):
+        """the replay in libiamx (iamx_yaw_feedback_*: host C++, ~0.1 us per pair instead of ~10 us
+        of python per pair with matches), seeded with the entries the tree already holds; None when
+        an entry names a partner outside the project (the python replay below handles any name)"""
+        import ctypes
+        from . import _lib
+        names = [im.name for im in image_list]
+        index_of = {n_: k for k, n_ in enumerate(names)}
+        if len(index_of) != len(names):
+            return None
+        order = sorted(range(len(names)), key=names.__getitem__)
+        rank = np.empty(len(names), np.int32)
+        rank[order] = np.arange(len(names), dtype=np.int32)
+        seeds = []
+        for x, name in enumerate(names):
+            inode = smart_node.getChild(name, False) if smart_node.hasChild(name) else None
+            if inode is None or not inode.hasChild("yaw_pairs"):
+                continue
+            acc = _yaw_pairs_of(name, inode.getChild("yaw_pairs", True))
+            if not acc:
+                continue
+            if any(k not in index_of for k in acc):
+                return None
+            seeds.append((x, np.array([index_of[k] for k in acc], np.int32),
+                          np.array([v[0] for v in acc.values()], np.float64),
+                          np.array([v[1] for v in acc.values()], np.float64),
+                          np.array([v[2] for v in acc.values()], np.float64)))
+        L = _lib.lib()
+        _p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        h = L.iamx_yaw_feedback_new(len(names), _p(rank))
+        if not h:
+            raise MemoryError("iamx_yaw_feedback_new")
+        h = ctypes.c_void_p(h)
+        self._free = L.iamx_yaw_feedback_free         # (kept: modules may be gone when __del__ runs)
+        for x, partner, err, w, dist in seeds:
+            _lib.check(L.iamx_yaw_feedback_seed(h, x, len(partner), _p(partner), _p(err), _p(w), _p(dist)),
+                       'iamx_yaw_feedback_seed')
+        return h
 
     # -- the running average of one image, lib/smart.py:265-283 ------------------------------
     def _state(self, x):
@@ -205,13 +258,15 @@ class PoseFeedback(object):
         pair is reached, and whether that image is still untouched (stored pose)."""
         import bisect
         h = len(hit_rows)
+        if self._native is not None:
+            return self._feed_native(pi, pj, quiet, hit_rows, yv_f, yv_r, ok)
         e1, e2 = [0] * h, [0] * h
         f1, f2 = np.zeros(h, bool), np.zeros(h, bool)
         names = None
         if h:
-            names = [im.name for im in self.image_list] if self._base is None else self._base[0]
-            if self._base is None:
-                self._base = (names,)
+            if self._base is None or self._base[0] is None:
+                self._base = ([im.name for im in self.image_list],) + tuple(self._base[1:] if self._base else ())
+            names = self._base[0]
             hi, hj = pi[hit_rows], pj[hit_rows]
             is_hit_img = np.zeros(len(self.image_list), bool)
             is_hit_img[hi] = True
@@ -264,14 +319,47 @@ class PoseFeedback(object):
             self.touched[seen] = True
         return e1, e2, f1, f2
 
+    def _feed_native(self, pi, pj, quiet, hit_rows, yv_f, yv_r, ok):
+        import ctypes
+        from . import _lib
+        h = len(hit_rows)
+        c = lambda a, dt: np.ascontiguousarray(a, dt)
+        _p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        pi_, pj_, q_ = c(pi, np.int32), c(pj, np.int32), c(quiet, np.uint8)
+        hr, f_, r_, ok_ = c(hit_rows, np.int64), c(yv_f, np.float64), c(yv_r, np.float64), c(ok, np.uint8)
+        e1, e2 = np.zeros(h), np.zeros(h)
+        f1, f2 = np.zeros(h, np.uint8), np.zeros(h, np.uint8)
+        rc = _lib.lib().iamx_yaw_feedback_feed(self._native, len(pi_), _p(pi_), _p(pj_), _p(q_), h, _p(hr),
+                                               _p(f_), _p(r_), _p(ok_), _p(e1), _p(e2), _p(f1), _p(f2))
+        if rc and b'infinity' in (_lib.lib().iamx_last_error() or b''):
+            raise OverflowError("cannot convert float infinity to integer")     # python's int(inf)
+        _lib.check(rc, 'iamx_yaw_feedback_feed')
+        return e1.tolist(), e2.tolist(), f1.astype(bool), f2.astype(bool)
+
+    def _sync_native(self):
+        if self._native is not None:
+            import ctypes
+            from . import _lib
+            n = len(self.image_list)
+            value, touched = np.zeros(n), np.zeros(n, np.uint8)
+            _lib.check(_lib.lib().iamx_yaw_feedback_state(self._native, value.ctypes.data_as(ctypes.c_void_p),
+                                                          touched.ctypes.data_as(ctypes.c_void_p)),
+                       'iamx_yaw_feedback_state')
+            self.value, self.touched = value.tolist(), touched.astype(bool)
+
     def _pose_base(self, x):
-        """(aircraft yaw, pitch, roll, camera ned): what set_aircraft_yaw_error_estimate() and
-        get_proj() read; none of them changes inside one find_matches call"""
+        """(aircraft yaw, cos / sin of roll / 2 and pitch / 2, camera ned): what
+        set_aircraft_yaw_error_estimate() and get_proj() read; none of them changes inside one
+        find_matches call"""
+        import math
         hit = self._base_of.get(x)
         if hit is None:
             im = self.image_list[x]
             _lla, ypr, _q = im.get_aircraft_pose()
-            hit = self._base_of[x] = (ypr[0], ypr[1], ypr[2], tuple(im.get_camera_pose()[0]))
+            d2r = math.pi / 180.0
+            hr, hp = ypr[2] * d2r / 2.0, ypr[1] * d2r / 2.0
+            hit = self._base_of[x] = (ypr[0], math.cos(hr), math.sin(hr), math.cos(hp), math.sin(hp),
+                                      tuple(im.get_camera_pose()[0]))
         return hit
 
     def projections(self, images, estimates):
@@ -280,15 +368,20 @@ class PoseFeedback(object):
         il = self.image_list
         base = [self._pose_base(x) for x in images]
         yaw = [b[0] + e for b, e in zip(base, estimates)]
-        first = il[images[0]]
-        body2cam_m = first.get_body2cam() if hasattr(first, 'get_body2cam') else np.linalg.inv(CAM2BODY)
-        return pose_matrices(yaw, [b[1] for b in base], [b[2] for b in base],
-                             np.array([b[3] for b in base], float).reshape(-1, 3), cam.get_body2cam(),
-                             np.asarray(body2cam_m, float))
+        if self._base is None or len(self._base) < 3:
+            first = il[images[0]]
+            body2cam_m = first.get_body2cam() if hasattr(first, 'get_body2cam') else np.linalg.inv(CAM2BODY)
+            self._base = (self._base[0] if self._base else None, np.asarray(cam.get_body2cam(), float),
+                          np.asarray(body2cam_m, float))
+        cols = np.array([b[1:5] for b in base], np.float64).reshape(-1, 4)
+        return pose_matrices(yaw, None, None, np.array([b[5] for b in base], float).reshape(-1, 3),
+                             self._base[1], self._base[2],
+                             half_trig=(cols[:, 0], cols[:, 1], cols[:, 2], cols[:, 3]))
 
     def settle(self):
         """the call is over: every touched image gets its last estimate, the way the reference's
         last set_aircraft_yaw_error_estimate() of that image left it"""
+        self._sync_native()
         for x in np.nonzero(self.touched)[0].tolist():
             self.image_list[x].set_aircraft_yaw_error_estimate(self.value[x])
 

@@ -399,6 +399,26 @@ int iamx_touch_pages(const void *p, int64_t bytes, int threads);
 int iamx_segment_mean_std(const double *z, const int64_t *starts, const int64_t *counts,
                           int64_t n_seg, int64_t n_z, double *mean, double *std, int threads);
 
+/* iamx_yaw_feedback_* -- the yaw-error FEEDBACK of the reference's pair loop as a prefix
+ * computation over the schedule (HOST code).  scripts/lib/matcher.py:987-993 sets both images'
+ * aircraft yaw-error estimate after every pair (lib/smart.py:251-283 update_yaw_error_estimate:
+ * 0 without matches / without a similarity fit, else the weighted average over the image's
+ * yaw_pairs entries -- values rounded through "%.1f", weights truncated like getInt, children in
+ * sorted-name order, entries closer than 0.5 m or more than 30 degrees off skipped), and
+ * lib/image.py:434-457 turns it into the camera pose the image's NEXT pair triangulates with.
+ * _new: name_rank [n_images] rank of every image's name in sorted order; _seed: entries an image's
+ * yaw_pairs node holds before the call; _feed: one round in schedule order (see the definition);
+ * _state: every image's current estimate and whether a pair of the call has touched it. */
+void *iamx_yaw_feedback_new(int n_images, const int32_t *name_rank);
+void iamx_yaw_feedback_free(void *h);
+int iamx_yaw_feedback_seed(void *h, int image, int n, const int32_t *partner_image, const double *err,
+                           const double *weight, const double *dist);
+int iamx_yaw_feedback_feed(void *h, int64_t n, const int32_t *pi, const int32_t *pj,
+                           const uint8_t *quiet, int64_t n_hits, const int64_t *hit_rows,
+                           const double *yv_f, const double *yv_r, const uint8_t *ok, double *e1,
+                           double *e2, uint8_t *fresh1, uint8_t *fresh2);
+int iamx_yaw_feedback_state(void *h, double *value, uint8_t *touched);
+
 /* iamx_group_level -- one group level of scripts/lib/groups.py:59-118 compute() (HOST arrays):
  * seed chain + sweeps until nothing can be added.  level [n_matches] in/out (-1 = unused),
  * placed_images [n_images] 0/1 from earlier levels, placed_matches [n_images] out.  Returns the

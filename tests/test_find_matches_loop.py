@@ -178,7 +178,12 @@ def _restore():
 
 
 @pytest.mark.parametrize('sort', [True, False])
-def test_pair_loop_equals_reference_loop_host_logic(tmp_path, _restore, sort):
+@pytest.mark.parametrize('native', [True, False])
+def test_pair_loop_equals_reference_loop_host_logic(tmp_path, _restore, sort, native, monkeypatch):
+    """native: the pose feedback replayed by libiamx's host routine (iamx_yaw_feedback_*) or by
+    the python form that stands in for it when the tree names partners outside the project"""
+    from imageanalysis_amd import smart
+    monkeypatch.setattr(smart, 'NATIVE_FEEDBACK', native)
     _run_cpu(0, 1, 0, str(tmp_path), sort)
 
 

@@ -14,7 +14,7 @@ matcher.detector_node.setString('detector', 'SIFT'); matcher.detector_node.setFl
 matcher.matcher_node.setFloat('match_ratio', 0.75); matcher.matcher_node.setInt('min_pairs', 25)
 matcher.matcher_node.setString('schedule', 'all-pairs')
 W, H, F = 5472, 3648, 3666.6665
-camera.set_K(F, F, W / 2.0, H / 2.0); camera.set_dist_coeffs([0.0] * 5); camera.set_image_params(W, H)
+camera.set_K(F, F, W / 2.0, H / 2.0); camera.set_dist_coeffs([0.0] * 5); camera.set_image_params(W, H); camera.set_mount_params(0.0, -90.0, 0.0)
 base = synth.make_survey_image(seed=1).cpu().numpy()
 for k in range(n):
     # shifted crops of one big texture so that neighbours overlap
@@ -27,7 +27,7 @@ class Proj(object):
 proj = Proj(); proj.image_list = []
 for k in range(n):
     im = iimg.Image(an, 'B%02d' % k)
-    im.set_camera_pose([0.0, 8.0 * k, -100.0], 0.0, -90.0, 0.0)
+    im.set_pose_from_camera([0.0, 8.0 * k, -100.0], 0.0, -90.0, 0.0)
     im.set_aircraft_pose(45.0, -93.0, 400.0, 0.0, 0.0, 0.0)
     getNode('/smart', True).getChild(im.name, True).setFloat('tri_surface_m', 0.0)
     proj.image_list.append(im)

@@ -60,6 +60,7 @@ def main():
     camera.set_K(F, F, W / 2.0, H / 2.0)
     camera.set_dist_coeffs([0.0] * 5)
     camera.set_image_params(W, H)
+    camera.set_mount_params(0.0, -90.0, 0.0)
 
     # ground points: enough that an image sees ~0.8 * kpts of them
     half_w, half_h = 0.5 * W / F * AGL, 0.5 * H / F * AGL
@@ -91,7 +92,7 @@ def main():
             ned = np.array([r * SPACING, k * SPACING, -AGL]) + rng.normal(0, 0.3, 3)
             yaw = (0.0 if r % 2 == 0 else 180.0) + rng.normal(0, 1.0)
             im = iimg.Image(an, names[len(proj.image_list)])
-            im.set_camera_pose(ned.tolist(), yaw, -90.0 + rng.normal(0, 0.5), rng.normal(0, 0.5))
+            im.set_pose_from_camera(ned.tolist(), yaw, -90.0 + rng.normal(0, 0.5), rng.normal(0, 0.5))
             # nadir projection with the yaw only (keypoints need to be consistent, not exact)
             cy, sy = np.cos(np.radians(yaw)), np.sin(np.radians(yaw))
             dn, de, dz = gnd[:, 0] - ned[0], gnd[:, 1] - ned[1], gnd[:, 2] - ned[2]
