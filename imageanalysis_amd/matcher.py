@@ -1512,7 +1512,7 @@ def find_matches(proj, K, strategy="smart", transform="homography", sort=False, 
         finally:
             if isinstance(the_matcher, DeviceMatcher):
                 the_matcher._pose_epoch = None
-            if hasattr(_deps.smart(), 'freeze_poses'):
+            if _deps.smart() is not None:
                 _deps.smart().freeze_poses(False)
 
 
@@ -1526,6 +1526,12 @@ def _find_matches(proj, K, strategy, transform, sort, review):
     if isinstance(the_matcher, DeviceMatcher):
         the_matcher._pose_epoch = object()
     _route_reset()
+    smart = _deps.smart()
+    if smart is not None:
+        # (camera positions and aircraft yaw angles do not change inside one call -- what the
+        #  feedback changes is the camera ATTITUDE --, and reading one back from the property
+        #  tree costs more than a pair's share of the kernels: smart.frozen_ned)
+        smart.freeze_poses(True)
     run = _MatchRun(proj, sort)
     run.schedule()
     run.prepare()

@@ -579,8 +579,10 @@ _frozen_ned = None
 
 
 def freeze_poses(on):
-    """find_matches brackets its pair loop with this: poses do not change inside one call, and
-    reading one back from the property tree costs more than a pair's share of the kernels"""
+    """find_matches brackets its pair loop with this: camera POSITIONS and aircraft yaw angles do
+    not change inside one call (the yaw-error feedback rewrites the camera attitude only,
+    lib/image.py:434-457), and reading one back from the property tree costs more than a pair's
+    share of the kernels"""
     global _frozen, _frozen_ned, _deferred
     _frozen = {} if on else None
     _frozen_ned = None
