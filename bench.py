@@ -382,6 +382,9 @@ def main():
                     help='BASELINE configs[4] at scale: N rendered 5472 x 3648 frames (N >= 512 asked '
                          'for) through the whole chain on one GPU, neighbour + distance-window '
                          'schedule; rendering and writing N JPEGs takes ~0.1 s per frame, untimed')
+    ap.add_argument('--e2e-window', type=int, default=0, metavar='F',
+                    help='with --e2e-full: render, detect and delete the JPEGs F frames at a time '
+                         '(a survey whose JPEGs do not fit the scratch disk: 10 000 x 20 MP = 80 GB)')
     ap.add_argument('--e2e', type=int, default=0, metavar='N',
                     help='also run the whole chain (detect -> match -> link -> triangulate -> BA, '
                          'BASELINE configs[4] shape) on N rendered images through the drop-in entry '
@@ -498,7 +501,8 @@ def main():
             # of a real survey; `--e2e-full N` runs the same at N >= 512
             e2e = e2e_bench(E2E_FRAMES, full_frame=True, schedule='distance')
         if args.e2e_full > 0:
-            e2e_big = e2e_bench(args.e2e_full, full_frame=True, schedule='distance')
+            e2e_big = e2e_bench(args.e2e_full, full_frame=True, schedule='distance',
+                                window=args.e2e_window)
         if args.e2e > 0:
             e2e_small = e2e_bench(args.e2e)
     # CPU baselines of the BA and SIFT sections run AFTER every timed GPU section: their OpenMP /
@@ -738,7 +742,7 @@ def dense_overlap_bench(dev, oracle_pairs=4, n_img=12, rows=16384):
             "verified_pairs": checked, "against": "oracle/cpu_ref.c"}
 
 
-def e2e_bench(n_images, full_frame=False, schedule=None):
+def e2e_bench(n_images, full_frame=False, schedule=None, window=0):
     """BASELINE configs[4] shape on one GPU: a rendered survey of n_images JPEGs on disk goes
     through the drop-in entry points exactly as scripts/process.py:236-407 drives the reference's
     modules -- Image.detect_features, matcher.find_matches, match_cleanup.*, groups.compute,
@@ -749,7 +753,11 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
     and scale 1.0.  schedule: 'all-pairs' (default with full_frame: the slice of a few dozen
     frames), 'distance' (neighbours in the list + every pair inside the reference's distance
     window, scripts/lib/matcher.py:886-903: the shape of a survey of hundreds / thousands of
-    frames) or 'neighbours' (the reference at HEAD)."""
+    frames) or 'neighbours' (the reference at HEAD).
+    window > 0: the survey does not fit the scratch disk as JPEGs (10 000 frames of 20 MP are
+    80 GB): it is rendered `window` frames at a time, every window goes through detect_features
+    (timed: the detect stage is the sum over the windows) and its JPEGs are deleted; the cache
+    files, which are what the later stages read, stay."""
     import contextlib
     import io
     import shutil
@@ -762,15 +770,7 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
     tmp = tempfile.mkdtemp(prefix='iamx_e2e_')
     out = {"images": rows * cols, "grid": [rows, cols]}
     try:
-        t0 = time.perf_counter()
-        if full_frame:
-            names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols, device='cuda',
-                                                                 **synth.FULL_FRAME)
-        else:
-            names, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols)
         scale = 0.4 if full_frame else 1.0
-        out["render_seconds_untimed"] = round(time.perf_counter() - t0, 2)
-        W, H = int(2 * K[0, 2]), int(2 * K[1, 2])
         an = os.path.join(tmp, 'ImageAnalysis')
         os.makedirs(os.path.join(an, 'cache'))
         os.makedirs(os.path.join(an, 'meta'))
@@ -791,13 +791,12 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         des_u8_was = iimg.DES_LIST_U8
         iimg.DES_LIST_U8 = n_images >= 1024
         out["des_list_dtype"] = 'uint8' if iimg.DES_LIST_U8 else 'float32'
-        node = getNode('/config/camera', True)
-        node.__dict__.pop('K_opt', None)
-        node.__dict__.pop('dist_coeffs_opt', None)
-        camera.set_K(K[0, 0], K[1, 1], K[0, 2], K[1, 2])
-        camera.set_dist_coeffs([0.0] * 5)
-        camera.set_image_params(W, H)
-        camera.set_mount_params(0.0, -90.0, 0.0)
+        sidecar_was = iimg.USE_DESC_SIDECAR
+        if window:
+            # (the raw uint8 sidecar of the .desc files is another 4.7 MB per frame: off where
+            #  the scratch disk is the limit; the reference's two cache files are written as always)
+            iimg.USE_DESC_SIDECAR = False
+            out["window_frames"] = int(window)
 
         class Proj(object):
             analysis_dir = an
@@ -813,16 +812,8 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
 
         proj = Proj()
         proj.image_list = []
-        for name, (ned, ypr) in zip(names, logged):
-            im = iimg.Image(an, name)
-            # (camera pose + the aircraft attitude that leads to it under the nadir mount:
-            #  find_matches re-derives the camera pose whenever it updates an image's yaw error)
-            im.set_pose_from_camera(ned.tolist(), *ypr.tolist())
-            getNode('/smart', True).getChild(name, True).setFloat('tri_surface_m', 0.0)
-            proj.image_list.append(im)
         quiet = contextlib.redirect_stdout(io.StringIO())
         stages = {}
-
         profile_stages = os.environ.get('IAMX_E2E_PROFILE', '').split(',')
 
         def timed(key, fn):
@@ -839,18 +830,62 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
                 with quiet:
                     r = fn()
             torch.cuda.synchronize()
-            stages[key] = round(time.perf_counter() - t, 3)
+            stages[key] = round(stages.get(key, 0.0) + time.perf_counter() - t, 3)
             return r
 
-        matcher.configure()
+        configured = []
+        names = []
 
-        def detect():
-            pf = iimg.prefetch(proj.image_list, scale=scale)
-            for im in proj.image_list:
+        def on_frames(names_, truth_, logged_, K_, first, stop):
+            """the frames [first, stop) are on disk: their Image objects, and in window mode their
+            detection right away (then the JPEGs go)"""
+            if not configured:
+                W_, H_ = int(2 * K_[0, 2]), int(2 * K_[1, 2])
+                node = getNode('/config/camera', True)
+                node.__dict__.pop('K_opt', None)
+                node.__dict__.pop('dist_coeffs_opt', None)
+                camera.set_K(K_[0, 0], K_[1, 1], K_[0, 2], K_[1, 2])
+                camera.set_dist_coeffs([0.0] * 5)
+                camera.set_image_params(W_, H_)
+                camera.set_mount_params(0.0, -90.0, 0.0)
+                matcher.configure()
+                configured.append(True)
+            fresh = []
+            for k in range(first, stop):
+                names.append(names_[k])
+                ned, ypr = logged_[k]
+                im = iimg.Image(an, names_[k])
+                # (camera pose + the aircraft attitude that leads to it under the nadir mount:
+                #  find_matches re-derives the camera pose whenever it updates an image's yaw error)
+                im.set_pose_from_camera(ned.tolist(), *ypr.tolist())
+                getNode('/smart', True).getChild(names_[k], True).setFloat('tri_surface_m', 0.0)
+                proj.image_list.append(im)
+                fresh.append(im)
+            if window:
+                timed("detect", lambda: detect(fresh))
+                for im in fresh:
+                    with contextlib.suppress(OSError):
+                        os.remove(im.image_file)
+
+        def detect(images):
+            pf = iimg.prefetch(images, scale=scale)
+            for im in images:
                 im.detect_features(scale)
             pf.close()
             iimg.cacheio.wait()
-        timed("detect", detect)
+
+        t0 = time.perf_counter()
+        if full_frame:
+            _n, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols, device='cuda',
+                                                              chunk=window or rows * cols,
+                                                              on_frames=on_frames, **synth.FULL_FRAME)
+        else:
+            _n, truth, logged, K = synth.make_rendered_survey(tmp, rows, cols, chunk=window or rows * cols,
+                                                              on_frames=on_frames)
+        out["render_seconds_untimed"] = round(time.perf_counter() - t0 - stages.get("detect", 0.0), 2)
+        W, H = int(2 * K[0, 2]), int(2 * K[1, 2])
+        if not window:
+            timed("detect", lambda: detect(proj.image_list))
         out["keypoints_per_image"] = int(np.mean([len(im.kp_list) for im in proj.image_list]))
         timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
                                                     transform='homography', sort=True))
@@ -918,6 +953,7 @@ def e2e_bench(n_images, full_frame=False, schedule=None):
         matcher.matcher_node.__dict__.pop('schedule', None)
         try:
             iimg.DES_LIST_U8 = des_u8_was
+            iimg.USE_DESC_SIDECAR = sidecar_was
         except NameError:
             pass
         shutil.rmtree(tmp, ignore_errors=True)

@@ -268,10 +268,14 @@ FULL_FRAME = dict(w=W_PX, h=H_PX, focal=FX, gsd=0.03)       # the FC6310S frame 
 
 
 def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, alt=100.0,
-                         spacing=(45.0, 40.0), gsd=0.11, seed=2024, device=None):
+                         spacing=(45.0, 40.0), gsd=0.11, seed=2024, device=None, chunk=0,
+                         on_frames=None):
     """Writes <project_dir>/images/Pnnn.JPG and returns (names, truth [(ned, ypr)], logged
     [(ned, ypr)], K).  Default camera = the FC6310S field of view at a quarter of its pixels;
-    **FULL_FRAME = the 5472x3648 frame itself (pass `device`: texture and ray casting on the GPU)."""
+    **FULL_FRAME = the 5472x3648 frame itself (pass `device`: texture and ray casting on the GPU).
+    chunk / on_frames: after every `chunk` frames (all of them on disk) on_frames(names, truth,
+    logged, K, first, stop) is called -- a survey larger than the scratch disk is rendered,
+    consumed and deleted a window at a time (10 000 frames of 20 MP are 80 GB of JPEG)."""
     from PIL import Image as PILImage
     from . import match_cleanup
     rng = np.random.default_rng(seed)
@@ -290,6 +294,7 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
     IK = np.linalg.inv(K)
     d2r = np.pi / 180.0
     names, truth, logged = [], [], []
+    handed = 0
     # (the JPEG encoder releases the interpreter: frames are encoded on a few threads while the
     #  next ones are rendered -- 2048 frames of 20 MP take a minute instead of four)
     from concurrent.futures import ThreadPoolExecutor
@@ -305,7 +310,7 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
                             25.0 + spacing[1] * k + rng.normal(0, 0.5), -alt + rng.normal(0, 0.5)])
             ypr = np.array([(0.0 if row % 2 == 0 else 180.0) + rng.normal(0, 2.0),
                             -90.0 + rng.normal(0, 1.5), rng.normal(0, 1.5)])
-            name = 'P%03d' % len(names)
+            name = ('P%03d' if rows * cols <= 9999 else 'P%05d') % len(names)
             q = tf.quaternion_from_euler(ypr[0] * d2r, ypr[1] * d2r, ypr[2] * d2r, 'rzyx')
             M = tf.quaternion_matrix(q)[:3, :3].dot(match_cleanup.CAM2BODY).dot(IK)
             if big:
@@ -321,7 +326,15 @@ def make_rendered_survey(project_dir, rows, cols, w=1368, h=912, focal=916.7, al
             names.append(name)
             truth.append((ned, ypr))
             logged.append((ned + rng.normal(0, 0.8, 3), ypr + rng.normal(0, 0.7, 3)))
+            if on_frames is not None and chunk > 0 and len(names) - handed >= chunk:
+                for f in saves:
+                    f.result()
+                saves = []
+                on_frames(names, truth, logged, K, handed, len(names))
+                handed = len(names)
     for f in saves:
         f.result()
     pool.shutdown()
+    if on_frames is not None and len(names) > handed:
+        on_frames(names, truth, logged, K, handed, len(names))
     return names, truth, logged, K
