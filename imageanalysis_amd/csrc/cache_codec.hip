@@ -566,12 +566,14 @@ int64_t record_member(const uint8_t *src, size_t len, int D, uint8_t *out, size_
 
 }  // namespace
 
-// upper bound of iamx_gzip_records' output: a Huffman code spends less than 9 bits on a byte of
-// its own histogram, a member carries a 150-byte code table and 18 bytes of gzip wrapper
+// upper bound of iamx_gzip_records' output: the bound the member encoder itself works to -- its
+// code lengths are depth-limited by rescaling the histogram, so "less than 9 bits per byte" of an
+// optimal Huffman code is not guaranteed; 15 bits per literal is (2 bytes per input byte), plus
+// the code table and the gzip wrapper of every member
 extern "C" int64_t iamx_gzip_records_bound(int64_t total, int64_t n_members)
 {
     if (total < 0 || n_members < 0) return 0;
-    return total + (total >> 3) + 256 * (n_members + 1);
+    return 2 * total + 1024 * (n_members + 1);
 }
 
 // gzip members of the buffers bufs[0..n_bufs) (as iamx_gzip_members: each member at most

@@ -989,8 +989,10 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         s_base = ntask ? atomicAdd(A.task_total + (small ? 0 : 1), ntask) + (small ? 0 : (int)gridDim.x) : 0;
     }
     __syncthreads();
+    // (a workgroup task carries the granularity it was cut to: the exact kernels check it)
+    const int tag = small ? 0 : (A.wg_shift << 24);
     for (int t = threadIdx.x; t < ntask; t += 256)
-        *reinterpret_cast<v2i *>(A.tasks + 2 * (s_base + t)) = v2i{p, t};
+        *reinterpret_cast<v2i *>(A.tasks + 2 * (s_base + t)) = v2i{p, t | tag};
 }
 
 // ---------------------------------------------------------------------------------
@@ -1244,7 +1246,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * ((int64_t)A.n_pairs + t));
         const int p = __builtin_amdgcn_readfirstlane(task.x);
-        const int tblk = __builtin_amdgcn_readfirstlane(task.y);
+        const int ttag = __builtin_amdgcn_readfirstlane(task.y);
+        if ((ttag >> 24) != 8) {        // cut for the other form of this stage: refuse loudly
+            if (threadIdx.x == 0) atomicAdd(A.zero_div + 1, 1);
+            continue;
+        }
+        const int tblk = ttag & 0xFFFFFF;
         const int64_t cb = A.out_off[p];
         const int cnt = __builtin_amdgcn_readfirstlane(A.cand_cnt[p]);
         const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
@@ -1406,7 +1413,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const v2i task = *reinterpret_cast<const v2i *>(A.tasks + 2 * ((int64_t)A.n_pairs + t));
         const int p = __builtin_amdgcn_readfirstlane(task.x);
-        const int tblk = __builtin_amdgcn_readfirstlane(task.y);
+        const int ttag = __builtin_amdgcn_readfirstlane(task.y);
+        if ((ttag >> 24) != 9) {        // cut for the other form of this stage: refuse loudly
+            if (threadIdx.x == 0) atomicAdd(A.zero_div + 1, 1);
+            continue;
+        }
+        const int tblk = ttag & 0xFFFFFF;
         const int64_t cb = A.out_off[p];
         const int cnt = __builtin_amdgcn_readfirstlane(A.cand_cnt[p]);
         const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
@@ -1713,6 +1725,12 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
 
 // the workgroup form of the exact stage the two entry points below agree on
 // (default: two candidate sets per wave, tasks of 256; IAMX_EXACT_SETS=4: four, tasks of 512)
+// Both entry points read the environment when they are called (tests and A/B tools switch forms
+// inside one process).  What ties them together is the task list itself: symcand_kernel writes
+// the granularity it cut the tasks to into every workgroup task (bits 24.. of the block index),
+// and the exact kernels refuse a task cut for the other form -- they raise the "unresolved rows"
+// flag, which find_matches turns into an exception, instead of mapping tasks to the wrong
+// candidates.
 static bool exact_four_sets()
 {
     const char *e = getenv("IAMX_EXACT_SETS"), *pr = getenv("IAMX_EXACT_PRUNE");

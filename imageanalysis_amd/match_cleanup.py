@@ -78,11 +78,14 @@ def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None
     # no list object or backing array has been replaced
     sig_n, sig_h = 0, 0
     for i1 in proj.image_list:
-        for m in i1.match_list.values():
+        for key, m in i1.match_list.items():
             sig_n += 1
             # (masked every step: an unmasked product is a python integer of millions of bits
-            #  after 10^5 lists, and the loop quadratic -- 6 s per scan on a 4186-frame survey)
-            sig_h = ((sig_h * 1000003) ^ id(m) ^ (id(m._a) if isinstance(m, MatchPairs) else 0)) & 0x3FFFFFFFFFFFFFFF
+            #  after 10^5 lists, and the loop quadratic -- 6 s per scan on a 4186-frame survey;
+            #  the KEY is part of it: a renamed / re-keyed entry that keeps its list object must
+            #  not find the old (key, partner) table)
+            sig_h = ((sig_h * 1000003) ^ id(m) ^ hash(key)
+                     ^ (id(m._a) if isinstance(m, MatchPairs) else 0)) & 0x3FFFFFFFFFFFFFFF
     cached = getattr(proj, '_iamx_scan', None) if wanted is None else None
     if cached is not None and cached[0] == (sig_n, sig_h, len(proj.image_list)):
         entries, rest, arrays, tables = cached[1:]
@@ -275,12 +278,25 @@ def make_match_structure(proj):
     # libiamx (round 4 concatenated them, repeated (i, j) per match and built the offsets
     # 0, 2, 4, ...: three fresh arrays of 8 bytes per match each)
     matches_direct = DirectMatches.from_blocks(ij_arr, counts, blocks)
-    # link_matches() normally receives this very object: the block form goes with it
-    proj._iamx_direct = (matches_direct, n, ij_arr, counts, blocks)
+    # link_matches() normally receives this very object: the block form goes with it.  The blocks
+    # ALIAS the live match lists (no copy of millions of pairs): a fingerprint of every block --
+    # length, first, middle and last row -- goes along, and link_matches() falls back to the
+    # flattened copy when a list was edited in between (an edit that keeps all four is not seen:
+    # the match lists are not to be changed between the two calls, as in process.py:305-317)
+    proj._iamx_direct = (matches_direct, n, ij_arr, counts, blocks, _blocks_fingerprint(blocks))
     if n:
         _log("Total feature pairs in image set:", n)
         _log("Keypoint average instances = %.1f (should be 2.0 here)" % 2.0)
     return matches_direct
+
+
+def _blocks_fingerprint(blocks):
+    fp = np.empty((len(blocks), 7), np.int64)
+    for k, b in enumerate(blocks):
+        m = len(b)
+        fp[k] = (m, b[0, 0], b[0, 1], b[m // 2, 0], b[m // 2, 1], b[m - 1, 0], b[m - 1, 1]) if m else \
+            (0, 0, 0, 0, 0, 0, 0)
+    return fp
 
 
 class DirectMatches(object):
@@ -452,10 +468,10 @@ def link_matches(proj, matches_direct):
     passes = np.zeros(1, np.int32)
     P = lambda a: c_void_p(a.ctypes.data)
     if cached is not None and cached[0] is matches_direct and cached[1] == n \
-            and matches_direct.untouched():
+            and matches_direct.untouched() and np.array_equal(_blocks_fingerprint(cached[4]), cached[5]):
         # untouched output of make_match_structure(): the pair blocks as they lie
         import ctypes
-        ij, counts, blocks = cached[2:]
+        ij, counts, blocks = cached[2:5]
         o_img, o_kp = empty_huge(2 * n, np.int32), empty_huge(2 * n, np.int32)
         o_ptr = np.zeros(n + 1, np.int64)
         ptrs = (ctypes.c_void_p * max(len(blocks), 1))(*[b.ctypes.data for b in blocks])
@@ -467,6 +483,13 @@ def link_matches(proj, matches_direct):
         o_ptr = np.zeros(n + 1, np.int64)
         n_chain = int(lib().iamx_link_matches(P(img), P(kp), P(ptr), n, P(o_img), P(o_kp), P(o_ptr),
                                               P(passes)))
+    # (the consolidation's scan tables pin every backing array they were made from, and the lists
+    #  check_for_pair_dups replaced: the stage ends here)
+    for attr in ('_iamx_scan',):
+        try:
+            delattr(proj, attr)
+        except AttributeError:
+            pass
     if n_chain < 0:
         raise RuntimeError("iamx_link_matches failed (%d): %s"
                            % (n_chain, (lib().iamx_last_error() or b'?').decode()))

@@ -105,15 +105,19 @@ def _workspace_bytes_per_pair(rows):
 
 
 def _batch_bytes():
-    """BATCH_BYTES on the 288 GB part it was chosen for; on a device with less free memory a
-    twelfth of what is free (three workspaces are pooled, and the descriptor / keypoint arenas,
-    result sets and the caller's own tensors need the rest), never below 256 MB"""
+    """BATCH_BYTES, unless device memory is really short: three workspaces are pooled, so the
+    figure shrinks to a quarter of what this process could still obtain -- the device's free
+    memory PLUS the blocks torch's caching allocator holds but does not use (a second
+    find_matches call in the same process, or a large resident arena, must not shrink the
+    batches: the partition of the schedule into rounds would depend on allocator state) --,
+    never below 256 MB"""
     try:
         import torch
         free, _total = torch.cuda.mem_get_info()
+        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
     except Exception:                     # noqa: BLE001  (no device yet: the 288 GB figure)
         return BATCH_BYTES
-    return int(max(256 << 20, min(BATCH_BYTES, free // 12)))
+    return int(max(256 << 20, min(BATCH_BYTES, free // 4)))
 
 
 def _pairs_per_batch(rows):
