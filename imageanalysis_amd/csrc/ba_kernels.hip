@@ -12,6 +12,7 @@
 // With body2cam = [[0,1,0],[0,0,1],[1,0,0]]:  Xc = (y1, y2, y0),  y = M(q)^T (X-ned) / |q|^2,
 // M the homogeneous (unnormalised) rotation matrix of q = (w,x,y,z).
 #include "iamx_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -184,6 +185,136 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
         *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
     } else {
         *reinterpret_cast<double2 *>(r + 2 * o) = r0;
+    }
+}
+
+// The same evaluation as a PERSISTENT, software-pipelined kernel.  ba_residual_lds_kernel is one
+// dependent chain per workgroup -- indices, then the point gather and the camera parameters behind
+// them, then arithmetic, then the store -- and a workgroup lives for exactly one such chain: with
+// ~3.7 generations of workgroups per launch the two memory latencies, not the 64 B per
+// observation, are the time (profiles/r5: 92 MB of HBM traffic in 27 us).  Here every WAVE walks
+// its share of the 128-observation chunks with three of them in flight: while chunk k is being
+// evaluated the point gather + camera parameters of chunk k+1 (whose indices arrived during the
+// previous step) and the indices / observed pixels of chunk k+2 are on their way.  Wave
+// synchronous, no workgroup barrier; camera blocks per wave in LDS, double buffered.
+constexpr int PIPE_MAXCAM = 16;
+
+struct ObsIdx {
+    int2 ci, pi;
+    double4 ob;
+};
+
+__device__ __forceinline__ void pipe_load_idx(const int32_t *__restrict__ cam_idx,
+                                              const int32_t *__restrict__ pt_idx,
+                                              const double *__restrict__ uv, int64_t o,
+                                              int64_t n_obs, ObsIdx &I)
+{
+    I.ci = make_int2(0, 0);
+    I.pi = make_int2(0, 0);
+    I.ob = make_double4(0, 0, 0, 0);
+    if (o + 1 < n_obs) {
+        I.ci = *reinterpret_cast<const int2 *>(cam_idx + o);
+        I.pi = *reinterpret_cast<const int2 *>(pt_idx + o);
+        I.ob = *reinterpret_cast<const double4 *>(uv + 2 * o);
+    } else if (o < n_obs) {
+        I.ci.x = I.ci.y = cam_idx[o];
+        I.pi.x = I.pi.y = pt_idx[o];
+        const double2 t = *reinterpret_cast<const double2 *>(uv + 2 * o);
+        I.ob = make_double4(t.x, t.y, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void ba_residual_pipe_kernel(
+    const double *__restrict__ cams, const double *__restrict__ pts,
+    const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
+    const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
+    double *__restrict__ r)
+{
+    __shared__ double Rs_all[4][2][PIPE_MAXCAM][12];    // per WAVE, double buffered
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_chunks = (n_obs + 127) / 128;
+    // (workgroups are dealt to the XCDs round robin; inside one step of the walk every XCD gets a
+    //  contiguous run of chunks: neighbouring chunks gather neighbouring points, one L2 each)
+    const int64_t wg = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int64_t first = wg * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    double cal[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cal[i] = calib[i];
+    auto obs_of = [&](int64_t c) { return (c * 64 + lane) * 2; };
+    ObsIdx A, B;                        // A: chunk k+2 (indices on their way), B: chunk k+1
+    double X0[3], X1[3], cp[7];         // of chunk k (gathered during the previous step)
+    int c_lo = 0, ncam = 0;
+    ObsIdx C;
+    // what the gather stage does for a chunk whose indices have arrived
+    auto gather = [&](const ObsIdx &I, int64_t o, double (&x0)[3], double (&x1)[3], double (&cpar)[7],
+                      int &lo_out, int &n_out) {
+        const double *q0 = pts + (int64_t)I.pi.x * 3, *q1 = pts + (int64_t)I.pi.y * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { x0[k] = q0[k]; x1[k] = q1[k]; }
+        int lo = o < n_obs ? min(I.ci.x, I.ci.y) : 0x7FFFFFFF, hi = o < n_obs ? max(I.ci.x, I.ci.y) : -1;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo = min(lo, __shfl_xor(lo, m));
+            hi = max(hi, __shfl_xor(hi, m));
+        }
+        lo_out = lo;
+        n_out = hi - lo + 1;
+        if (n_out <= PIPE_MAXCAM && lane < n_out) {
+            const double *cs = cams + (int64_t)(lo + lane) * 7;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cpar[k] = cs[k];
+        }
+    };
+    int64_t c = first;
+    if (c >= n_chunks) return;
+    // prologue: indices of the first two chunks, gather of the first
+    pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c), n_obs, C);
+    if (c + stride < n_chunks) pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c + stride), n_obs, B);
+    gather(C, obs_of(c), X0, X1, cp, c_lo, ncam);
+    int buf = 0;
+    for (; c < n_chunks; c += stride) {
+        const int64_t o = obs_of(c);
+        const bool has1 = c + stride < n_chunks, has2 = c + 2 * stride < n_chunks;
+        // stage 1: indices / observed pixels of chunk k+2
+        if (has2) pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c + 2 * stride), n_obs, A);
+        // stage 2: point gather + camera parameters of chunk k+1 (its indices were requested one
+        // step ago)
+        double nX0[3], nX1[3], ncp[7];
+        int n_lo = 0, n_ncam = 0;
+        if (has1) gather(B, obs_of(c + stride), nX0, nX1, ncp, n_lo, n_ncam);
+        // stage 3: chunk k -- camera blocks into this wave's LDS slice, then the residuals
+        double (*Rs)[12] = Rs_all[wave][buf];
+        const bool in_lds = ncam <= PIPE_MAXCAM;
+        if (in_lds && lane < ncam) cam_block(cp, Rs[lane]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (o < n_obs) {
+            double Rl0[12], Rl1[12];
+            if (!in_lds) {
+                cam_block(cams + (int64_t)C.ci.x * 7, Rl0);
+                cam_block(cams + (int64_t)C.ci.y * 7, Rl1);
+            }
+            const double *R0 = in_lds ? Rs[C.ci.x - c_lo] : Rl0;
+            const double2 r0 = residual_rt(R0, X0, make_double2(C.ob.x, C.ob.y), cal);
+            if (o + 1 < n_obs) {
+                const double *R1 = in_lds ? Rs[C.ci.y - c_lo] : Rl1;
+                const double2 r1 = residual_rt(R1, X1, make_double2(C.ob.z, C.ob.w), cal);
+                *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
+            } else {
+                *reinterpret_cast<double2 *>(r + 2 * o) = r0;
+            }
+        }
+        // rotate
+        C = B;
+        B = A;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { X0[k] = nX0[k]; X1[k] = nX1[k]; }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cp[k] = ncp[k];
+        c_lo = n_lo;
+        ncam = n_ncam;
+        buf ^= 1;
     }
 }
 
@@ -368,8 +499,22 @@ extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const d
                  "uv / r must be 32-byte aligned, cam_idx / pt_idx 8-byte aligned");
     hipStream_t st = iamx::as_stream(stream);
     (void)cam_scratch;           // kept in the signature; the camera blocks now live in LDS
-    hipLaunchKernelGGL(ba_residual_lds_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
-                       st, cams, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
+    // IAMX_BA_RESIDUAL=lds: the one-chain-per-workgroup form (A/B runs, tools/ba_resid_ab.py);
+    // default: the persistent pipelined walk, IAMX_BA_RESIDUAL_WGS workgroups (default 2048: eight
+    // per CU, every wave ~1.9 chunks... of 128 observations at configs[3]) -- never more than the
+    // chunks there are
+    const char *form = getenv("IAMX_BA_RESIDUAL"), *wgs = getenv("IAMX_BA_RESIDUAL_WGS");
+    if (form && form[0] == 'l') {
+        hipLaunchKernelGGL(ba_residual_lds_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
+                           st, cams, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
+    } else {
+        const int64_t need = (n_obs + 511) / 512;
+        int64_t g = wgs ? atoll(wgs) : 1024;
+        if (g < 1) g = 1;
+        if (g > need) g = need;
+        hipLaunchKernelGGL(ba_residual_pipe_kernel, dim3((unsigned)g), dim3(256), 0, st, cams, pts,
+                           cam_idx, pt_idx, uv, n_obs, calib, r);
+    }
     return iamx::check_launch("iamx_ba_residual_prepared");
 }
 
@@ -390,4 +535,26 @@ extern "C" int iamx_ba_residual_jac(const double *cams, int n_cams, const double
                            iamx::as_stream(stream), cams, n_cams, pts, cam_idx, pt_idx, uv, n_obs,
                            calib, r, Jc, Jp, Jk);
     return iamx::check_launch("iamx_ba_residual_jac");
+}
+
+// The yardstick of the HBM-bound kernels above: a plain grid-stride copy, 16 bytes per lane and
+// step (the form MI355X_MICROARCH.md measures at 6.29 TB/s), over whatever working set the caller
+// rotates through.  n16 = number of 16-byte words.
+namespace {
+__global__ __launch_bounds__(256) void copy16_kernel(const double2 *__restrict__ src,
+                                                     double2 *__restrict__ dst, int64_t n16)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+        dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int workgroups, void *stream)
+{
+    IAMX_REQUIRE(src && dst && n16 >= 0 && workgroups > 0, "bad argument");
+    IAMX_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte alignment");
+    if (n16 == 0) return IAMX_OK;
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)workgroups), dim3(256), 0, iamx::as_stream(stream),
+                       reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n16);
+    return iamx::check_launch("iamx_hbm_copy16");
 }

@@ -324,12 +324,18 @@ __device__ int compact_list(Lds &L, int32_t *list, int m, F keep)
 }
 
 // filter_duplicates: sequential first-come-wins on the "%.2f-%.2f" keys of either end point
-// (a dropped pair does not reserve its keys).  Parallel pre-check: without any repeated key
-// nothing is dropped; only otherwise one thread replays the python loop.
+// (a dropped pair does not reserve its keys).  A parallel pass gives every pair the hash slot of
+// its query key and of its train key (equal keys <=> equal slots) and notices whether any key
+// repeats at all; only then ONE thread replays the python loop -- on the slot numbers, entirely
+// in LDS (two flag reads and at most two flag writes per pair; SIFT reports a pixel once per
+// dominant orientation, so on real frames nearly every pair has repeats: the replay used to walk
+// the lists and the key tables in global memory, ~5 us per pair of dependent loads, 10 ms per
+// round of 256 pairs; profiles/r5_kernel_stats.txt against r6).
 __device__ int dedupe(Lds &L, const PostArgs &A, int32_t *list, int m, int img_q, int img_t)
 {
     const int32_t *kq = A.key2 + 2 * A.kp_off[img_q], *kt = A.key2 + 2 * A.kp_off[img_t];
     int *set1 = L.g.tab_key, *set2 = L.g.tab_val;          // slots hold list position + 1
+    unsigned short *slot_q = L.g.lg[0], *slot_t = L.g.lg[1];    // (the GMS grids are dead by now)
     for (int i = threadIdx.x; i < TAB; i += NT) { set1[i] = 0; set2[i] = 0; }
     if (threadIdx.x == 0) L.bcast[0] = 0;
     __syncthreads();
@@ -346,6 +352,7 @@ __device__ int dedupe(Lds &L, const PostArgs &A, int32_t *list, int m, int img_q
                 if (same(k, list[2 * (prev - 1) + side], row)) { L.bcast[0] = 1; break; }
                 h = (h + 1) & (TAB - 1);
             }
+            (side ? slot_t : slot_q)[i] = (unsigned short)h;
         }
     }
     __syncthreads();
@@ -356,23 +363,10 @@ __device__ int dedupe(Lds &L, const PostArgs &A, int32_t *list, int m, int img_q
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int i = 0; i < m; ++i) {
-            const int q = list[2 * i], t = list[2 * i + 1];
-            unsigned h1 = hash32((unsigned)kq[2 * q] * 0x9E3779B1u ^ (unsigned)kq[2 * q + 1]) & (TAB - 1);
-            bool used = false;
-            while (set1[h1]) {
-                if (same(kq, list[2 * (set1[h1] - 1)], q)) { used = true; break; }
-                h1 = (h1 + 1) & (TAB - 1);
-            }
-            unsigned h2 = hash32((unsigned)kt[2 * t] * 0x9E3779B1u ^ (unsigned)kt[2 * t + 1]) & (TAB - 1);
-            if (!used) {
-                while (set2[h2]) {
-                    if (same(kt, list[2 * (set2[h2] - 1) + 1], t)) { used = true; break; }
-                    h2 = (h2 + 1) & (TAB - 1);
-                }
-            }
-            if (!used) {
-                set1[h1] = i + 1;
-                set2[h2] = i + 1;
+            const int hq = slot_q[i], ht = slot_t[i];
+            if (!(set1[hq] | set2[ht])) {
+                set1[hq] = 1;
+                set2[ht] = 1;
                 L.g.bits[i] = 1;
             }
         }

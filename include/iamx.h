@@ -399,6 +399,11 @@ int iamx_touch_pages(const void *p, int64_t bytes, int threads);
 int iamx_segment_mean_std(const double *z, const int64_t *starts, const int64_t *counts,
                           int64_t n_seg, int64_t n_z, double *mean, double *std, int threads);
 
+/* iamx_hbm_copy16 -- measurement yardstick of the HBM-bound kernels (bench.py, tools/): a plain
+ * grid-stride device copy of n16 16-byte words, 16 bytes per lane and step, `workgroups` x 256
+ * threads.  No counterpart in the reference. */
+int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int workgroups, void *stream);
+
 /* iamx_yaw_feedback_* -- the yaw-error FEEDBACK of the reference's pair loop as a prefix
  * computation over the schedule (HOST code).  scripts/lib/matcher.py:987-993 sets both images'
  * aircraft yaw-error estimate after every pair (lib/smart.py:251-283 update_yaw_error_estimate:
