@@ -561,10 +561,11 @@ def main():
             "dense_overlap_pairs_per_sec": g(dense, "pairs_per_sec"),
             "dense_overlap_routed_pairs_per_sec": g(dense, "routed_pairs_per_sec"),
             "ba_seconds_to_ftol": g(ba, "seconds_to_ftol"), "ba_trf_it_per_sec": g(ba, "value"),
-            "ba_residual_frac_cache": g(ba, "residual", "frac"),
             "ba_residual_frac_out_of_cache": g(ba, "residual", "out_of_cache", "frac"),
-            "ba_jac_frac_cache": g(ba, "residual_jac", "frac"),
+            "ba_residual_frac_of_stream_same_mix": g(ba, "residual", "out_of_cache", "frac_of_stream_same_mix"),
+            "ba_residual_cache_resident_frac_of_hbm_peak": g(ba, "residual", "cache_resident", "frac_of_hbm_peak"),
             "ba_jac_frac_out_of_cache": g(ba, "residual_jac", "out_of_cache", "frac"),
+            "ba_jac_cache_resident_frac_of_hbm_peak": g(ba, "residual_jac", "cache_resident", "frac_of_hbm_peak"),
             "ba_schur_iteration_frac": g(ba, "schur_iteration", "frac"),
             "sift_frames_per_sec": g(sift, "value"), "sift_frac_hbm": g(sift, "roofline", "frac"),
             "sift_traffic_bytes": g(sift, "roofline", "traffic"),
@@ -1338,6 +1339,7 @@ def ba_bench(rank, world, dev, dist, args):
     # rotation, so that every launch finds its inputs evicted by the five launches before it.
     # (`timed` above re-launches ONE problem back to back: its 125 MB come out of the cache.)
     t_res_cold = t_jac_cold = copy_bw = None
+    stream_bw = {}
     n_rot = 6
     if world == 1:
         rot = [prob]
@@ -1359,18 +1361,28 @@ def ba_bench(rank, world, dev, dist, args):
         t_jac_cold = timed(rot_jac, 10) / n_rot
         del launch, rot
         torch.cuda.empty_cache()
-        # yardstick on the same box, same moment: a plain device copy over the same kind of
-        # rotating working set (6 x 62.5 MB read + 62.5 MB written = the residual's byte count)
-        n_el = int(62.5e6 // 8)
-        srcs = [torch.empty(n_el, dtype=torch.float64, device=dev).normal_() for _ in range(n_rot)]
-        dsts = [torch.empty(n_el, dtype=torch.float64, device=dev) for _ in range(n_rot)]
+        # yardsticks on the same box, same moment (iamx_hbm_copy16: a grid-stride stream kernel, 16 B
+        # per lane and step -- the form the hardware guide measures): six buffers in rotation, 125 MB
+        # moved per launch, as a plain copy (62.5 MB in, 62.5 MB out) and in the residual kernel's
+        # own mix (three words read per word written: 94 MB in, 31 MB out)
+        import ctypes
+        from imageanalysis_amd import _lib
+        Lc = _lib.lib()
+        stp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream_bw = {}
+        for k in (1, 3):
+            n_out = int(125.5e6 / (k + 1)) // 16
+            srcs = [torch.empty(2 * n_out * k, dtype=torch.float64, device=dev).normal_() for _ in range(n_rot)]
+            dsts = [torch.empty(2 * n_out, dtype=torch.float64, device=dev) for _ in range(n_rot)]
 
-        def rot_copy():
-            for a_, b_ in zip(srcs, dsts):
-                b_.copy_(a_)
-        copy_bw = 2 * n_el * 8 / (timed(rot_copy, 20) / n_rot) / 1e9
-        del srcs, dsts
-        torch.cuda.empty_cache()
+            def rot_copy():
+                for a_, b_ in zip(srcs, dsts):
+                    Lc.iamx_hbm_copy16(ctypes.c_void_p(a_.data_ptr()), ctypes.c_void_p(b_.data_ptr()),
+                                       n_out, k, 1024, stp)
+            stream_bw[k] = n_out * 16 * (k + 1) / (timed(rot_copy, 20) / n_rot) / 1e9
+            del srcs, dsts
+            torch.cuda.empty_cache()
+        copy_bw = stream_bw[1]
     # untimed warm-up solve (workspace and allocator blocks of every branch of the step selection,
     # code-object load), like --warmup for matching; the collector has the matching section's heap
     # behind it before the clock starts
@@ -1486,13 +1498,39 @@ def ba_bench(rank, world, dev, dist, args):
         if t is None:
             return None
         bw = bytes_per_obs * o_local / t / 1e9
+        mix = stream_bw.get(3) if bytes_per_obs == 64 else None
         return {"achieved": round(bw, 1), "frac": round(bw / HBM, 4),
-                "frac_of_achievable_6300": round(bw / 6300.0, 4), "us_per_launch": round(t * 1e6, 2),
-                "plain_copy_same_working_set_gbs": None if copy_bw is None else round(copy_bw, 1),
-                "frac_of_plain_copy": None if copy_bw is None else round(bw / copy_bw, 4),
+                "us_per_launch": round(t * 1e6, 2),
+                # what a pure stream kernel reaches over the same kind of rotating working set, same
+                # box, same moment (iamx_hbm_copy16, 1024 workgroups): as a copy, and in this kernel's
+                # own read : write mix -- the ceiling a gather + f64 arithmetic kernel is measured at
+                "stream_copy_gbs": None if copy_bw is None else round(copy_bw, 1),
+                "frac_of_stream_copy": None if copy_bw is None else round(bw / copy_bw, 4),
+                "stream_same_mix_gbs": None if mix is None else round(mix, 1),
+                "frac_of_stream_same_mix": None if mix is None else round(bw / mix, 4),
                 "working_set": "%d problem copies in rotation (%.0f MB > the 256 MiB Infinity Cache)"
                                % (n_rot, n_rot * bytes_per_obs * o_local / 1e6),
                 "timing": "hipEvents around %d rotations" % (20 if bytes_per_obs == 64 else 10)}
+
+    def hbm_first(bytes_per_obs, t_hot, t_cold, kernel, timing):
+        """the roofline object of a BA kernel: `achieved` / `frac` are the OUT-OF-CACHE figures (a
+        rotating working set that cannot sit in the 256 MiB Infinity Cache) whenever they were
+        measured (N = 1); back-to-back launches of one 125 / 439 MB problem are served from that
+        cache and are reported as what they are, `cache_resident`"""
+        c = cold(t_cold, bytes_per_obs)
+        hot = {"achieved": round(bytes_per_obs * o_local * world / t_hot / 1e9, 1),
+               "frac_of_hbm_peak": round(bytes_per_obs * o_local / t_hot / 1e9 / HBM, 4),
+               "us_per_launch": round(t_hot * 1e6, 2),
+               "working_set": "one problem, launched back to back: Infinity-Cache resident -- a "
+                              "cache-level figure, NOT an HBM fraction"}
+        tr = aux_traffic((kernel,), kernel)
+        out = {"bound": "hbm", "peak": HBM, "unit": "GB/s", "bytes_per_obs": bytes_per_obs,
+               "achieved": c["achieved"] if c else hot["achieved"],
+               "frac": c["frac"] if c else hot["frac_of_hbm_peak"],
+               "regime": "out of cache (rotating working set)" if c else "cache resident (N > 1: not rotated)",
+               "out_of_cache": c, "cache_resident": hot, "traffic": tr[0], "traffic_source": tr[1],
+               "timing": timing}
+        return out
     return {"metric": "ba_iterations_per_sec", "value": round(res.iterations / dt, 3),
             # time to the reference's stopping rule (ftol = 1e-4) is the figure that compares with
             # another inner solver: the Schur path takes more, cheaper outer iterations than LSMR
@@ -1506,29 +1544,12 @@ def ba_bench(rank, world, dev, dist, args):
             "seconds": round(dt, 3), "lsmr_reference": lsmr_ref,
             "cameras": C, "points": P, "observations": O, "rms_residual_px": round(mre, 3),
             "residual_evals_per_sec": round(1.0 / t_res, 1),
-            "residual": {"bound": "hbm", "achieved": round(64.0 * o_local * world / t_res / 1e9, 1),
-                         "peak": HBM, "unit": "GB/s",
-                         "frac": round(64.0 * o_local / t_res / 1e9 / HBM, 4),
-                         "bytes_per_obs": 64,
-                         # 125 MB per evaluation: back-to-back evaluations are served from the
-                         # 256 MB Infinity Cache (a plain copy of that size runs at 6.9 TB/s,
-                         # tools/hbm_copy_bw.py), so this is a cache-level, not an HBM, fraction
-                         "working_set": "Infinity-Cache resident (125 MB per evaluation)",
-                         "out_of_cache": cold(t_res_cold, 64.0),
-                         "traffic": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[0],
-                         "traffic_source": aux_traffic(('ba_residual_lds_kernel',), 'ba_residual_lds_kernel')[1],
-                         "timing": "hipEvents around 100 launches (rocprofv3 --stats of the same "
-                                   "kernel, ba_residual_lds_kernel: profiles/r5_kernel_stats.txt)"},
-            "residual_jac": {"bound": "hbm",
-                             "achieved": round(224.0 * o_local * world / t_jac / 1e9, 1),
-                             "peak": HBM, "unit": "GB/s",
-                             "frac": round(224.0 * o_local / t_jac / 1e9 / HBM, 4),
-                             "bytes_per_obs": 224,
-                             "out_of_cache": cold(t_jac_cold, 224.0),
-                             "traffic": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[0],
-                             "traffic_source": aux_traffic(('ba_residual_jac_kernel',), 'ba_residual_jac_kernel')[1],
-                             "timing": "hipEvents around 50 launches (ba_residual_jac_kernel: "
-                                       "profiles/r5_kernel_stats.txt)"},
+            "residual": hbm_first(64.0, t_res, t_res_cold, 'ba_residual_pipe_kernel',
+                                  "hipEvents around 100 launches / 20 rotations (kernel: ba_residual_pipe_kernel, "
+                                  "the persistent pipelined walk; IAMX_BA_RESIDUAL=lds selects the "
+                                  "one-chain-per-workgroup form, tools/ba_resid_ab.py compares them)"),
+            "residual_jac": hbm_first(224.0, t_jac, t_jac_cold, 'ba_residual_jac_kernel',
+                                      "hipEvents around 50 launches / 10 rotations (ba_residual_jac_kernel)"),
             "schur_iteration": schur_it, "lsmr_iteration": lsmr, "cpu_baseline": cpu,
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
 

@@ -72,7 +72,7 @@ SIGNATURES = {
     'iamx_pairs_fwd_rev': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int]),
     'iamx_touch_pages': (c_int, [c_void_p, c_int64, c_int]),
     'iamx_segment_mean_std': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int]),
-    'iamx_hbm_copy16': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    'iamx_hbm_copy16': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     'iamx_yaw_feedback_new': (c_void_p, [c_int, c_void_p]),
     'iamx_yaw_feedback_free': (None, [c_void_p]),
     'iamx_yaw_feedback_seed': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

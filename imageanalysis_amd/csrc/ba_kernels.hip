@@ -191,130 +191,138 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
 // The same evaluation as a PERSISTENT, software-pipelined kernel.  ba_residual_lds_kernel is one
 // dependent chain per workgroup -- indices, then the point gather and the camera parameters behind
 // them, then arithmetic, then the store -- and a workgroup lives for exactly one such chain: with
-// ~3.7 generations of workgroups per launch the two memory latencies, not the 64 B per
+// several generations of workgroups per launch the two memory latencies, not the 64 B per
 // observation, are the time (profiles/r5: 92 MB of HBM traffic in 27 us).  Here every WAVE walks
 // its share of the 128-observation chunks with three of them in flight: while chunk k is being
 // evaluated the point gather + camera parameters of chunk k+1 (whose indices arrived during the
-// previous step) and the indices / observed pixels of chunk k+2 are on their way.  Wave
-// synchronous, no workgroup barrier; camera blocks per wave in LDS, double buffered.
-constexpr int PIPE_MAXCAM = 16;
+// previous step) and the indices / observed pixels of chunk k+2 are on their way.
+// The loop body has NO branch around a load (clamped addresses instead): the compiler's wait
+// counters then stay exact and a step waits for the loads it needs, not for all of them (a first
+// version with `if (in range) load` waited for vmcnt(0) every step and ran slower than the form it
+// was to replace, profiles/r6_ba_resid_ab.txt).  Wave synchronous, no workgroup barrier; camera
+// blocks per wave in LDS, double buffered.  A chunk that spans more than PIPE_MAXCAM cameras
+// (legal: any observation order is) is remembered and redone per observation AFTER the loop.
+constexpr int PIPE_MAXCAM = 8;
+constexpr int PIPE_SETS = 5;
 
 struct ObsIdx {
     int2 ci, pi;
     double4 ob;
 };
 
-__device__ __forceinline__ void pipe_load_idx(const int32_t *__restrict__ cam_idx,
-                                              const int32_t *__restrict__ pt_idx,
-                                              const double *__restrict__ uv, int64_t o,
-                                              int64_t n_obs, ObsIdx &I)
-{
-    I.ci = make_int2(0, 0);
-    I.pi = make_int2(0, 0);
-    I.ob = make_double4(0, 0, 0, 0);
-    if (o + 1 < n_obs) {
-        I.ci = *reinterpret_cast<const int2 *>(cam_idx + o);
-        I.pi = *reinterpret_cast<const int2 *>(pt_idx + o);
-        I.ob = *reinterpret_cast<const double4 *>(uv + 2 * o);
-    } else if (o < n_obs) {
-        I.ci.x = I.ci.y = cam_idx[o];
-        I.pi.x = I.pi.y = pt_idx[o];
-        const double2 t = *reinterpret_cast<const double2 *>(uv + 2 * o);
-        I.ob = make_double4(t.x, t.y, 0, 0);
-    }
-}
-
 __global__ __launch_bounds__(256) void ba_residual_pipe_kernel(
     const double *__restrict__ cams, const double *__restrict__ pts,
     const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
     const double *__restrict__ uv, int64_t n_obs, const double *__restrict__ calib,
-    double *__restrict__ r)
+    double *__restrict__ r, int steps, int n_cams)
 {
     __shared__ double Rs_all[4][2][PIPE_MAXCAM][12];    // per WAVE, double buffered
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n_chunks = (n_obs + 127) / 128;
     // (workgroups are dealt to the XCDs round robin; inside one step of the walk every XCD gets a
     //  contiguous run of chunks: neighbouring chunks gather neighbouring points, one L2 each)
     const int64_t wg = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int64_t first = wg * 4 + wave, stride = (int64_t)gridDim.x * 4;
+    if (first >= n_chunks) return;
     double cal[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) cal[i] = calib[i];
-    auto obs_of = [&](int64_t c) { return (c * 64 + lane) * 2; };
-    ObsIdx A, B;                        // A: chunk k+2 (indices on their way), B: chunk k+1
-    double X0[3], X1[3], cp[7];         // of chunk k (gathered during the previous step)
-    int c_lo = 0, ncam = 0;
-    ObsIdx C;
-    // what the gather stage does for a chunk whose indices have arrived
-    auto gather = [&](const ObsIdx &I, int64_t o, double (&x0)[3], double (&x1)[3], double (&cpar)[7],
-                      int &lo_out, int &n_out) {
+    const int64_t last_pair = n_obs - 2;                 // (n_obs >= 2: the launcher checks)
+    // A lane's observation pair of chunk c is ALWAYS a valid pair: chunks past the end repeat the
+    // last chunk, pairs past the end repeat the last pair (n_obs - 2, n_obs - 1) -- such a lane
+    // computes and stores the same values to the same place as the lane that owns them.  So no
+    // load and no store of the walk sits behind a branch.
+    auto pair_of = [&](int64_t c) {
+        const int64_t cc = c < n_chunks ? c : n_chunks - 1;
+        const int64_t o = (cc * 64 + lane) * 2;
+        return o < last_pair ? o : last_pair;
+    };
+    auto load_idx = [&](int64_t c, ObsIdx &I) {
+        const int64_t ol = pair_of(c);
+        I.ci = *reinterpret_cast<const int2 *>(cam_idx + ol);
+        I.pi = *reinterpret_cast<const int2 *>(pt_idx + ol);
+        I.ob = *reinterpret_cast<const double4 *>(uv + 2 * ol);
+    };
+    // the gather stage of a chunk whose indices have arrived: both points, the camera range of
+    // the wave, the parameters of camera lo + min(lane, PIPE_MAXCAM - 1)
+    auto gather = [&](const ObsIdx &I, double (&x0)[3], double (&x1)[3], double (&cpar)[7], int &lo_out,
+                      int &hi_out) {
         const double *q0 = pts + (int64_t)I.pi.x * 3, *q1 = pts + (int64_t)I.pi.y * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { x0[k] = q0[k]; x1[k] = q1[k]; }
-        int lo = o < n_obs ? min(I.ci.x, I.ci.y) : 0x7FFFFFFF, hi = o < n_obs ? max(I.ci.x, I.ci.y) : -1;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            lo = min(lo, __shfl_xor(lo, m));
-            hi = max(hi, __shfl_xor(hi, m));
-        }
+        // camera range of the chunk: observations are camera-major in practice, so the first
+        // lane's first camera and the last lane's second bound it (two v_readlane instead of two
+        // dependent chains of six cross-lane exchanges, which one wave per SIMD cannot hide); a
+        // chunk where some lane falls outside gets hi = lo + PIPE_MAXCAM: the redo path
+        int lo = __builtin_amdgcn_readlane(I.ci.x, 0), hi = __builtin_amdgcn_readlane(I.ci.y, 63);
+        const bool inside = I.ci.x >= lo && I.ci.x <= hi && I.ci.y >= lo && I.ci.y <= hi;
+        if (__ballot(inside) != ~0ull || hi < lo) hi = lo + PIPE_MAXCAM;
         lo_out = lo;
-        n_out = hi - lo + 1;
-        if (n_out <= PIPE_MAXCAM && lane < n_out) {
-            const double *cs = cams + (int64_t)(lo + lane) * 7;
+        hi_out = hi;
+        const int cl = lo + (lane < PIPE_MAXCAM ? lane : PIPE_MAXCAM - 1);
+        const double *cs = cams + (int64_t)min(min(cl, hi), n_cams - 1) * 7;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) cpar[k] = cs[k];
-        }
+        for (int k = 0; k < 7; ++k) cpar[k] = cs[k];
     };
-    int64_t c = first;
-    if (c >= n_chunks) return;
-    // prologue: indices of the first two chunks, gather of the first
-    pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c), n_obs, C);
-    if (c + stride < n_chunks) pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c + stride), n_obs, B);
-    gather(C, obs_of(c), X0, X1, cp, c_lo, ncam);
-    int buf = 0;
-    for (; c < n_chunks; c += stride) {
-        const int64_t o = obs_of(c);
-        const bool has1 = c + stride < n_chunks, has2 = c + 2 * stride < n_chunks;
-        // stage 1: indices / observed pixels of chunk k+2
-        if (has2) pipe_load_idx(cam_idx, pt_idx, uv, obs_of(c + 2 * stride), n_obs, A);
-        // stage 2: point gather + camera parameters of chunk k+1 (its indices were requested one
-        // step ago)
-        double nX0[3], nX1[3], ncp[7];
-        int n_lo = 0, n_ncam = 0;
-        if (has1) gather(B, obs_of(c + stride), nX0, nX1, ncp, n_lo, n_ncam);
-        // stage 3: chunk k -- camera blocks into this wave's LDS slice, then the residuals
-        double (*Rs)[12] = Rs_all[wave][buf];
-        const bool in_lds = ncam <= PIPE_MAXCAM;
-        if (in_lds && lane < ncam) cam_block(cp, Rs[lane]);
+    // PIPE_SETS register sets take the roles "indices on their way" (chunks k+4, k+3), "gather on
+    // its way" (k+2, k+1) and "being evaluated" (k) in turn: with one wave per SIMD a step is as
+    // long as the slowest dependent load it waits for, and two steps of slack per stage halve
+    // that (three sets, one step of slack: 27.5 us on a rotating working set; profiles/r6).  The
+    // walk is unrolled by PIPE_SETS so that the roles rotate by NAME -- a register copy of a set
+    // whose loads are still in flight would make the step wait for them.  The launcher sizes the
+    // grid so that the steps per wave are a multiple of PIPE_SETS (`steps`).
+    struct Set {
+        ObsIdx idx;
+        double X0[3], X1[3], cp[7];
+        int lo, hi;
+    };
+    Set S[PIPE_SETS];
+    unsigned long long redo = 0ull;     // steps whose chunk spans more than PIPE_MAXCAM cameras
+    int step = 0;
+    auto do_step = [&](Set &Cs, Set &Gs, Set &As, int64_t c) __attribute__((always_inline)) {
+        load_idx(c + 4 * stride, As.idx);                                     // chunk k+4: indices
+        gather(Gs.idx, Gs.X0, Gs.X1, Gs.cp, Gs.lo, Gs.hi);                    // chunk k+2: gather
+        // chunk k -- camera blocks into this wave's LDS slice, then the residuals
+        double (*Rs)[12] = Rs_all[wave][step & 1];
+        if (lane < PIPE_MAXCAM) cam_block(Cs.cp, Rs[lane]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (o < n_obs) {
-            double Rl0[12], Rl1[12];
-            if (!in_lds) {
-                cam_block(cams + (int64_t)C.ci.x * 7, Rl0);
-                cam_block(cams + (int64_t)C.ci.y * 7, Rl1);
-            }
-            const double *R0 = in_lds ? Rs[C.ci.x - c_lo] : Rl0;
-            const double2 r0 = residual_rt(R0, X0, make_double2(C.ob.x, C.ob.y), cal);
-            if (o + 1 < n_obs) {
-                const double *R1 = in_lds ? Rs[C.ci.y - c_lo] : Rl1;
-                const double2 r1 = residual_rt(R1, X1, make_double2(C.ob.z, C.ob.w), cal);
-                *reinterpret_cast<double4 *>(r + 2 * o) = make_double4(r0.x, r0.y, r1.x, r1.y);
-            } else {
-                *reinterpret_cast<double2 *>(r + 2 * o) = r0;
+        redo |= (Cs.hi - Cs.lo >= PIPE_MAXCAM && c < n_chunks) ? 1ull << step : 0ull;    // (wave uniform)
+        const int k0 = max(0, min(Cs.idx.ci.x - Cs.lo, PIPE_MAXCAM - 1)), k1 = max(0, min(Cs.idx.ci.y - Cs.lo, PIPE_MAXCAM - 1));
+        const double2 r0 = residual_rt(Rs[k0], Cs.X0, make_double2(Cs.idx.ob.x, Cs.idx.ob.y), cal);
+        const double2 r1 = residual_rt(Rs[k1], Cs.X1, make_double2(Cs.idx.ob.z, Cs.idx.ob.w), cal);
+        *reinterpret_cast<double4 *>(r + 2 * pair_of(c)) = make_double4(r0.x, r0.y, r1.x, r1.y);
+        ++step;
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_idx(first + t * stride, S[t].idx);
+    gather(S[0].idx, S[0].X0, S[0].X1, S[0].cp, S[0].lo, S[0].hi);
+    gather(S[1].idx, S[1].X0, S[1].X1, S[1].cp, S[1].lo, S[1].hi);
+    {
+        int64_t c = first;
+        for (int g = 0; g < steps; g += PIPE_SETS) {
+#pragma unroll
+            for (int j = 0; j < PIPE_SETS; ++j) {
+                do_step(S[j], S[(j + 2) % PIPE_SETS], S[(j + 4) % PIPE_SETS], c);
+                c += stride;
             }
         }
-        // rotate
-        C = B;
-        B = A;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { X0[k] = nX0[k]; X1[k] = nX1[k]; }
-#pragma unroll
-        for (int k = 0; k < 7; ++k) cp[k] = ncp[k];
-        c_lo = n_lo;
-        ncam = n_ncam;
-        buf ^= 1;
+    }
+    // the chunks whose camera range did not fit the LDS slice: per observation, from registers
+    while (redo) {
+        const int st = __builtin_ctzll(redo);
+        redo &= redo - 1;
+        const int64_t o = ((first + (int64_t)st * stride) * 64 + lane) * 2;
+        for (int h = 0; h < 2; ++h) {
+            if (o + h >= n_obs) break;
+            double Rl[12], X[3];
+            cam_block(cams + (int64_t)cam_idx[o + h] * 7, Rl);
+            const double *q = pts + (int64_t)pt_idx[o + h] * 3;
+            X[0] = q[0]; X[1] = q[1]; X[2] = q[2];
+            const double2 ob = *reinterpret_cast<const double2 *>(uv + 2 * (o + h));
+            *reinterpret_cast<double2 *>(r + 2 * (o + h)) = residual_rt(Rl, X, ob, cal);
+        }
     }
 }
 
@@ -499,21 +507,26 @@ extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const d
                  "uv / r must be 32-byte aligned, cam_idx / pt_idx 8-byte aligned");
     hipStream_t st = iamx::as_stream(stream);
     (void)cam_scratch;           // kept in the signature; the camera blocks now live in LDS
-    // IAMX_BA_RESIDUAL=lds: the one-chain-per-workgroup form (A/B runs, tools/ba_resid_ab.py);
-    // default: the persistent pipelined walk, IAMX_BA_RESIDUAL_WGS workgroups (default 2048: eight
-    // per CU, every wave ~1.9 chunks... of 128 observations at configs[3]) -- never more than the
-    // chunks there are
+    // IAMX_BA_RESIDUAL=lds: the one-chain-per-workgroup form (A/B: tools/ba_resid_ab.py);
+    // default: the persistent pipelined walk on IAMX_BA_RESIDUAL_WGS workgroups -- at least so many
+    // that no wave walks more than 64 chunks (the redo mask), never more than there are chunks
     const char *form = getenv("IAMX_BA_RESIDUAL"), *wgs = getenv("IAMX_BA_RESIDUAL_WGS");
-    if (form && form[0] == 'l') {
+    if ((form && form[0] == 'l') || n_obs < 2) {
         hipLaunchKernelGGL(ba_residual_lds_kernel, dim3((unsigned)((n_obs + 511) / 512)), dim3(256), 0,
                            st, cams, pts, cam_idx, pt_idx, uv, n_obs, calib, r);
     } else {
-        const int64_t need = (n_obs + 511) / 512;
-        int64_t g = wgs ? atoll(wgs) : 1024;
+        // steps per wave: a multiple of PIPE_SETS (the walk is unrolled by it), at most 60 (the
+        // redo mask); then as few workgroups as cover the chunks in that many steps -- 256 (one per
+        // CU, one wave per SIMD) x 15 steps at configs[3]
+        const int64_t n_chunks = (n_obs + 127) / 128;
+        int64_t g = wgs ? atoll(wgs) : 256;
         if (g < 1) g = 1;
-        if (g > need) g = need;
+        int64_t steps = (n_chunks + 4 * g - 1) / (4 * g);
+        steps = (steps + PIPE_SETS - 1) / PIPE_SETS * PIPE_SETS;
+        if (steps > 60) steps = 60;
+        g = (n_chunks + 4 * steps - 1) / (4 * steps);
         hipLaunchKernelGGL(ba_residual_pipe_kernel, dim3((unsigned)g), dim3(256), 0, st, cams, pts,
-                           cam_idx, pt_idx, uv, n_obs, calib, r);
+                           cam_idx, pt_idx, uv, n_obs, calib, r, (int)steps, n_cams);
     }
     return iamx::check_launch("iamx_ba_residual_prepared");
 }
@@ -539,22 +552,43 @@ extern "C" int iamx_ba_residual_jac(const double *cams, int n_cams, const double
 
 // The yardstick of the HBM-bound kernels above: a plain grid-stride copy, 16 bytes per lane and
 // step (the form MI355X_MICROARCH.md measures at 6.29 TB/s), over whatever working set the caller
-// rotates through.  n16 = number of 16-byte words.
+// rotates through.  n16 = number of 16-byte words WRITTEN; reads_per_write source words are read
+// (and added up) per word written: 1 = a copy, 3 = the read : write mix of the residual kernel
+// (48 B in, 16 B out per observation).
 namespace {
+template <int K>
 __global__ __launch_bounds__(256) void copy16_kernel(const double2 *__restrict__ src,
                                                      double2 *__restrict__ dst, int64_t n16)
 {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
-        dst[i] = src[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+        double2 acc = src[i];
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            const double2 v = src[(int64_t)k * n16 + i];
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        dst[i] = acc;
+    }
 }
 }  // namespace
 
-extern "C" int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int workgroups, void *stream)
+extern "C" int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int reads_per_write,
+                               int workgroups, void *stream)
 {
     IAMX_REQUIRE(src && dst && n16 >= 0 && workgroups > 0, "bad argument");
+    IAMX_REQUIRE(reads_per_write >= 1 && reads_per_write <= 4, "reads_per_write must be 1..4");
     IAMX_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "16-byte alignment");
     if (n16 == 0) return IAMX_OK;
-    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)workgroups), dim3(256), 0, iamx::as_stream(stream),
-                       reinterpret_cast<const double2 *>(src), reinterpret_cast<double2 *>(dst), n16);
+    const dim3 g((unsigned)workgroups), b(256);
+    hipStream_t st = iamx::as_stream(stream);
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    switch (reads_per_write) {
+    case 1: hipLaunchKernelGGL(copy16_kernel<1>, g, b, 0, st, s2, d2, n16); break;
+    case 2: hipLaunchKernelGGL(copy16_kernel<2>, g, b, 0, st, s2, d2, n16); break;
+    case 3: hipLaunchKernelGGL(copy16_kernel<3>, g, b, 0, st, s2, d2, n16); break;
+    default: hipLaunchKernelGGL(copy16_kernel<4>, g, b, 0, st, s2, d2, n16); break;
+    }
     return iamx::check_launch("iamx_hbm_copy16");
 }

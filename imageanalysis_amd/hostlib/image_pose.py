@@ -34,6 +34,10 @@ class PoseImage(object):
             node.setBool('valid', True)
         else:
             node = self.node.getChild('camera_pose', True)
+            ac = self.node.getChild('aircraft_pose', False) if self.node.hasChild('aircraft_pose') else None
+            if ac is not None and ac.hasChild('derived_from_camera_pose'):
+                # (an aircraft pose this stand-in derived from an EARLIER camera pose of the node)
+                del self.node.__dict__['aircraft_pose']
         for i in range(3):
             node.setFloatEnum('ned', i, ned[i])
         node.setFloat('yaw_deg', yaw_deg)
@@ -79,6 +83,13 @@ class PoseImage(object):
         find_matches triangulates with"""
         from . import camera
         ac = self.node.getChild('aircraft_pose', True)
+        if not ac.hasChild('yaw_deg'):
+            # (stand-in only: a synthetic project that logged CAMERA poses and never an aircraft
+            #  pose -- the reference always has one, lib/pose.py:125-152 derives the camera pose
+            #  from it -- gets the aircraft attitude that leads to its camera pose under the
+            #  configured mount, so that the re-derivation below lands on that pose + the yaw error)
+            ned, ypr, _q = self.get_camera_pose()
+            self.set_pose_from_camera(ned, *ypr)
         ac.setFloat("yaw_error_deg", yaw_error_deg)
         yaw_deg, pitch_deg, roll_deg = ac.getFloat('yaw_deg'), ac.getFloat('pitch_deg'), ac.getFloat('roll_deg')
         ned2body = tf.quaternion_from_euler((yaw_deg + yaw_error_deg) * d2r, pitch_deg * d2r,
@@ -109,6 +120,7 @@ class PoseImage(object):
         inv = np.array([b[0], -b[1], -b[2], -b[3]]) / float(np.dot(b, b))
         y, p, r = tf.euler_from_quaternion(tf.quaternion_multiply(ned2cam, inv), 'rzyx')
         self.set_aircraft_pose(lla[0], lla[1], lla[2], y * r2d, p * r2d, r * r2d)
+        self.node.getChild('aircraft_pose', True).setBool('derived_from_camera_pose', True)
 
     def get_cam2body(self):
         return self.cam2body

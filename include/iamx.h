@@ -400,9 +400,12 @@ int iamx_segment_mean_std(const double *z, const int64_t *starts, const int64_t 
                           int64_t n_seg, int64_t n_z, double *mean, double *std, int threads);
 
 /* iamx_hbm_copy16 -- measurement yardstick of the HBM-bound kernels (bench.py, tools/): a plain
- * grid-stride device copy of n16 16-byte words, 16 bytes per lane and step, `workgroups` x 256
- * threads.  No counterpart in the reference. */
-int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int workgroups, void *stream);
+ * grid-stride device kernel that writes n16 16-byte words, each the sum of reads_per_write (1..4)
+ * source words (src holds reads_per_write x n16 words: 1 = a copy, 3 = the read : write mix of the
+ * BA residual kernel), 16 bytes per lane and step, `workgroups` x 256 threads.  No counterpart in
+ * the reference. */
+int iamx_hbm_copy16(const void *src, void *dst, int64_t n16, int reads_per_write, int workgroups,
+                    void *stream);
 
 /* iamx_yaw_feedback_* -- the yaw-error FEEDBACK of the reference's pair loop as a prefix
  * computation over the schedule (HOST code).  scripts/lib/matcher.py:987-993 sets both images'

@@ -138,6 +138,47 @@ def test_residual_prepared_equals_plain():
     assert np.abs(prob.download_m(prob.r) - plain).max() <= 1e-9 * np.abs(plain).max()
 
 
+@pytest.mark.parametrize('n_obs,order', [(1, 'sorted'), (2, 'sorted'), (3, 'sorted'), (129, 'sorted'),
+                                         (5001, 'sorted'), (5001, 'shuffled'), (70001, 'wide'),
+                                         (200000, 'sorted')])
+@pytest.mark.parametrize('form', ['pipe', 'lds'])
+def test_residual_prepared_forms_any_order_and_ragged_sizes(n_obs, order, form, monkeypatch):
+    """iamx_ba_residual_prepared -- the persistent pipelined walk (default) and the
+    one-chain-per-workgroup form -- against the plain-C oracle on odd / tiny observation counts and
+    on orders that are NOT camera-major: shuffled (every 128-observation chunk spans hundreds of
+    cameras: the walk redoes those chunks per observation) and 'wide' (camera-major, but 12 cameras
+    per chunk: more than the walk's LDS slice holds)."""
+    import ctypes
+    import torch
+    from imageanalysis_amd import _lib
+    from imageanalysis_amd.kernels import _ptr, stream_ptr
+    from oracle import cpu_ref
+    monkeypatch.setenv('IAMX_BA_RESIDUAL', form)
+    rng = np.random.default_rng(n_obs)
+    C, P = 300, 20000
+    cams = np.zeros((C, 7))
+    cams[:, :3] = rng.normal(0, 50, (C, 3)) * [1, 1, 0.05] + [0, 0, -100]
+    cams[:, 3:] = np.array([0.7071, 0, -0.7071, 0]) * rng.uniform(0.5, 2.0, (C, 1)) + rng.normal(0, 0.02, (C, 4))
+    pts = rng.normal(0, 40, (P, 3)) * [1, 1, 0.05]
+    ci = rng.integers(0, C, n_obs).astype(np.int32)
+    if order == 'sorted':
+        ci = np.sort(ci)
+    elif order == 'wide':
+        ci = (np.arange(n_obs) // 11 % C).astype(np.int32)
+    pi = rng.integers(0, P, n_obs).astype(np.int32)
+    uv = rng.uniform(0, 5000, (n_obs, 2))
+    calib = np.array([3666.6665, 3666.6665, 2736.0, 1824.0, -0.12, 0.083, -0.0016, -0.00096, -0.012])
+    d = [_dev(a) for a in (cams, pts, ci, pi, uv, calib)]
+    r = torch.full((2 * n_obs + 8,), 777.0, dtype=torch.float64, device='cuda')
+    _lib.check(_lib.lib().iamx_ba_residual_prepared(_ptr(d[0]), C, _ptr(d[1]), P, _ptr(d[2]), _ptr(d[3]),
+                                                    _ptr(d[4]), n_obs, _ptr(d[5]), None, _ptr(r),
+                                                    stream_ptr()), 'iamx_ba_residual_prepared')
+    got = r.cpu().numpy()
+    rr = cpu_ref.ba_residual(cams, pts, ci, pi, uv, calib[:4], calib[4:])
+    assert np.abs(got[:2 * n_obs] - rr).max() / np.abs(rr).max() < TIGHT
+    assert np.all(got[2 * n_obs:] == 777.0)              # nothing written past the end
+
+
 def test_config3_full_size_residual_and_operator():
     """BASELINE configs[3] at its full size (2812 cameras, ~270 k points, ~1.96 M observations):
     the residual against the plain-C oracle, and J v / J^T u of the device kernels against a SciPy

@@ -99,7 +99,7 @@ def _run_find_matches(rank, world, port, outdir):
     names = ['D%02d' % i for i in range(len(des))]
     proj = PoseProject(names)
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         f = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = f.des_list, f.kp_list
     matcher.detector_node.setString('detector', 'SIFT')
@@ -261,7 +261,7 @@ def _run_find_matches_again(rank, world, port, outdir):
     names = ['D%02d' % i for i in range(len(des))]
     proj = PoseProject(names)
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         f = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = f.des_list, f.kp_list
     matcher.detector_node.setString('detector', 'SIFT')
@@ -320,7 +320,7 @@ def _run_round0_failure(rank, world, port, where):
     names = ['D%02d' % i for i in range(len(des))]
     proj = PoseProject(names)
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         f = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = f.des_list, f.kp_list
     matcher.detector_node.setString('detector', 'SIFT')

@@ -16,6 +16,11 @@ MATCH_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'match_*.npz')))
 BA_CASES = sorted(glob.glob(os.path.join(GOLDEN, 'ba_*.npz')))
 
 
+# The synthetic strips below copy keypoints from image i-1 to image i with a pixel shift of
+# (+250, -120): with the FC6310S camera 100 m above the ground that is a camera step of 3.27 m
+# south and 6.82 m west, and the poses say so -- find_matches feeds the yaw error it estimates from
+# the matches back into the poses (scripts/lib/matcher.py:990-993), so a strip whose poses
+# contradict its pixels has its pairs triangulated to nonsense and discarded (:1001-1005).
 def _configure(match_ratio=0.75, min_pairs=25, w=5472, h=3648):
     from imageanalysis_amd import matcher
     from imageanalysis_amd.hostlib import camera
@@ -121,7 +126,7 @@ def test_find_matches_batched_equals_pairwise_oracle():
         des.append(d)
         xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         fresh = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
     proj.image_list[0].match_list['S01'] = [[1, 2]]          # "already done" -> skipped
@@ -172,7 +177,7 @@ def test_find_matches_growing_arena_and_oversize_pairs():
         des.append(d)
         xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         fresh = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
     old = matcher.PAIRS_PER_BATCH
@@ -355,7 +360,7 @@ def test_smart_json_written_ahead_of_time_equals_the_final_one(tmp_path, sort):
             out.mkdir()
             proj = PoseProject(names, analysis_dir=str(out))
             for i, im in enumerate(proj.image_list):
-                im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+                im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
                 fresh = _image(names[i], des[i], xy[i])
                 im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
             matcher.PAIRS_PER_BATCH, matcher.EARLY_SMART_ROUNDS = 2, after
@@ -409,7 +414,7 @@ def test_find_matches_dense_routing_gives_the_same_lists(route):
         des.append(d)
         xy.append(np.clip(p, 0, [W - 1, H - 1]).astype(np.float32))
     for i, im in enumerate(proj.image_list):
-        im.set_camera_pose([0.0, 25.0 * i, -100.0], 0.0, -90.0, 0.0)
+        im.set_camera_pose([-3.2727 * i, -6.8182 * i, -100.0], 0.0, -90.0, 0.0)
         fresh = _image(names[i], des[i], xy[i])
         im.des_list, im.kp_list = fresh.des_list, fresh.kp_list
     old = (matcher.PAIRS_PER_BATCH, matcher.DENSE_ROUTE, matcher.DENSE_SHARE, matcher.DENSE_PROBE)

@@ -44,8 +44,8 @@ def main():
     launch = [q.bound_launchers()[0] for q in rot]
     ref = None
     print("configs[3]: %d cameras, %d points, %d observations; 64 B/obs = %.1f MB per evaluation" % (C, P, O, 64e-6 * O))
-    for form, wgs in (('lds', 0), ('pipe', 256), ('pipe', 512), ('pipe', 768), ('pipe', 1024), ('pipe', 1536),
-                      ('pipe', 2048), ('pipe', 3072)):
+    grids = [int(a) for a in sys.argv[1:]] or [128, 192, 256, 320, 384, 512, 768, 1024, 2048]
+    for form, wgs in [('lds', 0)] + [('pipe', g) for g in grids]:
         os.environ['IAMX_BA_RESIDUAL'] = form
         if wgs:
             os.environ['IAMX_BA_RESIDUAL_WGS'] = str(wgs)
@@ -64,25 +64,29 @@ def main():
         print("%-4s wgs %4d: hot %6.2f us (%.3f of 8 TB/s), rotating %6.2f us (%.3f)%s"
               % (form, wgs, t_hot * 1e6, 64.0 * O / t_hot / 1e9 / HBM, t_cold * 1e6,
                  64.0 * O / t_cold / 1e9 / HBM, same))
-    # the yardstick: 62.5 MB read + 62.5 MB written per launch, six buffers in rotation
-    n_el = int(62.5e6 // 16)
-    srcs = [torch.empty(2 * n_el, dtype=torch.float64, device='cuda').normal_() for _ in range(n_rot)]
-    dsts = [torch.empty(2 * n_el, dtype=torch.float64, device='cuda') for _ in range(n_rot)]
+    # the yardsticks: 125 MB moved per launch, six buffers in rotation (and back to back): a copy
+    # (62.5 MB read + 62.5 MB written) and the residual's own mix (94 MB read + 31 MB written)
     L = _lib.lib()
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for wg in (1024, 2048, 4096, 8192):
-        def rot_copy():
-            for a_, b_ in zip(srcs, dsts):
-                L.iamx_hbm_copy16(ctypes.c_void_p(a_.data_ptr()), ctypes.c_void_p(b_.data_ptr()), n_el, wg, st)
-        t = timed(rot_copy, 20) / n_rot
-        print("copy16 %5d workgroups, rotating: %6.2f us = %.0f GB/s (%.3f of 8 TB/s)"
-              % (wg, t * 1e6, 2 * n_el * 16 / t / 1e9, 2 * n_el * 16 / t / 1e9 / HBM))
+    for k in (1, 3):
+        n_out = int(125.5e6 / (k + 1)) // 16
+        srcs = [torch.empty(2 * n_out * k, dtype=torch.float64, device='cuda').normal_() for _ in range(n_rot)]
+        dsts = [torch.empty(2 * n_out, dtype=torch.float64, device='cuda') for _ in range(n_rot)]
+        for wg in (1024, 2048, 8192):
+            def one(a_=srcs[0], b_=dsts[0]):
+                L.iamx_hbm_copy16(ctypes.c_void_p(a_.data_ptr()), ctypes.c_void_p(b_.data_ptr()), n_out, k, wg, st)
 
-    def rot_torch():
-        for a_, b_ in zip(srcs, dsts):
-            b_.copy_(a_)
-    t = timed(rot_torch, 20) / n_rot
-    print("torch copy_, rotating: %6.2f us = %.0f GB/s" % (t * 1e6, 2 * n_el * 16 / t / 1e9))
+            def rot_copy():
+                for a_, b_ in zip(srcs, dsts):
+                    one(a_, b_)
+            t_hot = timed(one, 100)
+            t = timed(rot_copy, 20) / n_rot
+            by = n_out * 16 * (k + 1)
+            print("stream %d:1 read:write, %5d workgroups: hot %6.2f us (%.3f), rotating %6.2f us = %.0f GB/s "
+                  "(%.3f of 8 TB/s)" % (k, wg, t_hot * 1e6, by / t_hot / 1e9 / HBM, t * 1e6, by / t / 1e9,
+                                        by / t / 1e9 / HBM))
+        del srcs, dsts
+        torch.cuda.empty_cache()
 
 
 if __name__ == '__main__':
