@@ -541,7 +541,8 @@ def main():
             "unresolved": m["unresolved"],
             "verified_pairs": verified["verified_pairs"] if verified else 0, "verify": verified,
             "roofline": roofline, "cpu_baseline": cpu, "config1_500": survey,
-            "per_rank_seconds": m.get("per_rank_seconds"), "gather": m.get("gather"),
+            "per_rank_seconds": m.get("per_rank_seconds"),
+            "per_rank_sweep_seconds": m.get("per_rank_sweep_seconds"), "gather": m.get("gather"),
             "dense_overlap": dense,
             "host_postprocess": host_post, "ba": ba,
             "sift": sift, "cleanup": cleanup,

@@ -189,5 +189,7 @@ def test_config4_at_512_frames_bounded_device_memory():
     routed = out["route_rounds"]["one_direction"] > 0
     assert rep["descriptor_arena_bytes"] / float(rep["descriptor_rows"]) < (440.0 if routed else 300.0)
     assert rep["pooled_workspace_bytes"] <= 3 * matcher.BATCH_BYTES
-    assert out["peak_hbm_bytes"] <= model["peak_bytes"] + 24 * 2 ** 30     # (+ 8 SIFT slots, BA)
+    # (+ 8 SIFT slots, BA; the model is evaluated at the MEAN keypoint count, the run sizes its
+    #  workspaces for 1.25 x the LARGEST count it knows: a few per cent of three 20 GB workspaces)
+    assert out["peak_hbm_bytes"] <= 1.05 * model["peak_bytes"] + 24 * 2 ** 30
     print({k: out[k] for k in ("stage_seconds", "total_seconds", "peak_hbm_bytes", "hbm_after_match", "hbm_model")})
