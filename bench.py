@@ -35,7 +35,7 @@ FLOP_PER_PAIR = 2.0 * KPTS * KPTS * DIM          # one distance matrix serves bo
 I8_DENSE_PEAK_TFLOPS = 5000.0                    # the task's dense i8 / fp8 nameplate (2 x the 2.5 PF bf16 dense figure); the guide has no i8 spec line,
                                                  # only the micro-benchmark below -- `frac` is against this, `frac_of_guide_ubench_3944` against that
 I8_UBENCH_TOPS = 3944.0                          # the guide's measured i8 MFMA micro-benchmark rate
-KNN2SYM_TRAFFIC_FILE = 'r5_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
+KNN2SYM_TRAFFIC_FILE = 'r6_knn2sym_traffic.json' # tools/update_traffic_json.py (PMC passes)
 CONFIG1_IMAGES = 500                             # configs[1]: C(500, 2) = 124 750 pairs
 CONFIG2_IMAGES = 2812                            # configs[2]: 3 952 266 pairs
 E2E_FRAMES = 128                                 # configs[4] slice of the default run (rendered 20 MP frames)
@@ -1284,7 +1284,7 @@ def sift_bench(rank, world, dev, dist, args):
                          "frac": round(alg / t_k / 1e9 / 8000.0, 4), "bytes_per_image": alg,
                          "traffic": sift_tr, "traffic_source": sift_tr_src,
                          "timing": "hipEvents around %d whole detects on the launch stream, steady state "
-                                   "(3 untimed before); per-kernel durations: profiles/r5_kernel_stats.txt "
+                                   "(3 untimed before); per-kernel durations: profiles/r6_kernel_stats.txt "
                                    "(rocprofv3 --kernel-trace --stats of the bench command)" % N_K},
             "concurrent_8": None if t_conc is None else {
                 "ms_per_image": round(t_conc * 1e3, 3), "achieved": round(alg / t_conc / 1e9, 1), "peak": 8000.0,
@@ -1463,7 +1463,7 @@ def ba_bench(rank, world, dev, dist, args):
         lsmr["traffic"], lsmr["traffic_source"] = aux_traffic(
             ('lsmr_fwd_kernel', 'lsmr_adj_kernel', 'lsmr_update3_kernel'), 'lsmr_update3_kernel')
         lsmr["timing"] = ("wall clock around %d fused iterations, queue kept full; per-kernel durations: "
-                          "profiles/r5_kernel_stats.txt" % its)
+                          "profiles/r6_kernel_stats.txt" % its)
     schur_it = None
     if world == 1:
         # one CG iteration of the Schur solver = three passes over the stored Jacobian blocks
@@ -1492,7 +1492,7 @@ def ba_bench(rank, world, dev, dist, args):
             ('schur_fwd_kernel', 'schur_pt_kernel', 'schur_adj_kernel', 'schur_pq_kernel',
              'schur_update1_kernel', 'schur_update2_kernel'), 'schur_fwd_kernel')
         schur_it["timing"] = ("wall clock, difference of a %d- and an 8-iteration solve; per-kernel "
-                              "durations: profiles/r5_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
+                              "durations: profiles/r6_kernel_stats.txt, profiles/r3_ba_schur_trace.txt"
                               % its)
     cpu = None                                              # filled in by main() at the end
     def cold(t, bytes_per_obs):
@@ -1555,7 +1555,7 @@ def ba_bench(rank, world, dev, dist, args):
             "dtype": "f64", "parallelism": "point-shard x%d" % world}
 
 
-AUX_TRAFFIC_FILE = 'r5_ba_sift_traffic.json'
+AUX_TRAFFIC_FILE = 'r6_ba_sift_traffic.json'
 
 
 def aux_traffic(bases, per):

@@ -9,14 +9,14 @@ import os
 import re
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r4'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r6'
 prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 SIFT = ('gray_up2x_kernel', 'blur_strip_kernel', 'downsample_kernel', 'extrema_kernel',
         'extrema_multi_kernel',
         'pyramid_tail_kernel', 'refine_kernel', 'orient_kernel', 'descriptor_kernel',
         'sort_count_kernel', 'sort_offsets_kernel', 'sort_scatter_kernel', 'sort_rank_kernel',
         'sort_compact_kernel', 'sort_gather_kernel')
-BA = ('ba_residual_lds_kernel', 'ba_residual_jac_kernel', 'acc_cam_kernel', 'acc_pt_kernel',
+BA = ('ba_residual_lds_kernel', 'ba_residual_pipe_kernel', 'ba_residual_jac_kernel', 'acc_cam_kernel', 'acc_pt_kernel',
       'schur_points_kernel', 'schur_fwd_kernel', 'schur_pt_kernel', 'schur_adj_kernel',
       'schur_pq_kernel', 'schur_update1_kernel', 'schur_update2_kernel',
       'schur_calib_reduce_kernel', 'schur_factor_kernel',

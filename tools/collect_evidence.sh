@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round evidence in one go (GPU box; run from the repository root through gpurun):
-#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r4)
+#   bash tools/collect_evidence.sh [tag]        -> gpurun_out/<tag>_*.{txt,json}   (default tag r6)
 # Raw rocprofv3 output goes to /tmp (gpurun merges at most 64 MiB back); the summaries come back
 # under gpurun_out/ -- copy the judged ones to profiles/ afterwards (tools/pull_evidence.sh).  Counter passes are separate runs with --pmc only.
-TAG="${1:-r5}"
+TAG="${1:-r6}"
 OUT="$PWD/gpurun_out"
 REPO="$PWD"
 mkdir -p "$OUT"
@@ -34,7 +34,7 @@ fi
 
 step "PMC: HBM traffic of the matching step (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err)
+    (cd /tmp && timeout 1200 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err)
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/p_$C "$OUT/${TAG}_knn2sym_pmc_${lc}.txt" > /dev/null
 done
@@ -49,7 +49,7 @@ done
 python "$REPO/tools/aux_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_ba_sift_traffic.json" "$OUT/"
 fi
 step "PMC: SQ / MFMA busy"
-(cd /tmp && timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
+(cd /tmp && timeout 1200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
     --output-format csv -d /tmp/p_sq -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_sq.err)
 $SUM /tmp/p_sq "$OUT/${TAG}_knn2sym_pmc_sq.txt" > /dev/null
@@ -64,13 +64,13 @@ python "$REPO/tools/update_traffic_json.py" "$TAG" || FAILED=1
 [ -f "$REPO/profiles/${TAG}_knn2sym_traffic.json" ] && cp "$REPO/profiles/${TAG}_knn2sym_traffic.json" "$OUT/"
 
 step "bench"
-timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
+timeout 1500 python bench.py --steps 20 --warmup 5 > "$OUT/${TAG}_bench_latest.json" 2> "$OUT/${TAG}_bench_latest.err"
 tail -c 600 "$OUT/${TAG}_bench_latest.json"; echo
 
 fi
 if [ "${STAGE:-AB}" != "A" ]; then
 step "kernel stats of the bench command"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
+(cd /tmp && timeout 1500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- \
     python "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-survey > "$OUT/${TAG}_bench_under_rocprof.json" 2> /tmp/p_stats.err)
 $SUM /tmp/p_stats "$OUT/${TAG}_kernel_stats.txt" > /dev/null
 python "$REPO/tools/prof_gaps.py" /tmp/p_stats lsmr > "$OUT/${TAG}_lsmr_gaps.txt" 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # After a gpurun call of tools/collect_evidence.sh: copy the judged summaries from gpurun_out/
 # (scratch, merged back by gpurun) into profiles/ (tracked).   bash tools/pull_evidence.sh [tag]
-TAG="${1:-r5}"
+TAG="${1:-r6}"
 cd "$(dirname "$0")/.."
 for f in knn2sym_pmc_fetch.txt knn2sym_pmc_write.txt knn2sym_pmc_sq.txt knn2sym_traffic.json \
          aux_pmc_fetch.txt aux_pmc_write.txt ba_sift_traffic.json kernel_stats.txt \
