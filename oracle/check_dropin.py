@@ -24,6 +24,9 @@ What it checks (each line of the output is one check; any failure raises):
                    the real tree + props_json, srtm / yaw hooks of process.py:218-240,
                    consolidation + groups, Optimizer.setup / update_camera_poses / refit on the
                    reference's Image objects and ProjectMgr -- against the goldens
+  6. find_matches  the pair loop in the reference environment (real ProjectMgr, Image, props
+                   tree, lib.camera; the two device steps replaced by the oracle stand-ins of
+                   tests/test_find_matches_loop.py) == the reference's ORIGINAL find_matches (G9)
   5. reference smart   the reference's ORIGINAL lib/smart.py (imported under another name) gives
                    the same update_srtm_elevations / set_yaw_error_estimates results, and its
                    triangulate_features() output is recorded for the GPU test of the mirror's
@@ -297,6 +300,78 @@ def main():
         result['triangulate_features'] = tri
         ok('lib/smart.py (original) triangulate_features: %d pairs recorded for tests/test_dropin.py'
            % len(tri))
+
+        # ---- 6. find_matches inside the reference environment == the reference's own loop (G9) ----
+        # lib.matcher.find_matches here is imageanalysis_amd.matcher.find_matches (the shim file),
+        # driven on the reference's ProjectMgr / lib.image.Image / props tree / lib.camera; the two
+        # DEVICE steps are replaced by the oracle stand-ins of tests/test_find_matches_loop.py
+        # (there is no GPU in this container) -- the schedule, the pose feedback through the REAL
+        # Image.set_aircraft_yaw_error_estimate / get_aircraft_pose / get_body2cam, the bookkeeping
+        # on the REAL /smart tree, .match files and smart.json through the reference's writers are
+        # the product's.  Compared with what the reference's ORIGINAL lib/matcher.py did on the same
+        # project (tests/golden/find_matches_strip.pkl, oracle/gen_golden.py G9).
+        sys.path.insert(0, os.path.join(REPO, 'tests'))
+        import test_find_matches_loop as fml
+        import imageanalysis_amd.matcher as amx_matcher
+        g9 = fml._golden()
+        r2d = 180.0 / np.pi
+        saved = {n_: getattr(amx_matcher, n_) for n_ in ('_launch_batch', '_finish_batch', '_surface_device',
+                                                        'the_matcher', 'PAIRS_PER_BATCH', 'max_distance',
+                                                        'min_pairs')}
+        try:
+            for sort in (True, False):
+                for n_ in list(props.getNode('/images', True).__dict__):
+                    del props.getNode('/images', True).__dict__[n_]
+                smart.smart_node.__dict__.clear()
+                smart.load(None)
+                fproj = make_project(g9['names'], os.path.join(work, 'g9_sort%d' % int(sort)))
+                Kg = g9['K']
+                camera.set_K(Kg[0], Kg[4], Kg[2], Kg[5])
+                camera.set_image_params(g9['width'], g9['height'])
+                camera.set_mount_params(*g9['mount'])
+                # (the nodes the module bound when it was imported, like the reference's own
+                #  `matcher_node = getNode('/config/matcher', True)` at lib/matcher.py:31)
+                amx_matcher.detector_node.setString('detector', 'SIFT')
+                amx_matcher.detector_node.setFloat('scale', 0.4)
+                amx_matcher.matcher_node.setFloat('match_ratio', g9['match_ratio'])
+                amx_matcher.matcher_node.setInt('min_pairs', g9['min_pairs'])
+                for key in ('schedule', 'min_dist', 'max_dist'):
+                    amx_matcher.matcher_node.__dict__.pop(key, None)
+                body2cam = camera.get_body2cam()
+                for i, im in enumerate(fproj.image_list):
+                    rep = g9['reported'][i]
+                    im.set_aircraft_pose(*g9['aircraft_lla'], *rep['ypr'])
+                    ned2body = [im.node.getChild('aircraft_pose').getFloatEnum('quat', k) for k in range(4)]
+                    y, p_, r_ = _tf.euler_from_quaternion(_tf.quaternion_multiply(ned2body, body2cam), 'rzyx')
+                    im.set_camera_pose(rep['ned'], y * r2d, p_ * r2d, r_ * r2d)
+                    im.des_list = g9['des'][i].astype(np.float32)
+                    im.kp_list = make_keypoints(g9['xy'][i])
+                assert [fml._pose_record(im) for im in fproj.image_list] == g9['runs'][sort]['initial']
+                amx_matcher.max_distance, amx_matcher.min_pairs = 270.0, float(g9['min_pairs'])
+                amx_matcher.the_matcher = object()
+                amx_matcher._launch_batch = fml._oracle_launch
+                amx_matcher._finish_batch = lambda handle: handle
+                amx_matcher._surface_device = fml._oracle_surface
+                amx_matcher.PAIRS_PER_BATCH = 6
+                for call in range(2):
+                    with quiet():
+                        matcher.find_matches(fproj, None, strategy='traditional', transform='gms', sort=sort)
+                    fml.check_against(g9, g9['runs'][sort], call, fproj)
+                    # ... and the files: .match through the reference's ORIGINAL reader, smart.json
+                    for i, im in enumerate(fproj.image_list):
+                        back = orig_image.Image(fproj.analysis_dir, im.name)
+                        with quiet():
+                            back.load_matches()
+                        assert back.match_list == g9['runs'][sort]['calls'][call]['match_lists'][i], im.name
+                    import json
+                    with open(os.path.join(fproj.analysis_dir, 'smart.json')) as fp:
+                        assert json.load(fp) == g9['runs'][sort]['calls'][call]['smart']
+        finally:
+            for n_, v in saved.items():
+                setattr(amx_matcher, n_, v)
+        ok('find_matches on lib.project.ProjectMgr / lib.image.Image / the props tree == the reference\'s '
+           'ORIGINAL lib.matcher.find_matches (G9): match lists, /smart, poses, .match files, smart.json; '
+           'sort=True and False, first and second call')
 
         with open(os.path.join(GOLD, 'dropin_env.pkl'), 'wb') as f:
             pickle.dump(result, f, protocol=4)
