@@ -163,9 +163,11 @@ def test_config4_at_128_frames_distance_schedule():
     assert 0 < out["peak_hbm_bytes"] < 200 * 2 ** 30
 
 
-def test_config4_at_512_frames_bounded_device_memory():
-    """BASELINE configs[4] at 512 rendered 20 MP frames (the judge's "a -m gpu test at >= 512
-    frames"): one connected block, sub-pixel residuals -- and the device memory the matching stage
+def test_config4_at_2048_frames_bounded_device_memory():
+    """BASELINE configs[4] at 2048 rendered 20 MP frames, rendered / detected / deleted 1024 at a
+    time like the 10 011-frame run of profiles/r6_e2e_full_10000.json (the whole survey's JPEGs
+    need not fit the scratch disk): one connected block, sub-pixel residuals -- and the device
+    memory the matching stage
     holds is what matcher.device_memory_model() says it is: the descriptor arena (the ONLY part
     that grows with the survey: two layouts x 140-144 B per row, no parity-partitioned copy) within
     5 % of the model, the pooled per-round workspaces inside the BATCH_BYTES budget, the peak of
@@ -173,13 +175,15 @@ def test_config4_at_512_frames_bounded_device_memory():
     sys.path.insert(0, REPO)
     import bench
     from imageanalysis_amd import matcher
-    out = bench.e2e_bench(512, full_frame=True, schedule='distance')
+    out = bench.e2e_bench(2048, full_frame=True, schedule='distance', window=1024)
     n = out["images"]
-    assert n >= 512 and out["schedule"] == 'distance' and out["groups"] == [n]
+    assert n >= 2048 and out["window_frames"] == 1024 and out["schedule"] == 'distance' and out["groups"] == [n]
     ba = out["ba"]
     assert ba["cameras"] == n and ba["mean_abs_residual_px_before"] > 10.0
     assert ba["mean_abs_residual_px_after"] < 1.0
-    assert abs(out["baseline_scale"] - 1.0) < 0.03 and out["max_baseline_error_m"] < 1.0
+    # (camera-to-camera distances up to 2.6 km across the block, against the truth the frames were
+    #  rendered from, one gauge scale: 0.95 m at 2048 frames in round 5)
+    assert abs(out["baseline_scale"] - 1.0) < 0.03 and out["max_baseline_error_m"] < 2.0
     rep, model = out["hbm_after_match"], out["hbm_model"]
     assert rep["images"] == n and rep["descriptor_rows"] == pytest.approx(n * out["keypoints_per_image"], rel=0.01)
     assert 0.9 * model["arena_bytes"] <= rep["descriptor_arena_bytes"] + rep["keypoint_arena_bytes"] \
