@@ -9,7 +9,11 @@ REPO="$PWD"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 SUM="python $REPO/tools/prof_summary.py"
-BENCH_PMC="python $REPO/bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey"
+# (counter passes on the 500-image survey: the same kernel instantiation and the same launch
+#  shape -- 4096 image pairs of 4096 x 4096 rows per launch -- as the 2812-image headline, 31
+#  launches instead of 965; rocprofv3 --pmc segfaults inside the 2812-image run on this pool's
+#  image, 6 s in, before the first sweep: profiles/r6_pmc_2812_segfault.txt)
+BENCH_PMC="python $REPO/bench.py --images 500 --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey"
 # BA + SIFT kernels (a small matching section in front of them)
 AUX_PMC="python $REPO/bench.py --images 64 --steps 1 --warmup 0 --no-cpu-baseline --verify-pairs 0 --no-e2e --no-sift-full --no-survey"
 

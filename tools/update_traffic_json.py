@@ -29,7 +29,7 @@ gui, _, _ = counter('%s_knn2sym_pmc_sq.txt' % tag, 'GRBM_GUI_ACTIVE')
 mops, _, _ = counter('%s_knn2sym_pmc_sq.txt' % tag, 'SQ_INSTS_VALU_MFMA_MOPS_I8')
 path = os.path.join(prof, '%s_knn2sym_traffic.json' % tag)
 d = json.load(open(path)) if os.path.exists(path) else {
-    "workload": "configs[2] (the metric's own survey), 2812 images, 965 launches of <= 4096 image pairs (both directions each)",
+    "workload": "counter passes on configs[1] (500 images, 31 launches of <= 4096 image pairs, both directions each): the same kernel instantiation and launch shape as the 2812-image headline (965 such launches); rocprofv3 --pmc segfaults inside the 2812-image run on this pool's image",
     "fetch_correction": "x2 on gfx950 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-B requests at 64 B)",
     "algorithmic_bytes_per_launch": 4024 * 1179648}
 d['kernel'] = re.sub(r'^kernel (void )?\(anonymous namespace\)::', '', kname).split('(')[0] + \
@@ -38,10 +38,10 @@ d['FETCH_SIZE_avg_per_launch_KB'] = round(fetch)
 d['WRITE_SIZE_avg_per_launch_KB'] = round(write)
 d['hbm_bytes_per_launch'] = int(round(fetch) * 1024 * 2 + round(write) * 1024)
 d['source'] = ('profiles/%s_knn2sym_pmc_fetch.txt, profiles/%s_knn2sym_pmc_write.txt (separate rocprofv3 --pmc passes of '
-               'bench.py --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey)' % (tag, tag))
+               'bench.py --images 500 --steps 1 --warmup 0 --no-ba --no-sift --no-cpu-baseline --verify-pairs 0 --no-e2e --no-survey)' % (tag, tag))
 d['mfma_busy'] = round(busy / (gui / 8 * 1024), 4)
 d['mfma_busy_source'] = ('profiles/%s_knn2sym_pmc_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES %.4g / (GRBM_GUI_ACTIVE '
-                         '%.4g / 8 XCDs x 1024 SIMDs), the same bench command (2812-image survey); the pipe executes '
+                         '%.4g / 8 XCDs x 1024 SIMDs), the same 500-image bench command; the pipe executes '
                          'ONE pass per distance matrix (%.4g MFMA_MOPS_I8 per dispatch = 4096 pairs x '
                          '65536 MFMAs)' % (tag, busy, gui, mops))
 # refuse a summary of a kernel the library does not launch (IAMX_EXPECT_KERNEL = iamx_knn2sym_kernel_id(2))
