@@ -382,6 +382,9 @@ def main():
                     help='BASELINE configs[4] at scale: N rendered 5472 x 3648 frames (N >= 512 asked '
                          'for) through the whole chain on one GPU, neighbour + distance-window '
                          'schedule; rendering and writing N JPEGs takes ~0.1 s per frame, untimed')
+    ap.add_argument('--e2e-fused', action='store_true',
+                    help='with --e2e-full: no separate detection stage; find_matches detects on demand '
+                         'as scripts/process.py calls it (detection overlaps the first rounds of matching)')
     ap.add_argument('--e2e-window', type=int, default=0, metavar='F',
                     help='with --e2e-full: render, detect and delete the JPEGs F frames at a time '
                          '(a survey whose JPEGs do not fit the scratch disk: 10 000 x 20 MP = 80 GB)')
@@ -502,7 +505,7 @@ def main():
             e2e = e2e_bench(E2E_FRAMES, full_frame=True, schedule='distance')
         if args.e2e_full > 0:
             e2e_big = e2e_bench(args.e2e_full, full_frame=True, schedule='distance',
-                                window=args.e2e_window)
+                                window=args.e2e_window, fused=args.e2e_fused)
         if args.e2e > 0:
             e2e_small = e2e_bench(args.e2e)
     # CPU baselines of the BA and SIFT sections run AFTER every timed GPU section: their OpenMP /
@@ -744,7 +747,7 @@ def dense_overlap_bench(dev, oracle_pairs=4, n_img=12, rows=16384):
             "verified_pairs": checked, "against": "oracle/cpu_ref.c"}
 
 
-def e2e_bench(n_images, full_frame=False, schedule=None, window=0):
+def e2e_bench(n_images, full_frame=False, schedule=None, window=0, fused=False):
     """BASELINE configs[4] shape on one GPU: a rendered survey of n_images JPEGs on disk goes
     through the drop-in entry points exactly as scripts/process.py:236-407 drives the reference's
     modules -- Image.detect_features, matcher.find_matches, match_cleanup.*, groups.compute,
@@ -756,6 +759,11 @@ def e2e_bench(n_images, full_frame=False, schedule=None, window=0):
     frames), 'distance' (neighbours in the list + every pair inside the reference's distance
     window, scripts/lib/matcher.py:886-903: the shape of a survey of hundreds / thousands of
     frames) or 'neighbours' (the reference at HEAD).
+    fused: no separate detection stage -- find_matches() meets undetected images and detects them
+    on demand, exactly as scripts/process.py:290 calls it (the reference has no detection stage of
+    its own either, lib/matcher.py:961-968): the decode / SIFT of the images later rounds need runs
+    on the prefetch workers' streams WHILE the first rounds of the distance-sorted schedule are
+    matched; the stage is reported as "detect+match".
     window > 0: the survey does not fit the scratch disk as JPEGs (10 000 frames of 20 MP are
     80 GB): it is rendered `window` frames at a time, every window goes through detect_features
     (timed: the detect stage is the sum over the windows) and its JPEGs are deleted; the cache
@@ -886,11 +894,17 @@ def e2e_bench(n_images, full_frame=False, schedule=None, window=0):
                                                               on_frames=on_frames)
         out["render_seconds_untimed"] = round(time.perf_counter() - t0 - stages.get("detect", 0.0), 2)
         W, H = int(2 * K[0, 2]), int(2 * K[1, 2])
-        if not window:
+        if not window and not fused:
             timed("detect", lambda: detect(proj.image_list))
+        out["fused_detect_and_match"] = bool(fused and not window)
+        def match():
+            matcher.find_matches(proj, K, strategy='traditional', transform='homography', sort=True)
+            iimg.cacheio.wait()
+        timed("detect+match" if out["fused_detect_and_match"] else "match", match)
+        for im in proj.image_list:                       # (the periodic flush may have dropped some)
+            if im.kp_list is None:
+                im.load_features()
         out["keypoints_per_image"] = int(np.mean([len(im.kp_list) for im in proj.image_list]))
-        timed("match", lambda: matcher.find_matches(proj, K, strategy='traditional',
-                                                    transform='homography', sort=True))
         out["image_pairs_matched"] = sum(len(im.match_list) for im in proj.image_list) // 2
         out["route_rounds"] = {"mode": matcher.DENSE_ROUTE, "symmetric": matcher._route['rounds'][0],
                                "one_direction": matcher._route['rounds'][1],
