@@ -47,6 +47,7 @@ max_distance = None
 min_pairs = 25
 
 MYMAX = 2000            # matcher.py:265
+SAVE_INTERVAL = 300     # seconds between the periodic saves of find_matches (matcher.py:923)
 PAIRS_PER_BATCH = 16384 # unordered pairs per device batch (per-batch host costs are ~3 ms: 4096 -> 16384
                         # took 0.5 s off the 2812-image all-pairs survey, profiles/r4_fm_config2.txt)
 BATCH_BYTES = 24 << 30  # ... as far as one batch's device workspace stays below this (three are pooled:
@@ -1856,7 +1857,7 @@ class _MatchRun(object):
         image_list, wi, wj = self.image_list, self.wi, self.wj
         rank, ws, n_pending = self.rank, self.ws, self.n_pending
         self.save_time = time.time()
-        self.save_interval = 300     # seconds
+        self.save_interval = SAVE_INTERVAL     # seconds
         _log("Processing worklist matches:")
         if ws > 1 and self.device and n_pending:
             # every image of the work list is detected by ONE rank; descriptors and keypoint

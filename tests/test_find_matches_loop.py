@@ -187,6 +187,15 @@ def test_pair_loop_equals_reference_loop_host_logic(tmp_path, _restore, sort, na
     _run_cpu(0, 1, 0, str(tmp_path), sort)
 
 
+def test_pair_loop_with_a_periodic_save_after_every_round(tmp_path, _restore, monkeypatch):
+    """the periodic save (scripts/lib/matcher.py:1008-1026: .match files of the dirty images,
+    smart.json, the descriptor cache flush) in the middle of the loop changes nothing: every round
+    is followed by one here"""
+    from imageanalysis_amd import matcher
+    monkeypatch.setattr(matcher, 'SAVE_INTERVAL', 0)
+    _run_cpu(0, 1, 0, str(tmp_path), True)
+
+
 @pytest.mark.parametrize('sort', [True, False])
 def test_pair_loop_equals_reference_loop_world2_gloo(tmp_path, sort):
     import torch.multiprocessing as mp
