@@ -219,3 +219,79 @@ def test_find_matches_equals_reference_loop(sort, ppb, monkeypatch):
     for call in range(2):
         matcher.find_matches(proj, None, strategy='traditional', transform='gms', sort=sort)
         check_against(g, g['runs'][sort], call, proj)
+
+
+def test_pose_feedback_native_replay_equals_python_replay_on_random_schedules():
+    """smart.PoseFeedback: libiamx's iamx_yaw_feedback_* against the python form it stands in for,
+    on random rounds -- pairs with matches and quiet pairs mixed, fits missing on either side,
+    yaw errors beyond the 30 degree gate, pairs closer than 0.5 m, large weights, entries an
+    earlier call left in the tree -- every estimate handed out and every final value bit-equal."""
+    from imageanalysis_amd import smart
+    from imageanalysis_amd._deps import getNode
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    rng = np.random.default_rng(2026)
+    n_img = 40
+    names = ['Z%03d' % i for i in rng.permutation(n_img)]      # (name order != index order)
+    for n_ in names:
+        getNode('/images', True).__dict__.pop(n_, None)
+    smart.smart_node.__dict__.clear()
+    smart.load(None)
+    proj = PoseProject(names)
+    # what an earlier call left: a few yaw_pairs entries, written the way the module writes them
+    for _ in range(25):
+        a, b = rng.choice(n_img, 2, replace=False)
+        smart._record_yaw(proj.image_list[a], proj.image_list[b], float(rng.normal(0, 12)),
+                          float(rng.uniform(0.2, 60)), float(rng.uniform(0, 360)), float(rng.uniform(0, 50)))
+    fbs = [smart.PoseFeedback(proj.image_list, native=True), smart.PoseFeedback(proj.image_list, native=False)]
+    assert fbs[0]._native is not None and fbs[1]._native is None
+    seq0 = 0
+    for rnd in range(30):
+        n = int(rng.integers(1, 60))
+        pi = rng.integers(0, n_img - 1, n).astype(np.int32)
+        pj = (pi + 1 + rng.integers(0, n_img - 1 - pi)).astype(np.int32)
+        quiet = rng.random(n) < 0.4
+        hit_rows = np.nonzero(~quiet)[0].astype(np.int64)
+        h = len(hit_rows)
+        yv = lambda: np.stack([rng.normal(0, 14, h), rng.choice([0.3, 5.0, 40.0, 123.4], h),
+                               rng.uniform(0, 360, h), np.abs(rng.normal(0, 30, h)) ** rng.choice([1, 3], h)], 1)
+        yv_f, yv_r = yv(), yv()
+        ok = rng.random((h, 2)) < 0.85
+        seq = seq0 + np.arange(n, dtype=np.int64)
+        seq0 += n
+        outs = [fb.feed(seq, pi, pj, quiet, hit_rows, yv_f, yv_r, ok) for fb in fbs]
+        for a, b in zip(outs[0], outs[1]):
+            assert list(a) == list(b), rnd
+    fbs[0]._sync_native()
+    assert list(fbs[0].value) == [float(v) for v in fbs[1].value]
+    assert list(fbs[0].touched) == list(fbs[1].touched)
+
+
+@pytest.mark.gpu
+def test_triangulate_packed_equals_the_per_image_form():
+    """iamx_triangulate_packed (one pair of projection matrices per PAIR, packed match rows) ==
+    iamx_triangulate_pairs (one matrix per image) bit for bit when the matrices are the images'
+    own, through the product's surface-stage entry (matcher._surface_device); uploaded rows and
+    several jobs in one call"""
+    from imageanalysis_amd import matcher, smart
+    g = _golden()
+    proj = make_project(g, device=True)
+    il = proj.image_list
+    rng = np.random.default_rng(5)
+    jobs, want = [], []
+    for pairs_of_job in (((0, 1), (1, 2), (0, 3)), ((5, 6),)):
+        pi, pj, P, off, rows = [], [], [], [0], []
+        for a, b in pairs_of_job:
+            m = int(rng.integers(30, 400))
+            pr = np.stack([rng.integers(0, len(il[a].kp_list), m), rng.integers(0, len(il[b].kp_list), m)], 1).astype(np.int32)
+            want.append(smart.triangulate_down(il[a], il[b], pr))
+            pi.append(a); pj.append(b); rows.append(pr); off.append(off[-1] + m)
+            P.append(np.stack([smart.projection_matrix(il[a]).ravel(), smart.projection_matrix(il[b]).ravel()]))
+        jobs.append(dict(pi=np.array(pi), pj=np.array(pj), proj=np.stack(P), m_off=np.array(off, np.int64),
+                         pairs=np.concatenate(rows), src=None))
+    got = matcher._surface_device(il, jobs)
+    k = 0
+    for job, z in zip(jobs, got):
+        for t in range(len(job['pi'])):
+            assert np.array_equal(z[job['m_off'][t]:job['m_off'][t + 1]], want[k]), k
+            k += 1
+    assert k == 4
