@@ -221,20 +221,27 @@ class Prefetch(object):
         self.depth = depth
         self.next = 0
         self.futs = {}
+        self.taken = set()
         # own threads: a job may wait for a pending cache write, which needs the shared workers
         self.workers = ThreadPoolExecutor(max_workers=max(1, depth), thread_name_prefix='iamx-pre')
         for _ in range(min(depth, len(self.todo))):
             self._schedule()
 
     def _schedule(self):
-        if self.next < len(self.todo):
+        while self.next < len(self.todo):
             item = self.todo[self.next]
             self.next += 1
+            if id(item) in self.taken:               # (asked for ahead of its turn: done inline)
+                continue
             self.futs[id(item)] = (item, self.workers.submit(self.fn, item))
+            break
 
     def take(self, item):
         ent = self.futs.pop(id(item), None)
         if ent is None:
+            # not in flight: never listed, or asked for ahead of its turn -- computed inline, and
+            # not a second time when its turn comes
+            self.taken.add(id(item))
             return self.fn(item)
         self._schedule()
         return ent[1].result()
