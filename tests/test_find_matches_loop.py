@@ -295,3 +295,40 @@ def test_triangulate_packed_equals_the_per_image_form():
             assert np.array_equal(z[job['m_off'][t]:job['m_off'][t + 1]], want[k]), k
             k += 1
     assert k == 4
+
+
+def _run_gpu_rank(rank, world, port, outdir, sort):
+    """one of two ranks on the SAME GPU over gloo (RCCL refuses two ranks per device; only the
+    collectives differ): the shipped device path on every rank, rank 0 books and runs the surface
+    stage for both"""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+    from test_dist_cpu import _init
+    torch.cuda.set_device(0)
+    _init(rank, world, port)
+    from imageanalysis_amd import matcher
+    g = _golden()
+    proj = make_project(g, device=True)
+    matcher.PAIRS_PER_BATCH = 4                       # several rounds, both ranks busy in each
+    for call in range(2):
+        matcher.find_matches(proj, None, strategy='traditional', transform='gms', sort=sort)
+        if rank == 0:
+            check_against(g, g['runs'][sort], call, proj)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(os.path.join(outdir, 'ok_%d' % rank), 'w') as f:
+        f.write('ok')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sort', [True, False])
+def test_find_matches_two_ranks_on_one_gpu_equals_reference_loop(tmp_path, sort):
+    """the N > 1 product path on the device: sharded feature exchange, round-robin deal, one byte
+    tensor per rank and round to rank 0, rank 0's pose feedback + triangulation of BOTH ranks'
+    pairs -- against the reference's own loop (G9)"""
+    import torch.multiprocessing as mp
+    from test_dist_cpu import _free_port
+    mp.spawn(_run_gpu_rank, args=(2, _free_port(), str(tmp_path), sort), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'ok_0')) and os.path.exists(os.path.join(str(tmp_path), 'ok_1'))
