@@ -288,13 +288,36 @@ def test_triangulate_packed_equals_the_per_image_form():
             P.append(np.stack([smart.projection_matrix(il[a]).ravel(), smart.projection_matrix(il[b]).ravel()]))
         jobs.append(dict(pi=np.array(pi), pj=np.array(pj), proj=np.stack(P), m_off=np.array(off, np.int64),
                          pairs=np.concatenate(rows), src=None))
+    # ... and a third job whose rows are read where an RCCL gather would have left them: the wire
+    # form of a rank's share (matcher._Part.to_wire) on the DEVICE, rows addressed inside it
+    import torch
+    j0 = jobs[0]
+    h = len(j0['pi'])
+    R = matcher._RoundResult(h)
+    R.n_fwd = R.n_rev = R.cc = np.zeros(h, np.int64)
+    R.quiet = np.zeros(h, bool)
+    R.hit_rows = np.arange(h, dtype=np.int64)
+    R.lo, R.hi = j0['m_off'][:-1].copy(), j0['m_off'][1:].copy()
+    R.fwd_all = j0['pairs']
+    R.fit = True
+    R.dist, R.same = np.ones(h), np.zeros(h, bool)
+    R.yv_f = R.yv_r = np.zeros((h, 4))
+    R.aff_ok = np.ones((h, 2), bool)
+    part = matcher._Part(np.arange(h, dtype=np.int64), j0['pi'].astype(np.int32), j0['pj'].astype(np.int32),
+                         np.zeros(h), np.zeros(h, np.int64), np.zeros(h, np.int64), R)
+    wire = part.to_wire()
+    back = matcher._Part.from_wire(wire, torch.from_numpy(wire).cuda())
+    assert back.R.src['kind'] == 'device' and np.array_equal(back.R.src['pairs'].cpu().numpy(), j0['pairs'])
+    assert np.array_equal(back.R.fwd_all, j0['pairs']) and np.array_equal(back.R.lo, R.lo)
+    jobs.append(dict(pi=j0['pi'], pj=j0['pj'], proj=j0['proj'], m_off=j0['m_off'], pairs=None, src=back.R.src))
+    want += want[:h]
     got = matcher._surface_device(il, jobs)
     k = 0
     for job, z in zip(jobs, got):
         for t in range(len(job['pi'])):
             assert np.array_equal(z[job['m_off'][t]:job['m_off'][t + 1]], want[k]), k
             k += 1
-    assert k == 4
+    assert k == 7
 
 
 def _run_gpu_rank(rank, world, port, outdir, sort):
