@@ -203,13 +203,13 @@ __global__ __launch_bounds__(256) void ba_residual_lds_kernel(
 // blocks per wave in LDS, double buffered.  A chunk that spans more than PIPE_MAXCAM cameras
 // (legal: any observation order is) is remembered and redone per observation AFTER the loop.
 constexpr int PIPE_MAXCAM = 8;
-constexpr int PIPE_SETS = 5;
 
 struct ObsIdx {
     int2 ci, pi;
     double4 ob;
 };
 
+template <int PIPE_SETS>
 __global__ __launch_bounds__(256) void ba_residual_pipe_kernel(
     const double *__restrict__ cams, const double *__restrict__ pts,
     const int32_t *__restrict__ cam_idx, const int32_t *__restrict__ pt_idx,
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void ba_residual_pipe_kernel(
     unsigned long long redo = 0ull;     // steps whose chunk spans more than PIPE_MAXCAM cameras
     int step = 0;
     auto do_step = [&](Set &Cs, Set &Gs, Set &As, int64_t c) __attribute__((always_inline)) {
-        load_idx(c + 4 * stride, As.idx);                                     // chunk k+4: indices
+        load_idx(c + (PIPE_SETS - 1) * stride, As.idx);                       // chunk k+4 (k+2): indices
         gather(Gs.idx, Gs.X0, Gs.X1, Gs.cp, Gs.lo, Gs.hi);                    // chunk k+2: gather
         // chunk k -- camera blocks into this wave's LDS slice, then the residuals
         double (*Rs)[12] = Rs_all[wave][step & 1];
@@ -295,16 +295,17 @@ __global__ __launch_bounds__(256) void ba_residual_pipe_kernel(
         *reinterpret_cast<double4 *>(r + 2 * pair_of(c)) = make_double4(r0.x, r0.y, r1.x, r1.y);
         ++step;
     };
+    constexpr int GA = (PIPE_SETS - 1) / 2;                // the gather runs GA steps ahead
 #pragma unroll
-    for (int t = 0; t < 4; ++t) load_idx(first + t * stride, S[t].idx);
-    gather(S[0].idx, S[0].X0, S[0].X1, S[0].cp, S[0].lo, S[0].hi);
-    gather(S[1].idx, S[1].X0, S[1].X1, S[1].cp, S[1].lo, S[1].hi);
+    for (int t = 0; t < PIPE_SETS - 1; ++t) load_idx(first + t * stride, S[t].idx);
+#pragma unroll
+    for (int t = 0; t < GA; ++t) gather(S[t].idx, S[t].X0, S[t].X1, S[t].cp, S[t].lo, S[t].hi);
     {
         int64_t c = first;
         for (int g = 0; g < steps; g += PIPE_SETS) {
 #pragma unroll
             for (int j = 0; j < PIPE_SETS; ++j) {
-                do_step(S[j], S[(j + 2) % PIPE_SETS], S[(j + 4) % PIPE_SETS], c);
+                do_step(S[j], S[(j + GA) % PIPE_SETS], S[(j + PIPE_SETS - 1) % PIPE_SETS], c);
                 c += stride;
             }
         }
@@ -519,14 +520,20 @@ extern "C" int iamx_ba_residual_prepared(const double *cams, int n_cams, const d
         // redo mask); then as few workgroups as cover the chunks in that many steps -- 256 (one per
         // CU, one wave per SIMD) x 15 steps at configs[3]
         const int64_t n_chunks = (n_obs + 127) / 128;
+        const char *sets_e = getenv("IAMX_BA_RESIDUAL_SETS");
+        const int sets = sets_e && sets_e[0] == '5' ? 5 : 3;
         int64_t g = wgs ? atoll(wgs) : 256;
         if (g < 1) g = 1;
         int64_t steps = (n_chunks + 4 * g - 1) / (4 * g);
-        steps = (steps + PIPE_SETS - 1) / PIPE_SETS * PIPE_SETS;
+        steps = (steps + sets - 1) / sets * sets;
         if (steps > 60) steps = 60;
         g = (n_chunks + 4 * steps - 1) / (4 * steps);
-        hipLaunchKernelGGL(ba_residual_pipe_kernel, dim3((unsigned)g), dim3(256), 0, st, cams, pts,
-                           cam_idx, pt_idx, uv, n_obs, calib, r, (int)steps, n_cams);
+        if (sets == 5)
+            hipLaunchKernelGGL(ba_residual_pipe_kernel<5>, dim3((unsigned)g), dim3(256), 0, st, cams, pts,
+                               cam_idx, pt_idx, uv, n_obs, calib, r, (int)steps, n_cams);
+        else
+            hipLaunchKernelGGL(ba_residual_pipe_kernel<3>, dim3((unsigned)g), dim3(256), 0, st, cams, pts,
+                               cam_idx, pt_idx, uv, n_obs, calib, r, (int)steps, n_cams);
     }
     return iamx::check_launch("iamx_ba_residual_prepared");
 }
