@@ -51,9 +51,12 @@ SIGNATURES = {
     'iamx_desc3_pack_f32': (c_int, [c_void_p, c_int64] + [c_void_p] * 7),
     'iamx_desc3_pack_batch_u8': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int]
                                  + [c_void_p] * 7),
-    'iamx_knn2sym_sweep': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int] + [c_void_p] * 3),
-    'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 7),
-    'iamx_knn2sym_exact': (c_int, [c_void_p] * 4 + [c_int64] + [c_void_p] * 8 + [c_int, c_double] + [c_void_p] * 7),
+    'iamx_knn2sym_narrow_bytes': (c_int64, [c_int64, c_int]),
+    'iamx_knn2sym_sweep': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int] + [c_void_p] * 4),
+    'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 8
+                                + [c_int64, c_int, c_void_p]),
+    'iamx_knn2sym_exact': (c_int, [c_void_p] * 4 + [c_int64] + [c_void_p] * 8 + [c_int, c_double]
+                           + [c_void_p] * 13 + [c_int64, c_int, c_void_p]),
     'iamx_match_postfilter_clip': (c_int, []),
     'iamx_match_pack_results': (c_int, [c_void_p] * 4 + [c_int, c_int, c_int64] + [c_void_p] * 4),
     'iamx_match_postfilter': (c_int, [c_void_p] * 9 + [c_int, c_double, c_double, c_double, c_double]

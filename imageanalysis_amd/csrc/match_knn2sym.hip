@@ -199,6 +199,9 @@ struct SymArgs {
     int32_t *col;                // [..][2]  (v1, v2)
     int32_t *rowp;               // [..][4]  (L, U1, U2, -)
     int n_u, total_wg;
+    uint8_t *colmask;            // [..] per column-result row: the groups (bit (tile & 3) + 4 * lane half)
+                                 //      whose minimum is <= v2 (NULL: not wanted) -- the only train rows
+                                 //      that can be the query's best or second (narrow exact stage)
 };
 
 // min over the 32 lanes of a half wave (lanes 0-31: g = 0, lanes 32-63: g = 1) of 16 registers
@@ -625,8 +628,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
             const int v1 = min(a1, b1), v2 = min(max(a1, b1), min(a2, b2));
             const int row = q0 + QW * rc + qb;
             const int sub = GROUPLO ? 0 : lo_lane;       // (GROUPLO: the accumulators never saw it)
-            if (g == 0 && row < nb)
+            const int own = (m[qb][0] <= v2 ? 1 : 0) | (m[qb][1] <= v2 ? 2 : 0) | (m[qb][2] <= v2 ? 4 : 0) |
+                            (m[qb][3] <= v2 ? 8 : 0);
+            const int oth = __shfl_xor(own, 32);
+            if (g == 0 && row < nb) {
                 *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1 - sub, v2 - sub};
+                if (A.colmask) A.colmask[A.col_off[u] + row] = (uint8_t)(own | (oth << 4));
+            }
         }
     }
 }
@@ -892,12 +900,55 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_x_kernel(SymArgs A)
 #endif  // IAMX_ABLATE
 
 // ---------------------------------------------------------------------------------
-// candidates: one workgroup per ORDERED pair.  Pass 1 visits the rows in SORTED order (the order
-// the sweep wrote its bounds in: coalesced reads) and drops a flag at the row's original
-// position; pass 2 lists the flagged rows in ascending original order at the pair's own slice
-// of cand_q (first entry out_off[p]: a pair cannot have more candidates than rows, so no scan
-// over the pairs is needed) and appends the pair's 64-candidate tasks to the exact stage's list.
+// candidates.  Pass 1 (symcand_rows_kernel, one thread per query row) visits the rows in SORTED
+// order (the order the sweep wrote its bounds in: coalesced reads) and drops a flag at the row's
+// original position; pass 2 (symcand_kernel, one workgroup per ORDERED pair) lists the flagged rows
+// in ascending original order at the pair's own slice of cand_q (first entry out_off[p]: a pair
+// cannot have more candidates than rows, so no scan over the pairs is needed) and appends the
+// pair's tasks to the exact stage's lists (pass 1 ran inside the per-pair workgroups until round 6:
+// 21 MB of row bounds per pair of 37 k-row images through ONE workgroup).
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// NARROW exact stage (round 6).  The sweep already knows WHERE a candidate's two smallest
+// distances can be: a query that was a B row has eight group minima over the streamed image
+// (group = (tile & 3, lane half): `colmask` says which are <= v2), a query that was an A row has one
+// (L, U1, U2) per 1024-row block of the register-resident image (`rowp`: block w can hold a row
+// at or below the upper bound of the second distance only if L_w <= U2).  Every other train row is
+// farther than the candidate's exact second distance.  So a candidate becomes ITEMS (candidate,
+// class), the items of an ordered pair are bucketed by class, and a task scans ONE class -- 1/8 of
+// the train image for the column direction, 1/nwg for the row direction -- for up to 256 items.
+// Each item leaves (best, row, second) of its class; a finish pass merges a candidate's items.
+// Results are those of the full scan: every row that can be the best, the second or tied with
+// either lies in a class of the candidate's mask ("narrow exact stage").
+//
+// One device buffer `nar` (iamx_knn2sym_narrow_bytes), carved up by narrow_layout() below.
+// ---------------------------------------------------------------------------------
+struct NarTask { int p, cls, item0, n; };
+struct NarLayout {
+    int64_t ctl, pair_base, mask, slot, items, res, tasks, total;
+    int64_t item_cap, task_cap;
+};
+// ctl[0] narrow tasks, ctl[1] items allocated (zero on entry, reset by the finish kernel)
+__host__ __device__ inline NarLayout narrow_layout(int64_t rows, int64_t n_pairs)
+{
+    NarLayout L;
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    L.item_cap = rows;
+    L.task_cap = rows / 64 + 80 * n_pairs + 64;
+    int64_t o = 0;
+    L.ctl = o;        o += 256;
+    L.pair_base = o;  o += up(n_pairs * 4);
+    L.mask = o;       o += up(rows * 8);
+    L.slot = o;       o += up(rows * 8);
+    L.items = o;      o += up(L.item_cap * 8);
+    L.res = o;        o += up(L.item_cap * 16);
+    L.tasks = o;      o += up(L.task_cap * 16);
+    L.total = o;
+    return L;
+}
+constexpr int NAR_MIN_TRAIN = 1024;      // narrow scans only for train images of at least this many rows
+constexpr int NAR_ITEMS = 256;           // items of a narrow task
+
 struct CandArgs {
     const int32_t *sn2, *sperm, *img_off, *img_n;
     const int32_t *pairs;        // [n_pairs][2] ordered (query image, train image)
@@ -913,8 +964,83 @@ struct CandArgs {
     int32_t *tasks;              // [..][2] (ordered pair, block): wave tasks from entry 0, workgroup tasks from entry n_pairs
     int32_t *d2;                 // [rows][2]: [.][1] of a candidate row = upper bound of its exact second distance
     int wg_shift;                // log2 of the candidates of a workgroup task (8, or 9 for the four-set form)
+    // narrow exact stage (nar == NULL: off)
+    const uint8_t *colmask;
+    int8_t *nar;
+    int64_t rows_total;
+    int n_pairs, wgrows;
 };
 
+// pass 1, one thread per query row of every ordered pair (block b belongs to the pair p with
+// out_off[p] / 256 + p <= b: every pair wastes less than one block): bounds -> candidate flag at
+// the row's original position, the upper bound of its second distance, its class mask.
+__global__ __launch_bounds__(256) void symcand_rows_kernel(CandArgs A)
+{
+    int lo = 0, hi = A.n_pairs;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)(A.out_off[mid] >> 8) + mid <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int p = lo;
+    const int pos = (int)((int64_t)blockIdx.x - ((A.out_off[p] >> 8) + p)) * 256 + threadIdx.x;
+    const int qimg = A.pairs[2 * p];
+    const int u = A.osrc[2 * p], role = A.osrc[2 * p + 1];
+    const int soff = A.img_off[qimg], n = A.img_n[qimg];
+    if (pos >= n) return;
+    const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
+    const int nwg = A.wg_off[u + 1] - A.wg_off[u];
+    const int64_t ob = A.out_off[p];
+    const int32_t *rowq = A.rowp + 4 * A.rowp_off[u];
+    // narrow exact stage: classes of this ordered pair's train image (8 groups of the streamed image
+    // when the query was a B row, the nwg row blocks of the register-resident image otherwise)
+    const int ncls = role == 0 ? 8 : nwg;
+    const bool nar_ok = A.nar != nullptr && A.img_n[A.pairs[2 * p + 1]] >= NAR_MIN_TRAIN && ncls <= 64;
+    const int n2 = A.sn2[soff + pos], par = n2 & 1;
+    long long Lb, Ub;
+    int U2 = 0x7FFFFFFF;
+    if (role == 0) {
+        const v2i v = *reinterpret_cast<const v2i *>(A.col + 2 * (A.col_off[u] + pos));
+        const long long cq = n2 >> 1;
+        Lb = 2 * (v.x + cq) + par;
+        Ub = 2 * (v.y + cq) + par + 1;
+    } else {
+        int L = 0x7FFFFFFF, U1 = 0x7FFFFFFF;
+        for (int w = 0; w < nwg; ++w) {
+            const v4i e = *reinterpret_cast<const v4i *>(rowq + 4 * ((int64_t)w * cap + pos));
+            L = min(L, e.x);
+            // merge the sorted pairs (U1, U2) and (e.y, e.z)
+            const int n1 = min(U1, e.y);
+            U2 = min(max(U1, e.y), min(U2, e.z));
+            U1 = n1;
+        }
+        Lb = 2ll * L + par;
+        Ub = 2ll * U2 + par + 1;
+    }
+    if (Lb < 0) Lb = 0;
+    const float f0 = (float)sqrt((double)Lb);
+    const float f1 = (float)sqrt((double)Ub);
+    const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
+    const int orig = A.sperm[soff + pos];
+    A.keep[ob + orig] = k ? 1 : 0;
+    // what the exact stage prunes its scan with: no row farther than this can be the best or
+    // the second of the candidate (replaced by the exact pair of distances there)
+    if (k) A.d2[2 * (ob + orig) + 1] = (int)(Ub < 0x7FFFFFFFll ? Ub : 0x7FFFFFFFll);
+    if (k && nar_ok) {
+        // the classes that can hold a row at or below Ub (every other row is farther than the
+        // exact second distance): group minimum <= v2, block lower bound <= U2
+        unsigned long long mk = 0ull;
+        if (role == 0) {
+            mk = A.colmask[A.col_off[u] + pos];
+        } else {
+            for (int w = 0; w < nwg; ++w)
+                if (rowq[4 * ((int64_t)w * cap + pos)] <= U2) mk |= 1ull << w;
+        }
+        const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
+        reinterpret_cast<unsigned long long *>(A.nar + NL.mask)[ob + orig] = mk;
+    }
+}
+
+// passes 2 and 3, one workgroup per ordered pair
 __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
 {
     __shared__ int wcnt[4];
@@ -922,44 +1048,13 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
     const int p = blockIdx.x;
     const int qimg = A.pairs[2 * p];
     const int u = A.osrc[2 * p], role = A.osrc[2 * p + 1];
-    const int soff = A.img_off[qimg], n = A.img_n[qimg];
-    const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
+    const int n = A.img_n[qimg];
     const int nwg = A.wg_off[u + 1] - A.wg_off[u];
     const int64_t ob = A.out_off[p];
-    const int32_t *colp = A.col + 2 * A.col_off[u];
-    const int32_t *rowq = A.rowp + 4 * A.rowp_off[u];
-    for (int pos = threadIdx.x; pos < n; pos += 256) {
-        const int n2 = A.sn2[soff + pos], par = n2 & 1;
-        long long Lb, Ub;
-        if (role == 0) {
-            const v2i v = *reinterpret_cast<const v2i *>(colp + 2 * pos);
-            const long long cq = n2 >> 1;
-            Lb = 2 * (v.x + cq) + par;
-            Ub = 2 * (v.y + cq) + par + 1;
-        } else {
-            int L = 0x7FFFFFFF, U1 = 0x7FFFFFFF, U2 = 0x7FFFFFFF;
-            for (int w = 0; w < nwg; ++w) {
-                const v4i e = *reinterpret_cast<const v4i *>(rowq + 4 * ((int64_t)w * cap + pos));
-                L = min(L, e.x);
-                // merge the sorted pairs (U1, U2) and (e.y, e.z)
-                const int n1 = min(U1, e.y);
-                U2 = min(max(U1, e.y), min(U2, e.z));
-                U1 = n1;
-            }
-            Lb = 2ll * L + par;
-            Ub = 2ll * U2 + par + 1;
-        }
-        if (Lb < 0) Lb = 0;
-        const float f0 = (float)sqrt((double)Lb);
-        const float f1 = (float)sqrt((double)Ub);
-        const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
-        const int orig = A.sperm[soff + pos];
-        A.keep[ob + orig] = k ? 1 : 0;
-        // what the exact stage prunes its scan with: no row farther than this can be the best or
-        // the second of the candidate (replaced by the exact pair of distances there)
-        if (k) A.d2[2 * (ob + orig) + 1] = (int)(Ub < 0x7FFFFFFFll ? Ub : 0x7FFFFFFFll);
-    }
-    __syncthreads();             // (workgroup-scope fence: the flags are read back below)
+    const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
+    const int ncls = role == 0 ? 8 : nwg;
+    const bool nar_ok = A.nar != nullptr && A.img_n[A.pairs[2 * p + 1]] >= NAR_MIN_TRAIN && ncls <= 64;
+    unsigned long long *maskv = reinterpret_cast<unsigned long long *>(A.nar + NL.mask);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int out = 0;
     for (int base = 0; base < n; base += 256) {
@@ -978,6 +1073,99 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
         if (k) A.cand_q[ob + out + woff + before] = i;
         out += tot;
         __syncthreads();
+    }
+    // ---- narrow exact stage: items (candidate, class) bucketed by class, tasks of one class
+    bool narrow = nar_ok && out > 64;
+    if (A.nar != nullptr) {
+        __shared__ int cls_cnt[64], cls_off[65], cls_task[65], s_nb;
+        int32_t *ctl = reinterpret_cast<int32_t *>(A.nar + NL.ctl);
+        int32_t *pair_base = reinterpret_cast<int32_t *>(A.nar + NL.pair_base);
+        v2i *slot = reinterpret_cast<v2i *>(A.nar + NL.slot);
+        v2i *items = reinterpret_cast<v2i *>(A.nar + NL.items);
+        NarTask *ntasks = reinterpret_cast<NarTask *>(A.nar + NL.tasks);
+        if (narrow) {
+            if (threadIdx.x < 64) cls_cnt[threadIdx.x] = 0;
+            __syncthreads();
+            int run = 0;                                   // result slots handed out so far
+            for (int base = 0; base < out; base += 256) {
+                const int i = base + threadIdx.x;
+                unsigned long long mk = 0ull;
+                if (i < out) mk = maskv[ob + A.cand_q[ob + i]];
+                const int nk = __popcll(mk);
+                int x = nk;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    const int y = __shfl_up(x, sft);
+                    if (lane >= sft) x += y;
+                }
+                if (lane == 63) wcnt[wave] = x;
+                __syncthreads();
+                int woff = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    if (w < wave) woff += wcnt[w];
+                    tot += wcnt[w];
+                }
+                if (i < out) {
+                    slot[ob + i] = v2i{run + woff + x - nk, nk};
+                    for (unsigned long long b = mk; b; b &= b - 1) atomicAdd(&cls_cnt[__ffsll((long long)b) - 1], 1);
+                }
+                run += tot;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                int o = 0, nt = 0;
+                for (int cidx = 0; cidx < 64; ++cidx) {
+                    cls_off[cidx] = o;
+                    cls_task[cidx] = nt;
+                    o += cls_cnt[cidx];
+                    nt += (cls_cnt[cidx] + NAR_ITEMS - 1) / NAR_ITEMS;
+                }
+                cls_off[64] = o;
+                cls_task[64] = nt;
+                // (a batch whose items or tasks do not fit falls back to the full scan, pair by pair)
+                const int b0 = atomicAdd(ctl + 1, run);
+                bool ok = (int64_t)b0 + run <= NL.item_cap;
+                int t0 = 0;
+                if (ok) {
+                    t0 = atomicAdd(ctl + 0, nt);
+                    ok = (int64_t)t0 + nt <= NL.task_cap;
+                }
+                s_nb = ok ? b0 : -1;
+                s_base = t0;
+                pair_base[p] = ok ? b0 : -1;
+            }
+            __syncthreads();
+            narrow = s_nb >= 0;
+            if (narrow) {
+                const int b0 = s_nb, t0 = s_base;
+                if (threadIdx.x < 64) {
+                    const int cidx = threadIdx.x, cnt_c = cls_cnt[cidx];
+                    for (int t = 0; t * NAR_ITEMS < cnt_c; ++t)
+                        ntasks[t0 + cls_task[cidx] + t] =
+                            NarTask{p, cidx, b0 + cls_off[cidx] + t * NAR_ITEMS, min(NAR_ITEMS, cnt_c - t * NAR_ITEMS)};
+                }
+                __syncthreads();
+                if (threadIdx.x < 64) cls_cnt[threadIdx.x] = 0;       // now the buckets' cursors
+                __syncthreads();
+                for (int i = threadIdx.x; i < out; i += 256) {
+                    const unsigned long long mk = maskv[ob + A.cand_q[ob + i]];
+                    int sl = b0 + slot[ob + i].x;
+                    for (unsigned long long b = mk; b; b &= b - 1, ++sl) {
+                        const int cidx = __ffsll((long long)b) - 1;
+                        const int at = atomicAdd(&cls_cnt[cidx], 1);
+                        items[b0 + cls_off[cidx] + at] = v2i{i, sl};
+                    }
+                }
+            }
+            __syncthreads();
+        } else if (threadIdx.x == 0) {
+            pair_base[p] = -1;
+        }
+    }
+    if (narrow) {
+        if (threadIdx.x == 0) A.cand_cnt[p] = out;
+        return;
     }
     // two task lists in one buffer: a pair with <= 64 candidates is ONE wave's task (entries
     // [0, n_pairs): at most one per pair), a pair with more gets workgroup tasks of 256 or 512 candidates
@@ -1558,6 +1746,311 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------
+// narrow exact stage: a task = up to 256 items (candidate, class) of one ordered pair and ONE
+// class, four waves x two sets of 32 as in symexact_wg_kernel; the class's rows come from the
+// SORTED store (the order the sweep's classes are defined in) as 32-row tiles through LDS:
+//   row direction  (query was an A row): class w = sorted rows [w * wgrows, (w + 1) * wgrows) of the
+//                  register-resident image, consecutive tiles;
+//   column direction (query was a B row): class (k, g) = the rows the sweep's lanes of half g saw
+//                  in tiles with (tile & 3) == k: rows 8 i + 4 g + (0..3), i = 0..3, of such a tile
+//                  -- a packed tile takes its 16 rows from two of them.
+// Per row: C operand = sct (halved norm term; 2^25 on rows past the end: never below a bound,
+// still no overflow in the key), parity and the row's position among the lane's 16 accumulators
+// (`pk`), the original row number (`idx`: what the reference breaks ties with).  The pruning test
+// is symexact_wg_kernel's; a tile that passes builds keys (acc << 5 | parity << 4 | position),
+// takes best and second with v_med3 / v_min and folds them at once -- the row number of the best
+// from LDS -- unless some lane holds two equal distances among its 16 rows: then every row of the
+// tile goes through the full (distance, original row) comparison.
+// ---------------------------------------------------------------------------------
+struct NarArgs {
+    const int8_t *desc;          // original-order store: the candidates' rows
+    const int32_t *norm_q, *img_off;
+    const int32_t *pairs, *osrc;
+    const int64_t *out_off;
+    const int32_t *cand_q;
+    const int32_t *d2;
+    const int8_t *sdesc;         // sorted store: the train rows
+    const int32_t *sn2, *sct, *sperm, *img_off3, *img_n;
+    int8_t *nar;
+    int64_t rows_total;
+    int n_pairs, wgrows;
+    // finish
+    const int32_t *cand_cnt;
+    double thresh;
+    int32_t *d2w, *cand_t;
+    double *cand_metric;
+    uint8_t *cand_keep;
+    int32_t *zero_div;
+};
+
+constexpr int NAR_HALF_INVALID = 1 << 25;
+constexpr int NAR_D_INVALID = 0x7FFFFFFF;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void symnarrow_kernel(NarArgs A)
+{
+    constexpr int SUB = 2, PR = 32 * SUB;
+    __shared__ __attribute__((aligned(16))) int8_t s_tile[2][PR * D];
+    __shared__ __attribute__((aligned(16))) int32_t s_half[2][PR];
+    __shared__ __attribute__((aligned(16))) int32_t s_pk[2][PR];
+    __shared__ __attribute__((aligned(16))) int32_t s_idx[2][PR];
+    const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
+    const int32_t *ctl = reinterpret_cast<const int32_t *>(A.nar + NL.ctl);
+    const NarTask *ntasks = reinterpret_cast<const NarTask *>(A.nar + NL.tasks);
+    const v2i *items = reinterpret_cast<const v2i *>(A.nar + NL.items);
+    v4i *res = reinterpret_cast<v4i *>(A.nar + NL.res);
+    const int total = ctl[0];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;      // staging: 16 bytes per thread
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const NarTask task = ntasks[t];
+        const int p = __builtin_amdgcn_readfirstlane(task.p);
+        const int cls = __builtin_amdgcn_readfirstlane(task.cls);
+        const int item0 = __builtin_amdgcn_readfirstlane(task.item0);
+        const int nit = __builtin_amdgcn_readfirstlane(task.n);
+        const int64_t cb = A.out_off[p];
+        const int qimg = A.pairs[2 * p], timg = A.pairs[2 * p + 1];
+        const int role = __builtin_amdgcn_readfirstlane(A.osrc[2 * p + 1]);
+        const int qoff = __builtin_amdgcn_readfirstlane(A.img_off[qimg]);
+        const int toff = __builtin_amdgcn_readfirstlane(A.img_off3[timg]);
+        const int nt = __builtin_amdgcn_readfirstlane(A.img_n[timg]);
+        // class geometry: packed tile j, packed row r -> sorted position (or -1)
+        int ntiles, first = 0, ck = 0, cg = 0;
+        if (role != 0) {
+            first = cls * A.wgrows;
+            const int last = min(nt, first + A.wgrows);
+            ntiles = last > first ? (last - first + 31) / 32 : 0;
+        } else {
+            ck = cls & 3;
+            cg = cls >> 2;
+            const int tt = (nt + 31) / 32;
+            const int nk = tt > ck ? (tt - ck + 3) / 4 : 0;
+            ntiles = (nk + 1) / 2;
+        }
+        auto position = [&](int j, int r) -> int {
+            int pos;
+            if (role != 0) {
+                pos = first + j * 32 + r;
+                if (pos >= first + A.wgrows) pos = nt;
+            } else {
+                const int T = 4 * (2 * j + (r >> 4)) + ck, rr = r & 15;
+                pos = T * 32 + 8 * (rr >> 2) + 4 * cg + (rr & 3);
+            }
+            return pos < nt ? pos : -1;
+        };
+        const int k_wave = wave * 64;                                   // first item of this wave
+        const int n_sets = nit - k_wave > 32 ? 2 : (nit - k_wave > 0 ? 1 : 0);
+        int slot[2], hmax[2];
+        bool live[2];
+        v4i bq[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int it = k_wave + h * 32 + c;
+            live[h] = it < nit;
+            const v2i item = items[item0 + (live[h] ? it : nit - 1)];
+            slot[h] = item.y;
+            const int q = A.cand_q[cb + item.x];
+            const v4i *src = reinterpret_cast<const v4i *>(A.desc + (int64_t)(qoff + q) * D);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[h][s] = ~src[2 * s + g];
+            const int ub = A.d2[2 * (cb + q) + 1];
+            int hm = (ub - A.norm_q[qoff + q]) >> 1;
+            hm = hm < (1 << 24) ? hm : (1 << 24);
+            hmax[h] = live[h] ? hm : -0x40000000;
+        }
+        const int8_t *tbase = A.sdesc + (int64_t)toff * D;
+        int bd1[2] = {NAR_D_INVALID, NAR_D_INVALID}, bi1[2] = {NAR_D_INVALID, NAR_D_INVALID};
+        int bd2[2] = {NAR_D_INVALID, NAR_D_INVALID};
+        auto fetch = [&](int ph, v4i (&row16)[SUB], v4i &meta) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                const int pos = position(ph * SUB + j, lrow);
+                row16[j] = pos >= 0 ? *reinterpret_cast<const v4i *>(tbase + (int64_t)pos * D + 16 * lchunk)
+                                    : v4i{0, 0, 0, 0};
+            }
+            meta = v4i{NAR_HALF_INVALID, 0, NAR_D_INVALID, 0};
+            if (threadIdx.x < PR) {
+                const int r = threadIdx.x & 31;
+                const int pos = position(ph * SUB + (threadIdx.x >> 5), r);
+                const int regpos = ((r >> 3) << 2) | (r & 3);
+                meta.y = regpos;
+                if (pos >= 0) {
+                    meta.x = A.sct[toff + pos];
+                    meta.y = ((A.sn2[toff + pos] & 1) << 4) | regpos;
+                    meta.z = A.sperm[toff + pos];
+                }
+            }
+        };
+        auto stage = [&](int buf, const v4i (&row16)[SUB], const v4i &meta) {
+#pragma unroll
+            for (int j = 0; j < SUB; ++j)
+                *reinterpret_cast<v4i *>(&s_tile[buf][(j * 32 + lrow) * D + 16 * (lchunk ^ ((lrow >> 1) & 7))]) = row16[j];
+            if (threadIdx.x < PR) {
+                s_half[buf][threadIdx.x] = meta.x;
+                s_pk[buf][threadIdx.x] = meta.y;
+                s_idx[buf][threadIdx.x] = meta.z;
+            }
+        };
+        v4i pre[SUB], pre_meta;
+        const int nph = (ntiles + SUB - 1) / SUB;
+        __syncthreads();                               // (the previous task's last tile is consumed)
+        if (nph > 0) {
+            fetch(0, pre, pre_meta);
+            stage(0, pre, pre_meta);
+        }
+        __syncthreads();
+        for (int ph = 0; ph < nph; ++ph) {
+            const int buf = ph & 1;
+            if (ph + 1 < nph) fetch(ph + 1, pre, pre_meta);
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                const int tile = ph * SUB + j;
+                if (n_sets > 0 && tile < ntiles) {
+                    v4i a[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        a[s] = *reinterpret_cast<const v4i *>(&s_tile[buf][(j * 32 + c) * D + 16 * ((2 * s + g) ^ ((c >> 1) & 7))]);
+                    v16i cin;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const v4i tv = *reinterpret_cast<const v4i *>(&s_half[buf][j * 32 + 8 * kk + 4 * g]);
+                        cin[4 * kk] = tv.x; cin[4 * kk + 1] = tv.y; cin[4 * kk + 2] = tv.z; cin[4 * kk + 3] = tv.w;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (h == 1 && n_sets < 2) break;
+                        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[h][0], cin, 0, 0, 0);
+#pragma unroll
+                        for (int s = 1; s < 4; ++s)
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                        const int t0 = min(min(acc[0], acc[1]), acc[2]), t1 = min(min(acc[3], acc[4]), acc[5]);
+                        const int t2 = min(min(acc[6], acc[7]), acc[8]), t3 = min(min(acc[9], acc[10]), acc[11]);
+                        const int t4 = min(min(acc[12], acc[13]), acc[14]);
+                        const int lo = min(min(min(t0, t1), t2), min(min(t3, t4), acc[15]));
+                        if (__ballot(lo <= hmax[h]) == 0ull) continue;
+                        v4i tk[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+                            tk[kk] = *reinterpret_cast<const v4i *>(&s_pk[buf][j * 32 + 8 * kk + 4 * g]);
+                        int m1 = 0x7FFFFFFF, m2 = 0x7FFFFFFF;
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const int key = (int)(((unsigned)acc[reg] << 5) + (unsigned)tk[reg >> 2][reg & 3]);
+                            m2 = med3_key(m1, m2, key);
+                            m1 = min(m1, key);
+                        }
+                        const int d1k = m1 >> 4, d2k = m2 >> 4;
+                        if (__ballot(d1k == d2k) == 0ull) {
+                            const int r1 = m1 & 15;
+                            const int i1k = s_idx[buf][j * 32 + 8 * (r1 >> 2) + 4 * g + (r1 & 3)];
+                            if (d1k < bd1[h] || (d1k == bd1[h] && i1k < bi1[h])) {
+                                bd2[h] = min(bd1[h], d2k);
+                                bd1[h] = d1k;
+                                bi1[h] = i1k;
+                            } else {
+                                bd2[h] = min(bd2[h], d1k);
+                            }
+                        } else {
+                            // two equal distances among a lane's 16 rows: every row through the full
+                            // (distance, original row) comparison
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) {
+                                const int dk = 2 * acc[reg] + ((tk[reg >> 2][reg & 3] >> 4) & 1);
+                                const int ik = s_idx[buf][j * 32 + 8 * (reg >> 2) + 4 * g + (reg & 3)];
+                                if (dk < bd1[h] || (dk == bd1[h] && ik < bi1[h])) {
+                                    bd2[h] = bd1[h];
+                                    bd1[h] = dk;
+                                    bi1[h] = ik;
+                                } else {
+                                    bd2[h] = min(bd2[h], dk);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (ph + 1 < nph) stage(buf ^ 1, pre, pre_meta);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // the two lane halves (rows +4 of every group of eight) -> one (best, row, second)
+            const int od1 = __shfl_xor(bd1[h], 32), oi1 = __shfl_xor(bi1[h], 32), od2 = __shfl_xor(bd2[h], 32);
+            int f_d, f_i, s_d;
+            if (od1 < bd1[h] || (od1 == bd1[h] && oi1 < bi1[h])) {
+                f_d = od1; f_i = oi1;
+                s_d = min(bd1[h], od2);
+            } else {
+                f_d = bd1[h]; f_i = bi1[h];
+                s_d = min(od1, bd2[h]);
+            }
+            if (g == 0 && live[h] && (h == 0 || n_sets == 2)) res[slot[h]] = v4i{f_d, f_i, s_d, 0};
+        }
+    }
+}
+
+// merge a candidate's items, then what exact_finish does: exact squared distances, train row,
+// metric, keep flag.  One workgroup per ordered pair (pairs the narrow stage did not take return).
+__global__ __launch_bounds__(256) void symnarrow_finish_kernel(NarArgs A)
+{
+    const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
+    const int32_t *pair_base = reinterpret_cast<const int32_t *>(A.nar + NL.pair_base);
+    const v2i *slot = reinterpret_cast<const v2i *>(A.nar + NL.slot);
+    const v4i *res = reinterpret_cast<const v4i *>(A.nar + NL.res);
+    const int p = blockIdx.x;
+    if (p == 0 && threadIdx.x == 0) {                   // the scan has consumed tasks and items
+        int32_t *ctl = reinterpret_cast<int32_t *>(A.nar + NL.ctl);
+        ctl[0] = ctl[1] = 0;
+    }
+    const int b0 = pair_base[p];
+    if (b0 < 0) return;
+    const int64_t cb = A.out_off[p];
+    const int cnt = A.cand_cnt[p];
+    const int qoff = A.img_off[A.pairs[2 * p]];
+    for (int k = threadIdx.x; k < cnt; k += 256) {
+        const v2i sl = slot[cb + k];
+        int f_d = NAR_D_INVALID, f_i = NAR_D_INVALID, s_d = NAR_D_INVALID;
+        for (int j = 0; j < sl.y; ++j) {
+            const v4i e = res[b0 + sl.x + j];
+            if (e.x < f_d || (e.x == f_d && e.y < f_i)) {
+                s_d = min(f_d, e.z);
+                f_d = e.x;
+                f_i = e.y;
+            } else {
+                s_d = min(s_d, e.x);
+            }
+        }
+        const int q = A.cand_q[cb + k];
+        // (no row at all, or no second one, below 2^26: the classes of the mask hold every row that
+        //  can matter, so this is a broken invariant -- flagged like an unresolved row)
+        if (f_d >= (1 << 26) || s_d >= (1 << 26)) {
+            atomicAdd(A.zero_div + 1, 1);
+            A.cand_t[cb + k] = 0;
+            A.cand_metric[cb + k] = 0.0;
+            A.cand_keep[cb + k] = 0;
+            continue;
+        }
+        const int na = A.norm_q[qoff + q];
+        const int d1 = f_d + na, d2 = s_d + na;
+        *reinterpret_cast<v2i *>(A.d2w + 2 * (cb + q)) = v2i{d1, d2};
+        const float f0 = (float)sqrt((double)d1);
+        const float f1 = (float)sqrt((double)d2);
+        double mt;
+        bool ok = false;
+        if (f1 == 0.0f) {
+            mt = __longlong_as_double(0x7FF8000000000000LL);    // python raises ZeroDivisionError
+            atomicAdd(A.zero_div, 1);
+        } else {
+            mt = (double)f0 * ((double)f0 / (double)f1);
+            ok = mt < A.thresh;
+        }
+        A.cand_t[cb + k] = f_i;
+        A.cand_metric[cb + k] = mt;
+        A.cand_keep[cb + k] = ok ? 1 : 0;
+    }
+}
+
 // in-place, order-preserving compaction of every pair's candidate list to its survivors
 __global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restrict__ cand_off,
                                                          const int32_t *__restrict__ cand_cnt,
@@ -1704,7 +2197,8 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
                                   const int32_t *img_off, const int32_t *img_n,
                                   const int32_t *upairs, const int32_t *wg_off,
                                   const int64_t *col_off, const int64_t *rowp_off, int n_u,
-                                  int total_wg, int form, int32_t *col, int32_t *rowp, void *stream)
+                                  int total_wg, int form, int32_t *col, int32_t *rowp,
+                                  uint8_t *colmask, void *stream)
 {
     IAMX_REQUIRE(sdesc && sn2 && sct && img_off && img_n && upairs && wg_off && col_off && rowp_off &&
                      col && rowp,
@@ -1712,7 +2206,8 @@ extern "C" int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const
     IAMX_REQUIRE(n_u >= 0 && total_wg >= 0, "negative count");
     IAMX_REQUIRE(form >= 0 && form <= 2, "form must be 0 (256 rows), 1 (512) or 2 (1024)");
     if (n_u == 0 || total_wg == 0) return IAMX_OK;
-    SymArgs a{sdesc, sn2, sct, img_off, img_n, upairs, wg_off, col_off, rowp_off, col, rowp, n_u, total_wg};
+    SymArgs a{sdesc, sn2, sct, img_off, img_n, upairs, wg_off, col_off, rowp_off, col, rowp, n_u, total_wg,
+              colmask};
     const dim3 g((unsigned)total_wg);
     hipStream_t st = iamx::as_stream(stream);
     // PIPE = 6: six epilogue VALU instructions beside every MFMA of the next pair of query
@@ -1738,6 +2233,19 @@ static bool exact_four_sets()
     return e && e[0] == '4';
 }
 
+// IAMX_EXACT_NARROW=0: every candidate through the full scan (A/B, tests)
+static bool narrow_enabled()
+{
+    const char *e = getenv("IAMX_EXACT_NARROW");
+    return !(e && e[0] == '0');
+}
+
+extern "C" int64_t iamx_knn2sym_narrow_bytes(int64_t rows, int n_pairs)
+{
+    if (rows <= 0 || n_pairs <= 0) return 0;
+    return narrow_layout(rows, n_pairs).total;
+}
+
 extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int32_t *img_off, const int32_t *img_n,
                                        const int32_t *pairs, const int32_t *osrc,
@@ -1746,14 +2254,22 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        const int32_t *col, const int32_t *rowp, int n_pairs,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
                                        int32_t *cand_q, int32_t *task_total, int32_t *tasks,
-                                       int32_t *d2, void *stream)
+                                       int32_t *d2, const uint8_t *colmask, void *nar,
+                                       int64_t rows_total, int form, void *stream)
 {
     IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
                      out_off && col && rowp && keep && cand_cnt && cand_q && task_total && tasks && d2,
                  "null pointer");
+    IAMX_REQUIRE(!nar || colmask, "narrow workspace without colmask");
+    IAMX_REQUIRE(form >= 0 && form <= 2, "form must be 0, 1 or 2");
     if (n_pairs <= 0) return IAMX_OK;
     CandArgs a{sn2, sperm, img_off, img_n, pairs, osrc, wg_off, col_off, rowp_off, out_off, col, rowp,
-               thresh, keep, cand_cnt, cand_q, task_total, tasks, d2, exact_four_sets() ? 9 : 8};
+               thresh, keep, cand_cnt, cand_q, task_total, tasks, d2, exact_four_sets() ? 9 : 8,
+               colmask, narrow_enabled() ? static_cast<int8_t *>(nar) : nullptr, rows_total, n_pairs,
+               iamx_knn2sym_rows_per_wg(form)};
+    IAMX_REQUIRE(rows_total > 0 && rows_total < (1ll << 31), "rows_total = rows of all ordered pairs");
+    hipLaunchKernelGGL(symcand_rows_kernel, dim3((unsigned)((rows_total >> 8) + n_pairs + 1)), dim3(256), 0,
+                       iamx::as_stream(stream), a);
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
@@ -1765,7 +2281,10 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
                                   int32_t *task_total, const int32_t *tasks, int32_t *cand_q,
                                   int n_pairs, double thresh, int32_t *d2, int32_t *cand_t,
                                   double *cand_metric, uint8_t *cand_keep, int32_t *surv_cnt,
-                                  int32_t *zero_div, void *stream)
+                                  int32_t *zero_div, const int8_t *sdesc, const int32_t *sn2,
+                                  const int32_t *sct, const int32_t *sperm, const int32_t *img_off3,
+                                  const int32_t *osrc, void *nar, int64_t rows_total, int form,
+                                  void *stream)
 {
     IAMX_REQUIRE(desc && norm_q && norm_t && key_t && img_off && img_n && pairs && out_off && cand_cnt &&
                      task_total && tasks && cand_q && d2 && cand_t && cand_metric && cand_keep &&
@@ -1800,6 +2319,17 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
         hipLaunchKernelGGL((symexact_wg_kernel<true, 4>), dim3(2048), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((symexact_wg_kernel<true, 2>), dim3(2048), dim3(256), 0, st, a);
+    if (nar && narrow_enabled()) {
+        // (the same switch and the same buffer as iamx_knn2sym_candidates: pairs it bucketed have
+        //  no task in the two lists above)
+        if (!(sdesc && sn2 && sct && sperm && img_off3 && osrc && rows_total > 0 && form >= 0 && form <= 2))
+            return iamx::fail(IAMX_EINVAL, "iamx_knn2sym_exact: narrow workspace without the sorted store");
+        NarArgs na{desc, norm_q, img_off, pairs, osrc, out_off, cand_q, d2, sdesc, sn2, sct, sperm, img_off3,
+                   img_n, static_cast<int8_t *>(nar), rows_total, n_pairs, iamx_knn2sym_rows_per_wg(form),
+                   cand_cnt, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
+        hipLaunchKernelGGL(symnarrow_kernel, dim3(2048), dim3(256), 0, st, na);
+        hipLaunchKernelGGL(symnarrow_finish_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, na);
+    }
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,
                        cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total);
     return iamx::check_launch("iamx_knn2sym_exact");

@@ -442,7 +442,7 @@ class PairWorkspace(object):
         self.unresolved = self.flags[1:2]
         self.surv_cnt = torch.zeros(p, dtype=I32, device=dev)
         # symmetric sweep: bounds per row (allocated on first use, grown when a batch needs more)
-        self.col = self.rowp = None
+        self.col = self.rowp = self.colmask = self.nar = None
         self.cand_keep = torch.empty(r, dtype=U8, device=dev)
         # exact stage of the symmetric form: two task lists in one buffer (wave tasks from entry
         # 0, workgroup tasks from entry n_pairs) and their two counters
@@ -453,6 +453,13 @@ class PairWorkspace(object):
         dev = self.d2.device
         if self.col is None or self.col.shape[0] < col_rows:
             self.col = torch.empty((max(col_rows, 1), 2), dtype=I32, device=dev)
+            # which of its eight train-row groups can hold a query's best / second (narrow exact stage)
+            self.colmask = torch.empty(max(col_rows, 1), dtype=U8, device=dev)
+        if self.nar is None:
+            # items / tasks / partial results of the narrow exact stage, sized for the workspace's
+            # row and pair capacity (its control words start at 0; the stage leaves them 0)
+            self.nar = torch.zeros(max(int(lib().iamx_knn2sym_narrow_bytes(self.max_rows, self.max_pairs)),
+                                       256), dtype=U8, device=dev)
         if self.rowp is None or self.rowp.shape[0] < rowp_rows:
             self.rowp = torch.empty((max(rowp_rows, 1), 4), dtype=I32, device=dev)
 
@@ -593,7 +600,7 @@ class PairBatch(object):
                                        _ptr(st.img_n), _ptr(self.d_upairs), _ptr(self.d_sym_wg),
                                        _ptr(self.d_col_off), _ptr(self.d_rowp_off), self.n_u,
                                        self.sym_total_wg, self.sym_form, _ptr(ws.col), _ptr(ws.rowp),
-                                       stream_ptr()), 'iamx_knn2sym_sweep')
+                                       _ptr(ws.colmask), stream_ptr()), 'iamx_knn2sym_sweep')
 
     def run_sym_filter(self, ws, thresh):
         """candidate rows from the sweep's bounds, exact top-2 + metric test for those rows,
@@ -604,7 +611,8 @@ class PairBatch(object):
                                         _ptr(self.d_col_off), _ptr(self.d_rowp_off), _ptr(self.d_out),
                                         _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),
                                         _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_q),
-                                        _ptr(ws.task_total), _ptr(ws.tasks), _ptr(ws.d2), s),
+                                        _ptr(ws.task_total), _ptr(ws.tasks), _ptr(ws.d2),
+                                        _ptr(ws.colmask), _ptr(ws.nar), ws.max_rows, self.sym_form, s),
               'iamx_knn2sym_candidates')
         check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.key_t),
                                    st.norm_t.numel(), _ptr(st.img_off),
@@ -612,7 +620,9 @@ class PairBatch(object):
                                    _ptr(ws.seg_count), _ptr(ws.task_total), _ptr(ws.tasks),
                                    _ptr(ws.surv_q), self.n_pairs, float(thresh), _ptr(ws.d2),
                                    _ptr(ws.surv_t), _ptr(ws.surv_metric), _ptr(ws.cand_keep),
-                                   _ptr(ws.surv_cnt), _ptr(ws.zero_div), s), 'iamx_knn2sym_exact')
+                                   _ptr(ws.surv_cnt), _ptr(ws.zero_div), _ptr(st.desc3), _ptr(st.sn2),
+                                   _ptr(st.sct), _ptr(st.sperm), _ptr(st.img_off3), _ptr(self.d_osrc),
+                                   _ptr(ws.nar), ws.max_rows, self.sym_form, s), 'iamx_knn2sym_exact')
         # pair p's survivors sit at the start of its own row range
         ws.surv_off[:self.n_pairs + 1].copy_(self.d_out, non_blocking=True)
 

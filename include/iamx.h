@@ -244,30 +244,53 @@ int iamx_desc3_pack_batch_u8(const uint8_t *src, const int64_t *src_off, const i
                              int n_img, int64_t total_rows, int max_rows_per_image, int8_t *dst,
                              int32_t *sn2, int32_t *sct, int32_t *sperm, int32_t *sinv,
                              int32_t *scratch, void *stream);
+/* Narrow exact stage (round 6).  The sweep knows WHERE a candidate's two smallest distances can
+ * be: a query that was a B row has eight group minima over the streamed image (group = (32-row
+ * tile & 3, lane half): colmask DEV [col rows] uint8 receives the groups whose minimum is <= v2),
+ * a query that was an A row one (L, U1, U2) per row block of the register-resident image (block w
+ * can hold a row at or below the upper bound of the second distance only if L_w <= U2).  With
+ * nar != NULL (DEV, iamx_knn2sym_narrow_bytes(rows_total, n_pairs) bytes, rows_total = rows of
+ * all ordered pairs = out_off[n_pairs]; its first 256 bytes must be 0 on the first call, the exact
+ * stage leaves them 0) iamx_knn2sym_candidates turns the candidates of every ordered pair with more
+ * than 64 of them (train image >= 1024 rows, <= 64 row blocks) into items (candidate, class) bucketed
+ * by class, and iamx_knn2sym_exact scans ONE class per task -- 1/8 of the train image (column
+ * direction) or one row block (row direction) instead of all of it -- and merges a candidate's
+ * items.  Results are those of the full scan: every row that can be the best, the second or tied
+ * with either lies in a class of the candidate's mask.  Pairs whose items do not fit the buffer take
+ * the full scan.  The same nar / colmask / form must be given to both calls; nar == NULL (or the
+ * environment switch IAMX_EXACT_NARROW=0, read by both) = full scan for every pair. */
+int64_t iamx_knn2sym_narrow_bytes(int64_t rows_total, int n_pairs);
 int iamx_knn2sym_sweep(const int8_t *sdesc, const int32_t *sn2, const int32_t *sct,
                        const int32_t *img_off, const int32_t *img_n, const int32_t *upairs,
                        const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
-                       int n_u, int total_wg, int form, int32_t *col, int32_t *rowp, void *stream);
+                       int n_u, int total_wg, int form, int32_t *col, int32_t *rowp,
+                       uint8_t *colmask /* may be NULL */, void *stream);
 int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int32_t *img_off,
                             const int32_t *img_n, const int32_t *pairs, const int32_t *osrc,
                             const int32_t *wg_off, const int64_t *col_off, const int64_t *rowp_off,
                             const int64_t *out_off, const int32_t *col, const int32_t *rowp,
                             int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
                             int32_t *cand_q, int32_t *task_total, int32_t *tasks, int32_t *d2,
-                            void *stream);
+                            const uint8_t *colmask, void *nar /* may be NULL */, int64_t rows_total,
+                            int form, void *stream);
 /* key_t DEV [total_rows] int32 scratch beside norm_t (total_rows = rows of the whole original-
  * order store): rewritten by every call with the per-row constant of the packed (distance, row)
  * key.  task_total DEV [2], tasks DEV [2 n_pairs + rows / 32 + 2][2] (iamx_knn2sym_candidates
  * fills them: a pair with <= 64 candidates is one WAVE task, entries from 0; a pair with more
  * gets WORKGROUP tasks of 256 candidates, entries from n_pairs -- four waves share every train
- * tile through LDS; both counters are reset by this call). */
+ * tile through LDS; both counters are reset by this call).  sdesc / sn2 / sct / sperm / img_off3 =
+ * the SORTED store of the sweep, osrc as for iamx_knn2sym_candidates: read by the narrow stage only
+ * (may be NULL with nar == NULL). */
 int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, const int32_t *norm_t,
                        int32_t *key_t, int64_t total_rows,
                        const int32_t *img_off, const int32_t *img_n, const int32_t *pairs,
                        const int64_t *out_off, const int32_t *cand_cnt, int32_t *task_total,
                        const int32_t *tasks, int32_t *cand_q, int n_pairs, double thresh,
                        int32_t *d2, int32_t *cand_t, double *cand_metric, uint8_t *cand_keep,
-                       int32_t *surv_cnt, int32_t *zero_div, void *stream);
+                       int32_t *surv_cnt, int32_t *zero_div, const int8_t *sdesc,
+                       const int32_t *sn2, const int32_t *sct, const int32_t *sperm,
+                       const int32_t *img_off3, const int32_t *osrc, void *nar /* may be NULL */,
+                       int64_t rows_total, int form, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Per-pair match filters on the device, both directions of n_pairs image pairs, one workgroup

@@ -43,7 +43,7 @@ def test_argument_checks_do_not_need_a_gpu():
     rc = L.iamx_ba_residual(None, 1, None, 1, None, None, None, 0, None, None, None)
     assert rc == -1
     assert L.iamx_comm_allgather(None, None, None, 16, None) == -1
-    assert L.iamx_knn2sym_sweep(*([None] * 9), 1, 1, 2, None, None, None) == -1
+    assert L.iamx_knn2sym_sweep(*([None] * 9), 1, 1, 2, None, None, None, None) == -1
 
 
 def test_product_has_no_cpu_fallback():

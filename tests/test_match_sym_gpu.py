@@ -176,6 +176,74 @@ def test_sym_forms_vs_general_kernel_and_oracle(sizes, form):
             assert np.array_equal(a['d2'][a['off'][p] + keep], d2), (i, j)
 
 
+def _narrow_pairs(ws, n_pairs):
+    """ordered pairs of the last batch whose candidates went through the narrow exact stage
+    (include/iamx.h: the int32 table behind the 256 control bytes of the narrow workspace)"""
+    return int((ws.nar[256:256 + 4 * n_pairs].view(__import__('torch').int32) >= 0).sum().item())
+
+
+@pytest.mark.parametrize('sizes,form', [
+    ([6000, 5500, 4096, 9000], 2),
+    ([2500, 3000, 4000, 2048], 1),
+    ([1024, 1500, 2047, 1100], 0),
+], ids=['rows1024', 'rows512', 'rows256'])
+def test_narrow_exact_stage_equals_full_scan(sizes, form, monkeypatch):
+    """Overlapping images (hundreds to thousands of candidates per ordered pair): the narrow exact
+    stage -- one class of train rows per task, chosen by the sweep's group minima / block bounds --
+    must leave what the full scan leaves (IAMX_EXACT_NARROW=0), what the general kernel leaves,
+    and what oracle/cpu_ref.c says.  Planted: noisy copies between ALL images (best and second in
+    arbitrary classes), exact duplicates inside an image far apart in the sorted order's terms
+    (ties on the best: lowest ORIGINAL row wins; second == best), triples of identical rows
+    (three-way ties inside one lane's rows), identical rows across images (zero distances)."""
+    import torch
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(300 + form)
+    imgs = [_sift_like(rng, n) for n in sizes]
+    base = imgs[0]
+    for k in range(1, len(imgs)):
+        m = int(min(len(imgs[k]), len(base)) * 0.5)
+        src = rng.permutation(len(base))[:m]
+        dst = rng.permutation(len(imgs[k]))[:m]
+        imgs[k][dst] = np.clip(base[src].astype(int) + rng.integers(-5, 6, (m, 128)), 0, 255)
+    n1 = sizes[1]
+    imgs[1][n1 - 150:n1 - 50] = imgs[1][10:110]                    # duplicates: ties on the best
+    imgs[1][n1 - 50:n1 - 25] = imgs[1][200:225]                    # triples
+    imgs[1][n1 - 25:n1] = imgs[1][200:225]
+    imgs[2][:60] = imgs[3][500:560]                                # zero distances across images
+    store = kernels.DescriptorStore.from_arrays(imgs)
+    pairs = [(i, j) for i in range(len(sizes)) for j in range(len(sizes)) if i != j]
+    thresh = 270.0 * 0.75
+    pb = kernels.PairBatch(store, np.asarray(pairs, np.int32), sym=True)
+    ws = kernels.PairWorkspace(pb.rows, pb.n_pairs)
+    pb.run(ws, thresh)
+    torch.cuda.synchronize()
+    assert pb.sym_form == form
+    assert _narrow_pairs(ws, pb.n_pairs) == len(pairs)            # every pair has > 64 candidates
+    assert int(ws.nar[:8].view(torch.int32).abs().sum().item()) == 0     # control words back to 0
+    a = _run(store, pairs, thresh, sym=True)
+    assert a['unresolved'] == 0
+    monkeypatch.setenv('IAMX_EXACT_NARROW', '0')
+    f = _run(store, pairs, thresh, sym=True)
+    monkeypatch.delenv('IAMX_EXACT_NARROW')
+    b = _run(store, pairs, thresh, fast=False, sym=False)
+    _same_survivors(a, f)
+    _same_survivors(a, b)
+    assert np.diff(a['soff']).min() > 64
+    for p in (0, 3, 4, 7, len(pairs) - 1):
+        i, j = pairs[p]
+        keep, tr, mt, d2, zd = _oracle_survivors(imgs[i], imgs[j], thresh)
+        lo, hi = a['soff'][p], a['soff'][p + 1]
+        assert np.array_equal(a['sq'][lo:hi], keep), (i, j)
+        assert np.array_equal(a['st'][lo:hi], tr), (i, j)
+        assert np.array_equal(a['sm'][lo:hi], mt), (i, j)
+        assert np.array_equal(a['d2'][a['off'][p] + keep], d2), (i, j)
+    # a second batch on the same workspace (control words and buckets reused)
+    pb.run(ws, thresh)
+    torch.cuda.synchronize()
+    first, count, q, t, m = ws.survivors(pb.n_pairs)
+    assert np.array_equal(np.cumsum(count), a['soff'][1:]) and a['unresolved'] == 0
+
+
 def test_sym_second_inside_best_group_and_loose_bounds():
     """Adversarial for the bounds of the sweep: the true second neighbour next to the best (same
     group of train rows), on both sides of the threshold; duplicates of the best; exact-zero
