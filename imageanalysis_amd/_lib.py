@@ -54,7 +54,7 @@ SIGNATURES = {
     'iamx_knn2sym_narrow_bytes': (c_int64, [c_int64, c_int]),
     'iamx_knn2sym_sweep': (c_int, [c_void_p] * 9 + [c_int, c_int, c_int] + [c_void_p] * 4),
     'iamx_knn2sym_candidates': (c_int, [c_void_p] * 12 + [c_int, c_double] + [c_void_p] * 8
-                                + [c_int64, c_int, c_void_p]),
+                                + [c_int64, c_int, c_int, c_void_p]),
     'iamx_knn2sym_exact': (c_int, [c_void_p] * 4 + [c_int64] + [c_void_p] * 8 + [c_int, c_double]
                            + [c_void_p] * 13 + [c_int64, c_int, c_void_p]),
     'iamx_match_postfilter_clip': (c_int, []),

@@ -928,7 +928,7 @@ struct NarLayout {
     int64_t ctl, pair_base, mask, slot, items, res, tasks, total;
     int64_t item_cap, task_cap;
 };
-// ctl[0] narrow tasks, ctl[1] items allocated (zero on entry, reset by the finish kernel)
+// ctl[0] narrow tasks, ctl[1] items allocated, ctl[2] tasks taken (zero on entry, reset by the finish kernel)
 __host__ __device__ inline NarLayout narrow_layout(int64_t rows, int64_t n_pairs)
 {
     NarLayout L;
@@ -971,18 +971,11 @@ struct CandArgs {
     int n_pairs, wgrows;
 };
 
-// pass 1, one thread per query row of every ordered pair (block b belongs to the pair p with
-// out_off[p] / 256 + p <= b: every pair wastes less than one block): bounds -> candidate flag at
-// the row's original position, the upper bound of its second distance, its class mask.
-__global__ __launch_bounds__(256) void symcand_rows_kernel(CandArgs A)
+// pass 1, one thread per query row of every ordered pair (grid: 256-row chunks of the largest
+// query image x ordered pairs): bounds -> candidate flag at the row's original position, the upper
+// bound of its second distance, its class mask.
+__device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int pos)
 {
-    int lo = 0, hi = A.n_pairs;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if ((int64_t)(A.out_off[mid] >> 8) + mid <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
-    }
-    const int p = lo;
-    const int pos = (int)((int64_t)blockIdx.x - ((A.out_off[p] >> 8) + p)) * 256 + threadIdx.x;
     const int qimg = A.pairs[2 * p];
     const int u = A.osrc[2 * p], role = A.osrc[2 * p + 1];
     const int soff = A.img_off[qimg], n = A.img_n[qimg];
@@ -1038,6 +1031,11 @@ __global__ __launch_bounds__(256) void symcand_rows_kernel(CandArgs A)
         const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
         reinterpret_cast<unsigned long long *>(A.nar + NL.mask)[ob + orig] = mk;
     }
+}
+
+__global__ __launch_bounds__(256) void symcand_rows_kernel(CandArgs A)
+{
+    for (int p = blockIdx.y; p < A.n_pairs; p += gridDim.y) symcand_rows_pair(A, p, blockIdx.x * 256 + threadIdx.x);
 }
 
 // passes 2 and 3, one workgroup per ordered pair
@@ -1787,7 +1785,8 @@ struct NarArgs {
 constexpr int NAR_HALF_INVALID = 1 << 25;
 constexpr int NAR_D_INVALID = 0x7FFFFFFF;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void symnarrow_kernel(NarArgs A)
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void symnarrow_kernel(NarArgs A)
 {
     constexpr int SUB = 2, PR = 32 * SUB;
     __shared__ __attribute__((aligned(16))) int8_t s_tile[2][PR * D];
@@ -1795,7 +1794,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __shared__ __attribute__((aligned(16))) int32_t s_pk[2][PR];
     __shared__ __attribute__((aligned(16))) int32_t s_idx[2][PR];
     const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
-    const int32_t *ctl = reinterpret_cast<const int32_t *>(A.nar + NL.ctl);
+    int32_t *ctl = reinterpret_cast<int32_t *>(A.nar + NL.ctl);
     const NarTask *ntasks = reinterpret_cast<const NarTask *>(A.nar + NL.tasks);
     const v2i *items = reinterpret_cast<const v2i *>(A.nar + NL.items);
     v4i *res = reinterpret_cast<v4i *>(A.nar + NL.res);
@@ -1803,7 +1802,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, g = lane >> 5;
     const int lrow = threadIdx.x >> 3, lchunk = threadIdx.x & 7;      // staging: 16 bytes per thread
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    // tasks are taken from a counter (ctl[2]; reset by the finish kernel): a column-direction task
+    // scans 4.5 x the rows of a row-direction one, and only part of the grid is resident at a time
+    __shared__ int s_task;
+    for (;;) {
+        __syncthreads();                               // (the previous task's last tile is consumed)
+        if (threadIdx.x == 0) s_task = atomicAdd(ctl + 2, 1);
+        __syncthreads();
+        const int t = s_task;
+        if (t >= total) break;
         const NarTask task = ntasks[t];
         const int p = __builtin_amdgcn_readfirstlane(task.p);
         const int cls = __builtin_amdgcn_readfirstlane(task.cls);
@@ -1894,7 +1901,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         };
         v4i pre[SUB], pre_meta;
         const int nph = (ntiles + SUB - 1) / SUB;
-        __syncthreads();                               // (the previous task's last tile is consumed)
         if (nph > 0) {
             fetch(0, pre, pre_meta);
             stage(0, pre, pre_meta);
@@ -2001,7 +2007,7 @@ __global__ __launch_bounds__(256) void symnarrow_finish_kernel(NarArgs A)
     const int p = blockIdx.x;
     if (p == 0 && threadIdx.x == 0) {                   // the scan has consumed tasks and items
         int32_t *ctl = reinterpret_cast<int32_t *>(A.nar + NL.ctl);
-        ctl[0] = ctl[1] = 0;
+        ctl[0] = ctl[1] = ctl[2] = 0;
     }
     const int b0 = pair_base[p];
     if (b0 < 0) return;
@@ -2255,7 +2261,7 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                                        double thresh, uint8_t *keep, int32_t *cand_cnt,
                                        int32_t *cand_q, int32_t *task_total, int32_t *tasks,
                                        int32_t *d2, const uint8_t *colmask, void *nar,
-                                       int64_t rows_total, int form, void *stream)
+                                       int64_t rows_total, int max_query_rows, int form, void *stream)
 {
     IAMX_REQUIRE(sn2 && sperm && img_off && img_n && pairs && osrc && wg_off && col_off && rowp_off &&
                      out_off && col && rowp && keep && cand_cnt && cand_q && task_total && tasks && d2,
@@ -2268,8 +2274,10 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                colmask, narrow_enabled() ? static_cast<int8_t *>(nar) : nullptr, rows_total, n_pairs,
                iamx_knn2sym_rows_per_wg(form)};
     IAMX_REQUIRE(rows_total > 0 && rows_total < (1ll << 31), "rows_total = rows of all ordered pairs");
-    hipLaunchKernelGGL(symcand_rows_kernel, dim3((unsigned)((rows_total >> 8) + n_pairs + 1)), dim3(256), 0,
-                       iamx::as_stream(stream), a);
+    IAMX_REQUIRE(max_query_rows > 0, "max_query_rows = rows of the largest query image");
+    hipLaunchKernelGGL(symcand_rows_kernel,
+                       dim3((unsigned)((max_query_rows + 255) / 256), (unsigned)(n_pairs < 65535 ? n_pairs : 65535)),
+                       dim3(256), 0, iamx::as_stream(stream), a);
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
 }
@@ -2327,7 +2335,11 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
         NarArgs na{desc, norm_q, img_off, pairs, osrc, out_off, cand_q, d2, sdesc, sn2, sct, sperm, img_off3,
                    img_n, static_cast<int8_t *>(nar), rows_total, n_pairs, iamx_knn2sym_rows_per_wg(form),
                    cand_cnt, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
-        hipLaunchKernelGGL(symnarrow_kernel, dim3(2048), dim3(256), 0, st, na);
+        const char *wpe = getenv("IAMX_NARROW_WPE");
+        if (wpe && wpe[0] == '2')
+            hipLaunchKernelGGL(symnarrow_kernel<2>, dim3(512), dim3(256), 0, st, na);
+        else
+            hipLaunchKernelGGL(symnarrow_kernel<3>, dim3(768), dim3(256), 0, st, na);
         hipLaunchKernelGGL(symnarrow_finish_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, na);
     }
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,

@@ -559,6 +559,7 @@ class PairBatch(object):
         if wg[-1] >= 2 ** 31:
             raise ValueError("batch too large: split the pair list")
         self.rows = int(self.out_off[-1])
+        self.max_query_rows = int(nq.max()) if P else 0
         self.total_wg = int(wg[-1])
         self.d_pairs = up(pairs)
         self.d_wg = up(wg.astype(np.int32))
@@ -612,7 +613,8 @@ class PairBatch(object):
                                         _ptr(ws.col), _ptr(ws.rowp), self.n_pairs, float(thresh),
                                         _ptr(ws.keep), _ptr(ws.seg_count), _ptr(ws.surv_q),
                                         _ptr(ws.task_total), _ptr(ws.tasks), _ptr(ws.d2),
-                                        _ptr(ws.colmask), _ptr(ws.nar), ws.max_rows, self.sym_form, s),
+                                        _ptr(ws.colmask), _ptr(ws.nar), ws.max_rows, self.max_query_rows,
+                                        self.sym_form, s),
               'iamx_knn2sym_candidates')
         check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.key_t),
                                    st.norm_t.numel(), _ptr(st.img_off),

@@ -272,7 +272,8 @@ int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm, const int3
                             int n_pairs, double thresh, uint8_t *keep, int32_t *cand_cnt,
                             int32_t *cand_q, int32_t *task_total, int32_t *tasks, int32_t *d2,
                             const uint8_t *colmask, void *nar /* may be NULL */, int64_t rows_total,
-                            int form, void *stream);
+                            int max_query_rows /* rows of the largest query image */, int form,
+                            void *stream);
 /* key_t DEV [total_rows] int32 scratch beside norm_t (total_rows = rows of the whole original-
  * order store): rewritten by every call with the per-row constant of the packed (distance, row)
  * key.  task_total DEV [2], tasks DEV [2 n_pairs + rows / 32 + 2][2] (iamx_knn2sym_candidates

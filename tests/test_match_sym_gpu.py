@@ -219,7 +219,7 @@ def test_narrow_exact_stage_equals_full_scan(sizes, form, monkeypatch):
     torch.cuda.synchronize()
     assert pb.sym_form == form
     assert _narrow_pairs(ws, pb.n_pairs) == len(pairs)            # every pair has > 64 candidates
-    assert int(ws.nar[:8].view(torch.int32).abs().sum().item()) == 0     # control words back to 0
+    assert int(ws.nar[:16].view(torch.int32).abs().sum().item()) == 0    # control words back to 0
     a = _run(store, pairs, thresh, sym=True)
     assert a['unresolved'] == 0
     monkeypatch.setenv('IAMX_EXACT_NARROW', '0')

@@ -43,3 +43,20 @@ print('%d ordered pairs in %.1f ms' % (len(ordered), dt * 1e3))
 for (a, b), r, c, s in zip(ordered.tolist(), rows, cand, surv):
     print('  %d -> %d: rows %6d  candidates %6d (%.1f %%)  survivors %5d' % (a, b, r, c, 100.0 * c / r, s))
 print('total: rows %d, candidates %d (%.1f %%), survivors %d' % (rows.sum(), cand.sum(), 100.0 * cand.sum() / rows.sum(), surv.sum()))
+
+# narrow exact stage: classes per candidate (the mask symcand_rows_kernel left; layout of the narrow
+# workspace: 256 control bytes, pair table, then one uint64 mask per query row at its original position)
+if ws.nar is not None and os.environ.get('IAMX_EXACT_NARROW', '1') != '0':
+    up = lambda v: (v + 255) // 256 * 256                                       # noqa: E731
+    mask_off = 256 + up(4 * pb.n_pairs)
+    masks = ws.nar[mask_off:mask_off + 8 * pb.rows].view(torch.int64).cpu().numpy()
+    keep = ws.keep[:pb.rows].cpu().numpy().astype(bool)
+    sel = np.nonzero(keep)[0]
+    sel = sel[::max(1, len(sel) // 200000)]
+    pc = np.array([bin(int(m) & (2 ** 64 - 1)).count('1') for m in masks[sel]])
+    osrc = pb.d_osrc.cpu().numpy().reshape(-1, 2)
+    role = np.repeat(osrc[:, 1], np.diff(pb.out_off))[sel]
+    for r, name in ((0, 'column direction (8 groups)'), (1, 'row direction (row blocks)')):
+        v = pc[role == r]
+        if len(v):
+            print('classes per candidate, %s: mean %.2f, histogram %s' % (name, v.mean(), np.bincount(v)[:12].tolist()))
