@@ -739,9 +739,12 @@ def dense_overlap_bench(dev, oracle_pairs=4, n_img=12, rows=16384):
             "pairs_per_sec_in_4096_row_units": round(len(und) * (rows / float(KPTS)) ** 2 / (sum(best) * 1e-3), 1),
             "sweep_tflops": round(flop_sweep / (best[0] * 1e-3) / 1e12, 1),
             "exact_stage_tflops": round(flop_exact / (best[1] * 1e-3) / 1e12, 1),
-            "exact_stage": "symexact_wg_kernel: 256 candidates per workgroup, train tiles shared through "
-                           "LDS, tiles that cannot hold a candidate's best or second skipped on the "
-                           "candidate test's bound (+ candidate test, compaction in the same interval)",
+            "exact_stage": "symnarrow_kernel: a candidate is re-scanned only against the classes of train "
+                           "rows the sweep's group minima / block bounds leave open (1/8 of the image or "
+                           "one row block per task of 256 (candidate, class) items, tiles through LDS, "
+                           "pruned on the candidate test's bound; exact_stage_tflops counts the FULL "
+                           "scan's flops it replaces) + candidate test, item bucketing, merge, compaction "
+                           "in the same interval; IAMX_EXACT_NARROW=0: symexact_wg_kernel's full scan",
             "one_direction_form": one_dir,
             "routed_pairs_per_sec": round(max(len(und) / (sum(best) * 1e-3), one_dir["pairs_per_sec"]), 1),
             "verified_pairs": checked, "against": "oracle/cpu_ref.c"}

@@ -108,8 +108,109 @@ __global__ __launch_bounds__(256) void pack3_rows_kernel(Pack3Args P, int64_t to
     }
 }
 
-// rank of every row inside its image = rows with a smaller key (ties: the earlier row), by
-// counting.  blockIdx.z splits the comparisons of a 256-row group over `gridDim.z` workgroups
+// rank of every row inside its image = rows with a smaller key (ties: the earlier row).
+// FIRST by binning (round 6; one workgroup per image): the keys of an image spread over a few
+// hundred thousand values, so 4096 equal-width bins between its smallest and its largest key hold a
+// few dozen rows each -- histogram in LDS, exclusive scan, the rows of a bin listed (row, key) in the
+// image's still unused sperm / sinv slices, and a row's rank = start of its bin + the rows of its bin
+// that come before it: n x (rows per bin) comparisons instead of n x n (51 ms per 256 frames of
+// 37 k rows -> well under one).  An image whose fullest bin exceeds RANK_BIN_LIMIT rows (constant
+// images, synthetic ties) is left to the counting kernel below: RANK_TODO at the head of its sct slice.
+constexpr int RANK_BINS = 4096;
+constexpr int RANK_BIN_LIMIT = 1024;
+constexpr int RANK_TODO = 0x52414E4B;
+
+__global__ __launch_bounds__(1024) void pack3_rank_bins_kernel(Pack3Args P)
+{
+    __shared__ int start[RANK_BINS + 1];
+    __shared__ int cursor[RANK_BINS];
+    __shared__ int wsum[16];
+    __shared__ int s_lo, s_hi, s_max;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = P.src_off ? P.src_off[img] : 0;
+    const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
+    const int d0 = P.dst_off ? P.dst_off[img] : 0;
+    if (n <= 0) return;
+    const int32_t *key = P.n2 + r0;
+    int32_t *list_row = P.sperm + d0, *list_key = P.sinv + d0;
+    if (tid == 0) { s_lo = 0x7FFFFFFF; s_hi = -0x7FFFFFFF; s_max = 0; }
+    for (int b = tid; b < RANK_BINS; b += 1024) cursor[b] = 0;
+    __syncthreads();
+    int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+    for (int r = tid; r < n; r += 1024) {
+        const int k = key[r];
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, __shfl_xor(lo, m));
+        hi = max(hi, __shfl_xor(hi, m));
+    }
+    if (lane == 0) { atomicMin(&s_lo, lo); atomicMax(&s_hi, hi); }
+    __syncthreads();
+    lo = s_lo;
+    int shift = 0;
+    while (((int64_t)s_hi - lo) >> shift >= RANK_BINS) ++shift;
+    for (int r = tid; r < n; r += 1024) atomicAdd(&cursor[(key[r] - lo) >> shift], 1);
+    __syncthreads();
+    // exclusive scan of the 4096 counts: 4 per thread, waves through shuffles, 16 wave sums through LDS
+    int c[4], t = 0, mx = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = cursor[4 * tid + k];
+        t += c[k];
+        mx = max(mx, c[k]);
+    }
+    int x = t;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        const int y = __shfl_up(x, sft);
+        if (lane >= sft) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = max(mx, __shfl_xor(mx, m));
+    if (lane == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + x - t;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        start[4 * tid + k] = run;
+        run += c[k];
+    }
+    if (tid == 1023) start[RANK_BINS] = run;
+    __syncthreads();
+    if (s_max > RANK_BIN_LIMIT) {                        // (uniform: the counting kernel takes the image)
+        if (tid == 0) P.sct[d0] = RANK_TODO;
+        return;
+    }
+    if (tid == 0) P.sct[d0] = 0;
+    for (int b = tid; b < RANK_BINS; b += 1024) cursor[b] = start[b];
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) {
+        const int k = key[r];
+        const int at = atomicAdd(&cursor[(k - lo) >> shift], 1);
+        list_row[at] = r;
+        list_key[at] = k;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int r = tid; r < n; r += 1024) {
+        const int k = key[r], b = (k - lo) >> shift;
+        const int e = start[b + 1];
+        int cnt = start[b];
+        for (int i = start[b]; i < e; ++i) {
+            const int kj = list_key[i], j = list_row[i];
+            cnt += (kj < k) || (kj == k && j < r);
+        }
+        P.pos[r0 + r] = cnt;
+    }
+}
+
+// The counting form (every image until round 6; now the images the binning kernel leaves).  blockIdx.z splits the comparisons of a 256-row group over `gridDim.z` workgroups
 // (each adds its part to pos[], zeroed by the caller): one 38 k-row frame is 150 groups x 38 k
 // compares -- 150 workgroups leave most of the chip idle (1.55 ms per frame, a fifth of the
 // match stage of a 128-frame survey); split 16 ways it is 0.15 ms.
@@ -120,6 +221,8 @@ __global__ __launch_bounds__(256) void pack3_rank_kernel(Pack3Args P)
     const int64_t r0 = P.src_off ? P.src_off[img] : 0;
     const int n = (int)(P.src_off ? P.src_off[img + 1] - r0 : P.single_n);
     if ((int)blockIdx.x * 256 >= n) return;
+    // (only the images pack3_rank_bins_kernel left: it drops RANK_TODO at the head of the image's sct slice)
+    if (P.sct[P.dst_off ? P.dst_off[img] : 0] != RANK_TODO) return;
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int mine = r < n ? P.n2[r0 + r] : 0;
     const int tiles = (n + 1023) / 1024, per = (tiles + (int)gridDim.z - 1) / (int)gridDim.z;
@@ -188,6 +291,24 @@ __global__ __launch_bounds__(256) void pack3_scatter_kernel(Pack3Args P)
 // ---------------------------------------------------------------------------------
 // sweep
 // ---------------------------------------------------------------------------------
+// a row partial in 8 bytes (16 until round 6: the partials are a quarter of the sweep's HBM traffic,
+// all of the candidate pass's, and what bounds the pairs of a round): the lower bound L and the
+// two upper bounds as 16-bit offsets from it -- an offset that does not fit (the waves' minima of a
+// row lie a few thousand apart) saturates and reads back as "no bound": still an upper bound.
+constexpr int ROW_NO_BOUND = 0x7F000000;
+__device__ __forceinline__ int pack_row_bounds(int L, int U1, int U2)
+{
+    const int d1 = min(U1 - L, 0xFFFF), d2 = min(U2 - L, 0xFFFF);
+    return d1 | (d2 << 16);
+}
+__device__ __forceinline__ void unpack_row_bounds(v2i e, int &L, int &U1, int &U2)
+{
+    const int d1 = e.y & 0xFFFF, d2 = (int)((unsigned)e.y >> 16);
+    L = e.x;
+    U1 = d1 == 0xFFFF ? ROW_NO_BOUND : e.x + d1;
+    U2 = d2 == 0xFFFF ? ROW_NO_BOUND : e.x + d2;
+}
+
 struct SymArgs {
     const int8_t *sdesc;
     const int32_t *sn2, *sct;
@@ -197,7 +318,7 @@ struct SymArgs {
     const int64_t *col_off;      // [n_u] first column-result row (sum of B caps)
     const int64_t *rowp_off;     // [n_u] first row partial (sum of workgroups x A caps)
     int32_t *col;                // [..][2]  (v1, v2)
-    int32_t *rowp;               // [..][4]  (L, U1, U2, -)
+    int32_t *rowp;               // [..][2]  (L, (U1 - L) | (U2 - L) << 16, each saturated at 0xFFFF = "no bound")
     int n_u, total_wg;
     uint8_t *colmask;            // [..] per column-result row: the groups (bit (tile & 3) + 4 * lane half)
                                  //      whose minimum is <= v2 (NULL: not wanted) -- the only train rows
@@ -418,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
             U2 = min(max(U1, uw), U2);
             U1 = min(U1, uw);
         }
-        *reinterpret_cast<v4i *>(A.rowp + 4 * (rbase + ch * CHUNK + tid)) = v4i{L, U1, U2, 0};
+        *reinterpret_cast<v2i *>(A.rowp + 2 * (rbase + ch * CHUNK + tid)) = v2i{L, pack_row_bounds(L, U1, U2)};
     };
 
     stage_direct(0, 0);
@@ -767,7 +888,7 @@ __global__ __launch_bounds__(NW * 64, 2) void knn2sym_x_kernel(SymArgs A)
             U2 = min(max(U1, uw), U2);
             U1 = min(U1, uw);
         }
-        *reinterpret_cast<v4i *>(A.rowp + 4 * (rbase + ch * CHUNK + mrow)) = v4i{L, U1, U2, 0};
+        *reinterpret_cast<v2i *>(A.rowp + 2 * (rbase + ch * CHUNK + mrow)) = v2i{L, pack_row_bounds(L, U1, U2)};
     };
     // barrier M(ch): see the header.  b2 = buffer of chunk ch+2 = buffer of chunk ch-1
     auto mid_barrier = [&](int ch, int b2) {
@@ -983,7 +1104,7 @@ __device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int 
     const int cap = (n + CHUNK - 1) / CHUNK * CHUNK;
     const int nwg = A.wg_off[u + 1] - A.wg_off[u];
     const int64_t ob = A.out_off[p];
-    const int32_t *rowq = A.rowp + 4 * A.rowp_off[u];
+    const int32_t *rowq = A.rowp + 2 * A.rowp_off[u];
     // narrow exact stage: classes of this ordered pair's train image (8 groups of the streamed image
     // when the query was a B row, the nwg row blocks of the register-resident image otherwise)
     const int ncls = role == 0 ? 8 : nwg;
@@ -999,11 +1120,12 @@ __device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int 
     } else {
         int L = 0x7FFFFFFF, U1 = 0x7FFFFFFF;
         for (int w = 0; w < nwg; ++w) {
-            const v4i e = *reinterpret_cast<const v4i *>(rowq + 4 * ((int64_t)w * cap + pos));
-            L = min(L, e.x);
-            // merge the sorted pairs (U1, U2) and (e.y, e.z)
-            const int n1 = min(U1, e.y);
-            U2 = min(max(U1, e.y), min(U2, e.z));
+            int eL, e1, e2;
+            unpack_row_bounds(*reinterpret_cast<const v2i *>(rowq + 2 * ((int64_t)w * cap + pos)), eL, e1, e2);
+            L = min(L, eL);
+            // merge the sorted pairs (U1, U2) and (e1, e2)
+            const int n1 = min(U1, e1);
+            U2 = min(max(U1, e1), min(U2, e2));
             U1 = n1;
         }
         Lb = 2ll * L + par;
@@ -1026,7 +1148,7 @@ __device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int 
             mk = A.colmask[A.col_off[u] + pos];
         } else {
             for (int w = 0; w < nwg; ++w)
-                if (rowq[4 * ((int64_t)w * cap + pos)] <= U2) mk |= 1ull << w;
+                if (rowq[2 * ((int64_t)w * cap + pos)] <= U2) mk |= 1ull << w;
         }
         const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
         reinterpret_cast<unsigned long long *>(A.nar + NL.mask)[ob + orig] = mk;
@@ -1785,7 +1907,9 @@ struct NarArgs {
 constexpr int NAR_HALF_INVALID = 1 << 25;
 constexpr int NAR_D_INVALID = 0x7FFFFFFF;
 
-template <int WPE>
+// ABL != 0: timing ablations (IAMX_NARROW_ABL; results are meaningless): 1 = no tile passes the
+// pruning test, 2 = and no MFMA
+template <int WPE, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void symnarrow_kernel(NarArgs A)
 {
     constexpr int SUB = 2, PR = 32 * SUB;
@@ -1926,15 +2050,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         if (h == 1 && n_sets < 2) break;
-                        v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[h][0], cin, 0, 0, 0);
+                        v16i acc;
+                        if constexpr (ABL == 2) {
+                            acc = cin;
 #pragma unroll
-                        for (int s = 1; s < 4; ++s)
-                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                            for (int s = 0; s < 4; ++s) acc[s] += a[s][0] ^ bq[h][s][1];
+                        } else {
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[0], bq[h][0], cin, 0, 0, 0);
+#pragma unroll
+                            for (int s = 1; s < 4; ++s)
+                                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[h][s], acc, 0, 0, 0);
+                        }
                         const int t0 = min(min(acc[0], acc[1]), acc[2]), t1 = min(min(acc[3], acc[4]), acc[5]);
                         const int t2 = min(min(acc[6], acc[7]), acc[8]), t3 = min(min(acc[9], acc[10]), acc[11]);
                         const int t4 = min(min(acc[12], acc[13]), acc[14]);
                         const int lo = min(min(min(t0, t1), t2), min(min(t3, t4), acc[15]));
-                        if (__ballot(lo <= hmax[h]) == 0ull) continue;
+                        if (__ballot(lo <= (ABL ? -0x7FFFFFF0 : hmax[h])) == 0ull) continue;
                         v4i tk[4];
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
@@ -2130,6 +2261,7 @@ static int pack3_launch(Pack3Args P, int64_t total_rows, int max_rows, void *str
     int split = 1;
     while (split < 32 && groups * split < 2048 && max_rows > 1024 * split) split *= 2;
     if (split > 1) (void)hipMemsetAsync(P.pos, 0, (size_t)total_rows * sizeof(int32_t), st);
+    hipLaunchKernelGGL(pack3_rank_bins_kernel, dim3((unsigned)P.n_img), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(pack3_rank_kernel,
                        dim3((unsigned)((max_rows + 255) / 256), (unsigned)P.n_img, (unsigned)split),
                        dim3(256), 0, st, P);
@@ -2336,7 +2468,12 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
                    img_n, static_cast<int8_t *>(nar), rows_total, n_pairs, iamx_knn2sym_rows_per_wg(form),
                    cand_cnt, thresh, d2, cand_t, cand_metric, cand_keep, zero_div};
         const char *wpe = getenv("IAMX_NARROW_WPE");
-        if (wpe && wpe[0] == '2')
+        const char *abl = getenv("IAMX_NARROW_ABL");
+        if (abl && abl[0] == '1')
+            hipLaunchKernelGGL((symnarrow_kernel<3, 1>), dim3(768), dim3(256), 0, st, na);
+        else if (abl && abl[0] == '2')
+            hipLaunchKernelGGL((symnarrow_kernel<3, 2>), dim3(768), dim3(256), 0, st, na);
+        else if (wpe && wpe[0] == '2')
             hipLaunchKernelGGL(symnarrow_kernel<2>, dim3(512), dim3(256), 0, st, na);
         else
             hipLaunchKernelGGL(symnarrow_kernel<3>, dim3(768), dim3(256), 0, st, na);

@@ -440,7 +440,11 @@ def _worker_stream():
     dev = torch.cuda.current_device()
     st = streams.get(dev)
     if st is None:
-        st = streams[dev] = torch.cuda.Stream(device=dev)
+        # high priority: a detection is ~40 short dependent kernels; beside find_matches' sweeps (long
+        # kernels that fill every CU) each of them would otherwise queue for the compute units
+        # the sweep's workgroups give back
+        prio = int(os.environ.get('IAMX_WORKER_PRIO', '-1'))
+        st = streams[dev] = torch.cuda.Stream(device=dev, priority=prio)
     return st
 
 

@@ -461,7 +461,7 @@ class PairWorkspace(object):
             self.nar = torch.zeros(max(int(lib().iamx_knn2sym_narrow_bytes(self.max_rows, self.max_pairs)),
                                        256), dtype=U8, device=dev)
         if self.rowp is None or self.rowp.shape[0] < rowp_rows:
-            self.rowp = torch.empty((max(rowp_rows, 1), 4), dtype=I32, device=dev)
+            self.rowp = torch.empty((max(rowp_rows, 1), 2), dtype=I32, device=dev)
 
     def survivor_counts(self, n_pairs):
         """host copies of (first, count) per pair only"""

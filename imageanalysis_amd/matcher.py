@@ -96,14 +96,14 @@ def _route_next():
 def _workspace_bytes_per_pair(rows):
     """device workspace one unordered image pair of `rows`-descriptor images needs in a batch:
     the per-row partial bounds of the symmetric sweep (workgroups of the register-resident image
-    x padded rows of the streamed one x 16 B) dominate -- 0.26 MB at 4096 rows, 39 MB at 50 k --,
+    x padded rows of the streamed one x 8 B) dominate -- 0.13 MB at 4096 rows, 20 MB at 50 k --,
     then ~48 B per query row and direction (distances, candidates, survivors), ~41 B for the
     narrow exact stage (class mask, result slots, items, partial results, group byte) and the
     per-pair result slots of the filters"""
     rows = max(int(rows), 1)
     wg_rows = 1024 if rows >= 4096 else (512 if rows >= 2048 else 256)
     cap = (rows + 127) // 128 * 128
-    return ((rows + wg_rows - 1) // wg_rows) * cap * 16 + 2 * rows * 90 + 96 * 1024
+    return ((rows + wg_rows - 1) // wg_rows) * cap * 8 + 2 * rows * 90 + 96 * 1024
 
 
 def _batch_bytes():

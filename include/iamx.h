@@ -206,7 +206,7 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  *   wg_off   DEV [n_u+1] int32  scan of ceil(n_B / rows_per_wg);  total_wg = wg_off[n_u]
  *   col_off  DEV [n_u] int64    first entry of pair u in col  (scan of rows_cap(B))
  *   rowp_off DEV [n_u] int64    first entry of pair u in rowp (scan of workgroups x rows_cap(A))
- *   col  DEV [..][2] int32, rowp DEV [..][4] int32 (16-byte aligned): the bounds, internal format
+ *   col  DEV [..][2] int32, rowp DEV [..][2] int32 (8-byte aligned): the bounds, internal format
  * Candidates: pairs DEV [n_pairs][2] ordered (query image, train image); osrc DEV [n_pairs][2] =
  *   (index u of its unordered pair, role: 0 if the query image is B, 1 if it is A);
  *   out_off DEV [n_pairs+1] int64 rows of each ordered pair; keep DEV [rows] uint8 scratch;

@@ -16,14 +16,21 @@ import torch  # noqa: E402
 
 from imageanalysis_amd import image as iimg, kernels, synth  # noqa: E402
 
-tmp = tempfile.mkdtemp(prefix='iamx_cand_')
-names, truth, logged, K = synth.make_rendered_survey(tmp, 2, 3, device='cuda', **synth.FULL_FRAME)
-des = []
-for n in names:
-    bgr = iimg._decode_bgr(os.path.join(tmp, 'images', n + '.JPG'))
-    kp, d32, d8 = iimg.features_from_bgr(bgr, 0.4, equalize=True, keep_u8=True)
-    des.append(np.ascontiguousarray(d8))
-    print(n, len(d8), 'keypoints')
+cache = os.environ.get('IAMX_CAND_CACHE')            # .npz of the detected descriptors (several runs, one render)
+if cache and os.path.exists(cache):
+    z = np.load(cache)
+    des = [z[k] for k in sorted(z.files)]
+else:
+    tmp = tempfile.mkdtemp(prefix='iamx_cand_')
+    names, truth, logged, K = synth.make_rendered_survey(tmp, 2, 3, device='cuda', **synth.FULL_FRAME)
+    des = []
+    for n in names:
+        bgr = iimg._decode_bgr(os.path.join(tmp, 'images', n + '.JPG'))
+        kp, d32, d8 = iimg.features_from_bgr(bgr, 0.4, equalize=True, keep_u8=True)
+        des.append(np.ascontiguousarray(d8))
+        print(n, len(d8), 'keypoints')
+    if cache:
+        np.savez(cache, **{'d%02d' % i: d for i, d in enumerate(des)})
 store = kernels.DescriptorStore.from_arrays(des)
 und = [(a, b) for a in range(len(des)) for b in range(a + 1, len(des))]
 ordered = np.array(und + [(b, a) for a, b in und], np.int32)
@@ -36,6 +43,21 @@ for it in range(2):
     pb.run(ws, thresh)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+# sweep and filter + exact stage apart (events on the launch stream, 10 repetitions)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+tt = [0.0, 0.0]
+for it in range(10):
+    ev[0].record()
+    pb.run_sym_sweep(ws)
+    ev[1].record()
+    pb.run_sym_filter(ws, thresh)
+    ev[2].record()
+    torch.cuda.synchronize()
+    tt[0] += ev[0].elapsed_time(ev[1]) / 10
+    tt[1] += ev[1].elapsed_time(ev[2]) / 10
+print('sweep %.3f ms, filter + exact stage %.3f ms (IAMX_EXACT_NARROW=%s IAMX_NARROW_ABL=%s IAMX_NARROW_WPE=%s)'
+      % (tt[0], tt[1], os.environ.get('IAMX_EXACT_NARROW', '1'), os.environ.get('IAMX_NARROW_ABL', '0'),
+         os.environ.get('IAMX_NARROW_WPE', '3')))
 cand = ws.seg_count[:pb.n_pairs].cpu().numpy()
 surv = ws.surv_cnt[:pb.n_pairs].cpu().numpy()
 rows = np.array([len(des[a]) for a, _b in ordered])
