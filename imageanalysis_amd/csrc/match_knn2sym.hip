@@ -298,8 +298,16 @@ __global__ __launch_bounds__(256) void pack3_scatter_kernel(Pack3Args P)
 constexpr int ROW_NO_BOUND = 0x7F000000;
 __device__ __forceinline__ int pack_row_bounds(int L, int U1, int U2)
 {
-    const int d1 = min(U1 - L, 0xFFFF), d2 = min(U2 - L, 0xFFFF);
-    return d1 | (d2 << 16);
+#if defined(IAMX_T_NOPACK)
+    return U1;                           // (timing only)
+#else
+    // v_cvt_pk_u16_u32: both offsets (never negative) saturated to 16 bits and packed in ONE
+    // instruction -- the merge sits on the critical path of its waves (one wave per SIMD: nothing
+    // hides a dependent VALU chain), every instruction in it shows in the sweep's time
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 d = __builtin_amdgcn_cvt_pk_u16((unsigned)(U1 - L), (unsigned)(U2 - L));
+    return (int)__builtin_bit_cast(unsigned, d);
+#endif
 }
 __device__ __forceinline__ void unpack_row_bounds(v2i e, int &L, int &U1, int &U2)
 {
@@ -528,13 +536,16 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
     constexpr int MROWS = CHUNK / MERGEW;                // rows a merging wave takes
     const int mrow = wave * MROWS + lane;                // (valid for wave < MERGEW, lane < MROWS)
     const bool merger = wave < MERGEW && lane < MROWS;
+    // (the waves' spreads S_w, read once behind the first barrier into scalar registers: the merge
+    //  sits on the critical path of its waves -- one wave per SIMD, nothing hides its LDS reads)
+    int spread_w[NW];
     auto merge_rows = [&](int ch, int buf) {
         const int tid = mrow;
         int L = BIG, U1 = BIG, U2 = BIG;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int R = lds_row[(buf * NW + w) * CHUNK + tid];
-            const int lw = R, uw = R + lds_cq[w];
+            const int lw = R, uw = R + spread_w[w];
             L = min(L, lw);
             U2 = min(max(U1, uw), U2);
             U1 = min(U1, uw);
@@ -545,6 +556,8 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
     stage_direct(0, 0);
     wait_direct();
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) spread_w[w] = __builtin_amdgcn_readfirstlane(lds_cq[w]);
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         if (ch + 1 < nchunks && (!(VARIANT & 64) || ch == 0)) stage_direct(ch + 1, buf ^ 1);
@@ -738,8 +751,13 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
     }
     if (merger) merge_rows(nchunks - 1, (nchunks - 1) & 1);
 
-    // ---- column results: two smallest of the 4 x 2 group minima of every query
+    // ---- column results: two smallest of the 4 x 2 group minima of every query, and the groups
+    // whose minimum is <= the second smallest (bit k + 4 g: tiles with (tile & 3) == k, lane half g):
+    // the only train rows that can be the query's best or second (narrow exact stage).  The masks of
+    // a lane's QW queries travel as ONE word (4 bits each: one lane exchange, one store for QW = 8).
     if (wave_valid) {
+        unsigned ownpack = 0;
+        int v1s[QW], v2s[QW];
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) {
             const int lo01 = min(m[qb][0], m[qb][1]), hi01 = max(m[qb][0], m[qb][1]);
@@ -747,14 +765,39 @@ __global__ __launch_bounds__(NW * 64, WPE) void knn2sym_kernel(SymArgs A)
             const int a1 = min(lo01, lo23), a2 = min(max(lo01, lo23), min(hi01, hi23));
             const int b1 = __shfl_xor(a1, 32), b2 = __shfl_xor(a2, 32);
             const int v1 = min(a1, b1), v2 = min(max(a1, b1), min(a2, b2));
-            const int row = q0 + QW * rc + qb;
-            const int sub = GROUPLO ? 0 : lo_lane;       // (GROUPLO: the accumulators never saw it)
-            const int own = (m[qb][0] <= v2 ? 1 : 0) | (m[qb][1] <= v2 ? 2 : 0) | (m[qb][2] <= v2 ? 4 : 0) |
-                            (m[qb][3] <= v2 ? 8 : 0);
-            const int oth = __shfl_xor(own, 32);
-            if (g == 0 && row < nb) {
-                *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row)) = v2i{v1 - sub, v2 - sub};
-                if (A.colmask) A.colmask[A.col_off[u] + row] = (uint8_t)(own | (oth << 4));
+            v1s[qb] = v1;
+            v2s[qb] = v2;
+#if !defined(IAMX_T_NOMASK)
+            const unsigned own = (m[qb][0] <= v2 ? 1u : 0u) | (m[qb][1] <= v2 ? 2u : 0u) |
+                                 (m[qb][2] <= v2 ? 4u : 0u) | (m[qb][3] <= v2 ? 8u : 0u);
+            ownpack |= own << (4 * qb);
+#endif
+        }
+        const unsigned othpack = A.colmask ? (unsigned)__shfl_xor((int)ownpack, 32) : 0u;
+        const int sub = GROUPLO ? 0 : lo_lane;           // (GROUPLO: the accumulators never saw it)
+        const int row0 = q0 + QW * rc;
+        if (g == 0) {
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb)
+                if (row0 + qb < nb)
+                    *reinterpret_cast<v2i *>(A.col + 2 * (A.col_off[u] + row0 + qb)) = v2i{v1s[qb] - sub, v2s[qb] - sub};
+            if (A.colmask) {
+                // byte qb = own nibble | other half's nibble << 4
+                uint8_t *dst = A.colmask + A.col_off[u] + row0;
+                if (QW == 8 && row0 + QW <= nb) {
+                    auto spread = [](unsigned nib4) {    // four nibbles -> the low nibbles of four bytes
+                        const unsigned x = (nib4 | (nib4 << 8)) & 0x00FF00FFu;
+                        return (x | (x << 4)) & 0x0F0F0F0Fu;
+                    };
+                    const unsigned lo = spread(ownpack & 0xFFFFu) | (spread(othpack & 0xFFFFu) << 4);
+                    const unsigned hi = spread(ownpack >> 16) | (spread(othpack >> 16) << 4);
+                    *reinterpret_cast<v2u *>(dst) = v2u{lo, hi};
+                } else {
+#pragma unroll
+                    for (int qb = 0; qb < QW; ++qb)
+                        if (row0 + qb < nb)
+                            dst[qb] = (uint8_t)(((ownpack >> (4 * qb)) & 15u) | (((othpack >> (4 * qb)) & 15u) << 4));
+                }
             }
         }
     }
@@ -1136,7 +1179,10 @@ __device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int 
     const float f1 = (float)sqrt((double)Ub);
     const bool k = f1 == 0.0f || (double)f0 * ((double)f0 / (double)f1) < A.thresh;
     const int orig = A.sperm[soff + pos];
-    A.keep[ob + orig] = k ? 1 : 0;
+    // the flag at the row's ORIGINAL position, one bit per row in a map cleared by the launch (a byte
+    // per row until round 6: 33 M scattered byte writes per launch of 4096 synthetic pairs were most of
+    // this kernel's time; now only the candidates write)
+    if (k) atomicOr(reinterpret_cast<unsigned *>(A.keep) + ((ob + orig) >> 5), 1u << ((ob + orig) & 31));
     // what the exact stage prunes its scan with: no row farther than this can be the best or
     // the second of the candidate (replaced by the exact pair of distances there)
     if (k) A.d2[2 * (ob + orig) + 1] = (int)(Ub < 0x7FFFFFFFll ? Ub : 0x7FFFFFFFll);
@@ -1157,7 +1203,12 @@ __device__ __forceinline__ void symcand_rows_pair(const CandArgs &A, int p, int 
 
 __global__ __launch_bounds__(256) void symcand_rows_kernel(CandArgs A)
 {
-    for (int p = blockIdx.y; p < A.n_pairs; p += gridDim.y) symcand_rows_pair(A, p, blockIdx.x * 256 + threadIdx.x);
+    // (1024 rows per workgroup: beside the next launch's sweep -- whose workgroups own their compute
+    //  units -- every workgroup of this grid waits for a unit to come free; 131 k small ones per
+    //  launch of 4096 synthetic pairs cost the sweep more than the kernel's own work)
+    for (int p = blockIdx.y; p < A.n_pairs; p += gridDim.y)
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) symcand_rows_pair(A, p, (blockIdx.x * 4 + k) * 256 + threadIdx.x);
 }
 
 // passes 2 and 3, one workgroup per ordered pair
@@ -1179,7 +1230,7 @@ __global__ __launch_bounds__(256) void symcand_kernel(CandArgs A)
     int out = 0;
     for (int base = 0; base < n; base += 256) {
         const int i = base + threadIdx.x;
-        const bool k = i < n && A.keep[ob + i];
+        const bool k = i < n && ((reinterpret_cast<const unsigned *>(A.keep)[(ob + i) >> 5] >> ((ob + i) & 31)) & 1u);
         const unsigned long long mask = __ballot(k);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));
         if (lane == 0) wcnt[wave] = __popcll(mask);
@@ -2128,14 +2179,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 }
 
 // merge a candidate's items, then what exact_finish does: exact squared distances, train row,
-// metric, keep flag.  One workgroup per ordered pair (pairs the narrow stage did not take return).
-__global__ __launch_bounds__(256) void symnarrow_finish_kernel(NarArgs A)
+// metric, keep flag.  The pair's workgroup of symcompact_kernel runs it in front of its compaction
+// (a kernel of its own until the launch count of the filter stage showed in the sweep running beside
+// it); pairs the narrow stage did not take return at once.
+__device__ __forceinline__ void narrow_finish_pair(const NarArgs &A, int p)
 {
     const NarLayout NL = narrow_layout(A.rows_total, A.n_pairs);
     const int32_t *pair_base = reinterpret_cast<const int32_t *>(A.nar + NL.pair_base);
     const v2i *slot = reinterpret_cast<const v2i *>(A.nar + NL.slot);
     const v4i *res = reinterpret_cast<const v4i *>(A.nar + NL.res);
-    const int p = blockIdx.x;
     if (p == 0 && threadIdx.x == 0) {                   // the scan has consumed tasks and items
         int32_t *ctl = reinterpret_cast<int32_t *>(A.nar + NL.ctl);
         ctl[0] = ctl[1] = ctl[2] = 0;
@@ -2189,16 +2241,22 @@ __global__ __launch_bounds__(256) void symnarrow_finish_kernel(NarArgs A)
 }
 
 // in-place, order-preserving compaction of every pair's candidate list to its survivors
-__global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *__restrict__ cand_off,
-                                                         const int32_t *__restrict__ cand_cnt,
-                                                         const uint8_t *__restrict__ cand_keep,
-                                                         int32_t *__restrict__ q, int32_t *__restrict__ t,
-                                                         double *__restrict__ metric,
-                                                         int32_t *__restrict__ surv_cnt,
-                                                         int32_t *__restrict__ task_total)
+// (no __restrict__: narrow_finish_pair writes cand_t / cand_metric / cand_keep through N first)
+__global__ __launch_bounds__(256) void symcompact_kernel(const int64_t *cand_off,
+                                                         const int32_t *cand_cnt,
+                                                         const uint8_t *cand_keep,
+                                                         int32_t *q, int32_t *t,
+                                                         double *metric,
+                                                         int32_t *surv_cnt,
+                                                         int32_t *task_total, NarArgs N)
 {
     __shared__ int wcnt[4];
     const int p = blockIdx.x;
+    if (N.nar != nullptr) {
+        narrow_finish_pair(N, p);
+        __threadfence_block();
+        __syncthreads();
+    }
     const int64_t b = cand_off[p];
     const int cnt = cand_cnt[p];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2407,8 +2465,9 @@ extern "C" int iamx_knn2sym_candidates(const int32_t *sn2, const int32_t *sperm,
                iamx_knn2sym_rows_per_wg(form)};
     IAMX_REQUIRE(rows_total > 0 && rows_total < (1ll << 31), "rows_total = rows of all ordered pairs");
     IAMX_REQUIRE(max_query_rows > 0, "max_query_rows = rows of the largest query image");
+    (void)hipMemsetAsync(keep, 0, (size_t)((rows_total + 31) / 32 * 4), iamx::as_stream(stream));
     hipLaunchKernelGGL(symcand_rows_kernel,
-                       dim3((unsigned)((max_query_rows + 255) / 256), (unsigned)(n_pairs < 65535 ? n_pairs : 65535)),
+                       dim3((unsigned)((max_query_rows + 1023) / 1024), (unsigned)(n_pairs < 65535 ? n_pairs : 65535)),
                        dim3(256), 0, iamx::as_stream(stream), a);
     hipLaunchKernelGGL(symcand_kernel, dim3((unsigned)n_pairs), dim3(256), 0, iamx::as_stream(stream), a);
     return iamx::check_launch("iamx_knn2sym_candidates");
@@ -2459,6 +2518,7 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
         hipLaunchKernelGGL((symexact_wg_kernel<true, 4>), dim3(2048), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((symexact_wg_kernel<true, 2>), dim3(2048), dim3(256), 0, st, a);
+    NarArgs nfin{};                                      // (nar == NULL: symcompact_kernel has nothing to merge)
     if (nar && narrow_enabled()) {
         // (the same switch and the same buffer as iamx_knn2sym_candidates: pairs it bucketed have
         //  no task in the two lists above)
@@ -2477,10 +2537,10 @@ extern "C" int iamx_knn2sym_exact(const int8_t *desc, const int32_t *norm_q, con
             hipLaunchKernelGGL(symnarrow_kernel<2>, dim3(512), dim3(256), 0, st, na);
         else
             hipLaunchKernelGGL(symnarrow_kernel<3>, dim3(768), dim3(256), 0, st, na);
-        hipLaunchKernelGGL(symnarrow_finish_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, na);
+        nfin = na;
     }
     hipLaunchKernelGGL(symcompact_kernel, dim3((unsigned)n_pairs), dim3(256), 0, st, out_off,
-                       cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total);
+                       cand_cnt, cand_keep, cand_q, cand_t, cand_metric, surv_cnt, task_total, nfin);
     return iamx::check_launch("iamx_knn2sym_exact");
 }
 

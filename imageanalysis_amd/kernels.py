@@ -428,7 +428,7 @@ class PairWorkspace(object):
         self.idx = torch.empty((r, 2), dtype=I32, device=dev)
         self.d2 = torch.empty((r, 2), dtype=I32, device=dev)
         self.metric = torch.empty(r, dtype=F64, device=dev)
-        self.keep = torch.empty(r, dtype=U8, device=dev)
+        self.keep = torch.empty(max(r, 8), dtype=U8, device=dev)   # (the symmetric form's bit map: whole words)
         self.seg_count = torch.zeros(p, dtype=I32, device=dev)
         self.surv_off = torch.zeros(p + 1, dtype=I64, device=dev)
         self.surv_q = torch.empty(r, dtype=I32, device=dev)

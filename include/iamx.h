@@ -209,7 +209,8 @@ int iamx_knn2v2_finish(const int8_t *desc_q, const int32_t *norm_q, const int32_
  *   col  DEV [..][2] int32, rowp DEV [..][2] int32 (8-byte aligned): the bounds, internal format
  * Candidates: pairs DEV [n_pairs][2] ordered (query image, train image); osrc DEV [n_pairs][2] =
  *   (index u of its unordered pair, role: 0 if the query image is B, 1 if it is A);
- *   out_off DEV [n_pairs+1] int64 rows of each ordered pair; keep DEV [rows] uint8 scratch;
+ *   out_off DEV [n_pairs+1] int64 rows of each ordered pair; keep DEV [max(rows, 8)] uint8 scratch
+ *   (4-byte aligned; used as a bit map, one bit per query row of rows_total, cleared by the call);
  *   cand_cnt DEV [n_pairs] (written); cand_q DEV [rows]: the candidate query rows (original
  *   numbering, ascending) of pair p at out_off[p] .. + cand_cnt[p] -- a pair's list lives in
  *   its own slice of the row range, no scan over the pairs;

@@ -72,7 +72,7 @@ if ws.nar is not None and os.environ.get('IAMX_EXACT_NARROW', '1') != '0':
     up = lambda v: (v + 255) // 256 * 256                                       # noqa: E731
     mask_off = 256 + up(4 * pb.n_pairs)
     masks = ws.nar[mask_off:mask_off + 8 * pb.rows].view(torch.int64).cpu().numpy()
-    keep = ws.keep[:pb.rows].cpu().numpy().astype(bool)
+    keep = np.unpackbits(ws.keep[:(pb.rows + 7) // 8].cpu().numpy(), bitorder='little')[:pb.rows].astype(bool)
     sel = np.nonzero(keep)[0]
     sel = sel[::max(1, len(sel) // 200000)]
     pc = np.array([bin(int(m) & (2 ** 64 - 1)).count('1') for m in masks[sel]])
