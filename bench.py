@@ -901,8 +901,31 @@ def e2e_bench(n_images, full_frame=False, schedule=None, window=0, fused=False):
             timed("detect", lambda: detect(proj.image_list))
         out["fused_detect_and_match"] = bool(fused and not window)
         def match():
+            trace = None
+            if os.environ.get('IAMX_MATCH_TRACE'):       # phases of the call on stderr (diagnosis)
+                trace = matcher._round_trace = []
+                orig_launch, t_call = matcher._launch_batch, time.perf_counter()
+
+                def launch(*a, **k):
+                    t = time.perf_counter()
+                    r = orig_launch(*a, **k)
+                    trace.append(('launch', time.perf_counter() - t, t - t_call))
+                    return r
+                matcher._launch_batch = launch
             matcher.find_matches(proj, K, strategy='traditional', transform='homography', sort=True)
+            t_fm = time.perf_counter()
             iimg.cacheio.wait()
+            if trace is not None:
+                matcher._launch_batch, matcher._round_trace = orig_launch, None
+                for ent in trace:
+                    if ent[0] == 'pre':
+                        print('trace pre   %-22s +%.3f s' % (ent[1], ent[2] - t_call), file=sys.stderr)
+                    elif ent[0] == 'launch':
+                        print('trace launch at +%.3f s took %.3f s' % (ent[2], ent[1]), file=sys.stderr)
+                    else:
+                        print('trace %s' % (ent,), file=sys.stderr)
+                print('trace find_matches returned +%.3f s, cache writes done +%.3f s'
+                      % (t_fm - t_call, time.perf_counter() - t_call), file=sys.stderr)
         timed("detect+match" if out["fused_detect_and_match"] else "match", match)
         for im in proj.image_list:                       # (the periodic flush may have dropped some)
             if im.kp_list is None:

@@ -114,6 +114,7 @@ SIGNATURES = {
     'iamx_gzip_records': (c_int64, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int64]),
     'iamx_u8_to_f32': (c_int, [c_void_p, c_void_p, c_int64, c_int]),
     'iamx_f32_to_u8_many': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    'iamx_u8_gather_many': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int]),
     'iamx_feat_records': (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),
     'iamx_pickle_pair_lists': (c_int64, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     'iamx_sift_workspace_bytes': (c_int64, [c_int, c_int]),

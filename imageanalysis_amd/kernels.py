@@ -33,6 +33,48 @@ def _dev(x, dtype):
 # --------------------------------------------------------------------------------------
 # descriptor store
 # --------------------------------------------------------------------------------------
+# Upload staging of DescriptorStore.set_images: two page-locked host buffers (a group of images is
+# gathered into one while the copy out of the other runs), one device buffer the pack kernels read
+# (re-used in stream order) and their scratch.  One set per device, kept for the process.
+STAGE_BYTES = 64 << 20
+STAGE_TAIL = 64 << 10            # int64 offsets of up to 8191 images per group
+_stages = {}
+_stage_lock = threading.Lock()
+
+
+def _upload_stage(dev, nbytes):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _stages.get(key)
+    if st is None or st['bytes'] < nbytes:
+        rows = (nbytes + 127) // 128
+        # (+ STAGE_TAIL bytes behind the rows: the group's row offsets travel with the same copy -- a
+        #  pageable `tensor.to(device)` of their own would make the host wait for the device per group)
+        st = _stages[key] = dict(bytes=rows * 128,
+                                 pin=[torch.empty(rows * 128 + STAGE_TAIL, dtype=U8).pin_memory() for _ in range(2)],
+                                 dev=torch.empty(rows * 128 + STAGE_TAIL, dtype=U8, device=dev),
+                                 scratch=torch.empty(3 * rows, dtype=I32, device=dev),
+                                 ev=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False], next=0)
+    return st
+
+
+def prewarm_upload_stage():
+    """Allocate the upload staging of the current device on a helper thread (page-locking its two
+    64 MB host buffers takes 0.1-0.2 s: matcher.configure() starts it, find_matches finds it done)."""
+    if not torch.cuda.is_available():
+        return None
+    idx = torch.cuda.current_device()
+
+    def _go():
+        try:
+            with torch.cuda.device(idx), _stage_lock:
+                _upload_stage(torch.device('cuda', idx), STAGE_BYTES)
+        except Exception:                     # noqa: BLE001  (best effort: set_images allocates what is missing)
+            pass
+    th = threading.Thread(target=_go, name='iamx-stage', daemon=True)
+    th.start()
+    return th
+
+
 class DescriptorStore(object):
     """All images' SIFT descriptors packed back to back in HBM (include/iamx.h, 'Descriptor
     store'): int8 rows (value-128), each image zero-padded to 128 rows, + two int32 norms
@@ -174,12 +216,15 @@ class DescriptorStore(object):
         return (src, scratch, scratch3)
 
     def set_images(self, first, arrays):
-        """Pack the descriptors of the consecutive images first .. first + len(arrays) - 1 in one
-        go: host arrays ([n,128] float32 or uint8) are turned into ONE uint8 block (float32 by
-        libiamx's threads), uploaded once and packed by the batched kernels -- 0.1 ms per image
-        where set_image() image by image costs 0.3 ms (a float32 upload and ~10 launches each:
-        0.85 s for the 2812 images of BASELINE configs[2]).  Enqueues on the current stream and
-        returns the temporaries the kernels read (keep them until the stream is synchronised)."""
+        """Pack the descriptors of the consecutive images first .. first + len(arrays) - 1: host
+        arrays ([n,128] float32 or uint8) go up in GROUPS of <= STAGE_BYTES -- gathered (float32:
+        converted) into one of two page-locked staging buffers by libiamx's threads, copied to the
+        device asynchronously and packed by the batched kernels while the threads fill the other
+        buffer.  (Until round 6 the whole list was concatenated into ONE pageable host block first:
+        2.4 GB copied by a numpy loop and uploaded synchronously for 512 frames of 37 k keypoints --
+        0.37 s of a 2.3 s match stage -- and 47 GB of host AND device temporaries at 10 000 frames.)
+        Enqueues on the current stream and returns the temporaries the kernels read (keep them
+        until the stream is synchronised)."""
         import ctypes
         k = len(arrays)
         if k == 0:
@@ -190,45 +235,78 @@ class DescriptorStore(object):
                     or tuple(a.shape) != (counts[i], 128):
                 raise ValueError("set_images: image %d is not a host [n,128] float32 / uint8 array" % (first + i))
         arrays = [np.ascontiguousarray(a) for a in arrays]
-        rows = int(sum(counts))
-        if rows == 0:
+        if int(sum(counts)) == 0:
             return ()
-        u8 = np.empty((rows, 128), np.uint8)
-        off = np.zeros(k + 1, np.int64)
-        np.cumsum(counts, out=off[1:])
-        f32 = [i for i, a in enumerate(arrays) if a.dtype == np.float32]
-        if len(f32) == k:
-            srcs = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
-            cnt = (ctypes.c_int64 * k)(*[a.size for a in arrays])
-            check(lib().iamx_f32_to_u8_many(srcs, cnt, k, u8.ctypes.data_as(ctypes.c_void_p),
-                                            min(16, os.cpu_count() or 1)), 'iamx_f32_to_u8_many')
-        else:
-            for i, a in enumerate(arrays):
-                u8[off[i]:off[i + 1]] = a if a.dtype == np.uint8 else \
-                    np.clip(np.rint(a), 0, 255).astype(np.uint8)
         dev = self.desc.device
-        src = torch.from_numpy(u8).to(dev)
         L, sp = lib(), stream_ptr()
-        # original-order store: image by image (one launch each: images are padded to 128 rows)
-        for i in range(k):
-            if counts[i]:
-                o = int(self.offsets[first + i])
-                check(L.iamx_desc_pack_u8(_ptr(src[int(off[i]):]), counts[i], _ptr(self.desc[o:]),
-                                          _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]), sp), 'iamx_desc_pack_u8')
-        src_off = torch.from_numpy(off).to(dev)
-        scratch = None
-        mx = int(max(counts))
-        if self.has_train_layout:
-            scratch = torch.empty(3 * rows, dtype=I32, device=dev)
-            check(L.iamx_desc2_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off2[first:]), k, rows, mx,
-                                             _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
-                                             _ptr(self.perm), _ptr(self.meta[first]), _ptr(scratch), sp),
-                  'iamx_desc2_pack_batch_u8')
-        scratch3 = torch.empty(3 * rows, dtype=I32, device=dev)
-        check(L.iamx_desc3_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off3[first:]), k, rows, mx,
-                                         _ptr(self.desc3), _ptr(self.sn2), _ptr(self.sct), _ptr(self.sperm),
-                                         _ptr(self.sinv), _ptr(scratch3), sp), 'iamx_desc3_pack_batch_u8')
-        return (src, src_off, scratch, scratch3)
+        threads = min(16, os.cpu_count() or 1)
+        keep = []
+        with _stage_lock:
+            self._set_images_staged(first, arrays, counts, keep, L, sp, threads, dev)
+        return tuple(keep)
+
+    def _set_images_staged(self, first, arrays, counts, keep, L, sp, threads, dev):
+        import ctypes
+        k = len(arrays)
+        stage = _upload_stage(dev, max(STAGE_BYTES, 128 * int(max(counts))))
+        keep.append(stage)
+        g0 = 0
+        while g0 < k:
+            g1, rows = g0, 0
+            while g1 < k and g1 - g0 < STAGE_TAIL // 8 - 1 and \
+                    (g1 == g0 or (rows + counts[g1]) * 128 <= stage['bytes']):
+                rows += counts[g1]
+                g1 += 1
+            n = g1 - g0
+            if rows == 0:
+                g0 = g1
+                continue
+            slot = stage['next'] = (stage['next'] + 1) % 2
+            pin, ev = stage['pin'][slot], stage['ev'][slot]
+            if stage['used'][slot]:
+                ev.synchronize()                     # the copy that read this buffer last has run
+            off = np.zeros(n + 1, np.int64)
+            np.cumsum(counts[g0:g1], out=off[1:])
+            grp = arrays[g0:g1]
+            dst = ctypes.c_void_p(pin.data_ptr())
+            srcs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in grp])
+            if all(a.dtype == np.float32 for a in grp):
+                cnt = (ctypes.c_int64 * n)(*[a.size for a in grp])
+                check(L.iamx_f32_to_u8_many(srcs, cnt, n, dst, threads), 'iamx_f32_to_u8_many')
+            elif all(a.dtype == np.uint8 for a in grp):
+                cnt = (ctypes.c_int64 * n)(*[a.size for a in grp])
+                check(L.iamx_u8_gather_many(srcs, cnt, n, dst, threads), 'iamx_u8_gather_many')
+            else:
+                host = pin.numpy()[:rows * 128].reshape(rows, 128)
+                for i, a in enumerate(grp):
+                    host[off[i]:off[i + 1]] = a if a.dtype == np.uint8 else \
+                        np.clip(np.rint(a), 0, 255).astype(np.uint8)
+            tail = stage['bytes']
+            pin[tail:tail + 8 * (n + 1)].view(torch.int64).copy_(torch.from_numpy(off))
+            # (two copies: the rows of the group, and the offsets behind the buffer's row area)
+            stage['dev'][:rows * 128].copy_(pin[:rows * 128], non_blocking=True)
+            stage['dev'][tail:tail + 8 * (n + 1)].copy_(pin[tail:tail + 8 * (n + 1)], non_blocking=True)
+            src = stage['dev'][:rows * 128].view(rows, 128)
+            ev.record()
+            stage['used'][slot] = True
+            # original-order store: image by image (one launch each: images are padded to 128 rows)
+            for i in range(n):
+                if counts[g0 + i]:
+                    o = int(self.offsets[first + g0 + i])
+                    check(L.iamx_desc_pack_u8(_ptr(src[int(off[i]):]), counts[g0 + i], _ptr(self.desc[o:]),
+                                              _ptr(self.norm_q[o:]), _ptr(self.norm_t[o:]), sp), 'iamx_desc_pack_u8')
+            src_off = stage['dev'][tail:tail + 8 * (n + 1)].view(torch.int64)
+            mx = int(max(counts[g0:g1]))
+            scratch = stage['scratch'][:3 * rows]
+            if self.has_train_layout:
+                check(L.iamx_desc2_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off2[first + g0:]), n, rows, mx,
+                                                 _ptr(self.desc2), _ptr(self.norm2), _ptr(self.cinit),
+                                                 _ptr(self.perm), _ptr(self.meta[first + g0]), _ptr(scratch), sp),
+                      'iamx_desc2_pack_batch_u8')
+            check(L.iamx_desc3_pack_batch_u8(_ptr(src), _ptr(src_off), _ptr(self.img_off3[first + g0:]), n, rows, mx,
+                                             _ptr(self.desc3), _ptr(self.sn2), _ptr(self.sct), _ptr(self.sperm),
+                                             _ptr(self.sinv), _ptr(scratch), sp), 'iamx_desc3_pack_batch_u8')
+            g0 = g1
 
     @classmethod
     def from_arrays(cls, arrays):

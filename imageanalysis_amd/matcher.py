@@ -166,9 +166,11 @@ class DeviceMatcher(object):
         idx, d2 = kernels.knn2(np.asarray(des1), np.asarray(des2))
         return idx.cpu().numpy(), np.sqrt(d2.cpu().numpy().astype(np.float32))
 
-    def slot_of(self, image):
+    def slot_of(self, image, pre=None):
         """Device slot of an image's descriptors; uploaded once per image (a host-side cache
-        flush + reload of the same image re-uses the rows already in HBM)."""
+        flush + reload of the same image re-uses the rows already in HBM).  pre: (xy, key2) of the
+        image's keypoints when the caller computed them already (find_matches' registration does,
+        on a few threads)."""
         ent = self._slots.get(image.name)
         if ent is not None and image.name in self._adopted and \
                 (image.des_list is None or not len(image.des_list)):
@@ -181,8 +183,10 @@ class DeviceMatcher(object):
         self._slots[image.name] = (slot, n)
         self._counts.append(n)
         self._pending.append((slot, image.des_list))
-        xy = _kp_xy(image)
-        self._kp[slot] = (xy, kp_key2(xy))
+        if pre is None:
+            xy = _kp_xy(image)
+            pre = (xy, kp_key2(xy))
+        self._kp[slot] = pre
         return slot
 
     def slot_known(self, image):
@@ -278,6 +282,7 @@ class DeviceMatcher(object):
         from . import kernels
         pend = self._pending
         want_train = getattr(self, '_train_layout', False)
+        _tm = [time.perf_counter()] if _round_trace is not None else None
         if self._store is None or len(self._store.counts) != len(self._counts):
             # (no parity-partitioned copy: find_matches' batches hold both directions of every
             #  pair -- a third less arena, 104 instead of 155 GB for 10 000 frames of 37 k keypoints)
@@ -302,6 +307,8 @@ class DeviceMatcher(object):
                 for name in ('desc3', 'sn2', 'sct', 'sperm', 'sinv'):
                     getattr(new, name)[:n_old3].copy_(getattr(old, name)[:n_old3])
             self._store = new
+        if _tm is not None:
+            _tm.append(time.perf_counter())
         # a run of consecutive new slots whose descriptors are host arrays goes up in ONE step
         # (DescriptorStore.set_images); anything else image by image
         keep = []
@@ -318,9 +325,15 @@ class DeviceMatcher(object):
         keep += [self._store.set_image(slot, des if hasattr(des, 'data_ptr') else
                                        np.ascontiguousarray(des), sync=False)
                  for slot, des in pend]
+        if _tm is not None:
+            _tm.append(time.perf_counter())
         if keep:
             import torch
             torch.cuda.current_stream().synchronize()        # one sync for the whole batch
+        if _tm is not None:
+            _round_trace.append(('pre', 'store(): arena %.3f enqueue %.3f sync %.3f (%d images)'
+                                 % (_tm[1] - _tm[0], _tm[2] - _tm[1], time.perf_counter() - _tm[2], len(pend) + len(bulk)),
+                                 time.perf_counter()))
         del keep
         self._pending = []
         if want_train and not self._store.has_train_layout:
@@ -403,6 +416,11 @@ def configure():
         quit()
     the_matcher = DeviceMatcher()
     min_pairs = matcher_node.getFloat('min_pairs')
+    try:                                          # (page-locked upload staging ready before find_matches)
+        from . import kernels
+        kernels.prewarm_upload_stage()
+    except Exception:                             # noqa: BLE001  (no device / no library: find_matches says so)
+        pass
 
 
 # --------------------------------------------------------------------------------------
@@ -1775,10 +1793,26 @@ class _MatchRun(object):
         def _register():
             try:
                 with _torch.cuda.device(_dev), _torch.cuda.stream(_stream):
-                    for im in ready:
-                        the_matcher.slot_of(im)
+                    _t = [time.perf_counter()]
+                    # (kp.pt arrays and their "%.2f" keys: 0.2 ms per image, outside the interpreter
+                    #  lock -- eight threads; the slots are handed out in list order afterwards)
+                    from concurrent.futures import ThreadPoolExecutor
+
+                    def _keys(im):
+                        xy = _kp_xy(im)
+                        return xy, kp_key2(xy)
+                    with ThreadPoolExecutor(max_workers=8, thread_name_prefix='iamx-keys') as ex:
+                        pre = list(ex.map(_keys, ready))
+                    for im, pk in zip(ready, pre):
+                        the_matcher.slot_of(im, pre=pk)
+                    _t.append(time.perf_counter())
                     the_matcher.store()
+                    _t.append(time.perf_counter())
                     the_matcher.keypoints()
+                    _t.append(time.perf_counter())
+                    if _round_trace is not None:
+                        _round_trace.append(('pre', 'registered: slots %.3f store %.3f keypoints %.3f'
+                                             % (_t[1] - _t[0], _t[2] - _t[1], _t[3] - _t[2]), _t[3]))
             except BaseException as exc:          # noqa: BLE001  (re-raised on the calling thread)
                 failed.append(exc)
         if len(ready) <= 1:

@@ -678,6 +678,10 @@ int iamx_u8_to_f32(const uint8_t *src, float *dst, int64_t n, int threads);
  * counts HOST [n] elements per image.  Feeds ONE upload + the batched pack kernels. */
 int iamx_f32_to_u8_many(const float *const *srcs, const int64_t *counts, int n, uint8_t *dst,
                         int threads);
+/* n host byte blocks (counts[i] bytes at srcs[i]) copied back to back into dst by `threads` threads:
+ * the uint8 descriptor arrays of a group of images into one page-locked staging buffer. */
+int iamx_u8_gather_many(const uint8_t *const *srcs, const int64_t *counts, int n, uint8_t *dst,
+                        int threads);
 int iamx_feat_records(const float *x, const float *y, const float *size, const float *angle,
                       const float *response, const int32_t *octave, const int32_t *class_id,
                       int64_t n, uint8_t *out);
