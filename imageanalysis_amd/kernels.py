@@ -80,23 +80,29 @@ class DescriptorStore(object):
     store'): int8 rows (value-128), each image zero-padded to 128 rows, + two int32 norms
     per row.  288 GB of HBM hold > 10^9 descriptors, so a whole survey stays resident."""
 
-    def __init__(self, counts, train_layout=True):
+    def __init__(self, counts, train_layout=True, reserve_rows=0, reserve_images=0):
         """train_layout=False: the parity-partitioned copy `desc2` (a third of the arena) is not
         kept.  Only the ONE-direction fast sweep reads it; a store that serves batches holding
         both directions of every pair (find_matches: the symmetric sweep reads `desc3`, the exact
         stage `desc`) does without, and a batch the symmetric sweep refuses (an image of < 2 rows)
-        then takes the general kernel, which reads `desc` only."""
+        then takes the general kernel, which reads `desc` only.
+        reserve_rows / reserve_images: capacity beyond `counts` -- try_extend() appends images
+        without re-allocating (find_matches meeting undetected images registers ~250 per round:
+        rebuilding a 40 GB arena each time was a quarter of that call form's time)."""
         dev = require_gpu()
         L = lib()
         self.has_train_layout = bool(train_layout)
         self.counts = [int(c) for c in counts]
+        reserve_rows, reserve_images = int(reserve_rows), int(reserve_images)
         pads = [int(L.iamx_desc_padded_rows(c)) for c in self.counts]
         offs = np.zeros(len(pads) + 1, np.int64)
         np.cumsum(pads, out=offs[1:])
         if offs[-1] >= 2 ** 31:
             raise ValueError("descriptor store limited to 2^31 rows")
         self.offsets = offs
-        total = max(int(offs[-1]), 1)
+        total = max(int(offs[-1]), reserve_rows, 1)
+        if total >= 2 ** 31:
+            total = max(int(offs[-1]), 1)
         self.desc = torch.empty((total, 128), dtype=I8, device=dev)
         self.norm_q = torch.empty(total, dtype=I32, device=dev)
         self.norm_t = torch.empty(total, dtype=I32, device=dev)
@@ -111,12 +117,12 @@ class DescriptorStore(object):
         if offs2[-1] >= 2 ** 31:
             raise ValueError("descriptor store limited to 2^31 rows")
         self.offsets2 = offs2
-        total2 = max(int(offs2[-1]), 1) if train_layout else 1
+        total2 = max(int(offs2[-1]), min(reserve_rows, 2 ** 31 - 1), 1) if train_layout else 1
         self.desc2 = torch.empty((total2, 128), dtype=I8, device=dev)
         self.norm2 = torch.empty(total2, dtype=I32, device=dev)
         self.cinit = torch.empty(total2, dtype=I32, device=dev)
         self.perm = torch.empty(total2, dtype=I32, device=dev)
-        self.meta = torch.zeros((max(len(caps), 1), 4), dtype=I32, device=dev)
+        self.meta = torch.zeros((max(len(caps), reserve_images, 1), 4), dtype=I32, device=dev)
         self.img_off2 = torch.from_numpy(offs2[:-1].astype(np.int32)).to(dev)
         # sorted layout of the symmetric sweep (rows ordered by |a-128|^2, include/iamx.h "desc3")
         caps3 = [int(L.iamx_desc3_rows_cap(c)) for c in self.counts]
@@ -124,7 +130,7 @@ class DescriptorStore(object):
         np.cumsum(caps3, out=offs3[1:])
         self.caps3 = np.asarray(caps3, np.int64)
         self.offsets3 = offs3
-        total3 = max(int(offs3[-1]), 1)
+        total3 = max(int(offs3[-1]), min(reserve_rows, 2 ** 31 - 1), 1)
         self.desc3 = torch.empty((total3, 128), dtype=I8, device=dev)
         self.sn2 = torch.empty(total3, dtype=I32, device=dev)
         self.sct = torch.empty(total3, dtype=I32, device=dev)
@@ -134,6 +140,41 @@ class DescriptorStore(object):
 
     def __len__(self):
         return len(self.counts)
+
+    @property
+    def rows_used(self):
+        """rows of the original-order layout that belong to images (the buffers may be larger)"""
+        return int(self.offsets[-1])
+
+    def try_extend(self, new_counts):
+        """Append images of new_counts rows each behind the existing ones if every layout's
+        buffers have room: the big buffers stay, the small per-image tables are rebuilt (batches
+        made earlier keep their own references; the rows of old images do not move).  -> False
+        (and nothing changed) when the capacity does not suffice."""
+        L = lib()
+        dev = self.desc.device
+        counts = self.counts + [int(c) for c in new_counts]
+        offs = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum([int(L.iamx_desc_padded_rows(c)) for c in counts], out=offs[1:])
+        offs2 = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum([int(L.iamx_desc2_rows_cap(c)) for c in counts], out=offs2[1:])
+        caps3 = [int(L.iamx_desc3_rows_cap(c)) for c in counts]
+        offs3 = np.zeros(len(counts) + 1, np.int64)
+        np.cumsum(caps3, out=offs3[1:])
+        if offs[-1] > self.desc.shape[0] or offs3[-1] > self.desc3.shape[0]:
+            return False
+        if self.has_train_layout and (offs2[-1] > self.desc2.shape[0] or len(counts) > self.meta.shape[0]):
+            return False
+        if max(offs[-1], offs2[-1], offs3[-1]) >= 2 ** 31:
+            return False
+        self.counts = counts
+        self.offsets, self.offsets2, self.offsets3 = offs, offs2, offs3
+        self.caps3 = np.asarray(caps3, np.int64)
+        self.img_off = torch.from_numpy(offs[:-1].astype(np.int32)).to(dev)
+        self.img_n = torch.tensor(counts, dtype=I32, device=dev)
+        self.img_off2 = torch.from_numpy(offs2[:-1].astype(np.int32)).to(dev)
+        self.img_off3 = torch.from_numpy(offs3[:-1].astype(np.int32)).to(dev)
+        return True
 
     def ensure_train_layout(self, chunk_rows=4 << 20):
         """Builds the parity-partitioned copy `desc2` of a store made without it, from the
@@ -695,7 +736,7 @@ class PairBatch(object):
                                         self.sym_form, s),
               'iamx_knn2sym_candidates')
         check(L.iamx_knn2sym_exact(_ptr(st.desc), _ptr(st.norm_q), _ptr(st.norm_t), _ptr(st.key_t),
-                                   st.norm_t.numel(), _ptr(st.img_off),
+                                   st.rows_used, _ptr(st.img_off),
                                    _ptr(st.img_n), _ptr(self.d_pairs), _ptr(self.d_out),
                                    _ptr(ws.seg_count), _ptr(ws.task_total), _ptr(ws.tasks),
                                    _ptr(ws.surv_q), self.n_pairs, float(thresh), _ptr(ws.d2),

@@ -283,10 +283,33 @@ class DeviceMatcher(object):
         pend = self._pending
         want_train = getattr(self, '_train_layout', False)
         _tm = [time.perf_counter()] if _round_trace is not None else None
-        if self._store is None or len(self._store.counts) != len(self._counts):
+        if self._store is not None and len(self._store.counts) < len(self._counts) and \
+                self._store.has_train_layout == bool(want_train) and \
+                self._store.counts == self._counts[:len(self._store.counts)] and \
+                self._store.try_extend(self._counts[len(self._store.counts):]):
+            pass                                   # the new images fit behind the old ones
+        elif self._store is None or len(self._store.counts) != len(self._counts):
             # (no parity-partitioned copy: find_matches' batches hold both directions of every
             #  pair -- a third less arena, 104 instead of 155 GB for 10 000 frames of 37 k keypoints)
-            new = kernels.DescriptorStore(self._counts, train_layout=want_train)
+            # Capacity: find_matches says how many images the survey has (expect_images); the
+            # rows so far give the mean.  Without that, half again what is needed now -- a call that
+            # meets undetected images registers a few hundred per round, and re-allocating and
+            # copying the arena every time was 10 of 42 s at 4186 frames.
+            need = sum(self._counts) + 256 * len(self._counts)
+            n_exp = max(int(getattr(self, 'expect_images', 0)), len(self._counts))
+            reserve = int(need * (n_exp / float(max(len(self._counts), 1))) * 1.03) if n_exp > len(self._counts) else 0
+            if self._store is not None and len(self._store.counts):
+                reserve = max(reserve, int(1.5 * need))
+            try:
+                import torch
+                free, _t = torch.cuda.mem_get_info()
+                free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+                if reserve * 290 > free // 2:        # (never more than half of what is left)
+                    reserve = 0
+            except Exception:                         # noqa: BLE001
+                reserve = 0
+            new = kernels.DescriptorStore(self._counts, train_layout=want_train,
+                                          reserve_rows=reserve, reserve_images=n_exp if reserve else 0)
             if self._store is not None and len(self._store.counts):
                 old = self._store
                 n_old, n_old2, k = int(old.offsets[-1]), int(old.offsets2[-1]), len(old.counts)
@@ -1825,6 +1848,8 @@ class _MatchRun(object):
         from . import dist as _dist
         from .matchpairs import MatchDict, QuietLedger
         image_list, names = self.image_list, self.names
+        if isinstance(the_matcher, DeviceMatcher):
+            the_matcher.expect_images = len(image_list)      # (capacity of the descriptor arena)
         early = self._register_early()
         if _round_trace is not None:
             _round_trace.append(('pre', 'helper started', time.perf_counter()))
