@@ -268,6 +268,16 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
     }
 }
 
+// IAMX_DESC_FORM (read once; A/B measurements): descriptor_kernel<FORM, WAVES> -- 0 = <0, 8> (rounds 2-5),
+// 1 = <1, 6>, 25 = <2, 5>, anything else <2, 4> (shipped).  Same box, 2189 x 1459 detect image, 37 k
+// keypoints (profiles/r6h_sift_desc_ab.txt): 791-824 / 653-667 / 637-646 / 614-628 us; forms 1 and 2 at
+// eight waves per SIMD spill (1.8 / 2.1 ms), form 2 at six keeps 36 B of scratch in the loop (763 us).
+inline int desc_form()
+{
+    static const int f = [] { const char *e = getenv("IAMX_DESC_FORM"); return e && e[0] ? atoi(e) : 24; }();
+    return f;
+}
+
 inline int xcd_enabled()
 {
     static const int on = [] { const char *e = getenv("IAMX_SIFT_NO_XCD"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -880,13 +890,29 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 }
 
 // one wave per keypoint: calcSIFTDescriptor
-// (8 waves per SIMD: 64 VGPRs and 32 B of scratch instead of 86 VGPRs / 5 waves -- the kernel waits
-//  on LDS atomics and image gathers more than it issues; 1.645 / 1.626 / 1.596 ms per detection at
-//  5 / 6 / 8 waves on one box, round 5)
-#ifndef IAMX_DESC_WAVES
-#define IAMX_DESC_WAVES 8
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_WAVES, IAMX_DESC_WAVES))) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
+// (form 0 ran 8 waves per SIMD -- 64 VGPRs and 32 B of scratch instead of 86 VGPRs / 5 waves: it waited
+//  on LDS atomics and image gathers more than it issued; 1.645 / 1.626 / 1.596 ms per detection at
+//  5 / 6 / 8 waves on one box, round 5.  Forms 1 and 2 issue: the counters of the third session say
+//  SQ_WAIT_INST_LDS 1.06e9 -> 2.3e7 wave cycles per launch, LDS-active cycles 3.1e8 -> 1.5e8, VALU
+//  instructions unchanged (2.96e8 -> 2.89e8: eight f64 adds replace the address arithmetic of
+//  eight atomics), VALU issue ~0.78 of the slots -- four waves per SIMD with 96 VGPRs are enough.)
+//
+// FORM (round 6, third session):
+//   0  every sample sends its eight terms to the histogram with eight f64 LDS atomics (rounds 2-5)
+//   1  RUN COMBINING: a lane walks consecutive samples of a window row, and consecutive samples mostly
+//      fall into the same (row bin, column bin, orientation bin) cell -- 0.61 of them on the 2189 x
+//      1459 detect image (gradient orientation is smooth at the keypoint's scale, a bin is ~6 pixels
+//      wide).  The lane keeps the eight f64 sums of its current cell in registers and sends them to
+//      LDS when the cell changes: 8 atomics per RUN instead of per sample.  Sums of float32 terms in
+//      float64 are exact in either grouping (the convention of the oracle: each bin = the exact sum
+//      of its terms, rounded to float32 once), so the result is the same bit for bit.
+//   2  form 1 + the row tables of the interval walk in registers: the lane reads the ends of its
+//      first three rows once, before the loop; the loop itself touches LDS only for the histogram
+//      (forms 0/1 read rowpre / rowlo for every sample, and each of those reads waits for the
+//      atomics queued before it); a lane that needs a fourth row or meets an empty one takes the
+//      LDS path for that step.
+template <int FORM, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
                                                          const int *__restrict__ n_kp, int cap_k,
                                                          uint8_t *__restrict__ desc, int xcd)
 {
@@ -894,6 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
     constexpr int HB = (d + 2) * (d + 2) * (n + 2);       // 360
     __shared__ double hist_s[4][HB];
     __shared__ float raw_s[4][d * d * n + 2];
+    __shared__ float sq_s[4][d * d * n];
     constexpr int DESC_ROWS = 160;                        // window rows handled by the interval walk
     __shared__ int rowlo_s[4][DESC_ROWS];
     __shared__ int rowpre_s[4][DESC_ROWS + 1];
@@ -950,6 +977,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
             const float *pc = img + (int64_t)(py + i) * w + (px + j);
             return Grad{pc[-1], pc[1], pc[-w], pc[w]};
         };
+        // (forms 1, 2) the lane's current cell and its eight partial sums
+        double run[8];
+        int run_base = -1;
+        auto flush_run = [&]() {
+            if (run_base >= 0) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int b = run_base + ((q4 >> 1) * (d + 2) + (q4 & 1)) * (n + 2);
+                    atomicAdd(&hist[b], run[2 * q4]);
+                    atomicAdd(&hist[b + 1], run[2 * q4 + 1]);
+                }
+            }
+        };
         auto accumulate = [&](int i, int j, const Grad g) {
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
@@ -970,13 +1010,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
             const float v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
             const float v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
             const float vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
+            if (FORM == 0) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int rr = r0 + 1 + (q4 >> 1), cc = c0 + 1 + (q4 & 1);
-                const int base = (rr * (d + 2) + cc) * (n + 2) + o0;
-                const float v1 = vv[q4] * fo;
-                atomicAdd(&hist[base], (double)(vv[q4] - v1));
-                atomicAdd(&hist[base + 1], (double)v1);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int rr = r0 + 1 + (q4 >> 1), cc = c0 + 1 + (q4 & 1);
+                    const int base = (rr * (d + 2) + cc) * (n + 2) + o0;
+                    const float v1 = vv[q4] * fo;
+                    atomicAdd(&hist[base], (double)(vv[q4] - v1));
+                    atomicAdd(&hist[base + 1], (double)v1);
+                }
+            } else {
+                // (24-bit multiplies: full rate, the 32-bit v_mul_lo_u32 is a quarter of that)
+                const int base = __mul24(r0 + 1, (d + 2) * (n + 2)) + __mul24(c0 + 1, n + 2) + o0;
+                if (base != run_base) {
+                    flush_run();
+                    run_base = base;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float v1 = vv[q4] * fo;
+                        run[2 * q4] = (double)(vv[q4] - v1);
+                        run[2 * q4 + 1] = (double)v1;
+                    }
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float v1 = vv[q4] * fo;
+                        run[2 * q4] += (double)(vv[q4] - v1);
+                        run[2 * q4 + 1] += (double)v1;
+                    }
+                }
             }
         };
         auto sample = [&](int i, int j) {
@@ -991,6 +1053,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
             int *rowlo = rowlo_s[wave], *rowpre = rowpre_s[wave];
             int carry = 0;
             const double cos_d = (double)cos_t, sin_d = (double)sin_t;
+            // (FORM >= 1: the bounds through one reciprocal per constraint instead of four f64
+            //  divisions per row -- the interval only has to CONTAIN the samples that pass the float32
+            //  test in accumulate(); floor / ceil leave a column of slack, an error of 1e-13 in a
+            //  bound moves it by a column only where the bound is that close to an integer, and then
+            //  both neighbours are inside the slack)
+            const double inv_a[2] = {1.0 / sin_d, 1.0 / cos_d};
             for (int base = 0; base < side; base += 64) {
                 const int row = base + lane;
                 int jl = 0, cnt = 0;
@@ -1005,7 +1073,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             if (fabs(aa[e]) < 1e-9) continue;          // no usable bound: keep all
-                            double x1 = (-1.0 - bb[e]) / aa[e], x2 = ((double)d - bb[e]) / aa[e];
+                            double x1, x2;
+                            if (FORM == 0) {
+                                x1 = (-1.0 - bb[e]) / aa[e];
+                                x2 = ((double)d - bb[e]) / aa[e];
+                            } else {
+                                x1 = (-1.0 - bb[e]) * inv_a[e];
+                                x2 = ((double)d - bb[e]) * inv_a[e];
+                            }
                             if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; }
                             lo = fmax(lo, floor(x1));
                             hi = fmin(hi, ceil(x2));
@@ -1037,6 +1112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
             // listed position lies inside the image (the intervals are clipped), so the loads
             // need no test.
             int row = 0;
+            if (FORM < 2) {
             if (s0 < s1) {
                 while (s0 >= rowpre[row + 1]) ++row;
                 int ci = row - radius, cj = rowlo[row] + (s0 - rowpre[row]);
@@ -1054,6 +1130,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
                     ci = ni; cj = nj; cg = ng;
                 }
             }
+            } else if (s0 < s1) {
+                // first row with rowpre[row + 1] > s0 (rows may be empty: rowpre is non-decreasing)
+                int lo = 0, hi = side - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rowpre[mid + 1] > s0) hi = mid; else lo = mid + 1;
+                }
+                row = lo;
+                // the ends of this row and the next two, the first columns of the next two: all the
+                // loop needs unless the lane's chunk spans more than three rows or meets an empty one
+                const int rmax = side - 1;
+                const int r1 = min(row + 1, rmax), r2 = min(row + 2, rmax);
+                int end0 = rowpre[row + 1];
+                const int end1 = rowpre[r1 + 1], end2 = rowpre[r2 + 1];
+                const int lo1 = rowlo[r1], lo2 = rowlo[r2];
+                int ahead = (row + 1 <= rmax && end1 > end0) ? ((row + 2 <= rmax && end2 > end1) ? 2 : 1) : 0;
+                int ci = row - radius, cj = rowlo[row] + (s0 - rowpre[row]);
+                const float *pc = img + (int64_t)(py + ci) * w + (px + cj);
+                Grad cg = Grad{pc[-1], pc[1], pc[-w], pc[w]};
+                int used = 0;                              // register rows consumed so far
+                for (int s = s0; s < s1; ++s) {
+                    int ni = ci, nj = cj;
+                    const float *pn = pc;
+                    Grad ng = cg;
+                    if (s + 1 < s1) {
+                        bool slow = false;
+                        if (s + 1 < end0) {
+                            nj = cj + 1;
+                            pn = pc + 1;
+                        } else if (used < ahead) {
+                            // (s + 1 == the first sample of the next row: rows are contiguous in the list)
+                            ++row;
+                            ni = row - radius;
+                            nj = used == 0 ? lo1 : lo2;
+                            end0 = used == 0 ? end1 : end2;
+                            ++used;
+                            pn = img + (int64_t)(py + ni) * w + (px + nj);
+                        } else {
+                            slow = true;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                            if (slow) {
+                                while (s + 1 >= rowpre[row + 1]) ++row;
+                                ni = row - radius;
+                                nj = rowlo[row] + (s + 1 - rowpre[row]);
+                                end0 = rowpre[row + 1];
+                                pn = img + (int64_t)(py + ni) * w + (px + nj);
+                            }
+                        }
+                        ng = Grad{pn[-1], pn[1], pn[-w], pn[w]};
+                    }
+                    accumulate(ci, cj, cg);
+                    ci = ni; cj = nj; cg = ng; pc = pn;
+                }
+            }
         } else {
             const int nsamp = side * side;
             for (int s = lane; s < nsamp; s += 64) {
@@ -1061,6 +1192,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
                 sample(i0 - radius, s - i0 * side - radius);
             }
         }
+        if (FORM >= 1) flush_run();
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);           // lgkmcnt(0): the LDS atomics have landed
@@ -1083,6 +1215,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         // the two norms are OpenCV's scalar loops: sequential float32 sums over k = 0 .. 127
+        if (FORM == 0) {
         if (lane == 0) {
             float nrm2 = 0.f;
             for (int t = 0; t < d * d * n; ++t) nrm2 += raw[t] * raw[t];
@@ -1095,6 +1228,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(IAMX_DESC_W
             const float s2 = sqrtf(nrm2);
             raw[d * d * n] = thr;
             raw[d * d * n + 1] = 512.f / (s2 > 1.1920929e-07f ? s2 : 1.1920929e-07f);
+        }
+        } else {
+            // ... of which only the ADDITIONS are sequential: every lane squares its own two values
+            // (the same float32 products), lane 0 adds the 128 squares in order -- 2 x 128 dependent
+            // additions instead of 2 x 128 x (compare, multiply, add) on one lane while 63 wait (a
+            // sixth of the kernel's instruction slots for a keypoint of the first layer)
+            float *sq = sq_s[wave];
+            sq[lane * 2] = v[0] * v[0];
+            sq[lane * 2 + 1] = v[1] * v[1];
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) {
+                float nrm2 = 0.f;
+                for (int t = 0; t < d * d * n; ++t) nrm2 += sq[t];
+                raw[d * d * n] = sqrtf(nrm2) * 0.2f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            const float thr0 = raw[d * d * n];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float val = v[e] < thr0 ? v[e] : thr0;
+                sq[lane * 2 + e] = val * val;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) {
+                float nrm2 = 0.f;
+                for (int t = 0; t < d * d * n; ++t) nrm2 += sq[t];
+                const float s2 = sqrtf(nrm2);
+                raw[d * d * n + 1] = 512.f / (s2 > 1.1920929e-07f ? s2 : 1.1920929e-07f);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1655,8 +1820,13 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
                        CAP_CAND, (float)sigma_d, kp, cap, n_out, xcd_enabled());
     {
         const unsigned g = (blocks(cap, 4) + 7u) & ~7u;     // (a multiple of 8: the XCD slabs)
-        hipLaunchKernelGGL(descriptor_kernel, dim3(g < 16384u ? g : 16384u), dim3(256), 0, st, T, kp,
-                           n_out, cap, desc, 0);     // (XCD slabs: -21 % traffic but +6 % time, profiles/r4_sift_ab.txt)
+        const dim3 dg(g < 16384u ? g : 16384u);     // (XCD slabs: -21 % traffic but +6 % time, profiles/r4_sift_ab.txt)
+        switch (desc_form()) {
+        case 0: hipLaunchKernelGGL((descriptor_kernel<0, 8>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
+        case 1: hipLaunchKernelGGL((descriptor_kernel<1, 6>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
+        case 25: hipLaunchKernelGGL((descriptor_kernel<2, 5>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
+        default: hipLaunchKernelGGL((descriptor_kernel<2, 4>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
+        }
     }
     return iamx::check_launch("iamx_sift_detect");
 }

@@ -483,3 +483,52 @@ def test_bulk_ingest_equals_image_by_image():
             for name in ('desc2', 'norm2', 'cinit', 'perm'):
                 assert torch.equal(getattr(a, name)[o2:o2 + n2], getattr(b, name)[o2:o2 + n2]), (name, i)
         assert torch.equal(a.meta, b.meta)
+
+
+@pytest.mark.parametrize('train_layout', [True, False], ids=['with_desc2', 'without_desc2'])
+def test_store_extended_in_place_equals_store_built_at_once(train_layout):
+    """DescriptorStore(reserve_rows, reserve_images) + try_extend (find_matches meeting undetected
+    images: a few hundred new images per round go behind the old rows, the arena is not rebuilt):
+    every layout of the extended store equals a store built with all images at once, the matches
+    of pairs across old and new images are the same, and try_extend says no -- changing nothing --
+    when the capacity does not suffice"""
+    import torch
+    from imageanalysis_amd import kernels
+    rng = np.random.default_rng(21)
+    counts = [4096, 4097, 130, 5000, 3333, 257, 1024, 700]
+    arrays = [_sift_like(rng, n) for n in counts]
+    k = 3
+    full = kernels.DescriptorStore(counts, train_layout=train_layout)
+    full.set_images(0, arrays)
+    ext = kernels.DescriptorStore(counts[:k], train_layout=train_layout,
+                                  reserve_rows=sum(counts) + 256 * len(counts), reserve_images=len(counts))
+    keep = [ext.set_images(0, arrays[:k])]
+    ptr = ext.desc.data_ptr()
+    assert ext.try_extend(counts[k:])
+    assert ext.desc.data_ptr() == ptr and ext.counts == counts
+    for i in range(k, len(counts)):
+        keep.append(ext.set_image(i, arrays[i], sync=False))
+    torch.cuda.synchronize()
+    assert np.array_equal(ext.offsets, full.offsets) and np.array_equal(ext.offsets3, full.offsets3)
+    assert ext.rows_used == full.rows_used
+    n, n3 = int(full.offsets[-1]), int(full.offsets3[-1])
+    for name, m in (('desc', n), ('norm_q', n), ('norm_t', n)):
+        assert torch.equal(getattr(ext, name)[:m], getattr(full, name)[:m]), name
+    for i, c in enumerate(counts):
+        o3 = int(full.offsets3[i])
+        for name, m in (('desc3', int(full.caps3[i])), ('sn2', c), ('sct', c), ('sperm', c), ('sinv', c)):
+            assert torch.equal(getattr(ext, name)[o3:o3 + m], getattr(full, name)[o3:o3 + m]), (name, i)
+    assert torch.equal(ext.img_off, full.img_off) and torch.equal(ext.img_n, full.img_n)
+    assert torch.equal(ext.img_off3, full.img_off3)
+    if train_layout:
+        n2 = int(full.offsets2[-1])
+        for name in ('desc2', 'norm2', 'cinit', 'perm'):
+            assert torch.equal(getattr(ext, name)[:n2], getattr(full, name)[:n2]), name
+        assert torch.equal(ext.meta[:len(counts)], full.meta[:len(counts)])
+    pairs = [(0, 4), (4, 0), (1, 7), (7, 1), (3, 5), (5, 3), (2, 6), (6, 2)]
+    _same_survivors(_run(ext, pairs, 0.7, sym=True), _run(full, pairs, 0.7, sym=True))
+    _same_survivors(_run(ext, pairs, 0.7, fast=False, sym=False), _run(full, pairs, 0.7, fast=False, sym=False))
+    # no room: nothing changes
+    before = list(ext.counts)
+    assert not ext.try_extend([1 << 20])
+    assert ext.counts == before and ext.desc.data_ptr() == ptr

@@ -3,10 +3,11 @@
 # traffic (separate --pmc FETCH_SIZE / WRITE_SIZE passes) of tools/sift_time.py, once per setting of
 # the environment switches given as arguments ("name:VAR=1" ...; "base:" = none).
 #   bash tools/sift_ab.sh base: noxcd:IAMX_SIFT_NO_XCD=1      -> gpurun_out/r4_sift_ab_<name>.txt
+#   PASSES=stats: times only (the report then shows no traffic column values)
 OUT="$PWD/gpurun_out"; REPO="$PWD"; mkdir -p "$OUT"; export TMPDIR=/tmp
 for spec in "$@"; do
     name="${spec%%:*}"; envs="${spec#*:}"
-    for pass in stats FETCH_SIZE WRITE_SIZE; do
+    for pass in ${PASSES:-stats FETCH_SIZE WRITE_SIZE}; do
         d=/tmp/ab_${name}_$pass; rm -rf $d
         if [ $pass = stats ]; then args="--kernel-trace --stats"; else args="--pmc $pass"; fi
         (cd /tmp && env $envs timeout 300 rocprofv3 $args --output-format csv -d $d -o s -- \

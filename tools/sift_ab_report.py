@@ -27,6 +27,8 @@ for line in open(os.path.join(out, 'r4_sift_ab_%s_stats.txt' % name)):
 pmc = {}
 for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
     cur = None
+    if not os.path.exists(os.path.join(out, 'r4_sift_ab_%s_%s.txt' % (name, ctr))):
+        continue                                 # (PASSES=stats)
     for line in open(os.path.join(out, 'r4_sift_ab_%s_%s.txt' % (name, ctr))):
         if line.strip().startswith('kernel'):
             cur = base(line)
