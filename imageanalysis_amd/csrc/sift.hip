@@ -278,6 +278,13 @@ inline int desc_form()
     return f;
 }
 
+// IAMX_DESC_SORT=0 (read once; A/B): the descriptor pass walks the keypoint list as orient_kernel left it
+inline bool desc_sorted()
+{
+    static const bool on = [] { const char *e = getenv("IAMX_DESC_SORT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 inline int xcd_enabled()
 {
     static const int on = [] { const char *e = getenv("IAMX_SIFT_NO_XCD"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -425,6 +432,7 @@ struct Pyr {
     // per octave: pointers of the 6 Gaussian levels, dims
     float *g[6];
     int h, w;
+    int diag;            // (int)sqrt(w^2 + h^2) in float64 (calcSIFTDescriptor's radius clip), filled by the host
 };
 constexpr int MAX_OCT = 16;
 struct PyrTable {
@@ -618,9 +626,11 @@ __device__ __forceinline__ float fast_atan2_cv(float y, float x)
 }
 
 // oracle exp32(): float64 range reduction, degree-7 float32 Horner polynomial for 2^f, x <= 0
+// CHECKED = false: the caller guarantees x >= -87 (the same value, without the test and its branch)
+template <bool CHECKED = true>
 __device__ __forceinline__ float exp32(float x)
 {
-    if (x < -87.f) return 0.f;
+    if (CHECKED && x < -87.f) return 0.f;
     const double t = (double)x * 1.4426950408889634;
     const double n = rint(t);
     const float f = (float)(t - n);
@@ -889,6 +899,89 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     flush_keypoints(kbuf, n_buf, kp, cap_k, n_kp, lane);
 }
 
+// ---------------------------------------------------------------------------------
+// Order of the descriptor pass (round 6, third session).  A keypoint's window is 43-85 pixels
+// square, 17-50 KB of cache lines, and neighbouring keypoints' windows overlap five-fold -- but
+// orient_kernel appends keypoints in whatever order its waves finish, the workgroups of the
+// descriptor kernel are dealt round-robin to the eight XCDs, and 512 waves per XCD then hold
+// ~15 MB of windows from all over the pyramid against 4 MB of L2: the kernel fetched 1.97 GB per
+// frame (53 KB per keypoint: no reuse at all) and, once the LDS atomics were out of the way,
+// waited for those gathers (SQ_WAIT_INST_ANY 0.42 of the wave cycles).  So the pass runs over a
+// permutation: keypoints are bucketed by (vertical stripe of the image = XCD, pyramid level,
+// 64-pixel band of rows) with one counting sort (count + rank, one-workgroup scan, scatter); XCD x
+// walks the keypoints of stripe x -- an eighth of every level, so the XCDs carry equal work --
+// level by level, top to bottom, and the ~512 keypoints it has in flight are neighbours in one
+// level: a region of ~2 MB.  The output rows do not move (kp[k] / desc[k] keep their index).
+// ---------------------------------------------------------------------------------
+constexpr int DB_ROWS = 64;                       // 64-pixel bands per level (levels taller than 4096 rows share the last)
+constexpr int DB_SEGS = 32;                       // octave index * 3 + layer - 1 (octaves past the tenth share the last)
+constexpr int DB_BUCKETS = 8 * DB_SEGS * DB_ROWS; // 16 384: the one-workgroup scan is 30 us for 65 536
+
+__global__ __launch_bounds__(256) void desc_bucket_count_kernel(PyrTable T, const float *__restrict__ kp,
+                                                                const int *__restrict__ n_kp, int cap_k,
+                                                                int *__restrict__ cnt, int *__restrict__ kb,
+                                                                int *__restrict__ kr, float2 *__restrict__ cs)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int total = *n_kp < cap_k ? *n_kp : cap_k;
+    if (k >= total) return;
+    const float *q = kp + (int64_t)k * 8;
+    const int addr = __float_as_int(q[6]);
+    const int o = addr >> 8, layer = addr & 255;
+    const float scale = o >= 1 ? 1.f / (float)(1 << (o - 1)) : 2.f;
+    const int px = max((int)(q[0] * scale), 0), py = max((int)(q[1] * scale), 0);
+    const int stripe = min((int)(((int64_t)px * 8) / T.oct[o].w), 7);
+    const int row = min(py >> 6, DB_ROWS - 1);
+    const int seg = min(max(o * 3 + layer - 1, 0), DB_SEGS - 1);
+    const int b = (stripe * DB_SEGS + seg) * DB_ROWS + row;
+    kb[k] = b;
+    kr[k] = atomicAdd(&cnt[b], 1);
+    // cosf / sinf of the descriptor's rotation (correctly rounded: float64 cos / sin, rounded once), one
+    // LANE per keypoint here instead of one WAVE per keypoint in descriptor_kernel: ~300 float64
+    // instructions that every wave of that kernel spent before its first sample
+    float ori = 360.f - q[3];
+    if (fabsf(ori - 360.f) < 1.1920929e-07f) ori = 0.f;
+    const float ang = ori * (float)(3.141592653589793 / 180.0);
+    cs[k] = make_float2((float)cos((double)ang), (float)sin((double)ang));
+}
+
+// cnt[b] -> first position of bucket b (exclusive prefix, in place); xcd_start[0..8] = the stripes' ranges
+__global__ __launch_bounds__(1024) void desc_bucket_scan_kernel(int *__restrict__ cnt, int *__restrict__ xcd_start)
+{
+    __shared__ int part[1024];
+    constexpr int PER = DB_BUCKETS / 1024;
+    const int lo = threadIdx.x * PER;
+    int sum = 0;
+    for (int j = lo; j < lo + PER; ++j) sum += cnt[j];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int sft = 1; sft < 1024; sft <<= 1) {
+        const int v = threadIdx.x >= sft ? part[threadIdx.x - sft] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    if ((lo % (DB_SEGS * DB_ROWS)) == 0) xcd_start[lo / (DB_SEGS * DB_ROWS)] = run;
+    if (threadIdx.x == 1023) xcd_start[8] = part[1023];
+    for (int j = lo; j < lo + PER; ++j) {
+        const int c = cnt[j];
+        cnt[j] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void desc_bucket_scatter_kernel(const int *__restrict__ n_kp, int cap_k,
+                                                                  const int *__restrict__ start,
+                                                                  const int *__restrict__ kb,
+                                                                  const int *__restrict__ kr, int *__restrict__ perm)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int total = *n_kp < cap_k ? *n_kp : cap_k;
+    if (k >= total) return;
+    perm[start[kb[k]] + kr[k]] = k;
+}
+
 // one wave per keypoint: calcSIFTDescriptor
 // (form 0 ran 8 waves per SIMD -- 64 VGPRs and 32 B of scratch instead of 86 VGPRs / 5 waves: it waited
 //  on LDS atomics and image gathers more than it issued; 1.645 / 1.626 / 1.596 ms per detection at
@@ -914,7 +1007,10 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 template <int FORM, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void descriptor_kernel(PyrTable T, const float *__restrict__ kp,
                                                          const int *__restrict__ n_kp, int cap_k,
-                                                         uint8_t *__restrict__ desc, int xcd)
+                                                         uint8_t *__restrict__ desc, int xcd,
+                                                         const int *__restrict__ perm,
+                                                         const int *__restrict__ xcd_start,
+                                                         const float2 *__restrict__ cs)
 {
     constexpr int d = 4, n = 8;
     constexpr int HB = (d + 2) * (d + 2) * (n + 2);       // 360
@@ -937,11 +1033,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     // The workgroups of one XCD walk a contiguous part of the list (appended by orient_kernel in
     // runs of image neighbours): the windows an XCD's L2 sees overlap instead of being spread over
     // the whole pyramid.
-    const int xcds = xcd ? 8 : 1;
-    const int my_xcd = xcd ? (int)(blockIdx.x & 7) : 0;
+    // With `perm` (the counting sort above): XCD x takes the positions xcd_start[x] .. xcd_start[x + 1]
+    // of the permutation, four consecutive ones (neighbours in one pyramid level) per workgroup.
+    const int xcds = (xcd || perm) ? 8 : 1;
+    const int my_xcd = xcds == 8 ? (int)(blockIdx.x & 7) : 0;
     const int slab = ((total + xcds - 1) / xcds + 3) & ~3;
-    const int k_end = min((my_xcd + 1) * slab, total);
-    for (int k = my_xcd * slab + (int)(blockIdx.x / xcds) * 4 + wave; k < k_end; k += (int)(gridDim.x / xcds) * 4) {
+    const int k_begin = perm ? xcd_start[my_xcd] : my_xcd * slab;
+    const int k_end = perm ? min(xcd_start[my_xcd + 1], total) : min((my_xcd + 1) * slab, total);
+    for (int kpos = k_begin + (int)(blockIdx.x / xcds) * 4 + wave; kpos < k_end; kpos += (int)(gridDim.x / xcds) * 4) {
+    const int k = perm ? perm[kpos] : kpos;
     for (int i = lane; i < HB; i += 64) hist[i] = 0.0;
     __builtin_amdgcn_wave_barrier();
     {
@@ -959,11 +1059,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
         const float scl = q[2] * scale * 0.5f;
         const int px = cv_round(ptx), py = cv_round(pty);
         const float ang = ori * (float)(3.141592653589793 / 180.0);
-        float cos_t = (float)cos((double)ang), sin_t = (float)sin((double)ang);   // cosf / sinf, correctly rounded
+        float cos_t, sin_t;                                                       // cosf / sinf, correctly rounded
+        if (cs) {
+            const float2 t = cs[k];                // (desc_bucket_count_kernel: the same expressions)
+            cos_t = t.x; sin_t = t.y;
+        } else {
+            cos_t = (float)cos((double)ang); sin_t = (float)sin((double)ang);
+        }
         const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
         const float hist_width = 3.f * scl;
         int radius = cv_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
-        const int diag = (int)sqrt((double)w * w + (double)h * h);
+        const int diag = FORM == 0 ? (int)sqrt((double)w * w + (double)h * h) : P.diag;
         radius = radius < diag ? radius : diag;
         cos_t /= hist_width;
         sin_t /= hist_width;
@@ -996,7 +1102,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d)) return;
             const float dx = g.xr - g.xl;
             const float dy = g.yu - g.yd;
-            const float wgt = exp32((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            // (-1 < rbin, cbin < d: |r_rot|, |c_rot| < 2.5, the argument of exp32 is > -1.6)
+            const float wgt = exp32<FORM == 0>((c_rot * c_rot + r_rot * r_rot) * exp_scale);
             const float og = fast_atan2_cv(dy, dx);
             const float mag = sqrtf(dx * dx + dy * dy) * wgt;
             const float obin = (og - ori) * bins_per_rad;
@@ -1004,12 +1111,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
             const int r0 = (int)fr0, c0 = (int)fc0;
             int o0 = (int)fo0;
             const float fr = rbin - fr0, fc = cbin - fc0, fo = obin - fo0;
-            if (o0 < 0) o0 += n;
-            if (o0 >= n) o0 -= n;
+            if (FORM == 0) {
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+            } else {
+                o0 &= n - 1;           // (og, ori in [0, 360]: -8 <= o0 <= 8, the same wrap in one instruction)
+            }
             const float v_r1 = mag * fr, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
-            const float v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
-            const float vv[4] = {v_rc00, v_rc01, v_rc10, v_rc11};
+            float vv[4], v1s[4];
+            if (FORM == 0) {
+                const float v_rc11 = v_r1 * fc, v_rc10 = v_r1 - v_rc11;
+                const float v_rc01 = v_r0 * fc, v_rc00 = v_r0 - v_rc01;
+                vv[0] = v_rc00; vv[1] = v_rc01; vv[2] = v_rc10; vv[3] = v_rc11;
+            } else {
+                // the same products and differences two at a time (v_pk_mul_f32 / v_pk_add_f32:
+                // separately rounded, like the scalar form)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 vr = {v_r0, v_r1};
+                const f2 c1 = vr * fc;                  // v_rc01, v_rc11
+                const f2 c0v = vr - c1;                 // v_rc00, v_rc10
+                const f2 c1o = c1 * fo, c0o = c0v * fo;
+                const f2 c1r = c1 - c1o, c0r = c0v - c0o;
+                vv[0] = c0r.x; vv[1] = c1r.x; vv[2] = c0r.y; vv[3] = c1r.y;        // vv[q] - v1
+                v1s[0] = c0o.x; v1s[1] = c1o.x; v1s[2] = c0o.y; v1s[3] = c1o.y;    // v1 = vv[q] * fo
+            }
             if (FORM == 0) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
@@ -1027,16 +1152,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                     run_base = base;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const float v1 = vv[q4] * fo;
-                        run[2 * q4] = (double)(vv[q4] - v1);
-                        run[2 * q4 + 1] = (double)v1;
+                        run[2 * q4] = (double)vv[q4];
+                        run[2 * q4 + 1] = (double)v1s[q4];
                     }
                 } else {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
-                        const float v1 = vv[q4] * fo;
-                        run[2 * q4] += (double)(vv[q4] - v1);
-                        run[2 * q4 + 1] += (double)v1;
+                        run[2 * q4] += (double)vv[q4];
+                        run[2 * q4 + 1] += (double)v1s[q4];
                     }
                 }
             }
@@ -1493,7 +1616,7 @@ struct Layout {
     int n_oct;
     int h[MAX_OCT], w[MAX_OCT];
     int64_t g_off[MAX_OCT][6];
-    int64_t up_off, cand_off, refined_off, count_off, total;
+    int64_t up_off, cand_off, refined_off, count_off, bucket_off, total;
 };
 
 Layout make_layout(int height, int width, int cap_c)
@@ -1516,6 +1639,7 @@ Layout make_layout(int height, int width, int cap_c)
     L.cand_off = take((int64_t)cap_c * sizeof(Cand));
     L.refined_off = take((int64_t)cap_c * sizeof(Refined));
     L.count_off = take(256);
+    L.bucket_off = take((int64_t)(DB_BUCKETS + 16) * 4);     // descriptor-pass buckets + the stripes' ranges
     L.total = off;
     return L;
 }
@@ -1690,6 +1814,7 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
     for (int o = 0; o < L.n_oct; ++o) {
         T.oct[o].h = L.h[o];
         T.oct[o].w = L.w[o];
+        T.oct[o].diag = (int)sqrt((double)L.w[o] * L.w[o] + (double)L.h[o] * L.h[o]);
         for (int i = 0; i < 6; ++i) T.oct[o].g[i] = reinterpret_cast<float *>(ws + L.g_off[o][i]);
     }
     Cand *cand = reinterpret_cast<Cand *>(ws + L.cand_off);
@@ -1698,6 +1823,12 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
     int *n_refined = n_cand + 1;
     (void)hipMemsetAsync(n_cand, 0, 8, st);
     (void)hipMemsetAsync(n_out, 0, 4, st);
+    // descriptor-pass order: bucket counters, and kb / kr / perm / (cos, sin) in the candidate list's memory (dead
+    // once refine_kernel has run); a capacity that does not fit there keeps the list order
+    int *bucket_cnt = reinterpret_cast<int *>(ws + L.bucket_off);
+    int *xcd_start = bucket_cnt + DB_BUCKETS;
+    const bool sorted_pass = desc_sorted() && (int64_t)cap * 20 <= (int64_t)CAP_CAND * (int64_t)sizeof(Cand);
+    if (sorted_pass) (void)hipMemsetAsync(bucket_cnt, 0, (size_t)(DB_BUCKETS + 16) * 4, st);
 
     // OpenCV's sigma is a double (1.6); the ABI carries a float, whose widening (1.60000002...)
     // would move every Gaussian tap in its last bits: take the parameter to 6 decimals
@@ -1820,12 +1951,24 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
                        CAP_CAND, (float)sigma_d, kp, cap, n_out, xcd_enabled());
     {
         const unsigned g = (blocks(cap, 4) + 7u) & ~7u;     // (a multiple of 8: the XCD slabs)
-        const dim3 dg(g < 16384u ? g : 16384u);     // (XCD slabs: -21 % traffic but +6 % time, profiles/r4_sift_ab.txt)
+        const dim3 dg(g < 16384u ? g : 16384u);     // (XCD slabs of the unsorted list: -21 % traffic but +6 % time, profiles/r4_sift_ab.txt)
+        const int *perm = nullptr;
+        float2 *csp = nullptr;
+        if (sorted_pass) {
+            int *kb = reinterpret_cast<int *>(cand), *kr = kb + cap, *pm = kr + cap;
+            csp = reinterpret_cast<float2 *>(pm + cap);
+            hipLaunchKernelGGL(desc_bucket_count_kernel, dim3(blocks(cap, 256)), dim3(256), 0, st, T, kp, n_out, cap,
+                               bucket_cnt, kb, kr, csp);
+            hipLaunchKernelGGL(desc_bucket_scan_kernel, dim3(1), dim3(1024), 0, st, bucket_cnt, xcd_start);
+            hipLaunchKernelGGL(desc_bucket_scatter_kernel, dim3(blocks(cap, 256)), dim3(256), 0, st, n_out, cap,
+                               bucket_cnt, kb, kr, pm);
+            perm = pm;
+        }
         switch (desc_form()) {
-        case 0: hipLaunchKernelGGL((descriptor_kernel<0, 8>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
-        case 1: hipLaunchKernelGGL((descriptor_kernel<1, 6>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
-        case 25: hipLaunchKernelGGL((descriptor_kernel<2, 5>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
-        default: hipLaunchKernelGGL((descriptor_kernel<2, 4>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0); break;
+        case 0: hipLaunchKernelGGL((descriptor_kernel<0, 8>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
+        case 1: hipLaunchKernelGGL((descriptor_kernel<1, 6>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
+        case 25: hipLaunchKernelGGL((descriptor_kernel<2, 5>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
+        default: hipLaunchKernelGGL((descriptor_kernel<2, 4>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
         }
     }
     return iamx::check_launch("iamx_sift_detect");

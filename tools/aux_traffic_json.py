@@ -14,6 +14,7 @@ prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 SIFT = ('gray_up2x_kernel', 'blur_strip_kernel', 'downsample_kernel', 'extrema_kernel',
         'extrema_multi_kernel',
         'pyramid_tail_kernel', 'refine_kernel', 'orient_kernel', 'descriptor_kernel',
+        'desc_bucket_count_kernel', 'desc_bucket_scan_kernel', 'desc_bucket_scatter_kernel',
         'sort_count_kernel', 'sort_offsets_kernel', 'sort_scatter_kernel', 'sort_rank_kernel',
         'sort_compact_kernel', 'sort_gather_kernel')
 BA = ('ba_residual_lds_kernel', 'ba_residual_pipe_kernel', 'ba_residual_jac_kernel', 'acc_cam_kernel', 'acc_pt_kernel',

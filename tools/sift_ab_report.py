@@ -8,7 +8,7 @@ import sys
 name = sys.argv[1]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
 SIFT = ('gray_up2x', 'blur_strip', 'downsample', 'extrema', 'pyramid_tail', 'refine', 'orient',
-        'descriptor', 'sort_')
+        'descriptor', 'desc_bucket', 'sort_')
 FRAMES = 3                                        # tools/sift_time.py runs three detects
 
 

@@ -4,7 +4,7 @@
 OUT="$PWD/gpurun_out"; REPO="$PWD"; mkdir -p "$OUT"; export TMPDIR=/tmp
 SETS=("SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
       "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT"
-      "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum FETCH_SIZE GRBM_GUI_ACTIVE")
+      )   # (a third set with TCC_HIT_sum / TCC_MISS_sum / FETCH_SIZE ran for minutes and returned nothing on this pool)
 for form in "$@"; do
     : > "$OUT/sift_desc_pmc_$form.txt"
     k=0
