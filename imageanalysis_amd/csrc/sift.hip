@@ -914,7 +914,7 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
 // level: a region of ~2 MB.  The output rows do not move (kp[k] / desc[k] keep their index).
 // ---------------------------------------------------------------------------------
 constexpr int DB_ROWS = 64;                       // 64-pixel bands per level (levels taller than 4096 rows share the last)
-constexpr int DB_SEGS = 32;                       // octave index * 3 + layer - 1 (octaves past the tenth share the last)
+constexpr int DB_SEGS = 32;                       // (3 - layer) * 10 + octave index (octaves past the tenth share a segment)
 constexpr int DB_BUCKETS = 8 * DB_SEGS * DB_ROWS; // 16 384: the one-workgroup scan is 30 us for 65 536
 
 __global__ __launch_bounds__(256) void desc_bucket_count_kernel(PyrTable T, const float *__restrict__ kp,
@@ -932,7 +932,10 @@ __global__ __launch_bounds__(256) void desc_bucket_count_kernel(PyrTable T, cons
     const int px = max((int)(q[0] * scale), 0), py = max((int)(q[1] * scale), 0);
     const int stripe = min((int)(((int64_t)px * 8) / T.oct[o].w), 7);
     const int row = min(py >> 6, DB_ROWS - 1);
-    const int seg = min(max(o * 3 + layer - 1, 0), DB_SEGS - 1);
+    // level order: the third layers of all octaves first, the first layers last -- a window of the
+    // third layer holds up to four times the samples of one of the first, and the launch ends with
+    // the workgroups that started last: those should be the short ones
+    const int seg = min(max((3 - layer) * 10 + min(o, 9), 0), DB_SEGS - 1);
     const int b = (stripe * DB_SEGS + seg) * DB_ROWS + row;
     kb[k] = b;
     kr[k] = atomicAdd(&cnt[b], 1);
