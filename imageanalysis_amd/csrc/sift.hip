@@ -831,8 +831,14 @@ __global__ __launch_bounds__(256) void orient_kernel(PyrTable T, const Refined *
     if (lane < ORI_BINS) hist[lane] = 0.0;
     __builtin_amdgcn_wave_barrier();
     const int side = 2 * radius + 1;
+    // e / side without the integer division (~30 instructions per sample): (e + 0.5) / side is at
+    // least 0.5 / side away from an integer and the float32 product is off by < 1.2e-7 x the quotient:
+    // a sixteenth of that distance at side = 511 (the radius formula gives side <= 35)
+    const float inv_side = 1.f / (float)side;
+    const bool small_side = side < 512;
     for (int e = lane; e < side * side; e += 64) {
-        const int i = e / side - radius, j = e % side - radius;
+        const int i0 = small_side ? (int)(((float)e + 0.5f) * inv_side) : e / side;
+        const int i = i0 - radius, j = e - i0 * side - radius;
         const int y = r + i, x = c + j;
         if (y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1) continue;
         const float dx = g[(int64_t)y * w + x + 1] - g[(int64_t)y * w + x - 1];
