@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float *__restrict
 }
 
 // IAMX_DESC_FORM (read once; A/B measurements): descriptor_kernel<FORM, WAVES> -- 0 = <0, 8> (rounds 2-5),
-// 1 = <1, 6>, 25 = <2, 5>, anything else <2, 4> (shipped).  Same box, 2189 x 1459 detect image, 37 k
+// 1 = <1, 6>, 25 = <2, 5>, 9 = <9, 4> (TIMING ONLY: form 2 with every gather from the window centre: 429 us,
+// what the kernel would take with its loads cache resident), anything else <2, 4> (shipped).  Same box, 2189 x 1459 detect image, 37 k
 // keypoints (profiles/r6h_sift_desc_ab.txt): 791-824 / 653-667 / 637-646 / 614-628 us; forms 1 and 2 at
 // eight waves per SIMD spill (1.8 / 2.1 ms), form 2 at six keeps 36 B of scratch in the loop (763 us).
 inline int desc_form()
@@ -1311,6 +1312,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
                                 pn = img + (int64_t)(py + ni) * w + (px + nj);
                             }
                         }
+                        if (FORM == 9) {      // timing only: every gather from the window centre (cache resident)
+                            const float *pz = img + (int64_t)py * w + px;
+                            ng = Grad{pz[-1], pz[1], pz[-w], pz[w]};
+                        } else
                         ng = Grad{pn[-1], pn[1], pn[-w], pn[w]};
                     }
                     accumulate(ci, cj, cg);
@@ -1976,6 +1981,7 @@ static int sift_enqueue_pyramid(const Layout &L, float contrast_threshold, float
         switch (desc_form()) {
         case 0: hipLaunchKernelGGL((descriptor_kernel<0, 8>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
         case 1: hipLaunchKernelGGL((descriptor_kernel<1, 6>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
+        case 9: hipLaunchKernelGGL((descriptor_kernel<9, 4>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
         case 25: hipLaunchKernelGGL((descriptor_kernel<2, 5>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
         default: hipLaunchKernelGGL((descriptor_kernel<2, 4>), dg, dim3(256), 0, st, T, kp, n_out, cap, desc, 0, perm, xcd_start, csp); break;
         }
