@@ -860,7 +860,16 @@ extern "C" int iamx_match_lists_scan(int32_t *const *lists, const int64_t *cnt, 
             const int64_t ba = kp_base[ia[b]], bb = kp_base[ib[b]];
             const int64_t na = kp_base[ia[b] + 1] - ba, nb = kp_base[ib[b] + 1] - bb;
             if (mode & 3) {
+                // (the per-keypoint tables of a survey are hundreds of MB and a list's rows point all
+                //  over two images' parts of them: the lines of the rows a few steps ahead are asked
+                //  for now -- an index outside its image is only prefetched, never dereferenced)
+                constexpr int64_t PF = 12;
                 for (int64_t k = 0; k < n; ++k) {
+                    if (k + PF < n) {
+                        const int64_t pa = ba + p[2 * (k + PF)], pc = bb + p[2 * (k + PF) + 1];
+                        if (mode & 1) { __builtin_prefetch(used + pa, 1, 1); __builtin_prefetch(used + pc, 1, 1); }
+                        if (mode & 2) { __builtin_prefetch(remap + pa, 0, 1); __builtin_prefetch(remap + pc, 0, 1); }
+                    }
                     const int64_t a = p[2 * k], c = p[2 * k + 1];
                     if (a < 0 || a >= na || c < 0 || c >= nb) { bad.store(1); break; }
                     if (mode & 1) { used[ba + a] = 1; used[bb + c] = 1; }

@@ -19,6 +19,8 @@ intersection runs on the GPU (csrc/triangulate.hip)."""
 import contextlib
 import gc
 
+import os
+
 import numpy as np
 
 from . import _deps
@@ -63,7 +65,7 @@ def _pairs(matches):
 # --------------------------------------------------------------------------------------
 # duplicates -- match_cleanup.py:19-188 (+ project.py:331-350 compute_kp_usage)
 # --------------------------------------------------------------------------------------
-SCAN_THREADS = 8
+SCAN_THREADS = max(1, min(16, os.cpu_count() or 8))    # (the GPU boxes grant sixteen cores)
 
 
 def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None):
@@ -76,16 +78,16 @@ def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None
     # the four scans of a consolidation walk the same lists: their tables (which lists are array
     # backed, the pointers, counts and image pairs) are made once and kept on the project while
     # no list object or backing array has been replaced
-    sig_n, sig_h = 0, 0
-    for i1 in proj.image_list:
-        for key, m in i1.match_list.items():
-            sig_n += 1
-            # (masked every step: an unmasked product is a python integer of millions of bits
-            #  after 10^5 lists, and the loop quadratic -- 6 s per scan on a 4186-frame survey;
-            #  the KEY is part of it: a renamed / re-keyed entry that keeps its list object must
-            #  not find the old (key, partner) table)
-            sig_h = ((sig_h * 1000003) ^ id(m) ^ hash(key)
-                     ^ (id(m._a) if isinstance(m, MatchPairs) else 0)) & 0x3FFFFFFFFFFFFFFF
+    # (three comprehensions and three tuple hashes: 48 ms for the 131 k lists of a 2048-frame survey,
+    #  75 ms as an explicit loop with its arithmetic -- per scan, four scans a stage.  The KEYS are
+    #  part of it: a renamed / re-keyed entry that keeps its list object must not find the old
+    #  (key, partner) table; so are the backing arrays: an edited MatchPairs leaves its array form)
+    lists = [m for i1 in proj.image_list for m in i1.match_list.values()]
+    sig_n = len(lists)
+    sig_h = (hash(tuple(map(id, lists))),
+             hash(tuple([id(getattr(m, '_a', None)) for m in lists])),
+             hash(tuple([k for i1 in proj.image_list for k in i1.match_list])))
+    del lists
     cached = getattr(proj, '_iamx_scan', None) if wanted is None else None
     if cached is not None and cached[0] == (sig_n, sig_h, len(proj.image_list)):
         entries, rest, arrays, tables = cached[1:]
@@ -105,6 +107,13 @@ def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None
                 else:
                     rest.append((i, key, j, matches))
     n = len(entries)
+    if mode == 4 and wanted is None:
+        # check_for_pair_dups and check_for_1vn_dups ask for the same scan back to back (0.4 s each on
+        # a 2048-frame survey): the second takes the first's counts while no list object, backing
+        # array or length has changed (a list check_for_pair_dups repaired is a new object)
+        kept = getattr(proj, '_iamx_scan4', None)
+        if kept is not None and kept[0] == (sig_n, sig_h, len(proj.image_list)) and len(kept[1]) == n:
+            return entries, kept[1], kept[2], rest
     dup_pairs, dup_first = np.zeros(n, np.int32), np.zeros(n, np.int32)
     if n:
         if base is None:
@@ -128,6 +137,9 @@ def _scan_lists(proj, index, mode, wanted=None, used=None, remap=None, base=None
         if mode & 2:
             for _i, _k, _j, m in entries:
                 m._pk = None                      # (the pickled form was made from the old pairs)
+            proj._iamx_scan4 = None               # (the pairs changed in place)
+    if mode == 4 and wanted is None:
+        proj._iamx_scan4 = ((sig_n, sig_h, len(proj.image_list)), dup_pairs, dup_first)
     return entries, dup_pairs, dup_first, rest
 
 
@@ -485,7 +497,7 @@ def link_matches(proj, matches_direct):
                                               P(passes)))
     # (the consolidation's scan tables pin every backing array they were made from, and the lists
     #  check_for_pair_dups replaced: the stage ends here)
-    for attr in ('_iamx_scan',):
+    for attr in ('_iamx_scan', '_iamx_scan4'):
         try:
             delattr(proj, attr)
         except AttributeError:
@@ -504,7 +516,7 @@ def link_matches(proj, matches_direct):
     f_img, f_kp = empty_huge(total, np.int32), empty_huge(total, np.int32)
     new_ptr = np.zeros(n_chain + 1, np.int64)
     rc = lib().iamx_chains_longest_first(P(o_img), P(o_kp), P(o_ptr), n_chain, P(f_img), P(f_kp),
-                                         P(new_ptr), 4)
+                                         P(new_ptr), min(SCAN_THREADS, 8))
     if rc != 0:
         raise RuntimeError("iamx_chains_longest_first failed (%d): %s"
                            % (rc, (lib().iamx_last_error() or b'?').decode()))

@@ -444,6 +444,74 @@ def test_consolidation_scans_stay_linear_in_the_number_of_lists():
     assert dt < 8.0, dt
 
 
+def test_duplicate_scan_is_shared_only_while_the_lists_stand(capfd, monkeypatch):
+    """check_for_1vn_dups takes the counts check_for_pair_dups' scan left (one native pass instead of
+    two) -- but only while no list object, array or length has changed: a list the first check
+    repaired, a list replaced or edited in between, and the remap of merge_duplicates all make it
+    scan again; the messages equal those of two independent scans"""
+    from imageanalysis_amd import match_cleanup
+    from imageanalysis_amd.hostlib.image_pose import PoseProject
+    from imageanalysis_amd.keypoints import KeyPointList
+    from imageanalysis_amd.matchpairs import MatchPairs
+
+    def project(pairs_ab):
+        proj = PoseProject(['A', 'B', 'C'])
+        z = np.zeros(8, np.float32)
+        for im in proj.image_list:
+            im.kp_list = KeyPointList(z + np.arange(8), z + 2 * np.arange(8), z + 3, z, z, z.astype(np.int32))
+            im.match_list = {}
+        a, b, c = proj.image_list
+        a.match_list['B'] = MatchPairs(np.array(pairs_ab, np.int32))
+        b.match_list['A'] = MatchPairs(np.array(pairs_ab, np.int32)[:, ::-1].copy())
+        a.match_list['C'] = MatchPairs(np.array([[0, 1], [2, 3]], np.int32))
+        c.match_list['A'] = MatchPairs(np.array([[1, 0], [3, 2]], np.int32))
+        return proj
+
+    calls = []
+    import imageanalysis_amd._lib as _lib
+    real = _lib.lib()
+
+    class Spy(object):
+        def __getattr__(self, name):
+            fn = getattr(real, name)
+            if name == 'iamx_match_lists_scan':
+                def wrapped(*a):
+                    calls.append(a[9])                      # mode
+                    return fn(*a)
+                return wrapped
+            return fn
+    monkeypatch.setattr(_lib, 'lib', lambda: Spy())
+    # (1) nothing to repair: ONE mode-4 scan serves both checks; column-0 repeats are still reported
+    proj = project([[0, 1], [0, 2], [3, 4]])
+    match_cleanup.check_for_pair_dups(proj)
+    match_cleanup.check_for_1vn_dups(proj)
+    assert calls.count(4) == 1
+    # (2) a repeated pair: the first check replaces the list, the second scans the new lists
+    del calls[:]
+    proj = project([[0, 1], [0, 1], [3, 4]])
+    match_cleanup.check_for_pair_dups(proj)
+    assert proj.image_list[0].match_list['B'] == [[0, 1], [3, 4]]
+    match_cleanup.check_for_1vn_dups(proj)
+    assert calls.count(4) == 2
+    # (3) a list replaced between the checks (same length, other object)
+    del calls[:]
+    proj = project([[0, 1], [2, 2], [3, 4]])
+    match_cleanup.check_for_pair_dups(proj)
+    proj.image_list[0].match_list['B'] = MatchPairs(np.array([[5, 1], [5, 2], [5, 4]], np.int32))
+    match_cleanup.check_for_1vn_dups(proj)
+    assert calls.count(4) == 2
+    # (4) the whole sequence: merge_duplicates' remap in front changes nothing about the sharing
+    del calls[:]
+    proj = project([[0, 1], [0, 2], [3, 4]])
+    match_cleanup.merge_duplicates(proj)
+    match_cleanup.check_for_pair_dups(proj)
+    match_cleanup.check_for_1vn_dups(proj)
+    assert calls.count(4) == 1
+    direct = match_cleanup.make_match_structure(proj)
+    match_cleanup.link_matches(proj, direct)
+    assert getattr(proj, '_iamx_scan4', None) is None       # (the stage's tables end with it)
+
+
 def test_link_matches_incremental_passes_equal_the_full_walk(capfd):
     """Late passes of iamx_link_matches only walk the chains that share a point with another chain
     (round 5).  Same chains, same order, same number of passes as the full walk (IAMX_LINK_FULL=1) and
