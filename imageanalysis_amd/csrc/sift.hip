@@ -18,7 +18,9 @@
 //   orient         one wave per refined candidate: calcOrientationHist (float32 terms, exact
 //                  f64 LDS-atomic sums), smoothing, peaks -> keypoints (atomic append)
 //   descriptor     one wave per keypoint: calcSIFTDescriptor, rotated 4x4x8 trilinear histogram
-//                  in LDS (float32 terms, f64 atomics), clip/normalise/quantise
+//                  in LDS (float32 terms summed exactly in float64: a lane combines the run of
+//                  samples that fall into one cell in registers, f64 atomics per run), the pass
+//                  ordered by (XCD stripe, level, row band), clip/normalise/quantise
 //   sort           removeDuplicatedSorted: OpenCV's output order, duplicates dropped
 // The Gaussian taps are explicit fused multiply-adds (one rounding per tap, `fmaf` in the CPU
 // oracle) in the oracle's tap order; the other per-pixel arithmetic of the pyramid (grey scale,

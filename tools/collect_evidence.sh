@@ -38,14 +38,16 @@ fi
 
 step "PMC: HBM traffic of the matching step (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 1200 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err)
+    # (a counter pass of this command takes ~20 s; one WRITE_SIZE pass of round 6 hung until its limit,
+    #  then 1200 s: a hung pass is retried once under a short limit)
+    (cd /tmp && { timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err || { rm -rf /tmp/p_$C; timeout 300 rocprofv3 --pmc $C --output-format csv -d /tmp/p_$C -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_$C.err; }; })
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/p_$C "$OUT/${TAG}_knn2sym_pmc_${lc}.txt" > /dev/null
 done
 if [ -z "$NO_AUX" ]; then
 step "PMC: HBM traffic of the BA and SIFT kernels (FETCH_SIZE, WRITE_SIZE: separate passes)"
 for C in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/a_$C -o b -- $AUX_PMC > /dev/null 2> /tmp/a_$C.err)
+    (cd /tmp && timeout 420 rocprofv3 --pmc $C --output-format csv -d /tmp/a_$C -o b -- $AUX_PMC > /dev/null 2> /tmp/a_$C.err)
     lc=$(echo $C | tr 'A-Z' 'a-z' | sed 's/_size//')
     $SUM /tmp/a_$C "$OUT/${TAG}_aux_pmc_${lc}.txt" > /dev/null
     cp "$OUT/${TAG}_aux_pmc_${lc}.txt" "$REPO/profiles/${TAG}_aux_pmc_${lc}.txt"
@@ -53,7 +55,7 @@ done
 python "$REPO/tools/aux_traffic_json.py" "$TAG" && cp "$REPO/profiles/${TAG}_ba_sift_traffic.json" "$OUT/"
 fi
 step "PMC: SQ / MFMA busy"
-(cd /tmp && timeout 1200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
+(cd /tmp && timeout 420 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES \
     SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
     --output-format csv -d /tmp/p_sq -o b -- $BENCH_PMC > /dev/null 2> /tmp/p_sq.err)
 $SUM /tmp/p_sq "$OUT/${TAG}_knn2sym_pmc_sq.txt" > /dev/null
