@@ -292,3 +292,42 @@ def test_simd_knn2_equals_the_plain_c_loop():
         a = cpu_ref.knn2_l2_u8_batch(imgs, pairs)
         b = cpu_ref.knn2_l2_u8_batch_simd(imgs, pairs)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), n_rows
+
+
+def test_identities_the_device_sift_kernels_rely_on():
+    """Three rewrites inside csrc/sift.hip that must not change a bit, checked on the host:
+    (1) orient_kernel's window index e // side as a float32 product ((e + 0.5) * (1 / side), side <
+    512); (2) descriptor_kernel's orientation-bin wrap as `o0 & 7` for every bin floor() can give
+    (-8 .. 8); (3) run combining -- a lane adds the terms of consecutive samples that fall into one
+    histogram cell in float64 registers first and sends the partial sums to the bin afterwards:
+    with sums of float32 terms exact in float64 the bins, rounded to float32 once, are the oracle's
+    whatever the grouping (the oracle's descriptor() bins terms one by one)"""
+    from oracle import sift_oracle as so
+    for side in range(1, 512):
+        e = np.arange(side * side + 64, dtype=np.int64)
+        q = ((e.astype(np.float32) + np.float32(0.5)) * (np.float32(1) / np.float32(side))).astype(np.int64)
+        assert np.array_equal(q, e // side), side
+    for o0 in range(-8, 9):
+        want = o0 + 8 if o0 < 0 else (o0 - 8 if o0 >= 8 else o0)
+        assert (o0 & 7) == want
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        n_terms, n_bins = 4000, 360
+        # magnitudes like mag * weight * trilinear fractions: products of float32 factors in (0, 1]
+        terms = (rng.random(n_terms) * rng.random(n_terms) * rng.random(n_terms) * 300).astype(np.float32)
+        terms[rng.random(n_terms) < 0.05] *= np.float32(1e-6)
+        cell = np.sort(rng.integers(0, n_bins, n_terms))[rng.permutation(n_terms) // 7 * 7 % n_terms]
+        one_by_one = so._bin_sums(n_bins, cell.tolist(), terms.tolist())
+        # grouped: runs of equal cell in a lane-like blocked walk, partial sums in float64, then the bins
+        grouped = np.zeros(n_bins, np.float64)
+        for lane in np.array_split(np.arange(n_terms), 64):
+            run_cell, run_sum = -1, 0.0
+            for k in lane.tolist():
+                if cell[k] != run_cell:
+                    if run_cell >= 0:
+                        grouped[run_cell] += run_sum
+                    run_cell, run_sum = int(cell[k]), 0.0
+                run_sum += float(terms[k])
+            if run_cell >= 0:
+                grouped[run_cell] += run_sum
+        assert np.array_equal(np.asarray(one_by_one, np.float32), grouped.astype(np.float32))
